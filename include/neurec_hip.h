@@ -1,0 +1,197 @@
+/* neurec_hip.h — C ABI of libneurec_hip.so, the MI355X (gfx950) engine for the
+ * NeuRec embedding hot path.
+ *
+ * Conventions
+ *   - Every pointer named d_* is a DEVICE pointer owned by the caller (e.g. a
+ *     PyTorch-ROCm tensor's data_ptr()).  The library never allocates or frees
+ *     caller-visible memory; scratch space is passed in as an explicit
+ *     workspace whose size comes from the matching *_workspace_bytes query.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
+ *     and the call returns without synchronising.
+ *   - Return value: 0 on success, otherwise one of NRHIP_ERR_*; a message is
+ *     available from nrhip_last_error() (thread-local).
+ *   - int = 32 bit, float = IEEE fp32, exactly as the reference asserts at
+ *     import (util/cython/tools.pyx:7-27).
+ *   - Item/user id arrays are int32, CSR index pointers are int64 where the
+ *     number of interactions may exceed 2^31 (training CSR, adjacency) and
+ *     int32 otherwise.
+ *
+ * Each entry point names the reference interface it stands in for
+ * (paths relative to the NeuRec tree, wubinzzu/NeuRec @ v1).
+ */
+#ifndef NEUREC_HIP_H
+#define NEUREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRHIP_OK 0
+#define NRHIP_ERR_ARG 1
+#define NRHIP_ERR_UNSUPPORTED 2
+#define NRHIP_ERR_HIP 3
+#define NRHIP_ERR_WORKSPACE 4
+
+#define NRHIP_ABI_VERSION 1
+#define NRHIP_MAX_TOPK 128 /* largest top_k the selection kernels accept */
+
+/* ---- library ------------------------------------------------------------ */
+int nrhip_abi_version(void);
+const char* nrhip_last_error(void);
+/* device facts used by bench/roofline reporting */
+int nrhip_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, int name_len);
+
+/* ---- evaluator ----------------------------------------------------------
+ * Replaces: cpp_evaluate_matrix / eval_one_user
+ *           (evaluator/backend/cpp/include/evaluate.h:23-72),
+ *           metric functions (evaluator/backend/cpp/include/metric.h:17-117),
+ *           the -inf train mask loop (evaluator/backend/cpp/uni_evaluator.py:140-143),
+ *           arg_top_k_2d (util/cython/include/arg_topk.h:15-45).
+ */
+
+/* Scratch needed by nrhip_eval_scores / nrhip_arg_topk for `rows` rows. */
+int nrhip_eval_workspace_bytes(int rows, int top_k, size_t* bytes);
+
+/* scores[r][train items of users[r]] = -inf, in place
+ * (uni_evaluator.py:140-143).  tr_indptr has one entry per user id + 1. */
+int nrhip_mask_train(float* d_scores, int64_t ld, const int32_t* d_users, int rows, int cols,
+                     const int64_t* d_tr_indptr, const int32_t* d_tr_indices, void* stream);
+
+/* Per row: rank the `cols` scores exactly like eval_one_user (partial sort of
+ * min(2*top_k, cols) indices by descending score, cut to top_k, libstdc++ tie
+ * behaviour included), then write n_metric*top_k cumulative metric values,
+ * metric-major (evaluate.h:43-47).  Truth of row r is the ascending id list
+ * d_truth_indices[d_truth_indptr[t] .. d_truth_indptr[t+1]) with
+ * t = d_users ? d_users[r] : r.  metric ids: 1 Precision 2 Recall 3 MAP
+ * 4 NDCG 5 MRR (metric.h:111-117).  d_topk_out (optional, may be NULL)
+ * receives the top_k ranked item ids per row.  d_n_exact (optional) receives
+ * the number of rows that needed the exact tie path. */
+int nrhip_eval_scores(const float* d_scores, int64_t ld, int rows, int cols,
+                      const int32_t* d_users, const int64_t* d_truth_indptr,
+                      const int32_t* d_truth_indices, const int32_t* metric_ids_host,
+                      int n_metric, int top_k, float* d_out, int32_t* d_topk_out,
+                      int32_t* d_n_exact, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Per row arg-top-K with std::partial_sort_copy(K) semantics
+ * (arg_topk.h:15-25): d_out[rows][top_k] int32. */
+int nrhip_arg_topk(const float* d_scores, int64_t ld, int rows, int cols, int top_k,
+                   int32_t* d_out, int32_t* d_n_exact, void* d_ws, size_t ws_bytes,
+                   void* stream);
+
+/* Column sums of a [rows][cols] fp32 matrix in fp64 (the np.mean of
+ * uni_evaluator.py:150-151 is sum/rows; the division is the caller's). */
+int nrhip_colsum_workspace_bytes(int rows, int cols, size_t* bytes);
+int nrhip_colsum_f64(const float* d_mat, int64_t ld, int rows, int cols, double* d_out,
+                     void* d_ws, size_t ws_bytes, void* stream);
+
+/* Scoring GEMM: S[r][i] = sum_k P[users[r]][k] * Q[i][k], fp32 MFMA, k
+ * ascending fused-multiply-add chain.  Replaces np.matmul(user_embed,
+ * item_embeddings.T) (model/general_recommender/MF.py:120-122) and the TF
+ * matmul of LightGCN.py:118-119.  d_users may be NULL (rows 0..rows-1).
+ * S has leading dimension lds >= cols; columns [cols, lds_pad) may be
+ * written with zeros where lds_pad = min(lds, roundup(cols,64)). */
+int nrhip_score_gemm_workspace_bytes(int rows, int cols, int d, size_t* bytes);
+/* Prepare the item side once per evaluation (k-major copy of Q inside ws). */
+int nrhip_score_gemm_prepare_items(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws,
+                                   size_t ws_bytes, void* stream);
+int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
+                     int d, float* d_S, int64_t lds, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---- sampler ------------------------------------------------------------
+ * Replaces: PairwiseSampler.__iter__ = _sampling_negative_items +
+ *           DataIterator(shuffle) (data/sampler.py:71-90,198-206;
+ *           util/data_iterator.py:58-60,145-152) and the rejection loop of
+ *           randint_choice (util/cython/random_choice.pyx:20-62).
+ *
+ * Train CSR: indptr[n_users+1] (int64), indices ascending per row; d_row_of[E]
+ * is the user of each CSR position (users_list of sampler.py:24-39).
+ * Output position p of the epoch stream holds triplet perm(p); with
+ * shuffle == 0 perm is the identity (user-major order, as the reference with
+ * shuffle=False).  d_neg_out has E*neg_num entries, row-major [E][neg_num]. */
+int nrhip_sample_bpr_epoch(const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                           const int32_t* d_row_of, int64_t n_inter, int n_items, int neg_num,
+                           uint64_t seed, uint64_t epoch, int shuffle, int64_t out_begin,
+                           int64_t out_count, int32_t* d_users_out, int32_t* d_pos_out,
+                           int32_t* d_neg_out, void* stream);
+
+/* batch_randint_choice(high, size, replace, p=None, exclusion)
+ * (random_choice.pyx:64-89): request q draws size[q] =
+ * d_out_offsets[q+1]-d_out_offsets[q] values into d_out[d_out_offsets[q] ..)
+ * (d_out_offsets has n_req+1 entries, total = d_out_offsets[n_req]),
+ * excluding the ascending, duplicate-free list
+ * d_excl[d_excl_indptr[q] .. d_excl_indptr[q+1]).  replace == 0 additionally
+ * forbids repeats inside one request. */
+int nrhip_randint_choice_batch(int high, int n_req, int64_t total, const int64_t* d_out_offsets,
+                               const int64_t* d_excl_indptr, const int32_t* d_excl, int replace,
+                               uint64_t seed, uint64_t call_counter, int32_t* d_out, void* stream);
+
+/* ---- BPR-MF training step -------------------------------------------------
+ * Replaces one sess.run((loss, optimizer)) of MF.train_model
+ * (model/general_recommender/MF.py:54-76,101; util/learner.py:9-10,19-22;
+ * util/tool.py:216-217).
+ *   grad:  gathers p_u,q_i,q_j; x=<p,q_i>-<p,q_j>; loss_b=softplus(-x);
+ *          row gradients (duplicates summed) accumulated into dense d_GP/d_GQ
+ *          (which must be zero on entry); d_terms is scratch for 2*batch
+ *          floats (per-triplet loss and l2 terms, reduced in a fixed order);
+ *          d_loss2[0] = sum_b loss_b, d_loss2[1] = reg * sum_b l2_b, the two
+ *          addends of MF.py:68-69 (the fetched loss is their sum).
+ *   adam:  TF-1.12 sparse Adam = all rows swept (see nr_core.h), and the
+ *          gradient buffer is cleared for the next step.               */
+int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                      const int32_t* d_pos, const int32_t* d_neg, int batch, float reg, float* d_GP,
+                      float* d_GQ, float* d_terms, float* d_loss2, void* stream);
+int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
+                         float alpha, float beta1, float beta2, float eps, void* stream);
+/* TF-1.12 dense ApplyAdam; d_grad cleared afterwards when clear_grad != 0. */
+int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
+                        float alpha, float beta1, float beta2, float eps, int clear_grad,
+                        void* stream);
+
+/* ---- sparse adjacency x embedding (LightGCN / NGCF propagation) ----------
+ * Replaces tf.sparse_tensor_dense_matmul(adj, ego)
+ * (model/general_recommender/LightGCN.py:140, NGCF.py:176) and its autodiff
+ * transpose.  Y[r] = sum_j vals[j]*X[indices[j]] over the CSR row r in
+ * ascending j (product and sum rounded separately), then
+ *   Y[r] += addend[r]            if d_addend != NULL
+ *   d_sum_out[r] = d_sum_in[r]+Y if d_sum_out != NULL (running layer sum,
+ *                                LightGCN.py:146-147)
+ * A plan splits long rows into segments; build it once per graph. */
+int nrhip_spmm_plan_bytes(int64_t n_rows, int64_t nnz, size_t* bytes);
+/* h_indptr is a HOST pointer (n_rows+1 entries): the segment plan is computed
+ * on the host, uploaded into the caller's device buffer d_plan_buf, and a
+ * host-side handle describing it is returned in *plan_out. */
+int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, void* d_plan_buf,
+                           size_t plan_bytes, void* stream, void** plan_out);
+int nrhip_spmm_plan_destroy(void* plan);
+int nrhip_spmm_plan_info(const void* plan, int64_t* n_segments, int64_t* n_split_rows);
+int nrhip_spmm_workspace_bytes(const void* plan, int d, size_t* bytes);
+/* d_Y may be NULL when only the running sum is wanted. */
+int nrhip_spmm_csr(const void* plan, const int32_t* d_indices, const float* d_vals,
+                   const float* d_X, int d, float* d_Y, const float* d_addend,
+                   const float* d_sum_in, float* d_sum_out, void* d_ws, size_t ws_bytes,
+                   void* stream);
+
+/* ---- LightGCN BPR head ----------------------------------------------------
+ * Replaces the lookups + create_bpr_loss of LightGCN.py:99-104,156-166 and
+ * their gradient.  d_Esum is the running layer sum (E* = Esum/(L+1));
+ * user rows first, item rows offset by n_users.  Accumulates
+ *   d_Gstar  += dLoss/dE*      (dense [N][d], zero on entry)
+ *   d_Greg   += reg * E0 rows  (dense [N][d], zero on entry)
+ * and writes the two scalars mf_loss, emb_loss into d_loss2[0..1]. */
+int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
+                            int n_layers, const int32_t* d_users, const int32_t* d_pos,
+                            const int32_t* d_neg, int batch, float reg, float* d_Gstar,
+                            float* d_Greg, float* d_terms, float* d_loss2, void* stream);
+
+/* y = a*x (+ y0)  elementwise helpers used between propagation passes. */
+int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream);
+int nrhip_add(const float* d_x, const float* d_y, float* d_out, int64_t n, void* stream);
+int nrhip_div_scalar(const float* d_x, float denom, float* d_y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUREC_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libneurec_hip.so (the C ABI declared in include/neurec_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load,
+importing this module raises.  Build it with ``python -m neurec_amd.build``.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneurec_hip.so")
+
+ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = 1, 2, 3, 4
+
+
+class NeuRecHipError(RuntimeError):
+    """A HIP runtime failure or workspace error reported by the native library."""
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "libneurec_hip.so is not built (expected at %s). Run `python -m neurec_amd.build` "
+            "(needs hipcc; the engine has no CPU fallback)." % LIB_PATH)
+    try:
+        return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise ImportError("cannot load %s: %s" % (LIB_PATH, e))
+
+
+lib = _load()
+
+p = C.c_void_p
+i32, i64, u64, f32 = C.c_int, C.c_int64, C.c_uint64, C.c_float
+sz = C.c_size_t
+psz = C.POINTER(C.c_size_t)
+
+# name -> argtypes; every function returns int status except where noted.
+SIGNATURES = {
+    "nrhip_device_info": [C.POINTER(i32), C.POINTER(i32), psz, C.c_char_p, i32],
+    "nrhip_eval_workspace_bytes": [i32, i32, psz],
+    "nrhip_mask_train": [p, i64, p, i32, i32, p, p, p],
+    "nrhip_eval_scores": [p, i64, i32, i32, p, p, p, C.POINTER(i32), i32, i32, p, p, p, p, sz, p],
+    "nrhip_arg_topk": [p, i64, i32, i32, i32, p, p, p, sz, p],
+    "nrhip_colsum_workspace_bytes": [i32, i32, psz],
+    "nrhip_colsum_f64": [p, i64, i32, i32, p, p, sz, p],
+    "nrhip_score_gemm_workspace_bytes": [i32, i32, i32, psz],
+    "nrhip_score_gemm_prepare_items": [p, i64, i32, i32, p, sz, p],
+    "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],
+    "nrhip_sample_bpr_epoch": [p, p, p, i64, i32, i32, u64, u64, i32, i64, i64, p, p, p, p],
+    "nrhip_randint_choice_batch": [i32, i32, i64, p, p, p, i32, u64, u64, p, p],
+    "nrhip_bpr_mf_grad": [p, p, i32, p, p, p, i32, f32, p, p, p, p, p],
+    "nrhip_adam_sparse_tf": [p, p, p, p, i64, f32, f32, f32, f32, p],
+    "nrhip_adam_dense_tf": [p, p, p, p, i64, f32, f32, f32, f32, i32, p],
+    "nrhip_spmm_plan_bytes": [i64, i64, psz],
+    "nrhip_spmm_plan_create": [p, i64, p, sz, p, C.POINTER(p)],
+    "nrhip_spmm_plan_destroy": [p],
+    "nrhip_spmm_plan_info": [p, C.POINTER(i64), C.POINTER(i64)],
+    "nrhip_spmm_workspace_bytes": [p, i32, psz],
+    "nrhip_spmm_csr": [p, p, p, p, i32, p, p, p, p, p, sz, p],
+    "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p],
+    "nrhip_scale": [p, f32, p, i64, p],
+    "nrhip_add": [p, p, p, i64, p],
+    "nrhip_div_scalar": [p, f32, p, i64, p],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == ABI mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+lib.nrhip_abi_version.argtypes = []
+lib.nrhip_abi_version.restype = C.c_int
+lib.nrhip_last_error.argtypes = []
+lib.nrhip_last_error.restype = C.c_char_p
+
+EXPORTED = sorted(list(SIGNATURES) + ["nrhip_abi_version", "nrhip_last_error"])
+
+if lib.nrhip_abi_version() != 1:  # pragma: no cover
+    raise ImportError("libneurec_hip.so ABI version %d, expected 1" % lib.nrhip_abi_version())
+
+
+def last_error():
+    return lib.nrhip_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Translate a status code into the exception type the reference would raise."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise NeuRecHipError("libneurec_hip status %d: %s" % (rc, msg))
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args))
+
+
+def is_stale():
+    """True when the .so on disk was built from different sources than the tree holds."""
+    return not _build.is_current()

@@ -1,0 +1,170 @@
+// adam.hip — TF-1.12 Adam sweeps and the small elementwise helpers between
+// propagation passes; plus the library-level entry points (error string,
+// ABI version, device facts).
+//
+// Stands in for tf.train.AdamOptimizer(lr).minimize(loss)
+// (util/learner.py:9-10 for MF, LightGCN.py:130): see nr_core.h for the exact
+// arithmetic of the dense (ApplyAdam) and sparse (_apply_sparse_shared)
+// variants.  Both sweep every element of the table each step — that is the
+// reference's semantics even for embedding gradients — so the
+// kernel is a pure HBM stream: 4 reads + 3 (or 4, with the gradient clear)
+// writes of n·4 bytes, 16 B per lane per access.
+#include "nr_common.h"
+#include <string.h>
+
+namespace {
+
+template <bool SPARSE, bool CLEAR>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ grad,
+                                                   int64_t n, float alpha, float b1, float b2,
+                                                   float omb1, float omb2, float eps) {
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 w = reinterpret_cast<float4*>(var)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    const float4 g = reinterpret_cast<const float4*>(grad)[i];
+    if (SPARSE) {
+      nr::adam_sparse_tf(g.x, w.x, mm.x, vv.x, alpha, b1, b2, omb1, omb2, eps);
+      nr::adam_sparse_tf(g.y, w.y, mm.y, vv.y, alpha, b1, b2, omb1, omb2, eps);
+      nr::adam_sparse_tf(g.z, w.z, mm.z, vv.z, alpha, b1, b2, omb1, omb2, eps);
+      nr::adam_sparse_tf(g.w, w.w, mm.w, vv.w, alpha, b1, b2, omb1, omb2, eps);
+    } else {
+      nr::adam_dense_tf(g.x, w.x, mm.x, vv.x, alpha, omb1, omb2, eps);
+      nr::adam_dense_tf(g.y, w.y, mm.y, vv.y, alpha, omb1, omb2, eps);
+      nr::adam_dense_tf(g.z, w.z, mm.z, vv.z, alpha, omb1, omb2, eps);
+      nr::adam_dense_tf(g.w, w.w, mm.w, vv.w, alpha, omb1, omb2, eps);
+    }
+    reinterpret_cast<float4*>(var)[i] = w;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (CLEAR) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // tail (n not a multiple of 4)
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float w = var[i], mm = m[i], vv = v[i];
+    const float g = grad[i];
+    if (SPARSE) nr::adam_sparse_tf(g, w, mm, vv, alpha, b1, b2, omb1, omb2, eps);
+    else nr::adam_dense_tf(g, w, mm, vv, alpha, omb1, omb2, eps);
+    var[i] = w; m[i] = mm; v[i] = vv;
+    if (CLEAR) grad[i] = 0.f;
+  }
+}
+
+enum { OP_SCALE = 0, OP_ADD = 1, OP_DIV = 2 };
+template <int OP>
+__global__ __launch_bounds__(256) void ewise_kernel(const float* __restrict__ x,
+                                                    const float* __restrict__ y, float a,
+                                                    float* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float r;
+    if (OP == OP_SCALE) r = __fmul_rn(a, x[i]);
+    else if (OP == OP_ADD) r = __fadd_rn(x[i], y[i]);
+    else r = x[i] / a;
+    out[i] = r;
+  }
+}
+
+inline unsigned sweep_blocks(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;   // 256 CUs x 16 resident blocks, grid-stride beyond
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+thread_local char g_err[512] = "";
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+void nrhip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+const char* nrhip_last_error(void) { return g_err; }
+
+int nrhip_abi_version(void) { return 1; }
+
+int nrhip_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, int name_len) {
+  int dev = 0;
+  NR_CHECK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  NR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  if (name && name_len > 0) {
+    snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return NR_OK;
+}
+
+int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
+                         float alpha, float beta1, float beta2, float eps, void* stream) {
+  NR_REQUIRE(d_var && d_m && d_v && d_grad && n >= 0, NR_ERR_ARG, "adam_sparse_tf: bad arguments");
+  NR_REQUIRE(aligned16(d_var) && aligned16(d_m) && aligned16(d_v) && aligned16(d_grad), NR_ERR_ARG,
+             "adam_sparse_tf: buffers must be 16-byte aligned");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL((adam_kernel<true, true>), dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
+                     (hipStream_t)stream, d_var, d_m, d_v, d_grad, n, alpha, beta1, beta2,
+                     1.0f - beta1, 1.0f - beta2, eps);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
+                        float alpha, float beta1, float beta2, float eps, int clear_grad,
+                        void* stream) {
+  NR_REQUIRE(d_var && d_m && d_v && d_grad && n >= 0, NR_ERR_ARG, "adam_dense_tf: bad arguments");
+  NR_REQUIRE(aligned16(d_var) && aligned16(d_m) && aligned16(d_v) && aligned16(d_grad), NR_ERR_ARG,
+             "adam_dense_tf: buffers must be 16-byte aligned");
+  if (n == 0) return NR_OK;
+  if (clear_grad)
+    hipLaunchKernelGGL((adam_kernel<false, true>), dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
+                       (hipStream_t)stream, d_var, d_m, d_v, d_grad, n, alpha, beta1, beta2,
+                       1.0f - beta1, 1.0f - beta2, eps);
+  else
+    hipLaunchKernelGGL((adam_kernel<false, false>), dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
+                       (hipStream_t)stream, d_var, d_m, d_v, d_grad, n, alpha, beta1, beta2,
+                       1.0f - beta1, 1.0f - beta2, eps);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream) {
+  NR_REQUIRE(d_x && d_y && n >= 0, NR_ERR_ARG, "scale: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(ewise_kernel<OP_SCALE>, dim3(sweep_blocks(n)), dim3(256), 0,
+                     (hipStream_t)stream, d_x, (const float*)nullptr, a, d_y, n);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_add(const float* d_x, const float* d_y, float* d_out, int64_t n, void* stream) {
+  NR_REQUIRE(d_x && d_y && d_out && n >= 0, NR_ERR_ARG, "add: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(ewise_kernel<OP_ADD>, dim3(sweep_blocks(n)), dim3(256), 0,
+                     (hipStream_t)stream, d_x, d_y, 0.f, d_out, n);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_div_scalar(const float* d_x, float denom, float* d_y, int64_t n, void* stream) {
+  NR_REQUIRE(d_x && d_y && n >= 0, NR_ERR_ARG, "div_scalar: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(ewise_kernel<OP_DIV>, dim3(sweep_blocks(n)), dim3(256), 0,
+                     (hipStream_t)stream, d_x, (const float*)nullptr, denom, d_y, n);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

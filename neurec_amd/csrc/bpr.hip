@@ -1,0 +1,219 @@
+// bpr.hip — embedding lookup + BPR-triplet forward/backward (MF and LightGCN heads).
+//
+// Stands in for the TF ops of one training step of
+//   MF          model/general_recommender/MF.py:54-72   (lookups :57-58, dots :59,
+//               loss util/learner.py:19-22, l2 util/tool.py:216-217)
+//   LightGCN    model/general_recommender/LightGCN.py:99-104 (six lookups),
+//               :156-166 (create_bpr_loss), util/tool.py:198-200,220-224
+// and for their autodiff: IndexedSlices row gradients with duplicates summed.
+//
+// One wave64 per triplet: the three embedding rows are gathered with one
+// coalesced 4·d-byte read each (lane = column), the two inner products are
+// wave shuffle reductions, the scalar loss/gradient math runs once per wave,
+// and row gradients are scattered with hardware fp32 atomics into dense
+// accumulators (duplicate rows inside a batch add up, as TF's
+// _apply_sparse_duplicate_indices does).  Per-triplet loss terms are written
+// out and reduced in a fixed order by reduce_loss_kernel.
+#include "nr_common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+template <int CPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int d,
+                                         int lane, float (&out)[CPL]) {
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    out[c] = (k < d) ? base[row * d + k] : 0.f;
+  }
+}
+
+template <int CPL>
+__device__ __forceinline__ float dot_rows(const float (&a)[CPL], const float (&b)[CPL]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) s = fmaf(a[c], b[c], s);
+  return nr_wave_sum_f32(s);
+}
+
+// ---- BPR-MF ------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, int d,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ GP,
+    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2) {
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int b = blockIdx.x * kWavesPerBlock + wave;
+  if (b >= batch) return;
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = __builtin_amdgcn_readfirstlane(pos[b]);
+  const int64_t j = __builtin_amdgcn_readfirstlane(neg[b]);
+  float p[CPL], qi[CPL], qj[CPL];
+  load_row<CPL>(P, u, d, lane, p);
+  load_row<CPL>(Q, i, d, lane, qi);
+  load_row<CPL>(Q, j, d, lane, qj);
+  const float x = dot_rows<CPL>(p, qi) - dot_rows<CPL>(p, qj);      // MF.py:59,67
+  const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(qj, qj) + dot_rows<CPL>(qi, qi));
+  const float g = nr::bpr_dloss(x);
+  if (lane == 0) {
+    term_mf[b] = nr::bpr_loss(x);
+    term_l2[b] = l2;
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    if (k < d) {
+      atomicAdd(&GP[u * d + k], g * (qi[c] - qj[c]) + reg * p[c]);
+      atomicAdd(&GQ[i * d + k], g * p[c] + reg * qi[c]);
+      atomicAdd(&GQ[j * d + k], -g * p[c] + reg * qj[c]);
+    }
+  }
+}
+
+// ---- LightGCN head --------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_kernel(
+    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
+    float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ Gstar,
+    float* __restrict__ Greg, float* __restrict__ term_mf, float* __restrict__ term_l2) {
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int b = blockIdx.x * kWavesPerBlock + wave;
+  if (b >= batch) return;
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
+  const int64_t j = (int64_t)n_users + __builtin_amdgcn_readfirstlane(neg[b]);
+  float eu[CPL], ei[CPL], ej[CPL], zu[CPL], zi[CPL], zj[CPL];
+  load_row<CPL>(Esum, u, d, lane, eu);
+  load_row<CPL>(Esum, i, d, lane, ei);
+  load_row<CPL>(Esum, j, d, lane, ej);
+  load_row<CPL>(E0, u, d, lane, zu);
+  load_row<CPL>(E0, i, d, lane, zi);
+  load_row<CPL>(E0, j, d, lane, zj);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {   // E* = mean over layers = sum / (L+1), LightGCN.py:146-147
+    eu[c] = eu[c] / layers_p1;
+    ei[c] = ei[c] / layers_p1;
+    ej[c] = ej[c] / layers_p1;
+  }
+  const float x = dot_rows<CPL>(eu, ei) - dot_rows<CPL>(eu, ej);     // LightGCN.py:157-158,162
+  const float l2 = 0.5f * (dot_rows<CPL>(zu, zu) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
+  const float g = nr::bpr_dloss(x);
+  if (lane == 0) {
+    term_mf[b] = nr::bpr_loss(x);
+    term_l2[b] = l2;
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    if (k < d) {
+      atomicAdd(&Gstar[u * d + k], g * (ei[c] - ej[c]));
+      atomicAdd(&Gstar[i * d + k], g * eu[c]);
+      atomicAdd(&Gstar[j * d + k], -g * eu[c]);
+      atomicAdd(&Greg[u * d + k], reg * zu[c]);    // regulariser on layer-0 rows, :160,164
+      atomicAdd(&Greg[i * d + k], reg * zi[c]);
+      atomicAdd(&Greg[j * d + k], reg * zj[c]);
+    }
+  }
+}
+
+// fixed-order reduction of the per-triplet terms: out[0] = Σ mf, out[1] = reg·Σ l2
+__global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restrict__ term_mf,
+                                                          const float* __restrict__ term_l2,
+                                                          int batch, float reg,
+                                                          float* __restrict__ out2) {
+  __shared__ double s_a[256], s_b[256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < batch; i += 256) { a += (double)term_mf[i]; b += (double)term_l2[i]; }
+  s_a[threadIdx.x] = a;
+  s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      s_a[threadIdx.x] += s_a[threadIdx.x + s];
+      s_b[threadIdx.x] += s_b[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = (float)s_a[0];
+    out2[1] = reg * (float)s_b[0];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                      const int32_t* d_pos, const int32_t* d_neg, int batch, float reg, float* d_GP,
+                      float* d_GQ, float* d_terms, float* d_loss2, void* stream) {
+  NR_REQUIRE(d_P && d_Q && d_users && d_pos && d_neg && d_GP && d_GQ && d_terms && d_loss2,
+             NR_ERR_ARG, "bpr_mf_grad: null pointer argument");
+  NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED, "bpr_mf_grad: embedding dim %d outside 1..256",
+             d);
+  NR_REQUIRE(batch >= 0, NR_ERR_ARG, "bpr_mf_grad: negative batch");
+  hipStream_t st = (hipStream_t)stream;
+  if (batch == 0) {
+    NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+    return NR_OK;
+  }
+  float* t_mf = d_terms;
+  float* t_l2 = d_terms + batch;
+  dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  if (d <= 64)
+    hipLaunchKernelGGL(bpr_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2);
+  else if (d <= 128)
+    hipLaunchKernelGGL(bpr_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2);
+  else
+    hipLaunchKernelGGL(bpr_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
+                     d_loss2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
+                            int n_layers, const int32_t* d_users, const int32_t* d_pos,
+                            const int32_t* d_neg, int batch, float reg, float* d_Gstar,
+                            float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
+  NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_terms &&
+                 d_loss2,
+             NR_ERR_ARG, "lightgcn_bpr_grad: null pointer argument");
+  NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
+             "lightgcn_bpr_grad: embedding dim %d outside 1..256", d);
+  NR_REQUIRE(batch >= 0 && n_layers >= 0 && n_users >= 0, NR_ERR_ARG,
+             "lightgcn_bpr_grad: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (batch == 0) {
+    NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+    return NR_OK;
+  }
+  float* t_mf = d_terms;
+  float* t_l2 = d_terms + batch;
+  const float lp1 = (float)(n_layers + 1);
+  dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  if (d <= 64)
+    hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<1>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
+  else if (d <= 128)
+    hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<2>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
+  else
+    hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<4>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
+                     d_loss2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// eval_select.hip — full-rank top-K selection + ranking metrics on a score matrix.
+//
+// Stands in for the reference's native evaluator:
+//   cpp_evaluate_matrix / eval_one_user  evaluator/backend/cpp/include/evaluate.h:23-72
+//   precision/recall/ap/ndcg/mrr        evaluator/backend/cpp/include/metric.h:17-117
+//   train-item -inf mask                evaluator/backend/cpp/uni_evaluator.py:140-143
+//   arg_top_k_2d                        util/cython/include/arg_topk.h:15-45
+//
+// Launch shape: one wave64 per user row (the reference: one thread-pool task
+// per row).  HBM-bound: each score is read exactly once with coalesced loads;
+// only scores that beat the wave's running threshold are staged in an LDS
+// candidate ring, which is periodically reduced to the current top sort_len.
+// Rows whose ranking is ambiguous under ties are re-ranked by an exact
+// emulation of libstdc++'s heap partial_sort_copy (nr_core.h) so that the
+// item order is the reference's, bit for bit.
+#include "nr_common.h"
+
+namespace {
+
+constexpr int kSelWaves = 4;          // waves (rows) per block
+constexpr int kSelSlots = 1024;       // candidate slots per wave (8 KiB)
+constexpr int kMaxSort = 2 * 128;     // NRHIP_MAX_TOPK * 2
+constexpr int kRankStride = kMaxSort; // ints per row in the rank workspace
+
+struct InvLog2Table { double v[128]; };
+struct MetricIds { int n; int id[8]; };
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // DS operations of one wave execute in order; this only pins the compiler.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Pull the `want` largest keys out of keys[0..cnt) into top[0..take) in
+// descending order; returns take and the largest key left behind (0 if none).
+__device__ int wave_extract_top(uint64_t* keys, int cnt, uint64_t* top, int want,
+                                uint64_t& next_best) {
+  const int lane = nr_lane();
+  const int take = want < cnt ? want : cnt;
+  for (int r = 0; r <= take; ++r) {
+    uint64_t best = 0;
+    int slot = -1;
+    for (int i = lane; i < cnt; i += NR_WAVE) {
+      uint64_t k = keys[i];
+      if (k > best) { best = k; slot = i; }
+    }
+    uint64_t w = nr_wave_max_u64(best);
+    if (r == take) { next_best = w; break; }
+    if (best == w && slot >= 0) keys[slot] = 0;   // keys are unique: one lane clears
+    top[r] = w;                                    // every lane writes the same value
+  }
+  return take;
+}
+
+// ----------------------------------------------------------------------------
+// Selection kernel.  VEC = floats per lane per load (4 needs 16-byte aligned
+// rows).  rank[row][0..cut) <- item ids in rank order; flag[row] <- 1 when
+// ties make the parallel answer ambiguous w.r.t. the reference's heap order.
+// ----------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
+    const float* __restrict__ scores, int64_t ld, int rows, int cols, int sort_len, int cut,
+    int32_t* __restrict__ rank, int32_t* __restrict__ flag) {
+  __shared__ uint64_t s_keys[kSelWaves][kSelSlots];
+  __shared__ uint64_t s_top[kSelWaves][kMaxSort];
+  const int wave = threadIdx.x / NR_WAVE;
+  const int lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+
+  uint64_t* keys = s_keys[wave];
+  uint64_t* top = s_top[wave];
+  const float* srow = scores + (int64_t)row * ld;
+
+  int cnt = 0;                        // wave-uniform
+  float tau = -INFINITY;              // wave-uniform: score of the current sort_len-th best
+  bool btie = false;                  // a tie straddled the kept/dropped boundary
+  uint32_t btie_order = 0;
+
+  auto refresh = [&]() {
+    wave_lds_sync();
+    uint64_t nb = 0;
+    int take = wave_extract_top(keys, cnt, top, sort_len, nb);
+    wave_lds_sync();
+    if (take == sort_len) {
+      uint32_t last = nr::key_order(top[take - 1]);
+      tau = nr::unorder_f32(last);
+      if (nb != 0 && nr::key_order(nb) == last) { btie = true; btie_order = last; }
+    }
+    for (int r = lane; r < take; r += NR_WAVE) keys[r] = top[r];
+    cnt = take;
+    wave_lds_sync();
+  };
+
+  constexpr int UNITS = (VEC == 4) ? 4 : 8;      // loads in flight per lane
+  constexpr int UNIT_ELEMS = NR_WAVE * VEC;
+  const int step = UNITS * UNIT_ELEMS;
+
+  for (int base = 0; base < cols; base += step) {
+    float v[UNITS][VEC];
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      const int e0 = base + u * UNIT_ELEMS + lane * VEC;
+      if constexpr (VEC == 4) {
+        if (e0 + 3 < cols) {
+          const float4 t = *reinterpret_cast<const float4*>(srow + e0);
+          v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) v[u][c] = (e0 + c < cols) ? srow[e0 + c] : NAN;
+        }
+      } else {
+        v[u][0] = (e0 < cols) ? srow[e0] : NAN;   // NaN never passes `>= tau`
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      if (cnt > kSelSlots - UNIT_ELEMS) refresh();
+      const int e0 = base + u * UNIT_ELEMS + lane * VEC;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const bool pass = v[u][c] >= tau;
+        const uint64_t mask = __ballot(pass);
+        if (mask) {
+          if (pass) keys[cnt + nr_mbcnt(mask)] = nr::pack_key(v[u][c], (uint32_t)(e0 + c));
+          cnt += __popcll(mask);
+        }
+      }
+    }
+  }
+
+  // final ranking
+  wave_lds_sync();
+  uint64_t nb = 0;
+  const int take = wave_extract_top(keys, cnt, top, sort_len, nb);
+  wave_lds_sync();
+
+  bool tie = false;
+  for (int r = lane; r < cut && r < take; r += NR_WAVE) {
+    const uint64_t a = top[r];
+    const uint64_t b = (r + 1 < take) ? top[r + 1] : nb;
+    if (b != 0 && nr::key_order(a) == nr::key_order(b)) tie = true;
+    rank[(int64_t)row * kRankStride + r] = (int32_t)nr::key_index(a);
+  }
+  if (btie && take >= cut && cut >= 1 && nr::key_order(top[cut - 1]) == btie_order) tie = true;
+  const bool any_tie = __ballot(tie) != 0;
+  if (lane == 0) flag[row] = any_tie ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------
+// Exact path for flagged rows: wave-cooperative replay of
+// std::partial_sort_copy's heap (see nr_core.h).  The heap lives in LDS and
+// every lane executes the (uniform) heap code; lanes only differ while
+// scanning the row 64 scores at a time for elements that beat the heap root.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
+    const float* __restrict__ scores, int64_t ld, int rows, int cols, int sort_len, int cut,
+    int32_t* __restrict__ rank, const int32_t* __restrict__ flag, int32_t* __restrict__ n_exact) {
+  __shared__ float s_val[kSelWaves][kMaxSort];
+  __shared__ int s_idx[kSelWaves][kMaxSort];
+  const int wave = threadIdx.x / NR_WAVE;
+  const int lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows || flag[row] == 0) return;
+
+  const float* srow = scores + (int64_t)row * ld;
+  nr::HeapView h{s_val[wave], s_idx[wave]};
+  const int m = sort_len < cols ? sort_len : cols;
+  for (int i = lane; i < m; i += NR_WAVE) { h.val[i] = srow[i]; h.idx[i] = i; }
+  wave_lds_sync();
+  nr::heap_make(h, m);
+  wave_lds_sync();
+  for (int base = m; base < cols; base += NR_WAVE) {
+    const int e = base + lane;
+    bool live = e < cols;
+    const float v = live ? srow[e] : 0.f;
+    for (;;) {
+      const float root = h.val[0];
+      const uint64_t mask = __ballot(live && v > root);
+      if (!mask) break;
+      const int t = __builtin_ctzll(mask);
+      const float vt = __builtin_bit_cast(
+          float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+      nr::heap_adjust(h, 0, m, vt, base + t);
+      wave_lds_sync();
+      live = live && lane > t;
+    }
+  }
+  nr::heap_sort(h, m);
+  wave_lds_sync();
+  for (int r = lane; r < cut && r < m; r += NR_WAVE)
+    rank[(int64_t)row * kRankStride + r] = h.idx[r];
+  if (lane == 0 && n_exact) atomicAdd(n_exact, 1);
+}
+
+// ----------------------------------------------------------------------------
+// Metrics: one wave per row; lane k tests rank k against the user's ascending
+// test list, then lane m evaluates metric m sequentially over k (the float /
+// double sequence of metric.h, see nr::metric_eval).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
+    const int32_t* __restrict__ rank, int rows, int top_k, const int32_t* __restrict__ users,
+    const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices, MetricIds mids,
+    InvLog2Table tbl, float* __restrict__ out, int32_t* __restrict__ topk_out) {
+  __shared__ unsigned char s_hit[kSelWaves][128];
+  const int wave = threadIdx.x / NR_WAVE;
+  const int lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  const int64_t t = users ? (int64_t)users[row] : (int64_t)row;
+  const int64_t tb = t_indptr[t], te = t_indptr[t + 1];
+  const int T = (int)(te - tb);
+  for (int k = lane; k < top_k; k += NR_WAVE) {
+    const int32_t item = rank[(int64_t)row * kRankStride + k];
+    s_hit[wave][k] = nr::sorted_contains(t_indices + tb, T, item) ? 1 : 0;
+    if (topk_out) topk_out[(int64_t)row * top_k + k] = item;
+  }
+  wave_lds_sync();
+  if (lane < mids.n) {
+    const unsigned char* hit = s_hit[wave];
+    float* o = out + ((int64_t)row * mids.n + lane) * top_k;
+    nr::metric_eval(mids.id[lane], [hit](int i) { return hit[i] != 0; }, top_k, T, tbl.v, o);
+  }
+}
+
+__global__ void copy_rank_kernel(const int32_t* __restrict__ rank, int rows, int top_k,
+                                 int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * top_k) return;
+  const int r = (int)(i / top_k), k = (int)(i % top_k);
+  out[i] = rank[(int64_t)r * kRankStride + k];
+}
+
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void mask_train_kernel(
+    float* __restrict__ scores, int64_t ld, const int32_t* __restrict__ users, int rows, int cols,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices) {
+  const int wave = threadIdx.x / NR_WAVE;
+  const int lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
+  const int64_t b = indptr[u], e = indptr[u + 1];
+  float* srow = scores + (int64_t)row * ld;
+  for (int64_t j = b + lane; j < e; j += NR_WAVE) {
+    const int32_t it = indices[j];
+    if (it >= 0 && it < cols) srow[it] = -INFINITY;
+  }
+}
+
+// column sums in fp64: stage 1 sums 256-row slabs, stage 2 adds the slabs in
+// slab order (fixed order => deterministic).
+constexpr int kSlabRows = 256;
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ mat, int64_t ld,
+                                                     int rows, int cols,
+                                                     double* __restrict__ partial) {
+  __shared__ double s_part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * kSlabRows;
+  const int r1 = min(rows, r0 + kSlabRows);
+  double acc = 0.0;
+  if (c < cols)
+    for (int r = r0 + g; r < r1; r += 4) acc += (double)mat[(int64_t)r * ld + c];
+  s_part[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && c < cols)
+    partial[(int64_t)blockIdx.y * cols + c] =
+        ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) +
+        s_part[3][threadIdx.x];
+}
+__global__ void colsum_stage2(const double* __restrict__ partial, int n_slabs, int cols,
+                              double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double acc = 0.0;
+  for (int s = 0; s < n_slabs; ++s) acc += partial[(int64_t)s * cols + c];
+  out[c] = acc;
+}
+
+struct EvalWs {
+  int32_t* rank;
+  int32_t* flag;
+  int32_t* n_exact;
+};
+size_t eval_ws_bytes(int rows) {
+  return nr_align_up((size_t)rows * kRankStride * sizeof(int32_t), 256) +
+         nr_align_up((size_t)rows * sizeof(int32_t), 256) + 256;
+}
+EvalWs carve_ws(void* ws, int rows) {
+  char* p = (char*)ws;
+  EvalWs w;
+  w.rank = (int32_t*)p;
+  p += nr_align_up((size_t)rows * kRankStride * sizeof(int32_t), 256);
+  w.flag = (int32_t*)p;
+  p += nr_align_up((size_t)rows * sizeof(int32_t), 256);
+  w.n_exact = (int32_t*)p;
+  return w;
+}
+
+int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sort_len, int cut,
+                  const EvalWs& w, hipStream_t st) {
+  const int blocks = (rows + kSelWaves - 1) / kSelWaves;
+  NR_CHECK_HIP(hipMemsetAsync(w.n_exact, 0, sizeof(int32_t), st));
+  const bool vec4 = (ld % 4 == 0) && (((uintptr_t)d_scores) % 16 == 0);
+  if (vec4)
+    hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st,
+                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag);
+  else
+    hipLaunchKernelGGL(select_rows_kernel<1>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st,
+                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(exact_rows_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_scores,
+                     ld, rows, cols, sort_len, cut, w.rank, w.flag, w.n_exact);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_eval_workspace_bytes(int rows, int top_k, size_t* bytes) {
+  NR_REQUIRE(rows >= 0 && top_k >= 1 && top_k <= 128 && bytes, NR_ERR_ARG,
+             "eval_workspace_bytes: rows=%d top_k=%d (top_k must be in 1..128)", rows, top_k);
+  *bytes = eval_ws_bytes(rows > 0 ? rows : 1);
+  return NR_OK;
+}
+
+int nrhip_mask_train(float* d_scores, int64_t ld, const int32_t* d_users, int rows, int cols,
+                     const int64_t* d_tr_indptr, const int32_t* d_tr_indices, void* stream) {
+  NR_REQUIRE(d_scores && d_tr_indptr && d_tr_indices && ld >= cols && rows >= 0, NR_ERR_ARG,
+             "mask_train: bad arguments");
+  if (rows == 0) return NR_OK;
+  hipLaunchKernelGGL(mask_train_kernel, dim3((rows + kSelWaves - 1) / kSelWaves),
+                     dim3(kSelWaves * NR_WAVE), 0, (hipStream_t)stream, d_scores, ld, d_users, rows,
+                     cols, d_tr_indptr, d_tr_indices);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_eval_scores(const float* d_scores, int64_t ld, int rows, int cols,
+                      const int32_t* d_users, const int64_t* d_truth_indptr,
+                      const int32_t* d_truth_indices, const int32_t* metric_ids_host, int n_metric,
+                      int top_k, float* d_out, int32_t* d_topk_out, int32_t* d_n_exact, void* d_ws,
+                      size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_scores && d_truth_indptr && d_truth_indices && metric_ids_host && d_out && d_ws,
+             NR_ERR_ARG, "eval_scores: null pointer argument");
+  NR_REQUIRE(top_k >= 1 && top_k <= 128, NR_ERR_UNSUPPORTED,
+             "eval_scores: top_k=%d outside 1..128", top_k);
+  NR_REQUIRE(cols >= top_k, NR_ERR_ARG,
+             "eval_scores: %d columns < top_k=%d (the reference reads past its buffer here)", cols,
+             top_k);
+  NR_REQUIRE(n_metric >= 1 && n_metric <= 8, NR_ERR_ARG, "eval_scores: n_metric=%d outside 1..8",
+             n_metric);
+  NR_REQUIRE(ld >= cols && rows >= 0, NR_ERR_ARG, "eval_scores: ld=%lld < cols=%d",
+             (long long)ld, cols);
+  MetricIds mids;
+  mids.n = n_metric;
+  for (int i = 0; i < n_metric; ++i) {
+    NR_REQUIRE(metric_ids_host[i] >= 1 && metric_ids_host[i] <= 5, NR_ERR_ARG,
+               "eval_scores: metric id %d is not one of 1..5", metric_ids_host[i]);
+    mids.id[i] = metric_ids_host[i];
+  }
+  if (rows == 0) return NR_OK;
+  NR_REQUIRE(ws_bytes >= eval_ws_bytes(rows), NR_ERR_WORKSPACE,
+             "eval_scores: workspace %zu < %zu bytes", ws_bytes, eval_ws_bytes(rows));
+  hipStream_t st = (hipStream_t)stream;
+  EvalWs w = carve_ws(d_ws, rows);
+  const int sort_len = (2 * top_k < cols) ? 2 * top_k : cols;   // evaluate.h:37
+  int rc = run_selection(d_scores, ld, rows, cols, sort_len, top_k, w, st);
+  if (rc != NR_OK) return rc;
+  InvLog2Table tbl;
+  for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));  // metric.h:78
+  hipLaunchKernelGGL(metrics_kernel, dim3((rows + kSelWaves - 1) / kSelWaves),
+                     dim3(kSelWaves * NR_WAVE), 0, st, w.rank, rows, top_k, d_users,
+                     d_truth_indptr, d_truth_indices, mids, tbl, d_out, d_topk_out);
+  NR_LAUNCH_CHECK();
+  if (d_n_exact)
+    NR_CHECK_HIP(hipMemcpyAsync(d_n_exact, w.n_exact, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return NR_OK;
+}
+
+int nrhip_arg_topk(const float* d_scores, int64_t ld, int rows, int cols, int top_k,
+                   int32_t* d_out, int32_t* d_n_exact, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_scores && d_out && d_ws, NR_ERR_ARG, "arg_topk: null pointer argument");
+  NR_REQUIRE(top_k >= 1 && top_k <= 256, NR_ERR_UNSUPPORTED, "arg_topk: top_k=%d outside 1..256",
+             top_k);
+  NR_REQUIRE(cols >= top_k && ld >= cols && rows >= 0, NR_ERR_ARG,
+             "arg_topk: cols=%d top_k=%d ld=%lld", cols, top_k, (long long)ld);
+  if (rows == 0) return NR_OK;
+  NR_REQUIRE(ws_bytes >= eval_ws_bytes(rows), NR_ERR_WORKSPACE,
+             "arg_topk: workspace %zu < %zu bytes", ws_bytes, eval_ws_bytes(rows));
+  hipStream_t st = (hipStream_t)stream;
+  EvalWs w = carve_ws(d_ws, rows);
+  int rc = run_selection(d_scores, ld, rows, cols, top_k, top_k, w, st);   // arg_topk.h:22
+  if (rc != NR_OK) return rc;
+  const int64_t n = (int64_t)rows * top_k;
+  hipLaunchKernelGGL(copy_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.rank,
+                     rows, top_k, d_out);
+  NR_LAUNCH_CHECK();
+  if (d_n_exact)
+    NR_CHECK_HIP(hipMemcpyAsync(d_n_exact, w.n_exact, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return NR_OK;
+}
+
+int nrhip_colsum_workspace_bytes(int rows, int cols, size_t* bytes) {
+  NR_REQUIRE(rows >= 0 && cols >= 0 && bytes, NR_ERR_ARG, "colsum_workspace_bytes: bad arguments");
+  *bytes = (size_t)((rows + kSlabRows - 1) / kSlabRows + 1) * (size_t)cols * sizeof(double);
+  return NR_OK;
+}
+
+int nrhip_colsum_f64(const float* d_mat, int64_t ld, int rows, int cols, double* d_out,
+                     void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_mat && d_out && d_ws && ld >= cols, NR_ERR_ARG, "colsum_f64: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0 || cols == 0) {
+    if (cols) NR_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * cols, st));
+    return NR_OK;
+  }
+  const int n_slabs = (rows + kSlabRows - 1) / kSlabRows;
+  NR_REQUIRE(ws_bytes >= (size_t)n_slabs * cols * sizeof(double), NR_ERR_WORKSPACE,
+             "colsum_f64: workspace too small");
+  hipLaunchKernelGGL(colsum_stage1, dim3((cols + 63) / 64, n_slabs), dim3(256), 0, st, d_mat, ld,
+                     rows, cols, (double*)d_ws);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_stage2, dim3((cols + 255) / 256), dim3(256), 0, st,
+                     (const double*)d_ws, n_slabs, cols, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

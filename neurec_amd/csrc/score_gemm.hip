@@ -1,0 +1,194 @@
+// score_gemm.hip — evaluation scoring  S = P[users] · Qᵀ  on the fp32 matrix cores.
+//
+// Stands in for np.matmul(user_embed, item_embeddings.T)
+// (model/general_recommender/MF.py:120-122, NGCF.py:149-150) and the TF
+// matmul of LightGCN.predict (LightGCN.py:118-119,187-189).
+//
+// Numerics: every score is the k-ascending chain
+//     acc = 0;  for k in 0..d-1: acc = fmaf(P[u][k], Q[i][k], acc)
+// which is what v_mfma_f32_32x32x2_f32 computes bit for bit when the k-steps
+// are issued in order (exact fp32 in, fp32 accumulate; no reduced precision).
+// oracle/ restates the same chain on the CPU.
+//
+// Layout: both factors are first copied k-major (PT[k][user], QT[k][item]) so
+// that an MFMA operand — lane l wants element [row l&31][k = 2s + (l>>5)] —
+// is one coalesced 128-byte segment per half-wave, straight from L2 to a
+// VGPR: no LDS staging, no barriers.  A wave keeps a 64-user A panel in
+// registers and streams 64-item B tiles; the four waves of a block take
+// four user panels against the same item tiles so the B lines are shared in
+// L1.  The kernel is bound by the HBM write of S (4·I bytes per user), not by
+// the matrix pipe: d is only 16..128.
+#include "nr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// dst[k][r] = (r < n && k < d) ? src[id(r)][k] : 0   for k < dp, r < npad
+__global__ __launch_bounds__(256) void gather_transpose_kernel(
+    const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ ids, int n, int d,
+    float* __restrict__ dst, int npad, int dp) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = r0 + rr * 4 + ty, k = k0 + tx;
+    float val = 0.f;
+    if (r < n && k < d) {
+      const int64_t sr = ids ? (int64_t)ids[r] : (int64_t)r;
+      val = src[sr * ld + k];
+    }
+    tile[rr * 4 + ty][tx] = val;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = k0 + kk * 4 + ty, r = r0 + tx;
+    if (k < dp && r < npad) dst[(int64_t)k * npad + r] = tile[tx][kk * 4 + ty];
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_gemm_kernel(
+    const float* __restrict__ PT, int bpad, const float* __restrict__ QT, int ipad, int rows,
+    float* __restrict__ S, int64_t lds, int wcols, int tiles_per_chunk) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int u0 = (blockIdx.x * 4 + wave) * 64;
+  if (u0 >= bpad) return;
+
+  float a0[KS], a1[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float* p = PT + (int64_t)(2 * s + h) * bpad + u0 + j;
+    a0[s] = p[0];
+    a1[s] = p[32];
+  }
+  const int n_tiles = ipad / 64;
+  const int t_begin = blockIdx.y * tiles_per_chunk;
+  const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int it = t * 64;
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const float* q = QT + (int64_t)h * ipad + it + j;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float b0 = q[(int64_t)(2 * s) * ipad];
+      const float b1 = q[(int64_t)(2 * s) * ipad + 32];
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1, c11, 0, 0, 0);
+    }
+    // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const int ua = u0 + rr, ub = u0 + 32 + rr;
+      const int ca = it + j, cb = it + 32 + j;
+      if (ua < rows) {
+        if (ca < wcols) S[(int64_t)ua * lds + ca] = c00[reg];
+        if (cb < wcols) S[(int64_t)ua * lds + cb] = c01[reg];
+      }
+      if (ub < rows) {
+        if (ca < wcols) S[(int64_t)ub * lds + ca] = c10[reg];
+        if (cb < wcols) S[(int64_t)ub * lds + cb] = c11[reg];
+      }
+    }
+  }
+}
+
+int padded_dim(int d) {
+  const int opts[5] = {16, 32, 48, 64, 128};
+  for (int i = 0; i < 5; ++i)
+    if (d <= opts[i]) return opts[i];
+  return -1;
+}
+inline int round_up64(int x) { return (x + 63) / 64 * 64; }
+
+struct GemmWs {
+  float* QT;
+  float* PT;
+  size_t qt_bytes, pt_bytes;
+};
+GemmWs carve(void* ws, int rows, int cols, int dp) {
+  GemmWs g;
+  g.qt_bytes = nr_align_up((size_t)dp * round_up64(cols) * sizeof(float), 256);
+  g.pt_bytes = nr_align_up((size_t)dp * round_up64(rows > 0 ? rows : 1) * sizeof(float), 256);
+  g.QT = (float*)ws;
+  g.PT = (float*)((char*)ws + g.qt_bytes);
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_score_gemm_workspace_bytes(int rows, int cols, int d, size_t* bytes) {
+  NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && d >= 1, NR_ERR_ARG,
+             "score_gemm_workspace_bytes: bad arguments");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_gemm: embedding dim %d > 128 not built", d);
+  GemmWs g = carve(nullptr, rows, cols, dp);
+  *bytes = g.qt_bytes + g.pt_bytes;
+  return NR_OK;
+}
+
+int nrhip_score_gemm_prepare_items(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws,
+                                   size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_Q && d_ws && cols >= 1 && d >= 1 && ldq >= d, NR_ERR_ARG,
+             "score_gemm_prepare_items: bad arguments");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_gemm: embedding dim %d > 128 not built", d);
+  GemmWs g = carve(d_ws, 0, cols, dp);
+  NR_REQUIRE(ws_bytes >= g.qt_bytes, NR_ERR_WORKSPACE, "score_gemm_prepare_items: workspace small");
+  const int ipad = round_up64(cols);
+  hipLaunchKernelGGL(gather_transpose_kernel, dim3(ipad / 64, (dp + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, d_Q, ldq, (const int32_t*)nullptr, cols, d, g.QT, ipad,
+                     dp);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
+                     int d, float* d_S, int64_t lds, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_P && d_S && d_ws && cols >= 1 && d >= 1 && ldp >= d && lds >= cols && rows >= 0,
+             NR_ERR_ARG, "score_gemm: bad arguments");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_gemm: embedding dim %d > 128 not built", d);
+  if (rows == 0) return NR_OK;
+  GemmWs g = carve(d_ws, rows, cols, dp);
+  NR_REQUIRE(ws_bytes >= g.qt_bytes + g.pt_bytes, NR_ERR_WORKSPACE,
+             "score_gemm: workspace %zu < %zu", ws_bytes, g.qt_bytes + g.pt_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int bpad = round_up64(rows), ipad = round_up64(cols);
+  hipLaunchKernelGGL(gather_transpose_kernel, dim3(bpad / 64, (dp + 63) / 64), dim3(256), 0, st,
+                     d_P, ldp, d_users, rows, d, g.PT, bpad, dp);
+  NR_LAUNCH_CHECK();
+  const int wcols = (int)(lds < (int64_t)ipad ? lds : (int64_t)ipad);
+  const int bx = (bpad / 64 + 3) / 4;
+  const int n_tiles = ipad / 64;
+  // aim for >= 2048 blocks so all 256 CUs stay busy, but keep chunks >= 4 tiles
+  int tpc = (int)(((int64_t)n_tiles * bx + 2047) / 2048);
+  if (tpc < 4) tpc = 4;
+  if (tpc > n_tiles) tpc = n_tiles;
+  const int by = (n_tiles + tpc - 1) / tpc;
+  dim3 grid(bx, by), block(256);
+#define NR_GEMM_CASE(KS)                                                                    \
+  hipLaunchKernelGGL(score_gemm_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QT, ipad, rows, \
+                     d_S, lds, wcols, tpc)
+  switch (dp) {
+    case 16: NR_GEMM_CASE(8); break;
+    case 32: NR_GEMM_CASE(16); break;
+    case 48: NR_GEMM_CASE(24); break;
+    case 64: NR_GEMM_CASE(32); break;
+    case 128: NR_GEMM_CASE(64); break;
+    default: NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "score_gemm: dp=%d", dp);
+  }
+#undef NR_GEMM_CASE
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+"""Tensor-level front end of the HIP engine.
+
+PyTorch-ROCm is used for device memory, streams and (elsewhere) collectives;
+every computation below is a call into libneurec_hip.so through the C ABI
+(include/neurec_hip.h) with raw device pointers.  Nothing here computes on the
+CPU and nothing falls back to torch ops.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+
+METRIC_IDS = {"Precision": 1, "Recall": 2, "MAP": 3, "NDCG": 4, "MRR": 5}  # metric.h:111-117
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("neurec_amd needs a ROCm GPU (MI355X / gfx950); no CPU path exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return C.c_void_p(0)
+        raise ValueError("tensor argument is None")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("expected a CUDA/ROCm tensor, got %r" % (type(t),))
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class Workspace:
+    """A grow-only device scratch buffer (the C ABI never allocates)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=require_gpu())
+        return self.buf
+
+
+class DeviceCSR:
+    """indptr (int64) + ascending indices (int32) of a sparse 0/1 matrix on the device."""
+
+    def __init__(self, indptr, indices, n_cols):
+        dev = require_gpu()
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.n_rows = len(indptr) - 1
+        self.n_cols = int(n_cols)
+        self.nnz = int(indptr[-1])
+        self.h_indptr = indptr
+        self.indptr = torch.from_numpy(indptr).to(dev)
+        self.indices = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).to(dev)
+
+    @staticmethod
+    def from_scipy(mat):
+        m = mat.tocsr().copy()
+        m.sum_duplicates()
+        m.sort_indices()
+        return DeviceCSR(m.indptr, m.indices, m.shape[1])
+
+    @staticmethod
+    def from_dict(d, n_rows, n_cols):
+        """{row: iterable of column ids} (the reference's user->items dicts)."""
+        counts = np.zeros(n_rows + 1, dtype=np.int64)
+        for r, items in d.items():
+            counts[int(r) + 1] = len(items)
+        indptr = np.cumsum(counts)
+        indices = np.empty(int(indptr[-1]), dtype=np.int32)
+        for r, items in d.items():
+            b = indptr[int(r)]
+            indices[b:b + len(items)] = np.sort(np.asarray(items, dtype=np.int32))
+        return DeviceCSR(indptr, indices, n_cols)
+
+    def row_of(self):
+        """User id of every CSR position (users_list of data/sampler.py:24-39)."""
+        rows = np.repeat(np.arange(self.n_rows, dtype=np.int32), np.diff(self.h_indptr))
+        return torch.from_numpy(rows if len(rows) else np.zeros(1, np.int32)).to(self.indptr.device)
+
+
+# ----------------------------------------------------------------------------- evaluator
+_eval_ws = Workspace()
+_gemm_ws = Workspace()
+_misc_ws = Workspace()
+
+
+def mask_train(scores, users, train_csr, cols=None):
+    """scores[r, train items of users[r]] = -inf in place (uni_evaluator.py:140-143)."""
+    rows = scores.shape[0]
+    cols = scores.shape[1] if cols is None else cols
+    call("nrhip_mask_train", _ptr(scores, torch.float32), scores.stride(0),
+         _ptr(users, torch.int32, allow_none=True), rows, cols, _ptr(train_csr.indptr),
+         _ptr(train_csr.indices), _stream())
+
+
+def eval_scores(scores, truth_csr, metric_ids, top_k, users=None, cols=None, out=None,
+                want_topk=False, want_exact_count=False):
+    """Top-K + metrics of each score row; returns float32 [rows, len(metric_ids)*top_k]."""
+    if scores.dim() != 2 or scores.stride(1) != 1:
+        raise ValueError("scores must be 2-D with unit inner stride")
+    rows = scores.shape[0]
+    cols = scores.shape[1] if cols is None else cols
+    dev = scores.device
+    nm = len(metric_ids)
+    if out is None:
+        out = torch.empty((rows, nm * top_k), dtype=torch.float32, device=dev)
+    topk = torch.empty((rows, top_k), dtype=torch.int32, device=dev) if want_topk else None
+    nex = torch.zeros(1, dtype=torch.int32, device=dev) if want_exact_count else None
+    nbytes = C.c_size_t(0)
+    call("nrhip_eval_workspace_bytes", rows, top_k, C.byref(nbytes))
+    ws = _eval_ws.get(nbytes.value)
+    ids = (C.c_int * nm)(*[int(m) for m in metric_ids])
+    call("nrhip_eval_scores", C.c_void_p(scores.data_ptr()), scores.stride(0), rows, cols,
+         _ptr(users, torch.int32, allow_none=True), _ptr(truth_csr.indptr),
+         _ptr(truth_csr.indices), ids, nm, top_k, _ptr(out, torch.float32),
+         _ptr(topk, allow_none=True), _ptr(nex, allow_none=True), _ptr(ws), ws.numel(), _stream())
+    res = [out]
+    if want_topk:
+        res.append(topk)
+    if want_exact_count:
+        res.append(nex)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def arg_topk(scores, top_k, cols=None, want_exact_count=False):
+    """Per-row arg-top-K (util/cython/arg_topk.pyx:16-35) -> int32 [rows, top_k]."""
+    rows = scores.shape[0]
+    cols = scores.shape[1] if cols is None else cols
+    out = torch.empty((rows, top_k), dtype=torch.int32, device=scores.device)
+    nex = torch.zeros(1, dtype=torch.int32, device=scores.device) if want_exact_count else None
+    nbytes = C.c_size_t(0)
+    call("nrhip_eval_workspace_bytes", rows, min(top_k, 128), C.byref(nbytes))
+    ws = _eval_ws.get(nbytes.value)
+    call("nrhip_arg_topk", C.c_void_p(scores.data_ptr()), scores.stride(0), rows, cols, top_k,
+         _ptr(out), _ptr(nex, allow_none=True), _ptr(ws), ws.numel(), _stream())
+    return (out, nex) if want_exact_count else out
+
+
+def colsum(mat):
+    """fp64 column sums of a float32 matrix (deterministic order)."""
+    rows, cols = mat.shape
+    out = torch.empty(cols, dtype=torch.float64, device=mat.device)
+    nbytes = C.c_size_t(0)
+    call("nrhip_colsum_workspace_bytes", rows, cols, C.byref(nbytes))
+    ws = _misc_ws.get(nbytes.value)
+    call("nrhip_colsum_f64", _ptr(mat, torch.float32), mat.stride(0), rows, cols, _ptr(out),
+         _ptr(ws), ws.numel(), _stream())
+    return out
+
+
+class ScoreGemm:
+    """S = P[users] @ Q.T on the fp32 matrix cores; Q is prepared once per evaluation."""
+
+    def __init__(self, item_table, max_rows):
+        self.cols, self.d = item_table.shape
+        self.max_rows = int(max_rows)
+        nbytes = C.c_size_t(0)
+        call("nrhip_score_gemm_workspace_bytes", self.max_rows, self.cols, self.d, C.byref(nbytes))
+        self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=item_table.device)
+        self.ld = (self.cols + 63) // 64 * 64
+        call("nrhip_score_gemm_prepare_items", _ptr(item_table, torch.float32),
+             item_table.stride(0), self.cols, self.d, _ptr(self.ws), self.ws.numel(), _stream())
+
+    def new_score_buffer(self, rows=None):
+        rows = self.max_rows if rows is None else rows
+        return torch.empty((rows, self.ld), dtype=torch.float32, device=self.ws.device)
+
+    def __call__(self, user_table, users, out=None):
+        rows = user_table.shape[0] if users is None else users.numel()
+        if rows > self.max_rows:
+            raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
+        if out is None:
+            out = self.new_score_buffer(rows)
+        call("nrhip_score_gemm", _ptr(user_table, torch.float32), user_table.stride(0),
+             _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d,
+             C.c_void_p(out.data_ptr()), out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
+        return out[:rows]
+
+
+# ----------------------------------------------------------------------------- sampler
+def sample_bpr_epoch(train_csr, row_of, n_items, neg_num, seed, epoch, shuffle=True, begin=0,
+                     count=None, out=None):
+    """One epoch (or a slice of it) of BPR triplets: (users, pos, neg) int32 device tensors."""
+    n_inter = train_csr.nnz
+    count = n_inter - begin if count is None else count
+    dev = train_csr.indptr.device
+    if out is None:
+        users = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
+        pos = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
+        neg = torch.empty(max(count * neg_num, 1), dtype=torch.int32, device=dev)
+    else:
+        users, pos, neg = out
+    call("nrhip_sample_bpr_epoch", _ptr(train_csr.indptr), _ptr(train_csr.indices),
+         _ptr(row_of, torch.int32), n_inter, n_items, neg_num, C.c_uint64(seed & (2**64 - 1)),
+         C.c_uint64(epoch), 1 if shuffle else 0, begin, count, _ptr(users), _ptr(pos), _ptr(neg),
+         _stream())
+    return users[:count], pos[:count], neg[:count * neg_num]
+
+
+def randint_choice_batch(high, sizes, exclusion_csr, replace, seed, counter):
+    """Device half of batch_randint_choice: returns an int32 tensor of sum(sizes) draws."""
+    dev = require_gpu()
+    sizes = np.asarray(sizes, dtype=np.int64)
+    off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=off[1:])
+    total = int(off[-1])
+    d_off = torch.from_numpy(off).to(dev)
+    out = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    eptr = exclusion_csr.indptr if exclusion_csr is not None else None
+    eidx = exclusion_csr.indices if exclusion_csr is not None else None
+    call("nrhip_randint_choice_batch", int(high), len(sizes), total, _ptr(d_off),
+         _ptr(eptr, allow_none=True), _ptr(eidx, allow_none=True), 1 if replace else 0,
+         C.c_uint64(seed & (2**64 - 1)), C.c_uint64(counter), _ptr(out), _stream())
+    return out[:total], off
+
+
+# ----------------------------------------------------------------------------- training
+class AdamState:
+    """fp32 running powers of beta1/beta2, advanced like TF-1.12's _finish."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lr = np.float32(lr)
+        self.beta1, self.beta2, self.eps = np.float32(beta1), np.float32(beta2), np.float32(eps)
+        self.b1p, self.b2p = np.float32(beta1), np.float32(beta2)
+        self.t = 0
+
+    def alpha(self):
+        one = np.float32(1.0)
+        return np.float32(self.lr * np.sqrt(one - self.b2p) / (one - self.b1p))
+
+    def advance(self):
+        self.b1p = np.float32(self.b1p * self.beta1)
+        self.b2p = np.float32(self.b2p * self.beta2)
+        self.t += 1
+
+
+def adam_sparse(var, m, v, grad, st):
+    call("nrhip_adam_sparse_tf", _ptr(var, torch.float32), _ptr(m), _ptr(v), _ptr(grad),
+         var.numel(), float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
+         _stream())
+
+
+def adam_dense(var, m, v, grad, st, clear_grad=True):
+    call("nrhip_adam_dense_tf", _ptr(var, torch.float32), _ptr(m), _ptr(v), _ptr(grad),
+         var.numel(), float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
+         1 if clear_grad else 0, _stream())
+
+
+def bpr_mf_grad(P, Q, users, pos, neg, reg, GP, GQ, terms, loss2):
+    call("nrhip_bpr_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
+         _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32), users.numel(),
+         float(reg), _ptr(GP), _ptr(GQ), _ptr(terms), _ptr(loss2), _stream())
+
+
+def lightgcn_bpr_grad(Esum, E0, n_users, n_layers, users, pos, neg, reg, Gstar, Greg, terms, loss2):
+    call("nrhip_lightgcn_bpr_grad", _ptr(Esum, torch.float32), _ptr(E0, torch.float32), n_users,
+         E0.shape[1], n_layers, _ptr(users, torch.int32), _ptr(pos, torch.int32),
+         _ptr(neg, torch.int32), users.numel(), float(reg), _ptr(Gstar), _ptr(Greg), _ptr(terms),
+         _ptr(loss2), _stream())
+
+
+def scale(x, a, out):
+    call("nrhip_scale", _ptr(x), float(a), _ptr(out), x.numel(), _stream())
+
+
+def add(x, y, out):
+    call("nrhip_add", _ptr(x), _ptr(y), _ptr(out), x.numel(), _stream())
+
+
+def div_scalar(x, denom, out):
+    call("nrhip_div_scalar", _ptr(x), float(denom), _ptr(out), x.numel(), _stream())
+
+
+class SpmmCSR:
+    """A CSR matrix resident on the device plus its row-segment plan."""
+
+    def __init__(self, indptr, indices, vals, n_cols=None):
+        dev = require_gpu()
+        self.h_indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.n_rows = len(self.h_indptr) - 1
+        self.nnz = int(self.h_indptr[-1])
+        self.n_cols = self.n_rows if n_cols is None else n_cols
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        val = np.ascontiguousarray(vals, dtype=np.float32)
+        self.indices = torch.from_numpy(idx if len(idx) else np.zeros(1, np.int32)).to(dev)
+        self.vals = torch.from_numpy(val if len(val) else np.zeros(1, np.float32)).to(dev)
+        nbytes = C.c_size_t(0)
+        call("nrhip_spmm_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
+        self.plan_buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
+        self.plan = C.c_void_p(0)
+        call("nrhip_spmm_plan_create", self.h_indptr.ctypes.data_as(C.c_void_p), self.n_rows,
+             _ptr(self.plan_buf), self.plan_buf.numel(), _stream(), C.byref(self.plan))
+        nseg, nsplit = C.c_int64(0), C.c_int64(0)
+        call("nrhip_spmm_plan_info", self.plan, C.byref(nseg), C.byref(nsplit))
+        self.n_segments, self.n_split_rows = nseg.value, nsplit.value
+        self._ws = {}
+
+    @staticmethod
+    def from_scipy(mat):
+        m = mat.tocsr().astype(np.float32)
+        m.sort_indices()
+        return SpmmCSR(m.indptr, m.indices, m.data, m.shape[1])
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None) is not None and self.plan.value:
+                _lib.lib.nrhip_spmm_plan_destroy(self.plan)
+                self.plan = C.c_void_p(0)
+        except Exception:
+            pass
+
+    def _workspace(self, d):
+        if d not in self._ws:
+            nbytes = C.c_size_t(0)
+            call("nrhip_spmm_workspace_bytes", self.plan, d, C.byref(nbytes))
+            self._ws[d] = torch.empty(max(nbytes.value, 256), dtype=torch.uint8,
+                                      device=self.indices.device)
+        return self._ws[d]
+
+    def matmul(self, X, out=None, addend=None, sum_in=None, sum_out=None):
+        """out = A @ X (+ addend); sum_out = sum_in + out (each optional)."""
+        d = X.shape[1]
+        ws = self._workspace(d)
+        call("nrhip_spmm_csr", self.plan, _ptr(self.indices), _ptr(self.vals),
+             _ptr(X, torch.float32), d, _ptr(out, torch.float32, allow_none=True),
+             _ptr(addend, allow_none=True), _ptr(sum_in, allow_none=True),
+             _ptr(sum_out, allow_none=True), _ptr(ws), ws.numel(), _stream())
+        return out
+
+    def algorithmic_bytes(self, d):
+        """CSR idx+val read once, X read once, Y written once."""
+        return self.nnz * 8 + (self.n_rows + 1) * 8 + 2 * self.n_rows * d * 4
+
+
+def device_info():
+    cu, clk, mem = C.c_int(0), C.c_int(0), C.c_size_t(0)
+    name = C.create_string_buffer(128)
+    call("nrhip_device_info", C.byref(cu), C.byref(clk), C.byref(mem), name, 128)
+    return {"cu_count": cu.value, "clock_khz": clk.value, "hbm_bytes": mem.value,
+            "name": name.value.decode()}

@@ -1,0 +1,213 @@
+"""oracle.train — numpy restatement of the TensorFlow-1.12 half of the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+TensorFlow 1.12.3 (requirements.txt:4) is not installable here, so the graph
+half of the reference (model forward/backward/Adam) cannot be executed; this
+module restates its arithmetic from the reference's model files plus the
+published TF-1.12 kernels [EXT]:
+
+  MF graph        model/general_recommender/MF.py:54-72, util/learner.py:19-22,
+                  util/tool.py:216-217
+  LightGCN graph  model/general_recommender/LightGCN.py:34-78 (adjacency),
+                  :132-149 (propagation + layer mean), :156-166 (loss)
+  Adam            tf.train.AdamOptimizer [EXT]: python/training/adam.py
+                  (_apply_sparse_shared: every row decays/updates each step) and
+                  core/kernels/training_ops.cc ApplyAdam (dense)
+  softplus        core/kernels/softplus_op.h (thresholded form) [EXT]
+
+Every function takes `dtype`: np.float32 is the restatement, np.float64 its
+error-bar twin.  PARITY UNPINNED by the reference for this half (no TF here);
+the pin is fp32-vs-fp64 agreement and the HIP engine agreeing with both.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+# ------------------------------------------------------------------ shared pieces
+def tf_softplus(z):
+    z = np.asarray(z)
+    thr = np.log(np.finfo(z.dtype).eps) + 2.0
+    with np.errstate(over="ignore"):
+        e = np.exp(z)
+        return np.where(z > -thr, z, np.where(z < thr, e, np.log1p(e))).astype(z.dtype)
+
+
+def bpr_terms(x):
+    """loss_b = -log_sigmoid(x) = softplus(-x);  dloss/dx = -sigmoid(-x)."""
+    x = np.asarray(x)
+    with np.errstate(over="ignore"):
+        g = (-1.0 / (1.0 + np.exp(x))).astype(x.dtype)
+    return tf_softplus(-x), g
+
+
+class Adam:
+    """Running fp32 powers as TF keeps them (beta1_power *= beta1 after each step)."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, dtype=np.float32):
+        self.dt = dtype
+        self.lr, self.b1, self.b2, self.eps = dtype(lr), dtype(beta1), dtype(beta2), dtype(eps)
+        self.b1p, self.b2p = dtype(beta1), dtype(beta2)
+
+    def alpha(self):
+        one = self.dt(1)
+        return self.dt(self.lr * np.sqrt(one - self.b2p) / (one - self.b1p))
+
+    def advance(self):
+        self.b1p = self.dt(self.b1p * self.b1)
+        self.b2p = self.dt(self.b2p * self.b2)
+
+    def dense(self, var, m, v, g):
+        """training_ops ApplyAdam, in place."""
+        one = self.dt(1)
+        a = self.alpha()
+        m += (g - m) * (one - self.b1)
+        v += (g * g - v) * (one - self.b2)
+        var -= (m * a) / (np.sqrt(v) + self.eps)
+
+    def sparse_swept(self, var, m, v, g_dense):
+        """adam.py _apply_sparse_shared with the summed row gradient scattered into
+        g_dense (zeros elsewhere): all rows decay and move every step."""
+        one = self.dt(1)
+        a = self.alpha()
+        m *= self.b1
+        m += g_dense * (one - self.b1)
+        v *= self.b2
+        v += (g_dense * g_dense) * (one - self.b2)
+        var -= a * m / (np.sqrt(v) + self.eps)
+
+
+# ------------------------------------------------------------------ BPR-MF
+def mf_loss_and_grads(P, Q, users, pos, neg, reg):
+    """One batch of MF.py:54-72: returns loss, dense dP, dense dQ (duplicates summed)."""
+    dt = P.dtype.type
+    p, qi, qj = P[users], Q[pos], Q[neg]
+    x = np.sum(p * qi, axis=1, dtype=dt) - np.sum(p * qj, axis=1, dtype=dt)
+    lb, g = bpr_terms(x)
+    l2 = (np.sum(p * p, dtype=dt) + np.sum(qj * qj, dtype=dt) + np.sum(qi * qi, dtype=dt)) / dt(2)
+    loss = np.sum(lb, dtype=dt) + dt(reg) * l2
+    gp = g[:, None] * (qi - qj) + dt(reg) * p
+    gqi = g[:, None] * p + dt(reg) * qi
+    gqj = -g[:, None] * p + dt(reg) * qj
+    dP = np.zeros_like(P)
+    dQ = np.zeros_like(Q)
+    np.add.at(dP, users, gp)
+    np.add.at(dQ, pos, gqi)
+    np.add.at(dQ, neg, gqj)
+    return loss, dP, dQ
+
+
+def mf_step(P, Q, mP, vP, mQ, vQ, users, pos, neg, reg, adam):
+    """sess.run((loss, optimizer)) of MF.py:101 — updates the six arrays in place."""
+    loss, dP, dQ = mf_loss_and_grads(P, Q, users, pos, neg, reg)
+    adam.sparse_swept(P, mP, vP, dP)
+    adam.sparse_swept(Q, mQ, vQ, dQ)
+    adam.advance()
+    return loss
+
+
+# ------------------------------------------------------------------ LightGCN
+def lightgcn_adjacency(user_idx, item_idx, n_users, n_items, adj_type="pre"):
+    """LightGCN.create_adj_mat (LightGCN.py:34-78): fp32 CSR on N = U+I nodes."""
+    user_np = np.asarray(user_idx, dtype=np.int32)
+    item_np = np.asarray(item_idx, dtype=np.int32)
+    ratings = np.ones_like(user_np, dtype=np.float32)
+    n = n_users + n_items
+    tmp = sp.csr_matrix((ratings, (user_np, item_np + n_users)), shape=(n, n))
+    adj = tmp + tmp.T
+
+    def single(a):
+        rowsum = np.array(a.sum(1))
+        with np.errstate(divide="ignore"):
+            d_inv = np.power(rowsum, -1).flatten()
+        d_inv[np.isinf(d_inv)] = 0.0
+        return sp.diags(d_inv).dot(a).tocoo()
+
+    if adj_type == "plain":
+        out = adj
+    elif adj_type == "norm":
+        out = single(adj + sp.eye(adj.shape[0]))
+    elif adj_type == "gcmc":
+        out = single(adj)
+    elif adj_type == "pre":
+        rowsum = np.array(adj.sum(1))
+        with np.errstate(divide="ignore"):
+            d_inv = np.power(rowsum, -0.5).flatten()
+        d_inv[np.isinf(d_inv)] = 0.0
+        d_mat = sp.diags(d_inv)
+        out = d_mat.dot(adj).dot(d_mat)
+    else:
+        mean_adj = single(adj)
+        out = mean_adj + sp.eye(mean_adj.shape[0])
+    out = out.tocsr().astype(np.float32)
+    out.sort_indices()
+    return out
+
+
+def spmm_rowwise(A, X):
+    """Y = A @ X with per-row ascending-column accumulation, product and sum rounded
+    separately in X's dtype (what scipy's csr_matvecs does; TF-CPU's
+    SparseTensorDenseMatMul walks the nnz in the same order)."""
+    return (A.astype(X.dtype) @ X).astype(X.dtype)
+
+
+def lightgcn_propagate(A, E0, n_layers):
+    """_create_lightgcn_embed (LightGCN.py:132-149): returns (E*, [E0..EL])."""
+    dt = E0.dtype.type
+    layers = [E0]
+    ego = E0
+    for _ in range(n_layers):
+        ego = spmm_rowwise(A, ego)
+        layers.append(ego)
+    acc = layers[0].copy()
+    for e in layers[1:]:
+        acc = acc + e
+    return (acc / dt(n_layers + 1)).astype(E0.dtype), layers
+
+
+def lightgcn_loss_and_grad(A, At, E0, n_users, n_layers, users, pos, neg, reg):
+    """Loss (LightGCN.py:156-166) and dLoss/dE0 through the propagation."""
+    dt = E0.dtype.type
+    Estar, _ = lightgcn_propagate(A, E0, n_layers)
+    iu, ii, ij = np.asarray(users), n_users + np.asarray(pos), n_users + np.asarray(neg)
+    eu, ei, ej = Estar[iu], Estar[ii], Estar[ij]
+    x = np.sum(eu * ei, axis=1, dtype=dt) - np.sum(eu * ej, axis=1, dtype=dt)
+    lb, g = bpr_terms(x)
+    zu, zi, zj = E0[iu], E0[ii], E0[ij]
+    regularizer = (np.sum(zu * zu, dtype=dt) + np.sum(zi * zi, dtype=dt) +
+                   np.sum(zj * zj, dtype=dt)) / dt(2)
+    mf_loss = np.sum(lb, dtype=dt)
+    emb_loss = dt(reg) * regularizer
+    Gstar = np.zeros_like(E0)
+    np.add.at(Gstar, iu, g[:, None] * (ei - ej))
+    np.add.at(Gstar, ii, g[:, None] * eu)
+    np.add.at(Gstar, ij, -g[:, None] * eu)
+    H = Gstar / dt(n_layers + 1)
+    G = H
+    for _ in range(n_layers):
+        G = H + spmm_rowwise(At, G)
+    R = np.zeros_like(E0)
+    np.add.at(R, iu, dt(reg) * zu)
+    np.add.at(R, ii, dt(reg) * zi)
+    np.add.at(R, ij, dt(reg) * zj)
+    return mf_loss, emb_loss, (G + R).astype(E0.dtype)
+
+
+def lightgcn_step(A, At, E0, m, v, n_users, n_layers, users, pos, neg, reg, adam):
+    """sess.run(self.opt) of LightGCN.py:178 — E0, m, v updated in place."""
+    mf_loss, emb_loss, grad = lightgcn_loss_and_grad(A, At, E0, n_users, n_layers, users, pos,
+                                                     neg, reg)
+    adam.dense(E0, m, v, grad)
+    adam.advance()
+    return mf_loss, emb_loss
+
+
+# ------------------------------------------------------------------ sampler structure
+def generate_positive_items(user_pos_dict):
+    """_generate_positive_items (data/sampler.py:24-39)."""
+    users_list, pos_items_list, user_pos_len = [], [], []
+    for user, pos_items in user_pos_dict.items():
+        user_pos_len.append([user, len(pos_items)])
+        users_list.extend([user] * len(pos_items))
+        pos_items_list.extend(pos_items)
+    return user_pos_len, users_list, pos_items_list
