@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py — BPR triplets/sec (+ eval users/sec, NDCG@10) on LightGCN-gowalla, MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of B=1024 BPR triplets of the
+gowalla-shaped synthetic graph (BASELINE.json configs[2]): device-side sampling of the
+epoch stream (amortised: one launch per epoch, inside the timed region), LightGCN
+propagation forward (3 SpMM), BPR head, propagation backward (3 SpMM), dense TF-Adam.
+All inputs are resident in HBM before the timed region.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--shape", default="gowalla")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=1024)     # conf/LightGCN.properties:5
+    ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--eval-batch", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--no-eval", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(train, test, E0, args, n_eval_users=1024):
+    """The CPU oracle (a port of the reference's TF graph: scipy CSR SpMM + numpy, 1 thread)
+    timed on this box's host cores on a bounded sample: `cpu_steps` LightGCN steps of the
+    same workload; plus the reference's own C++ evaluator (oracle/_ref, 8 threads, fed by
+    np.matmul as MF.py:120-122 does) on 1,024 users when it travelled with the snapshot."""
+    from oracle import native, ref, train as otrain
+    U, I = train.shape
+    coo = train.tocoo()
+    A = otrain.lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    At = A                                               # 'pre' is symmetric
+    E = E0.copy()
+    m, v = np.zeros_like(E), np.zeros_like(E)
+    adam = otrain.Adam(0.01)
+    rng = np.random.RandomState(1)
+    B = args.batch
+    rows = np.repeat(np.arange(U), np.diff(train.indptr))
+    otrain.lightgcn_step(A, At, E, m, v, U, args.layers, rows[:B], train.indices[:B],
+                         rng.randint(0, I, B), 1e-3, adam)          # warm caches
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        pick = rng.randint(0, train.nnz, B)
+        otrain.lightgcn_step(A, At, E, m, v, U, args.layers, rows[pick], train.indices[pick],
+                             rng.randint(0, I, B), 1e-3, adam)
+    dt = time.perf_counter() - t0
+    out = {"value": args.cpu_steps * B / dt, "unit": "triplets/s", "cores": 1, "kind": "port",
+           "sample": "%d LightGCN steps (B=%d, L=%d, d=%d) of the same graph, scipy CSR SpMM + "
+                     "numpy fp32, single thread" % (args.cpu_steps, B, args.layers, args.dim),
+           "host_cores_available": os.cpu_count()}
+    # evaluator leg
+    users = np.arange(min(n_eval_users, U), dtype=np.int32)
+    P, Q = E[:U], E[U:]
+    truth = [test.indices[test.indptr[u]:test.indptr[u + 1]].tolist() or [0] for u in users]
+    t0 = time.perf_counter()
+    for b in range(0, len(users), 128):                  # test_batch_size=128, NeuRec.properties:40
+        ub = users[b:b + 128]
+        S = np.ascontiguousarray(np.matmul(P[ub], Q.T), dtype=np.float32)
+        native.mask_train(S, ub, train.indptr.astype(np.int64), train.indices)
+        if ref.available():
+            ref.eval_matrix(S, truth[b:b + 128], [1, 2, 4, 3, 5], 20, threads=8)
+        else:
+            native.eval_matrix(S, truth[b:b + 128], [1, 2, 4, 3, 5], 20, threads=8)
+    dte = time.perf_counter() - t0
+    out["eval"] = {"value": len(users) / dte, "unit": "users/s", "cores": 8,
+                   "kind": "reference" if ref.available() else "port",
+                   "sample": "%d users, np.matmul + C++ evaluator, num_thread=8, batch 128" % len(users)}
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    from neurec_amd import engine as E, parallel, synth
+    from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
+
+    comm = parallel.init_from_env()
+    if args.gpus != comm.world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, comm.world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    # ---------------- workload, resident in HBM before anything is timed
+    train, test = synth.interactions(args.shape, seed=2018, scale=args.scale)
+    U, I = train.shape
+    coo = train.tocoo()
+    from neurec_amd.graph import lightgcn_adjacency
+    A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    E0 = synth.xavier_uniform(U + I, args.dim, np.random.RandomState(2017))
+    lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)   # lr, reg: conf/LightGCN.properties
+    trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
+    sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=args.batch, shuffle=True, seed=2018,
+                              rank=comm.rank, world=comm.world)
+    loss2 = torch.zeros(2, device=dev)
+    grad_sync = comm.allreduce_sum_ if comm.active else None
+
+    def batch_stream():
+        while True:
+            for b in sampler.batches():
+                if b[0].numel() == args.batch:          # fixed-size steps for the timed region
+                    yield b
+    stream = batch_stream()
+
+    def run_steps(n):
+        for _ in range(n):
+            bu, bp, bn = next(stream)
+            lg.step(bu, bp, bn, loss2, grad_sync=grad_sync)
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize(); comm.barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize(); comm.barrier()
+    dt = comm.max_float(time.perf_counter() - t0)
+    triplets_per_s = comm.world * args.steps * args.batch / dt
+
+    # ---------------- roofline of the dominant kernel (CSR SpMM): HIP events on the launch stream
+    reps = 20
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lg.propagate(); torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        lg.propagate()                                   # L forward launches
+        g = lg.H
+        for k in range(args.layers):                     # L backward launches
+            lg.At.matmul(g, out=(lg.Ga, lg.Gb)[k % 2], addend=lg.H)
+            g = (lg.Ga, lg.Gb)[k % 2]
+    ev1.record(); torch.cuda.synchronize()
+    spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
+    spmm_bytes = lg.A.algorithmic_bytes(args.dim)
+    achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "spmm_seg_kernel<%d>" % args.dim, "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "bytes_per_launch": spmm_bytes, "us_per_launch": spmm_ms * 1e3,
+                "launches_per_step": 2 * args.layers,
+                "step_algorithmic_bytes": lg.step_bytes()}
+
+    # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)
+    eval_info = None
+    if not args.no_eval:
+        test_users = np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)
+        mine = torch.from_numpy(parallel.shard_users(test_users, comm.rank, comm.world)).to(dev)
+        ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch)
+
+        def evaluate():
+            eu, ei = lg.final_embeddings()
+            sums = ev.evaluate_factors(eu.contiguous(), ei.contiguous(), mine) * mine.numel()
+            t = torch.from_numpy(np.asarray(sums, np.float64)).to(dev)
+            comm.allreduce_sum_(t)
+            return (t / len(test_users)).cpu().numpy()
+        evaluate()
+        torch.cuda.synchronize(); comm.barrier()
+        t0 = time.perf_counter()
+        means = evaluate()
+        torch.cuda.synchronize(); comm.barrier()
+        dte = comm.max_float(time.perf_counter() - t0)
+        eval_info = {"users_per_sec": len(test_users) / dte, "ms": dte * 1e3,
+                     "n_users": int(len(test_users)), "ndcg@10": float(means[2 * 20 + 9]),
+                     "recall@20": float(means[1 * 20 + 19]),
+                     "design": "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel"}
+
+    line = {
+        "metric": "BPR triplets/sec (LightGCN-gowalla)", "value": triplets_per_s,
+        "unit": "triplets/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LightGCN on synthetic %s-shaped interactions (U=%d, I=%d, E=%d), "
+                               "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
+                               % (args.shape, U, I, train.nnz, args.layers, args.dim, args.batch),
+                   "global_batch": comm.world * args.batch,
+                   "parallelism": "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world
+                   if comm.active else "single GPU"},
+        "final_loss": [float(x) for x in loss2.cpu().numpy()],
+        "eval": eval_info, "roofline": roofline,
+        "device": E.device_info(),
+    }
+    if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(train, test, E0, args)
+    else:
+        line["cpu_baseline"] = None
+    if comm.rank == 0:
+        print(json.dumps(line))
+    comm.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -320,8 +320,10 @@ int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sor
 extern "C" {
 
 int nrhip_eval_workspace_bytes(int rows, int top_k, size_t* bytes) {
-  NR_REQUIRE(rows >= 0 && top_k >= 1 && top_k <= 128 && bytes, NR_ERR_ARG,
-             "eval_workspace_bytes: rows=%d top_k=%d (top_k must be in 1..128)", rows, top_k);
+  NR_REQUIRE(rows >= 0 && top_k >= 1 && bytes, NR_ERR_ARG,
+             "eval_workspace_bytes: rows=%d top_k=%d", rows, top_k);
+  NR_REQUIRE(top_k <= 128, NR_ERR_UNSUPPORTED, "eval: top_k=%d outside the built range 1..128",
+             top_k);
   *bytes = eval_ws_bytes(rows > 0 ? rows : 1);
   return NR_OK;
 }

@@ -67,8 +67,7 @@ template <int D>
 __device__ __forceinline__ void epilogue_store(float (&acc)[Shape<D>::CPL], int64_t row, int col0,
                                                float* __restrict__ Y,
                                                const float* __restrict__ addend,
-                                               const float* __restrict__ sum_in,
-                                               float* __restrict__ sum_out) {
+                                               const float* sum_in, float* sum_out) {
 #pragma unroll
   for (int c = 0; c < Shape<D>::CPL; ++c) {
     const int64_t o = row * D + col0 + c * Shape<D>::LPR;
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void spmm_seg_kernel(
     const int32_t* __restrict__ seg_len, const int32_t* __restrict__ seg_slot, int64_t n_seg,
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float* __restrict__ X, float* __restrict__ Y, const float* __restrict__ addend,
-    const float* __restrict__ sum_in, float* __restrict__ sum_out, float* __restrict__ partial) {
+    const float* sum_in, float* sum_out, float* __restrict__ partial) {   // sum_in may alias sum_out
   using S = Shape<D>;
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -177,8 +176,8 @@ template <int D>
 __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void spmm_fix_kernel(
     const int32_t* __restrict__ multi_row, const int32_t* __restrict__ multi_first,
     const int32_t* __restrict__ multi_nseg, int64_t n_multi, const float* __restrict__ partial,
-    float* __restrict__ Y, const float* __restrict__ addend, const float* __restrict__ sum_in,
-    float* __restrict__ sum_out) {
+    float* __restrict__ Y, const float* __restrict__ addend, const float* sum_in,
+    float* sum_out) {
   using S = Shape<D>;
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int64_t m = (int64_t)blockIdx.x * kWavesPerBlock + wave;

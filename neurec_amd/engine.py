@@ -173,6 +173,12 @@ class ScoreGemm:
         call("nrhip_score_gemm_workspace_bytes", self.max_rows, self.cols, self.d, C.byref(nbytes))
         self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=item_table.device)
         self.ld = (self.cols + 63) // 64 * 64
+        self.prepare(item_table)
+
+    def prepare(self, item_table):
+        """(Re)load the item side — call once per evaluation, after the table changed."""
+        if tuple(item_table.shape) != (self.cols, self.d):
+            raise ValueError("item table shape changed")
         call("nrhip_score_gemm_prepare_items", _ptr(item_table, torch.float32),
              item_table.stride(0), self.cols, self.d, _ptr(self.ws), self.ws.numel(), _stream())
 
@@ -344,7 +350,7 @@ class SpmmCSR:
 
     def algorithmic_bytes(self, d):
         """CSR idx+val read once, X read once, Y written once."""
-        return self.nnz * 8 + (self.n_rows + 1) * 8 + 2 * self.n_rows * d * 4
+        return self.nnz * 8 + (self.n_rows + 1) * 4 + 2 * self.n_rows * d * 4
 
 
 def device_info():

@@ -1,0 +1,75 @@
+"""One process per GPU over RCCL (torch.distributed backend "nccl" on ROCm); gloo on CPU
+for the multi-process tests.
+
+How the hot path shards:
+  * sampler    — every rank owns a contiguous slice of each epoch's triplet stream
+                 (units are independent; no exchange).
+  * training   — triplets are data-parallel: tables replicated, each rank back-propagates
+                 its own batch and the dense dL/dE0 is summed with ONE all-reduce per step
+                 (the only exchange step); Adam then runs identically on every rank.  The
+                 result equals the reference run with batch_size = world * B.
+  * evaluation — test users are split across ranks (independent units); the metric column
+                 sums are all-reduced once at the end.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    def __init__(self, rank=0, world=1, local_rank=0, backend=None):
+        self.rank, self.world, self.local_rank, self.backend = rank, world, local_rank, backend
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def barrier(self):
+        if self.active:
+            dist.barrier()
+
+    def allreduce_sum_(self, t):
+        """In-place SUM all-reduce (RCCL on GPU tensors, gloo on CPU tensors)."""
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def max_float(self, x):
+        if not self.active:
+            return float(x)
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def shutdown(self):
+        if self.active and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def init_from_env(backend=None):
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (set by torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return Comm(rank, world, local_rank, backend)
+
+
+def partition(n, rank, world):
+    """Contiguous block partition of range(n): rank r owns [lo, hi)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def shard_users(user_ids, rank, world):
+    lo, hi = partition(len(user_ids), rank, world)
+    return user_ids[lo:hi]

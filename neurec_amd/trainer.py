@@ -1,0 +1,208 @@
+"""Device-resident training/evaluation engines for the hot path.
+
+Host-side orchestration only: buffers live in HBM as torch tensors, every
+arithmetic step is a HIP kernel launched through the C ABI (engine.py).  These
+classes are what the drop-in model plugins (neurec_amd/model/general_recommender)
+and bench.py drive.
+
+  BprEpochSampler   PairwiseSampler.__iter__        data/sampler.py:198-206
+  MFEngine          MF.build_graph + one sess.run   model/general_recommender/MF.py:45-76,101
+  LightGCNEngine    LightGCN.build_graph + sess.run model/general_recommender/LightGCN.py:80-149,178
+  FullRankEvaluator UniEvaluator.evaluate           evaluator/backend/cpp/uni_evaluator.py:101-157
+"""
+import numpy as np
+import torch
+
+from . import engine as E
+
+
+class BprEpochSampler:
+    """Per-epoch BPR triplet stream generated on the device (no host round trip)."""
+
+    def __init__(self, train_csr, n_items, neg_num=1, batch_size=1024, shuffle=True,
+                 drop_last=False, seed=2018, rank=0, world=1):
+        if neg_num <= 0:
+            raise ValueError("'neg_num' must be a positive integer.")
+        if train_csr.nnz == 0:
+            raise ValueError("'user_pos_dict' cannot be empty.")
+        deg_max = int(np.diff(train_csr.h_indptr).max())
+        if n_items <= deg_max:
+            raise ValueError("The number of 'exclusion' is greater than 'high'.")
+        self.csr, self.n_items, self.neg_num = train_csr, int(n_items), int(neg_num)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), drop_last
+        self.seed, self.epoch = int(seed), 0
+        self.row_of = train_csr.row_of()
+        # multi-GPU: rank r owns the contiguous slice [lo, hi) of every epoch's stream
+        n = train_csr.nnz
+        self.lo = (n * rank) // world
+        self.hi = (n * (rank + 1)) // world
+        self.n_local = self.hi - self.lo
+        dev = train_csr.indptr.device
+        self._users = torch.empty(max(self.n_local, 1), dtype=torch.int32, device=dev)
+        self._pos = torch.empty(max(self.n_local, 1), dtype=torch.int32, device=dev)
+        self._neg = torch.empty(max(self.n_local * self.neg_num, 1), dtype=torch.int32, device=dev)
+
+    def __len__(self):
+        if self.drop_last:
+            return self.n_local // self.batch_size
+        return (self.n_local + self.batch_size - 1) // self.batch_size
+
+    def sample_epoch(self):
+        """Fill the epoch buffers; returns (users, pos, neg) device tensors of the whole epoch."""
+        out = E.sample_bpr_epoch(self.csr, self.row_of, self.n_items, self.neg_num, self.seed,
+                                 self.epoch, self.shuffle, self.lo, self.n_local,
+                                 out=(self._users, self._pos, self._neg))
+        self.epoch += 1
+        return out
+
+    def batches(self):
+        """Yield device-tensor batches (views, no copies) for one epoch."""
+        users, pos, neg = self.sample_epoch()
+        B = self.batch_size
+        for k in range(len(self)):
+            b, e = k * B, min((k + 1) * B, self.n_local)
+            nb = neg[b * self.neg_num:e * self.neg_num]
+            yield users[b:e], pos[b:e], (nb if self.neg_num == 1 else nb.view(-1, self.neg_num))
+
+
+class MFEngine:
+    """BPR-MF tables + TF-style Adam state in HBM; step() = one reference sess.run."""
+
+    def __init__(self, user_table, item_table, lr, reg, max_batch):
+        dev = E.require_gpu()
+        self.P = torch.as_tensor(user_table, dtype=torch.float32).contiguous().to(dev)
+        self.Q = torch.as_tensor(item_table, dtype=torch.float32).contiguous().to(dev)
+        self.mP, self.vP = torch.zeros_like(self.P), torch.zeros_like(self.P)
+        self.mQ, self.vQ = torch.zeros_like(self.Q), torch.zeros_like(self.Q)
+        self.GP, self.GQ = torch.zeros_like(self.P), torch.zeros_like(self.Q)
+        self.reg = float(reg)
+        self.adam = E.AdamState(lr)
+        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.max_batch = max_batch
+
+    def step(self, users, pos, neg, loss_out):
+        """loss_out: 2-float device tensor receiving (bpr_sum, reg_term)."""
+        if users.numel() > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        E.bpr_mf_grad(self.P, self.Q, users, pos, neg, self.reg, self.GP, self.GQ, self.terms,
+                      loss_out)
+        E.adam_sparse(self.P, self.mP, self.vP, self.GP, self.adam)
+        E.adam_sparse(self.Q, self.mQ, self.vQ, self.GQ, self.adam)
+        self.adam.advance()
+
+
+class LightGCNEngine:
+    """LightGCN on one GPU: E0 (user rows then item rows), its Adam state, the
+    normalised adjacency (and its transpose when not symmetric) and the layer
+    buffers all stay resident in HBM."""
+
+    def __init__(self, adj_csr, n_users, n_items, embed, n_layers, lr, reg, max_batch,
+                 adj_t_csr=None):
+        dev = E.require_gpu()
+        self.n_users, self.n_items, self.n_layers = int(n_users), int(n_items), int(n_layers)
+        self.N = self.n_users + self.n_items
+        self.A = adj_csr if isinstance(adj_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_csr)
+        if adj_t_csr is None:
+            self.At = self.A
+        else:
+            self.At = adj_t_csr if isinstance(adj_t_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_t_csr)
+        self.E0 = torch.as_tensor(embed, dtype=torch.float32).contiguous().to(dev)
+        assert self.E0.shape[0] == self.N
+        self.d = self.E0.shape[1]
+        z = lambda: torch.zeros_like(self.E0)
+        self.m, self.v = z(), z()
+        self.Ea, self.Eb = z(), z()          # ping-pong layer buffers
+        self.Esum = z()                      # running sum over layers (E* = Esum/(L+1))
+        self.Gstar, self.Greg = z(), z()     # dL/dE*, reg*E0 rows
+        self.H, self.Ga, self.Gb = z(), z(), z()
+        self.reg = float(reg)
+        self.adam = E.AdamState(lr)
+        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.max_batch = max_batch
+
+    # -- forward: Esum = sum_k A^k E0  (LightGCN.py:132-149) -------------------------
+    def propagate(self):
+        if self.n_layers == 0:
+            self.Esum.copy_(self.E0)
+            return self.Esum
+        src, acc_in = self.E0, self.E0
+        bufs = (self.Ea, self.Eb)
+        for k in range(self.n_layers):
+            out = None if k == self.n_layers - 1 else bufs[k % 2]   # last layer: only the sum
+            self.A.matmul(src, out=out, sum_in=acc_in, sum_out=self.Esum)
+            src, acc_in = out, self.Esum
+        return self.Esum
+
+    def final_embeddings(self):
+        """(user, item) E* tables = mean over layers — the assign_opt of LightGCN.py:110-116."""
+        self.propagate()
+        Estar = torch.empty_like(self.Esum)
+        E.div_scalar(self.Esum, float(self.n_layers + 1), Estar)
+        return Estar[:self.n_users], Estar[self.n_users:]
+
+    # -- one training step = sess.run(self.opt) (LightGCN.py:178) ---------------------
+    def step(self, users, pos, neg, loss_out, grad_sync=None):
+        """grad_sync(tensor): optional in-place all-reduce of dL/dE0 across ranks (parallel.py)."""
+        if users.numel() > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        L = self.n_layers
+        self.propagate()
+        E.lightgcn_bpr_grad(self.Esum, self.E0, self.n_users, L, users, pos, neg, self.reg,
+                            self.Gstar, self.Greg, self.terms, loss_out)
+        # backward through mean + propagation: G_L = H, G_k = H + A^T G_{k+1}, H = Gstar/(L+1)
+        E.div_scalar(self.Gstar, float(L + 1), self.H)
+        g = self.H
+        bufs = (self.Ga, self.Gb)
+        for k in range(L):
+            self.At.matmul(g, out=bufs[k % 2], addend=self.H)
+            g = bufs[k % 2]
+        E.add(g, self.Greg, self.Gstar)          # total dL/dE0 (reuses Gstar as the grad buffer)
+        if grad_sync is not None:
+            grad_sync(self.Gstar)
+        E.adam_dense(self.E0, self.m, self.v, self.Gstar, self.adam, clear_grad=True)
+        self.Greg.zero_()
+        self.adam.advance()
+
+    def step_bytes(self):
+        """Algorithmic HBM bytes of one step."""
+        nd4 = self.N * self.d * 4
+        spmm = 2 * self.n_layers * self.A.algorithmic_bytes(self.d)   # At has the same nnz
+        adam = 7 * nd4
+        return spmm + adam
+
+
+class FullRankEvaluator:
+    """Full-rank evaluation on the device: score GEMM -> -inf train mask -> top-K ->
+    metrics, batch by batch; only the per-user metric matrix (or its column sums)
+    ever crosses PCIe."""
+
+    def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048):
+        self.train, self.test = train_csr, test_csr
+        self.metric_ids = [int(m) for m in metric_ids]
+        self.top_k = int(top_k)
+        self.batch_rows = int(batch_rows)
+        self._gemm = None
+        self._scores = None
+
+    def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False):
+        """Returns float64 column means [n_metric*top_k] (or the fp32 np.mean when
+        exact_mean) over `test_users` (int32 device tensor)."""
+        n = test_users.numel()
+        nm = len(self.metric_ids)
+        if self._gemm is None or self._gemm.cols != item_table.shape[0] or \
+                self._gemm.d != item_table.shape[1]:
+            self._gemm = E.ScoreGemm(item_table, self.batch_rows)
+            self._scores = self._gemm.new_score_buffer()
+        else:
+            self._gemm.prepare(item_table)
+        per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
+        cols = item_table.shape[0]
+        for b in range(0, n, self.batch_rows):
+            u = test_users[b:b + self.batch_rows]
+            S = self._gemm(user_table, u, out=self._scores)
+            E.mask_train(S, u, self.train, cols=cols)
+            E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
+                          out=per_user[b:b + u.numel()])
+        if exact_mean:
+            return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
+        return (E.colsum(per_user) / n).cpu().numpy()

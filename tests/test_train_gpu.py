@@ -1,0 +1,214 @@
+"""HIP training path against oracle.train: CSR SpMM (+ fused epilogues), BPR heads, TF-Adam
+sweeps, and whole MF / LightGCN steps.
+
+Tolerances (fp32, stated per north_star): loss and embeddings within 1e-5; kernels whose
+operation order is identical to the oracle's (SpMM single-segment rows, Adam) bit-exact."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from neurec_amd import engine
+    return engine
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _graph(rng, U, I, per_user_lo, per_user_hi, hubs=0):
+    users, items = [], []
+    for u in range(U):
+        n = rng.randint(per_user_lo, per_user_hi)
+        it = rng.choice(I, n, replace=False)
+        users += [u] * n; items += it.tolist()
+    for h in range(hubs):                              # hub items interacted by most users
+        uu = rng.choice(U, int(U * 0.9), replace=False)
+        users += uu.tolist(); items += [h] * len(uu)
+    m = sp.csr_matrix((np.ones(len(users), np.float32), (users, items)), shape=(U, I))
+    m.data[:] = 1.0
+    coo = m.tocoo()
+    return coo.row, coo.col
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+def test_spmm_matches_scipy_rowwise(eng, d):
+    import torch
+    from oracle import train
+    rng = np.random.RandomState(d)
+    U, I = 700, 500
+    ur, ic = _graph(rng, U, I, 0, 30, hubs=2)         # 2 hub columns: rows of ~630 nnz -> split rows
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    X = rng.randn(U + I, d).astype(np.float32)
+    csr = eng.SpmmCSR.from_scipy(A)
+    assert csr.n_split_rows >= 2
+    Y = torch.empty_like(_dev(X))
+    csr.matmul(_dev(X), out=Y)
+    got, want = Y.cpu().numpy(), train.spmm_rowwise(A, X)
+    short = np.diff(A.indptr) <= 256
+    np.testing.assert_array_equal(got[short], want[short])          # same order, same roundings
+    ref64 = A.astype(np.float64) @ X.astype(np.float64)
+    assert np.abs(got - ref64).max() < 2e-5                          # split rows: reassociated, not wrong
+    assert np.abs(got[~short] - want[~short]).max() < 1e-5
+    # fused epilogues: addend and running sum (in-place sum_in == sum_out allowed)
+    add, acc = rng.randn(U + I, d).astype(np.float32), rng.randn(U + I, d).astype(np.float32)
+    Y2, S2 = torch.empty_like(Y), _dev(acc)
+    csr.matmul(_dev(X), out=Y2, addend=_dev(add), sum_in=S2, sum_out=S2)
+    np.testing.assert_array_equal(Y2.cpu().numpy()[short], (want + add)[short])
+    np.testing.assert_array_equal(S2.cpu().numpy()[short], (acc + (want + add))[short])
+    S3 = torch.empty_like(Y)
+    csr.matmul(_dev(X), out=None, sum_in=_dev(acc), sum_out=S3)     # sum only (last forward layer)
+    np.testing.assert_array_equal(S3.cpu().numpy()[short], (acc + want)[short])
+    # non-symmetric ('norm') adjacency and its transpose
+    An = train.lightgcn_adjacency(ur, ic, U, I, "norm")
+    Ant = An.T.tocsr(); Ant.sort_indices()
+    for M in (An, Ant):
+        c = eng.SpmmCSR.from_scipy(M)
+        Yn = torch.empty_like(Y); c.matmul(_dev(X), out=Yn)
+        sh = np.diff(M.indptr) <= 256
+        np.testing.assert_array_equal(Yn.cpu().numpy()[sh], train.spmm_rowwise(M, X)[sh])
+
+
+def test_spmm_empty_rows_and_tiny(eng):
+    import torch
+    A = sp.csr_matrix(([0.5, 2.0, -1.0], ([0, 0, 3], [1, 3, 0])), shape=(5, 5), dtype=np.float32)
+    X = np.arange(5 * 64, dtype=np.float32).reshape(5, 64) / 7
+    c = eng.SpmmCSR.from_scipy(A)
+    Y = torch.full((5, 64), 7.0, device="cuda")
+    c.matmul(_dev(X), out=Y)
+    np.testing.assert_array_equal(Y.cpu().numpy(), (A @ X).astype(np.float32))   # empty rows -> 0
+
+
+def test_adam_sweeps_bit_exact(eng):
+    from oracle import train
+    rng = np.random.RandomState(0)
+    n = 70839 * 3 + 1                                   # not a multiple of 4: exercises the tail
+    for sparse in (True, False):
+        var = rng.randn(n).astype(np.float32); m = (rng.randn(n) * 1e-2).astype(np.float32)
+        v = (rng.rand(n) * 1e-3).astype(np.float32); g = (rng.randn(n) * 0.1).astype(np.float32)
+        if sparse:
+            g[rng.rand(n) < 0.9] = 0
+        dv, dm, dvv, dg = _dev(var), _dev(m), _dev(v), _dev(g)
+        st, ad = eng.AdamState(0.001), train.Adam(0.001)
+        for _ in range(4):
+            st.advance(); ad.advance()
+        assert st.alpha() == ad.alpha()
+        if sparse:
+            eng.adam_sparse(dv, dm, dvv, dg, st); ad.sparse_swept(var, m, v, g)
+        else:
+            eng.adam_dense(dv, dm, dvv, dg, st, clear_grad=True); ad.dense(var, m, v, g)
+        np.testing.assert_array_equal(dm.cpu().numpy(), m)
+        np.testing.assert_array_equal(dvv.cpu().numpy(), v)
+        np.testing.assert_array_equal(dv.cpu().numpy(), var)
+        assert not dg.cpu().numpy().any()               # gradient buffer cleared for the next step
+
+
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_bpr_mf_step_tracks_oracle(eng, d):
+    import torch
+    from neurec_amd.trainer import MFEngine
+    from oracle import train
+    rng = np.random.RandomState(d)
+    U, I, B, reg, lr = 300, 400, 512, 0.01, 0.001
+    P = (rng.randn(U, d) * 0.01).astype(np.float32); Q = (rng.randn(I, d) * 0.01).astype(np.float32)
+    mf = MFEngine(P, Q, lr, reg, B)
+    oP, oQ = P.copy(), Q.copy()
+    om = [np.zeros_like(P), np.zeros_like(P), np.zeros_like(Q), np.zeros_like(Q)]
+    P64, Q64 = P.astype(np.float64), Q.astype(np.float64)
+    om64 = [np.zeros_like(P64), np.zeros_like(P64), np.zeros_like(Q64), np.zeros_like(Q64)]
+    ad, ad64 = train.Adam(lr), train.Adam(lr, dtype=np.float64)
+    loss2 = torch.zeros(2, device="cuda")
+    for step in range(6):
+        bu = rng.randint(0, U, B).astype(np.int32); bp = rng.randint(0, I, B).astype(np.int32)
+        bn = rng.randint(0, I, B).astype(np.int32)
+        if step == 0:
+            bu[:50] = bu[0]; bp[:20] = bp[0]; bn[20:40] = bp[0]       # heavy duplicates in a batch
+        mf.step(_dev(bu), _dev(bp), _dev(bn), loss2)
+        want = train.mf_step(oP, oQ, om[0], om[1], om[2], om[3], bu, bp, bn, reg, ad)
+        want64 = train.mf_step(P64, Q64, om64[0], om64[1], om64[2], om64[3], bu, bp, bn, reg, ad64)
+        got = float(loss2.sum().item())
+        assert abs(got - want64) <= 1e-5 * abs(want64), (step, got, want, want64)
+        assert abs(got - want) <= 1e-5 * abs(want)
+    assert np.abs(mf.P.cpu().numpy() - P64).max() < 1e-5 and np.abs(mf.Q.cpu().numpy() - Q64).max() < 1e-5
+    assert np.abs(mf.P.cpu().numpy() - oP).max() < 2e-6
+
+
+@pytest.mark.parametrize("adj_type,L,d", [("pre", 3, 64), ("pre", 1, 16), ("norm", 2, 64), ("pre", 0, 64)])
+def test_lightgcn_step_tracks_oracle(eng, adj_type, L, d):
+    import torch
+    from neurec_amd.trainer import LightGCNEngine
+    from oracle import train
+    rng = np.random.RandomState(L * 10 + d)
+    U, I, B, reg, lr = 400, 300, 256, 1e-3, 0.01
+    ur, ic = _graph(rng, U, I, 1, 25, hubs=1)
+    A = train.lightgcn_adjacency(ur, ic, U, I, adj_type)
+    At = A.T.tocsr(); At.sort_indices()
+    lim = np.sqrt(6.0 / (U + d))
+    E0 = rng.uniform(-lim, lim, (U + I, d)).astype(np.float32)
+    lg = LightGCNEngine(A, U, I, E0, L, lr, reg, B, adj_t_csr=None if adj_type == "pre" else At)
+    o32, m32, v32 = E0.copy(), np.zeros_like(E0), np.zeros_like(E0)
+    o64 = E0.astype(np.float64); m64, v64 = np.zeros_like(o64), np.zeros_like(o64)
+    A64, At64 = A.astype(np.float64), At.astype(np.float64)
+    ad, ad64 = train.Adam(lr), train.Adam(lr, dtype=np.float64)
+    # forward only first: E* against the oracle's propagation
+    eu, ei = lg.final_embeddings()
+    want_star, _ = train.lightgcn_propagate(A, E0, L)
+    got_star = np.concatenate([eu.cpu().numpy(), ei.cpu().numpy()])
+    assert np.abs(got_star - want_star).max() < 1e-6
+    loss2 = torch.zeros(2, device="cuda")
+    for step in range(5):
+        bu = rng.randint(0, U, B).astype(np.int32); bp = rng.randint(0, I, B).astype(np.int32)
+        bn = rng.randint(0, I, B).astype(np.int32)
+        lg.step(_dev(bu), _dev(bp), _dev(bn), loss2)
+        w32 = train.lightgcn_step(A, At, o32, m32, v32, U, L, bu, bp, bn, reg, ad)
+        w64 = train.lightgcn_step(A64, At64, o64, m64, v64, U, L, bu, bp, bn, reg, ad64)
+        got = loss2.cpu().numpy()
+        assert abs(got[0] - w64[0]) <= 1e-5 * abs(w64[0]), (step, got, w32, w64)
+        assert abs(got[1] - w64[1]) <= 1e-5 * max(abs(w64[1]), 1e-3)
+    gotE = lg.E0.cpu().numpy()
+    assert np.abs(gotE - o64).max() < 1e-5, np.abs(gotE - o64).max()
+    assert np.abs(gotE - o32).max() < 1e-5
+    assert not lg.Greg.cpu().numpy().any() and not lg.Gstar.cpu().numpy().any()   # buffers re-armed
+
+
+def test_lightgcn_training_improves_ndcg_end_to_end(eng):
+    """Sampler -> LightGCN steps -> full-rank evaluator, all on the device: learning happens."""
+    import torch
+    from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
+    from oracle import train
+    rng = np.random.RandomState(5)
+    U, I, d, L = 300, 200, 64, 2
+    # planted structure: user u likes items of its cluster
+    ur, ic = [], []
+    for u in range(U):
+        base = (u % 10) * 20
+        its = base + rng.choice(20, 9, replace=False)
+        ur += [u] * 9; ic += its.tolist()
+    ur, ic = np.array(ur), np.array(ic)
+    is_test = np.arange(len(ur)) % 9 == 0
+    tr = sp.csr_matrix((np.ones((~is_test).sum()), (ur[~is_test], ic[~is_test])), shape=(U, I))
+    te = sp.csr_matrix((np.ones(is_test.sum()), (ur[is_test], ic[is_test])), shape=(U, I))
+    trc, tec = eng.DeviceCSR.from_scipy(tr), eng.DeviceCSR.from_scipy(te)
+    A = train.lightgcn_adjacency(ur[~is_test], ic[~is_test], U, I, "pre")
+    lim = np.sqrt(6.0 / (U + d))
+    lg = LightGCNEngine(A, U, I, rng.uniform(-lim, lim, (U + I, d)).astype(np.float32), L, 0.01,
+                        1e-3, 512)
+    sampler = BprEpochSampler(trc, I, batch_size=512, seed=2018)
+    ev = FullRankEvaluator(trc, tec, [4], 10, batch_rows=512)
+    users = torch.arange(U, dtype=torch.int32, device="cuda")
+    loss2 = torch.zeros(2, device="cuda")
+
+    def ndcg10():
+        eu, ei = lg.final_embeddings()
+        return ev.evaluate_factors(eu.contiguous(), ei.contiguous(), users)[9]
+    before = ndcg10()
+    for _ in range(30):
+        for bu, bp, bn in sampler.batches():
+            lg.step(bu, bp, bn, loss2)
+    after = ndcg10()
+    assert after > before + 0.2 and after > 0.5, (before, after)
