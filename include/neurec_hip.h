@@ -162,17 +162,38 @@ int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int
 int nrhip_spmm_plan_bytes(int64_t n_rows, int64_t nnz, size_t* bytes);
 /* h_indptr is a HOST pointer (n_rows+1 entries): the segment plan is computed
  * on the host, uploaded into the caller's device buffer d_plan_buf, and a
- * host-side handle describing it is returned in *plan_out. */
-int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, void* d_plan_buf,
-                           size_t plan_bytes, void* stream, void** plan_out);
+ * host-side handle describing it is returned in *plan_out.  item_rows /
+ * item_nnz bound the whole-row work items (0 = tuned defaults; at most 32 rows
+ * and 256 non-zeros). */
+int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_rows, int item_nnz,
+                           void* d_plan_buf, size_t plan_bytes, void* stream, void** plan_out);
 int nrhip_spmm_plan_destroy(void* plan);
-int nrhip_spmm_plan_info(const void* plan, int64_t* n_segments, int64_t* n_split_rows);
+int nrhip_spmm_plan_info(const void* plan, int64_t* n_work_items, int64_t* n_split_rows);
 int nrhip_spmm_workspace_bytes(const void* plan, int d, size_t* bytes);
 /* d_Y may be NULL when only the running sum is wanted. */
-int nrhip_spmm_csr(const void* plan, const int32_t* d_indices, const float* d_vals,
-                   const float* d_X, int d, float* d_Y, const float* d_addend,
-                   const float* d_sum_in, float* d_sum_out, void* d_ws, size_t ws_bytes,
-                   void* stream);
+int nrhip_spmm_csr(const void* plan, const int64_t* d_indptr, const int32_t* d_indices,
+                   const float* d_vals, const float* d_X, int d, float* d_Y,
+                   const float* d_addend, const float* d_sum_in, float* d_sum_out, void* d_ws,
+                   size_t ws_bytes, void* stream);
+
+/* The same product with work skipped (d >= 64; either mask may be NULL, not both):
+ *   d_x_row_nonzero[c] == 0 promises X[c][:] == 0: those terms are skipped instead of
+ *     gathered (first backward hop of a training step: dLoss/dE* is non-zero on the batch
+ *     rows only);
+ *   d_y_row_wanted[r] == 0 says output row r is not needed: it is left untouched (last
+ *     forward hop of a training step: the loss reads E* on the batch rows only).
+ * Produced rows are bit-identical to nrhip_spmm_csr's. */
+int nrhip_spmm_csr_masked(const void* plan, const int64_t* d_indptr, const int32_t* d_indices,
+                          const float* d_vals, const float* d_X, const uint8_t* d_x_row_nonzero,
+                          const uint8_t* d_y_row_wanted, int d, float* d_Y, const float* d_addend,
+                          const float* d_sum_in, float* d_sum_out, void* d_ws, size_t ws_bytes,
+                          void* stream);
+/* Only the listed rows of A·X (+ epilogue) are produced; other rows of the outputs are left
+ * untouched.  d_rows may repeat; d_sum_out must not alias d_sum_in.  d in {64,128,256}. */
+int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
+                        const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,
+                        const float* d_addend, const float* d_sum_in, float* d_sum_out,
+                        void* stream);
 
 /* ---- LightGCN BPR head ----------------------------------------------------
  * Replaces the lookups + create_bpr_loss of LightGCN.py:99-104,156-166 and
@@ -185,6 +206,12 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
                             int n_layers, const int32_t* d_users, const int32_t* d_pos,
                             const int32_t* d_neg, int batch, float reg, float* d_Gstar,
                             float* d_Greg, float* d_terms, float* d_loss2, void* stream);
+
+/* Node rows touched by a batch: d_rows_out[3*batch] = users | n_users+pos | n_users+neg and
+ * d_row_flag[those rows] = 1 (d_row_flag: n_nodes bytes, zero on entry). */
+int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                              int batch, int n_users, int32_t* d_rows_out, uint8_t* d_row_flag,
+                              void* stream);
 
 /* y = a*x (+ y0)  elementwise helpers used between propagation passes. */
 int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream);

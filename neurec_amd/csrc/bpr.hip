@@ -120,6 +120,18 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_ker
   }
 }
 
+__global__ __launch_bounds__(256) void mark_batch_kernel(const int32_t* __restrict__ users,
+                                                         const int32_t* __restrict__ pos,
+                                                         const int32_t* __restrict__ neg, int batch,
+                                                         int n_users, int32_t* __restrict__ rows,
+                                                         uint8_t* __restrict__ flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int u = users[b], i = n_users + pos[b], j = n_users + neg[b];
+  rows[b] = u; rows[batch + b] = i; rows[2 * batch + b] = j;
+  flag[u] = 1; flag[i] = 1; flag[j] = 1;
+}
+
 // fixed-order reduction of the per-triplet terms: out[0] = Σ mf, out[1] = reg·Σ l2
 __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restrict__ term_mf,
                                                           const float* __restrict__ term_l2,
@@ -176,6 +188,19 @@ int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* 
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
                      d_loss2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                              int batch, int n_users, int32_t* d_rows_out, uint8_t* d_row_flag,
+                              void* stream) {
+  NR_REQUIRE(d_users && d_pos && d_neg && d_rows_out && d_row_flag && batch >= 0 && n_users >= 0,
+             NR_ERR_ARG, "lightgcn_mark_batch: bad arguments");
+  if (batch == 0) return NR_OK;
+  hipLaunchKernelGGL(mark_batch_kernel, dim3((batch + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, d_users, d_pos, d_neg, batch, n_users, d_rows_out,
+                     d_row_flag);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -273,6 +273,13 @@ def bpr_mf_grad(P, Q, users, pos, neg, reg, GP, GQ, terms, loss2):
          float(reg), _ptr(GP), _ptr(GQ), _ptr(terms), _ptr(loss2), _stream())
 
 
+def lightgcn_mark_batch(users, pos, neg, n_users, rows_out, row_flag):
+    """rows_out[3B] = users | n_users+pos | n_users+neg; row_flag[those] = 1."""
+    call("nrhip_lightgcn_mark_batch", _ptr(users, torch.int32), _ptr(pos, torch.int32),
+         _ptr(neg, torch.int32), users.numel(), int(n_users), _ptr(rows_out, torch.int32),
+         _ptr(row_flag, torch.uint8), _stream())
+
+
 def lightgcn_bpr_grad(Esum, E0, n_users, n_layers, users, pos, neg, reg, Gstar, Greg, terms, loss2):
     call("nrhip_lightgcn_bpr_grad", _ptr(Esum, torch.float32), _ptr(E0, torch.float32), n_users,
          E0.shape[1], n_layers, _ptr(users, torch.int32), _ptr(pos, torch.int32),
@@ -295,7 +302,7 @@ def div_scalar(x, denom, out):
 class SpmmCSR:
     """A CSR matrix resident on the device plus its row-segment plan."""
 
-    def __init__(self, indptr, indices, vals, n_cols=None):
+    def __init__(self, indptr, indices, vals, n_cols=None, item_rows=0, item_nnz=0):
         dev = require_gpu()
         self.h_indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         self.n_rows = len(self.h_indptr) - 1
@@ -305,22 +312,23 @@ class SpmmCSR:
         val = np.ascontiguousarray(vals, dtype=np.float32)
         self.indices = torch.from_numpy(idx if len(idx) else np.zeros(1, np.int32)).to(dev)
         self.vals = torch.from_numpy(val if len(val) else np.zeros(1, np.float32)).to(dev)
+        self.indptr = torch.from_numpy(self.h_indptr).to(dev)
         nbytes = C.c_size_t(0)
         call("nrhip_spmm_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
         self.plan_buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
         self.plan = C.c_void_p(0)
         call("nrhip_spmm_plan_create", self.h_indptr.ctypes.data_as(C.c_void_p), self.n_rows,
-             _ptr(self.plan_buf), self.plan_buf.numel(), _stream(), C.byref(self.plan))
+             int(item_rows), int(item_nnz), _ptr(self.plan_buf), self.plan_buf.numel(), _stream(), C.byref(self.plan))
         nseg, nsplit = C.c_int64(0), C.c_int64(0)
         call("nrhip_spmm_plan_info", self.plan, C.byref(nseg), C.byref(nsplit))
         self.n_segments, self.n_split_rows = nseg.value, nsplit.value
         self._ws = {}
 
     @staticmethod
-    def from_scipy(mat):
+    def from_scipy(mat, item_rows=0, item_nnz=0):
         m = mat.tocsr().astype(np.float32)
         m.sort_indices()
-        return SpmmCSR(m.indptr, m.indices, m.data, m.shape[1])
+        return SpmmCSR(m.indptr, m.indices, m.data, m.shape[1], item_rows, item_nnz)
 
     def __del__(self):
         try:
@@ -338,14 +346,36 @@ class SpmmCSR:
                                       device=self.indices.device)
         return self._ws[d]
 
-    def matmul(self, X, out=None, addend=None, sum_in=None, sum_out=None):
-        """out = A @ X (+ addend); sum_out = sum_in + out (each optional)."""
+    def matmul(self, X, out=None, addend=None, sum_in=None, sum_out=None, x_row_nonzero=None,
+               y_row_wanted=None):
+        """out = A @ X (+ addend); sum_out = sum_in + out (each optional).
+        x_row_nonzero: optional uint8 [n_cols]; 0 promises that row of X is all zero (skipped).
+        y_row_wanted: optional uint8 [n_rows]; rows with 0 are not produced (left untouched)."""
         d = X.shape[1]
         ws = self._workspace(d)
-        call("nrhip_spmm_csr", self.plan, _ptr(self.indices), _ptr(self.vals),
-             _ptr(X, torch.float32), d, _ptr(out, torch.float32, allow_none=True),
-             _ptr(addend, allow_none=True), _ptr(sum_in, allow_none=True),
-             _ptr(sum_out, allow_none=True), _ptr(ws), ws.numel(), _stream())
+        if x_row_nonzero is None and y_row_wanted is None:
+            call("nrhip_spmm_csr", self.plan, _ptr(self.indptr), _ptr(self.indices),
+                 _ptr(self.vals), _ptr(X, torch.float32), d,
+                 _ptr(out, torch.float32, allow_none=True), _ptr(addend, allow_none=True),
+                 _ptr(sum_in, allow_none=True), _ptr(sum_out, allow_none=True), _ptr(ws),
+                 ws.numel(), _stream())
+        else:
+            call("nrhip_spmm_csr_masked", self.plan, _ptr(self.indptr), _ptr(self.indices),
+                 _ptr(self.vals), _ptr(X, torch.float32),
+                 _ptr(x_row_nonzero, torch.uint8, allow_none=True),
+                 _ptr(y_row_wanted, torch.uint8, allow_none=True), d,
+                 _ptr(out, torch.float32, allow_none=True), _ptr(addend, allow_none=True),
+                 _ptr(sum_in, allow_none=True), _ptr(sum_out, allow_none=True), _ptr(ws),
+                 ws.numel(), _stream())
+        return out
+
+    def matmul_rows(self, X, rows, out=None, addend=None, sum_in=None, sum_out=None):
+        """Only the listed rows (int32 device tensor, repeats allowed) of A @ X (+ epilogue)."""
+        d = X.shape[1]
+        call("nrhip_spmm_csr_rows", _ptr(self.indptr), _ptr(self.indices), _ptr(self.vals),
+             _ptr(X, torch.float32), d, _ptr(rows, torch.int32), rows.numel(),
+             _ptr(out, torch.float32, allow_none=True), _ptr(addend, allow_none=True),
+             _ptr(sum_in, allow_none=True), _ptr(sum_out, allow_none=True), _stream())
         return out
 
     def algorithmic_bytes(self, d):

@@ -119,6 +119,9 @@ class LightGCNEngine:
         self.adam = E.AdamState(lr)
         self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
+        self.Esum_rows = z()                 # E-sum on the batch rows (training steps)
+        self.batch_rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
+        self.row_flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
 
     # -- forward: Esum = sum_k A^k E0  (LightGCN.py:132-149) -------------------------
     def propagate(self):
@@ -142,31 +145,53 @@ class LightGCNEngine:
 
     # -- one training step = sess.run(self.opt) (LightGCN.py:178) ---------------------
     def step(self, users, pos, neg, loss_out, grad_sync=None):
-        """grad_sync(tensor): optional in-place all-reduce of dL/dE0 across ranks (parallel.py)."""
-        if users.numel() > self.max_batch:
+        """grad_sync(tensor): optional in-place all-reduce of dL/dE0 across ranks (parallel.py).
+
+        Same arithmetic as propagating everything, minus work whose result is never read or is
+        known to be zero: the loss only reads E* on the 3B batch rows, so the LAST forward hop is
+        formed for those rows only; dL/dE* is non-zero on those rows only, so the FIRST backward
+        hop skips every all-zero source row.  With L=3 that is 4 full SpMM passes instead of 6."""
+        B = users.numel()
+        if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
         L = self.n_layers
-        self.propagate()
-        E.lightgcn_bpr_grad(self.Esum, self.E0, self.n_users, L, users, pos, neg, self.reg,
+        rows = self.batch_rows[:3 * B]
+        E.lightgcn_mark_batch(users, pos, neg, self.n_users, rows, self.row_flag)
+        if L == 0:
+            esum = self.E0
+        else:
+            src, acc_in = self.E0, self.E0
+            bufs = (self.Ea, self.Eb)
+            for k in range(L - 1):
+                self.A.matmul(src, out=bufs[k % 2], sum_in=acc_in, sum_out=self.Esum)
+                src, acc_in = bufs[k % 2], self.Esum
+            if self.d >= 64:
+                self.A.matmul(src, sum_in=acc_in, sum_out=self.Esum_rows, y_row_wanted=self.row_flag)
+            else:
+                self.A.matmul(src, sum_in=acc_in, sum_out=self.Esum_rows)
+            esum = self.Esum_rows                 # valid on the batch rows, which is all that is read
+        E.lightgcn_bpr_grad(esum, self.E0, self.n_users, L, users, pos, neg, self.reg,
                             self.Gstar, self.Greg, self.terms, loss_out)
         # backward through mean + propagation: G_L = H, G_k = H + A^T G_{k+1}, H = Gstar/(L+1)
         E.div_scalar(self.Gstar, float(L + 1), self.H)
         g = self.H
         bufs = (self.Ga, self.Gb)
         for k in range(L):
-            self.At.matmul(g, out=bufs[k % 2], addend=self.H)
+            self.At.matmul(g, out=bufs[k % 2], addend=self.H,
+                           x_row_nonzero=self.row_flag if (k == 0 and self.d >= 64) else None)
             g = bufs[k % 2]
         E.add(g, self.Greg, self.Gstar)          # total dL/dE0 (reuses Gstar as the grad buffer)
         if grad_sync is not None:
             grad_sync(self.Gstar)
         E.adam_dense(self.E0, self.m, self.v, self.Gstar, self.adam, clear_grad=True)
         self.Greg.zero_()
+        self.row_flag.zero_()
         self.adam.advance()
 
     def step_bytes(self):
         """Algorithmic HBM bytes of one step."""
         nd4 = self.N * self.d * 4
-        spmm = 2 * self.n_layers * self.A.algorithmic_bytes(self.d)   # At has the same nnz
+        spmm = 2 * max(self.n_layers - 1, 0) * self.A.algorithmic_bytes(self.d)   # full passes only
         adam = 7 * nd4
         return spmm + adam
 

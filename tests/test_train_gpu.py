@@ -212,3 +212,50 @@ def test_lightgcn_training_improves_ndcg_end_to_end(eng):
             lg.step(bu, bp, bn, loss2)
     after = ndcg10()
     assert after > before + 0.2, (before, after)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_spmm_row_subset_and_masked_variants_equal_full_product(eng, d):
+    """The two work-skipping variants used inside a training step return exactly the rows /
+    values of the full product (they only skip work whose result is unused or zero)."""
+    import torch
+    from oracle import train
+    rng = np.random.RandomState(d + 1)
+    U, I = 900, 700
+    ur, ic = _graph(rng, U, I, 0, 40, hubs=3)          # hub item rows ~800 nnz: 4 segments
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    N = U + I
+    X = rng.randn(N, d).astype(np.float32)
+    csr = eng.SpmmCSR.from_scipy(A)
+    acc = rng.randn(N, d).astype(np.float32)
+    full = torch.empty(N, d, device="cuda")
+    csr.matmul(_dev(X), out=None, sum_in=_dev(acc), sum_out=full)
+    rows = np.concatenate([rng.randint(0, N, 500), [U, U + 1, U + 2, 0, 0, U]]).astype(np.int32)
+    part = torch.full((N, d), 123.0, device="cuda")
+    csr.matmul_rows(_dev(X), _dev(rows), sum_in=_dev(acc), sum_out=part)
+    got, want = part.cpu().numpy(), full.cpu().numpy()
+    np.testing.assert_array_equal(got[rows], want[rows])
+    untouched = np.setdiff1d(np.arange(N), rows)
+    assert np.all(got[untouched] == 123.0)
+    # masked: only flagged rows of X are non-zero
+    flag = np.zeros(N, np.uint8); flag[rng.choice(N, 150, replace=False)] = 1; flag[U] = 1
+    Xz = X * flag[:, None]
+    add = rng.randn(N, d).astype(np.float32)
+    y_full, y_mask = torch.empty(N, d, device="cuda"), torch.empty(N, d, device="cuda")
+    csr.matmul(_dev(Xz), out=y_full, addend=_dev(add))
+    csr.matmul(_dev(Xz), out=y_mask, addend=_dev(add), x_row_nonzero=_dev(flag))
+    np.testing.assert_array_equal(y_mask.cpu().numpy(), y_full.cpu().numpy())
+    # wanted-rows filter (hub rows U, U+1 included): produced rows identical, others untouched
+    wanted = np.zeros(N, np.uint8); wanted[rows] = 1
+    part2 = torch.full((N, d), 321.0, device="cuda")
+    csr.matmul(_dev(X), out=None, sum_in=_dev(acc), sum_out=part2, y_row_wanted=_dev(wanted))
+    got2 = part2.cpu().numpy()
+    np.testing.assert_array_equal(got2[wanted == 1], want[wanted == 1])
+    assert np.all(got2[wanted == 0] == 321.0)
+    # both filters at once
+    y_both = torch.full((N, d), 5.0, device="cuda")
+    csr.matmul(_dev(Xz), out=y_both, addend=_dev(add), x_row_nonzero=_dev(flag),
+               y_row_wanted=_dev(wanted))
+    gb = y_both.cpu().numpy()
+    np.testing.assert_array_equal(gb[wanted == 1], y_full.cpu().numpy()[wanted == 1])
+    assert np.all(gb[wanted == 0] == 5.0)
