@@ -1,0 +1,88 @@
+"""LightGCN on the HIP engine.
+
+Paper: LightGCN: Simplifying and Powering Graph Convolution Network for Recommendation
+(He, Deng, Wang, Li, Zhang, Wang).  Plugin-compatible with
+model/general_recommender/LightGCN.py: same constructor, config keys
+(conf/LightGCN.properties), adjacency options, training loop and log lines.  Every training
+step re-propagates the whole graph, as the reference's loss graph does; propagation is the CSR
+SpMM kernel, the BPR head / its gradient / dense Adam are HIP kernels, triplets are sampled on
+the device, and evaluation ranks from the propagated tables without leaving HBM.
+"""
+import numpy as np
+
+from ...data import PairwiseSampler
+from ...graph import is_symmetric, lightgcn_adjacency, transpose_csr
+from ...util import timer
+from ..AbstractRecommender import AbstractRecommender
+from ._common import predict_scores
+
+
+class LightGCN(AbstractRecommender):
+    def __init__(self, sess, dataset, config):
+        super(LightGCN, self).__init__(dataset, config)
+        self.lr = config["lr"]
+        self.reg = config["reg"]
+        self.emb_dim = config["embed_size"]
+        self.batch_size = config["batch_size"]
+        self.epochs = config["epochs"]
+        self.n_layers = config["n_layers"]
+        self.dataset = dataset
+        self.n_users, self.n_items = self.dataset.num_users, self.dataset.num_items
+        self.user_pos_train = self.dataset.get_user_train_dict(by_time=False)
+        self.all_users = list(self.user_pos_train.keys())
+        self.norm_adj = self.create_adj_mat(config["adj_type"])
+        self.sess = sess                      # unused: there is no TensorFlow session
+        self.engine = None
+        self._final = None
+
+    @timer
+    def create_adj_mat(self, adj_type):
+        user_list, item_list = self.dataset.get_train_interactions()
+        adj = lightgcn_adjacency(user_list, item_list, self.n_users, self.n_items, adj_type)
+        print({"plain": "use the plain adjacency matrix", "norm": "use the normalized adjacency matrix",
+               "gcmc": "use the gcmc adjacency matrix", "pre": "use the pre adjcency matrix"}
+              .get(adj_type, "use the mean adjacency matrix"))
+        return adj
+
+    def build_graph(self):
+        from ...trainer import LightGCNEngine
+        rng = np.random.RandomState(2017)                 # main.py:12
+        n = self.n_users + self.n_items
+        # tf.contrib.layers.xavier_initializer() on [n_users, d] and [n_items, d] (LightGCN.py:87-89)
+        lim_u = np.sqrt(6.0 / (self.n_users + self.emb_dim))
+        lim_i = np.sqrt(6.0 / (self.n_items + self.emb_dim))
+        table = np.empty((n, self.emb_dim), dtype=np.float32)
+        table[:self.n_users] = rng.uniform(-lim_u, lim_u, (self.n_users, self.emb_dim))
+        table[self.n_users:] = rng.uniform(-lim_i, lim_i, (self.n_items, self.emb_dim))
+        adj_t = None if is_symmetric(self.norm_adj) else transpose_csr(self.norm_adj)
+        self.engine = LightGCNEngine(self.norm_adj, self.n_users, self.n_items, table,
+                                     self.n_layers, self.lr, self.reg, self.batch_size,
+                                     adj_t_csr=adj_t)
+
+    def train_model(self):
+        import torch
+        data_iter = PairwiseSampler(self.dataset, neg_num=1, batch_size=self.batch_size,
+                                    shuffle=True, as_tensors=True)
+        loss2 = torch.zeros(2, device=self.engine.E0.device)
+        self.logger.info(self.evaluator.metrics_info())
+        for epoch in range(self.epochs):
+            for bat_users, bat_pos_items, bat_neg_items in data_iter:
+                self.engine.step(bat_users, bat_pos_items, bat_neg_items, loss2)
+            result = self.evaluate_model()
+            self.logger.info("epoch %d:\t%s" % (epoch, result))
+
+    def evaluate_model(self):
+        # the reference's assign_opt: snapshot the propagated tables once per evaluation
+        eu, ei = self.engine.final_embeddings()
+        self._final = (eu.contiguous(), ei.contiguous())
+        return self.evaluator.evaluate(self)
+
+    def get_eval_factors(self):
+        if self._final is None:
+            eu, ei = self.engine.final_embeddings()
+            self._final = (eu.contiguous(), ei.contiguous())
+        return self._final
+
+    def predict(self, users, candidate_items=None):
+        eu, ei = self.get_eval_factors()
+        return predict_scores(eu, ei, users, candidate_items)

@@ -1,0 +1,84 @@
+"""BPR-MF on the HIP engine.
+
+Reference: Steffen Rendle et al., "BPR: Bayesian Personalized Ranking from Implicit Feedback."
+UAI 2009.  Plugin-compatible with model/general_recommender/MF.py: same constructor, config
+keys (conf/MF.properties), training loop, log lines and `predict` contract; the per-batch
+`sess.run((loss, optimizer))` is one fused gather/BPR/scatter kernel plus two TF-semantics Adam
+sweeps on tables that never leave HBM, and the triplets are sampled on the device.
+"""
+from time import time
+
+import numpy as np
+
+from ...data import PairwiseSampler
+from ...util import timer
+from ...util.tool import get_initializer
+from ..AbstractRecommender import AbstractRecommender
+from ._common import predict_scores
+
+
+class MF(AbstractRecommender):
+    def __init__(self, sess, dataset, conf):
+        super(MF, self).__init__(dataset, conf)
+        self.learning_rate = conf["learning_rate"]
+        self.embedding_size = conf["embedding_size"]
+        self.learner = conf["learner"]
+        self.loss_function = conf["loss_function"]
+        self.is_pairwise = conf["is_pairwise"]
+        self.num_epochs = conf["epochs"]
+        self.reg_mf = conf["reg_mf"]
+        self.batch_size = conf["batch_size"]
+        self.verbose = conf["verbose"]
+        self.num_negatives = conf["num_negatives"]
+        self.init_method = conf["init_method"]
+        self.stddev = conf["stddev"]
+        self.dataset = dataset
+        self.num_users = dataset.num_users
+        self.num_items = dataset.num_items
+        self.sess = sess                      # unused: there is no TensorFlow session
+        self.engine = None
+
+    def build_graph(self):
+        from ...trainer import MFEngine
+        if self.is_pairwise is not True or str(self.loss_function).lower() != "bpr":
+            raise NotImplementedError("the HIP MF engine implements the pairwise BPR loss "
+                                      "(is_pairwise=True, loss_function=bpr)")
+        if str(self.learner).lower() != "adam":
+            raise NotImplementedError("the HIP MF engine implements learner=adam")
+        init = get_initializer(self.init_method, self.stddev, seed=2017)   # main.py:12
+        users = init([self.num_users, self.embedding_size])
+        items = init([self.num_items, self.embedding_size])
+        self.engine = MFEngine(users, items, self.learning_rate, self.reg_mf, self.batch_size)
+
+    # ---------- training process -------
+    def train_model(self):
+        import torch
+        self.logger.info(self.evaluator.metrics_info())
+        data_iter = PairwiseSampler(self.dataset, neg_num=1, batch_size=self.batch_size,
+                                    shuffle=True, as_tensors=True)
+        losses = torch.zeros((max(len(data_iter), 1), 2), device=self.engine.P.device)
+        for epoch in range(1, self.num_epochs + 1):
+            training_start_time = time()
+            n = 0
+            for bat_users, bat_items_pos, bat_items_neg in data_iter:
+                self.engine.step(bat_users, bat_items_pos, bat_items_neg, losses[n])
+                n += 1
+            per_step = losses[:n].cpu().numpy()           # one D2H copy per epoch
+            total_loss = 0.0
+            for a, b in per_step:                          # `total_loss += loss`, MF.py:102
+                total_loss += np.float32(a) + np.float32(b)
+            self.logger.info("[iter %d : loss : %f, time: %f]" % (epoch, total_loss / len(data_iter),
+                                                                 time() - training_start_time))
+            if epoch % self.verbose == 0:
+                self.logger.info("epoch %d:\t%s" % (epoch, self.evaluate()))
+
+    @timer
+    def evaluate(self):
+        return self.evaluator.evaluate(self)
+
+    def get_eval_factors(self):
+        """Device tables for the evaluator's on-GPU factor path."""
+        return self.engine.P, self.engine.Q
+
+    def predict(self, user_ids, candidate_items=None):
+        return predict_scores(self.engine.P, self.engine.Q, user_ids, candidate_items)

@@ -1,0 +1,134 @@
+"""End-to-end drop-in runs on the GPU: `NeuRec.properties` + `conf/*.properties` + a `.rating`
+file -> `neurec_amd.main` -> logs and metric lines in the reference's format, with the
+evaluator's two entrances (on-device factor path, plugin score-matrix path) agreeing with the
+CPU statement of the reference evaluator."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from neurec_amd import defaults
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_dataset(root, n_users=120, n_items=90, seed=3):
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "dataset"), exist_ok=True)
+    with open(os.path.join(root, "dataset", "toy.rating"), "w") as f:
+        for u in range(n_users):
+            liked = (u % 6) * 15 + rng.choice(15, 10, replace=False)       # 6 taste clusters
+            for it in liked:
+                f.write("%d\t%d\t%d\t%d\n" % (u + 7, it + 300, 5, rng.randint(1, 10**6)))
+
+
+def _run(tmp_path, argv):
+    from neurec_amd.main import main
+    path = defaults.write_default_configs(str(tmp_path), overrides={
+        "data.input.path": os.path.join(str(tmp_path), "dataset"), "data.input.dataset": "toy",
+        "test_batch_size": "64"})
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        return main(argv=argv, properties=path)
+    finally:
+        os.chdir(cwd)
+
+
+def _log_text(tmp_path, model):
+    folder = os.path.join(str(tmp_path), "log", "toy", model)
+    files = os.listdir(folder)
+    assert len(files) == 1 and files[0].startswith("toy_%s_" % model) and files[0].endswith(".log")
+    with open(os.path.join(folder, files[0])) as f:
+        return f.read()
+
+
+def _oracle_line(model, evaluator):
+    """The reference driver restated on the CPU: np.matmul-free fmaf scores -> -inf mask ->
+    cpp_evaluate_matrix semantics -> float32 mean -> '%.8f' string."""
+    from oracle import native
+    P, Q = [t.cpu().numpy() for t in model.get_eval_factors()]
+    uni = evaluator.evaluator
+    users = list(uni.user_pos_test.keys())
+    S = native.score_gemm(P, np.asarray(users, np.int32), Q)
+    for r, u in enumerate(users):
+        if u in uni.user_pos_train and len(uni.user_pos_train[u]) > 0:
+            S[r][uni.user_pos_train[u]] = -np.inf                            # uni_evaluator.py:140-143
+    res = native.eval_matrix(S, [uni.user_pos_test[u] for u in users], uni.metrics, uni.max_top)
+    final = np.mean(res, axis=0).reshape(uni.metrics_num, uni.max_top)[:, uni.top_show - 1].reshape(-1)
+    return "\t".join([("%.8f" % x).ljust(12) for x in final])
+
+
+def test_mf_config_drops_in_and_learns(tmp_path):
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=MF", "--epochs=12", "--batch_size=128",
+                            "--learning_rate=0.01", "--reg_mf=0.001", "--verbose=4"])
+    text = _log_text(tmp_path, "MF")
+    assert "Dataset name: toy" in text and "MF's hyperparameters:" in text
+    assert "metrics:\tPrecision@10" in text
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert [int(i[0]) for i in iters] == list(range(1, 13))
+    losses = [float(i[1]) for i in iters]
+    assert losses[-1] < 0.8 * losses[0]                                      # BPR loss goes down
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == [4, 8, 12]                          # every `verbose` epochs
+    last = evals[-1][1].split("\t")
+    assert len(last) == 10 and all(re.fullmatch(r"\d\.\d{8}\s*", x) for x in last)
+    # factor path == score-matrix (plugin) path == CPU oracle, to the last printed digit
+    uni = model.evaluator.evaluator
+    users = list(uni.user_pos_test.keys())
+    line_factor = uni._format(uni._evaluate_factors(model, users))
+    line_scores = uni._format(uni._evaluate_scores(model, users))
+    assert line_factor == line_scores == _oracle_line(model, model.evaluator)
+    assert float(line_factor.split("\t")[4]) > 0.3                           # NDCG@10 is the 5th number
+    # predict contract: [B, I] float32 array; candidate mode -> list of per-user arrays
+    full = model.predict([0, 5, 9], None)
+    assert full.shape == (3, model.num_items) and full.dtype == np.float32
+    cand = model.predict([0, 5], [[1, 2, 3], [7]])
+    assert [len(c) for c in cand] == [3, 1] and np.array_equal(cand[0], full[0][[1, 2, 3]])
+
+
+def test_lightgcn_config_drops_in(tmp_path):
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=LightGCN", "--epochs=6", "--batch_size=256",
+                            "--n_layers=3", "--topk=[5,10]", "--metric=[\"Recall\",\"NDCG\"]"])
+    text = _log_text(tmp_path, "LightGCN")
+    assert "use the pre adjcency matrix" not in text          # that line goes to stdout, as in the reference
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == list(range(6))                      # LightGCN.py:172-180
+    assert "metrics:\tRecall@5" in text and "NDCG@10" in text
+    first, last = [float(evals[i][1].split("\t")[3]) for i in (0, -1)]
+    assert last > first and last > 0.3                                       # NDCG@10 improves
+    model._final = None
+    assert evals[-1][1] == _oracle_line(model, model.evaluator)
+
+
+def test_candidate_negative_mode_and_groups(tmp_path):
+    """rec.evaluate.neg > 0 (leave-one-out protocol) and group_view go through the same kernels."""
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=MF", "--epochs=2", "--batch_size=128", "--splitter=loo",
+                            "--rec.evaluate.neg=20", "--topk=[5]", "--verbose=2"])
+    text = _log_text(tmp_path, "MF")
+    line = re.findall(r"epoch 2:\t(.+)", text)[0].split("\t")
+    assert len(line) == 5
+    # restate candidate-mode evaluation on the CPU (uni_evaluator.py:123-131)
+    from oracle import native
+    uni = model.evaluator.evaluator
+    P, Q = [t.cpu().numpy() for t in model.get_eval_factors()]
+    users = list(uni.user_pos_test.keys())
+    rows, truth = [], []
+    for u in users:
+        cand = list(uni.user_pos_test[u]) + uni.user_neg_test[u]
+        rows.append(native.score_gemm(P, np.asarray([u], np.int32), Q)[0][cand])
+        truth.append(list(range(len(uni.user_pos_test[u]))))
+    width = max(len(r) for r in rows)
+    S = np.full((len(rows), width), -np.inf, np.float32)
+    for r, v in enumerate(rows):
+        S[r, :len(v)] = v
+    res = native.eval_matrix(S, truth, uni.metrics, uni.max_top)
+    want = np.mean(res, axis=0).reshape(5, 5)[:, 4]
+    assert [x.strip() for x in line] == ["%.8f" % x for x in want]

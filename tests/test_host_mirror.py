@@ -1,0 +1,233 @@
+"""Host side of the drop-in surface (no GPU): Configurator, DataIterator, Dataset, dict views,
+sampler bookkeeping — checked against the reference's own pure-Python modules where
+/root/reference is present (loaded file-by-file; the packages themselves import TensorFlow),
+and against the reference behaviours recorded in SURVEY.md Appendix A everywhere."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from neurec_amd import defaults
+from neurec_amd.util import Configurator, DataIterator
+from neurec_amd.util.tool import csr_to_user_dict, pad_sequences, typeassert
+
+REF = "/root/reference"
+has_ref = os.path.isdir(REF)
+
+
+def _load_ref_module(rel, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ------------------------------------------------------------------ Configurator
+def test_configurator_coercion_and_precedence(tmp_path):
+    path = defaults.write_default_configs(str(tmp_path), overrides={"odd": "bare_word", "flag": "TRUE"})
+    conf = Configurator(path, default_section="hyperparameters",
+                        argv=["--recommender=LightGCN", "--n_layers=3", "--only_cli=[1,2]", "--lr=1e-2"])
+    assert conf["recommender"] == "LightGCN" and conf["n_layers"] == 3      # CLI overwrites file keys
+    assert conf["only_cli"] == [1, 2] and "only_cli" in conf               # CLI-only keys visible
+    assert conf["data.convert.separator"] == "\t"                          # '\t' is eval-ed
+    assert conf["topk"] == [10, 20] and conf["group_view"] is None
+    assert conf["reg"] == 1e-3 and conf["lr"] == 1e-2 and conf["by_time"] is False
+    assert conf["odd"] == "bare_word" and conf["flag"] is True
+    assert conf.batch_size == 1024                                          # attribute access
+    assert conf.params_str().startswith("LightGCN_lr=1e-2_reg=1e-3_embed_size=64_n_layers=3")
+    with pytest.raises(KeyError):
+        conf["missing"]
+    with pytest.raises(TypeError):
+        conf[3]
+    with pytest.raises(SyntaxError):
+        Configurator(path, argv=["recommender=MF"])
+    with pytest.raises(FileNotFoundError):
+        Configurator(str(tmp_path / "nope.properties"))
+    assert "NeuRec hyperparameters:" in str(conf) and "LightGCN's hyperparameters:" in str(conf)
+
+
+@pytest.mark.skipif(not has_ref, reason="/root/reference not present")
+def test_configurator_reads_unchanged_reference_files_like_the_reference():
+    ref_mod = _load_ref_module("util/configurator.py", "ref_configurator")
+    cwd, argv = os.getcwd(), sys.argv
+    os.chdir(REF)
+    try:
+        for model in ("MF", "LightGCN", "NGCF", "MultiVAE"):
+            sys.argv = ["main.py", "--recommender=%s" % model, "--num_thread=4"]
+            theirs = ref_mod.Configurator("NeuRec.properties", default_section="hyperparameters")
+            ours = Configurator("NeuRec.properties", default_section="hyperparameters",
+                                argv=sys.argv[1:])
+            keys = list(theirs.lib_arg) + list(theirs.alg_arg)
+            assert keys == list(ours.lib_arg) + list(ours.alg_arg)
+            for k in keys:
+                assert ours[k] == theirs[k] and type(ours[k]) is type(theirs[k]), k
+            assert ours.params_str() == theirs.params_str()
+            assert str(ours) == str(theirs)
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
+
+
+# ------------------------------------------------------------------ DataIterator
+def test_data_iterator_batches_like_the_reference():
+    users, items, labels = list(range(10)), list(range(10, 20)), list(range(20, 30))
+    got = list(DataIterator(users, items, labels, batch_size=4, shuffle=False))
+    assert [len(b[0]) for b in got] == [4, 4, 2] and got[2] == [[8, 9], [18, 19], [28, 29]]
+    assert list(DataIterator(users, batch_size=3)) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+    assert len(DataIterator(users, batch_size=4, drop_last=True)) == 2
+    with pytest.raises(ValueError):
+        DataIterator(users, items[:3])
+    if has_ref:
+        ref_mod = _load_ref_module("util/data_iterator.py", "ref_data_iterator")
+        for kw in ({"batch_size": 3, "shuffle": True}, {"batch_size": 4, "shuffle": True, "drop_last": True}):
+            np.random.seed(2018)
+            theirs = list(ref_mod.DataIterator(users, items, **kw))
+            np.random.seed(2018)
+            ours = list(DataIterator(users, items, **kw))
+            assert ours == theirs               # same np.random.permutation stream, same batches
+
+
+# ------------------------------------------------------------------ helpers
+def test_dict_views_padding_and_typeassert():
+    m = sp.csr_matrix(np.array([[0, 1, 0, 1], [0, 0, 0, 0], [1, 0, 0, 0]]))
+    assert csr_to_user_dict(m) == {0: [1, 3], 2: [0]}          # empty rows omitted, items ascending
+    x = pad_sequences([[1, 2, 3], [4], []], value=-np.inf, dtype=np.float32)
+    assert x.shape == (3, 3) and x[1, 0] == 4 and np.isinf(x[1, 1]) and np.isinf(x[2]).all()
+    assert pad_sequences([[1, 2, 3]], max_len=2, truncating="pre").tolist() == [[2, 3]]
+
+    @typeassert(a=int, b=(dict, None.__class__))
+    def f(a, b=None):
+        return a
+    assert f(1) == 1 and f(1, {}) == 1
+    with pytest.raises(TypeError):
+        f("x")
+
+
+# ------------------------------------------------------------------ Dataset
+def _write_rating_file(tmp_path, n_users=40, n_items=60, seed=0):
+    rng = np.random.RandomState(seed)
+    rows = []
+    for u in range(n_users):
+        for it in rng.choice(n_items, rng.randint(5, 20), replace=False):
+            rows.append((u + 1000, it + 5000, rng.randint(1, 6), rng.randint(10**6, 10**7)))
+    rng.shuffle(rows)
+    os.makedirs(tmp_path / "dataset", exist_ok=True)
+    with open(tmp_path / "dataset" / "toy.rating", "w") as f:
+        for r in rows:
+            f.write("\t".join(str(x) for x in r) + "\n")
+    return rows
+
+
+def test_dataset_split_cache_and_views(tmp_path):
+    from neurec_amd.data import Dataset
+    rows = _write_rating_file(tmp_path)
+    path = defaults.write_default_configs(str(tmp_path), overrides={
+        "data.input.path": str(tmp_path / "dataset"), "data.input.dataset": "toy"})
+    conf = Configurator(path, default_section="hyperparameters", argv=[])
+    np.random.seed(2018)
+    ds = Dataset(conf)
+    n_per_user = {}
+    for u, *_ in rows:
+        n_per_user[u] = n_per_user.get(u, 0) + 1
+    assert ds.num_users == 40 and ds.num_ratings == len(rows)
+    # ratio split: ceil(0.8 * n_u) train items per user (data/utils.py:73)
+    train_deg = np.diff(ds.train_matrix.indptr)
+    assert sorted(train_deg) == sorted(int(np.ceil(0.8 * n)) for n in n_per_user.values())
+    assert ds.train_matrix.multiply(ds.test_matrix).nnz == 0
+    tr, te = ds.get_user_train_dict(), ds.get_user_test_dict()
+    assert all(list(v) == sorted(v) for v in tr.values()) and set(te) <= set(tr)
+    users, items = ds.get_train_interactions()
+    assert len(users) == ds.train_matrix.nnz
+    assert "The number of users: 40" in str(ds)
+    # second construction loads the md5-validated cache and reproduces the same matrices
+    cache = tmp_path / "dataset" / "_tmp_toy"
+    assert (cache / "toy_ratio_u0_i0.md5").is_file() and (cache / "toy_ratio_u0_i0.user2id").is_file()
+    ds2 = Dataset(conf)
+    assert (ds2.train_matrix != ds.train_matrix).nnz == 0 and ds2.userids == ds.userids
+    # leave-one-out splitter + sampled test negatives
+    conf_loo = Configurator(path, default_section="hyperparameters",
+                            argv=["--splitter=loo", "--rec.evaluate.neg=7", "--by_time=True"])
+    ds3 = Dataset(conf_loo)
+    assert set(np.diff(ds3.test_matrix.indptr)) <= {0, 1}
+    neg = ds3.get_user_test_neg_dict()
+    assert all(len(v) == 7 for v in neg.values())
+    for u, v in neg.items():
+        assert not set(v) & set(ds3.train_matrix[u].indices) and not set(v) & set(ds3.test_matrix[u].indices)
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "dataset", "ml-100k.rating")),
+                    reason="real ml-100k only exists in the reference tree")
+def test_dataset_on_real_ml100k_matches_survey_counts(tmp_path):
+    from neurec_amd.data import Dataset
+    path = defaults.write_default_configs(str(tmp_path), overrides={
+        "data.input.path": os.path.join(REF, "dataset"), "data.cache.path": str(tmp_path)})
+    np.random.seed(2018)
+    ds = Dataset(Configurator(path, default_section="hyperparameters", argv=[]))
+    assert (ds.num_users, ds.num_items) == (943, 1682)
+    assert ds.train_matrix.nnz == 80367 and ds.test_matrix.nnz == 19633
+    assert len(ds.get_user_test_dict()) == 943
+
+
+# ------------------------------------------------------------------ sampler bookkeeping
+def test_positive_item_flattening_matches_reference_structure():
+    from neurec_amd.data.sampler import _generate_positive_items
+    toy = {0: [1, 3], 2: [0], 5: [2, 4, 6, 7]}
+    user_pos_len, users_list, pos_items_list = _generate_positive_items(toy)
+    assert users_list == [0, 0, 2, 5, 5, 5, 5]
+    assert pos_items_list == [1, 3, 0, 2, 4, 6, 7]
+    assert user_pos_len == [[0, 2], [2, 1], [5, 4]]
+    with pytest.raises(TypeError):
+        _generate_positive_items([1, 2])
+    with pytest.raises(ValueError):
+        _generate_positive_items({})
+
+
+def test_grouped_evaluator_buckets_users_by_training_degree():
+    from neurec_amd.evaluator.grouped_evaluator import GroupedEvaluator
+    train = {u: list(range(u + 1)) for u in range(12)}                       # degree u+1
+    test = {u: [100] for u in range(12)}
+    g = GroupedEvaluator(train, test, group_view=[3, 6, 10], top_k=[5])
+    assert [len(v) for v in g.grouped_user.values()] == [3, 3, 4]            # (0,3] (3,6] (6,10]
+    assert list(g.grouped_user)[0].startswith("(0,3]:")
+    assert "Precision@5" in g.metrics_info()
+    with pytest.raises(ValueError):
+        GroupedEvaluator({0: list(range(50))}, {0: [1]}, group_view=[3], top_k=[5])
+    with pytest.raises(TypeError):
+        GroupedEvaluator(train, test, group_view=(3, 6), top_k=[5])
+
+
+def test_evaluator_argument_validation_and_header():
+    from neurec_amd.evaluator import ProxyEvaluator
+    ev = ProxyEvaluator({0: [1]}, {0: [2]}, metric=["Precision", "NDCG"], top_k=[10, 20])
+    assert ev.metrics_info() == "metrics:\t" + "\t".join(
+        ["Precision@10".ljust(12), "Precision@20".ljust(12), "NDCG@10".ljust(12), "NDCG@20".ljust(12)])
+    with pytest.raises(ValueError):
+        ProxyEvaluator({0: [1]}, {0: [2]}, metric=["HitRatio"])
+    with pytest.raises(TypeError):
+        ProxyEvaluator({0: [1]}, {0: [2]}, metric=3)
+    with pytest.raises(TypeError):
+        ProxyEvaluator([1], {0: [2]})
+
+
+def test_compat_aliases_reference_import_paths():
+    from neurec_amd import compat
+    compat.install()
+    from model.AbstractRecommender import AbstractRecommender      # noqa: F401
+    from util import Configurator as C2, DataIterator as D2         # noqa: F401
+    from data import PairwiseSampler                                 # noqa: F401
+    from evaluator import ProxyEvaluator                             # noqa: F401
+    from util.cython.tools import float_type, is_ndarray
+    assert float_type is np.float32
+    a = np.zeros((2, 2), np.float32)
+    assert is_ndarray(a, np.float32) and not is_ndarray(a[:1], np.float32) and not is_ndarray(a, np.int32)
+
+
+def test_find_recommender_dispatch():
+    from neurec_amd.main import find_recommender
+    assert find_recommender("MF").__name__ == "MF"
+    assert find_recommender("LightGCN").__module__.endswith("general_recommender.LightGCN")
+    with pytest.raises(ImportError):
+        find_recommender("NoSuchModel")

@@ -1,0 +1,111 @@
+"""Multi-process path on CPU (gloo, world_size 2): the sharding plan and the one exchange step
+of neurec_amd/parallel.py.  The HIP kernels cannot run here, so the per-rank compute is played
+by the CPU oracle — inside this test only — which is enough to prove the distributed algebra:
+  * data-parallel triplets + ONE all-reduce of dL/dE0 per step == the single-process step on the
+    concatenated batch (the reference run with batch_size = world * B);
+  * test users split across ranks + all-reduced metric sums == the single-process evaluation;
+  * every rank's slice of the epoch stream is disjoint and their union is the epoch.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from neurec_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _graph():
+    from oracle import train
+    rng = np.random.RandomState(0)
+    U, I, d = 60, 50, 16
+    users = np.repeat(np.arange(U), 5)
+    items = np.concatenate([rng.choice(I, 5, replace=False) for _ in range(U)])
+    A = train.lightgcn_adjacency(users, items, U, I, "pre")
+    E0 = (rng.randn(U + I, d) * 0.1).astype(np.float64)
+    return A.astype(np.float64), E0, U, I
+
+
+def _worker(rank, world, port, out):
+    from oracle import native, train
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = parallel.init_from_env(backend="gloo")
+    assert comm.active and comm.rank == rank and comm.world == world
+    A, E0, U, I = _graph()
+    m, v = np.zeros_like(E0), np.zeros_like(E0)
+    adam = train.Adam(0.01, dtype=np.float64)
+    rng = np.random.RandomState(5)
+    B = 32
+    for step in range(3):
+        bu, bp, bn = rng.randint(0, U, world * B), rng.randint(0, I, world * B), rng.randint(0, I, world * B)
+        lo, hi = parallel.partition(world * B, rank, world)                 # this rank's triplets
+        _, _, g = train.lightgcn_loss_and_grad(A, A.T.tocsr(), E0, U, 2, bu[lo:hi], bp[lo:hi],
+                                               bn[lo:hi], 1e-3)
+        gt = torch.from_numpy(g)
+        comm.allreduce_sum_(gt)                                             # the one exchange step
+        adam.dense(E0, m, v, gt.numpy())
+        adam.advance()
+    # evaluation: users sharded, metric sums all-reduced
+    users = np.arange(U, dtype=np.int32)
+    mine = parallel.shard_users(users, rank, world)
+    S = native.score_gemm(E0[:U].astype(np.float32), mine, E0[U:].astype(np.float32))
+    truth = [[int((u * 7) % I)] for u in mine]
+    sums = torch.from_numpy(native.eval_matrix(S, truth, [2, 4], 10).astype(np.float64).sum(0))
+    comm.allreduce_sum_(sums)
+    slowest = comm.max_float(float(rank))
+    comm.barrier()
+    if rank == 0:
+        np.savez(out, E0=E0, means=(sums / U).numpy(), slowest=slowest)
+    comm.shutdown()
+
+
+def test_two_rank_training_and_eval_match_single_process(tmp_path):
+    from oracle import native, train
+    out = str(tmp_path / "rank0.npz")
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    # single process, batch = world * B
+    A, E0, U, I = _graph()
+    m, v = np.zeros_like(E0), np.zeros_like(E0)
+    adam = train.Adam(0.01, dtype=np.float64)
+    rng = np.random.RandomState(5)
+    for step in range(3):
+        bu, bp, bn = rng.randint(0, U, 64), rng.randint(0, I, 64), rng.randint(0, I, 64)
+        train.lightgcn_step(A, A.T.tocsr(), E0, m, v, U, 2, bu, bp, bn, 1e-3, adam)
+    assert np.abs(got["E0"] - E0).max() < 1e-12
+    S = native.score_gemm(E0[:U].astype(np.float32), None, E0[U:].astype(np.float32))
+    want = native.eval_matrix(S, [[int((u * 7) % I)] for u in range(U)], [2, 4], 10).astype(np.float64).mean(0)
+    np.testing.assert_allclose(got["means"], want, rtol=1e-12)
+    assert got["slowest"] == 1.0                                             # max over ranks
+
+
+def test_partition_covers_range_without_overlap():
+    for n in (0, 1, 7, 1024, 813886):
+        for world in (1, 2, 3, 8):
+            cuts = [parallel.partition(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    users = np.arange(10)
+    assert np.concatenate([parallel.shard_users(users, r, 3) for r in range(3)]).tolist() == list(range(10))
+
+
+def test_single_process_comm_is_a_no_op():
+    comm = parallel.Comm()
+    t = torch.ones(3)
+    assert comm.allreduce_sum_(t) is t and not comm.active and comm.max_float(2.5) == 2.5
+    comm.barrier()
