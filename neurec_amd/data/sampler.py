@@ -47,7 +47,7 @@ def _sampling_negative_items(user_pos_len, neg_num, item_num, user_pos_dict):
     for neg_items in drawn:
         if isinstance(neg_items, list):
             if neg_num > 1:
-                neg_items = np.reshape(neg_items, newshape=[-1, neg_num])
+                neg_items = np.reshape(neg_items, [-1, neg_num])
             neg_items_list.extend(neg_items)
         else:
             neg_items_list.append(neg_items)

@@ -63,8 +63,8 @@ class UniEvaluator(HIPEvaluator):
         return self._device_state
 
     def _format(self, final_result):
-        final_result = np.reshape(final_result, newshape=[self.metrics_num, self.max_top])
-        final_result = np.reshape(final_result[:, self.top_show - 1], newshape=[-1])
+        final_result = np.reshape(final_result, [self.metrics_num, self.max_top])
+        final_result = np.reshape(final_result[:, self.top_show - 1], [-1])
         return "\t".join([("%.8f" % x).ljust(12) for x in final_result])
 
     # ------------------------------------------------------------------ evaluate
