@@ -150,6 +150,19 @@ int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int
                         float alpha, float beta1, float beta2, float eps, int clear_grad,
                         void* stream);
 
+/* Dense ApplyAdam with gradient = d_grad_a + d_grad_b (added in fp32, one rounding); the
+ * gradient buffers are read-only. */
+int nrhip_adam_dense_tf2(float* d_var, float* d_m, float* d_v, const float* d_grad_a,
+                         const float* d_grad_b, int64_t n, float alpha, float beta1, float beta2,
+                         float eps, void* stream);
+/* Row-sparse helpers over a list of row ids of a [*, d] buffer (repeats allowed):
+ * dst[row] = src[row] / denom; and zeroing of the listed rows of up to four buffers plus a
+ * per-row byte flag (any of them may be NULL). */
+int nrhip_rows_div(const int32_t* d_rows, int n_listed, int d, const float* d_src, float denom,
+                   float* d_dst, void* stream);
+int nrhip_rows_clear(const int32_t* d_rows, int n_listed, int d, float* d_b0, float* d_b1,
+                     float* d_b2, float* d_b3, uint8_t* d_flag, void* stream);
+
 /* ---- sparse adjacency x embedding (LightGCN / NGCF propagation) ----------
  * Replaces tf.sparse_tensor_dense_matmul(adj, ego)
  * (model/general_recommender/LightGCN.py:140, NGCF.py:176) and its autodiff
@@ -164,9 +177,12 @@ int nrhip_spmm_plan_bytes(int64_t n_rows, int64_t nnz, size_t* bytes);
  * on the host, uploaded into the caller's device buffer d_plan_buf, and a
  * host-side handle describing it is returned in *plan_out.  item_rows /
  * item_nnz bound the whole-row work items (0 = tuned defaults; at most 32 rows
- * and 256 non-zeros). */
+ * and 256 non-zeros).  split_row (0 = none) is a locality hint for bipartite graphs: rows
+ * below it (user nodes) and from it on (item nodes) gather from disjoint halves of X and are
+ * scheduled on disjoint halves of the XCDs. */
 int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_rows, int item_nnz,
-                           void* d_plan_buf, size_t plan_bytes, void* stream, void** plan_out);
+                           int64_t split_row, void* d_plan_buf, size_t plan_bytes, void* stream,
+                           void** plan_out);
 int nrhip_spmm_plan_destroy(void* plan);
 int nrhip_spmm_plan_info(const void* plan, int64_t* n_work_items, int64_t* n_split_rows);
 int nrhip_spmm_workspace_bytes(const void* plan, int d, size_t* bytes);
@@ -201,7 +217,8 @@ int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const
  * user rows first, item rows offset by n_users.  Accumulates
  *   d_Gstar  += dLoss/dE*      (dense [N][d], zero on entry)
  *   d_Greg   += reg * E0 rows  (dense [N][d], zero on entry)
- * and writes the two scalars mf_loss, emb_loss into d_loss2[0..1]. */
+ * and writes the two scalars mf_loss, emb_loss into d_loss2[0..1] (d_loss2 may be NULL:
+ * the reference never fetches LightGCN's loss during training, LightGCN.py:178). */
 int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
                             int n_layers, const int32_t* d_users, const int32_t* d_pos,
                             const int32_t* d_neg, int batch, float reg, float* d_Gstar,

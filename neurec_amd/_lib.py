@@ -53,8 +53,11 @@ SIGNATURES = {
     "nrhip_bpr_mf_grad": [p, p, i32, p, p, p, i32, f32, p, p, p, p, p],
     "nrhip_adam_sparse_tf": [p, p, p, p, i64, f32, f32, f32, f32, p],
     "nrhip_adam_dense_tf": [p, p, p, p, i64, f32, f32, f32, f32, i32, p],
+    "nrhip_adam_dense_tf2": [p, p, p, p, p, i64, f32, f32, f32, f32, p],
+    "nrhip_rows_div": [p, i32, i32, p, f32, p, p],
+    "nrhip_rows_clear": [p, i32, i32, p, p, p, p, p, p],
     "nrhip_spmm_plan_bytes": [i64, i64, psz],
-    "nrhip_spmm_plan_create": [p, i64, i32, i32, p, sz, p, C.POINTER(p)],
+    "nrhip_spmm_plan_create": [p, i64, i32, i32, i64, p, sz, p, C.POINTER(p)],
     "nrhip_spmm_plan_destroy": [p],
     "nrhip_spmm_plan_info": [p, C.POINTER(i64), C.POINTER(i64)],
     "nrhip_spmm_workspace_bytes": [p, i32, psz],

@@ -53,6 +53,65 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
   }
 }
 
+// dense ApplyAdam whose gradient is the sum of two buffers (g = g1 + g2, one rounding — the
+// same value a separate elementwise add would have produced); neither buffer is modified.
+__global__ __launch_bounds__(256) void adam_dense2_kernel(float* __restrict__ var,
+                                                          float* __restrict__ m,
+                                                          float* __restrict__ v,
+                                                          const float* __restrict__ g1,
+                                                          const float* __restrict__ g2, int64_t n,
+                                                          float alpha, float omb1, float omb2,
+                                                          float eps) {
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 w = reinterpret_cast<float4*>(var)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    const float4 a = reinterpret_cast<const float4*>(g1)[i];
+    const float4 b = reinterpret_cast<const float4*>(g2)[i];
+    nr::adam_dense_tf(__fadd_rn(a.x, b.x), w.x, mm.x, vv.x, alpha, omb1, omb2, eps);
+    nr::adam_dense_tf(__fadd_rn(a.y, b.y), w.y, mm.y, vv.y, alpha, omb1, omb2, eps);
+    nr::adam_dense_tf(__fadd_rn(a.z, b.z), w.z, mm.z, vv.z, alpha, omb1, omb2, eps);
+    nr::adam_dense_tf(__fadd_rn(a.w, b.w), w.w, mm.w, vv.w, alpha, omb1, omb2, eps);
+    reinterpret_cast<float4*>(var)[i] = w;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float w = var[i], mm = m[i], vv = v[i];
+    nr::adam_dense_tf(__fadd_rn(g1[i], g2[i]), w, mm, vv, alpha, omb1, omb2, eps);
+    var[i] = w; m[i] = mm; v[i] = vv;
+  }
+}
+
+// Row-sparse helpers over a list of row ids (repeats allowed: every operation is idempotent).
+// One wave per listed row, lane = column.
+__global__ __launch_bounds__(256) void rows_div_kernel(const int32_t* __restrict__ rows,
+                                                       int n_listed, int d,
+                                                       const float* __restrict__ src, float denom,
+                                                       float* __restrict__ dst) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= n_listed) return;
+  const int64_t r = rows[w];
+  for (int k = lane; k < d; k += 64) dst[r * d + k] = src[r * d + k] / denom;
+}
+__global__ __launch_bounds__(256) void rows_clear_kernel(const int32_t* __restrict__ rows,
+                                                         int n_listed, int d, float* b0, float* b1,
+                                                         float* b2, float* b3,
+                                                         uint8_t* __restrict__ flag) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= n_listed) return;
+  const int64_t r = rows[w];
+  for (int k = lane; k < d; k += 64) {
+    if (b0) b0[r * d + k] = 0.f;
+    if (b1) b1[r * d + k] = 0.f;
+    if (b2) b2[r * d + k] = 0.f;
+    if (b3) b3[r * d + k] = 0.f;
+  }
+  if (flag && lane == 0) flag[r] = 0;
+}
+
 enum { OP_SCALE = 0, OP_ADD = 1, OP_DIV = 2 };
 template <int OP>
 __global__ __launch_bounds__(256) void ewise_kernel(const float* __restrict__ x,
@@ -136,6 +195,43 @@ int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int
     hipLaunchKernelGGL((adam_kernel<false, false>), dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
                        (hipStream_t)stream, d_var, d_m, d_v, d_grad, n, alpha, beta1, beta2,
                        1.0f - beta1, 1.0f - beta2, eps);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_adam_dense_tf2(float* d_var, float* d_m, float* d_v, const float* d_grad_a,
+                         const float* d_grad_b, int64_t n, float alpha, float beta1, float beta2,
+                         float eps, void* stream) {
+  NR_REQUIRE(d_var && d_m && d_v && d_grad_a && d_grad_b && n >= 0, NR_ERR_ARG,
+             "adam_dense_tf2: bad arguments");
+  NR_REQUIRE(aligned16(d_var) && aligned16(d_m) && aligned16(d_v) && aligned16(d_grad_a) &&
+                 aligned16(d_grad_b),
+             NR_ERR_ARG, "adam_dense_tf2: buffers must be 16-byte aligned");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(adam_dense2_kernel, dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
+                     (hipStream_t)stream, d_var, d_m, d_v, d_grad_a, d_grad_b, n, alpha,
+                     1.0f - beta1, 1.0f - beta2, eps);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_rows_div(const int32_t* d_rows, int n_listed, int d, const float* d_src, float denom,
+                   float* d_dst, void* stream) {
+  NR_REQUIRE(d_rows && d_src && d_dst && n_listed >= 0 && d >= 1, NR_ERR_ARG,
+             "rows_div: bad arguments");
+  if (n_listed == 0) return NR_OK;
+  hipLaunchKernelGGL(rows_div_kernel, dim3((n_listed + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     d_rows, n_listed, d, d_src, denom, d_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_rows_clear(const int32_t* d_rows, int n_listed, int d, float* d_b0, float* d_b1,
+                     float* d_b2, float* d_b3, uint8_t* d_flag, void* stream) {
+  NR_REQUIRE(d_rows && n_listed >= 0 && d >= 1, NR_ERR_ARG, "rows_clear: bad arguments");
+  if (n_listed == 0) return NR_OK;
+  hipLaunchKernelGGL(rows_clear_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, d_rows, n_listed, d, d_b0, d_b1, d_b2, d_b3, d_flag);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -209,8 +209,7 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
                             int n_layers, const int32_t* d_users, const int32_t* d_pos,
                             const int32_t* d_neg, int batch, float reg, float* d_Gstar,
                             float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
-  NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_terms &&
-                 d_loss2,
+  NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_terms,
              NR_ERR_ARG, "lightgcn_bpr_grad: null pointer argument");
   NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
              "lightgcn_bpr_grad: embedding dim %d outside 1..256", d);
@@ -218,7 +217,7 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
              "lightgcn_bpr_grad: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (batch == 0) {
-    NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+    if (d_loss2) NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
     return NR_OK;
   }
   float* t_mf = d_terms;
@@ -235,9 +234,11 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<4>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
                        lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
-                     d_loss2);
-  NR_LAUNCH_CHECK();
+  if (d_loss2) {
+    hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
+                       d_loss2);
+    NR_LAUNCH_CHECK();
+  }
   return NR_OK;
 }
 

@@ -35,6 +35,7 @@
 // (SURVEY.md §8d); the gathers themselves are served by L2 / Infinity Cache.
 #include "nr_common.h"
 #include <limits.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <new>
 #include <vector>
@@ -49,7 +50,7 @@ constexpr int kGather = 16;      // row gathers in flight per wave (8/16/32 meas
 struct SpmmPlan {
   int64_t n_rows, nnz;
   // --- work items (d >= 64 path)
-  int64_t n_items;
+  int64_t n_items, n_hub_items, n_a_items, n_b_items;   // items = [hub | class A | class B]
   int item_rows, item_nnz;   // limits the items were cut with
   int32_t* item_row0;   // first row of the run (whole-row items) or the row (segment items)
   int32_t* item_nrows;  // rows in the run (1..item_rows); 0 marks a segment of a split row
@@ -227,8 +228,8 @@ template <int D, int WPB, int TR, int G, bool MASKED>
 __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
     const int32_t* __restrict__ item_row0, const int32_t* __restrict__ item_nrows,
     const int64_t* __restrict__ item_begin, const int32_t* __restrict__ item_len,
-    const int32_t* __restrict__ item_slot, float* __restrict__ partial, int64_t n_items,
-    const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ item_slot, float* __restrict__ partial, int n_hub, int n_a,
+    int n_b, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float* __restrict__ X, float* __restrict__ Y, const float* __restrict__ addend,
     const float* sum_in, float* sum_out, const uint8_t* __restrict__ col_mask,
@@ -236,8 +237,33 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
   constexpr int CPL = D / NR_WAVE;
   __shared__ float s_tile[WPB][TR][D];
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
-  const int64_t item = (int64_t)blockIdx.x * WPB + wave;
-  if (item >= n_items) return;
+  // Item order is [hub segments | class A | class B].  Classes are a locality hint: in a
+  // bipartite graph user rows gather only item rows and vice versa, so running class A on
+  // XCDs 0-3 and class B on XCDs 4-7 (block b lands on XCD b % 8 — observed, used for speed
+  // only) halves the table each XCD's private L2 has to hold.
+  const int hub_blocks = ((n_hub + WPB - 1) / WPB + 7) / 8 * 8;
+  int64_t item;
+  if ((int)blockIdx.x < hub_blocks) {
+    item = (int64_t)blockIdx.x * WPB + wave;
+    if (item >= n_hub) return;
+  } else {
+    const int bb = blockIdx.x - hub_blocks;
+    if (n_b == 0) {
+      item = (int64_t)bb * WPB + wave;
+      if (item >= n_a) return;
+      item += n_hub;
+    } else {
+      const int xcd = bb & 7, j = bb >> 3;
+      const int64_t local = ((int64_t)j * 4 + (xcd & 3)) * WPB + wave;
+      if (xcd < 4) {
+        if (local >= n_a) return;
+        item = n_hub + local;
+      } else {
+        if (local >= n_b) return;
+        item = (int64_t)n_hub + n_a + local;
+      }
+    }
+  }
   // wave-uniform descriptor -> SGPRs (threadIdx-derived values look divergent to hipcc)
   const int r0 = __builtin_amdgcn_readfirstlane(item_row0[item]);
   const int nr = __builtin_amdgcn_readfirstlane(item_nrows[item]);
@@ -529,13 +555,16 @@ int launch_items(const SpmmPlan* p, const int64_t* indptr, const int32_t* indice
                  const float* vals, const float* X, float* Y, const float* addend,
                  const float* sum_in, float* sum_out, float* partial, const uint8_t* col_mask,
                  const uint8_t* row_mask, hipStream_t st) {
-  const int64_t blocks = (p->n_items + WPB - 1) / WPB;
-  if (blocks > 0) {
+  const int64_t hub_blocks = ((p->n_hub_items + WPB - 1) / WPB + 7) / 8 * 8;
+  const int64_t ba = (p->n_a_items + WPB - 1) / WPB, bb = (p->n_b_items + WPB - 1) / WPB;
+  const int64_t blocks = hub_blocks + (p->n_b_items == 0 ? ba : 8 * ((std::max(ba, bb) + 3) / 4));
+  if (p->n_items > 0) {
     dim3 grid((unsigned)blocks), block(WPB * NR_WAVE);
 #define NR_ITEM_LAUNCH(TR, M)                                                                  \
   hipLaunchKernelGGL((spmm_item_kernel<D, WPB, TR, kGather, M>), grid, block, 0, st,            \
                      p->item_row0, p->item_nrows, p->item_begin, p->item_len, p->item_slot,     \
-                     partial, p->n_items, indptr, indices, vals, X, Y, addend, sum_in, sum_out, \
+                     partial, (int)p->n_hub_items, (int)p->n_a_items, (int)p->n_b_items, indptr,   \
+                     indices, vals, X, Y, addend, sum_in, sum_out,                               \
                      col_mask, row_mask)
     if (col_mask || row_mask) {
       if (p->item_rows <= 16) NR_ITEM_LAUNCH(16, true); else NR_ITEM_LAUNCH(32, true);
@@ -575,7 +604,9 @@ int nrhip_spmm_plan_bytes(int64_t n_rows, int64_t nnz, size_t* bytes) {
 }
 
 int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_rows, int item_nnz,
-                           void* d_plan_buf, size_t plan_bytes, void* stream, void** plan_out) {
+                           int64_t split_row, void* d_plan_buf, size_t plan_bytes, void* stream,
+                           void** plan_out) {
+  if (split_row <= 0 || split_row >= n_rows) split_row = 0;
   if (item_rows <= 0) item_rows = 16;       // defaults tuned on the gowalla-shaped graph
   if (item_nnz <= 0) item_nnz = 256;
   if (item_rows > kItemRows) item_rows = kItemRows;
@@ -622,8 +653,11 @@ int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_row
       seg_slot.push_back(-1);
     }
   }
-  // whole-row work items: greedy runs of consecutive short rows
+  const int64_t n_hub_items = (int64_t)it_row0.size();
+  int64_t n_a_items = 0;
+  // whole-row work items: greedy runs of consecutive short rows (rows < split_row = class A)
   for (int64_t r = 0; r < n_rows;) {
+    if (split_row && r == split_row) n_a_items = (int64_t)it_row0.size() - n_hub_items;
     const int64_t len_r = h_indptr[r + 1] - h_indptr[r];
     if (len_r > kSegLen) { ++r; continue; }
     const int64_t r0 = r;
@@ -633,6 +667,7 @@ int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_row
       const int64_t l = h_indptr[r + 1] - h_indptr[r];
       if (l > kSegLen) break;                       // a split row ends the run
       if (nr > 0 && tot + l > item_nnz) break;
+      if (nr > 0 && split_row && r == split_row) break;   // runs do not straddle the classes
       tot += l; ++nr; ++r;
     }
     it_row0.push_back((int32_t)r0); it_nrows.push_back(nr); it_begin.push_back(h_indptr[r0]);
@@ -645,6 +680,10 @@ int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_row
   p->nnz = nnz;
   p->item_rows = item_rows;
   p->item_nnz = item_nnz;
+  p->n_hub_items = n_hub_items;
+  if (!split_row) n_a_items = (int64_t)it_row0.size() - n_hub_items;
+  p->n_a_items = n_a_items;
+  p->n_b_items = (int64_t)it_row0.size() - n_hub_items - n_a_items;
   p->n_seg = (int64_t)seg_row.size();
   p->n_items = (int64_t)it_row0.size();
   p->n_multi_seg = n_multi_seg;

@@ -267,6 +267,25 @@ def adam_dense(var, m, v, grad, st, clear_grad=True):
          1 if clear_grad else 0, _stream())
 
 
+def adam_dense2(var, m, v, grad_a, grad_b, st):
+    """Dense TF Adam with gradient grad_a + grad_b (both left untouched)."""
+    call("nrhip_adam_dense_tf2", _ptr(var, torch.float32), _ptr(m), _ptr(v), _ptr(grad_a),
+         _ptr(grad_b), var.numel(), float(st.alpha()), float(st.beta1), float(st.beta2),
+         float(st.eps), _stream())
+
+
+def rows_div(rows, src, denom, dst):
+    call("nrhip_rows_div", _ptr(rows, torch.int32), rows.numel(), src.shape[1], _ptr(src),
+         float(denom), _ptr(dst), _stream())
+
+
+def rows_clear(rows, d, bufs=(), flag=None):
+    b = list(bufs) + [None] * (4 - len(bufs))
+    call("nrhip_rows_clear", _ptr(rows, torch.int32), rows.numel(), int(d),
+         _ptr(b[0], allow_none=True), _ptr(b[1], allow_none=True), _ptr(b[2], allow_none=True),
+         _ptr(b[3], allow_none=True), _ptr(flag, allow_none=True), _stream())
+
+
 def bpr_mf_grad(P, Q, users, pos, neg, reg, GP, GQ, terms, loss2):
     call("nrhip_bpr_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
          _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32), users.numel(),
@@ -284,7 +303,7 @@ def lightgcn_bpr_grad(Esum, E0, n_users, n_layers, users, pos, neg, reg, Gstar, 
     call("nrhip_lightgcn_bpr_grad", _ptr(Esum, torch.float32), _ptr(E0, torch.float32), n_users,
          E0.shape[1], n_layers, _ptr(users, torch.int32), _ptr(pos, torch.int32),
          _ptr(neg, torch.int32), users.numel(), float(reg), _ptr(Gstar), _ptr(Greg), _ptr(terms),
-         _ptr(loss2), _stream())
+         _ptr(loss2, allow_none=True), _stream())
 
 
 def scale(x, a, out):
@@ -302,7 +321,7 @@ def div_scalar(x, denom, out):
 class SpmmCSR:
     """A CSR matrix resident on the device plus its row-segment plan."""
 
-    def __init__(self, indptr, indices, vals, n_cols=None, item_rows=0, item_nnz=0):
+    def __init__(self, indptr, indices, vals, n_cols=None, item_rows=0, item_nnz=0, split_row=0):
         dev = require_gpu()
         self.h_indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         self.n_rows = len(self.h_indptr) - 1
@@ -318,17 +337,17 @@ class SpmmCSR:
         self.plan_buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
         self.plan = C.c_void_p(0)
         call("nrhip_spmm_plan_create", self.h_indptr.ctypes.data_as(C.c_void_p), self.n_rows,
-             int(item_rows), int(item_nnz), _ptr(self.plan_buf), self.plan_buf.numel(), _stream(), C.byref(self.plan))
+             int(item_rows), int(item_nnz), int(split_row), _ptr(self.plan_buf), self.plan_buf.numel(), _stream(), C.byref(self.plan))
         nseg, nsplit = C.c_int64(0), C.c_int64(0)
         call("nrhip_spmm_plan_info", self.plan, C.byref(nseg), C.byref(nsplit))
         self.n_segments, self.n_split_rows = nseg.value, nsplit.value
         self._ws = {}
 
     @staticmethod
-    def from_scipy(mat, item_rows=0, item_nnz=0):
+    def from_scipy(mat, item_rows=0, item_nnz=0, split_row=0):
         m = mat.tocsr().astype(np.float32)
         m.sort_indices()
-        return SpmmCSR(m.indptr, m.indices, m.data, m.shape[1], item_rows, item_nnz)
+        return SpmmCSR(m.indptr, m.indices, m.data, m.shape[1], item_rows, item_nnz, split_row)
 
     def __del__(self):
         try:

@@ -101,11 +101,11 @@ class LightGCNEngine:
         dev = E.require_gpu()
         self.n_users, self.n_items, self.n_layers = int(n_users), int(n_items), int(n_layers)
         self.N = self.n_users + self.n_items
-        self.A = adj_csr if isinstance(adj_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_csr)
+        self.A = adj_csr if isinstance(adj_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_csr, split_row=n_users)
         if adj_t_csr is None:
             self.At = self.A
         else:
-            self.At = adj_t_csr if isinstance(adj_t_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_t_csr)
+            self.At = adj_t_csr if isinstance(adj_t_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_t_csr, split_row=n_users)
         self.E0 = torch.as_tensor(embed, dtype=torch.float32).contiguous().to(dev)
         assert self.E0.shape[0] == self.N
         self.d = self.E0.shape[1]
@@ -122,6 +122,7 @@ class LightGCNEngine:
         self.Esum_rows = z()                 # E-sum on the batch rows (training steps)
         self.batch_rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
         self.row_flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.Gsync = None                    # allocated on first multi-GPU step
 
     # -- forward: Esum = sum_k A^k E0  (LightGCN.py:132-149) -------------------------
     def propagate(self):
@@ -144,7 +145,7 @@ class LightGCNEngine:
         return Estar[:self.n_users], Estar[self.n_users:]
 
     # -- one training step = sess.run(self.opt) (LightGCN.py:178) ---------------------
-    def step(self, users, pos, neg, loss_out, grad_sync=None):
+    def step(self, users, pos, neg, loss_out=None, grad_sync=None):
         """grad_sync(tensor): optional in-place all-reduce of dL/dE0 across ranks (parallel.py).
 
         Same arithmetic as propagating everything, minus work whose result is never read or is
@@ -172,20 +173,25 @@ class LightGCNEngine:
             esum = self.Esum_rows                 # valid on the batch rows, which is all that is read
         E.lightgcn_bpr_grad(esum, self.E0, self.n_users, L, users, pos, neg, self.reg,
                             self.Gstar, self.Greg, self.terms, loss_out)
-        # backward through mean + propagation: G_L = H, G_k = H + A^T G_{k+1}, H = Gstar/(L+1)
-        E.div_scalar(self.Gstar, float(L + 1), self.H)
+        # backward through mean + propagation: G_L = H, G_k = H + A^T G_{k+1}, H = Gstar/(L+1).
+        # Gstar, Greg and H are non-zero on the batch rows only, so they are derived and
+        # re-zeroed row-sparsely; the dense passes are the SpMM hops and Adam.
+        E.rows_div(rows, self.Gstar, float(L + 1), self.H)
         g = self.H
         bufs = (self.Ga, self.Gb)
         for k in range(L):
             self.At.matmul(g, out=bufs[k % 2], addend=self.H,
                            x_row_nonzero=self.row_flag if (k == 0 and self.d >= 64) else None)
             g = bufs[k % 2]
-        E.add(g, self.Greg, self.Gstar)          # total dL/dE0 (reuses Gstar as the grad buffer)
-        if grad_sync is not None:
-            grad_sync(self.Gstar)
-        E.adam_dense(self.E0, self.m, self.v, self.Gstar, self.adam, clear_grad=True)
-        self.Greg.zero_()
-        self.row_flag.zero_()
+        if grad_sync is not None and self.Gsync is None:
+            self.Gsync = torch.zeros_like(self.E0)
+        if grad_sync is None:
+            E.adam_dense2(self.E0, self.m, self.v, g, self.Greg, self.adam)   # grad = g + Greg
+        else:
+            E.add(g, self.Greg, self.Gsync)      # total dL/dE0 of this rank
+            grad_sync(self.Gsync)                # summed over ranks (RCCL all-reduce)
+            E.adam_dense(self.E0, self.m, self.v, self.Gsync, self.adam, clear_grad=False)
+        E.rows_clear(rows, self.d, (self.Gstar, self.Greg, self.H), self.row_flag)
         self.adam.advance()
 
     def step_bytes(self):
