@@ -230,6 +230,54 @@ int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, cons
                               int batch, int n_users, int32_t* d_rows_out, uint8_t* d_row_flag,
                               void* stream);
 
+/* ---- whole training steps issued natively -----------------------------------
+ * One call enqueues every kernel of a step (the reference's sess.run(opt) is one
+ * call into its native runtime too: LightGCN.py:178, MF.py:101).  The context only
+ * records caller-owned device pointers; nothing is allocated on the device. */
+typedef struct nrhip_lightgcn_buffers {
+  const void* plan;          /* SpMM plan of the adjacency A              */
+  const void* plan_t;        /* plan of A^T (== plan when A is symmetric) */
+  const int64_t* indptr;  const int32_t* indices;  const float* vals;      /* A   */
+  const int64_t* indptr_t; const int32_t* indices_t; const float* vals_t;  /* A^T */
+  float* E0; float* m; float* v;            /* [n_nodes][d] embeddings + Adam moments */
+  float* Ea; float* Eb; float* Esum; float* Esum_rows;   /* layer buffers          */
+  float* Gstar; float* Greg; float* H; float* Ga; float* Gb;   /* gradient buffers   */
+  int32_t* batch_rows;       /* 3*max_batch                      */
+  uint8_t* row_flag;         /* n_nodes bytes, zero between steps */
+  float* terms;              /* 2*max_batch                      */
+  void* spmm_ws; size_t spmm_ws_bytes;
+  int n_users; int n_nodes; int d; int n_layers; int max_batch;
+  float reg;
+} nrhip_lightgcn_buffers;
+int nrhip_lightgcn_ctx_create(const nrhip_lightgcn_buffers* bufs, void** ctx_out);
+int nrhip_lightgcn_ctx_destroy(void* ctx);
+/* alpha = lr*sqrt(1-b2^t)/(1-b1^t) in fp32 (the caller keeps the running powers).
+ * d_loss2 may be NULL (loss not fetched). */
+int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
+                        const int32_t* d_neg, int batch, float alpha, float beta1, float beta2,
+                        float eps, float* d_loss2, void* stream);
+
+/* The same step cut at its one exchange point (multi-GPU): _grad leaves this rank's total
+ * dLoss/dE0 in d_grad_out ([n_nodes][d]); the caller sums it over ranks (RCCL all-reduce);
+ * _apply runs Adam on the summed gradient. */
+int nrhip_lightgcn_step_grad(void* ctx, const int32_t* d_users, const int32_t* d_pos,
+                             const int32_t* d_neg, int batch, float* d_loss2, float* d_grad_out,
+                             void* stream);
+int nrhip_lightgcn_step_apply(void* ctx, float* d_grad, float alpha, float beta1, float beta2,
+                              float eps, void* stream);
+
+typedef struct nrhip_mf_buffers {
+  float* P; float* Q; float* mP; float* vP; float* mQ; float* vQ; float* GP; float* GQ;
+  float* terms;              /* 2*max_batch */
+  int n_users; int n_items; int d; int max_batch;
+  float reg;
+} nrhip_mf_buffers;
+int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out);
+int nrhip_mf_ctx_destroy(void* ctx);
+int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                  int batch, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                  void* stream);
+
 /* y = a*x (+ y0)  elementwise helpers used between propagation passes. */
 int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream);
 int nrhip_add(const float* d_x, const float* d_y, float* d_out, int64_t n, void* stream);

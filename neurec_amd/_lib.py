@@ -36,6 +36,25 @@ i32, i64, u64, f32 = C.c_int, C.c_int64, C.c_uint64, C.c_float
 sz = C.c_size_t
 psz = C.POINTER(C.c_size_t)
 
+
+
+class LightGCNBuffers(C.Structure):
+    """nrhip_lightgcn_buffers (include/neurec_hip.h)"""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "plan", "plan_t", "indptr", "indices", "vals", "indptr_t", "indices_t", "vals_t",
+        "E0", "m", "v", "Ea", "Eb", "Esum", "Esum_rows", "Gstar", "Greg", "H", "Ga", "Gb",
+        "batch_rows", "row_flag", "terms", "spmm_ws")] + [
+        ("spmm_ws_bytes", C.c_size_t), ("n_users", C.c_int), ("n_nodes", C.c_int), ("d", C.c_int),
+        ("n_layers", C.c_int), ("max_batch", C.c_int), ("reg", C.c_float)]
+
+
+class MFBuffers(C.Structure):
+    """nrhip_mf_buffers (include/neurec_hip.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("P", "Q", "mP", "vP", "mQ", "vQ", "GP", "GQ", "terms")] + [
+        ("n_users", C.c_int), ("n_items", C.c_int), ("d", C.c_int), ("max_batch", C.c_int),
+        ("reg", C.c_float)]
+
+
 # name -> argtypes; every function returns int status except where noted.
 SIGNATURES = {
     "nrhip_device_info": [C.POINTER(i32), C.POINTER(i32), psz, C.c_char_p, i32],
@@ -66,6 +85,14 @@ SIGNATURES = {
     "nrhip_spmm_csr_rows": [p, p, p, p, i32, p, i32, p, p, p, p, p],
     "nrhip_lightgcn_mark_batch": [p, p, p, i32, i32, p, p, p],
     "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p],
+    "nrhip_lightgcn_ctx_create": [C.POINTER(LightGCNBuffers), C.POINTER(p)],
+    "nrhip_lightgcn_ctx_destroy": [p],
+    "nrhip_lightgcn_step": [p, p, p, p, i32, f32, f32, f32, f32, p, p],
+    "nrhip_lightgcn_step_grad": [p, p, p, p, i32, p, p, p],
+    "nrhip_lightgcn_step_apply": [p, p, f32, f32, f32, f32, p],
+    "nrhip_mf_ctx_create": [C.POINTER(MFBuffers), C.POINTER(p)],
+    "nrhip_mf_ctx_destroy": [p],
+    "nrhip_mf_step": [p, p, p, p, i32, f32, f32, f32, f32, p, p],
     "nrhip_scale": [p, f32, p, i64, p],
     "nrhip_add": [p, p, p, i64, p],
     "nrhip_div_scalar": [p, f32, p, i64, p],

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(HERE, "libneurec_hip.so")
 STAMP = os.path.join(OBJ_DIR, "sources.sha256")
 
 SOURCES = ["eval_select.hip", "score_gemm.hip", "sampler.hip", "spmm.hip", "bpr.hip", "adam.hip",
-           "dense.hip"]
+           "step.hip", "dense.hip"]
 HEADERS = ["nr_core.h", "nr_common.h"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -38,6 +38,8 @@ def _digest():
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode())
             h.update(f.read())
+    with open(os.path.join(ROOT, "include", "neurec_hip.h"), "rb") as f:
+        h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 

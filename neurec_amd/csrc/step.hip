@@ -1,0 +1,194 @@
+// step.hip — whole training steps issued from native code.
+//
+// One C call enqueues every kernel of a step (the launch sequence the Python engines used to
+// issue one ctypes call at a time): the reference's `sess.run(opt)` is one call into its
+// native runtime too (model/general_recommender/LightGCN.py:178, MF.py:101).  At ~15
+// launches per 0.3 ms step the per-call interpreter overhead, not the GPU, was the limit.
+// No arithmetic lives here — only the order of the nrhip_* launches declared in
+// include/neurec_hip.h.
+#include "nr_common.h"
+#include "neurec_hip.h"
+#include <new>
+
+namespace {
+
+struct LightGCNCtx {
+  nrhip_lightgcn_buffers b;
+};
+struct MFCtx {
+  nrhip_mf_buffers b;
+};
+
+}  // namespace
+
+#define NR_TRY(call)            \
+  do {                          \
+    int _rc = (call);           \
+    if (_rc != NR_OK) return _rc; \
+  } while (0)
+
+extern "C" {
+
+int nrhip_lightgcn_ctx_create(const nrhip_lightgcn_buffers* bufs, void** ctx_out) {
+  NR_REQUIRE(bufs && ctx_out, NR_ERR_ARG, "lightgcn_ctx_create: null argument");
+  const nrhip_lightgcn_buffers& b = *bufs;
+  NR_REQUIRE(b.plan && b.plan_t && b.indptr && b.indices && b.vals && b.indptr_t && b.indices_t &&
+                 b.vals_t && b.E0 && b.m && b.v && b.Ea && b.Eb && b.Esum && b.Esum_rows &&
+                 b.Gstar && b.Greg && b.H && b.Ga && b.Gb && b.batch_rows && b.row_flag && b.terms,
+             NR_ERR_ARG, "lightgcn_ctx_create: a buffer pointer is null");
+  NR_REQUIRE(b.n_users > 0 && b.n_nodes > b.n_users && b.n_layers >= 0 && b.max_batch > 0,
+             NR_ERR_ARG, "lightgcn_ctx_create: bad sizes");
+  NR_REQUIRE(b.d == 16 || b.d == 32 || b.d == 64 || b.d == 128 || b.d == 256, NR_ERR_UNSUPPORTED,
+             "lightgcn_ctx_create: embedding dim %d not built (16, 32, 64, 128, 256)", b.d);
+  LightGCNCtx* c = new (std::nothrow) LightGCNCtx();
+  NR_REQUIRE(c, NR_ERR_ARG, "lightgcn_ctx_create: out of host memory");
+  c->b = b;
+  *ctx_out = c;
+  return NR_OK;
+}
+
+int nrhip_lightgcn_ctx_destroy(void* ctx) {
+  delete (LightGCNCtx*)ctx;
+  return NR_OK;
+}
+
+// forward + backward of one step; *g_out = buffer holding G_0 (dL/dE0 without the reg rows)
+static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_users,
+                            const int32_t* d_pos, const int32_t* d_neg, int batch, float* d_loss2,
+                            void* stream, const float** g_out) {
+  const int L = b.n_layers, d = b.d;
+  const bool skip = d >= 64;                 // the work-skipping variants exist for d >= 64
+  NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, b.n_users, b.batch_rows,
+                                   b.row_flag, stream));
+  // forward: L-1 full hops, the last one only on the batch rows
+  const float* esum = b.E0;
+  if (L > 0) {
+    const float* src = b.E0;
+    const float* acc_in = b.E0;
+    float* ping[2] = {b.Ea, b.Eb};
+    for (int k = 0; k < L - 1; ++k) {
+      NR_TRY(nrhip_spmm_csr(b.plan, b.indptr, b.indices, b.vals, src, d, ping[k & 1], nullptr,
+                            acc_in, b.Esum, b.spmm_ws, b.spmm_ws_bytes, stream));
+      src = ping[k & 1];
+      acc_in = b.Esum;
+    }
+    if (skip)
+      NR_TRY(nrhip_spmm_csr_masked(b.plan, b.indptr, b.indices, b.vals, src, nullptr, b.row_flag,
+                                   d, nullptr, nullptr, acc_in, b.Esum_rows, b.spmm_ws,
+                                   b.spmm_ws_bytes, stream));
+    else
+      NR_TRY(nrhip_spmm_csr(b.plan, b.indptr, b.indices, b.vals, src, d, nullptr, nullptr, acc_in,
+                            b.Esum_rows, b.spmm_ws, b.spmm_ws_bytes, stream));
+    esum = b.Esum_rows;
+  }
+  NR_TRY(nrhip_lightgcn_bpr_grad(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
+                                 b.Gstar, b.Greg, b.terms, d_loss2, stream));
+  // backward: H = Gstar/(L+1) on the batch rows; G_k = H + A^T G_{k+1}
+  NR_TRY(nrhip_rows_div(b.batch_rows, 3 * batch, d, b.Gstar, (float)(L + 1), b.H, stream));
+  const float* g = b.H;
+  float* gping[2] = {b.Ga, b.Gb};
+  for (int k = 0; k < L; ++k) {
+    if (k == 0 && skip)
+      NR_TRY(nrhip_spmm_csr_masked(b.plan_t, b.indptr_t, b.indices_t, b.vals_t, g, b.row_flag,
+                                   nullptr, d, gping[k & 1], b.H, nullptr, nullptr, b.spmm_ws,
+                                   b.spmm_ws_bytes, stream));
+    else
+      NR_TRY(nrhip_spmm_csr(b.plan_t, b.indptr_t, b.indices_t, b.vals_t, g, d, gping[k & 1], b.H,
+                            nullptr, nullptr, b.spmm_ws, b.spmm_ws_bytes, stream));
+    g = gping[k & 1];
+  }
+  *g_out = g;
+  return NR_OK;
+}
+
+static int lightgcn_check(void* ctx, const int32_t* u, const int32_t* p, const int32_t* n,
+                          int batch) {
+  NR_REQUIRE(ctx && u && p && n, NR_ERR_ARG, "lightgcn_step: null argument");
+  const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
+  NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG,
+             "lightgcn_step: batch %d outside 0..%d", batch, b.max_batch);
+  return NR_OK;
+}
+
+// One training step (LightGCN.py:178); neurec_amd/trainer.py:LightGCNEngine documents the sequence.
+int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
+                        const int32_t* d_neg, int batch, float alpha, float beta1, float beta2,
+                        float eps, float* d_loss2, void* stream) {
+  NR_TRY(lightgcn_check(ctx, d_users, d_pos, d_neg, batch));
+  if (batch == 0) return NR_OK;
+  const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
+  const float* g = nullptr;
+  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_loss2, stream, &g));
+  NR_TRY(nrhip_adam_dense_tf2(b.E0, b.m, b.v, g, b.Greg, (int64_t)b.n_nodes * b.d, alpha, beta1,
+                              beta2, eps, stream));
+  NR_TRY(nrhip_rows_clear(b.batch_rows, 3 * batch, b.d, b.Gstar, b.Greg, b.H, nullptr, b.row_flag,
+                          stream));
+  return NR_OK;
+}
+
+// Multi-GPU form: the same step cut at its one exchange point.  _grad leaves this rank's total
+// dL/dE0 (G_0 + reg rows) in d_grad_out; the caller all-reduces it; _apply runs Adam on it.
+int nrhip_lightgcn_step_grad(void* ctx, const int32_t* d_users, const int32_t* d_pos,
+                             const int32_t* d_neg, int batch, float* d_loss2, float* d_grad_out,
+                             void* stream) {
+  NR_TRY(lightgcn_check(ctx, d_users, d_pos, d_neg, batch));
+  NR_REQUIRE(d_grad_out, NR_ERR_ARG, "lightgcn_step_grad: null output");
+  const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
+  const int64_t n = (int64_t)b.n_nodes * b.d;
+  if (batch == 0) {
+    NR_CHECK_HIP(hipMemsetAsync(d_grad_out, 0, n * sizeof(float), (hipStream_t)stream));
+    return NR_OK;
+  }
+  const float* g = nullptr;
+  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_loss2, stream, &g));
+  NR_TRY(nrhip_add(g, b.Greg, d_grad_out, n, stream));
+  NR_TRY(nrhip_rows_clear(b.batch_rows, 3 * batch, b.d, b.Gstar, b.Greg, b.H, nullptr, b.row_flag,
+                          stream));
+  return NR_OK;
+}
+
+int nrhip_lightgcn_step_apply(void* ctx, float* d_grad, float alpha, float beta1, float beta2,
+                              float eps, void* stream) {
+  NR_REQUIRE(ctx && d_grad, NR_ERR_ARG, "lightgcn_step_apply: null argument");
+  const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
+  return nrhip_adam_dense_tf(b.E0, b.m, b.v, d_grad, (int64_t)b.n_nodes * b.d, alpha, beta1, beta2,
+                             eps, 0, stream);
+}
+
+int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out) {
+  NR_REQUIRE(bufs && ctx_out, NR_ERR_ARG, "mf_ctx_create: null argument");
+  const nrhip_mf_buffers& b = *bufs;
+  NR_REQUIRE(b.P && b.Q && b.mP && b.vP && b.mQ && b.vQ && b.GP && b.GQ && b.terms, NR_ERR_ARG,
+             "mf_ctx_create: a buffer pointer is null");
+  NR_REQUIRE(b.n_users > 0 && b.n_items > 0 && b.d >= 1 && b.d <= 256 && b.max_batch > 0,
+             NR_ERR_ARG, "mf_ctx_create: bad sizes");
+  MFCtx* c = new (std::nothrow) MFCtx();
+  NR_REQUIRE(c, NR_ERR_ARG, "mf_ctx_create: out of host memory");
+  c->b = b;
+  *ctx_out = c;
+  return NR_OK;
+}
+
+int nrhip_mf_ctx_destroy(void* ctx) {
+  delete (MFCtx*)ctx;
+  return NR_OK;
+}
+
+// One BPR-MF step = sess.run((loss, optimizer)) (MF.py:101)
+int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                  int batch, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                  void* stream) {
+  NR_REQUIRE(ctx && d_users && d_pos && d_neg && d_loss2, NR_ERR_ARG, "mf_step: null argument");
+  const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
+  NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG, "mf_step: batch %d outside 0..%d",
+             batch, b.max_batch);
+  NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ, b.terms,
+                           d_loss2, stream));
+  NR_TRY(nrhip_adam_sparse_tf(b.P, b.mP, b.vP, b.GP, (int64_t)b.n_users * b.d, alpha, beta1, beta2,
+                              eps, stream));
+  NR_TRY(nrhip_adam_sparse_tf(b.Q, b.mQ, b.vQ, b.GQ, (int64_t)b.n_items * b.d, alpha, beta1, beta2,
+                              eps, stream));
+  return NR_OK;
+}
+
+}  // extern "C"

@@ -402,6 +402,81 @@ class SpmmCSR:
         return self.nnz * 8 + (self.n_rows + 1) * 4 + 2 * self.n_rows * d * 4
 
 
+class NativeStep:
+    """Context of the native step drivers (csrc/step.hip): a record of device pointers owned by
+    the Python engine object, which must outlive it."""
+
+    def __init__(self, kind, handle, owner):
+        self.kind, self.handle, self.owner = kind, handle, owner
+
+    @staticmethod
+    def for_lightgcn(eng):
+        b = _lib.LightGCNBuffers()
+        ws = eng.A._workspace(eng.d)
+        wst = eng.At._workspace(eng.d)
+        ws = ws if ws.numel() >= wst.numel() else wst
+        vals = dict(plan=eng.A.plan.value, plan_t=eng.At.plan.value, indptr=eng.A.indptr,
+                    indices=eng.A.indices, vals=eng.A.vals, indptr_t=eng.At.indptr,
+                    indices_t=eng.At.indices, vals_t=eng.At.vals, E0=eng.E0, m=eng.m, v=eng.v,
+                    Ea=eng.Ea, Eb=eng.Eb, Esum=eng.Esum, Esum_rows=eng.Esum_rows, Gstar=eng.Gstar,
+                    Greg=eng.Greg, H=eng.H, Ga=eng.Ga, Gb=eng.Gb, batch_rows=eng.batch_rows,
+                    row_flag=eng.row_flag, terms=eng.terms, spmm_ws=ws)
+        for k, t in vals.items():
+            setattr(b, k, t if isinstance(t, int) else t.data_ptr())
+        b.spmm_ws_bytes, b.n_users, b.n_nodes = ws.numel(), eng.n_users, eng.N
+        b.d, b.n_layers, b.max_batch, b.reg = eng.d, eng.n_layers, eng.max_batch, eng.reg
+        h = C.c_void_p(0)
+        call("nrhip_lightgcn_ctx_create", C.byref(b), C.byref(h))
+        ctx = NativeStep("lightgcn", h, eng)
+        ctx._keep = (ws,)
+        return ctx
+
+    @staticmethod
+    def for_mf(eng):
+        b = _lib.MFBuffers()
+        for k in ("P", "Q", "mP", "vP", "mQ", "vQ", "GP", "GQ", "terms"):
+            setattr(b, k, getattr(eng, k).data_ptr())
+        b.n_users, b.n_items, b.d = eng.P.shape[0], eng.Q.shape[0], eng.P.shape[1]
+        b.max_batch, b.reg = eng.max_batch, eng.reg
+        h = C.c_void_p(0)
+        call("nrhip_mf_ctx_create", C.byref(b), C.byref(h))
+        return NativeStep("mf", h, eng)
+
+    def __del__(self):
+        try:
+            if self.handle and self.handle.value:
+                name = "nrhip_lightgcn_ctx_destroy" if self.kind == "lightgcn" else "nrhip_mf_ctx_destroy"
+                getattr(_lib.lib, name)(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _idx(t):
+        if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("batch ids must be contiguous int32 device tensors")
+        return C.c_void_p(t.data_ptr())
+
+    def lightgcn_step(self, users, pos, neg, st, loss2=None):
+        call("nrhip_lightgcn_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
+             users.numel(), float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
+             _ptr(loss2, allow_none=True), _stream())
+
+    def lightgcn_step_grad(self, users, pos, neg, loss2, grad_out):
+        call("nrhip_lightgcn_step_grad", self.handle, self._idx(users), self._idx(pos),
+             self._idx(neg), users.numel(), _ptr(loss2, allow_none=True),
+             _ptr(grad_out, torch.float32), _stream())
+
+    def lightgcn_step_apply(self, grad, st):
+        call("nrhip_lightgcn_step_apply", self.handle, _ptr(grad, torch.float32),
+             float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps), _stream())
+
+    def mf_step(self, users, pos, neg, st, loss2):
+        call("nrhip_mf_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
+             users.numel(), float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
+             _ptr(loss2, torch.float32), _stream())
+
+
 def device_info():
     cu, clk, mem = C.c_int(0), C.c_int(0), C.c_size_t(0)
     name = C.create_string_buffer(128)

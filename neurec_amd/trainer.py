@@ -79,9 +79,16 @@ class MFEngine:
         self.adam = E.AdamState(lr)
         self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
+        self._ctx = E.NativeStep.for_mf(self)
 
     def step(self, users, pos, neg, loss_out):
-        """loss_out: 2-float device tensor receiving (bpr_sum, reg_term)."""
+        """One native call: fused gather/BPR/scatter kernel + the two TF-sparse Adam sweeps.
+        loss_out: 2-float device tensor receiving (bpr_sum, reg_term)."""
+        self._ctx.mf_step(users, pos, neg, self.adam, loss_out)
+        self.adam.advance()
+
+    def step_reference(self, users, pos, neg, loss_out):
+        """The same step as individual engine calls (what nrhip_mf_step enqueues)."""
         if users.numel() > self.max_batch:
             raise ValueError("batch larger than max_batch")
         E.bpr_mf_grad(self.P, self.Q, users, pos, neg, self.reg, self.GP, self.GQ, self.terms,
@@ -123,6 +130,7 @@ class LightGCNEngine:
         self.batch_rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
         self.row_flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
         self.Gsync = None                    # allocated on first multi-GPU step
+        self._ctx = E.NativeStep.for_lightgcn(self)
 
     # -- forward: Esum = sum_k A^k E0  (LightGCN.py:132-149) -------------------------
     def propagate(self):
@@ -146,9 +154,21 @@ class LightGCNEngine:
 
     # -- one training step = sess.run(self.opt) (LightGCN.py:178) ---------------------
     def step(self, users, pos, neg, loss_out=None, grad_sync=None):
-        """grad_sync(tensor): optional in-place all-reduce of dL/dE0 across ranks (parallel.py).
+        """One native call enqueues the whole step (csrc/step.hip); `step_reference` below is the
+        same launch sequence spelled out in Python.  grad_sync(tensor): optional in-place
+        all-reduce of dL/dE0 across ranks — the step is then cut at that one exchange point."""
+        if grad_sync is None:
+            self._ctx.lightgcn_step(users, pos, neg, self.adam, loss_out)
+        else:
+            if self.Gsync is None:
+                self.Gsync = torch.zeros_like(self.E0)
+            self._ctx.lightgcn_step_grad(users, pos, neg, loss_out, self.Gsync)
+            grad_sync(self.Gsync)                # summed over ranks (RCCL all-reduce)
+            self._ctx.lightgcn_step_apply(self.Gsync, self.adam)
+        self.adam.advance()
 
-        Same arithmetic as propagating everything, minus work whose result is never read or is
+    def step_reference(self, users, pos, neg, loss_out=None, grad_sync=None):
+        """Same arithmetic as propagating everything, minus work whose result is never read or is
         known to be zero: the loss only reads E* on the 3B batch rows, so the LAST forward hop is
         formed for those rows only; dL/dE* is non-zero on those rows only, so the FIRST backward
         hop skips every all-zero source row.  With L=3 that is 4 full SpMM passes instead of 6."""

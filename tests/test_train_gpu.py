@@ -259,3 +259,42 @@ def test_spmm_row_subset_and_masked_variants_equal_full_product(eng, d):
     gb = y_both.cpu().numpy()
     np.testing.assert_array_equal(gb[wanted == 1], y_full.cpu().numpy()[wanted == 1])
     assert np.all(gb[wanted == 0] == 5.0)
+
+
+def test_native_step_equals_python_launch_sequence(eng):
+    """csrc/step.hip only orders launches: it must leave the same state as the spelled-out
+    Python sequence (up to the atomics' summation order inside the scatter)."""
+    import torch
+    from neurec_amd.trainer import LightGCNEngine, MFEngine
+    from oracle import train
+    rng = np.random.RandomState(77)
+    U, I, d, L, B = 500, 400, 64, 3, 512
+    ur, ic = _graph(rng, U, I, 1, 30, hubs=2)
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    E0 = rng.uniform(-0.1, 0.1, (U + I, d)).astype(np.float32)
+    a, b = LightGCNEngine(A, U, I, E0, L, 0.01, 1e-3, B), LightGCNEngine(A, U, I, E0, L, 0.01, 1e-3, B)
+    la, lb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    for step in range(4):
+        bu, bp, bn = (_dev(rng.randint(0, n, B).astype(np.int32)) for n in (U, I, I))
+        a.step(bu, bp, bn, la)
+        b.step_reference(bu, bp, bn, lb)
+        assert abs(float(la[0]) - float(lb[0])) <= 1e-6 * abs(float(lb[0]))
+    assert np.abs(a.E0.cpu().numpy() - b.E0.cpu().numpy()).max() < 1e-5      # scatter atomics are unordered
+    assert a.adam.t == b.adam.t == 4
+    # multi-GPU form of the step with an identity "all-reduce" == the single call
+    c = LightGCNEngine(A, U, I, E0, L, 0.01, 1e-3, B)
+    rng2 = np.random.RandomState(78)
+    d2 = LightGCNEngine(A, U, I, E0, L, 0.01, 1e-3, B)
+    for step in range(3):
+        bu, bp, bn = (_dev(rng2.randint(0, n, B).astype(np.int32)) for n in (U, I, I))
+        c.step(bu, bp, bn, None, grad_sync=lambda t: t)
+        d2.step(bu, bp, bn, None)
+    assert np.abs(c.E0.cpu().numpy() - d2.E0.cpu().numpy()).max() < 1e-5
+    P = (rng.randn(U, 32) * 0.01).astype(np.float32); Q = (rng.randn(I, 32) * 0.01).astype(np.float32)
+    m1, m2 = MFEngine(P, Q, 0.001, 0.01, B), MFEngine(P, Q, 0.001, 0.01, B)
+    for step in range(3):
+        bu, bp, bn = (_dev(rng.randint(0, n, B).astype(np.int32)) for n in (U, I, I))
+        m1.step(bu, bp, bn, la)
+        m2.step_reference(bu, bp, bn, lb)
+    assert np.abs(m1.P.cpu().numpy() - m2.P.cpu().numpy()).max() < 1e-7
+    assert abs(float(la.sum()) - float(lb.sum())) <= 1e-6 * abs(float(lb.sum()))
