@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)     # conf/LightGCN.properties:5
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
-    ap.add_argument("--eval-batch", type=int, default=2048)
+    ap.add_argument("--eval-batch", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--no-eval", action="store_true")
