@@ -38,7 +38,7 @@ class Comm:
     def max_float(self, x):
         if not self.active:
             return float(x)
-        dev = "cuda" if self.backend == "nccl" else "cpu"
+        dev = "cuda" if (self.backend == "nccl" and torch.cuda.is_available()) else "cpu"
         t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -54,8 +54,11 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        backend = os.environ.get("NEUREC_DIST_BACKEND") or \
+            ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # one process per GPU; with fewer GPUs than ranks (tests: 2 ranks on one GPU over gloo)
+        # ranks share devices round-robin
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
