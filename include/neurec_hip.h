@@ -278,10 +278,40 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
                   int batch, float alpha, float beta1, float beta2, float eps, float* d_loss2,
                   void* stream);
 
+/* ---- NGCF propagation layer, dense half (second-model coverage) ---------------
+ * Replaces the per-layer TF ops of NGCF._create_ngcf_embed
+ * (model/general_recommender/NGCF.py:181-198) and their gradient; the sparse half
+ * (S = A·E, NGCF.py:174-179) is nrhip_spmm_csr.  Width d = 16 (conf/NGCF.properties).
+ *   fwd: T1 = S·Wg+bg, T2 = (E⊙S)·Wb+bb, Z = lrelu(T1)+lrelu(T2), E' = Z/keep·mask,
+ *        out = l2_normalize(E').  d_mask (n_rows*d bytes) is read when mask_given, else
+ *        drawn from (seed, step, layer) and written (the backward pass needs it).
+ *        d_out points at this layer's column block of the concatenated output, row
+ *        stride ldo (NGCF.py:200).
+ *   bwd: from dLoss/d out (d_dout, stride ldo) and dLoss/dE' coming from the next layer
+ *        (d_dego_next, may be NULL): d_dS (to be pushed through A^T), d_dego_direct
+ *        (= dBi ⊙ S), and the four weight gradients. */
+int nrhip_ngcf_workspace_bytes(int64_t n_rows, size_t* bytes);
+int nrhip_ngcf_layer_fwd(const float* d_ego, const float* d_S, const float* d_Wg,
+                         const float* d_bg, const float* d_Wb, const float* d_bb, int64_t n_rows,
+                         int d, float keep, uint8_t* d_mask, int mask_given, uint64_t seed,
+                         uint64_t step, int layer, float* d_ego_out, float* d_out, int64_t ldo,
+                         void* stream);
+int nrhip_ngcf_layer_bwd(const float* d_ego, const float* d_S, const float* d_Wg,
+                         const float* d_bg, const float* d_Wb, const float* d_bb, int64_t n_rows,
+                         int d, float keep, const uint8_t* d_mask, const float* d_dout, int64_t ldo,
+                         const float* d_dego_next, float* d_dS, float* d_dego_direct, float* d_dT1,
+                         float* d_dT2, float* d_dWg, float* d_dbg, float* d_dWb, float* d_dbb,
+                         void* d_ws, size_t ws_bytes, void* stream);
+
 /* y = a*x (+ y0)  elementwise helpers used between propagation passes. */
 int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream);
 int nrhip_add(const float* d_x, const float* d_y, float* d_out, int64_t n, void* stream);
 int nrhip_div_scalar(const float* d_x, float denom, float* d_y, int64_t n, void* stream);
+/* the same on row-strided [rows][cols] views (column blocks of a wider matrix) */
+int nrhip_add2d(const float* d_x, int64_t ldx, const float* d_y, int64_t ldy, float* d_out,
+                int64_t ldo, int64_t rows, int cols, void* stream);
+int nrhip_copy2d(const float* d_x, int64_t ldx, float* d_out, int64_t ldo, int64_t rows, int cols,
+                 void* stream);
 
 #ifdef __cplusplus
 }

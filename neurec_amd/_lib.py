@@ -93,9 +93,15 @@ SIGNATURES = {
     "nrhip_mf_ctx_create": [C.POINTER(MFBuffers), C.POINTER(p)],
     "nrhip_mf_ctx_destroy": [p],
     "nrhip_mf_step": [p, p, p, p, i32, f32, f32, f32, f32, p, p],
+    "nrhip_ngcf_workspace_bytes": [i64, psz],
+    "nrhip_ngcf_layer_fwd": [p, p, p, p, p, p, i64, i32, f32, p, i32, u64, u64, i32, p, p, i64, p],
+    "nrhip_ngcf_layer_bwd": [p, p, p, p, p, p, i64, i32, f32, p, p, i64, p, p, p, p, p, p, p, p, p,
+                             p, sz, p],
     "nrhip_scale": [p, f32, p, i64, p],
     "nrhip_add": [p, p, p, i64, p],
     "nrhip_div_scalar": [p, f32, p, i64, p],
+    "nrhip_add2d": [p, i64, p, i64, p, i64, i64, i32, p],
+    "nrhip_copy2d": [p, i64, p, i64, i64, i32, p],
 }
 
 for _name, _args in SIGNATURES.items():

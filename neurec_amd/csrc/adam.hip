@@ -127,6 +127,31 @@ __global__ __launch_bounds__(256) void ewise_kernel(const float* __restrict__ x,
   }
 }
 
+// out[r][c] = x[r][c] + y[r][c] on row-strided views (column blocks of wider matrices)
+__global__ __launch_bounds__(256) void add2d_kernel(const float* __restrict__ x, int64_t ldx,
+                                                    const float* __restrict__ y, int64_t ldy,
+                                                    float* __restrict__ out, int64_t ldo,
+                                                    int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    out[r * ldo + c] = __fadd_rn(x[r * ldx + c], y[r * ldy + c]);
+  }
+}
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     float* __restrict__ out, int64_t ldo,
+                                                     int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    out[r * ldo + c] = x[r * ldx + c];
+  }
+}
+
 inline unsigned sweep_blocks(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;   // 256 CUs x 16 resident blocks, grid-stride beyond
@@ -232,6 +257,29 @@ int nrhip_rows_clear(const int32_t* d_rows, int n_listed, int d, float* d_b0, fl
   if (n_listed == 0) return NR_OK;
   hipLaunchKernelGGL(rows_clear_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
                      (hipStream_t)stream, d_rows, n_listed, d, d_b0, d_b1, d_b2, d_b3, d_flag);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_add2d(const float* d_x, int64_t ldx, const float* d_y, int64_t ldy, float* d_out,
+                int64_t ldo, int64_t rows, int cols, void* stream) {
+  NR_REQUIRE(d_x && d_y && d_out && rows >= 0 && cols >= 1 && ldx >= cols && ldy >= cols &&
+                 ldo >= cols,
+             NR_ERR_ARG, "add2d: bad arguments");
+  if (rows == 0) return NR_OK;
+  hipLaunchKernelGGL(add2d_kernel, dim3(sweep_blocks(rows * cols)), dim3(256), 0,
+                     (hipStream_t)stream, d_x, ldx, d_y, ldy, d_out, ldo, rows, cols);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_copy2d(const float* d_x, int64_t ldx, float* d_out, int64_t ldo, int64_t rows, int cols,
+                 void* stream) {
+  NR_REQUIRE(d_x && d_out && rows >= 0 && cols >= 1 && ldx >= cols && ldo >= cols, NR_ERR_ARG,
+             "copy2d: bad arguments");
+  if (rows == 0) return NR_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(sweep_blocks(rows * cols)), dim3(256), 0,
+                     (hipStream_t)stream, d_x, ldx, d_out, ldo, rows, cols);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -22,6 +22,12 @@ MODELS = {
     "LightGCN": [("lr", "0.01"), ("reg", "1e-3"), ("embed_size", "64"), ("n_layers", "6"),
                  ("batch_size", "1024"), ("epochs", "500"), ("n_fold", "100"),
                  ("adj_type", "pre")],
+    "NGCF": [("epochs", "500"), ("batch_size", "512"), ("embedding_size", "16"),
+             ("layer_size", "[16,16]"), ("learning_rate", "0.001"), ("node_dropout_flag", "False"),
+             ("adj_type", "norm"), ("alg_type", "ngcf"), ("loss_function", "BPR"),
+             ("learner", "adam"), ("reg", "0.0"), ("node_dropout_ratio", "0.1"),
+             ("mess_dropout_ratio", "0.1"), ("embed_init_method", "xavier_normal"),
+             ("weight_init_method", "xavier_normal"), ("stddev", "0.01"), ("verbose", "1")],
 }
 
 

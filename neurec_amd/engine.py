@@ -402,6 +402,40 @@ class SpmmCSR:
         return self.nnz * 8 + (self.n_rows + 1) * 4 + 2 * self.n_rows * d * 4
 
 
+def add2d(x, y, out):
+    """out = x + y on 2-D views with unit inner stride (column blocks allowed)."""
+    call("nrhip_add2d", C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(y.data_ptr()), y.stride(0),
+         C.c_void_p(out.data_ptr()), out.stride(0), x.shape[0], x.shape[1], _stream())
+
+
+def copy2d(x, out):
+    call("nrhip_copy2d", C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(out.data_ptr()),
+         out.stride(0), x.shape[0], x.shape[1], _stream())
+
+
+def ngcf_layer_fwd(ego, S, W, keep, mask, mask_given, seed, step, layer, ego_out, out_block):
+    """W = (W_gc, b_gc, W_bi, b_bi); out_block: this layer's column block of the concat output."""
+    call("nrhip_ngcf_layer_fwd", _ptr(ego, torch.float32), _ptr(S, torch.float32), _ptr(W[0]),
+         _ptr(W[1]), _ptr(W[2]), _ptr(W[3]), ego.shape[0], ego.shape[1], float(keep),
+         _ptr(mask, torch.uint8), 1 if mask_given else 0, C.c_uint64(seed & (2**64 - 1)),
+         C.c_uint64(step), int(layer), _ptr(ego_out, torch.float32),
+         C.c_void_p(out_block.data_ptr()), out_block.stride(0), _stream())
+
+
+def ngcf_layer_bwd(ego, S, W, keep, mask, dout_block, dego_next, dS, dego_direct, dT1, dT2, dW, ws):
+    call("nrhip_ngcf_layer_bwd", _ptr(ego, torch.float32), _ptr(S, torch.float32), _ptr(W[0]),
+         _ptr(W[1]), _ptr(W[2]), _ptr(W[3]), ego.shape[0], ego.shape[1], float(keep),
+         _ptr(mask, torch.uint8), C.c_void_p(dout_block.data_ptr()), dout_block.stride(0),
+         _ptr(dego_next, allow_none=True), _ptr(dS), _ptr(dego_direct), _ptr(dT1), _ptr(dT2),
+         _ptr(dW[0]), _ptr(dW[1]), _ptr(dW[2]), _ptr(dW[3]), _ptr(ws), ws.numel(), _stream())
+
+
+def ngcf_workspace(n_rows, device):
+    nbytes = C.c_size_t(0)
+    call("nrhip_ngcf_workspace_bytes", int(n_rows), C.byref(nbytes))
+    return torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+
+
 class NativeStep:
     """Context of the native step drivers (csrc/step.hip): a record of device pointers owned by
     the Python engine object, which must outlive it."""

@@ -83,3 +83,35 @@ def transpose_csr(a):
 
 def is_symmetric(a):
     return (a != a.T).nnz == 0
+
+
+def ngcf_adjacency(train_matrix, adj_type="norm"):
+    """NGCF.get_adj_mat (NGCF.py:299-318).  Unlike LightGCN, the bipartite block carries the
+    *values* of the train matrix (`self.graph = dataset.train_matrix.toarray()`, NGCF.py:40), and
+    the default `norm` type is the row-normalised D^-1 (A + I) — not symmetric, so the backward
+    pass needs the transpose.  Built sparsely (the reference densifies U×I, ≈9.8 GB at gowalla)."""
+    r = sp.csr_matrix(train_matrix, dtype=np.float32)
+    r.sum_duplicates()
+    n = r.shape[0] + r.shape[1]
+    a = sp.bmat([[None, r], [r.T.tocsr(), None]], format="csr", dtype=np.float32)
+    a.sort_indices()
+
+    def row_normalised(m):                         # d_inv follows m's dtype (fp64 once eye is added)
+        deg = np.asarray(m.sum(1)).ravel()
+        dinv = _inv_power(deg, -1)
+        rows = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+        return sp.csr_matrix((dinv[rows] * m.data, m.indices.copy(), m.indptr.copy()), shape=m.shape)
+
+    if adj_type == "plain":
+        out = a
+    elif adj_type == "norm":
+        ai = (a.astype(np.float64) + sp.eye(n, dtype=np.float64)).tocsr()
+        ai.sort_indices()
+        out = row_normalised(ai)
+    elif adj_type == "gcmc":
+        out = row_normalised(a)
+    else:
+        out = (row_normalised(a).astype(np.float64) + sp.eye(n, dtype=np.float64)).tocsr()
+    out = out.tocsr().astype(np.float32)
+    out.sort_indices()
+    return out

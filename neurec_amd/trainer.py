@@ -257,3 +257,98 @@ class FullRankEvaluator:
         if exact_mean:
             return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
         return (E.colsum(per_user) / n).cpu().numpy()
+
+
+class NGCFEngine:
+    """NGCF (alg_type=ngcf) on one GPU: ego embeddings E0 [N][d], per-layer weights
+    (W_gc, b_gc, W_bi, b_bi), the (row-normalised, non-symmetric) adjacency and its transpose.
+    A step = L sparse hops + L fused dense layers forward, the BPR head on the concatenated
+    output, the same backwards, dense TF-Adam on E0 and on every weight
+    (model/general_recommender/NGCF.py:91-110,160-202)."""
+
+    def __init__(self, adj, adj_t, n_users, n_items, embed, weights, lr, reg, mess_dropout,
+                 max_batch, seed=2017):
+        dev = E.require_gpu()
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.N = self.n_users + self.n_items
+        self.A = E.SpmmCSR.from_scipy(adj)
+        self.At = E.SpmmCSR.from_scipy(adj_t)
+        f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
+        self.E0 = f(embed)
+        self.d = self.E0.shape[1]
+        self.L = len(weights)
+        self.W = [tuple(f(np.reshape(w, -1) if w.ndim == 2 and w.shape[0] == 1 else w) for w in ws)
+                  for ws in weights]
+        for ws in self.W:
+            assert ws[0].shape == (self.d, self.d), "layer width must equal the embedding size (16)"
+        self.dsum = self.d * (self.L + 1)
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        self.Out, self.dOut = z(self.N, self.dsum), z(self.N, self.dsum)
+        self.S = [z(self.N, self.d) for _ in range(self.L)]
+        self.ego = [self.E0] + [z(self.N, self.d) for _ in range(self.L)]
+        self.mask = [torch.zeros(self.N, self.d, dtype=torch.uint8, device=dev) for _ in range(self.L)]
+        self.dS, self.dEd, self.dT1, self.dT2 = (z(self.N, self.d) for _ in range(4))
+        self.dEgo = [z(self.N, self.d), z(self.N, self.d)]
+        self.gE0 = z(self.N, self.d)
+        self.mE, self.vE = z(self.N, self.d), z(self.N, self.d)
+        self.gW = [tuple(torch.zeros_like(w) for w in ws) for ws in self.W]
+        self.mW = [tuple(torch.zeros_like(w) for w in ws) for ws in self.W]
+        self.vW = [tuple(torch.zeros_like(w) for w in ws) for ws in self.W]
+        self.keep = 1.0 - float(mess_dropout)
+        self.reg, self.seed, self.t = float(reg), int(seed), 0
+        self.adam = E.AdamState(lr)
+        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
+        self.flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.ws = E.ngcf_workspace(self.N, dev)
+        self.max_batch = max_batch
+
+    def forward(self, masks=None):
+        """Fills self.Out = concat(E0, out_1..out_L).  masks: optional list of uint8 [N][d] device
+        tensors (tests); otherwise a fresh dropout draw per call — evaluation included, as in the
+        reference (NGCF.py:193 has no training flag)."""
+        d = self.d
+        E.copy2d(self.E0, self.Out[:, :d])
+        for k in range(self.L):
+            self.A.matmul(self.ego[k], out=self.S[k])
+            if masks is not None:
+                self.mask[k].copy_(masks[k])
+            E.ngcf_layer_fwd(self.ego[k], self.S[k], self.W[k], self.keep, self.mask[k],
+                             masks is not None, self.seed, self.t, k, self.ego[k + 1],
+                             self.Out[:, (k + 1) * d:(k + 2) * d])
+        self.t += 1
+        return self.Out
+
+    def final_embeddings(self):
+        out = self.forward()
+        return out[:self.n_users], out[self.n_users:]
+
+    def step(self, users, pos, neg, loss_out, masks=None):
+        B, d = users.numel(), self.d
+        if B > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        self.forward(masks)
+        U = self.n_users
+        rows = self.rows[:3 * B]
+        E.lightgcn_mark_batch(users, pos, neg, U, rows, self.flag)
+        # the BPR head of NGCF.py:91-100 is the MF head on the rows of the concatenated output
+        E.bpr_mf_grad(self.Out[:U], self.Out[U:], users, pos, neg, self.reg, self.dOut[:U],
+                      self.dOut[U:], self.terms, loss_out)
+        dego = None
+        for k in range(self.L - 1, -1, -1):
+            E.ngcf_layer_bwd(self.ego[k], self.S[k], self.W[k], self.keep, self.mask[k],
+                             self.dOut[:, (k + 1) * d:(k + 2) * d], dego, self.dS, self.dEd,
+                             self.dT1, self.dT2, self.gW[k], self.ws)
+            nxt = self.dEgo[k % 2]
+            self.At.matmul(self.dS, out=nxt, addend=self.dEd)     # dE_k = dBi⊙S + A^T dS
+            dego = nxt
+        if dego is None:
+            E.copy2d(self.dOut[:, :d], self.gE0)
+        else:
+            E.add2d(self.dOut[:, :d], dego, self.gE0)
+        E.adam_dense(self.E0, self.mE, self.vE, self.gE0, self.adam, clear_grad=False)
+        for k in range(self.L):
+            for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k]):
+                E.adam_dense(w, m, v, g, self.adam, clear_grad=False)
+        E.rows_clear(rows, self.dsum, (self.dOut,), self.flag)
+        self.adam.advance()

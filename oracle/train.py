@@ -211,3 +211,95 @@ def generate_positive_items(user_pos_dict):
         users_list.extend([user] * len(pos_items))
         pos_items_list.extend(pos_items)
     return user_pos_len, users_list, pos_items_list
+
+
+# ------------------------------------------------------------------ NGCF (alg_type=ngcf)
+def ngcf_adjacency(train_matrix, adj_type="norm"):
+    """NGCF.get_adj_mat (NGCF.py:299-318): A carries the *rating values* of the train matrix
+    (`self.graph = dataset.train_matrix.toarray()`, NGCF.py:40); `norm` = D^-1 (A + I),
+    computed in fp64 because sp.eye is fp64, rounded to fp32 when handed to TF."""
+    R = sp.csr_matrix(train_matrix, dtype=np.float32)
+    U, I = R.shape
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+
+    def single(a):
+        rowsum = np.array(a.sum(1))
+        with np.errstate(divide="ignore"):
+            d_inv = np.power(rowsum, -1).flatten()
+        d_inv[np.isinf(d_inv)] = 0.0
+        return sp.diags(d_inv).dot(a).tocoo()
+
+    if adj_type == "plain":
+        out = A
+    elif adj_type == "norm":
+        out = single(A + sp.eye(A.shape[0]))
+    elif adj_type == "gcmc":
+        out = single(A)
+    else:
+        out = single(A) + sp.eye(A.shape[0])
+    out = out.tocsr().astype(np.float32)
+    out.sort_indices()
+    return out
+
+
+def _leaky(x, alpha=0.2):
+    return np.where(x > 0, x, x * x.dtype.type(alpha))
+
+
+def ngcf_forward(A, E0, weights, masks, keep):
+    """_create_ngcf_embed (NGCF.py:160-202).  weights: list of (W_gc, b_gc, W_bi, b_bi) per layer;
+    masks: list of {0,1} arrays [N, d_out] (the dropout draw is an input, TF's Philox stream is
+    not reproducible); keep = 1 - mess_dropout_ratio.  Returns (concat output, cache)."""
+    dt = E0.dtype.type
+    ego = E0
+    outs, cache = [E0], []
+    for (Wg, bg, Wb, bb), mask in zip(weights, masks):
+        S = spmm_rowwise(A, ego)
+        T1 = S @ Wg + bg
+        Bi = ego * S
+        T2 = Bi @ Wb + bb
+        Z = _leaky(T1) + _leaky(T2)
+        Zd = (Z / dt(keep)) * mask.astype(E0.dtype)          # tf.nn.dropout: x / keep_prob * mask
+        ss = np.sum(Zd * Zd, axis=1, keepdims=True, dtype=dt)
+        inv = dt(1) / np.sqrt(np.maximum(ss, dt(1e-12)))      # tf.nn.l2_normalize
+        norm = Zd * inv
+        cache.append((ego, S, T1, T2, Bi, Zd, ss, inv, norm, mask))
+        outs.append(norm)
+        ego = Zd
+    return np.concatenate(outs, axis=1).astype(E0.dtype), cache
+
+
+def ngcf_loss_and_grads(A, At, E0, weights, masks, keep, n_users, users, pos, neg, reg):
+    """Loss (NGCF.py:91-110) and gradients w.r.t. E0 and every layer weight."""
+    dt = E0.dtype.type
+    out, cache = ngcf_forward(A, E0, weights, masks, keep)
+    iu, ii, ij = np.asarray(users), n_users + np.asarray(pos), n_users + np.asarray(neg)
+    eu, ei, ej = out[iu], out[ii], out[ij]
+    x = np.sum(eu * ei, axis=1, dtype=dt) - np.sum(eu * ej, axis=1, dtype=dt)
+    lb, g = bpr_terms(x)
+    l2 = (np.sum(eu * eu, dtype=dt) + np.sum(ei * ei, dtype=dt) + np.sum(ej * ej, dtype=dt)) / dt(2)
+    loss = np.sum(lb, dtype=dt) + dt(reg) * l2
+    dOut = np.zeros_like(out)
+    np.add.at(dOut, iu, g[:, None] * (ei - ej) + dt(reg) * eu)
+    np.add.at(dOut, ii, g[:, None] * eu + dt(reg) * ei)
+    np.add.at(dOut, ij, -g[:, None] * eu + dt(reg) * ej)
+    d0 = E0.shape[1]
+    widths = [w[0].shape[1] for w in weights]
+    offs = np.cumsum([d0] + widths)
+    dEgo = np.zeros((E0.shape[0], widths[-1]), E0.dtype) if weights else None
+    wgrads = [None] * len(weights)
+    for k in range(len(weights) - 1, -1, -1):
+        ego, S, T1, T2, Bi, Zd, ss, inv, norm, mask = cache[k]
+        Wg, bg, Wb, bb = weights[k]
+        dNorm = dOut[:, offs[k]:offs[k + 1]]
+        dot = np.sum(dNorm * norm, axis=1, keepdims=True, dtype=dt)
+        dZd = np.where(ss > dt(1e-12), (dNorm - norm * dot) * inv, dNorm * inv) + dEgo
+        dZ = dZd * mask.astype(E0.dtype) / dt(keep)
+        dT1 = dZ * np.where(T1 > 0, dt(1), dt(0.2))
+        dT2 = dZ * np.where(T2 > 0, dt(1), dt(0.2))
+        wgrads[k] = (S.T @ dT1, dT1.sum(0, keepdims=True), Bi.T @ dT2, dT2.sum(0, keepdims=True))
+        dBi = dT2 @ Wb.T
+        dS = dT1 @ Wg.T + dBi * ego
+        dEgo = dBi * S + spmm_rowwise(At, dS.astype(E0.dtype))
+    dE0 = dOut[:, :d0] + (dEgo if weights else 0)
+    return loss, dE0.astype(E0.dtype), wgrads

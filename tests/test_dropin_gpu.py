@@ -132,3 +132,19 @@ def test_candidate_negative_mode_and_groups(tmp_path):
     res = native.eval_matrix(S, truth, uni.metrics, uni.max_top)
     want = np.mean(res, axis=0).reshape(5, 5)[:, 4]
     assert [x.strip() for x in line] == ["%.8f" % x for x in want]
+
+
+def test_ngcf_config_drops_in(tmp_path):
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=NGCF", "--epochs=8", "--batch_size=128",
+                            "--learning_rate=0.01", "--verbose=4", "--mess_dropout_ratio=0.0"])
+    text = _log_text(tmp_path, "NGCF")
+    assert "use the normalized adjacency matrix" in text and "using xavier initialization" in text
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 8 and float(iters[-1][1]) < float(iters[0][1])
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == [4, 8]
+    # with dropout off the evaluation forward is deterministic: the logged line is reproducible
+    assert evals[-1][1] == _oracle_line(model, model.evaluator)
+    assert model.get_eval_factors()[0].shape[1] == 48                        # concat of 3 blocks of 16
