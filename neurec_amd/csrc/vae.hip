@@ -1,0 +1,477 @@
+// vae.hip — Mult-VAE encoder/decoder kernels (second-model coverage, config 5).
+//
+// Stands in for the TF graph of model/general_recommender/MultiVAE.py:73-135:
+//   q-network  h0 = dropout(l2_normalize(x));  h1 = act(h0·W_q0 + b);  [mu | logvar] = h1·W_q1 + b
+//   sample     z = mu + is_training · eps · exp(logvar/2),  eps ~ N(0, 0.01²)
+//   p-network  g1 = act(z·W_p0 + b);  logits = g1·W_p1 + b;  log_softmax
+//   loss       -mean_b Σ_i logsm·x  +  anneal · mean_b KL_b  (+ 2·reg-term, MultiVAE.py:126-135)
+// and for its gradient.  Sizes at the configured p_dim=[16,32]: hidden h = 32, latent z = 16,
+// batch B = 512, I = 40,981 items (gowalla).
+//
+// What is a GEMM and what is not.  x is a multi-hot user row, so h0·W_q0 is NOT a dense
+// [B,I]×[I,32] product: it is a bag-sum of ~27 rows of W_q0 per user (one wave per user row,
+// straight from the train CSR, no dense [B,I] input is ever built — the reference fills 84 MB
+// of it on the host per batch, MultiVAE.py:152-165).  The only dense product with a large
+// dimension on both sides is logits = g1·W_p1ᵀ ([B,32]×[32,I]): that one runs on the fp32
+// matrix cores through nrhip_score_gemm (W_p1 is stored item-major, [I][32]).  Its two
+// gradients stream the [B,I] dlogits slab once each: dW_p1 (thread per item, g1 staged in LDS)
+// and dg1 (two user rows per block against coalesced W_p1 rows).  The 16/32-wide middle
+// layers are register-resident per-row math, as in dense.hip.
+#include "nr_common.h"
+
+namespace {
+
+constexpr int kMaxD = 32;       // hidden / 2*latent widths up to 32
+
+enum { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_RELU = 2, ACT_IDENTITY = 3 };
+
+__device__ __forceinline__ float act_fwd(int a, float x) {
+  if (a == ACT_TANH) return tanhf(x);
+  if (a == ACT_SIGMOID) return 1.0f / (1.0f + expf(-x));
+  if (a == ACT_RELU) return fmaxf(x, 0.f);
+  return x;
+}
+// derivative w.r.t. the pre-activation, from the output y
+__device__ __forceinline__ float act_bwd(int a, float y) {
+  if (a == ACT_TANH) return 1.0f - y * y;
+  if (a == ACT_SIGMOID) return y * (1.0f - y);
+  if (a == ACT_RELU) return y > 0.f ? 1.0f : 0.f;
+  return 1.0f;
+}
+
+__device__ __forceinline__ float uniform01(uint64_t h) {
+  return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// ----------------------------------------------------------------------------
+// Encoder + sampling + first decoder layer: one wave per batch row.
+// Row r of the batch is the item list indices[indptr[rows[r]] .. indptr[rows[r]+1]).
+// Lane j < h owns hidden column j.  Saves what the backward pass needs.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_encode_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const int32_t* __restrict__ rows, int batch, int h, int z, const float* __restrict__ Wq0,
+    const float* __restrict__ bq0, const float* __restrict__ Wq1, const float* __restrict__ bq1,
+    const float* __restrict__ Wp0, const float* __restrict__ bp0, int act, float keep,
+    const float* __restrict__ drop_given /* per CSR position, {0,1}, or NULL */,
+    const float* __restrict__ eps_given /* [batch][z] or NULL */, float is_training, uint64_t seed,
+    uint64_t step, float* __restrict__ h0val /* per CSR position */, float* __restrict__ H1,
+    float* __restrict__ MU, float* __restrict__ LOGVAR, float* __restrict__ EPSSTD,
+    float* __restrict__ ZS, float* __restrict__ G1, float* __restrict__ KLb) {
+  __shared__ float s_vec[4][kMaxD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= batch) return;
+  const int64_t u = rows[r];
+  const int64_t b = indptr[u], e = indptr[u + 1];
+  const int n = (int)(e - b);
+  // l2_normalize of a 0/1 row: every non-zero becomes 1/sqrt(max(n, 1e-12))
+  const float inv = 1.0f / sqrtf(fmaxf((float)n, 1e-12f));
+  float a1 = 0.f;
+  for (int64_t t = b; t < e; ++t) {
+    float kp;
+    if (drop_given) kp = drop_given[t];
+    else kp = (keep >= 1.0f || uniform01(nr::splitmix64(nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull)) ^ (uint64_t)t)) < keep) ? 1.f : 0.f;
+    const float val = (inv / keep) * kp;                  // x/keep_prob * mask (tf.nn.dropout)
+    if (lane == 0 && h0val) h0val[t] = val;
+    if (lane < h) a1 = fmaf(val, Wq0[(int64_t)indices[t] * h + lane], a1);
+  }
+  float h1 = 0.f;
+  if (lane < h) { h1 = act_fwd(act, a1 + bq0[lane]); H1[(int64_t)r * h + lane] = h1; }
+  float* sv = s_vec[wave];
+  if (lane < h) sv[lane] = h1;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // h2 = h1·W_q1 + b_q1   (2z columns)
+  float h2 = 0.f;
+  if (lane < 2 * z) {
+    h2 = bq1[lane];
+    for (int k = 0; k < h; ++k) h2 = fmaf(sv[k], Wq1[k * 2 * z + lane], h2);
+  }
+  // lanes [0,z): mu ; lanes [z,2z): logvar
+  const float logvar = __shfl(h2, lane + z, 64);          // valid for lane < z
+  float zs = 0.f, klt = 0.f;
+  if (lane < z) {
+    const float mu = h2;
+    const float sd = expf(0.5f * logvar);
+    float eps;
+    if (eps_given) eps = eps_given[(int64_t)r * z + lane];
+    else {                                                // Box-Muller, N(0, 0.01²)
+      const uint64_t k0 = nr::splitmix64(nr::splitmix64(seed ^ 0xabcdull ^ (step << 20)) ^ ((uint64_t)r * z + lane));
+      const float u1 = uniform01(k0), u2 = uniform01(nr::splitmix64(k0));
+      eps = 0.01f * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    }
+    const float es = eps * sd;
+    zs = mu + is_training * es;
+    MU[(int64_t)r * z + lane] = mu;
+    LOGVAR[(int64_t)r * z + lane] = logvar;
+    EPSSTD[(int64_t)r * z + lane] = es;
+    ZS[(int64_t)r * z + lane] = zs;
+    klt = 0.5f * (-logvar + expf(logvar) + mu * mu - 1.0f);
+  }
+  klt = nr_wave_sum_f32(klt);
+  if (lane == 0) KLb[r] = klt;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < z) sv[lane] = zs;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < h) {
+    float a3 = bp0[lane];
+    for (int k = 0; k < z; ++k) a3 = fmaf(sv[k], Wp0[k * h + lane], a3);
+    G1[(int64_t)r * h + lane] = act_fwd(act, a3);
+  }
+}
+
+// logits[b][i] += bias[i]  (in place; the GEMM produced g1·W_p1ᵀ)
+__global__ __launch_bounds__(256) void add_row_bias_kernel(float* __restrict__ S, int64_t ld,
+                                                           int batch, int cols,
+                                                           const float* __restrict__ bias) {
+  const int64_t n = (int64_t)batch * cols;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    S[r * ld + c] += bias[c];
+  }
+}
+
+// ----------------------------------------------------------------------------
+// log-softmax + multinomial likelihood + dlogits, one block per batch row, in place:
+//   S[b][i] <- (softmax_i · n_b − x_bi) / B ;  nll[b] = −Σ_{i∈x_b} (l_i − lse)
+// (l_i = S[b][i] + bias[i]).  x_b is kept as a bitmap in LDS.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_softmax_grad_kernel(
+    float* __restrict__ S, int64_t ld, int cols, const float* __restrict__ bias,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const int32_t* __restrict__ rows, float inv_batch, float* __restrict__ nll,
+    uint32_t* __restrict__ bitmap_ws, int bitmap_words) {
+  __shared__ float s_red[256];
+  __shared__ float s_lse;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  float* srow = S + (int64_t)r * ld;
+  const int64_t u = rows[r];
+  const int64_t b = indptr[u], e = indptr[u + 1];
+  uint32_t* bm = bitmap_ws + (int64_t)r * bitmap_words;
+  for (int w = tid; w < bitmap_words; w += 256) bm[w] = 0u;
+  __syncthreads();
+  for (int64_t t = b + tid; t < e; t += 256) atomicOr(&bm[indices[t] >> 5], 1u << (indices[t] & 31));
+  float mx = -INFINITY;
+  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, srow[i] + bias[i]);
+  s_red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] = fmaxf(s_red[tid], s_red[tid + s]); __syncthreads(); }
+  mx = s_red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = tid; i < cols; i += 256) sum += expf(srow[i] + bias[i] - mx);
+  s_red[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  if (tid == 0) s_lse = mx + logf(s_red[0]);
+  __syncthreads();
+  const float lse = s_lse;
+  const float nb = (float)(e - b);
+  float ll = 0.f;
+  for (int i = tid; i < cols; i += 256) {
+    const float l = srow[i] + bias[i] - lse;                 // log-softmax
+    const bool x = (bm[i >> 5] >> (i & 31)) & 1u;
+    if (x) ll += l;
+    srow[i] = (expf(l) * nb - (x ? 1.f : 0.f)) * inv_batch;
+  }
+  s_red[tid] = ll;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  if (tid == 0) nll[r] = -s_red[0];
+}
+
+// ----------------------------------------------------------------------------
+// dW_p1[i][:] = Σ_b dlogits[b][i]·g1[b][:],  db_p1[i] = Σ_b dlogits[b][i].
+// Thread per item i (coalesced across i for every b), g1 staged in LDS.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__ dlogits,
+                                                       int64_t ld, int batch, int cols, int h,
+                                                       const float* __restrict__ G1,
+                                                       float* __restrict__ dWp1,
+                                                       float* __restrict__ dbp1) {
+  extern __shared__ __attribute__((aligned(16))) float s_g1[];    // [batch][h]
+  for (int i = threadIdx.x; i < batch * h; i += 256) s_g1[i] = G1[i];
+  __syncthreads();
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= cols) return;
+  float acc[kMaxD];
+#pragma unroll
+  for (int j = 0; j < kMaxD; ++j) acc[j] = 0.f;
+  float bsum = 0.f;
+  for (int b = 0; b < batch; ++b) {
+    const float g = dlogits[(int64_t)b * ld + item];
+    bsum += g;
+    const float* gr = s_g1 + b * h;
+#pragma unroll
+    for (int j = 0; j < kMaxD; ++j)
+      if (j < h) acc[j] = fmaf(g, gr[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxD; ++j)
+    if (j < h) dWp1[(int64_t)item * h + j] = acc[j];
+  dbp1[item] = bsum;
+}
+
+// dg1[b][:] = Σ_i dlogits[b][i]·W_p1[i][:]  — two batch rows per block
+__global__ __launch_bounds__(256) void vae_dg1_kernel(const float* __restrict__ dlogits, int64_t ld,
+                                                      int batch, int cols, int h,
+                                                      const float* __restrict__ Wp1,
+                                                      float* __restrict__ dG1) {
+  __shared__ float s_red[2][kMaxD][4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = blockIdx.x * 2, r1 = min(r0 + 1, batch - 1);
+  float a0[kMaxD], a1[kMaxD];
+#pragma unroll
+  for (int j = 0; j < kMaxD; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  for (int i = tid; i < cols; i += 256) {
+    const float g0 = dlogits[(int64_t)r0 * ld + i], g1 = dlogits[(int64_t)r1 * ld + i];
+    const float* w = Wp1 + (int64_t)i * h;
+#pragma unroll
+    for (int j = 0; j < kMaxD; ++j)
+      if (j < h) { const float ww = w[j]; a0[j] = fmaf(g0, ww, a0[j]); a1[j] = fmaf(g1, ww, a1[j]); }
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxD; ++j) {
+    if (j < h) {
+      const float s0 = nr_wave_sum_f32(a0[j]), s1 = nr_wave_sum_f32(a1[j]);
+      if (lane == 0) { s_red[0][j][wave] = s0; s_red[1][j][wave] = s1; }
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * h) {
+    const int which = tid / h, j = tid % h;
+    const int r = which == 0 ? r0 : r0 + 1;
+    if (r < batch)
+      dG1[(int64_t)r * h + j] = ((s_red[which][j][0] + s_red[which][j][1]) + s_red[which][j][2]) +
+                                s_red[which][j][3];
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Middle of the backward pass, one wave per batch row:
+//   da3 = dg1·act'(g1);  dz = da3·W_p0ᵀ;  dmu = dz + anneal·mu/B;
+//   dlogvar = dz·(eps·std)/2 + anneal·(exp(logvar)−1)/(2B);  dh2 = [dmu | dlogvar];
+//   da1 = (dh2·W_q1ᵀ)·act'(h1)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_mid_bwd_kernel(
+    int batch, int h, int z, int act, float anneal, float inv_batch, const float* __restrict__ dG1,
+    const float* __restrict__ G1, const float* __restrict__ H1, const float* __restrict__ MU,
+    const float* __restrict__ LOGVAR, const float* __restrict__ EPSSTD,
+    const float* __restrict__ Wp0, const float* __restrict__ Wq1, float* __restrict__ DA3,
+    float* __restrict__ DH2, float* __restrict__ DA1) {
+  __shared__ float s_vec[4][kMaxD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= batch) return;
+  float* sv = s_vec[wave];
+  float da3 = 0.f;
+  if (lane < h) {
+    da3 = dG1[(int64_t)r * h + lane] * act_bwd(act, G1[(int64_t)r * h + lane]);
+    DA3[(int64_t)r * h + lane] = da3;
+    sv[lane] = da3;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float dh2 = 0.f;
+  if (lane < 2 * z) {
+    const int k = lane < z ? lane : lane - z;
+    float dz = 0.f;
+    for (int j = 0; j < h; ++j) dz = fmaf(sv[j], Wp0[k * h + j], dz);       // da3·W_p0ᵀ
+    if (lane < z) {
+      dh2 = dz + anneal * MU[(int64_t)r * z + k] * inv_batch;
+    } else {
+      dh2 = dz * EPSSTD[(int64_t)r * z + k] * 0.5f +
+            anneal * 0.5f * (expf(LOGVAR[(int64_t)r * z + k]) - 1.0f) * inv_batch;
+    }
+    DH2[(int64_t)r * 2 * z + lane] = dh2;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 2 * z) sv[lane] = dh2;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < h) {
+    float acc = 0.f;
+    for (int j = 0; j < 2 * z; ++j) acc = fmaf(sv[j], Wq1[lane * 2 * z + j], acc);   // dh2·W_q1ᵀ
+    DA1[(int64_t)r * h + lane] = acc * act_bwd(act, H1[(int64_t)r * h + lane]);
+  }
+}
+
+// Small weight gradients, reduced over the batch: out[k][j] = Σ_b X[b][k]·G[b][j] and
+// bias[j] = Σ_b G[b][j].  One thread per output element (K·J + J ≤ 1056).
+__global__ __launch_bounds__(256) void vae_small_wgrad_kernel(const float* __restrict__ X, int K,
+                                                              const float* __restrict__ G, int J,
+                                                              int batch, float* __restrict__ dW,
+                                                              float* __restrict__ db) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o < K * J) {
+    const int k = o / J, j = o % J;
+    float acc = 0.f;
+    for (int b = 0; b < batch; ++b) acc = fmaf(X[(int64_t)b * K + k], G[(int64_t)b * J + j], acc);
+    dW[o] = acc;
+  } else if (o < K * J + J) {
+    const int j = o - K * J;
+    float acc = 0.f;
+    for (int b = 0; b < batch; ++b) acc += G[(int64_t)b * J + j];
+    db[j] = acc;
+  }
+}
+
+// dW_q0[item][:] += h0[b][item]·da1[b][:] over the batch's CSR entries (scatter, fp32 atomics)
+__global__ __launch_bounds__(256) void vae_dwq0_kernel(const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const int32_t* __restrict__ rows, int batch,
+                                                       int h, const float* __restrict__ h0val,
+                                                       const float* __restrict__ DA1,
+                                                       float* __restrict__ dWq0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= batch || lane >= h) return;
+  const int64_t u = rows[r];
+  const float g = DA1[(int64_t)r * h + lane];
+  for (int64_t t = indptr[u]; t < indptr[u + 1]; ++t)
+    atomicAdd(&dWq0[(int64_t)indices[t] * h + lane], h0val[t] * g);
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n,
+                                                   float* __restrict__ out) {
+  __shared__ double s[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)x[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = (float)(s[0] / (double)n);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_vae_encode(const int64_t* d_indptr, const int32_t* d_indices, const int32_t* d_rows,
+                     int batch, int h, int z, const float* d_Wq0, const float* d_bq0,
+                     const float* d_Wq1, const float* d_bq1, const float* d_Wp0,
+                     const float* d_bp0, int act, float keep, const float* d_drop_given,
+                     const float* d_eps_given, float is_training, uint64_t seed, uint64_t step,
+                     float* d_h0val, float* d_H1, float* d_MU, float* d_LOGVAR, float* d_EPSSTD,
+                     float* d_ZS, float* d_G1, float* d_KLb, void* stream) {
+  NR_REQUIRE(d_indptr && d_indices && d_rows && d_Wq0 && d_bq0 && d_Wq1 && d_bq1 && d_Wp0 &&
+                 d_bp0 && d_H1 && d_MU && d_LOGVAR && d_EPSSTD && d_ZS && d_G1 && d_KLb,
+             NR_ERR_ARG, "vae_encode: null pointer argument");
+  NR_REQUIRE(h >= 1 && h <= kMaxD && z >= 1 && 2 * z <= kMaxD, NR_ERR_UNSUPPORTED,
+             "vae_encode: hidden %d / latent %d outside the built range (h <= 32, 2z <= 32)", h, z);
+  NR_REQUIRE(act >= 0 && act <= 3 && keep > 0.f && keep <= 1.f && batch >= 0, NR_ERR_ARG,
+             "vae_encode: bad activation / keep / batch");
+  if (batch == 0) return NR_OK;
+  hipLaunchKernelGGL(vae_encode_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     d_indptr, d_indices, d_rows, batch, h, z, d_Wq0, d_bq0, d_Wq1, d_bq1, d_Wp0,
+                     d_bp0, act, keep, d_drop_given, d_eps_given, is_training, seed, step, d_h0val,
+                     d_H1, d_MU, d_LOGVAR, d_EPSSTD, d_ZS, d_G1, d_KLb);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_add_row_bias(float* d_S, int64_t ld, int batch, int cols, const float* d_bias,
+                       void* stream) {
+  NR_REQUIRE(d_S && d_bias && ld >= cols && batch >= 0 && cols >= 1, NR_ERR_ARG,
+             "add_row_bias: bad arguments");
+  if (batch == 0) return NR_OK;
+  int64_t blocks = ((int64_t)batch * cols + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_row_bias_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, d_S, ld, batch, cols, d_bias);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_vae_workspace_bytes(int batch, int cols, size_t* bytes) {
+  NR_REQUIRE(bytes && batch >= 0 && cols >= 1, NR_ERR_ARG, "vae_workspace_bytes: bad arguments");
+  *bytes = (size_t)(batch > 0 ? batch : 1) * (size_t)((cols + 31) / 32) * sizeof(uint32_t);
+  return NR_OK;
+}
+
+/* d_S holds g1·W_p1ᵀ (no bias) on entry and dLoss/dlogits on exit. */
+int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int h,
+                                const float* d_bp1, const int64_t* d_indptr,
+                                const int32_t* d_indices, const int32_t* d_rows,
+                                const float* d_G1, const float* d_Wp1, float* d_nll,
+                                float* d_dWp1, float* d_dbp1, float* d_dG1, void* d_ws,
+                                size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_S && d_bp1 && d_indptr && d_indices && d_rows && d_G1 && d_Wp1 && d_nll && d_dWp1 &&
+                 d_dbp1 && d_dG1 && d_ws && ld >= cols && batch >= 1 && cols >= 1,
+             NR_ERR_ARG, "vae_decoder_loss_grad: bad arguments");
+  NR_REQUIRE(h >= 1 && h <= kMaxD, NR_ERR_UNSUPPORTED, "vae_decoder: hidden %d > 32", h);
+  NR_REQUIRE((size_t)batch * h * sizeof(float) <= 150 * 1024, NR_ERR_UNSUPPORTED,
+             "vae_decoder: batch*hidden = %d floats does not fit LDS", batch * h);
+  const int words = (cols + 31) / 32;
+  NR_REQUIRE(ws_bytes >= (size_t)batch * words * sizeof(uint32_t), NR_ERR_WORKSPACE,
+             "vae_decoder_loss_grad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vae_softmax_grad_kernel, dim3(batch), dim3(256), 0, st, d_S, ld, cols, d_bp1,
+                     d_indptr, d_indices, d_rows, 1.0f / (float)batch, d_nll, (uint32_t*)d_ws, words);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 255) / 256), dim3(256),
+                     (size_t)batch * h * sizeof(float), st, d_S, ld, batch, cols, h, d_G1, d_dWp1,
+                     d_dbp1);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + 1) / 2), dim3(256), 0, st, d_S, ld, batch, cols,
+                     h, d_Wp1, d_dG1);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_vae_mid_backward(int batch, int h, int z, int act, float anneal, const float* d_dG1,
+                           const float* d_G1, const float* d_H1, const float* d_MU,
+                           const float* d_LOGVAR, const float* d_EPSSTD, const float* d_ZS,
+                           const float* d_Wp0, const float* d_Wq1, float* d_DA3, float* d_DH2,
+                           float* d_DA1, float* d_dWp0, float* d_dbp0, float* d_dWq1,
+                           float* d_dbq1, float* d_dbq0, void* stream) {
+  NR_REQUIRE(d_dG1 && d_G1 && d_H1 && d_MU && d_LOGVAR && d_EPSSTD && d_ZS && d_Wp0 && d_Wq1 &&
+                 d_DA3 && d_DH2 && d_DA1 && d_dWp0 && d_dbp0 && d_dWq1 && d_dbq1 && d_dbq0 &&
+                 batch >= 1,
+             NR_ERR_ARG, "vae_mid_backward: bad arguments");
+  NR_REQUIRE(h >= 1 && h <= kMaxD && z >= 1 && 2 * z <= kMaxD, NR_ERR_UNSUPPORTED,
+             "vae_mid_backward: widths outside the built range");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vae_mid_bwd_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, batch, h, z, act,
+                     anneal, 1.0f / (float)batch, d_dG1, d_G1, d_H1, d_MU, d_LOGVAR, d_EPSSTD,
+                     d_Wp0, d_Wq1, d_DA3, d_DH2, d_DA1);
+  NR_LAUNCH_CHECK();
+  // dW_p0 = zsᵀ·da3 [z][h];  dW_q1 = h1ᵀ·dh2 [h][2z];  db_q0 = Σ da1
+  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((z * h + h + 255) / 256), dim3(256), 0, st, d_ZS,
+                     z, d_DA3, h, batch, d_dWp0, d_dbp0);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((h * 2 * z + 2 * z + 255) / 256), dim3(256), 0, st,
+                     d_H1, h, d_DH2, 2 * z, batch, d_dWq1, d_dbq1);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3(1), dim3(256), 0, st, d_H1, 0, d_DA1, h, batch,
+                     (float*)nullptr, d_dbq0);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* dW_q0 (dense [n_items][h], zero on entry) += scatter of the batch. */
+int nrhip_vae_dwq0(const int64_t* d_indptr, const int32_t* d_indices, const int32_t* d_rows,
+                   int batch, int h, const float* d_h0val, const float* d_DA1, float* d_dWq0,
+                   void* stream) {
+  NR_REQUIRE(d_indptr && d_indices && d_rows && d_h0val && d_DA1 && d_dWq0 && batch >= 0 &&
+                 h >= 1 && h <= kMaxD,
+             NR_ERR_ARG, "vae_dwq0: bad arguments");
+  if (batch == 0) return NR_OK;
+  hipLaunchKernelGGL(vae_dwq0_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     d_indptr, d_indices, d_rows, batch, h, d_h0val, d_DA1, d_dWq0);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream) {
+  NR_REQUIRE(d_x && d_out && n >= 1, NR_ERR_ARG, "mean_f32: bad arguments");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_x, n, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

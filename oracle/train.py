@@ -303,3 +303,81 @@ def ngcf_loss_and_grads(A, At, E0, weights, masks, keep, n_users, users, pos, ne
         dEgo = dBi * S + spmm_rowwise(At, dS.astype(E0.dtype))
     dE0 = dOut[:, :d0] + (dEgo if weights else 0)
     return loss, dE0.astype(E0.dtype), wgrads
+
+
+# ------------------------------------------------------------------ MultiVAE
+def _act(name, x):
+    if name == "tanh":
+        return np.tanh(x)
+    if name == "sigmoid":
+        return 1 / (1 + np.exp(-x))
+    if name == "relu":
+        return np.maximum(x, 0)
+    if name == "identity":
+        return x
+    raise NotImplementedError(name)
+
+
+def _act_grad(name, y, x):
+    """derivative w.r.t. the pre-activation x, given the output y"""
+    if name == "tanh":
+        return 1 - y * y
+    if name == "sigmoid":
+        return y * (1 - y)
+    if name == "relu":
+        return (x > 0).astype(x.dtype)
+    return np.ones_like(x)
+
+
+def multivae_forward(X, Wq, bq, Wp, bp, drop_mask, keep, eps, is_training, act="tanh"):
+    """q_graph / p_graph / _create_inference (MultiVAE.py:73-124).  X: dense multi-hot [B, I];
+    Wq = [W_q0 [I,h], W_q1 [h, 2*z]], Wp = [W_p0 [z,h], W_p1 [h, I]] (two layers each, the shape
+    conf/MultiVAE.properties p_dim=[z,h] gives); drop_mask [B, I] in {0,1}; eps [B, z] ~ N(0, 0.01²)
+    (both random draws are inputs).  Returns logits, log_softmax, KL, cache."""
+    dt = X.dtype.type
+    ss = np.sum(X * X, axis=1, keepdims=True, dtype=dt)
+    h0 = X / np.sqrt(np.maximum(ss, dt(1e-12)))
+    h0 = h0 / dt(keep) * drop_mask.astype(X.dtype)
+    a1 = h0 @ Wq[0] + bq[0]
+    h1 = _act(act, a1)
+    h2 = h1 @ Wq[1] + bq[1]
+    z = h2.shape[1] // 2
+    mu, logvar = h2[:, :z], h2[:, z:]
+    std = np.exp(dt(0.5) * logvar)
+    KL = np.mean(np.sum(dt(0.5) * (-logvar + np.exp(logvar) + mu * mu - dt(1)), axis=1, dtype=dt), dtype=dt)
+    zs = mu + dt(is_training) * eps * std
+    a3 = zs @ Wp[0] + bp[0]
+    g1 = _act(act, a3)
+    logits = g1 @ Wp[1] + bp[1]
+    mx = logits.max(axis=1, keepdims=True)
+    lse = mx + np.log(np.sum(np.exp(logits - mx), axis=1, keepdims=True, dtype=dt))
+    logsm = logits - lse
+    return logits, logsm, KL, (h0, a1, h1, mu, logvar, std, zs, a3, g1)
+
+
+def multivae_loss_and_grads(X, Wq, bq, Wp, bp, drop_mask, keep, eps, anneal, reg, act="tanh"):
+    """neg-ELBO of MultiVAE.py:126-135 and its gradients (all dense, as TF produces them)."""
+    dt = X.dtype.type
+    B = X.shape[0]
+    logits, logsm, KL, (h0, a1, h1, mu, logvar, std, zs, a3, g1) = multivae_forward(
+        X, Wq, bq, Wp, bp, drop_mask, keep, eps, 1.0, act)
+    neg_ll = -np.mean(np.sum(logsm * X, axis=1, dtype=dt), dtype=dt)
+    reg_var = dt(reg) * sum(np.sum(w * w, dtype=dt) / dt(2) for w in list(Wq) + list(Wp))
+    loss = neg_ll + dt(anneal) * KL + dt(2) * reg_var
+    n = np.sum(X, axis=1, keepdims=True, dtype=dt)
+    dlogits = (np.exp(logsm) * n - X) / dt(B)
+    gWp1 = g1.T @ dlogits + dt(2 * reg) * Wp[1]
+    gbp1 = dlogits.sum(0)
+    da3 = (dlogits @ Wp[1].T) * _act_grad(act, g1, a3)
+    gWp0 = zs.T @ da3 + dt(2 * reg) * Wp[0]
+    gbp0 = da3.sum(0)
+    dz = da3 @ Wp[0].T
+    dmu = dz + dt(anneal) * mu / dt(B)
+    dlogvar = dz * eps * std * dt(0.5) + dt(anneal) * dt(0.5) * (np.exp(logvar) - dt(1)) / dt(B)
+    dh2 = np.concatenate([dmu, dlogvar], axis=1)
+    gWq1 = h1.T @ dh2 + dt(2 * reg) * Wq[1]
+    gbq1 = dh2.sum(0)
+    da1 = (dh2 @ Wq[1].T) * _act_grad(act, h1, a1)
+    gWq0 = h0.T @ da1 + dt(2 * reg) * Wq[0]
+    gbq0 = da1.sum(0)
+    return loss, ([gWq0, gWq1], [gbq0, gbq1], [gWp0, gWp1], [gbp0, gbp1]), (neg_ll, KL)
