@@ -303,6 +303,57 @@ int nrhip_ngcf_layer_bwd(const float* d_ego, const float* d_S, const float* d_Wg
                          float* d_dT2, float* d_dWg, float* d_dbg, float* d_dWb, float* d_dbb,
                          void* d_ws, size_t ws_bytes, void* stream);
 
+/* ---- Mult-VAE (second-model coverage) ------------------------------------------
+ * Replaces the TF graph of model/general_recommender/MultiVAE.py:73-135 (q_graph, the
+ * reparameterised sample, p_graph, log_softmax, neg-ELBO) and its gradient, for the
+ * two-layer shape conf/MultiVAE.properties gives (p_dim=[z,h]: I -> h -> 2z | z -> h -> I)
+ * with h <= 32 and 2z <= 32.  The multi-hot input batch is never densified: batch row r
+ * is the CSR row d_rows[r] of the train matrix (MultiVAE.py:152-165 builds it densely on
+ * the host).  W_p1 is kept item-major, [n_items][h] (the transpose of the TF variable).
+ *
+ *   nrhip_vae_encode   l2-normalise + dropout + h1 = act(x·W_q0+b) + [mu|logvar] + sample
+ *                      + g1 = act(z·W_p0+b); per-row KL.  d_drop_given (per CSR position,
+ *                      {0,1}) / d_eps_given ([batch][z]) replace the internal draws when
+ *                      non-NULL (tests; eps ~ N(0,0.01²) as MultiVAE.py:108).  d_h0val
+ *                      (per CSR position, may be NULL) receives the dropped-out input value.
+ *   logits             = nrhip_score_gemm(P=g1, Q=W_p1) (+ b_p1, nrhip_add_row_bias or
+ *                      fused below)
+ *   nrhip_vae_decoder_loss_grad   d_S holds g1·W_p1ᵀ (bias NOT added) on entry and
+ *                      dLoss/dlogits on exit; writes nll[b] = -Σ_i log_softmax·x, dW_p1
+ *                      ([n_items][h]), db_p1, dg1.
+ *   nrhip_vae_mid_backward        the 16/32-wide layers' backward and weight gradients.
+ *   nrhip_vae_dwq0     scatter of h0ᵀ·da1 into a zeroed dense [n_items][h] gradient.
+ * act: 0 tanh, 1 sigmoid, 2 relu, 3 identity (util/tool.py activation_function). */
+int nrhip_vae_encode(const int64_t* d_indptr, const int32_t* d_indices, const int32_t* d_rows,
+                     int batch, int h, int z, const float* d_Wq0, const float* d_bq0,
+                     const float* d_Wq1, const float* d_bq1, const float* d_Wp0,
+                     const float* d_bp0, int act, float keep, const float* d_drop_given,
+                     const float* d_eps_given, float is_training, uint64_t seed, uint64_t step,
+                     float* d_h0val, float* d_H1, float* d_MU, float* d_LOGVAR, float* d_EPSSTD,
+                     float* d_ZS, float* d_G1, float* d_KLb, void* stream);
+int nrhip_add_row_bias(float* d_S, int64_t ld, int batch, int cols, const float* d_bias,
+                       void* stream);
+int nrhip_vae_workspace_bytes(int batch, int cols, size_t* bytes);
+int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int h,
+                                const float* d_bp1, const int64_t* d_indptr,
+                                const int32_t* d_indices, const int32_t* d_rows,
+                                const float* d_G1, const float* d_Wp1, float* d_nll,
+                                float* d_dWp1, float* d_dbp1, float* d_dG1, void* d_ws,
+                                size_t ws_bytes, void* stream);
+int nrhip_vae_mid_backward(int batch, int h, int z, int act, float anneal, const float* d_dG1,
+                           const float* d_G1, const float* d_H1, const float* d_MU,
+                           const float* d_LOGVAR, const float* d_EPSSTD, const float* d_ZS,
+                           const float* d_Wp0, const float* d_Wq1, float* d_DA3, float* d_DH2,
+                           float* d_DA1, float* d_dWp0, float* d_dbp0, float* d_dWq1,
+                           float* d_dbq1, float* d_dbq0, void* stream);
+int nrhip_vae_dwq0(const int64_t* d_indptr, const int32_t* d_indices, const int32_t* d_rows,
+                   int batch, int h, const float* d_h0val, const float* d_DA1, float* d_dWq0,
+                   void* stream);
+/* y += a*x ; *d_out += sum(x*x) (fp64) ; *d_out = mean(x) */
+int nrhip_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
+int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* stream);
+int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
+
 /* y = a*x (+ y0)  elementwise helpers used between propagation passes. */
 int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream);
 int nrhip_add(const float* d_x, const float* d_y, float* d_out, int64_t n, void* stream);

@@ -97,6 +97,17 @@ SIGNATURES = {
     "nrhip_ngcf_layer_fwd": [p, p, p, p, p, p, i64, i32, f32, p, i32, u64, u64, i32, p, p, i64, p],
     "nrhip_ngcf_layer_bwd": [p, p, p, p, p, p, i64, i32, f32, p, p, i64, p, p, p, p, p, p, p, p, p,
                              p, sz, p],
+    "nrhip_vae_encode": [p, p, p, i32, i32, i32, p, p, p, p, p, p, i32, f32, p, p, f32, u64, u64,
+                         p, p, p, p, p, p, p, p, p],
+    "nrhip_add_row_bias": [p, i64, i32, i32, p, p],
+    "nrhip_vae_workspace_bytes": [i32, i32, psz],
+    "nrhip_vae_decoder_loss_grad": [p, i64, i32, i32, i32, p, p, p, p, p, p, p, p, p, p, p, sz, p],
+    "nrhip_vae_mid_backward": [i32, i32, i32, i32, f32, p, p, p, p, p, p, p, p, p, p, p, p, p, p,
+                               p, p, p, p],
+    "nrhip_vae_dwq0": [p, p, p, i32, i32, p, p, p, p],
+    "nrhip_axpy": [f32, p, p, i64, p],
+    "nrhip_sumsq_accumulate": [p, i64, p, p],
+    "nrhip_mean_f32": [p, i32, p, p],
     "nrhip_scale": [p, f32, p, i64, p],
     "nrhip_add": [p, p, p, i64, p],
     "nrhip_div_scalar": [p, f32, p, i64, p],

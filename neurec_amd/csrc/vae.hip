@@ -193,23 +193,30 @@ __global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__
                                                        const float* __restrict__ G1,
                                                        float* __restrict__ dWp1,
                                                        float* __restrict__ dbp1) {
-  extern __shared__ __attribute__((aligned(16))) float s_g1[];    // [batch][h]
-  for (int i = threadIdx.x; i < batch * h; i += 256) s_g1[i] = G1[i];
-  __syncthreads();
+  constexpr int kSlab = 256;                                       // batch rows staged per round
+  __shared__ __attribute__((aligned(16))) float s_g1[kSlab * kMaxD];
   const int item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= cols) return;
   float acc[kMaxD];
 #pragma unroll
   for (int j = 0; j < kMaxD; ++j) acc[j] = 0.f;
   float bsum = 0.f;
-  for (int b = 0; b < batch; ++b) {
-    const float g = dlogits[(int64_t)b * ld + item];
-    bsum += g;
-    const float* gr = s_g1 + b * h;
+  for (int b0 = 0; b0 < batch; b0 += kSlab) {
+    const int nb = min(kSlab, batch - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * h; i += 256) s_g1[i] = G1[(int64_t)b0 * h + i];
+    __syncthreads();
+    if (item < cols) {
+      for (int b = 0; b < nb; ++b) {
+        const float g = dlogits[(int64_t)(b0 + b) * ld + item];
+        bsum += g;
+        const float* gr = s_g1 + b * h;
 #pragma unroll
-    for (int j = 0; j < kMaxD; ++j)
-      if (j < h) acc[j] = fmaf(g, gr[j], acc[j]);
+        for (int j = 0; j < kMaxD; ++j)
+          if (j < h) acc[j] = fmaf(g, gr[j], acc[j]);
+      }
+    }
   }
+  if (item >= cols) return;
 #pragma unroll
   for (int j = 0; j < kMaxD; ++j)
     if (j < h) dWp1[(int64_t)item * h + j] = acc[j];
@@ -347,6 +354,28 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, 
   if (threadIdx.x == 0) *out = (float)(s[0] / (double)n);
 }
 
+// y += a·x  (the 2·reg·W term of the regulariser's gradient)
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x,
+                                                   float* __restrict__ y, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+
+// out += Σ x²  (double accumulation; one atomic per block)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n,
+                                                    double* __restrict__ out) {
+  __shared__ double s[256];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    acc += (double)x[i] * (double)x[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(out, s[0]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -404,8 +433,6 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
                  d_dbp1 && d_dG1 && d_ws && ld >= cols && batch >= 1 && cols >= 1,
              NR_ERR_ARG, "vae_decoder_loss_grad: bad arguments");
   NR_REQUIRE(h >= 1 && h <= kMaxD, NR_ERR_UNSUPPORTED, "vae_decoder: hidden %d > 32", h);
-  NR_REQUIRE((size_t)batch * h * sizeof(float) <= 150 * 1024, NR_ERR_UNSUPPORTED,
-             "vae_decoder: batch*hidden = %d floats does not fit LDS", batch * h);
   const int words = (cols + 31) / 32;
   NR_REQUIRE(ws_bytes >= (size_t)batch * words * sizeof(uint32_t), NR_ERR_WORKSPACE,
              "vae_decoder_loss_grad: workspace too small");
@@ -413,9 +440,8 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
   hipLaunchKernelGGL(vae_softmax_grad_kernel, dim3(batch), dim3(256), 0, st, d_S, ld, cols, d_bp1,
                      d_indptr, d_indices, d_rows, 1.0f / (float)batch, d_nll, (uint32_t*)d_ws, words);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 255) / 256), dim3(256),
-                     (size_t)batch * h * sizeof(float), st, d_S, ld, batch, cols, h, d_G1, d_dWp1,
-                     d_dbp1);
+  hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, d_S, ld, batch,
+                     cols, h, d_G1, d_dWp1, d_dbp1);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + 1) / 2), dim3(256), 0, st, d_S, ld, batch, cols,
                      h, d_Wp1, d_dG1);
@@ -463,6 +489,29 @@ int nrhip_vae_dwq0(const int64_t* d_indptr, const int32_t* d_indices, const int3
   if (batch == 0) return NR_OK;
   hipLaunchKernelGGL(vae_dwq0_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      d_indptr, d_indices, d_rows, batch, h, d_h0val, d_DA1, d_dWq0);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream) {
+  NR_REQUIRE(d_x && d_y && n >= 0, NR_ERR_ARG, "axpy: bad arguments");
+  if (n == 0) return NR_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, d_x,
+                     d_y, n);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* *d_out += sum(x*x) in fp64 (zero it first for a plain sum of squares). */
+int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* stream) {
+  NR_REQUIRE(d_x && d_out && n >= 0, NR_ERR_ARG, "sumsq: bad arguments");
+  if (n == 0) return NR_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, n,
+                     d_out);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -28,6 +28,12 @@ MODELS = {
              ("learner", "adam"), ("reg", "0.0"), ("node_dropout_ratio", "0.1"),
              ("mess_dropout_ratio", "0.1"), ("embed_init_method", "xavier_normal"),
              ("weight_init_method", "xavier_normal"), ("stddev", "0.01"), ("verbose", "1")],
+    "MultiVAE": [("epochs", "500"), ("p_dim", "[16,32]"), ("batch_size", "512"), ("reg", "0.0"),
+                 ("learning_rate", "0.001"), ("activation", "tanh"),
+                 ("loss_function", "multinominal-likelihood"), ("learner", "adam"),
+                 ("anneal_cap", "0.2"), ("total_anneal_steps", "2000"),
+                 ("weight_init_method", "xavier_normal"), ("bias_init_method", "tnormal"),
+                 ("stddev", "0.01"), ("verbose", "1")],
 }
 
 

@@ -101,9 +101,11 @@ _misc_ws = Workspace()
 
 def mask_train(scores, users, train_csr, cols=None):
     """scores[r, train items of users[r]] = -inf in place (uni_evaluator.py:140-143)."""
+    if scores.dim() != 2 or scores.stride(1) != 1 or scores.dtype != torch.float32:
+        raise ValueError("scores must be a 2-D float32 tensor with unit inner stride")
     rows = scores.shape[0]
     cols = scores.shape[1] if cols is None else cols
-    call("nrhip_mask_train", _ptr(scores, torch.float32), scores.stride(0),
+    call("nrhip_mask_train", C.c_void_p(scores.data_ptr()), scores.stride(0),
          _ptr(users, torch.int32, allow_none=True), rows, cols, _ptr(train_csr.indptr),
          _ptr(train_csr.indices), _stream())
 
@@ -517,3 +519,63 @@ def device_info():
     call("nrhip_device_info", C.byref(cu), C.byref(clk), C.byref(mem), name, 128)
     return {"cu_count": cu.value, "clock_khz": clk.value, "hbm_bytes": mem.value,
             "name": name.value.decode()}
+
+
+# ----------------------------------------------------------------------------- Mult-VAE
+VAE_ACTS = {"tanh": 0, "sigmoid": 1, "relu": 2, "identity": 3}
+
+
+def vae_encode(csr, rows, Wq0, bq0, Wq1, bq1, Wp0, bp0, act, keep, is_training, seed, step, bufs,
+               drop_given=None, eps_given=None, h0val=None):
+    """bufs = (H1, MU, LOGVAR, EPSSTD, ZS, G1, KLb) — see nrhip_vae_encode."""
+    h, z = Wq0.shape[1], Wp0.shape[0]
+    call("nrhip_vae_encode", _ptr(csr.indptr), _ptr(csr.indices), _ptr(rows, torch.int32),
+         rows.numel(), h, z, _ptr(Wq0, torch.float32), _ptr(bq0), _ptr(Wq1), _ptr(bq1), _ptr(Wp0),
+         _ptr(bp0), VAE_ACTS[act], float(keep), _ptr(drop_given, torch.float32, allow_none=True),
+         _ptr(eps_given, torch.float32, allow_none=True), float(is_training),
+         C.c_uint64(seed & (2**64 - 1)), C.c_uint64(step), _ptr(h0val, torch.float32, allow_none=True),
+         *[_ptr(b, torch.float32) for b in bufs], _stream())
+
+
+def add_row_bias(S, cols, bias):
+    call("nrhip_add_row_bias", _ptr(S, torch.float32), S.stride(0), S.shape[0], cols, _ptr(bias),
+         _stream())
+
+
+def vae_workspace(batch, cols, device):
+    nbytes = C.c_size_t(0)
+    call("nrhip_vae_workspace_bytes", batch, cols, C.byref(nbytes))
+    return torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+
+
+def vae_decoder_loss_grad(S, cols, bp1, csr, rows, G1, Wp1, nll, dWp1, dbp1, dG1, ws):
+    call("nrhip_vae_decoder_loss_grad", _ptr(S, torch.float32), S.stride(0), rows.numel(), cols,
+         G1.shape[1], _ptr(bp1), _ptr(csr.indptr), _ptr(csr.indices), _ptr(rows, torch.int32),
+         _ptr(G1), _ptr(Wp1), _ptr(nll), _ptr(dWp1), _ptr(dbp1), _ptr(dG1), _ptr(ws), ws.numel(),
+         _stream())
+
+
+def vae_mid_backward(batch, act, anneal, dG1, G1, H1, MU, LOGVAR, EPSSTD, ZS, Wp0, Wq1, DA3, DH2,
+                     DA1, dWp0, dbp0, dWq1, dbq1, dbq0):
+    z, h = Wp0.shape
+    call("nrhip_vae_mid_backward", batch, h, z, VAE_ACTS[act], float(anneal),
+         *[_ptr(t, torch.float32) for t in (dG1, G1, H1, MU, LOGVAR, EPSSTD, ZS, Wp0, Wq1, DA3, DH2,
+                                            DA1, dWp0, dbp0, dWq1, dbq1, dbq0)], _stream())
+
+
+def vae_dwq0(csr, rows, h0val, DA1, dWq0):
+    call("nrhip_vae_dwq0", _ptr(csr.indptr), _ptr(csr.indices), _ptr(rows, torch.int32),
+         rows.numel(), DA1.shape[1], _ptr(h0val, torch.float32), _ptr(DA1), _ptr(dWq0), _stream())
+
+
+def axpy(a, x, y):
+    call("nrhip_axpy", float(a), _ptr(x, torch.float32), _ptr(y, torch.float32), x.numel(), _stream())
+
+
+def sumsq_accumulate(x, out_f64):
+    call("nrhip_sumsq_accumulate", _ptr(x, torch.float32), x.numel(), _ptr(out_f64, torch.float64),
+         _stream())
+
+
+def mean_f32(x, out):
+    call("nrhip_mean_f32", _ptr(x, torch.float32), x.numel(), _ptr(out, torch.float32), _stream())

@@ -106,7 +106,11 @@ class UniEvaluator(HIPEvaluator):
             else:
                 ranking_score = model.predict(batch_users, None)
                 if isinstance(ranking_score, torch.Tensor):
-                    scores = ranking_score.to(device=E.require_gpu(), dtype=torch.float32).contiguous()
+                    # a device tensor stays where it is; row-strided views (a padded score
+                    # slab sliced to [B, n_items]) are consumed in place
+                    scores = ranking_score.to(device=E.require_gpu(), dtype=torch.float32)
+                    if scores.dim() != 2 or scores.stride(1) != 1:
+                        scores = scores.contiguous()
                 else:
                     scores = torch.from_numpy(np.array(ranking_score, dtype=float_type)).to(E.require_gpu())
                 st = self._device(scores.shape[1])

@@ -1,0 +1,149 @@
+"""Mult-VAE on the HIP engine.
+
+Paper: Dawen Liang, Rahul G. Krishnan, Matthew D. Hoffman, Tony Jebara, "Variational
+Autoencoders for Collaborative Filtering", WWW 2018.  Plugin-compatible with
+model/general_recommender/MultiVAE.py: same constructor, config keys (conf/MultiVAE.properties),
+epoch loop (user permutation, int(num_users/batch_size) full batches, KL annealing over
+update_count, keep_prob 0.8) and log lines.
+
+What is mirrored on purpose (stated rather than hidden):
+  * only int(num_users / batch_size) batches run per epoch — the tail users are skipped
+    (MultiVAE.py:147);
+  * `predict` feeds ONE rating row that is never cleared between the users of a call, so user
+    k of a predict batch is scored on the union of the histories of users 0..k
+    (MultiVAE.py:186-206).  `predict_accumulates_rows = True` reproduces that; set the
+    attribute to False for the per-user input the paper describes.
+Restriction: the kernels are built for the two-layer shape p_dim=[z, h] with h <= 32, z <= 16
+(the configured [16, 32]); other shapes raise NotImplementedError.
+"""
+from time import time
+
+import numpy as np
+
+from ...util import timer
+from ...util.tool import csr_to_user_dict, get_initializer
+from ..AbstractRecommender import AbstractRecommender
+
+
+class MultiVAE(AbstractRecommender):
+    predict_accumulates_rows = True
+
+    def __init__(self, sess, dataset, conf):
+        super(MultiVAE, self).__init__(dataset, conf)
+        self.learning_rate = conf["learning_rate"]
+        self.learner = conf["learner"]
+        self.batch_size = conf["batch_size"]
+        self.act = conf["activation"]
+        self.reg = conf["reg"]
+        self.num_epochs = conf["epochs"]
+        self.anneal_cap = conf["anneal_cap"]
+        self.total_anneal_steps = conf["total_anneal_steps"]
+        self.weight_init_method = conf["weight_init_method"]
+        self.bias_init_method = conf["bias_init_method"]
+        self.stddev = conf["stddev"]
+        self.verbose = conf["verbose"]
+        self.dataset = dataset
+        self.num_users = dataset.num_users
+        self.num_items = dataset.num_items
+        self.p_dims = list(conf["p_dim"]) + [self.num_items]
+        self.q_dims = self.p_dims[::-1]
+        self.dims = self.q_dims + self.p_dims[1:]
+        self.train_dict = csr_to_user_dict(dataset.train_matrix)
+        self.sess = sess
+        self.engine = None
+
+    def build_graph(self):
+        from ... import engine as E
+        from ...trainer import MultiVAEEngine
+        if len(self.p_dims) != 3:
+            raise NotImplementedError("the HIP Mult-VAE engine implements p_dim=[z, h] (two layers)")
+        if str(self.learner).lower() != "adam":
+            raise NotImplementedError("the HIP Mult-VAE engine implements learner=adam")
+        if self.act not in E.VAE_ACTS:
+            raise NotImplementedError("activation %r is not built (tanh/sigmoid/relu/identity)" % self.act)
+        z, h, n = self.p_dims
+        w_init = get_initializer(self.weight_init_method, self.stddev, seed=2017)
+        b_init = get_initializer(self.bias_init_method, self.stddev, seed=2018)
+        params = {
+            "Wq0": w_init([n, h]), "bq0": b_init([h]),
+            "Wq1": w_init([h, 2 * z]), "bq1": b_init([2 * z]),
+            "Wp0": w_init([z, h]), "bp0": b_init([h]),
+            # TF variable weight_p_1to2 is [h, n]; the engine keeps it item-major
+            "Wp1t": np.ascontiguousarray(w_init([h, n]).T), "bp1": b_init([n]),
+        }
+        train = self.dataset.train_matrix.tocsr().astype(np.float32)
+        train.sort_indices()
+        self._train_csr = train
+        self.engine = MultiVAEEngine(E.DeviceCSR.from_scipy(train), n, params, self.learning_rate,
+                                     self.reg, self.act, max(self.batch_size, 1))
+
+    # ------------------------------------------------------------------ training
+    def train_model(self):
+        import torch
+        update_count = 0.0
+        self.logger.info(self.evaluator.metrics_info())
+        dev = self.engine.stats.device
+        n_batches = int(self.num_users / self.batch_size)
+        for epoch in range(1, self.num_epochs + 1):
+            random_perm_doc_idx = np.random.permutation(self.num_users).astype(np.int32)
+            perm_dev = torch.from_numpy(random_perm_doc_idx).to(dev)
+            training_start_time = time()
+            num_training_instances = self.num_users
+            stats = torch.zeros((max(n_batches, 1), 2), dtype=torch.float32, device=dev)
+            anneals, reg_total = [], 0.0
+            for num_batch in range(n_batches):
+                rows = perm_dev[num_batch * self.batch_size:(num_batch + 1) * self.batch_size]
+                if self.total_anneal_steps > 0:
+                    anneal = min(self.anneal_cap, 1. * update_count / self.total_anneal_steps)
+                else:
+                    anneal = self.anneal_cap
+                self.engine.step(rows.contiguous(), anneal, keep=0.8)
+                stats[num_batch].copy_(self.engine.stats)
+                if self.reg != 0.0:                    # 2·reg_var term (host read; reg defaults to 0)
+                    loss, neg_ll, kl = self.engine.loss()
+                    reg_total += loss - neg_ll - anneal * kl
+                anneals.append(anneal)
+                update_count += 1
+            total_loss = reg_total
+            for (neg_ll, kl), anneal in zip(stats[:len(anneals)].cpu().numpy(), anneals):
+                total_loss += float(neg_ll) + anneal * float(kl)
+            self.logger.info("[iter %d : loss : %f, time: %f]" % (epoch, total_loss / num_training_instances,
+                                                                 time() - training_start_time))
+            if epoch % self.verbose == 0:
+                self.logger.info("epoch %d:\t%s" % (epoch, self.evaluate()))
+
+    @timer
+    def evaluate(self):
+        return self.evaluator.evaluate(self)
+
+    # ------------------------------------------------------------------ inference
+    def _predict_rows(self, user_ids):
+        """CSR of the input rows of one predict call (see the module docstring)."""
+        from ... import engine as E
+        train = self._train_csr
+        if not self.predict_accumulates_rows:
+            return None, np.asarray(user_ids, dtype=np.int32)
+        seen = np.zeros(self.num_items, dtype=bool)
+        indptr = np.zeros(len(user_ids) + 1, dtype=np.int64)
+        chunks = []
+        for k, u in enumerate(user_ids):
+            seen[train.indices[train.indptr[u]:train.indptr[u + 1]]] = True
+            idx = np.flatnonzero(seen).astype(np.int32)
+            chunks.append(idx)
+            indptr[k + 1] = indptr[k] + len(idx)
+        indices = np.concatenate(chunks) if chunks else np.zeros(0, np.int32)
+        return E.DeviceCSR(indptr, indices, self.num_items), np.arange(len(user_ids), dtype=np.int32)
+
+    def predict(self, user_ids, candidate_items_user_ids=None):
+        """Logits of the p-network (self.h in the reference) for each user; full-rank mode returns a
+        [B, num_items] device tensor view, candidate mode a list of per-user numpy arrays."""
+        import torch
+        user_ids = list(user_ids)
+        csr, rows = self._predict_rows(user_ids)
+        S = self.engine.logits(torch.from_numpy(rows).to(self.engine.stats.device), csr=csr,
+                               out=self.engine.gemm_out(len(user_ids)))
+        ratings = S[:, :self.num_items]
+        if candidate_items_user_ids is not None:
+            host = ratings.cpu().numpy()
+            return [host[k, items] for k, items in enumerate(candidate_items_user_ids)]
+        return ratings

@@ -352,3 +352,113 @@ class NGCFEngine:
                 E.adam_dense(w, m, v, g, self.adam, clear_grad=False)
         E.rows_clear(rows, self.dsum, (self.dOut,), self.flag)
         self.adam.advance()
+
+
+class MultiVAEEngine:
+    """Mult-VAE (model/general_recommender/MultiVAE.py) for the two-layer shape of
+    conf/MultiVAE.properties: I -> h -> [mu|logvar] (2z) and z -> h -> I.
+
+    Parameters live on the GPU as W_q0 [I][h], b_q0 [h], W_q1 [h][2z], b_q1 [2z], W_p0 [z][h],
+    b_p0 [h], W_p1ᵀ [I][h] (item-major — the transpose of the TF variable), b_p1 [I].
+    A step = encode (bag-sum over each user's CSR row; no dense [B][I] input) -> logits on the
+    matrix cores -> softmax/neg-ELBO gradient in place -> the two wide weight gradients -> the
+    narrow layers -> dense TF-Adam on all eight variables (MultiVAE.py:126-139)."""
+
+    NAMES = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1t", "bp1")
+
+    def __init__(self, train_csr, n_items, params, lr, reg, act, max_batch, seed=2017):
+        dev = E.require_gpu()
+        self.csr, self.n_items = train_csr, int(n_items)
+        f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
+        self.P = {k: f(params[k]) for k in self.NAMES}
+        self.h, self.z = self.P["Wp0"].shape[1], self.P["Wp0"].shape[0]
+        assert self.P["Wq0"].shape == (self.n_items, self.h)
+        assert self.P["Wq1"].shape == (self.h, 2 * self.z)
+        assert self.P["Wp1t"].shape == (self.n_items, self.h)
+        self.G = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.M = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.V = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.act, self.reg, self.seed, self.t = act, float(reg), int(seed), 0
+        self.adam = E.AdamState(lr)
+        self.max_batch = int(max_batch)
+        B, h, z = self.max_batch, self.h, self.z
+        zf = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.H1, self.G1, self.dG1, self.DA3, self.DA1 = (zf(B, h) for _ in range(5))
+        self.MU, self.LOGVAR, self.EPSSTD, self.ZS = (zf(B, z) for _ in range(4))
+        self.DH2 = zf(B, 2 * z)
+        self.KLb, self.nll = zf(B), zf(B)
+        self.h0val = zf(max(train_csr.nnz, 1))
+        self.gemm = E.ScoreGemm(self.P["Wp1t"], B)
+        self.S = self.gemm.new_score_buffer(B)
+        self.ws = E.vae_workspace(B, self.n_items, dev)
+        self.stats = zf(2)                         # [neg_ll, KL] of the last step
+        self.regsum = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def gemm_out(self, rows):
+        """a fresh [rows][ld] score slab (predict hands its result to the evaluator)"""
+        return self.gemm.new_score_buffer(rows)
+
+    def _fwd_bufs(self, B):
+        return (self.H1[:B], self.MU[:B], self.LOGVAR[:B], self.EPSSTD[:B], self.ZS[:B],
+                self.G1[:B], self.KLb[:B])
+
+    def logits(self, rows, csr=None, out=None):
+        """p_graph output for the given CSR rows at is_training=0, keep_prob=1 (MultiVAE.py:186-206
+        feeds only input_ph).  Any number of rows (processed max_batch at a time); returns a
+        [B][ld] score slab whose columns >= n_items are padding."""
+        P, B = self.P, rows.numel()
+        csr = self.csr if csr is None else csr
+        if out is None:
+            out = self.S if B <= self.max_batch else self.gemm.new_score_buffer(B)
+        self.gemm.prepare(P["Wp1t"])
+        for lo in range(0, B, self.max_batch):
+            n = min(self.max_batch, B - lo)
+            E.vae_encode(csr, rows[lo:lo + n], P["Wq0"], P["bq0"], P["Wq1"], P["bq1"], P["Wp0"],
+                         P["bp0"], self.act, 1.0, 0.0, self.seed, self.t, self._fwd_bufs(n))
+            S = self.gemm(self.G1[:n], None, out=out[lo:lo + n])
+            E.add_row_bias(S, self.n_items, P["bp1"])
+        return out[:B]
+
+    def step(self, rows, anneal, keep=0.8, drop_given=None, eps_given=None, want_loss=True,
+             apply=True):
+        """One optimiser step on the users `rows` (int32 device tensor).  Leaves
+        stats = [neg_ll, KL]; loss = neg_ll + anneal·KL + 2·reg_var (see loss()).
+        apply=False stops after the gradients (self.G; the caller zeroes G["Wq0"] afterwards)."""
+        P, G, B = self.P, self.G, rows.numel()
+        if B > self.max_batch or B < 1:
+            raise ValueError("batch size %d outside [1, %d]" % (B, self.max_batch))
+        E.vae_encode(self.csr, rows, P["Wq0"], P["bq0"], P["Wq1"], P["bq1"], P["Wp0"], P["bp0"],
+                     self.act, keep, 1.0, self.seed, self.t, self._fwd_bufs(B),
+                     drop_given=drop_given, eps_given=eps_given, h0val=self.h0val)
+        self.gemm.prepare(P["Wp1t"])
+        S = self.gemm(self.G1[:B], None, out=self.S)
+        E.vae_decoder_loss_grad(S, self.n_items, P["bp1"], self.csr, rows, self.G1[:B], P["Wp1t"],
+                                self.nll[:B], G["Wp1t"], G["bp1"], self.dG1[:B], self.ws)
+        E.vae_mid_backward(B, self.act, anneal, self.dG1[:B], self.G1[:B], self.H1[:B], self.MU[:B],
+                           self.LOGVAR[:B], self.EPSSTD[:B], self.ZS[:B], P["Wp0"], P["Wq1"],
+                           self.DA3[:B], self.DH2[:B], self.DA1[:B], G["Wp0"], G["bp0"], G["Wq1"],
+                           G["bq1"], G["bq0"])
+        E.vae_dwq0(self.csr, rows, self.h0val, self.DA1[:B], G["Wq0"])   # G["Wq0"] is zero here
+        if want_loss:
+            E.mean_f32(self.nll[:B], self.stats[0:1])
+            E.mean_f32(self.KLb[:B], self.stats[1:2])
+        if self.reg != 0.0:
+            if want_loss:
+                self.regsum.zero_()
+            for k in ("Wq0", "Wq1", "Wp0", "Wp1t"):
+                if want_loss:
+                    E.sumsq_accumulate(P[k], self.regsum)
+                E.axpy(2.0 * self.reg, P[k], G[k])
+        self.last_anneal = float(anneal)
+        if not apply:
+            return
+        for k in self.NAMES:
+            E.adam_dense(P[k], self.M[k], self.V[k], G[k], self.adam, clear_grad=(k == "Wq0"))
+        self.adam.advance()
+        self.t += 1
+
+    def loss(self):
+        """Host read of the last step's neg-ELBO (syncs)."""
+        neg_ll, kl = (float(x) for x in self.stats.cpu())
+        reg_var = self.reg * float(self.regsum.item()) / 2.0 if self.reg != 0.0 else 0.0
+        return neg_ll + self.last_anneal * kl + 2.0 * reg_var, neg_ll, kl

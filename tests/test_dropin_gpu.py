@@ -148,3 +148,40 @@ def test_ngcf_config_drops_in(tmp_path):
     # with dropout off the evaluation forward is deterministic: the logged line is reproducible
     assert evals[-1][1] == _oracle_line(model, model.evaluator)
     assert model.get_eval_factors()[0].shape[1] == 48                        # concat of 3 blocks of 16
+
+
+def test_multivae_config_drops_in(tmp_path):
+    """conf/MultiVAE.properties -> HIP Mult-VAE: log lines, loss falls, and `predict` reproduces
+    the reference's accumulating input row (MultiVAE.py:186-206) — checked against the oracle
+    forward on the cumulative-union rows."""
+    from oracle import train
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=MultiVAE", "--epochs=30", "--batch_size=32",
+                            "--learning_rate=0.01", "--verbose=15", "--total_anneal_steps=50"])
+    text = _log_text(tmp_path, "MultiVAE")
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 30 and float(iters[-1][1]) < float(iters[0][1])
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == [15, 30]
+    # the six taste clusters are learnable, even through the accumulating predict rows
+    ndcg20 = float(evals[-1][1].split()[5])
+    assert ndcg20 > 0.15
+    users = [5, 17, 3, 44]
+    got = model.predict(users, None).cpu().numpy()
+    P = {k: v.cpu().numpy().astype(np.float64) for k, v in model.engine.P.items()}
+    R = model.dataset.train_matrix.tocsr()
+    X = np.zeros((len(users), model.num_items))
+    row = np.zeros(model.num_items)
+    for k, u in enumerate(users):
+        row[R[u].indices] = 1
+        X[k] = row
+    want, _, _, _ = train.multivae_forward(X, [P["Wq0"], P["Wq1"]], [P["bq0"], P["bq1"]],
+                                           [P["Wp0"], P["Wp1t"].T], [P["bp0"], P["bp1"]],
+                                           np.ones_like(X), 1.0, np.zeros((len(users), 16)), 0.0, "tanh")
+    assert np.abs(got - want).max() < 1e-5
+    model.predict_accumulates_rows = False
+    solo = model.predict(users, None).cpu().numpy()
+    assert np.abs(solo[0] - want[0]).max() < 1e-5 and np.abs(solo[1] - want[1]).max() > 1e-4
+    cand = model.predict(users, [[1, 2, 3]] * 4)
+    assert np.allclose(cand[2], solo[2][[1, 2, 3]])

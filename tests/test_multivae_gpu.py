@@ -1,0 +1,162 @@
+"""Mult-VAE kernels (CSR bag encoder, MFMA logits, in-place softmax/ELBO gradient, wide and narrow
+weight gradients, dense TF-Adam) against oracle.train.multivae_*: the dropout mask and the
+N(0, 0.01²) noise are supplied as inputs (TF's Philox stream is not reproducible; both are data)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1t", "bp1")
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _problem(seed, U=300, I=1000, h=32, z=16):
+    rng = np.random.RandomState(seed)
+    R = sp.random(U, I, 0.03, random_state=seed, format="csr", dtype=np.float32)
+    R.data[:] = 1.0
+    R = R.tolil(); R[5, :] = 0; R = R.tocsr(); R.eliminate_zeros()      # a user with no history
+    R.sort_indices()
+    s = 0.3
+    params = {
+        "Wq0": (rng.randn(I, h) * s).astype(np.float32), "bq0": (rng.randn(h) * 0.05).astype(np.float32),
+        "Wq1": (rng.randn(h, 2 * z) * s).astype(np.float32), "bq1": (rng.randn(2 * z) * 0.05).astype(np.float32),
+        "Wp0": (rng.randn(z, h) * s).astype(np.float32), "bp0": (rng.randn(h) * 0.05).astype(np.float32),
+        "Wp1t": (rng.randn(I, h) * s).astype(np.float32), "bp1": (rng.randn(I) * 0.05).astype(np.float32),
+    }
+    return rng, R, params
+
+
+def _oracle_args(params, dt=np.float64):
+    p = {k: v.astype(dt) for k, v in params.items()}
+    return ([p["Wq0"], p["Wq1"]], [p["bq0"], p["bq1"]], [p["Wp0"], p["Wp1t"].T.copy()],
+            [p["bp0"], p["bp1"]])
+
+
+def _batch_inputs(rng, R, rows, keep, z):
+    """dense X / drop mask for the oracle and the per-CSR-position mask for the kernel"""
+    X = np.asarray(R[rows].todense(), dtype=np.float64)
+    drop_pos = (rng.rand(R.nnz) < keep).astype(np.float32)
+    D = np.ones_like(X)
+    for b, u in enumerate(rows):
+        lo, hi = R.indptr[u], R.indptr[u + 1]
+        D[b, R.indices[lo:hi]] = drop_pos[lo:hi]
+    eps = (rng.randn(len(rows), z) * 0.01).astype(np.float32)
+    return X, D, drop_pos, eps
+
+
+def _engine(R, params, lr=0.001, reg=0.0, act="tanh", B=64):
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import MultiVAEEngine
+    csr = E.DeviceCSR.from_scipy(R)
+    return MultiVAEEngine(csr, R.shape[1], params, lr, reg, act, B)
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "relu"])
+def test_multivae_logits_match_oracle(act):
+    from oracle import train
+    rng, R, params = _problem(3)
+    eng = _engine(R, params, act=act)
+    rows = rng.choice(R.shape[0], 64, replace=False).astype(np.int32)
+    rows[0] = 5
+    S = eng.logits(_dev(rows)).cpu().numpy()[:, :R.shape[1]]
+    X = np.asarray(R[rows].todense(), dtype=np.float64)
+    Wq, bq, Wp, bp = _oracle_args(params)
+    want, _, _, _ = train.multivae_forward(X, Wq, bq, Wp, bp, np.ones_like(X), 1.0,
+                                           np.zeros((64, 16)), 0.0, act)
+    assert np.abs(S - want).max() < 1e-5
+
+
+@pytest.mark.parametrize("reg,anneal,act", [(0.0, 0.2, "tanh"), (0.01, 0.07, "tanh"), (0.0, 0.2, "relu")])
+def test_multivae_loss_and_grads_match_oracle(reg, anneal, act):
+    from oracle import train
+    rng, R, params = _problem(4)
+    B, keep, z = 64, 0.8, 16
+    eng = _engine(R, params, reg=reg, act=act, B=B)
+    rows = rng.choice(R.shape[0], B, replace=False).astype(np.int32)
+    rows[3] = 5
+    X, D, drop_pos, eps = _batch_inputs(rng, R, rows, keep, z)
+    eng.step(_dev(rows), anneal, keep, drop_given=_dev(drop_pos), eps_given=_dev(eps), apply=False)
+    loss, neg_ll, kl = eng.loss()
+    Wq, bq, Wp, bp = _oracle_args(params)
+    wl, (gWq, gbq, gWp, gbp), (wnll, wkl) = train.multivae_loss_and_grads(
+        X, Wq, bq, Wp, bp, D, keep, eps.astype(np.float64), anneal, reg, act)
+    assert abs(neg_ll - wnll) < 1e-5 * max(1.0, abs(wnll))
+    assert abs(kl - wkl) < 1e-5 * max(1.0, abs(wkl))
+    assert abs(loss - wl) < 1e-5 * max(1.0, abs(wl))
+    want = {"Wq0": gWq[0], "bq0": gbq[0], "Wq1": gWq[1], "bq1": gbq[1], "Wp0": gWp[0],
+            "bp0": gbp[0], "Wp1t": gWp[1].T, "bp1": gbp[1]}
+    for k in NAMES:
+        got = eng.G[k].cpu().numpy()
+        scale = max(np.abs(want[k]).max(), 1e-3)
+        assert np.abs(got - want[k]).max() < 2e-5 * scale, k
+
+
+def test_multivae_steps_track_oracle():
+    """five Adam steps, fp32 oracle alongside: parameters stay within 1e-5"""
+    from oracle import train
+    rng, R, params = _problem(5)
+    B, keep, z, lr = 48, 0.8, 16, 0.001
+    eng = _engine(R, params, lr=lr, B=64)
+    ref = {k: v.astype(np.float64) for k, v in params.items()}
+    ref["Wp1"] = ref.pop("Wp1t").T.copy()
+    order = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1", "bp1")
+    adam = train.Adam(lr, dtype=np.float64)
+    m = {k: np.zeros_like(ref[k]) for k in order}
+    v = {k: np.zeros_like(ref[k]) for k in order}
+    for it in range(5):
+        rows = rng.choice(R.shape[0], B, replace=False).astype(np.int32)
+        X, D, drop_pos, eps = _batch_inputs(rng, R, rows, keep, z)
+        anneal = min(0.2, it / 10.0)
+        eng.step(_dev(rows), anneal, keep, drop_given=_dev(drop_pos), eps_given=_dev(eps))
+        wl, (gWq, gbq, gWp, gbp), _ = train.multivae_loss_and_grads(
+            X, [ref["Wq0"], ref["Wq1"]], [ref["bq0"], ref["bq1"]], [ref["Wp0"], ref["Wp1"]],
+            [ref["bp0"], ref["bp1"]], D, keep, eps.astype(np.float64), anneal, 0.0, "tanh")
+        assert abs(eng.loss()[0] - wl) < 1e-5 * max(1.0, abs(wl))
+        g = dict(zip(order, (gWq[0], gbq[0], gWq[1], gbq[1], gWp[0], gbp[0], gWp[1], gbp[1])))
+        for k in order:
+            adam.dense(ref[k], m[k], v[k], g[k])
+        adam.advance()
+    for k in order:
+        got = eng.P["Wp1t" if k == "Wp1" else k].cpu().numpy()
+        want = ref[k].T if k == "Wp1" else ref[k]
+        # Adam's first steps move every weight by ~lr·sign(g): entries whose gradient is at
+        # rounding level may differ in direction, so compare in units of lr
+        assert np.abs(got - want).max() < 0.05 * lr * 5 + 1e-6, k
+        assert np.mean(np.abs(got - want)) < 1e-6, k
+
+
+def test_multivae_device_draws():
+    """device-drawn dropout keeps ~keep of the entries; eps ~ N(0, 0.01²); reproducible per step"""
+    rng, R, params = _problem(6)
+    eng = _engine(R, params, B=256)
+    rows = _dev(np.arange(256, dtype=np.int32))
+    eng.step(rows, 0.1, 0.8, apply=False)
+    eng.G["Wq0"].zero_()
+    h0 = eng.h0val.cpu().numpy()
+    pos = np.concatenate([np.arange(R.indptr[u], R.indptr[u + 1]) for u in range(256)])
+    kept = np.mean(h0[pos] != 0)
+    assert abs(kept - 0.8) < 0.02
+    es = eng.EPSSTD[:256].cpu().numpy() / np.exp(0.5 * eng.LOGVAR[:256].cpu().numpy())
+    assert abs(es.mean()) < 1e-3 and abs(es.std() - 0.01) < 1e-3
+    first = h0.copy()
+    eng.step(rows, 0.1, 0.8, apply=False)                  # same step counter -> same draw
+    eng.G["Wq0"].zero_()
+    assert np.array_equal(first, eng.h0val.cpu().numpy())
+
+
+def test_multivae_rejects_unbuilt_widths():
+    rng, R, params = _problem(7, h=32, z=16)
+    bad = dict(params)
+    bad["Wp0"] = np.zeros((16, 64), np.float32)
+    bad["Wq0"] = np.zeros((R.shape[1], 64), np.float32)
+    bad["bq0"] = np.zeros(64, np.float32); bad["bp0"] = np.zeros(64, np.float32)
+    bad["Wq1"] = np.zeros((64, 32), np.float32)
+    bad["Wp1t"] = np.zeros((R.shape[1], 64), np.float32)
+    eng = _engine(R, bad)
+    with pytest.raises(NotImplementedError):
+        eng.logits(_dev(np.arange(8, dtype=np.int32)))
