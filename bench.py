@@ -156,7 +156,9 @@ def main():
     spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
     spmm_bytes = lg.A.algorithmic_bytes(args.dim)
     achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "spmm_item_kernel<%d,...>" % args.dim, "achieved": achieved,
+    kernel = ("spmm_blocked_kernel<false,16,8>" if lg.A.blocked is not None
+              else "spmm_item_kernel<%d,...>" % args.dim)
+    roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "bytes_per_launch": spmm_bytes, "us_per_launch": spmm_ms * 1e3,
                 "launches_per_step": 2 * args.layers,

@@ -97,6 +97,14 @@ SIGNATURES = {
     "nrhip_ngcf_layer_fwd": [p, p, p, p, p, p, i64, i32, f32, p, i32, u64, u64, i32, p, p, i64, p],
     "nrhip_ngcf_layer_bwd": [p, p, p, p, p, p, i64, i32, f32, p, p, i64, p, p, p, p, p, p, p, p, p,
                              p, sz, p],
+    "nrhip_spmm_blocked_plan_bytes": [i64, i64, psz],
+    "nrhip_spmm_blocked_plan_create": [p, p, i64, i64, i32, i64, i32, i32, i32, i32, i32, p, sz, p,
+                                       C.POINTER(p)],
+    "nrhip_spmm_blocked_plan_destroy": [p],
+    "nrhip_spmm_blocked_plan_info": [p, p, p, p, p],
+    "nrhip_spmm_blocked_tune": [i32],
+    "nrhip_spmm_blocked": [p, p, p, p, p, p, p, p, p, p, p],
+    "nrhip_spmm_plan_attach_blocked": [p, p],
     "nrhip_vae_encode": [p, p, p, i32, i32, i32, p, p, p, p, p, p, i32, f32, p, p, f32, u64, u64,
                          p, p, p, p, p, p, p, p, p],
     "nrhip_add_row_bias": [p, i64, i32, i32, p, p],

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(HERE, "libneurec_hip.so")
 STAMP = os.path.join(OBJ_DIR, "sources.sha256")
 
 SOURCES = ["eval_select.hip", "score_gemm.hip", "sampler.hip", "spmm.hip", "bpr.hip", "adam.hip",
-           "step.hip", "dense.hip", "vae.hip"]
+           "step.hip", "dense.hip", "vae.hip", "spmm_slab.hip", "spmm_blocked.hip"]
 HEADERS = ["nr_core.h", "nr_common.h"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

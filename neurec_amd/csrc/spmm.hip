@@ -40,6 +40,13 @@
 #include <new>
 #include <vector>
 
+// spmm_blocked.hip
+extern "C" int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                  const float* d_X, float* d_Y, const float* d_addend,
+                                  const float* d_sum_in, float* d_sum_out,
+                                  const uint8_t* d_x_row_nonzero, const uint8_t* d_y_row_wanted,
+                                  void* stream);
+
 namespace {
 
 constexpr int kSegLen = 256;     // non-zeros per segment of a split (hub) row
@@ -49,6 +56,7 @@ constexpr int kGather = 16;      // row gathers in flight per wave (8/16/32 meas
 
 struct SpmmPlan {
   int64_t n_rows, nnz;
+  const void* blocked;       // optional cache-blocked schedule for d = 64 (spmm_blocked.hip); not owned
   // --- work items (d >= 64 path)
   int64_t n_items, n_hub_items, n_a_items, n_b_items;   // items = [hub | class A | class B]
   int item_rows, item_nnz;   // limits the items were cut with
@@ -678,6 +686,7 @@ int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_row
   NR_REQUIRE(p, NR_ERR_ARG, "spmm_plan_create: out of host memory");
   p->n_rows = n_rows;
   p->nnz = nnz;
+  p->blocked = nullptr;
   p->item_rows = item_rows;
   p->item_nnz = item_nnz;
   p->n_hub_items = n_hub_items;
@@ -736,6 +745,12 @@ int nrhip_spmm_plan_destroy(void* plan) {
   return NR_OK;
 }
 
+int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan) {
+  NR_REQUIRE(plan, NR_ERR_ARG, "spmm_plan_attach_blocked: null plan");
+  ((SpmmPlan*)plan)->blocked = blocked_plan;       // NULL detaches
+  return NR_OK;
+}
+
 int nrhip_spmm_plan_info(const void* plan, int64_t* n_work_items, int64_t* n_split_rows) {
   NR_REQUIRE(plan, NR_ERR_ARG, "spmm_plan_info: null plan");
   const SpmmPlan* p = (const SpmmPlan*)plan;
@@ -762,6 +777,9 @@ static int spmm_dispatch(const char* who, const void* plan, const int64_t* d_ind
              "%s: sum_out needs sum_in", who);
   const SpmmPlan* p = (const SpmmPlan*)plan;
   hipStream_t st = (hipStream_t)stream;
+  if (d == 64 && p->blocked)   // persistent lane-group kernel (same contract, same masks)
+    return nrhip_spmm_blocked(p->blocked, d_indices, d_vals, d_X, d_Y, d_addend, d_sum_in,
+                              d_sum_out, d_col_mask, d_row_mask, stream);
   if (d < 64)   // the 16/32-wide path has no work-skipping variants
     NR_REQUIRE(d_row_mask == nullptr, NR_ERR_UNSUPPORTED,
                "%s: row mask needs an embedding dim >= 64", who);

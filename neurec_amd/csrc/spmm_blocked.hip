@@ -1,0 +1,458 @@
+// spmm_blocked.hip — cache-blocked, persistent-workgroup SpMM  Y = Â·X  for d = 64.
+//
+// Why: at the gowalla shape one pass gathers 1.62 M rows of 256 B (415 MB) out of an 18 MB
+// table.  A pure random-gather micro-benchmark of that pattern (scripts/exp_gather.py) tops out
+// at ≈9 TB/s — the L2-miss path into the Infinity Cache — and the work-item kernel of spmm.hip
+// already sits on that ceiling.  The same gathers run at 16-17 TB/s when (a) every XCD only
+// touches a ≤2.6 MB window of the table at a time, so its private 4 MB L2 holds it, and (b) a load
+// instruction moves four rows (16 lanes × 16 B each) instead of one
+// (scripts/exp_gather_blocked.py).  This kernel is built on those two facts.
+//
+// Schedule (host, once per matrix):
+//   * one workgroup per CU (16 waves), workgroup b on XCD b % 8.  With a bipartite split the
+//     user rows go to XCDs 0-3 and the item rows to XCDs 4-7 (they gather from disjoint halves
+//     of the table); each workgroup owns a contiguous run of rows, balanced by non-zeros;
+//   * the column range a class gathers from is cut into K blocks of ≤ block_bytes; a row's
+//     non-zeros (ascending columns) fall into ≤ K contiguous sub-lists, one per block;
+//   * phase k of the kernel walks the sub-lists of block k.  All workgroups of an XCD move
+//     through the phases at about the same pace (equal work, no barrier needed), so the XCD's
+//     L2 holds one block at a time.
+// Kernel: every row of the workgroup has a 256-byte accumulator in LDS that lives across the
+// phases.  A 16-lane group owns one sub-list: it loads the accumulator, adds a_j·X[col_j] in
+// ascending column order (products and sums rounded separately — the order of the reference's
+// CPU kernel, so rows are bit-identical to oracle/), and stores it back.  Sub-lists longer
+// than 64 are cut into segments with their own partial accumulators, added in segment order
+// after the phase (deterministic; only such hub rows deviate from the sequential order).
+// Epilogue as in spmm.hip: y += addend, sum_out = sum_in + y.
+#include "nr_common.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int kD = 64;
+constexpr int kSegDefault = 64;     // longest sub-list one lane group walks alone
+constexpr int kRMaxDefault = 416;   // row accumulators per workgroup (104 KB)
+constexpr int kPMaxDefault = 192;   // segment partial slots per workgroup and phase (48 KB)
+constexpr int kMaxPhases = 32;
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+struct BlockedPlan {
+  int64_t n_rows, nnz, n_ent, n_cmb;
+  int n_wg, n_phases;
+  int seg, r_max, p_max, waves;
+  int32_t* wg_row0;
+  int32_t* wg_nrows;
+  int32_t* wg_ent_off;   // [n_wg][n_phases + 1]
+  int32_t* wg_cmb_off;   // [n_wg][n_phases + 1]
+  int4* ent;             // {accumulator slot, length, first non-zero, owning row slot}
+  int4* cmb;             // {row slot, first partial slot, segments, 0}
+};
+
+size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
+  const size_t max_ent = (size_t)std::min<int64_t>(nnz, n_rows * (int64_t)kMaxPhases) + (size_t)(nnz / 16) + 64;
+  const size_t max_cmb = (size_t)(nnz / 16) + 64;
+  const size_t wg = 4096;   // generous bound on workgroups
+  return nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
+         2 * nr_align_up(wg * 4, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256);
+}
+
+template <bool MASKED, int kWaves, int kG>
+__global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
+    const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_nrows,
+    const int32_t* __restrict__ wg_ent_off, const int32_t* __restrict__ wg_cmb_off,
+    const int4* __restrict__ ent, const int4* __restrict__ cmb, int n_phases,
+    const int32_t* __restrict__ indices, const float* __restrict__ vals,
+    const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
+    const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ col_mask,
+    const uint8_t* __restrict__ row_mask, int kRMax) {
+  constexpr int kGroups = kWaves * 4;
+  extern __shared__ float4 s_acc[];          // [(r_max + p_max)][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4, gbase = lane & 48;
+  const int wg = blockIdx.x;
+  const int r0 = wg_row0[wg], nr = wg_nrows[wg];
+  for (int i = tid; i < nr * 16; i += kWaves * NR_WAVE) s_acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int32_t* eoff = wg_ent_off + (int64_t)wg * (n_phases + 1);
+  const int32_t* coff = wg_cmb_off + (int64_t)wg * (n_phases + 1);
+  for (int k = 0; k < n_phases; ++k) {
+    const int e0 = eoff[k], e1 = eoff[k + 1];
+    // Software pipeline over this lane group's sub-lists (entries ei, ei+64, ...): the next
+    // entry's descriptor is requested before, and its first 16 (column, value) pairs right
+    // after, the current entry's gathers are issued — so in steady state a sub-list costs one
+    // gather round trip, not three dependent ones.
+    int ei = e0 + wave * 4 + g;
+    int4 cur = make_int4(0, 0, 0, 0);
+    if (ei < e1) cur = ent[ei];
+    int cur_idx = 0;
+    float cur_val = 0.f;
+    if (c < cur.y) {
+      cur_idx = indices[(uint32_t)cur.z + c];
+      cur_val = vals[(uint32_t)cur.z + c];
+    }
+    for (int base = e0 + wave * 4; base < e1; base += kGroups) {
+      const bool live = ei < e1;
+      const int ein = ei + kGroups;
+      int4 nxt = make_int4(0, 0, 0, 0);
+      if (ein < e1) nxt = ent[ein];
+      const int slot = cur.x;
+      int len = cur.y;
+      const uint32_t begin = (uint32_t)cur.z;
+      if constexpr (MASKED) {
+        if (row_mask && live && row_mask[r0 + cur.w] == 0) len = 0;    // output row not wanted
+      }
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && slot < kRMax) acc = s_acc[slot * 16 + c];            // segments start from zero
+      int maxlen = max(len, __shfl_xor(len, 16, NR_WAVE));
+      maxlen = max(maxlen, __shfl_xor(maxlen, 32, NR_WAVE));
+      maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+      int nxt_idx = 0;
+      float nxt_val = 0.f;
+      for (int k0 = 0; k0 < maxlen || k0 == 0; k0 += 16) {
+        int my_idx = cur_idx;
+        float my_val = cur_val;
+        if (k0 > 0) {                                // long sub-list: later chunks are not pipelined
+          my_idx = 0;
+          my_val = 0.f;
+          if (k0 + c < len) {
+            my_idx = indices[begin + k0 + c];
+            my_val = vals[begin + k0 + c];
+          }
+        }
+        if constexpr (MASKED) {
+          if (col_mask && k0 + c < len && col_mask[my_idx] == 0) my_idx = -1;   // X row all zero
+        }
+        const int nn = min(16, maxlen - k0);
+        for (int t0 = 0; t0 < nn || (k0 == 0 && t0 == 0); t0 += kG) {
+          float a[kG];
+          float4 x[kG];
+          bool on[kG];
+#pragma unroll
+          for (int u = 0; u < kG; ++u) {
+            const int src = gbase | ((t0 + u) & 15);
+            const int col = __shfl(my_idx, src, NR_WAVE);
+            a[u] = __shfl(my_val, src, NR_WAVE);
+            on[u] = k0 + t0 + u < len;
+            if constexpr (MASKED) {
+              on[u] = on[u] && col >= 0;
+              x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (on[u]) x[u] = X[(int64_t)col * 16 + c];
+            } else {
+              x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (t0 + u < nn) x[u] = X[(int64_t)max(col, 0) * 16 + c];   // wave-uniform guard
+            }
+          }
+          if (k0 == 0 && t0 == 0 && c < nxt.y) {     // prefetch the next sub-list's first chunk
+            nxt_idx = indices[(uint32_t)nxt.z + c];
+            nxt_val = vals[(uint32_t)nxt.z + c];
+          }
+#pragma unroll
+          for (int u = 0; u < kG; ++u)
+            if (on[u]) {
+              acc.x = __fadd_rn(acc.x, __fmul_rn(a[u], x[u].x));
+              acc.y = __fadd_rn(acc.y, __fmul_rn(a[u], x[u].y));
+              acc.z = __fadd_rn(acc.z, __fmul_rn(a[u], x[u].z));
+              acc.w = __fadd_rn(acc.w, __fmul_rn(a[u], x[u].w));
+            }
+        }
+      }
+      if (live) s_acc[slot * 16 + c] = acc;
+      cur = nxt;
+      cur_idx = nxt_idx;
+      cur_val = nxt_val;
+      ei = ein;
+    }
+    const int c0 = coff[k], c1 = coff[k + 1];
+    if (c1 > c0) {                                  // workgroup-uniform
+      __syncthreads();
+      for (int ci = c0 + wave * 4 + g; ci < c1; ci += kGroups) {
+        const int4 cm = cmb[ci];
+        float4 acc = s_acc[cm.x * 16 + c];
+        for (int s = 0; s < cm.z; ++s) {
+          const float4 p = s_acc[(cm.y + s) * 16 + c];
+          acc.x = __fadd_rn(acc.x, p.x); acc.y = __fadd_rn(acc.y, p.y);
+          acc.z = __fadd_rn(acc.z, p.z); acc.w = __fadd_rn(acc.w, p.w);
+        }
+        s_acc[cm.x * 16 + c] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nr * 16; i += kWaves * NR_WAVE) {
+    const int row = r0 + (i >> 4);
+    if constexpr (MASKED) {
+      if (row_mask && row_mask[row] == 0) continue;
+    }
+    const int64_t o = (int64_t)row * 16 + (i & 15);
+    float4 y = s_acc[i];
+    if (addend) {
+      const float4 ad = addend[o];
+      y.x = __fadd_rn(y.x, ad.x); y.y = __fadd_rn(y.y, ad.y);
+      y.z = __fadd_rn(y.z, ad.z); y.w = __fadd_rn(y.w, ad.w);
+    }
+    if (Y) Y[o] = y;
+    if (sum_out) {
+      const float4 si = sum_in[o];
+      sum_out[o] = make_float4(__fadd_rn(si.x, y.x), __fadd_rn(si.y, y.y), __fadd_rn(si.z, y.z),
+                               __fadd_rn(si.w, y.w));
+    }
+  }
+}
+
+struct HostEnt { int32_t slot, len; uint32_t begin; int32_t owner; };
+int s_gathers_in_flight = 8;     // tuning knob (nrhip_spmm_blocked_tune)
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_spmm_blocked_plan_bytes(int64_t n_rows, int64_t nnz, size_t* bytes) {
+  NR_REQUIRE(bytes && n_rows >= 0 && nnz >= 0, NR_ERR_ARG, "spmm_blocked_plan_bytes: bad arguments");
+  *bytes = blocked_plan_bytes(n_rows, nnz);
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_indices,
+                                   int64_t n_rows, int64_t split_row, int d, int64_t block_bytes,
+                                   int n_workgroups, int waves_per_wg, int seg_len, int r_max,
+                                   int p_max, void* d_plan_buf, size_t plan_bytes, void* stream,
+                                   void** plan_out) {
+  const int kWaves = waves_per_wg > 0 ? waves_per_wg : 16;
+  const int kSeg = seg_len > 0 ? seg_len : kSegDefault;
+  const int kRMax = r_max > 0 ? r_max : kRMaxDefault * kWaves / 16;
+  const int kPMax = p_max > 0 ? p_max : kPMaxDefault * kWaves / 16;
+  NR_REQUIRE(kWaves == 16 || kWaves == 8, NR_ERR_UNSUPPORTED, "spmm_blocked: waves per workgroup %d (8, 16)", kWaves);
+  NR_REQUIRE(kSeg >= 16 && (size_t)(kRMax + kPMax) * kD * 4 <= (size_t)kMaxLdsBytes, NR_ERR_UNSUPPORTED,
+             "spmm_blocked: seg %d / accumulators %d+%d do not fit", kSeg, kRMax, kPMax);
+  NR_REQUIRE(h_indptr && h_indices && d_plan_buf && plan_out && n_rows > 0, NR_ERR_ARG,
+             "spmm_blocked_plan_create: bad arguments");
+  NR_REQUIRE(d == kD, NR_ERR_UNSUPPORTED, "spmm_blocked: embedding dim %d not built (64)", d);
+  const int64_t nnz = h_indptr[n_rows] - h_indptr[0];
+  NR_REQUIRE(h_indptr[0] == 0 && nnz < ((int64_t)1 << 32), NR_ERR_UNSUPPORTED,
+             "spmm_blocked: indptr must start at 0 and hold < 2^32 non-zeros");
+  NR_REQUIRE(plan_bytes >= blocked_plan_bytes(n_rows, nnz), NR_ERR_WORKSPACE,
+             "spmm_blocked_plan_create: plan buffer %zu < %zu bytes", plan_bytes,
+             blocked_plan_bytes(n_rows, nnz));
+  if (block_bytes <= 0) block_bytes = (int64_t)1 << 40;     // measured: phases cost more than they save
+  if (split_row <= 0 || split_row >= n_rows) split_row = 0;
+  int n_wg = n_workgroups;
+  if (n_wg <= 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    NR_CHECK_HIP(hipGetDevice(&dev));
+    NR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    n_wg = prop.multiProcessorCount * (16 / kWaves);
+  }
+  n_wg = n_wg / 8 * 8;
+  NR_REQUIRE(n_wg >= 8 && n_wg <= 4096, NR_ERR_UNSUPPORTED, "spmm_blocked: %d workgroups", n_wg);
+
+  struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; };
+  std::vector<ClassDesc> classes;
+  if (split_row) {
+    ClassDesc a{0, split_row, {}}, b{split_row, n_rows, {}};
+    for (int w = 0; w < n_wg; ++w) ((w & 7) < 4 ? a : b).wgs.push_back(w);
+    classes.push_back(a);
+    classes.push_back(b);
+  } else {
+    ClassDesc a{0, n_rows, {}};
+    for (int w = 0; w < n_wg; ++w) a.wgs.push_back(w);
+    classes.push_back(a);
+  }
+  std::vector<int32_t> wg_row0(n_wg, 0), wg_nrows(n_wg, 0);
+  std::vector<std::vector<std::vector<HostEnt>>> wg_ent(n_wg);     // [wg][phase][entries]
+  std::vector<std::vector<std::vector<int4>>> wg_cmb(n_wg);
+  int n_phases = 1;
+  for (const ClassDesc& cl : classes) {
+    const int64_t cb = h_indptr[cl.ra], ce = h_indptr[cl.rb];
+    int32_t cmin = INT32_MAX, cmax = -1;
+    for (int64_t t = cb; t < ce; ++t) {
+      cmin = std::min(cmin, h_indices[t]);
+      cmax = std::max(cmax, h_indices[t]);
+    }
+    if (cmax < cmin) { cmin = 0; cmax = 0; }
+    const int64_t span = (int64_t)cmax + 1 - cmin;
+    int64_t K = (span * kD * 4 + block_bytes - 1) / block_bytes;
+    K = std::max<int64_t>(K, 1);
+    NR_REQUIRE(K <= kMaxPhases, NR_ERR_UNSUPPORTED,
+               "spmm_blocked: gathered table of %lld rows needs %lld column blocks (max %d) — "
+               "use the work-item kernel", (long long)span, (long long)K, kMaxPhases);
+    const int64_t width = (span + K - 1) / K;
+    n_phases = std::max<int>(n_phases, (int)K);
+    // contiguous row runs, balanced by non-zeros, at most kRMax rows each
+    int64_t r = cl.ra, left = ce - cb;
+    for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
+      const int w = cl.wgs[wi];
+      const int64_t wgs_left = (int64_t)cl.wgs.size() - (int64_t)wi;
+      const int64_t target = (left + wgs_left - 1) / wgs_left;
+      const int64_t rstart = r;
+      int64_t got = 0;
+      while (r < cl.rb && (r - rstart) < kRMax) {
+        const int64_t l = h_indptr[r + 1] - h_indptr[r];
+        // stop at the non-zero target unless the rows left would overflow the later workgroups
+        const bool must_take = (cl.rb - r) > (wgs_left - 1) * (int64_t)kRMax;
+        if (!must_take && wgs_left > 1 && got > 0 && got + l / 2 > target) break;
+        got += l;
+        ++r;
+      }
+      if (wgs_left == 1)
+        NR_REQUIRE(r == cl.rb, NR_ERR_UNSUPPORTED,
+                   "spmm_blocked: %lld rows do not fit %zu workgroups x %d accumulators — use the "
+                   "work-item kernel", (long long)(cl.rb - cl.ra), cl.wgs.size(), kRMax);
+      left -= got;
+      wg_row0[w] = (int32_t)rstart;
+      wg_nrows[w] = (int32_t)(r - rstart);
+      wg_ent[w].assign((size_t)K, {});
+      wg_cmb[w].assign((size_t)K, {});
+      std::vector<int> pcount((size_t)K, 0);
+      for (int64_t row = rstart; row < r; ++row) {
+        const int32_t slot = (int32_t)(row - rstart);
+        int64_t t = h_indptr[row];
+        const int64_t te = h_indptr[row + 1];
+        while (t < te) {
+          const int64_t k = ((int64_t)h_indices[t] - cmin) / width;
+          int64_t t2 = t + 1;
+          const int64_t col_end = cmin + (k + 1) * width;       // first column of the next block
+          while (t2 < te && h_indices[t2] < col_end) ++t2;
+          const int64_t len = t2 - t;
+          if (len <= kSeg) {
+            wg_ent[w][(size_t)k].push_back(HostEnt{slot, (int32_t)len, (uint32_t)t, slot});
+          } else {
+            const int ns = (int)((len + kSeg - 1) / kSeg);
+            NR_REQUIRE(pcount[(size_t)k] + ns <= kPMax, NR_ERR_UNSUPPORTED,
+                       "spmm_blocked: more than %d hub segments in one workgroup phase — use the "
+                       "work-item kernel", kPMax);
+            const int first = kRMax + pcount[(size_t)k];
+            for (int s = 0; s < ns; ++s)
+              wg_ent[w][(size_t)k].push_back(
+                  HostEnt{first + s, (int32_t)std::min<int64_t>(kSeg, len - (int64_t)s * kSeg),
+                          (uint32_t)(t + (int64_t)s * kSeg), slot});
+            wg_cmb[w][(size_t)k].push_back(make_int4(slot, first, ns, 0));
+            pcount[(size_t)k] += ns;
+          }
+          t = t2;
+        }
+      }
+      for (auto& v : wg_ent[w])
+        std::stable_sort(v.begin(), v.end(), [](const HostEnt& a, const HostEnt& b) { return a.len > b.len; });
+    }
+  }
+  // flatten
+  std::vector<int32_t> ent_off((size_t)n_wg * (n_phases + 1), 0), cmb_off((size_t)n_wg * (n_phases + 1), 0);
+  std::vector<int4> ent, cmb;
+  for (int w = 0; w < n_wg; ++w) {
+    for (int k = 0; k <= n_phases; ++k) {
+      ent_off[(size_t)w * (n_phases + 1) + k] = (int32_t)ent.size();
+      cmb_off[(size_t)w * (n_phases + 1) + k] = (int32_t)cmb.size();
+      if (k < n_phases && (size_t)k < wg_ent[w].size()) {
+        for (const HostEnt& e : wg_ent[w][(size_t)k])
+          ent.push_back(make_int4(e.slot, e.len, (int)e.begin, e.owner));
+        for (const int4& cm : wg_cmb[w][(size_t)k]) cmb.push_back(cm);
+      }
+    }
+  }
+  BlockedPlan* p = new (std::nothrow) BlockedPlan();
+  NR_REQUIRE(p, NR_ERR_ARG, "spmm_blocked_plan_create: out of host memory");
+  p->n_rows = n_rows; p->nnz = nnz; p->n_wg = n_wg; p->n_phases = n_phases;
+  p->seg = kSeg; p->r_max = kRMax; p->p_max = kPMax; p->waves = kWaves;
+  p->n_ent = (int64_t)ent.size(); p->n_cmb = (int64_t)cmb.size();
+  char* q = (char*)d_plan_buf;
+  auto carve = [&](size_t bytes) { void* r = q; q += nr_align_up(bytes, 256); return r; };
+  p->ent = (int4*)carve(ent.size() * 16 + 16);
+  p->cmb = (int4*)carve(cmb.size() * 16 + 16);
+  p->wg_row0 = (int32_t*)carve((size_t)n_wg * 4);
+  p->wg_nrows = (int32_t*)carve((size_t)n_wg * 4);
+  p->wg_ent_off = (int32_t*)carve(ent_off.size() * 4);
+  p->wg_cmb_off = (int32_t*)carve(cmb_off.size() * 4);
+  if ((size_t)(q - (char*)d_plan_buf) > plan_bytes) {
+    delete p;
+    nrhip_set_error("spmm_blocked_plan_create: plan needs %zu bytes, buffer has %zu",
+                    (size_t)(q - (char*)d_plan_buf), plan_bytes);
+    return NR_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipSuccess;
+  auto up = [&](void* dst, const void* src, size_t n) {
+    if (n && e == hipSuccess) e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
+  };
+  up(p->ent, ent.data(), ent.size() * 16);
+  up(p->cmb, cmb.data(), cmb.size() * 16);
+  up(p->wg_row0, wg_row0.data(), wg_row0.size() * 4);
+  up(p->wg_nrows, wg_nrows.data(), wg_nrows.size() * 4);
+  up(p->wg_ent_off, ent_off.data(), ent_off.size() * 4);
+  up(p->wg_cmb_off, cmb_off.data(), cmb_off.size() * 4);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  const int lds = (kRMax + kPMax) * kD * 4;
+  auto allow = [&](const void* fn) {
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  };
+  allow((const void*)spmm_blocked_kernel<false, 16, 8>); allow((const void*)spmm_blocked_kernel<true, 16, 8>);
+  allow((const void*)spmm_blocked_kernel<false, 16, 4>); allow((const void*)spmm_blocked_kernel<true, 16, 4>);
+  allow((const void*)spmm_blocked_kernel<false, 8, 8>); allow((const void*)spmm_blocked_kernel<true, 8, 8>);
+  allow((const void*)spmm_blocked_kernel<false, 8, 4>); allow((const void*)spmm_blocked_kernel<true, 8, 4>);
+  if (e != hipSuccess) {
+    delete p;
+    nrhip_set_error("spmm_blocked_plan_create: %s", hipGetErrorString(e));
+    return NR_ERR_HIP;
+  }
+  *plan_out = p;
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked_tune(int gathers_in_flight) {
+  NR_REQUIRE(gathers_in_flight == 4 || gathers_in_flight == 8, NR_ERR_UNSUPPORTED,
+             "spmm_blocked_tune: gathers in flight %d (4, 8)", gathers_in_flight);
+  s_gathers_in_flight = gathers_in_flight;
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked_plan_destroy(void* plan) {
+  delete (BlockedPlan*)plan;
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked_plan_info(const void* plan, int* n_workgroups, int* n_phases,
+                                 int64_t* n_entries, int64_t* n_split) {
+  NR_REQUIRE(plan, NR_ERR_ARG, "spmm_blocked_plan_info: null plan");
+  const BlockedPlan* p = (const BlockedPlan*)plan;
+  if (n_workgroups) *n_workgroups = p->n_wg;
+  if (n_phases) *n_phases = p->n_phases;
+  if (n_entries) *n_entries = p->n_ent;
+  if (n_split) *n_split = p->n_cmb;
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* d_vals,
+                       const float* d_X, float* d_Y, const float* d_addend, const float* d_sum_in,
+                       float* d_sum_out, const uint8_t* d_x_row_nonzero,
+                       const uint8_t* d_y_row_wanted, void* stream) {
+  NR_REQUIRE(plan && d_indices && d_vals && d_X && (d_Y || d_sum_out), NR_ERR_ARG,
+             "spmm_blocked: null pointer argument");
+  NR_REQUIRE((d_sum_out == nullptr) || (d_sum_in != nullptr), NR_ERR_ARG,
+             "spmm_blocked: sum_out needs sum_in");
+  const BlockedPlan* p = (const BlockedPlan*)plan;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)p->n_wg), block(p->waves * NR_WAVE);
+  const size_t lds = (size_t)(p->r_max + p->p_max) * kD * 4;
+  const bool masked = d_x_row_nonzero || d_y_row_wanted;
+  const int gif = s_gathers_in_flight;
+#define NR_BLK(M, W, GG)                                                                           \
+  hipLaunchKernelGGL((spmm_blocked_kernel<M, W, GG>), grid, block, lds, st, p->wg_row0, p->wg_nrows, \
+                     p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, d_indices, d_vals,   \
+                     (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,                      \
+                     (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,   \
+                     p->r_max)
+  if (p->waves == 16) {
+    if (masked) { if (gif == 4) NR_BLK(true, 16, 4); else NR_BLK(true, 16, 8); }
+    else { if (gif == 4) NR_BLK(false, 16, 4); else NR_BLK(false, 16, 8); }
+  } else {
+    if (masked) { if (gif == 4) NR_BLK(true, 8, 4); else NR_BLK(true, 8, 8); }
+    else { if (gif == 4) NR_BLK(false, 8, 4); else NR_BLK(false, 8, 8); }
+  }
+#undef NR_BLK
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,409 @@
+// spmm_slab.hip — Y = Â·X on column-slab-major embeddings.
+//
+// Layout: an [N][d] fp32 table is stored as S = d/SW slabs, slab s holding columns
+// [s·SW, (s+1)·SW) of every row contiguously: Xs[s][n][SW].  With SW = 16 a slab of the
+// gowalla-shaped table is 70,839 × 64 B = 4.5 MB, and the half of it one class of rows
+// gathers from (user rows read item rows and vice versa) is 2.6 / 1.9 MB — it fits the 4 MB
+// L2 of one XCD.  The launch pins (slab, row class) pairs to XCDs (block b runs on XCD b % 8),
+// so every gather after the first touch of a row is an L2 hit.
+//
+// Work decomposition: one lane group of SW lanes owns one *entry* (a whole row, or one
+// segment of a split hub row); a wave64 carries 64/SW entries at once, so every vector
+// instruction (index broadcast, gather, multiply, add) advances 64/SW non-zeros — the
+// row-major kernel spent ~5 VALU instructions per non-zero on a single row.  Entries are
+// sorted by length within their class at plan time, so the groups of a wave finish together.
+// Products and sums are rounded separately, in ascending column order within an entry.
+#include "nr_common.h"
+#include <algorithm>
+
+namespace {
+
+template <int SW, int WPB, int G>
+__global__ __launch_bounds__(WPB* NR_WAVE) void spmm_slab_kernel(
+    const int32_t* __restrict__ ent_row, const int64_t* __restrict__ ent_begin,
+    const int32_t* __restrict__ ent_len, const int32_t* __restrict__ ent_slot, int n_a, int n_b,
+    const int32_t* __restrict__ indices, const float* __restrict__ vals,
+    const float* __restrict__ Xs, float* __restrict__ Ys, const float* __restrict__ addend,
+    const float* sum_in, float* sum_out, float* __restrict__ partial, int64_t slab_stride, int S) {
+  constexpr int GROUPS = NR_WAVE / SW;
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int c = lane % SW, g = lane / SW;
+  const int P = n_b > 0 ? 2 * S : S;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  int pair, bip;                                   // (slab, class) pair; block index inside it
+  if (P <= 8) {
+    const int rep = 8 / P;
+    pair = xcd % P;
+    bip = j * rep + xcd / P;
+  } else {
+    const int per = P / 8;
+    pair = xcd + 8 * (j % per);
+    bip = j / per;
+  }
+  const int slab = pair % S, cls = pair / S;
+  const int n_cls = cls ? n_b : n_a, base = cls ? n_a : 0;
+  const int64_t e0 = ((int64_t)bip * WPB + wave) * GROUPS;
+  if (e0 >= n_cls) return;
+  const bool live = e0 + g < n_cls;
+  const int64_t e = base + e0 + (live ? g : 0);
+  const int row = ent_row[e];
+  const int len = live ? ent_len[e] : 0;
+  const int slot = ent_slot[e];
+  const int64_t rb = ent_begin[e];
+  int maxlen = len;
+#pragma unroll
+  for (int m = SW; m < NR_WAVE; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m, NR_WAVE));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+
+  const float* __restrict__ X = Xs + (int64_t)slab * slab_stride;
+  const int gbase = lane & ~(SW - 1);
+  float acc = 0.f;
+  for (int k0 = 0; k0 < maxlen; k0 += SW) {
+    int my_idx = 0;
+    float my_val = 0.f;
+    if (k0 + c < len) {
+      my_idx = indices[rb + k0 + c];
+      my_val = vals[rb + k0 + c];
+    }
+    const int nleft = min(SW, maxlen - k0);
+    for (int t0 = 0; t0 < nleft; t0 += G) {
+      float a[G], x[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int src = gbase | ((t0 + u) & (SW - 1));
+        const int col = __shfl(my_idx, src, NR_WAVE);
+        a[u] = __shfl(my_val, src, NR_WAVE);
+        x[u] = X[(uint32_t)col * SW + c];           // past the end: col 0, a 0 (row 0 is L2-hot)
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (k0 + t0 + u < len) acc = __fadd_rn(acc, __fmul_rn(a[u], x[u]));
+    }
+  }
+  if (!live) return;
+  if (slot >= 0) {
+    partial[((int64_t)slot * S + slab) * SW + c] = acc;
+    return;
+  }
+  const int64_t o = (int64_t)slab * slab_stride + (int64_t)row * SW + c;
+  float y = acc;
+  if (addend) y = __fadd_rn(y, addend[o]);
+  if (Ys) Ys[o] = y;
+  if (sum_out) sum_out[o] = __fadd_rn(sum_in[o], y);
+}
+
+// split rows: add the segment partials in segment order
+template <int SW>
+__global__ __launch_bounds__(256) void spmm_slab_fix_kernel(
+    const int32_t* __restrict__ multi_row, const int32_t* __restrict__ multi_first,
+    const int32_t* __restrict__ multi_nseg, int n_multi, const float* __restrict__ partial,
+    float* __restrict__ Ys, const float* __restrict__ addend, const float* sum_in, float* sum_out,
+    int64_t slab_stride, int S) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per = S * SW;
+  if (t >= (int64_t)n_multi * per) return;
+  const int m = (int)(t / per), sc = (int)(t % per), slab = sc / SW, c = sc % SW;
+  const int first = multi_first[m], nseg = multi_nseg[m];
+  float acc = partial[((int64_t)first * S + slab) * SW + c];
+  for (int s = 1; s < nseg; ++s)
+    acc = __fadd_rn(acc, partial[((int64_t)(first + s) * S + slab) * SW + c]);
+  const int64_t o = (int64_t)slab * slab_stride + (int64_t)multi_row[m] * SW + c;
+  float y = acc;
+  if (addend) y = __fadd_rn(y, addend[o]);
+  if (Ys) Ys[o] = y;
+  if (sum_out) sum_out[o] = __fadd_rn(sum_in[o], y);
+}
+
+template <int SW, int WPB, int G>
+int launch_slab(const int32_t* ent_row, const int64_t* ent_begin, const int32_t* ent_len,
+                const int32_t* ent_slot, int n_a, int n_b, const int32_t* multi_row,
+                const int32_t* multi_first, const int32_t* multi_nseg, int n_multi,
+                const int32_t* indices, const float* vals, const float* Xs, int64_t n_rows, int d,
+                float* Ys, const float* addend, const float* sum_in, float* sum_out, float* partial,
+                hipStream_t st) {
+  constexpr int GROUPS = NR_WAVE / SW;
+  const int S = d / SW;
+  const int P = n_b > 0 ? 2 * S : S;
+  const int64_t ents = std::max(n_a, n_b);
+  const int64_t bpp = (ents + (int64_t)GROUPS * WPB - 1) / ((int64_t)GROUPS * WPB);   // blocks per pair
+  int64_t blocks;
+  if (P <= 8) {
+    const int rep = 8 / P;
+    blocks = 8 * ((bpp + rep - 1) / rep);
+  } else {
+    blocks = 8 * bpp * (P / 8);
+  }
+  if (blocks > 0) {
+    hipLaunchKernelGGL((spmm_slab_kernel<SW, WPB, G>), dim3((unsigned)blocks), dim3(WPB * NR_WAVE), 0,
+                       st, ent_row, ent_begin, ent_len, ent_slot, n_a, n_b, indices, vals, Xs, Ys,
+                       addend, sum_in, sum_out, partial, n_rows * SW, S);
+    NR_LAUNCH_CHECK();
+  }
+  if (n_multi > 0) {
+    const int64_t threads = (int64_t)n_multi * d;
+    hipLaunchKernelGGL(spmm_slab_fix_kernel<SW>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       st, multi_row, multi_first, multi_nseg, n_multi, partial, Ys, addend, sum_in,
+                       sum_out, n_rows * SW, S);
+    NR_LAUNCH_CHECK();
+  }
+  return NR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Experimental entry (round 1): entries and split-row tables are built by the caller. */
+int nrhip_spmm_slab(const int32_t* d_ent_row, const int64_t* d_ent_begin, const int32_t* d_ent_len,
+                    const int32_t* d_ent_slot, int n_a, int n_b, const int32_t* d_multi_row,
+                    const int32_t* d_multi_first, const int32_t* d_multi_nseg, int n_multi,
+                    const int32_t* d_indices, const float* d_vals, const float* d_Xs,
+                    int64_t n_rows, int d, int slab_width, int waves_per_block, float* d_Ys,
+                    const float* d_addend, const float* d_sum_in, float* d_sum_out,
+                    float* d_partial, void* stream) {
+  NR_REQUIRE(d_ent_row && d_ent_begin && d_ent_len && d_ent_slot && d_indices && d_vals && d_Xs &&
+                 (d_Ys || d_sum_out),
+             NR_ERR_ARG, "spmm_slab: null pointer argument");
+  NR_REQUIRE(d % slab_width == 0 && n_rows * (int64_t)slab_width < (int64_t)1 << 31, NR_ERR_UNSUPPORTED,
+             "spmm_slab: d %% slab_width != 0 or slab larger than 2^31 floats");
+  hipStream_t st = (hipStream_t)stream;
+#define NR_SLAB(SW, WPB, G)                                                                        \
+  return launch_slab<SW, WPB, G>(d_ent_row, d_ent_begin, d_ent_len, d_ent_slot, n_a, n_b,          \
+                                 d_multi_row, d_multi_first, d_multi_nseg, n_multi, d_indices,      \
+                                 d_vals, d_Xs, n_rows, d, d_Ys, d_addend, d_sum_in, d_sum_out,      \
+                                 d_partial, st)
+  if (slab_width == 8 && waves_per_block == 4) NR_SLAB(8, 4, 8);
+  if (slab_width == 16 && waves_per_block == 4) NR_SLAB(16, 4, 16);
+  if (slab_width == 16 && waves_per_block == 8) NR_SLAB(16, 8, 16);
+  if (slab_width == 16 && waves_per_block == 2) NR_SLAB(16, 2, 16);
+  if (slab_width == 32 && waves_per_block == 4) NR_SLAB(32, 4, 16);
+  if (slab_width == 64 && waves_per_block == 4) NR_SLAB(64, 4, 16);
+#undef NR_SLAB
+  NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "spmm_slab: (slab_width %d, waves %d) not built", slab_width,
+             waves_per_block);
+  return NR_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Micro-benchmark (scripts/exp_gather.py): what bounds random row gathers of a [N][64] fp32
+// table?  Each wave sums `per_wave` listed rows; VEC floats per lane => 64/(64/VEC) ... i.e.
+// VEC = 1: one 256 B row per load instruction; VEC = 2: two rows; VEC = 4: four rows (dwordx4).
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void exp_gather_kernel(const int32_t* __restrict__ ids,
+                                                         int64_t n, int per_wave,
+                                                         const float* __restrict__ T,
+                                                         float* __restrict__ out) {
+  constexpr int LPR = 64 / VEC;             // lanes per row
+  constexpr int RPI = NR_WAVE / LPR;        // rows per load instruction
+  const int lane = nr_lane();
+  const int64_t w = (int64_t)blockIdx.x * 4 + threadIdx.x / NR_WAVE;
+  const int64_t b = w * per_wave;
+  if (b >= n) return;
+  const int len = (int)min((int64_t)per_wave, n - b);
+  const int g = lane / LPR, c = lane % LPR;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  for (int k0 = 0; k0 < len; k0 += NR_WAVE) {
+    const int my = (k0 + lane < len) ? ids[b + k0 + lane] : 0;
+    const int nn = min(NR_WAVE, len - k0);
+    for (int t0 = 0; t0 < nn; t0 += G * RPI) {
+      float x[G][VEC];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int src = min(t0 + u * RPI + g, nn - 1);
+        const int row = (RPI == 1) ? __builtin_amdgcn_readlane(my, min(t0 + u, nn - 1))
+                                   : __shfl(my, src, NR_WAVE);
+        const float* p = T + (int64_t)row * 64 + c * VEC;
+        if constexpr (VEC == 4) {
+          const float4 q = *(const float4*)p;
+          x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
+        } else if constexpr (VEC == 2) {
+          const float2 q = *(const float2*)p;
+          x[u][0] = q.x; x[u][1] = q.y;
+        } else {
+          x[u][0] = *p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += x[u][v];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s += acc[v];
+  out[w * NR_WAVE + lane] = s;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_gather(const int32_t* d_ids, int64_t n, int per_wave, const float* d_T,
+                                int vec, int in_flight, float* d_out, void* stream) {
+  NR_REQUIRE(d_ids && d_T && d_out && n > 0 && per_wave > 0, NR_ERR_ARG, "exp_gather: bad arguments");
+  const int64_t waves = (n + per_wave - 1) / per_wave;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NR_EXP(V, GG)                                                                             \
+  if (vec == V && in_flight == GG) {                                                              \
+    hipLaunchKernelGGL((exp_gather_kernel<V, GG>), grid, block, 0, st, d_ids, n, per_wave, d_T, d_out); \
+    NR_LAUNCH_CHECK();                                                                            \
+    return NR_OK;                                                                                 \
+  }
+  NR_EXP(1, 16) NR_EXP(1, 8) NR_EXP(2, 8) NR_EXP(2, 16) NR_EXP(4, 4) NR_EXP(4, 8) NR_EXP(4, 16)
+#undef NR_EXP
+  NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "exp_gather: (vec %d, in_flight %d) not built", vec, in_flight);
+  return NR_OK;
+}
+
+// Same question for the slab-major layout T[4][N][16]: (slab, class) pairs pinned to XCDs, 64-byte
+// row pieces, VEC floats per lane (16/VEC lanes per piece, 64·VEC/16 pieces per load instruction).
+// ids[0, half) are the gathers of class A (values in [split, N)), ids[half, 2·half) of class B.
+namespace {
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void exp_gather_slab_kernel(const int32_t* __restrict__ ids,
+                                                              int64_t half, int per_wave,
+                                                              const float* __restrict__ T, int64_t N,
+                                                              float* __restrict__ out) {
+  constexpr int LPP = 16 / VEC;             // lanes per 64-byte piece
+  constexpr int PPI = NR_WAVE / LPP;        // pieces per load instruction
+  const int lane = nr_lane();
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slab = xcd & 3, cls = xcd >> 2;
+  const int64_t chunk = (int64_t)j * 4 + threadIdx.x / NR_WAVE;
+  if (chunk * per_wave >= half) return;
+  const int64_t b = cls * half + chunk * per_wave;
+  const int len = (int)min((int64_t)per_wave, half - chunk * per_wave);
+  const int g = lane / LPP, c = lane % LPP;
+  const float* __restrict__ Ts = T + (int64_t)slab * N * 16;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  for (int k0 = 0; k0 < len; k0 += NR_WAVE) {
+    const int my = (k0 + lane < len) ? ids[b + k0 + lane] : 0;
+    const int nn = min(NR_WAVE, len - k0);
+    for (int t0 = 0; t0 < nn; t0 += G * PPI) {
+      float x[G][VEC];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int src = min(t0 + u * PPI + g, nn - 1);
+        const int row = __shfl(my, src, NR_WAVE);
+        const float* p = Ts + (uint32_t)row * 16 + c * VEC;
+        if constexpr (VEC == 4) {
+          const float4 q = *(const float4*)p;
+          x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
+        } else if constexpr (VEC == 2) {
+          const float2 q = *(const float2*)p;
+          x[u][0] = q.x; x[u][1] = q.y;
+        } else {
+          x[u][0] = *p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += x[u][v];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s += acc[v];
+  out[((int64_t)blockIdx.x * 4 + threadIdx.x / NR_WAVE) * NR_WAVE + lane] = s;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_gather_slab(const int32_t* d_ids, int64_t half, int per_wave,
+                                     const float* d_T, int64_t n_rows, int vec, int in_flight,
+                                     float* d_out, void* stream) {
+  NR_REQUIRE(d_ids && d_T && d_out && half > 0 && per_wave > 0, NR_ERR_ARG, "exp_gather_slab: bad arguments");
+  const int64_t chunks = (half + per_wave - 1) / per_wave;
+  dim3 grid((unsigned)(8 * ((chunks + 3) / 4))), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NR_EXP(V, GG)                                                                             \
+  if (vec == V && in_flight == GG) {                                                              \
+    hipLaunchKernelGGL((exp_gather_slab_kernel<V, GG>), grid, block, 0, st, d_ids, half, per_wave, \
+                       d_T, n_rows, d_out);                                                       \
+    NR_LAUNCH_CHECK();                                                                            \
+    return NR_OK;                                                                                 \
+  }
+  NR_EXP(1, 16) NR_EXP(1, 8) NR_EXP(2, 8) NR_EXP(4, 4) NR_EXP(4, 8) NR_EXP(4, 2)
+#undef NR_EXP
+  NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "exp_gather_slab: (vec %d, in_flight %d) not built", vec, in_flight);
+  return NR_OK;
+}
+
+// Column-blocked persistent variant on the ROW-MAJOR [N][64] table: 256 workgroups (one per CU),
+// workgroup b on XCD b % 8; XCDs 0-3 gather from rows [split, N), XCDs 4-7 from rows [0, split).
+// Every workgroup walks K phases; in phase k all its gathers fall in the k-th column block of its
+// class's table, so the XCD's 4 MB L2 only has to hold one block at a time.
+// ids layout: [wg][k][per_phase] (per_phase ids per workgroup and phase).
+namespace {
+template <int VEC, int G, int WAVES>
+__global__ __launch_bounds__(WAVES* NR_WAVE) void exp_gather_blocked_kernel(
+    const int32_t* __restrict__ ids, int K, int per_phase, const float* __restrict__ T,
+    float* __restrict__ out) {
+  constexpr int LPR = 64 / VEC;
+  constexpr int RPI = NR_WAVE / LPR;
+  const int lane = nr_lane(), wave = threadIdx.x / NR_WAVE;
+  const int g = lane / LPR, c = lane % LPR;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  const int share = (per_phase + WAVES - 1) / WAVES;
+  for (int k = 0; k < K; ++k) {
+    const int64_t base = ((int64_t)blockIdx.x * K + k) * per_phase;
+    const int lo = wave * share, hi = min(per_phase, lo + share);
+    for (int k0 = lo; k0 < hi; k0 += NR_WAVE) {
+      const int my = (k0 + lane < hi) ? ids[base + k0 + lane] : 0;
+      const int nn = min(NR_WAVE, hi - k0);
+      for (int t0 = 0; t0 < nn; t0 += G * RPI) {
+        float x[G][VEC];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int src = min(t0 + u * RPI + g, nn - 1);
+          const int row = __shfl(my, src, NR_WAVE);
+          const float* p = T + (int64_t)row * 64 + c * VEC;
+          if constexpr (VEC == 4) {
+            const float4 q = *(const float4*)p;
+            x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
+          } else {
+            x[u][0] = *p;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] += x[u][v];
+      }
+    }
+    __syncthreads();
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s += acc[v];
+  out[((int64_t)blockIdx.x * WAVES + wave) * NR_WAVE + lane] = s;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_gather_blocked(const int32_t* d_ids, int n_wg, int K, int per_phase,
+                                        const float* d_T, int vec, int in_flight, int waves,
+                                        float* d_out, void* stream) {
+  NR_REQUIRE(d_ids && d_T && d_out && K > 0 && per_phase > 0, NR_ERR_ARG, "exp_gather_blocked: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+#define NR_EXP(V, GG, W)                                                                          \
+  if (vec == V && in_flight == GG && waves == W) {                                                \
+    hipLaunchKernelGGL((exp_gather_blocked_kernel<V, GG, W>), dim3(n_wg), dim3(W * NR_WAVE), 0, st, \
+                       d_ids, K, per_phase, d_T, d_out);                                          \
+    NR_LAUNCH_CHECK();                                                                            \
+    return NR_OK;                                                                                 \
+  }
+  NR_EXP(1, 16, 16) NR_EXP(1, 8, 16) NR_EXP(4, 4, 16) NR_EXP(4, 8, 16) NR_EXP(4, 4, 8) NR_EXP(1, 16, 8)
+  NR_EXP(4, 2, 16)
+#undef NR_EXP
+  NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "exp_gather_blocked: variant not built");
+  return NR_OK;
+}

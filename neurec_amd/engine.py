@@ -6,6 +6,7 @@ every computation below is a call into libneurec_hip.so through the C ABI
 CPU and nothing falls back to torch ops.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -331,6 +332,10 @@ class SpmmCSR:
         self.n_cols = self.n_rows if n_cols is None else n_cols
         idx = np.ascontiguousarray(indices, dtype=np.int32)
         val = np.ascontiguousarray(vals, dtype=np.float32)
+        self.h_indices = idx
+        self.split_row = int(split_row)
+        self.blocked = None               # lane-group schedule for d = 64 (built on first use)
+        self._blocked_tried = False
         self.indices = torch.from_numpy(idx if len(idx) else np.zeros(1, np.int32)).to(dev)
         self.vals = torch.from_numpy(val if len(val) else np.zeros(1, np.float32)).to(dev)
         self.indptr = torch.from_numpy(self.h_indptr).to(dev)
@@ -353,11 +358,41 @@ class SpmmCSR:
 
     def __del__(self):
         try:
+            if getattr(self, "blocked", None) is not None and self.blocked.value:
+                _lib.lib.nrhip_spmm_blocked_plan_destroy(self.blocked)
+                self.blocked = None
             if getattr(self, "plan", None) is not None and self.plan.value:
                 _lib.lib.nrhip_spmm_plan_destroy(self.plan)
                 self.plan = C.c_void_p(0)
         except Exception:
             pass
+
+    def ensure_schedule(self, d):
+        """For d == 64 build the persistent lane-group schedule (spmm_blocked.hip) once and attach
+        it to the plan; matrices it does not fit keep the work-item kernel.  NEUREC_SPMM_BLOCKED=0
+        disables it (A/B measurements)."""
+        if d != 64 or self._blocked_tried:
+            return self.blocked is not None
+        self._blocked_tried = True
+        if os.environ.get("NEUREC_SPMM_BLOCKED", "1") == "0" or self.nnz == 0:
+            return False
+        nbytes = C.c_size_t(0)
+        call("nrhip_spmm_blocked_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
+        buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=self.indices.device)
+        plan = C.c_void_p(0)
+        try:
+            call("nrhip_spmm_blocked_plan_create", self.h_indptr.ctypes.data_as(C.c_void_p),
+                 self.h_indices.ctypes.data_as(C.c_void_p), self.n_rows, self.split_row, d, 0, 0, 0,
+                 0, 0, 0, _ptr(buf), buf.numel(), _stream(), C.byref(plan))
+        except NotImplementedError:
+            return False                   # does not fit the schedule: work-item kernel stays
+        self.blocked, self.blocked_buf = plan, buf
+        call("nrhip_spmm_plan_attach_blocked", self.plan, plan)
+        return True
+
+    def exact_row_nnz(self, d):
+        """Rows with at most this many non-zeros are summed strictly in ascending column order."""
+        return 64 if (d == 64 and self.ensure_schedule(d)) else 256
 
     def _workspace(self, d):
         if d not in self._ws:
@@ -373,6 +408,7 @@ class SpmmCSR:
         x_row_nonzero: optional uint8 [n_cols]; 0 promises that row of X is all zero (skipped).
         y_row_wanted: optional uint8 [n_rows]; rows with 0 are not produced (left untouched)."""
         d = X.shape[1]
+        self.ensure_schedule(d)
         ws = self._workspace(d)
         if x_row_nonzero is None and y_row_wanted is None:
             call("nrhip_spmm_csr", self.plan, _ptr(self.indptr), _ptr(self.indices),
@@ -448,6 +484,8 @@ class NativeStep:
     @staticmethod
     def for_lightgcn(eng):
         b = _lib.LightGCNBuffers()
+        eng.A.ensure_schedule(eng.d)
+        eng.At.ensure_schedule(eng.d)
         ws = eng.A._workspace(eng.d)
         wst = eng.At._workspace(eng.d)
         ws = ws if ws.numel() >= wst.numel() else wst
