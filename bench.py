@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--eval-batch", type=int, default=16384)
+    ap.add_argument("--dp-mode", choices=("triplets", "allreduce"), default="triplets",
+                    help="N>1 exchange: all-gather the batch ids (default) or all-reduce dL/dE0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--no-eval", action="store_true")
@@ -111,12 +113,14 @@ def main():
     from neurec_amd.graph import lightgcn_adjacency
     A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
     E0 = synth.xavier_uniform(U + I, args.dim, np.random.RandomState(2017))
-    lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)   # lr, reg: conf/LightGCN.properties
+    exchange = comm.active and args.dp_mode == "triplets"
+    lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,                # lr, reg: conf/LightGCN.properties
+                        args.batch * (comm.world if exchange else 1))
     trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
     sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=args.batch, shuffle=True, seed=2018,
                               rank=comm.rank, world=comm.world)
     loss2 = torch.zeros(2, device=dev)
-    grad_sync = comm.allreduce_sum_ if comm.active else None
+    grad_sync = comm.allreduce_sum_ if (comm.active and not exchange) else None
 
     def batch_stream():
         while True:
@@ -124,13 +128,22 @@ def main():
                 if b[0].numel() == args.batch:          # fixed-size steps for the timed region
                     yield b
     stream = batch_stream()
+    inflight = [comm.allgather_cat_start(next(stream))] if exchange else None
 
     def run_steps(n, loss_out=None):
         # the reference never fetches LightGCN's loss while training (LightGCN.py:173-180), so
         # the timed steps do not reduce it either; it is evaluated once after the timed region
         for _ in range(n):
-            bu, bp, bn = next(stream)
-            lg.step(bu, bp, bn, loss_out, grad_sync=grad_sync)
+            if exchange:
+                # ids of this step were all-gathered while the previous step ran; start the
+                # next step's gather before launching this step
+                token = inflight[0]
+                inflight[0] = comm.allgather_cat_start(next(stream))
+                bu, bp, bn = comm.allgather_cat_finish(token)
+                lg.step(bu, bp, bn, loss_out)
+            else:
+                bu, bp, bn = next(stream)
+                lg.step(bu, bp, bn, loss_out, grad_sync=grad_sync)
 
     run_steps(args.warmup)
     torch.cuda.synchronize(); comm.barrier()
@@ -197,7 +210,10 @@ def main():
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
                                % (args.shape, U, I, train.nnz, args.layers, args.dim, args.batch),
                    "global_batch": comm.world * args.batch,
-                   "parallelism": "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world
+                   "parallelism": ("dp%d (replicated tables; per step one all-gather of 12 B/triplet "
+                                   "of ids, every rank steps on the global batch)" % comm.world
+                                   if exchange else
+                                   "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()],
         "eval": eval_info, "roofline": roofline,

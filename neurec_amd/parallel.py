@@ -4,10 +4,17 @@ for the multi-process tests.
 How the hot path shards:
   * sampler    — every rank owns a contiguous slice of each epoch's triplet stream
                  (units are independent; no exchange).
-  * training   — triplets are data-parallel: tables replicated, each rank back-propagates
-                 its own batch and the dense dL/dE0 is summed with ONE all-reduce per step
-                 (the only exchange step); Adam then runs identically on every rank.  The
-                 result equals the reference run with batch_size = world * B.
+  * training   — tables replicated; the step's one exchange is either
+                 (a) "triplets" (default): every rank samples B triplets, the 12·B bytes of ids
+                     are all-gathered (prefetched one step ahead, so the collective hides behind
+                     the previous step) and every rank runs the step on the world·B global batch —
+                     bit-identical tables on all ranks, no gradient traffic; or
+                 (b) "allreduce": each rank back-propagates its own batch and the dense dL/dE0
+                     ([N][d] fp32) is summed with one all-reduce before Adam.
+                 Both equal the reference run with batch_size = world * B.  The graph
+                 propagation itself is replicated (the whole gowalla-size problem is 0.03 % of
+                 one GPU's HBM): its cost is per step, not per triplet, so more ranks amortise
+                 it over more triplets — DESIGN.md states what that does and does not buy.
   * evaluation — test users are split across ranks (independent units); the metric column
                  sums are all-reduced once at the end.
 """
@@ -34,6 +41,33 @@ class Comm:
         if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
+
+    def allgather_cat_start(self, parts):
+        """Begin all-gathering equal-length 1-D tensors (e.g. a batch's users/pos/neg ids).
+        Returns a token for allgather_cat_finish; the collective runs asynchronously."""
+        if not self.active:
+            return (list(parts), None, None)
+        packed = torch.stack([p.contiguous() for p in parts]).contiguous()        # [P][k]
+        out = torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype,
+                          device=packed.device)
+        if self.backend == "nccl":
+            work = dist.all_gather_into_tensor(out, packed, async_op=True)
+            return (None, out, work)
+        # gloo (tests: CPU tensors, or two ranks sharing one GPU) gathers host tensors only
+        host_in = packed.cpu()
+        host_out = torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype)
+        work = dist.all_gather([host_out[r] for r in range(self.world)], host_in, async_op=True)
+        return (packed.device, host_out, work)
+
+    def allgather_cat_finish(self, token):
+        """-> list of P tensors, each the rank-major concatenation [world * k]."""
+        parts, out, work = token
+        if work is None:
+            return parts
+        work.wait()
+        if parts is not None:                      # gloo path: `parts` holds the target device
+            out = out.to(parts)
+        return [out[:, i, :].reshape(-1).contiguous() for i in range(out.shape[1])]
 
     def max_float(self, x):
         if not self.active:

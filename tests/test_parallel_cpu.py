@@ -92,6 +92,34 @@ def test_two_rank_training_and_eval_match_single_process(tmp_path):
     assert got["slowest"] == 1.0                                             # max over ranks
 
 
+def _gather_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = parallel.init_from_env(backend="gloo")
+    mine = [torch.arange(5, dtype=torch.int32) + 100 * rank + 10 * k for k in range(3)]
+    tok_a = comm.allgather_cat_start(mine)                     # two collectives in flight
+    tok_b = comm.allgather_cat_start([t + 1000 for t in mine])
+    a, b = comm.allgather_cat_finish(tok_a), comm.allgather_cat_finish(tok_b)
+    if rank == 1:
+        np.savez(out, a=torch.stack(a).numpy(), b=torch.stack(b).numpy())
+    comm.barrier()
+    comm.shutdown()
+
+
+def test_triplet_allgather_is_rank_major_concatenation(tmp_path):
+    out = str(tmp_path / "g.npz")
+    mp.start_processes(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True,
+                       start_method="spawn")
+    got = np.load(out)
+    want = np.stack([np.concatenate([np.arange(5) + 100 * r + 10 * k for r in range(2)]) for k in range(3)])
+    np.testing.assert_array_equal(got["a"], want)
+    np.testing.assert_array_equal(got["b"], want + 1000)
+    # single process: the helper is the identity
+    comm = parallel.Comm()
+    parts = [torch.arange(3, dtype=torch.int32)] * 3
+    assert comm.allgather_cat_finish(comm.allgather_cat_start(parts))[1] is parts[1]
+
+
 def test_partition_covers_range_without_overlap():
     for n in (0, 1, 7, 1024, 813886):
         for world in (1, 2, 3, 8):

@@ -29,7 +29,7 @@ def _setup():
     return tr, te, A, E0, U, I
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode="allreduce"):
     import torch
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_DIST_BACKEND="gloo")
@@ -37,13 +37,23 @@ def _worker(rank, world, port, out):
     from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
     comm = parallel.init_from_env()
     tr, te, A, E0, U, I = _setup()
-    lg = LightGCNEngine(A, U, I, E0, 2, 0.01, 1e-3, 256)
+    lg = LightGCNEngine(A, U, I, E0, 2, 0.01, 1e-3, 256 * (world if mode == "triplets" else 1))
     trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
     sampler = BprEpochSampler(trc, I, batch_size=256, seed=5, rank=rank, world=world)
     it = sampler.batches()
-    for _ in range(4):
-        bu, bp, bn = next(it)
-        lg.step(bu, bp, bn, None, grad_sync=comm.allreduce_sum_)
+    if mode == "triplets":                   # ids all-gathered one step ahead, global-batch step
+        token = comm.allgather_cat_start(next(it))
+        for s in range(4):
+            cur = token
+            if s < 3:
+                token = comm.allgather_cat_start(next(it))
+            bu, bp, bn = comm.allgather_cat_finish(cur)
+            assert bu.numel() == 256 * world
+            lg.step(bu, bp, bn, None)
+    else:
+        for _ in range(4):
+            bu, bp, bn = next(it)
+            lg.step(bu, bp, bn, None, grad_sync=comm.allreduce_sum_)
     users = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
     mine = torch.from_numpy(parallel.shard_users(users, rank, world)).cuda()
     eu, ei = lg.final_embeddings()
@@ -56,13 +66,15 @@ def _worker(rank, world, port, out):
     comm.shutdown()
 
 
-def test_two_ranks_equal_one_process_with_doubled_batch(tmp_path):
+@pytest.mark.parametrize("mode", ["allreduce", "triplets"])
+def test_two_ranks_equal_one_process_with_doubled_batch(tmp_path, mode):
     import torch
     import torch.multiprocessing as mp
     from neurec_amd import engine as E
     from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
     out = str(tmp_path / "r0.npz")
-    mp.start_processes(_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, _free_port(), out, mode), nprocs=2, join=True,
+                       start_method="spawn")
     got = np.load(out)
     tr, te, A, E0, U, I = _setup()
     lg = LightGCNEngine(A, U, I, E0, 2, 0.01, 1e-3, 512)
