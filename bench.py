@@ -171,9 +171,18 @@ def main():
     achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
     kernel = ("spmm_blocked_kernel<false,16,8>" if lg.A.blocked is not None
               else "spmm_item_kernel<%d,...>" % args.dim)
+    # traffic: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc pass
+    # over this same command (profiles/r01_pmc_traffic.json, scripts/gpu_pmc.sh) is reported when
+    # it is for the kernel that ran and the default workload, else null
+    traffic = None
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    default_workload = (args.shape, args.scale, args.dim, args.layers) == ("gowalla", 1.0, 64, 3)
+    if default_workload and os.path.isfile(pmc_file):
+        with open(pmc_file) as fh:
+            traffic = json.load(fh).get(kernel, {}).get("traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "bytes_per_launch": spmm_bytes, "us_per_launch": spmm_ms * 1e3,
+                "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, profiles/r01_pmc_traffic.json)", "bytes_per_launch": spmm_bytes, "us_per_launch": spmm_ms * 1e3,
                 "launches_per_step": 2 * args.layers,
                 "step_algorithmic_bytes": lg.step_bytes()}
 
