@@ -380,6 +380,15 @@ int nrhip_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* stream);
 int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
 
+/* Row lookups of a row-sharded table (BASELINE config 4; the reference's tf.nn.embedding_lookup of
+ * LightGCN.py:99-104 and its IndexedSlices gradient when the rows live on another rank):
+ * d_dst[w][0..d) = d_src[d_rows[w]][0..d) (d_dst row stride ld_dst), and the reverse
+ * d_dst[d_rows[w]] += d_src[w] (fp32 atomics, repeats summed). */
+int nrhip_rows_gather(const int32_t* d_rows, int n_listed, int d, const float* d_src, float* d_dst,
+                      int64_t ld_dst, void* stream);
+int nrhip_rows_scatter_add(const int32_t* d_rows, int n_listed, int d, const float* d_src,
+                           int64_t ld_src, float* d_dst, void* stream);
+
 /* y = a*x (+ y0)  elementwise helpers used between propagation passes. */
 int nrhip_scale(const float* d_x, float a, float* d_y, int64_t n, void* stream);
 int nrhip_add(const float* d_x, const float* d_y, float* d_out, int64_t n, void* stream);

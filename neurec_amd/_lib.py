@@ -116,6 +116,8 @@ SIGNATURES = {
     "nrhip_axpy": [f32, p, p, i64, p],
     "nrhip_sumsq_accumulate": [p, i64, p, p],
     "nrhip_mean_f32": [p, i32, p, p],
+    "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
+    "nrhip_rows_scatter_add": [p, i32, i32, p, i64, p, p],
     "nrhip_scale": [p, f32, p, i64, p],
     "nrhip_add": [p, p, p, i64, p],
     "nrhip_div_scalar": [p, f32, p, i64, p],

@@ -96,6 +96,26 @@ __global__ __launch_bounds__(256) void rows_div_kernel(const int32_t* __restrict
   const int64_t r = rows[w];
   for (int k = lane; k < d; k += 64) dst[r * d + k] = src[r * d + k] / denom;
 }
+// dst[w][:] = src[rows[w]][:]  /  dst[rows[w]][:] += src[w][:]  (row lookups of a sharded table)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const int32_t* __restrict__ rows,
+                                                          int n_listed, int d,
+                                                          const float* __restrict__ src,
+                                                          float* __restrict__ dst, int64_t ld_dst) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= n_listed) return;
+  const int64_t r = rows[w];
+  for (int k = lane; k < d; k += 64) dst[(int64_t)w * ld_dst + k] = src[r * d + k];
+}
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int32_t* __restrict__ rows,
+                                                               int n_listed, int d,
+                                                               const float* __restrict__ src,
+                                                               int64_t ld_src,
+                                                               float* __restrict__ dst) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= n_listed) return;
+  const int64_t r = rows[w];
+  for (int k = lane; k < d; k += 64) atomicAdd(&dst[r * d + k], src[(int64_t)w * ld_src + k]);
+}
 __global__ __launch_bounds__(256) void rows_clear_kernel(const int32_t* __restrict__ rows,
                                                          int n_listed, int d, float* b0, float* b1,
                                                          float* b2, float* b3,
@@ -247,6 +267,28 @@ int nrhip_rows_div(const int32_t* d_rows, int n_listed, int d, const float* d_sr
   if (n_listed == 0) return NR_OK;
   hipLaunchKernelGGL(rows_div_kernel, dim3((n_listed + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      d_rows, n_listed, d, d_src, denom, d_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_rows_gather(const int32_t* d_rows, int n_listed, int d, const float* d_src, float* d_dst,
+                      int64_t ld_dst, void* stream) {
+  NR_REQUIRE(d_rows && d_src && d_dst && n_listed >= 0 && d >= 1 && ld_dst >= d, NR_ERR_ARG,
+             "rows_gather: bad arguments");
+  if (n_listed == 0) return NR_OK;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, d_rows, n_listed, d, d_src, d_dst, ld_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_rows_scatter_add(const int32_t* d_rows, int n_listed, int d, const float* d_src,
+                           int64_t ld_src, float* d_dst, void* stream) {
+  NR_REQUIRE(d_rows && d_src && d_dst && n_listed >= 0 && d >= 1 && ld_src >= d, NR_ERR_ARG,
+             "rows_scatter_add: bad arguments");
+  if (n_listed == 0) return NR_OK;
+  hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, d_rows, n_listed, d, d_src, ld_src, d_dst);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -282,6 +282,20 @@ def rows_div(rows, src, denom, dst):
          float(denom), _ptr(dst), _stream())
 
 
+def rows_gather(rows, src, dst):
+    """dst[w, :d] = src[rows[w]] (dst may be a column block of a wider row-major buffer)."""
+    d = src.shape[1]
+    call("nrhip_rows_gather", _ptr(rows, torch.int32), rows.numel(), d, _ptr(src, torch.float32),
+         C.c_void_p(dst.data_ptr()), dst.stride(0), _stream())
+
+
+def rows_scatter_add(rows, src, dst):
+    """dst[rows[w]] += src[w, :d] (fp32 atomics; repeats summed)."""
+    d = dst.shape[1]
+    call("nrhip_rows_scatter_add", _ptr(rows, torch.int32), rows.numel(), d,
+         C.c_void_p(src.data_ptr()), src.stride(0), _ptr(dst, torch.float32), _stream())
+
+
 def rows_clear(rows, d, bufs=(), flag=None):
     b = list(bufs) + [None] * (4 - len(bufs))
     call("nrhip_rows_clear", _ptr(rows, torch.int32), rows.numel(), int(d),

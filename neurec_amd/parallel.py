@@ -69,6 +69,59 @@ class Comm:
             out = out.to(parts)
         return [out[:, i, :].reshape(-1).contiguous() for i in range(out.shape[1])]
 
+    # ---- row-sharded tables (BASELINE config 4) ---------------------------------------------
+    def all_gather_rows(self, local, out):
+        """out[world·n][...] = rank-major concatenation of every rank's `local` [n][...]
+        (identical shape on all ranks).  RCCL all-gather; gloo stages through the host."""
+        if not self.active:
+            out.copy_(local)
+            return out
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(out, local.contiguous())
+            return out
+        host = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype)
+        dist.all_gather([host[r] for r in range(self.world)], local.detach().cpu().contiguous())
+        out.copy_(host.reshape(out.shape))
+        return out
+
+    def all_to_all_rows(self, send, send_counts):
+        """Variable all-to-all of rows: `send` [n][...] is ordered by destination rank,
+        `send_counts[r]` rows go to rank r.  Returns (recv [m][...], recv_counts) ordered by
+        source rank.  RCCL all_to_all_single over xGMI; gloo: host-staged point-to-point."""
+        send_counts = [int(c) for c in send_counts]
+        if not self.active:
+            return send, send_counts
+        tail = tuple(send.shape[1:])
+        if self.backend == "nccl":
+            sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc)
+            recv_counts = [int(c) for c in rc.cpu()]
+            recv = torch.empty((sum(recv_counts),) + tail, dtype=send.dtype, device=send.device)
+            dist.all_to_all_single(recv, send.contiguous(), recv_counts, send_counts)
+            return recv, recv_counts
+        mat = torch.empty((self.world, self.world), dtype=torch.int64)
+        dist.all_gather([mat[r] for r in range(self.world)], torch.tensor(send_counts, dtype=torch.int64))
+        recv_counts = [int(mat[r, self.rank]) for r in range(self.world)]
+        host_send = send.detach().cpu().contiguous()
+        host_recv = torch.empty((sum(recv_counts),) + tail, dtype=send.dtype)
+        reqs, so, ro = [], 0, 0
+        for r in range(self.world):
+            s_chunk = host_send[so:so + send_counts[r]]
+            r_chunk = host_recv[ro:ro + recv_counts[r]]
+            if r == self.rank:
+                r_chunk.copy_(s_chunk)
+            else:
+                if send_counts[r]:
+                    reqs.append(dist.isend(s_chunk.contiguous(), r))
+                if recv_counts[r]:
+                    reqs.append(dist.irecv(r_chunk, r))
+            so += send_counts[r]
+            ro += recv_counts[r]
+        for q in reqs:
+            q.wait()
+        return host_recv.to(send.device), recv_counts
+
     def max_float(self, x):
         if not self.active:
             return float(x)
@@ -100,6 +153,12 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return Comm(rank, world, local_rank, backend)
+
+
+def block_size(n, world):
+    """Rows per rank of the padded block partition used for row-sharded tables: rank r owns
+    global rows [r·b, min((r+1)·b, n)), so an all-gather of the padded blocks is the table."""
+    return (n + world - 1) // world
 
 
 def partition(n, rank, world):

@@ -108,6 +108,10 @@ class LightGCNEngine:
         dev = E.require_gpu()
         self.n_users, self.n_items, self.n_layers = int(n_users), int(n_items), int(n_layers)
         self.N = self.n_users + self.n_items
+        if adj_t_csr is None and not isinstance(adj_csr, E.SpmmCSR):
+            from .graph import is_symmetric, transpose_csr
+            if not is_symmetric(adj_csr):            # 'norm'/'gcmc'/'mean': backward needs A^T
+                adj_t_csr = transpose_csr(adj_csr)
         self.A = adj_csr if isinstance(adj_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_csr, split_row=n_users)
         if adj_t_csr is None:
             self.At = self.A

@@ -137,3 +137,39 @@ def test_single_process_comm_is_a_no_op():
     t = torch.ones(3)
     assert comm.allreduce_sum_(t) is t and not comm.active and comm.max_float(2.5) == 2.5
     comm.barrier()
+
+
+def _rows_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = parallel.init_from_env(backend="gloo")
+    b = parallel.block_size(7, world)                                   # 7 rows over 2 ranks: blocks of 4
+    local = torch.full((b, 3), float(rank + 1))
+    table = torch.zeros(b * world, 3)
+    comm.all_gather_rows(local, table)
+    # rank r sends r+1 rows to rank 0 and 2 rows to rank 1, payload = 10*rank + destination
+    counts = [rank + 1, 2]
+    send = torch.cat([torch.full((c, 2), 10.0 * rank + dst) for dst, c in enumerate(counts)])
+    recv, rc = comm.all_to_all_rows(send, counts)
+    back, bc = comm.all_to_all_rows(recv + 100.0, rc)                  # answers travel the reverse route
+    np.savez(out % rank, table=table.numpy(), recv=recv.numpy(), rc=np.asarray(rc), back=back.numpy(),
+             bc=np.asarray(bc))
+    comm.barrier()
+    comm.shutdown()
+
+
+def test_row_sharding_collectives(tmp_path):
+    """the two exchange primitives of the row-sharded engine (neurec_amd/sharded.py) on gloo"""
+    out = str(tmp_path / "rows%d.npz")
+    mp.start_processes(_rows_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    want_table = np.repeat(np.array([1.0, 2.0]), 4)[:, None] * np.ones((1, 3))
+    np.testing.assert_array_equal(r0["table"], want_table)
+    np.testing.assert_array_equal(r1["table"], want_table)
+    assert r0["rc"].tolist() == [1, 2] and r1["rc"].tolist() == [2, 2]
+    np.testing.assert_array_equal(r0["recv"][:, 0], [0, 10, 10])        # from rank 0 (1 row), rank 1 (2 rows)
+    np.testing.assert_array_equal(r1["recv"][:, 0], [1, 1, 11, 11])
+    assert r0["bc"].tolist() == [1, 2] and r1["bc"].tolist() == [2, 2]
+    np.testing.assert_array_equal(r0["back"][:, 0], [100, 101, 101])     # my rows, answered, in my send order
+    np.testing.assert_array_equal(r1["back"][:, 0], [110, 110, 111, 111])
+    assert parallel.block_size(7, 2) == 4 and parallel.block_size(8, 2) == 4 and parallel.block_size(1, 8) == 1
