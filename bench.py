@@ -37,8 +37,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--eval-batch", type=int, default=16384)
-    ap.add_argument("--dp-mode", choices=("triplets", "allreduce"), default="triplets",
-                    help="N>1 exchange: all-gather the batch ids (default) or all-reduce dL/dE0")
+    ap.add_argument("--dp-mode", choices=("triplets", "allreduce", "rowshard"), default="triplets",
+                    help="N>1 exchange: all-gather the batch ids (default), all-reduce dL/dE0, or "
+                         "row-sharded tables (all-gather per hop + all-to-all lookups; config 4 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--no-eval", action="store_true")
@@ -114,13 +115,18 @@ def main():
     A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
     E0 = synth.xavier_uniform(U + I, args.dim, np.random.RandomState(2017))
     exchange = comm.active and args.dp_mode == "triplets"
-    lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,                # lr, reg: conf/LightGCN.properties
-                        args.batch * (comm.world if exchange else 1))
+    rowshard = args.dp_mode == "rowshard"
+    if rowshard:
+        from neurec_amd.sharded import ShardedLightGCN
+        lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
+    else:
+        lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,            # lr, reg: conf/LightGCN.properties
+                            args.batch * (comm.world if exchange else 1))
     trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
     sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=args.batch, shuffle=True, seed=2018,
                               rank=comm.rank, world=comm.world)
     loss2 = torch.zeros(2, device=dev)
-    grad_sync = comm.allreduce_sum_ if (comm.active and not exchange) else None
+    grad_sync = comm.allreduce_sum_ if (comm.active and not exchange and not rowshard) else None
 
     def batch_stream():
         while True:
@@ -141,6 +147,9 @@ def main():
                 inflight[0] = comm.allgather_cat_start(next(stream))
                 bu, bp, bn = comm.allgather_cat_finish(token)
                 lg.step(bu, bp, bn, loss_out)
+            elif rowshard:
+                bu, bp, bn = next(stream)
+                lg.step(bu, bp, bn, loss_out)
             else:
                 bu, bp, bn = next(stream)
                 lg.step(bu, bp, bn, loss_out, grad_sync=grad_sync)
@@ -160,6 +169,10 @@ def main():
     lg.propagate(); torch.cuda.synchronize()
     ev0.record()
     for _ in range(reps):
+        if rowshard:                                     # local SpMM launches only (no collectives)
+            for k in range(2 * args.layers):
+                lg.A.matmul(lg.X, out=(lg.Ya, lg.Yb)[k % 2], addend=lg.H)
+            continue
         lg.propagate()                                   # L forward launches
         g = lg.H
         for k in range(args.layers):                     # L backward launches
@@ -184,7 +197,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, profiles/r01_pmc_traffic.json)", "bytes_per_launch": spmm_bytes, "us_per_launch": spmm_ms * 1e3,
                 "launches_per_step": 2 * args.layers,
-                "step_algorithmic_bytes": lg.step_bytes()}
+                "step_algorithmic_bytes": lg.step_bytes() if hasattr(lg, "step_bytes") else None}
 
     # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)
     eval_info = None
@@ -222,6 +235,8 @@ def main():
                    "parallelism": ("dp%d (replicated tables; per step one all-gather of 12 B/triplet "
                                    "of ids, every rank steps on the global batch)" % comm.world
                                    if exchange else
+                                   "rowshard%d (tables row-sharded; all-gather per hop, all-to-all "
+                                   "row lookups, owner-local Adam)" % comm.world if rowshard else
                                    "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()],
