@@ -380,6 +380,33 @@ int nrhip_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* stream);
 int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
 
+/* ---- the other losses and optimisers of util/learner.py (MF.py:62-76 with is_pairwise /
+ * loss_function / learner other than bpr + adam) ----------------------------------------------
+ * Same contract as nrhip_bpr_mf_grad (dense zeroed d_GP/d_GQ, d_terms scratch of 2*batch floats,
+ * d_loss2 = {data loss, reg * l2}).
+ *   pairwise loss_kind  (learner.py:19-29):  0 bpr  1 hinge = sum max(y+1, 0)  2 square = sum (1-y)^2
+ *   pointwise loss_kind (learner.py:31-41):  0 cross_entropy = tf.losses.sigmoid_cross_entropy (batch
+ *                        MEAN)  1 square = sum (label - x)^2;  instances are (user, item, label) as
+ *                        PointwiseSampler yields them (data/sampler.py:93-155); regulariser
+ *                        l2_loss(p, q) (MF.py:71-72).
+ * nrhip_optimizer_rows_tf applies the TF-1.12 *sparse* update of learner.py:2-16 to the rows flagged
+ * in d_row_flag (set with nrhip_mark_rows; cleared again here, like the gradient rows):
+ *   kind 0 gd; 1 adagrad (slot0 = accumulator, initialise to 1e-8); 2 rmsprop (slot0 = ms
+ *   initialised to 1, slot1 = mom initialised to 0, hyper1 = decay 0.9, hyper2 = momentum 0,
+ *   eps 1e-10); 3 momentum (slot0 = accumulator, hyper1 = momentum 0.9). */
+int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                           const int32_t* d_pos, const int32_t* d_neg, int batch, float reg,
+                           int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
+                           void* stream);
+int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                            const int32_t* d_items, const float* d_labels, int batch, float reg,
+                            int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
+                            void* stream);
+int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, void* stream);
+int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
+                            uint8_t* d_row_flag, int64_t n_rows, int d, float lr, float hyper1,
+                            float hyper2, float eps, void* stream);
+
 /* Row lookups of a row-sharded table (BASELINE config 4; the reference's tf.nn.embedding_lookup of
  * LightGCN.py:99-104 and its IndexedSlices gradient when the rows live on another rank):
  * d_dst[w][0..d) = d_src[d_rows[w]][0..d) (d_dst row stride ld_dst), and the reverse

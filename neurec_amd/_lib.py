@@ -116,6 +116,10 @@ SIGNATURES = {
     "nrhip_axpy": [f32, p, p, i64, p],
     "nrhip_sumsq_accumulate": [p, i64, p, p],
     "nrhip_mean_f32": [p, i32, p, p],
+    "nrhip_pairwise_mf_grad": [p, p, i32, p, p, p, i32, f32, i32, p, p, p, p, p],
+    "nrhip_pointwise_mf_grad": [p, p, i32, p, p, p, i32, f32, i32, p, p, p, p, p],
+    "nrhip_mark_rows": [p, i32, i32, p, p],
+    "nrhip_optimizer_rows_tf": [i32, p, p, p, p, p, i64, i32, f32, f32, f32, f32, p],
     "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
     "nrhip_rows_scatter_add": [p, i32, i32, p, i64, p, p],
     "nrhip_scale": [p, f32, p, i64, p],

@@ -96,6 +96,65 @@ __global__ __launch_bounds__(256) void rows_div_kernel(const int32_t* __restrict
   const int64_t r = rows[w];
   for (int k = lane; k < d; k += 64) dst[r * d + k] = src[r * d + k] / denom;
 }
+// ---- the other optimisers of util/learner.py:2-16, TF-1.12 sparse application ------------------
+// (GradientDescent scatter_sub, SparseApplyAdagrad, SparseApplyRMSProp, SparseApplyMomentum):
+// only the rows a batch touched move.  grad is a dense [n_rows][d] buffer holding the summed
+// row gradients (zero elsewhere); flag[row] != 0 marks the touched rows.  One wave per row;
+// the row's gradient and flag are cleared on the way out.
+//   gd        var -= lr*g
+//   adagrad   a += g*g;                       var -= (lr*g) * rsqrt(a)          (a starts at 1e-8)
+//   rmsprop   ms = ms*rho + (g*g)*(1-rho);    mom = mom*momentum + rsqrt(ms+eps)*lr*g;  var -= mom
+//             (ms starts at 1, rho = 0.9, momentum = 0, eps = 1e-10: tf.train.RMSPropOptimizer(lr))
+//   momentum  a = a*momentum + g;             var -= a*lr
+enum { OPT_GD = 0, OPT_ADAGRAD = 1, OPT_RMSPROP = 2, OPT_MOMENTUM = 3 };
+template <int KIND>
+__global__ __launch_bounds__(256) void optimizer_rows_kernel(float* __restrict__ var,
+                                                             float* __restrict__ s0,
+                                                             float* __restrict__ s1,
+                                                             float* __restrict__ grad,
+                                                             uint8_t* __restrict__ flag,
+                                                             int64_t n_rows, int d, float lr,
+                                                             float h1, float h2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += stride) {
+    if (flag[r] == 0) continue;
+    for (int k = lane; k < d; k += 64) {
+      const int64_t o = r * d + k;
+      const float g = grad[o];
+      float v = var[o];
+      if (KIND == OPT_GD) {
+        v = __fsub_rn(v, __fmul_rn(lr, g));
+      } else if (KIND == OPT_ADAGRAD) {
+        const float a = __fadd_rn(s0[o], __fmul_rn(g, g));
+        s0[o] = a;
+        v = __fsub_rn(v, __fmul_rn(__fmul_rn(lr, g), 1.0f / sqrtf(a)));
+      } else if (KIND == OPT_RMSPROP) {
+        const float ms = __fadd_rn(__fmul_rn(s0[o], h1), __fmul_rn(__fmul_rn(g, g), 1.0f - h1));
+        s0[o] = ms;
+        const float mom = __fadd_rn(__fmul_rn(s1[o], h2),
+                                    __fmul_rn(__fmul_rn(1.0f / sqrtf(__fadd_rn(ms, eps)), lr), g));
+        s1[o] = mom;
+        v = __fsub_rn(v, mom);
+      } else {
+        const float a = __fadd_rn(__fmul_rn(s0[o], h1), g);
+        s0[o] = a;
+        v = __fsub_rn(v, __fmul_rn(a, lr));
+      }
+      var[o] = v;
+      grad[o] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) flag[r] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void mark_rows_kernel(const int32_t* __restrict__ ids, int n,
+                                                        int offset, uint8_t* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[(int64_t)ids[i] + offset] = 1;
+}
+
 // dst[w][:] = src[rows[w]][:]  /  dst[rows[w]][:] += src[w][:]  (row lookups of a sharded table)
 __global__ __launch_bounds__(256) void rows_gather_kernel(const int32_t* __restrict__ rows,
                                                           int n_listed, int d,
@@ -267,6 +326,41 @@ int nrhip_rows_div(const int32_t* d_rows, int n_listed, int d, const float* d_sr
   if (n_listed == 0) return NR_OK;
   hipLaunchKernelGGL(rows_div_kernel, dim3((n_listed + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      d_rows, n_listed, d, d_src, denom, d_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, void* stream) {
+  NR_REQUIRE(d_ids && d_flag && n >= 0, NR_ERR_ARG, "mark_rows: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(mark_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     d_ids, n, offset, d_flag);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
+                            uint8_t* d_row_flag, int64_t n_rows, int d, float lr, float hyper1,
+                            float hyper2, float eps, void* stream) {
+  NR_REQUIRE(d_var && d_grad && d_row_flag && n_rows >= 0 && d >= 1, NR_ERR_ARG,
+             "optimizer_rows_tf: bad arguments");
+  NR_REQUIRE(kind >= OPT_GD && kind <= OPT_MOMENTUM, NR_ERR_ARG,
+             "optimizer_rows_tf: unknown optimiser %d (0 gd, 1 adagrad, 2 rmsprop, 3 momentum)", kind);
+  NR_REQUIRE(kind == OPT_GD || d_slot0, NR_ERR_ARG, "optimizer_rows_tf: slot buffer missing");
+  NR_REQUIRE(kind != OPT_RMSPROP || d_slot1, NR_ERR_ARG, "optimizer_rows_tf: rmsprop needs two slots");
+  if (n_rows == 0) return NR_OK;
+  int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NR_OPT(K)                                                                                  \
+  hipLaunchKernelGGL(optimizer_rows_kernel<K>, grid, block, 0, st, d_var, d_slot0, d_slot1, d_grad, \
+                     d_row_flag, n_rows, d, lr, hyper1, hyper2, eps)
+  if (kind == OPT_GD) NR_OPT(OPT_GD);
+  else if (kind == OPT_ADAGRAD) NR_OPT(OPT_ADAGRAD);
+  else if (kind == OPT_RMSPROP) NR_OPT(OPT_RMSPROP);
+  else NR_OPT(OPT_MOMENTUM);
+#undef NR_OPT
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

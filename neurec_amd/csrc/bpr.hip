@@ -44,7 +44,8 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, int d,
     const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ GP,
-    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2) {
+    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
+    int loss_kind) {
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int b = blockIdx.x * kWavesPerBlock + wave;
   if (b >= batch) return;
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
   load_row<CPL>(Q, j, d, lane, qj);
   const float x = dot_rows<CPL>(p, qi) - dot_rows<CPL>(p, qj);      // MF.py:59,67
   const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(qj, qj) + dot_rows<CPL>(qi, qi));
-  const float g = nr::bpr_dloss(x);
+  const float g = nr::pairwise_dloss(loss_kind, x);
   if (lane == 0) {
-    term_mf[b] = nr::bpr_loss(x);
+    term_mf[b] = nr::pairwise_loss(loss_kind, x);
     term_l2[b] = l2;
   }
 #pragma unroll
@@ -69,6 +70,40 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
       atomicAdd(&GP[u * d + k], g * (qi[c] - qj[c]) + reg * p[c]);
       atomicAdd(&GQ[i * d + k], g * p[c] + reg * qi[c]);
       atomicAdd(&GQ[j * d + k], -g * p[c] + reg * qj[c]);
+    }
+  }
+}
+
+// ---- pointwise MF (is_pairwise=False, MF.py:70-72): (user, item, label) instances ---------------
+template <int CPL>
+__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void pointwise_mf_grad_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, int d,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+    const float* __restrict__ labels, int batch, float reg, float scale, float* __restrict__ GP,
+    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
+    int loss_kind) {
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int b = blockIdx.x * kWavesPerBlock + wave;
+  if (b >= batch) return;
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = __builtin_amdgcn_readfirstlane(items[b]);
+  const float z = labels[b];
+  float p[CPL], q[CPL];
+  load_row<CPL>(P, u, d, lane, p);
+  load_row<CPL>(Q, i, d, lane, q);
+  const float x = dot_rows<CPL>(p, q);                               // MF.py:59
+  const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(q, q));
+  const float g = nr::pointwise_dloss(loss_kind, z, x) * scale;
+  if (lane == 0) {
+    term_mf[b] = nr::pointwise_loss(loss_kind, z, x) * scale;
+    term_l2[b] = l2;
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    if (k < d) {
+      atomicAdd(&GP[u * d + k], g * q[c] + reg * p[c]);
+      atomicAdd(&GQ[i * d + k], g * p[c] + reg * q[c]);
     }
   }
 }
@@ -160,14 +195,16 @@ __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restric
 
 extern "C" {
 
-int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                      const int32_t* d_pos, const int32_t* d_neg, int batch, float reg, float* d_GP,
-                      float* d_GQ, float* d_terms, float* d_loss2, void* stream) {
+static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q, int d,
+                            const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                            int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
+                            float* d_terms, float* d_loss2, void* stream) {
   NR_REQUIRE(d_P && d_Q && d_users && d_pos && d_neg && d_GP && d_GQ && d_terms && d_loss2,
-             NR_ERR_ARG, "bpr_mf_grad: null pointer argument");
-  NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED, "bpr_mf_grad: embedding dim %d outside 1..256",
-             d);
-  NR_REQUIRE(batch >= 0, NR_ERR_ARG, "bpr_mf_grad: negative batch");
+             NR_ERR_ARG, "%s: null pointer argument", who);
+  NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED, "%s: embedding dim %d outside 1..256", who, d);
+  NR_REQUIRE(batch >= 0, NR_ERR_ARG, "%s: negative batch", who);
+  NR_REQUIRE(loss_kind >= nr::NR_PAIR_BPR && loss_kind <= nr::NR_PAIR_SQUARE, NR_ERR_ARG,
+             "%s: unknown pairwise loss %d (0 bpr, 1 hinge, 2 square)", who, loss_kind);
   hipStream_t st = (hipStream_t)stream;
   if (batch == 0) {
     NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
@@ -178,13 +215,65 @@ int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* 
   dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
   if (d <= 64)
     hipLaunchKernelGGL(bpr_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2);
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind);
   else if (d <= 128)
     hipLaunchKernelGGL(bpr_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2);
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind);
   else
     hipLaunchKernelGGL(bpr_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2);
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
+                     d_loss2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                      const int32_t* d_pos, const int32_t* d_neg, int batch, float reg, float* d_GP,
+                      float* d_GQ, float* d_terms, float* d_loss2, void* stream) {
+  return pairwise_mf_grad("bpr_mf_grad", d_P, d_Q, d, d_users, d_pos, d_neg, batch, reg,
+                          nr::NR_PAIR_BPR, d_GP, d_GQ, d_terms, d_loss2, stream);
+}
+
+int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                           const int32_t* d_pos, const int32_t* d_neg, int batch, float reg,
+                           int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
+                           void* stream) {
+  return pairwise_mf_grad("pairwise_mf_grad", d_P, d_Q, d, d_users, d_pos, d_neg, batch, reg,
+                          loss_kind, d_GP, d_GQ, d_terms, d_loss2, stream);
+}
+
+int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
+                            const int32_t* d_items, const float* d_labels, int batch, float reg,
+                            int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
+                            void* stream) {
+  NR_REQUIRE(d_P && d_Q && d_users && d_items && d_labels && d_GP && d_GQ && d_terms && d_loss2,
+             NR_ERR_ARG, "pointwise_mf_grad: null pointer argument");
+  NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
+             "pointwise_mf_grad: embedding dim %d outside 1..256", d);
+  NR_REQUIRE(batch >= 0, NR_ERR_ARG, "pointwise_mf_grad: negative batch");
+  NR_REQUIRE(loss_kind == nr::NR_POINT_CROSS_ENTROPY || loss_kind == nr::NR_POINT_SQUARE, NR_ERR_ARG,
+             "pointwise_mf_grad: unknown pointwise loss %d (0 cross_entropy, 1 square)", loss_kind);
+  hipStream_t st = (hipStream_t)stream;
+  if (batch == 0) {
+    NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+    return NR_OK;
+  }
+  float* t_mf = d_terms;
+  float* t_l2 = d_terms + batch;
+  // tf.losses.sigmoid_cross_entropy averages over the batch; the squared loss is a plain sum
+  const float scale = loss_kind == nr::NR_POINT_CROSS_ENTROPY ? 1.0f / (float)batch : 1.0f;
+  dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  if (d <= 64)
+    hipLaunchKernelGGL(pointwise_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
+                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+  else if (d <= 128)
+    hipLaunchKernelGGL(pointwise_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
+                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+  else
+    hipLaunchKernelGGL(pointwise_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
+                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
                      d_loss2);

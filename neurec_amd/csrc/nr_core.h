@@ -299,6 +299,39 @@ NR_HD float bpr_loss(float x) { return tf_softplus(-x); }
 NR_HD float bpr_dloss(float x) { return -1.0f / (1.0f + expf(x)); }
 
 // ----------------------------------------------------------------------------
+// The other losses of util/learner.py, per element, and their derivative w.r.t. the logit.
+//   pairwise  (learner.py:19-29), y = x_pos - x_neg, all summed over the batch:
+//       bpr    -log_sigmoid(y)
+//       hinge  max(y + 1, 0)        (as written in the reference: margin added, not subtracted)
+//       square (1 - y)^2
+//   pointwise (learner.py:31-41), z = label, x = logit:
+//       cross_entropy  tf.losses.sigmoid_cross_entropy = MEAN over the batch of
+//                      max(x,0) - x*z + log1p(exp(-|x|));   d/dx = sigmoid(x) - z
+//       square         sum of (z - x)^2
+// ----------------------------------------------------------------------------
+enum { NR_PAIR_BPR = 0, NR_PAIR_HINGE = 1, NR_PAIR_SQUARE = 2 };
+enum { NR_POINT_CROSS_ENTROPY = 0, NR_POINT_SQUARE = 1 };
+
+NR_HD float pairwise_loss(int kind, float y) {
+  if (kind == NR_PAIR_BPR) return bpr_loss(y);
+  if (kind == NR_PAIR_HINGE) return fmaxf(y + 1.0f, 0.0f);
+  return (1.0f - y) * (1.0f - y);
+}
+NR_HD float pairwise_dloss(int kind, float y) {
+  if (kind == NR_PAIR_BPR) return bpr_dloss(y);
+  if (kind == NR_PAIR_HINGE) return (y + 1.0f > 0.0f) ? 1.0f : 0.0f;
+  return -2.0f * (1.0f - y);
+}
+NR_HD float pointwise_loss(int kind, float z, float x) {
+  if (kind == NR_POINT_CROSS_ENTROPY) return fmaxf(x, 0.0f) - x * z + log1pf(expf(-fabsf(x)));
+  return (z - x) * (z - x);
+}
+NR_HD float pointwise_dloss(int kind, float z, float x) {
+  if (kind == NR_POINT_CROSS_ENTROPY) return 1.0f / (1.0f + expf(-x)) - z;
+  return -2.0f * (z - x);
+}
+
+// ----------------------------------------------------------------------------
 // Adam, TF-1.12 arithmetic [EXT].  `alpha` = lr*sqrt(1-b2^t)/(1-b1^t) (fp32,
 // computed by the caller from running fp32 powers); eps is added outside the
 // bias correction.  No fused multiply-adds: each product/sum is rounded like

@@ -132,3 +132,92 @@ class PointwiseSampler(Sampler):
         if self.drop_last:
             return n_sample // self.batch_size
         return (n_sample + self.batch_size - 1) // self.batch_size
+
+
+def _generative_time_order_positive_items(user_pos_dict, high_order=1):
+    """Sliding windows over each user's time-ordered sequence (data/sampler.py:42-68): instance k
+    of a user pairs the `high_order` items starting at position k with the item that follows."""
+    if high_order <= 0:
+        raise ValueError("'high_order' must be a positive integer.")
+    if not isinstance(user_pos_dict, dict):
+        raise TypeError("'user_pos_dict' must be a dict.")
+    if not user_pos_dict:
+        raise ValueError("'user_pos_dict' cannot be empty.")
+    users_list, recent_items_list, pos_items_list, user_pos_len = [], [], [], []
+    for user, seq_items in user_pos_dict.items():
+        num_instance = len(seq_items) - high_order
+        if num_instance <= 0:
+            continue
+        user_pos_len.append([user, num_instance])
+        users_list.extend([user] * num_instance)
+        if high_order == 1:
+            recent_items_list.extend(seq_items[:num_instance])
+        else:
+            recent_items_list.extend([list(seq_items[k:k + high_order]) for k in range(num_instance)])
+        pos_items_list.extend(seq_items[high_order:])
+    return user_pos_len, users_list, recent_items_list, pos_items_list
+
+
+class _TimeOrderBase(Sampler):
+    def __init__(self, dataset, high_order, neg_num, batch_size, shuffle, drop_last):
+        if high_order < 0:
+            raise ValueError("'high_order' must be a positive integer.")
+        if neg_num <= 0:
+            raise ValueError("'neg_num' must be a positive integer.")
+        self.batch_size = batch_size
+        self.drop_last = drop_last
+        self.shuffle = shuffle
+        self.neg_num = neg_num
+        self.item_num = dataset.num_items
+        self.user_pos_dict = dataset.get_user_train_dict(by_time=True)
+
+    def __len__(self):
+        n_sample = len(self.users_list)
+        if self.drop_last:
+            return n_sample // self.batch_size
+        return (n_sample + self.batch_size - 1) // self.batch_size
+
+
+class TimeOrderPointwiseSampler(_TimeOrderBase):
+    """`(user, recent_items, item, label)`; negatives exclude the user's whole train sequence and
+    are drawn on the device (data/sampler.py:216-289)."""
+
+    def __init__(self, dataset, high_order=1, neg_num=1, batch_size=1024, shuffle=True, drop_last=False):
+        super(TimeOrderPointwiseSampler, self).__init__(dataset, high_order, neg_num, batch_size,
+                                                        shuffle, drop_last)
+        self.user_pos_len, users_list, recent_items_list, self.pos_items_list = \
+            _generative_time_order_positive_items(self.user_pos_dict, high_order=high_order)
+        self.users_list = users_list * (self.neg_num + 1)
+        self.recent_items_list = recent_items_list * (self.neg_num + 1)
+        n_pos = len(self.pos_items_list)
+        self.all_labels = [1.0] * n_pos + [0.0] * (n_pos * self.neg_num)
+
+    def __iter__(self):
+        neg_items_list = _sampling_negative_items(self.user_pos_len, self.neg_num,
+                                                  self.item_num, self.user_pos_dict)
+        neg_items = np.reshape(np.array(neg_items_list, dtype=np.int32).T, [-1]).tolist()
+        data_iter = DataIterator(self.users_list, self.recent_items_list,
+                                 self.pos_items_list + neg_items, self.all_labels,
+                                 batch_size=self.batch_size, shuffle=self.shuffle,
+                                 drop_last=self.drop_last)
+        for bat_users, bat_recent, bat_next, bat_labels in data_iter:
+            yield bat_users, bat_recent, bat_next, bat_labels
+
+
+class TimeOrderPairwiseSampler(_TimeOrderBase):
+    """`(user, recent_items, next_item, neg_items)` (data/sampler.py:292-354)."""
+
+    def __init__(self, dataset, high_order=1, neg_num=1, batch_size=1024, shuffle=True, drop_last=False):
+        super(TimeOrderPairwiseSampler, self).__init__(dataset, high_order, neg_num, batch_size,
+                                                       shuffle, drop_last)
+        self.user_pos_len, self.users_list, self.recent_items_list, self.pos_items_list = \
+            _generative_time_order_positive_items(self.user_pos_dict, high_order=high_order)
+
+    def __iter__(self):
+        neg_items_list = _sampling_negative_items(self.user_pos_len, self.neg_num,
+                                                  self.item_num, self.user_pos_dict)
+        data_iter = DataIterator(self.users_list, self.recent_items_list, self.pos_items_list,
+                                 neg_items_list, batch_size=self.batch_size, shuffle=self.shuffle,
+                                 drop_last=self.drop_last)
+        for bat_users, bat_recent, bat_pos, bat_neg in data_iter:
+            yield bat_users, bat_recent, bat_pos, bat_neg

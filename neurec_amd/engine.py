@@ -309,6 +309,37 @@ def bpr_mf_grad(P, Q, users, pos, neg, reg, GP, GQ, terms, loss2):
          float(reg), _ptr(GP), _ptr(GQ), _ptr(terms), _ptr(loss2), _stream())
 
 
+PAIRWISE_LOSSES = {"bpr": 0, "hinge": 1, "square": 2}                # learner.py:19-29
+POINTWISE_LOSSES = {"cross_entropy": 0, "square": 1}                  # learner.py:31-41
+ROW_OPTIMIZERS = {"gd": 0, "adagrad": 1, "rmsprop": 2, "momentum": 3}  # learner.py:2-16 (adam: adam_sparse)
+
+
+def pairwise_mf_grad(P, Q, users, pos, neg, reg, loss, GP, GQ, terms, loss2):
+    call("nrhip_pairwise_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
+         _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32), users.numel(),
+         float(reg), PAIRWISE_LOSSES[loss], _ptr(GP), _ptr(GQ), _ptr(terms), _ptr(loss2), _stream())
+
+
+def pointwise_mf_grad(P, Q, users, items, labels, reg, loss, GP, GQ, terms, loss2):
+    call("nrhip_pointwise_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
+         _ptr(users, torch.int32), _ptr(items, torch.int32), _ptr(labels, torch.float32),
+         users.numel(), float(reg), POINTWISE_LOSSES[loss], _ptr(GP), _ptr(GQ), _ptr(terms),
+         _ptr(loss2), _stream())
+
+
+def mark_rows(ids, flag, offset=0):
+    call("nrhip_mark_rows", _ptr(ids, torch.int32), ids.numel(), int(offset), _ptr(flag, torch.uint8),
+         _stream())
+
+
+def optimizer_rows(kind, var, slot0, slot1, grad, flag, lr, hyper1=0.0, hyper2=0.0, eps=0.0):
+    """TF-1.12 sparse update of the flagged rows (learner.py:2-16); clears grad rows and flags."""
+    call("nrhip_optimizer_rows_tf", ROW_OPTIMIZERS[kind], _ptr(var, torch.float32),
+         _ptr(slot0, torch.float32, allow_none=True), _ptr(slot1, torch.float32, allow_none=True),
+         _ptr(grad, torch.float32), _ptr(flag, torch.uint8), var.shape[0], var.shape[1], float(lr),
+         float(hyper1), float(hyper2), float(eps), _stream())
+
+
 def lightgcn_mark_batch(users, pos, neg, n_users, rows_out, row_flag):
     """rows_out[3B] = users | n_users+pos | n_users+neg; row_flag[those] = 1."""
     call("nrhip_lightgcn_mark_batch", _ptr(users, torch.int32), _ptr(pos, torch.int32),

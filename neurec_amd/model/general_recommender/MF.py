@@ -10,7 +10,7 @@ from time import time
 
 import numpy as np
 
-from ...data import PairwiseSampler
+from ...data import PairwiseSampler, PointwiseSampler
 from ...util import timer
 from ...util.tool import get_initializer
 from ..AbstractRecommender import AbstractRecommender
@@ -39,29 +39,40 @@ class MF(AbstractRecommender):
         self.engine = None
 
     def build_graph(self):
-        from ...trainer import MFEngine
-        if self.is_pairwise is not True or str(self.loss_function).lower() != "bpr":
-            raise NotImplementedError("the HIP MF engine implements the pairwise BPR loss "
-                                      "(is_pairwise=True, loss_function=bpr)")
-        if str(self.learner).lower() != "adam":
-            raise NotImplementedError("the HIP MF engine implements learner=adam")
+        from ...trainer import GeneralMFEngine, MFEngine
         init = get_initializer(self.init_method, self.stddev, seed=2017)   # main.py:12
         users = init([self.num_users, self.embedding_size])
         items = init([self.num_items, self.embedding_size])
-        self.engine = MFEngine(users, items, self.learning_rate, self.reg_mf, self.batch_size)
+        self._fast = (self.is_pairwise is True and str(self.loss_function).lower() == "bpr"
+                      and str(self.learner).lower() == "adam")
+        if self._fast:                         # conf/MF.properties as shipped: one native call per step
+            self.engine = MFEngine(users, items, self.learning_rate, self.reg_mf, self.batch_size)
+        else:                                  # the other losses / optimisers of util/learner.py
+            self.engine = GeneralMFEngine(users, items, self.learning_rate, self.reg_mf,
+                                          self.batch_size, loss=self.loss_function,
+                                          pairwise=self.is_pairwise is True, learner=self.learner)
 
     # ---------- training process -------
     def train_model(self):
         import torch
         self.logger.info(self.evaluator.metrics_info())
-        data_iter = PairwiseSampler(self.dataset, neg_num=1, batch_size=self.batch_size,
-                                    shuffle=True, as_tensors=True)
-        losses = torch.zeros((max(len(data_iter), 1), 2), device=self.engine.P.device)
+        dev = self.engine.P.device
+        if self.is_pairwise is True:           # MF.py:88-93
+            data_iter = PairwiseSampler(self.dataset, neg_num=1, batch_size=self.batch_size,
+                                        shuffle=True, as_tensors=True)
+        else:
+            data_iter = PointwiseSampler(self.dataset, neg_num=self.num_negatives,
+                                         batch_size=self.batch_size, shuffle=True)
+        losses = torch.zeros((max(len(data_iter), 1), 2), device=dev)
         for epoch in range(1, self.num_epochs + 1):
             training_start_time = time()
             n = 0
-            for bat_users, bat_items_pos, bat_items_neg in data_iter:
-                self.engine.step(bat_users, bat_items_pos, bat_items_neg, losses[n])
+            for bat_users, bat_items, bat_third in data_iter:
+                if self.is_pairwise is not True:      # host lists from the pointwise iterator
+                    bat_users = torch.tensor(bat_users, dtype=torch.int32, device=dev)
+                    bat_items = torch.tensor(bat_items, dtype=torch.int32, device=dev)
+                    bat_third = torch.tensor(bat_third, dtype=torch.float32, device=dev)
+                self.engine.step(bat_users, bat_items, bat_third, losses[n])
                 n += 1
             per_step = losses[:n].cpu().numpy()           # one D2H copy per epoch
             total_loss = 0.0

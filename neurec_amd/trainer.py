@@ -98,6 +98,68 @@ class MFEngine:
         self.adam.advance()
 
 
+class GeneralMFEngine:
+    """MF with every loss / optimiser combination conf/MF.properties allows (MF.py:62-76,
+    util/learner.py): pairwise {bpr, hinge, square} on (user, pos, neg) triplets or pointwise
+    {cross_entropy, square} on (user, item, label) instances; learner in {adam, gd, adagrad,
+    rmsprop, momentum} with TF-1.12's *sparse* application (Adam sweeps every row, the others
+    move only the rows the batch touched)."""
+
+    def __init__(self, user_table, item_table, lr, reg, max_batch, loss="bpr", pairwise=True,
+                 learner="adam", momentum=0.9):
+        dev = E.require_gpu()
+        loss, learner = str(loss).lower(), str(learner).lower()
+        table = E.PAIRWISE_LOSSES if pairwise else E.POINTWISE_LOSSES
+        if loss not in table:
+            raise Exception("please choose a suitable loss function")        # learner.py:28,40
+        if learner != "adam" and learner not in E.ROW_OPTIMIZERS:
+            raise ValueError("please select a suitable optimizer")           # learner.py:15
+        self.loss, self.pairwise, self.learner = loss, bool(pairwise), learner
+        self.P = torch.as_tensor(user_table, dtype=torch.float32).contiguous().to(dev)
+        self.Q = torch.as_tensor(item_table, dtype=torch.float32).contiguous().to(dev)
+        self.GP, self.GQ = torch.zeros_like(self.P), torch.zeros_like(self.Q)
+        self.reg, self.lr, self.momentum = float(reg), float(lr), float(momentum)
+        self.adam = E.AdamState(lr)
+        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.max_batch = max_batch
+        self.flagP = torch.zeros(self.P.shape[0], dtype=torch.uint8, device=dev)
+        self.flagQ = torch.zeros(self.Q.shape[0], dtype=torch.uint8, device=dev)
+        init = {"adam": 0.0, "gd": None, "adagrad": 1e-8, "rmsprop": 1.0, "momentum": 0.0}[learner]
+        mk = lambda t, v: None if v is None else torch.full_like(t, v)
+        self.s0P, self.s0Q = mk(self.P, init), mk(self.Q, init)
+        two = learner in ("adam", "rmsprop")
+        self.s1P, self.s1Q = (mk(self.P, 0.0), mk(self.Q, 0.0)) if two else (None, None)
+
+    def _apply(self, var, s0, s1, grad, flag):
+        if self.learner == "adam":
+            E.adam_sparse(var, s0, s1, grad, self.adam)
+        elif self.learner == "rmsprop":
+            E.optimizer_rows("rmsprop", var, s0, s1, grad, flag, self.lr, 0.9, 0.0, 1e-10)
+        elif self.learner == "momentum":
+            E.optimizer_rows("momentum", var, s0, None, grad, flag, self.lr, self.momentum)
+        else:
+            E.optimizer_rows(self.learner, var, s0, None, grad, flag, self.lr)
+
+    def step(self, users, items, third, loss_out):
+        """pairwise: third = negative items (int32); pointwise: third = labels (float32)."""
+        if users.numel() > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        if self.pairwise:
+            E.pairwise_mf_grad(self.P, self.Q, users, items, third, self.reg, self.loss, self.GP,
+                               self.GQ, self.terms, loss_out)
+        else:
+            E.pointwise_mf_grad(self.P, self.Q, users, items, third, self.reg, self.loss, self.GP,
+                                self.GQ, self.terms, loss_out)
+        if self.learner != "adam":
+            E.mark_rows(users, self.flagP)
+            E.mark_rows(items, self.flagQ)
+            if self.pairwise:
+                E.mark_rows(third, self.flagQ)
+        self._apply(self.P, self.s0P, self.s1P, self.GP, self.flagP)
+        self._apply(self.Q, self.s0Q, self.s1Q, self.GQ, self.flagQ)
+        self.adam.advance()
+
+
 class LightGCNEngine:
     """LightGCN on one GPU: E0 (user rows then item rows), its Adam state, the
     normalised adjacency (and its transpose when not symmetric) and the layer

@@ -97,6 +97,81 @@ def mf_loss_and_grads(P, Q, users, pos, neg, reg):
     return loss, dP, dQ
 
 
+def pairwise_terms(kind, y):
+    """util/learner.py:19-29 per element + derivative: bpr | hinge (max(y+1,0), as written) | square."""
+    if kind == "bpr":
+        return bpr_terms(y)
+    if kind == "hinge":
+        return np.maximum(y + 1, 0).astype(y.dtype), (y + 1 > 0).astype(y.dtype)
+    if kind == "square":
+        return (1 - y) ** 2, -2 * (1 - y)
+    raise Exception("please choose a suitable loss function")
+
+
+def pointwise_terms(kind, z, x):
+    """util/learner.py:31-41 per element + d/dx; cross_entropy is tf.losses.sigmoid_cross_entropy
+    (stable form, averaged over the batch by the caller), square is summed."""
+    if kind == "cross_entropy":
+        return (np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))).astype(x.dtype), \
+               (1 / (1 + np.exp(-x)) - z).astype(x.dtype)
+    if kind == "square":
+        return (z - x) ** 2, -2 * (z - x)
+    raise Exception("please choose a suitable loss function")
+
+
+def mf_general_loss_and_grads(P, Q, users, items, third, reg, pairwise, kind):
+    """MF.py:62-72 for every (is_pairwise, loss_function): returns (data loss, reg term, dP, dQ)."""
+    dt = P.dtype.type
+    dP, dQ = np.zeros_like(P), np.zeros_like(Q)
+    p, qi = P[users], Q[items]
+    if pairwise:
+        qj = Q[third]
+        y = np.sum(p * qi, axis=1, dtype=dt) - np.sum(p * qj, axis=1, dtype=dt)
+        lb, g = pairwise_terms(kind, y)
+        l2 = (np.sum(p * p, dtype=dt) + np.sum(qj * qj, dtype=dt) + np.sum(qi * qi, dtype=dt)) / dt(2)
+        np.add.at(dP, users, g[:, None] * (qi - qj) + dt(reg) * p)
+        np.add.at(dQ, items, g[:, None] * p + dt(reg) * qi)
+        np.add.at(dQ, third, -g[:, None] * p + dt(reg) * qj)
+        return np.sum(lb, dtype=dt), dt(reg) * l2, dP, dQ
+    z = np.asarray(third, dtype=P.dtype)
+    x = np.sum(p * qi, axis=1, dtype=dt)
+    lb, g = pointwise_terms(kind, z, x)
+    scale = dt(1) / dt(len(x)) if kind == "cross_entropy" else dt(1)
+    l2 = (np.sum(p * p, dtype=dt) + np.sum(qi * qi, dtype=dt)) / dt(2)
+    np.add.at(dP, users, (g * scale)[:, None] * qi + dt(reg) * p)
+    np.add.at(dQ, items, (g * scale)[:, None] * p + dt(reg) * qi)
+    return np.sum(lb * scale, dtype=dt), dt(reg) * l2, dP, dQ
+
+
+class RowOptimizer:
+    """TF-1.12 sparse application of learner.py:2-16 for gd / adagrad / rmsprop / momentum: only
+    the rows in `rows` move (duplicate row gradients already summed in the dense g)."""
+
+    def __init__(self, kind, lr, shape, dtype=np.float32, momentum=0.9):
+        self.kind, self.dt = kind, dtype
+        self.lr, self.mom = dtype(lr), dtype(momentum)
+        self.s0 = {"gd": None, "adagrad": np.full(shape, 1e-8, dtype), "rmsprop": np.ones(shape, dtype),
+                   "momentum": np.zeros(shape, dtype)}[kind]
+        self.s1 = np.zeros(shape, dtype) if kind == "rmsprop" else None
+
+    def apply(self, var, g, rows):
+        rows = np.unique(rows)
+        dt, gr = self.dt, g[rows]
+        if self.kind == "gd":
+            var[rows] -= self.lr * gr
+        elif self.kind == "adagrad":
+            self.s0[rows] += gr * gr
+            var[rows] -= (self.lr * gr) * (dt(1) / np.sqrt(self.s0[rows]))
+        elif self.kind == "rmsprop":
+            rho, eps = dt(0.9), dt(1e-10)
+            self.s0[rows] = self.s0[rows] * rho + (gr * gr) * (dt(1) - rho)
+            self.s1[rows] = self.s1[rows] * dt(0.0) + (dt(1) / np.sqrt(self.s0[rows] + eps)) * self.lr * gr
+            var[rows] -= self.s1[rows]
+        else:
+            self.s0[rows] = self.s0[rows] * self.mom + gr
+            var[rows] -= self.s0[rows] * self.lr
+
+
 def mf_step(P, Q, mP, vP, mQ, vQ, users, pos, neg, reg, adam):
     """sess.run((loss, optimizer)) of MF.py:101 — updates the six arrays in place."""
     loss, dP, dQ = mf_loss_and_grads(P, Q, users, pos, neg, reg)

@@ -185,3 +185,17 @@ def test_multivae_config_drops_in(tmp_path):
     assert np.abs(solo[0] - want[0]).max() < 1e-5 and np.abs(solo[1] - want[1]).max() > 1e-4
     cand = model.predict(users, [[1, 2, 3]] * 4)
     assert np.allclose(cand[2], solo[2][[1, 2, 3]])
+
+
+def test_mf_pointwise_and_other_learners_drop_in(tmp_path):
+    """conf/MF.properties with is_pairwise=False (PointwiseSampler, sigmoid cross-entropy) and a
+    non-Adam learner: runs end to end, loss falls, evaluation line printed."""
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    _run(tmp_path, ["--recommender=MF", "--epochs=6", "--batch_size=256", "--learning_rate=0.05",
+                    "--is_pairwise=False", "--loss_function=cross_entropy", "--learner=adagrad",
+                    "--num_negatives=2", "--verbose=6", "--embedding_size=16"])
+    text = _log_text(tmp_path, "MF")
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 6 and float(iters[-1][1]) < float(iters[0][1])
+    assert len(re.findall(r"epoch 6:\t", text)) == 1

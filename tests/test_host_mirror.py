@@ -231,3 +231,40 @@ def test_find_recommender_dispatch():
     assert find_recommender("LightGCN").__module__.endswith("general_recommender.LightGCN")
     with pytest.raises(ImportError):
         find_recommender("NoSuchModel")
+
+
+def test_time_order_windows_match_reference_structure():
+    """_generative_time_order_positive_items (data/sampler.py:42-68): windows, skipped short users,
+    error behaviour — host-only, no device."""
+    from neurec_amd.data.sampler import _generative_time_order_positive_items as gen
+    d = {7: [5, 3, 9, 1], 2: [4], 4: [8, 6, 2]}
+    upl, users, recent, pos = gen(d, high_order=1)
+    assert upl == [[7, 3], [4, 2]] and users == [7, 7, 7, 4, 4]
+    assert recent == [5, 3, 9, 8, 6] and pos == [3, 9, 1, 6, 2]
+    upl, users, recent, pos = gen(d, high_order=2)
+    assert upl == [[7, 2], [4, 1]] and recent == [[5, 3], [3, 9], [8, 6]] and pos == [9, 1, 2]
+    import pytest
+    with pytest.raises(ValueError):
+        gen(d, high_order=0)
+    with pytest.raises(TypeError):
+        gen([1, 2], high_order=1)
+    with pytest.raises(ValueError):
+        gen({}, high_order=1)
+
+
+def test_sampler_structure_matches_reference_golden():
+    """tests/golden/sampler_structure.json was produced by the reference's own
+    _generate_positive_items / _generative_time_order_positive_items (make_golden_sampler_structure.py)."""
+    import json
+    import os
+    from neurec_amd.data.sampler import _generate_positive_items, _generative_time_order_positive_items
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sampler_structure.json")) as f:
+        g = json.load(f)
+    seqs = {int(u): g["seqs"][str(u)] for u in g["order"]}          # same insertion order
+    upl, ul, pl = _generate_positive_items(seqs)
+    assert (upl, ul, pl) == (g["positive"]["user_pos_len"], g["positive"]["users"], g["positive"]["pos"])
+    for h in (1, 2, 4):
+        want = g["time_%d" % h]
+        upl, ul, rl, pl = _generative_time_order_positive_items(seqs, high_order=h)
+        assert upl == want["user_pos_len"] and ul == want["users"] and pl == want["pos"]
+        assert [list(r) if isinstance(r, (list, tuple)) else r for r in rl] == want["recent"]

@@ -138,3 +138,51 @@ def test_sampler_front_end_batches_and_errors(eng):
     wu = whole.sample_epoch()[0].cpu().numpy()
     cat = np.concatenate([p_.sample_epoch()[0].cpu().numpy() for p_ in parts])
     np.testing.assert_array_equal(cat, wu)
+
+
+class _SeqDataset:
+    """minimal stand-in for data.Dataset: what the samplers read"""
+    def __init__(self, seqs, num_items):
+        self._seqs, self.num_items = seqs, num_items
+
+    def get_user_train_dict(self, by_time=False):
+        return {u: list(s) if by_time else sorted(s) for u, s in self._seqs.items()}
+
+
+def test_time_order_and_pointwise_samplers(eng):
+    """data/sampler.py:93-155,216-354 — instance structure as the reference builds it, negatives
+    from the device kernel: never one of the user's train items, aligned with the positives."""
+    from neurec_amd.data import (PointwiseSampler, TimeOrderPairwiseSampler,
+                                 TimeOrderPointwiseSampler)
+    rng = np.random.RandomState(8)
+    n_items = 120
+    seqs = {u: rng.choice(n_items, rng.randint(1, 12), replace=False).tolist() for u in range(40)}
+    ds = _SeqDataset(seqs, n_items)
+    for high_order, neg_num in ((1, 1), (3, 2)):
+        want_n = sum(max(len(s) - high_order, 0) for s in seqs.values())
+        pw = TimeOrderPairwiseSampler(ds, high_order=high_order, neg_num=neg_num, batch_size=50, shuffle=False)
+        rows = [(u, r, p, n) for bu, br, bp, bn in pw for u, r, p, n in zip(bu, br, bp, bn)]
+        assert len(rows) == want_n and len(pw) == (want_n + 49) // 50
+        k = 0
+        for u, s in seqs.items():                                   # shuffle=False: user-major, window order
+            for t in range(len(s) - high_order):
+                uu, rec, pos, neg = rows[k]; k += 1
+                assert uu == u and pos == s[t + high_order]
+                assert (rec == s[t]) if high_order == 1 else (list(rec) == s[t:t + high_order])
+                negs = [neg] if neg_num == 1 else list(neg)
+                assert len(negs) == neg_num and not set(negs) & set(s) and all(0 <= x < n_items for x in negs)
+        pt = TimeOrderPointwiseSampler(ds, high_order=high_order, neg_num=neg_num, batch_size=64, shuffle=True)
+        inst = [(u, p, l) for bu, br, bp, bl in pt for u, p, l in zip(bu, bp, bl)]
+        assert len(inst) == want_n * (neg_num + 1) == len(pt.users_list)
+        assert sum(l for _, _, l in inst) == want_n                  # one positive per window
+        for u, it, lab in inst:
+            assert (it in seqs[u]) == (lab == 1.0)
+    po = PointwiseSampler(ds, neg_num=2, batch_size=32, shuffle=True)
+    inst = [(u, p, l) for bu, bp, bl in po for u, p, l in zip(bu, bp, bl)]
+    n_pos = sum(len(s) for s in seqs.values())
+    assert len(inst) == 3 * n_pos and sum(l for _, _, l in inst) == n_pos
+    assert all((it in seqs[u]) == (lab == 1.0) for u, it, lab in inst)
+    with pytest.raises(ValueError):
+        TimeOrderPairwiseSampler(ds, high_order=1, neg_num=0)
+    with pytest.raises(ValueError):
+        TimeOrderPointwiseSampler(ds, high_order=0)                  # _generative_time_order_positive_items
