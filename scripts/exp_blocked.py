@@ -51,11 +51,10 @@ Yr_ref = torch.zeros_like(X); csr.matmul(X, out=Yr_ref, y_row_wanted=flag)
 print("work-item masked: col %.1f us, row %.1f us" % (
     bench(lambda: csr.matmul(Xs, out=Ym_ref, x_row_nonzero=flag)),
     bench(lambda: csr.matmul(X, out=Yr_ref, y_row_wanted=flag))), flush=True)
-for split, bb, waves, seg, gif in [(U, 1 << 20, 16, 64, 8), (U, 1 << 20, 16, 64, 4), (U, 1 << 20, 16, 128, 8),
-                                  (U, 1 << 20, 16, 32, 8), (U, 1 << 20, 16, 256, 8),
-                                  (U, 1 << 20, 8, 64, 8), (U, 1 << 20, 8, 64, 4), (U, 1 << 20, 8, 128, 4),
-                                  (U, 1 << 20, 8, 32, 4), (U, 6144, 8, 64, 4), (U, 4096, 8, 64, 4),
-                                  (0, 1 << 20, 8, 64, 4), (0, 1 << 20, 16, 64, 8)]:
+for split, bb, waves, seg, gif in [(U, 1 << 20, 16, 64, 8), (U, 6144, 16, 32, 8), (U, 6144, 16, 16, 8),
+                                  (U, 4096, 16, 32, 8), (U, 4096, 16, 16, 8), (U, 4096, 16, 16, 4),
+                                  (U, 3072, 16, 32, 8), (U, 3072, 16, 16, 8), (U, 2560, 16, 16, 8),
+                                  (U, 1 << 20, 16, 32, 8), (U, 1 << 20, 16, 16, 8)]:
         lib.nrhip_spmm_blocked_tune(gif)
         buf = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
         plan = p()
