@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-mf", action="store_true")
     return ap.parse_args()
 
 
@@ -199,6 +200,31 @@ def main():
                 "launches_per_step": 2 * args.layers,
                 "step_algorithmic_bytes": lg.step_bytes() if hasattr(lg, "step_bytes") else None}
 
+    # ---------------- BPR-MF on the same interactions (BASELINE configs[1]: d=64, B=512) — reported
+    # next to the headline, not instead of it.  A step = fused gather/BPR/scatter kernel + the two
+    # TF-sparse Adam sweeps (every row of both tables decays each step).
+    mf_info = None
+    if comm.rank == 0 and not args.no_mf:
+        from neurec_amd.trainer import MFEngine
+        rs = np.random.RandomState(2017)
+        mf = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32),
+                      0.001, 0.0, 512)                                   # conf/MF.properties
+        mf_sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=512, shuffle=True, seed=2018)
+        mf_batches = [b for b in mf_sampler.batches() if b[0].numel() == 512][:400]
+        mf_loss = torch.zeros(2, device=dev)
+        for b in mf_batches[:50]:
+            mf.step(b[0], b[1], b[2], mf_loss)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in mf_batches[50:]:
+            mf.step(b[0], b[1], b[2], mf_loss)
+        torch.cuda.synchronize()
+        mf_dt = (time.perf_counter() - t0) / max(len(mf_batches) - 50, 1)
+        sweep = 2 * 4 * (U + I) * 64 * 4        # var, m, v, grad read + var, m, v, grad(cleared) written
+        mf_info = {"triplets_per_sec": 512 / mf_dt, "ms_per_step": mf_dt * 1e3, "batch": 512, "dim": 64,
+                   "adam_sweep_bytes_per_step": sweep, "adam_sweep_GBps": sweep / mf_dt / 1e9,
+                   "note": "TF-1.12 sparse Adam decays every row each step: the step is the table sweep"}
+
     # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)
     eval_info = None
     if not args.no_eval:
@@ -240,7 +266,7 @@ def main():
                                    "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()],
-        "eval": eval_info, "roofline": roofline,
+        "eval": eval_info, "mf": mf_info, "roofline": roofline,
         "device": E.device_info(),
     }
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/pmc
 mkdir -p "$OUT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/$c" -o b -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-eval > /dev/null 2> "$OLDPWD/$OUT/$c.err" )
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/$c" -o b -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-eval --no-mf > /dev/null 2> "$OLDPWD/$OUT/$c.err" )
   f=$(find "$OUT/$c" -name "*counter_collection.csv" | head -1)
   echo "== $c : $f"
   [ -n "$f" ] && python - "$f" <<'PY'
