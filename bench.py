@@ -163,6 +163,8 @@ def main():
     dt = comm.max_float(time.perf_counter() - t0)
     triplets_per_s = comm.world * args.steps * args.batch / dt
     run_steps(1, loss2)                                  # untimed: loss of one more step, for the record
+    if exchange:
+        comm.allgather_cat_finish(inflight[0])           # drain the prefetched id gather
 
     # ---------------- roofline of the dominant kernel (CSR SpMM): HIP events on the launch stream
     reps = 20
@@ -183,7 +185,8 @@ def main():
     spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
     spmm_bytes = lg.A.algorithmic_bytes(args.dim)
     achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-    kernel = ("spmm_blocked_kernel<false,16,8>" if lg.A.blocked is not None
+    kernel = (("spmm_blocked_kernel<false,16,8>" if args.dim == 64 else
+               "spmm_blocked_kernel<false,16,8,%d>" % args.dim) if lg.A.ensure_schedule(args.dim)
               else "spmm_item_kernel<%d,...>" % args.dim)
     # traffic: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc pass
     # over this same command (profiles/r01_pmc_traffic.json, scripts/gpu_pmc.sh) is reported when

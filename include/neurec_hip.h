@@ -206,13 +206,13 @@ int nrhip_spmm_csr_masked(const void* plan, const int64_t* d_indptr, const int32
                           void* stream);
 /* Only the listed rows of A·X (+ epilogue) are produced; other rows of the outputs are left
  * untouched.  d_rows may repeat; d_sum_out must not alias d_sum_in.  d in {64,128,256}. */
-/* Persistent lane-group schedule for d = 64 (spmm_blocked.hip): one workgroup per CU owns a run
- * of rows (256-byte accumulators in LDS), a 16-lane group walks one row with 16-byte loads, so a
- * load instruction moves four rows; sub-lists longer than seg_len are cut into segments whose
+/* Persistent lane-group schedule for d = 64 / 128 / 256 (spmm_blocked.hip): one workgroup per CU
+ * owns a run of rows (4·d-byte accumulators in LDS), a d/4-lane group walks one row with 16-byte
+ * loads, so a load instruction moves 4 / 2 / 1 rows; sub-lists longer than seg_len are cut into segments whose
  * partials are added in segment order.  Optional column blocking (block_bytes) cuts the gathered
  * table into L2-sized windows walked phase by phase.  Same contract and masks as nrhip_spmm_csr /
  * _masked; rows of <= seg_len non-zeros are bit-identical to the sequential order.  Attach it to
- * an SpMM plan and nrhip_spmm_csr / _masked / the step drivers use it for d == 64.
+ * an SpMM plan (per d) and nrhip_spmm_csr / _masked / the step drivers use it for that d.
  * 0 selects a default for block_bytes (no blocking), n_workgroups (one per CU),
  * waves_per_wg (16), seg_len (64), r_max / p_max (LDS accumulators).  NR_ERR_UNSUPPORTED when the
  * matrix does not fit the schedule (the work-item kernel remains). */
@@ -230,7 +230,7 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
                        const float* d_X, float* d_Y, const float* d_addend, const float* d_sum_in,
                        float* d_sum_out, const uint8_t* d_x_row_nonzero,
                        const uint8_t* d_y_row_wanted, void* stream);
-int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan);
+int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d);
 
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,

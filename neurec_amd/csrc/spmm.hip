@@ -56,7 +56,7 @@ constexpr int kGather = 16;      // row gathers in flight per wave (8/16/32 meas
 
 struct SpmmPlan {
   int64_t n_rows, nnz;
-  const void* blocked;       // optional cache-blocked schedule for d = 64 (spmm_blocked.hip); not owned
+  const void* blocked[3];    // optional lane-group schedules for d = 64 / 128 / 256 (spmm_blocked.hip); not owned
   // --- work items (d >= 64 path)
   int64_t n_items, n_hub_items, n_a_items, n_b_items;   // items = [hub | class A | class B]
   int item_rows, item_nnz;   // limits the items were cut with
@@ -686,7 +686,7 @@ int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_row
   NR_REQUIRE(p, NR_ERR_ARG, "spmm_plan_create: out of host memory");
   p->n_rows = n_rows;
   p->nnz = nnz;
-  p->blocked = nullptr;
+  p->blocked[0] = p->blocked[1] = p->blocked[2] = nullptr;
   p->item_rows = item_rows;
   p->item_nnz = item_nnz;
   p->n_hub_items = n_hub_items;
@@ -745,9 +745,10 @@ int nrhip_spmm_plan_destroy(void* plan) {
   return NR_OK;
 }
 
-int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan) {
-  NR_REQUIRE(plan, NR_ERR_ARG, "spmm_plan_attach_blocked: null plan");
-  ((SpmmPlan*)plan)->blocked = blocked_plan;       // NULL detaches
+int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d) {
+  NR_REQUIRE(plan && (d == 64 || d == 128 || d == 256), NR_ERR_ARG,
+             "spmm_plan_attach_blocked: null plan or dim %d not in (64, 128, 256)", d);
+  ((SpmmPlan*)plan)->blocked[d == 64 ? 0 : d == 128 ? 1 : 2] = blocked_plan;       // NULL detaches
   return NR_OK;
 }
 
@@ -777,8 +778,9 @@ static int spmm_dispatch(const char* who, const void* plan, const int64_t* d_ind
              "%s: sum_out needs sum_in", who);
   const SpmmPlan* p = (const SpmmPlan*)plan;
   hipStream_t st = (hipStream_t)stream;
-  if (d == 64 && p->blocked)   // persistent lane-group kernel (same contract, same masks)
-    return nrhip_spmm_blocked(p->blocked, d_indices, d_vals, d_X, d_Y, d_addend, d_sum_in,
+  const int bslot = d == 64 ? 0 : d == 128 ? 1 : d == 256 ? 2 : -1;
+  if (bslot >= 0 && p->blocked[bslot])   // persistent lane-group kernel (same contract, same masks)
+    return nrhip_spmm_blocked(p->blocked[bslot], d_indices, d_vals, d_X, d_Y, d_addend, d_sum_in,
                               d_sum_out, d_col_mask, d_row_mask, stream);
   if (d < 64)   // the 16/32-wide path has no work-skipping variants
     NR_REQUIRE(d_row_mask == nullptr, NR_ERR_UNSUPPORTED,

@@ -1,4 +1,5 @@
-// spmm_blocked.hip — cache-blocked, persistent-workgroup SpMM  Y = Â·X  for d = 64.
+// spmm_blocked.hip — persistent-workgroup, lane-group SpMM  Y = Â·X  for d = 64 / 128 / 256
+// (optionally cache-blocked by column windows).
 //
 // Why: at the gowalla shape one pass gathers 1.62 M rows of 256 B (415 MB) out of an 18 MB
 // table.  A pure random-gather micro-benchmark of that pattern (scripts/exp_gather.py) tops out
@@ -31,7 +32,6 @@
 
 namespace {
 
-constexpr int kD = 64;
 constexpr int kSegDefault = 64;     // longest sub-list one lane group walks alone
 constexpr int kRMaxDefault = 416;   // row accumulators per workgroup (104 KB)
 constexpr int kPMaxDefault = 192;   // segment partial slots per workgroup and phase (48 KB)
@@ -41,7 +41,7 @@ constexpr int kMaxLdsBytes = 160 * 1024;
 struct BlockedPlan {
   int64_t n_rows, nnz, n_ent, n_cmb;
   int n_wg, n_phases;
-  int seg, r_max, p_max, waves;
+  int seg, r_max, p_max, waves, d;
   int32_t* wg_row0;
   int32_t* wg_nrows;
   int32_t* wg_ent_off;   // [n_wg][n_phases + 1]
@@ -53,12 +53,12 @@ struct BlockedPlan {
 size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
   const size_t max_ent = (size_t)std::min<int64_t>(nnz, n_rows * (int64_t)kMaxPhases) + (size_t)(nnz / 16) + 64;
   const size_t max_cmb = (size_t)(nnz / 16) + 64;
-  const size_t wg = 4096;   // generous bound on workgroups
+  const size_t wg = 4096 + (size_t)(n_rows / 32);   // generous bound on workgroups
   return nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
          2 * nr_align_up(wg * 4, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256);
 }
 
-template <bool MASKED, int kWaves, int kG>
+template <bool MASKED, int kWaves, int kG, int D>
 __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_nrows,
     const int32_t* __restrict__ wg_ent_off, const int32_t* __restrict__ wg_cmb_off,
@@ -67,13 +67,15 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
     const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ col_mask,
     const uint8_t* __restrict__ row_mask, int kRMax) {
-  constexpr int kGroups = kWaves * 4;
-  extern __shared__ float4 s_acc[];          // [(r_max + p_max)][16]
+  constexpr int LPR = D / 4;                   // lanes per row: 16-byte pieces of a d-float row
+  constexpr int GPW = NR_WAVE / LPR;           // lane groups (rows in flight) per wave: 4 / 2 / 1
+  constexpr int kGroups = kWaves * GPW;
+  extern __shared__ float4 s_acc[];          // [(r_max + p_max)][LPR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4, gbase = lane & 48;
+  const int c = lane & (LPR - 1), g = lane / LPR, gbase = lane & ~(LPR - 1);
   const int wg = blockIdx.x;
   const int r0 = wg_row0[wg], nr = wg_nrows[wg];
-  for (int i = tid; i < nr * 16; i += kWaves * NR_WAVE) s_acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < nr * LPR; i += kWaves * NR_WAVE) s_acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const int32_t* eoff = wg_ent_off + (int64_t)wg * (n_phases + 1);
   const int32_t* coff = wg_cmb_off + (int64_t)wg * (n_phases + 1);
@@ -83,16 +85,16 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     // entry's descriptor is requested before, and its first 16 (column, value) pairs right
     // after, the current entry's gathers are issued — so in steady state a sub-list costs one
     // gather round trip, not three dependent ones.
-    int ei = e0 + wave * 4 + g;
+    int ei = e0 + wave * GPW + g;
     int4 cur = make_int4(0, 0, 0, 0);
     if (ei < e1) cur = ent[ei];
     int cur_idx = 0;
     float cur_val = 0.f;
-    if (c < cur.y) {
+    if (c < 16 && c < cur.y) {
       cur_idx = indices[(uint32_t)cur.z + c];
       cur_val = vals[(uint32_t)cur.z + c];
     }
-    for (int base = e0 + wave * 4; base < e1; base += kGroups) {
+    for (int base = e0 + wave * GPW; base < e1; base += kGroups) {
       const bool live = ei < e1;
       const int ein = ei + kGroups;
       int4 nxt = make_int4(0, 0, 0, 0);
@@ -104,9 +106,10 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
         if (row_mask && live && row_mask[r0 + cur.w] == 0) len = 0;    // output row not wanted
       }
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live && slot < kRMax) acc = s_acc[slot * 16 + c];            // segments start from zero
-      int maxlen = max(len, __shfl_xor(len, 16, NR_WAVE));
-      maxlen = max(maxlen, __shfl_xor(maxlen, 32, NR_WAVE));
+      if (live && slot < kRMax) acc = s_acc[slot * LPR + c];           // segments start from zero
+      int maxlen = len;
+#pragma unroll
+      for (int m = LPR; m < NR_WAVE; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m, NR_WAVE));
       maxlen = __builtin_amdgcn_readfirstlane(maxlen);
       int nxt_idx = 0;
       float nxt_val = 0.f;
@@ -116,13 +119,13 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
         if (k0 > 0) {                                // long sub-list: later chunks are not pipelined
           my_idx = 0;
           my_val = 0.f;
-          if (k0 + c < len) {
+          if (c < 16 && k0 + c < len) {
             my_idx = indices[begin + k0 + c];
             my_val = vals[begin + k0 + c];
           }
         }
         if constexpr (MASKED) {
-          if (col_mask && k0 + c < len && col_mask[my_idx] == 0) my_idx = -1;   // X row all zero
+          if (col_mask && c < 16 && k0 + c < len && col_mask[my_idx] == 0) my_idx = -1;   // X row all zero
         }
         const int nn = min(16, maxlen - k0);
         for (int t0 = 0; t0 < nn || (k0 == 0 && t0 == 0); t0 += kG) {
@@ -138,13 +141,13 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
             if constexpr (MASKED) {
               on[u] = on[u] && col >= 0;
               x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (on[u]) x[u] = X[(int64_t)col * 16 + c];
+              if (on[u]) x[u] = X[(int64_t)col * LPR + c];
             } else {
               x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (t0 + u < nn) x[u] = X[(int64_t)max(col, 0) * 16 + c];   // wave-uniform guard
+              if (t0 + u < nn) x[u] = X[(int64_t)max(col, 0) * LPR + c];   // wave-uniform guard
             }
           }
-          if (k0 == 0 && t0 == 0 && c < nxt.y) {     // prefetch the next sub-list's first chunk
+          if (k0 == 0 && t0 == 0 && c < 16 && c < nxt.y) {     // prefetch the next sub-list's first chunk
             nxt_idx = indices[(uint32_t)nxt.z + c];
             nxt_val = vals[(uint32_t)nxt.z + c];
           }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
             }
         }
       }
-      if (live) s_acc[slot * 16 + c] = acc;
+      if (live) s_acc[slot * LPR + c] = acc;
       cur = nxt;
       cur_idx = nxt_idx;
       cur_val = nxt_val;
@@ -167,25 +170,25 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const int c0 = coff[k], c1 = coff[k + 1];
     if (c1 > c0) {                                  // workgroup-uniform
       __syncthreads();
-      for (int ci = c0 + wave * 4 + g; ci < c1; ci += kGroups) {
+      for (int ci = c0 + wave * GPW + g; ci < c1; ci += kGroups) {
         const int4 cm = cmb[ci];
-        float4 acc = s_acc[cm.x * 16 + c];
+        float4 acc = s_acc[cm.x * LPR + c];
         for (int s = 0; s < cm.z; ++s) {
-          const float4 p = s_acc[(cm.y + s) * 16 + c];
+          const float4 p = s_acc[(cm.y + s) * LPR + c];
           acc.x = __fadd_rn(acc.x, p.x); acc.y = __fadd_rn(acc.y, p.y);
           acc.z = __fadd_rn(acc.z, p.z); acc.w = __fadd_rn(acc.w, p.w);
         }
-        s_acc[cm.x * 16 + c] = acc;
+        s_acc[cm.x * LPR + c] = acc;
       }
     }
     __syncthreads();
   }
-  for (int i = tid; i < nr * 16; i += kWaves * NR_WAVE) {
-    const int row = r0 + (i >> 4);
+  for (int i = tid; i < nr * LPR; i += kWaves * NR_WAVE) {
+    const int row = r0 + i / LPR;
     if constexpr (MASKED) {
       if (row_mask && row_mask[row] == 0) continue;
     }
-    const int64_t o = (int64_t)row * 16 + (i & 15);
+    const int64_t o = (int64_t)row * LPR + (i & (LPR - 1));
     float4 y = s_acc[i];
     if (addend) {
       const float4 ad = addend[o];
@@ -221,14 +224,16 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
                                    void** plan_out) {
   const int kWaves = waves_per_wg > 0 ? waves_per_wg : 16;
   const int kSeg = seg_len > 0 ? seg_len : kSegDefault;
-  const int kRMax = r_max > 0 ? r_max : kRMaxDefault * kWaves / 16;
-  const int kPMax = p_max > 0 ? p_max : kPMaxDefault * kWaves / 16;
+  const int kD = d;
+  const int kRMax = r_max > 0 ? r_max : kRMaxDefault * kWaves / 16 * 64 / (d > 0 ? d : 64);
+  const int kPMax = p_max > 0 ? p_max : kPMaxDefault * kWaves / 16 * 64 / (d > 0 ? d : 64);
+  NR_REQUIRE(d == 64 || d == 128 || d == 256, NR_ERR_UNSUPPORTED,
+             "spmm_blocked: embedding dim %d not built (64, 128, 256)", d);
   NR_REQUIRE(kWaves == 16 || kWaves == 8, NR_ERR_UNSUPPORTED, "spmm_blocked: waves per workgroup %d (8, 16)", kWaves);
   NR_REQUIRE(kSeg >= 16 && (size_t)(kRMax + kPMax) * kD * 4 <= (size_t)kMaxLdsBytes, NR_ERR_UNSUPPORTED,
              "spmm_blocked: seg %d / accumulators %d+%d do not fit", kSeg, kRMax, kPMax);
   NR_REQUIRE(h_indptr && h_indices && d_plan_buf && plan_out && n_rows > 0, NR_ERR_ARG,
              "spmm_blocked_plan_create: bad arguments");
-  NR_REQUIRE(d == kD, NR_ERR_UNSUPPORTED, "spmm_blocked: embedding dim %d not built (64)", d);
   const int64_t nnz = h_indptr[n_rows] - h_indptr[0];
   NR_REQUIRE(h_indptr[0] == 0 && nnz < ((int64_t)1 << 32), NR_ERR_UNSUPPORTED,
              "spmm_blocked: indptr must start at 0 and hold < 2^32 non-zeros");
@@ -246,7 +251,18 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     n_wg = prop.multiProcessorCount * (16 / kWaves);
   }
   n_wg = n_wg / 8 * 8;
-  NR_REQUIRE(n_wg >= 8 && n_wg <= 4096, NR_ERR_UNSUPPORTED, "spmm_blocked: %d workgroups", n_wg);
+  if (n_workgroups <= 0 && n_wg >= 8) {
+    // more rows than one workgroup per CU can hold accumulators for: launch a multiple of the CU
+    // count (the extra workgroups queue behind the resident ones; without column blocking the
+    // rounds are independent)
+    const int64_t per_class = split_row ? n_wg / 2 : n_wg;
+    const int64_t biggest = split_row ? std::max<int64_t>(split_row, n_rows - split_row) : n_rows;
+    const int64_t cap = (int64_t)kRMax * 9 / 10;
+    const int64_t mult = (biggest + per_class * cap - 1) / (per_class * cap);
+    if (mult > 1) n_wg = (int)std::min<int64_t>((int64_t)n_wg * mult, 4096 + n_rows / 32) / 8 * 8;
+  }
+  NR_REQUIRE(n_wg >= 8 && n_wg <= 4096 + n_rows / 32, NR_ERR_UNSUPPORTED, "spmm_blocked: %d workgroups",
+             n_wg);
 
   struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; };
   std::vector<ClassDesc> classes;
@@ -355,7 +371,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   BlockedPlan* p = new (std::nothrow) BlockedPlan();
   NR_REQUIRE(p, NR_ERR_ARG, "spmm_blocked_plan_create: out of host memory");
   p->n_rows = n_rows; p->nnz = nnz; p->n_wg = n_wg; p->n_phases = n_phases;
-  p->seg = kSeg; p->r_max = kRMax; p->p_max = kPMax; p->waves = kWaves;
+  p->seg = kSeg; p->r_max = kRMax; p->p_max = kPMax; p->waves = kWaves; p->d = d;
   p->n_ent = (int64_t)ent.size(); p->n_cmb = (int64_t)cmb.size();
   char* q = (char*)d_plan_buf;
   auto carve = [&](size_t bytes) { void* r = q; q += nr_align_up(bytes, 256); return r; };
@@ -387,10 +403,13 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   auto allow = [&](const void* fn) {
     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   };
-  allow((const void*)spmm_blocked_kernel<false, 16, 8>); allow((const void*)spmm_blocked_kernel<true, 16, 8>);
-  allow((const void*)spmm_blocked_kernel<false, 16, 4>); allow((const void*)spmm_blocked_kernel<true, 16, 4>);
-  allow((const void*)spmm_blocked_kernel<false, 8, 8>); allow((const void*)spmm_blocked_kernel<true, 8, 8>);
-  allow((const void*)spmm_blocked_kernel<false, 8, 4>); allow((const void*)spmm_blocked_kernel<true, 8, 4>);
+#define NR_ALLOW(DD)                                                                             \
+  allow((const void*)spmm_blocked_kernel<false, 16, 8, DD>); allow((const void*)spmm_blocked_kernel<true, 16, 8, DD>); \
+  allow((const void*)spmm_blocked_kernel<false, 16, 4, DD>); allow((const void*)spmm_blocked_kernel<true, 16, 4, DD>); \
+  allow((const void*)spmm_blocked_kernel<false, 8, 8, DD>); allow((const void*)spmm_blocked_kernel<true, 8, 8, DD>);   \
+  allow((const void*)spmm_blocked_kernel<false, 8, 4, DD>); allow((const void*)spmm_blocked_kernel<true, 8, 4, DD>)
+  if (d == 64) { NR_ALLOW(64); } else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
+#undef NR_ALLOW
   if (e != hipSuccess) {
     delete p;
     nrhip_set_error("spmm_blocked_plan_create: %s", hipGetErrorString(e));
@@ -434,22 +453,25 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
   const BlockedPlan* p = (const BlockedPlan*)plan;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)p->n_wg), block(p->waves * NR_WAVE);
-  const size_t lds = (size_t)(p->r_max + p->p_max) * kD * 4;
+  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
   const bool masked = d_x_row_nonzero || d_y_row_wanted;
   const int gif = s_gathers_in_flight;
-#define NR_BLK(M, W, GG)                                                                           \
-  hipLaunchKernelGGL((spmm_blocked_kernel<M, W, GG>), grid, block, lds, st, p->wg_row0, p->wg_nrows, \
-                     p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, d_indices, d_vals,   \
-                     (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,                      \
-                     (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,   \
+#define NR_BLK(M, W, GG, DD)                                                                       \
+  hipLaunchKernelGGL((spmm_blocked_kernel<M, W, GG, DD>), grid, block, lds, st, p->wg_row0,        \
+                     p->wg_nrows, p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases,        \
+                     d_indices, d_vals, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,  \
+                     (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,  \
                      p->r_max)
-  if (p->waves == 16) {
-    if (masked) { if (gif == 4) NR_BLK(true, 16, 4); else NR_BLK(true, 16, 8); }
-    else { if (gif == 4) NR_BLK(false, 16, 4); else NR_BLK(false, 16, 8); }
-  } else {
-    if (masked) { if (gif == 4) NR_BLK(true, 8, 4); else NR_BLK(true, 8, 8); }
-    else { if (gif == 4) NR_BLK(false, 8, 4); else NR_BLK(false, 8, 8); }
+#define NR_BLK_D(DD)                                                                               \
+  if (p->waves == 16) {                                                                            \
+    if (masked) { if (gif == 4) NR_BLK(true, 16, 4, DD); else NR_BLK(true, 16, 8, DD); }           \
+    else { if (gif == 4) NR_BLK(false, 16, 4, DD); else NR_BLK(false, 16, 8, DD); }                \
+  } else {                                                                                         \
+    if (masked) { if (gif == 4) NR_BLK(true, 8, 4, DD); else NR_BLK(true, 8, 8, DD); }             \
+    else { if (gif == 4) NR_BLK(false, 8, 4, DD); else NR_BLK(false, 8, 8, DD); }                  \
   }
+  if (p->d == 64) { NR_BLK_D(64) } else if (p->d == 128) { NR_BLK_D(128) } else { NR_BLK_D(256) }
+#undef NR_BLK_D
 #undef NR_BLK
   NR_LAUNCH_CHECK();
   return NR_OK;

@@ -184,10 +184,14 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
              batch, b.max_batch);
   NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ, b.terms,
                            d_loss2, stream));
-  NR_TRY(nrhip_adam_sparse_tf(b.P, b.mP, b.vP, b.GP, (int64_t)b.n_users * b.d, alpha, beta1, beta2,
-                              eps, stream));
-  NR_TRY(nrhip_adam_sparse_tf(b.Q, b.mQ, b.vQ, b.GQ, (int64_t)b.n_items * b.d, alpha, beta1, beta2,
-                              eps, stream));
+  const int64_t nu = (int64_t)b.n_users * b.d, ni = (int64_t)b.n_items * b.d;
+  if (b.Q == b.P + nu && b.mQ == b.mP + nu && b.vQ == b.vP + nu && b.GQ == b.GP + nu) {
+    // both tables (and their moments / gradients) are one allocation: one sweep, one launch
+    NR_TRY(nrhip_adam_sparse_tf(b.P, b.mP, b.vP, b.GP, nu + ni, alpha, beta1, beta2, eps, stream));
+    return NR_OK;
+  }
+  NR_TRY(nrhip_adam_sparse_tf(b.P, b.mP, b.vP, b.GP, nu, alpha, beta1, beta2, eps, stream));
+  NR_TRY(nrhip_adam_sparse_tf(b.Q, b.mQ, b.vQ, b.GQ, ni, alpha, beta1, beta2, eps, stream));
   return NR_OK;
 }
 

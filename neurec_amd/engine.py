@@ -379,8 +379,8 @@ class SpmmCSR:
         val = np.ascontiguousarray(vals, dtype=np.float32)
         self.h_indices = idx
         self.split_row = int(split_row)
-        self.blocked = None               # lane-group schedule for d = 64 (built on first use)
-        self._blocked_tried = False
+        self.blocked = None               # lane-group schedule of the last dim asked for
+        self._blocked = {}                # d -> (plan handle | None, buffer), built on first use
         self.indices = torch.from_numpy(idx if len(idx) else np.zeros(1, np.int32)).to(dev)
         self.vals = torch.from_numpy(val if len(val) else np.zeros(1, np.float32)).to(dev)
         self.indptr = torch.from_numpy(self.h_indptr).to(dev)
@@ -403,41 +403,46 @@ class SpmmCSR:
 
     def __del__(self):
         try:
-            if getattr(self, "blocked", None) is not None and self.blocked.value:
-                _lib.lib.nrhip_spmm_blocked_plan_destroy(self.blocked)
-                self.blocked = None
+            for plan, _buf in getattr(self, "_blocked", {}).values():
+                if plan is not None and plan.value:
+                    _lib.lib.nrhip_spmm_blocked_plan_destroy(plan)
+            self._blocked = {}
             if getattr(self, "plan", None) is not None and self.plan.value:
                 _lib.lib.nrhip_spmm_plan_destroy(self.plan)
                 self.plan = C.c_void_p(0)
         except Exception:
             pass
 
-    def ensure_schedule(self, d):
-        """For d == 64 build the persistent lane-group schedule (spmm_blocked.hip) once and attach
-        it to the plan; matrices it does not fit keep the work-item kernel.  NEUREC_SPMM_BLOCKED=0
+    def ensure_schedule(self, d, force=False):
+        """Build the persistent lane-group schedule (spmm_blocked.hip) once and attach it to the
+        plan.  Used for d == 64, where it is 1.3x faster than the work-item kernel; at d = 128 the
+        two measure equal (92.7 vs 96.7 us per gowalla pass) and the work-item kernel keeps rows of
+        up to 256 non-zeros in strict order, so 128 / 256 are attached only with force=True.
+        Matrices the schedule does not fit keep the work-item kernel.  NEUREC_SPMM_BLOCKED=0
         disables it (A/B measurements)."""
-        if d != 64 or self._blocked_tried:
-            return self.blocked is not None
-        self._blocked_tried = True
-        if os.environ.get("NEUREC_SPMM_BLOCKED", "1") == "0" or self.nnz == 0:
+        if d not in (64, 128, 256) or (d != 64 and not force and d not in self._blocked):
             return False
-        nbytes = C.c_size_t(0)
-        call("nrhip_spmm_blocked_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
-        buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=self.indices.device)
-        plan = C.c_void_p(0)
-        try:
-            call("nrhip_spmm_blocked_plan_create", self.h_indptr.ctypes.data_as(C.c_void_p),
-                 self.h_indices.ctypes.data_as(C.c_void_p), self.n_rows, self.split_row, d, 0, 0, 0,
-                 0, 0, 0, _ptr(buf), buf.numel(), _stream(), C.byref(plan))
-        except NotImplementedError:
-            return False                   # does not fit the schedule: work-item kernel stays
-        self.blocked, self.blocked_buf = plan, buf
-        call("nrhip_spmm_plan_attach_blocked", self.plan, plan)
-        return True
+        if d not in self._blocked:
+            self._blocked[d] = (None, None)
+            if os.environ.get("NEUREC_SPMM_BLOCKED", "1") != "0" and self.nnz > 0:
+                nbytes = C.c_size_t(0)
+                call("nrhip_spmm_blocked_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
+                buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=self.indices.device)
+                plan = C.c_void_p(0)
+                try:
+                    call("nrhip_spmm_blocked_plan_create", self.h_indptr.ctypes.data_as(C.c_void_p),
+                         self.h_indices.ctypes.data_as(C.c_void_p), self.n_rows, self.split_row, d,
+                         0, 0, 0, 0, 0, 0, _ptr(buf), buf.numel(), _stream(), C.byref(plan))
+                    call("nrhip_spmm_plan_attach_blocked", self.plan, plan, d)
+                    self._blocked[d] = (plan, buf)
+                except NotImplementedError:
+                    pass                   # does not fit the schedule: work-item kernel stays
+        self.blocked = self._blocked[d][0]
+        return self.blocked is not None
 
     def exact_row_nnz(self, d):
         """Rows with at most this many non-zeros are summed strictly in ascending column order."""
-        return 64 if (d == 64 and self.ensure_schedule(d)) else 256
+        return 64 if self.ensure_schedule(d) else 256
 
     def _workspace(self, d):
         if d not in self._ws:

@@ -70,11 +70,17 @@ class MFEngine:
 
     def __init__(self, user_table, item_table, lr, reg, max_batch):
         dev = E.require_gpu()
-        self.P = torch.as_tensor(user_table, dtype=torch.float32).contiguous().to(dev)
-        self.Q = torch.as_tensor(item_table, dtype=torch.float32).contiguous().to(dev)
-        self.mP, self.vP = torch.zeros_like(self.P), torch.zeros_like(self.P)
-        self.mQ, self.vQ = torch.zeros_like(self.Q), torch.zeros_like(self.Q)
-        self.GP, self.GQ = torch.zeros_like(self.P), torch.zeros_like(self.Q)
+        ut = torch.as_tensor(user_table, dtype=torch.float32)
+        it = torch.as_tensor(item_table, dtype=torch.float32)
+        nu = ut.shape[0]
+        # user and item tables (and their moments / gradients) share one allocation each, so the
+        # TF-sparse Adam sweep of a step is a single launch over [U+I][d]
+        self._table = torch.cat([ut, it]).contiguous().to(dev)
+        self._m, self._v, self._g = (torch.zeros_like(self._table) for _ in range(3))
+        self.P, self.Q = self._table[:nu], self._table[nu:]
+        self.mP, self.mQ = self._m[:nu], self._m[nu:]
+        self.vP, self.vQ = self._v[:nu], self._v[nu:]
+        self.GP, self.GQ = self._g[:nu], self._g[nu:]
         self.reg = float(reg)
         self.adam = E.AdamState(lr)
         self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)

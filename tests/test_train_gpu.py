@@ -75,6 +75,41 @@ def test_spmm_matches_scipy_rowwise(eng, d):
         assert np.abs(Yn.cpu().numpy() - train.spmm_rowwise(M, X)).max() < 1e-5
 
 
+@pytest.mark.parametrize("d", [128, 256])
+def test_spmm_lane_group_kernel_wide_rows(eng, d):
+    """the persistent lane-group kernel at d = 128 / 256 (2 / 1 rows per load instruction), forced:
+    same contract as the work-item kernel, rows of <= 64 nnz in strict order"""
+    import torch
+    from oracle import train
+    rng = np.random.RandomState(d + 5)
+    U, I = 600, 450
+    ur, ic = _graph(rng, U, I, 0, 30, hubs=2)
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    X = rng.randn(U + I, d).astype(np.float32)
+    add, acc = rng.randn(U + I, d).astype(np.float32), rng.randn(U + I, d).astype(np.float32)
+    csr = eng.SpmmCSR.from_scipy(A, split_row=U)
+    assert csr.ensure_schedule(d, force=True) and csr.exact_row_nnz(d) == 64
+    Y, S = torch.empty_like(_dev(X)), torch.empty_like(_dev(X))
+    csr.matmul(_dev(X), out=Y, addend=_dev(add), sum_in=_dev(acc), sum_out=S)
+    want = train.spmm_rowwise(A, X)
+    short = np.diff(A.indptr) <= 64
+    np.testing.assert_array_equal(Y.cpu().numpy()[short], (want + add)[short])
+    np.testing.assert_array_equal(S.cpu().numpy()[short], (acc + (want + add))[short])
+    assert np.abs(Y.cpu().numpy() - (want + add)).max() < 1e-5
+    flag = np.zeros(U + I, np.uint8); flag[rng.choice(U + I, 120, replace=False)] = 1
+    Xz = X * flag[:, None]
+    y_full, y_mask = torch.empty_like(Y), torch.empty_like(Y)
+    csr.matmul(_dev(Xz), out=y_full)
+    csr.matmul(_dev(Xz), out=y_mask, x_row_nonzero=_dev(flag))
+    np.testing.assert_array_equal(y_mask.cpu().numpy(), y_full.cpu().numpy())
+    part = torch.full((U + I, d), 9.0, device="cuda")
+    csr.matmul(_dev(X), out=part, y_row_wanted=_dev(flag))
+    got = part.cpu().numpy()
+    full = torch.empty_like(Y); csr.matmul(_dev(X), out=full)
+    np.testing.assert_array_equal(got[flag == 1], full.cpu().numpy()[flag == 1])
+    assert np.all(got[flag == 0] == 9.0)
+
+
 def test_spmm_empty_rows_and_tiny(eng):
     import torch
     A = sp.csr_matrix(([0.5, 2.0, -1.0], ([0, 0, 3], [1, 3, 0])), shape=(5, 5), dtype=np.float32)
@@ -300,5 +335,7 @@ def test_native_step_equals_python_launch_sequence(eng):
         bu, bp, bn = (_dev(rng.randint(0, n, B).astype(np.int32)) for n in (U, I, I))
         m1.step(bu, bp, bn, la)
         m2.step_reference(bu, bp, bn, lb)
-    assert np.abs(m1.P.cpu().numpy() - m2.P.cpu().numpy()).max() < 1e-7
+    # atomics order the duplicate rows' sums differently run to run; where a summed gradient nearly
+    # cancels, Adam's eps-dominated ratio amplifies that rounding noise to ~1e-6 of a step
+    assert np.abs(m1.P.cpu().numpy() - m2.P.cpu().numpy()).max() < 5e-6
     assert abs(float(la.sum()) - float(lb.sum())) <= 1e-6 * abs(float(lb.sum()))
