@@ -250,6 +250,14 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
                             const int32_t* d_neg, int batch, float reg, float* d_Gstar,
                             float* d_Greg, float* d_terms, float* d_loss2, void* stream);
 
+/* Same head, accumulating dLoss/dE* already divided by (n_layers+1) into d_H (zero on entry) —
+ * the H = Gstar/(L+1) the backward hops start from.  Only for n_layers+1 a power of two, where
+ * dividing every term is bit-identical to dividing the sum (NRHIP_ERR_ARG otherwise). */
+int nrhip_lightgcn_bpr_grad_h(const float* d_Esum, const float* d_E0, int n_users, int d,
+                              int n_layers, const int32_t* d_users, const int32_t* d_pos,
+                              const int32_t* d_neg, int batch, float reg, float* d_H,
+                              float* d_Greg, float* d_terms, float* d_loss2, void* stream);
+
 /* Node rows touched by a batch: d_rows_out[3*batch] = users | n_users+pos | n_users+neg and
  * d_row_flag[those rows] = 1 (d_row_flag: n_nodes bytes, zero on entry). */
 int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,

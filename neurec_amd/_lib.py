@@ -85,6 +85,7 @@ SIGNATURES = {
     "nrhip_spmm_csr_rows": [p, p, p, p, i32, p, i32, p, p, p, p, p],
     "nrhip_lightgcn_mark_batch": [p, p, p, i32, i32, p, p, p],
     "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p],
+    "nrhip_lightgcn_bpr_grad_h": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p],
     "nrhip_lightgcn_ctx_create": [C.POINTER(LightGCNBuffers), C.POINTER(p)],
     "nrhip_lightgcn_ctx_destroy": [p],
     "nrhip_lightgcn_step": [p, p, p, p, i32, f32, f32, f32, f32, p, p],

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_ker
     const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
     float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ Gstar,
-    float* __restrict__ Greg, float* __restrict__ term_mf, float* __restrict__ term_l2) {
+    float* __restrict__ Greg, float* __restrict__ term_mf, float* __restrict__ term_l2,
+    float grad_div) {
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int b = blockIdx.x * kWavesPerBlock + wave;
   if (b >= batch) return;
@@ -145,9 +146,10 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_ker
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
     if (k < d) {
-      atomicAdd(&Gstar[u * d + k], g * (ei[c] - ej[c]));
-      atomicAdd(&Gstar[i * d + k], g * eu[c]);
-      atomicAdd(&Gstar[j * d + k], -g * eu[c]);
+      // grad_div is 1 or a power of two: dividing each term is then exactly dividing the sum
+      atomicAdd(&Gstar[u * d + k], (g * (ei[c] - ej[c])) / grad_div);
+      atomicAdd(&Gstar[i * d + k], (g * eu[c]) / grad_div);
+      atomicAdd(&Gstar[j * d + k], (-g * eu[c]) / grad_div);
       atomicAdd(&Greg[u * d + k], reg * zu[c]);    // regulariser on layer-0 rows, :160,164
       atomicAdd(&Greg[i * d + k], reg * zi[c]);
       atomicAdd(&Greg[j * d + k], reg * zj[c]);
@@ -294,10 +296,10 @@ int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, cons
   return NR_OK;
 }
 
-int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
-                            int n_layers, const int32_t* d_users, const int32_t* d_pos,
-                            const int32_t* d_neg, int batch, float reg, float* d_Gstar,
-                            float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
+static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
+                         const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                         int batch, float reg, float* d_Gstar, float* d_Greg, float* d_terms,
+                         float* d_loss2, float grad_div, void* stream) {
   NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_terms,
              NR_ERR_ARG, "lightgcn_bpr_grad: null pointer argument");
   NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
@@ -315,13 +317,13 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
   dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
   if (d <= 64)
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<1>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div);
   else if (d <= 128)
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<2>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div);
   else
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<4>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2);
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div);
   NR_LAUNCH_CHECK();
   if (d_loss2) {
     hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
@@ -329,6 +331,27 @@ int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users,
     NR_LAUNCH_CHECK();
   }
   return NR_OK;
+}
+
+int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
+                            int n_layers, const int32_t* d_users, const int32_t* d_pos,
+                            const int32_t* d_neg, int batch, float reg, float* d_Gstar,
+                            float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
+  return lightgcn_head(d_Esum, d_E0, n_users, d, n_layers, d_users, d_pos, d_neg, batch, reg,
+                       d_Gstar, d_Greg, d_terms, d_loss2, 1.0f, stream);
+}
+
+/* Same head, accumulating dLoss/dE* already divided by (n_layers+1) — the H = Gstar/(L+1) of the
+ * backward pass — into d_H.  Only when L+1 is a power of two: dividing every term is then
+ * bit-identical to dividing the sum, and the rows_div pass disappears. */
+int nrhip_lightgcn_bpr_grad_h(const float* d_Esum, const float* d_E0, int n_users, int d,
+                              int n_layers, const int32_t* d_users, const int32_t* d_pos,
+                              const int32_t* d_neg, int batch, float reg, float* d_H,
+                              float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
+  NR_REQUIRE(n_layers >= 0 && ((n_layers + 1) & n_layers) == 0, NR_ERR_ARG,
+             "lightgcn_bpr_grad_h: n_layers + 1 = %d is not a power of two", n_layers + 1);
+  return lightgcn_head(d_Esum, d_E0, n_users, d, n_layers, d_users, d_pos, d_neg, batch, reg, d_H,
+                       d_Greg, d_terms, d_loss2, (float)(n_layers + 1), stream);
 }
 
 }  // extern "C"

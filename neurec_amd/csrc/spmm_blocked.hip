@@ -94,6 +94,10 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       cur_idx = indices[(uint32_t)cur.z + c];
       cur_val = vals[(uint32_t)cur.z + c];
     }
+    int cur_want = 1;                                // row filter of the current entry (prefetched)
+    if constexpr (MASKED) {
+      if (row_mask && ei < e1) cur_want = row_mask[r0 + cur.w];
+    }
     for (int base = e0 + wave * GPW; base < e1; base += kGroups) {
       const bool live = ei < e1;
       const int ein = ei + kGroups;
@@ -103,8 +107,9 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       int len = cur.y;
       const uint32_t begin = (uint32_t)cur.z;
       if constexpr (MASKED) {
-        if (row_mask && live && row_mask[r0 + cur.w] == 0) len = 0;    // output row not wanted
+        if (cur_want == 0) len = 0;                                    // output row not wanted
       }
+      int nxt_want = 1;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (live && slot < kRMax) acc = s_acc[slot * LPR + c];           // segments start from zero
       int maxlen = len;
@@ -147,9 +152,14 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
               if (t0 + u < nn) x[u] = X[(int64_t)max(col, 0) * LPR + c];   // wave-uniform guard
             }
           }
-          if (k0 == 0 && t0 == 0 && c < 16 && c < nxt.y) {     // prefetch the next sub-list's first chunk
-            nxt_idx = indices[(uint32_t)nxt.z + c];
-            nxt_val = vals[(uint32_t)nxt.z + c];
+          if (k0 == 0 && t0 == 0) {                  // prefetch for the next sub-list: first chunk, row filter
+            if (c < 16 && c < nxt.y) {
+              nxt_idx = indices[(uint32_t)nxt.z + c];
+              nxt_val = vals[(uint32_t)nxt.z + c];
+            }
+            if constexpr (MASKED) {
+              if (row_mask && ein < e1) nxt_want = row_mask[r0 + nxt.w];
+            }
           }
 #pragma unroll
           for (int u = 0; u < kG; ++u)
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       cur = nxt;
       cur_idx = nxt_idx;
       cur_val = nxt_val;
+      cur_want = nxt_want;
       ei = ein;
     }
     const int c0 = coff[k], c1 = coff[k + 1];

@@ -81,10 +81,16 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
                             b.Esum_rows, b.spmm_ws, b.spmm_ws_bytes, stream));
     esum = b.Esum_rows;
   }
-  NR_TRY(nrhip_lightgcn_bpr_grad(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
-                                 b.Gstar, b.Greg, b.terms, d_loss2, stream));
   // backward: H = Gstar/(L+1) on the batch rows; G_k = H + A^T G_{k+1}
-  NR_TRY(nrhip_rows_div(b.batch_rows, 3 * batch, d, b.Gstar, (float)(L + 1), b.H, stream));
+  if (((L + 1) & L) == 0) {
+    // L+1 a power of two (the configured L = 3): the head accumulates H directly — exact
+    NR_TRY(nrhip_lightgcn_bpr_grad_h(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch,
+                                     b.reg, b.H, b.Greg, b.terms, d_loss2, stream));
+  } else {
+    NR_TRY(nrhip_lightgcn_bpr_grad(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
+                                   b.Gstar, b.Greg, b.terms, d_loss2, stream));
+    NR_TRY(nrhip_rows_div(b.batch_rows, 3 * batch, d, b.Gstar, (float)(L + 1), b.H, stream));
+  }
   const float* g = b.H;
   float* gping[2] = {b.Ga, b.Gb};
   for (int k = 0; k < L; ++k) {
