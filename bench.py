@@ -250,7 +250,8 @@ def main():
         eval_info = {"users_per_sec": len(test_users) / dte, "ms": dte * 1e3,
                      "n_users": int(len(test_users)), "ndcg@10": float(means[2 * 20 + 9]),
                      "recall@20": float(means[1 * 20 + 19]),
-                     "design": "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel"}
+                     "design": "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel; scoring of batch "
+                               "b+1 overlaps ranking of batch b (two streams, two slabs)"}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-gowalla)", "value": triplets_per_s,

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
     wave_lds_sync();
   };
 
-  constexpr int UNITS = (VEC == 4) ? 4 : 8;      // loads in flight per lane
+  constexpr int UNITS = 8;                        // loads in flight per lane
   constexpr int UNIT_ELEMS = NR_WAVE * VEC;
   const int step = UNITS * UNIT_ELEMS;
 

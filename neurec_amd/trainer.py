@@ -299,13 +299,15 @@ class FullRankEvaluator:
     metrics, batch by batch; only the per-user metric matrix (or its column sums)
     ever crosses PCIe."""
 
-    def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048):
+    def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True):
         self.train, self.test = train_csr, test_csr
         self.metric_ids = [int(m) for m in metric_ids]
         self.top_k = int(top_k)
         self.batch_rows = int(batch_rows)
-        self._gemm = None
+        self.overlap = bool(overlap)         # score batch b+1 (MFMA / HBM-write bound) while batch b
+        self._gemm = None                    # is being ranked (HBM-read bound) on a second stream
         self._scores = None
+        self._side = None
 
     def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False):
         """Returns float64 column means [n_metric*top_k] (or the fp32 np.mean when
@@ -315,17 +317,42 @@ class FullRankEvaluator:
         if self._gemm is None or self._gemm.cols != item_table.shape[0] or \
                 self._gemm.d != item_table.shape[1]:
             self._gemm = E.ScoreGemm(item_table, self.batch_rows)
-            self._scores = self._gemm.new_score_buffer()
+            self._scores = [self._gemm.new_score_buffer()]
         else:
             self._gemm.prepare(item_table)
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
         cols = item_table.shape[0]
-        for b in range(0, n, self.batch_rows):
-            u = test_users[b:b + self.batch_rows]
-            S = self._gemm(user_table, u, out=self._scores)
-            E.mask_train(S, u, self.train, cols=cols)
-            E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
-                          out=per_user[b:b + u.numel()])
+        starts = list(range(0, n, self.batch_rows))
+        if not self.overlap or len(starts) < 2:
+            for b in starts:
+                u = test_users[b:b + self.batch_rows]
+                S = self._gemm(user_table, u, out=self._scores[0])
+                E.mask_train(S, u, self.train, cols=cols)
+                E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
+                              out=per_user[b:b + u.numel()])
+        else:
+            # two score slabs, two HIP streams: GEMM + mask of batch b+1 on the current stream,
+            # top-K + metrics of batch b on the side stream; events order the slab hand-offs
+            if len(self._scores) < 2:
+                self._scores.append(self._gemm.new_score_buffer())
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=test_users.device)
+            main, side = torch.cuda.current_stream(), self._side
+            ranked = [None, None]                       # per slab: event "ranking finished"
+            for k, b in enumerate(starts):
+                u = test_users[b:b + self.batch_rows]
+                slab = self._scores[k % 2]
+                if ranked[k % 2] is not None:
+                    main.wait_event(ranked[k % 2])      # the slab is free again
+                S = self._gemm(user_table, u, out=slab)
+                E.mask_train(S, u, self.train, cols=cols)
+                scored = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(scored)
+                    E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
+                                  out=per_user[b:b + u.numel()])
+                    ranked[k % 2] = side.record_event()
+            main.wait_stream(side)
         if exact_mean:
             return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
         return (E.colsum(per_user) / n).cpu().numpy()
