@@ -235,6 +235,11 @@ def main():
         mine = torch.from_numpy(parallel.shard_users(test_users, comm.rank, comm.world)).to(dev)
         ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch)
 
+        if exchange:
+            # replicas ran the same global steps, but fp32 scatter atomics sum in different orders:
+            # re-align the tables (ulp-level drift) before the users are scored shard by shard
+            comm.broadcast_(lg.E0, 0)
+
         def evaluate():
             eu, ei = lg.final_embeddings()
             sums = ev.evaluate_factors(eu.contiguous(), ei.contiguous(), mine) * mine.numel()

@@ -122,6 +122,13 @@ class Comm:
             q.wait()
         return host_recv.to(send.device), recv_counts
 
+    def broadcast_(self, t, src=0):
+        """In-place broadcast from rank `src` (used to re-align replicas whose scatter atomics
+        summed in different orders)."""
+        if self.active:
+            dist.broadcast(t, src=src)
+        return t
+
     def max_float(self, x):
         if not self.active:
             return float(x)

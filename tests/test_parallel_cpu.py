@@ -100,6 +100,9 @@ def _gather_worker(rank, world, port, out):
     tok_a = comm.allgather_cat_start(mine)                     # two collectives in flight
     tok_b = comm.allgather_cat_start([t + 1000 for t in mine])
     a, b = comm.allgather_cat_finish(tok_a), comm.allgather_cat_finish(tok_b)
+    bc = torch.full((3,), float(rank))
+    comm.broadcast_(bc, 1)
+    assert bc.tolist() == [1.0, 1.0, 1.0]
     if rank == 1:
         np.savez(out, a=torch.stack(a).numpy(), b=torch.stack(b).numpy())
     comm.barrier()
