@@ -232,6 +232,20 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
                        const uint8_t* d_y_row_wanted, void* stream);
 int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d);
 
+/* Last backward hop of a step and the optimiser in one pass (LightGCN.py:130,140 fused):
+ * d_var / d_m / d_v <- TF-1.12 ApplyAdam with the dense gradient (A·X + d_addend) + d_grad_b; the
+ * product itself is never stored.  Needs the d = 64 lane-group schedule attached to the plan
+ * (nrhip_spmm_plan_has_blocked(plan, 64) != 0), NRHIP_ERR_UNSUPPORTED otherwise. */
+int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
+                        const float* d_X, int d, const float* d_addend, const float* d_grad_b,
+                        float* d_var, float* d_m, float* d_v, float alpha, float beta1, float beta2,
+                        float eps, void* stream);
+int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
+                            const float* d_X, const float* d_addend, const float* d_grad_b,
+                            float* d_var, float* d_m, float* d_v, float alpha, float beta1,
+                            float beta2, float eps, void* stream);
+int nrhip_spmm_plan_has_blocked(const void* plan, int d);   /* 1 / 0, not a status code */
+
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,
                         const float* d_addend, const float* d_sum_in, float* d_sum_out,

@@ -47,6 +47,12 @@ extern "C" int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, co
                                   const uint8_t* d_x_row_nonzero, const uint8_t* d_y_row_wanted,
                                   void* stream);
 
+extern "C" int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices,
+                                       const float* d_vals, const float* d_X,
+                                       const float* d_addend, const float* d_grad_b, float* d_var,
+                                       float* d_m, float* d_v, float alpha, float beta1,
+                                       float beta2, float eps, void* stream);
+
 namespace {
 
 constexpr int kSegLen = 256;     // non-zeros per segment of a split (hub) row
@@ -750,6 +756,28 @@ int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d) 
              "spmm_plan_attach_blocked: null plan or dim %d not in (64, 128, 256)", d);
   ((SpmmPlan*)plan)->blocked[d == 64 ? 0 : d == 128 ? 1 : 2] = blocked_plan;       // NULL detaches
   return NR_OK;
+}
+
+/* Last backward hop + optimiser in one pass: var/m/v <- TF-Adam with gradient
+ * (A·X + addend) + grad_b.  Needs the d = 64 lane-group schedule attached to the plan;
+ * NR_ERR_UNSUPPORTED otherwise (callers then run nrhip_spmm_csr + nrhip_adam_dense_tf2). */
+int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
+                        const float* d_X, int d, const float* d_addend, const float* d_grad_b,
+                        float* d_var, float* d_m, float* d_v, float alpha, float beta1, float beta2,
+                        float eps, void* stream) {
+  NR_REQUIRE(plan, NR_ERR_ARG, "spmm_csr_adam: null plan");
+  const SpmmPlan* p = (const SpmmPlan*)plan;
+  NR_REQUIRE(d == 64 && p->blocked[0], NR_ERR_UNSUPPORTED,
+             "spmm_csr_adam: needs the d = 64 lane-group schedule");
+  return nrhip_spmm_blocked_adam(p->blocked[0], d_indices, d_vals, d_X, d_addend, d_grad_b, d_var,
+                                 d_m, d_v, alpha, beta1, beta2, eps, stream);
+}
+
+int nrhip_spmm_plan_has_blocked(const void* plan, int d) {
+  if (!plan) return 0;
+  const SpmmPlan* p = (const SpmmPlan*)plan;
+  const int slot = d == 64 ? 0 : d == 128 ? 1 : d == 256 ? 2 : -1;
+  return slot >= 0 && p->blocked[slot] != nullptr;
 }
 
 int nrhip_spmm_plan_info(const void* plan, int64_t* n_work_items, int64_t* n_split_rows) {

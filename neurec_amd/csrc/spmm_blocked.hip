@@ -58,7 +58,15 @@ size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
          2 * nr_align_up(wg * 4, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256);
 }
 
-template <bool MASKED, int kWaves, int kG, int D>
+// Optional fused optimiser epilogue (last backward hop of a LightGCN step): instead of storing
+// y, treat g = y + grad_b[row] as the dense gradient of `var` and apply TF-1.12 ApplyAdam to the
+// row (training_ops: m += (g-m)(1-b1); v += (g²-v)(1-b2); var -= m·alpha/(sqrt(v)+eps)).
+struct AdamEpilogue {
+  float4* var; float4* m; float4* v; const float4* grad_b;
+  float alpha, omb1, omb2, eps;
+};
+
+template <bool MASKED, int kWaves, int kG, int D, bool ADAM = false>
 __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_nrows,
     const int32_t* __restrict__ wg_ent_off, const int32_t* __restrict__ wg_cmb_off,
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
     const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ col_mask,
-    const uint8_t* __restrict__ row_mask, int kRMax) {
+    const uint8_t* __restrict__ row_mask, int kRMax, AdamEpilogue ad) {
   constexpr int LPR = D / 4;                   // lanes per row: 16-byte pieces of a d-float row
   constexpr int GPW = NR_WAVE / LPR;           // lane groups (rows in flight) per wave: 4 / 2 / 1
   constexpr int kGroups = kWaves * GPW;
@@ -205,6 +213,16 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       const float4 ad = addend[o];
       y.x = __fadd_rn(y.x, ad.x); y.y = __fadd_rn(y.y, ad.y);
       y.z = __fadd_rn(y.z, ad.z); y.w = __fadd_rn(y.w, ad.w);
+    }
+    if constexpr (ADAM) {
+      const float4 gb = ad.grad_b[o];
+      float4 w = ad.var[o], mm = ad.m[o], vv = ad.v[o];
+      nr::adam_dense_tf(__fadd_rn(y.x, gb.x), w.x, mm.x, vv.x, ad.alpha, ad.omb1, ad.omb2, ad.eps);
+      nr::adam_dense_tf(__fadd_rn(y.y, gb.y), w.y, mm.y, vv.y, ad.alpha, ad.omb1, ad.omb2, ad.eps);
+      nr::adam_dense_tf(__fadd_rn(y.z, gb.z), w.z, mm.z, vv.z, ad.alpha, ad.omb1, ad.omb2, ad.eps);
+      nr::adam_dense_tf(__fadd_rn(y.w, gb.w), w.w, mm.w, vv.w, ad.alpha, ad.omb1, ad.omb2, ad.eps);
+      ad.var[o] = w; ad.m[o] = mm; ad.v[o] = vv;
+      continue;
     }
     if (Y) Y[o] = y;
     if (sum_out) {
@@ -472,7 +490,7 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
                      p->wg_nrows, p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases,        \
                      d_indices, d_vals, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,  \
                      (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,  \
-                     p->r_max)
+                     p->r_max, AdamEpilogue{})
 #define NR_BLK_D(DD)                                                                               \
   if (p->waves == 16) {                                                                            \
     if (masked) { if (gif == 4) NR_BLK(true, 16, 4, DD); else NR_BLK(true, 16, 8, DD); }           \
@@ -484,6 +502,37 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
   if (p->d == 64) { NR_BLK_D(64) } else if (p->d == 128) { NR_BLK_D(128) } else { NR_BLK_D(256) }
 #undef NR_BLK_D
 #undef NR_BLK
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Y is not stored: the rows' results (plus d_addend) are consumed as the dense gradient
+ * g = y + d_grad_b and TF-Adam is applied to d_var / d_m / d_v in the same pass (d = 64 only). */
+int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
+                            const float* d_X, const float* d_addend, const float* d_grad_b,
+                            float* d_var, float* d_m, float* d_v, float alpha, float beta1,
+                            float beta2, float eps, void* stream) {
+  NR_REQUIRE(plan && d_indices && d_vals && d_X && d_grad_b && d_var && d_m && d_v, NR_ERR_ARG,
+             "spmm_blocked_adam: null pointer argument");
+  const BlockedPlan* p = (const BlockedPlan*)plan;
+  NR_REQUIRE(p->d == 64 && p->waves == 16, NR_ERR_UNSUPPORTED,
+             "spmm_blocked_adam: built for d = 64 schedules with 16 waves");
+  NR_REQUIRE(d_X != d_var, NR_ERR_ARG, "spmm_blocked_adam: the operand must not be the updated table");
+  static bool s_allowed = false;
+  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
+  if (!s_allowed) {
+    NR_CHECK_HIP(hipFuncSetAttribute((const void*)spmm_blocked_kernel<false, 16, 8, 64, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+    s_allowed = true;
+  }
+  AdamEpilogue ad{(float4*)d_var, (float4*)d_m, (float4*)d_v, (const float4*)d_grad_b,
+                  alpha, 1.0f - beta1, 1.0f - beta2, eps};
+  hipLaunchKernelGGL((spmm_blocked_kernel<false, 16, 8, 64, true>), dim3((unsigned)p->n_wg),
+                     dim3(16 * NR_WAVE), lds, (hipStream_t)stream, p->wg_row0, p->wg_nrows,
+                     p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, d_indices, d_vals,
+                     (const float4*)d_X, (float4*)nullptr, (const float4*)d_addend,
+                     (const float4*)nullptr, (float4*)nullptr, (const uint8_t*)nullptr,
+                     (const uint8_t*)nullptr, p->r_max, ad);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

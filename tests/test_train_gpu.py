@@ -339,3 +339,41 @@ def test_native_step_equals_python_launch_sequence(eng):
     # cancels, Adam's eps-dominated ratio amplifies that rounding noise to ~1e-6 of a step
     assert np.abs(m1.P.cpu().numpy() - m2.P.cpu().numpy()).max() < 5e-6
     assert abs(float(la.sum()) - float(lb.sum())) <= 1e-6 * abs(float(lb.sum()))
+
+
+def test_spmm_with_fused_adam_epilogue_equals_two_passes(eng):
+    """nrhip_spmm_csr_adam (last backward hop + ApplyAdam in one pass) == nrhip_spmm_csr followed by
+    nrhip_adam_dense_tf2, bit for bit (same products, same sums, same Adam arithmetic)."""
+    import ctypes as C
+    import torch
+    from neurec_amd._lib import call
+    from oracle import train
+    rng = np.random.RandomState(31)
+    U, I, d = 900, 700, 64
+    ur, ic = _graph(rng, U, I, 0, 30, hubs=2)
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    N = U + I
+    csr = eng.SpmmCSR.from_scipy(A, split_row=U)
+    assert csr.ensure_schedule(d)
+    X, H, Gb = (_dev(rng.randn(N, d).astype(np.float32) * s) for s in (1.0, 0.1, 0.01))
+    var0, m0, v0 = rng.randn(N, d).astype(np.float32), rng.randn(N, d).astype(np.float32) * 0.01, \
+        (rng.rand(N, d).astype(np.float32) * 1e-3)
+    st = eng.AdamState(0.01); st.advance(); st.advance()
+    # two passes
+    var_a, m_a, v_a = _dev(var0), _dev(m0), _dev(v0)
+    Y = torch.empty(N, d, device="cuda")
+    csr.matmul(X, out=Y, addend=H)
+    eng.adam_dense2(var_a, m_a, v_a, Y, Gb, st)
+    # one pass
+    var_b, m_b, v_b = _dev(var0), _dev(m0), _dev(v0)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    call("nrhip_spmm_csr_adam", csr.plan, ptr(csr.indices), ptr(csr.vals), ptr(X), d, ptr(H), ptr(Gb),
+         ptr(var_b), ptr(m_b), ptr(v_b), float(st.alpha()), float(st.beta1), float(st.beta2),
+         float(st.eps), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for a, b in ((var_a, var_b), (m_a, m_b), (v_a, v_b)):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    # without the schedule the entry point refuses (the step driver then runs the two passes)
+    plain = eng.SpmmCSR.from_scipy(A)
+    with pytest.raises(NotImplementedError):
+        call("nrhip_spmm_csr_adam", plain.plan, ptr(plain.indices), ptr(plain.vals), ptr(X), d, ptr(H),
+             ptr(Gb), ptr(var_b), ptr(m_b), ptr(v_b), 0.01, 0.9, 0.999, 1e-8, C.c_void_p(0))
