@@ -236,14 +236,17 @@ int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d);
  * d_var / d_m / d_v <- TF-1.12 ApplyAdam with the dense gradient (A·X + d_addend) + d_grad_b; the
  * product itself is never stored.  Needs the d = 64 lane-group schedule attached to the plan
  * (nrhip_spmm_plan_has_blocked(plan, 64) != 0), NRHIP_ERR_UNSUPPORTED otherwise. */
+/* clear_consumed != 0 additionally zeroes the non-zero entries of d_addend / d_grad_b and the set
+ * bytes of d_row_flag (may be NULL) as they are read — what nrhip_rows_clear would do after the
+ * step (both buffers are row-sparse there). */
 int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
-                        const float* d_X, int d, const float* d_addend, const float* d_grad_b,
-                        float* d_var, float* d_m, float* d_v, float alpha, float beta1, float beta2,
-                        float eps, void* stream);
+                        const float* d_X, int d, float* d_addend, float* d_grad_b, float* d_var,
+                        float* d_m, float* d_v, float alpha, float beta1, float beta2, float eps,
+                        int clear_consumed, uint8_t* d_row_flag, void* stream);
 int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
-                            const float* d_X, const float* d_addend, const float* d_grad_b,
-                            float* d_var, float* d_m, float* d_v, float alpha, float beta1,
-                            float beta2, float eps, void* stream);
+                            const float* d_X, float* d_addend, float* d_grad_b, float* d_var,
+                            float* d_m, float* d_v, float alpha, float beta1, float beta2,
+                            float eps, int clear_consumed, uint8_t* d_row_flag, void* stream);
 int nrhip_spmm_plan_has_blocked(const void* plan, int d);   /* 1 / 0, not a status code */
 
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,

@@ -48,10 +48,10 @@ extern "C" int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, co
                                   void* stream);
 
 extern "C" int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices,
-                                       const float* d_vals, const float* d_X,
-                                       const float* d_addend, const float* d_grad_b, float* d_var,
-                                       float* d_m, float* d_v, float alpha, float beta1,
-                                       float beta2, float eps, void* stream);
+                                       const float* d_vals, const float* d_X, float* d_addend,
+                                       float* d_grad_b, float* d_var, float* d_m, float* d_v,
+                                       float alpha, float beta1, float beta2, float eps,
+                                       int clear_consumed, uint8_t* d_row_flag, void* stream);
 
 namespace {
 
@@ -762,15 +762,16 @@ int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d) 
  * (A·X + addend) + grad_b.  Needs the d = 64 lane-group schedule attached to the plan;
  * NR_ERR_UNSUPPORTED otherwise (callers then run nrhip_spmm_csr + nrhip_adam_dense_tf2). */
 int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
-                        const float* d_X, int d, const float* d_addend, const float* d_grad_b,
-                        float* d_var, float* d_m, float* d_v, float alpha, float beta1, float beta2,
-                        float eps, void* stream) {
+                        const float* d_X, int d, float* d_addend, float* d_grad_b, float* d_var,
+                        float* d_m, float* d_v, float alpha, float beta1, float beta2, float eps,
+                        int clear_consumed, uint8_t* d_row_flag, void* stream) {
   NR_REQUIRE(plan, NR_ERR_ARG, "spmm_csr_adam: null plan");
   const SpmmPlan* p = (const SpmmPlan*)plan;
   NR_REQUIRE(d == 64 && p->blocked[0], NR_ERR_UNSUPPORTED,
              "spmm_csr_adam: needs the d = 64 lane-group schedule");
   return nrhip_spmm_blocked_adam(p->blocked[0], d_indices, d_vals, d_X, d_addend, d_grad_b, d_var,
-                                 d_m, d_v, alpha, beta1, beta2, eps, stream);
+                                 d_m, d_v, alpha, beta1, beta2, eps, clear_consumed, d_row_flag,
+                                 stream);
 }
 
 int nrhip_spmm_plan_has_blocked(const void* plan, int d) {

@@ -64,6 +64,9 @@ size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
 struct AdamEpilogue {
   float4* var; float4* m; float4* v; const float4* grad_b;
   float alpha, omb1, omb2, eps;
+  // optional: re-arm the step's sparse buffers on the way (what rows_clear would do afterwards):
+  // zero the addend / grad_b entries that were non-zero and the row flags
+  float4* addend_rw; float4* grad_b_rw; uint8_t* flag_rw;
 };
 
 template <bool MASKED, int kWaves, int kG, int D, bool ADAM = false>
@@ -216,6 +219,13 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     }
     if constexpr (ADAM) {
       const float4 gb = ad.grad_b[o];
+      if (ad.addend_rw) {
+        const float4 hv = addend[o];
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hv.x != 0.f || hv.y != 0.f || hv.z != 0.f || hv.w != 0.f) ad.addend_rw[o] = zero;
+        if (gb.x != 0.f || gb.y != 0.f || gb.z != 0.f || gb.w != 0.f) ad.grad_b_rw[o] = zero;
+        if ((i & (LPR - 1)) == 0 && ad.flag_rw && ad.flag_rw[row] != 0) ad.flag_rw[row] = 0;
+      }
       float4 w = ad.var[o], mm = ad.m[o], vv = ad.v[o];
       nr::adam_dense_tf(__fadd_rn(y.x, gb.x), w.x, mm.x, vv.x, ad.alpha, ad.omb1, ad.omb2, ad.eps);
       nr::adam_dense_tf(__fadd_rn(y.y, gb.y), w.y, mm.y, vv.y, ad.alpha, ad.omb1, ad.omb2, ad.eps);
@@ -507,11 +517,13 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
 }
 
 /* Y is not stored: the rows' results (plus d_addend) are consumed as the dense gradient
- * g = y + d_grad_b and TF-Adam is applied to d_var / d_m / d_v in the same pass (d = 64 only). */
+ * g = y + d_grad_b and TF-Adam is applied to d_var / d_m / d_v in the same pass (d = 64 only).
+ * clear_consumed: also zero the non-zero entries of d_addend / d_grad_b and the set bytes of
+ * d_row_flag (may be NULL) once read — the re-arming nrhip_rows_clear would do afterwards. */
 int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
-                            const float* d_X, const float* d_addend, const float* d_grad_b,
-                            float* d_var, float* d_m, float* d_v, float alpha, float beta1,
-                            float beta2, float eps, void* stream) {
+                            const float* d_X, float* d_addend, float* d_grad_b, float* d_var,
+                            float* d_m, float* d_v, float alpha, float beta1, float beta2,
+                            float eps, int clear_consumed, uint8_t* d_row_flag, void* stream) {
   NR_REQUIRE(plan && d_indices && d_vals && d_X && d_grad_b && d_var && d_m && d_v, NR_ERR_ARG,
              "spmm_blocked_adam: null pointer argument");
   const BlockedPlan* p = (const BlockedPlan*)plan;
@@ -525,8 +537,11 @@ int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const fl
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
     s_allowed = true;
   }
+  NR_REQUIRE(!clear_consumed || d_addend, NR_ERR_ARG, "spmm_blocked_adam: clear_consumed needs an addend");
   AdamEpilogue ad{(float4*)d_var, (float4*)d_m, (float4*)d_v, (const float4*)d_grad_b,
-                  alpha, 1.0f - beta1, 1.0f - beta2, eps};
+                  alpha, 1.0f - beta1, 1.0f - beta2, eps,
+                  clear_consumed ? (float4*)d_addend : nullptr,
+                  clear_consumed ? (float4*)d_grad_b : nullptr, clear_consumed ? d_row_flag : nullptr};
   hipLaunchKernelGGL((spmm_blocked_kernel<false, 16, 8, 64, true>), dim3((unsigned)p->n_wg),
                      dim3(16 * NR_WAVE), lds, (hipStream_t)stream, p->wg_row0, p->wg_nrows,
                      p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, d_indices, d_vals,

@@ -28,9 +28,10 @@ struct MFCtx {
   } while (0)
 
 extern "C" int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
-                                   const float* d_X, int d, const float* d_addend,
-                                   const float* d_grad_b, float* d_var, float* d_m, float* d_v,
-                                   float alpha, float beta1, float beta2, float eps, void* stream);
+                                   const float* d_X, int d, float* d_addend, float* d_grad_b,
+                                   float* d_var, float* d_m, float* d_v, float alpha, float beta1,
+                                   float beta2, float eps, int clear_consumed,
+                                   uint8_t* d_row_flag, void* stream);
 extern "C" int nrhip_spmm_plan_has_blocked(const void* plan, int d);
 
 extern "C" {
@@ -65,7 +66,8 @@ struct AdamArgs { float alpha, beta1, beta2, eps; };
 // carry it as a fused epilogue (d = 64 lane-group schedule, L >= 2) *g_out comes back NULL.
 static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_users,
                             const int32_t* d_pos, const int32_t* d_neg, int batch, float* d_loss2,
-                            void* stream, const float** g_out, const AdamArgs* adam = nullptr) {
+                            void* stream, const float** g_out, const AdamArgs* adam = nullptr,
+                            bool* rearmed = nullptr) {
   const int L = b.n_layers, d = b.d;
   const bool skip = d >= 64;                 // the work-skipping variants exist for d >= 64
   NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, b.n_users, b.batch_rows,
@@ -103,13 +105,18 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
   }
   const float* g = b.H;
   float* gping[2] = {b.Ga, b.Gb};
-  const bool fuse = adam && L >= 2 && nrhip_spmm_plan_has_blocked(b.plan_t, d);
+  const bool fuse = adam && rearmed && L >= 2 && nrhip_spmm_plan_has_blocked(b.plan_t, d);
   for (int k = 0; k < L; ++k) {
     if (k == L - 1 && fuse) {
       // last hop: G_0 = H + A^T G_1 is consumed row by row as the Adam gradient (+ reg rows)
+      // ... and re-arms H, Greg and the row flags as it reads them (Gstar is untouched when the
+      // head wrote H directly), so no rows_clear pass follows
+      const bool rearm = ((L + 1) & L) == 0;
       NR_TRY(nrhip_spmm_csr_adam(b.plan_t, b.indices_t, b.vals_t, g, d, b.H, b.Greg, b.E0, b.m, b.v,
-                                 adam->alpha, adam->beta1, adam->beta2, adam->eps, stream));
+                                 adam->alpha, adam->beta1, adam->beta2, adam->eps, rearm ? 1 : 0,
+                                 b.row_flag, stream));
       *g_out = nullptr;
+      if (rearm) *rearmed = true;
       return NR_OK;
     }
     if (k == 0 && skip)
@@ -143,10 +150,12 @@ int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
   const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
   const float* g = nullptr;
   const AdamArgs adam{alpha, beta1, beta2, eps};
-  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_loss2, stream, &g, &adam));
+  bool rearmed = false;
+  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_loss2, stream, &g, &adam, &rearmed));
   if (g)   // not folded into the last hop
     NR_TRY(nrhip_adam_dense_tf2(b.E0, b.m, b.v, g, b.Greg, (int64_t)b.n_nodes * b.d, alpha, beta1,
                                 beta2, eps, stream));
+  if (rearmed) return NR_OK;
   NR_TRY(nrhip_rows_clear(b.batch_rows, 3 * batch, b.d, b.Gstar, b.Greg, b.H, nullptr, b.row_flag,
                           stream));
   return NR_OK;

@@ -369,11 +369,24 @@ def test_spmm_with_fused_adam_epilogue_equals_two_passes(eng):
     ptr = lambda t: C.c_void_p(t.data_ptr())
     call("nrhip_spmm_csr_adam", csr.plan, ptr(csr.indices), ptr(csr.vals), ptr(X), d, ptr(H), ptr(Gb),
          ptr(var_b), ptr(m_b), ptr(v_b), float(st.alpha()), float(st.beta1), float(st.beta2),
-         float(st.eps), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+         float(st.eps), 0, C.c_void_p(0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     for a, b in ((var_a, var_b), (m_a, m_b), (v_a, v_b)):
         np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    # clear_consumed: same update, and the sparse inputs / flags come back zeroed
+    var_c, m_c, v_c = _dev(var0), _dev(m0), _dev(v0)
+    flags = np.zeros(N, np.uint8); flags[rng.choice(N, 200, replace=False)] = 1
+    Hs = H * _dev(flags[:, None].astype(np.float32)); Gs = Gb * _dev(flags[:, None].astype(np.float32))
+    var_d, m_d, v_d = _dev(var0), _dev(m0), _dev(v0)
+    Y2 = torch.empty(N, d, device="cuda"); csr.matmul(X, out=Y2, addend=Hs)
+    eng.adam_dense2(var_d, m_d, v_d, Y2, Gs, st)
+    fl = _dev(flags)
+    call("nrhip_spmm_csr_adam", csr.plan, ptr(csr.indices), ptr(csr.vals), ptr(X), d, ptr(Hs), ptr(Gs),
+         ptr(var_c), ptr(m_c), ptr(v_c), float(st.alpha()), float(st.beta1), float(st.beta2),
+         float(st.eps), 1, ptr(fl), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    np.testing.assert_array_equal(var_c.cpu().numpy(), var_d.cpu().numpy())
+    assert not Hs.cpu().numpy().any() and not Gs.cpu().numpy().any() and not fl.cpu().numpy().any()
     # without the schedule the entry point refuses (the step driver then runs the two passes)
     plain = eng.SpmmCSR.from_scipy(A)
     with pytest.raises(NotImplementedError):
         call("nrhip_spmm_csr_adam", plain.plan, ptr(plain.indices), ptr(plain.vals), ptr(X), d, ptr(H),
-             ptr(Gb), ptr(var_b), ptr(m_b), ptr(v_b), 0.01, 0.9, 0.999, 1e-8, C.c_void_p(0))
+             ptr(Gb), ptr(var_b), ptr(m_b), ptr(v_b), 0.01, 0.9, 0.999, 1e-8, 0, C.c_void_p(0), C.c_void_p(0))
