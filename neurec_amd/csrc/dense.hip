@@ -212,20 +212,24 @@ __global__ __launch_bounds__(64) void ngcf_wgrad16_kernel(
   }
   if (kk == 0) { p[512 + c] = sum1; p[528 + c] = sum2; }
 }
+// one wave per output element: lanes stride the slabs, fp64 accumulation, shuffle reduce
 __global__ __launch_bounds__(256) void ngcf_wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                 int n_slabs, float* __restrict__ dWg,
                                                                 float* __restrict__ dWb,
                                                                 float* __restrict__ dbg,
                                                                 float* __restrict__ dbb) {
-  for (int i = threadIdx.x; i < 544; i += 256) {
-    double acc = 0.0;
-    for (int s = 0; s < n_slabs; ++s) acc += (double)partial[(int64_t)s * 544 + i];
-    const float v = (float)acc;
-    if (i < 256) dWg[i] = v;
-    else if (i < 512) dWb[i - 256] = v;
-    else if (i < 528) dbg[i - 512] = v;
-    else dbb[i - 528] = v;
-  }
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= 544) return;
+  double acc = 0.0;
+  for (int s = lane; s < n_slabs; s += 64) acc += (double)partial[(int64_t)s * 544 + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane != 0) return;
+  const float v = (float)acc;
+  if (i < 256) dWg[i] = v;
+  else if (i < 512) dWb[i - 256] = v;
+  else if (i < 528) dbg[i - 512] = v;
+  else dbb[i - 528] = v;
 }
 
 }  // namespace
@@ -276,7 +280,7 @@ int nrhip_ngcf_layer_bwd(const float* d_ego, const float* d_S, const float* d_Wg
   hipLaunchKernelGGL(ngcf_wgrad16_kernel, dim3((unsigned)n_slabs), dim3(64), 0, st, d_ego, d_S,
                      d_dT1, d_dT2, n_rows, (float*)d_ws);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ngcf_wgrad_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)d_ws,
+  hipLaunchKernelGGL(ngcf_wgrad_reduce_kernel, dim3(136), dim3(256), 0, st, (const float*)d_ws,
                      n_slabs, d_dWg, d_dWb, d_dbg, d_dbb);
   NR_LAUNCH_CHECK();
   return NR_OK;

@@ -68,13 +68,35 @@ __global__ __launch_bounds__(256) void vae_encode_kernel(
   // l2_normalize of a 0/1 row: every non-zero becomes 1/sqrt(max(n, 1e-12))
   const float inv = 1.0f / sqrtf(fmaxf((float)n, 1e-12f));
   float a1 = 0.f;
-  for (int64_t t = b; t < e; ++t) {
-    float kp;
-    if (drop_given) kp = drop_given[t];
-    else kp = (keep >= 1.0f || uniform01(nr::splitmix64(nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull)) ^ (uint64_t)t)) < keep) ? 1.f : 0.f;
-    const float val = (inv / keep) * kp;                  // x/keep_prob * mask (tf.nn.dropout)
-    if (lane == 0 && h0val) h0val[t] = val;
-    if (lane < h) a1 = fmaf(val, Wq0[(int64_t)indices[t] * h + lane], a1);
+  const uint64_t drop_key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull));
+  // 64 (item, value) pairs per chunk, one per lane; then 8 row gathers of W_q0 in flight at a time
+  // (the sum stays in ascending item order)
+  for (int64_t t0 = b; t0 < e; t0 += NR_WAVE) {
+    const int nn = (int)min((int64_t)NR_WAVE, e - t0);
+    int my_item = 0;
+    float my_val = 0.f;
+    if (lane < nn) {
+      const int64_t t = t0 + lane;
+      float kp;
+      if (drop_given) kp = drop_given[t];
+      else kp = (keep >= 1.0f || uniform01(nr::splitmix64(drop_key ^ (uint64_t)t)) < keep) ? 1.f : 0.f;
+      my_val = (inv / keep) * kp;                         // x/keep_prob * mask (tf.nn.dropout)
+      my_item = indices[t];
+      if (h0val) h0val[t] = my_val;
+    }
+    for (int s0 = 0; s0 < nn; s0 += 8) {
+      float w[8], v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = min(s0 + u, nn - 1);
+        const int item = __builtin_amdgcn_readlane(my_item, src);
+        v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), src));
+        w[u] = (lane < h) ? Wq0[(int64_t)item * h + lane] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < nn) a1 = fmaf(v[u], w[u], a1);
+    }
   }
   float h1 = 0.f;
   if (lane < h) { h1 = act_fwd(act, a1 + bq0[lane]); H1[(int64_t)r * h + lane] = h1; }
@@ -155,29 +177,48 @@ __global__ __launch_bounds__(256) void vae_softmax_grad_kernel(
   for (int w = tid; w < bitmap_words; w += 256) bm[w] = 0u;
   __syncthreads();
   for (int64_t t = b + tid; t < e; t += 256) atomicOr(&bm[indices[t] >> 5], 1u << (indices[t] & 31));
-  float mx = -INFINITY;
-  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, srow[i] + bias[i]);
+  // pass A: online (max, sum of exp) over the row, 16-byte loads; pass B: gradient in place
+  const int cols4 = cols & ~3;
+  const float4* srow4 = reinterpret_cast<const float4*>(srow);
+  const float4* bias4 = reinterpret_cast<const float4*>(bias);
+  float mx = -INFINITY, sum = 0.f;
+  auto fold = [&](float x) {
+    if (x > mx) { sum = sum * expf(mx - x) + 1.0f; mx = x; }
+    else sum += expf(x - mx);
+  };
+  for (int i = tid; i < cols4 / 4; i += 256) {
+    const float4 a = srow4[i], bb = bias4[i];
+    fold(a.x + bb.x); fold(a.y + bb.y); fold(a.z + bb.z); fold(a.w + bb.w);
+  }
+  for (int i = cols4 + tid; i < cols; i += 256) fold(srow[i] + bias[i]);
   s_red[tid] = mx;
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] = fmaxf(s_red[tid], s_red[tid + s]); __syncthreads(); }
-  mx = s_red[0];
+  const float gmx = s_red[0];
   __syncthreads();
-  float sum = 0.f;
-  for (int i = tid; i < cols; i += 256) sum += expf(srow[i] + bias[i] - mx);
-  s_red[tid] = sum;
+  s_red[tid] = (mx == -INFINITY) ? 0.f : sum * expf(mx - gmx);
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-  if (tid == 0) s_lse = mx + logf(s_red[0]);
+  if (tid == 0) s_lse = gmx + logf(s_red[0]);
   __syncthreads();
   const float lse = s_lse;
   const float nb = (float)(e - b);
   float ll = 0.f;
-  for (int i = tid; i < cols; i += 256) {
-    const float l = srow[i] + bias[i] - lse;                 // log-softmax
+  auto grad = [&](float xv, int i) {
+    const float l = xv - lse;                                  // log-softmax
     const bool x = (bm[i >> 5] >> (i & 31)) & 1u;
     if (x) ll += l;
-    srow[i] = (expf(l) * nb - (x ? 1.f : 0.f)) * inv_batch;
+    return (expf(l) * nb - (x ? 1.f : 0.f)) * inv_batch;
+  };
+  float4* srow4w = reinterpret_cast<float4*>(srow);
+  for (int i = tid; i < cols4 / 4; i += 256) {
+    const float4 a = srow4[i], bb = bias4[i];
+    float4 o;
+    o.x = grad(a.x + bb.x, 4 * i); o.y = grad(a.y + bb.y, 4 * i + 1);
+    o.z = grad(a.z + bb.z, 4 * i + 2); o.w = grad(a.w + bb.w, 4 * i + 3);
+    srow4w[i] = o;
   }
+  for (int i = cols4 + tid; i < cols; i += 256) srow[i] = grad(srow[i] + bias[i], i);
   s_red[tid] = ll;
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
@@ -203,16 +244,31 @@ __global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__
   for (int b0 = 0; b0 < batch; b0 += kSlab) {
     const int nb = min(kSlab, batch - b0);
     __syncthreads();
-    for (int i = threadIdx.x; i < nb * h; i += 256) s_g1[i] = G1[(int64_t)b0 * h + i];
+    // g1 rows staged zero-padded to kMaxD columns: the inner product below needs no h predicate
+    for (int i = threadIdx.x; i < nb * kMaxD; i += 256) {
+      const int bb = i / kMaxD, j = i % kMaxD;
+      s_g1[i] = j < h ? G1[(int64_t)(b0 + bb) * h + j] : 0.f;
+    }
     __syncthreads();
     if (item < cols) {
-      for (int b = 0; b < nb; ++b) {
-        const float g = dlogits[(int64_t)(b0 + b) * ld + item];
-        bsum += g;
-        const float* gr = s_g1 + b * h;
+      for (int bb = 0; bb < nb; bb += 8) {        // 8 independent loads in flight per thread
+        float g[8];
 #pragma unroll
-        for (int j = 0; j < kMaxD; ++j)
-          if (j < h) acc[j] = fmaf(g, gr[j], acc[j]);
+        for (int u = 0; u < 8; ++u)
+          g[u] = (bb + u < nb) ? dlogits[(int64_t)(b0 + bb + u) * ld + item] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          bsum += g[u];
+          const float4* gr = reinterpret_cast<const float4*>(s_g1 + min(bb + u, nb - 1) * kMaxD);
+#pragma unroll
+          for (int j4 = 0; j4 < kMaxD / 4; ++j4) {
+            const float4 w = gr[j4];               // wave-uniform address: LDS broadcast
+            acc[4 * j4] = fmaf(g[u], w.x, acc[4 * j4]);
+            acc[4 * j4 + 1] = fmaf(g[u], w.y, acc[4 * j4 + 1]);
+            acc[4 * j4 + 2] = fmaf(g[u], w.z, acc[4 * j4 + 2]);
+            acc[4 * j4 + 3] = fmaf(g[u], w.w, acc[4 * j4 + 3]);
+          }
+        }
       }
     }
   }
@@ -223,38 +279,65 @@ __global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__
   dbp1[item] = bsum;
 }
 
-// dg1[b][:] = Σ_i dlogits[b][i]·W_p1[i][:]  — two batch rows per block
-__global__ __launch_bounds__(256) void vae_dg1_kernel(const float* __restrict__ dlogits, int64_t ld,
-                                                      int batch, int cols, int h,
-                                                      const float* __restrict__ Wp1,
-                                                      float* __restrict__ dG1) {
-  __shared__ float s_red[2][kMaxD][4];
+// dg1[b][:] = Σ_i dlogits[b][i]·W_p1[i][:]  — two batch rows per block of 8 waves.  A wave takes
+// every 8th 64-item chunk: the two rows' dlogits of the chunk are one coalesced load each, a lane
+// owns a column quad (q = lane & 7 -> columns 4q..4q+3) of item (lane >> 3) of each 8-item step,
+// so a 16-byte load per lane brings eight W_p1 rows per instruction.
+constexpr int kDg1Waves = 8;
+__global__ __launch_bounds__(kDg1Waves* NR_WAVE) void vae_dg1_kernel(
+    const float* __restrict__ dlogits, int64_t ld, int batch, int cols, int h,
+    const float* __restrict__ Wp1, float* __restrict__ dG1) {
+  __shared__ float s_red[kDg1Waves][2][kMaxD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane & 7, t = lane >> 3;
   const int r0 = blockIdx.x * 2, r1 = min(r0 + 1, batch - 1);
-  float a0[kMaxD], a1[kMaxD];
-#pragma unroll
-  for (int j = 0; j < kMaxD; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
-  for (int i = tid; i < cols; i += 256) {
-    const float g0 = dlogits[(int64_t)r0 * ld + i], g1 = dlogits[(int64_t)r1 * ld + i];
-    const float* w = Wp1 + (int64_t)i * h;
-#pragma unroll
-    for (int j = 0; j < kMaxD; ++j)
-      if (j < h) { const float ww = w[j]; a0[j] = fmaf(g0, ww, a0[j]); a1[j] = fmaf(g1, ww, a1[j]); }
-  }
-#pragma unroll
-  for (int j = 0; j < kMaxD; ++j) {
-    if (j < h) {
-      const float s0 = nr_wave_sum_f32(a0[j]), s1 = nr_wave_sum_f32(a1[j]);
-      if (lane == 0) { s_red[0][j][wave] = s0; s_red[1][j][wave] = s1; }
+  const int hq = (h + 3) / 4;                      // column quads in use (h <= 32 -> <= 8)
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  for (int c0 = wave * NR_WAVE; c0 < cols; c0 += kDg1Waves * NR_WAVE) {
+    const int nn = min(NR_WAVE, cols - c0);
+    float d0 = 0.f, d1 = 0.f;
+    if (lane < nn) {
+      d0 = dlogits[(int64_t)r0 * ld + c0 + lane];
+      d1 = dlogits[(int64_t)r1 * ld + c0 + lane];
     }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int it = 8 * s + t;                    // item of this lane in the chunk
+      const float g0 = __shfl(d0, it, NR_WAVE), g1 = __shfl(d1, it, NR_WAVE);
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < nn && q < hq) {
+        const float* wp = Wp1 + (int64_t)(c0 + it) * h + 4 * q;
+        if ((h & 3) == 0) w = *(const float4*)wp;
+        else { w.x = wp[0]; if (4 * q + 1 < h) w.y = wp[1]; if (4 * q + 2 < h) w.z = wp[2]; if (4 * q + 3 < h) w.w = wp[3]; }
+      }
+      a0.x = fmaf(g0, w.x, a0.x); a0.y = fmaf(g0, w.y, a0.y); a0.z = fmaf(g0, w.z, a0.z); a0.w = fmaf(g0, w.w, a0.w);
+      a1.x = fmaf(g1, w.x, a1.x); a1.y = fmaf(g1, w.y, a1.y); a1.z = fmaf(g1, w.z, a1.z); a1.w = fmaf(g1, w.w, a1.w);
+    }
+  }
+  // sum the eight item lanes (t) of every column quad, then the waves
+#pragma unroll
+  for (int m = 8; m < NR_WAVE; m <<= 1) {
+    a0.x += __shfl_xor(a0.x, m, NR_WAVE); a0.y += __shfl_xor(a0.y, m, NR_WAVE);
+    a0.z += __shfl_xor(a0.z, m, NR_WAVE); a0.w += __shfl_xor(a0.w, m, NR_WAVE);
+    a1.x += __shfl_xor(a1.x, m, NR_WAVE); a1.y += __shfl_xor(a1.y, m, NR_WAVE);
+    a1.z += __shfl_xor(a1.z, m, NR_WAVE); a1.w += __shfl_xor(a1.w, m, NR_WAVE);
+  }
+  if (t == 0) {
+    s_red[wave][0][4 * q] = a0.x; s_red[wave][0][4 * q + 1] = a0.y;
+    s_red[wave][0][4 * q + 2] = a0.z; s_red[wave][0][4 * q + 3] = a0.w;
+    s_red[wave][1][4 * q] = a1.x; s_red[wave][1][4 * q + 1] = a1.y;
+    s_red[wave][1][4 * q + 2] = a1.z; s_red[wave][1][4 * q + 3] = a1.w;
   }
   __syncthreads();
   if (tid < 2 * h) {
     const int which = tid / h, j = tid % h;
-    const int r = which == 0 ? r0 : r0 + 1;
-    if (r < batch)
-      dG1[(int64_t)r * h + j] = ((s_red[which][j][0] + s_red[which][j][1]) + s_red[which][j][2]) +
-                                s_red[which][j][3];
+    const int r = r0 + which;
+    if (r < batch) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < kDg1Waves; ++w) sum += s_red[w][which][j];
+      dG1[(int64_t)r * h + j] = sum;
+    }
   }
 }
 
@@ -308,22 +391,24 @@ __global__ __launch_bounds__(256) void vae_mid_bwd_kernel(
 }
 
 // Small weight gradients, reduced over the batch: out[k][j] = Σ_b X[b][k]·G[b][j] and
-// bias[j] = Σ_b G[b][j].  One thread per output element (K·J + J ≤ 1056).
+// bias[j] = Σ_b G[b][j].  One wave per output element (K·J + J <= 1056), lanes stride the batch.
 __global__ __launch_bounds__(256) void vae_small_wgrad_kernel(const float* __restrict__ X, int K,
                                                               const float* __restrict__ G, int J,
                                                               int batch, float* __restrict__ dW,
                                                               float* __restrict__ db) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= K * J + J) return;
+  float acc = 0.f;
   if (o < K * J) {
     const int k = o / J, j = o % J;
-    float acc = 0.f;
-    for (int b = 0; b < batch; ++b) acc = fmaf(X[(int64_t)b * K + k], G[(int64_t)b * J + j], acc);
-    dW[o] = acc;
-  } else if (o < K * J + J) {
+    for (int b = lane; b < batch; b += NR_WAVE) acc = fmaf(X[(int64_t)b * K + k], G[(int64_t)b * J + j], acc);
+    acc = nr_wave_sum_f32(acc);
+    if (lane == 0) dW[o] = acc;
+  } else {
     const int j = o - K * J;
-    float acc = 0.f;
-    for (int b = 0; b < batch; ++b) acc += G[(int64_t)b * J + j];
-    db[j] = acc;
+    for (int b = lane; b < batch; b += NR_WAVE) acc += G[(int64_t)b * J + j];
+    acc = nr_wave_sum_f32(acc);
+    if (lane == 0) db[j] = acc;
   }
 }
 
@@ -336,11 +421,21 @@ __global__ __launch_bounds__(256) void vae_dwq0_kernel(const int64_t* __restrict
                                                        float* __restrict__ dWq0) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
-  if (r >= batch || lane >= h) return;
+  if (r >= batch) return;
   const int64_t u = rows[r];
-  const float g = DA1[(int64_t)r * h + lane];
-  for (int64_t t = indptr[u]; t < indptr[u + 1]; ++t)
-    atomicAdd(&dWq0[(int64_t)indices[t] * h + lane], h0val[t] * g);
+  const float g = lane < h ? DA1[(int64_t)r * h + lane] : 0.f;
+  const int64_t b = indptr[u], e = indptr[u + 1];
+  for (int64_t t0 = b; t0 < e; t0 += NR_WAVE) {          // 64 (item, value) pairs per coalesced load
+    const int nn = (int)min((int64_t)NR_WAVE, e - t0);
+    int my_item = 0;
+    float my_val = 0.f;
+    if (lane < nn) { my_item = indices[t0 + lane]; my_val = h0val[t0 + lane]; }
+    for (int s = 0; s < nn; ++s) {
+      const int item = __builtin_amdgcn_readlane(my_item, s);
+      const float val = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), s));
+      if (lane < h) atomicAdd(&dWq0[(int64_t)item * h + lane], val * g);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n,
@@ -443,8 +538,8 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
   hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, d_S, ld, batch,
                      cols, h, d_G1, d_dWp1, d_dbp1);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + 1) / 2), dim3(256), 0, st, d_S, ld, batch, cols,
-                     h, d_Wp1, d_dG1);
+  hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + 1) / 2), dim3(kDg1Waves * NR_WAVE), 0, st, d_S,
+                     ld, batch, cols, h, d_Wp1, d_dG1);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -467,13 +562,13 @@ int nrhip_vae_mid_backward(int batch, int h, int z, int act, float anneal, const
                      d_Wp0, d_Wq1, d_DA3, d_DH2, d_DA1);
   NR_LAUNCH_CHECK();
   // dW_p0 = zsᵀ·da3 [z][h];  dW_q1 = h1ᵀ·dh2 [h][2z];  db_q0 = Σ da1
-  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((z * h + h + 255) / 256), dim3(256), 0, st, d_ZS,
+  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((z * h + h + 3) / 4), dim3(256), 0, st, d_ZS,
                      z, d_DA3, h, batch, d_dWp0, d_dbp0);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((h * 2 * z + 2 * z + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((h * 2 * z + 2 * z + 3) / 4), dim3(256), 0, st,
                      d_H1, h, d_DH2, 2 * z, batch, d_dWq1, d_dbq1);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3(1), dim3(256), 0, st, d_H1, 0, d_DA1, h, batch,
+  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((h + 3) / 4), dim3(256), 0, st, d_H1, 0, d_DA1, h, batch,
                      (float*)nullptr, d_dbq0);
   NR_LAUNCH_CHECK();
   return NR_OK;
