@@ -103,11 +103,35 @@ __global__ __launch_bounds__(kRowsPerBlock) void ngcf_layer_fwd_kernel(
   RowMath<D>::affine(s, s_w, s_w + 2 * D * D, t1);
   RowMath<D>::affine(bi, s_w + D * D, s_w + 2 * D * D + D, t2);
   float ss = 0.f;
+  // the row's D mask bytes travel as 16-byte words; a fresh draw takes four 16-bit uniforms from
+  // each 64-bit hash (D/4 hashes per row)
+  static_assert(D % 16 == 0, "mask rows are moved as uint4");
+  uint32_t mw[D / 4];
+  if (mask_given) {
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) {
+      const uint4 m4 = reinterpret_cast<const uint4*>(mask_io + r * D)[q];
+      mw[4 * q] = m4.x; mw[4 * q + 1] = m4.y; mw[4 * q + 2] = m4.z; mw[4 * q + 3] = m4.w;
+    }
+  } else {
+    const uint64_t key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull + layer));
+#pragma unroll
+    for (int q = 0; q < D / 4; ++q) {
+      const uint64_t hsh = nr::splitmix64(key ^ ((uint64_t)r * (D / 4) + q));
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((float)((hsh >> (16 * i)) & 0xffffu) * (1.0f / 65536.0f) < keep) w |= 1u << (8 * i);
+      mw[q] = w;
+    }
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q)
+      reinterpret_cast<uint4*>(mask_io + r * D)[q] =
+          make_uint4(mw[4 * q], mw[4 * q + 1], mw[4 * q + 2], mw[4 * q + 3]);
+  }
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    bool kp;
-    if (mask_given) kp = mask_io[r * D + k] != 0;
-    else { kp = keep_draw(seed, step, layer, (uint64_t)r * D + k, keep); mask_io[r * D + k] = kp ? 1 : 0; }
+    const bool kp = ((mw[k / 4] >> (8 * (k % 4))) & 0xffu) != 0;
     const float zz = __fadd_rn(lrelu(t1[k]), lrelu(t2[k]));
     z[k] = kp ? zz / keep : 0.f;
     ss = fmaf(z[k], z[k], ss);
@@ -140,9 +164,15 @@ __global__ __launch_bounds__(kRowsPerBlock) void ngcf_layer_bwd_kernel(
   RowMath<D>::affine(bi, s_w + D * D, s_w + 2 * D * D + D, t2);
   float ss = 0.f;
   bool kp[D];
+  uint32_t mw[D / 4];
+#pragma unroll
+  for (int q = 0; q < D / 16; ++q) {
+    const uint4 m4 = reinterpret_cast<const uint4*>(mask + r * D)[q];
+    mw[4 * q] = m4.x; mw[4 * q + 1] = m4.y; mw[4 * q + 2] = m4.z; mw[4 * q + 3] = m4.w;
+  }
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    kp[k] = mask[r * D + k] != 0;
+    kp[k] = ((mw[k / 4] >> (8 * (k % 4))) & 0xffu) != 0;
     const float zz = __fadd_rn(lrelu(t1[k]), lrelu(t2[k]));
     z[k] = kp[k] ? zz / keep : 0.f;
     ss = fmaf(z[k], z[k], ss);
