@@ -62,7 +62,7 @@ constexpr int kGather = 16;      // row gathers in flight per wave (8/16/32 meas
 
 struct SpmmPlan {
   int64_t n_rows, nnz;
-  const void* blocked[3];    // optional lane-group schedules for d = 64 / 128 / 256 (spmm_blocked.hip); not owned
+  const void* blocked[5];    // optional lane-group schedules for d = 16 / 32 / 64 / 128 / 256 (spmm_blocked.hip); not owned
   // --- work items (d >= 64 path)
   int64_t n_items, n_hub_items, n_a_items, n_b_items;   // items = [hub | class A | class B]
   int item_rows, item_nnz;   // limits the items were cut with
@@ -83,6 +83,10 @@ struct SpmmPlan {
   int32_t* multi_first;
   int32_t* multi_nseg;
 };
+
+inline int blocked_slot(int d) {
+  return d == 16 ? 0 : d == 32 ? 1 : d == 64 ? 2 : d == 128 ? 3 : d == 256 ? 4 : -1;
+}
 
 struct PlanSizes {
   size_t max_seg, max_multi, max_item;
@@ -692,7 +696,7 @@ int nrhip_spmm_plan_create(const int64_t* h_indptr, int64_t n_rows, int item_row
   NR_REQUIRE(p, NR_ERR_ARG, "spmm_plan_create: out of host memory");
   p->n_rows = n_rows;
   p->nnz = nnz;
-  p->blocked[0] = p->blocked[1] = p->blocked[2] = nullptr;
+  for (int i = 0; i < 5; ++i) p->blocked[i] = nullptr;
   p->item_rows = item_rows;
   p->item_nnz = item_nnz;
   p->n_hub_items = n_hub_items;
@@ -752,9 +756,9 @@ int nrhip_spmm_plan_destroy(void* plan) {
 }
 
 int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d) {
-  NR_REQUIRE(plan && (d == 64 || d == 128 || d == 256), NR_ERR_ARG,
-             "spmm_plan_attach_blocked: null plan or dim %d not in (64, 128, 256)", d);
-  ((SpmmPlan*)plan)->blocked[d == 64 ? 0 : d == 128 ? 1 : 2] = blocked_plan;       // NULL detaches
+  NR_REQUIRE(plan && blocked_slot(d) >= 0, NR_ERR_ARG,
+             "spmm_plan_attach_blocked: null plan or dim %d not in (16, 32, 64, 128, 256)", d);
+  ((SpmmPlan*)plan)->blocked[blocked_slot(d)] = blocked_plan;       // NULL detaches
   return NR_OK;
 }
 
@@ -767,9 +771,9 @@ int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float*
                         int clear_consumed, uint8_t* d_row_flag, void* stream) {
   NR_REQUIRE(plan, NR_ERR_ARG, "spmm_csr_adam: null plan");
   const SpmmPlan* p = (const SpmmPlan*)plan;
-  NR_REQUIRE(d == 64 && p->blocked[0], NR_ERR_UNSUPPORTED,
+  NR_REQUIRE(d == 64 && p->blocked[blocked_slot(64)], NR_ERR_UNSUPPORTED,
              "spmm_csr_adam: needs the d = 64 lane-group schedule");
-  return nrhip_spmm_blocked_adam(p->blocked[0], d_indices, d_vals, d_X, d_addend, d_grad_b, d_var,
+  return nrhip_spmm_blocked_adam(p->blocked[blocked_slot(64)], d_indices, d_vals, d_X, d_addend, d_grad_b, d_var,
                                  d_m, d_v, alpha, beta1, beta2, eps, clear_consumed, d_row_flag,
                                  stream);
 }
@@ -777,7 +781,7 @@ int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float*
 int nrhip_spmm_plan_has_blocked(const void* plan, int d) {
   if (!plan) return 0;
   const SpmmPlan* p = (const SpmmPlan*)plan;
-  const int slot = d == 64 ? 0 : d == 128 ? 1 : d == 256 ? 2 : -1;
+  const int slot = blocked_slot(d);
   return slot >= 0 && p->blocked[slot] != nullptr;
 }
 
@@ -807,7 +811,7 @@ static int spmm_dispatch(const char* who, const void* plan, const int64_t* d_ind
              "%s: sum_out needs sum_in", who);
   const SpmmPlan* p = (const SpmmPlan*)plan;
   hipStream_t st = (hipStream_t)stream;
-  const int bslot = d == 64 ? 0 : d == 128 ? 1 : d == 256 ? 2 : -1;
+  const int bslot = blocked_slot(d);
   if (bslot >= 0 && p->blocked[bslot])   // persistent lane-group kernel (same contract, same masks)
     return nrhip_spmm_blocked(p->blocked[bslot], d_indices, d_vals, d_X, d_Y, d_addend, d_sum_in,
                               d_sum_out, d_col_mask, d_row_mask, stream);

@@ -81,6 +81,11 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
   constexpr int LPR = D / 4;                   // lanes per row: 16-byte pieces of a d-float row
   constexpr int GPW = NR_WAVE / LPR;           // lane groups (rows in flight) per wave: 4 / 2 / 1
   constexpr int kGroups = kWaves * GPW;
+  // a 16-entry (column, value) chunk of a sub-list is carried by CL lanes of the group, IPL
+  // entries each (narrow rows have fewer than 16 lanes per group)
+  constexpr int CL = LPR < 16 ? LPR : 16;
+  constexpr int IPL = 16 / CL;
+  static_assert(kG % IPL == 0, "broadcast component must be a compile-time index");
   extern __shared__ float4 s_acc[];          // [(r_max + p_max)][LPR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & (LPR - 1), g = lane / LPR, gbase = lane & ~(LPR - 1);
@@ -99,11 +104,16 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     int ei = e0 + wave * GPW + g;
     int4 cur = make_int4(0, 0, 0, 0);
     if (ei < e1) cur = ent[ei];
-    int cur_idx = 0;
-    float cur_val = 0.f;
-    if (c < 16 && c < cur.y) {
-      cur_idx = indices[(uint32_t)cur.z + c];
-      cur_val = vals[(uint32_t)cur.z + c];
+    int cur_idx[IPL];
+    float cur_val[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+      cur_idx[i] = 0;
+      cur_val[i] = 0.f;
+      if (c < CL && c * IPL + i < cur.y) {
+        cur_idx[i] = indices[(uint32_t)cur.z + c * IPL + i];
+        cur_val[i] = vals[(uint32_t)cur.z + c * IPL + i];
+      }
     }
     int cur_want = 1;                                // row filter of the current entry (prefetched)
     if constexpr (MASKED) {
@@ -127,21 +137,29 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
 #pragma unroll
       for (int m = LPR; m < NR_WAVE; m <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, m, NR_WAVE));
       maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-      int nxt_idx = 0;
-      float nxt_val = 0.f;
+      int nxt_idx[IPL];
+      float nxt_val[IPL];
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) { nxt_idx[i] = 0; nxt_val[i] = 0.f; }
       for (int k0 = 0; k0 < maxlen || k0 == 0; k0 += 16) {
-        int my_idx = cur_idx;
-        float my_val = cur_val;
-        if (k0 > 0) {                                // long sub-list: later chunks are not pipelined
-          my_idx = 0;
-          my_val = 0.f;
-          if (c < 16 && k0 + c < len) {
-            my_idx = indices[begin + k0 + c];
-            my_val = vals[begin + k0 + c];
+        int my_idx[IPL];
+        float my_val[IPL];
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+          my_idx[i] = cur_idx[i];
+          my_val[i] = cur_val[i];
+          if (k0 > 0) {                              // long sub-list: later chunks are not pipelined
+            my_idx[i] = 0;
+            my_val[i] = 0.f;
+            if (c < CL && k0 + c * IPL + i < len) {
+              my_idx[i] = indices[begin + k0 + c * IPL + i];
+              my_val[i] = vals[begin + k0 + c * IPL + i];
+            }
           }
-        }
-        if constexpr (MASKED) {
-          if (col_mask && c < 16 && k0 + c < len && col_mask[my_idx] == 0) my_idx = -1;   // X row all zero
+          if constexpr (MASKED) {
+            if (col_mask && c < CL && k0 + c * IPL + i < len && col_mask[my_idx[i]] == 0)
+              my_idx[i] = -1;                        // X row all zero
+          }
         }
         const int nn = min(16, maxlen - k0);
         for (int t0 = 0; t0 < nn || (k0 == 0 && t0 == 0); t0 += kG) {
@@ -150,9 +168,11 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
           bool on[kG];
 #pragma unroll
           for (int u = 0; u < kG; ++u) {
-            const int src = gbase | ((t0 + u) & 15);
-            const int col = __shfl(my_idx, src, NR_WAVE);
-            a[u] = __shfl(my_val, src, NR_WAVE);
+            // entry t0+u of the chunk sits in lane (t0+u)/IPL of the group, component u % IPL
+            // (t0 is a multiple of kG, kG of IPL)
+            const int src = gbase | (((t0 + u) & 15) / IPL);
+            const int col = __shfl(my_idx[u % IPL], src, NR_WAVE);
+            a[u] = __shfl(my_val[u % IPL], src, NR_WAVE);
             on[u] = k0 + t0 + u < len;
             if constexpr (MASKED) {
               on[u] = on[u] && col >= 0;
@@ -164,10 +184,12 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
             }
           }
           if (k0 == 0 && t0 == 0) {                  // prefetch for the next sub-list: first chunk, row filter
-            if (c < 16 && c < nxt.y) {
-              nxt_idx = indices[(uint32_t)nxt.z + c];
-              nxt_val = vals[(uint32_t)nxt.z + c];
-            }
+#pragma unroll
+            for (int i = 0; i < IPL; ++i)
+              if (c < CL && c * IPL + i < nxt.y) {
+                nxt_idx[i] = indices[(uint32_t)nxt.z + c * IPL + i];
+                nxt_val[i] = vals[(uint32_t)nxt.z + c * IPL + i];
+              }
             if constexpr (MASKED) {
               if (row_mask && ein < e1) nxt_want = row_mask[r0 + nxt.w];
             }
@@ -184,8 +206,8 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       }
       if (live) s_acc[slot * LPR + c] = acc;
       cur = nxt;
-      cur_idx = nxt_idx;
-      cur_val = nxt_val;
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) { cur_idx[i] = nxt_idx[i]; cur_val[i] = nxt_val[i]; }
       cur_want = nxt_want;
       ei = ein;
     }
@@ -266,8 +288,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   const int kD = d;
   const int kRMax = r_max > 0 ? r_max : kRMaxDefault * kWaves / 16 * 64 / (d > 0 ? d : 64);
   const int kPMax = p_max > 0 ? p_max : kPMaxDefault * kWaves / 16 * 64 / (d > 0 ? d : 64);
-  NR_REQUIRE(d == 64 || d == 128 || d == 256, NR_ERR_UNSUPPORTED,
-             "spmm_blocked: embedding dim %d not built (64, 128, 256)", d);
+  NR_REQUIRE(d == 16 || d == 32 || d == 64 || d == 128 || d == 256, NR_ERR_UNSUPPORTED,
+             "spmm_blocked: embedding dim %d not built (16, 32, 64, 128, 256)", d);
   NR_REQUIRE(kWaves == 16 || kWaves == 8, NR_ERR_UNSUPPORTED, "spmm_blocked: waves per workgroup %d (8, 16)", kWaves);
   NR_REQUIRE(kSeg >= 16 && (size_t)(kRMax + kPMax) * kD * 4 <= (size_t)kMaxLdsBytes, NR_ERR_UNSUPPORTED,
              "spmm_blocked: seg %d / accumulators %d+%d do not fit", kSeg, kRMax, kPMax);
@@ -447,7 +469,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   allow((const void*)spmm_blocked_kernel<false, 16, 4, DD>); allow((const void*)spmm_blocked_kernel<true, 16, 4, DD>); \
   allow((const void*)spmm_blocked_kernel<false, 8, 8, DD>); allow((const void*)spmm_blocked_kernel<true, 8, 8, DD>);   \
   allow((const void*)spmm_blocked_kernel<false, 8, 4, DD>); allow((const void*)spmm_blocked_kernel<true, 8, 4, DD>)
-  if (d == 64) { NR_ALLOW(64); } else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
+  if (d == 16) { NR_ALLOW(16); } else if (d == 32) { NR_ALLOW(32); } else if (d == 64) { NR_ALLOW(64); }
+  else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
 #undef NR_ALLOW
   if (e != hipSuccess) {
     delete p;
@@ -509,7 +532,8 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
     if (masked) { if (gif == 4) NR_BLK(true, 8, 4, DD); else NR_BLK(true, 8, 8, DD); }             \
     else { if (gif == 4) NR_BLK(false, 8, 4, DD); else NR_BLK(false, 8, 8, DD); }                  \
   }
-  if (p->d == 64) { NR_BLK_D(64) } else if (p->d == 128) { NR_BLK_D(128) } else { NR_BLK_D(256) }
+  if (p->d == 16) { NR_BLK_D(16) } else if (p->d == 32) { NR_BLK_D(32) } else if (p->d == 64) { NR_BLK_D(64) }
+  else if (p->d == 128) { NR_BLK_D(128) } else { NR_BLK_D(256) }
 #undef NR_BLK_D
 #undef NR_BLK
   NR_LAUNCH_CHECK();

@@ -415,12 +415,14 @@ class SpmmCSR:
 
     def ensure_schedule(self, d, force=False):
         """Build the persistent lane-group schedule (spmm_blocked.hip) once and attach it to the
-        plan.  Used for d == 64, where it is 1.3x faster than the work-item kernel; at d = 128 the
+        plan.  Used for d <= 64 (1.3x faster than the work-item kernel at 64, 3-4x faster than the
+        narrow-row segment kernel at 16); at d = 128 the
         two measure equal (92.7 vs 96.7 us per gowalla pass) and the work-item kernel keeps rows of
         up to 256 non-zeros in strict order, so 128 / 256 are attached only with force=True.
         Matrices the schedule does not fit keep the work-item kernel.  NEUREC_SPMM_BLOCKED=0
         disables it (A/B measurements)."""
-        if d not in (64, 128, 256) or (d != 64 and not force and d not in self._blocked):
+        if d not in (16, 32, 64, 128, 256) or \
+                (d in (128, 256) and not force and d not in self._blocked):
             return False
         if d not in self._blocked:
             self._blocked[d] = (None, None)

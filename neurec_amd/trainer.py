@@ -370,8 +370,8 @@ class NGCFEngine:
         dev = E.require_gpu()
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.N = self.n_users + self.n_items
-        self.A = E.SpmmCSR.from_scipy(adj)
-        self.At = E.SpmmCSR.from_scipy(adj_t)
+        self.A = E.SpmmCSR.from_scipy(adj, split_row=n_users)
+        self.At = E.SpmmCSR.from_scipy(adj_t, split_row=n_users)
         f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
         self.E0 = f(embed)
         self.d = self.E0.shape[1]
