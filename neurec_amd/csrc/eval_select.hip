@@ -15,6 +15,9 @@
 // item order is the reference's, bit for bit.
 #include "nr_common.h"
 
+extern "C" int nrhip_score_gemm_items_kmajor(const void* d_ws, int cols, int d, const float** qt,
+                                             int* ipad);   // score_gemm.hip
+
 namespace {
 
 constexpr int kSelWaves = 4;          // waves (rows) per block
@@ -247,6 +250,89 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void mask_train_kernel(
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Pruned evaluation, level 2 (nrhip_eval_tiles).  Level 1 (nrhip_score_tilemax) left, per user,
+// the maximum admissible score of every 64-item tile.  The K+1 best items of a user lie in the
+// K+1 tiles with the largest maxima, and if the (K+1)-th and (K+2)-th tile maxima differ no
+// item outside those tiles can reach or tie the kept set.  So: rank the tile maxima, rescore
+// only the K+1 chosen tiles (the k-ascending fmaf chain the MFMA evaluates — bit-identical),
+// strike the train items, select on the compact row, map the columns back to item ids.  Rows
+// whose answer could depend on ties (inside the compact row or between the two boundary tile
+// maxima) are flagged; the caller re-ranks those from a full score row.
+// ----------------------------------------------------------------------------------------------
+constexpr int kTileItems = 64;
+
+// one wave per user row: sort the chosen tile ids, rescore them, strike train items / pad columns
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
+    const float* __restrict__ P, int64_t ldp, const float* __restrict__ QT, int64_t ipad, int d,
+    const int32_t* __restrict__ users, int rows, int cols, const int32_t* __restrict__ tiles,
+    int tiles_ld, int n_keep, const int64_t* __restrict__ tr_indptr,
+    const int32_t* __restrict__ tr_indices, float* __restrict__ C, int64_t cld,
+    int32_t* __restrict__ tilemap) {
+  __shared__ __attribute__((aligned(16))) float s_p[kSelWaves][128];
+  __shared__ int32_t s_map[kSelWaves][64];
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
+  // ascending tile order keeps "compact column order == item id order" (ties are broken by index)
+  const int mine = lane < n_keep ? tiles[(int64_t)row * tiles_ld + lane] : INT_MAX;
+  int pos = 0;
+  for (int i = 0; i < n_keep; ++i) pos += (__builtin_amdgcn_readlane(mine, i) < mine) ? 1 : 0;
+  if (lane < n_keep) { s_map[wave][pos] = mine; tilemap[(int64_t)row * n_keep + pos] = mine; }
+  for (int k = lane; k < d; k += NR_WAVE) s_p[wave][k] = P[u * ldp + k];
+  wave_lds_sync();
+  float* crow = C + (int64_t)row * cld;
+  for (int s = 0; s < n_keep; ++s) {
+    const int item = s_map[wave][s] * kTileItems + lane;
+    // k-major item copy: lanes = the tile's 64 consecutive items, one coalesced 256-byte load per
+    // k, 8 in flight; the chain is the k-ascending fmaf sequence of the scoring MFMA (MF.py:120-122)
+    const float* q = QT + item;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < d; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = q[(int64_t)min(k0 + i, d - 1) * ipad];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (k0 + i < d) acc = fmaf(s_p[wave][k0 + i], v[i], acc);
+    }
+    crow[s * kTileItems + lane] = item < cols ? acc : -INFINITY;
+  }
+  wave_lds_sync();
+  // strike the user's train items that fall in a chosen tile (uni_evaluator.py:140-143)
+  const int64_t tb = tr_indptr[u], te = tr_indptr[u + 1];
+  for (int64_t t = tb + lane; t < te; t += NR_WAVE) {
+    const int item = tr_indices[t], tile = item / kTileItems;
+    int lo = 0, hi = n_keep;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_map[wave][mid] < tile) lo = mid + 1; else hi = mid; }
+    if (lo < n_keep && s_map[wave][lo] == tile) crow[lo * kTileItems + (item % kTileItems)] = -INFINITY;
+  }
+}
+
+// compact column -> item id; boundary check on the tile maxima; flag_out |= select's tie flag
+__global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ rank,
+                                                         const int32_t* __restrict__ sel_flag,
+                                                         const int32_t* __restrict__ tilemap,
+                                                         const int32_t* __restrict__ tiles,
+                                                         int tiles_ld, const float* __restrict__ M,
+                                                         int64_t mld, int rows, int n_keep, int cut,
+                                                         int32_t* __restrict__ flag_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  for (int k = lane; k < cut; k += NR_WAVE) {
+    const int col = rank[(int64_t)row * kRankStride + k];
+    rank[(int64_t)row * kRankStride + k] =
+        tilemap[(int64_t)row * n_keep + col / kTileItems] * kTileItems + col % kTileItems;
+  }
+  if (lane == 0) {
+    const float inside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep - 1]];
+    const float outside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep]];
+    flag_out[row] = (sel_flag[row] != 0 || !(inside > outside)) ? 1 : 0;
+  }
+}
+
 // column sums in fp64: stage 1 sums 256-row slabs, stage 2 adds the slabs in
 // slab order (fixed order => deterministic).
 constexpr int kSlabRows = 256;
@@ -379,6 +465,107 @@ int nrhip_eval_scores(const float* d_scores, int64_t ld, int rows, int cols,
   NR_LAUNCH_CHECK();
   if (d_n_exact)
     NR_CHECK_HIP(hipMemcpyAsync(d_n_exact, w.n_exact, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return NR_OK;
+}
+
+/* Workspace of nrhip_eval_tiles for `rows` rows (includes the selection scratch). */
+static size_t eval_tiles_ws_bytes(int rows, int top_k) {
+  const size_t r = (size_t)(rows > 0 ? rows : 1);
+  const int n_keep = top_k + 1;
+  return eval_ws_bytes((int)r) + nr_align_up(r * (size_t)(n_keep + 1) * 4, 256) +
+         nr_align_up(r * (size_t)n_keep * 4, 256) +
+         nr_align_up(r * (size_t)n_keep * kTileItems * sizeof(float), 256);
+}
+
+int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes) {
+  NR_REQUIRE(bytes && rows >= 0 && top_k >= 1 && top_k <= 62, NR_ERR_ARG,
+             "eval_tiles_workspace_bytes: rows=%d top_k=%d (1..62)", rows, top_k);
+  *bytes = eval_tiles_ws_bytes(rows, top_k);
+  return NR_OK;
+}
+
+/* Pruned full-rank evaluation of `rows` users from the tile maxima d_M[rows][mld] of
+ * nrhip_score_tilemax (same users, same cols): writes the metric rows like nrhip_eval_scores and
+ * d_flag_out[r] = 1 for the rows whose ranking may depend on ties — those rows of d_out are
+ * provisional and must be recomputed from a full score row (nrhip_score_gemm + nrhip_mask_train +
+ * nrhip_eval_scores).  Needs ceil(cols/64) >= top_k + 2 tiles. */
+int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ldp,
+                     const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
+                     const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                     const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                     const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
+                     int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_M && d_P && d_gemm_ws && d_tr_indptr && d_tr_indices && d_truth_indptr && d_truth_indices &&
+                 metric_ids_host && d_out && d_flag_out && d_ws,
+             NR_ERR_ARG, "eval_tiles: null pointer argument");
+  NR_REQUIRE(top_k >= 1 && top_k <= 62, NR_ERR_UNSUPPORTED, "eval_tiles: top_k=%d outside 1..62", top_k);
+  NR_REQUIRE(d >= 1 && d <= 128 && ldp >= d, NR_ERR_UNSUPPORTED,
+             "eval_tiles: embedding dim %d outside 1..128", d);
+  const float* qt = nullptr;
+  int ipad = 0;
+  {
+    const int rc0 = nrhip_score_gemm_items_kmajor(d_gemm_ws, cols, d, &qt, &ipad);
+    if (rc0 != NR_OK) return rc0;
+  }
+  const int n_tiles = (cols + kTileItems - 1) / kTileItems;
+  NR_REQUIRE(n_tiles >= top_k + 2 && mld >= n_tiles, NR_ERR_ARG,
+             "eval_tiles: %d tiles < top_k + 2 (use the full score path)", n_tiles);
+  NR_REQUIRE(n_metric >= 1 && n_metric <= 8 && rows >= 0, NR_ERR_ARG, "eval_tiles: bad sizes");
+  MetricIds mids;
+  mids.n = n_metric;
+  for (int i = 0; i < n_metric; ++i) {
+    NR_REQUIRE(metric_ids_host[i] >= 1 && metric_ids_host[i] <= 5, NR_ERR_ARG,
+               "eval_tiles: metric id %d is not one of 1..5", metric_ids_host[i]);
+    mids.id[i] = metric_ids_host[i];
+  }
+  if (rows == 0) return NR_OK;
+  NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, top_k), NR_ERR_WORKSPACE,
+             "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, top_k));
+  hipStream_t st = (hipStream_t)stream;
+  const int n_keep = top_k + 1, tiles_ld = n_keep + 1;
+  EvalWs w = carve_ws(d_ws, rows);
+  char* p = (char*)d_ws + eval_ws_bytes(rows);
+  int32_t* tiles = (int32_t*)p;   p += nr_align_up((size_t)rows * tiles_ld * 4, 256);
+  int32_t* tilemap = (int32_t*)p; p += nr_align_up((size_t)rows * n_keep * 4, 256);
+  float* C = (float*)p;
+  const int64_t cld = (int64_t)n_keep * kTileItems;
+  // 1. the top_k + 2 largest tile maxima per user (their order among equal maxima is irrelevant)
+  const int blocks = (rows + kSelWaves - 1) / kSelWaves;
+  if ((mld % 4 == 0) && (((uintptr_t)d_M) % 16 == 0))
+    hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
+                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag);
+  else
+    hipLaunchKernelGGL(select_rows_kernel<1>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
+                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag);
+  NR_LAUNCH_CHECK();
+  {
+    const int64_t n = (int64_t)rows * tiles_ld;
+    hipLaunchKernelGGL(copy_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.rank,
+                       rows, tiles_ld, tiles);
+    NR_LAUNCH_CHECK();
+  }
+  // 2. rescore the top_k + 1 chosen tiles, train items struck out
+  hipLaunchKernelGGL(rescore_tiles_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_P, ldp,
+                     qt, (int64_t)ipad, d, d_users, rows, cols, tiles, tiles_ld, n_keep, d_tr_indptr,
+                     d_tr_indices, C, cld, tilemap);
+  NR_LAUNCH_CHECK();
+  // 3. rank the compact rows (no in-place exact path: a tie needs the full row)
+  const int ccols = (int)cld;
+  const int sort_len = (2 * top_k < ccols) ? 2 * top_k : ccols;
+  hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld,
+                     rows, ccols, sort_len, top_k, w.rank, w.flag);
+  NR_LAUNCH_CHECK();
+  // 4. columns -> item ids, boundary check, flags
+  hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
+                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k, d_flag_out);
+  NR_LAUNCH_CHECK();
+  // 5. metrics
+  InvLog2Table tbl;
+  for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));
+  hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, w.rank, rows,
+                     top_k, d_users, d_truth_indptr, d_truth_indices, mids, tbl, d_out,
+                     (int32_t*)nullptr);
+  NR_LAUNCH_CHECK();
   return NR_OK;
 }
 

@@ -19,6 +19,7 @@
 // L1.  The kernel is bound by the HBM write of S (4·I bytes per user), not by
 // the matrix pipe: d is only 16..128.
 #include "nr_common.h"
+#include <limits.h>
 
 namespace {
 
@@ -95,6 +96,106 @@ __global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_gemm_kernel(
         if (ca < wcols) S[(int64_t)ub * lds + ca] = c10[reg];
         if (cb < wcols) S[(int64_t)ub * lds + cb] = c11[reg];
       }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Tile maxima for the pruned evaluation: the same MFMA loop with the operands swapped (item tile
+// as the row operand, user panel as the column operand), so that a lane holds 32 item scores of
+// ONE user per 64-item tile and the tile maximum is an in-lane reduction.  The user's train items
+// are struck out (-inf) before the maximum — a cursor per user column walks the ascending train
+// list as the tiles go by — and so are the pad columns >= cols.  S is never written:
+// M[user][tile] = max over the tile's admissible items, 4·⌈I/64⌉ bytes per user instead of 4·I.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void strike(f32x16& c, int reg) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (r == reg) c[r] = -INFINITY;
+}
+__device__ __forceinline__ float max16(const f32x16& c) {
+  float m = c[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
+  return m;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_tilemax_kernel(
+    const float* __restrict__ PT, int bpad, const float* __restrict__ QT, int ipad, int rows,
+    int cols, const int32_t* __restrict__ users, const int64_t* __restrict__ tr_indptr,
+    const int32_t* __restrict__ tr_indices, float* __restrict__ M, int64_t mld,
+    int tiles_per_chunk) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int u0 = (blockIdx.x * 4 + wave) * 64;
+  if (u0 >= bpad) return;
+
+  float a0[KS], a1[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float* p = PT + (int64_t)(2 * s + h) * bpad + u0 + j;
+    a0[s] = p[0];
+    a1[s] = p[32];
+  }
+  const int n_tiles = ipad / 64;
+  const int t_begin = blockIdx.y * tiles_per_chunk;
+  const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+  // train-list cursors of this lane's two users (column j of user block 0 / 1)
+  const int ra = u0 + j, rb = u0 + 32 + j;
+  int64_t pa = 0, ea = 0, pb = 0, eb = 0;
+  if (ra < rows) { const int64_t u = users ? users[ra] : ra; pa = tr_indptr[u]; ea = tr_indptr[u + 1]; }
+  if (rb < rows) { const int64_t u = users ? users[rb] : rb; pb = tr_indptr[u]; eb = tr_indptr[u + 1]; }
+  auto lower = [&](int64_t lo, int64_t hi, int key) {        // first position with item >= key
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tr_indices[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  pa = lower(pa, ea, t_begin * 64);
+  pb = lower(pb, eb, t_begin * 64);
+  int na = pa < ea ? tr_indices[pa] : INT_MAX;                // next train item of each user
+  int nb = pb < eb ? tr_indices[pb] : INT_MAX;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int it = t * 64;
+    f32x16 c00 = {0}, c10 = {0}, c01 = {0}, c11 = {0};   // cXY: item block X (rows) x user block Y
+    const float* q = QT + (int64_t)h * ipad + it + j;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float b0 = q[(int64_t)(2 * s) * ipad];
+      const float b1 = q[(int64_t)(2 * s) * ipad + 32];
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0[s], c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0[s], c10, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1[s], c01, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1[s], c11, 0, 0, 0);
+    }
+    // rows of the 32x32 result held by this lane: item = it + 32*X + (reg&3) + 8*(reg>>2) + 4*h
+    if (__ballot(na < it + 64 || nb < it + 64)) {            // rare: a train item falls in the tile
+      while (na < it + 64) {
+        const int o = na - it, row = o & 31;
+        if (((row >> 2) & 1) == h) { const int reg = (row & 3) + 4 * (row >> 3); if (o < 32) strike(c00, reg); else strike(c10, reg); }
+        ++pa; na = pa < ea ? tr_indices[pa] : INT_MAX;
+      }
+      while (nb < it + 64) {
+        const int o = nb - it, row = o & 31;
+        if (((row >> 2) & 1) == h) { const int reg = (row & 3) + 4 * (row >> 3); if (o < 32) strike(c01, reg); else strike(c11, reg); }
+        ++pb; nb = pb < eb ? tr_indices[pb] : INT_MAX;
+      }
+    }
+    if (it + 64 > cols) {                                     // last tile: pad columns
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (it + rr >= cols) { c00[reg] = -INFINITY; c01[reg] = -INFINITY; }
+        if (it + 32 + rr >= cols) { c10[reg] = -INFINITY; c11[reg] = -INFINITY; }
+      }
+    }
+    float ma = fmaxf(max16(c00), max16(c10)), mb = fmaxf(max16(c01), max16(c11));
+    ma = fmaxf(ma, __shfl_xor(ma, 32, 64));
+    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    if (h == 0) {
+      if (ra < rows) M[(int64_t)ra * mld + t] = ma;
+      if (rb < rows) M[(int64_t)rb * mld + t] = mb;
     }
   }
 }
@@ -187,6 +288,60 @@ int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int 
     default: NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "score_gemm: dp=%d", dp);
   }
 #undef NR_GEMM_CASE
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* The k-major item copy made by nrhip_score_gemm_prepare_items: QT[k][item], k < roundup(d),
+ * item < *ipad (zero padded).  Used by the level-2 rescoring of the pruned evaluation. */
+int nrhip_score_gemm_items_kmajor(const void* d_ws, int cols, int d, const float** qt, int* ipad) {
+  NR_REQUIRE(d_ws && qt && ipad && cols >= 1, NR_ERR_ARG, "score_gemm_items_kmajor: bad arguments");
+  NR_REQUIRE(padded_dim(d) > 0, NR_ERR_UNSUPPORTED, "score_gemm: embedding dim %d > 128 not built", d);
+  *qt = (const float*)d_ws;
+  *ipad = round_up64(cols);
+  return NR_OK;
+}
+
+/* Pruned evaluation, level 1 (see nrhip_eval_tiles): M[r][t] = max over the admissible items of
+ * 64-item tile t of the scores of user row r — train items of the user and columns >= cols
+ * excluded — computed by the scoring loop without ever writing the scores.  Item side prepared
+ * with nrhip_score_gemm_prepare_items; d_M has rows x mld floats, mld >= ceil(cols/64). */
+int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
+                        int d, const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                        float* d_M, int64_t mld, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_P && d_M && d_ws && d_tr_indptr && d_tr_indices && cols >= 1 && d >= 1 && ldp >= d &&
+                 rows >= 0 && mld >= (cols + 63) / 64,
+             NR_ERR_ARG, "score_tilemax: bad arguments");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_tilemax: embedding dim %d > 128 not built", d);
+  if (rows == 0) return NR_OK;
+  GemmWs g = carve(d_ws, rows, cols, dp);
+  NR_REQUIRE(ws_bytes >= g.qt_bytes + g.pt_bytes, NR_ERR_WORKSPACE,
+             "score_tilemax: workspace %zu < %zu", ws_bytes, g.qt_bytes + g.pt_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int bpad = round_up64(rows), ipad = round_up64(cols);
+  hipLaunchKernelGGL(gather_transpose_kernel, dim3(bpad / 64, (dp + 63) / 64), dim3(256), 0, st,
+                     d_P, ldp, d_users, rows, d, g.PT, bpad, dp);
+  NR_LAUNCH_CHECK();
+  const int bx = (bpad / 64 + 3) / 4;
+  const int n_tiles = ipad / 64;
+  int tpc = (int)(((int64_t)n_tiles * bx + 2047) / 2048);
+  if (tpc < 4) tpc = 4;
+  if (tpc > n_tiles) tpc = n_tiles;
+  const int by = (n_tiles + tpc - 1) / tpc;
+  dim3 grid(bx, by), block(256);
+#define NR_TMAX_CASE(KS)                                                                       \
+  hipLaunchKernelGGL(score_tilemax_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QT, ipad, rows, \
+                     cols, d_users, d_tr_indptr, d_tr_indices, d_M, mld, tpc)
+  switch (dp) {
+    case 16: NR_TMAX_CASE(8); break;
+    case 32: NR_TMAX_CASE(16); break;
+    case 48: NR_TMAX_CASE(24); break;
+    case 64: NR_TMAX_CASE(32); break;
+    case 128: NR_TMAX_CASE(64); break;
+    default: NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "score_tilemax: dp=%d", dp);
+  }
+#undef NR_TMAX_CASE
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

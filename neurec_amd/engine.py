@@ -201,6 +201,45 @@ class ScoreGemm:
         return out[:rows]
 
 
+    def tile_maxima(self, user_table, users, train_csr, out=None):
+        """Pruned evaluation, level 1: M[r][t] = max admissible score of user row r over 64-item
+        tile t (train items and pad columns excluded); the scores themselves are never stored."""
+        rows = user_table.shape[0] if users is None else users.numel()
+        if rows > self.max_rows:
+            raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
+        n_tiles = (self.cols + 63) // 64
+        mld = (n_tiles + 3) // 4 * 4
+        if out is None:
+            out = torch.empty((rows, mld), dtype=torch.float32, device=self.ws.device)
+        call("nrhip_score_tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
+             _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d,
+             _ptr(train_csr.indptr), _ptr(train_csr.indices), _ptr(out, torch.float32),
+             out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
+        return out[:rows]
+
+
+_tiles_ws = Workspace()
+
+
+def eval_tiles(M, user_table, gemm, users, train_csr, truth_csr, metric_ids, top_k, out, flags):
+    """Pruned evaluation, level 2 (nrhip_eval_tiles): metric rows into `out`, tie flags into
+    `flags` (int32 per row; flagged rows must be recomputed from full score rows).  `gemm` is the
+    ScoreGemm whose prepared (k-major) item copy the rescoring reads."""
+    rows = M.shape[0]
+    nbytes = C.c_size_t(0)
+    call("nrhip_eval_tiles_workspace_bytes", rows, top_k, C.byref(nbytes))
+    ws = _tiles_ws.get(nbytes.value)
+    nm = len(metric_ids)
+    ids = (C.c_int * nm)(*[int(m) for m in metric_ids])
+    call("nrhip_eval_tiles", C.c_void_p(M.data_ptr()), M.stride(0), _ptr(user_table, torch.float32),
+         user_table.stride(0), _ptr(gemm.ws), gemm.d,
+         _ptr(users, torch.int32, allow_none=True), rows, gemm.cols,
+         _ptr(train_csr.indptr), _ptr(train_csr.indices), _ptr(truth_csr.indptr),
+         _ptr(truth_csr.indices), ids, nm, top_k, _ptr(out, torch.float32),
+         _ptr(flags, torch.int32), _ptr(ws), ws.numel(), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- sampler
 def sample_bpr_epoch(train_csr, row_of, n_items, neg_num, seed, epoch, shuffle=True, begin=0,
                      count=None, out=None):

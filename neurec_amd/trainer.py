@@ -299,7 +299,9 @@ class FullRankEvaluator:
     metrics, batch by batch; only the per-user metric matrix (or its column sums)
     ever crosses PCIe."""
 
-    def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True):
+    def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True,
+                 pruned=False):
+        self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
         self.train, self.test = train_csr, test_csr
         self.metric_ids = [int(m) for m in metric_ids]
         self.top_k = int(top_k)
@@ -323,7 +325,9 @@ class FullRankEvaluator:
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
-        if not self.overlap or len(starts) < 2:
+        if self.pruned and (cols + 63) // 64 >= self.top_k + 2 and self.top_k <= 62 and n > 0:
+            self._evaluate_pruned(user_table, item_table, test_users, per_user, starts)
+        elif not self.overlap or len(starts) < 2:
             for b in starts:
                 u = test_users[b:b + self.batch_rows]
                 S = self._gemm(user_table, u, out=self._scores[0])
@@ -356,6 +360,33 @@ class FullRankEvaluator:
         if exact_mean:
             return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
         return (E.colsum(per_user) / n).cpu().numpy()
+
+    def _evaluate_pruned(self, user_table, item_table, test_users, per_user, starts):
+        """Level 1: tile maxima from the scoring loop (scores never stored); level 2: rescore and
+        rank the top_k+1 best tiles per user.  Rows whose ranking could depend on ties come back
+        flagged and are recomputed from full score rows — same numbers as the materialised path."""
+        cols = item_table.shape[0]
+        n = test_users.numel()
+        flags = torch.zeros(n, dtype=torch.int32, device=test_users.device)
+        self.n_flagged = 0
+        for b in starts:
+            u = test_users[b:b + self.batch_rows]
+            M = self._gemm.tile_maxima(user_table, u, self.train)
+            E.eval_tiles(M, user_table, self._gemm, u, self.train, self.test, self.metric_ids,
+                         self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()])
+        redo = torch.nonzero(flags, as_tuple=False).flatten()            # one host sync per evaluation
+        self.n_flagged = int(redo.numel())
+        if self.n_flagged:
+            fixed = torch.empty((self.n_flagged, per_user.shape[1]), dtype=torch.float32,
+                                device=per_user.device)
+            for lo in range(0, self.n_flagged, self.batch_rows):
+                idx = redo[lo:lo + self.batch_rows]
+                u = test_users[idx].contiguous()
+                S = self._gemm(user_table, u, out=self._scores[0])
+                E.mask_train(S, u, self.train, cols=cols)
+                E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
+                              out=fixed[lo:lo + u.numel()])
+            per_user[redo] = fixed                                       # plumbing copy of the rows
 
 
 class NGCFEngine:

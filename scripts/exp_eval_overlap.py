@@ -14,9 +14,9 @@ Q = torch.from_numpy((rng.randn(I, 64) * 0.1).astype(np.float32)).cuda()
 trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
 users = torch.from_numpy(np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)).cuda()
 ref = None
-for rows in (2048, 4096, 8192, 16384):
-    for overlap in (False, True):
-        ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=rows, overlap=overlap)
+for rows in (4096, 8192, 16384, 29858):
+    for overlap, pruned in ((False, False), (True, False), (False, True)):
+        ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=rows, overlap=overlap, pruned=pruned)
         m = ev.evaluate_factors(P, Q, users)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -26,5 +26,6 @@ for rows in (2048, 4096, 8192, 16384):
         dt = (time.perf_counter() - t0) / 5
         if ref is None:
             ref = m
-        print("batch_rows=%5d overlap=%d : %.2f ms  %.2f M users/s  same=%s"
-              % (rows, overlap, dt * 1e3, users.numel() / dt / 1e6, np.array_equal(ref, m)), flush=True)
+        print("batch_rows=%5d overlap=%d pruned=%d : %.2f ms  %.2f M users/s  same=%s flagged=%s"
+              % (rows, overlap, pruned, dt * 1e3, users.numel() / dt / 1e6, np.array_equal(ref, m),
+                 getattr(ev, "n_flagged", "-")), flush=True)

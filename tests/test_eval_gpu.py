@@ -206,3 +206,42 @@ def test_colsum(eng):
     m = rng.rand(3001, 100).astype(np.float32)
     got = eng.colsum(_dev(m)).cpu().numpy()
     np.testing.assert_allclose(got, m.astype(np.float64).sum(0), rtol=1e-13)
+
+
+@pytest.mark.parametrize("d,ties", [(64, False), (50, False), (16, True)])
+def test_pruned_evaluation_equals_materialised_scores(d, ties):
+    """nrhip_score_tilemax + nrhip_eval_tiles (no score matrix) == score GEMM -> mask -> select:
+    identical per-user metric rows, with tie-dependent rows recomputed through the full path."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(d)
+    U, I = 700, 5000                                   # 79 tiles of 64 items, last one partial
+    P = rng.randn(U, d).astype(np.float32) * 0.3
+    Q = rng.randn(I, d).astype(np.float32) * 0.3
+    if ties:                                           # coarse values: many exactly equal scores
+        P, Q = np.round(P * 2) / 2, np.round(Q * 2) / 2
+        Q[100:140] = Q[100]                            # identical items spanning two tiles
+    tr = sp.random(U, I, 0.01, random_state=1, format="csr", dtype=np.float32)
+    hot = rng.choice(I, 300, replace=False)            # make train items score high for their users
+    tr = tr.tolil()
+    for u in range(0, U, 3):
+        best = np.argsort(-(P[u] @ Q.T))[:rng.randint(1, 30)]
+        tr[u, best] = 1.0
+    tr = tr.tocsr(); tr.data[:] = 1.0; tr.sort_indices()
+    te = sp.random(U, I, 0.004, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    users = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    ud = torch.from_numpy(users).cuda()
+    full = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256)
+    lean = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, pruned=True)
+    a = full.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    b = lean.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    np.testing.assert_array_equal(a, b)
+    if ties:
+        assert lean.n_flagged > 0                      # the tie rows really went through the full path
+    else:
+        assert lean.n_flagged <= len(users) // 20
