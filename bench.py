@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)     # conf/LightGCN.properties:5
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
-    ap.add_argument("--eval-batch", type=int, default=16384)
+    ap.add_argument("--eval-batch", type=int, default=32768)
     ap.add_argument("--dp-mode", choices=("triplets", "allreduce", "rowshard"), default="triplets",
                     help="N>1 exchange: all-gather the batch ids (default), all-reduce dL/dE0, or "
                          "row-sharded tables (all-gather per hop + all-to-all lookups; config 4 path)")

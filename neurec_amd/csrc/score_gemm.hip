@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(
 }
 
 template <int KS>
-__global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_gemm_kernel(
+__global__ __launch_bounds__(256, 1) void score_gemm_kernel(
     const float* __restrict__ PT, int bpad, const float* __restrict__ QT, int ipad, int rows,
     float* __restrict__ S, int64_t lds, int wcols, int tiles_per_chunk) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -69,18 +69,27 @@ __global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_gemm_kernel(
   const int n_tiles = ipad / 64;
   const int t_begin = blockIdx.y * tiles_per_chunk;
   const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int it = t * 64;
-    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-    const float* q = QT + (int64_t)h * ipad + it + j;
+  // B operands of the next tile are requested before the current tile's MFMAs are issued, so the
+  // matrix pipe does not wait on L2 at every tile boundary (two register sets, tile loop unrolled
+  // by two)
+  float bA0[KS], bA1[KS], bB0[KS], bB1[KS];
+  auto load_b = [&](int t, float (&x0)[KS], float (&x1)[KS]) {
+    const float* q = QT + (int64_t)h * ipad + t * 64 + j;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float b0 = q[(int64_t)(2 * s) * ipad];
-      const float b1 = q[(int64_t)(2 * s) * ipad + 32];
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0, c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1, c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0, c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1, c11, 0, 0, 0);
+      x0[s] = q[(int64_t)(2 * s) * ipad];
+      x1[s] = q[(int64_t)(2 * s) * ipad + 32];
+    }
+  };
+  auto tile = [&](int t, const float (&x0)[KS], const float (&x1)[KS]) {
+    const int it = t * 64;
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x0[s], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], x1[s], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x0[s], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], x1[s], c11, 0, 0, 0);
     }
     // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -97,9 +106,18 @@ __global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_gemm_kernel(
         if (cb < wcols) S[(int64_t)ub * lds + cb] = c11[reg];
       }
     }
+  };
+  if (t_begin >= t_end) return;
+  load_b(t_begin, bA0, bA1);
+  for (int t = t_begin; t < t_end; t += 2) {
+    if (t + 1 < t_end) load_b(t + 1, bB0, bB1);
+    tile(t, bA0, bA1);
+    if (t + 1 < t_end) {
+      if (t + 2 < t_end) load_b(t + 2, bA0, bA1);
+      tile(t + 1, bB0, bB1);
+    }
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Tile maxima for the pruned evaluation: the same MFMA loop with the operands swapped (item tile
@@ -122,7 +140,7 @@ __device__ __forceinline__ float max16(const f32x16& c) {
 }
 
 template <int KS>
-__global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_tilemax_kernel(
+__global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
     const float* __restrict__ PT, int bpad, const float* __restrict__ QT, int ipad, int rows,
     int cols, const int32_t* __restrict__ users, const int64_t* __restrict__ tr_indptr,
     const int32_t* __restrict__ tr_indices, float* __restrict__ M, int64_t mld,
@@ -156,18 +174,24 @@ __global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_tilemax_kernel(
   int na = pa < ea ? tr_indices[pa] : INT_MAX;                // next train item of each user
   int nb = pb < eb ? tr_indices[pb] : INT_MAX;
 
-  for (int t = t_begin; t < t_end; ++t) {
-    const int it = t * 64;
-    f32x16 c00 = {0}, c10 = {0}, c01 = {0}, c11 = {0};   // cXY: item block X (rows) x user block Y
-    const float* q = QT + (int64_t)h * ipad + it + j;
+  float bA0[KS], bA1[KS], bB0[KS], bB1[KS];             // two B register sets (see score_gemm_kernel)
+  auto load_b = [&](int t, float (&x0)[KS], float (&x1)[KS]) {
+    const float* q = QT + (int64_t)h * ipad + t * 64 + j;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float b0 = q[(int64_t)(2 * s) * ipad];
-      const float b1 = q[(int64_t)(2 * s) * ipad + 32];
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0[s], c00, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0[s], c10, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1[s], c01, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1[s], c11, 0, 0, 0);
+      x0[s] = q[(int64_t)(2 * s) * ipad];
+      x1[s] = q[(int64_t)(2 * s) * ipad + 32];
+    }
+  };
+  auto tile = [&](int t, const float (&x0)[KS], const float (&x1)[KS]) {
+    const int it = t * 64;
+    f32x16 c00 = {0}, c10 = {0}, c01 = {0}, c11 = {0};   // cXY: item block X (rows) x user block Y
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[s], a0[s], c00, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[s], a0[s], c10, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[s], a1[s], c01, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[s], a1[s], c11, 0, 0, 0);
     }
     // rows of the 32x32 result held by this lane: item = it + 32*X + (reg&3) + 8*(reg>>2) + 4*h
     if (__ballot(na < it + 64 || nb < it + 64)) {            // rare: a train item falls in the tile
@@ -196,6 +220,16 @@ __global__ __launch_bounds__(256, (KS <= 32 ? 2 : 1)) void score_tilemax_kernel(
     if (h == 0) {
       if (ra < rows) M[(int64_t)ra * mld + t] = ma;
       if (rb < rows) M[(int64_t)rb * mld + t] = mb;
+    }
+  };
+  if (t_begin >= t_end) return;
+  load_b(t_begin, bA0, bA1);
+  for (int t = t_begin; t < t_end; t += 2) {
+    if (t + 1 < t_end) load_b(t + 1, bB0, bB1);
+    tile(t, bA0, bA1);
+    if (t + 1 < t_end) {
+      if (t + 2 < t_end) load_b(t + 2, bA0, bA1);
+      tile(t + 1, bB0, bB1);
     }
   }
 }
