@@ -21,7 +21,7 @@ extern "C" int nrhip_score_gemm_items_kmajor(const void* d_ws, int cols, int d, 
 namespace {
 
 constexpr int kSelWaves = 4;          // waves (rows) per block
-constexpr int kSelSlots = 1024;       // candidate slots per wave (8 KiB)
+constexpr int kSelSlots = 512;        // candidate slots per wave (4 KiB)
 constexpr int kMaxSort = 2 * 128;     // NRHIP_MAX_TOPK * 2
 constexpr int kRankStride = kMaxSort; // ints per row in the rank workspace
 
@@ -55,6 +55,86 @@ __device__ int wave_extract_top(uint64_t* keys, int cnt, uint64_t* top, int want
   return take;
 }
 
+
+// ----------------------------------------------------------------------------
+// Cheap ring maintenance.  wave_extract_top above costs ~100 VALU instructions per extracted key
+// (PMC: 13.7 k VALU per 41 k-element row, all of it refreshes); what a refresh needs is only the
+// `want`-th largest score and the keys at or above it, in any order:
+//   * a 32-pass radix select over the keys' order words (held in registers, MAXPL per lane),
+//   * an in-place stable compaction of the keys with order >= that value.
+// The select stops at the first prefix that leaves at most `slack` keys more than wanted: that
+// prefix is a lower bound of the want-th largest score, which is all a threshold has to be.
+// Every key at or above the threshold is kept (ties included), so no tie can straddle the kept /
+// dropped boundary here.  Returns the number kept (>= want); T receives the threshold order word.
+// ----------------------------------------------------------------------------
+constexpr int kMaxPerLane = kSelSlots / NR_WAVE;
+
+__device__ int wave_radix_compact(uint64_t* keys, int cnt, int want, int slack, uint32_t& T) {
+  const int lane = nr_lane();
+  uint32_t ord[kMaxPerLane];
+  bool valid[kMaxPerLane];
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int idx = lane + NR_WAVE * i;
+    valid[i] = idx < cnt;
+    ord[i] = valid[i] ? nr::key_order(keys[idx]) : 0u;
+  }
+  uint32_t prefix = 0;
+  int need = want, cand = cnt;                   // candidates = keys that match `prefix` so far
+  for (int b = 31; b >= 0; --b) {
+    int c1 = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i) {
+      const uint32_t x = ord[i] ^ prefix;
+      const bool hi_match = (b == 31) ? true : ((x >> (b + 1)) == 0u);
+      c1 += __popcll(__ballot(valid[i] && hi_match && ((ord[i] >> b) & 1u)));
+    }
+    if (c1 >= need) { prefix |= (1u << b); cand = c1; }
+    else { need -= c1; cand -= c1; }
+    // prefix (low bits zero) is already a valid threshold: (want - need) + cand keys lie at or
+    // above it.  Stop as soon as that is at most `slack` more than wanted.
+    if (cand <= need + slack) break;
+  }
+  T = prefix;
+  int out = 0;
+  const int chunks = (cnt + NR_WAVE - 1) / NR_WAVE;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    if (i >= chunks) break;
+    const int idx = lane + NR_WAVE * i;
+    const uint64_t k = valid[i] ? keys[idx] : 0ull;          // whole chunk read before any write
+    const bool keep = valid[i] && ord[i] >= prefix;
+    const uint64_t mask = __ballot(keep);
+    wave_lds_sync();
+    if (keep) keys[out + nr_mbcnt(mask)] = k;                // out + rank <= idx: never ahead of a read
+    out += __popcll(mask);
+    wave_lds_sync();
+  }
+  return out;
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  const uint32_t lo = __shfl_xor((uint32_t)v, m, NR_WAVE);
+  const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, NR_WAVE);
+  return ((uint64_t)hi << 32) | lo;
+}
+// descending bitonic sort of one key per lane (0 = empty sorts last)
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v) {
+  const int lane = nr_lane();
+#pragma unroll
+  for (int k = 2; k <= NR_WAVE; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t o = shfl_xor_u64(v, j);
+      const bool desc_block = (lane & k) == 0;
+      const bool lower = (lane & j) == 0;
+      const bool take_max = lower == desc_block;
+      v = take_max ? (v > o ? v : o) : (v < o ? v : o);
+    }
+  }
+  return v;
+}
+
 // ----------------------------------------------------------------------------
 // Selection kernel.  VEC = floats per lane per load (4 needs 16-byte aligned
 // rows).  rank[row][0..cut) <- item ids in rank order; flag[row] <- 1 when
@@ -80,8 +160,22 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
   bool btie = false;                  // a tie straddled the kept/dropped boundary
   uint32_t btie_order = 0;
 
+  int limit = max(128, 2 * sort_len);             // ring fill that triggers the next refresh
+  if (limit > kSelSlots - NR_WAVE * VEC) limit = kSelSlots - NR_WAVE * VEC;
+
   auto refresh = [&]() {
     wave_lds_sync();
+    if (cnt >= sort_len) {                       // cheap path: threshold + compaction, ties all kept
+      uint32_t T;
+      const int kept = wave_radix_compact(keys, cnt, sort_len, 16, T);
+      if (kept <= limit / 2 + sort_len) {
+        tau = nr::unorder_f32(T);
+        cnt = kept;
+        wave_lds_sync();
+        return;
+      }
+      cnt = kept;                                // a huge tie group: fall through to the exact cut
+    }
     uint64_t nb = 0;
     int take = wave_extract_top(keys, cnt, top, sort_len, nb);
     wave_lds_sync();
@@ -101,25 +195,45 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
 
   for (int base = 0; base < cols; base += step) {
     float v[UNITS][VEC];
+    if (base + step <= cols) {                 // interior of the row: unconditional back-to-back loads
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-      const int e0 = base + u * UNIT_ELEMS + lane * VEC;
-      if constexpr (VEC == 4) {
-        if (e0 + 3 < cols) {
+      for (int u = 0; u < UNITS; ++u) {
+        const int e0 = base + u * UNIT_ELEMS + lane * VEC;
+        if constexpr (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4*>(srow + e0);
           v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
         } else {
-#pragma unroll
-          for (int c = 0; c < VEC; ++c) v[u][c] = (e0 + c < cols) ? srow[e0 + c] : NAN;
+          v[u][0] = srow[e0];
         }
-      } else {
-        v[u][0] = (e0 < cols) ? srow[e0] : NAN;   // NaN never passes `>= tau`
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        const int e0 = base + u * UNIT_ELEMS + lane * VEC;
+        if constexpr (VEC == 4) {
+          if (e0 + 3 < cols) {
+            const float4 t = *reinterpret_cast<const float4*>(srow + e0);
+            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+          } else {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) v[u][c] = (e0 + c < cols) ? srow[e0 + c] : NAN;
+          }
+        } else {
+          v[u][0] = (e0 < cols) ? srow[e0] : NAN;   // NaN never passes `>= tau`
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
-      if (cnt > kSelSlots - UNIT_ELEMS) refresh();
+      // the threshold is refreshed early and then less and less often (128, 256, ... slots): a
+      // finite tau after the first few hundred elements is what keeps the ring quiet afterwards
+      if (cnt > limit) { refresh(); limit = min(2 * limit, kSelSlots - UNIT_ELEMS); }
       const int e0 = base + u * UNIT_ELEMS + lane * VEC;
+      if constexpr (VEC == 4) {
+        // one vote per 16-byte word first: most words hold nothing >= tau once tau is finite
+        const float m = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
+        if (__ballot(m >= tau) == 0) continue;
+      }
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
         const bool pass = v[u][c] >= tau;
@@ -132,10 +246,27 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
     }
   }
 
-  // final ranking
+  // final ranking: compact to the keys at or above the sort_len-th score, then (when they fit one
+  // per lane) a register bitonic sort; otherwise the selection loop
   wave_lds_sync();
   uint64_t nb = 0;
-  const int take = wave_extract_top(keys, cnt, top, sort_len, nb);
+  int take;
+  bool sorted_in_regs = false;
+  if (cnt >= sort_len && sort_len < NR_WAVE) {
+    uint32_t T;
+    cnt = wave_radix_compact(keys, cnt, sort_len, NR_WAVE - sort_len < 16 ? NR_WAVE - sort_len : 16, T);
+    wave_lds_sync();
+    if (cnt <= NR_WAVE) {
+      const uint64_t mine = wave_sort_desc(lane < cnt ? keys[lane] : 0ull);
+      take = sort_len;                           // cnt >= sort_len here
+      if (lane < take) top[lane] = mine;
+      const uint32_t nlo = __builtin_amdgcn_readlane((uint32_t)mine, take < NR_WAVE ? take : 0);
+      const uint32_t nhi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), take < NR_WAVE ? take : 0);
+      nb = (take < cnt) ? (((uint64_t)nhi << 32) | nlo) : 0ull;   // best key left behind, if any
+      sorted_in_regs = true;
+    }
+  }
+  if (!sorted_in_regs) take = wave_extract_top(keys, cnt, top, sort_len, nb);
   wave_lds_sync();
 
   bool tie = false;

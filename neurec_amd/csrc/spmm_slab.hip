@@ -407,3 +407,50 @@ extern "C" int nrhip_exp_gather_blocked(const int32_t* d_ids, int n_wg, int K, i
   NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "exp_gather_blocked: variant not built");
   return NR_OK;
 }
+
+// Micro-benchmark: read-back bandwidth of a [rows][ld] fp32 slab by access pattern.
+// WPR waves share one row (WPR = 1: one row stream per wave, the select kernel's pattern;
+// WPR = 4: a 256-thread block walks one row).  U 16-byte loads in flight per lane.
+namespace {
+template <int WPR, int U>
+__global__ __launch_bounds__(256) void exp_rowmax_kernel(const float* __restrict__ S, int64_t ld,
+                                                         int rows, int cols, float* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * 4 + wave) / WPR, part = (blockIdx.x * 4 + wave) % WPR;
+  if (row >= rows) return;
+  const float4* p = reinterpret_cast<const float4*>(S + (int64_t)row * ld);
+  const int n4 = cols / 4;
+  float m = -INFINITY;
+  for (int base = part * U * 64; base < n4; base += WPR * U * 64) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 64 + lane;
+      v[u] = i < n4 ? p[i] : make_float4(m, m, m, m);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) m = fmaxf(fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)), m);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, __shfl_xor(m, 4, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
+  if (lane == 0) out[(int64_t)row * WPR + part] = m;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_rowmax(const float* d_S, int64_t ld, int rows, int cols, int waves_per_row,
+                                int in_flight, float* d_out, void* stream) {
+  NR_REQUIRE(d_S && d_out && rows > 0 && cols > 0, NR_ERR_ARG, "exp_rowmax: bad arguments");
+  const int64_t waves = (int64_t)rows * waves_per_row;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NR_EXP(W, UU)                                                                             \
+  if (waves_per_row == W && in_flight == UU) {                                                    \
+    hipLaunchKernelGGL((exp_rowmax_kernel<W, UU>), grid, block, 0, st, d_S, ld, rows, cols, d_out); \
+    NR_LAUNCH_CHECK();                                                                            \
+    return NR_OK;                                                                                 \
+  }
+  NR_EXP(1, 4) NR_EXP(1, 8) NR_EXP(1, 16) NR_EXP(4, 4) NR_EXP(4, 8) NR_EXP(2, 8) NR_EXP(4, 2)
+#undef NR_EXP
+  NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "exp_rowmax: variant not built");
+  return NR_OK;
+}
