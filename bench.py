@@ -42,6 +42,7 @@ def parse():
                          "row-sharded tables (all-gather per hop + all-to-all lookups; config 4 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--eval-mode", choices=("pruned", "materialised"), default="pruned")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-mf", action="store_true")
     return ap.parse_args()
@@ -233,7 +234,8 @@ def main():
     if not args.no_eval:
         test_users = np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)
         mine = torch.from_numpy(parallel.shard_users(test_users, comm.rank, comm.world)).to(dev)
-        ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch)
+        ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch,
+                               pruned=args.eval_mode == "pruned")
 
         if exchange:
             # replicas ran the same global steps, but fp32 scatter atomics sum in different orders:
@@ -255,8 +257,12 @@ def main():
         eval_info = {"users_per_sec": len(test_users) / dte, "ms": dte * 1e3,
                      "n_users": int(len(test_users)), "ndcg@10": float(means[2 * 20 + 9]),
                      "recall@20": float(means[1 * 20 + 19]),
-                     "design": "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel; scoring of batch "
-                               "b+1 overlaps ranking of batch b (two streams, two slabs)"}
+                     "design": ("pruned: tile maxima in the fp32-MFMA scoring loop (no score matrix) -> top-21 "
+                                "32-item tiles per user rescored + ranked; tie rows redone from full rows"
+                                if args.eval_mode == "pruned" else
+                                "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel; scoring of "
+                                "batch b+1 overlaps ranking of batch b (two streams, two slabs)"),
+                     "rows_redone_for_ties": getattr(ev, "n_flagged", 0) if args.eval_mode == "pruned" else None}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-gowalla)", "value": triplets_per_s,

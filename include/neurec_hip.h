@@ -104,14 +104,15 @@ int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int 
  * Same results as nrhip_score_gemm + nrhip_mask_train + nrhip_eval_scores
  * (uni_evaluator.py:132-151 -> evaluate.h:23-72) without materialising the [rows][cols] scores:
  *   level 1  nrhip_score_tilemax: the scoring loop keeps, per user, only the maximum admissible
- *            score of every 64-item tile (train items and pad columns struck out in registers):
- *            d_M[rows][mld], mld >= ceil(cols/64).  Item side prepared as for nrhip_score_gemm.
+ *            score of every 32-item tile (train items and pad columns struck out in registers):
+ *            d_M[rows][mld], mld even and >= 2*ceil(cols/64) (32-item tiles).  Item side prepared as
+ *            for nrhip_score_gemm.
  *   level 2  nrhip_eval_tiles: the top_k+1 best items of a user lie in the top_k+1 tiles with the
  *            largest maxima; those tiles are rescored (same k-ascending fmaf chain, bit-identical),
  *            ranked and measured.  d_flag_out[r] = 1 marks rows whose ranking may depend on ties
  *            (inside the kept set, or between the two boundary tile maxima): their rows of d_out
  *            are provisional — recompute them through the full score path.
- * Needs ceil(cols/64) >= top_k + 2 and top_k <= 62. */
+ * Needs 2*ceil(cols/64) >= top_k + 2 and top_k <= 62. */
 int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
                         int d, const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
                         float* d_M, int64_t mld, void* d_ws, size_t ws_bytes, void* stream);

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void mask_train_kernel(
 // whose answer could depend on ties (inside the compact row or between the two boundary tile
 // maxima) are flagged; the caller re-ranks those from a full score row.
 // ----------------------------------------------------------------------------------------------
-constexpr int kTileItems = 64;
+constexpr int kTileItems = 32;   // one MFMA row block of the scoring loop
 
 // one wave per user row: sort the chosen tile ids, rescore them, strike train items / pad columns
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
@@ -415,10 +415,13 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
   for (int k = lane; k < d; k += NR_WAVE) s_p[wave][k] = P[u * ldp + k];
   wave_lds_sync();
   float* crow = C + (int64_t)row * cld;
-  for (int s = 0; s < n_keep; ++s) {
-    const int item = s_map[wave][s] * kTileItems + lane;
-    // k-major item copy: lanes = the tile's 64 consecutive items, one coalesced 256-byte load per
-    // k, 8 in flight; the chain is the k-ascending fmaf sequence of the scoring MFMA (MF.py:120-122)
+  for (int s = 0; s < n_keep; s += 2) {
+    // two 32-item tiles per pass: lanes 0-31 take tile s, lanes 32-63 tile s+1.  k-major item
+    // copy: a coalesced 128-byte load per half wave and k, 8 in flight; the chain is the
+    // k-ascending fmaf sequence of the scoring MFMA (MF.py:120-122)
+    const int sl = s + (lane >> 5);
+    const bool have = sl < n_keep;
+    const int item = (have ? s_map[wave][sl] : 0) * kTileItems + (lane & 31);
     const float* q = QT + item;
     float acc = 0.f;
     for (int k0 = 0; k0 < d; k0 += 8) {
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
       for (int i = 0; i < 8; ++i)
         if (k0 + i < d) acc = fmaf(s_p[wave][k0 + i], v[i], acc);
     }
-    crow[s * kTileItems + lane] = item < cols ? acc : -INFINITY;
+    if (have) crow[sl * kTileItems + (lane & 31)] = item < cols ? acc : -INFINITY;
   }
   wave_lds_sync();
   // strike the user's train items that fall in a chosen tile (uni_evaluator.py:140-143)
@@ -638,7 +641,7 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
     const int rc0 = nrhip_score_gemm_items_kmajor(d_gemm_ws, cols, d, &qt, &ipad);
     if (rc0 != NR_OK) return rc0;
   }
-  const int n_tiles = (cols + kTileItems - 1) / kTileItems;
+  const int n_tiles = 2 * ((cols + 63) / 64);      // 32-item tiles, as nrhip_score_tilemax writes them
   NR_REQUIRE(n_tiles >= top_k + 2 && mld >= n_tiles, NR_ERR_ARG,
              "eval_tiles: %d tiles < top_k + 2 (use the full score path)", n_tiles);
   NR_REQUIRE(n_metric >= 1 && n_metric <= 8 && rows >= 0, NR_ERR_ARG, "eval_tiles: bad sizes");

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256, 1) void score_gemm_kernel(
 // ONE user per 64-item tile and the tile maximum is an in-lane reduction.  The user's train items
 // are struck out (-inf) before the maximum — a cursor per user column walks the ascending train
 // list as the tiles go by — and so are the pad columns >= cols.  S is never written:
-// M[user][tile] = max over the tile's admissible items, 4·⌈I/64⌉ bytes per user instead of 4·I.
+// M[user][tile] = max over the admissible items of 32-item tile `tile` (one MFMA row block),
+// 4·2·⌈I/64⌉ bytes per user instead of 4·I.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void strike(f32x16& c, int reg) {
 #pragma unroll
@@ -214,12 +215,14 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
         if (it + 32 + rr >= cols) { c10[reg] = -INFINITY; c11[reg] = -INFINITY; }
       }
     }
-    float ma = fmaxf(max16(c00), max16(c10)), mb = fmaxf(max16(c01), max16(c11));
-    ma = fmaxf(ma, __shfl_xor(ma, 32, 64));
-    mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+    // one maximum per 32-item half tile (= one MFMA row block): the two lane halves hold
+    // different rows of the same block
+    float ma0 = max16(c00), ma1 = max16(c10), mb0 = max16(c01), mb1 = max16(c11);
+    ma0 = fmaxf(ma0, __shfl_xor(ma0, 32, 64)); ma1 = fmaxf(ma1, __shfl_xor(ma1, 32, 64));
+    mb0 = fmaxf(mb0, __shfl_xor(mb0, 32, 64)); mb1 = fmaxf(mb1, __shfl_xor(mb1, 32, 64));
     if (h == 0) {
-      if (ra < rows) M[(int64_t)ra * mld + t] = ma;
-      if (rb < rows) M[(int64_t)rb * mld + t] = mb;
+      if (ra < rows) *reinterpret_cast<float2*>(M + (int64_t)ra * mld + 2 * t) = make_float2(ma0, ma1);
+      if (rb < rows) *reinterpret_cast<float2*>(M + (int64_t)rb * mld + 2 * t) = make_float2(mb0, mb1);
     }
   };
   if (t_begin >= t_end) return;
@@ -337,15 +340,16 @@ int nrhip_score_gemm_items_kmajor(const void* d_ws, int cols, int d, const float
 }
 
 /* Pruned evaluation, level 1 (see nrhip_eval_tiles): M[r][t] = max over the admissible items of
- * 64-item tile t of the scores of user row r — train items of the user and columns >= cols
+ * 32-item tile t of the scores of user row r — train items of the user and columns >= cols
  * excluded — computed by the scoring loop without ever writing the scores.  Item side prepared
- * with nrhip_score_gemm_prepare_items; d_M has rows x mld floats, mld >= ceil(cols/64). */
+ * with nrhip_score_gemm_prepare_items; d_M has rows x mld floats, mld even, >= 2*ceil(cols/64)
+ * (tiles beyond ceil(cols/32) hold -inf). */
 int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
                         int d, const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
                         float* d_M, int64_t mld, void* d_ws, size_t ws_bytes, void* stream) {
   NR_REQUIRE(d_P && d_M && d_ws && d_tr_indptr && d_tr_indices && cols >= 1 && d >= 1 && ldp >= d &&
-                 rows >= 0 && mld >= (cols + 63) / 64,
-             NR_ERR_ARG, "score_tilemax: bad arguments");
+                 rows >= 0 && mld >= 2 * ((cols + 63) / 64) && mld % 2 == 0,
+             NR_ERR_ARG, "score_tilemax: bad arguments (mld must be even and >= 2*ceil(cols/64))");
   const int dp = padded_dim(d);
   NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_tilemax: embedding dim %d > 128 not built", d);
   if (rows == 0) return NR_OK;

@@ -202,12 +202,12 @@ class ScoreGemm:
 
 
     def tile_maxima(self, user_table, users, train_csr, out=None):
-        """Pruned evaluation, level 1: M[r][t] = max admissible score of user row r over 64-item
+        """Pruned evaluation, level 1: M[r][t] = max admissible score of user row r over 32-item
         tile t (train items and pad columns excluded); the scores themselves are never stored."""
         rows = user_table.shape[0] if users is None else users.numel()
         if rows > self.max_rows:
             raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
-        n_tiles = (self.cols + 63) // 64
+        n_tiles = 2 * ((self.cols + 63) // 64)          # 32-item tiles
         mld = (n_tiles + 3) // 4 * 4
         if out is None:
             out = torch.empty((rows, mld), dtype=torch.float32, device=self.ws.device)

@@ -295,12 +295,15 @@ class LightGCNEngine:
 
 
 class FullRankEvaluator:
-    """Full-rank evaluation on the device: score GEMM -> -inf train mask -> top-K ->
-    metrics, batch by batch; only the per-user metric matrix (or its column sums)
-    ever crosses PCIe."""
+    """Full-rank evaluation on the device; only the per-user metric matrix (or its column sums)
+    ever crosses PCIe.  Two designs with identical results (tests/test_eval_gpu.py):
+      pruned=True  (default) tile maxima from the scoring loop -> the top_k+1 best 32-item tiles per
+                   user rescored, ranked, measured; no [batch][I] score matrix (see _evaluate_pruned);
+      pruned=False score GEMM -> -inf train mask -> top-K -> metrics on a materialised slab, batch
+                   by batch (scoring of batch b+1 overlapped with the ranking of batch b)."""
 
     def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True,
-                 pruned=False):
+                 pruned=True):
         self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
         self.train, self.test = train_csr, test_csr
         self.metric_ids = [int(m) for m in metric_ids]
@@ -325,7 +328,7 @@ class FullRankEvaluator:
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
-        if self.pruned and (cols + 63) // 64 >= self.top_k + 2 and self.top_k <= 62 and n > 0:
+        if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0:
             self._evaluate_pruned(user_table, item_table, test_users, per_user, starts)
         elif not self.overlap or len(starts) < 2:
             for b in starts:

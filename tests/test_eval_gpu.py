@@ -236,7 +236,7 @@ def test_pruned_evaluation_equals_materialised_scores(d, ties):
     trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
     Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
     ud = torch.from_numpy(users).cuda()
-    full = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256)
+    full = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, pruned=False)
     lean = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, pruned=True)
     a = full.evaluate_factors(Pd, Qd, ud, exact_mean=True)
     b = lean.evaluate_factors(Pd, Qd, ud, exact_mean=True)
