@@ -304,20 +304,33 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
   wave_lds_sync();
   nr::heap_make(h, m);
   wave_lds_sync();
-  for (int base = m; base < cols; base += NR_WAVE) {
-    const int e = base + lane;
-    bool live = e < cols;
-    const float v = live ? srow[e] : 0.f;
-    for (;;) {
-      const float root = h.val[0];
-      const uint64_t mask = __ballot(live && v > root);
-      if (!mask) break;
-      const int t = __builtin_ctzll(mask);
-      const float vt = __builtin_bit_cast(
-          float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
-      nr::heap_adjust(h, 0, m, vt, base + t);
-      wave_lds_sync();
-      live = live && lane > t;
+  // the scan is a chain of dependent loads unless the row is fetched ahead: 8 groups of 64 scores
+  // in flight, offered to the heap in index order
+  constexpr int kAhead = 8;
+  for (int base0 = m; base0 < cols; base0 += kAhead * NR_WAVE) {
+    float vv[kAhead];
+#pragma unroll
+    for (int g = 0; g < kAhead; ++g) {
+      const int e = base0 + g * NR_WAVE + lane;
+      vv[g] = e < cols ? srow[e] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < kAhead; ++g) {
+      const int base = base0 + g * NR_WAVE;
+      if (base >= cols) break;
+      bool live = base + lane < cols;
+      const float v = vv[g];
+      for (;;) {
+        const float root = h.val[0];
+        const uint64_t mask = __ballot(live && v > root);
+        if (!mask) break;
+        const int t = __builtin_ctzll(mask);
+        const float vt = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+        nr::heap_adjust(h, 0, m, vt, base + t);
+        wave_lds_sync();
+        live = live && lane > t;
+      }
     }
   }
   nr::heap_sort(h, m);
