@@ -145,3 +145,69 @@ class ShardedLightGCN:
         self.adam.advance()
         gs.zero_(); gr.zero_(); self.Greg.zero_(); self.Ga.zero_()    # buffers the head accumulates into
         return loss_out
+
+
+class ShardedMF:
+    """BPR-MF with both tables row-sharded (SURVEY §8e "BPR-MF step"): rank r owns the padded block
+    [r·b, (r+1)·b) of the node rows (users first, then items) with its Adam moments.  One step
+    (MF.py:54-76,101) = ids to the owners (all-to-all) -> the requested rows back (all-to-all) ->
+    the BPR head on the compact [3B][d] block -> gradient rows to the owners (all-to-all),
+    scatter-added (duplicates summed) -> owner-local TF-sparse Adam, which sweeps every local row
+    (SURVEY H2).  Equals the single-process step on the concatenated global batch."""
+
+    def __init__(self, comm, user_table, item_table, lr, reg, max_batch):
+        dev = E.require_gpu()
+        self.comm, self.rank, self.world = comm, comm.rank, comm.world
+        ut = np.asarray(user_table, dtype=np.float32)
+        it = np.asarray(item_table, dtype=np.float32)
+        self.n_users, self.n_items, self.d = ut.shape[0], it.shape[0], ut.shape[1]
+        self.N = self.n_users + self.n_items
+        self.b = parallel.block_size(self.N, self.world)
+        self.lo = min(self.rank * self.b, self.N)
+        self.hi = min(self.lo + self.b, self.N)
+        self.n_loc = self.hi - self.lo
+        full = np.concatenate([ut, it])
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        self.T = z(self.b, self.d)                                   # my rows of [P ; Q]
+        self.T[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(full[self.lo:self.hi])).to(dev)
+        self.m, self.v, self.G = z(self.b, self.d), z(self.b, self.d), z(self.b, self.d)
+        self.reg, self.max_batch = float(reg), int(max_batch)
+        self.adam = E.AdamState(lr)
+        B3 = 3 * self.max_batch
+        self.req = z(B3, self.d)
+        self.gP, self.gQ = z(self.max_batch, self.d), z(2 * self.max_batch, self.d)
+        self.terms = z(2 * self.max_batch)
+        self._ar = torch.arange(2 * self.max_batch, dtype=torch.int32, device=dev)
+
+    def step(self, users, pos, neg, loss_out):
+        B, d = users.numel(), self.d
+        if B > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        nodes = torch.cat([users.long(), pos.long() + self.n_users, neg.long() + self.n_users])
+        owner = torch.div(nodes, self.b, rounding_mode="floor")
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=self.world)[:self.world].cpu().tolist()
+        local = (nodes - owner * self.b)[order].to(torch.int32).contiguous()
+        asked, asked_counts = self.comm.all_to_all_rows(local, counts)          # exchange 1: ids
+        rows = torch.empty((asked.numel(), d), dtype=torch.float32, device=self.T.device)
+        E.rows_gather(asked, self.T, rows)
+        got, _ = self.comm.all_to_all_rows(rows, asked_counts)                  # exchange 2: rows
+        req = self.req[:3 * B]
+        req[order] = got
+        # compact tables: P' = rows [0,B) (one per triplet), Q' = rows [B,3B) (pos then neg)
+        P, Q = req[:B], req[B:3 * B]
+        gP, gQ = self.gP[:B], self.gQ[:2 * B]
+        E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], (self._ar[:B] + B).contiguous(), self.reg,
+                      gP, gQ, self.terms, loss_out)
+        back = torch.cat([gP, gQ])[order].contiguous()
+        mine, _ = self.comm.all_to_all_rows(back, counts)                       # exchange 3: gradients
+        E.rows_scatter_add(asked, mine, self.G)
+        E.adam_sparse(self.T, self.m, self.v, self.G, self.adam)                # clears G
+        self.adam.advance()
+        gP.zero_(); gQ.zero_()
+
+    def tables(self):
+        """Full (P, Q) on every rank (one all-gather; evaluation entrance)."""
+        full = torch.empty(self.b * self.world, self.d, dtype=torch.float32, device=self.T.device)
+        self.comm.all_gather_rows(self.T, full)
+        return full[:self.n_users], full[self.n_users:self.N]

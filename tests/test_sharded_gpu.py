@@ -83,3 +83,53 @@ def test_sharded_lightgcn_equals_single_process(tmp_path, adj_type, d):
     eu, ei = lg.final_embeddings()
     assert np.abs(got["eu"] - eu.cpu().numpy()).max() < 1e-5
     assert np.abs(got["ei"] - ei.cpu().numpy()).max() < 1e-5
+
+
+def _mf_worker(rank, world, port, out):
+    import torch
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_DIST_BACKEND="gloo")
+    from neurec_amd import parallel
+    from neurec_amd.sharded import ShardedMF
+    comm = parallel.init_from_env()
+    rng = np.random.RandomState(21)
+    U, I, d = 500, 333, 64
+    P0 = (rng.randn(U, d) * 0.05).astype(np.float32)
+    Q0 = (rng.randn(I, d) * 0.05).astype(np.float32)
+    eng = ShardedMF(comm, P0, Q0, 0.001, 0.01, 96)
+    losses = []
+    for step in _batches(U, I, world, 96, 4):
+        bu, bp, bn = (torch.from_numpy(x).cuda() for x in step[rank])
+        l2 = torch.zeros(2, device="cuda")
+        eng.step(bu, bp, bn, l2)
+        comm.allreduce_sum_(l2)
+        losses.append(l2.cpu().numpy())
+    P, Q = eng.tables()
+    if rank == 0:
+        np.savez(out, P=P.cpu().numpy(), Q=Q.cpu().numpy(), losses=np.asarray(losses))
+    comm.barrier()
+    comm.shutdown()
+
+
+def test_sharded_mf_equals_single_process(tmp_path):
+    """row-sharded BPR-MF (three all-to-alls per step) == MFEngine on the concatenated batch"""
+    import torch
+    import torch.multiprocessing as mp
+    from neurec_amd.trainer import MFEngine
+    out = str(tmp_path / "mf.npz")
+    mp.start_processes(_mf_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    rng = np.random.RandomState(21)
+    U, I, d = 500, 333, 64
+    P0 = (rng.randn(U, d) * 0.05).astype(np.float32)
+    Q0 = (rng.randn(I, d) * 0.05).astype(np.float32)
+    mf = MFEngine(P0, Q0, 0.001, 0.01, 192)
+    want_losses = []
+    for step in _batches(U, I, 2, 96, 4):
+        bu, bp, bn = (torch.from_numpy(np.concatenate([s[k] for s in step])).cuda() for k in range(3))
+        l2 = torch.zeros(2, device="cuda")
+        mf.step(bu, bp, bn, l2)
+        want_losses.append(l2.cpu().numpy())
+    np.testing.assert_allclose(got["losses"], np.asarray(want_losses), rtol=1e-5)
+    assert np.abs(got["P"] - mf.P.cpu().numpy()).max() < 5e-6
+    assert np.abs(got["Q"] - mf.Q.cpu().numpy()).max() < 5e-6
