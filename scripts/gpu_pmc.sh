@@ -14,11 +14,16 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 with open(sys.argv[1]) as fh:
     for row in csv.DictReader(fh):
-        k = row.get("Kernel_Name", "")[:60]
+        k = row.get("Kernel_Name", "")
+        if k.startswith("void "):
+            k = k[5:]
+        if k.startswith("(anonymous namespace)::"):
+            k = k[len("(anonymous namespace)::"):]
+        k = k.split("(")[0][:70]
         agg[k][0] += 1
         agg[k][1] += float(row.get("Counter_Value", 0) or 0)
 for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
-    print("%-60s calls=%5d  avg=%.1f (counter units, KB per FETCH/WRITE_SIZE)" % (k, n, v / n))
+    print("%-70s calls=%5d  avg=%.1f (counter units, KB per FETCH/WRITE_SIZE)" % (k, n, v / n))
 PY
   find "$OUT/$c" -name "*.csv" -size +5M -delete
 done
