@@ -28,6 +28,7 @@
 #include "nr_common.h"
 #include <algorithm>
 #include <new>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -48,6 +49,10 @@ struct BlockedPlan {
   int32_t* wg_cmb_off;   // [n_wg][n_phases + 1]
   int4* ent;             // {accumulator slot, length, first non-zero, owning row slot}
   int4* cmb;             // {row slot, first partial slot, segments, 0}
+  // masked hops of a training step (d = 64, one phase): dedicated kernels below
+  uint32_t* wg_nnz;      // [n_wg][2] first non-zero of the workgroup's rows, count
+  int nnz_cap, ent_cap;  // largest slice / descriptor list of a workgroup
+  int colmask_ok;
 };
 
 size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
@@ -55,7 +60,7 @@ size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
   const size_t max_cmb = (size_t)(nnz / 16) + 64;
   const size_t wg = 4096 + (size_t)(n_rows / 32);   // generous bound on workgroups
   return nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
-         2 * nr_align_up(wg * 4, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256);
+         3 * nr_align_up(wg * 8, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256);
 }
 
 // Optional fused optimiser epilogue (last backward hop of a LightGCN step): instead of storing
@@ -265,6 +270,213 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The column-masked hop of a LightGCN step (first backward hop, d = 64): only columns of batch rows
+// contribute.  In the general masked kernel above it costs 27-29 us: every lane group still walks
+// all its sub-lists through the descriptor -> columns -> mask -> rows chain.  Here the workgroup's
+// (column, value) slice is staged in LDS with one bulk read, the mask is applied there, every
+// sub-list is compacted in place, and the walk only sees the survivors, several sub-lists in
+// flight per lane group (no accumulators in LDS: a finished row goes straight to memory).
+// Same sub-lists, same order of additions, same combine: bit-identical to spmm_blocked_kernel.
+// (The mirror-image kernel for the row-masked forward hop — a wave per wanted sub-list — was built
+// too and removed: a real batch is dominated by hub rows, whose gathers are ~45 % of a full pass,
+// so that hop is bound by gather throughput, not by the walk: profiles/r01_exp_masked_hops.txt.)
+
+__device__ __forceinline__ void masked_row_out(float4 y, int64_t o, const float4* __restrict__ addend,
+                                               bool addend_row_nonzero, float4* __restrict__ Y,
+                                               const float4* sum_in, float4* sum_out) {
+  if (addend) {
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);       // a row promised zero is not read
+    if (addend_row_nonzero) av = addend[o];
+    y.x = __fadd_rn(y.x, av.x); y.y = __fadd_rn(y.y, av.y);
+    y.z = __fadd_rn(y.z, av.z); y.w = __fadd_rn(y.w, av.w);
+  }
+  if (Y) Y[o] = y;
+  if (sum_out) {
+    const float4 si = sum_in[o];
+    sum_out[o] = make_float4(__fadd_rn(si.x, y.x), __fadd_rn(si.y, y.y), __fadd_rn(si.z, y.z),
+                             __fadd_rn(si.w, y.w));
+  }
+}
+
+__global__ __launch_bounds__(16 * NR_WAVE) void spmm_colmasked_kernel(
+    const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_ent_off,
+    const int32_t* __restrict__ wg_cmb_off, const uint32_t* __restrict__ wg_nnz,
+    const int4* __restrict__ ent, const int4* __restrict__ cmb,
+    const int32_t* __restrict__ indices, const float* __restrict__ vals,
+    const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
+    const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ col_mask,
+    int addend_masked, int kRMax, int p_max, int ent_cap) {
+  constexpr int RS = 16, LPR = 16, GPW = 4, kGroups = 64;
+  extern __shared__ float4 s_mem[];
+  float4* s_part = s_mem;                                          // [p_max][16]
+  int4* s_ent = (int4*)(s_mem + (size_t)p_max * RS);               // [ent_cap]
+  int2* s_iv = (int2*)(s_ent + ent_cap);                           // [non-zeros of the workgroup]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & (LPR - 1), g = lane / LPR;
+  const int wg = blockIdx.x;
+  const int r0 = wg_row0[wg];
+  const uint32_t nz0 = wg_nnz[2 * wg];
+  const int nz = (int)wg_nnz[2 * wg + 1];
+  const int e0 = wg_ent_off[2 * wg], ne = wg_ent_off[2 * wg + 1] - e0;
+  const int c0 = wg_cmb_off[2 * wg], c1 = wg_cmb_off[2 * wg + 1];
+  {
+    constexpr int kStage = 8;                                      // loads in flight per lane while staging
+    int4 e = make_int4(0, 0, 0, 0);
+    if (tid < ne) e = ent[e0 + tid];                               // first 1024 descriptors ride along
+    for (int i0 = 0; i0 < nz; i0 += kStage * 16 * NR_WAVE) {
+      int col[kStage];
+      float v[kStage];
+      uint8_t keep[kStage];
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = i0 + k * 16 * NR_WAVE + tid;
+        col[k] = 0;
+        v[k] = 0.f;
+        if (i < nz) {
+          col[k] = indices[nz0 + i];
+          v[k] = vals[nz0 + i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) keep[k] = col_mask[col[k]];
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) {
+        const int i = i0 + k * 16 * NR_WAVE + tid;
+        if (i < nz) s_iv[i] = make_int2(keep[k] ? col[k] : -1, __float_as_int(v[k]));
+      }
+    }
+    for (int i = tid; i < ne; i += 16 * NR_WAVE) {
+      if (i >= 16 * NR_WAVE) e = ent[e0 + i];
+      e.z = (int)((uint32_t)e.z - nz0);                            // offset inside the staged slice
+      // bit 30 of the owner: the addend row of this output row may be non-zero
+      if (!addend_masked || col_mask[r0 + e.w] != 0) e.w |= 1 << 30;
+      s_ent[i] = e;
+    }
+  }
+  __syncthreads();
+  // compact every sub-list to its surviving (column, value) pairs, in place and in order
+  for (int base = wave * GPW; base < ne; base += kGroups) {
+    const int ei = base + g;
+    int4 ds = make_int4(0, 0, 0, 0);
+    if (ei < ne) ds = s_ent[ei];
+    int maxlen = ds.y;
+#pragma unroll
+    for (int sh = LPR; sh < NR_WAVE; sh <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, sh, NR_WAVE));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    int w = 0;
+    for (int k0 = 0; k0 < maxlen; k0 += LPR) {
+      const bool in = k0 + c < ds.y;
+      int2 iv = make_int2(-1, 0);
+      if (in) iv = s_iv[ds.z + k0 + c];
+      const bool keep = iv.x >= 0;
+      const unsigned long long m = __ballot(keep);
+      const uint32_t gm = (uint32_t)(m >> (g * LPR)) & 0xFFFFu;
+      if (keep) s_iv[ds.z + w + __popc(gm & ((1u << c) - 1u))] = iv;
+      w += __popc(gm);
+    }
+    if (ei < ne && c == 0) s_ent[ei].y = w;
+  }
+  // walk: rounds of kQ gathers per lane, four rounds in flight (the survivors of a sub-list are few,
+  // so depth comes from running several sub-lists ahead); rounds retire in issue order
+  {
+    constexpr int kQ = 4;
+    struct Round { float4 x[kQ]; int off, n, slot, owner; bool first, last, live; };
+    int ibase = wave * GPW, it0 = 0, imax = 0;      // issue cursor: batch of sub-lists, position
+    int4 ids = make_int4(0, 0, 0, 0);
+    bool ihas = ibase < ne;                         // wave-uniform: rounds left to issue
+    auto open = [&]() {
+      ids = make_int4(0, 0, 0, 0);
+      if (ibase + g < ne) ids = s_ent[ibase + g];
+      int m = ids.y;
+#pragma unroll
+      for (int sh = LPR; sh < NR_WAVE; sh <<= 1) m = max(m, __shfl_xor(m, sh, NR_WAVE));
+      imax = __builtin_amdgcn_readfirstlane(m);
+    };
+    auto issue = [&](Round& r) {
+      r.off = ids.z + it0;
+      r.n = ids.y - it0;
+      r.slot = ids.x;
+      r.owner = ids.w;
+      r.first = it0 == 0;
+      r.live = ibase + g < ne;
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) {
+        r.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < r.n) r.x[u] = X[(int64_t)s_iv[r.off + u].x * RS + c];
+      }
+      r.last = it0 + kQ >= imax;
+      if (r.last) {
+        ibase += kGroups;
+        it0 = 0;
+        ihas = ibase < ne;
+        if (ihas) open();
+      } else {
+        it0 += kQ;
+      }
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto retire = [&](const Round& r) {
+      if (r.first) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float a[kQ];
+#pragma unroll
+      for (int u = 0; u < kQ; ++u) a[u] = __int_as_float(s_iv[u < r.n ? r.off + u : 0].y);
+#pragma unroll
+      for (int u = 0; u < kQ; ++u)
+        if (u < r.n) {
+          acc.x = __fadd_rn(acc.x, __fmul_rn(a[u], r.x[u].x));
+          acc.y = __fadd_rn(acc.y, __fmul_rn(a[u], r.x[u].y));
+          acc.z = __fadd_rn(acc.z, __fmul_rn(a[u], r.x[u].z));
+          acc.w = __fadd_rn(acc.w, __fmul_rn(a[u], r.x[u].w));
+        }
+      if (r.last && r.live) {
+        if (r.slot < kRMax)
+          masked_row_out(acc, ((int64_t)r0 + (r.owner & 0xFFFFFF)) * RS + c, addend, (r.owner >> 30) & 1,
+                         Y, sum_in, sum_out);
+        else
+          s_part[(size_t)(r.slot - kRMax) * RS + c] = acc;
+      }
+    };
+    Round q0, q1, q2, q3;
+    bool v0 = false, v1 = false, v2 = false, v3 = false;
+    if (ihas) open();
+    v0 = ihas; if (v0) issue(q0);
+    v1 = ihas; if (v1) issue(q1);
+    v2 = ihas; if (v2) issue(q2);
+    while (v0) {
+      v3 = ihas; if (v3) issue(q3);
+      retire(q0);
+      if (!v1) break;
+      v0 = ihas; if (v0) issue(q0);
+      retire(q1);
+      if (!v2) break;
+      v1 = ihas; if (v1) issue(q1);
+      retire(q2);
+      if (!v3) break;
+      v2 = ihas; if (v2) issue(q2);
+      retire(q3);
+    }
+  }
+  if (c1 > c0) {                                           // workgroup-uniform
+    __syncthreads();
+    for (int ci = c0 + wave * GPW + g; ci < c1; ci += kGroups) {
+      const int4 cm = cmb[ci];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sgm = 0; sgm < cm.z; ++sgm) {
+        const float4 q = s_part[(size_t)(cm.y - kRMax + sgm) * RS + c];
+        acc.x = __fadd_rn(acc.x, q.x); acc.y = __fadd_rn(acc.y, q.y);
+        acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
+      }
+      const bool addend_on = !addend_masked || col_mask[r0 + cm.x] != 0;
+      masked_row_out(acc, ((int64_t)r0 + cm.x) * RS + c, addend, addend_on, Y, sum_in, sum_out);
+    }
+  }
+}
+
+size_t colmask_lds_bytes(const BlockedPlan* p) {
+  return (size_t)p->p_max * 256 + (size_t)p->ent_cap * 16 + (size_t)p->nnz_cap * 8;
+}
+
 struct HostEnt { int32_t slot, len; uint32_t begin; int32_t owner; };
 int s_gathers_in_flight = 8;     // tuning knob (nrhip_spmm_blocked_tune)
 
@@ -325,11 +537,35 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   NR_REQUIRE(n_wg >= 8 && n_wg <= 4096 + n_rows / 32, NR_ERR_UNSUPPORTED, "spmm_blocked: %d workgroups",
              n_wg);
 
+  // cost of a row for balancing: its non-zeros plus a fixed cost per sub-list (descriptor, first
+  // index chunk and the short last gather round; fitted on the per-workgroup timeline,
+  // profiles/r01_exp_spmm_timeline.txt)
+  int ent_cost = 6;
+  if (const char* e = getenv("NEUREC_SPMM_ENTCOST")) ent_cost = atoi(e);
+  auto row_cost = [&](int64_t l) { return l + (int64_t)ent_cost * std::max<int64_t>(1, (l + kSeg - 1) / kSeg); };
   struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; };
   std::vector<ClassDesc> classes;
   if (split_row) {
     ClassDesc a{0, split_row, {}}, b{split_row, n_rows, {}};
-    for (int w = 0; w < n_wg; ++w) ((w & 7) < 4 ? a : b).wgs.push_back(w);
+    // workgroups per class in proportion to the class's cost; class A fills XCDs 0.. first
+    // (workgroup w runs on XCD w % 8), so at most one XCD serves both halves of the table
+    int64_t cost_a = 0, cost_b = 0;
+    for (int64_t r = 0; r < n_rows; ++r) (r < split_row ? cost_a : cost_b) += row_cost(h_indptr[r + 1] - h_indptr[r]);
+    int n_a = (int)((double)n_wg * (double)cost_a / (double)std::max<int64_t>(cost_a + cost_b, 1) + 0.5);
+    n_a = std::min(std::max(n_a, 1), n_wg - 1);
+    {
+      // every class must still fit its rows into its workgroups' accumulators
+      const int64_t cap = (int64_t)kRMax * 9 / 10;
+      const int need_a = (int)((split_row + cap - 1) / cap), need_b = (int)((n_rows - split_row + cap - 1) / cap);
+      n_a = std::max(n_a, std::min(need_a, n_wg - 1));
+      n_a = std::min(n_a, std::max(n_wg - need_b, 1));
+    }
+    std::vector<int> order;                    // workgroup ids, XCD-major
+    for (int x = 0; x < 8; ++x)
+      for (int w = x; w < n_wg; w += 8) order.push_back(w);
+    for (int i = 0; i < n_wg; ++i) (i < n_a ? a : b).wgs.push_back(order[i]);
+    std::sort(a.wgs.begin(), a.wgs.end());
+    std::sort(b.wgs.begin(), b.wgs.end());
     classes.push_back(a);
     classes.push_back(b);
   } else {
@@ -357,8 +593,9 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
                "use the work-item kernel", (long long)span, (long long)K, kMaxPhases);
     const int64_t width = (span + K - 1) / K;
     n_phases = std::max<int>(n_phases, (int)K);
-    // contiguous row runs, balanced by non-zeros, at most kRMax rows each
-    int64_t r = cl.ra, left = ce - cb;
+    // contiguous row runs, balanced by cost, at most kRMax rows each
+    int64_t r = cl.ra, left = 0;
+    for (int64_t q = cl.ra; q < cl.rb; ++q) left += row_cost(h_indptr[q + 1] - h_indptr[q]);
     for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
       const int w = cl.wgs[wi];
       const int64_t wgs_left = (int64_t)cl.wgs.size() - (int64_t)wi;
@@ -366,8 +603,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
       const int64_t rstart = r;
       int64_t got = 0;
       while (r < cl.rb && (r - rstart) < kRMax) {
-        const int64_t l = h_indptr[r + 1] - h_indptr[r];
-        // stop at the non-zero target unless the rows left would overflow the later workgroups
+        const int64_t l = row_cost(h_indptr[r + 1] - h_indptr[r]);
+        // stop at the cost target unless the rows left would overflow the later workgroups
         const bool must_take = (cl.rb - r) > (wgs_left - 1) * (int64_t)kRMax;
         if (!must_take && wgs_left > 1 && got > 0 && got + l / 2 > target) break;
         got += l;
@@ -387,6 +624,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
         const int32_t slot = (int32_t)(row - rstart);
         int64_t t = h_indptr[row];
         const int64_t te = h_indptr[row + 1];
+        if (t == te) wg_ent[w][0].push_back(HostEnt{slot, 0, (uint32_t)t, slot});   // empty row
         while (t < te) {
           const int64_t k = ((int64_t)h_indices[t] - cmin) / width;
           int64_t t2 = t + 1;
@@ -429,8 +667,26 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
       }
     }
   }
+  std::vector<uint32_t> wg_nnz((size_t)n_wg * 2, 0);
+  int64_t nnz_cap = 0, ent_cap = 0;
+  for (int w = 0; w < n_wg; ++w) {
+    const int64_t b = h_indptr[wg_row0[w]], en = h_indptr[(int64_t)wg_row0[w] + wg_nrows[w]];
+    wg_nnz[2 * (size_t)w] = (uint32_t)b;
+    wg_nnz[2 * (size_t)w + 1] = (uint32_t)(en - b);
+    nnz_cap = std::max(nnz_cap, en - b);
+    ent_cap = std::max<int64_t>(ent_cap, ent_off[(size_t)w * (n_phases + 1) + n_phases] -
+                                             ent_off[(size_t)w * (n_phases + 1)]);
+  }
   BlockedPlan* p = new (std::nothrow) BlockedPlan();
   NR_REQUIRE(p, NR_ERR_ARG, "spmm_blocked_plan_create: out of host memory");
+  p->nnz_cap = (int)std::min<int64_t>(nnz_cap, INT32_MAX / 16);
+  p->ent_cap = (int)std::min<int64_t>((ent_cap + 15) / 16 * 16, INT32_MAX / 32);
+  {
+    const char* off = getenv("NEUREC_SPMM_COLMASK_FAST");     // "0": A/B against the general kernel
+    const bool on = d == 64 && kWaves == 16 && n_phases == 1 && !(off && off[0] == '0');
+    const size_t base = (size_t)kPMax * 256 + (size_t)p->ent_cap * 16;
+    p->colmask_ok = on && nnz_cap < ((int64_t)1 << 24) && base + (size_t)nnz_cap * 8 <= (size_t)kMaxLdsBytes;
+  }
   p->n_rows = n_rows; p->nnz = nnz; p->n_wg = n_wg; p->n_phases = n_phases;
   p->seg = kSeg; p->r_max = kRMax; p->p_max = kPMax; p->waves = kWaves; p->d = d;
   p->n_ent = (int64_t)ent.size(); p->n_cmb = (int64_t)cmb.size();
@@ -442,6 +698,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   p->wg_nrows = (int32_t*)carve((size_t)n_wg * 4);
   p->wg_ent_off = (int32_t*)carve(ent_off.size() * 4);
   p->wg_cmb_off = (int32_t*)carve(cmb_off.size() * 4);
+  p->wg_nnz = (uint32_t*)carve(wg_nnz.size() * 4);
   if ((size_t)(q - (char*)d_plan_buf) > plan_bytes) {
     delete p;
     nrhip_set_error("spmm_blocked_plan_create: plan needs %zu bytes, buffer has %zu",
@@ -459,6 +716,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   up(p->wg_nrows, wg_nrows.data(), wg_nrows.size() * 4);
   up(p->wg_ent_off, ent_off.data(), ent_off.size() * 4);
   up(p->wg_cmb_off, cmb_off.data(), cmb_off.size() * 4);
+  up(p->wg_nnz, wg_nnz.data(), wg_nnz.size() * 4);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   const int lds = (kRMax + kPMax) * kD * 4;
   auto allow = [&](const void* fn) {
@@ -472,6 +730,9 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   if (d == 16) { NR_ALLOW(16); } else if (d == 32) { NR_ALLOW(32); } else if (d == 64) { NR_ALLOW(64); }
   else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
 #undef NR_ALLOW
+  if (p->colmask_ok && e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)spmm_colmasked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)colmask_lds_bytes(p));
   if (e != hipSuccess) {
     delete p;
     nrhip_set_error("spmm_blocked_plan_create: %s", hipGetErrorString(e));
@@ -518,6 +779,16 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
   const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
   const bool masked = d_x_row_nonzero || d_y_row_wanted;
   const int gif = s_gathers_in_flight;
+  if (p->colmask_ok && d_x_row_nonzero && !d_y_row_wanted) {
+    // an addend that is the operand itself shares its promise (zero rows where the mask is 0)
+    hipLaunchKernelGGL(spmm_colmasked_kernel, grid, block, colmask_lds_bytes(p), st, p->wg_row0,
+                       p->wg_ent_off, p->wg_cmb_off, p->wg_nnz, p->ent, p->cmb, d_indices, d_vals,
+                       (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,
+                       (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero,
+                       d_addend == d_X ? 1 : 0, p->r_max, p->p_max, p->ent_cap);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+  }
 #define NR_BLK(M, W, GG, DD)                                                                       \
   hipLaunchKernelGGL((spmm_blocked_kernel<M, W, GG, DD>), grid, block, lds, st, p->wg_row0,        \
                      p->wg_nrows, p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases,        \
