@@ -454,3 +454,42 @@ extern "C" int nrhip_exp_rowmax(const float* d_S, int64_t ld, int rows, int cols
   NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "exp_rowmax: variant not built");
   return NR_OK;
 }
+
+// Does a stream of 128-byte gathers that only ever touches the FIRST half of 256-byte rows use all
+// L2 channels?  mode 0: always half 0; mode 1: half = row parity (both halves, same line count);
+// mode 2: half 1 only.  8 lanes x 16 bytes per gather, 8 gathers per lane group in flight.
+namespace {
+__global__ __launch_bounds__(256) void exp_halfline_kernel(const int32_t* __restrict__ ids, int64_t n,
+                                                           int per_wave, const float4* __restrict__ T,
+                                                           int mode, float4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t b = wave * per_wave;
+  if (b >= n) return;
+  const int len = (int)min((int64_t)per_wave, n - b);
+  const int g = lane >> 3, c = lane & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < len; k0 += 64) {
+    const int my = (k0 + lane < len) ? ids[b + k0 + lane] : 0;
+    float4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = __shfl(my, u * 8 + g, 64);
+      const int half = mode == 0 ? 0 : (mode == 1 ? (row & 1) : 1);
+      x[u] = T[(int64_t)row * 16 + half * 8 + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+  }
+  if (acc.x == 123.456f) out[wave] = acc;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_halfline(const int32_t* d_ids, int64_t n, int per_wave, const float* d_T, int mode,
+                                  float* d_out, void* stream) {
+  const int64_t waves = (n + per_wave - 1) / per_wave;
+  hipLaunchKernelGGL(exp_halfline_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     d_ids, n, per_wave, (const float4*)d_T, mode, (float4*)d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
