@@ -265,7 +265,9 @@ int nrhip_spmm_plan_attach_blocked(void* plan, const void* blocked_plan, int d);
  * (nrhip_spmm_plan_has_blocked(plan, 64) != 0), NRHIP_ERR_UNSUPPORTED otherwise. */
 /* clear_consumed != 0 additionally zeroes the non-zero entries of d_addend / d_grad_b and the set
  * bytes of d_row_flag (may be NULL) as they are read — what nrhip_rows_clear would do after the
- * step (both buffers are row-sparse there). */
+ * step (both buffers are row-sparse there).  With clear_consumed and a d_row_flag, the flags are
+ * also a promise: rows of d_addend / d_grad_b whose flag byte is 0 are all zero (they are not
+ * read). */
 int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, float* d_addend, float* d_grad_b, float* d_var,
                         float* d_m, float* d_v, float alpha, float beta1, float beta2, float eps,

@@ -13,8 +13,9 @@
 // and row gradients are scattered with hardware fp32 atomics into dense
 // accumulators (duplicate rows inside a batch add up, as TF's
 // _apply_sparse_duplicate_indices does).  Per-triplet loss terms are written
-// out and reduced in a fixed order by reduce_loss_kernel.
+// out and reduced in a fixed order by the block that finishes last (finish_loss).
 #include "nr_common.h"
+#include <atomic>
 
 namespace {
 
@@ -38,9 +39,51 @@ __device__ __forceinline__ float dot_rows(const float (&a)[CPL], const float (&b
   return nr_wave_sum_f32(s);
 }
 
+// Fixed-order reduction of the per-triplet terms, out2[0] = Σ mf, out2[1] = reg·Σ l2, done by the
+// block that finishes last (no second launch: a 1-block reduction kernel cost 4.8 us per step,
+// 17 % of an MF step).  `done` is one of a small pool of device counters, zero between launches.
+__device__ unsigned g_done_pool[64];
+
+__device__ __forceinline__ void finish_loss(const float* term_mf, const float* term_l2, int batch,
+                                            float reg, float* __restrict__ out2, unsigned* done) {
+  if (out2 == nullptr) return;
+  __shared__ bool s_last;
+  __shared__ double s_a[256], s_b[256];
+  // The terms were stored with agent scope (write-through); waiting for their completion is all
+  // the ordering needed before the counter moves.  A full __threadfence() here costs an L2
+  // write-back per block (the row-gradient atomics leave the L2 dirty): +6 us on an MF step.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < batch; i += 256) {   // other blocks' terms: read past the L1
+    a += (double)__hip_atomic_load(&term_mf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b += (double)__hip_atomic_load(&term_l2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s_a[threadIdx.x] = a;
+  s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      s_a[threadIdx.x] += s_a[threadIdx.x + s];
+      s_b[threadIdx.x] += s_b[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = (float)s_a[0];
+    out2[1] = reg * (float)s_b[0];
+    *done = 0;                                       // re-armed for the next launch that draws it
+  }
+}
+
 // ---- BPR-MF ------------------------------------------------------------------
 template <int CPL>
-__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
+__device__ __forceinline__ void bpr_mf_grad_body(
     const float* __restrict__ P, const float* __restrict__ Q, int d,
     const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ GP,
@@ -60,8 +103,9 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
   const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(qj, qj) + dot_rows<CPL>(qi, qi));
   const float g = nr::pairwise_dloss(loss_kind, x);
   if (lane == 0) {
-    term_mf[b] = nr::pairwise_loss(loss_kind, x);
-    term_l2[b] = l2;
+    // agent-scope stores: written through to where the block that finishes last reads them
+    __hip_atomic_store(&term_mf[b], nr::pairwise_loss(loss_kind, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
@@ -74,9 +118,21 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
   }
 }
 
+template <int CPL>
+__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, int d,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ GP,
+    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
+    int loss_kind,
+    float* __restrict__ out2, unsigned* done) {
+  bpr_mf_grad_body<CPL>(P, Q, d, users, pos, neg, batch, reg, GP, GQ, term_mf, term_l2, loss_kind);
+  finish_loss(term_mf, term_l2, batch, reg, out2, done);
+}
+
 // ---- pointwise MF (is_pairwise=False, MF.py:70-72): (user, item, label) instances ---------------
 template <int CPL>
-__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void pointwise_mf_grad_kernel(
+__device__ __forceinline__ void pointwise_mf_grad_body(
     const float* __restrict__ P, const float* __restrict__ Q, int d,
     const int32_t* __restrict__ users, const int32_t* __restrict__ items,
     const float* __restrict__ labels, int batch, float reg, float scale, float* __restrict__ GP,
@@ -95,8 +151,9 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void pointwise_mf_grad_ker
   const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(q, q));
   const float g = nr::pointwise_dloss(loss_kind, z, x) * scale;
   if (lane == 0) {
-    term_mf[b] = nr::pointwise_loss(loss_kind, z, x) * scale;
-    term_l2[b] = l2;
+    // agent-scope stores: written through to where the block that finishes last reads them
+    __hip_atomic_store(&term_mf[b], nr::pointwise_loss(loss_kind, z, x) * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
@@ -108,9 +165,21 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void pointwise_mf_grad_ker
   }
 }
 
+template <int CPL>
+__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void pointwise_mf_grad_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, int d,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+    const float* __restrict__ labels, int batch, float reg, float scale, float* __restrict__ GP,
+    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
+    int loss_kind,
+    float* __restrict__ out2, unsigned* done) {
+  pointwise_mf_grad_body<CPL>(P, Q, d, users, items, labels, batch, reg, scale, GP, GQ, term_mf, term_l2, loss_kind);
+  finish_loss(term_mf, term_l2, batch, reg, out2, done);
+}
+
 // ---- LightGCN head --------------------------------------------------------------
 template <int CPL>
-__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_kernel(
+__device__ __forceinline__ void lightgcn_bpr_grad_body(
     const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
     float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ Gstar,
@@ -139,8 +208,9 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_ker
   const float l2 = 0.5f * (dot_rows<CPL>(zu, zu) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
   const float g = nr::bpr_dloss(x);
   if (lane == 0) {
-    term_mf[b] = nr::bpr_loss(x);
-    term_l2[b] = l2;
+    // agent-scope stores: written through to where the block that finishes last reads them
+    __hip_atomic_store(&term_mf[b], nr::bpr_loss(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
@@ -157,6 +227,18 @@ __global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_ker
   }
 }
 
+template <int CPL>
+__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_kernel(
+    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
+    float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ Gstar,
+    float* __restrict__ Greg, float* __restrict__ term_mf, float* __restrict__ term_l2,
+    float grad_div,
+    float* __restrict__ out2, unsigned* done) {
+  lightgcn_bpr_grad_body<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, Gstar, Greg, term_mf, term_l2, grad_div);
+  finish_loss(term_mf, term_l2, batch, reg, out2, done);
+}
+
 __global__ __launch_bounds__(256) void mark_batch_kernel(const int32_t* __restrict__ users,
                                                          const int32_t* __restrict__ pos,
                                                          const int32_t* __restrict__ neg, int batch,
@@ -169,28 +251,15 @@ __global__ __launch_bounds__(256) void mark_batch_kernel(const int32_t* __restri
   flag[u] = 1; flag[i] = 1; flag[j] = 1;
 }
 
-// fixed-order reduction of the per-triplet terms: out[0] = Σ mf, out[1] = reg·Σ l2
-__global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restrict__ term_mf,
-                                                          const float* __restrict__ term_l2,
-                                                          int batch, float reg,
-                                                          float* __restrict__ out2) {
-  __shared__ double s_a[256], s_b[256];
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < batch; i += 256) { a += (double)term_mf[i]; b += (double)term_l2[i]; }
-  s_a[threadIdx.x] = a;
-  s_b[threadIdx.x] = b;
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      s_a[threadIdx.x] += s_a[threadIdx.x + s];
-      s_b[threadIdx.x] += s_b[threadIdx.x + s];
-    }
-    __syncthreads();
+unsigned* next_done_counter() {
+  static unsigned* base = nullptr;
+  static std::atomic<unsigned> next{0};
+  if (!base) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_done_pool)) != hipSuccess) return nullptr;
+    base = (unsigned*)p;
   }
-  if (threadIdx.x == 0) {
-    out2[0] = (float)s_a[0];
-    out2[1] = reg * (float)s_b[0];
-  }
+  return base + (next.fetch_add(1) & 63u);
 }
 
 }  // namespace
@@ -215,18 +284,17 @@ static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q,
   float* t_mf = d_terms;
   float* t_l2 = d_terms + batch;
   dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  unsigned* done = next_done_counter();
+  NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
   if (d <= 64)
     hipLaunchKernelGGL(bpr_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
   else if (d <= 128)
     hipLaunchKernelGGL(bpr_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
   else
     hipLaunchKernelGGL(bpr_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
-                     d_loss2);
+                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -267,18 +335,17 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, const int
   // tf.losses.sigmoid_cross_entropy averages over the batch; the squared loss is a plain sum
   const float scale = loss_kind == nr::NR_POINT_CROSS_ENTROPY ? 1.0f / (float)batch : 1.0f;
   dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  unsigned* done = next_done_counter();
+  NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
   if (d <= 64)
     hipLaunchKernelGGL(pointwise_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
-                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
   else if (d <= 128)
     hipLaunchKernelGGL(pointwise_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
-                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind);
+                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
   else
     hipLaunchKernelGGL(pointwise_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
-                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
-                     d_loss2);
+                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -315,21 +382,18 @@ static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, in
   float* t_l2 = d_terms + batch;
   const float lp1 = (float)(n_layers + 1);
   dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  unsigned* done = next_done_counter();
+  NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
   if (d <= 64)
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<1>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div);
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
   else if (d <= 128)
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<2>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div);
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
   else
     hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<4>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div);
+                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
   NR_LAUNCH_CHECK();
-  if (d_loss2) {
-    hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, st, t_mf, t_l2, batch, reg,
-                       d_loss2);
-    NR_LAUNCH_CHECK();
-  }
   return NR_OK;
 }
 

@@ -239,19 +239,26 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     }
     const int64_t o = (int64_t)row * LPR + (i & (LPR - 1));
     float4 y = s_acc[i];
+    // with row flags (re-arming step buffers) the addend / grad_b rows of unflagged rows are all
+    // zero by contract and are not read: two of the seven epilogue streams touch batch rows only
+    bool flagged = true;
+    if constexpr (ADAM) {
+      if (ad.flag_rw) flagged = ad.flag_rw[row] != 0;
+    }
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (addend) {
-      const float4 ad = addend[o];
-      y.x = __fadd_rn(y.x, ad.x); y.y = __fadd_rn(y.y, ad.y);
-      y.z = __fadd_rn(y.z, ad.z); y.w = __fadd_rn(y.w, ad.w);
+      if (flagged) hv = addend[o];
+      y.x = __fadd_rn(y.x, hv.x); y.y = __fadd_rn(y.y, hv.y);
+      y.z = __fadd_rn(y.z, hv.z); y.w = __fadd_rn(y.w, hv.w);
     }
     if constexpr (ADAM) {
-      const float4 gb = ad.grad_b[o];
+      float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (flagged) gb = ad.grad_b[o];
       if (ad.addend_rw) {
-        const float4 hv = addend[o];
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hv.x != 0.f || hv.y != 0.f || hv.z != 0.f || hv.w != 0.f) ad.addend_rw[o] = zero;
         if (gb.x != 0.f || gb.y != 0.f || gb.z != 0.f || gb.w != 0.f) ad.grad_b_rw[o] = zero;
-        if ((i & (LPR - 1)) == 0 && ad.flag_rw && ad.flag_rw[row] != 0) ad.flag_rw[row] = 0;
+        if ((i & (LPR - 1)) == 0 && ad.flag_rw && flagged) ad.flag_rw[row] = 0;
       }
       float4 w = ad.var[o], mm = ad.m[o], vv = ad.v[o];
       nr::adam_dense_tf(__fadd_rn(y.x, gb.x), w.x, mm.x, vv.x, ad.alpha, ad.omb1, ad.omb2, ad.eps);
