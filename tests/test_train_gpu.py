@@ -390,3 +390,46 @@ def test_spmm_with_fused_adam_epilogue_equals_two_passes(eng):
     with pytest.raises(NotImplementedError):
         call("nrhip_spmm_csr_adam", plain.plan, ptr(plain.indices), ptr(plain.vals), ptr(X), d, ptr(H),
              ptr(Gb), ptr(var_b), ptr(m_b), ptr(v_b), 0.01, 0.9, 0.999, 1e-8, 0, C.c_void_p(0), C.c_void_p(0))
+
+
+@pytest.mark.gpu
+def test_spmm_column_masked_kernel_variants(eng, monkeypatch):
+    """spmm_colmasked_kernel (LDS-staged slice, sub-lists compacted to the surviving columns) against
+    the oracle's row-wise product and against the general masked kernel: empty rows, hub rows split
+    into segments, an addend that is the operand itself (its zero rows are not read), running sum."""
+    import torch
+    from oracle import train
+    rng = np.random.RandomState(77)
+    U, I, d = 1100, 800, 64
+    ur, ic = _graph(rng, U, I, 0, 50, hubs=3)
+    keep = ~np.isin(ur, [5, 6, 700, U - 1]) & ~np.isin(ic, [9, 10, I - 1])     # users / items nobody touches
+    ur, ic = ur[keep], ic[keep]
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    N = U + I
+    assert (np.diff(A.indptr) == 0).sum() >= 7 and (np.diff(A.indptr) > 128).any()
+    flag = np.zeros(N, np.uint8); flag[rng.choice(N, 300, replace=False)] = 1; flag[[U, U + 1]] = 1
+    X = (rng.randn(N, d).astype(np.float32)) * flag[:, None]
+    add, acc = rng.randn(N, d).astype(np.float32), rng.randn(N, d).astype(np.float32)
+    want = train.spmm_rowwise(A, X)
+    short = np.diff(A.indptr) <= 64
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("NEUREC_SPMM_COLMASK_FAST", fast)
+        csr = eng.SpmmCSR.from_scipy(A, split_row=U)
+        assert csr.ensure_schedule(d)
+        Xd, fl = _dev(X), _dev(flag)
+        y0 = torch.full((N, d), 9.0, device="cuda")
+        csr.matmul(Xd, out=y0, x_row_nonzero=fl)
+        y1 = torch.full((N, d), 9.0, device="cuda")
+        csr.matmul(Xd, out=y1, addend=Xd, x_row_nonzero=fl)              # H + A·H, the step's use
+        y2, s2 = torch.full((N, d), 9.0, device="cuda"), torch.full((N, d), 9.0, device="cuda")
+        csr.matmul(Xd, out=y2, addend=_dev(add), sum_in=_dev(acc), sum_out=s2, x_row_nonzero=fl)
+        outs[fast] = [t.cpu().numpy() for t in (y0, y1, y2, s2)]
+    y0, y1, y2, s2 = outs["1"]
+    np.testing.assert_array_equal(y0[short], want[short])               # same order, same roundings
+    assert np.abs(y0 - want).max() < 1e-5
+    np.testing.assert_array_equal(y1[short], (want + X)[short])
+    np.testing.assert_array_equal(y2[short], (want + add)[short])
+    np.testing.assert_array_equal(s2, acc + y2)
+    for a, b in zip(outs["1"], outs["0"]):                              # and bit-identical to the general kernel
+        np.testing.assert_array_equal(a, b)
