@@ -19,7 +19,11 @@ LIB_PATH = os.path.join(HERE, "libneurec_hip.so")
 STAMP = os.path.join(OBJ_DIR, "sources.sha256")
 
 SOURCES = ["eval_select.hip", "score_gemm.hip", "sampler.hip", "spmm.hip", "bpr.hip", "adam.hip",
-           "step.hip", "dense.hip", "vae.hip", "spmm_slab.hip", "spmm_blocked.hip"]
+           "step.hip", "dense.hip", "vae.hip", "spmm_blocked.hip"]
+# micro-benchmarks behind the design decisions in DESIGN.md (scripts/exp_*.py): their own library,
+# nothing of it is linked into the product
+EXP_SOURCES = ["experiments/gather_experiments.hip"]
+EXP_LIB_PATH = os.path.join(HERE, "libneurec_exp.so")
 HEADERS = ["nr_core.h", "nr_common.h"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -83,5 +87,28 @@ def build_extension(force=False, verbose=True):
     return LIB_PATH
 
 
+def build_experiments(verbose=True):
+    """Compile csrc/experiments/ into libneurec_exp.so (used by scripts/exp_*.py only)."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    for src in EXP_SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".o"))
+        r = subprocess.run([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        objs.append(obj)
+    # error reporting (nrhip_set_error) lives in the product library: link against it
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", EXP_LIB_PATH] + objs +
+                       ["-L", HERE, "-lneurec_hip", "-Wl,-rpath,$ORIGIN"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", EXP_LIB_PATH)
+    return EXP_LIB_PATH
+
+
 if __name__ == "__main__":
     build_extension(force="--force" in sys.argv)
+    if "--experiments" in sys.argv:
+        build_experiments()

@@ -3,8 +3,10 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurec_amd._lib import lib
+import _explib
+explib = _explib.load()
 
-fn = lib.nrhip_exp_halfline
+fn = explib.nrhip_exp_halfline
 fn.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 fn.restype = C.c_int
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,4 +1,4 @@
-"""GPU experiment: slab-major SpMM (spmm_slab.hip) against the row-major work-item kernel on the
+"""GPU experiment: slab-major SpMM (csrc/experiments/gather_experiments.hip) against the row-major work-item kernel on the
 gowalla-shaped graph: correctness (vs the row-major result) and time per pass, for slab widths
 8/16/32/64 and hub segment lengths."""
 import ctypes as C
@@ -11,6 +11,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurec_amd import engine as E, synth, graph
 from neurec_amd._lib import lib
+import _explib
+explib = _explib.load()
 
 
 def bench(fn, reps=40):
@@ -56,7 +58,7 @@ def plan(indptr, split_row, seg_len, sort=True):
             len(multi["row"]), slot)
 
 
-fn = lib.nrhip_spmm_slab
+fn = explib.nrhip_spmm_slab
 p, i32, i64 = C.c_void_p, C.c_int, C.c_int64
 fn.argtypes = [p, p, p, p, i32, i32, p, p, p, i32, p, p, p, i64, i32, i32, i32, p, p, p, p, p, p]
 fn.restype = C.c_int

@@ -1,9 +1,15 @@
-"""GPU experiment: per-workgroup timeline of the masked-hop kernels (temporary instrumentation build)."""
+"""GPU experiment: per-workgroup timeline of an SpMM kernel.  Needs a temporarily instrumented build:
+a `__device__ unsigned long long g_prof[4096 * 24]` in spmm_blocked.hip, `wall_clock64()` stamps stored by thread 0
+(and lane 0 of every wave) at the phase boundaries of the kernel under study, and an
+`extern "C" int nrhip_exp_spmm_prof(void* host_out)` that copies the array out (hipMemcpyFromSymbol).  The results
+of the round are in profiles/r01_exp_spmm_timeline.txt, r01_exp_halfrow_two_pass.txt, r01_exp_masked_hops.txt."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neurec_amd import engine as E, synth, graph
 from neurec_amd._lib import lib
+if not hasattr(lib, "nrhip_exp_spmm_prof"):
+    sys.exit("exp_spmm_prof.py needs an instrumented build of spmm_blocked.hip (see the docstring)")
 
 tr, te = synth.interactions("gowalla")
 coo = tr.tocoo(); U, I = tr.shape

@@ -22,7 +22,9 @@ for name, fn in (("flat sum", lambda: S.sum()), ("row max", lambda: S.amax(dim=1
 
 import ctypes as C
 from neurec_amd._lib import lib
-fn = lib.nrhip_exp_rowmax
+import _explib
+explib = _explib.load()
+fn = explib.nrhip_exp_rowmax
 fn.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 fn.restype = C.c_int
 out = torch.empty(B * 4, device="cuda")

@@ -33,6 +33,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.nrhip_abi_version() == 1
 
 
+def test_library_exports_nothing_undeclared():
+    """The product library's C surface is exactly the header (experiments live in libneurec_exp.so);
+    nrhip_set_error is the one internal hook (error text shared with that second library)."""
+    import shutil
+    import subprocess
+    from neurec_amd import build
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", build.build_extension()], capture_output=True,
+                         text=True, check=True).stdout
+    exported = set(re.findall(r" T (nrhip_\w+)", out))
+    assert exported - set(declared_symbols()) == {"nrhip_set_error"}
+
+
 def test_python_binding_covers_the_header():
     from neurec_amd import _lib
     assert set(declared_symbols()) == set(_lib.EXPORTED)
