@@ -53,14 +53,23 @@ struct BlockedPlan {
   uint32_t* wg_nnz;      // [n_wg][2] first non-zero of the workgroup's rows, count
   int nnz_cap, ent_cap;  // largest slice / descriptor list of a workgroup
   int colmask_ok;
+  // wanted-rows schedule (row-masked hop): the same sub-lists dealt to the workgroups by descending
+  // row length, descriptors carry global rows
+  int4* w_ent;           // {0 | r_max + partial slot, length, first non-zero, row}
+  int4* w_cmb;           // {row, first partial slot, segments, 0}
+  int32_t* w_ent_off;    // [n_wg][2]
+  int32_t* w_cmb_off;    // [n_wg][2]
+  int wanted_ok, w_ent_cap, w_nnz_cap;
 };
 
 size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
   const size_t max_ent = (size_t)std::min<int64_t>(nnz, n_rows * (int64_t)kMaxPhases) + (size_t)(nnz / 16) + 64;
   const size_t max_cmb = (size_t)(nnz / 16) + 64;
   const size_t wg = 4096 + (size_t)(n_rows / 32);   // generous bound on workgroups
+  const size_t w_ent = (size_t)n_rows + (size_t)(nnz / 16) + 64;        // wanted-rows schedule (one phase)
   return nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
-         3 * nr_align_up(wg * 8, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256);
+         3 * nr_align_up(wg * 8, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256) +
+         nr_align_up(w_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) + 2 * nr_align_up(wg * 8, 256);
 }
 
 // Optional fused optimiser epilogue (last backward hop of a LightGCN step): instead of storing
@@ -278,8 +287,8 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// The column-masked hop of a LightGCN step (first backward hop, d = 64): only columns of batch rows
-// contribute.  In the general masked kernel above it costs 27-29 us: every lane group still walks
+// The masked hops of a LightGCN step (d = 64).  Column-masked (first backward hop): only columns of
+// batch rows contribute.  In the general masked kernel above it costs 27-29 us: every lane group still walks
 // all its sub-lists through the descriptor -> columns -> mask -> rows chain.  Here the workgroup's
 // (column, value) slice is staged in LDS with one bulk read, the mask is applied there, every
 // sub-list is compacted in place, and the walk only sees the survivors, several sub-lists in
@@ -306,14 +315,125 @@ __device__ __forceinline__ void masked_row_out(float4 y, int64_t o, const float4
   }
 }
 
-__global__ __launch_bounds__(16 * NR_WAVE) void spmm_colmasked_kernel(
+// Walk of LDS-staged sub-lists by 16-lane groups (d = 64): rounds of kQ gathers per lane, three
+// rounds in flight (the staged sub-lists are short, so depth comes from running several of them
+// ahead); rounds retire in issue order.  s_ent[i] = {accumulator slot, length, offset into s_iv,
+// row - r0 | bit 30: addend row may be non-zero | bit 29: row not wanted}.
+// Every round issues exactly kQ + 1 loads, unconditionally (idle lanes and rounds read row 0 of X):
+// only then can the compiler count the loads younger than the round it retires and wait with
+// vmcnt(N > 0); with predicated loads it must assume none were issued and waits for all of them
+// (vmcnt(0)), which silently turns the ring into one round in flight (measured: 14 us -> see
+// profiles/r01_exp_masked_hops.txt).  The "+ 1" is the epilogue operand of the row a round
+// completes (addend, else sum_in), requested with the round's gathers for the same reason.
+__device__ __forceinline__ void staged_walk(const int4* s_ent, const int2* s_iv, int ne, int r0,
+                                            const float4* __restrict__ X, float4* __restrict__ Y,
+                                            const float4* __restrict__ addend, const float4* sum_in,
+                                            float4* sum_out, float4* s_part, int kRMax, int wave,
+                                            int g, int c) {
+  constexpr int RS = 16, LPR = 16, GPW = 4, kGroups = 64;
+  constexpr int kQ = 4;
+  struct Round { float4 x[kQ]; float4 pre; int off, n, slot, owner; bool first, last, live, valid; };
+  const float4* pre_src = addend ? addend : (sum_in ? sum_in : X);   // workgroup-uniform, never null
+  int ibase = wave * GPW, it0 = 0, imax = 0;      // issue cursor: batch of sub-lists, position
+  int4 ids = make_int4(0, 0, 0, 0);
+  bool ihas = ibase < ne;                         // wave-uniform: rounds left to issue
+  auto open = [&]() {
+    ids = make_int4(0, 0, 0, 0);
+    if (ibase + g < ne) ids = s_ent[ibase + g];
+    int m = ids.y;
+#pragma unroll
+    for (int sh = LPR; sh < NR_WAVE; sh <<= 1) m = max(m, __shfl_xor(m, sh, NR_WAVE));
+    imax = __builtin_amdgcn_readfirstlane(m);
+  };
+  auto issue = [&](Round& r) {
+    r.valid = ihas;
+    r.off = ids.z + it0;
+    r.n = ihas ? ids.y - it0 : 0;
+    r.slot = ids.x;
+    r.owner = ids.w;
+    r.first = it0 == 0;
+    r.live = ihas && ibase + g < ne;
+    r.last = ihas && it0 + kQ >= imax;
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      int col = s_iv[u < r.n ? r.off + u : 0].x;
+      if (u >= r.n) col = 0;
+      r.x[u] = X[(int64_t)col * RS + c];
+    }
+    const bool want_pre = r.last && r.live && r.slot < kRMax && !((r.owner >> 29) & 1) &&
+                          (!addend || ((r.owner >> 30) & 1));
+    r.pre = pre_src[(want_pre ? ((int64_t)r0 + (r.owner & 0xFFFFFF)) * RS : 0) + c];
+    if (r.last) {
+      ibase += kGroups;
+      it0 = 0;
+      ihas = ibase < ne;
+      if (ihas) open();
+    } else if (ihas) {
+      it0 += kQ;
+    }
+  };
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto retire = [&](const Round& r) {
+    if (r.first) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float a[kQ];
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) a[u] = __int_as_float(s_iv[u < r.n ? r.off + u : 0].y);
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const float4 t = make_float4(__fadd_rn(acc.x, __fmul_rn(a[u], r.x[u].x)),
+                                   __fadd_rn(acc.y, __fmul_rn(a[u], r.x[u].y)),
+                                   __fadd_rn(acc.z, __fmul_rn(a[u], r.x[u].z)),
+                                   __fadd_rn(acc.w, __fmul_rn(a[u], r.x[u].w)));
+      if (u < r.n) acc = t;
+    }
+    if (r.last && r.live && !((r.owner >> 29) & 1)) {
+      if (r.slot < kRMax) {
+        const int64_t o = ((int64_t)r0 + (r.owner & 0xFFFFFF)) * RS + c;
+        float4 y = acc;
+        if (addend) {
+          float4 av = make_float4(0.f, 0.f, 0.f, 0.f);     // a row promised zero was not read
+          if ((r.owner >> 30) & 1) av = r.pre;
+          y.x = __fadd_rn(y.x, av.x); y.y = __fadd_rn(y.y, av.y);
+          y.z = __fadd_rn(y.z, av.z); y.w = __fadd_rn(y.w, av.w);
+        }
+        if (Y) Y[o] = y;
+        if (sum_out) {
+          float4 si = r.pre;
+          if (addend) si = sum_in[o];                      // both operands: this one is read late
+          sum_out[o] = make_float4(__fadd_rn(si.x, y.x), __fadd_rn(si.y, y.y), __fadd_rn(si.z, y.z),
+                                   __fadd_rn(si.w, y.w));
+        }
+      } else {
+        s_part[(size_t)(r.slot - kRMax) * RS + c] = acc;
+      }
+    }
+  };
+  Round q0, q1, q2;                               // three rounds in flight: what 128 VGPRs hold
+  if (ihas) open();
+  issue(q0);
+  issue(q1);
+  while (true) {
+    issue(q2);
+    if (!q0.valid) break;
+    retire(q0);
+    issue(q0);
+    if (!q1.valid) break;
+    retire(q1);
+    issue(q1);
+    if (!q2.valid) break;
+    retire(q2);
+  }
+}
+
+template <bool COLMASK, bool ROWMASK>
+__global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
     const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_ent_off,
     const int32_t* __restrict__ wg_cmb_off, const uint32_t* __restrict__ wg_nnz,
     const int4* __restrict__ ent, const int4* __restrict__ cmb,
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
     const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ col_mask,
-    int addend_masked, int kRMax, int p_max, int ent_cap) {
+    const uint8_t* __restrict__ row_mask, int addend_masked, int kRMax, int p_max, int ent_cap) {
   constexpr int RS = 16, LPR = 16, GPW = 4, kGroups = 64;
   extern __shared__ float4 s_mem[];
   float4* s_part = s_mem;                                          // [p_max][16]
@@ -346,7 +466,10 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_colmasked_kernel(
         }
       }
 #pragma unroll
-      for (int k = 0; k < kStage; ++k) keep[k] = col_mask[col[k]];
+      for (int k = 0; k < kStage; ++k) {
+        keep[k] = 1;
+        if constexpr (COLMASK) keep[k] = col_mask[col[k]];
+      }
 #pragma unroll
       for (int k = 0; k < kStage; ++k) {
         const int i = i0 + k * 16 * NR_WAVE + tid;
@@ -356,14 +479,24 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_colmasked_kernel(
     for (int i = tid; i < ne; i += 16 * NR_WAVE) {
       if (i >= 16 * NR_WAVE) e = ent[e0 + i];
       e.z = (int)((uint32_t)e.z - nz0);                            // offset inside the staged slice
-      // bit 30 of the owner: the addend row of this output row may be non-zero
-      if (!addend_masked || col_mask[r0 + e.w] != 0) e.w |= 1 << 30;
+      // bit 30 of the owner: the addend row of this output row may be non-zero;
+      // bit 29: the output row is not wanted (nothing is gathered, nothing is written)
+      const int owner = e.w;
+      bool addend_on = true;
+      if constexpr (COLMASK) addend_on = !addend_masked || col_mask[r0 + owner] != 0;
+      if (addend_on) e.w |= 1 << 30;
+      if constexpr (ROWMASK) {
+        if (row_mask[r0 + owner] == 0) {
+          e.y = 0;
+          e.w |= 1 << 29;
+        }
+      }
       s_ent[i] = e;
     }
   }
   __syncthreads();
   // compact every sub-list to its surviving (column, value) pairs, in place and in order
-  for (int base = wave * GPW; base < ne; base += kGroups) {
+  for (int base = wave * GPW; COLMASK && base < ne; base += kGroups) {
     const int ei = base + g;
     int4 ds = make_int4(0, 0, 0, 0);
     if (ei < ne) ds = s_ent[ei];
@@ -384,102 +517,120 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_colmasked_kernel(
     }
     if (ei < ne && c == 0) s_ent[ei].y = w;
   }
-  // walk: rounds of kQ gathers per lane, four rounds in flight (the survivors of a sub-list are few,
-  // so depth comes from running several sub-lists ahead); rounds retire in issue order
-  {
-    constexpr int kQ = 4;
-    struct Round { float4 x[kQ]; int off, n, slot, owner; bool first, last, live; };
-    int ibase = wave * GPW, it0 = 0, imax = 0;      // issue cursor: batch of sub-lists, position
-    int4 ids = make_int4(0, 0, 0, 0);
-    bool ihas = ibase < ne;                         // wave-uniform: rounds left to issue
-    auto open = [&]() {
-      ids = make_int4(0, 0, 0, 0);
-      if (ibase + g < ne) ids = s_ent[ibase + g];
-      int m = ids.y;
-#pragma unroll
-      for (int sh = LPR; sh < NR_WAVE; sh <<= 1) m = max(m, __shfl_xor(m, sh, NR_WAVE));
-      imax = __builtin_amdgcn_readfirstlane(m);
-    };
-    auto issue = [&](Round& r) {
-      r.off = ids.z + it0;
-      r.n = ids.y - it0;
-      r.slot = ids.x;
-      r.owner = ids.w;
-      r.first = it0 == 0;
-      r.live = ibase + g < ne;
-#pragma unroll
-      for (int u = 0; u < kQ; ++u) {
-        r.x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u < r.n) r.x[u] = X[(int64_t)s_iv[r.off + u].x * RS + c];
-      }
-      r.last = it0 + kQ >= imax;
-      if (r.last) {
-        ibase += kGroups;
-        it0 = 0;
-        ihas = ibase < ne;
-        if (ihas) open();
-      } else {
-        it0 += kQ;
-      }
-    };
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto retire = [&](const Round& r) {
-      if (r.first) acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      float a[kQ];
-#pragma unroll
-      for (int u = 0; u < kQ; ++u) a[u] = __int_as_float(s_iv[u < r.n ? r.off + u : 0].y);
-#pragma unroll
-      for (int u = 0; u < kQ; ++u)
-        if (u < r.n) {
-          acc.x = __fadd_rn(acc.x, __fmul_rn(a[u], r.x[u].x));
-          acc.y = __fadd_rn(acc.y, __fmul_rn(a[u], r.x[u].y));
-          acc.z = __fadd_rn(acc.z, __fmul_rn(a[u], r.x[u].z));
-          acc.w = __fadd_rn(acc.w, __fmul_rn(a[u], r.x[u].w));
-        }
-      if (r.last && r.live) {
-        if (r.slot < kRMax)
-          masked_row_out(acc, ((int64_t)r0 + (r.owner & 0xFFFFFF)) * RS + c, addend, (r.owner >> 30) & 1,
-                         Y, sum_in, sum_out);
-        else
-          s_part[(size_t)(r.slot - kRMax) * RS + c] = acc;
-      }
-    };
-    Round q0, q1, q2, q3;
-    bool v0 = false, v1 = false, v2 = false, v3 = false;
-    if (ihas) open();
-    v0 = ihas; if (v0) issue(q0);
-    v1 = ihas; if (v1) issue(q1);
-    v2 = ihas; if (v2) issue(q2);
-    while (v0) {
-      v3 = ihas; if (v3) issue(q3);
-      retire(q0);
-      if (!v1) break;
-      v0 = ihas; if (v0) issue(q0);
-      retire(q1);
-      if (!v2) break;
-      v1 = ihas; if (v1) issue(q1);
-      retire(q2);
-      if (!v3) break;
-      v2 = ihas; if (v2) issue(q2);
-      retire(q3);
-    }
-  }
+  staged_walk(s_ent, s_iv, ne, r0, X, Y, addend, sum_in, sum_out, s_part, kRMax, wave, g, c);
   if (c1 > c0) {                                           // workgroup-uniform
     __syncthreads();
     for (int ci = c0 + wave * GPW + g; ci < c1; ci += kGroups) {
       const int4 cm = cmb[ci];
+      if constexpr (ROWMASK) {
+        if (row_mask[r0 + cm.x] == 0) continue;
+      }
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int sgm = 0; sgm < cm.z; ++sgm) {
         const float4 q = s_part[(size_t)(cm.y - kRMax + sgm) * RS + c];
         acc.x = __fadd_rn(acc.x, q.x); acc.y = __fadd_rn(acc.y, q.y);
         acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
       }
-      const bool addend_on = !addend_masked || col_mask[r0 + cm.x] != 0;
+      bool addend_on = true;
+      if constexpr (COLMASK) addend_on = !addend_masked || col_mask[r0 + cm.x] != 0;
       masked_row_out(acc, ((int64_t)r0 + cm.x) * RS + c, addend, addend_on, Y, sum_in, sum_out);
     }
   }
 }
 
+// Row-masked hop (last forward hop: only the batch rows are produced).  A real batch always holds
+// the hub rows (positives are drawn in proportion to degree): ~45 % of all non-zeros belong to
+// wanted rows, and in the row-run schedule they sit in a few workgroups that then do a full
+// pass's work while the rest idle.  This kernel runs on a second schedule of the same sub-lists,
+// dealt to the workgroups by descending row length (descriptors carry global rows): the
+// workgroup collects its wanted sub-lists, stages their (column, value) pairs in LDS (a wave per
+// sub-list, in chunks if they outgrow the buffer) and walks them with staged_walk.
+__global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
+    const int32_t* __restrict__ w_ent_off, const int32_t* __restrict__ w_cmb_off,
+    const int4* __restrict__ w_ent, const int4* __restrict__ w_cmb,
+    const int32_t* __restrict__ indices, const float* __restrict__ vals,
+    const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
+    const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ row_mask, int kRMax,
+    int p_max, int ent_cap, int nnz_cap) {
+  constexpr int RS = 16;
+  extern __shared__ float4 s_mem[];
+  float4* s_part = s_mem;                                          // [p_max][16]
+  int4* s_now = (int4*)(s_mem + (size_t)p_max * RS);               // sub-lists of this chunk
+  int4* s_later = s_now + ent_cap;                                 // sub-lists that did not fit
+  int2* s_iv = (int2*)(s_later + ent_cap);                         // [nnz_cap]
+  __shared__ int s_n_now, s_n_later, s_cursor;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int wg = blockIdx.x;
+  const int e0 = w_ent_off[2 * wg], ne = w_ent_off[2 * wg + 1] - e0;
+  const int c0 = w_cmb_off[2 * wg], c1 = w_cmb_off[2 * wg + 1];
+  if (tid == 0) { s_n_now = 0; s_n_later = 0; s_cursor = 0; }
+  __syncthreads();
+  // wanted sub-lists of this workgroup, each with room reserved in the staging buffer (.x keeps
+  // the slot, .z becomes the staging offset; the first non-zero moves to a register copy)
+  for (int i = tid; i < ne; i += 16 * NR_WAVE) {
+    const int4 e = w_ent[e0 + i];
+    if (row_mask[e.w] != 0) {
+      const int off = atomicAdd(&s_cursor, e.y);
+      if (off + e.y <= nnz_cap) s_now[atomicAdd(&s_n_now, 1)] = make_int4(e.x, e.y | (off << 8), e.z, e.w);
+      else s_later[atomicAdd(&s_n_later, 1)] = e;
+    }
+  }
+  __syncthreads();
+  while (true) {
+    const int n_now = s_n_now, n_later = s_n_later;
+    // stage: a wave per sub-list (<= 64 pairs, one coalesced read each); .y = length | offset << 8
+    for (int k = wave; k < n_now; k += 16) {
+      const int4 e = s_now[k];
+      const int len = e.y & 0xFF, off = e.y >> 8;
+      if (lane < len)
+        s_iv[off + lane] = make_int2(indices[(uint32_t)e.z + lane], __float_as_int(vals[(uint32_t)e.z + lane]));
+    }
+    __syncthreads();
+    for (int k = tid; k < n_now; k += 16 * NR_WAVE) {              // descriptors in staged_walk's format
+      const int4 e = s_now[k];
+      s_now[k] = make_int4(e.x, e.y & 0xFF, e.y >> 8, e.w | (1 << 30));
+    }
+    __syncthreads();
+    staged_walk(s_now, s_iv, n_now, 0, X, Y, addend, sum_in, sum_out, s_part, kRMax, wave, g, c);
+    if (n_later == 0) break;                                       // workgroup-uniform
+    __syncthreads();
+    if (tid == 0) { s_n_now = 0; s_n_later = 0; s_cursor = 0; }
+    __syncthreads();
+    // next chunk: re-deal the deferred sub-lists (s_later -> s_now, overflow back into s_later's
+    // already consumed prefix: entry k is read before any slot <= k is written)
+    for (int k0 = 0; k0 < n_later; k0 += 16 * NR_WAVE) {
+      const int k = k0 + tid;
+      int4 e = make_int4(0, 0, 0, 0);
+      if (k < n_later) e = s_later[k];
+      __syncthreads();
+      if (k < n_later) {
+        const int off = atomicAdd(&s_cursor, e.y);
+        if (off + e.y <= nnz_cap) s_now[atomicAdd(&s_n_now, 1)] = make_int4(e.x, e.y | (off << 8), e.z, e.w);
+        else s_later[atomicAdd(&s_n_later, 1)] = e;
+      }
+      __syncthreads();
+    }
+  }
+  if (c1 > c0) {                                                   // workgroup-uniform
+    __syncthreads();
+    for (int ci = c0 + wave * 4 + g; ci < c1; ci += 64) {
+      const int4 cm = w_cmb[ci];
+      if (row_mask[cm.x] == 0) continue;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sgm = 0; sgm < cm.z; ++sgm) {
+        const float4 q = s_part[(size_t)(cm.y - kRMax + sgm) * RS + c];
+        acc.x = __fadd_rn(acc.x, q.x); acc.y = __fadd_rn(acc.y, q.y);
+        acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
+      }
+      masked_row_out(acc, (int64_t)cm.x * RS + c, addend, true, Y, sum_in, sum_out);
+    }
+  }
+}
+
+size_t wanted_lds_bytes(const BlockedPlan* p) {
+  return (size_t)p->p_max * 256 + 2 * (size_t)p->w_ent_cap * 16 + (size_t)p->w_nnz_cap * 8;
+}
 size_t colmask_lds_bytes(const BlockedPlan* p) {
   return (size_t)p->p_max * 256 + (size_t)p->ent_cap * 16 + (size_t)p->nnz_cap * 8;
 }
@@ -689,10 +840,56 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   p->nnz_cap = (int)std::min<int64_t>(nnz_cap, INT32_MAX / 16);
   p->ent_cap = (int)std::min<int64_t>((ent_cap + 15) / 16 * 16, INT32_MAX / 32);
   {
-    const char* off = getenv("NEUREC_SPMM_COLMASK_FAST");     // "0": A/B against the general kernel
+    const char* off = getenv("NEUREC_SPMM_MASKED_FAST");     // "0": A/B against the general kernel
     const bool on = d == 64 && kWaves == 16 && n_phases == 1 && !(off && off[0] == '0');
     const size_t base = (size_t)kPMax * 256 + (size_t)p->ent_cap * 16;
     p->colmask_ok = on && nnz_cap < ((int64_t)1 << 24) && base + (size_t)nnz_cap * 8 <= (size_t)kMaxLdsBytes;
+    p->wanted_ok = on && kSeg <= 255 && n_rows < ((int64_t)1 << 24);
+  }
+  std::vector<int4> w_ent, w_cmb;
+  std::vector<int32_t> w_ent_off((size_t)n_wg * 2, 0), w_cmb_off((size_t)n_wg * 2, 0);
+  p->w_ent_cap = 0;
+  p->w_nnz_cap = 0;
+  if (p->wanted_ok) {
+    std::vector<int32_t> order((size_t)n_rows);
+    for (int64_t r = 0; r < n_rows; ++r) order[(size_t)r] = (int32_t)r;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+      return h_indptr[a + 1] - h_indptr[a] > h_indptr[b + 1] - h_indptr[b];
+    });
+    std::vector<std::vector<int4>> we((size_t)n_wg), wc((size_t)n_wg);
+    std::vector<int> wp((size_t)n_wg, 0);
+    for (int64_t k = 0; k < n_rows && p->wanted_ok; ++k) {
+      const int32_t row = order[(size_t)k];
+      const size_t w = (size_t)(k % n_wg);
+      const int64_t b = h_indptr[row], len = h_indptr[row + 1] - b;
+      if (len <= kSeg) {
+        we[w].push_back(make_int4(0, (int)len, (int)(uint32_t)b, row));
+      } else {
+        const int ns = (int)((len + kSeg - 1) / kSeg);
+        if (wp[w] + ns > kPMax) { p->wanted_ok = 0; break; }
+        for (int sg = 0; sg < ns; ++sg)
+          we[w].push_back(make_int4(kRMax + wp[w] + sg, (int)std::min<int64_t>(kSeg, len - (int64_t)sg * kSeg),
+                                    (int)(uint32_t)(b + (int64_t)sg * kSeg), row));
+        wc[w].push_back(make_int4(row, kRMax + wp[w], ns, 0));
+        wp[w] += ns;
+      }
+    }
+    for (int w = 0; w < n_wg && p->wanted_ok; ++w) {
+      w_ent_off[2 * (size_t)w] = (int32_t)w_ent.size();
+      w_cmb_off[2 * (size_t)w] = (int32_t)w_cmb.size();
+      w_ent.insert(w_ent.end(), we[(size_t)w].begin(), we[(size_t)w].end());
+      w_cmb.insert(w_cmb.end(), wc[(size_t)w].begin(), wc[(size_t)w].end());
+      w_ent_off[2 * (size_t)w + 1] = (int32_t)w_ent.size();
+      w_cmb_off[2 * (size_t)w + 1] = (int32_t)w_cmb.size();
+      p->w_ent_cap = std::max<int>(p->w_ent_cap, (int)we[(size_t)w].size());
+    }
+    p->w_ent_cap = (p->w_ent_cap + 15) / 16 * 16;
+    // LDS: partial slots + two descriptor lists + whatever is left for staged (column, value) pairs
+    const int64_t left = (int64_t)kMaxLdsBytes - 256 - (int64_t)kPMax * 256 - 2 * (int64_t)p->w_ent_cap * 16;
+    p->w_nnz_cap = (int)std::min<int64_t>(left / 8, (int64_t)1 << 22);
+    if (const char* cap = getenv("NEUREC_SPMM_WANTED_NNZ_CAP"))     // tests: force the chunked path
+      p->w_nnz_cap = std::min(p->w_nnz_cap, std::max(atoi(cap), 4 * kSeg));
+    if (p->w_nnz_cap < 4 * kSeg) p->wanted_ok = 0;
   }
   p->n_rows = n_rows; p->nnz = nnz; p->n_wg = n_wg; p->n_phases = n_phases;
   p->seg = kSeg; p->r_max = kRMax; p->p_max = kPMax; p->waves = kWaves; p->d = d;
@@ -706,6 +903,10 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   p->wg_ent_off = (int32_t*)carve(ent_off.size() * 4);
   p->wg_cmb_off = (int32_t*)carve(cmb_off.size() * 4);
   p->wg_nnz = (uint32_t*)carve(wg_nnz.size() * 4);
+  p->w_ent = (int4*)carve(w_ent.size() * 16 + 16);
+  p->w_cmb = (int4*)carve(w_cmb.size() * 16 + 16);
+  p->w_ent_off = (int32_t*)carve(w_ent_off.size() * 4);
+  p->w_cmb_off = (int32_t*)carve(w_cmb_off.size() * 4);
   if ((size_t)(q - (char*)d_plan_buf) > plan_bytes) {
     delete p;
     nrhip_set_error("spmm_blocked_plan_create: plan needs %zu bytes, buffer has %zu",
@@ -724,6 +925,10 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   up(p->wg_ent_off, ent_off.data(), ent_off.size() * 4);
   up(p->wg_cmb_off, cmb_off.data(), cmb_off.size() * 4);
   up(p->wg_nnz, wg_nnz.data(), wg_nnz.size() * 4);
+  up(p->w_ent, w_ent.data(), w_ent.size() * 16);
+  up(p->w_cmb, w_cmb.data(), w_cmb.size() * 16);
+  up(p->w_ent_off, w_ent_off.data(), w_ent_off.size() * 4);
+  up(p->w_cmb_off, w_cmb_off.data(), w_cmb_off.size() * 4);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   const int lds = (kRMax + kPMax) * kD * 4;
   auto allow = [&](const void* fn) {
@@ -737,9 +942,15 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   if (d == 16) { NR_ALLOW(16); } else if (d == 32) { NR_ALLOW(32); } else if (d == 64) { NR_ALLOW(64); }
   else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
 #undef NR_ALLOW
-  if (p->colmask_ok && e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)spmm_colmasked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)colmask_lds_bytes(p));
+  if (p->wanted_ok && e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)spmm_wanted_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)wanted_lds_bytes(p));
+  if (p->colmask_ok)
+    for (const void* fn : {(const void*)spmm_staged_masked_kernel<true, false>,
+                           (const void*)spmm_staged_masked_kernel<false, true>,
+                           (const void*)spmm_staged_masked_kernel<true, true>})
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colmask_lds_bytes(p));
   if (e != hipSuccess) {
     delete p;
     nrhip_set_error("spmm_blocked_plan_create: %s", hipGetErrorString(e));
@@ -786,13 +997,28 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
   const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
   const bool masked = d_x_row_nonzero || d_y_row_wanted;
   const int gif = s_gathers_in_flight;
-  if (p->colmask_ok && d_x_row_nonzero && !d_y_row_wanted) {
+  if (p->wanted_ok && d_y_row_wanted && !d_x_row_nonzero) {
+    hipLaunchKernelGGL(spmm_wanted_rows_kernel, grid, block, wanted_lds_bytes(p), st, p->w_ent_off,
+                       p->w_cmb_off, p->w_ent, p->w_cmb, d_indices, d_vals, (const float4*)d_X,
+                       (float4*)d_Y, (const float4*)d_addend, (const float4*)d_sum_in,
+                       (float4*)d_sum_out, d_y_row_wanted, p->r_max, p->p_max, p->w_ent_cap,
+                       p->w_nnz_cap);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+  }
+  if (p->colmask_ok && masked) {
     // an addend that is the operand itself shares its promise (zero rows where the mask is 0)
-    hipLaunchKernelGGL(spmm_colmasked_kernel, grid, block, colmask_lds_bytes(p), st, p->wg_row0,
-                       p->wg_ent_off, p->wg_cmb_off, p->wg_nnz, p->ent, p->cmb, d_indices, d_vals,
-                       (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,
-                       (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero,
-                       d_addend == d_X ? 1 : 0, p->r_max, p->p_max, p->ent_cap);
+    const int addend_masked = d_x_row_nonzero && d_addend == d_X ? 1 : 0;
+#define NR_STAGED(CM, RM)                                                                          \
+  hipLaunchKernelGGL((spmm_staged_masked_kernel<CM, RM>), grid, block, colmask_lds_bytes(p), st,   \
+                     p->wg_row0, p->wg_ent_off, p->wg_cmb_off, p->wg_nnz, p->ent, p->cmb, d_indices, \
+                     d_vals, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,             \
+                     (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,  \
+                     addend_masked, p->r_max, p->p_max, p->ent_cap)
+    if (d_x_row_nonzero && d_y_row_wanted) NR_STAGED(true, true);
+    else if (d_x_row_nonzero) NR_STAGED(true, false);
+    else NR_STAGED(false, true);
+#undef NR_STAGED
     NR_LAUNCH_CHECK();
     return NR_OK;
   }

@@ -36,7 +36,7 @@ flag[torch.from_numpy(np.concatenate([coo.row[pick], U + coo.col[pick], U + rs.r
 Xs = X * flag[:, None].float()
 plans = {}
 for mode in ("0", "1"):
-    os.environ["NEUREC_SPMM_COLMASK_FAST"] = mode
+    os.environ["NEUREC_SPMM_MASKED_FAST"] = mode
     buf = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
     plan = p()
     rc = lib.nrhip_spmm_blocked_plan_create(indptr.ctypes.data_as(p), indices.ctypes.data_as(p), N, U, d, 0, 0, 0, 0, 0, 0,

@@ -414,7 +414,7 @@ def test_spmm_column_masked_kernel_variants(eng, monkeypatch):
     short = np.diff(A.indptr) <= 64
     outs = {}
     for fast in ("1", "0"):
-        monkeypatch.setenv("NEUREC_SPMM_COLMASK_FAST", fast)
+        monkeypatch.setenv("NEUREC_SPMM_MASKED_FAST", fast)
         csr = eng.SpmmCSR.from_scipy(A, split_row=U)
         assert csr.ensure_schedule(d)
         Xd, fl = _dev(X), _dev(flag)
@@ -432,4 +432,55 @@ def test_spmm_column_masked_kernel_variants(eng, monkeypatch):
     np.testing.assert_array_equal(y2[short], (want + add)[short])
     np.testing.assert_array_equal(s2, acc + y2)
     for a, b in zip(outs["1"], outs["0"]):                              # and bit-identical to the general kernel
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nnz_cap", [0, 256])
+def test_spmm_wanted_rows_kernel(eng, monkeypatch, nnz_cap):
+    """spmm_wanted_rows_kernel (row-masked hop on the dealt schedule, sub-lists staged in LDS) against
+    the oracle and the general masked kernel; nnz_cap=256 forces the chunked path (wanted sub-lists
+    outgrow the staging buffer and are re-dealt)."""
+    import torch
+    from oracle import train
+    rng = np.random.RandomState(78)
+    U, I, d = 1100, 800, 64
+    ur, ic = _graph(rng, U, I, 0, 50, hubs=3)
+    keep = ~np.isin(ur, [5, 6, 700, U - 1]) & ~np.isin(ic, [9, 10, I - 1])
+    ur, ic = ur[keep], ic[keep]
+    A = train.lightgcn_adjacency(ur, ic, U, I, "pre")
+    N = U + I
+    lens = np.diff(A.indptr)
+    X = rng.randn(N, d).astype(np.float32)
+    add, acc = rng.randn(N, d).astype(np.float32), rng.randn(N, d).astype(np.float32)
+    wanted = np.zeros(N, np.uint8)
+    wanted[rng.choice(N, 400, replace=False)] = 1
+    wanted[[U, U + 1, U + 2, 5, U + 9]] = 1                      # the hub rows and two empty rows
+    if nnz_cap:                                                  # many sub-lists in few workgroups
+        wanted[np.argsort(-lens)[:300]] = 1
+    want = train.spmm_rowwise(A, X)
+    short = (lens <= 64) & (wanted == 1)
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("NEUREC_SPMM_MASKED_FAST", fast)
+        if nnz_cap:
+            monkeypatch.setenv("NEUREC_SPMM_WANTED_NNZ_CAP", str(nnz_cap))
+        csr = eng.SpmmCSR.from_scipy(A, split_row=U)
+        assert csr.ensure_schedule(d)
+        Xd, wd = _dev(X), _dev(wanted)
+        y0 = torch.full((N, d), 7.0, device="cuda")
+        csr.matmul(Xd, out=y0, y_row_wanted=wd)
+        s1 = torch.full((N, d), 7.0, device="cuda")
+        csr.matmul(Xd, out=None, sum_in=_dev(acc), sum_out=s1, y_row_wanted=wd)     # the step's use
+        y2, s2 = torch.full((N, d), 7.0, device="cuda"), torch.full((N, d), 7.0, device="cuda")
+        csr.matmul(Xd, out=y2, addend=_dev(add), sum_in=_dev(acc), sum_out=s2, y_row_wanted=wd)
+        outs[fast] = [t.cpu().numpy() for t in (y0, s1, y2, s2)]
+    y0, s1, y2, s2 = outs["1"]
+    np.testing.assert_array_equal(y0[short], want[short])
+    assert np.abs(y0 - want)[wanted == 1].max() < 1e-5
+    assert np.all(y0[wanted == 0] == 7.0) and np.all(s1[wanted == 0] == 7.0)
+    np.testing.assert_array_equal(s1[wanted == 1], (acc + y0)[wanted == 1])
+    np.testing.assert_array_equal(y2[short], (want + add)[short])
+    np.testing.assert_array_equal(s2[wanted == 1], (acc + y2)[wanted == 1])
+    for a, b in zip(outs["1"], outs["0"]):
         np.testing.assert_array_equal(a, b)
