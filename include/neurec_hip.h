@@ -278,6 +278,24 @@ int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const fl
                             float eps, int clear_consumed, uint8_t* d_row_flag, void* stream);
 int nrhip_spmm_plan_has_blocked(const void* plan, int d);   /* 1 / 0, not a status code */
 
+/* Last forward hop of a step with the layer sum completed on the way (LightGCN.py:143-146 on the
+ * batch rows): for rows with d_y_row_wanted[r] != 0,
+ *   d_sum_out[r] = ((d_sum_in[r] + d_layer_a[r]) + d_layer_b[r]) + (A·X)[r]
+ * (d_layer_a / d_layer_b optional, NULL = term absent; other rows of d_sum_out untouched).  The
+ * full hops before it then need no running-sum streams.  Same additions in the same order as
+ * nrhip_spmm_csr with sum_in / sum_out hop by hop.  Needs the d = 64 wanted-rows schedule
+ * (nrhip_spmm_plan_has_wanted(plan, 64) != 0), NRHIP_ERR_UNSUPPORTED otherwise. */
+int nrhip_spmm_csr_wanted_layers(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                 const float* d_X, int d, const float* d_sum_in,
+                                 const float* d_layer_a, const float* d_layer_b, float* d_sum_out,
+                                 const uint8_t* d_y_row_wanted, void* stream);
+int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                     const float* d_X, const float* d_sum_in, const float* d_layer_a,
+                                     const float* d_layer_b, float* d_sum_out,
+                                     const uint8_t* d_y_row_wanted, void* stream);
+int nrhip_spmm_plan_has_wanted(const void* plan, int d);    /* 1 / 0, not a status code */
+int nrhip_spmm_blocked_has_wanted(const void* blocked_plan); /* 1 / 0, not a status code */
+
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,
                         const float* d_addend, const float* d_sum_in, float* d_sum_out,

@@ -111,6 +111,10 @@ SIGNATURES = {
     "nrhip_spmm_blocked": [p, p, p, p, p, p, p, p, p, p, p],
     "nrhip_spmm_plan_attach_blocked": [p, p, i32],
     "nrhip_spmm_plan_has_blocked": [p, i32],
+    "nrhip_spmm_plan_has_wanted": [p, i32],
+    "nrhip_spmm_blocked_has_wanted": [p],
+    "nrhip_spmm_csr_wanted_layers": [p, p, p, p, i32, p, p, p, p, p, p],
+    "nrhip_spmm_blocked_wanted_layers": [p, p, p, p, p, p, p, p, p, p],
     "nrhip_spmm_csr_adam": [p, p, p, p, i32, p, p, p, p, p, f32, f32, f32, f32, i32, p, p],
     "nrhip_spmm_blocked_adam": [p, p, p, p, p, p, p, p, p, f32, f32, f32, f32, i32, p, p],
     "nrhip_vae_encode": [p, p, p, i32, i32, i32, p, p, p, p, p, p, i32, f32, p, p, f32, u64, u64,

@@ -47,6 +47,12 @@ extern "C" int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, co
                                   const uint8_t* d_x_row_nonzero, const uint8_t* d_y_row_wanted,
                                   void* stream);
 
+extern "C" int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t* d_indices,
+                                                const float* d_vals, const float* d_X,
+                                                const float* d_sum_in, const float* d_layer_a,
+                                                const float* d_layer_b, float* d_sum_out,
+                                                const uint8_t* d_y_row_wanted, void* stream);
+extern "C" int nrhip_spmm_blocked_has_wanted(const void* plan);
 extern "C" int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices,
                                        const float* d_vals, const float* d_X, float* d_addend,
                                        float* d_grad_b, float* d_var, float* d_m, float* d_v,
@@ -776,6 +782,24 @@ int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float*
   return nrhip_spmm_blocked_adam(p->blocked[blocked_slot(64)], d_indices, d_vals, d_X, d_addend, d_grad_b, d_var,
                                  d_m, d_v, alpha, beta1, beta2, eps, clear_consumed, d_row_flag,
                                  stream);
+}
+
+int nrhip_spmm_csr_wanted_layers(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                 const float* d_X, int d, const float* d_sum_in,
+                                 const float* d_layer_a, const float* d_layer_b, float* d_sum_out,
+                                 const uint8_t* d_y_row_wanted, void* stream) {
+  NR_REQUIRE(plan, NR_ERR_ARG, "spmm_csr_wanted_layers: null plan");
+  const SpmmPlan* p = (const SpmmPlan*)plan;
+  NR_REQUIRE(d == 64 && p->blocked[blocked_slot(64)], NR_ERR_UNSUPPORTED,
+             "spmm_csr_wanted_layers: needs the d = 64 lane-group schedule");
+  return nrhip_spmm_blocked_wanted_layers(p->blocked[blocked_slot(64)], d_indices, d_vals, d_X, d_sum_in,
+                                          d_layer_a, d_layer_b, d_sum_out, d_y_row_wanted, stream);
+}
+
+int nrhip_spmm_plan_has_wanted(const void* plan, int d) {
+  if (!plan || d != 64) return 0;
+  const SpmmPlan* p = (const SpmmPlan*)plan;
+  return p->blocked[blocked_slot(64)] ? nrhip_spmm_blocked_has_wanted(p->blocked[blocked_slot(64)]) : 0;
 }
 
 int nrhip_spmm_plan_has_blocked(const void* plan, int d) {

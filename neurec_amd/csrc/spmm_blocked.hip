@@ -298,9 +298,24 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
 // too and removed: a real batch is dominated by hub rows, whose gathers are ~45 % of a full pass,
 // so that hop is bound by gather throughput, not by the walk: profiles/r01_exp_masked_hops.txt.)
 
+struct LayerChain { const float4* a; const float4* b; };   // optional further terms of the running sum
+
+__device__ __forceinline__ float4 chain_sum(float4 si, const LayerChain& ch, int64_t o) {
+  if (ch.a) {
+    const float4 t = ch.a[o];
+    si = make_float4(__fadd_rn(si.x, t.x), __fadd_rn(si.y, t.y), __fadd_rn(si.z, t.z), __fadd_rn(si.w, t.w));
+  }
+  if (ch.b) {
+    const float4 t = ch.b[o];
+    si = make_float4(__fadd_rn(si.x, t.x), __fadd_rn(si.y, t.y), __fadd_rn(si.z, t.z), __fadd_rn(si.w, t.w));
+  }
+  return si;
+}
+
 __device__ __forceinline__ void masked_row_out(float4 y, int64_t o, const float4* __restrict__ addend,
                                                bool addend_row_nonzero, float4* __restrict__ Y,
-                                               const float4* sum_in, float4* sum_out) {
+                                               const float4* sum_in, float4* sum_out,
+                                               const LayerChain* chain = nullptr) {
   if (addend) {
     float4 av = make_float4(0.f, 0.f, 0.f, 0.f);       // a row promised zero is not read
     if (addend_row_nonzero) av = addend[o];
@@ -309,7 +324,8 @@ __device__ __forceinline__ void masked_row_out(float4 y, int64_t o, const float4
   }
   if (Y) Y[o] = y;
   if (sum_out) {
-    const float4 si = sum_in[o];
+    float4 si = sum_in[o];
+    if (chain) si = chain_sum(si, *chain, o);
     sum_out[o] = make_float4(__fadd_rn(si.x, y.x), __fadd_rn(si.y, y.y), __fadd_rn(si.z, y.z),
                              __fadd_rn(si.w, y.w));
   }
@@ -329,7 +345,7 @@ __device__ __forceinline__ void staged_walk(const int4* s_ent, const int2* s_iv,
                                             const float4* __restrict__ X, float4* __restrict__ Y,
                                             const float4* __restrict__ addend, const float4* sum_in,
                                             float4* sum_out, float4* s_part, int kRMax, int wave,
-                                            int g, int c) {
+                                            int g, int c, LayerChain chain = LayerChain{nullptr, nullptr}) {
   constexpr int RS = 16, LPR = 16, GPW = 4, kGroups = 64;
   constexpr int kQ = 4;
   struct Round { float4 x[kQ]; float4 pre; int off, n, slot, owner; bool first, last, live, valid; };
@@ -400,6 +416,7 @@ __device__ __forceinline__ void staged_walk(const int4* s_ent, const int2* s_iv,
         if (sum_out) {
           float4 si = r.pre;
           if (addend) si = sum_in[o];                      // both operands: this one is read late
+          si = chain_sum(si, chain, o);
           sum_out[o] = make_float4(__fadd_rn(si.x, y.x), __fadd_rn(si.y, y.y), __fadd_rn(si.z, y.z),
                                    __fadd_rn(si.w, y.w));
         }
@@ -551,7 +568,7 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
     const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ row_mask, int kRMax,
-    int p_max, int ent_cap, int nnz_cap) {
+    int p_max, int ent_cap, int nnz_cap, LayerChain chain) {
   constexpr int RS = 16;
   extern __shared__ float4 s_mem[];
   float4* s_part = s_mem;                                          // [p_max][16]
@@ -592,7 +609,7 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
       s_now[k] = make_int4(e.x, e.y & 0xFF, e.y >> 8, e.w | (1 << 30));
     }
     __syncthreads();
-    staged_walk(s_now, s_iv, n_now, 0, X, Y, addend, sum_in, sum_out, s_part, kRMax, wave, g, c);
+    staged_walk(s_now, s_iv, n_now, 0, X, Y, addend, sum_in, sum_out, s_part, kRMax, wave, g, c, chain);
     if (n_later == 0) break;                                       // workgroup-uniform
     __syncthreads();
     if (tid == 0) { s_n_now = 0; s_n_later = 0; s_cursor = 0; }
@@ -623,7 +640,7 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
         acc.x = __fadd_rn(acc.x, q.x); acc.y = __fadd_rn(acc.y, q.y);
         acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
       }
-      masked_row_out(acc, (int64_t)cm.x * RS + c, addend, true, Y, sum_in, sum_out);
+      masked_row_out(acc, (int64_t)cm.x * RS + c, addend, true, Y, sum_in, sum_out, &chain);
     }
   }
 }
@@ -1002,7 +1019,7 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
                        p->w_cmb_off, p->w_ent, p->w_cmb, d_indices, d_vals, (const float4*)d_X,
                        (float4*)d_Y, (const float4*)d_addend, (const float4*)d_sum_in,
                        (float4*)d_sum_out, d_y_row_wanted, p->r_max, p->p_max, p->w_ent_cap,
-                       p->w_nnz_cap);
+                       p->w_nnz_cap, LayerChain{nullptr, nullptr});
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
@@ -1042,6 +1059,33 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
 #undef NR_BLK
   NR_LAUNCH_CHECK();
   return NR_OK;
+}
+
+/* Row-masked hop with the running layer sum completed on the way (LightGCN.py:143-146 on the batch
+ * rows): d_sum_out[r] = ((d_sum_in[r] + d_layer_a[r]) + d_layer_b[r]) + (A·X)[r] for the rows with
+ * d_y_row_wanted[r] != 0 (d_layer_a / d_layer_b optional) — the full hops before it then need no
+ * running-sum streams at all.  Needs the wanted-rows schedule (d = 64). */
+int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                     const float* d_X, const float* d_sum_in, const float* d_layer_a,
+                                     const float* d_layer_b, float* d_sum_out,
+                                     const uint8_t* d_y_row_wanted, void* stream) {
+  NR_REQUIRE(plan && d_indices && d_vals && d_X && d_sum_in && d_sum_out && d_y_row_wanted, NR_ERR_ARG,
+             "spmm_blocked_wanted_layers: null pointer argument");
+  NR_REQUIRE(d_layer_a || !d_layer_b, NR_ERR_ARG, "spmm_blocked_wanted_layers: layer_b without layer_a");
+  const BlockedPlan* p = (const BlockedPlan*)plan;
+  NR_REQUIRE(p->wanted_ok, NR_ERR_UNSUPPORTED, "spmm_blocked_wanted_layers: no wanted-rows schedule");
+  hipLaunchKernelGGL(spmm_wanted_rows_kernel, dim3((unsigned)p->n_wg), dim3(p->waves * NR_WAVE),
+                     wanted_lds_bytes(p), (hipStream_t)stream, p->w_ent_off, p->w_cmb_off, p->w_ent,
+                     p->w_cmb, d_indices, d_vals, (const float4*)d_X, (float4*)nullptr,
+                     (const float4*)nullptr, (const float4*)d_sum_in, (float4*)d_sum_out,
+                     d_y_row_wanted, p->r_max, p->p_max, p->w_ent_cap, p->w_nnz_cap,
+                     LayerChain{(const float4*)d_layer_a, (const float4*)d_layer_b});
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked_has_wanted(const void* plan) {
+  return plan && ((const BlockedPlan*)plan)->wanted_ok ? 1 : 0;
 }
 
 /* Y is not stored: the rows' results (plus d_addend) are consumed as the dense gradient

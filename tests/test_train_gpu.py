@@ -484,3 +484,20 @@ def test_spmm_wanted_rows_kernel(eng, monkeypatch, nnz_cap):
     np.testing.assert_array_equal(s2[wanted == 1], (acc + y2)[wanted == 1])
     for a, b in zip(outs["1"], outs["0"]):
         np.testing.assert_array_equal(a, b)
+    # layer chain: ((sum_in + layer_a) + layer_b) + A·X on the wanted rows, terms optional
+    import ctypes as C
+    from neurec_amd._lib import call, lib
+    monkeypatch.setenv("NEUREC_SPMM_MASKED_FAST", "1")
+    csr = eng.SpmmCSR.from_scipy(A, split_row=U)
+    assert csr.ensure_schedule(d) and lib.nrhip_spmm_plan_has_wanted(csr.plan, d) == 1
+    la, lb = rng.randn(N, d).astype(np.float32), rng.randn(N, d).astype(np.float32)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    Xd, wd, accd, lad, lbd = _dev(X), _dev(wanted), _dev(acc), _dev(la), _dev(lb)
+    w = wanted == 1
+    for a_, b_, ref in ((None, None, acc + y0), (lad, None, (acc + la) + y0), (lad, lbd, ((acc + la) + lb) + y0)):
+        out = torch.full((N, d), 7.0, device="cuda")
+        call("nrhip_spmm_csr_wanted_layers", csr.plan, ptr(csr.indices), ptr(csr.vals), ptr(Xd), d, ptr(accd),
+             ptr(a_), ptr(b_), ptr(out), ptr(wd), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        got = out.cpu().numpy()
+        np.testing.assert_array_equal(got[w], ref[w])
+        assert np.all(got[~w] == 7.0)
