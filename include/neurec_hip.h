@@ -293,8 +293,23 @@ int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t* d_indices,
                                      const float* d_X, const float* d_sum_in, const float* d_layer_a,
                                      const float* d_layer_b, float* d_sum_out,
                                      const uint8_t* d_y_row_wanted, void* stream);
-int nrhip_spmm_plan_has_wanted(const void* plan, int d);    /* 1 / 0, not a status code */
-int nrhip_spmm_blocked_has_wanted(const void* blocked_plan); /* 1 / 0, not a status code */
+/* The same hop told the batch instead of flags: wanted rows = d_users | n_users + d_pos |
+ * n_users + d_neg.  It does nrhip_lightgcn_mark_batch's job on the way (one launch less per step):
+ * d_row_flag (zero on entry) gets 1 on those rows, d_rows_out (optional) the 3*batch rows.  Needs
+ * nrhip_spmm_plan_has_wanted(plan, 64) == 2 (a matrix of <= 131072 rows: one bit per row in LDS). */
+int nrhip_spmm_csr_wanted_batch(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                const float* d_X, int d, const float* d_sum_in, const float* d_layer_a,
+                                const float* d_layer_b, float* d_sum_out, const int32_t* d_users,
+                                const int32_t* d_pos, const int32_t* d_neg, int batch, int n_users,
+                                uint8_t* d_row_flag, int32_t* d_rows_out, void* stream);
+int nrhip_spmm_blocked_wanted_batch(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                    const float* d_X, const float* d_sum_in, const float* d_layer_a,
+                                    const float* d_layer_b, float* d_sum_out, const int32_t* d_users,
+                                    const int32_t* d_pos, const int32_t* d_neg, int batch, int n_users,
+                                    uint8_t* d_row_flag, int32_t* d_rows_out, void* stream);
+/* 0: no wanted-rows schedule, 1: flag form only, 2: flag and batch forms (not status codes) */
+int nrhip_spmm_plan_has_wanted(const void* plan, int d);
+int nrhip_spmm_blocked_has_wanted(const void* blocked_plan);
 
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,

@@ -115,6 +115,8 @@ SIGNATURES = {
     "nrhip_spmm_blocked_has_wanted": [p],
     "nrhip_spmm_csr_wanted_layers": [p, p, p, p, i32, p, p, p, p, p, p],
     "nrhip_spmm_blocked_wanted_layers": [p, p, p, p, p, p, p, p, p, p],
+    "nrhip_spmm_csr_wanted_batch": [p, p, p, p, i32, p, p, p, p, p, p, p, i32, i32, p, p, p],
+    "nrhip_spmm_blocked_wanted_batch": [p, p, p, p, p, p, p, p, p, p, p, i32, i32, p, p, p],
     "nrhip_spmm_csr_adam": [p, p, p, p, i32, p, p, p, p, p, f32, f32, f32, f32, i32, p, p],
     "nrhip_spmm_blocked_adam": [p, p, p, p, p, p, p, p, p, f32, f32, f32, f32, i32, p, p],
     "nrhip_vae_encode": [p, p, p, i32, i32, i32, p, p, p, p, p, p, i32, f32, p, p, f32, u64, u64,

@@ -52,6 +52,13 @@ extern "C" int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t*
                                                 const float* d_sum_in, const float* d_layer_a,
                                                 const float* d_layer_b, float* d_sum_out,
                                                 const uint8_t* d_y_row_wanted, void* stream);
+extern "C" int nrhip_spmm_blocked_wanted_batch(const void* plan, const int32_t* d_indices,
+                                               const float* d_vals, const float* d_X,
+                                               const float* d_sum_in, const float* d_layer_a,
+                                               const float* d_layer_b, float* d_sum_out,
+                                               const int32_t* d_users, const int32_t* d_pos,
+                                               const int32_t* d_neg, int batch, int n_users,
+                                               uint8_t* d_row_flag, int32_t* d_rows_out, void* stream);
 extern "C" int nrhip_spmm_blocked_has_wanted(const void* plan);
 extern "C" int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices,
                                        const float* d_vals, const float* d_X, float* d_addend,
@@ -794,6 +801,20 @@ int nrhip_spmm_csr_wanted_layers(const void* plan, const int32_t* d_indices, con
              "spmm_csr_wanted_layers: needs the d = 64 lane-group schedule");
   return nrhip_spmm_blocked_wanted_layers(p->blocked[blocked_slot(64)], d_indices, d_vals, d_X, d_sum_in,
                                           d_layer_a, d_layer_b, d_sum_out, d_y_row_wanted, stream);
+}
+
+int nrhip_spmm_csr_wanted_batch(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                const float* d_X, int d, const float* d_sum_in, const float* d_layer_a,
+                                const float* d_layer_b, float* d_sum_out, const int32_t* d_users,
+                                const int32_t* d_pos, const int32_t* d_neg, int batch, int n_users,
+                                uint8_t* d_row_flag, int32_t* d_rows_out, void* stream) {
+  NR_REQUIRE(plan, NR_ERR_ARG, "spmm_csr_wanted_batch: null plan");
+  const SpmmPlan* p = (const SpmmPlan*)plan;
+  NR_REQUIRE(d == 64 && p->blocked[blocked_slot(64)], NR_ERR_UNSUPPORTED,
+             "spmm_csr_wanted_batch: needs the d = 64 lane-group schedule");
+  return nrhip_spmm_blocked_wanted_batch(p->blocked[blocked_slot(64)], d_indices, d_vals, d_X, d_sum_in,
+                                         d_layer_a, d_layer_b, d_sum_out, d_users, d_pos, d_neg, batch,
+                                         n_users, d_row_flag, d_rows_out, stream);
 }
 
 int nrhip_spmm_plan_has_wanted(const void* plan, int d) {

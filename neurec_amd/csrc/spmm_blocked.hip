@@ -59,7 +59,7 @@ struct BlockedPlan {
   int4* w_cmb;           // {row, first partial slot, segments, 0}
   int32_t* w_ent_off;    // [n_wg][2]
   int32_t* w_cmb_off;    // [n_wg][2]
-  int wanted_ok, w_ent_cap, w_nnz_cap;
+  int wanted_ok, w_ent_cap, w_nnz_cap, w_bitmap_words;
 };
 
 size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
@@ -555,6 +555,13 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
   }
 }
 
+struct BatchLists {        // a step's triplets; rows = users | n_users + pos | n_users + neg
+  const int32_t* users; const int32_t* pos; const int32_t* neg;
+  int batch, n_users;
+  uint8_t* row_flag;       // out: 1 on the batch rows (must be zero elsewhere on entry)
+  int32_t* rows_out;       // out (optional): the 3*batch rows, list order users, pos, neg
+};
+
 // Row-masked hop (last forward hop: only the batch rows are produced).  A real batch always holds
 // the hub rows (positives are drawn in proportion to degree): ~45 % of all non-zeros belong to
 // wanted rows, and in the row-run schedule they sit in a few workgroups that then do a full
@@ -568,13 +575,14 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
     const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ row_mask, int kRMax,
-    int p_max, int ent_cap, int nnz_cap, LayerChain chain) {
+    int p_max, int ent_cap, int nnz_cap, LayerChain chain, BatchLists bl, int bitmap_words) {
   constexpr int RS = 16;
   extern __shared__ float4 s_mem[];
   float4* s_part = s_mem;                                          // [p_max][16]
   int4* s_now = (int4*)(s_mem + (size_t)p_max * RS);               // sub-lists of this chunk
   int4* s_later = s_now + ent_cap;                                 // sub-lists that did not fit
-  int2* s_iv = (int2*)(s_later + ent_cap);                         // [nnz_cap]
+  uint32_t* s_bits = (uint32_t*)(s_later + ent_cap);               // [bitmap_words] wanted rows (batch form)
+  int2* s_iv = (int2*)(s_bits + bitmap_words);                     // [nnz_cap]
   __shared__ int s_n_now, s_n_later, s_cursor;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -582,12 +590,32 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
   const int e0 = w_ent_off[2 * wg], ne = w_ent_off[2 * wg + 1] - e0;
   const int c0 = w_cmb_off[2 * wg], c1 = w_cmb_off[2 * wg + 1];
   if (tid == 0) { s_n_now = 0; s_n_later = 0; s_cursor = 0; }
+  const bool by_batch = bl.users != nullptr;                       // workgroup-uniform
+  if (by_batch) {
+    // the batch itself says which rows are wanted: every workgroup builds the bit set in LDS
+    // (no mark_batch launch before this kernel, no flag gather per descriptor); the workgroups
+    // share the work of publishing the flags / row list the later kernels of the step read
+    for (int i = tid; i < bitmap_words; i += 16 * NR_WAVE) s_bits[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < 3 * bl.batch; i += 16 * NR_WAVE) {
+      const int which = i / bl.batch, b = i - which * bl.batch;
+      const int row = which == 0 ? bl.users[b] : bl.n_users + (which == 1 ? bl.pos[b] : bl.neg[b]);
+      atomicOr(&s_bits[row >> 5], 1u << (row & 31));
+      if (i % (int)gridDim.x == wg) {
+        bl.row_flag[row] = 1;
+        if (bl.rows_out) bl.rows_out[i] = row;
+      }
+    }
+  }
   __syncthreads();
+  auto is_wanted = [&](int row) -> bool {
+    return by_batch ? ((s_bits[row >> 5] >> (row & 31)) & 1u) != 0u : row_mask[row] != 0;
+  };
   // wanted sub-lists of this workgroup, each with room reserved in the staging buffer (.x keeps
   // the slot, .z becomes the staging offset; the first non-zero moves to a register copy)
   for (int i = tid; i < ne; i += 16 * NR_WAVE) {
     const int4 e = w_ent[e0 + i];
-    if (row_mask[e.w] != 0) {
+    if (is_wanted(e.w)) {
       const int off = atomicAdd(&s_cursor, e.y);
       if (off + e.y <= nnz_cap) s_now[atomicAdd(&s_n_now, 1)] = make_int4(e.x, e.y | (off << 8), e.z, e.w);
       else s_later[atomicAdd(&s_n_later, 1)] = e;
@@ -633,7 +661,7 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
     __syncthreads();
     for (int ci = c0 + wave * 4 + g; ci < c1; ci += 64) {
       const int4 cm = w_cmb[ci];
-      if (row_mask[cm.x] == 0) continue;
+      if (!is_wanted(cm.x)) continue;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int sgm = 0; sgm < cm.z; ++sgm) {
         const float4 q = s_part[(size_t)(cm.y - kRMax + sgm) * RS + c];
@@ -646,7 +674,8 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
 }
 
 size_t wanted_lds_bytes(const BlockedPlan* p) {
-  return (size_t)p->p_max * 256 + 2 * (size_t)p->w_ent_cap * 16 + (size_t)p->w_nnz_cap * 8;
+  return (size_t)p->p_max * 256 + 2 * (size_t)p->w_ent_cap * 16 + (size_t)p->w_bitmap_words * 4 +
+         (size_t)p->w_nnz_cap * 8;
 }
 size_t colmask_lds_bytes(const BlockedPlan* p) {
   return (size_t)p->p_max * 256 + (size_t)p->ent_cap * 16 + (size_t)p->nnz_cap * 8;
@@ -867,6 +896,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   std::vector<int32_t> w_ent_off((size_t)n_wg * 2, 0), w_cmb_off((size_t)n_wg * 2, 0);
   p->w_ent_cap = 0;
   p->w_nnz_cap = 0;
+  p->w_bitmap_words = 0;
   if (p->wanted_ok) {
     std::vector<int32_t> order((size_t)n_rows);
     for (int64_t r = 0; r < n_rows; ++r) order[(size_t)r] = (int32_t)r;
@@ -902,7 +932,10 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     }
     p->w_ent_cap = (p->w_ent_cap + 15) / 16 * 16;
     // LDS: partial slots + two descriptor lists + whatever is left for staged (column, value) pairs
-    const int64_t left = (int64_t)kMaxLdsBytes - 256 - (int64_t)kPMax * 256 - 2 * (int64_t)p->w_ent_cap * 16;
+    // a bit per row for the batch form of the kernel, when the matrix is small enough to afford it
+    p->w_bitmap_words = n_rows <= 131072 ? (int)((n_rows + 127) / 128 * 4) : 0;
+    const int64_t left = (int64_t)kMaxLdsBytes - 256 - (int64_t)kPMax * 256 - 2 * (int64_t)p->w_ent_cap * 16 -
+                         (int64_t)p->w_bitmap_words * 4;
     p->w_nnz_cap = (int)std::min<int64_t>(left / 8, (int64_t)1 << 22);
     if (const char* cap = getenv("NEUREC_SPMM_WANTED_NNZ_CAP"))     // tests: force the chunked path
       p->w_nnz_cap = std::min(p->w_nnz_cap, std::max(atoi(cap), 4 * kSeg));
@@ -1019,7 +1052,7 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
                        p->w_cmb_off, p->w_ent, p->w_cmb, d_indices, d_vals, (const float4*)d_X,
                        (float4*)d_Y, (const float4*)d_addend, (const float4*)d_sum_in,
                        (float4*)d_sum_out, d_y_row_wanted, p->r_max, p->p_max, p->w_ent_cap,
-                       p->w_nnz_cap, LayerChain{nullptr, nullptr});
+                       p->w_nnz_cap, LayerChain{nullptr, nullptr}, BatchLists{}, p->w_bitmap_words);
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
@@ -1079,13 +1112,44 @@ int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t* d_indices,
                      p->w_cmb, d_indices, d_vals, (const float4*)d_X, (float4*)nullptr,
                      (const float4*)nullptr, (const float4*)d_sum_in, (float4*)d_sum_out,
                      d_y_row_wanted, p->r_max, p->p_max, p->w_ent_cap, p->w_nnz_cap,
-                     LayerChain{(const float4*)d_layer_a, (const float4*)d_layer_b});
+                     LayerChain{(const float4*)d_layer_a, (const float4*)d_layer_b}, BatchLists{},
+                     p->w_bitmap_words);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
 
-int nrhip_spmm_blocked_has_wanted(const void* plan) {
-  return plan && ((const BlockedPlan*)plan)->wanted_ok ? 1 : 0;
+/* The same hop told the batch instead of flags: wanted rows = d_users | n_users + d_pos |
+ * n_users + d_neg.  It also does nrhip_lightgcn_mark_batch's job on the way: d_row_flag (zero on
+ * entry) gets 1 on those rows, d_rows_out (optional) the 3*batch rows.  Needs
+ * nrhip_spmm_blocked_has_wanted(plan) == 2 (wanted-rows schedule and a matrix of <= 131072 rows). */
+int nrhip_spmm_blocked_wanted_batch(const void* plan, const int32_t* d_indices, const float* d_vals,
+                                    const float* d_X, const float* d_sum_in, const float* d_layer_a,
+                                    const float* d_layer_b, float* d_sum_out, const int32_t* d_users,
+                                    const int32_t* d_pos, const int32_t* d_neg, int batch, int n_users,
+                                    uint8_t* d_row_flag, int32_t* d_rows_out, void* stream) {
+  NR_REQUIRE(plan && d_indices && d_vals && d_X && d_sum_in && d_sum_out && d_users && d_pos && d_neg &&
+                 d_row_flag && batch >= 0 && n_users >= 0,
+             NR_ERR_ARG, "spmm_blocked_wanted_batch: bad arguments");
+  NR_REQUIRE(d_layer_a || !d_layer_b, NR_ERR_ARG, "spmm_blocked_wanted_batch: layer_b without layer_a");
+  const BlockedPlan* p = (const BlockedPlan*)plan;
+  NR_REQUIRE(p->wanted_ok && p->w_bitmap_words > 0, NR_ERR_UNSUPPORTED,
+             "spmm_blocked_wanted_batch: no wanted-rows schedule with a row bit set");
+  if (batch == 0) return NR_OK;
+  hipLaunchKernelGGL(spmm_wanted_rows_kernel, dim3((unsigned)p->n_wg), dim3(p->waves * NR_WAVE),
+                     wanted_lds_bytes(p), (hipStream_t)stream, p->w_ent_off, p->w_cmb_off, p->w_ent,
+                     p->w_cmb, d_indices, d_vals, (const float4*)d_X, (float4*)nullptr,
+                     (const float4*)nullptr, (const float4*)d_sum_in, (float4*)d_sum_out,
+                     (const uint8_t*)nullptr, p->r_max, p->p_max, p->w_ent_cap, p->w_nnz_cap,
+                     LayerChain{(const float4*)d_layer_a, (const float4*)d_layer_b},
+                     BatchLists{d_users, d_pos, d_neg, batch, n_users, d_row_flag, d_rows_out},
+                     p->w_bitmap_words);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_spmm_blocked_has_wanted(const void* plan) {      // 0 no, 1 flag form, 2 flag and batch forms
+  if (!plan || !((const BlockedPlan*)plan)->wanted_ok) return 0;
+  return ((const BlockedPlan*)plan)->w_bitmap_words > 0 ? 2 : 1;
 }
 
 /* Y is not stored: the rows' results (plus d_addend) are consumed as the dense gradient

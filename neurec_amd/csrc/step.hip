@@ -34,6 +34,13 @@ extern "C" int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, c
                                    uint8_t* d_row_flag, void* stream);
 extern "C" int nrhip_spmm_plan_has_blocked(const void* plan, int d);
 extern "C" int nrhip_spmm_plan_has_wanted(const void* plan, int d);
+extern "C" int nrhip_spmm_csr_wanted_batch(const void* plan, const int32_t* d_indices,
+                                           const float* d_vals, const float* d_X, int d,
+                                           const float* d_sum_in, const float* d_layer_a,
+                                           const float* d_layer_b, float* d_sum_out,
+                                           const int32_t* d_users, const int32_t* d_pos,
+                                           const int32_t* d_neg, int batch, int n_users,
+                                           uint8_t* d_row_flag, int32_t* d_rows_out, void* stream);
 extern "C" int nrhip_spmm_csr_wanted_layers(const void* plan, const int32_t* d_indices,
                                             const float* d_vals, const float* d_X, int d,
                                             const float* d_sum_in, const float* d_layer_a,
@@ -76,8 +83,12 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
                             bool* rearmed = nullptr) {
   const int L = b.n_layers, d = b.d;
   const bool skip = d >= 64;                 // the work-skipping variants exist for d >= 64
-  NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, b.n_users, b.batch_rows,
-                                   b.row_flag, stream));
+  // 0: no wanted-rows schedule; 1: it takes row flags; 2: it takes the batch itself and publishes
+  // the flags / row list on the way (no mark_batch launch)
+  const int wanted_form = (skip && L > 0) ? nrhip_spmm_plan_has_wanted(b.plan, d) : 0;
+  if (wanted_form != 2)
+    NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, b.n_users, b.batch_rows,
+                                     b.row_flag, stream));
   // forward: L-1 full hops, the last one only on the batch rows
   const float* esum = b.E0;
   if (L > 0) {
@@ -87,7 +98,7 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
     // With the wanted-rows schedule the last hop completes the layer sum itself from the last two
     // layers (they are still in the ping-pong buffers), so only hops before those keep the running
     // sum: at L = 3 none does — four 18 MB streams less per step, same additions in the same order.
-    const bool chain = skip && nrhip_spmm_plan_has_wanted(b.plan, d);
+    const bool chain = wanted_form != 0;
     const float* layer[2] = {nullptr, nullptr};     // outputs of the last two full hops, oldest first
     for (int k = 0; k < L - 1; ++k) {
       const bool keep_sum = !chain || k < L - 3;
@@ -101,8 +112,13 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
     }
     if (chain) {
       if (L - 1 == 1) { layer[0] = layer[1]; layer[1] = nullptr; }
-      NR_TRY(nrhip_spmm_csr_wanted_layers(b.plan, b.indices, b.vals, src, d, acc_in, layer[0], layer[1],
-                                          b.Esum_rows, b.row_flag, stream));
+      if (wanted_form == 2)
+        NR_TRY(nrhip_spmm_csr_wanted_batch(b.plan, b.indices, b.vals, src, d, acc_in, layer[0], layer[1],
+                                           b.Esum_rows, d_users, d_pos, d_neg, batch, b.n_users,
+                                           b.row_flag, b.batch_rows, stream));
+      else
+        NR_TRY(nrhip_spmm_csr_wanted_layers(b.plan, b.indices, b.vals, src, d, acc_in, layer[0], layer[1],
+                                            b.Esum_rows, b.row_flag, stream));
     } else if (skip)
       NR_TRY(nrhip_spmm_csr_masked(b.plan, b.indptr, b.indices, b.vals, src, nullptr, b.row_flag,
                                    d, nullptr, nullptr, acc_in, b.Esum_rows, b.spmm_ws,

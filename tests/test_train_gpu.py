@@ -489,7 +489,7 @@ def test_spmm_wanted_rows_kernel(eng, monkeypatch, nnz_cap):
     from neurec_amd._lib import call, lib
     monkeypatch.setenv("NEUREC_SPMM_MASKED_FAST", "1")
     csr = eng.SpmmCSR.from_scipy(A, split_row=U)
-    assert csr.ensure_schedule(d) and lib.nrhip_spmm_plan_has_wanted(csr.plan, d) == 1
+    assert csr.ensure_schedule(d) and lib.nrhip_spmm_plan_has_wanted(csr.plan, d) == 2
     la, lb = rng.randn(N, d).astype(np.float32), rng.randn(N, d).astype(np.float32)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     Xd, wd, accd, lad, lbd = _dev(X), _dev(wanted), _dev(acc), _dev(la), _dev(lb)
@@ -501,3 +501,25 @@ def test_spmm_wanted_rows_kernel(eng, monkeypatch, nnz_cap):
         got = out.cpu().numpy()
         np.testing.assert_array_equal(got[w], ref[w])
         assert np.all(got[~w] == 7.0)
+    # batch form: the triplets instead of flags; it publishes the flags and the row list itself
+    B = 300
+    bu, bp, bn = (rng.randint(0, U, B).astype(np.int32), rng.randint(0, I, B).astype(np.int32),
+                  rng.randint(0, I, B).astype(np.int32))
+    bp[:3] = [0, 1, 2]                                            # the hub items
+    rows_ref = np.concatenate([bu, U + bp, U + bn])
+    wb = np.zeros(N, bool); wb[rows_ref] = True
+    yb = torch.full((N, d), 7.0, device="cuda")
+    csr.matmul(Xd, out=yb, y_row_wanted=_dev(wb.astype(np.uint8)))
+    ref = ((acc + la) + lb) + yb.cpu().numpy()
+    out = torch.full((N, d), 7.0, device="cuda")
+    flags = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    rows_out = torch.full((3 * B,), -1, dtype=torch.int32, device="cuda")
+    bud, bpd, bnd = _dev(bu), _dev(bp), _dev(bn)                 # keep them alive across the call
+    call("nrhip_spmm_csr_wanted_batch", csr.plan, ptr(csr.indices), ptr(csr.vals), ptr(Xd), d, ptr(accd),
+         ptr(lad), ptr(lbd), ptr(out), ptr(bud), ptr(bpd), ptr(bnd), B, U, ptr(flags),
+         ptr(rows_out), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[wb], ref[wb])
+    assert np.all(got[~wb] == 7.0)
+    np.testing.assert_array_equal(flags.cpu().numpy().astype(bool), wb)
+    np.testing.assert_array_equal(rows_out.cpu().numpy(), rows_ref)
