@@ -493,3 +493,38 @@ extern "C" int nrhip_exp_halfline(const int32_t* d_ids, int64_t n, int per_wave,
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
+
+// What the fp32 matrix pipe sustains when nothing else happens: `iters` rounds of 128 independent-
+// enough v_mfma_f32_32x32x2_f32 (4 accumulators, operands in registers) per wave.
+namespace {
+typedef float exp_f32x16 __attribute__((ext_vector_type(16)));
+template <int WPS>
+__global__ __launch_bounds__(256 * WPS, 1) void exp_mfma_peak_kernel(float* out, int iters, float seed) {
+  float a[32], b[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) { a[s] = seed + threadIdx.x * 0.001f + s; b[s] = seed - s; }
+  exp_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], a[s], c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], b[s], c3, 0, 0, 0);
+    }
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += c0[i] + c1[i] + c2[i] + c3[i];
+  if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_mfma_peak(int blocks, int waves_per_simd, int iters, float* d_out, void* stream) {
+  if (waves_per_simd == 2)
+    hipLaunchKernelGGL(exp_mfma_peak_kernel<2>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, d_out, iters, 1.0f);
+  else
+    hipLaunchKernelGGL(exp_mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, iters, 1.0f);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}

@@ -50,6 +50,25 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(
   }
 }
 
+// Operand-ordered copy of the k-major item table for the MFMA loops: QS[tile][x][s4][lane] (float4)
+// holds, for lane = 32·h + j, the four B values QT[2·(4·s4 + e) + h][64·tile + 32·x + j], e = 0..3 —
+// exactly what that lane feeds to four consecutive k-steps.  One coalesced 1 KB load per (x, s4).
+__global__ __launch_bounds__(256) void swizzle_items_kernel(const float* __restrict__ QT, int ipad,
+                                                            int ks, float4* __restrict__ QS,
+                                                            int64_t n_vec) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= n_vec) return;
+  const int lane = (int)(v & 63);
+  const int64_t r = v >> 6;
+  const int s4 = (int)(r % (ks / 4));
+  const int64_t r2 = r / (ks / 4);
+  const int x = (int)(r2 & 1);
+  const int64_t t = r2 >> 1;
+  const int j = lane & 31, h = lane >> 5;
+  const float* q = QT + (int64_t)(8 * s4 + h) * ipad + t * 64 + x * 32 + j;
+  QS[v] = make_float4(q[0], q[(int64_t)2 * ipad], q[(int64_t)4 * ipad], q[(int64_t)6 * ipad]);
+}
+
 template <int KS>
 __global__ __launch_bounds__(256, 1) void score_gemm_kernel(
     const float* __restrict__ PT, int bpad, const float* __restrict__ QT, int ipad, int rows,
@@ -73,12 +92,18 @@ __global__ __launch_bounds__(256, 1) void score_gemm_kernel(
   // matrix pipe does not wait on L2 at every tile boundary (two register sets, tile loop unrolled
   // by two)
   float bA0[KS], bA1[KS], bB0[KS], bB1[KS];
+  // B operands of a tile from the operand-ordered item copy (swizzle_items_kernel): 16-byte loads,
+  // 2·KS/4 per tile instead of 2·KS.  Not a bandwidth matter: with 64 loads per tile and the next
+  // tile's loads in flight, the first MFMA of a tile would have to wait with vmcnt(> 63) — the
+  // counter has 6 bits, so it waited for the newest loads too and every tile stalled a memory
+  // round trip (60 % of the MFMA peak; the ISA showed `s_waitcnt vmcnt(62)` before the first MFMA).
   auto load_b = [&](int t, float (&x0)[KS], float (&x1)[KS]) {
-    const float* q = QT + (int64_t)h * ipad + t * 64 + j;
+    const float4* q = reinterpret_cast<const float4*>(QT) + (int64_t)t * (2 * (KS / 4) * 64) + lane;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      x0[s] = q[(int64_t)(2 * s) * ipad];
-      x1[s] = q[(int64_t)(2 * s) * ipad + 32];
+    for (int s4 = 0; s4 < KS / 4; ++s4) {
+      const float4 v = q[s4 * 64], w = q[(KS / 4 + s4) * 64];
+      x0[4 * s4] = v.x; x0[4 * s4 + 1] = v.y; x0[4 * s4 + 2] = v.z; x0[4 * s4 + 3] = v.w;
+      x1[4 * s4] = w.x; x1[4 * s4 + 1] = w.y; x1[4 * s4 + 2] = w.z; x1[4 * s4 + 3] = w.w;
     }
   };
   auto tile = [&](int t, const float (&x0)[KS], const float (&x1)[KS]) {
@@ -108,12 +133,15 @@ __global__ __launch_bounds__(256, 1) void score_gemm_kernel(
     }
   };
   if (t_begin >= t_end) return;
+  // the loads of the tile after next are issued unconditionally (clamped to the chunk's last tile):
+  // a load behind a branch cannot be counted, and `s_waitcnt vmcnt(0)` before the MFMAs would wait
+  // for the tile just requested
   load_b(t_begin, bA0, bA1);
   for (int t = t_begin; t < t_end; t += 2) {
-    if (t + 1 < t_end) load_b(t + 1, bB0, bB1);
+    load_b(min(t + 1, t_end - 1), bB0, bB1);
     tile(t, bA0, bA1);
     if (t + 1 < t_end) {
-      if (t + 2 < t_end) load_b(t + 2, bA0, bA1);
+      load_b(min(t + 2, t_end - 1), bA0, bA1);
       tile(t + 1, bB0, bB1);
     }
   }
@@ -128,15 +156,14 @@ __global__ __launch_bounds__(256, 1) void score_gemm_kernel(
 // M[user][tile] = max over the admissible items of 32-item tile `tile` (one MFMA row block),
 // 4·2·⌈I/64⌉ bytes per user instead of 4·I.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void strike(f32x16& c, int reg) {
+// maximum of the 16 accumulator values whose bit in `struck` is clear.  The struck positions are
+// collected as bits (one or per strike) and applied inside the reduction: writing -inf into a
+// run-time-indexed accumulator register costs a 16-way select per strike plus the AGPR round trip
+// (the epilogue was ~800 instructions per tile against 128 MFMAs, a third of the kernel's time).
+__device__ __forceinline__ float max16_except(const f32x16& c, uint32_t struck) {
+  float m = -INFINITY;
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (r == reg) c[r] = -INFINITY;
-}
-__device__ __forceinline__ float max16(const f32x16& c) {
-  float m = c[0];
-#pragma unroll
-  for (int r = 1; r < 16; ++r) m = fmaxf(m, c[r]);
+  for (int r = 0; r < 16; ++r) m = fmaxf(m, (struck >> r) & 1u ? -INFINITY : c[r]);
   return m;
 }
 
@@ -174,14 +201,25 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
   pb = lower(pb, eb, t_begin * 64);
   int na = pa < ea ? tr_indices[pa] : INT_MAX;                // next train item of each user
   int nb = pb < eb ? tr_indices[pb] : INT_MAX;
+  // ... and the one after it, requested a strike ahead: 94 % of the tiles hold a train item of one
+  // of the wave's 64 users, and a cursor that loads its next item when it needs it puts a memory
+  // round trip (1.5 us against 3.4 us of MFMAs) into every tile
+  int na2 = pa + 1 < ea ? tr_indices[pa + 1] : INT_MAX;
+  int nb2 = pb + 1 < eb ? tr_indices[pb + 1] : INT_MAX;
 
   float bA0[KS], bA1[KS], bB0[KS], bB1[KS];             // two B register sets (see score_gemm_kernel)
+  // B operands of a tile from the operand-ordered item copy (swizzle_items_kernel): 16-byte loads,
+  // 2·KS/4 per tile instead of 2·KS.  Not a bandwidth matter: with 64 loads per tile and the next
+  // tile's loads in flight, the first MFMA of a tile would have to wait with vmcnt(> 63) — the
+  // counter has 6 bits, so it waited for the newest loads too and every tile stalled a memory
+  // round trip (60 % of the MFMA peak; the ISA showed `s_waitcnt vmcnt(62)` before the first MFMA).
   auto load_b = [&](int t, float (&x0)[KS], float (&x1)[KS]) {
-    const float* q = QT + (int64_t)h * ipad + t * 64 + j;
+    const float4* q = reinterpret_cast<const float4*>(QT) + (int64_t)t * (2 * (KS / 4) * 64) + lane;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      x0[s] = q[(int64_t)(2 * s) * ipad];
-      x1[s] = q[(int64_t)(2 * s) * ipad + 32];
+    for (int s4 = 0; s4 < KS / 4; ++s4) {
+      const float4 v = q[s4 * 64], w = q[(KS / 4 + s4) * 64];
+      x0[4 * s4] = v.x; x0[4 * s4 + 1] = v.y; x0[4 * s4 + 2] = v.z; x0[4 * s4 + 3] = v.w;
+      x1[4 * s4] = w.x; x1[4 * s4 + 1] = w.y; x1[4 * s4 + 2] = w.z; x1[4 * s4 + 3] = w.w;
     }
   };
   auto tile = [&](int t, const float (&x0)[KS], const float (&x1)[KS]) {
@@ -195,29 +233,32 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
       c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[s], a1[s], c11, 0, 0, 0);
     }
     // rows of the 32x32 result held by this lane: item = it + 32*X + (reg&3) + 8*(reg>>2) + 4*h
-    if (__ballot(na < it + 64 || nb < it + 64)) {            // rare: a train item falls in the tile
+    // struck accumulator registers of user a / b: bits 0-15 item block 0, bits 16-31 item block 1
+    uint32_t ka = 0u, kb = 0u;
+    if (__ballot(na < it + 64 || nb < it + 64)) {            // a train item of some user falls in the tile
       while (na < it + 64) {
         const int o = na - it, row = o & 31;
-        if (((row >> 2) & 1) == h) { const int reg = (row & 3) + 4 * (row >> 3); if (o < 32) strike(c00, reg); else strike(c10, reg); }
-        ++pa; na = pa < ea ? tr_indices[pa] : INT_MAX;
+        if (((row >> 2) & 1) == h) ka |= 1u << ((row & 3) + 4 * (row >> 3) + (o < 32 ? 0 : 16));
+        ++pa; na = na2; na2 = pa + 1 < ea ? tr_indices[pa + 1] : INT_MAX;
       }
       while (nb < it + 64) {
         const int o = nb - it, row = o & 31;
-        if (((row >> 2) & 1) == h) { const int reg = (row & 3) + 4 * (row >> 3); if (o < 32) strike(c01, reg); else strike(c11, reg); }
-        ++pb; nb = pb < eb ? tr_indices[pb] : INT_MAX;
+        if (((row >> 2) & 1) == h) kb |= 1u << ((row & 3) + 4 * (row >> 3) + (o < 32 ? 0 : 16));
+        ++pb; nb = nb2; nb2 = pb + 1 < eb ? tr_indices[pb + 1] : INT_MAX;
       }
     }
     if (it + 64 > cols) {                                     // last tile: pad columns
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (it + rr >= cols) { c00[reg] = -INFINITY; c01[reg] = -INFINITY; }
-        if (it + 32 + rr >= cols) { c10[reg] = -INFINITY; c11[reg] = -INFINITY; }
+        if (it + rr >= cols) { ka |= 1u << reg; kb |= 1u << reg; }
+        if (it + 32 + rr >= cols) { ka |= 1u << (16 + reg); kb |= 1u << (16 + reg); }
       }
     }
     // one maximum per 32-item half tile (= one MFMA row block): the two lane halves hold
     // different rows of the same block
-    float ma0 = max16(c00), ma1 = max16(c10), mb0 = max16(c01), mb1 = max16(c11);
+    float ma0 = max16_except(c00, ka & 0xFFFFu), ma1 = max16_except(c10, ka >> 16);
+    float mb0 = max16_except(c01, kb & 0xFFFFu), mb1 = max16_except(c11, kb >> 16);
     ma0 = fmaxf(ma0, __shfl_xor(ma0, 32, 64)); ma1 = fmaxf(ma1, __shfl_xor(ma1, 32, 64));
     mb0 = fmaxf(mb0, __shfl_xor(mb0, 32, 64)); mb1 = fmaxf(mb1, __shfl_xor(mb1, 32, 64));
     if (h == 0) {
@@ -226,12 +267,15 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
     }
   };
   if (t_begin >= t_end) return;
+  // the loads of the tile after next are issued unconditionally (clamped to the chunk's last tile):
+  // a load behind a branch cannot be counted, and `s_waitcnt vmcnt(0)` before the MFMAs would wait
+  // for the tile just requested
   load_b(t_begin, bA0, bA1);
   for (int t = t_begin; t < t_end; t += 2) {
-    if (t + 1 < t_end) load_b(t + 1, bB0, bB1);
+    load_b(min(t + 1, t_end - 1), bB0, bB1);
     tile(t, bA0, bA1);
     if (t + 1 < t_end) {
-      if (t + 2 < t_end) load_b(t + 2, bA0, bA1);
+      load_b(min(t + 2, t_end - 1), bA0, bA1);
       tile(t + 1, bB0, bB1);
     }
   }
@@ -246,15 +290,18 @@ int padded_dim(int d) {
 inline int round_up64(int x) { return (x + 63) / 64 * 64; }
 
 struct GemmWs {
-  float* QT;
+  float* QT;     // k-major item copy (rescoring reads it)
+  float* QS;     // operand-ordered item copy (the MFMA loops read it), same size
   float* PT;
-  size_t qt_bytes, pt_bytes;
+  size_t qt_bytes, pt_bytes;   // qt_bytes covers both item copies
 };
 GemmWs carve(void* ws, int rows, int cols, int dp) {
   GemmWs g;
-  g.qt_bytes = nr_align_up((size_t)dp * round_up64(cols) * sizeof(float), 256);
+  const size_t one = nr_align_up((size_t)dp * round_up64(cols) * sizeof(float), 256);
+  g.qt_bytes = 2 * one;
   g.pt_bytes = nr_align_up((size_t)dp * round_up64(rows > 0 ? rows : 1) * sizeof(float), 256);
   g.QT = (float*)ws;
+  g.QS = (float*)((char*)ws + one);
   g.PT = (float*)((char*)ws + g.qt_bytes);
   return g;
 }
@@ -286,6 +333,10 @@ int nrhip_score_gemm_prepare_items(const float* d_Q, int64_t ldq, int cols, int 
                      (hipStream_t)stream, d_Q, ldq, (const int32_t*)nullptr, cols, d, g.QT, ipad,
                      dp);
   NR_LAUNCH_CHECK();
+  const int64_t n_vec = (int64_t)(ipad / 64) * 2 * (dp / 8) * 64;      // ks = dp / 2 k-pairs per operand
+  hipLaunchKernelGGL(swizzle_items_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, g.QT, ipad, dp / 2, (float4*)g.QS, n_vec);
+  NR_LAUNCH_CHECK();
   return NR_OK;
 }
 
@@ -314,7 +365,7 @@ int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int 
   const int by = (n_tiles + tpc - 1) / tpc;
   dim3 grid(bx, by), block(256);
 #define NR_GEMM_CASE(KS)                                                                    \
-  hipLaunchKernelGGL(score_gemm_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QT, ipad, rows, \
+  hipLaunchKernelGGL(score_gemm_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QS, ipad, rows, \
                      d_S, lds, wcols, tpc)
   switch (dp) {
     case 16: NR_GEMM_CASE(8); break;
@@ -369,7 +420,7 @@ int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, i
   const int by = (n_tiles + tpc - 1) / tpc;
   dim3 grid(bx, by), block(256);
 #define NR_TMAX_CASE(KS)                                                                       \
-  hipLaunchKernelGGL(score_tilemax_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QT, ipad, rows, \
+  hipLaunchKernelGGL(score_tilemax_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QS, ipad, rows, \
                      cols, d_users, d_tr_indptr, d_tr_indices, d_M, mld, tpc)
   switch (dp) {
     case 16: NR_TMAX_CASE(8); break;

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Matrix-pipe utilisation of the evaluation scoring kernel: SQ counters per launch (separate passes).
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out/pmc_mfma
+mkdir -p "$OUT"
+i=0
+while read -r group; do
+  [ -z "$group" ] && continue
+  i=$((i+1))
+  ( cd /tmp && timeout 200 rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OLDPWD/$OUT/g$i" -o b -- python "$OLDPWD/bench.py" --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-mf > /dev/null 2> "$OLDPWD/$OUT/g$i.err" )
+  f=$(find "$OUT/g$i" -name "*counter_collection.csv" | head -1)
+  echo "== $group"
+  if [ -n "$f" ]; then python - "$f" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+with open(sys.argv[1]) as fh:
+    for row in csv.DictReader(fh):
+        if "score_tilemax" not in row.get("Kernel_Name", ""):
+            continue
+        k = row.get("Counter_Name", "")
+        agg[k][0] += 1
+        agg[k][1] += float(row.get("Counter_Value", 0) or 0)
+for k, (n, v) in sorted(agg.items()):
+    print("   %-40s launches=%3d  avg/launch=%.5g" % (k, n, v / n))
+PY
+  else tail -3 "$OUT/g$i.err"; fi
+  rm -rf "$OUT/g$i"
+done <<'GROUPS'
+SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU
+SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
+SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+GROUPS
