@@ -252,14 +252,18 @@ __global__ __launch_bounds__(256) void mark_batch_kernel(const int32_t* __restri
 }
 
 unsigned* next_done_counter() {
-  static unsigned* base = nullptr;
+  static std::atomic<unsigned*> base[64];          // the symbol has one address per device
   static std::atomic<unsigned> next{0};
-  if (!base) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  unsigned* b = base[dev].load(std::memory_order_acquire);
+  if (!b) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_done_pool)) != hipSuccess) return nullptr;
-    base = (unsigned*)p;
+    b = (unsigned*)p;
+    base[dev].store(b, std::memory_order_release);
   }
-  return base + (next.fetch_add(1) & 63u);
+  return b + (next.fetch_add(1) & 63u);
 }
 
 }  // namespace

@@ -989,7 +989,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   allow((const void*)spmm_blocked_kernel<false, 16, 4, DD>); allow((const void*)spmm_blocked_kernel<true, 16, 4, DD>); \
   allow((const void*)spmm_blocked_kernel<false, 8, 8, DD>); allow((const void*)spmm_blocked_kernel<true, 8, 8, DD>);   \
   allow((const void*)spmm_blocked_kernel<false, 8, 4, DD>); allow((const void*)spmm_blocked_kernel<true, 8, 4, DD>)
-  if (d == 16) { NR_ALLOW(16); } else if (d == 32) { NR_ALLOW(32); } else if (d == 64) { NR_ALLOW(64); }
+  if (d == 16) { NR_ALLOW(16); } else if (d == 32) { NR_ALLOW(32); }
+  else if (d == 64) { NR_ALLOW(64); allow((const void*)spmm_blocked_kernel<false, 16, 8, 64, true>); }
   else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
 #undef NR_ALLOW
   if (p->wanted_ok && e == hipSuccess)
@@ -1166,13 +1167,7 @@ int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const fl
   NR_REQUIRE(p->d == 64 && p->waves == 16, NR_ERR_UNSUPPORTED,
              "spmm_blocked_adam: built for d = 64 schedules with 16 waves");
   NR_REQUIRE(d_X != d_var, NR_ERR_ARG, "spmm_blocked_adam: the operand must not be the updated table");
-  static bool s_allowed = false;
-  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
-  if (!s_allowed) {
-    NR_CHECK_HIP(hipFuncSetAttribute((const void*)spmm_blocked_kernel<false, 16, 8, 64, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-    s_allowed = true;
-  }
+  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;   // allowed at plan creation
   NR_REQUIRE(!clear_consumed || d_addend, NR_ERR_ARG, "spmm_blocked_adam: clear_consumed needs an addend");
   AdamEpilogue ad{(float4*)d_var, (float4*)d_m, (float4*)d_v, (const float4*)d_grad_b,
                   alpha, 1.0f - beta1, 1.0f - beta2, eps,
