@@ -227,7 +227,11 @@ __global__ __launch_bounds__(256) void vae_softmax_grad_kernel(
 
 // ----------------------------------------------------------------------------
 // dW_p1[i][:] = Σ_b dlogits[b][i]·g1[b][:],  db_p1[i] = Σ_b dlogits[b][i].
-// Thread per item i (coalesced across i for every b), g1 staged in LDS.
+// A block = 64 items x 4 waves; wave q takes every 4th group of 64 batch rows of the staged slab
+// (the lanes of a wave read 64 consecutive items of a row: one 256-byte load), 16 loads in flight
+// per lane, and the four partial sums meet in LDS.  The first version gave an item to a thread
+// for all batch rows: 640 waves on 1,024 SIMDs, each a chain of batch/8 memory round trips (1.5 us
+// each on this part) — 89 us for 84 MB.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__ dlogits,
                                                        int64_t ld, int batch, int cols, int h,
@@ -235,8 +239,11 @@ __global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__
                                                        float* __restrict__ dWp1,
                                                        float* __restrict__ dbp1) {
   constexpr int kSlab = 256;                                       // batch rows staged per round
-  __shared__ __attribute__((aligned(16))) float s_g1[kSlab * kMaxD];
-  const int item = blockIdx.x * 256 + threadIdx.x;
+  constexpr int kInFlight = 16;
+  __shared__ __attribute__((aligned(16))) float s_g1[kSlab * kMaxD];   // 32 KB; reused for the reduction
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int item = blockIdx.x * 64 + lane;
+  const int item_c = min(item, cols - 1);                          // idle lanes read a valid column
   float acc[kMaxD];
 #pragma unroll
   for (int j = 0; j < kMaxD; ++j) acc[j] = 0.f;
@@ -245,100 +252,147 @@ __global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__
     const int nb = min(kSlab, batch - b0);
     __syncthreads();
     // g1 rows staged zero-padded to kMaxD columns: the inner product below needs no h predicate
-    for (int i = threadIdx.x; i < nb * kMaxD; i += 256) {
+    for (int i = threadIdx.x; i < kSlab * kMaxD; i += 256) {
       const int bb = i / kMaxD, j = i % kMaxD;
-      s_g1[i] = j < h ? G1[(int64_t)(b0 + bb) * h + j] : 0.f;
+      s_g1[i] = (bb < nb && j < h) ? G1[(int64_t)(b0 + bb) * h + j] : 0.f;
     }
     __syncthreads();
-    if (item < cols) {
-      for (int bb = 0; bb < nb; bb += 8) {        // 8 independent loads in flight per thread
-        float g[8];
+    for (int bb = q * 64; bb < nb; bb += 4 * 64) {                 // this wave's 64-row groups
+      for (int u0 = 0; u0 < 64; u0 += kInFlight) {
+        float g[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          g[u] = (bb + u < nb) ? dlogits[(int64_t)(b0 + bb + u) * ld + item] : 0.f;
+        for (int u = 0; u < kInFlight; ++u)                        // rows past the slab: row 0, weight 0 (zero g1)
+          g[u] = dlogits[(int64_t)(b0 + min(bb + u0 + u, nb - 1)) * ld + item_c];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          bsum += g[u];
-          const float4* gr = reinterpret_cast<const float4*>(s_g1 + min(bb + u, nb - 1) * kMaxD);
+        for (int u = 0; u < kInFlight; ++u) {
+          const bool in = bb + u0 + u < nb;
+          const float gv = in ? g[u] : 0.f;
+          bsum += gv;
+          const float4* gr = reinterpret_cast<const float4*>(s_g1 + min(bb + u0 + u, nb - 1) * kMaxD);
 #pragma unroll
           for (int j4 = 0; j4 < kMaxD / 4; ++j4) {
             const float4 w = gr[j4];               // wave-uniform address: LDS broadcast
-            acc[4 * j4] = fmaf(g[u], w.x, acc[4 * j4]);
-            acc[4 * j4 + 1] = fmaf(g[u], w.y, acc[4 * j4 + 1]);
-            acc[4 * j4 + 2] = fmaf(g[u], w.z, acc[4 * j4 + 2]);
-            acc[4 * j4 + 3] = fmaf(g[u], w.w, acc[4 * j4 + 3]);
+            acc[4 * j4] = fmaf(gv, w.x, acc[4 * j4]);
+            acc[4 * j4 + 1] = fmaf(gv, w.y, acc[4 * j4 + 1]);
+            acc[4 * j4 + 2] = fmaf(gv, w.z, acc[4 * j4 + 2]);
+            acc[4 * j4 + 3] = fmaf(gv, w.w, acc[4 * j4 + 3]);
           }
         }
       }
     }
   }
-  if (item >= cols) return;
+  // waves 1..3 hand their partial sums to wave 0 through LDS ([3][33][64], lane-contiguous)
+  __syncthreads();
+  float* s_red = s_g1;
+  if (q > 0) {
+#pragma unroll
+    for (int j = 0; j < kMaxD; ++j) s_red[((q - 1) * (kMaxD + 1) + j) * 64 + lane] = acc[j];
+    s_red[((q - 1) * (kMaxD + 1) + kMaxD) * 64 + lane] = bsum;
+  }
+  __syncthreads();
+  if (q != 0 || item >= cols) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+#pragma unroll
+    for (int j = 0; j < kMaxD; ++j) acc[j] += s_red[(w * (kMaxD + 1) + j) * 64 + lane];
+    bsum += s_red[(w * (kMaxD + 1) + kMaxD) * 64 + lane];
+  }
 #pragma unroll
   for (int j = 0; j < kMaxD; ++j)
     if (j < h) dWp1[(int64_t)item * h + j] = acc[j];
   dbp1[item] = bsum;
 }
 
-// dg1[b][:] = Σ_i dlogits[b][i]·W_p1[i][:]  — two batch rows per block of 8 waves.  A wave takes
-// every 8th 64-item chunk: the two rows' dlogits of the chunk are one coalesced load each, a lane
-// owns a column quad (q = lane & 7 -> columns 4q..4q+3) of item (lane >> 3) of each 8-item step,
-// so a 16-byte load per lane brings eight W_p1 rows per instruction.
+// dg1[b][:] = Σ_i dlogits[b][i]·W_p1[i][:].  A block of 8 waves takes kDg1Rows batch rows against
+// one of kDg1Split item ranges: W_p1 is then streamed batch/16 times instead of batch/2 times (the
+// first version: 1.3 GB through the L2s, 189 us).  A wave takes every 8th 64-item chunk of the
+// range: each row's dlogits of the chunk are one coalesced load, a lane owns a column quad
+// (q = lane & 7 -> columns 4q..4q+3) of item (lane >> 3) of each 8-item step, so a 16-byte load per
+// lane brings eight W_p1 rows per instruction.  Partial sums per item range go to the workspace and
+// are added in range order by vae_dg1_reduce_kernel (deterministic).
 constexpr int kDg1Waves = 8;
+constexpr int kDg1Rows = 16;
+constexpr int kDg1Split = 8;
 __global__ __launch_bounds__(kDg1Waves* NR_WAVE) void vae_dg1_kernel(
     const float* __restrict__ dlogits, int64_t ld, int batch, int cols, int h,
-    const float* __restrict__ Wp1, float* __restrict__ dG1) {
-  __shared__ float s_red[kDg1Waves][2][kMaxD];
+    const float* __restrict__ Wp1, float* __restrict__ part) {
+  __shared__ float s_red[kDg1Waves][kDg1Rows][kMaxD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = lane & 7, t = lane >> 3;
-  const int r0 = blockIdx.x * 2, r1 = min(r0 + 1, batch - 1);
+  const int r0 = blockIdx.x * kDg1Rows;
+  const int chunks = (cols + NR_WAVE - 1) / NR_WAVE;
+  const int per = (chunks + kDg1Split - 1) / kDg1Split;
+  const int ch0 = blockIdx.y * per, ch1 = min(chunks, ch0 + per);
   const int hq = (h + 3) / 4;                      // column quads in use (h <= 32 -> <= 8)
-  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-  for (int c0 = wave * NR_WAVE; c0 < cols; c0 += kDg1Waves * NR_WAVE) {
+  float4 a[kDg1Rows];
+#pragma unroll
+  for (int r = 0; r < kDg1Rows; ++r) a[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ch = ch0 + wave; ch < ch1; ch += kDg1Waves) {
+    const int c0 = ch * NR_WAVE;
     const int nn = min(NR_WAVE, cols - c0);
-    float d0 = 0.f, d1 = 0.f;
-    if (lane < nn) {
-      d0 = dlogits[(int64_t)r0 * ld + c0 + lane];
-      d1 = dlogits[(int64_t)r1 * ld + c0 + lane];
+    float dv[kDg1Rows];
+#pragma unroll
+    for (int r = 0; r < kDg1Rows; ++r)            // unconditional loads (clamped), zeroed afterwards
+      dv[r] = dlogits[(int64_t)min(r0 + r, batch - 1) * ld + c0 + min(lane, nn - 1)];
+    float4 w[8];
+#pragma unroll
+    for (int sI = 0; sI < 8; ++sI) {
+      const int it = min(8 * sI + t, nn - 1);
+      const float* wp = Wp1 + (int64_t)(c0 + it) * h + 4 * min(q, hq - 1);
+      if ((h & 3) == 0) w[sI] = *(const float4*)wp;
+      else {
+        w[sI].x = wp[0];
+        w[sI].y = 4 * q + 1 < h ? wp[1] : 0.f;
+        w[sI].z = 4 * q + 2 < h ? wp[2] : 0.f;
+        w[sI].w = 4 * q + 3 < h ? wp[3] : 0.f;
+      }
+      if (8 * sI + t >= nn || q >= hq) w[sI] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int it = 8 * s + t;                    // item of this lane in the chunk
-      const float g0 = __shfl(d0, it, NR_WAVE), g1 = __shfl(d1, it, NR_WAVE);
-      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < nn && q < hq) {
-        const float* wp = Wp1 + (int64_t)(c0 + it) * h + 4 * q;
-        if ((h & 3) == 0) w = *(const float4*)wp;
-        else { w.x = wp[0]; if (4 * q + 1 < h) w.y = wp[1]; if (4 * q + 2 < h) w.z = wp[2]; if (4 * q + 3 < h) w.w = wp[3]; }
+    for (int r = 0; r < kDg1Rows; ++r) {
+      const float d = (lane < nn && r0 + r < batch) ? dv[r] : 0.f;
+#pragma unroll
+      for (int sI = 0; sI < 8; ++sI) {
+        const float gv = __shfl(d, 8 * sI + t, NR_WAVE);
+        a[r].x = fmaf(gv, w[sI].x, a[r].x); a[r].y = fmaf(gv, w[sI].y, a[r].y);
+        a[r].z = fmaf(gv, w[sI].z, a[r].z); a[r].w = fmaf(gv, w[sI].w, a[r].w);
       }
-      a0.x = fmaf(g0, w.x, a0.x); a0.y = fmaf(g0, w.y, a0.y); a0.z = fmaf(g0, w.z, a0.z); a0.w = fmaf(g0, w.w, a0.w);
-      a1.x = fmaf(g1, w.x, a1.x); a1.y = fmaf(g1, w.y, a1.y); a1.z = fmaf(g1, w.z, a1.z); a1.w = fmaf(g1, w.w, a1.w);
     }
   }
   // sum the eight item lanes (t) of every column quad, then the waves
 #pragma unroll
-  for (int m = 8; m < NR_WAVE; m <<= 1) {
-    a0.x += __shfl_xor(a0.x, m, NR_WAVE); a0.y += __shfl_xor(a0.y, m, NR_WAVE);
-    a0.z += __shfl_xor(a0.z, m, NR_WAVE); a0.w += __shfl_xor(a0.w, m, NR_WAVE);
-    a1.x += __shfl_xor(a1.x, m, NR_WAVE); a1.y += __shfl_xor(a1.y, m, NR_WAVE);
-    a1.z += __shfl_xor(a1.z, m, NR_WAVE); a1.w += __shfl_xor(a1.w, m, NR_WAVE);
-  }
-  if (t == 0) {
-    s_red[wave][0][4 * q] = a0.x; s_red[wave][0][4 * q + 1] = a0.y;
-    s_red[wave][0][4 * q + 2] = a0.z; s_red[wave][0][4 * q + 3] = a0.w;
-    s_red[wave][1][4 * q] = a1.x; s_red[wave][1][4 * q + 1] = a1.y;
-    s_red[wave][1][4 * q + 2] = a1.z; s_red[wave][1][4 * q + 3] = a1.w;
-  }
-  __syncthreads();
-  if (tid < 2 * h) {
-    const int which = tid / h, j = tid % h;
-    const int r = r0 + which;
-    if (r < batch) {
-      float sum = 0.f;
+  for (int r = 0; r < kDg1Rows; ++r) {
 #pragma unroll
-      for (int w = 0; w < kDg1Waves; ++w) sum += s_red[w][which][j];
-      dG1[(int64_t)r * h + j] = sum;
+    for (int m = 8; m < NR_WAVE; m <<= 1) {
+      a[r].x += __shfl_xor(a[r].x, m, NR_WAVE); a[r].y += __shfl_xor(a[r].y, m, NR_WAVE);
+      a[r].z += __shfl_xor(a[r].z, m, NR_WAVE); a[r].w += __shfl_xor(a[r].w, m, NR_WAVE);
+    }
+    if (t == 0) {
+      s_red[wave][r][4 * q] = a[r].x; s_red[wave][r][4 * q + 1] = a[r].y;
+      s_red[wave][r][4 * q + 2] = a[r].z; s_red[wave][r][4 * q + 3] = a[r].w;
     }
   }
+  __syncthreads();
+  for (int i = tid; i < kDg1Rows * kMaxD; i += kDg1Waves * NR_WAVE) {
+    const int r = i / kMaxD, j = i % kMaxD;
+    if (r0 + r < batch && j < h) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < kDg1Waves; ++w2) sum += s_red[w2][r][j];
+      part[((int64_t)blockIdx.y * batch + r0 + r) * kMaxD + j] = sum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vae_dg1_reduce_kernel(const float* __restrict__ part, int batch,
+                                                             int h, float* __restrict__ dG1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= batch * h) return;
+  const int r = i / h, j = i % h;
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < kDg1Split; ++k) sum += part[((int64_t)k * batch + r) * kMaxD + j];
+  dG1[i] = sum;
 }
 
 // ----------------------------------------------------------------------------
@@ -513,7 +567,10 @@ int nrhip_add_row_bias(float* d_S, int64_t ld, int batch, int cols, const float*
 
 int nrhip_vae_workspace_bytes(int batch, int cols, size_t* bytes) {
   NR_REQUIRE(bytes && batch >= 0 && cols >= 1, NR_ERR_ARG, "vae_workspace_bytes: bad arguments");
-  *bytes = (size_t)(batch > 0 ? batch : 1) * (size_t)((cols + 31) / 32) * sizeof(uint32_t);
+  const size_t rows = (size_t)(batch > 0 ? batch : 1);
+  // positive-item bit rows of the softmax gradient, then the dg1 partial sums per item range
+  *bytes = nr_align_up(rows * (size_t)((cols + 31) / 32) * sizeof(uint32_t), 256) +
+           (size_t)kDg1Split * rows * kMaxD * sizeof(float);
   return NR_OK;
 }
 
@@ -529,17 +586,22 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
              NR_ERR_ARG, "vae_decoder_loss_grad: bad arguments");
   NR_REQUIRE(h >= 1 && h <= kMaxD, NR_ERR_UNSUPPORTED, "vae_decoder: hidden %d > 32", h);
   const int words = (cols + 31) / 32;
-  NR_REQUIRE(ws_bytes >= (size_t)batch * words * sizeof(uint32_t), NR_ERR_WORKSPACE,
+  const size_t bits_bytes = nr_align_up((size_t)batch * words * sizeof(uint32_t), 256);
+  NR_REQUIRE(ws_bytes >= bits_bytes + (size_t)kDg1Split * batch * kMaxD * sizeof(float), NR_ERR_WORKSPACE,
              "vae_decoder_loss_grad: workspace too small");
+  float* part = (float*)((char*)d_ws + bits_bytes);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(vae_softmax_grad_kernel, dim3(batch), dim3(256), 0, st, d_S, ld, cols, d_bp1,
                      d_indptr, d_indices, d_rows, 1.0f / (float)batch, d_nll, (uint32_t*)d_ws, words);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, d_S, ld, batch,
+  hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, d_S, ld, batch,
                      cols, h, d_G1, d_dWp1, d_dbp1);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + 1) / 2), dim3(kDg1Waves * NR_WAVE), 0, st, d_S,
-                     ld, batch, cols, h, d_Wp1, d_dG1);
+  hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + kDg1Rows - 1) / kDg1Rows, kDg1Split),
+                     dim3(kDg1Waves * NR_WAVE), 0, st, d_S, ld, batch, cols, h, d_Wp1, part);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vae_dg1_reduce_kernel, dim3((batch * h + 255) / 256), dim3(256), 0, st, part, batch, h,
+                     d_dG1);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
