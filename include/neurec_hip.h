@@ -182,6 +182,13 @@ int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int
 int nrhip_adam_dense_tf2(float* d_var, float* d_m, float* d_v, const float* d_grad_a,
                          const float* d_grad_b, int64_t n, float alpha, float beta1, float beta2,
                          float eps, void* stream);
+/* Dense ApplyAdam on up to 16 tensors in one launch (a model's weight matrices and biases:
+ * util/learner.py:9-10 applied to every trainable of NGCF.py:91-110 / MultiVAE.py:47-70).  Host
+ * arrays of device pointers and lengths; clear_grad_host (optional) as in nrhip_adam_dense_tf. */
+int nrhip_adam_dense_tf_multi(int n_tensors, float* const* d_vars_host, float* const* d_ms_host,
+                              float* const* d_vs_host, float* const* d_grads_host,
+                              const int64_t* sizes_host, const int32_t* clear_grad_host, float alpha,
+                              float beta1, float beta2, float eps, void* stream);
 /* Row-sparse helpers over a list of row ids of a [*, d] buffer (repeats allowed):
  * dst[row] = src[row] / denom; and zeroing of the listed rows of up to four buffers plus a
  * per-row byte flag (any of them may be NULL). */

@@ -77,6 +77,7 @@ SIGNATURES = {
     "nrhip_adam_sparse_tf": [p, p, p, p, i64, f32, f32, f32, f32, p],
     "nrhip_adam_dense_tf": [p, p, p, p, i64, f32, f32, f32, f32, i32, p],
     "nrhip_adam_dense_tf2": [p, p, p, p, p, i64, f32, f32, f32, f32, p],
+    "nrhip_adam_dense_tf_multi": [i32, p, p, p, p, p, p, f32, f32, f32, f32, p],
     "nrhip_rows_div": [p, i32, i32, p, f32, p, p],
     "nrhip_rows_clear": [p, i32, i32, p, p, p, p, p, p],
     "nrhip_spmm_plan_bytes": [i64, i64, psz],

@@ -10,6 +10,7 @@
 // kernel is a pure HBM stream: 4 reads + 3 (or 4, with the gradient clear)
 // writes of n·4 bytes, 16 B per lane per access.
 #include "nr_common.h"
+#include <algorithm>
 #include <string.h>
 
 namespace {
@@ -242,6 +243,46 @@ thread_local char g_err[512] = "";
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Several dense TF-Adam updates in one launch (a model's weight matrices and biases: sixteen
+// 5-us launches per NGCF step otherwise).  blockIdx.y = tensor.
+constexpr int kMaxMulti = 16;
+struct MultiAdam {
+  float* var[kMaxMulti]; float* m[kMaxMulti]; float* v[kMaxMulti]; float* grad[kMaxMulti];
+  int64_t n[kMaxMulti];
+  int clear[kMaxMulti];
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(MultiAdam t, float alpha, float omb1, float omb2,
+                                                         float eps) {
+  const int k = blockIdx.y;
+  float* __restrict__ var = t.var[k];
+  float* __restrict__ m = t.m[k];
+  float* __restrict__ v = t.v[k];
+  float* __restrict__ grad = t.grad[k];
+  const int64_t n = t.n[k], n4 = n / 4;
+  const bool clear = t.clear[k] != 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 w = reinterpret_cast<float4*>(var)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    const float4 g = reinterpret_cast<const float4*>(grad)[i];
+    nr::adam_dense_tf(g.x, w.x, mm.x, vv.x, alpha, omb1, omb2, eps);
+    nr::adam_dense_tf(g.y, w.y, mm.y, vv.y, alpha, omb1, omb2, eps);
+    nr::adam_dense_tf(g.z, w.z, mm.z, vv.z, alpha, omb1, omb2, eps);
+    nr::adam_dense_tf(g.w, w.w, mm.w, vv.w, alpha, omb1, omb2, eps);
+    reinterpret_cast<float4*>(var)[i] = w;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (clear) reinterpret_cast<float4*>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float w = var[i], mm = m[i], vv = v[i];
+    nr::adam_dense_tf(grad[i], w, mm, vv, alpha, omb1, omb2, eps);
+    var[i] = w; m[i] = mm; v[i] = vv;
+    if (clear) grad[i] = 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -315,6 +356,33 @@ int nrhip_adam_dense_tf2(float* d_var, float* d_m, float* d_v, const float* d_gr
   hipLaunchKernelGGL(adam_dense2_kernel, dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
                      (hipStream_t)stream, d_var, d_m, d_v, d_grad_a, d_grad_b, n, alpha,
                      1.0f - beta1, 1.0f - beta2, eps);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Dense TF-1.12 ApplyAdam on up to 16 tensors in one launch (host arrays of device pointers and
+ * lengths; clear_grad[k] != 0 zeroes tensor k's gradient as nrhip_adam_dense_tf does). */
+int nrhip_adam_dense_tf_multi(int n_tensors, float* const* d_vars, float* const* d_ms,
+                              float* const* d_vs, float* const* d_grads, const int64_t* sizes,
+                              const int32_t* clear_grad, float alpha, float beta1, float beta2,
+                              float eps, void* stream) {
+  NR_REQUIRE(n_tensors >= 0 && n_tensors <= kMaxMulti && (n_tensors == 0 || (d_vars && d_ms && d_vs && d_grads && sizes)),
+             NR_ERR_ARG, "adam_dense_tf_multi: 0..%d tensors", kMaxMulti);
+  if (n_tensors == 0) return NR_OK;
+  MultiAdam t{};
+  int64_t biggest = 0;
+  for (int k = 0; k < n_tensors; ++k) {
+    NR_REQUIRE(d_vars[k] && d_ms[k] && d_vs[k] && d_grads[k] && sizes[k] >= 0, NR_ERR_ARG,
+               "adam_dense_tf_multi: tensor %d: bad arguments", k);
+    NR_REQUIRE(aligned16(d_vars[k]) && aligned16(d_ms[k]) && aligned16(d_vs[k]) && aligned16(d_grads[k]),
+               NR_ERR_ARG, "adam_dense_tf_multi: tensor %d: buffers must be 16-byte aligned", k);
+    t.var[k] = d_vars[k]; t.m[k] = d_ms[k]; t.v[k] = d_vs[k]; t.grad[k] = d_grads[k];
+    t.n[k] = sizes[k];
+    t.clear[k] = clear_grad ? clear_grad[k] : 0;
+    biggest = std::max<int64_t>(biggest, sizes[k]);
+  }
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(sweep_blocks(biggest / 4 + 1), n_tensors), dim3(256), 0,
+                     (hipStream_t)stream, t, alpha, 1.0f - beta1, 1.0f - beta2, eps);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -309,6 +309,21 @@ def adam_dense(var, m, v, grad, st, clear_grad=True):
          1 if clear_grad else 0, _stream())
 
 
+def adam_dense_multi(tensors, st):
+    """Dense TF-Adam on several (var, m, v, grad[, clear_grad]) tuples in one launch (<= 16 per launch)."""
+    for lo in range(0, len(tensors), 16):
+        part = tensors[lo:lo + 16]
+        n = len(part)
+        for t in part:
+            for x in t[:4]:
+                _ptr(x, torch.float32)                       # type / device / contiguity checks
+        arr = lambda i: (C.c_void_p * n)(*[t[i].data_ptr() for t in part])
+        sizes = (C.c_int64 * n)(*[t[0].numel() for t in part])
+        clear = (C.c_int32 * n)(*[1 if (len(t) > 4 and t[4]) else 0 for t in part])
+        call("nrhip_adam_dense_tf_multi", n, arr(0), arr(1), arr(2), arr(3), sizes, clear, st.alpha(),
+             st.beta1, st.beta2, st.eps, _stream())
+
+
 def adam_dense2(var, m, v, grad_a, grad_b, st):
     """Dense TF Adam with gradient grad_a + grad_b (both left untouched)."""
     call("nrhip_adam_dense_tf2", _ptr(var, torch.float32), _ptr(m), _ptr(v), _ptr(grad_a),

@@ -479,10 +479,10 @@ class NGCFEngine:
             E.copy2d(self.dOut[:, :d], self.gE0)
         else:
             E.add2d(self.dOut[:, :d], dego, self.gE0)
-        E.adam_dense(self.E0, self.mE, self.vE, self.gE0, self.adam, clear_grad=False)
-        for k in range(self.L):
-            for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k]):
-                E.adam_dense(w, m, v, g, self.adam, clear_grad=False)
+        # every trainable in one launch (17 tensors = 2 launches; they were 17)
+        E.adam_dense_multi([(self.E0, self.mE, self.vE, self.gE0)] +
+                           [(w, m, v, g) for k in range(self.L)
+                            for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k])], self.adam)
         E.rows_clear(rows, self.dsum, (self.dOut,), self.flag)
         self.adam.advance()
 
@@ -585,8 +585,7 @@ class MultiVAEEngine:
         self.last_anneal = float(anneal)
         if not apply:
             return
-        for k in self.NAMES:
-            E.adam_dense(P[k], self.M[k], self.V[k], G[k], self.adam, clear_grad=(k == "Wq0"))
+        E.adam_dense_multi([(P[k], self.M[k], self.V[k], G[k], k == "Wq0") for k in self.NAMES], self.adam)
         self.adam.advance()
         self.t += 1
 
