@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void vae_encode_kernel(
   const float inv = 1.0f / sqrtf(fmaxf((float)n, 1e-12f));
   float a1 = 0.f;
   const uint64_t drop_key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull));
-  // 64 (item, value) pairs per chunk, one per lane; then 8 row gathers of W_q0 in flight at a time
+  // 64 (item, value) pairs per chunk, one per lane; then 32 row gathers of W_q0 in flight at a time
   // (the sum stays in ascending item order)
   for (int64_t t0 = b; t0 < e; t0 += NR_WAVE) {
     const int nn = (int)min((int64_t)NR_WAVE, e - t0);
@@ -84,18 +84,19 @@ __global__ __launch_bounds__(256) void vae_encode_kernel(
       my_item = indices[t];
       if (h0val) h0val[t] = my_val;
     }
-    for (int s0 = 0; s0 < nn; s0 += 8) {
-      float w[8], v[8];
+    constexpr int kRowsInFlight = 32;                      // a typical user's whole list in one round trip
+    for (int s0 = 0; s0 < nn; s0 += kRowsInFlight) {
+      float w[kRowsInFlight];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int src = min(s0 + u, nn - 1);
-        const int item = __builtin_amdgcn_readlane(my_item, src);
-        v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), src));
-        w[u] = (lane < h) ? Wq0[(int64_t)item * h + lane] : 0.f;
+      for (int u = 0; u < kRowsInFlight; ++u) {
+        const int item = __shfl(my_item, min(s0 + u, nn - 1), NR_WAVE);
+        w[u] = Wq0[(int64_t)item * h + min(lane, h - 1)];    // unconditional; lanes >= h discard it
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (s0 + u < nn) a1 = fmaf(v[u], w[u], a1);
+      for (int u = 0; u < kRowsInFlight; ++u) {
+        const float v = __shfl(my_val, min(s0 + u, nn - 1), NR_WAVE);
+        if (s0 + u < nn) a1 = fmaf(v, w[u], a1);
+      }
     }
   }
   float h1 = 0.f;
