@@ -187,9 +187,24 @@ __global__ __launch_bounds__(256) void vae_softmax_grad_kernel(
     if (x > mx) { sum = sum * expf(mx - x) + 1.0f; mx = x; }
     else sum += expf(x - mx);
   };
-  for (int i = tid; i < cols4 / 4; i += 256) {
-    const float4 a = srow4[i], bb = bias4[i];
-    fold(a.x + bb.x); fold(a.y + bb.y); fold(a.z + bb.z); fold(a.w + bb.w);
+  // kUn independent 16-byte loads per thread and round (unconditional, clamped): the folds below
+  // branch, so the compiler will not overlap one iteration's loads with the next one's — 40 rounds
+  // of one memory round trip each were most of this kernel's 60 us
+  constexpr int kUn = 4;
+  const int n4 = cols4 / 4;
+  for (int i0 = tid; i0 < n4; i0 += 256 * kUn) {
+    float4 a[kUn], bb[kUn];
+#pragma unroll
+    for (int k = 0; k < kUn; ++k) {
+      const int i = min(i0 + k * 256, n4 - 1);
+      a[k] = srow4[i];
+      bb[k] = bias4[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kUn; ++k)
+      if (i0 + k * 256 < n4) {
+        fold(a[k].x + bb[k].x); fold(a[k].y + bb[k].y); fold(a[k].z + bb[k].z); fold(a[k].w + bb[k].w);
+      }
   }
   for (int i = cols4 + tid; i < cols; i += 256) fold(srow[i] + bias[i]);
   s_red[tid] = mx;
@@ -205,21 +220,35 @@ __global__ __launch_bounds__(256) void vae_softmax_grad_kernel(
   const float lse = s_lse;
   const float nb = (float)(e - b);
   float ll = 0.f;
-  auto grad = [&](float xv, int i) {
+  auto grad = [&](float xv, bool x) {
     const float l = xv - lse;                                  // log-softmax
-    const bool x = (bm[i >> 5] >> (i & 31)) & 1u;
     if (x) ll += l;
     return (expf(l) * nb - (x ? 1.f : 0.f)) * inv_batch;
   };
   float4* srow4w = reinterpret_cast<float4*>(srow);
-  for (int i = tid; i < cols4 / 4; i += 256) {
-    const float4 a = srow4[i], bb = bias4[i];
-    float4 o;
-    o.x = grad(a.x + bb.x, 4 * i); o.y = grad(a.y + bb.y, 4 * i + 1);
-    o.z = grad(a.z + bb.z, 4 * i + 2); o.w = grad(a.w + bb.w, 4 * i + 3);
-    srow4w[i] = o;
+  for (int i0 = tid; i0 < n4; i0 += 256 * kUn) {
+    float4 a[kUn], bb[kUn];
+    uint32_t bits[kUn];                                      // 4 consecutive items share a bitmap word
+#pragma unroll
+    for (int k = 0; k < kUn; ++k) {
+      const int i = min(i0 + k * 256, n4 - 1);
+      a[k] = srow4[i];
+      bb[k] = bias4[i];
+      bits[k] = bm[i >> 3] >> ((4 * i) & 31);
+    }
+#pragma unroll
+    for (int k = 0; k < kUn; ++k) {
+      const int i = i0 + k * 256;
+      if (i < n4) {
+        float4 o;
+        o.x = grad(a[k].x + bb[k].x, bits[k] & 1u); o.y = grad(a[k].y + bb[k].y, (bits[k] >> 1) & 1u);
+        o.z = grad(a[k].z + bb[k].z, (bits[k] >> 2) & 1u); o.w = grad(a[k].w + bb[k].w, (bits[k] >> 3) & 1u);
+        srow4w[i] = o;
+      }
+    }
   }
-  for (int i = cols4 + tid; i < cols; i += 256) srow[i] = grad(srow[i] + bias[i], i);
+  for (int i = cols4 + tid; i < cols; i += 256)
+    srow[i] = grad(srow[i] + bias[i], ((bm[i >> 5] >> (i & 31)) & 1u) != 0u);
   s_red[tid] = ll;
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
