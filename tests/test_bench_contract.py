@@ -1,0 +1,54 @@
+"""bench.py's output contract, checked on the committed bench line of the round
+(profiles/r01_bench.json) and on the argument parser — no GPU needed."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r01_bench.json")) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_carries_every_contract_field():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "triplets/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value and ms_per_step describe the same run: steps * global batch / time
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > r["bytes_per_launch"]      # misses re-read rows
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+
+
+def test_bench_metric_is_the_north_star_metric():
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    d = _line()
+    text = json.dumps(base).lower()
+    assert "triplets" in text and "triplets" in d["metric"].lower()
+    assert "lightgcn" in d["metric"].lower() and "gowalla" in d["config"]["workload"].lower()
+
+
+def test_bench_cli_has_the_contract_flags_and_safe_defaults():
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert re.search(r'add_argument\(\s*"%s"' % flag, src), flag
+    m = re.search(r'add_argument\(\s*"--gpus"[^)]*default=(\d+)', src)
+    assert m and int(m.group(1)) == 1
+    # nothing measured may touch the reference tree or the oracle outside the cpu_baseline leg
+    assert "/root/reference" not in src
