@@ -6,6 +6,13 @@ SpMM kernel consumes — N = n_users + n_items nodes, user rows first, ascending
 fp32 values — with the reference's rounding: every value is produced by the same sequence
 of fp32 (or, where the reference silently promotes through `sp.eye`, fp64) operations.
 
+Pinned: tests/test_adjacency_golden.py compares every adj_type bit-for-bit with matrices made by
+the reference's own methods (tests/golden/make_golden_adjacency.py).  One order difference is
+known and stated: for LightGCN `gcmc` the reference's single scipy product leaves each row's
+columns in descending order and hands TF the COO that way; here every adjacency is canonical
+(ascending columns) — same entries, same values, the row sums of that one non-default type may
+differ from a TF-CPU run in the last ulp.
+
 This runs once per training run on the host, exactly where the reference runs it; it is not
 on the measured path.
 """
