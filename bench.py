@@ -125,8 +125,12 @@ def main():
         lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,            # lr, reg: conf/LightGCN.properties
                             args.batch * (comm.world if exchange else 1))
     trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
+    # single GPU / all-reduce / row-shard modes step on the sampler's own batches: their batch plans
+    # (the order of the duplicate-row gradient sums) are sorted once per epoch by the sampler; in
+    # the id-exchange mode the global batch only exists after the all-gather: sorted inside the step
     sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=args.batch, shuffle=True, seed=2018,
-                              rank=comm.rank, world=comm.world)
+                              rank=comm.rank, world=comm.world,
+                              plan_users=None if (exchange or rowshard) else U)
     loss2 = torch.zeros(2, device=dev)
     grad_sync = comm.allreduce_sum_ if (comm.active and not exchange and not rowshard) else None
 
@@ -153,8 +157,8 @@ def main():
                 bu, bp, bn = next(stream)
                 lg.step(bu, bp, bn, loss_out)
             else:
-                bu, bp, bn = next(stream)
-                lg.step(bu, bp, bn, loss_out, grad_sync=grad_sync)
+                b = next(stream)
+                lg.step(b[0], b[1], b[2], loss_out, grad_sync=grad_sync, plan=b.plan)
 
     run_steps(args.warmup)
     torch.cuda.synchronize(); comm.barrier()
@@ -213,15 +217,16 @@ def main():
         rs = np.random.RandomState(2017)
         mf = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32),
                       0.001, 0.0, 512)                                   # conf/MF.properties
-        mf_sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=512, shuffle=True, seed=2018)
+        mf_sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=512, shuffle=True, seed=2018,
+                                     plan_users=U)
         mf_batches = [b for b in mf_sampler.batches() if b[0].numel() == 512][:400]
         mf_loss = torch.zeros(2, device=dev)
         for b in mf_batches[:50]:
-            mf.step(b[0], b[1], b[2], mf_loss)
+            mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b in mf_batches[50:]:
-            mf.step(b[0], b[1], b[2], mf_loss)
+            mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
         torch.cuda.synchronize()
         mf_dt = (time.perf_counter() - t0) / max(len(mf_batches) - 50, 1)
         sweep = 2 * 4 * (U + I) * 64 * 4        # var, m, v, grad read + var, m, v, grad(cleared) written
@@ -237,10 +242,8 @@ def main():
         ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch,
                                pruned=args.eval_mode == "pruned")
 
-        if exchange:
-            # replicas ran the same global steps, but fp32 scatter atomics sum in different orders:
-            # re-align the tables (ulp-level drift) before the users are scored shard by shard
-            comm.broadcast_(lg.E0, 0)
+        # replicas that ran the same global steps hold bit-identical tables (row gradients are
+        # summed in batch order, nothing is unordered): no re-alignment before sharded scoring
 
         def evaluate():
             eu, ei = lg.final_embeddings()

@@ -159,17 +159,33 @@ int nrhip_randint_choice_batch(int high, int n_req, int64_t total, const int64_t
  * Replaces one sess.run((loss, optimizer)) of MF.train_model
  * (model/general_recommender/MF.py:54-76,101; util/learner.py:9-10,19-22;
  * util/tool.py:216-217).
+ *   plan:  the occurrences (row, position) of every batch of an epoch stream sorted
+ *          by row then position — what makes the row-gradient sums deterministic:
+ *          TF adds the IndexedSlices that hit one row in batch order
+ *          (unsorted_segment_sum; the positive lookups' slices before the negative
+ *          lookups'), and so do the kernels given this order.  d_third = NULL for
+ *          pointwise (user, item) instances.  Batch k covers stream elements
+ *          [k*batch, min((k+1)*batch, n_total)); its n_cls*len keys are written at
+ *          d_plan_out + n_cls*k*batch (n_cls = 3 with d_third, else 2).  Item ids are
+ *          offset by n_users in the keys.  (n_cls-1)*batch <= 16384.
  *   grad:  gathers p_u,q_i,q_j; x=<p,q_i>-<p,q_j>; loss_b=softplus(-x);
- *          row gradients (duplicates summed) accumulated into dense d_GP/d_GQ
- *          (which must be zero on entry); d_terms is scratch for 2*batch
- *          floats (per-triplet loss and l2 terms, reduced in a fixed order);
- *          d_loss2[0] = sum_b loss_b, d_loss2[1] = reg * sum_b l2_b, the two
- *          addends of MF.py:68-69 (the fetched loss is their sum).
+ *          row gradients (duplicates summed in batch order) STORED into the rows of
+ *          dense d_GP/d_GQ the batch touches (all other rows are left alone: keep them
+ *          zero); d_work is scratch for 8*batch floats (per-triplet loss and l2 terms,
+ *          reduced in a fixed order; then room for a plan); d_plan = this batch's slice
+ *          of an nrhip_bpr_plan output, or NULL: the plan is then sorted on the spot
+ *          (one more launch); d_loss2[0] = sum_b loss_b, d_loss2[1] = reg * sum_b l2_b,
+ *          the two addends of MF.py:68-69 (the fetched loss is their sum).
+ *          NRHIP_ATOMIC_SCATTER=1 in the environment selects the former kernels that
+ *          scatter with fp32 atomics (order of the sums arbitrary; an A/B knob).
  *   adam:  TF-1.12 sparse Adam = all rows swept (see nr_core.h), and the
  *          gradient buffer is cleared for the next step.               */
-int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                      const int32_t* d_pos, const int32_t* d_neg, int batch, float reg, float* d_GP,
-                      float* d_GQ, float* d_terms, float* d_loss2, void* stream);
+int nrhip_bpr_plan(const int32_t* d_users, const int32_t* d_items, const int32_t* d_third,
+                   int64_t n_total, int batch, int n_users, uint64_t* d_plan_out, void* stream);
+int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
+                      const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                      float reg, float* d_GP, float* d_GQ, float* d_work, float* d_loss2,
+                      const uint64_t* d_plan, void* stream);
 int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
                          float alpha, float beta1, float beta2, float eps, void* stream);
 /* TF-1.12 dense ApplyAdam; d_grad cleared afterwards when clear_grad != 0. */
@@ -326,23 +342,27 @@ int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const
 /* ---- LightGCN BPR head ----------------------------------------------------
  * Replaces the lookups + create_bpr_loss of LightGCN.py:99-104,156-166 and
  * their gradient.  d_Esum is the running layer sum (E* = Esum/(L+1));
- * user rows first, item rows offset by n_users.  Accumulates
- *   d_Gstar  += dLoss/dE*      (dense [N][d], zero on entry)
- *   d_Greg   += reg * E0 rows  (dense [N][d], zero on entry)
+ * user rows first, item rows offset by n_users.  Stores, on the rows the batch touches
+ * (duplicates summed in batch order, see nrhip_bpr_plan; other rows are left alone),
+ *   d_Gstar  = dLoss/dE*      (dense [N][d], zero elsewhere)
+ *   d_Greg   = reg * E0 rows  (dense [N][d], zero elsewhere)
  * and writes the two scalars mf_loss, emb_loss into d_loss2[0..1] (d_loss2 may be NULL:
- * the reference never fetches LightGCN's loss during training, LightGCN.py:178). */
+ * the reference never fetches LightGCN's loss during training, LightGCN.py:178).
+ * d_work: 8*batch floats; d_plan: the batch's plan or NULL (sorted on the spot). */
 int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
                             int n_layers, const int32_t* d_users, const int32_t* d_pos,
                             const int32_t* d_neg, int batch, float reg, float* d_Gstar,
-                            float* d_Greg, float* d_terms, float* d_loss2, void* stream);
+                            float* d_Greg, float* d_work, float* d_loss2, const uint64_t* d_plan,
+                            void* stream);
 
-/* Same head, accumulating dLoss/dE* already divided by (n_layers+1) into d_H (zero on entry) —
+/* Same head, storing dLoss/dE* already divided by (n_layers+1) into d_H (zero elsewhere) —
  * the H = Gstar/(L+1) the backward hops start from.  Only for n_layers+1 a power of two, where
  * dividing every term is bit-identical to dividing the sum (NRHIP_ERR_ARG otherwise). */
 int nrhip_lightgcn_bpr_grad_h(const float* d_Esum, const float* d_E0, int n_users, int d,
                               int n_layers, const int32_t* d_users, const int32_t* d_pos,
                               const int32_t* d_neg, int batch, float reg, float* d_H,
-                              float* d_Greg, float* d_terms, float* d_loss2, void* stream);
+                              float* d_Greg, float* d_work, float* d_loss2, const uint64_t* d_plan,
+                              void* stream);
 
 /* Node rows touched by a batch: d_rows_out[3*batch] = users | n_users+pos | n_users+neg and
  * d_row_flag[those rows] = 1 (d_row_flag: n_nodes bytes, zero on entry). */
@@ -364,7 +384,7 @@ typedef struct nrhip_lightgcn_buffers {
   float* Gstar; float* Greg; float* H; float* Ga; float* Gb;   /* gradient buffers   */
   int32_t* batch_rows;       /* 3*max_batch                      */
   uint8_t* row_flag;         /* n_nodes bytes, zero between steps */
-  float* terms;              /* 2*max_batch                      */
+  float* terms;              /* 8*max_batch floats (loss terms + room for a batch plan) */
   void* spmm_ws; size_t spmm_ws_bytes;
   int n_users; int n_nodes; int d; int n_layers; int max_batch;
   float reg;
@@ -372,31 +392,32 @@ typedef struct nrhip_lightgcn_buffers {
 int nrhip_lightgcn_ctx_create(const nrhip_lightgcn_buffers* bufs, void** ctx_out);
 int nrhip_lightgcn_ctx_destroy(void* ctx);
 /* alpha = lr*sqrt(1-b2^t)/(1-b1^t) in fp32 (the caller keeps the running powers).
- * d_loss2 may be NULL (loss not fetched). */
+ * d_loss2 may be NULL (loss not fetched).  d_plan: this batch's nrhip_bpr_plan slice (keys built
+ * with n_users = the context's) or NULL. */
 int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
-                        const int32_t* d_neg, int batch, float alpha, float beta1, float beta2,
-                        float eps, float* d_loss2, void* stream);
+                        const int32_t* d_neg, int batch, const uint64_t* d_plan, float alpha,
+                        float beta1, float beta2, float eps, float* d_loss2, void* stream);
 
 /* The same step cut at its one exchange point (multi-GPU): _grad leaves this rank's total
  * dLoss/dE0 in d_grad_out ([n_nodes][d]); the caller sums it over ranks (RCCL all-reduce);
  * _apply runs Adam on the summed gradient. */
 int nrhip_lightgcn_step_grad(void* ctx, const int32_t* d_users, const int32_t* d_pos,
-                             const int32_t* d_neg, int batch, float* d_loss2, float* d_grad_out,
-                             void* stream);
+                             const int32_t* d_neg, int batch, const uint64_t* d_plan,
+                             float* d_loss2, float* d_grad_out, void* stream);
 int nrhip_lightgcn_step_apply(void* ctx, float* d_grad, float alpha, float beta1, float beta2,
                               float eps, void* stream);
 
 typedef struct nrhip_mf_buffers {
   float* P; float* Q; float* mP; float* vP; float* mQ; float* vQ; float* GP; float* GQ;
-  float* terms;              /* 2*max_batch */
+  float* terms;              /* 8*max_batch floats */
   int n_users; int n_items; int d; int max_batch;
   float reg;
 } nrhip_mf_buffers;
 int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out);
 int nrhip_mf_ctx_destroy(void* ctx);
 int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, float alpha, float beta1, float beta2, float eps, float* d_loss2,
-                  void* stream);
+                  int batch, const uint64_t* d_plan, float alpha, float beta1, float beta2, float eps,
+                  float* d_loss2, void* stream);
 
 /* ---- NGCF propagation layer, dense half (second-model coverage) ---------------
  * Replaces the per-layer TF ops of NGCF._create_ngcf_embed
@@ -476,8 +497,8 @@ int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
 
 /* ---- the other losses and optimisers of util/learner.py (MF.py:62-76 with is_pairwise /
  * loss_function / learner other than bpr + adam) ----------------------------------------------
- * Same contract as nrhip_bpr_mf_grad (dense zeroed d_GP/d_GQ, d_terms scratch of 2*batch floats,
- * d_loss2 = {data loss, reg * l2}).
+ * Same contract as nrhip_bpr_mf_grad (dense d_GP/d_GQ zero outside the batch rows, d_work scratch of
+ * 8*batch floats, optional d_plan, d_loss2 = {data loss, reg * l2}).
  *   pairwise loss_kind  (learner.py:19-29):  0 bpr  1 hinge = sum max(y+1, 0)  2 square = sum (1-y)^2
  *   pointwise loss_kind (learner.py:31-41):  0 cross_entropy = tf.losses.sigmoid_cross_entropy (batch
  *                        MEAN)  1 square = sum (label - x)^2;  instances are (user, item, label) as
@@ -488,14 +509,14 @@ int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
  *   kind 0 gd; 1 adagrad (slot0 = accumulator, initialise to 1e-8); 2 rmsprop (slot0 = ms
  *   initialised to 1, slot1 = mom initialised to 0, hyper1 = decay 0.9, hyper2 = momentum 0,
  *   eps 1e-10); 3 momentum (slot0 = accumulator, hyper1 = momentum 0.9). */
-int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                           const int32_t* d_pos, const int32_t* d_neg, int batch, float reg,
-                           int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
-                           void* stream);
-int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                            const int32_t* d_items, const float* d_labels, int batch, float reg,
-                            int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
-                            void* stream);
+int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
+                           const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                           int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
+                           float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream);
+int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
+                            const int32_t* d_users, const int32_t* d_items, const float* d_labels,
+                            int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
+                            float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream);
 int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, void* stream);
 int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
                             uint8_t* d_row_flag, int64_t n_rows, int d, float lr, float hyper1,

@@ -73,7 +73,8 @@ SIGNATURES = {
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],
     "nrhip_sample_bpr_epoch": [p, p, p, i64, i32, i32, u64, u64, i32, i64, i64, p, p, p, p],
     "nrhip_randint_choice_batch": [i32, i32, i64, p, p, p, i32, u64, u64, p, p],
-    "nrhip_bpr_mf_grad": [p, p, i32, p, p, p, i32, f32, p, p, p, p, p],
+    "nrhip_bpr_plan": [p, p, p, i64, i32, i32, p, p],
+    "nrhip_bpr_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p],
     "nrhip_adam_sparse_tf": [p, p, p, p, i64, f32, f32, f32, f32, p],
     "nrhip_adam_dense_tf": [p, p, p, p, i64, f32, f32, f32, f32, i32, p],
     "nrhip_adam_dense_tf2": [p, p, p, p, p, i64, f32, f32, f32, f32, p],
@@ -89,16 +90,16 @@ SIGNATURES = {
     "nrhip_spmm_csr_masked": [p, p, p, p, p, p, p, i32, p, p, p, p, p, sz, p],
     "nrhip_spmm_csr_rows": [p, p, p, p, i32, p, i32, p, p, p, p, p],
     "nrhip_lightgcn_mark_batch": [p, p, p, i32, i32, p, p, p],
-    "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p],
-    "nrhip_lightgcn_bpr_grad_h": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p],
+    "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p],
+    "nrhip_lightgcn_bpr_grad_h": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p],
     "nrhip_lightgcn_ctx_create": [C.POINTER(LightGCNBuffers), C.POINTER(p)],
     "nrhip_lightgcn_ctx_destroy": [p],
-    "nrhip_lightgcn_step": [p, p, p, p, i32, f32, f32, f32, f32, p, p],
-    "nrhip_lightgcn_step_grad": [p, p, p, p, i32, p, p, p],
+    "nrhip_lightgcn_step": [p, p, p, p, i32, p, f32, f32, f32, f32, p, p],
+    "nrhip_lightgcn_step_grad": [p, p, p, p, i32, p, p, p, p],
     "nrhip_lightgcn_step_apply": [p, p, f32, f32, f32, f32, p],
     "nrhip_mf_ctx_create": [C.POINTER(MFBuffers), C.POINTER(p)],
     "nrhip_mf_ctx_destroy": [p],
-    "nrhip_mf_step": [p, p, p, p, i32, f32, f32, f32, f32, p, p],
+    "nrhip_mf_step": [p, p, p, p, i32, p, f32, f32, f32, f32, p, p],
     "nrhip_ngcf_workspace_bytes": [i64, psz],
     "nrhip_ngcf_layer_fwd": [p, p, p, p, p, p, i64, i32, f32, p, i32, u64, u64, i32, p, p, i64, p],
     "nrhip_ngcf_layer_bwd": [p, p, p, p, p, p, i64, i32, f32, p, p, i64, p, p, p, p, p, p, p, p, p,
@@ -131,8 +132,8 @@ SIGNATURES = {
     "nrhip_axpy": [f32, p, p, i64, p],
     "nrhip_sumsq_accumulate": [p, i64, p, p],
     "nrhip_mean_f32": [p, i32, p, p],
-    "nrhip_pairwise_mf_grad": [p, p, i32, p, p, p, i32, f32, i32, p, p, p, p, p],
-    "nrhip_pointwise_mf_grad": [p, p, i32, p, p, p, i32, f32, i32, p, p, p, p, p],
+    "nrhip_pairwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
+    "nrhip_pointwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
     "nrhip_mark_rows": [p, i32, i32, p, p],
     "nrhip_optimizer_rows_tf": [i32, p, p, p, p, p, i64, i32, f32, f32, f32, f32, p],
     "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
@@ -155,8 +156,10 @@ lib.nrhip_last_error.restype = C.c_char_p
 
 EXPORTED = sorted(list(SIGNATURES) + ["nrhip_abi_version", "nrhip_last_error"])
 
-if lib.nrhip_abi_version() != 1:  # pragma: no cover
-    raise ImportError("libneurec_hip.so ABI version %d, expected 1" % lib.nrhip_abi_version())
+ABI_VERSION = 2      # 2: deterministic row-gradient sums (batch plans) in the BPR heads / steps
+if lib.nrhip_abi_version() != ABI_VERSION:  # pragma: no cover
+    raise ImportError("libneurec_hip.so ABI version %d, expected %d"
+                      % (lib.nrhip_abi_version(), ABI_VERSION))
 
 
 def last_error():

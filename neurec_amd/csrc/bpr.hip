@@ -7,13 +7,19 @@
 //               :156-166 (create_bpr_loss), util/tool.py:198-200,220-224
 // and for their autodiff: IndexedSlices row gradients with duplicates summed.
 //
-// One wave64 per triplet: the three embedding rows are gathered with one
-// coalesced 4·d-byte read each (lane = column), the two inner products are
-// wave shuffle reductions, the scalar loss/gradient math runs once per wave,
-// and row gradients are scattered with hardware fp32 atomics into dense
-// accumulators (duplicate rows inside a batch add up, as TF's
-// _apply_sparse_duplicate_indices does).  Per-triplet loss terms are written
-// out and reduced in a fixed order by the block that finishes last (finish_loss).
+// Row gradients are DETERMINISTIC: TF sums the slices of an IndexedSlices gradient that hit
+// the same row with unsorted_segment_sum, i.e. in batch order (the users' slices; for the item
+// table the positive lookups' slices, then the negative lookups').  The kernels reproduce that
+// order with a *batch plan* (bpr_plan_kernel): the 3·B occurrences (row, position) of a batch
+// sorted by row then position — built once per epoch for every batch by the sampler, or per
+// call when the caller has none.  One wave64 per sorted occurrence gathers its triplet's rows
+// (one coalesced 4·d-byte read each, lane = column), forms the two inner products with wave
+// shuffles and leaves its occurrence's gradient row in LDS; the wave of the FIRST occurrence
+// of a row then adds the following occurrences in order (from LDS while they are in its
+// workgroup, recomputed beyond) and stores the row — no atomics, bit-identical run to run
+// and to np.add.at in the oracle.  The former one-wave-per-triplet kernels that scatter with
+// fp32 hardware atomics stay as an A/B knob (NRHIP_ATOMIC_SCATTER=1).  Per-triplet loss terms
+// are written out and reduced in a fixed order by the block that finishes last (finish_loss).
 #include "nr_common.h"
 #include <atomic>
 
@@ -251,6 +257,332 @@ __global__ __launch_bounds__(256) void mark_batch_kernel(const int32_t* __restri
   flag[u] = 1; flag[i] = 1; flag[j] = 1;
 }
 
+
+// =================================================================================
+// Deterministic aggregation: the batch plan and the sorted-occurrence kernels
+// =================================================================================
+// key = (global row << 32) | occurrence position p, with p = class·nb + triplet (class 0 the
+// users, class 1 the items / positives, class 2 the negatives; nb = triplets in the batch) and
+// global row = user id, or n_users + item id.  Sorted ascending: rows grouped, occurrences of a
+// row in batch order, the positive lookups of an item before its negative lookups.
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanMaxKeys = 16384;          // 128 KB of LDS per sorting workgroup
+
+// grid (n_batches, 2): y = 0 sorts the batch's user occurrences, y = 1 its item occurrences (the
+// two key ranges do not overlap, so the concatenation is the sorted whole).
+__global__ __launch_bounds__(kPlanThreads) void bpr_plan_kernel(
+    const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+    const int32_t* __restrict__ third, int64_t n_total, int batch, int n_cls, int n_users,
+    int np2_user, int np2_item, uint64_t* __restrict__ skey) {
+  extern __shared__ uint64_t s_key[];
+  const int64_t first = (int64_t)blockIdx.x * batch;
+  const int nb = (int)((n_total - first) < (int64_t)batch ? (n_total - first) : (int64_t)batch);
+  const bool item_side = blockIdx.y == 1;
+  const int n = item_side ? (n_cls - 1) * nb : nb;
+  const int np2 = item_side ? np2_item : np2_user;
+  for (int k = threadIdx.x; k < np2; k += kPlanThreads) {
+    uint64_t key = ~0ull;
+    if (k < n) {
+      if (!item_side) {
+        key = ((uint64_t)(uint32_t)users[first + k] << 32) | (uint32_t)k;
+      } else {
+        const int c = k / nb, t = k - c * nb;
+        const int32_t it = (c == 0 ? items : third)[first + t];
+        key = ((uint64_t)(uint32_t)(n_users + it) << 32) | (uint32_t)((c + 1) * nb + t);
+      }
+    }
+    s_key[k] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (np2 >> 1); i += kPlanThreads) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const uint64_t a = s_key[lo], b = s_key[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > b) == up) {
+          s_key[lo] = b;
+          s_key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  uint64_t* out = skey + first * n_cls + (item_side ? nb : 0);
+  for (int k = threadIdx.x; k < n; k += kPlanThreads) out[k] = s_key[k];
+}
+
+constexpr int kOccWaves = 16;                 // sorted occurrences per workgroup
+
+__device__ __forceinline__ uint64_t plan_key(const uint64_t* __restrict__ skey, int s) {
+  const uint64_t k = skey[s];
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)k);
+}
+
+// ---- MF (pairwise: third = negative items; pointwise: third = float labels) ------------------
+template <int CPL, bool PAIR>
+__device__ __forceinline__ void mf_occurrence(
+    const float* __restrict__ P, const float* __restrict__ Q, int d,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ items, const void* third,
+    int batch, float reg, float scale, int loss_kind, uint32_t p, int lane, float (&out)[CPL],
+    float* __restrict__ term_mf, float* __restrict__ term_l2, bool write_terms) {
+  const int cls = (int)(p / (uint32_t)batch), b = (int)(p - (uint32_t)cls * (uint32_t)batch);
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = __builtin_amdgcn_readfirstlane(items[b]);
+  float pu[CPL], qi[CPL];
+  load_row<CPL>(P, u, d, lane, pu);
+  load_row<CPL>(Q, i, d, lane, qi);
+  if (PAIR) {
+    const int64_t j = __builtin_amdgcn_readfirstlane(((const int32_t*)third)[b]);
+    float qj[CPL];
+    load_row<CPL>(Q, j, d, lane, qj);
+    const float x = dot_rows<CPL>(pu, qi) - dot_rows<CPL>(pu, qj);      // MF.py:59,67
+    const float g = nr::pairwise_dloss(loss_kind, x);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      out[c] = cls == 0 ? g * (qi[c] - qj[c]) + reg * pu[c]
+             : cls == 1 ? g * pu[c] + reg * qi[c]
+                        : -g * pu[c] + reg * qj[c];
+    if (write_terms && cls == 0) {
+      const float l2 = 0.5f * (dot_rows<CPL>(pu, pu) + dot_rows<CPL>(qj, qj) + dot_rows<CPL>(qi, qi));
+      if (lane == 0) {
+        __hip_atomic_store(&term_mf[b], nr::pairwise_loss(loss_kind, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else {
+    const float z = ((const float*)third)[b];
+    const float x = dot_rows<CPL>(pu, qi);                               // MF.py:59
+    const float g = nr::pointwise_dloss(loss_kind, z, x) * scale;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      out[c] = cls == 0 ? g * qi[c] + reg * pu[c] : g * pu[c] + reg * qi[c];
+    if (write_terms && cls == 0) {
+      const float l2 = 0.5f * (dot_rows<CPL>(pu, pu) + dot_rows<CPL>(qi, qi));
+      if (lane == 0) {
+        __hip_atomic_store(&term_mf[b], nr::pointwise_loss(loss_kind, z, x) * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+template <int CPL, bool PAIR>
+__global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, int d, int n_users,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ items, const void* third,
+    int batch, const uint64_t* __restrict__ skey, int n_occ, float reg, float scale, int loss_kind,
+    float* __restrict__ GP, float* __restrict__ GQ, float* __restrict__ term_mf,
+    float* __restrict__ term_l2, float* __restrict__ out2, unsigned* done) {
+  __shared__ float s_g[kOccWaves][CPL * NR_WAVE];
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int s = blockIdx.x * kOccWaves + wave;
+  const bool active = s < n_occ;
+  uint64_t key = 0;
+  float acc[CPL];
+  if (active) {
+    key = plan_key(skey, s);
+    mf_occurrence<CPL, PAIR>(P, Q, d, users, items, third, batch, reg, scale, loss_kind,
+                             (uint32_t)key, lane, acc, term_mf, term_l2, true);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) s_g[wave][lane + c * NR_WAVE] = acc[c];
+  }
+  __syncthreads();
+  if (active) {
+    const uint32_t row = (uint32_t)(key >> 32);
+    const bool head = s == 0 || (uint32_t)(plan_key(skey, s - 1) >> 32) != row;
+    if (head) {
+      for (int t = 1; s + t < n_occ; ++t) {
+        const uint64_t k2 = plan_key(skey, s + t);
+        if ((uint32_t)(k2 >> 32) != row) break;
+        if (wave + t < kOccWaves) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] += s_g[wave + t][lane + c * NR_WAVE];
+        } else {                                  // the run leaves this workgroup: recompute
+          float more[CPL];
+          mf_occurrence<CPL, PAIR>(P, Q, d, users, items, third, batch, reg, scale, loss_kind,
+                                   (uint32_t)k2, lane, more, term_mf, term_l2, false);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] += more[c];
+        }
+      }
+      float* dst = row < (uint32_t)n_users ? GP + (int64_t)row * d
+                                           : GQ + (int64_t)(row - (uint32_t)n_users) * d;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int k = lane + c * NR_WAVE;
+        if (k < d) dst[k] = acc[c];
+      }
+    }
+  }
+  finish_loss(term_mf, term_l2, batch, reg, out2, done);
+}
+
+// ---- LightGCN head -----------------------------------------------------------------------------
+template <int CPL>
+__device__ __forceinline__ void lightgcn_occurrence(
+    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
+    float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, float reg, float grad_div, uint32_t p, int lane,
+    float (&h)[CPL], float (&r)[CPL], float* __restrict__ term_mf, float* __restrict__ term_l2,
+    bool write_terms) {
+  const int cls = (int)(p / (uint32_t)batch), b = (int)(p - (uint32_t)cls * (uint32_t)batch);
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
+  const int64_t j = (int64_t)n_users + __builtin_amdgcn_readfirstlane(neg[b]);
+  float eu[CPL], ei[CPL], ej[CPL], z[CPL];
+  load_row<CPL>(Esum, u, d, lane, eu);
+  load_row<CPL>(Esum, i, d, lane, ei);
+  load_row<CPL>(Esum, j, d, lane, ej);
+  load_row<CPL>(E0, cls == 0 ? u : cls == 1 ? i : j, d, lane, z);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {   // E* = mean over layers = sum / (L+1), LightGCN.py:146-147
+    eu[c] = eu[c] / layers_p1;
+    ei[c] = ei[c] / layers_p1;
+    ej[c] = ej[c] / layers_p1;
+  }
+  const float x = dot_rows<CPL>(eu, ei) - dot_rows<CPL>(eu, ej);     // LightGCN.py:157-158,162
+  const float g = nr::bpr_dloss(x);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    // grad_div is 1 or a power of two: dividing each term is then exactly dividing the sum
+    h[c] = cls == 0 ? (g * (ei[c] - ej[c])) / grad_div
+         : cls == 1 ? (g * eu[c]) / grad_div
+                    : (-g * eu[c]) / grad_div;
+    r[c] = reg * z[c];                             // regulariser on layer-0 rows, :160,164
+  }
+  if (write_terms && cls == 0) {
+    float zi[CPL], zj[CPL];
+    load_row<CPL>(E0, i, d, lane, zi);
+    load_row<CPL>(E0, j, d, lane, zj);
+    const float l2 = 0.5f * (dot_rows<CPL>(z, z) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
+    if (lane == 0) {
+      __hip_atomic_store(&term_mf[b], nr::bpr_loss(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kernel(
+    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
+    float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, const uint64_t* __restrict__ skey, int n_occ,
+    float reg, float* __restrict__ Gstar, float* __restrict__ Greg, float* __restrict__ term_mf,
+    float* __restrict__ term_l2, float grad_div, float* __restrict__ out2, unsigned* done) {
+  __shared__ float s_h[kOccWaves][CPL * NR_WAVE];
+  __shared__ float s_r[kOccWaves][CPL * NR_WAVE];
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int s = blockIdx.x * kOccWaves + wave;
+  const bool active = s < n_occ;
+  uint64_t key = 0;
+  float h[CPL], r[CPL];
+  if (active) {
+    key = plan_key(skey, s);
+    lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
+                             (uint32_t)key, lane, h, r, term_mf, term_l2, true);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      s_h[wave][lane + c * NR_WAVE] = h[c];
+      s_r[wave][lane + c * NR_WAVE] = r[c];
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const uint32_t row = (uint32_t)(key >> 32);
+    const bool head = s == 0 || (uint32_t)(plan_key(skey, s - 1) >> 32) != row;
+    if (head) {
+      for (int t = 1; s + t < n_occ; ++t) {
+        const uint64_t k2 = plan_key(skey, s + t);
+        if ((uint32_t)(k2 >> 32) != row) break;
+        if (wave + t < kOccWaves) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            h[c] += s_h[wave + t][lane + c * NR_WAVE];
+            r[c] += s_r[wave + t][lane + c * NR_WAVE];
+          }
+        } else {                                  // the run leaves this workgroup: recompute
+          float h2[CPL], r2[CPL];
+          lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg,
+                                   grad_div, (uint32_t)k2, lane, h2, r2, term_mf, term_l2, false);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            h[c] += h2[c];
+            r[c] += r2[c];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int k = lane + c * NR_WAVE;
+        if (k < d) {
+          Gstar[(int64_t)row * d + k] = h[c];
+          Greg[(int64_t)row * d + k] = r[c];
+        }
+      }
+    }
+  }
+  finish_loss(term_mf, term_l2, batch, reg, out2, done);
+}
+
+// NRHIP_ATOMIC_SCATTER=1: the former one-wave-per-triplet kernels (fp32 hardware atomics, row sums
+// in arbitrary order) — an A/B knob for measurements, not a product path.
+bool atomic_scatter_knob() {
+  static const bool on = [] {
+    const char* e = getenv("NRHIP_ATOMIC_SCATTER");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
+// np2 >= n, a power of two, at least 2
+int plan_pow2(int n) {
+  int p = 2;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+int launch_plan(const int32_t* d_users, const int32_t* d_items, const int32_t* d_third,
+                int64_t n_total, int batch, int n_cls, int n_users, uint64_t* d_skey,
+                hipStream_t st) {
+  NR_REQUIRE((int64_t)(n_cls - 1) * batch <= kPlanMaxKeys, NR_ERR_UNSUPPORTED,
+             "bpr_plan: batch %d too large for the deterministic aggregation (at most %d item "
+             "occurrences per batch); NRHIP_ATOMIC_SCATTER=1 lifts the limit", batch, kPlanMaxKeys);
+  static bool attr_set = false;
+  if (!attr_set) {
+    NR_CHECK_HIP(hipFuncSetAttribute((const void*)bpr_plan_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kPlanMaxKeys * (int)sizeof(uint64_t)));
+    attr_set = true;
+  }
+  const int nb_max = (int)(n_total < (int64_t)batch ? n_total : (int64_t)batch);
+  const int np2_user = plan_pow2(nb_max), np2_item = plan_pow2((n_cls - 1) * nb_max);
+  const int64_t n_batches = (n_total + batch - 1) / batch;
+  hipLaunchKernelGGL(bpr_plan_kernel, dim3((unsigned)n_batches, 2), dim3(kPlanThreads),
+                     (size_t)np2_item * sizeof(uint64_t), st, d_users, d_items, d_third, n_total,
+                     batch, n_cls, n_users, np2_user, np2_item, d_skey);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+// the plan to use: the caller's, or one sorted now into the tail of the work buffer
+// (d_work = [2·batch loss terms][3·batch keys] as floats: 8·batch floats in all)
+int resolve_plan(const uint64_t* d_plan, const int32_t* d_users, const int32_t* d_items,
+                 const int32_t* d_third, int batch, int n_cls, int n_users, float* d_work,
+                 hipStream_t st, const uint64_t** out) {
+  if (d_plan) {
+    *out = d_plan;
+    return NR_OK;
+  }
+  uint64_t* own = (uint64_t*)(d_work + 2 * (size_t)batch);
+  NR_REQUIRE(((uintptr_t)own & 7u) == 0, NR_ERR_ARG, "work buffer is not 8-byte aligned");
+  int rc = launch_plan(d_users, d_items, d_third, batch, batch, n_cls, n_users, own, st);
+  *out = own;
+  return rc;
+}
+
 unsigned* next_done_counter() {
   static std::atomic<unsigned*> base[64];          // the symbol has one address per device
   static std::atomic<unsigned> next{0};
@@ -270,14 +602,36 @@ unsigned* next_done_counter() {
 
 extern "C" {
 
-static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q, int d,
+int nrhip_bpr_plan(const int32_t* d_users, const int32_t* d_items, const int32_t* d_third,
+                   int64_t n_total, int batch, int n_users, uint64_t* d_plan_out, void* stream) {
+  NR_REQUIRE(d_users && d_items && d_plan_out, NR_ERR_ARG, "bpr_plan: null pointer argument");
+  NR_REQUIRE(n_total >= 0 && batch >= 1 && n_users >= 0, NR_ERR_ARG, "bpr_plan: bad sizes");
+  if (n_total == 0) return NR_OK;
+  return launch_plan(d_users, d_items, d_third, n_total, batch, d_third ? 3 : 2, n_users,
+                     d_plan_out, (hipStream_t)stream);
+}
+
+#define NR_BY_WIDTH(KERNEL, ...)                                                          \
+  do {                                                                                    \
+    if (d <= 64) hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, st, __VA_ARGS__);        \
+    else if (d <= 128) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, st, __VA_ARGS__);                \
+  } while (0)
+#define NR_BY_WIDTH2(KERNEL, FLAG, ...)                                                         \
+  do {                                                                                          \
+    if (d <= 64) hipLaunchKernelGGL((KERNEL<1, FLAG>), grid, block, 0, st, __VA_ARGS__);        \
+    else if (d <= 128) hipLaunchKernelGGL((KERNEL<2, FLAG>), grid, block, 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<4, FLAG>), grid, block, 0, st, __VA_ARGS__);                \
+  } while (0)
+
+static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q, int d, int n_users,
                             const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
                             int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
-                            float* d_terms, float* d_loss2, void* stream) {
-  NR_REQUIRE(d_P && d_Q && d_users && d_pos && d_neg && d_GP && d_GQ && d_terms && d_loss2,
+                            float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream) {
+  NR_REQUIRE(d_P && d_Q && d_users && d_pos && d_neg && d_GP && d_GQ && d_work && d_loss2,
              NR_ERR_ARG, "%s: null pointer argument", who);
   NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED, "%s: embedding dim %d outside 1..256", who, d);
-  NR_REQUIRE(batch >= 0, NR_ERR_ARG, "%s: negative batch", who);
+  NR_REQUIRE(batch >= 0 && n_users >= 0, NR_ERR_ARG, "%s: negative batch / n_users", who);
   NR_REQUIRE(loss_kind >= nr::NR_PAIR_BPR && loss_kind <= nr::NR_PAIR_SQUARE, NR_ERR_ARG,
              "%s: unknown pairwise loss %d (0 bpr, 1 hinge, 2 square)", who, loss_kind);
   hipStream_t st = (hipStream_t)stream;
@@ -285,48 +639,53 @@ static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q,
     NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
     return NR_OK;
   }
-  float* t_mf = d_terms;
-  float* t_l2 = d_terms + batch;
-  dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+  float* t_mf = d_work;
+  float* t_l2 = d_work + batch;
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (d <= 64)
-    hipLaunchKernelGGL(bpr_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
-  else if (d <= 128)
-    hipLaunchKernelGGL(bpr_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
-  else
-    hipLaunchKernelGGL(bpr_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_pos,
-                       d_neg, batch, reg, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
+  if (atomic_scatter_knob()) {
+    dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+    NR_BY_WIDTH(bpr_mf_grad_kernel, d_P, d_Q, d, d_users, d_pos, d_neg, batch, reg, d_GP, d_GQ, t_mf,
+                t_l2, loss_kind, d_loss2, done);
+  } else {
+    const uint64_t* plan = nullptr;
+    int rc = resolve_plan(d_plan, d_users, d_pos, d_neg, batch, 3, n_users, d_work, st, &plan);
+    if (rc != NR_OK) return rc;
+    const int n_occ = 3 * batch;
+    dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
+    NR_BY_WIDTH2(mf_grad_sorted_kernel, true, d_P, d_Q, d, n_users, d_users, d_pos,
+                 (const void*)d_neg, batch, plan, n_occ, reg, 1.0f, loss_kind, d_GP, d_GQ, t_mf, t_l2,
+                 d_loss2, done);
+  }
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
 
-int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                      const int32_t* d_pos, const int32_t* d_neg, int batch, float reg, float* d_GP,
-                      float* d_GQ, float* d_terms, float* d_loss2, void* stream) {
-  return pairwise_mf_grad("bpr_mf_grad", d_P, d_Q, d, d_users, d_pos, d_neg, batch, reg,
-                          nr::NR_PAIR_BPR, d_GP, d_GQ, d_terms, d_loss2, stream);
+int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
+                      const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                      float reg, float* d_GP, float* d_GQ, float* d_work, float* d_loss2,
+                      const uint64_t* d_plan, void* stream) {
+  return pairwise_mf_grad("bpr_mf_grad", d_P, d_Q, d, n_users, d_users, d_pos, d_neg, batch, reg,
+                          nr::NR_PAIR_BPR, d_GP, d_GQ, d_work, d_loss2, d_plan, stream);
 }
 
-int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                           const int32_t* d_pos, const int32_t* d_neg, int batch, float reg,
-                           int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
-                           void* stream) {
-  return pairwise_mf_grad("pairwise_mf_grad", d_P, d_Q, d, d_users, d_pos, d_neg, batch, reg,
-                          loss_kind, d_GP, d_GQ, d_terms, d_loss2, stream);
+int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
+                           const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                           int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
+                           float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream) {
+  return pairwise_mf_grad("pairwise_mf_grad", d_P, d_Q, d, n_users, d_users, d_pos, d_neg, batch,
+                          reg, loss_kind, d_GP, d_GQ, d_work, d_loss2, d_plan, stream);
 }
 
-int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, const int32_t* d_users,
-                            const int32_t* d_items, const float* d_labels, int batch, float reg,
-                            int loss_kind, float* d_GP, float* d_GQ, float* d_terms, float* d_loss2,
-                            void* stream) {
-  NR_REQUIRE(d_P && d_Q && d_users && d_items && d_labels && d_GP && d_GQ && d_terms && d_loss2,
+int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
+                            const int32_t* d_users, const int32_t* d_items, const float* d_labels,
+                            int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
+                            float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream) {
+  NR_REQUIRE(d_P && d_Q && d_users && d_items && d_labels && d_GP && d_GQ && d_work && d_loss2,
              NR_ERR_ARG, "pointwise_mf_grad: null pointer argument");
   NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
              "pointwise_mf_grad: embedding dim %d outside 1..256", d);
-  NR_REQUIRE(batch >= 0, NR_ERR_ARG, "pointwise_mf_grad: negative batch");
+  NR_REQUIRE(batch >= 0 && n_users >= 0, NR_ERR_ARG, "pointwise_mf_grad: negative batch / n_users");
   NR_REQUIRE(loss_kind == nr::NR_POINT_CROSS_ENTROPY || loss_kind == nr::NR_POINT_SQUARE, NR_ERR_ARG,
              "pointwise_mf_grad: unknown pointwise loss %d (0 cross_entropy, 1 square)", loss_kind);
   hipStream_t st = (hipStream_t)stream;
@@ -334,22 +693,26 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, const int
     NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
     return NR_OK;
   }
-  float* t_mf = d_terms;
-  float* t_l2 = d_terms + batch;
+  float* t_mf = d_work;
+  float* t_l2 = d_work + batch;
   // tf.losses.sigmoid_cross_entropy averages over the batch; the squared loss is a plain sum
   const float scale = loss_kind == nr::NR_POINT_CROSS_ENTROPY ? 1.0f / (float)batch : 1.0f;
-  dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (d <= 64)
-    hipLaunchKernelGGL(pointwise_mf_grad_kernel<1>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
-                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
-  else if (d <= 128)
-    hipLaunchKernelGGL(pointwise_mf_grad_kernel<2>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
-                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
-  else
-    hipLaunchKernelGGL(pointwise_mf_grad_kernel<4>, grid, block, 0, st, d_P, d_Q, d, d_users, d_items,
-                       d_labels, batch, reg, scale, d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
+  if (atomic_scatter_knob()) {
+    dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+    NR_BY_WIDTH(pointwise_mf_grad_kernel, d_P, d_Q, d, d_users, d_items, d_labels, batch, reg, scale,
+                d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
+  } else {
+    const uint64_t* plan = nullptr;
+    int rc = resolve_plan(d_plan, d_users, d_items, nullptr, batch, 2, n_users, d_work, st, &plan);
+    if (rc != NR_OK) return rc;
+    const int n_occ = 2 * batch;
+    dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
+    NR_BY_WIDTH2(mf_grad_sorted_kernel, false, d_P, d_Q, d, n_users, d_users, d_items,
+                 (const void*)d_labels, batch, plan, n_occ, reg, scale, loss_kind, d_GP, d_GQ, t_mf,
+                 t_l2, d_loss2, done);
+  }
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -369,9 +732,9 @@ int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, cons
 
 static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
                          const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                         int batch, float reg, float* d_Gstar, float* d_Greg, float* d_terms,
-                         float* d_loss2, float grad_div, void* stream) {
-  NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_terms,
+                         int batch, float reg, float* d_Gstar, float* d_Greg, float* d_work,
+                         float* d_loss2, float grad_div, const uint64_t* d_plan, void* stream) {
+  NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_work,
              NR_ERR_ARG, "lightgcn_bpr_grad: null pointer argument");
   NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
              "lightgcn_bpr_grad: embedding dim %d outside 1..256", d);
@@ -382,21 +745,24 @@ static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, in
     if (d_loss2) NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
     return NR_OK;
   }
-  float* t_mf = d_terms;
-  float* t_l2 = d_terms + batch;
+  float* t_mf = d_work;
+  float* t_l2 = d_work + batch;
   const float lp1 = (float)(n_layers + 1);
-  dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (d <= 64)
-    hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<1>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
-  else if (d <= 128)
-    hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<2>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
-  else
-    hipLaunchKernelGGL(lightgcn_bpr_grad_kernel<4>, grid, block, 0, st, d_Esum, d_E0, n_users, d,
-                       lp1, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
+  if (atomic_scatter_knob()) {
+    dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
+    NR_BY_WIDTH(lightgcn_bpr_grad_kernel, d_Esum, d_E0, n_users, d, lp1, d_users, d_pos, d_neg, batch,
+                reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
+  } else {
+    const uint64_t* plan = nullptr;
+    int rc = resolve_plan(d_plan, d_users, d_pos, d_neg, batch, 3, n_users, d_work, st, &plan);
+    if (rc != NR_OK) return rc;
+    const int n_occ = 3 * batch;
+    dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
+    NR_BY_WIDTH(lightgcn_grad_sorted_kernel, d_Esum, d_E0, n_users, d, lp1, d_users, d_pos, d_neg,
+                batch, plan, n_occ, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
+  }
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -404,22 +770,24 @@ static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, in
 int nrhip_lightgcn_bpr_grad(const float* d_Esum, const float* d_E0, int n_users, int d,
                             int n_layers, const int32_t* d_users, const int32_t* d_pos,
                             const int32_t* d_neg, int batch, float reg, float* d_Gstar,
-                            float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
+                            float* d_Greg, float* d_work, float* d_loss2, const uint64_t* d_plan,
+                            void* stream) {
   return lightgcn_head(d_Esum, d_E0, n_users, d, n_layers, d_users, d_pos, d_neg, batch, reg,
-                       d_Gstar, d_Greg, d_terms, d_loss2, 1.0f, stream);
+                       d_Gstar, d_Greg, d_work, d_loss2, 1.0f, d_plan, stream);
 }
 
-/* Same head, accumulating dLoss/dE* already divided by (n_layers+1) — the H = Gstar/(L+1) of the
+/* Same head, writing dLoss/dE* already divided by (n_layers+1) — the H = Gstar/(L+1) of the
  * backward pass — into d_H.  Only when L+1 is a power of two: dividing every term is then
  * bit-identical to dividing the sum, and the rows_div pass disappears. */
 int nrhip_lightgcn_bpr_grad_h(const float* d_Esum, const float* d_E0, int n_users, int d,
                               int n_layers, const int32_t* d_users, const int32_t* d_pos,
                               const int32_t* d_neg, int batch, float reg, float* d_H,
-                              float* d_Greg, float* d_terms, float* d_loss2, void* stream) {
+                              float* d_Greg, float* d_work, float* d_loss2, const uint64_t* d_plan,
+                              void* stream) {
   NR_REQUIRE(n_layers >= 0 && ((n_layers + 1) & n_layers) == 0, NR_ERR_ARG,
              "lightgcn_bpr_grad_h: n_layers + 1 = %d is not a power of two", n_layers + 1);
   return lightgcn_head(d_Esum, d_E0, n_users, d, n_layers, d_users, d_pos, d_neg, batch, reg, d_H,
-                       d_Greg, d_terms, d_loss2, (float)(n_layers + 1), stream);
+                       d_Greg, d_work, d_loss2, (float)(n_layers + 1), d_plan, stream);
 }
 
 }  // extern "C"

@@ -78,8 +78,9 @@ struct AdamArgs { float alpha, beta1, beta2, eps; };
 // adam != nullptr: the caller wants the optimiser applied too; when the last backward hop can
 // carry it as a fused epilogue (d = 64 lane-group schedule, L >= 2) *g_out comes back NULL.
 static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_users,
-                            const int32_t* d_pos, const int32_t* d_neg, int batch, float* d_loss2,
-                            void* stream, const float** g_out, const AdamArgs* adam = nullptr,
+                            const int32_t* d_pos, const int32_t* d_neg, int batch,
+                            const uint64_t* d_plan, float* d_loss2, void* stream,
+                            const float** g_out, const AdamArgs* adam = nullptr,
                             bool* rearmed = nullptr) {
   const int L = b.n_layers, d = b.d;
   const bool skip = d >= 64;                 // the work-skipping variants exist for d >= 64
@@ -132,10 +133,10 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
   if (((L + 1) & L) == 0) {
     // L+1 a power of two (the configured L = 3): the head accumulates H directly — exact
     NR_TRY(nrhip_lightgcn_bpr_grad_h(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch,
-                                     b.reg, b.H, b.Greg, b.terms, d_loss2, stream));
+                                     b.reg, b.H, b.Greg, b.terms, d_loss2, d_plan, stream));
   } else {
     NR_TRY(nrhip_lightgcn_bpr_grad(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
-                                   b.Gstar, b.Greg, b.terms, d_loss2, stream));
+                                   b.Gstar, b.Greg, b.terms, d_loss2, d_plan, stream));
     NR_TRY(nrhip_rows_div(b.batch_rows, 3 * batch, d, b.Gstar, (float)(L + 1), b.H, stream));
   }
   const float* g = b.H;
@@ -178,15 +179,16 @@ static int lightgcn_check(void* ctx, const int32_t* u, const int32_t* p, const i
 
 // One training step (LightGCN.py:178); neurec_amd/trainer.py:LightGCNEngine documents the sequence.
 int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
-                        const int32_t* d_neg, int batch, float alpha, float beta1, float beta2,
-                        float eps, float* d_loss2, void* stream) {
+                        const int32_t* d_neg, int batch, const uint64_t* d_plan, float alpha,
+                        float beta1, float beta2, float eps, float* d_loss2, void* stream) {
   NR_TRY(lightgcn_check(ctx, d_users, d_pos, d_neg, batch));
   if (batch == 0) return NR_OK;
   const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
   const float* g = nullptr;
   const AdamArgs adam{alpha, beta1, beta2, eps};
   bool rearmed = false;
-  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_loss2, stream, &g, &adam, &rearmed));
+  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_plan, d_loss2, stream, &g, &adam,
+                          &rearmed));
   if (g)   // not folded into the last hop
     NR_TRY(nrhip_adam_dense_tf2(b.E0, b.m, b.v, g, b.Greg, (int64_t)b.n_nodes * b.d, alpha, beta1,
                                 beta2, eps, stream));
@@ -199,8 +201,8 @@ int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
 // Multi-GPU form: the same step cut at its one exchange point.  _grad leaves this rank's total
 // dL/dE0 (G_0 + reg rows) in d_grad_out; the caller all-reduces it; _apply runs Adam on it.
 int nrhip_lightgcn_step_grad(void* ctx, const int32_t* d_users, const int32_t* d_pos,
-                             const int32_t* d_neg, int batch, float* d_loss2, float* d_grad_out,
-                             void* stream) {
+                             const int32_t* d_neg, int batch, const uint64_t* d_plan,
+                             float* d_loss2, float* d_grad_out, void* stream) {
   NR_TRY(lightgcn_check(ctx, d_users, d_pos, d_neg, batch));
   NR_REQUIRE(d_grad_out, NR_ERR_ARG, "lightgcn_step_grad: null output");
   const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
@@ -210,7 +212,7 @@ int nrhip_lightgcn_step_grad(void* ctx, const int32_t* d_users, const int32_t* d
     return NR_OK;
   }
   const float* g = nullptr;
-  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_loss2, stream, &g));
+  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_plan, d_loss2, stream, &g));
   NR_TRY(nrhip_add(g, b.Greg, d_grad_out, n, stream));
   NR_TRY(nrhip_rows_clear(b.batch_rows, 3 * batch, b.d, b.Gstar, b.Greg, b.H, nullptr, b.row_flag,
                           stream));
@@ -246,14 +248,14 @@ int nrhip_mf_ctx_destroy(void* ctx) {
 
 // One BPR-MF step = sess.run((loss, optimizer)) (MF.py:101)
 int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, float alpha, float beta1, float beta2, float eps, float* d_loss2,
-                  void* stream) {
+                  int batch, const uint64_t* d_plan, float alpha, float beta1, float beta2, float eps,
+                  float* d_loss2, void* stream) {
   NR_REQUIRE(ctx && d_users && d_pos && d_neg && d_loss2, NR_ERR_ARG, "mf_step: null argument");
   const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
   NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG, "mf_step: batch %d outside 0..%d",
              batch, b.max_batch);
-  NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ, b.terms,
-                           d_loss2, stream));
+  NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, b.n_users, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ,
+                           b.terms, d_loss2, d_plan, stream));
   const int64_t nu = (int64_t)b.n_users * b.d, ni = (int64_t)b.n_items * b.d;
   if (b.Q == b.P + nu && b.mQ == b.mP + nu && b.vQ == b.vP + nu && b.GQ == b.GP + nu) {
     // both tables (and their moments / gradients) are one allocation: one sweep, one launch

@@ -73,6 +73,9 @@ class PairwiseSampler(Sampler):
             _generate_positive_items(self.user_pos_dict)
         self._seed = seed
         self._device_sampler = None
+        # device batches carry their batch plan (ordered row-gradient sums) keyed for this many
+        # user rows — the model's table height
+        self._plan_users = getattr(dataset, "num_users", None) if as_tensors else None
 
     def _device(self):
         if self._device_sampler is None:
@@ -81,14 +84,16 @@ class PairwiseSampler(Sampler):
             csr = E.DeviceCSR.from_dict(self.user_pos_dict, max(self.user_pos_dict) + 1, self.item_num)
             self._device_sampler = BprEpochSampler(csr, self.item_num, neg_num=self.neg_num,
                                                    batch_size=self.batch_size, shuffle=self.shuffle,
-                                                   drop_last=self.drop_last, seed=self._seed)
+                                                   drop_last=self.drop_last, seed=self._seed,
+                                                   plan_users=self._plan_users)
         return self._device_sampler
 
     def __iter__(self):
-        for users, pos, neg in self._device().batches():
+        for batch in self._device().batches():
             if self.as_tensors:
-                yield users, pos, neg
+                yield batch              # a 3-tuple of device tensors; `.plan` = its batch plan
             else:
+                users, pos, neg = batch
                 yield users.tolist(), pos.tolist(), neg.tolist()
 
     def __len__(self):

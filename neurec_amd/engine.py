@@ -357,10 +357,33 @@ def rows_clear(rows, d, bufs=(), flag=None):
          _ptr(b[3], allow_none=True), _ptr(flag, allow_none=True), _stream())
 
 
-def bpr_mf_grad(P, Q, users, pos, neg, reg, GP, GQ, terms, loss2):
-    call("nrhip_bpr_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
+def bpr_plan(users, items, third, batch, n_users, out=None):
+    """Batch plans of a whole stream of (user, item[, third]) ids cut into batches of `batch`:
+    uint64 keys (row << 32 | position; item rows offset by n_users) sorted per batch — the order
+    in which the gradient kernels add the occurrences of a row (TF's unsorted_segment_sum order).
+    Returned as an int64 tensor of n_cls * len(users) keys; batch k's slice starts at
+    n_cls * k * batch."""
+    n = users.numel()
+    n_cls = 2 if third is None else 3
+    if out is None:
+        out = torch.empty(max(n_cls * n, 1), dtype=torch.int64, device=users.device)
+    call("nrhip_bpr_plan", _ptr(users, torch.int32), _ptr(items, torch.int32),
+         _ptr(third, torch.int32, allow_none=True), n, int(batch), int(n_users),
+         _ptr(out, torch.int64), _stream())
+    return out[:n_cls * n]
+
+
+def _work(terms, batch):
+    if terms.numel() < 8 * batch:
+        raise ValueError("work buffer holds %d floats, 8 * batch = %d needed" % (terms.numel(), 8 * batch))
+    return _ptr(terms, torch.float32)
+
+
+def bpr_mf_grad(P, Q, users, pos, neg, reg, GP, GQ, terms, loss2, plan=None):
+    call("nrhip_bpr_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1], P.shape[0],
          _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32), users.numel(),
-         float(reg), _ptr(GP), _ptr(GQ), _ptr(terms), _ptr(loss2), _stream())
+         float(reg), _ptr(GP), _ptr(GQ), _work(terms, users.numel()), _ptr(loss2),
+         _ptr(plan, torch.int64, allow_none=True), _stream())
 
 
 PAIRWISE_LOSSES = {"bpr": 0, "hinge": 1, "square": 2}                # learner.py:19-29
@@ -368,17 +391,18 @@ POINTWISE_LOSSES = {"cross_entropy": 0, "square": 1}                  # learner.
 ROW_OPTIMIZERS = {"gd": 0, "adagrad": 1, "rmsprop": 2, "momentum": 3}  # learner.py:2-16 (adam: adam_sparse)
 
 
-def pairwise_mf_grad(P, Q, users, pos, neg, reg, loss, GP, GQ, terms, loss2):
+def pairwise_mf_grad(P, Q, users, pos, neg, reg, loss, GP, GQ, terms, loss2, plan=None):
     call("nrhip_pairwise_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
-         _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32), users.numel(),
-         float(reg), PAIRWISE_LOSSES[loss], _ptr(GP), _ptr(GQ), _ptr(terms), _ptr(loss2), _stream())
+         P.shape[0], _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32),
+         users.numel(), float(reg), PAIRWISE_LOSSES[loss], _ptr(GP), _ptr(GQ),
+         _work(terms, users.numel()), _ptr(loss2), _ptr(plan, torch.int64, allow_none=True), _stream())
 
 
-def pointwise_mf_grad(P, Q, users, items, labels, reg, loss, GP, GQ, terms, loss2):
+def pointwise_mf_grad(P, Q, users, items, labels, reg, loss, GP, GQ, terms, loss2, plan=None):
     call("nrhip_pointwise_mf_grad", _ptr(P, torch.float32), _ptr(Q, torch.float32), P.shape[1],
-         _ptr(users, torch.int32), _ptr(items, torch.int32), _ptr(labels, torch.float32),
-         users.numel(), float(reg), POINTWISE_LOSSES[loss], _ptr(GP), _ptr(GQ), _ptr(terms),
-         _ptr(loss2), _stream())
+         P.shape[0], _ptr(users, torch.int32), _ptr(items, torch.int32), _ptr(labels, torch.float32),
+         users.numel(), float(reg), POINTWISE_LOSSES[loss], _ptr(GP), _ptr(GQ),
+         _work(terms, users.numel()), _ptr(loss2), _ptr(plan, torch.int64, allow_none=True), _stream())
 
 
 def mark_rows(ids, flag, offset=0):
@@ -401,11 +425,13 @@ def lightgcn_mark_batch(users, pos, neg, n_users, rows_out, row_flag):
          _ptr(row_flag, torch.uint8), _stream())
 
 
-def lightgcn_bpr_grad(Esum, E0, n_users, n_layers, users, pos, neg, reg, Gstar, Greg, terms, loss2):
+def lightgcn_bpr_grad(Esum, E0, n_users, n_layers, users, pos, neg, reg, Gstar, Greg, terms, loss2,
+                      plan=None):
     call("nrhip_lightgcn_bpr_grad", _ptr(Esum, torch.float32), _ptr(E0, torch.float32), n_users,
          E0.shape[1], n_layers, _ptr(users, torch.int32), _ptr(pos, torch.int32),
-         _ptr(neg, torch.int32), users.numel(), float(reg), _ptr(Gstar), _ptr(Greg), _ptr(terms),
-         _ptr(loss2, allow_none=True), _stream())
+         _ptr(neg, torch.int32), users.numel(), float(reg), _ptr(Gstar), _ptr(Greg),
+         _work(terms, users.numel()), _ptr(loss2, allow_none=True),
+         _ptr(plan, torch.int64, allow_none=True), _stream())
 
 
 def scale(x, a, out):
@@ -637,24 +663,32 @@ class NativeStep:
             raise TypeError("batch ids must be contiguous int32 device tensors")
         return C.c_void_p(t.data_ptr())
 
-    def lightgcn_step(self, users, pos, neg, st, loss2=None):
-        call("nrhip_lightgcn_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
-             users.numel(), float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
-             _ptr(loss2, allow_none=True), _stream())
+    @staticmethod
+    def _plan(plan, n_occ):
+        if plan is None:
+            return C.c_void_p(0)
+        if plan.dtype != torch.int64 or not plan.is_cuda or plan.numel() != n_occ:
+            raise TypeError("batch plan must be the int64 device tensor of %d keys bpr_plan made" % n_occ)
+        return C.c_void_p(plan.data_ptr())
 
-    def lightgcn_step_grad(self, users, pos, neg, loss2, grad_out):
+    def lightgcn_step(self, users, pos, neg, st, loss2=None, plan=None):
+        call("nrhip_lightgcn_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
+             users.numel(), self._plan(plan, 3 * users.numel()), float(st.alpha()), float(st.beta1),
+             float(st.beta2), float(st.eps), _ptr(loss2, allow_none=True), _stream())
+
+    def lightgcn_step_grad(self, users, pos, neg, loss2, grad_out, plan=None):
         call("nrhip_lightgcn_step_grad", self.handle, self._idx(users), self._idx(pos),
-             self._idx(neg), users.numel(), _ptr(loss2, allow_none=True),
-             _ptr(grad_out, torch.float32), _stream())
+             self._idx(neg), users.numel(), self._plan(plan, 3 * users.numel()),
+             _ptr(loss2, allow_none=True), _ptr(grad_out, torch.float32), _stream())
 
     def lightgcn_step_apply(self, grad, st):
         call("nrhip_lightgcn_step_apply", self.handle, _ptr(grad, torch.float32),
              float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps), _stream())
 
-    def mf_step(self, users, pos, neg, st, loss2):
+    def mf_step(self, users, pos, neg, st, loss2, plan=None):
         call("nrhip_mf_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
-             users.numel(), float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
-             _ptr(loss2, torch.float32), _stream())
+             users.numel(), self._plan(plan, 3 * users.numel()), float(st.alpha()), float(st.beta1),
+             float(st.beta2), float(st.eps), _ptr(loss2, torch.float32), _stream())
 
 
 def device_info():

@@ -66,8 +66,9 @@ class LightGCN(AbstractRecommender):
         loss2 = torch.zeros(2, device=self.engine.E0.device)
         self.logger.info(self.evaluator.metrics_info())
         for epoch in range(self.epochs):
-            for bat_users, bat_pos_items, bat_neg_items in data_iter:
-                self.engine.step(bat_users, bat_pos_items, bat_neg_items, loss2)
+            for batch in data_iter:
+                bat_users, bat_pos_items, bat_neg_items = batch
+                self.engine.step(bat_users, bat_pos_items, bat_neg_items, loss2, plan=batch.plan)
             result = self.evaluate_model()
             self.logger.info("epoch %d:\t%s" % (epoch, result))
 

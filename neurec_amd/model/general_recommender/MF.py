@@ -67,12 +67,16 @@ class MF(AbstractRecommender):
         for epoch in range(1, self.num_epochs + 1):
             training_start_time = time()
             n = 0
-            for bat_users, bat_items, bat_third in data_iter:
+            for batch in data_iter:
+                bat_users, bat_items, bat_third = batch
                 if self.is_pairwise is not True:      # host lists from the pointwise iterator
                     bat_users = torch.tensor(bat_users, dtype=torch.int32, device=dev)
                     bat_items = torch.tensor(bat_items, dtype=torch.int32, device=dev)
                     bat_third = torch.tensor(bat_third, dtype=torch.float32, device=dev)
-                self.engine.step(bat_users, bat_items, bat_third, losses[n])
+                if self._fast:                        # the batch's plan came with it from the sampler
+                    self.engine.step(bat_users, bat_items, bat_third, losses[n], plan=batch.plan)
+                else:
+                    self.engine.step(bat_users, bat_items, bat_third, losses[n])
                 n += 1
             per_step = losses[:n].cpu().numpy()           # one D2H copy per epoch
             total_loss = 0.0

@@ -9,10 +9,13 @@ update_count, keep_prob 0.8) and log lines.
 What is mirrored on purpose (stated rather than hidden):
   * only int(num_users / batch_size) batches run per epoch — the tail users are skipped
     (MultiVAE.py:147);
-  * `predict` feeds ONE rating row that is never cleared between the users of a call, so user
-    k of a predict batch is scored on the union of the histories of users 0..k
-    (MultiVAE.py:186-206).  `predict_accumulates_rows = True` reproduces that; set the
-    attribute to False for the per-user input the paper describes.
+What is NOT mirrored by default:
+  * the reference's `predict` feeds ONE rating row that is never cleared between the users of a
+    call, so user k of a predict batch is scored on the union of the histories of users 0..k
+    (MultiVAE.py:186-206): the metrics then depend on how test users are batched and other users'
+    interactions leak into every score.  Here each user is scored on their own history (the model
+    that was trained).  `--reference_predict_rows=True` (or `predict_accumulates_rows = True`) is
+    the explicit compatibility switch that reproduces the reference's rows; it is logged when on.
 Restriction: the kernels are built for the two-layer shape p_dim=[z, h] with h <= 32, z <= 16
 (the configured [16, 32]); other shapes raise NotImplementedError.
 """
@@ -26,7 +29,7 @@ from ..AbstractRecommender import AbstractRecommender
 
 
 class MultiVAE(AbstractRecommender):
-    predict_accumulates_rows = True
+    predict_accumulates_rows = False
 
     def __init__(self, sess, dataset, conf):
         super(MultiVAE, self).__init__(dataset, conf)
@@ -51,6 +54,11 @@ class MultiVAE(AbstractRecommender):
         self.train_dict = csr_to_user_dict(dataset.train_matrix)
         self.sess = sess
         self.engine = None
+        if "reference_predict_rows" in conf:
+            self.predict_accumulates_rows = bool(conf["reference_predict_rows"])
+        if self.predict_accumulates_rows:
+            self.logger.info("reference_predict_rows=True: predict() accumulates the rating row over "
+                             "the users of a call, as MultiVAE.py:186-206 does")
 
     def build_graph(self):
         from ... import engine as E

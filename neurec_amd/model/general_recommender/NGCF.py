@@ -87,8 +87,9 @@ class NGCF(AbstractRecommender):
             training_start_time = time()
             num_training_instances = len(data_iter)
             n = 0
-            for bat_users, bat_items_pos, bat_items_neg in data_iter:
-                self.engine.step(bat_users, bat_items_pos, bat_items_neg, losses[n])
+            for batch in data_iter:
+                bat_users, bat_items_pos, bat_items_neg = batch
+                self.engine.step(bat_users, bat_items_pos, bat_items_neg, losses[n], plan=batch.plan)
                 n += 1
             total_loss = 0.0
             for a, b in losses[:n].cpu().numpy():

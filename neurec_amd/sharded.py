@@ -57,7 +57,7 @@ class ShardedLightGCN:
         B3 = 3 * self.max_batch
         self.req_rows = z(B3, 2 * self.d)                   # [Esum | E0] rows of my triplets
         self.gc_star, self.gc_reg = z(B3, self.d), z(B3, self.d)
-        self.terms = z(2 * self.max_batch)
+        self.terms = z(8 * self.max_batch)
         self.adam = E.AdamState(lr)
         self._cu = torch.arange(self.max_batch, dtype=torch.int32, device=dev)
         self._cp = self._cu.clone()
@@ -176,7 +176,7 @@ class ShardedMF:
         B3 = 3 * self.max_batch
         self.req = z(B3, self.d)
         self.gP, self.gQ = z(self.max_batch, self.d), z(2 * self.max_batch, self.d)
-        self.terms = z(2 * self.max_batch)
+        self.terms = z(8 * self.max_batch)
         self._ar = torch.arange(2 * self.max_batch, dtype=torch.int32, device=dev)
 
     def step(self, users, pos, neg, loss_out):

@@ -16,11 +16,25 @@ import torch
 from . import engine as E
 
 
+class TripletBatch(tuple):
+    """(users, pos, neg) device views of one batch; `.plan` = the batch's sorted occurrence keys
+    (engine.bpr_plan) or None.  Unpacks like the reference sampler's 3-tuples."""
+    plan = None
+
+    def __new__(cls, users, pos, neg, plan=None):
+        self = super().__new__(cls, (users, pos, neg))
+        self.plan = plan
+        return self
+
+
 class BprEpochSampler:
-    """Per-epoch BPR triplet stream generated on the device (no host round trip)."""
+    """Per-epoch BPR triplet stream generated on the device (no host round trip).  With
+    `plan_users` = the number of user rows of the model that will consume the stream (neg_num = 1)
+    every epoch also gets the batch plans of all its batches in one launch — the order in which
+    the gradient kernels sum the occurrences of a row (engine.bpr_plan)."""
 
     def __init__(self, train_csr, n_items, neg_num=1, batch_size=1024, shuffle=True,
-                 drop_last=False, seed=2018, rank=0, world=1):
+                 drop_last=False, seed=2018, rank=0, world=1, plan_users=None):
         if neg_num <= 0:
             raise ValueError("'neg_num' must be a positive integer.")
         if train_csr.nnz == 0:
@@ -41,6 +55,10 @@ class BprEpochSampler:
         self._users = torch.empty(max(self.n_local, 1), dtype=torch.int32, device=dev)
         self._pos = torch.empty(max(self.n_local, 1), dtype=torch.int32, device=dev)
         self._neg = torch.empty(max(self.n_local * self.neg_num, 1), dtype=torch.int32, device=dev)
+        self.plan_users = None if plan_users is None else int(plan_users)
+        self.plans = self.plan_users is not None and self.neg_num == 1 and 2 * self.batch_size <= 16384
+        self._plan = (torch.empty(max(3 * self.n_local, 1), dtype=torch.int64, device=dev)
+                      if self.plans else None)
 
     def __len__(self):
         if self.drop_last:
@@ -53,6 +71,8 @@ class BprEpochSampler:
                                  self.epoch, self.shuffle, self.lo, self.n_local,
                                  out=(self._users, self._pos, self._neg))
         self.epoch += 1
+        if self.plans and self.n_local > 0:
+            E.bpr_plan(out[0], out[1], out[2], self.batch_size, self.plan_users, out=self._plan)
         return out
 
     def batches(self):
@@ -62,7 +82,9 @@ class BprEpochSampler:
         for k in range(len(self)):
             b, e = k * B, min((k + 1) * B, self.n_local)
             nb = neg[b * self.neg_num:e * self.neg_num]
-            yield users[b:e], pos[b:e], (nb if self.neg_num == 1 else nb.view(-1, self.neg_num))
+            yield TripletBatch(users[b:e], pos[b:e],
+                               nb if self.neg_num == 1 else nb.view(-1, self.neg_num),
+                               self._plan[3 * b:3 * e] if self.plans else None)
 
 
 class MFEngine:
@@ -83,22 +105,23 @@ class MFEngine:
         self.GP, self.GQ = self._g[:nu], self._g[nu:]
         self.reg = float(reg)
         self.adam = E.AdamState(lr)
-        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
         self._ctx = E.NativeStep.for_mf(self)
 
-    def step(self, users, pos, neg, loss_out):
-        """One native call: fused gather/BPR/scatter kernel + the two TF-sparse Adam sweeps.
-        loss_out: 2-float device tensor receiving (bpr_sum, reg_term)."""
-        self._ctx.mf_step(users, pos, neg, self.adam, loss_out)
+    def step(self, users, pos, neg, loss_out, plan=None):
+        """One native call: fused gather/BPR/ordered row sums kernel + the TF-sparse Adam sweep.
+        loss_out: 2-float device tensor receiving (bpr_sum, reg_term); plan: the batch's
+        TripletBatch.plan (None: sorted inside the step)."""
+        self._ctx.mf_step(users, pos, neg, self.adam, loss_out, plan)
         self.adam.advance()
 
-    def step_reference(self, users, pos, neg, loss_out):
+    def step_reference(self, users, pos, neg, loss_out, plan=None):
         """The same step as individual engine calls (what nrhip_mf_step enqueues)."""
         if users.numel() > self.max_batch:
             raise ValueError("batch larger than max_batch")
         E.bpr_mf_grad(self.P, self.Q, users, pos, neg, self.reg, self.GP, self.GQ, self.terms,
-                      loss_out)
+                      loss_out, plan)
         E.adam_sparse(self.P, self.mP, self.vP, self.GP, self.adam)
         E.adam_sparse(self.Q, self.mQ, self.vQ, self.GQ, self.adam)
         self.adam.advance()
@@ -126,7 +149,7 @@ class GeneralMFEngine:
         self.GP, self.GQ = torch.zeros_like(self.P), torch.zeros_like(self.Q)
         self.reg, self.lr, self.momentum = float(reg), float(lr), float(momentum)
         self.adam = E.AdamState(lr)
-        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
         self.flagP = torch.zeros(self.P.shape[0], dtype=torch.uint8, device=dev)
         self.flagQ = torch.zeros(self.Q.shape[0], dtype=torch.uint8, device=dev)
@@ -196,7 +219,7 @@ class LightGCNEngine:
         self.H, self.Ga, self.Gb = z(), z(), z()
         self.reg = float(reg)
         self.adam = E.AdamState(lr)
-        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
         self.Esum_rows = z()                 # E-sum on the batch rows (training steps)
         self.batch_rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
@@ -225,21 +248,22 @@ class LightGCNEngine:
         return Estar[:self.n_users], Estar[self.n_users:]
 
     # -- one training step = sess.run(self.opt) (LightGCN.py:178) ---------------------
-    def step(self, users, pos, neg, loss_out=None, grad_sync=None):
+    def step(self, users, pos, neg, loss_out=None, grad_sync=None, plan=None):
         """One native call enqueues the whole step (csrc/step.hip); `step_reference` below is the
         same launch sequence spelled out in Python.  grad_sync(tensor): optional in-place
-        all-reduce of dL/dE0 across ranks — the step is then cut at that one exchange point."""
+        all-reduce of dL/dE0 across ranks — the step is then cut at that one exchange point.
+        plan: the batch's TripletBatch.plan (None: sorted inside the step, one more launch)."""
         if grad_sync is None:
-            self._ctx.lightgcn_step(users, pos, neg, self.adam, loss_out)
+            self._ctx.lightgcn_step(users, pos, neg, self.adam, loss_out, plan)
         else:
             if self.Gsync is None:
                 self.Gsync = torch.zeros_like(self.E0)
-            self._ctx.lightgcn_step_grad(users, pos, neg, loss_out, self.Gsync)
+            self._ctx.lightgcn_step_grad(users, pos, neg, loss_out, self.Gsync, plan)
             grad_sync(self.Gsync)                # summed over ranks (RCCL all-reduce)
             self._ctx.lightgcn_step_apply(self.Gsync, self.adam)
         self.adam.advance()
 
-    def step_reference(self, users, pos, neg, loss_out=None, grad_sync=None):
+    def step_reference(self, users, pos, neg, loss_out=None, grad_sync=None, plan=None):
         """Same arithmetic as propagating everything, minus work whose result is never read or is
         known to be zero: the loss only reads E* on the 3B batch rows, so the LAST forward hop is
         formed for those rows only; dL/dE* is non-zero on those rows only, so the FIRST backward
@@ -264,7 +288,7 @@ class LightGCNEngine:
                 self.A.matmul(src, sum_in=acc_in, sum_out=self.Esum_rows)
             esum = self.Esum_rows                 # valid on the batch rows, which is all that is read
         E.lightgcn_bpr_grad(esum, self.E0, self.n_users, L, users, pos, neg, self.reg,
-                            self.Gstar, self.Greg, self.terms, loss_out)
+                            self.Gstar, self.Greg, self.terms, loss_out, plan)
         # backward through mean + propagation: G_L = H, G_k = H + A^T G_{k+1}, H = Gstar/(L+1).
         # Gstar, Greg and H are non-zero on the batch rows only, so they are derived and
         # re-zeroed row-sparsely; the dense passes are the SpMM hops and Adam.
@@ -430,7 +454,7 @@ class NGCFEngine:
         self.keep = 1.0 - float(mess_dropout)
         self.reg, self.seed, self.t = float(reg), int(seed), 0
         self.adam = E.AdamState(lr)
-        self.terms = torch.empty(2 * max_batch, dtype=torch.float32, device=dev)
+        self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
         self.flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
         self.ws = E.ngcf_workspace(self.N, dev)
@@ -456,7 +480,7 @@ class NGCFEngine:
         out = self.forward()
         return out[:self.n_users], out[self.n_users:]
 
-    def step(self, users, pos, neg, loss_out, masks=None):
+    def step(self, users, pos, neg, loss_out, masks=None, plan=None):
         B, d = users.numel(), self.d
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
@@ -466,7 +490,7 @@ class NGCFEngine:
         E.lightgcn_mark_batch(users, pos, neg, U, rows, self.flag)
         # the BPR head of NGCF.py:91-100 is the MF head on the rows of the concatenated output
         E.bpr_mf_grad(self.Out[:U], self.Out[U:], users, pos, neg, self.reg, self.dOut[:U],
-                      self.dOut[U:], self.terms, loss_out)
+                      self.dOut[U:], self.terms, loss_out, plan)
         dego = None
         for k in range(self.L - 1, -1, -1):
             E.ngcf_layer_bwd(self.ego[k], self.S[k], self.W[k], self.keep, self.mask[k],

@@ -69,7 +69,9 @@ def get_initializer(init_method, stddev, seed=None):
         elif init_method == "normal":
             w = rng.normal(0.0, stddev, size=shape)
         elif init_method == "xavier_normal":
-            w = tnormal(shape, np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978 * 0.87962566103423978)
+            # tf.contrib.layers.xavier_initializer(uniform=False) = variance_scaling(factor=1,
+            # FAN_AVG): truncated normal with stddev sqrt(1.3 * factor / n), n = (fan_in + fan_out) / 2
+            w = tnormal(shape, np.sqrt(1.3 * 2.0 / (fi + fo)))
         elif init_method == "xavier_uniform":
             lim = np.sqrt(6.0 / (fi + fo))
             w = rng.uniform(-lim, lim, size=shape)

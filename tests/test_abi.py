@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, "declared in neurec_hip.h but not exported: %s" % missing
-    assert lib.nrhip_abi_version() == 1
+    assert lib.nrhip_abi_version() == 2      # 2: batch plans (ordered row-gradient sums) in the BPR heads
 
 
 def test_library_exports_nothing_undeclared():

@@ -1,0 +1,188 @@
+"""Deterministic row-gradient aggregation.
+
+TF sums the IndexedSlices of a gather's gradient that hit the same row with
+unsorted_segment_sum: in batch order, the item table's positive-lookup slices before its
+negative-lookup slices (MF.py:57-72, LightGCN.py:99-104).  The HIP heads reproduce that
+order through a batch plan (sorted (row, position) keys), so
+  * the plan equals a host sort of the same keys,
+  * the dense row gradients equal an ordered host accumulation of the per-occurrence rows
+    (np.add.at — what oracle/train.py does) BIT FOR BIT, duplicates and hub rows included,
+  * two runs of N steps leave identical tables, with or without a precomputed plan."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _host_plan(users, items, third, batch, n_users):
+    out = []
+    n = len(users)
+    for b0 in range(0, n, batch):
+        e = min(b0 + batch, n)
+        nb = e - b0
+        rows = [users[b0:e].astype(np.uint64)]
+        rows.append(items[b0:e].astype(np.uint64) + np.uint64(n_users))
+        if third is not None:
+            rows.append(third[b0:e].astype(np.uint64) + np.uint64(n_users))
+        rows = np.concatenate(rows)
+        pos = np.arange(len(rows), dtype=np.uint64)
+        assert len(rows) == (2 if third is None else 3) * nb
+        out.append(np.sort((rows << np.uint64(32)) | pos))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("n,batch", [(1, 1), (700, 256), (4096, 1024), (5000, 512), (9000, 4096)])
+def test_batch_plan_equals_host_sort(n, batch):
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(n)
+    U, I = 37, 53                                    # few rows: long runs of duplicates
+    users = rng.randint(0, U, n).astype(np.int32)
+    pos = rng.randint(0, I, n).astype(np.int32)
+    neg = rng.randint(0, I, n).astype(np.int32)
+    got3 = E.bpr_plan(_dev(users), _dev(pos), _dev(neg), batch, U).cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal(got3, _host_plan(users, pos, neg, batch, U))
+    got2 = E.bpr_plan(_dev(users), _dev(pos), None, batch, U).cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal(got2, _host_plan(users, pos, None, batch, U))
+
+
+def test_plan_rejects_batches_beyond_the_lds_sort():
+    from neurec_amd import engine as E
+    ids = _dev(np.zeros(20000, np.int32))
+    with pytest.raises(NotImplementedError):
+        E.bpr_plan(ids, ids, ids, 8193, 5)           # 2 * 8193 item occurrences > 16384
+    E.bpr_plan(ids, ids, ids, 8192, 5)
+
+
+def _ordered_rows(n_rows, d, idx_lists, contrib_lists):
+    out = np.zeros((n_rows, d), np.float32)
+    for idx, c in zip(idx_lists, contrib_lists):
+        np.add.at(out, idx, c)                       # sequential, in batch order
+    return out
+
+
+@pytest.mark.parametrize("d,U,I,B", [(64, 40, 30, 1024), (16, 300, 200, 512), (128, 5, 7, 333), (48, 64, 64, 64)])
+def test_mf_head_row_sums_are_the_ordered_sums_bit_for_bit(d, U, I, B):
+    """Per-occurrence rows come from the kernel itself (a batch without duplicates is their
+    ground truth: each row then holds exactly one occurrence), the duplicate-heavy batch must
+    equal their np.add.at accumulation."""
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(d + B)
+    P = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.1).astype(np.float32)
+    users = rng.randint(0, U, B).astype(np.int32)
+    pos = rng.randint(0, I, B).astype(np.int32)
+    neg = rng.randint(0, I, B).astype(np.int32)
+    reg = 0.01
+    # expanded problem: triplet b owns private copies of its three rows -> no duplicates at all
+    Px, Qx = P[users], np.concatenate([Q[pos], Q[neg]])
+    ar = np.arange(B, dtype=np.int32)
+    GPx, GQx = torch.zeros(B, d, device="cuda"), torch.zeros(2 * B, d, device="cuda")
+    work, l2 = torch.zeros(8 * B, device="cuda"), torch.zeros(2, device="cuda")
+    E.bpr_mf_grad(_dev(Px), _dev(Qx), _dev(ar), _dev(ar), _dev(ar + B), reg, GPx, GQx, work, l2)
+    occ_u, occ_q = GPx.cpu().numpy(), GQx.cpu().numpy()
+    want_P = _ordered_rows(U, d, [users], [occ_u])
+    want_Q = _ordered_rows(I, d, [pos, neg], [occ_q[:B], occ_q[B:]])
+    # the real batch, twice: plan sorted inside the call / plan handed in
+    for given in (False, True):
+        GP, GQ = torch.zeros(U, d, device="cuda"), torch.zeros(I, d, device="cuda")
+        l2b = torch.zeros(2, device="cuda")
+        plan = E.bpr_plan(_dev(users), _dev(pos), _dev(neg), B, U) if given else None
+        E.bpr_mf_grad(_dev(P), _dev(Q), _dev(users), _dev(pos), _dev(neg), reg, GP, GQ, work, l2b, plan)
+        np.testing.assert_array_equal(GP.cpu().numpy(), want_P)
+        np.testing.assert_array_equal(GQ.cpu().numpy(), want_Q)
+        np.testing.assert_array_equal(l2b.cpu().numpy(), l2.cpu().numpy())   # same terms, same order
+
+
+def test_lightgcn_head_row_sums_are_the_ordered_sums_bit_for_bit():
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(9)
+    U, I, d, B, L = 23, 31, 64, 777, 3
+    N = U + I
+    Es = rng.randn(N, d).astype(np.float32)
+    E0 = (rng.randn(N, d) * 0.1).astype(np.float32)
+    users = rng.randint(0, U, B).astype(np.int32)
+    pos = rng.randint(0, I, B).astype(np.int32)
+    neg = rng.randint(0, I, B).astype(np.int32)
+    node = np.concatenate([users, U + pos, U + neg])
+    ar = np.arange(B, dtype=np.int32)
+    work, l2 = torch.zeros(8 * B, device="cuda"), torch.zeros(2, device="cuda")
+    Gx, Rx = torch.zeros(3 * B, d, device="cuda"), torch.zeros(3 * B, d, device="cuda")
+    E.lightgcn_bpr_grad(_dev(Es[node]), _dev(E0[node]), B, L, _dev(ar), _dev(ar), _dev(ar + B), 1e-3,
+                        Gx, Rx, work, l2)
+    want_G = _ordered_rows(N, d, [node], [Gx.cpu().numpy()])
+    want_R = _ordered_rows(N, d, [node], [Rx.cpu().numpy()])
+    G, R = torch.zeros(N, d, device="cuda"), torch.zeros(N, d, device="cuda")
+    l2b = torch.zeros(2, device="cuda")
+    E.lightgcn_bpr_grad(_dev(Es), _dev(E0), U, L, _dev(users), _dev(pos), _dev(neg), 1e-3, G, R, work, l2b)
+    np.testing.assert_array_equal(G.cpu().numpy(), want_G)
+    np.testing.assert_array_equal(R.cpu().numpy(), want_R)
+    np.testing.assert_array_equal(l2b.cpu().numpy(), l2.cpu().numpy())
+
+
+def test_fifty_steps_twice_give_identical_tables():
+    """LightGCN (gowalla-like duplicates: positives drawn by degree) and BPR-MF: two engines fed the
+    same 50 batches end bit-identical; so does a run that hands the sampler's plans in."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.graph import lightgcn_adjacency
+    from neurec_amd.trainer import BprEpochSampler, LightGCNEngine, MFEngine
+    train, _ = synth.interactions("gowalla", seed=3, scale=0.05)
+    U, I = train.shape
+    coo = train.tocoo()
+    A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    E0 = synth.xavier_uniform(U + I, 64, np.random.RandomState(2017))
+    trc = E.DeviceCSR.from_scipy(train)
+    runs = []
+    for given in (False, False, True):
+        lg = LightGCNEngine(A, U, I, E0, 3, 0.01, 1e-3, 1024)
+        rs = np.random.RandomState(1)
+        mf = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32),
+                      0.001, 0.01, 1024)
+        sampler = BprEpochSampler(trc, I, batch_size=1024, seed=11, plan_users=U if given else None)
+        loss = torch.zeros(2, device="cuda")
+        n = 0
+        while n < 50:
+            for b in sampler.batches():
+                assert (b.plan is not None) == given
+                lg.step(b[0], b[1], b[2], None, plan=b.plan)
+                mf.step(b[0], b[1], b[2], loss, plan=b.plan)
+                n += 1
+                if n == 50:
+                    break
+        runs.append((lg.E0.cpu().numpy(), mf.P.cpu().numpy(), mf.Q.cpu().numpy(), loss.cpu().numpy()))
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_loss_reduction_by_the_last_block_sees_every_term():
+    """finish_loss hands the per-triplet terms to the block that finishes last through agent-scope
+    stores and a relaxed counter (csrc/bpr.hip): stress it — 300 launches, every reduced loss must
+    equal the fp64-accumulated sum of the terms the launch left in the work buffer."""
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(4)
+    U, I, d, B = 2000, 3000, 64, 2048
+    P, Q = _dev((rng.randn(U, d) * 0.3).astype(np.float32)), _dev((rng.randn(I, d) * 0.3).astype(np.float32))
+    GP, GQ = torch.zeros(U, d, device="cuda"), torch.zeros(I, d, device="cuda")
+    work = torch.zeros(8 * B, device="cuda")
+    outs = torch.zeros(300, 2, device="cuda")
+    want = np.zeros((300, 2), np.float32)
+    ids = [(_dev(rng.randint(0, U, B).astype(np.int32)), _dev(rng.randint(0, I, B).astype(np.int32)),
+            _dev(rng.randint(0, I, B).astype(np.int32))) for _ in range(300)]
+    terms = []
+    for k, (u, p, n) in enumerate(ids):
+        E.bpr_mf_grad(P, Q, u, p, n, 0.05, GP, GQ, work, outs[k])
+        terms.append(work[:2 * B].clone())
+    got = outs.cpu().numpy()
+    for k, t in enumerate(terms):
+        t = t.cpu().numpy().astype(np.float64)
+        want[k] = np.float32(t[:B].sum()), np.float32(0.05) * np.float32(t[B:].sum())
+    np.testing.assert_array_equal(got, want)

@@ -151,15 +151,17 @@ def test_ngcf_config_drops_in(tmp_path):
 
 
 def test_multivae_config_drops_in(tmp_path):
-    """conf/MultiVAE.properties -> HIP Mult-VAE: log lines, loss falls, and `predict` reproduces
-    the reference's accumulating input row (MultiVAE.py:186-206) — checked against the oracle
-    forward on the cumulative-union rows."""
+    """conf/MultiVAE.properties -> HIP Mult-VAE: log lines, loss falls; `predict` scores each user
+    on their own history by default, and with reference_predict_rows=True on the reference's
+    accumulating input row (MultiVAE.py:186-206) — both checked against the oracle forward."""
     from oracle import train
     _write_dataset(str(tmp_path))
     np.random.seed(2018)
     model = _run(tmp_path, ["--recommender=MultiVAE", "--epochs=30", "--batch_size=32",
-                            "--learning_rate=0.01", "--verbose=15", "--total_anneal_steps=50"])
+                            "--learning_rate=0.01", "--verbose=15", "--total_anneal_steps=50",
+                            "--reference_predict_rows=True"])
     text = _log_text(tmp_path, "MultiVAE")
+    assert "reference_predict_rows=True" in text and model.predict_accumulates_rows
     iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
     assert len(iters) == 30 and float(iters[-1][1]) < float(iters[0][1])
     evals = re.findall(r"epoch (\d+):\t(.+)", text)

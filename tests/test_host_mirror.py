@@ -268,3 +268,27 @@ def test_sampler_structure_matches_reference_golden():
         upl, ul, rl, pl = _generative_time_order_positive_items(seqs, high_order=h)
         assert upl == want["user_pos_len"] and ul == want["users"] and pl == want["pos"]
         assert [list(r) if isinstance(r, (list, tuple)) else r for r in rl] == want["recent"]
+
+
+# ------------------------------------------------------------------ initialisers (util/tool.py:79-97)
+def test_initializer_scales_follow_tf_contrib_variance_scaling():
+    """tf.contrib.layers.variance_scaling_initializer draws a truncated normal (|x| <= 2 sd) with
+    sd = sqrt(1.3 * factor / n): xavier_normal is factor 1 / FAN_AVG, he_normal factor 2 / FAN_IN;
+    the uniform variants use limit sqrt(3 * factor / n).  A normal truncated at 2 sd keeps
+    0.87962566 of its standard deviation."""
+    from neurec_amd.util.tool import get_initializer
+    fi, fo = 300, 64
+    shape = (fi, fo)
+    kept = 0.87962566103423978
+    for name, sd in (("xavier_normal", np.sqrt(1.3 * 2.0 / (fi + fo))), ("he_normal", np.sqrt(1.3 * 2.0 / fi)),
+                     ("tnormal", 0.01)):
+        w = get_initializer(name, 0.01, seed=5)(shape)
+        assert w.dtype == np.float32 and w.shape == shape
+        assert np.abs(w).max() <= 2 * sd * (1 + 1e-6)
+        assert abs(w.std() / (kept * sd) - 1) < 0.02, name
+    for name, lim in (("xavier_uniform", np.sqrt(6.0 / (fi + fo))), ("he_uniform", np.sqrt(6.0 / fi)),
+                      ("uniform", 0.01)):
+        w = get_initializer(name, 0.01, seed=5)(shape)
+        assert np.abs(w).max() <= lim and abs(w.std() / (lim / np.sqrt(3)) - 1) < 0.02, name
+    w = get_initializer("normal", 0.01, seed=5)(shape)
+    assert abs(w.std() / 0.01 - 1) < 0.02
