@@ -65,13 +65,17 @@ __device__ __forceinline__ void finish_loss(const float* term_mf, const float* t
     s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < batch; i += 256) {   // other blocks' terms: read past the L1
-    a += (double)__hip_atomic_load(&term_mf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    b += (double)__hip_atomic_load(&term_l2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the first 256 threads reduce (callers launch 256- or 1024-thread blocks): fixed partition,
+  // fixed tree — the same sum whatever the block shape
+  if (threadIdx.x < 256) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < batch; i += 256) {   // other blocks' terms: read past the L1
+      a += (double)__hip_atomic_load(&term_mf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b += (double)__hip_atomic_load(&term_l2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
   }
-  s_a[threadIdx.x] = a;
-  s_b[threadIdx.x] = b;
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) {
     if ((int)threadIdx.x < s) {
