@@ -48,51 +48,93 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(train, test, E0, args, n_eval_users=1024):
-    """The CPU oracle (a port of the reference's TF graph: scipy CSR SpMM + numpy, 1 thread)
-    timed on this box's host cores on a bounded sample: `cpu_steps` LightGCN steps of the
-    same workload; plus the reference's own C++ evaluator (oracle/_ref, 8 threads, fed by
-    np.matmul as MF.py:120-122 does) on 1,024 users when it travelled with the snapshot."""
+def cpu_baseline(train, test, E0, args, eval_tables=None, n_eval_users=1024):
+    """SURVEY §8d's CPU legs, timed on this box's host cores on bounded samples of the same workload:
+      (i)   the reference's own PairwiseSampler epoch (data/sampler.py + util/data_iterator.py +
+            util/cython/random_choice.pyx compiled as they are into oracle/_ref; 1 Python thread);
+      (ii)  the LightGCN step port (oracle.train: scipy CSR SpMM + numpy, 1 thread) AND its
+            torch-CPU twin at torch.set_num_threads(nproc) (oracle.train_torch) — `value` is the
+            faster of the two, with the cores it used;
+      (iii) the reference's own C++ evaluator (oracle/_ref, num_thread=8, test_batch_size=128) fed by
+            np.matmul as MF.py:120-122 does, on `eval_tables` (the GPU run's E* tables, so that its
+            NDCG@10 can be compared with the GPU evaluator's on the same users)."""
     from oracle import native, ref, train as otrain
+    from oracle.train_torch import TorchLightGCN
     U, I = train.shape
     coo = train.tocoo()
     A = otrain.lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
-    At = A                                               # 'pre' is symmetric
+    B = args.batch
+    rows = np.repeat(np.arange(U), np.diff(train.indptr))
+    rng = np.random.RandomState(1)
+    picks = [(rng.randint(0, train.nnz, B), rng.randint(0, I, B)) for _ in range(args.cpu_steps + 1)]
+    nproc = os.cpu_count() or 1
+
+    def time_steps(step):
+        step(rows[picks[0][0]], train.indices[picks[0][0]], picks[0][1])        # warm caches
+        t0 = time.perf_counter()
+        for pick, neg in picks[1:]:
+            step(rows[pick], train.indices[pick], neg)
+        return args.cpu_steps * B / (time.perf_counter() - t0)
     E = E0.copy()
     m, v = np.zeros_like(E), np.zeros_like(E)
     adam = otrain.Adam(0.01)
-    rng = np.random.RandomState(1)
-    B = args.batch
-    rows = np.repeat(np.arange(U), np.diff(train.indptr))
-    otrain.lightgcn_step(A, At, E, m, v, U, args.layers, rows[:B], train.indices[:B],
-                         rng.randint(0, I, B), 1e-3, adam)          # warm caches
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        pick = rng.randint(0, train.nnz, B)
-        otrain.lightgcn_step(A, At, E, m, v, U, args.layers, rows[pick], train.indices[pick],
-                             rng.randint(0, I, B), 1e-3, adam)
-    dt = time.perf_counter() - t0
-    out = {"value": args.cpu_steps * B / dt, "unit": "triplets/s", "cores": 1, "kind": "port",
-           "sample": "%d LightGCN steps (B=%d, L=%d, d=%d) of the same graph, scipy CSR SpMM + "
-                     "numpy fp32, single thread" % (args.cpu_steps, B, args.layers, args.dim),
-           "host_cores_available": os.cpu_count()}
-    # evaluator leg
-    users = np.arange(min(n_eval_users, U), dtype=np.int32)
-    P, Q = E[:U], E[U:]
-    truth = [test.indices[test.indptr[u]:test.indptr[u + 1]].tolist() or [0] for u in users]
+    scipy_1t = time_steps(lambda u, p, n: otrain.lightgcn_step(A, A, E, m, v, U, args.layers, u, p, n,
+                                                               1e-3, adam))
+    import torch
+    before = torch.get_num_threads()
+    tl = TorchLightGCN(A, E0, U, args.layers, 0.01, 1e-3, nproc)
+    torch_nt = time_steps(tl.step)
+    torch.set_num_threads(before)
+    best_torch = torch_nt > scipy_1t
+    out = {"value": max(scipy_1t, torch_nt), "unit": "triplets/s",
+           "cores": nproc if best_torch else 1, "kind": "port",
+           "sample": "%d LightGCN steps (B=%d, L=%d, d=%d) of the same graph; faster of scipy CSR SpMM + "
+                     "numpy fp32 on 1 thread (%.0f triplets/s) and torch-CPU sparse-CSR at %d threads "
+                     "(%.0f triplets/s)" % (args.cpu_steps, B, args.layers, args.dim, scipy_1t, nproc,
+                                            torch_nt),
+           "step_scipy_1thread": scipy_1t, "step_torch_nproc": torch_nt,
+           "host_cores_available": nproc}
+    # (i) sampler leg: the reference's own code when oracle/_ref travelled with the snapshot
+    mod = ref.sampler_module()
+    if mod is not None:
+        class _Dataset:                                   # what PairwiseSampler reads (sampler.py:191-192)
+            num_items = I
+
+            @staticmethod
+            def get_user_train_dict():
+                return {u: train.indices[train.indptr[u]:train.indptr[u + 1]].tolist()
+                        for u in range(U) if train.indptr[u + 1] > train.indptr[u]}
+        np.random.seed(2018)                              # main.py:10
+        smp = mod.PairwiseSampler(_Dataset, neg_num=1, batch_size=B, shuffle=True)
+        t0 = time.perf_counter()
+        n = 0
+        for bu, _, _ in smp:
+            n += len(bu)
+        out["sampler"] = {"value": n / (time.perf_counter() - t0), "unit": "triplets/s", "cores": 1,
+                          "kind": "reference",
+                          "sample": "one PairwiseSampler epoch (%d triplets, B=%d): the reference's "
+                                    "data/sampler.py + util/data_iterator.py + Cython random_choice, "
+                                    "compiled unchanged" % (n, B)}
+    else:
+        out["sampler"] = None                             # oracle/_ref did not travel: not timed
+    # (iii) evaluator leg
+    users = np.flatnonzero(np.diff(test.indptr) > 0)[:n_eval_users].astype(np.int32)
+    P, Q = eval_tables if eval_tables is not None else (E[:U], E[U:])
+    truth = [test.indices[test.indptr[u]:test.indptr[u + 1]].tolist() for u in users]
+    res = []
     t0 = time.perf_counter()
     for b in range(0, len(users), 128):                  # test_batch_size=128, NeuRec.properties:40
         ub = users[b:b + 128]
         S = np.ascontiguousarray(np.matmul(P[ub], Q.T), dtype=np.float32)
         native.mask_train(S, ub, train.indptr.astype(np.int64), train.indices)
-        if ref.available():
-            ref.eval_matrix(S, truth[b:b + 128], [1, 2, 4, 3, 5], 20, threads=8)
-        else:
-            native.eval_matrix(S, truth[b:b + 128], [1, 2, 4, 3, 5], 20, threads=8)
+        fn = ref.eval_matrix if ref.available() else native.eval_matrix
+        res.append(fn(S, truth[b:b + 128], [1, 2, 4, 3, 5], 20, threads=8))
     dte = time.perf_counter() - t0
     out["eval"] = {"value": len(users) / dte, "unit": "users/s", "cores": 8,
                    "kind": "reference" if ref.available() else "port",
-                   "sample": "%d users, np.matmul + C++ evaluator, num_thread=8, batch 128" % len(users)}
+                   "sample": "%d users, np.matmul + C++ evaluator, num_thread=8, batch 128" % len(users),
+                   "ndcg@10": float(np.mean(np.concatenate(res), axis=0)[2 * 20 + 9]),
+                   "users": users}
     return out
 
 
@@ -162,10 +204,17 @@ def main():
 
     run_steps(args.warmup)
     torch.cuda.synchronize(); comm.barrier()
+    epochs_before = sampler.epoch
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize(); comm.barrier()
     dt = comm.max_float(time.perf_counter() - t0)
+    # what the timed region held: the sampler (+ batch-plan) launch happens once per epoch of
+    # len(sampler) steps, so a short run may contain none — said here rather than implied
+    timed_region = {"steps": args.steps, "steps_per_epoch": len(sampler),
+                    "sampler_launches": sampler.epoch - epochs_before,
+                    "batch_plan_launches": (sampler.epoch - epochs_before) if sampler.plans else
+                    ("one per step (sorted inside the step)" if not rowshard else 0)}
     triplets_per_s = comm.world * args.steps * args.batch / dt
     run_steps(1, loss2)                                  # untimed: loss of one more step, for the record
     if exchange:
@@ -283,12 +332,27 @@ def main():
                                    "row lookups, owner-local Adam)" % comm.world if rowshard else
                                    "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
-        "final_loss": [float(x) for x in loss2.cpu().numpy()],
+        "final_loss": [float(x) for x in loss2.cpu().numpy()], "timed_region": timed_region,
         "eval": eval_info, "mf": mf_info, "roofline": roofline,
         "device": E.device_info(),
     }
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(train, test, E0, args)
+        tables = None
+        if eval_info is not None:
+            eu, ei = lg.final_embeddings()
+            tables = (eu.cpu().numpy(), ei.cpu().numpy())
+        cb = cpu_baseline(train, test, E0, args, eval_tables=tables)
+        sample_users = cb["eval"].pop("users")
+        if eval_info is not None:
+            # same embeddings, same users: the GPU evaluator's NDCG@10 next to the reference C++ fed
+            # by np.matmul (north_star: equal within 1e-5; BLAS and the fmaf chain differ in the last
+            # ulps of a score, so a near-tie may swap)
+            mine = ev.evaluate_factors(eu.contiguous(), ei.contiguous(),
+                                       torch.from_numpy(sample_users).to(dev), exact_mean=True)
+            eval_info["ndcg10_oracle_absdiff"] = abs(float(mine[2 * 20 + 9]) - cb["eval"]["ndcg@10"])
+            eval_info["ndcg10_oracle_sample"] = "%d users, np.matmul scores + %s C++ evaluator" % (
+                len(sample_users), "the reference's own" if cb["eval"]["kind"] == "reference" else "the oracle's")
+        line["cpu_baseline"] = cb
     else:
         line["cpu_baseline"] = None
     if comm.rank == 0:

@@ -61,3 +61,45 @@ def random_choice_module():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def _load_ext(name):
+    hits = glob.glob(os.path.join(_REF_DIR, name + "*.so"))
+    if not hits:
+        return None
+    spec = importlib.util.spec_from_file_location(name, hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sampler_module():
+    """The reference's data/sampler.py (PairwiseSampler & co.) with its own util/data_iterator.py and
+    util/cython/random_choice.pyx underneath — all three compiled unchanged by oracle/Makefile.
+    Their `from util import DataIterator` / `from util.cython.random_choice import ...` /
+    `from collections import Iterable` lines are satisfied here with the compiled modules (the
+    reference's `util` package itself imports TensorFlow).  None where oracle/_ref is incomplete."""
+    import collections
+    import collections.abc
+    import sys
+    import types
+    rc, di = random_choice_module(), _load_ext("data_iterator")
+    if rc is None or di is None or not glob.glob(os.path.join(_REF_DIR, "sampler*.so")):
+        return None
+    if not hasattr(collections, "Iterable"):            # data/sampler.py:6 predates python 3.10
+        collections.Iterable = collections.abc.Iterable
+    saved = {k: sys.modules.get(k) for k in ("util", "util.cython", "util.cython.random_choice")}
+    util = types.ModuleType("util")
+    util.DataIterator = di.DataIterator
+    cy = types.ModuleType("util.cython")
+    cy.random_choice = rc
+    util.cython = cy
+    sys.modules.update({"util": util, "util.cython": cy, "util.cython.random_choice": rc})
+    try:
+        return _load_ext("sampler")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

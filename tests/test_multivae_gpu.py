@@ -97,37 +97,56 @@ def test_multivae_loss_and_grads_match_oracle(reg, anneal, act):
 
 
 def test_multivae_steps_track_oracle():
-    """five Adam steps, fp32 oracle alongside: parameters stay within 1e-5"""
+    """Five Adam steps on all eight variables.  Pin = the fp32 restatement at north_star's 1e-5; the
+    fp64 twin measures how far fp32 arithmetic itself drifts here (Adam moves every weight by
+    ~lr·sign(g), entries whose gradient is at rounding level go either way) and only that measured
+    distance is granted on top — printed next to the assert."""
     from oracle import train
     rng, R, params = _problem(5)
     B, keep, z, lr = 48, 0.8, 16, 0.001
     eng = _engine(R, params, lr=lr, B=64)
-    ref = {k: v.astype(np.float64) for k, v in params.items()}
-    ref["Wp1"] = ref.pop("Wp1t").T.copy()
     order = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1", "bp1")
-    adam = train.Adam(lr, dtype=np.float64)
-    m = {k: np.zeros_like(ref[k]) for k in order}
-    v = {k: np.zeros_like(ref[k]) for k in order}
+    steps = []
     for it in range(5):
         rows = rng.choice(R.shape[0], B, replace=False).astype(np.int32)
-        X, D, drop_pos, eps = _batch_inputs(rng, R, rows, keep, z)
-        anneal = min(0.2, it / 10.0)
+        steps.append((rows,) + _batch_inputs(rng, R, rows, keep, z) + (min(0.2, it / 10.0),))
+    got_loss = []
+    for rows, X, D, drop_pos, eps, anneal in steps:
         eng.step(_dev(rows), anneal, keep, drop_given=_dev(drop_pos), eps_given=_dev(eps))
-        wl, (gWq, gbq, gWp, gbp), _ = train.multivae_loss_and_grads(
-            X, [ref["Wq0"], ref["Wq1"]], [ref["bq0"], ref["bq1"]], [ref["Wp0"], ref["Wp1"]],
-            [ref["bp0"], ref["bp1"]], D, keep, eps.astype(np.float64), anneal, 0.0, "tanh")
-        assert abs(eng.loss()[0] - wl) < 1e-5 * max(1.0, abs(wl))
-        g = dict(zip(order, (gWq[0], gbq[0], gWq[1], gbq[1], gWp[0], gbp[0], gWp[1], gbp[1])))
-        for k in order:
-            adam.dense(ref[k], m[k], v[k], g[k])
-        adam.advance()
+        got_loss.append(eng.loss()[0])
+
+    def run(dt):
+        ref = {k: v.astype(dt) for k, v in params.items()}
+        ref["Wp1"] = ref.pop("Wp1t").T.copy()
+        adam = train.Adam(lr, dtype=dt)
+        m = {k: np.zeros_like(ref[k]) for k in order}
+        v = {k: np.zeros_like(ref[k]) for k in order}
+        losses = []
+        for rows, X, D, drop_pos, eps, anneal in steps:
+            wl, (gWq, gbq, gWp, gbp), _ = train.multivae_loss_and_grads(
+                X.astype(dt), [ref["Wq0"], ref["Wq1"]], [ref["bq0"], ref["bq1"]], [ref["Wp0"], ref["Wp1"]],
+                [ref["bp0"], ref["bp1"]], D.astype(dt), keep, eps.astype(dt), anneal, 0.0, "tanh")
+            g = dict(zip(order, (gWq[0], gbq[0], gWq[1], gbq[1], gWp[0], gbp[0], gWp[1], gbp[1])))
+            for k in order:
+                adam.dense(ref[k], m[k], v[k], g[k].astype(dt))
+            adam.advance()
+            losses.append(float(wl))
+        return np.asarray(losses), ref
+    l32, r32 = run(np.float32)
+    l64, r64 = run(np.float64)
+    d32 = d64 = bar = 0.0
     for k in order:
         got = eng.P["Wp1t" if k == "Wp1" else k].cpu().numpy()
-        want = ref[k].T if k == "Wp1" else ref[k]
-        # Adam's first steps move every weight by ~lr·sign(g): entries whose gradient is at
-        # rounding level may differ in direction, so compare in units of lr
-        assert np.abs(got - want).max() < 0.05 * lr * 5 + 1e-6, k
-        assert np.mean(np.abs(got - want)) < 1e-6, k
+        got = got.T if k == "Wp1" else got
+        d32 = max(d32, np.abs(got - r32[k]).max())
+        d64 = max(d64, np.abs(got - r64[k]).max())
+        bar = max(bar, np.abs(r32[k].astype(np.float64) - r64[k]).max())
+    dl32 = (np.abs(np.asarray(got_loss) - l32) / np.maximum(1.0, np.abs(l32))).max()
+    dl64 = (np.abs(np.asarray(got_loss) - l64) / np.maximum(1.0, np.abs(l64))).max()
+    print("Mult-VAE: loss rel err vs fp32 oracle %.1e, vs fp64 %.1e; parameters max abs err vs fp32 oracle "
+          "%.1e, vs fp64 %.1e (oracle fp32-vs-fp64 %.1e)" % (dl32, dl64, d32, d64, bar))
+    assert dl32 <= 1e-5 and dl64 <= 1e-5
+    assert d32 <= 1e-5 + bar and d64 <= 1e-5 + bar
 
 
 def test_multivae_device_draws():

@@ -51,34 +51,52 @@ def test_ngcf_forward_matches_oracle():
 
 @pytest.mark.parametrize("reg,drop", [(0.0, 0.1), (0.01, 0.0)])
 def test_ngcf_steps_track_oracle(reg, drop):
+    """Five Adam steps on E0 and all eight weight tensors.  The pin is the fp32 restatement
+    (north_star's 1e-5); the fp64 twin shows how far fp32 arithmetic itself drifts on this
+    problem (Adam moves every coordinate by ~lr·sign(g): coordinates whose gradient is at
+    rounding level go either way), and only that measured distance is granted on top."""
     import torch
     from neurec_amd.trainer import NGCFEngine
     from oracle import train
     rng, R, A, At, E0, W, U, I = _problem(2)
     B, lr, keep = 128, 0.005, 1.0 - drop
     eng = NGCFEngine(A, At, U, I, E0, W, lr, reg, drop, B)
-    A64, At64 = A.astype(np.float64), At.astype(np.float64)
-    oE = E0.astype(np.float64)
-    oW = [[w.astype(np.float64) for w in ws] for ws in W]
-    params = [oE] + [w for ws in oW for w in ws]
-    ms, vs = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
-    ad = train.Adam(lr, dtype=np.float64)
+    steps = [(tuple(rng.randint(0, n, B).astype(np.int32) for n in (U, I, I)),
+              [(rng.rand(U + I, 16) < keep).astype(np.uint8) for _ in W]) for _ in range(5)]
     loss2 = torch.zeros(2, device="cuda")
-    for step in range(5):
-        bu, bp, bn = (rng.randint(0, n, B).astype(np.int32) for n in (U, I, I))
-        masks = [(rng.rand(U + I, 16) < keep).astype(np.uint8) for _ in W]
+    got_loss = []
+    for (bu, bp, bn), masks in steps:
         eng.step(_dev(bu), _dev(bp), _dev(bn), loss2, masks=[_dev(m) for m in masks])
-        loss, dE, wg = train.ngcf_loss_and_grads(A64, At64, oE, [tuple(ws) for ws in oW],
-                                                 [m.astype(np.float64) for m in masks], keep, U,
-                                                 bu, bp, bn, reg)
-        grads = [dE] + [g for gs in wg for g in gs]
-        for p, m, v, g in zip(params, ms, vs, grads):
-            ad.dense(p, m, v, g.reshape(p.shape))
-        ad.advance()
-        got = float(loss2.sum().item())
-        assert abs(got - loss) <= 2e-5 * abs(loss), (step, got, loss)
-    assert np.abs(eng.E0.cpu().numpy() - oE).max() < 2e-5
-    for k in range(len(W)):
-        for j in range(4):
-            assert np.abs(eng.W[k][j].cpu().numpy().reshape(oW[k][j].shape) - oW[k][j]).max() < 5e-5, (k, j)
+        got_loss.append(float(loss2.sum().item()))
+
+    def run(dt):
+        A_, At_ = A.astype(dt), At.astype(dt)
+        oE = E0.astype(dt)
+        oW = [[w.astype(dt) for w in ws] for ws in W]
+        params = [oE] + [w for ws in oW for w in ws]
+        ms, vs = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
+        ad = train.Adam(lr, dtype=dt)
+        losses = []
+        for (bu, bp, bn), masks in steps:
+            loss, dE, wg = train.ngcf_loss_and_grads(A_, At_, oE, [tuple(ws) for ws in oW],
+                                                     [m.astype(dt) for m in masks], keep, U, bu, bp, bn, reg)
+            for p, m, v, g in zip(params, ms, vs, [dE] + [g for gs in wg for g in gs]):
+                ad.dense(p, m, v, g.reshape(p.shape))
+            ad.advance()
+            losses.append(float(loss))
+        return np.asarray(losses), params
+    l32, p32 = run(np.float32)
+    l64, p64 = run(np.float64)
+    got = [eng.E0.cpu().numpy()] + [eng.W[k][j].cpu().numpy() for k in range(len(W)) for j in range(4)]
+    d32 = max(np.abs(g.reshape(a.shape) - a).max() for g, a in zip(got, p32))
+    d64 = max(np.abs(g.reshape(a.shape) - a).max() for g, a in zip(got, p64))
+    bar = max(np.abs(a.astype(np.float64) - b).max() for a, b in zip(p32, p64))
+    dl32 = (np.abs(np.asarray(got_loss) - l32) / np.abs(l32)).max()
+    dl64 = (np.abs(np.asarray(got_loss) - l64) / np.abs(l64)).max()
+    barl = (np.abs(l32 - l64) / np.abs(l64)).max()
+    print("NGCF reg=%g drop=%g: loss rel err vs fp32 oracle %.1e, vs fp64 %.1e (oracle fp32-vs-fp64 %.1e); "
+          "parameters max abs err vs fp32 oracle %.1e, vs fp64 %.1e (oracle fp32-vs-fp64 %.1e)"
+          % (reg, drop, dl32, dl64, barl, d32, d64, bar))
+    assert dl32 <= 1e-5 and dl64 <= 1e-5 + barl
+    assert d32 <= 1e-5 + bar and d64 <= 1e-5 + bar        # fp32 runs differ from each other by <= bar too
     assert not eng.dOut.cpu().numpy().any() and not eng.flag.cpu().numpy().any()

@@ -158,3 +158,50 @@ def test_tf_sparse_adam_sweeps_untouched_rows():
     train.Adam.sparse_swept(ad, P, m, v, g)
     assert np.all(m[0] == np.float32(0.5) * np.float32(0.9)) and np.all(P[0] < 1.0)
     assert np.all(m[1] > m[0])
+
+
+def test_torch_cpu_step_port_tracks_the_numpy_oracle():
+    """oracle.train_torch (bench.py's nproc-thread CPU baseline leg) is the same step as
+    oracle.train.lightgcn_step: four steps, losses within 1e-6 relative, tables within 1e-4 (fp32
+    sums in a different association)."""
+    from oracle import train as O
+    from oracle.train_torch import TorchLightGCN
+    rng = np.random.RandomState(0)
+    U, I, d, L = 300, 200, 32, 3
+    users = np.repeat(np.arange(U), 5)
+    items = np.concatenate([rng.choice(I, 5, replace=False) for _ in range(U)])
+    A = O.lightgcn_adjacency(users, items, U, I, "pre")
+    E0 = rng.uniform(-0.1, 0.1, (U + I, d)).astype(np.float32)
+    t = TorchLightGCN(A, E0, U, L, 0.01, 1e-3, 2)
+    e, m, v, ad = E0.copy(), np.zeros_like(E0), np.zeros_like(E0), O.Adam(0.01)
+    for _ in range(4):
+        u, p, n = rng.randint(0, U, 256), rng.randint(0, I, 256), rng.randint(0, I, 256)
+        a, b = t.step(u, p, n), O.lightgcn_step(A, A, e, m, v, U, L, u, p, n, 1e-3, ad)
+        assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(b[1])
+    assert np.abs(t.E.numpy() - e).max() < 1e-4
+
+
+@pytest.mark.skipif(not __import__("oracle.ref", fromlist=["x"]).sampler_module(),
+                    reason="oracle/_ref (reference sampler modules) not built")
+def test_reference_sampler_module_runs_an_epoch():
+    """oracle.ref.sampler_module() = the reference's data/sampler.py compiled unchanged: one epoch
+    has the structure SURVEY Appendix A records (aligned triplets, negatives outside the user's
+    train items, last short batch kept)."""
+    from oracle import ref
+    mod = ref.sampler_module()
+    d = {0: [1, 3], 2: [0], 5: [2, 4, 6, 7]}
+
+    class DS:
+        num_items = 10
+
+        @staticmethod
+        def get_user_train_dict():
+            return d
+    s = mod.PairwiseSampler(DS, neg_num=1, batch_size=4, shuffle=False)
+    batches = list(s)
+    assert len(s) == 2 and [len(b[0]) for b in batches] == [4, 3]
+    users = sum((b[0] for b in batches), [])
+    pos = sum((b[1] for b in batches), [])
+    neg = sum((b[2] for b in batches), [])
+    assert users == [0, 0, 2, 5, 5, 5, 5] and pos == [1, 3, 0, 2, 4, 6, 7]
+    assert all(n not in d[u] and 0 <= n < 10 for u, n in zip(users, neg))
