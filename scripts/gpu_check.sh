@@ -24,7 +24,7 @@ for ph in $PHASES; do
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -30 | tee -a "$OUT/summary.txt" ;;
     bench)
       echo "== bench" | tee -a "$OUT/summary.txt"
-      timeout 300 python bench.py --gpus 1 --steps 300 --warmup 30 ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"
+      timeout 420 python bench.py --gpus 1 --steps 300 --warmup 30 ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"
       tail -5 "$OUT/bench.err" | tee -a "$OUT/summary.txt"; cat "$OUT/bench.json" | tee -a "$OUT/summary.txt" ;;
     prof)
       echo "== rocprofv3 kernel stats" | tee -a "$OUT/summary.txt"
