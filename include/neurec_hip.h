@@ -266,7 +266,7 @@ int nrhip_spmm_csr_masked(const void* plan, const int64_t* d_indptr, const int32
  * 0 selects a default for block_bytes (no blocking), n_workgroups (one per CU),
  * waves_per_wg (16), seg_len (64), r_max / p_max (LDS accumulators).  NR_ERR_UNSUPPORTED when the
  * matrix does not fit the schedule (the work-item kernel remains). */
-int nrhip_spmm_blocked_plan_bytes(int64_t n_rows, int64_t nnz, size_t* bytes);
+int nrhip_spmm_blocked_plan_bytes(int64_t n_rows, int64_t nnz, int d, size_t* bytes);
 int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_indices,
                                    int64_t n_rows, int64_t split_row, int d, int64_t block_bytes,
                                    int n_workgroups, int waves_per_wg, int seg_len, int r_max,
@@ -276,6 +276,14 @@ int nrhip_spmm_blocked_plan_destroy(void* plan);
 int nrhip_spmm_blocked_plan_info(const void* plan, int* n_workgroups, int* n_phases,
                                  int64_t* n_entries, int64_t* n_split);
 int nrhip_spmm_blocked_tune(int gathers_in_flight);
+/* d = 64 plans also carry the *affinity schedule* of the full pass (cache-blocked by column windows,
+ * no phase barriers: csrc/spmm_blocked.hip); it reads a plan-owned (column, value) stream that
+ * nrhip_spmm_blocked_pack fills from the matrix's CSR arrays — once per matrix, again if the values
+ * change.  Calls that pass those same arrays then run it; results keep the contract of
+ * nrhip_spmm_csr (rows of <= 64 non-zeros in strict ascending-column order).
+ * nrhip_spmm_blocked_affinity: number of column windows in use (0 = base schedule), not a status. */
+int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d_vals, void* stream);
+int nrhip_spmm_blocked_affinity(const void* plan, int* windows_b);
 int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* d_vals,
                        const float* d_X, float* d_Y, const float* d_addend, const float* d_sum_in,
                        float* d_sum_out, const uint8_t* d_x_row_nonzero,

@@ -104,7 +104,9 @@ SIGNATURES = {
     "nrhip_ngcf_layer_fwd": [p, p, p, p, p, p, i64, i32, f32, p, i32, u64, u64, i32, p, p, i64, p],
     "nrhip_ngcf_layer_bwd": [p, p, p, p, p, p, i64, i32, f32, p, p, i64, p, p, p, p, p, p, p, p, p,
                              p, sz, p],
-    "nrhip_spmm_blocked_plan_bytes": [i64, i64, psz],
+    "nrhip_spmm_blocked_plan_bytes": [i64, i64, i32, psz],
+    "nrhip_spmm_blocked_pack": [p, p, p, p],
+    "nrhip_spmm_blocked_affinity": [p, C.POINTER(i32)],
     "nrhip_spmm_blocked_plan_create": [p, p, i64, i64, i32, i64, i32, i32, i32, i32, i32, p, sz, p,
                                        C.POINTER(p)],
     "nrhip_spmm_blocked_plan_destroy": [p],

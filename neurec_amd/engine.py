@@ -508,7 +508,7 @@ class SpmmCSR:
             self._blocked[d] = (None, None)
             if os.environ.get("NEUREC_SPMM_BLOCKED", "1") != "0" and self.nnz > 0:
                 nbytes = C.c_size_t(0)
-                call("nrhip_spmm_blocked_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
+                call("nrhip_spmm_blocked_plan_bytes", self.n_rows, self.nnz, int(d), C.byref(nbytes))
                 buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=self.indices.device)
                 plan = C.c_void_p(0)
                 try:
@@ -516,6 +516,8 @@ class SpmmCSR:
                          self.h_indices.ctypes.data_as(C.c_void_p), self.n_rows, self.split_row, d,
                          0, 0, 0, 0, 0, 0, _ptr(buf), buf.numel(), _stream(), C.byref(plan))
                     call("nrhip_spmm_plan_attach_blocked", self.plan, plan, d)
+                    # the affinity schedule's (column, value) stream (d = 64): filled once
+                    call("nrhip_spmm_blocked_pack", plan, _ptr(self.indices), _ptr(self.vals), _stream())
                     self._blocked[d] = (plan, buf)
                 except NotImplementedError:
                     pass                   # does not fit the schedule: work-item kernel stays
