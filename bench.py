@@ -256,23 +256,41 @@ def main():
     spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
     spmm_bytes = lg.A.algorithmic_bytes(args.dim)
     achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-    kernel = (("spmm_blocked_kernel<false,16,8>" if args.dim == 64 else
-               "spmm_blocked_kernel<false,16,8,%d>" % args.dim) if lg.A.ensure_schedule(args.dim)
-              else "spmm_item_kernel<%d,...>" % args.dim)
-    # traffic: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc pass
-    # over this same command (profiles/r01_pmc_traffic.json, scripts/gpu_pmc.sh) is reported when
-    # it is for the kernel that ran and the default workload, else null
-    traffic = None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    kernel = lg.A.full_pass_kernel(args.dim)
+    # traffic: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc passes
+    # over this same command (scripts/gpu_pmc.sh -> profiles/r02_pmc_traffic.json) are reported when
+    # they are for the kernel that ran, the default workload AND the SpMM sources they were measured
+    # on (hash stamped in the file) — otherwise null
+    traffic, traffic_note = None, "no PMC pass for this kernel / workload"
+    here = os.path.dirname(os.path.abspath(__file__))
+    pmc_file = os.path.join(here, "profiles", "r02_pmc_traffic.json")
     default_workload = (args.shape, args.scale, args.dim, args.layers) == ("gowalla", 1.0, 64, 3)
     if default_workload and os.path.isfile(pmc_file):
+        import hashlib
+        h = hashlib.sha256()
+        for name in ("spmm_blocked.hip", "spmm.hip"):
+            with open(os.path.join(here, "neurec_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
         with open(pmc_file) as fh:
-            traffic = json.load(fh).get(kernel, {}).get("traffic_bytes_per_launch")
+            doc = json.load(fh)
+        if doc.get("_spmm_sources_sha16") != h.hexdigest()[:16]:
+            traffic_note = "stale: csrc/spmm*.hip changed since the PMC pass of profiles/r02_pmc_traffic.json"
+        else:
+            hit = [v for k, v in doc["kernels"].items() if k.replace(" ", "") == kernel.replace(" ", "")]
+            if hit:
+                traffic = hit[0]["traffic_bytes_per_launch"]
+                traffic_note = ("bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc "
+                                "passes (profiles/r02_pmc_traffic.json, sources %s)" % doc["_spmm_sources_sha16"])
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, profiles/r01_pmc_traffic.json)", "bytes_per_launch": spmm_bytes, "us_per_launch": spmm_ms * 1e3,
-                "launches_per_step": 2 * args.layers,
-                "step_algorithmic_bytes": lg.step_bytes() if hasattr(lg, "step_bytes") else None}
+                "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": spmm_bytes,
+                "us_per_launch": spmm_ms * 1e3, "launches_per_step": 2 * args.layers,
+                "step_algorithmic_bytes": lg.step_bytes() if hasattr(lg, "step_bytes") else None,
+                "step_bytes_survey_8d": lg.step_bytes_survey() if hasattr(lg, "step_bytes_survey") else None}
+    if roofline["step_algorithmic_bytes"]:
+        # the whole step against the same roof: every launch's algorithmic bytes / the step time
+        roofline["step_frac"] = roofline["step_algorithmic_bytes"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
+        roofline["step_frac_survey_8d"] = roofline["step_bytes_survey_8d"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
 
     # ---------------- BPR-MF on the same interactions (BASELINE configs[1]: d=64, B=512) — reported
     # next to the headline, not instead of it.  A step = fused gather/BPR/scatter kernel + the two
@@ -295,10 +313,28 @@ def main():
             mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
         torch.cuda.synchronize()
         mf_dt = (time.perf_counter() - t0) / max(len(mf_batches) - 50, 1)
-        sweep = 2 * 4 * (U + I) * 64 * 4        # var, m, v, grad read + var, m, v, grad(cleared) written
+        torch.cuda.synchronize()
+        # the same steps with TF's literal all-rows sweep (the checker) for the record
+        mf_sweep = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32),
+                            0.001, 0.0, 512, lazy=False)
+        for b in mf_batches[:50]:
+            mf_sweep.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in mf_batches[50:]:
+            mf_sweep.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
+        torch.cuda.synchronize()
+        sweep_dt = (time.perf_counter() - t0) / max(len(mf_batches) - 50, 1)
+        touched = 512 * (72 * 64 + 12)           # 3 rows x (read + write of p, m, v) + ids, per triplet
         mf_info = {"triplets_per_sec": 512 / mf_dt, "ms_per_step": mf_dt * 1e3, "batch": 512, "dim": 64,
-                   "adam_sweep_bytes_per_step": sweep, "adam_sweep_GBps": sweep / mf_dt / 1e9,
-                   "note": "TF-1.12 sparse Adam decays every row each step: the step is the table sweep"}
+                   "optimizer": "TF-1.12 sparse Adam by exact lazy replay (bit-identical to the all-rows sweep)",
+                   "roofline": {"bound": "hbm", "bytes_per_step": touched, "unit": "GB/s",
+                                "achieved": touched / mf_dt / 1e9, "peak": HBM_PEAK_GBS,
+                                "frac": touched / mf_dt / 1e9 / HBM_PEAK_GBS,
+                                "note": "SURVEY 8d bound (72 d + 12) B per triplet; two dependent launches of "
+                                        "~2.4 MB each are launch-latency-bound, not bandwidth-bound"},
+                   "sweep_ms_per_step": sweep_dt * 1e3,
+                   "sweep_GBps": 2 * 4 * (U + I) * 64 * 4 / sweep_dt / 1e9}
 
     # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)
     eval_info = None

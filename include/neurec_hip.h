@@ -188,6 +188,29 @@ int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
                       const uint64_t* d_plan, void* stream);
 int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
                          float alpha, float beta1, float beta2, float eps, void* stream);
+/* The same optimiser, exactly, without the sweep (SURVEY.md H2 "lazy replay"): d_last[row] = last
+ * step applied to the row (int32, zero at step 0); when step t touches a row its missed
+ * zero-gradient steps are replayed in registers with the step sizes d_alpha_tab[s] (fp32, 1-based,
+ * >= t + 1 entries, each made exactly like the `alpha` of nrhip_adam_sparse_tf), then step t is
+ * applied with the row's gradient (cleared afterwards).  d_plan / n_occ: the batch's nrhip_bpr_plan
+ * slice — rows must be rows of this [n_rows][d] table (user rows first, item rows offset by the plan's
+ * n_users).  Every call also brings rows r = t (mod period) up to step t, so no row is ever more
+ * than `period` steps behind.  d_plan = NULL, n_occ = 0, period = 1: flush every row to step t —
+ * required before the table (or m, v) is read; afterwards the buffers are bit-identical to t sweeps. */
+int nrhip_adam_sparse_tf_lazy(float* d_var, float* d_m, float* d_v, float* d_grad, int32_t* d_last,
+                              const int32_t* d_stamp, int64_t n_rows, int d, const uint64_t* d_plan,
+                              int n_occ, const float* d_alpha_tab, int t, int period, float beta1,
+                              float beta2, float eps, void* stream);
+/* The gradient half of a lazy step: nrhip_bpr_mf_grad on the one-allocation table [n_users +
+ * n_items][d] (d_G likewise), every gathered row first brought to step t - 1 in registers (nothing
+ * written back), the batch's rows stamped d_stamp[row] = t (int32 per row; the optimiser call of the
+ * same step takes it to tell batch rows from scheduled rows).  d_plan is required. */
+int nrhip_bpr_mf_grad_lazy(const float* d_table, const float* d_m, const float* d_v,
+                           const int32_t* d_last, const float* d_alpha_tab, int32_t* d_stamp, int t,
+                           float beta1, float beta2, float eps, int d, int n_users,
+                           const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                           float reg, float* d_G, float* d_work, float* d_loss2, const uint64_t* d_plan,
+                           void* stream);
 /* TF-1.12 dense ApplyAdam; d_grad cleared afterwards when clear_grad != 0. */
 int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int64_t n,
                         float alpha, float beta1, float beta2, float eps, int clear_grad,
@@ -420,12 +443,18 @@ typedef struct nrhip_mf_buffers {
   float* terms;              /* 8*max_batch floats */
   int n_users; int n_items; int d; int max_batch;
   float reg;
+  /* lazy sparse Adam (nrhip_adam_sparse_tf_lazy): last != NULL selects it; needs P|Q, mP|mQ, vP|vQ,
+   * GP|GQ each one [n_users + n_items][d] allocation */
+  int32_t* last; int32_t* stamp; const float* alpha_tab; int alpha_len; int lazy_period;
 } nrhip_mf_buffers;
 int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out);
 int nrhip_mf_ctx_destroy(void* ctx);
+/* step_index: 1-based index of this optimiser step (lazy mode: alpha must equal alpha_tab[step_index]) */
 int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, const uint64_t* d_plan, float alpha, float beta1, float beta2, float eps,
-                  float* d_loss2, void* stream);
+                  int batch, const uint64_t* d_plan, int step_index, float alpha, float beta1,
+                  float beta2, float eps, float* d_loss2, void* stream);
+/* lazy mode: bring every row of both tables to step `steps_done` (no-op otherwise) */
+int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float eps, void* stream);
 
 /* ---- NGCF propagation layer, dense half (second-model coverage) ---------------
  * Replaces the per-layer TF ops of NGCF._create_ngcf_embed

@@ -52,7 +52,9 @@ class MFBuffers(C.Structure):
     """nrhip_mf_buffers (include/neurec_hip.h)"""
     _fields_ = [(n, C.c_void_p) for n in ("P", "Q", "mP", "vP", "mQ", "vQ", "GP", "GQ", "terms")] + [
         ("n_users", C.c_int), ("n_items", C.c_int), ("d", C.c_int), ("max_batch", C.c_int),
-        ("reg", C.c_float)]
+        ("reg", C.c_float), ("last", C.c_void_p), ("stamp", C.c_void_p), ("alpha_tab", C.c_void_p),
+        ("alpha_len", C.c_int),
+        ("lazy_period", C.c_int)]
 
 
 # name -> argtypes; every function returns int status except where noted.
@@ -99,7 +101,11 @@ SIGNATURES = {
     "nrhip_lightgcn_step_apply": [p, p, f32, f32, f32, f32, p],
     "nrhip_mf_ctx_create": [C.POINTER(MFBuffers), C.POINTER(p)],
     "nrhip_mf_ctx_destroy": [p],
-    "nrhip_mf_step": [p, p, p, p, i32, p, f32, f32, f32, f32, p, p],
+    "nrhip_mf_step": [p, p, p, p, i32, p, i32, f32, f32, f32, f32, p, p],
+    "nrhip_mf_flush": [p, i32, f32, f32, f32, p],
+    "nrhip_adam_sparse_tf_lazy": [p, p, p, p, p, p, i64, i32, p, i32, p, i32, i32, f32, f32, f32, p],
+    "nrhip_bpr_mf_grad_lazy": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, p, p, p, i32, f32, p, p, p,
+                               p, p],
     "nrhip_ngcf_workspace_bytes": [i64, psz],
     "nrhip_ngcf_layer_fwd": [p, p, p, p, p, p, i64, i32, f32, p, i32, u64, u64, i32, p, p, i64, p],
     "nrhip_ngcf_layer_bwd": [p, p, p, p, p, p, i64, i32, f32, p, p, i64, p, p, p, p, p, p, p, p, p,

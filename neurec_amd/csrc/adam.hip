@@ -54,6 +54,85 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
   }
 }
 
+
+// ---- exact lazy replay of TF-1.12's sparse Adam -----------------------------------
+// _apply_sparse_shared decays m and v of EVERY row and moves EVERY row each step; a row the batch
+// did not touch sees g = 0:  m <- m·b1 (+0),  v <- v·b2 (+0),  var <- var - lr_s·m/(sqrt(v)+eps).
+// That recurrence only involves the row itself, so it can be run late: last[row] remembers the
+// last step applied; when step t touches the row, the missed steps last+1..t-1 are replayed in
+// registers with the very same instruction sequence (nr::adam_sparse_tf with g = 0 and that step's
+// lr_s from a host-made table), then step t is applied with the row's summed gradient.  Identical
+// bits, 2.4 MB of touched rows per step instead of a 145 MB sweep.  To bound the replay (a row
+// untouched for 10^4 steps would hold one wave for 10^4 iterations), every step also brings the
+// rows r = t (mod period) up to date: no row is ever more than `period` steps behind.  A flush
+// (plan = NULL, period = 1) brings every row to step t — before tables are read.
+// The gradient kernel of step t must see every row it gathers as of step t - 1: it replays the
+// same missed steps in registers (bpr.hip: load_row_lazy) and stamps the batch's rows with t, which
+// is how a scheduled-row wave here knows to leave a row to the batch wave that owns it.
+// One wave per sorted batch occurrence (the first occurrence of a row does the row) + one per
+// scheduled row; rows whose m and v are still all zero replay nothing (0·b1 = 0, var - 0 = var).
+template <int CPL>
+__global__ __launch_bounds__(256) void adam_lazy_kernel(
+    float* __restrict__ var, float* __restrict__ m, float* __restrict__ v, float* __restrict__ grad,
+    int32_t* __restrict__ last, const int32_t* __restrict__ stamp, int d, int64_t n_rows,
+    const uint64_t* __restrict__ skey, int n_occ, const float* __restrict__ alpha_tab, int t, int period,
+    float b1, float b2, float omb1, float omb2, float eps) {
+  const int lane = nr_lane();
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t row;
+  bool has_grad;
+  if (w < n_occ) {
+    row = (int64_t)(skey[w] >> 32);
+    if (w > 0 && (int64_t)(skey[w - 1] >> 32) == row) return;      // a later occurrence of the row
+    has_grad = true;
+  } else {
+    row = (int64_t)(t % period) + (w - n_occ) * period;
+    if (row >= n_rows) return;
+    if (stamp && stamp[row] == t) return;                          // in this step's batch: done above
+    has_grad = false;
+  }
+  row = __builtin_amdgcn_readfirstlane((int)row);
+  const int from = __builtin_amdgcn_readfirstlane(last[row]) + 1;
+  const int upto = has_grad ? t - 1 : t;                           // steps replayed with g = 0
+  float wv[CPL], mm[CPL], vv[CPL];
+  bool quiet = true;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    wv[c] = mm[c] = vv[c] = 0.f;
+    if (k < d) {
+      wv[c] = var[row * d + k];
+      mm[c] = m[row * d + k];
+      vv[c] = v[row * d + k];
+    }
+    quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
+  }
+  if (!__all(quiet)) nr_lazy_replay<CPL>(wv, mm, vv, from, upto, alpha_tab, lane, b1, b2, omb1, omb2, eps);
+  if (has_grad) {
+    const float a = alpha_tab[t];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int k = lane + c * NR_WAVE;
+      float g = 0.f;
+      if (k < d) {
+        g = grad[row * d + k];
+        grad[row * d + k] = 0.f;                                   // re-armed, as the sweep does
+      }
+      nr::adam_sparse_tf(g, wv[c], mm[c], vv[c], a, b1, b2, omb1, omb2, eps);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    if (k < d) {
+      var[row * d + k] = wv[c];
+      m[row * d + k] = mm[c];
+      v[row * d + k] = vv[c];
+    }
+  }
+  if (lane == 0) last[row] = t;
+}
+
 // dense ApplyAdam whose gradient is the sum of two buffers (g = g1 + g2, one rounding — the
 // same value a separate elementwise add would have produced); neither buffer is modified.
 __global__ __launch_bounds__(256) void adam_dense2_kernel(float* __restrict__ var,
@@ -321,6 +400,33 @@ int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, in
   hipLaunchKernelGGL((adam_kernel<true, true>), dim3(sweep_blocks(n / 4 + 1)), dim3(256), 0,
                      (hipStream_t)stream, d_var, d_m, d_v, d_grad, n, alpha, beta1, beta2,
                      1.0f - beta1, 1.0f - beta2, eps);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Exact lazy form of nrhip_adam_sparse_tf on a [n_rows][d] table: see adam_lazy_kernel.  d_last
+ * (int32 per row, zero at step 0) = last step applied; d_alpha_tab[s] = lr_s of step s (1-based,
+ * fp32, made by the caller exactly as the per-step `alpha` it would pass to the sweep), at least
+ * t + 1 entries; d_plan / n_occ = the batch's sorted occurrences (rows are table rows), t = this
+ * step.  d_plan = NULL, n_occ = 0, period = 1: flush — every row brought to step t. */
+int nrhip_adam_sparse_tf_lazy(float* d_var, float* d_m, float* d_v, float* d_grad, int32_t* d_last,
+                              const int32_t* d_stamp, int64_t n_rows, int d, const uint64_t* d_plan,
+                              int n_occ, const float* d_alpha_tab, int t, int period, float beta1,
+                              float beta2, float eps, void* stream) {
+  NR_REQUIRE(d_var && d_m && d_v && d_grad && d_last && d_alpha_tab && (n_occ == 0 || d_stamp), NR_ERR_ARG,
+             "adam_sparse_tf_lazy: null pointer argument");
+  NR_REQUIRE(n_rows >= 0 && d >= 1 && d <= 256 && n_occ >= 0 && (n_occ == 0 || d_plan) && t >= 0 &&
+                 period >= 1, NR_ERR_ARG, "adam_sparse_tf_lazy: bad sizes");
+  const int64_t scheduled = (n_rows + period - 1) / period;
+  const int64_t waves = (int64_t)n_occ + scheduled;
+  if (waves == 0) return NR_OK;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NR_LAZY(CPL)                                                                                  \
+  hipLaunchKernelGGL(adam_lazy_kernel<CPL>, grid, block, 0, st, d_var, d_m, d_v, d_grad, d_last, d_stamp, d, n_rows, \
+                     d_plan, n_occ, d_alpha_tab, t, period, beta1, beta2, 1.0f - beta1, 1.0f - beta2, eps)
+  if (d <= 64) NR_LAZY(1); else if (d <= 128) NR_LAZY(2); else NR_LAZY(4);
+#undef NR_LAZY
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

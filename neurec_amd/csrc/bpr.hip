@@ -45,6 +45,39 @@ __device__ __forceinline__ float dot_rows(const float (&a)[CPL], const float (&b
   return nr_wave_sum_f32(s);
 }
 
+// Lazy sparse Adam (adam.hip: adam_lazy_kernel): a table row may be several optimiser steps behind.
+// The head must see it as TF would — every row moved every step — so it replays the row's missed
+// zero-gradient steps in registers (same instruction sequence as the optimiser's own replay; nothing
+// is written back here) before using it.  m / v / last are indexed by global row (users, then
+// n_users + item): lazy mode keeps P|Q as one table.
+struct LazyTables {
+  const float* m; const float* v; const int32_t* last; const float* alpha_tab;
+  int32_t* stamp;                   // stamp[row] = t on the rows of this batch (for the optimiser launch)
+  int t;                            // the step being taken: rows are brought to step t - 1
+  float b1, b2, omb1, omb2, eps;
+};
+
+template <int CPL>
+__device__ __forceinline__ void load_row_lazy(const float* __restrict__ base, int64_t row, int64_t grow,
+                                              int d, int lane, const LazyTables& lz, float (&out)[CPL]) {
+  float mm[CPL], vv[CPL];
+  bool quiet = true;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    out[c] = mm[c] = vv[c] = 0.f;
+    if (k < d) {
+      out[c] = base[row * d + k];
+      mm[c] = lz.m[grow * d + k];
+      vv[c] = lz.v[grow * d + k];
+    }
+    quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
+  }
+  const int from = __builtin_amdgcn_readfirstlane(lz.last[grow]) + 1;
+  if (__all(quiet)) return;
+  nr_lazy_replay<CPL>(out, mm, vv, from, lz.t - 1, lz.alpha_tab, lane, lz.b1, lz.b2, lz.omb1, lz.omb2, lz.eps);
+}
+
 // Fixed-order reduction of the per-triplet terms, out2[0] = Σ mf, out2[1] = reg·Σ l2, done by the
 // block that finishes last (no second launch: a 1-block reduction kernel cost 4.8 us per step,
 // 17 % of an MF step).  `done` is one of a small pool of device counters, zero between launches.
@@ -326,22 +359,28 @@ __device__ __forceinline__ uint64_t plan_key(const uint64_t* __restrict__ skey, 
 }
 
 // ---- MF (pairwise: third = negative items; pointwise: third = float labels) ------------------
-template <int CPL, bool PAIR>
+template <int CPL, bool PAIR, bool LAZY>
 __device__ __forceinline__ void mf_occurrence(
-    const float* __restrict__ P, const float* __restrict__ Q, int d,
+    const float* __restrict__ P, const float* __restrict__ Q, int d, int n_users,
     const int32_t* __restrict__ users, const int32_t* __restrict__ items, const void* third,
     int batch, float reg, float scale, int loss_kind, uint32_t p, int lane, float (&out)[CPL],
-    float* __restrict__ term_mf, float* __restrict__ term_l2, bool write_terms) {
+    float* __restrict__ term_mf, float* __restrict__ term_l2, bool write_terms, const LazyTables& lz) {
   const int cls = (int)(p / (uint32_t)batch), b = (int)(p - (uint32_t)cls * (uint32_t)batch);
   const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
   const int64_t i = __builtin_amdgcn_readfirstlane(items[b]);
   float pu[CPL], qi[CPL];
-  load_row<CPL>(P, u, d, lane, pu);
-  load_row<CPL>(Q, i, d, lane, qi);
+  if constexpr (LAZY) {
+    load_row_lazy<CPL>(P, u, u, d, lane, lz, pu);
+    load_row_lazy<CPL>(Q, i, (int64_t)n_users + i, d, lane, lz, qi);
+  } else {
+    load_row<CPL>(P, u, d, lane, pu);
+    load_row<CPL>(Q, i, d, lane, qi);
+  }
   if (PAIR) {
     const int64_t j = __builtin_amdgcn_readfirstlane(((const int32_t*)third)[b]);
     float qj[CPL];
-    load_row<CPL>(Q, j, d, lane, qj);
+    if constexpr (LAZY) load_row_lazy<CPL>(Q, j, (int64_t)n_users + j, d, lane, lz, qj);
+    else load_row<CPL>(Q, j, d, lane, qj);
     const float x = dot_rows<CPL>(pu, qi) - dot_rows<CPL>(pu, qj);      // MF.py:59,67
     const float g = nr::pairwise_dloss(loss_kind, x);
 #pragma unroll
@@ -373,13 +412,13 @@ __device__ __forceinline__ void mf_occurrence(
   }
 }
 
-template <int CPL, bool PAIR>
+template <int CPL, bool PAIR, bool LAZY = false>
 __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, int d, int n_users,
     const int32_t* __restrict__ users, const int32_t* __restrict__ items, const void* third,
     int batch, const uint64_t* __restrict__ skey, int n_occ, float reg, float scale, int loss_kind,
     float* __restrict__ GP, float* __restrict__ GQ, float* __restrict__ term_mf,
-    float* __restrict__ term_l2, float* __restrict__ out2, unsigned* done) {
+    float* __restrict__ term_l2, float* __restrict__ out2, unsigned* done, LazyTables lz) {
   __shared__ float s_g[kOccWaves][CPL * NR_WAVE];
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int s = blockIdx.x * kOccWaves + wave;
@@ -388,8 +427,8 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
   float acc[CPL];
   if (active) {
     key = plan_key(skey, s);
-    mf_occurrence<CPL, PAIR>(P, Q, d, users, items, third, batch, reg, scale, loss_kind,
-                             (uint32_t)key, lane, acc, term_mf, term_l2, true);
+    mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale, loss_kind,
+                                   (uint32_t)key, lane, acc, term_mf, term_l2, true, lz);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) s_g[wave][lane + c * NR_WAVE] = acc[c];
   }
@@ -406,11 +445,14 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
           for (int c = 0; c < CPL; ++c) acc[c] += s_g[wave + t][lane + c * NR_WAVE];
         } else {                                  // the run leaves this workgroup: recompute
           float more[CPL];
-          mf_occurrence<CPL, PAIR>(P, Q, d, users, items, third, batch, reg, scale, loss_kind,
-                                   (uint32_t)k2, lane, more, term_mf, term_l2, false);
+          mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale,
+                                         loss_kind, (uint32_t)k2, lane, more, term_mf, term_l2, false, lz);
 #pragma unroll
           for (int c = 0; c < CPL; ++c) acc[c] += more[c];
         }
+      }
+      if constexpr (LAZY) {
+        if (lane == 0) lz.stamp[row] = lz.t;       // "in this step's batch": the optimiser launch reads it
       }
       float* dst = row < (uint32_t)n_users ? GP + (int64_t)row * d
                                            : GQ + (int64_t)(row - (uint32_t)n_users) * d;
@@ -659,7 +701,7 @@ static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q,
     dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
     NR_BY_WIDTH2(mf_grad_sorted_kernel, true, d_P, d_Q, d, n_users, d_users, d_pos,
                  (const void*)d_neg, batch, plan, n_occ, reg, 1.0f, loss_kind, d_GP, d_GQ, t_mf, t_l2,
-                 d_loss2, done);
+                 d_loss2, done, LazyTables{});
   }
   NR_LAUNCH_CHECK();
   return NR_OK;
@@ -671,6 +713,52 @@ int nrhip_bpr_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
                       const uint64_t* d_plan, void* stream) {
   return pairwise_mf_grad("bpr_mf_grad", d_P, d_Q, d, n_users, d_users, d_pos, d_neg, batch, reg,
                           nr::NR_PAIR_BPR, d_GP, d_GQ, d_work, d_loss2, d_plan, stream);
+}
+
+/* nrhip_bpr_mf_grad on a table kept by nrhip_adam_sparse_tf_lazy: rows are read as of step t - 1
+ * (missed zero-gradient steps replayed in registers) and stamped d_stamp[row] = t.  d_table =
+ * [n_users + n_items][d] (users first), d_m / d_v / d_last / d_alpha_tab as in the optimiser call.
+ * A plan is required (d_plan != NULL). */
+int nrhip_bpr_mf_grad_lazy(const float* d_table, const float* d_m, const float* d_v,
+                           const int32_t* d_last, const float* d_alpha_tab, int32_t* d_stamp, int t,
+                           float beta1, float beta2, float eps, int d, int n_users,
+                           const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                           float reg, float* d_G, float* d_work, float* d_loss2, const uint64_t* d_plan,
+                           void* stream) {
+  NR_REQUIRE(d_table && d_m && d_v && d_last && d_alpha_tab && d_stamp && d_users && d_pos && d_neg &&
+                 d_G && d_work && d_loss2 && d_plan, NR_ERR_ARG, "bpr_mf_grad_lazy: null pointer argument");
+  NR_REQUIRE(d >= 1 && d <= 256 && batch >= 0 && n_users >= 0 && t >= 1, NR_ERR_ARG,
+             "bpr_mf_grad_lazy: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (batch == 0) {
+    NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+    return NR_OK;
+  }
+  unsigned* done = next_done_counter();
+  NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
+  const LazyTables lz{d_m, d_v, d_last, d_alpha_tab, d_stamp, t, beta1, beta2, 1.0f - beta1, 1.0f - beta2, eps};
+  const float* d_P = d_table;
+  const float* d_Q = d_table + (size_t)n_users * d;
+  float* d_GP = d_G;
+  float* d_GQ = d_G + (size_t)n_users * d;
+  float* t_mf = d_work;
+  float* t_l2 = d_work + batch;
+  const int n_occ = 3 * batch;
+  dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
+  if (d <= 64)
+    hipLaunchKernelGGL((mf_grad_sorted_kernel<1, true, true>), grid, block, 0, st, d_P, d_Q, d, n_users,
+                       d_users, d_pos, (const void*)d_neg, batch, d_plan, n_occ, reg, 1.0f,
+                       (int)nr::NR_PAIR_BPR, d_GP, d_GQ, t_mf, t_l2, d_loss2, done, lz);
+  else if (d <= 128)
+    hipLaunchKernelGGL((mf_grad_sorted_kernel<2, true, true>), grid, block, 0, st, d_P, d_Q, d, n_users,
+                       d_users, d_pos, (const void*)d_neg, batch, d_plan, n_occ, reg, 1.0f,
+                       (int)nr::NR_PAIR_BPR, d_GP, d_GQ, t_mf, t_l2, d_loss2, done, lz);
+  else
+    hipLaunchKernelGGL((mf_grad_sorted_kernel<4, true, true>), grid, block, 0, st, d_P, d_Q, d, n_users,
+                       d_users, d_pos, (const void*)d_neg, batch, d_plan, n_occ, reg, 1.0f,
+                       (int)nr::NR_PAIR_BPR, d_GP, d_GQ, t_mf, t_l2, d_loss2, done, lz);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
 }
 
 int nrhip_pairwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_users,
@@ -715,7 +803,7 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_use
     dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
     NR_BY_WIDTH2(mf_grad_sorted_kernel, false, d_P, d_Q, d, n_users, d_users, d_items,
                  (const void*)d_labels, batch, plan, n_occ, reg, scale, loss_kind, d_GP, d_GQ, t_mf,
-                 t_l2, d_loss2, done);
+                 t_l2, d_loss2, done, LazyTables{});
   }
   NR_LAUNCH_CHECK();
   return NR_OK;

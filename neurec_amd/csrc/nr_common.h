@@ -82,3 +82,25 @@ __device__ __forceinline__ int nr_mbcnt(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
+
+// Replay of TF-1.12 sparse Adam's zero-gradient steps from..upto on one table row held in registers
+// (lane = column): the literal per-step sequence (nr::adam_sparse_tf with g = 0) with that step's
+// lr_s.  The step sizes of up to 64 steps come in with ONE coalesced load (lane j holds step
+// from + j) and are broadcast with v_readlane — a scalar load per iteration would put a memory
+// round trip on every step of the chain.  Used by the lazy optimiser (adam.hip) and by the gradient
+// kernel that must see rows as of the previous step (bpr.hip).
+template <int CPL>
+__device__ __forceinline__ void nr_lazy_replay(float (&w)[CPL], float (&mm)[CPL], float (&vv)[CPL],
+                                               int from, int upto, const float* __restrict__ alpha_tab,
+                                               int lane, float b1, float b2, float omb1, float omb2,
+                                               float eps) {
+  for (int s0 = from; s0 <= upto; s0 += NR_WAVE) {
+    const int n = min(NR_WAVE, upto - s0 + 1);
+    const float mine = alpha_tab[s0 + (lane < n ? lane : 0)];
+    for (int j = 0; j < n; ++j) {
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) nr::adam_sparse_tf(0.f, w[c], mm[c], vv[c], a, b1, b2, omb1, omb2, eps);
+    }
+  }
+}

@@ -248,16 +248,39 @@ int nrhip_mf_ctx_destroy(void* ctx) {
 
 // One BPR-MF step = sess.run((loss, optimizer)) (MF.py:101)
 int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, const uint64_t* d_plan, float alpha, float beta1, float beta2, float eps,
-                  float* d_loss2, void* stream) {
+                  int batch, const uint64_t* d_plan, int step_index, float alpha, float beta1,
+                  float beta2, float eps, float* d_loss2, void* stream) {
   NR_REQUIRE(ctx && d_users && d_pos && d_neg && d_loss2, NR_ERR_ARG, "mf_step: null argument");
   const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
   NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG, "mf_step: batch %d outside 0..%d",
              batch, b.max_batch);
+  const int64_t nu = (int64_t)b.n_users * b.d, ni = (int64_t)b.n_items * b.d;
+  const bool one_table = b.Q == b.P + nu && b.mQ == b.mP + nu && b.vQ == b.vP + nu && b.GQ == b.GP + nu;
+  if (b.last) {
+    // exact lazy replay instead of the sweep: the head leaves the batch's plan (the caller's, or
+    // the one it sorted into the work buffer) — the optimiser walks the same sorted occurrences
+    NR_REQUIRE(one_table && b.stamp, NR_ERR_ARG,
+               "mf_step: lazy Adam needs P|Q (and m, v, G) as one allocation and a stamp array");
+    NR_REQUIRE(step_index >= 1 && step_index < b.alpha_len, NR_ERR_ARG,
+               "mf_step: step %d outside the step-size table (1..%d)", step_index, b.alpha_len - 1);
+    const uint64_t* plan = d_plan;
+    if (!plan && batch > 0) {                  // no plan from the sampler: sort it into the work buffer
+      uint64_t* own = (uint64_t*)(b.terms + 2 * (size_t)batch);
+      NR_TRY(nrhip_bpr_plan(d_users, d_pos, d_neg, batch, batch, b.n_users, own, stream));
+      plan = own;
+    }
+    if (batch > 0)
+      NR_TRY(nrhip_bpr_mf_grad_lazy(b.P, b.mP, b.vP, b.last, b.alpha_tab, b.stamp, step_index, beta1, beta2,
+                                    eps, b.d, b.n_users, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.terms,
+                                    d_loss2, plan, stream));
+    return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, b.stamp,
+                                     (int64_t)b.n_users + b.n_items, b.d, batch ? plan : nullptr,
+                                     3 * batch, b.alpha_tab, step_index, b.lazy_period, beta1, beta2, eps,
+                                     stream);
+  }
   NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, b.n_users, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ,
                            b.terms, d_loss2, d_plan, stream));
-  const int64_t nu = (int64_t)b.n_users * b.d, ni = (int64_t)b.n_items * b.d;
-  if (b.Q == b.P + nu && b.mQ == b.mP + nu && b.vQ == b.vP + nu && b.GQ == b.GP + nu) {
+  if (one_table) {
     // both tables (and their moments / gradients) are one allocation: one sweep, one launch
     NR_TRY(nrhip_adam_sparse_tf(b.P, b.mP, b.vP, b.GP, nu + ni, alpha, beta1, beta2, eps, stream));
     return NR_OK;
@@ -265,6 +288,15 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
   NR_TRY(nrhip_adam_sparse_tf(b.P, b.mP, b.vP, b.GP, nu, alpha, beta1, beta2, eps, stream));
   NR_TRY(nrhip_adam_sparse_tf(b.Q, b.mQ, b.vQ, b.GQ, ni, alpha, beta1, beta2, eps, stream));
   return NR_OK;
+}
+
+int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float eps, void* stream) {
+  NR_REQUIRE(ctx, NR_ERR_ARG, "mf_flush: null context");
+  const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
+  if (!b.last || steps_done <= 0) return NR_OK;
+  NR_REQUIRE(steps_done < b.alpha_len, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
+  return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, nullptr, (int64_t)b.n_users + b.n_items,
+                                   b.d, nullptr, 0, b.alpha_tab, steps_done, 1, beta1, beta2, eps, stream);
 }
 
 }  // extern "C"

@@ -296,6 +296,16 @@ class AdamState:
         self.b2p = np.float32(self.b2p * self.beta2)
         self.t += 1
 
+    def alpha_table(self, n_steps):
+        """alpha of steps 1..n_steps (index 0 unused) with the same fp32 operations as alpha() /
+        advance(): running products by cumprod (sequential fp32 multiplications), then the formula."""
+        one = np.float32(1.0)
+        b1p = np.cumprod(np.full(n_steps, self.beta1, np.float32), dtype=np.float32)
+        b2p = np.cumprod(np.full(n_steps, self.beta2, np.float32), dtype=np.float32)
+        tab = np.zeros(n_steps + 1, np.float32)
+        tab[1:] = (self.lr * np.sqrt(one - b2p) / (one - b1p)).astype(np.float32)
+        return tab
+
 
 def adam_sparse(var, m, v, grad, st):
     call("nrhip_adam_sparse_tf", _ptr(var, torch.float32), _ptr(m), _ptr(v), _ptr(grad),
@@ -573,6 +583,20 @@ class SpmmCSR:
         """CSR idx+val read once, X read once, Y written once."""
         return self.nnz * 8 + (self.n_rows + 1) * 4 + 2 * self.n_rows * d * 4
 
+    def masked_bytes(self, d):
+        """A hop whose operand or result lives on the batch rows only: the CSR arrays and
+        one dense [N][d] stream."""
+        return self.nnz * 8 + (self.n_rows + 1) * 4 + self.n_rows * d * 4
+
+    def full_pass_kernel(self, d):
+        """Name (as rocprofv3 prints it) of the kernel an unmasked matmul at width d launches."""
+        if self.ensure_schedule(d):
+            wb = C.c_int(0)
+            if _lib.lib.nrhip_spmm_blocked_affinity(self.blocked, C.byref(wb)) > 0:
+                return "spmm_affinity_kernel<false>"
+            return "spmm_blocked_kernel<false, 16, 8, %d, false>" % d
+        return "spmm_item_kernel<%d, ...>" % d
+
 
 def add2d(x, y, out):
     """out = x + y on 2-D views with unit inner stride (column blocks allowed)."""
@@ -642,10 +666,14 @@ class NativeStep:
     @staticmethod
     def for_mf(eng):
         b = _lib.MFBuffers()
-        for k in ("P", "Q", "mP", "vP", "mQ", "vQ", "GP", "GQ", "terms"):
-            setattr(b, k, getattr(eng, k).data_ptr())
-        b.n_users, b.n_items, b.d = eng.P.shape[0], eng.Q.shape[0], eng.P.shape[1]
+        for k in ("_P", "_Q", "mP", "vP", "mQ", "vQ", "GP", "GQ", "terms"):
+            setattr(b, k.lstrip("_"), getattr(eng, k).data_ptr())
+        b.n_users, b.n_items, b.d = eng._P.shape[0], eng._Q.shape[0], eng._P.shape[1]
         b.max_batch, b.reg = eng.max_batch, eng.reg
+        if eng.lazy:
+            b.last, b.alpha_tab = eng._last.data_ptr(), eng._alpha_tab.data_ptr()
+            b.stamp = eng._stamp.data_ptr()
+            b.alpha_len, b.lazy_period = eng._alpha_tab.numel(), eng.lazy_period
         h = C.c_void_p(0)
         call("nrhip_mf_ctx_create", C.byref(b), C.byref(h))
         return NativeStep("mf", h, eng)
@@ -689,8 +717,12 @@ class NativeStep:
 
     def mf_step(self, users, pos, neg, st, loss2, plan=None):
         call("nrhip_mf_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
-             users.numel(), self._plan(plan, 3 * users.numel()), float(st.alpha()), float(st.beta1),
-             float(st.beta2), float(st.eps), _ptr(loss2, torch.float32), _stream())
+             users.numel(), self._plan(plan, 3 * users.numel()), st.t + 1, float(st.alpha()),
+             float(st.beta1), float(st.beta2), float(st.eps), _ptr(loss2, torch.float32), _stream())
+
+    def mf_flush(self, st):
+        call("nrhip_mf_flush", self.handle, st.t, float(st.beta1), float(st.beta2), float(st.eps),
+             _stream())
 
 
 def device_info():

@@ -88,42 +88,79 @@ class BprEpochSampler:
 
 
 class MFEngine:
-    """BPR-MF tables + TF-style Adam state in HBM; step() = one reference sess.run."""
+    """BPR-MF tables + TF-style Adam state in HBM; step() = one reference sess.run.
 
-    def __init__(self, user_table, item_table, lr, reg, max_batch):
+    lazy=True (default): TF-1.12's sparse Adam — which decays and moves EVERY row each step — is
+    applied by exact lazy replay (nrhip_adam_sparse_tf_lazy): a row's missed zero-gradient steps
+    are replayed in registers when the row is next touched, bit-identical to sweeping the table
+    every step (lazy=False, the checker).  lazy_period bounds how far a row may fall behind (rows
+    r = t mod period are refreshed every step): measured on MI355X at the gowalla shape, B = 512
+    (scripts/exp_mf_lazy.py): sweep 29.9 us/step; period 4: 22.7, 8: 23.9, 16: 27.1, 64: 48.4 — the
+    replay is a chain of exact fp32 sqrt + divide per missed step, run again by the gradient kernel
+    for every row it gathers, so short bounds win.  The tables are only current after flush(); the
+    P / Q / mP / ... properties flush for you."""
+
+    ALPHA_STEPS = 1 << 20           # step-size table: 4 MB, enough for 1 M optimiser steps
+
+    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=4):
         dev = E.require_gpu()
         ut = torch.as_tensor(user_table, dtype=torch.float32)
         it = torch.as_tensor(item_table, dtype=torch.float32)
         nu = ut.shape[0]
         # user and item tables (and their moments / gradients) share one allocation each, so the
-        # TF-sparse Adam sweep of a step is a single launch over [U+I][d]
+        # TF-sparse Adam update of a step is a single launch over [U+I][d]
         self._table = torch.cat([ut, it]).contiguous().to(dev)
         self._m, self._v, self._g = (torch.zeros_like(self._table) for _ in range(3))
-        self.P, self.Q = self._table[:nu], self._table[nu:]
-        self.mP, self.mQ = self._m[:nu], self._m[nu:]
-        self.vP, self.vQ = self._v[:nu], self._v[nu:]
+        self._P, self._Q = self._table[:nu], self._table[nu:]
+        self._views = {"mP": self._m[:nu], "mQ": self._m[nu:], "vP": self._v[:nu], "vQ": self._v[nu:]}
         self.GP, self.GQ = self._g[:nu], self._g[nu:]
         self.reg = float(reg)
         self.adam = E.AdamState(lr)
         self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
+        self.lazy, self.lazy_period = bool(lazy), int(lazy_period)
+        self._stale = False
+        if self.lazy:
+            self._last = torch.zeros(self._table.shape[0], dtype=torch.int32, device=dev)
+            self._stamp = torch.zeros(self._table.shape[0], dtype=torch.int32, device=dev)
+            self._alpha_tab = torch.from_numpy(self.adam.alpha_table(self.ALPHA_STEPS)).to(dev)
         self._ctx = E.NativeStep.for_mf(self)
 
+    # tables and moments as the sweep would have left them: brought up to date on access
+    def flush(self):
+        if self.lazy and self._stale:
+            self._ctx.mf_flush(self.adam)
+            self._stale = False
+
+    P = property(lambda self: (self.flush(), self._P)[1])
+    Q = property(lambda self: (self.flush(), self._Q)[1])
+    mP = property(lambda self: (self.flush(), self._views["mP"])[1])
+    mQ = property(lambda self: (self.flush(), self._views["mQ"])[1])
+    vP = property(lambda self: (self.flush(), self._views["vP"])[1])
+    vQ = property(lambda self: (self.flush(), self._views["vQ"])[1])
+
     def step(self, users, pos, neg, loss_out, plan=None):
-        """One native call: fused gather/BPR/ordered row sums kernel + the TF-sparse Adam sweep.
-        loss_out: 2-float device tensor receiving (bpr_sum, reg_term); plan: the batch's
-        TripletBatch.plan (None: sorted inside the step)."""
+        """One native call: fused gather/BPR/ordered row sums kernel + TF-sparse Adam (lazy replay on
+        the touched and scheduled rows, or the full sweep).  loss_out: 2-float device tensor
+        receiving (bpr_sum, reg_term); plan: the batch's TripletBatch.plan (None: sorted inside the
+        step)."""
+        if self.lazy and self.adam.t + 2 >= self._alpha_tab.numel():
+            raise NotImplementedError("more than %d optimiser steps: enlarge MFEngine.ALPHA_STEPS" % self.ALPHA_STEPS)
         self._ctx.mf_step(users, pos, neg, self.adam, loss_out, plan)
         self.adam.advance()
+        self._stale = True
 
     def step_reference(self, users, pos, neg, loss_out, plan=None):
-        """The same step as individual engine calls (what nrhip_mf_step enqueues)."""
+        """The same step as individual engine calls with the sweep (what nrhip_mf_step enqueues when
+        lazy=False)."""
+        if self.lazy:
+            raise ValueError("step_reference sweeps the table: build the engine with lazy=False")
         if users.numel() > self.max_batch:
             raise ValueError("batch larger than max_batch")
-        E.bpr_mf_grad(self.P, self.Q, users, pos, neg, self.reg, self.GP, self.GQ, self.terms,
+        E.bpr_mf_grad(self._P, self._Q, users, pos, neg, self.reg, self.GP, self.GQ, self.terms,
                       loss_out, plan)
-        E.adam_sparse(self.P, self.mP, self.vP, self.GP, self.adam)
-        E.adam_sparse(self.Q, self.mQ, self.vQ, self.GQ, self.adam)
+        E.adam_sparse(self._P, self._views["mP"], self._views["vP"], self.GP, self.adam)
+        E.adam_sparse(self._Q, self._views["mQ"], self._views["vQ"], self.GQ, self.adam)
         self.adam.advance()
 
 
@@ -311,11 +348,26 @@ class LightGCNEngine:
         self.adam.advance()
 
     def step_bytes(self):
-        """Algorithmic HBM bytes of one step."""
+        """Algorithmic HBM bytes of one step AS IMPLEMENTED, every launch counted:
+        L-1 full forward hops, the wanted-rows hop, the head's 9 row gathers + 2 row stores per
+        triplet, the column-masked hop, L-2 full backward hops, and the last hop with the optimiser
+        in it (CSR + operand read; E0, m, v read and written; the gradient never leaves registers).
+        SURVEY §8d's figure for the reference's own graph (every hop full, Adam as a separate pass)
+        is step_bytes_survey()."""
+        L, nd4 = self.n_layers, self.N * self.d * 4
+        full, masked = self.A.algorithmic_bytes(self.d), self.A.masked_bytes(self.d)
+        if L == 0:
+            return 7 * nd4
+        head = self.max_batch * (11 * self.d * 4 + 12)
+        fwd = (L - 1) * full + masked
+        bwd = masked + max(L - 2, 0) * full if L >= 2 else 0
+        last = self.A.nnz * 8 + (self.N + 1) * 4 + nd4 + 6 * nd4
+        return fwd + head + bwd + last
+
+    def step_bytes_survey(self):
+        """2L full SpMM passes + dense Adam 7·N·d·4 + six [B][d] gathers."""
         nd4 = self.N * self.d * 4
-        spmm = 2 * max(self.n_layers - 1, 0) * self.A.algorithmic_bytes(self.d)   # full passes only
-        adam = 7 * nd4
-        return spmm + adam
+        return 2 * self.n_layers * self.A.algorithmic_bytes(self.d) + 7 * nd4 + 6 * self.max_batch * self.d * 4
 
 
 class FullRankEvaluator:

@@ -331,7 +331,7 @@ def test_native_step_equals_python_launch_sequence(eng):
     # the cut form adds G_0 + reg rows before Adam, the fused form inside it: same fp32 addition
     np.testing.assert_array_equal(c.E0.cpu().numpy(), d2.E0.cpu().numpy())
     P = (rng.randn(U, 32) * 0.01).astype(np.float32); Q = (rng.randn(I, 32) * 0.01).astype(np.float32)
-    m1, m2 = MFEngine(P, Q, 0.001, 0.01, B), MFEngine(P, Q, 0.001, 0.01, B)
+    m1, m2 = MFEngine(P, Q, 0.001, 0.01, B), MFEngine(P, Q, 0.001, 0.01, B, lazy=False)   # lazy replay vs sweep
     for step in range(3):
         bu, bp, bn = (_dev(rng.randint(0, n, B).astype(np.int32)) for n in (U, I, I))
         m1.step(bu, bp, bn, la)
