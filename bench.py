@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (same guide); v_mfma_f32_32x32x2_f32
 
 
 def parse():
@@ -368,6 +369,53 @@ def main():
                                 "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel; scoring of "
                                 "batch b+1 overlaps ranking of batch b (two streams, two slabs)"),
                      "rows_redone_for_ties": getattr(ev, "n_flagged", 0) if args.eval_mode == "pruned" else None}
+
+        # rooflines of the evaluation's two halves, HIP events on the launch stream around the kernels
+        # of the first batch (north_star: MFMA for the scoring matmul, HBM GB/s for the top-K)
+        if args.eval_mode == "pruned" and mine.numel() > 0:
+            eu, ei = lg.final_embeddings()
+            eu, ei = eu.contiguous(), ei.contiguous()
+            ub = mine[:args.eval_batch]
+            nb, d_e, top_k = ub.numel(), eu.shape[1], 20
+            ev._gemm.prepare(ei)
+            M = ev._gemm.tile_maxima(eu, ub, trc)
+            per = torch.empty((nb, 5 * top_k), dtype=torch.float32, device=dev)
+            flg = torch.zeros(nb, dtype=torch.int32, device=dev)
+            E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                M = ev._gemm.tile_maxima(eu, ub, trc)
+            e1.record()
+            for _ in range(3):
+                E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg)
+            e2.record()
+            torch.cuda.synchronize()
+            t_score, t_rank = e0.elapsed_time(e1) / 3e3, e1.elapsed_time(e2) / 3e3       # seconds
+            flops = 2.0 * I * d_e * nb
+            tiles = 2 * ((I + 63) // 64)
+            # level 2, algorithmic HBM bytes: per user its tile maxima and factor row read and M*K metrics
+            # written; the k-major item copy and the train/test lists read once.  (The top_k+1 rescored
+            # tiles per user are gathers from that L2-resident item copy: reported apart, not HBM bytes.)
+            rank_bytes = nb * (tiles * 4 + d_e * 4 + 5 * top_k * 4) + I * d_e * 4 + \
+                (int(train.indptr[-1]) + int(test.indptr[-1])) * 4
+            rescore_l2_bytes = nb * (top_k + 1) * 64 * d_e * 4
+            eval_info["roofline"] = {
+                "bound": "mfma", "kernel": "score_tilemax_kernel<32>", "users": nb,
+                "achieved": flops / t_score / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / t_score / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_score * 1e3,
+                "flops_per_user": 2.0 * I * d_e}
+            eval_info["roofline_topk"] = {
+                "bound": "hbm", "kernel": "rescore_tiles_kernel + select_rows_kernel + metrics_kernel (nrhip_eval_tiles)",
+                "achieved": rank_bytes / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS, "ms": t_rank * 1e3,
+                "bytes": rank_bytes, "rescore_gather_bytes_from_l2": rescore_l2_bytes,
+                "rescore_gather_GBps": rescore_l2_bytes / t_rank / 1e9,
+                "note": "pruned design: the [users][I] score matrix is never written; the top-K works on "
+                        "tile maxima and %d rescored tiles per user gathered from the L2-resident item "
+                        "copy, so its HBM bytes are small and the phase is bound by those L2 gathers and "
+                        "by latency, not by HBM" % (top_k + 1)}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-gowalla)", "value": triplets_per_s,

@@ -423,10 +423,14 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int s = blockIdx.x * kOccWaves + wave;
   const bool active = s < n_occ;
-  uint64_t key = 0;
+  uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
   float acc[CPL];
   if (active) {
     key = plan_key(skey, s);
+    // the neighbours in the sorted order decide "first occurrence of its row" and "another one
+    // follows": requested now, with everything else, not as a dependent load after the barrier
+    if (s > 0) kprev = plan_key(skey, s - 1);
+    if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
     mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale, loss_kind,
                                    (uint32_t)key, lane, acc, term_mf, term_l2, true, lz);
 #pragma unroll
@@ -435,10 +439,10 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
   __syncthreads();
   if (active) {
     const uint32_t row = (uint32_t)(key >> 32);
-    const bool head = s == 0 || (uint32_t)(plan_key(skey, s - 1) >> 32) != row;
+    const bool head = s == 0 || (uint32_t)(kprev >> 32) != row;
     if (head) {
       for (int t = 1; s + t < n_occ; ++t) {
-        const uint64_t k2 = plan_key(skey, s + t);
+        const uint64_t k2 = t == 1 ? knext : plan_key(skey, s + t);
         if ((uint32_t)(k2 >> 32) != row) break;
         if (wave + t < kOccWaves) {
 #pragma unroll
@@ -523,10 +527,12 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int s = blockIdx.x * kOccWaves + wave;
   const bool active = s < n_occ;
-  uint64_t key = 0;
+  uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
   float h[CPL], r[CPL];
   if (active) {
     key = plan_key(skey, s);
+    if (s > 0) kprev = plan_key(skey, s - 1);      // neighbours in the sorted order: see mf_grad_sorted_kernel
+    if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
     lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
                              (uint32_t)key, lane, h, r, term_mf, term_l2, true);
 #pragma unroll
@@ -538,10 +544,10 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
   __syncthreads();
   if (active) {
     const uint32_t row = (uint32_t)(key >> 32);
-    const bool head = s == 0 || (uint32_t)(plan_key(skey, s - 1) >> 32) != row;
+    const bool head = s == 0 || (uint32_t)(kprev >> 32) != row;
     if (head) {
       for (int t = 1; s + t < n_occ; ++t) {
-        const uint64_t k2 = plan_key(skey, s + t);
+        const uint64_t k2 = t == 1 ? knext : plan_key(skey, s + t);
         if ((uint32_t)(k2 >> 32) != row) break;
         if (wave + t < kOccWaves) {
 #pragma unroll
