@@ -196,7 +196,13 @@ def main():
 
     def batch_stream():
         while True:
-            for b in sampler.batches():
+            for k, b in enumerate(sampler.batches()):
+                if k == 0 and rowshard:
+                    # routing counts of the whole epoch: one pass, one device->host copy — the
+                    # steps then run without host synchronisation (sharded.RowRouter.plan_epoch)
+                    lg.plan_epoch(sampler._users[:sampler.n_local], sampler._pos[:sampler.n_local],
+                                  sampler._neg[:sampler.n_local], args.batch)
+                b.index = k
                 if b[0].numel() == args.batch:          # fixed-size steps for the timed region
                     yield b
     stream = batch_stream()
@@ -214,8 +220,8 @@ def main():
                 bu, bp, bn = comm.allgather_cat_finish(token)
                 lg.step(bu, bp, bn, loss_out)
             elif rowshard:
-                bu, bp, bn = next(stream)
-                lg.step(bu, bp, bn, loss_out)
+                b = next(stream)
+                lg.step(b[0], b[1], b[2], loss_out, batch_index=b.index)
             else:
                 b = next(stream)
                 lg.step(b[0], b[1], b[2], loss_out, grad_sync=grad_sync, plan=b.plan)

@@ -555,6 +555,13 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_use
                             int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
                             float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream);
 int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, void* stream);
+/* Ordered sums of gradient rows that arrive from other ranks (row-sharded tables): sort the
+ * keys (local row << 32 | global occurrence position) — n <= 16384 per call — then every row's run
+ * is added in key order and stored, exactly the order of the single-process head on the global batch.
+ * d_index_of_pos[position] = index of that occurrence's row in d_src. */
+int nrhip_sort_u64(uint64_t* d_keys, int n, void* stream);
+int nrhip_rows_sum_sorted(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
+                          const float* d_src, int64_t ld_src, float* d_dst, void* stream);
 int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
                             uint8_t* d_row_flag, int64_t n_rows, int d, float lr, float hyper1,
                             float hyper2, float eps, void* stream);

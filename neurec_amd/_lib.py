@@ -143,6 +143,8 @@ SIGNATURES = {
     "nrhip_pairwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
     "nrhip_pointwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
     "nrhip_mark_rows": [p, i32, i32, p, p],
+    "nrhip_sort_u64": [p, i32, p],
+    "nrhip_rows_sum_sorted": [p, i32, p, i32, p, i64, p, p],
     "nrhip_optimizer_rows_tf": [i32, p, p, p, p, p, i64, i32, f32, f32, f32, f32, p],
     "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
     "nrhip_rows_scatter_add": [p, i32, i32, p, i64, p, p],

@@ -579,6 +579,63 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
   finish_loss(term_mf, term_l2, batch, reg, out2, done);
 }
 
+
+// ---- ordered row sums for gradient rows that arrive from other ranks (row-sharded tables) -------
+// keys (row << 32 | global occurrence position) are sorted; the first key of a row's run adds the
+// run's source rows in that order (src index = index_of_pos[position]) and STORES the sum — the
+// same order the single-process head uses (unsorted_segment_sum over the global batch).
+__global__ __launch_bounds__(kPlanThreads) void sort_u64_kernel(uint64_t* __restrict__ keys, int n, int np2) {
+  extern __shared__ uint64_t s_key[];
+  for (int k = threadIdx.x; k < np2; k += kPlanThreads) s_key[k] = k < n ? keys[k] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (np2 >> 1); i += kPlanThreads) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const uint64_t a = s_key[lo], b = s_key[hi];
+        if ((a > b) == ((lo & k) == 0)) {
+          s_key[lo] = b;
+          s_key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int k = threadIdx.x; k < n; k += kPlanThreads) keys[k] = s_key[k];
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void rows_sum_sorted_kernel(const uint64_t* __restrict__ skey, int n,
+                                                              const int32_t* __restrict__ index_of_pos,
+                                                              int d, const float* __restrict__ src,
+                                                              int64_t ld_src, float* __restrict__ dst) {
+  const int lane = nr_lane();
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n) return;
+  const uint64_t key = plan_key(skey, s);
+  const uint32_t row = (uint32_t)(key >> 32);
+  if (s > 0 && (uint32_t)(plan_key(skey, s - 1) >> 32) == row) return;
+  float acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  for (int t = 0; s + t < n; ++t) {
+    const uint64_t k2 = t == 0 ? key : plan_key(skey, s + t);
+    if ((uint32_t)(k2 >> 32) != row) break;
+    const int64_t i = __builtin_amdgcn_readfirstlane(index_of_pos[(uint32_t)k2]);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int k = lane + c * NR_WAVE;
+      if (k < d) acc[c] = t == 0 ? src[i * ld_src + k] : acc[c] + src[i * ld_src + k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    if (k < d) dst[(int64_t)row * d + k] = acc[c];
+  }
+}
+
 // NRHIP_ATOMIC_SCATTER=1: the former one-wave-per-triplet kernels (fp32 hardware atomics, row sums
 // in arbitrary order) — an A/B knob for measurements, not a product path.
 bool atomic_scatter_knob() {
@@ -661,6 +718,47 @@ int nrhip_bpr_plan(const int32_t* d_users, const int32_t* d_items, const int32_t
   if (n_total == 0) return NR_OK;
   return launch_plan(d_users, d_items, d_third, n_total, batch, d_third ? 3 : 2, n_users,
                      d_plan_out, (hipStream_t)stream);
+}
+
+/* In-place ascending sort of n <= 16384 64-bit keys (one workgroup, LDS bitonic network). */
+int nrhip_sort_u64(uint64_t* d_keys, int n, void* stream) {
+  NR_REQUIRE(d_keys && n >= 0, NR_ERR_ARG, "sort_u64: bad arguments");
+  NR_REQUIRE(n <= kPlanMaxKeys, NR_ERR_UNSUPPORTED, "sort_u64: %d keys (at most %d)", n, kPlanMaxKeys);
+  if (n <= 1) return NR_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NR_CHECK_HIP(hipFuncSetAttribute((const void*)sort_u64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kPlanMaxKeys * (int)sizeof(uint64_t)));
+    attr_set = true;
+  }
+  const int np2 = plan_pow2(n);
+  hipLaunchKernelGGL(sort_u64_kernel, dim3(1), dim3(kPlanThreads), (size_t)np2 * sizeof(uint64_t),
+                     (hipStream_t)stream, d_keys, n, np2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* d_dst[row] = sum of the source rows of the row's run in the SORTED keys (row << 32 | position),
+ * added in key order (the first one stored, the rest added); source row of a key =
+ * d_src[d_index_of_pos[position]].  Rows of d_dst outside the keys are left alone. */
+int nrhip_rows_sum_sorted(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
+                          const float* d_src, int64_t ld_src, float* d_dst, void* stream) {
+  NR_REQUIRE(d_sorted_keys && d_index_of_pos && d_src && d_dst && n >= 0 && d >= 1 && d <= 256 &&
+                 ld_src >= d, NR_ERR_ARG, "rows_sum_sorted: bad arguments");
+  if (n == 0) return NR_OK;
+  dim3 grid((n + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d <= 64)
+    hipLaunchKernelGGL(rows_sum_sorted_kernel<1>, grid, block, 0, st, d_sorted_keys, n, d_index_of_pos, d,
+                       d_src, ld_src, d_dst);
+  else if (d <= 128)
+    hipLaunchKernelGGL(rows_sum_sorted_kernel<2>, grid, block, 0, st, d_sorted_keys, n, d_index_of_pos, d,
+                       d_src, ld_src, d_dst);
+  else
+    hipLaunchKernelGGL(rows_sum_sorted_kernel<4>, grid, block, 0, st, d_sorted_keys, n, d_index_of_pos, d,
+                       d_src, ld_src, d_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
 }
 
 #define NR_BY_WIDTH(KERNEL, ...)                                                          \

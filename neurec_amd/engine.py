@@ -360,6 +360,21 @@ def rows_scatter_add(rows, src, dst):
          C.c_void_p(src.data_ptr()), src.stride(0), _ptr(dst, torch.float32), _stream())
 
 
+def rows_sum_sorted(keys, index_of_pos, src, dst):
+    """dst[row] = ordered sum of src rows per run of the sorted int64 keys (row << 32 | position)."""
+    call("nrhip_rows_sum_sorted", _ptr(keys, torch.int64), keys.numel(), _ptr(index_of_pos, torch.int32),
+         dst.shape[1], C.c_void_p(src.data_ptr()), src.stride(0), _ptr(dst, torch.float32), _stream())
+
+
+def sort_keys(keys):
+    """Ascending in-place sort of int64 keys (non-negative): one LDS bitonic workgroup up to 16384
+    keys, torch.sort beyond (bookkeeping, not arithmetic)."""
+    if keys.numel() <= 16384:
+        call("nrhip_sort_u64", _ptr(keys, torch.int64), keys.numel(), _stream())
+        return keys
+    return torch.sort(keys)[0]
+
+
 def rows_clear(rows, d, bufs=(), flag=None):
     b = list(bufs) + [None] * (4 - len(bufs))
     call("nrhip_rows_clear", _ptr(rows, torch.int32), rows.numel(), int(d),

@@ -84,25 +84,32 @@ class Comm:
         out.copy_(host.reshape(out.shape))
         return out
 
-    def all_to_all_rows(self, send, send_counts):
+    def all_to_all_rows(self, send, send_counts, recv_counts=None):
         """Variable all-to-all of rows: `send` [n][...] is ordered by destination rank,
         `send_counts[r]` rows go to rank r.  Returns (recv [m][...], recv_counts) ordered by
-        source rank.  RCCL all_to_all_single over xGMI; gloo: host-staged point-to-point."""
+        source rank.  With `recv_counts` given (e.g. from RowRouter.plan_epoch) nothing is
+        exchanged or copied to the host besides the rows themselves; without, the counts are
+        exchanged first (one host synchronisation).  RCCL all_to_all_single over xGMI; gloo:
+        host-staged point-to-point."""
         send_counts = [int(c) for c in send_counts]
         if not self.active:
             return send, send_counts
         tail = tuple(send.shape[1:])
         if self.backend == "nccl":
-            sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
-            rc = torch.empty_like(sc)
-            dist.all_to_all_single(rc, sc)
-            recv_counts = [int(c) for c in rc.cpu()]
+            if recv_counts is None:
+                sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+                rc = torch.empty_like(sc)
+                dist.all_to_all_single(rc, sc)
+                recv_counts = [int(c) for c in rc.cpu()]
+            recv_counts = [int(c) for c in recv_counts]
             recv = torch.empty((sum(recv_counts),) + tail, dtype=send.dtype, device=send.device)
             dist.all_to_all_single(recv, send.contiguous(), recv_counts, send_counts)
             return recv, recv_counts
-        mat = torch.empty((self.world, self.world), dtype=torch.int64)
-        dist.all_gather([mat[r] for r in range(self.world)], torch.tensor(send_counts, dtype=torch.int64))
-        recv_counts = [int(mat[r, self.rank]) for r in range(self.world)]
+        if recv_counts is None:
+            mat = torch.empty((self.world, self.world), dtype=torch.int64)
+            dist.all_gather([mat[r] for r in range(self.world)], torch.tensor(send_counts, dtype=torch.int64))
+            recv_counts = [int(mat[r, self.rank]) for r in range(self.world)]
+        recv_counts = [int(c) for c in recv_counts]
         host_send = send.detach().cpu().contiguous()
         host_recv = torch.empty((sum(recv_counts),) + tail, dtype=send.dtype)
         reqs, so, ro = [], 0, 0

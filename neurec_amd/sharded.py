@@ -4,19 +4,31 @@ a dozen of them).
 
 Partition: the N = U + I node rows are cut into `world` padded blocks of b = ⌈N/world⌉ rows; rank r
 owns rows [r·b, (r+1)·b) of the embedding table E0, of its Adam moments and of every layer
-buffer, plus the CSR rows of Â (and of Âᵀ when Â is not symmetric) for those nodes.
+buffer, plus the CSR rows of Â (and of Âᵀ when Â is not symmetric) for those nodes.  A rank can
+be built from its own row block alone (`local_rows=`): no rank needs the whole graph.
 
 One LightGCN step (LightGCN.py:132-166,178) then has exactly these exchange points:
   * per propagation hop (L forward, L backward): ONE all-gather of the [b][d] blocks into the
     [world·b][d] operand of the local SpMM  (RCCL all-gather over xGMI; N·d·4 bytes per hop);
   * BPR head: the 3·B rows a rank's triplets touch live on their owners — ids go out with an
     all-to-all, owners answer with the rows (Esum and E0 side by side), the head runs locally on
-    the compact [3B][d] block, and the 3·B gradient rows return by the reverse all-to-all and are
-    scatter-added into the owners' buffers;
+    the compact [3B][d] block, and the 3·B gradient rows return by the reverse all-to-all;
+  * the owners add the rows they receive IN THE ORDER OF THE GLOBAL BATCH (class, rank, position
+    — what TF's unsorted_segment_sum over the concatenated batch does, and what the single-GPU
+    head does): keys (row, global position) are sorted (nrhip_sort_u64) and every row's run is
+    summed in key order (nrhip_rows_sum_sorted).  No atomics: the sharded step is bit-identical to
+    the single-process step on the concatenated batch (tests assert array_equal);
   * Adam is owner-local (dense TF-Adam on the rank's block): no exchange.
-The result equals the single-process step on the concatenated global batch (tests: two ranks
-vs one process).  All arithmetic is the same HIP kernels as the replicated engine; the
-collectives are torch.distributed plumbing (`parallel.Comm`).
+Routing needs the per-destination row counts on the host (all_to_all_single takes Python lists).
+`plan_epoch` computes them for every batch of an epoch stream in one pass and ONE device→host
+copy, so the steps themselves run without host synchronisation; a step on a batch that was not
+planned falls back to counting on the spot (one sync).
+Why the per-hop all-gather is not overlapped with the SpMM over the already-local columns: a
+row's sum would become (local columns) + (remote columns) instead of ascending-column order —
+a different fp32 association from the single-GPU kernel and from TF's, so rankings could no
+longer be called identical.  The exact form is kept; the hop's communication is exposed.
+All arithmetic is the same HIP kernels as the replicated engine; the collectives are
+torch.distributed plumbing (`parallel.Comm`).
 """
 import numpy as np
 import torch
@@ -25,9 +37,113 @@ from . import engine as E
 from . import parallel
 
 
+class RowRouter:
+    """Requests for table rows by global node id -> owners and back, for block-partitioned tables."""
+
+    CODE = 1 << 24                       # occurrence code = class * CODE + position in the rank's batch
+
+    def __init__(self, comm, block_rows):
+        self.comm, self.b = comm, int(block_rows)
+        self.world, self.rank = comm.world, comm.rank
+        self._epoch = None               # (batch, send counts [nb][world], recv counts, sizes [nb][world])
+
+    # ---- per-epoch routing tables: no host sync inside the steps
+    def plan_epoch(self, classes, offsets, batch):
+        """classes: list of int32 device tensors (one per id class: users, pos, neg) holding this
+        rank's slice of the epoch stream; offsets: global-id offset per class.  One pass + one
+        count exchange + one device->host copy for the whole epoch."""
+        n = classes[0].numel()
+        nb = (n + batch - 1) // batch
+        dev = classes[0].device
+        which = torch.arange(n, device=dev) // batch
+        cnt = torch.zeros(nb * self.world, dtype=torch.int64, device=dev)
+        for ids, off in zip(classes, offsets):
+            owner = torch.div(ids.long() + off, self.b, rounding_mode="floor")
+            cnt += torch.bincount(which * self.world + owner, minlength=nb * self.world)
+        send = cnt.view(nb, self.world)
+        sizes = torch.full((nb,), batch, dtype=torch.int64, device=dev)
+        if nb:
+            sizes[-1] = n - (nb - 1) * batch
+        recv, all_sizes = self._exchange_counts(send, sizes)
+        self._epoch = (int(batch), send.cpu().tolist(), recv.cpu().tolist(), all_sizes.cpu().tolist())
+
+    def _exchange_counts(self, send, sizes):
+        """send [nb][world] (what I send to r in batch k) -> recv [nb][world] (what r sends me);
+        sizes [nb] -> [nb][world] batch length of every rank."""
+        if not self.comm.active:
+            return send.clone(), sizes.view(-1, 1).clone()
+        import torch.distributed as dist
+        nb = send.shape[0]
+        host = self.comm.backend != "nccl"
+        s = send.t().contiguous()                                   # [world][nb]: row r goes to rank r
+        r = torch.empty_like(s)
+        g = torch.empty((self.world, nb), dtype=torch.int64, device=s.device)
+        if host:
+            s, r, g, sizes = s.cpu(), r.cpu(), g.cpu(), sizes.cpu()
+            mat = torch.empty((self.world,) + tuple(s.shape), dtype=torch.int64)     # gloo: no all_to_all
+            dist.all_gather(list(mat.unbind(0)), s)
+            r = mat[:, self.rank, :].contiguous()
+            dist.all_gather(list(g.unbind(0)), sizes.contiguous())
+            r, g = r.to(send.device), g.to(send.device)
+        else:
+            dist.all_to_all_single(r, s)
+            dist.all_gather_into_tensor(g, sizes.contiguous())
+        return r.t().contiguous(), g.t().contiguous()
+
+    def epoch_counts(self, k, batch_len):
+        ep = self._epoch
+        if ep is None or k is None or k >= len(ep[1]) or ep[3][k][self.rank] != batch_len:
+            return None
+        return ep[1][k], ep[2][k], ep[3][k]
+
+    # ---- one batch
+    def request(self, class_ids, offsets, planned=None):
+        """ids of one batch -> (order, asked local rows, asked occurrence codes, send_counts,
+        recv_counts, sizes).  planned = epoch_counts(k, B) or None (then counted now: host sync)."""
+        B = class_ids[0].numel()
+        nodes = torch.cat([ids.long() + off for ids, off in zip(class_ids, offsets)])
+        code = torch.cat([torch.arange(B, device=nodes.device, dtype=torch.int32) + c * self.CODE
+                          for c in range(len(class_ids))])
+        owner = torch.div(nodes, self.b, rounding_mode="floor")
+        order = torch.argsort(owner, stable=True)
+        local = (nodes - owner * self.b)[order].to(torch.int32)
+        packed = torch.stack([local, code[order]], dim=1).contiguous()          # [n][2] int32
+        if planned is None:
+            send_counts = torch.bincount(owner, minlength=self.world)[:self.world]
+            sizes = torch.tensor([B], dtype=torch.int64, device=nodes.device)
+            recv, all_sizes = self._exchange_counts(send_counts.view(1, -1), sizes)
+            send_counts, recv_counts = send_counts.cpu().tolist(), recv[0].cpu().tolist()
+            sizes = all_sizes[0].cpu().tolist()
+        else:
+            send_counts, recv_counts, sizes = planned
+        asked, _ = self.comm.all_to_all_rows(packed, send_counts, recv_counts)
+        return order, asked[:, 0].contiguous(), asked[:, 1].contiguous(), send_counts, recv_counts, sizes
+
+    def ordered_keys(self, asked_rows, asked_code, recv_counts, sizes):
+        """Sorted keys (local row << 32 | global position) of the rows received from the other ranks and
+        the index_of_pos table: global position = class * G + (offset of the source rank) + b, G = the
+        global batch length — the occurrence order of the single-process head on the concatenated batch."""
+        dev = asked_rows.device
+        n = asked_rows.numel()
+        G = int(sum(sizes))
+        off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.int64, device=dev)
+        src = torch.repeat_interleave(torch.arange(self.world, device=dev),
+                                      torch.tensor(recv_counts, dtype=torch.int64, device=dev), output_size=n)
+        cls = torch.div(asked_code, self.CODE, rounding_mode="floor").long()
+        gpos = cls * G + off[src] + (asked_code.long() - cls * self.CODE)
+        index_of_pos = torch.zeros(3 * G, dtype=torch.int32, device=dev)
+        index_of_pos[gpos] = torch.arange(n, dtype=torch.int32, device=dev)
+        keys = E.sort_keys(((asked_rows.long() << 32) | gpos).contiguous())
+        return keys, index_of_pos
+
+
 class ShardedLightGCN:
     def __init__(self, comm, adj_csr, n_users, n_items, embed, n_layers, lr, reg, max_batch,
-                 symmetric=None):
+                 symmetric=None, local_rows=None, local_rows_t=None):
+        """adj_csr: the full [N][N] scipy adjacency (each rank slices its block), or None with
+        local_rows = (indptr, indices, vals) of this rank's row block only (global column ids;
+        local_rows_t for Âᵀ when Â is not symmetric).  embed: the full [N][d] table or just this
+        rank's [n_loc][d] rows."""
         dev = E.require_gpu()
         self.comm, self.rank, self.world = comm, comm.rank, comm.world
         self.n_users, self.n_items = int(n_users), int(n_items)
@@ -38,18 +154,23 @@ class ShardedLightGCN:
         self.hi = min(self.lo + self.b, self.N)
         self.n_loc = self.hi - self.lo
         self.Npad = self.b * self.world
-        a = adj_csr.tocsr().astype(np.float32)
-        a.sort_indices()
-        if symmetric is None:
-            symmetric = (a != a.T).nnz == 0
-        # local row block, padded to b rows (empty rows) so every rank runs the same shapes
-        self.A = self._local_rows(a)
-        self.At = self.A if symmetric else self._local_rows(a.T.tocsr())
+        if local_rows is not None:
+            self.A = self._from_block(*local_rows)
+            self.At = self.A if local_rows_t is None else self._from_block(*local_rows_t)
+        else:
+            a = adj_csr.tocsr().astype(np.float32)
+            a.sort_indices()
+            if symmetric is None:
+                symmetric = (a != a.T).nnz == 0
+            # local row block, padded to b rows (empty rows) so every rank runs the same shapes
+            self.A = self._local_rows(a)
+            self.At = self.A if symmetric else self._local_rows(a.T.tocsr())
         embed = np.asarray(embed, dtype=np.float32)
         self.d = embed.shape[1]
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         self.E0 = z(self.b, self.d)
-        self.E0[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(embed[self.lo:self.hi])).to(dev)
+        mine = embed if (embed.shape[0] == self.n_loc and embed.shape[0] != self.N) else embed[self.lo:self.hi]
+        self.E0[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
         self.m, self.v = z(self.b, self.d), z(self.b, self.d)
         self.X = z(self.Npad, self.d)                       # gathered operand of the local SpMM
         self.Ya, self.Yb, self.Esum = (z(self.b, self.d) for _ in range(3))
@@ -61,13 +182,23 @@ class ShardedLightGCN:
         self.adam = E.AdamState(lr)
         self._cu = torch.arange(self.max_batch, dtype=torch.int32, device=dev)
         self._cp = self._cu.clone()
+        self.router = RowRouter(comm, self.b)
+        self._offsets = (0, self.n_users, self.n_users)
+
+    def _from_block(self, indptr, indices, vals):
+        ip = np.zeros(self.b + 1, dtype=np.int64)
+        ip[1:self.n_loc + 1] = np.asarray(indptr, dtype=np.int64)[1:self.n_loc + 1]
+        ip[self.n_loc + 1:] = ip[self.n_loc]
+        return E.SpmmCSR(ip, np.asarray(indices, np.int32), np.asarray(vals, np.float32), n_cols=self.Npad)
 
     def _local_rows(self, a):
         blk = a[self.lo:self.hi]
-        indptr = np.zeros(self.b + 1, dtype=np.int64)
-        indptr[1:self.n_loc + 1] = blk.indptr[1:]
-        indptr[self.n_loc + 1:] = blk.indptr[-1]
-        return E.SpmmCSR(indptr, blk.indices, blk.data, n_cols=self.Npad)
+        return self._from_block(blk.indptr, blk.indices, blk.data)
+
+    def plan_epoch(self, users, pos, neg, batch):
+        """Routing counts of every batch of this rank's epoch stream (see RowRouter.plan_epoch);
+        afterwards step(..., batch_index=k) runs without host synchronisation."""
+        self.router.plan_epoch([users, pos, neg], self._offsets, batch)
 
     # ------------------------------------------------------------------ propagation
     def propagate(self):
@@ -96,42 +227,35 @@ class ShardedLightGCN:
         self.comm.all_gather_rows(loc, self.X)
         return self.X[:self.n_users], self.X[self.n_users:self.N]
 
-    # ------------------------------------------------------------------ lookups
-    def _route(self, node_ids):
-        """Sort requested global node ids by owner: (order, local ids sorted, counts)."""
-        owner = torch.div(node_ids, self.b, rounding_mode="floor")
-        order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=self.world)[:self.world].cpu().tolist()
-        local = (node_ids - owner * self.b)[order].to(torch.int32).contiguous()
-        return order, local, counts
-
-    def step(self, users, pos, neg, loss_out=None):
+    def step(self, users, pos, neg, loss_out=None, batch_index=None):
         """One optimiser step on this rank's B triplets (global batch = all ranks' triplets)."""
         B, d, dev = users.numel(), self.d, self.E0.device
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
         esum = self.propagate()
         # --- lookup: ids -> owners -> [Esum | E0] rows back
-        nodes = torch.cat([users.long(), pos.long() + self.n_users, neg.long() + self.n_users])
-        order, local, counts = self._route(nodes)
-        asked, asked_counts = self.comm.all_to_all_rows(local, counts)
+        planned = self.router.epoch_counts(batch_index, B)
+        order, asked, asked_code, send_counts, recv_counts, sizes = \
+            self.router.request([users, pos, neg], self._offsets, planned)
         rows = torch.empty((asked.numel(), 2 * d), dtype=torch.float32, device=dev)
         E.rows_gather(asked, esum, rows[:, :d])
         E.rows_gather(asked, self.E0, rows[:, d:])
-        got, _ = self.comm.all_to_all_rows(rows, asked_counts)
+        got, _ = self.comm.all_to_all_rows(rows, recv_counts, send_counts)
         req = self.req_rows[:3 * B]
         req[order] = got                                               # back to request order (plumbing copy)
         es = req[:, :d].contiguous()
         e0 = req[:, d:].contiguous()
-        # --- BPR head on the compact block: "users" = rows [0,B), "items" = rows [B,3B)
+        # --- BPR head on the compact block: "users" = rows [0,B), "items" = rows [B,3B); every
+        #     occurrence has its own row there, so gs / gr hold one gradient row per occurrence
         gs, gr = self.gc_star[:3 * B], self.gc_reg[:3 * B]
         E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B],
                             (self._cp[:B] + B).contiguous(), self.reg, gs, gr, self.terms, loss_out)
-        # --- gradients back to the owners, summed into H (= dL/dE*, then /(L+1)) and Greg
+        # --- gradient rows back to the owners, added there in the order of the global batch
         back = torch.cat([gs, gr], dim=1)[order].contiguous()
-        mine, _ = self.comm.all_to_all_rows(back, counts)
-        E.rows_scatter_add(asked, mine[:, :d], self.Ga)                 # Ga: scratch for Gstar rows
-        E.rows_scatter_add(asked, mine[:, d:], self.Greg)
+        mine, _ = self.comm.all_to_all_rows(back, send_counts, recv_counts)
+        keys, index_of_pos = self.router.ordered_keys(asked, asked_code, recv_counts, sizes)
+        E.rows_sum_sorted(keys, index_of_pos, mine[:, :d], self.Ga)     # Ga: scratch for the Gstar rows
+        E.rows_sum_sorted(keys, index_of_pos, mine[:, d:], self.Greg)
         E.div_scalar(self.Ga, float(self.L + 1), self.H)
         # --- backward hops: G_k = H + Aᵀ G_{k+1}
         g = self.H
@@ -143,7 +267,7 @@ class ShardedLightGCN:
             g = out
         E.adam_dense2(self.E0, self.m, self.v, g, self.Greg, self.adam)
         self.adam.advance()
-        gs.zero_(); gr.zero_(); self.Greg.zero_(); self.Ga.zero_()    # buffers the head accumulates into
+        self.Greg.zero_(); self.Ga.zero_()                              # rows the ordered sums stored
         return loss_out
 
 
@@ -151,9 +275,10 @@ class ShardedMF:
     """BPR-MF with both tables row-sharded (SURVEY §8e "BPR-MF step"): rank r owns the padded block
     [r·b, (r+1)·b) of the node rows (users first, then items) with its Adam moments.  One step
     (MF.py:54-76,101) = ids to the owners (all-to-all) -> the requested rows back (all-to-all) ->
-    the BPR head on the compact [3B][d] block -> gradient rows to the owners (all-to-all),
-    scatter-added (duplicates summed) -> owner-local TF-sparse Adam, which sweeps every local row
-    (SURVEY H2).  Equals the single-process step on the concatenated global batch."""
+    the BPR head on the compact [3B][d] block -> gradient rows to the owners (all-to-all), added
+    there in the order of the global batch (sorted keys, no atomics) -> owner-local TF-sparse Adam,
+    which sweeps every local row.  Bit-identical to the single-process step on the
+    concatenated global batch."""
 
     def __init__(self, comm, user_table, item_table, lr, reg, max_batch):
         dev = E.require_gpu()
@@ -178,20 +303,22 @@ class ShardedMF:
         self.gP, self.gQ = z(self.max_batch, self.d), z(2 * self.max_batch, self.d)
         self.terms = z(8 * self.max_batch)
         self._ar = torch.arange(2 * self.max_batch, dtype=torch.int32, device=dev)
+        self.router = RowRouter(comm, self.b)
+        self._offsets = (0, self.n_users, self.n_users)
 
-    def step(self, users, pos, neg, loss_out):
+    def plan_epoch(self, users, pos, neg, batch):
+        self.router.plan_epoch([users, pos, neg], self._offsets, batch)
+
+    def step(self, users, pos, neg, loss_out, batch_index=None):
         B, d = users.numel(), self.d
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
-        nodes = torch.cat([users.long(), pos.long() + self.n_users, neg.long() + self.n_users])
-        owner = torch.div(nodes, self.b, rounding_mode="floor")
-        order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=self.world)[:self.world].cpu().tolist()
-        local = (nodes - owner * self.b)[order].to(torch.int32).contiguous()
-        asked, asked_counts = self.comm.all_to_all_rows(local, counts)          # exchange 1: ids
+        planned = self.router.epoch_counts(batch_index, B)
+        order, asked, asked_code, send_counts, recv_counts, sizes = \
+            self.router.request([users, pos, neg], self._offsets, planned)      # exchange 1: ids
         rows = torch.empty((asked.numel(), d), dtype=torch.float32, device=self.T.device)
         E.rows_gather(asked, self.T, rows)
-        got, _ = self.comm.all_to_all_rows(rows, asked_counts)                  # exchange 2: rows
+        got, _ = self.comm.all_to_all_rows(rows, recv_counts, send_counts)      # exchange 2: rows
         req = self.req[:3 * B]
         req[order] = got
         # compact tables: P' = rows [0,B) (one per triplet), Q' = rows [B,3B) (pos then neg)
@@ -200,11 +327,11 @@ class ShardedMF:
         E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], (self._ar[:B] + B).contiguous(), self.reg,
                       gP, gQ, self.terms, loss_out)
         back = torch.cat([gP, gQ])[order].contiguous()
-        mine, _ = self.comm.all_to_all_rows(back, counts)                       # exchange 3: gradients
-        E.rows_scatter_add(asked, mine, self.G)
+        mine, _ = self.comm.all_to_all_rows(back, send_counts, recv_counts)     # exchange 3: gradients
+        keys, index_of_pos = self.router.ordered_keys(asked, asked_code, recv_counts, sizes)
+        E.rows_sum_sorted(keys, index_of_pos, mine, self.G)
         E.adam_sparse(self.T, self.m, self.v, self.G, self.adam)                # clears G
         self.adam.advance()
-        gP.zero_(); gQ.zero_()
 
     def tables(self):
         """Full (P, Q) on every rank (one all-gather; evaluation entrance)."""
