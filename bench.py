@@ -32,7 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--shape", default="gowalla")
+    ap.add_argument("--shape", default="gowalla",
+                    help="gowalla | ml-100k (host-generated twins) | config4 (BASELINE configs[3], generated "
+                         "on the device; needs --dp-mode rowshard; --scale shrinks it)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=1024)     # conf/LightGCN.properties:5
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
@@ -170,21 +172,46 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     # ---------------- workload, resident in HBM before anything is timed
-    train, test = synth.interactions(args.shape, seed=2018, scale=args.scale)
-    U, I = train.shape
-    coo = train.tocoo()
-    from neurec_amd.graph import lightgcn_adjacency
-    A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
-    E0 = synth.xavier_uniform(U + I, args.dim, np.random.RandomState(2017))
     exchange = comm.active and args.dp_mode == "triplets"
     rowshard = args.dp_mode == "rowshard"
-    if rowshard:
+    config4 = args.shape == "config4"
+    if config4:
+        # BASELINE configs[3] (U = 10^7, I = 10^6, E = 2·10^8 at --scale 1): the graph is generated
+        # ON THE DEVICE (Philox counter stream, SURVEY 8d: never materialised on the host), every rank
+        # builds only its own row block of the adjacency, tables are row-sharded.
+        if not rowshard:
+            raise SystemExit("--shape config4 runs with --dp-mode rowshard (row-sharded tables)")
+        from neurec_amd import parallel as par
         from neurec_amd.sharded import ShardedLightGCN
-        lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
+        U, I, n_edges = (max(int(x * args.scale), 64) for x in synth.CONFIG4)
+        tr_ptr, tr_idx = synth.device_interactions(U, I, n_edges, seed=2018, device=dev)
+        n_train = int(tr_ptr[-1])
+        blk = par.block_size(U + I, comm.world)
+        lo, hi = min(comm.rank * blk, U + I), min((comm.rank + 1) * blk, U + I)
+        rows = synth.device_lightgcn_adjacency(tr_ptr, tr_idx, U, I, lo, hi)
+        lim = float(np.sqrt(6.0 / (U + I + args.dim)))
+        g = torch.Generator(device=dev); g.manual_seed(2017 + comm.rank)
+        E0 = (torch.rand(hi - lo, args.dim, generator=g, device=dev) * 2 - 1) * lim
+        lg = ShardedLightGCN(comm, None, U, I, E0, args.layers, 0.01, 1e-3, args.batch, local_rows=rows)
+        del rows
+        trc, tec, train, test = E.DeviceCSR(tr_ptr, tr_idx, I), None, None, None
+        args.no_eval, args.no_mf, args.no_cpu_baseline = True, True, True
+        train_nnz = n_train
     else:
-        lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,            # lr, reg: conf/LightGCN.properties
-                            args.batch * (comm.world if exchange else 1))
-    trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
+        train, test = synth.interactions(args.shape, seed=2018, scale=args.scale)
+        U, I = train.shape
+        train_nnz = train.nnz
+        coo = train.tocoo()
+        from neurec_amd.graph import lightgcn_adjacency
+        A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+        E0 = synth.xavier_uniform(U + I, args.dim, np.random.RandomState(2017))
+        if rowshard:
+            from neurec_amd.sharded import ShardedLightGCN
+            lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
+        else:
+            lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,        # lr, reg: conf/LightGCN.properties
+                                args.batch * (comm.world if exchange else 1))
+        trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
     # single GPU / all-reduce / row-shard modes step on the sampler's own batches: their batch plans
     # (the order of the duplicate-row gradient sums) are sorted once per epoch by the sampler; in
     # the id-exchange mode the global batch only exists after the all-gather: sorted inside the step
@@ -245,7 +272,7 @@ def main():
         comm.allgather_cat_finish(inflight[0])           # drain the prefetched id gather
 
     # ---------------- roofline of the dominant kernel (CSR SpMM): HIP events on the launch stream
-    reps = 20
+    reps = 20 if lg.A.nnz < 50_000_000 else 3
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lg.propagate(); torch.cuda.synchronize()
     ev0.record()
@@ -430,7 +457,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "LightGCN on synthetic %s-shaped interactions (U=%d, I=%d, E=%d), "
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
-                               % (args.shape, U, I, train.nnz, args.layers, args.dim, args.batch),
+                               % (args.shape, U, I, train_nnz, args.layers, args.dim, args.batch),
                    "global_batch": comm.world * args.batch,
                    "parallelism": ("dp%d (replicated tables; per step one all-gather of 12 B/triplet "
                                    "of ids, every rank steps on the global batch)" % comm.world

@@ -59,14 +59,19 @@ class DeviceCSR:
 
     def __init__(self, indptr, indices, n_cols):
         dev = require_gpu()
-        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        if isinstance(indices, torch.Tensor):          # already on the device (synth.device_*): no host copy
+            self.indptr = indptr.to(dev, torch.int64).contiguous()
+            self.indices = indices.to(dev, torch.int32).contiguous()
+            indptr = self.indptr.cpu().numpy()
+        else:
+            indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+            indices = np.ascontiguousarray(indices, dtype=np.int32)
+            self.indptr = torch.from_numpy(indptr).to(dev)
+            self.indices = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).to(dev)
         self.n_rows = len(indptr) - 1
         self.n_cols = int(n_cols)
         self.nnz = int(indptr[-1])
         self.h_indptr = indptr
-        self.indptr = torch.from_numpy(indptr).to(dev)
-        self.indices = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).to(dev)
 
     @staticmethod
     def from_scipy(mat):
@@ -90,8 +95,10 @@ class DeviceCSR:
 
     def row_of(self):
         """User id of every CSR position (users_list of data/sampler.py:24-39)."""
-        rows = np.repeat(np.arange(self.n_rows, dtype=np.int32), np.diff(self.h_indptr))
-        return torch.from_numpy(rows if len(rows) else np.zeros(1, np.int32)).to(self.indptr.device)
+        if self.nnz == 0:
+            return torch.zeros(1, dtype=torch.int32, device=self.indptr.device)
+        return torch.repeat_interleave(torch.arange(self.n_rows, dtype=torch.int32, device=self.indptr.device),
+                                       self.indptr[1:] - self.indptr[:-1], output_size=self.nnz)
 
 
 # ----------------------------------------------------------------------------- evaluator
@@ -476,19 +483,26 @@ class SpmmCSR:
 
     def __init__(self, indptr, indices, vals, n_cols=None, item_rows=0, item_nnz=0, split_row=0):
         dev = require_gpu()
-        self.h_indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        if isinstance(indices, torch.Tensor):          # device-built matrices (synth.device_*): stay there
+            self.indptr = indptr.to(dev, torch.int64).contiguous()
+            self.h_indptr = self.indptr.cpu().numpy()
+            self.indices = indices.to(dev, torch.int32).contiguous()
+            self.vals = vals.to(dev, torch.float32).contiguous()
+            self._h_indices = None                     # fetched only if a lane-group schedule is built
+        else:
+            self.h_indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+            idx = np.ascontiguousarray(indices, dtype=np.int32)
+            val = np.ascontiguousarray(vals, dtype=np.float32)
+            self._h_indices = idx
+            self.indices = torch.from_numpy(idx if len(idx) else np.zeros(1, np.int32)).to(dev)
+            self.vals = torch.from_numpy(val if len(val) else np.zeros(1, np.float32)).to(dev)
+            self.indptr = torch.from_numpy(self.h_indptr).to(dev)
         self.n_rows = len(self.h_indptr) - 1
         self.nnz = int(self.h_indptr[-1])
         self.n_cols = self.n_rows if n_cols is None else n_cols
-        idx = np.ascontiguousarray(indices, dtype=np.int32)
-        val = np.ascontiguousarray(vals, dtype=np.float32)
-        self.h_indices = idx
         self.split_row = int(split_row)
         self.blocked = None               # lane-group schedule of the last dim asked for
         self._blocked = {}                # d -> (plan handle | None, buffer), built on first use
-        self.indices = torch.from_numpy(idx if len(idx) else np.zeros(1, np.int32)).to(dev)
-        self.vals = torch.from_numpy(val if len(val) else np.zeros(1, np.float32)).to(dev)
-        self.indptr = torch.from_numpy(self.h_indptr).to(dev)
         nbytes = C.c_size_t(0)
         call("nrhip_spmm_plan_bytes", self.n_rows, self.nnz, C.byref(nbytes))
         self.plan_buf = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
@@ -499,6 +513,12 @@ class SpmmCSR:
         call("nrhip_spmm_plan_info", self.plan, C.byref(nseg), C.byref(nsplit))
         self.n_segments, self.n_split_rows = nseg.value, nsplit.value
         self._ws = {}
+
+    @property
+    def h_indices(self):
+        if self._h_indices is None:
+            self._h_indices = self.indices[:self.nnz].cpu().numpy()
+        return self._h_indices
 
     @staticmethod
     def from_scipy(mat, item_rows=0, item_nnz=0, split_row=0):

@@ -165,12 +165,17 @@ class ShardedLightGCN:
             # local row block, padded to b rows (empty rows) so every rank runs the same shapes
             self.A = self._local_rows(a)
             self.At = self.A if symmetric else self._local_rows(a.T.tocsr())
-        embed = np.asarray(embed, dtype=np.float32)
-        self.d = embed.shape[1]
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        self.E0 = z(self.b, self.d)
-        mine = embed if (embed.shape[0] == self.n_loc and embed.shape[0] != self.N) else embed[self.lo:self.hi]
-        self.E0[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+        if isinstance(embed, torch.Tensor):             # this rank's rows, already on the device
+            self.d = embed.shape[1]
+            self.E0 = z(self.b, self.d)
+            self.E0[:self.n_loc] = embed[:self.n_loc] if embed.shape[0] == self.n_loc else embed[self.lo:self.hi]
+        else:
+            embed = np.asarray(embed, dtype=np.float32)
+            self.d = embed.shape[1]
+            self.E0 = z(self.b, self.d)
+            mine = embed if (embed.shape[0] == self.n_loc and embed.shape[0] != self.N) else embed[self.lo:self.hi]
+            self.E0[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
         self.m, self.v = z(self.b, self.d), z(self.b, self.d)
         self.X = z(self.Npad, self.d)                       # gathered operand of the local SpMM
         self.Ya, self.Yb, self.Esum = (z(self.b, self.d) for _ in range(3))
@@ -186,6 +191,11 @@ class ShardedLightGCN:
         self._offsets = (0, self.n_users, self.n_users)
 
     def _from_block(self, indptr, indices, vals):
+        if isinstance(indices, torch.Tensor):          # a block built on the device (synth.device_*)
+            ip = torch.zeros(self.b + 1, dtype=torch.int64, device=indices.device)
+            ip[1:self.n_loc + 1] = indptr[1:self.n_loc + 1]
+            ip[self.n_loc + 1:] = ip[self.n_loc]
+            return E.SpmmCSR(ip, indices, vals, n_cols=self.Npad)
         ip = np.zeros(self.b + 1, dtype=np.int64)
         ip[1:self.n_loc + 1] = np.asarray(indptr, dtype=np.int64)[1:self.n_loc + 1]
         ip[self.n_loc + 1:] = ip[self.n_loc]

@@ -61,3 +61,81 @@ def xavier_uniform(rows, d, rng):
     """tf.contrib.layers.xavier_initializer() for a [rows, d] variable (LightGCN.py:87-89) [EXT]."""
     lim = np.sqrt(6.0 / (rows + d))
     return rng.uniform(-lim, lim, (rows, d)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- on the device
+CONFIG4 = (10_000_000, 1_000_000, 200_000_000)      # BASELINE configs[3]: users, items, train edges
+
+
+def device_interactions(n_users, n_items, n_edges, seed=2018, device="cuda", max_degree=2000):
+    """The interaction law of `interactions` (log-normal user degrees floored at 8 and rescaled to
+    n_edges, capped; items by inverse-CDF draws from p ∝ (rank + 10)^-0.8 with shuffled ranks),
+    generated ON THE DEVICE from torch's counter-based Philox stream — SURVEY §8d asks that the
+    config-4 graph (2·10⁸ edges) is never materialised on the host.  Duplicate (user, item) draws
+    are dropped, so the edge count comes out a little under n_edges.  Returns device tensors
+    (indptr int64 [U+1], item indices int32 ascending per user)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    deg = torch.exp(torch.randn(n_users, generator=g, device=device) * 0.9 + 2.9).round().clamp_(min=8)
+    deg = (deg * (n_edges / float(deg.sum()))).round().clamp_(1, min(max_degree, n_items // 4)).long()
+    pop = (torch.arange(n_items, device=device, dtype=torch.float64) + 10.0) ** -0.8
+    pop = pop[torch.randperm(n_items, generator=g, device=device)]           # popularity is not tied to the id
+    cdf = torch.cumsum(pop / pop.sum(), 0).float()
+    owner = torch.repeat_interleave(torch.arange(n_users, device=device), deg)
+    items = torch.searchsorted(cdf, torch.rand(owner.numel(), generator=g, device=device)).clamp_(max=n_items - 1)
+    key = torch.unique(owner * n_items + items)                               # dedup; sorted by (user, item)
+    del owner, items
+    users = torch.div(key, n_items, rounding_mode="floor")
+    indices = (key - users * n_items).to(torch.int32)
+    indptr = torch.zeros(n_users + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(torch.bincount(users, minlength=n_users), 0)
+    return indptr, indices
+
+
+def device_lightgcn_adjacency(indptr, indices, n_users, n_items, row_lo=0, row_hi=None):
+    """Rows [row_lo, row_hi) of the `pre` adjacency D^-1/2 A D^-1/2 (LightGCN.py:63-72, the fp32
+    rounding of graph.lightgcn_adjacency: (d_r^-1/2 · 1) · d_c^-1/2) of the bipartite graph given as a
+    device CSR of the U x I train matrix; N = U + I nodes, user rows first.  Device tensors
+    (indptr int64 relative to the block, indices int32 global columns ascending, vals fp32) — each
+    rank of a row-sharded run builds only its own block."""
+    import torch
+    dev = indptr.device
+    N = n_users + n_items
+    row_hi = N if row_hi is None else row_hi
+    nnz_u = int(indptr[-1])
+    deg_u = (indptr[1:] - indptr[:-1])
+    deg_i = torch.bincount(indices[:nnz_u].long(), minlength=n_items)
+    # d^-1/2 exactly as graph.lightgcn_adjacency makes it (numpy's fp32 power — torch's differs in the
+    # last ulp on a third of the degrees): the N degrees take the host detour, the edges never do
+    from .graph import _inv_power
+    deg = torch.cat([deg_u, deg_i]).cpu().numpy().astype(np.float32)
+    dinv = torch.from_numpy(_inv_power(deg, np.float32(-0.5)).astype(np.float32)).to(dev)
+    parts_ptr, parts_idx, parts_val = [], [], []
+    # user rows of the block: columns U + item, already ascending
+    ulo, uhi = min(row_lo, n_users), min(row_hi, n_users)
+    if uhi > ulo:
+        b, e = int(indptr[ulo]), int(indptr[uhi])
+        cols = indices[b:e].long() + n_users
+        rows = torch.repeat_interleave(torch.arange(ulo, uhi, device=dev), deg_u[ulo:uhi], output_size=e - b)
+        parts_idx.append(cols.to(torch.int32))
+        parts_val.append((dinv[rows] * 1.0) * dinv[cols])
+        parts_ptr.append(deg_u[ulo:uhi])
+    # item rows of the block: the transpose, users ascending per item
+    ilo, ihi = max(row_lo, n_users) - n_users, max(row_hi, n_users) - n_users
+    if ihi > ilo:
+        it = indices[:nnz_u].long()
+        sel = (it >= ilo) & (it < ihi)
+        us = torch.repeat_interleave(torch.arange(n_users, device=dev), deg_u, output_size=nnz_u)[sel]
+        it = it[sel]
+        order = torch.argsort(it * n_users + us)                             # by (item, user)
+        it, us = it[order], us[order]
+        parts_idx.append(us.to(torch.int32))
+        parts_val.append((dinv[it + n_users] * 1.0) * dinv[us])
+        parts_ptr.append(deg_i[ilo:ihi])
+    counts = torch.cat(parts_ptr) if parts_ptr else torch.zeros(0, dtype=torch.int64, device=dev)
+    ptr = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0)
+    idx = torch.cat(parts_idx) if parts_idx else torch.zeros(0, dtype=torch.int32, device=dev)
+    val = torch.cat(parts_val) if parts_val else torch.zeros(0, dtype=torch.float32, device=dev)
+    return ptr, idx, val
