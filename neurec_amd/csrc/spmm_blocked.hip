@@ -60,6 +60,7 @@ struct BlockedPlan {
   int32_t* w_ent_off;    // [n_wg][2]
   int32_t* w_cmb_off;    // [n_wg][2]
   int wanted_ok, w_ent_cap, w_nnz_cap, w_bitmap_words;
+  int ww_ok;             // the row-masked hop runs spmm_wanted_wave_kernel on the wanted-rows schedule
   // affinity schedule (d = 64 full pass, cache-blocked without phase barriers): per lane group a
   // stream of rounds of four (column, value) pairs, phase-major
   int aff_ok, aff_packed, aff_phases_a, aff_phases_b;
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
                                       row_mask, ad);
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // Affinity schedule: the cache-blocked full pass without phase barriers (d = 64).
 //
@@ -488,7 +490,8 @@ __global__ __launch_bounds__(256) void aff_pack_kernel(const int32_t* __restrict
 // too and removed: a real batch is dominated by hub rows, whose gathers are ~45 % of a full pass,
 // so that hop is bound by gather throughput, not by the walk: profiles/r01_exp_masked_hops.txt.)
 
-struct LayerChain { const float4* a; const float4* b; };   // optional further terms of the running sum
+struct LayerChain { const float4* a; const float4* b; };
+__device__ __forceinline__ int4 zero_int4() { return make_int4(0, 0, 0, 0); }   // optional further terms of the running sum
 
 __device__ __forceinline__ float4 chain_sum(float4 si, const LayerChain& ch, int64_t o) {
   if (ch.a) {
@@ -863,12 +866,173 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-masked hop, wave-cooperative form (same schedule as spmm_wanted_rows_kernel: sub-lists dealt to
+// the workgroups by descending row length, a hub's 64-segments with partial slots in LDS).  The
+// staged walk gives a sub-list to ONE 16-lane group: a 64-long hub segment is sixteen dependent
+// rounds of four gathers (8 us at the 1.5 us round trip this part shows even when idle).  Here a
+// sub-list belongs to a whole wave: lane L holds pair L, lane group g gathers the rows of pairs
+// 16g..16g+15 — all 64 gathers of a segment are in flight at once — and the sums still run in the
+// strict order used everywhere else: group 0 adds its 16 products, hands the running sum to group
+// 1, ... (products and sums rounded separately; bit-identical to the one-group walk).  A hub's 49
+// segments are three rounds of the workgroup's 16 waves instead of 16 rounds of one lane group.
+// Measured (scripts/exp_wanted_hop.py, MI355X): dealing the segments of a hub to DIFFERENT
+// workgroups, with partial sums meeting in global memory behind a per-row counter, was tried
+// first and is slower (26.6 us on a real batch against 24.0 us for the staged kernel): fifty
+// counters take ~1,250 same-address atomics and every segment pays store-completion + atomic +
+// reload round trips.
+struct WantedEpi {
+  float4* Y; const float4* addend; const float4* sum_in; float4* sum_out; LayerChain chain;
+};
+
+__global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
+    const int32_t* __restrict__ w_ent_off, const int32_t* __restrict__ w_cmb_off,
+    const int4* __restrict__ w_ent, const int4* __restrict__ w_cmb, const int32_t* __restrict__ indices,
+    const float* __restrict__ vals, const float4* __restrict__ X, WantedEpi ep,
+    const uint8_t* __restrict__ row_mask, BatchLists bl, int kRMax, int p_max, int bitmap_words,
+    int ent_cap) {
+  constexpr int RS = 16;
+  extern __shared__ float4 s_mem[];
+  float4* s_part = s_mem;                                          // [p_max][16] partial sums of hub segments
+  int4* s_want = (int4*)(s_mem + (size_t)p_max * RS);              // [ent_cap] wanted sub-lists
+  uint32_t* s_bits = (uint32_t*)(s_want + ent_cap);                // [bitmap_words] wanted rows (batch form)
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int wg = blockIdx.x;
+  const int e0 = w_ent_off[2 * wg], ne = w_ent_off[2 * wg + 1] - e0;
+  const int c0 = w_cmb_off[2 * wg], c1 = w_cmb_off[2 * wg + 1];
+  if (tid == 0) s_n = 0;
+  const bool by_batch = bl.users != nullptr;                       // workgroup-uniform
+  if (by_batch) {
+    for (int i = tid; i < bitmap_words; i += 16 * NR_WAVE) s_bits[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < 3 * bl.batch; i += 16 * NR_WAVE) {
+      const int which = i / bl.batch, b = i - which * bl.batch;
+      const int row = which == 0 ? bl.users[b] : bl.n_users + (which == 1 ? bl.pos[b] : bl.neg[b]);
+      atomicOr(&s_bits[row >> 5], 1u << (row & 31));
+      if (i % (int)gridDim.x == wg) {                              // publishing is shared out
+        bl.row_flag[row] = 1;
+        if (bl.rows_out) bl.rows_out[i] = row;
+      }
+    }
+  }
+  __syncthreads();
+  auto is_wanted = [&](int row) -> bool {
+    return by_batch ? ((s_bits[row >> 5] >> (row & 31)) & 1u) != 0u : row_mask[row] != 0;
+  };
+  for (int i = tid; i < ne; i += 16 * NR_WAVE) {
+    const int4 e = w_ent[e0 + i];
+    if (is_wanted(e.w)) s_want[atomicAdd(&s_n, 1)] = e;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  // this wave's sub-lists: k = wave, wave + 16, ...; the next one's pairs are requested while the
+  // current one's gathers are in flight
+  int k = wave;
+  int4 e = zero_int4();
+  int col = 0;
+  float val = 0.f;
+  if (k < n) {
+    e = s_want[k];
+    if (lane < e.y) {
+      col = indices[(uint32_t)e.z + lane];
+      val = vals[(uint32_t)e.z + lane];
+    }
+  }
+  while (k < n) {
+    const int len = e.y, slot = e.x, row = e.w;
+    float4 x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cj = __shfl(col, (g << 4) | j, NR_WAVE);           // lanes past the end hold column 0
+      x[j] = X[(int64_t)cj * RS + c];
+    }
+    float a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = __shfl(val, (g << 4) | j, NR_WAVE);
+    const int kn = k + 16;
+    int4 en = zero_int4();
+    int coln = 0;
+    float valn = 0.f;
+    if (kn < n) {
+      en = s_want[kn];
+      if (lane < en.y) {
+        coln = indices[(uint32_t)en.z + lane];
+        valn = vals[(uint32_t)en.z + lane];
+      }
+    }
+    float4 acc = zero, carry = zero;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      if (gg * 16 < len) {                                         // wave-uniform
+        if (g == gg) {
+          acc = carry;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float4 t = make_float4(__fadd_rn(acc.x, __fmul_rn(a[j], x[j].x)),
+                                         __fadd_rn(acc.y, __fmul_rn(a[j], x[j].y)),
+                                         __fadd_rn(acc.z, __fmul_rn(a[j], x[j].z)),
+                                         __fadd_rn(acc.w, __fmul_rn(a[j], x[j].w)));
+            if (gg * 16 + j < len) acc = t;
+          }
+        }
+        const int src = (gg << 4) | c;
+        carry = make_float4(__shfl(acc.x, src, NR_WAVE), __shfl(acc.y, src, NR_WAVE),
+                            __shfl(acc.z, src, NR_WAVE), __shfl(acc.w, src, NR_WAVE));
+      }
+    }
+    if (g == 0) {
+      if (slot < kRMax)
+        masked_row_out(carry, (int64_t)row * RS + c, ep.addend, true, ep.Y, ep.sum_in, ep.sum_out, &ep.chain);
+      else
+        s_part[(size_t)(slot - kRMax) * RS + c] = carry;
+    }
+    k = kn;
+    e = en;
+    col = coln;
+    val = valn;
+  }
+  if (c1 > c0) {                                                   // workgroup-uniform
+    __syncthreads();
+    for (int ci = c0 + wave * 4 + g; ci < c1; ci += 64) {
+      const int4 cm = w_cmb[ci];
+      if (!is_wanted(cm.x)) continue;
+      float4 acc = zero;
+      for (int sgm = 0; sgm < cm.z; ++sgm) {
+        const float4 q = s_part[(size_t)(cm.y - kRMax + sgm) * RS + c];
+        acc.x = __fadd_rn(acc.x, q.x); acc.y = __fadd_rn(acc.y, q.y);
+        acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
+      }
+      masked_row_out(acc, (int64_t)cm.x * RS + c, ep.addend, true, ep.Y, ep.sum_in, ep.sum_out, &ep.chain);
+    }
+  }
+}
+
 size_t wanted_lds_bytes(const BlockedPlan* p) {
   return (size_t)p->p_max * 256 + 2 * (size_t)p->w_ent_cap * 16 + (size_t)p->w_bitmap_words * 4 +
          (size_t)p->w_nnz_cap * 8;
 }
+int ww_bitmap_words(const BlockedPlan* p) { return (int)((p->n_rows + 127) / 128 * 4); }
+size_t ww_lds_bytes(const BlockedPlan* p) {
+  return (size_t)p->p_max * 256 + (size_t)p->w_ent_cap * 16 + (size_t)ww_bitmap_words(p) * 4 + 16;
+}
 size_t colmask_lds_bytes(const BlockedPlan* p) {
   return (size_t)p->p_max * 256 + (size_t)p->ent_cap * 16 + (size_t)p->nnz_cap * 8;
+}
+
+// launch of the wave-cooperative wanted-rows kernel (all three entrances of the row-masked hop)
+int launch_wanted_wave(const BlockedPlan* p, const int32_t* d_indices, const float* d_vals, const float* d_X,
+                       float* d_Y, const float* d_addend, const float* d_sum_in, float* d_sum_out,
+                       const uint8_t* d_y_row_wanted, LayerChain chain, BatchLists bl, hipStream_t st) {
+  hipLaunchKernelGGL(spmm_wanted_wave_kernel, dim3((unsigned)p->n_wg), dim3(16 * NR_WAVE), ww_lds_bytes(p), st,
+                     p->w_ent_off, p->w_cmb_off, p->w_ent, p->w_cmb, d_indices, d_vals, (const float4*)d_X,
+                     WantedEpi{(float4*)d_Y, (const float4*)d_addend, (const float4*)d_sum_in,
+                               (float4*)d_sum_out, chain},
+                     d_y_row_wanted, bl, p->r_max, p->p_max, ww_bitmap_words(p), p->w_ent_cap);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
 }
 
 struct HostEnt { int32_t slot, len; uint32_t begin; int32_t owner; };
@@ -1253,6 +1417,15 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
       p->w_nnz_cap = std::min(p->w_nnz_cap, std::max(atoi(cap), 4 * kSeg));
     if (p->w_nnz_cap < 4 * kSeg) p->wanted_ok = 0;
   }
+  // NEUREC_SPMM_WANTED_WAVE=1: the row-masked hop runs the wave-cooperative walker on the wanted-rows
+  // schedule above instead of the staged lane-group walker.  Off by default: measured on MI355X
+  // (scripts/exp_wanted_hop.py, profiles/r02_exp_wanted_hop.txt) it wins on short rows (7.4 vs 12.4 us
+  // for 2.9 k of them) but not on a real batch (25.2 vs 23.7 us) — a hub's 0.8 MB of gathers go
+  // through ONE CU's 64 B/clk vector-memory path whichever way its waves are organised.
+  {
+    const char* on = getenv("NEUREC_SPMM_WANTED_WAVE");
+    p->ww_ok = p->wanted_ok && n_rows <= 131072 * 4 && on && on[0] == '1';
+  }
   AffHost aff;
   {
     // cache-blocked full pass without phase barriers (spmm_affinity_kernel): its own schedule on
@@ -1360,6 +1533,9 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   if (p->wanted_ok && e == hipSuccess)
     e = hipFuncSetAttribute((const void*)spmm_wanted_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)wanted_lds_bytes(p));
+  if (p->ww_ok && e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)spmm_wanted_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ww_lds_bytes(p));
   if (p->colmask_ok)
     for (const void* fn : {(const void*)spmm_staged_masked_kernel<true, false>,
                            (const void*)spmm_staged_masked_kernel<false, true>,
@@ -1441,6 +1617,9 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
   const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
   const bool masked = d_x_row_nonzero || d_y_row_wanted;
   const int gif = s_gathers_in_flight;
+  if (p->ww_ok && d_y_row_wanted && !d_x_row_nonzero)
+    return launch_wanted_wave(p, d_indices, d_vals, d_X, d_Y, d_addend, d_sum_in, d_sum_out, d_y_row_wanted,
+                              LayerChain{nullptr, nullptr}, BatchLists{}, st);
   if (p->wanted_ok && d_y_row_wanted && !d_x_row_nonzero) {
     hipLaunchKernelGGL(spmm_wanted_rows_kernel, grid, block, wanted_lds_bytes(p), st, p->w_ent_off,
                        p->w_cmb_off, p->w_ent, p->w_cmb, d_indices, d_vals, (const float4*)d_X,
@@ -1508,6 +1687,10 @@ int nrhip_spmm_blocked_wanted_layers(const void* plan, const int32_t* d_indices,
              "spmm_blocked_wanted_layers: null pointer argument");
   NR_REQUIRE(d_layer_a || !d_layer_b, NR_ERR_ARG, "spmm_blocked_wanted_layers: layer_b without layer_a");
   const BlockedPlan* p = (const BlockedPlan*)plan;
+  if (p->ww_ok)
+    return launch_wanted_wave(p, d_indices, d_vals, d_X, nullptr, nullptr, d_sum_in, d_sum_out, d_y_row_wanted,
+                              LayerChain{(const float4*)d_layer_a, (const float4*)d_layer_b}, BatchLists{},
+                              (hipStream_t)stream);
   NR_REQUIRE(p->wanted_ok, NR_ERR_UNSUPPORTED, "spmm_blocked_wanted_layers: no wanted-rows schedule");
   hipLaunchKernelGGL(spmm_wanted_rows_kernel, dim3((unsigned)p->n_wg), dim3(p->waves * NR_WAVE),
                      wanted_lds_bytes(p), (hipStream_t)stream, p->w_ent_off, p->w_cmb_off, p->w_ent,
@@ -1534,9 +1717,14 @@ int nrhip_spmm_blocked_wanted_batch(const void* plan, const int32_t* d_indices, 
              NR_ERR_ARG, "spmm_blocked_wanted_batch: bad arguments");
   NR_REQUIRE(d_layer_a || !d_layer_b, NR_ERR_ARG, "spmm_blocked_wanted_batch: layer_b without layer_a");
   const BlockedPlan* p = (const BlockedPlan*)plan;
+  if (batch == 0) return NR_OK;
+  if (p->ww_ok)
+    return launch_wanted_wave(p, d_indices, d_vals, d_X, nullptr, nullptr, d_sum_in, d_sum_out, nullptr,
+                              LayerChain{(const float4*)d_layer_a, (const float4*)d_layer_b},
+                              BatchLists{d_users, d_pos, d_neg, batch, n_users, d_row_flag, d_rows_out},
+                              (hipStream_t)stream);
   NR_REQUIRE(p->wanted_ok && p->w_bitmap_words > 0, NR_ERR_UNSUPPORTED,
              "spmm_blocked_wanted_batch: no wanted-rows schedule with a row bit set");
-  if (batch == 0) return NR_OK;
   hipLaunchKernelGGL(spmm_wanted_rows_kernel, dim3((unsigned)p->n_wg), dim3(p->waves * NR_WAVE),
                      wanted_lds_bytes(p), (hipStream_t)stream, p->w_ent_off, p->w_cmb_off, p->w_ent,
                      p->w_cmb, d_indices, d_vals, (const float4*)d_X, (float4*)nullptr,
@@ -1550,6 +1738,7 @@ int nrhip_spmm_blocked_wanted_batch(const void* plan, const int32_t* d_indices, 
 }
 
 int nrhip_spmm_blocked_has_wanted(const void* plan) {      // 0 no, 1 flag form, 2 flag and batch forms
+  if (plan && ((const BlockedPlan*)plan)->ww_ok) return 2;
   if (!plan || !((const BlockedPlan*)plan)->wanted_ok) return 0;
   return ((const BlockedPlan*)plan)->w_bitmap_words > 0 ? 2 : 1;
 }
