@@ -60,7 +60,20 @@ struct BlockedPlan {
   int32_t* w_ent_off;    // [n_wg][2]
   int32_t* w_cmb_off;    // [n_wg][2]
   int wanted_ok, w_ent_cap, w_nnz_cap, w_bitmap_words;
-  int ww_ok;             // the row-masked hop runs spmm_wanted_wave_kernel on the wanted-rows schedule
+  // wave-cooperative row-masked hop (spmm_wanted_wave_kernel): units dealt by descending length; a row
+  // of > 64 non-zeros is cut into 64-segments grouped in chunks of <= 8 consecutive segments, each
+  // chunk a unit of its own (a hub's bytes spread over several CUs); partial sums in global memory
+  int ww_ok, ww_ent_cap;
+  int32_t* ww_off;       // [n_wg + 1] entries
+  int32_t* ww_choff;     // [n_wg + 1] chunks
+  int4* ww_ent;          // {0 | 1 + global partial slot | -(1 + LDS slot), length, first non-zero, row}
+  int32_t* ww_gch;       // hub index of every chunk
+  int4* ww_hub;          // {row, first partial slot, segments, chunks}
+  int32_t* ww_lcoff;     // [n_wg + 1] one-chunk rows (segment sums stay in LDS)
+  int4* ww_lcmb;         // {row, first LDS slot, segments, 0}
+  int ww_lds_slots;      // LDS partial slots per workgroup
+  float* ww_part;        // [segments of multi-chunk rows][64]
+  unsigned* ww_cnt;      // [multi-chunk rows] chunks finished (zero between launches)
   // affinity schedule (d = 64 full pass, cache-blocked without phase barriers): per lane group a
   // stream of rounds of four (column, value) pairs, phase-major
   int aff_ok, aff_packed, aff_phases_a, aff_phases_b;
@@ -102,7 +115,12 @@ size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
   const size_t max_cmb = (size_t)(nnz / 16) + 64;
   const size_t wg = 4096 + (size_t)(n_rows / 32);   // generous bound on workgroups
   const size_t w_ent = (size_t)n_rows + (size_t)(nnz / 16) + 64;        // wanted-rows schedule (one phase)
-  return nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
+  // wave-cooperative wanted-rows schedule: an entry per row or 64-segment, a partial row per segment
+  const size_t ww_seg = (size_t)(nnz / 32) + 64, ww_ents = (size_t)n_rows + ww_seg;
+  const size_t ww = 3 * nr_align_up((wg + 1) * 4, 256) + nr_align_up(ww_ents * 16 + 16, 256) +
+                    nr_align_up(ww_seg * 4 + 4, 256) + 2 * nr_align_up(max_cmb * 16 + 16, 256) +
+                    nr_align_up(ww_seg * 256 + 256, 256) + nr_align_up(max_cmb * 4 + 4, 256);
+  return ww + nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
          3 * nr_align_up(wg * 8, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256) +
          nr_align_up(w_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) + 2 * nr_align_up(wg * 8, 256);
 }
@@ -867,41 +885,52 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row-masked hop, wave-cooperative form (same schedule as spmm_wanted_rows_kernel: sub-lists dealt to
-// the workgroups by descending row length, a hub's 64-segments with partial slots in LDS).  The
-// staged walk gives a sub-list to ONE 16-lane group: a 64-long hub segment is sixteen dependent
-// rounds of four gathers (8 us at the 1.5 us round trip this part shows even when idle).  Here a
-// sub-list belongs to a whole wave: lane L holds pair L, lane group g gathers the rows of pairs
-// 16g..16g+15 — all 64 gathers of a segment are in flight at once — and the sums still run in the
-// strict order used everywhere else: group 0 adds its 16 products, hands the running sum to group
-// 1, ... (products and sums rounded separately; bit-identical to the one-group walk).  A hub's 49
-// segments are three rounds of the workgroup's 16 waves instead of 16 rounds of one lane group.
-// Measured (scripts/exp_wanted_hop.py, MI355X): dealing the segments of a hub to DIFFERENT
-// workgroups, with partial sums meeting in global memory behind a per-row counter, was tried
-// first and is slower (26.6 us on a real batch against 24.0 us for the staged kernel): fifty
-// counters take ~1,250 same-address atomics and every segment pays store-completion + atomic +
-// reload round trips.
+// Row-masked hop, wave-cooperative form.  Two things bound the staged walk on a real batch (which
+// always holds the hub rows: positives are drawn by degree):
+//  (1) a sub-list given to ONE 16-lane group is up to sixteen dependent rounds of four gathers —
+//      here a sub-list belongs to a whole wave: lane L holds pair L, lane group g gathers the rows
+//      of pairs 16g..16g+15, so all 64 gathers of a segment are in flight at once, and the sums
+//      still run in the strict order used everywhere else: group 0 adds its 16 products, hands
+//      the running sum to group 1, ... (products and sums rounded separately: bit-identical);
+//  (2) a hub's 3,077 x 256 B = 0.8 MB of gathers through ONE CU's vector-memory path (64 B/clk)
+//      is >= 5 us whatever the waves do — here a row of > 64 non-zeros is cut into chunks of <= 8
+//      consecutive 64-segments and every chunk is dealt on its own, so the biggest hub runs on 7 CUs.
+//      Segment sums go to a global buffer (agent-scope stores); a chunk ends with ONE counter update
+//      per row (not one per segment: 1,250 same-address atomics cost more than they saved,
+//      profiles/r02_exp_wanted_hop.txt), and the chunk that finishes a row last adds ALL its segment
+//      sums one by one in segment order — the same association as the full pass.
 struct WantedEpi {
   float4* Y; const float4* addend; const float4* sum_in; float4* sum_out; LayerChain chain;
 };
+#ifdef NR_WW_TIMELINE      // experiment builds only (scripts/exp_wanted_timeline.sh): per-workgroup phase stamps
+__device__ unsigned long long g_ww_dbg[256 * 8];
+#define NR_WW_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_ww_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define NR_WW_STAMP_END(i) do { __syncthreads(); NR_WW_STAMP(i); } while (0)
+#else
+#define NR_WW_STAMP(i)
+#define NR_WW_STAMP_END(i)
+#endif
 
 __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
-    const int32_t* __restrict__ w_ent_off, const int32_t* __restrict__ w_cmb_off,
-    const int4* __restrict__ w_ent, const int4* __restrict__ w_cmb, const int32_t* __restrict__ indices,
+    const int32_t* __restrict__ ww_off, const int32_t* __restrict__ ww_choff,
+    const int4* __restrict__ ww_ent, const int32_t* __restrict__ ww_gch, const int4* __restrict__ ww_hub,
+    const int32_t* __restrict__ ww_lcoff, const int4* __restrict__ ww_lcmb,
+    float* ww_part, unsigned* ww_cnt, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float4* __restrict__ X, WantedEpi ep,
-    const uint8_t* __restrict__ row_mask, BatchLists bl, int kRMax, int p_max, int bitmap_words,
-    int ent_cap) {
+    const uint8_t* __restrict__ row_mask, BatchLists bl, int bitmap_words, int ent_cap, int lds_slots) {
   constexpr int RS = 16;
   extern __shared__ float4 s_mem[];
-  float4* s_part = s_mem;                                          // [p_max][16] partial sums of hub segments
-  int4* s_want = (int4*)(s_mem + (size_t)p_max * RS);              // [ent_cap] wanted sub-lists
+  float4* s_part = s_mem;                                          // [lds_slots][16] segment sums of one-chunk rows
+  int4* s_want = (int4*)(s_mem + (size_t)lds_slots * RS);          // [ent_cap] wanted sub-lists
   uint32_t* s_bits = (uint32_t*)(s_want + ent_cap);                // [bitmap_words] wanted rows (batch form)
   __shared__ int s_n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int wg = blockIdx.x;
-  const int e0 = w_ent_off[2 * wg], ne = w_ent_off[2 * wg + 1] - e0;
-  const int c0 = w_cmb_off[2 * wg], c1 = w_cmb_off[2 * wg + 1];
+  const int e0 = ww_off[wg], ne = ww_off[wg + 1] - e0;
+  const int h0 = ww_choff[wg], h1 = ww_choff[wg + 1];
+  const int l0 = ww_lcoff[wg], l1 = ww_lcoff[wg + 1];
+  NR_WW_STAMP(0);
   if (tid == 0) s_n = 0;
   const bool by_batch = bl.users != nullptr;                       // workgroup-uniform
   if (by_batch) {
@@ -921,11 +950,13 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
   auto is_wanted = [&](int row) -> bool {
     return by_batch ? ((s_bits[row >> 5] >> (row & 31)) & 1u) != 0u : row_mask[row] != 0;
   };
+  NR_WW_STAMP(1);
   for (int i = tid; i < ne; i += 16 * NR_WAVE) {
-    const int4 e = w_ent[e0 + i];
+    const int4 e = ww_ent[e0 + i];
     if (is_wanted(e.w)) s_want[atomicAdd(&s_n, 1)] = e;
   }
   __syncthreads();
+  NR_WW_STAMP(2);
   const int n = s_n;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   // this wave's sub-lists: k = wave, wave + 16, ...; the next one's pairs are requested while the
@@ -949,9 +980,16 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
       const int cj = __shfl(col, (g << 4) | j, NR_WAVE);           // lanes past the end hold column 0
       x[j] = X[(int64_t)cj * RS + c];
     }
-    float a[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = __shfl(val, (g << 4) | j, NR_WAVE);
+    // the row's epilogue operands ride with the gathers (requested after the sum they would be one
+    // more memory round trip per sub-list); rows that end in a partial slot read element 0
+    const int64_t o = (int64_t)row * RS + c;
+    const int64_t oe = slot == 0 ? o : (int64_t)c;
+    float4 pre_si = zero, pre_a = zero, pre_b = zero;               // (an addend is read late: 128 VGPRs)
+    if (ep.sum_out) {
+      pre_si = ep.sum_in[oe];
+      if (ep.chain.a) pre_a = ep.chain.a[oe];
+      if (ep.chain.b) pre_b = ep.chain.b[oe];
+    }
     const int kn = k + 16;
     int4 en = zero_int4();
     int coln = 0;
@@ -963,6 +1001,12 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
         valn = vals[(uint32_t)en.z + lane];
       }
     }
+    // products first (pair j of this lane group: value broadcast from lane 16g + j), in place
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float aj = __shfl(val, (g << 4) | j, NR_WAVE);
+      x[j] = make_float4(__fmul_rn(aj, x[j].x), __fmul_rn(aj, x[j].y), __fmul_rn(aj, x[j].z), __fmul_rn(aj, x[j].w));
+    }
     float4 acc = zero, carry = zero;
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
@@ -971,10 +1015,8 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
           acc = carry;
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const float4 t = make_float4(__fadd_rn(acc.x, __fmul_rn(a[j], x[j].x)),
-                                         __fadd_rn(acc.y, __fmul_rn(a[j], x[j].y)),
-                                         __fadd_rn(acc.z, __fmul_rn(a[j], x[j].z)),
-                                         __fadd_rn(acc.w, __fmul_rn(a[j], x[j].w)));
+            const float4 t = make_float4(__fadd_rn(acc.x, x[j].x), __fadd_rn(acc.y, x[j].y),
+                                         __fadd_rn(acc.z, x[j].z), __fadd_rn(acc.w, x[j].w));
             if (gg * 16 + j < len) acc = t;
           }
         }
@@ -984,30 +1026,97 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
       }
     }
     if (g == 0) {
-      if (slot < kRMax)
-        masked_row_out(carry, (int64_t)row * RS + c, ep.addend, true, ep.Y, ep.sum_in, ep.sum_out, &ep.chain);
-      else
-        s_part[(size_t)(slot - kRMax) * RS + c] = carry;
+      if (slot == 0) {                                             // masked_row_out on the prefetched operands
+        float4 y = carry;
+        if (ep.addend) {
+          const float4 pre_add = ep.addend[o];
+          y = make_float4(__fadd_rn(y.x, pre_add.x), __fadd_rn(y.y, pre_add.y), __fadd_rn(y.z, pre_add.z),
+                          __fadd_rn(y.w, pre_add.w));
+        }
+        if (ep.Y) ep.Y[o] = y;
+        if (ep.sum_out) {
+          float4 si = pre_si;
+          if (ep.chain.a)
+            si = make_float4(__fadd_rn(si.x, pre_a.x), __fadd_rn(si.y, pre_a.y), __fadd_rn(si.z, pre_a.z),
+                             __fadd_rn(si.w, pre_a.w));
+          if (ep.chain.b)
+            si = make_float4(__fadd_rn(si.x, pre_b.x), __fadd_rn(si.y, pre_b.y), __fadd_rn(si.z, pre_b.z),
+                             __fadd_rn(si.w, pre_b.w));
+          ep.sum_out[o] = make_float4(__fadd_rn(si.x, y.x), __fadd_rn(si.y, y.y), __fadd_rn(si.z, y.z),
+                                      __fadd_rn(si.w, y.w));
+        }
+      } else if (slot < 0) {                                       // a segment of a one-chunk row: LDS
+        s_part[(size_t)(-slot - 1) * RS + c] = carry;
+      } else {                                                     // a segment of a multi-chunk row: global,
+        float* mine = ww_part + (size_t)(slot - 1) * 64 + c * 4;   // agent scope (written through)
+        __hip_atomic_store(mine + 0, carry.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, carry.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2, carry.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 3, carry.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     k = kn;
     e = en;
     col = coln;
     val = valn;
   }
-  if (c1 > c0) {                                                   // workgroup-uniform
+  if (l1 > l0) {                                                   // workgroup-uniform: rows whose segments all ran here
     __syncthreads();
-    for (int ci = c0 + wave * 4 + g; ci < c1; ci += 64) {
-      const int4 cm = w_cmb[ci];
+    for (int li = l0 + wave * 4 + g; li < l1; li += 64) {
+      const int4 cm = ww_lcmb[li];                                 // {row, first LDS slot, segments}
       if (!is_wanted(cm.x)) continue;
       float4 acc = zero;
       for (int sgm = 0; sgm < cm.z; ++sgm) {
-        const float4 q = s_part[(size_t)(cm.y - kRMax + sgm) * RS + c];
+        const float4 q = s_part[(size_t)(cm.y + sgm) * RS + c];
         acc.x = __fadd_rn(acc.x, q.x); acc.y = __fadd_rn(acc.y, q.y);
         acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
       }
       masked_row_out(acc, (int64_t)cm.x * RS + c, ep.addend, true, ep.Y, ep.sum_in, ep.sum_out, &ep.chain);
     }
   }
+  NR_WW_STAMP_END(3);
+  if (tid == 0 && blockIdx.x < 256) {
+#ifdef NR_WW_TIMELINE
+    g_ww_dbg[blockIdx.x * 8 + 6] = (unsigned long long)n;
+    g_ww_dbg[blockIdx.x * 8 + 7] = (unsigned long long)(h1 - h0);
+#endif
+  }
+  if (h1 > h0) {                                                   // workgroup-uniform: this workgroup holds chunks
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                                 // segment sums have left before a count moves
+    __syncthreads();
+    for (int hi = h0 + wave; hi < h1; hi += 16) {
+      const int hub = ww_gch[hi];
+      const int4 hd = ww_hub[hub];                                 // {row, first partial slot, segments, chunks}
+      if (!is_wanted(hd.x)) continue;
+      unsigned old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(&ww_cnt[hub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old != (unsigned)hd.w - 1u) continue;                    // another chunk of the row is still out
+      // all segment sums of the row, 16 at a time in flight, added in segment order
+      float4 sum = zero;
+      for (int s0 = 0; s0 < hd.z; s0 += 16) {
+        float4 q[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float* qp = ww_part + ((size_t)hd.y + min(s0 + j, hd.z - 1)) * 64 + c * 4;
+          q[j].x = __hip_atomic_load(qp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q[j].y = __hip_atomic_load(qp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q[j].z = __hip_atomic_load(qp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q[j].w = __hip_atomic_load(qp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (s0 + j < hd.z)
+            sum = make_float4(__fadd_rn(sum.x, q[j].x), __fadd_rn(sum.y, q[j].y), __fadd_rn(sum.z, q[j].z),
+                              __fadd_rn(sum.w, q[j].w));
+      }
+      if (g == 0)
+        masked_row_out(sum, (int64_t)hd.x * RS + c, ep.addend, true, ep.Y, ep.sum_in, ep.sum_out, &ep.chain);
+      if (lane == 0) __hip_atomic_store(&ww_cnt[hub], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    }
+  }
+  NR_WW_STAMP_END(4);
 }
 
 size_t wanted_lds_bytes(const BlockedPlan* p) {
@@ -1016,7 +1125,7 @@ size_t wanted_lds_bytes(const BlockedPlan* p) {
 }
 int ww_bitmap_words(const BlockedPlan* p) { return (int)((p->n_rows + 127) / 128 * 4); }
 size_t ww_lds_bytes(const BlockedPlan* p) {
-  return (size_t)p->p_max * 256 + (size_t)p->w_ent_cap * 16 + (size_t)ww_bitmap_words(p) * 4 + 16;
+  return (size_t)p->ww_lds_slots * 256 + (size_t)p->ww_ent_cap * 16 + (size_t)ww_bitmap_words(p) * 4 + 16;
 }
 size_t colmask_lds_bytes(const BlockedPlan* p) {
   return (size_t)p->p_max * 256 + (size_t)p->ent_cap * 16 + (size_t)p->nnz_cap * 8;
@@ -1027,10 +1136,11 @@ int launch_wanted_wave(const BlockedPlan* p, const int32_t* d_indices, const flo
                        float* d_Y, const float* d_addend, const float* d_sum_in, float* d_sum_out,
                        const uint8_t* d_y_row_wanted, LayerChain chain, BatchLists bl, hipStream_t st) {
   hipLaunchKernelGGL(spmm_wanted_wave_kernel, dim3((unsigned)p->n_wg), dim3(16 * NR_WAVE), ww_lds_bytes(p), st,
-                     p->w_ent_off, p->w_cmb_off, p->w_ent, p->w_cmb, d_indices, d_vals, (const float4*)d_X,
+                     p->ww_off, p->ww_choff, p->ww_ent, p->ww_gch, p->ww_hub, p->ww_lcoff, p->ww_lcmb, p->ww_part,
+                     p->ww_cnt, d_indices, d_vals, (const float4*)d_X,
                      WantedEpi{(float4*)d_Y, (const float4*)d_addend, (const float4*)d_sum_in,
                                (float4*)d_sum_out, chain},
-                     d_y_row_wanted, bl, p->r_max, p->p_max, ww_bitmap_words(p), p->w_ent_cap);
+                     d_y_row_wanted, bl, ww_bitmap_words(p), p->ww_ent_cap, p->ww_lds_slots);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -1417,14 +1527,88 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
       p->w_nnz_cap = std::min(p->w_nnz_cap, std::max(atoi(cap), 4 * kSeg));
     if (p->w_nnz_cap < 4 * kSeg) p->wanted_ok = 0;
   }
-  // NEUREC_SPMM_WANTED_WAVE=1: the row-masked hop runs the wave-cooperative walker on the wanted-rows
-  // schedule above instead of the staged lane-group walker.  Off by default: measured on MI355X
-  // (scripts/exp_wanted_hop.py, profiles/r02_exp_wanted_hop.txt) it wins on short rows (7.4 vs 12.4 us
-  // for 2.9 k of them) but not on a real batch (25.2 vs 23.7 us) — a hub's 0.8 MB of gathers go
-  // through ONE CU's 64 B/clk vector-memory path whichever way its waves are organised.
+  // wave-cooperative row-masked hop (spmm_wanted_wave_kernel): its own schedule — whole rows of <= 64
+  // non-zeros and CHUNKS of <= kChunk consecutive 64-segments of longer rows are the units, dealt to
+  // the workgroups by descending length.  NEUREC_SPMM_WANTED_WAVE=0 keeps the staged lane-group
+  // walker (A/B runs).
+  std::vector<int4> ww_ent, ww_hub, ww_lcmb;
+  std::vector<int32_t> ww_off((size_t)n_wg + 1, 0), ww_choff((size_t)n_wg + 1, 0), ww_lcoff((size_t)n_wg + 1, 0), ww_gch;
+  int64_t ww_segments = 0;
+  p->ww_ok = 0;
+  p->ww_ent_cap = 0;
+  p->ww_lds_slots = 0;
   {
-    const char* on = getenv("NEUREC_SPMM_WANTED_WAVE");
-    p->ww_ok = p->wanted_ok && n_rows <= 131072 * 4 && on && on[0] == '1';
+    const char* off = getenv("NEUREC_SPMM_WANTED_WAVE");
+    const bool on = d == 64 && kWaves == 16 && kSeg <= 64 && n_rows <= 131072 * 4 && !(off && off[0] == '0');
+    if (on) {
+      constexpr int kChunk = 8;
+      // hub >= 0: chunk of a multi-chunk row (global partials); hub == -2: a one-chunk row of > 64
+      // non-zeros (segment sums in LDS); hub == -1: a whole row of <= 64
+      struct Unit { int64_t len; int32_t row; int hub, seg0, nseg; };
+      std::vector<Unit> units;
+      for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t len = h_indptr[r + 1] - h_indptr[r];
+        if (len <= kSeg) {
+          units.push_back(Unit{len, (int32_t)r, -1, 0, 0});
+          continue;
+        }
+        const int ns = (int)((len + kSeg - 1) / kSeg), nch = (ns + kChunk - 1) / kChunk;
+        if (nch == 1) {
+          units.push_back(Unit{len, (int32_t)r, -2, 0, ns});
+          continue;
+        }
+        const int hub = (int)ww_hub.size();
+        ww_hub.push_back(make_int4((int)r, (int)ww_segments, ns, nch));
+        for (int ch = 0; ch < nch; ++ch) {
+          const int s0 = ch * kChunk, s1 = std::min(ns, s0 + kChunk);
+          units.push_back(Unit{std::min<int64_t>(len - (int64_t)s0 * kSeg, (int64_t)(s1 - s0) * kSeg), (int32_t)r,
+                               hub, s0, s1 - s0});
+        }
+        ww_segments += ns;
+      }
+      std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.len > b.len; });
+      std::vector<std::vector<int4>> per((size_t)n_wg), perl((size_t)n_wg);
+      std::vector<std::vector<int32_t>> perch((size_t)n_wg);
+      std::vector<int> lds_used((size_t)n_wg, 0);
+      for (size_t k = 0; k < units.size(); ++k) {
+        const Unit& u = units[k];
+        const size_t w = k % (size_t)n_wg;
+        const int64_t b = h_indptr[u.row], len = h_indptr[u.row + 1] - b;
+        if (u.hub == -1) {
+          per[w].push_back(make_int4(0, (int)len, (int)(uint32_t)b, u.row));
+        } else if (u.hub == -2) {
+          perl[w].push_back(make_int4(u.row, lds_used[w], u.nseg, 0));
+          for (int sg = 0; sg < u.nseg; ++sg)
+            per[w].push_back(make_int4(-(1 + lds_used[w] + sg), (int)std::min<int64_t>(kSeg, len - (int64_t)sg * kSeg),
+                                       (int)(uint32_t)(b + (int64_t)sg * kSeg), u.row));
+          lds_used[w] += u.nseg;
+        } else {
+          for (int sg = u.seg0; sg < u.seg0 + u.nseg; ++sg)
+            per[w].push_back(make_int4(1 + ww_hub[(size_t)u.hub].y + sg,
+                                       (int)std::min<int64_t>(kSeg, len - (int64_t)sg * kSeg),
+                                       (int)(uint32_t)(b + (int64_t)sg * kSeg), u.row));
+          perch[w].push_back(u.hub);
+        }
+      }
+      p->ww_lds_slots = 0;
+      for (int w = 0; w < n_wg; ++w) {
+        ww_off[(size_t)w] = (int32_t)ww_ent.size();
+        ww_choff[(size_t)w] = (int32_t)ww_gch.size();
+        ww_lcoff[(size_t)w] = (int32_t)ww_lcmb.size();
+        ww_ent.insert(ww_ent.end(), per[(size_t)w].begin(), per[(size_t)w].end());
+        ww_gch.insert(ww_gch.end(), perch[(size_t)w].begin(), perch[(size_t)w].end());
+        ww_lcmb.insert(ww_lcmb.end(), perl[(size_t)w].begin(), perl[(size_t)w].end());
+        p->ww_ent_cap = std::max<int>(p->ww_ent_cap, (int)per[(size_t)w].size());
+        p->ww_lds_slots = std::max(p->ww_lds_slots, lds_used[(size_t)w]);
+      }
+      ww_off[(size_t)n_wg] = (int32_t)ww_ent.size();
+      ww_choff[(size_t)n_wg] = (int32_t)ww_gch.size();
+      ww_lcoff[(size_t)n_wg] = (int32_t)ww_lcmb.size();
+      p->ww_ent_cap = (p->ww_ent_cap + 15) / 16 * 16;
+      p->ww_ok = ww_segments < ((int64_t)1 << 30) &&
+                 (size_t)p->ww_lds_slots * 256 + (size_t)p->ww_ent_cap * 16 +
+                         (size_t)((n_rows + 127) / 128 * 16) + 1024 <= (size_t)kMaxLdsBytes;
+    }
   }
   AffHost aff;
   {
@@ -1464,6 +1648,19 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   p->w_cmb = (int4*)carve(w_cmb.size() * 16 + 16);
   p->w_ent_off = (int32_t*)carve(w_ent_off.size() * 4);
   p->w_cmb_off = (int32_t*)carve(w_cmb_off.size() * 4);
+  p->ww_off = p->ww_choff = p->ww_gch = p->ww_lcoff = nullptr; p->ww_ent = p->ww_hub = p->ww_lcmb = nullptr;
+  p->ww_part = nullptr; p->ww_cnt = nullptr;
+  if (p->ww_ok) {
+    p->ww_off = (int32_t*)carve(ww_off.size() * 4);
+    p->ww_choff = (int32_t*)carve(ww_choff.size() * 4);
+    p->ww_ent = (int4*)carve(ww_ent.size() * 16 + 16);
+    p->ww_gch = (int32_t*)carve(ww_gch.size() * 4 + 4);
+    p->ww_hub = (int4*)carve(ww_hub.size() * 16 + 16);
+    p->ww_lcoff = (int32_t*)carve(ww_lcoff.size() * 4);
+    p->ww_lcmb = (int4*)carve(ww_lcmb.size() * 16 + 16);
+    p->ww_part = (float*)carve((size_t)ww_segments * 256 + 256);
+    p->ww_cnt = (unsigned*)carve(ww_hub.size() * 4 + 4);
+  }
   p->a_goff = p->a_npart = p->a_cmb_off = p->a_perm = nullptr;
   p->a_cmb = p->a_iv = nullptr;
   p->a_rd = nullptr;
@@ -1499,6 +1696,16 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   up(p->w_cmb, w_cmb.data(), w_cmb.size() * 16);
   up(p->w_ent_off, w_ent_off.data(), w_ent_off.size() * 4);
   up(p->w_cmb_off, w_cmb_off.data(), w_cmb_off.size() * 4);
+  if (p->ww_ok) {
+    up(p->ww_off, ww_off.data(), ww_off.size() * 4);
+    up(p->ww_choff, ww_choff.data(), ww_choff.size() * 4);
+    up(p->ww_ent, ww_ent.data(), ww_ent.size() * 16);
+    up(p->ww_gch, ww_gch.data(), ww_gch.size() * 4);
+    up(p->ww_hub, ww_hub.data(), ww_hub.size() * 16);
+    up(p->ww_lcoff, ww_lcoff.data(), ww_lcoff.size() * 4);
+    up(p->ww_lcmb, ww_lcmb.data(), ww_lcmb.size() * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(p->ww_cnt, 0, ww_hub.size() * 4 + 4, st);
+  }
   if (p->aff_ok) {
     const size_t rounds = aff.rd.size() + kAffSlackRounds;
     if (e == hipSuccess) e = hipMemsetAsync(p->a_rd, 0, rounds * 4, st);       // slack rounds: ignored words
@@ -1579,6 +1786,14 @@ int nrhip_spmm_blocked_affinity(const void* plan, int* windows_b) {
   if (windows_b) *windows_b = p->aff_ok && p->aff_packed ? p->aff_phases_b : 0;
   return p->aff_ok && p->aff_packed ? p->aff_phases_a : 0;
 }
+
+#ifdef NR_WW_TIMELINE
+int nrhip_ww_timeline(unsigned long long* h_out) {
+  NR_CHECK_HIP(hipDeviceSynchronize());
+  NR_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_ww_dbg), sizeof(unsigned long long) * 256 * 8));
+  return NR_OK;
+}
+#endif
 
 int nrhip_spmm_blocked_tune(int gathers_in_flight) {
   NR_REQUIRE(gathers_in_flight == 4 || gathers_in_flight == 8, NR_ERR_UNSUPPORTED,
