@@ -23,6 +23,10 @@ class LightGCN(AbstractRecommender):
         self.lr = config["lr"]
         self.reg = config["reg"]
         self.emb_dim = config["embed_size"]
+        if self.emb_dim not in (16, 32, 64, 128, 256):
+            # fail here, by name, not as an opaque context error inside the native step
+            raise NotImplementedError("the HIP LightGCN engine is built for embed_size in (16, 32, 64, 128, 256); "
+                                      "got %r" % (self.emb_dim,))
         self.batch_size = config["batch_size"]
         self.epochs = config["epochs"]
         self.n_layers = config["n_layers"]

@@ -70,6 +70,9 @@ class MultiVAE(AbstractRecommender):
         if self.act not in E.VAE_ACTS:
             raise NotImplementedError("activation %r is not built (tanh/sigmoid/relu/identity)" % self.act)
         z, h, n = self.p_dims
+        if not (1 <= z <= 16 and 1 <= h <= 32):
+            raise NotImplementedError("the HIP Mult-VAE kernels are built for p_dim=[z <= 16, h <= 32] "
+                                      "(conf/MultiVAE.properties ships [16, 32]); got [%d, %d]" % (z, h))
         w_init = get_initializer(self.weight_init_method, self.stddev, seed=2017)
         b_init = get_initializer(self.bias_init_method, self.stddev, seed=2018)
         params = {

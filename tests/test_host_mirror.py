@@ -292,3 +292,34 @@ def test_initializer_scales_follow_tf_contrib_variance_scaling():
         assert np.abs(w).max() <= lim and abs(w.std() / (lim / np.sqrt(3)) - 1) < 0.02, name
     w = get_initializer("normal", 0.01, seed=5)(shape)
     assert abs(w.std() / 0.01 - 1) < 0.02
+
+
+def test_unsupported_shapes_fail_early_and_by_name():
+    """shapes the kernels are not built for are refused in the Python constructors with a
+    message that lists what is supported (no opaque native error later)."""
+    from neurec_amd.evaluator.backend.hip.uni_evaluator import UniEvaluator
+    with pytest.raises(NotImplementedError, match="at most 128"):
+        UniEvaluator({0: [1]}, {0: [2]}, top_k=200)
+    from neurec_amd.model.general_recommender.LightGCN import LightGCN
+
+    class _Conf(dict):
+        def __getattr__(self, k):
+            return self[k]
+    conf = _Conf(lr=0.01, reg=1e-3, embed_size=48, batch_size=8, epochs=1, n_layers=2, adj_type="pre",
+                 recommender="LightGCN")
+    with pytest.raises(NotImplementedError, match="16, 32, 64, 128, 256"):
+        LightGCN.__init__.__wrapped__(object.__new__(LightGCN), None, None, conf) if hasattr(LightGCN.__init__, "__wrapped__") \
+            else _try_lightgcn(LightGCN, conf)
+
+
+def _try_lightgcn(cls, conf):
+    import types
+    obj = object.__new__(cls)
+    # AbstractRecommender.__init__ needs a dataset for its logger; bypass it: the width check comes first
+    import neurec_amd.model.general_recommender.LightGCN as mod
+    orig = mod.AbstractRecommender.__init__
+    mod.AbstractRecommender.__init__ = lambda self, dataset, conf: None
+    try:
+        cls.__init__(obj, None, types.SimpleNamespace(num_users=3, num_items=3), conf)
+    finally:
+        mod.AbstractRecommender.__init__ = orig
