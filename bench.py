@@ -340,11 +340,11 @@ def main():
         mf_batches = [b for b in mf_sampler.batches() if b[0].numel() == 512][:400]
         mf_loss = torch.zeros(2, device=dev)
         for b in mf_batches[:50]:
-            mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
+            mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan, next_plan=b.next_plan)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b in mf_batches[50:]:
-            mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan)
+            mf.step(b[0], b[1], b[2], mf_loss, plan=b.plan, next_plan=b.next_plan)
         torch.cuda.synchronize()
         mf_dt = (time.perf_counter() - t0) / max(len(mf_batches) - 50, 1)
         torch.cuda.synchronize()

@@ -195,12 +195,15 @@ int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, in
  * applied with the row's gradient (cleared afterwards).  d_plan / n_occ: the batch's nrhip_bpr_plan
  * slice — rows must be rows of this [n_rows][d] table (user rows first, item rows offset by the plan's
  * n_users).  Every call also brings rows r = t (mod period) up to step t, so no row is ever more
- * than `period` steps behind.  d_plan = NULL, n_occ = 0, period = 1: flush every row to step t —
- * required before the table (or m, v) is read; afterwards the buffers are bit-identical to t sweeps. */
+ * than `period` steps behind.  d_next_plan / n_next_occ (optional): the NEXT step's batch plan — its
+ * rows are brought to step t too, so that the next gradient kernel replays nothing.
+ * d_plan = NULL, n_occ = 0, period = 1: flush every row to step t — required before the table (or m,
+ * v) is read; afterwards the buffers are bit-identical to t sweeps. */
 int nrhip_adam_sparse_tf_lazy(float* d_var, float* d_m, float* d_v, float* d_grad, int32_t* d_last,
                               const int32_t* d_stamp, int64_t n_rows, int d, const uint64_t* d_plan,
-                              int n_occ, const float* d_alpha_tab, int t, int period, float beta1,
-                              float beta2, float eps, void* stream);
+                              int n_occ, const uint64_t* d_next_plan, int n_next_occ,
+                              const float* d_alpha_tab, int t, int period, float beta1, float beta2,
+                              float eps, void* stream);
 /* The gradient half of a lazy step: nrhip_bpr_mf_grad on the one-allocation table [n_users +
  * n_items][d] (d_G likewise), every gathered row first brought to step t - 1 in registers (nothing
  * written back), the batch's rows stamped d_stamp[row] = t (int32 per row; the optimiser call of the
@@ -449,10 +452,13 @@ typedef struct nrhip_mf_buffers {
 } nrhip_mf_buffers;
 int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out);
 int nrhip_mf_ctx_destroy(void* ctx);
-/* step_index: 1-based index of this optimiser step (lazy mode: alpha must equal alpha_tab[step_index]) */
+/* step_index: 1-based index of this optimiser step (lazy mode: alpha must equal alpha_tab[step_index]);
+ * d_next_plan / next_batch: the following batch's plan and length, or NULL / 0 (lazy mode: its rows are
+ * brought up to date by this step's optimiser launch) */
 int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, const uint64_t* d_plan, int step_index, float alpha, float beta1,
-                  float beta2, float eps, float* d_loss2, void* stream);
+                  int batch, const uint64_t* d_plan, const uint64_t* d_next_plan, int next_batch,
+                  int step_index, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                  void* stream);
 /* lazy mode: bring every row of both tables to step `steps_done` (no-op otherwise) */
 int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float eps, void* stream);
 

@@ -101,9 +101,9 @@ SIGNATURES = {
     "nrhip_lightgcn_step_apply": [p, p, f32, f32, f32, f32, p],
     "nrhip_mf_ctx_create": [C.POINTER(MFBuffers), C.POINTER(p)],
     "nrhip_mf_ctx_destroy": [p],
-    "nrhip_mf_step": [p, p, p, p, i32, p, i32, f32, f32, f32, f32, p, p],
+    "nrhip_mf_step": [p, p, p, p, i32, p, p, i32, i32, f32, f32, f32, f32, p, p],
     "nrhip_mf_flush": [p, i32, f32, f32, f32, p],
-    "nrhip_adam_sparse_tf_lazy": [p, p, p, p, p, p, i64, i32, p, i32, p, i32, i32, f32, f32, f32, p],
+    "nrhip_adam_sparse_tf_lazy": [p, p, p, p, p, p, i64, i32, p, i32, p, i32, p, i32, i32, f32, f32, f32, p],
     "nrhip_bpr_mf_grad_lazy": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, p, p, p, i32, f32, p, p, p,
                                p, p],
     "nrhip_ngcf_workspace_bytes": [i64, psz],

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
 // bits, 2.4 MB of touched rows per step instead of a 145 MB sweep.  To bound the replay (a row
 // untouched for 10^4 steps would hold one wave for 10^4 iterations), every step also brings the
 // rows r = t (mod period) up to date: no row is ever more than `period` steps behind.  A flush
-// (plan = NULL, period = 1) brings every row to step t — before tables are read.
+// (plan = NULL, period = 1) brings every row to step t — before tables are read.  Given the NEXT
+// batch's plan, the rows that batch will gather are brought to step t as well (zero-gradient replay),
+// so that the next gradient kernel finds them current and replays nothing.
 // The gradient kernel of step t must see every row it gathers as of step t - 1: it replays the
 // same missed steps in registers (bpr.hip: load_row_lazy) and stamps the batch's rows with t, which
 // is how a scheduled-row wave here knows to leave a row to the batch wave that owns it.
@@ -75,27 +77,30 @@ template <int CPL>
 __global__ __launch_bounds__(256) void adam_lazy_kernel(
     float* __restrict__ var, float* __restrict__ m, float* __restrict__ v, float* __restrict__ grad,
     int32_t* __restrict__ last, const int32_t* __restrict__ stamp, int d, int64_t n_rows,
-    const uint64_t* __restrict__ skey, int n_occ, const float* __restrict__ alpha_tab, int t, int period,
-    float b1, float b2, float omb1, float omb2, float eps) {
+    const uint64_t* __restrict__ skey, int n_occ, const uint64_t* __restrict__ skey_next, int n_next,
+    const float* __restrict__ alpha_tab, int t, int period, float b1, float b2, float omb1, float omb2,
+    float eps) {
   const int lane = nr_lane();
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int64_t row;
-  bool has_grad;
-  if (w < n_occ) {
+  bool has_grad = false;
+  if (w < n_occ) {                                                 // rows of this step's batch
     row = (int64_t)(skey[w] >> 32);
     if (w > 0 && (int64_t)(skey[w - 1] >> 32) == row) return;      // a later occurrence of the row
     has_grad = true;
-  } else {
-    row = (int64_t)(t % period) + (w - n_occ) * period;
+  } else if (w < (int64_t)n_occ + n_next) {                        // rows the NEXT step's batch will gather:
+    const int64_t k = w - n_occ;                                   // brought to step t now, so that its
+    row = (int64_t)(skey_next[k] >> 32);                           // gradient kernel finds them current
+    if (k > 0 && (int64_t)(skey_next[k - 1] >> 32) == row) return;
+  } else {                                                         // scheduled rows: r = t (mod period)
+    row = (int64_t)(t % period) + (w - n_occ - n_next) * period;
     if (row >= n_rows) return;
-    if (stamp && stamp[row] == t) return;                          // in this step's batch: done above
-    has_grad = false;
   }
   row = __builtin_amdgcn_readfirstlane((int)row);
-  const int from = __builtin_amdgcn_readfirstlane(last[row]) + 1;
-  const int upto = has_grad ? t - 1 : t;                           // steps replayed with g = 0
+  // everything that depends only on the row is requested at once: the claim / stamp, the row's three
+  // vectors, and the step sizes of the last 64 steps (lane j: step t - 63 + j; a replay never reaches
+  // further back than `period` <= 64 steps unless the caller flushes rarely — then the table is read)
   float wv[CPL], mm[CPL], vv[CPL];
-  bool quiet = true;
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
@@ -105,11 +110,39 @@ __global__ __launch_bounds__(256) void adam_lazy_kernel(
       mm[c] = m[row * d + k];
       vv[c] = v[row * d + k];
     }
-    quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
   }
-  if (!__all(quiet)) nr_lazy_replay<CPL>(wv, mm, vv, from, upto, alpha_tab, lane, b1, b2, omb1, omb2, eps);
+  const int a_lo = t - (NR_WAVE - 1);
+  const float a_mine = alpha_tab[max(a_lo + lane, 0)];
+  int from;
   if (has_grad) {
-    const float a = alpha_tab[t];
+    from = __builtin_amdgcn_readfirstlane(last[row]) + 1;
+  } else {
+    const int st = stamp ? stamp[row] : -1;
+    // a row may be both scheduled and in the next batch: whoever raises last[row] to t first owns it
+    int old = 0;
+    if (lane == 0 && st != t) old = atomicMax(&last[row], t);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (st == t || old >= t) return;               // in this step's batch (done above) / already claimed
+    from = old + 1;
+  }
+  const int upto = has_grad ? t - 1 : t;                           // steps replayed with g = 0
+  bool quiet = true;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
+  const bool replayed = !__all(quiet) && from <= upto;
+  if (replayed) {
+    if (from >= a_lo && from >= 1) {               // the usual case: the steps are in the lanes already
+      for (int s2 = from; s2 <= upto; ++s2) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_mine), s2 - a_lo));
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) nr::adam_sparse_tf(0.f, wv[c], mm[c], vv[c], a, b1, b2, omb1, omb2, eps);
+      }
+    } else {
+      nr_lazy_replay<CPL>(wv, mm, vv, from, upto, alpha_tab, lane, b1, b2, omb1, omb2, eps);
+    }
+  }
+  if (has_grad) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_mine), NR_WAVE - 1));   // alpha_tab[t]
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int k = lane + c * NR_WAVE;
@@ -121,16 +154,18 @@ __global__ __launch_bounds__(256) void adam_lazy_kernel(
       nr::adam_sparse_tf(g, wv[c], mm[c], vv[c], a, b1, b2, omb1, omb2, eps);
     }
   }
+  if (has_grad || replayed) {
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int k = lane + c * NR_WAVE;
-    if (k < d) {
-      var[row * d + k] = wv[c];
-      m[row * d + k] = mm[c];
-      v[row * d + k] = vv[c];
+    for (int c = 0; c < CPL; ++c) {
+      const int k = lane + c * NR_WAVE;
+      if (k < d) {
+        var[row * d + k] = wv[c];
+        m[row * d + k] = mm[c];
+        v[row * d + k] = vv[c];
+      }
     }
   }
-  if (lane == 0) last[row] = t;
+  if (has_grad && lane == 0) last[row] = t;
 }
 
 // dense ApplyAdam whose gradient is the sum of two buffers (g = g1 + g2, one rounding — the
@@ -411,20 +446,23 @@ int nrhip_adam_sparse_tf(float* d_var, float* d_m, float* d_v, float* d_grad, in
  * step.  d_plan = NULL, n_occ = 0, period = 1: flush — every row brought to step t. */
 int nrhip_adam_sparse_tf_lazy(float* d_var, float* d_m, float* d_v, float* d_grad, int32_t* d_last,
                               const int32_t* d_stamp, int64_t n_rows, int d, const uint64_t* d_plan,
-                              int n_occ, const float* d_alpha_tab, int t, int period, float beta1,
-                              float beta2, float eps, void* stream) {
+                              int n_occ, const uint64_t* d_next_plan, int n_next_occ,
+                              const float* d_alpha_tab, int t, int period, float beta1, float beta2,
+                              float eps, void* stream) {
   NR_REQUIRE(d_var && d_m && d_v && d_grad && d_last && d_alpha_tab && (n_occ == 0 || d_stamp), NR_ERR_ARG,
              "adam_sparse_tf_lazy: null pointer argument");
-  NR_REQUIRE(n_rows >= 0 && d >= 1 && d <= 256 && n_occ >= 0 && (n_occ == 0 || d_plan) && t >= 0 &&
-                 period >= 1, NR_ERR_ARG, "adam_sparse_tf_lazy: bad sizes");
+  NR_REQUIRE(n_rows >= 0 && d >= 1 && d <= 256 && n_occ >= 0 && (n_occ == 0 || d_plan) && n_next_occ >= 0 &&
+                 (n_next_occ == 0 || d_next_plan) && t >= 0 && period >= 1,
+             NR_ERR_ARG, "adam_sparse_tf_lazy: bad sizes");
   const int64_t scheduled = (n_rows + period - 1) / period;
-  const int64_t waves = (int64_t)n_occ + scheduled;
+  const int64_t waves = (int64_t)n_occ + n_next_occ + scheduled;
   if (waves == 0) return NR_OK;
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define NR_LAZY(CPL)                                                                                  \
   hipLaunchKernelGGL(adam_lazy_kernel<CPL>, grid, block, 0, st, d_var, d_m, d_v, d_grad, d_last, d_stamp, d, n_rows, \
-                     d_plan, n_occ, d_alpha_tab, t, period, beta1, beta2, 1.0f - beta1, 1.0f - beta2, eps)
+                     d_plan, n_occ, d_next_plan, n_next_occ, d_alpha_tab, t, period, beta1, beta2,          \
+                     1.0f - beta1, 1.0f - beta2, eps)
   if (d <= 64) NR_LAZY(1); else if (d <= 128) NR_LAZY(2); else NR_LAZY(4);
 #undef NR_LAZY
   NR_LAUNCH_CHECK();

@@ -60,20 +60,25 @@ struct LazyTables {
 template <int CPL>
 __device__ __forceinline__ void load_row_lazy(const float* __restrict__ base, int64_t row, int64_t grow,
                                               int d, int lane, const LazyTables& lz, float (&out)[CPL]) {
+  const int from = __builtin_amdgcn_readfirstlane(lz.last[grow]) + 1;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    out[c] = k < d ? base[row * d + k] : 0.f;
+  }
+  if (from >= lz.t) return;                      // current (the optimiser was told this batch was coming)
   float mm[CPL], vv[CPL];
   bool quiet = true;
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
-    out[c] = mm[c] = vv[c] = 0.f;
+    mm[c] = vv[c] = 0.f;
     if (k < d) {
-      out[c] = base[row * d + k];
       mm[c] = lz.m[grow * d + k];
       vv[c] = lz.v[grow * d + k];
     }
     quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
   }
-  const int from = __builtin_amdgcn_readfirstlane(lz.last[grow]) + 1;
   if (__all(quiet)) return;
   nr_lazy_replay<CPL>(out, mm, vv, from, lz.t - 1, lz.alpha_tab, lane, lz.b1, lz.b2, lz.omb1, lz.omb2, lz.eps);
 }

@@ -248,8 +248,9 @@ int nrhip_mf_ctx_destroy(void* ctx) {
 
 // One BPR-MF step = sess.run((loss, optimizer)) (MF.py:101)
 int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, const uint64_t* d_plan, int step_index, float alpha, float beta1,
-                  float beta2, float eps, float* d_loss2, void* stream) {
+                  int batch, const uint64_t* d_plan, const uint64_t* d_next_plan, int next_batch,
+                  int step_index, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                  void* stream) {
   NR_REQUIRE(ctx && d_users && d_pos && d_neg && d_loss2, NR_ERR_ARG, "mf_step: null argument");
   const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
   NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG, "mf_step: batch %d outside 0..%d",
@@ -275,8 +276,8 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
                                     d_loss2, plan, stream));
     return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, b.stamp,
                                      (int64_t)b.n_users + b.n_items, b.d, batch ? plan : nullptr,
-                                     3 * batch, b.alpha_tab, step_index, b.lazy_period, beta1, beta2, eps,
-                                     stream);
+                                     3 * batch, d_next_plan, d_next_plan ? 3 * next_batch : 0, b.alpha_tab,
+                                     step_index, b.lazy_period, beta1, beta2, eps, stream);
   }
   NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, b.n_users, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ,
                            b.terms, d_loss2, d_plan, stream));
@@ -296,7 +297,8 @@ int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float ep
   if (!b.last || steps_done <= 0) return NR_OK;
   NR_REQUIRE(steps_done < b.alpha_len, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
   return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, nullptr, (int64_t)b.n_users + b.n_items,
-                                   b.d, nullptr, 0, b.alpha_tab, steps_done, 1, beta1, beta2, eps, stream);
+                                   b.d, nullptr, 0, nullptr, 0, b.alpha_tab, steps_done, 1, beta1, beta2, eps,
+                                   stream);
 }
 
 }  // extern "C"

@@ -750,10 +750,12 @@ class NativeStep:
         call("nrhip_lightgcn_step_apply", self.handle, _ptr(grad, torch.float32),
              float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps), _stream())
 
-    def mf_step(self, users, pos, neg, st, loss2, plan=None):
+    def mf_step(self, users, pos, neg, st, loss2, plan=None, next_plan=None):
+        n_next = 0 if next_plan is None else next_plan.numel() // 3
         call("nrhip_mf_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
-             users.numel(), self._plan(plan, 3 * users.numel()), st.t + 1, float(st.alpha()),
-             float(st.beta1), float(st.beta2), float(st.eps), _ptr(loss2, torch.float32), _stream())
+             users.numel(), self._plan(plan, 3 * users.numel()), self._plan(next_plan, 3 * n_next), n_next,
+             st.t + 1, float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
+             _ptr(loss2, torch.float32), _stream())
 
     def mf_flush(self, st):
         call("nrhip_mf_flush", self.handle, st.t, float(st.beta1), float(st.beta2), float(st.eps),

@@ -74,7 +74,8 @@ class MF(AbstractRecommender):
                     bat_items = torch.tensor(bat_items, dtype=torch.int32, device=dev)
                     bat_third = torch.tensor(bat_third, dtype=torch.float32, device=dev)
                 if self._fast:                        # the batch's plan came with it from the sampler
-                    self.engine.step(bat_users, bat_items, bat_third, losses[n], plan=batch.plan)
+                    self.engine.step(bat_users, bat_items, bat_third, losses[n], plan=batch.plan,
+                                     next_plan=batch.next_plan)
                 else:
                     self.engine.step(bat_users, bat_items, bat_third, losses[n])
                 n += 1

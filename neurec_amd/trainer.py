@@ -18,12 +18,14 @@ from . import engine as E
 
 class TripletBatch(tuple):
     """(users, pos, neg) device views of one batch; `.plan` = the batch's sorted occurrence keys
-    (engine.bpr_plan) or None.  Unpacks like the reference sampler's 3-tuples."""
+    (engine.bpr_plan) or None; `.next_plan` = the plan of the batch that follows it in the epoch
+    (None for the last).  Unpacks like the reference sampler's 3-tuples."""
     plan = None
+    next_plan = None
 
-    def __new__(cls, users, pos, neg, plan=None):
+    def __new__(cls, users, pos, neg, plan=None, next_plan=None):
         self = super().__new__(cls, (users, pos, neg))
-        self.plan = plan
+        self.plan, self.next_plan = plan, next_plan
         return self
 
 
@@ -82,9 +84,11 @@ class BprEpochSampler:
         for k in range(len(self)):
             b, e = k * B, min((k + 1) * B, self.n_local)
             nb = neg[b * self.neg_num:e * self.neg_num]
+            e2 = min((k + 2) * B, self.n_local)
             yield TripletBatch(users[b:e], pos[b:e],
                                nb if self.neg_num == 1 else nb.view(-1, self.neg_num),
-                               self._plan[3 * b:3 * e] if self.plans else None)
+                               self._plan[3 * b:3 * e] if self.plans else None,
+                               self._plan[3 * e:3 * e2] if (self.plans and e2 > e) else None)
 
 
 class MFEngine:
@@ -94,15 +98,18 @@ class MFEngine:
     applied by exact lazy replay (nrhip_adam_sparse_tf_lazy): a row's missed zero-gradient steps
     are replayed in registers when the row is next touched, bit-identical to sweeping the table
     every step (lazy=False, the checker).  lazy_period bounds how far a row may fall behind (rows
-    r = t mod period are refreshed every step): measured on MI355X at the gowalla shape, B = 512
-    (scripts/exp_mf_lazy.py): sweep 29.9 us/step; period 4: 22.7, 8: 23.9, 16: 27.1, 64: 48.4 — the
-    replay is a chain of exact fp32 sqrt + divide per missed step, run again by the gradient kernel
-    for every row it gathers, so short bounds win.  The tables are only current after flush(); the
-    P / Q / mP / ... properties flush for you."""
+    r = t mod period are refreshed every step).  Measured on MI355X at the gowalla shape, B = 512
+    (scripts/exp_mf_lazy.py), sweep 29.0-29.9 us/step; lazy with the sampler's next-batch plans (the
+    optimiser launch of step t brings the rows step t+1 will gather up to date, so the gradient
+    kernel replays nothing): period 4: 20.2, 8: 19.2, 16: 19.3, 32: 20.7, 64: 23.8 us; without next
+    plans the gradient kernel redoes the replay (a chain of exact fp32 sqrt + divide per missed
+    step) for every row it gathers: period 4: 22.7, 16: 27.1, 64: 48.4 us.  What is left is two
+    dependent launches of ~9-10 us, each a chain of 4-5 memory round trips.  The tables are only
+    current after flush(); the P / Q / mP / ... properties flush for you."""
 
     ALPHA_STEPS = 1 << 20           # step-size table: 4 MB, enough for 1 M optimiser steps
 
-    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=4):
+    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=16):
         dev = E.require_gpu()
         ut = torch.as_tensor(user_table, dtype=torch.float32)
         it = torch.as_tensor(item_table, dtype=torch.float32)
@@ -139,14 +146,16 @@ class MFEngine:
     vP = property(lambda self: (self.flush(), self._views["vP"])[1])
     vQ = property(lambda self: (self.flush(), self._views["vQ"])[1])
 
-    def step(self, users, pos, neg, loss_out, plan=None):
+    def step(self, users, pos, neg, loss_out, plan=None, next_plan=None):
         """One native call: fused gather/BPR/ordered row sums kernel + TF-sparse Adam (lazy replay on
         the touched and scheduled rows, or the full sweep).  loss_out: 2-float device tensor
         receiving (bpr_sum, reg_term); plan: the batch's TripletBatch.plan (None: sorted inside the
-        step)."""
+        step); next_plan: TripletBatch.next_plan — lazy mode brings the rows of the coming batch up to
+        date in this step's optimiser launch, so its gradient kernel replays nothing (same results
+        with or without)."""
         if self.lazy and self.adam.t + 2 >= self._alpha_tab.numel():
             raise NotImplementedError("more than %d optimiser steps: enlarge MFEngine.ALPHA_STEPS" % self.ALPHA_STEPS)
-        self._ctx.mf_step(users, pos, neg, self.adam, loss_out, plan)
+        self._ctx.mf_step(users, pos, neg, self.adam, loss_out, plan, next_plan if self.lazy else None)
         self.adam.advance()
         self._stale = True
 

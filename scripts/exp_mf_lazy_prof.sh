@@ -13,10 +13,10 @@ batches = [b for b in smp.batches() if b[0].numel() == 512][:400]
 loss = torch.zeros(2, device="cuda")
 rs = np.random.RandomState(2017)
 mf = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32), 0.001, 0.0, 512, lazy=True, lazy_period=int(sys.argv[1]))
-for b in batches: mf.step(b[0], b[1], b[2], loss, plan=b.plan)
+for b in batches: mf.step(b[0], b[1], b[2], loss, plan=b.plan, next_plan=b.next_plan)
 torch.cuda.synchronize()
 PY
-for per in 4 16; do
+for per in 16; do
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm$per -o m -- python /tmp/mf1.py $per > /dev/null 2>&1 )
 echo "== period $per"; f=$(find /tmp/pm$per -name "*kernel_stats.csv" | head -1); python -c "import csv,sys; [print(r[\"Name\"][:60], r[\"Calls\"], r[\"AverageNs\"], r[\"MinNs\"], r[\"MaxNs\"]) for r in list(csv.DictReader(open(sys.argv[1])))[:4]]" "$f"
 done

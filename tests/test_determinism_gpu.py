@@ -216,3 +216,33 @@ def test_lazy_sparse_adam_is_bit_identical_to_the_sweep(d, period, reg):
         np.testing.assert_array_equal(getattr(lazy, name).cpu().numpy(), getattr(sweep, name).cpu().numpy(), err_msg=name)
     np.testing.assert_array_equal(lazy.P.cpu().numpy()[600:], P0[600:])          # never touched: never moved
     assert not lazy.GP.cpu().numpy().any() and not lazy.GQ.cpu().numpy().any()     # gradients re-armed
+
+
+def test_lazy_adam_with_next_batch_plans_is_bit_identical_to_the_sweep():
+    """The sampler's batches carry their own plan and the next batch's: the optimiser launch of step t
+    brings the rows step t+1 will gather up to date, the gradient kernel then replays nothing.  Across
+    epoch boundaries (no next plan on an epoch's last batch, short last batches) the tables and moments
+    still equal the all-rows sweep bit for bit."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.trainer import BprEpochSampler, MFEngine
+    tr, _ = synth.interactions("ml-100k", seed=4)
+    U, I = tr.shape
+    trc = E.DeviceCSR.from_scipy(tr)
+    rs = np.random.RandomState(3)
+    P0, Q0 = (rs.randn(U, 64) * 0.05).astype(np.float32), (rs.randn(I, 64) * 0.05).astype(np.float32)
+    lazy = MFEngine(P0, Q0, 0.002, 0.01, 2048, lazy=True, lazy_period=16)
+    sweep = MFEngine(P0, Q0, 0.002, 0.01, 2048, lazy=False)
+    sampler = BprEpochSampler(trc, I, batch_size=2048, seed=5, plan_users=U)     # 39 batches per epoch
+    la, lb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    n, with_next = 0, 0
+    for epoch in range(3):
+        for b in sampler.batches():
+            with_next += b.next_plan is not None
+            lazy.step(b[0], b[1], b[2], la, plan=b.plan, next_plan=b.next_plan)
+            sweep.step(b[0], b[1], b[2], lb, plan=b.plan)
+            n += 1
+            assert float(la[0]) == float(lb[0]) and float(la[1]) == float(lb[1]), n
+    assert n == 3 * len(sampler) and with_next == 3 * (len(sampler) - 1)
+    for name in ("P", "Q", "mP", "mQ", "vP", "vQ"):
+        np.testing.assert_array_equal(getattr(lazy, name).cpu().numpy(), getattr(sweep, name).cpu().numpy(), err_msg=name)
