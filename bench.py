@@ -186,12 +186,12 @@ def main():
         U, I, n_edges = (max(int(x * args.scale), 64) for x in synth.CONFIG4)
         tr_ptr, tr_idx = synth.device_interactions(U, I, n_edges, seed=2018, device=dev)
         n_train = int(tr_ptr[-1])
-        blk = par.block_size(U + I, comm.world)
-        lo, hi = min(comm.rank * blk, U + I), min((comm.rank + 1) * blk, U + I)
-        rows = synth.device_lightgcn_adjacency(tr_ptr, tr_idx, U, I, lo, hi)
+        part = par.BipartitePartition(U, I, comm.world)     # every rank: a slice of the users AND of the items
+        ur, ir = part.users_of(comm.rank), part.items_of(comm.rank)
+        rows = synth.device_lightgcn_rank_rows(tr_ptr, tr_idx, U, I, ur, ir)
         lim = float(np.sqrt(6.0 / (U + I + args.dim)))
         g = torch.Generator(device=dev); g.manual_seed(2017 + comm.rank)
-        E0 = (torch.rand(hi - lo, args.dim, generator=g, device=dev) * 2 - 1) * lim
+        E0 = (torch.rand((ur[1] - ur[0]) + (ir[1] - ir[0]), args.dim, generator=g, device=dev) * 2 - 1) * lim
         lg = ShardedLightGCN(comm, None, U, I, E0, args.layers, 0.01, 1e-3, args.batch, local_rows=rows)
         del rows
         trc, tec, train, test = E.DeviceCSR(tr_ptr, tr_idx, I), None, None, None
@@ -455,6 +455,9 @@ def main():
         "unit": "triplets/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "data_note": "train AND test interactions are synthetic twins of the named shape (neurec_amd/synth.py); SURVEY "
+                     "8d names the reference's real dataset/gowalla.test as the test split, but /root/reference does "
+                     "not exist on the GPU box and gowalla.train is absent from the reference tree altogether",
         "config": {"workload": "LightGCN on synthetic %s-shaped interactions (U=%d, I=%d, E=%d), "
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
                                % (args.shape, U, I, train_nnz, args.layers, args.dim, args.batch),

@@ -2,10 +2,14 @@
 meant to be replicated — U = 10⁷, I = 10⁶, d = 128 is 5.6 GB per [N][d] buffer and the step keeps
 a dozen of them).
 
-Partition: the N = U + I node rows are cut into `world` padded blocks of b = ⌈N/world⌉ rows; rank r
-owns rows [r·b, (r+1)·b) of the embedding table E0, of its Adam moments and of every layer
-buffer, plus the CSR rows of Â (and of Âᵀ when Â is not symmetric) for those nodes.  A rank can
-be built from its own row block alone (`local_rows=`): no rank needs the whole graph.
+Partition (`parallel.BipartitePartition`): every rank owns a slice of the users AND a slice of the items
+— rank r holds users [r·bu, (r+1)·bu) then items [r·bi, (r+1)·bi), padded to b = bu + bi rows — of the
+embedding table E0, of its Adam moments and of every layer buffer, plus the CSR rows of Â (and of Âᵀ
+when Â is not symmetric) for those nodes.  (A contiguous cut of [users; items] would give the last
+rank every item row: 52 % of the non-zeros at config 4.)  An all-gather of the padded blocks lays a
+table out rank-major; the local CSR blocks carry positions in that layout as column indices, in
+ascending-node-id storage order (the order the row sums run in).  A rank can be built from its own
+rows alone (`local_rows=`): no rank needs the whole graph.
 
 One LightGCN step (LightGCN.py:132-166,178) then has exactly these exchange points:
   * per propagation hop (L forward, L backward): ONE all-gather of the [b][d] blocks into the
@@ -42,8 +46,8 @@ class RowRouter:
 
     CODE = 1 << 24                       # occurrence code = class * CODE + position in the rank's batch
 
-    def __init__(self, comm, block_rows):
-        self.comm, self.b = comm, int(block_rows)
+    def __init__(self, comm, part):
+        self.comm, self.part = comm, part
         self.world, self.rank = comm.world, comm.rank
         self._epoch = None               # (batch, send counts [nb][world], recv counts, sizes [nb][world])
 
@@ -58,7 +62,7 @@ class RowRouter:
         which = torch.arange(n, device=dev) // batch
         cnt = torch.zeros(nb * self.world, dtype=torch.int64, device=dev)
         for ids, off in zip(classes, offsets):
-            owner = torch.div(ids.long() + off, self.b, rounding_mode="floor")
+            owner, _ = self.part.owner_local(ids.long() + off)
             cnt += torch.bincount(which * self.world + owner, minlength=nb * self.world)
         send = cnt.view(nb, self.world)
         sizes = torch.full((nb,), batch, dtype=torch.int64, device=dev)
@@ -104,9 +108,9 @@ class RowRouter:
         nodes = torch.cat([ids.long() + off for ids, off in zip(class_ids, offsets)])
         code = torch.cat([torch.arange(B, device=nodes.device, dtype=torch.int32) + c * self.CODE
                           for c in range(len(class_ids))])
-        owner = torch.div(nodes, self.b, rounding_mode="floor")
+        owner, local = self.part.owner_local(nodes)
         order = torch.argsort(owner, stable=True)
-        local = (nodes - owner * self.b)[order].to(torch.int32)
+        local = local[order].to(torch.int32)
         packed = torch.stack([local, code[order]], dim=1).contiguous()          # [n][2] int32
         if planned is None:
             send_counts = torch.bincount(owner, minlength=self.world)[:self.world]
@@ -149,11 +153,11 @@ class ShardedLightGCN:
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.N = self.n_users + self.n_items
         self.L, self.reg, self.max_batch = int(n_layers), float(reg), int(max_batch)
-        self.b = parallel.block_size(self.N, self.world)
-        self.lo = min(self.rank * self.b, self.N)
-        self.hi = min(self.lo + self.b, self.N)
-        self.n_loc = self.hi - self.lo
-        self.Npad = self.b * self.world
+        self.part = parallel.BipartitePartition(self.n_users, self.n_items, self.world)
+        self.b, self.Npad = self.part.b, self.part.n_pad
+        self.ulo, self.uhi = self.part.users_of(self.rank)
+        self.ilo, self.ihi = self.part.items_of(self.rank)
+        self.nu, self.ni = self.uhi - self.ulo, self.ihi - self.ilo
         if local_rows is not None:
             self.A = self._from_block(*local_rows)
             self.At = self.A if local_rows_t is None else self._from_block(*local_rows_t)
@@ -162,20 +166,27 @@ class ShardedLightGCN:
             a.sort_indices()
             if symmetric is None:
                 symmetric = (a != a.T).nnz == 0
-            # local row block, padded to b rows (empty rows) so every rank runs the same shapes
             self.A = self._local_rows(a)
             self.At = self.A if symmetric else self._local_rows(a.T.tocsr())
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        if isinstance(embed, torch.Tensor):             # this rank's rows, already on the device
+        if isinstance(embed, torch.Tensor):             # this rank's rows (users then items) or the full table
             self.d = embed.shape[1]
-            self.E0 = z(self.b, self.d)
-            self.E0[:self.n_loc] = embed[:self.n_loc] if embed.shape[0] == self.n_loc else embed[self.lo:self.hi]
+            src_u, src_i = ((embed[:self.nu], embed[self.nu:self.nu + self.ni])
+                            if embed.shape[0] == self.nu + self.ni and embed.shape[0] != self.N else
+                            (embed[self.ulo:self.uhi], embed[self.n_users + self.ilo:self.n_users + self.ihi]))
+            src_u, src_i = src_u.to(dev), src_i.to(dev)
         else:
             embed = np.asarray(embed, dtype=np.float32)
             self.d = embed.shape[1]
-            self.E0 = z(self.b, self.d)
-            mine = embed if (embed.shape[0] == self.n_loc and embed.shape[0] != self.N) else embed[self.lo:self.hi]
-            self.E0[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+            if embed.shape[0] == self.nu + self.ni and embed.shape[0] != self.N:
+                hu, hi_ = embed[:self.nu], embed[self.nu:]
+            else:
+                hu, hi_ = embed[self.ulo:self.uhi], embed[self.n_users + self.ilo:self.n_users + self.ihi]
+            src_u = torch.from_numpy(np.ascontiguousarray(hu)).to(dev)
+            src_i = torch.from_numpy(np.ascontiguousarray(hi_)).to(dev)
+        self.E0 = z(self.b, self.d)
+        self.E0[:self.nu] = src_u
+        self.E0[self.part.bu:self.part.bu + self.ni] = src_i
         self.m, self.v = z(self.b, self.d), z(self.b, self.d)
         self.X = z(self.Npad, self.d)                       # gathered operand of the local SpMM
         self.Ya, self.Yb, self.Esum = (z(self.b, self.d) for _ in range(3))
@@ -187,23 +198,42 @@ class ShardedLightGCN:
         self.adam = E.AdamState(lr)
         self._cu = torch.arange(self.max_batch, dtype=torch.int32, device=dev)
         self._cp = self._cu.clone()
-        self.router = RowRouter(comm, self.b)
+        self.router = RowRouter(comm, self.part)
         self._offsets = (0, self.n_users, self.n_users)
+        self._gidx = None
 
     def _from_block(self, indptr, indices, vals):
-        if isinstance(indices, torch.Tensor):          # a block built on the device (synth.device_*)
+        """CSR of this rank's nu user rows followed by its ni item rows, GLOBAL node ids as columns
+        (numpy or device tensors) -> the padded [b]-row local block whose columns are positions in the
+        gathered layout; a row keeps its storage order (ascending node id)."""
+        bu = self.part.bu
+        if isinstance(indices, torch.Tensor):
             ip = torch.zeros(self.b + 1, dtype=torch.int64, device=indices.device)
-            ip[1:self.n_loc + 1] = indptr[1:self.n_loc + 1]
-            ip[self.n_loc + 1:] = ip[self.n_loc]
-            return E.SpmmCSR(ip, indices, vals, n_cols=self.Npad)
+            ip[1:self.nu + 1] = indptr[1:self.nu + 1]
+            ip[self.nu + 1:bu + 1] = indptr[self.nu]
+            ip[bu + 1:bu + self.ni + 1] = indptr[self.nu + 1:self.nu + self.ni + 1]
+            ip[bu + self.ni + 1:] = indptr[self.nu + self.ni]
+            cols = self.part.position(indices.long()).to(torch.int32)
+            return E.SpmmCSR(ip, cols, vals, n_cols=self.Npad)
+        indptr = np.asarray(indptr, dtype=np.int64)
         ip = np.zeros(self.b + 1, dtype=np.int64)
-        ip[1:self.n_loc + 1] = np.asarray(indptr, dtype=np.int64)[1:self.n_loc + 1]
-        ip[self.n_loc + 1:] = ip[self.n_loc]
-        return E.SpmmCSR(ip, np.asarray(indices, np.int32), np.asarray(vals, np.float32), n_cols=self.Npad)
+        ip[1:self.nu + 1] = indptr[1:self.nu + 1]
+        ip[self.nu + 1:bu + 1] = indptr[self.nu]
+        ip[bu + 1:bu + self.ni + 1] = indptr[self.nu + 1:self.nu + self.ni + 1]
+        ip[bu + self.ni + 1:] = indptr[self.nu + self.ni]
+        cols = self.part.position(np.asarray(indices, dtype=np.int64)).astype(np.int32)
+        return E.SpmmCSR(ip, cols, np.asarray(vals, np.float32), n_cols=self.Npad)
 
     def _local_rows(self, a):
-        blk = a[self.lo:self.hi]
+        import scipy.sparse as sp
+        blk = sp.vstack([a[self.ulo:self.uhi], a[self.n_users + self.ilo:self.n_users + self.ihi]]).tocsr()
         return self._from_block(blk.indptr, blk.indices, blk.data)
+
+    def natural(self, gathered):
+        """[n_pad][d] gathered (rank-major) table -> (user rows [U][d], item rows [I][d]) in id order"""
+        if self._gidx is None:
+            self._gidx = self.part.gathered_index(gathered.device)
+        return gathered[self._gidx[0]], gathered[self._gidx[1]]
 
     def plan_epoch(self, users, pos, neg, batch):
         """Routing counts of every batch of this rank's epoch stream (see RowRouter.plan_epoch);
@@ -225,17 +255,12 @@ class ShardedLightGCN:
             src, acc_in = out, self.Esum
         return self.Esum
 
-    def final_embeddings_local(self):
-        out = torch.empty_like(self.Esum)
-        E.div_scalar(self.propagate(), float(self.L + 1), out)
-        return out[:self.n_loc]
-
     def final_embeddings(self):
         """Full (user, item) tables on every rank (one all-gather; evaluation entrance)."""
         loc = torch.zeros_like(self.Esum)
         E.div_scalar(self.propagate(), float(self.L + 1), loc)
         self.comm.all_gather_rows(loc, self.X)
-        return self.X[:self.n_users], self.X[self.n_users:self.N]
+        return self.natural(self.X)
 
     def step(self, users, pos, neg, loss_out=None, batch_index=None):
         """One optimiser step on this rank's B triplets (global batch = all ranks' triplets)."""
@@ -297,14 +322,14 @@ class ShardedMF:
         it = np.asarray(item_table, dtype=np.float32)
         self.n_users, self.n_items, self.d = ut.shape[0], it.shape[0], ut.shape[1]
         self.N = self.n_users + self.n_items
-        self.b = parallel.block_size(self.N, self.world)
-        self.lo = min(self.rank * self.b, self.N)
-        self.hi = min(self.lo + self.b, self.N)
-        self.n_loc = self.hi - self.lo
-        full = np.concatenate([ut, it])
+        self.part = parallel.BipartitePartition(self.n_users, self.n_items, self.world)
+        self.b = self.part.b
+        ulo, uhi = self.part.users_of(self.rank)
+        ilo, ihi = self.part.items_of(self.rank)
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        self.T = z(self.b, self.d)                                   # my rows of [P ; Q]
-        self.T[:self.n_loc] = torch.from_numpy(np.ascontiguousarray(full[self.lo:self.hi])).to(dev)
+        self.T = z(self.b, self.d)                                   # my user rows, then my item rows
+        self.T[:uhi - ulo] = torch.from_numpy(np.ascontiguousarray(ut[ulo:uhi])).to(dev)
+        self.T[self.part.bu:self.part.bu + ihi - ilo] = torch.from_numpy(np.ascontiguousarray(it[ilo:ihi])).to(dev)
         self.m, self.v, self.G = z(self.b, self.d), z(self.b, self.d), z(self.b, self.d)
         self.reg, self.max_batch = float(reg), int(max_batch)
         self.adam = E.AdamState(lr)
@@ -313,8 +338,9 @@ class ShardedMF:
         self.gP, self.gQ = z(self.max_batch, self.d), z(2 * self.max_batch, self.d)
         self.terms = z(8 * self.max_batch)
         self._ar = torch.arange(2 * self.max_batch, dtype=torch.int32, device=dev)
-        self.router = RowRouter(comm, self.b)
+        self.router = RowRouter(comm, self.part)
         self._offsets = (0, self.n_users, self.n_users)
+        self._gidx = None
 
     def plan_epoch(self, users, pos, neg, batch):
         self.router.plan_epoch([users, pos, neg], self._offsets, batch)
@@ -347,4 +373,6 @@ class ShardedMF:
         """Full (P, Q) on every rank (one all-gather; evaluation entrance)."""
         full = torch.empty(self.b * self.world, self.d, dtype=torch.float32, device=self.T.device)
         self.comm.all_gather_rows(self.T, full)
-        return full[:self.n_users], full[self.n_users:self.N]
+        if self._gidx is None:
+            self._gidx = self.part.gathered_index(full.device)
+        return full[self._gidx[0]], full[self._gidx[1]]

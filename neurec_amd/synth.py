@@ -139,3 +139,13 @@ def device_lightgcn_adjacency(indptr, indices, n_users, n_items, row_lo=0, row_h
     idx = torch.cat(parts_idx) if parts_idx else torch.zeros(0, dtype=torch.int32, device=dev)
     val = torch.cat(parts_val) if parts_val else torch.zeros(0, dtype=torch.float32, device=dev)
     return ptr, idx, val
+
+
+def device_lightgcn_rank_rows(indptr, indices, n_users, n_items, user_range, item_range):
+    """CSR of a rank's rows under parallel.BipartitePartition: its user rows, then its item rows
+    (global node ids as columns) — the `local_rows=` input of sharded.ShardedLightGCN."""
+    import torch
+    pu, iu, vu = device_lightgcn_adjacency(indptr, indices, n_users, n_items, user_range[0], user_range[1])
+    pi, ii, vi = device_lightgcn_adjacency(indptr, indices, n_users, n_items, n_users + item_range[0],
+                                           n_users + item_range[1])
+    return torch.cat([pu, pi[1:] + pu[-1]]), torch.cat([iu, ii]), torch.cat([vu, vi])

@@ -176,3 +176,30 @@ def test_row_sharding_collectives(tmp_path):
     np.testing.assert_array_equal(r0["back"][:, 0], [100, 101, 101])     # my rows, answered, in my send order
     np.testing.assert_array_equal(r1["back"][:, 0], [110, 110, 111, 111])
     assert parallel.block_size(7, 2) == 4 and parallel.block_size(8, 2) == 4 and parallel.block_size(1, 8) == 1
+
+
+def test_bipartite_partition_balances_users_and_items():
+    """parallel.BipartitePartition: every rank owns a slice of the users AND of the items (a contiguous
+    cut of [users; items] would give the last rank every item row — half of all non-zeros at config 4);
+    position() is a bijection onto the gathered layout, owner/local agree between numpy and torch."""
+    import numpy as np
+    import torch
+    from neurec_amd.parallel import BipartitePartition
+    for U, I, world in ((10, 7, 3), (943, 1682, 2), (1000, 100, 8), (5, 3, 8)):
+        p = BipartitePartition(U, I, world)
+        nodes = np.arange(U + I)
+        owner, local = p.owner_local(nodes)
+        pos = p.position(nodes)
+        assert len(set(pos.tolist())) == U + I and pos.max() < p.n_pad
+        to, tl = p.owner_local(torch.arange(U + I))
+        assert (to.numpy() == owner).all() and (tl.numpy() == local).all()
+        for r in range(world):
+            (ulo, uhi), (ilo, ihi) = p.users_of(r), p.items_of(r)
+            mine = np.flatnonzero(owner == r)
+            assert set(mine.tolist()) == set(range(ulo, uhi)) | set(range(U + ilo, U + ihi))
+            assert (local[ulo:uhi] == np.arange(uhi - ulo)).all()
+            assert (local[U + ilo:U + ihi] == p.bu + np.arange(ihi - ilo)).all()
+        gu, gi = p.gathered_index()
+        assert (gu.numpy() == pos[:U]).all() and (gi.numpy() == pos[U:]).all()
+        # balance: no rank holds more than its share (+1 block rounding) of either side
+        assert max(uhi - ulo for ulo, uhi in (p.users_of(r) for r in range(world))) <= p.bu

@@ -46,10 +46,13 @@ def _worker(rank, world, port, out, adj_type, d, backend="gloo"):
     comm = parallel.init_from_env()
     tr, A, E0, U, I = _setup(adj_type, d)
     if adj_type == "pre":
-        # built from this rank's row block alone (no rank holds the whole graph) ...
-        b = parallel.block_size(U + I, world)
-        blk = A[rank * b:min((rank + 1) * b, U + I)]
-        eng = ShardedLightGCN(comm, None, U, I, E0[rank * b:min((rank + 1) * b, U + I)], 2, 0.01, 1e-3, 128,
+        # built from this rank's rows alone (its users, then its items; no rank holds the whole graph) ...
+        import scipy.sparse as sp
+        part = parallel.BipartitePartition(U, I, world)
+        (ulo, uhi), (ilo, ihi) = part.users_of(rank), part.items_of(rank)
+        blk = sp.vstack([A[ulo:uhi], A[U + ilo:U + ihi]]).tocsr()
+        emb = np.concatenate([E0[ulo:uhi], E0[U + ilo:U + ihi]])
+        eng = ShardedLightGCN(comm, None, U, I, emb, 2, 0.01, 1e-3, 128,
                               local_rows=(blk.indptr, blk.indices, blk.data))
     else:
         eng = ShardedLightGCN(comm, A, U, I, E0, 2, 0.01, 1e-3, 128)
@@ -70,7 +73,8 @@ def _worker(rank, world, port, out, adj_type, d, backend="gloo"):
     table = torch.zeros(eng.Npad, d, device="cuda")
     comm.all_gather_rows(eng.E0, table)
     if rank == 0:
-        np.savez(out, E0=table[:U + I].cpu().numpy(), losses=np.asarray(losses),
+        tu, ti = eng.natural(table)                       # rank-major gathered layout -> id order
+        np.savez(out, E0=torch.cat([tu, ti]).cpu().numpy(), losses=np.asarray(losses),
                  eu=eu.cpu().numpy(), ei=ei.cpu().numpy())
     comm.barrier()
     comm.shutdown()
