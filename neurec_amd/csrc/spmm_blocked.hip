@@ -696,6 +696,8 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
 #pragma unroll
       for (int k = 0; k < kStage; ++k) {
         keep[k] = 1;
+        // (r02 A/B: replacing these per-pair mask bytes by a hash — no memory — takes the hop from 20.3 to
+        // 18.6 us: an LDS bit set instead of the byte gathers could save at most ~1.5 us)
         if constexpr (COLMASK) keep[k] = col_mask[col[k]];
       }
 #pragma unroll

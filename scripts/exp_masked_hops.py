@@ -28,7 +28,7 @@ indptr = np.ascontiguousarray(A.indptr.astype(np.int64)); indices = np.ascontigu
 ind_d = torch.from_numpy(indices).cuda(); val_d = torch.from_numpy(A.data.astype(np.float32)).cuda()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-nb = sz(0); lib.nrhip_spmm_blocked_plan_bytes(N, A.nnz, C.byref(nb))
+nb = sz(0); lib.nrhip_spmm_blocked_plan_bytes(N, A.nnz, d, C.byref(nb))
 flag = torch.zeros(N, dtype=torch.uint8, device="cuda")
 rs = np.random.RandomState(7)                         # a batch as the sampler draws it: 1024 interactions + negatives
 pick = rs.randint(0, coo.nnz, 1024)
