@@ -246,3 +246,33 @@ def test_lazy_adam_with_next_batch_plans_is_bit_identical_to_the_sweep():
     assert n == 3 * len(sampler) and with_next == 3 * (len(sampler) - 1)
     for name in ("P", "Q", "mP", "mQ", "vP", "vQ"):
         np.testing.assert_array_equal(getattr(lazy, name).cpu().numpy(), getattr(sweep, name).cpu().numpy(), err_msg=name)
+
+
+def test_global_batch_of_8192_sorts_its_plan_inside_the_step():
+    """The 8-GPU id-exchange mode steps on a global batch of 8 x 1,024 triplets whose plan can only be
+    sorted inside the step (16,384 item occurrences: the LDS sort's limit): same tables as with the
+    plan handed in, and the plan equals the host sort."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.graph import lightgcn_adjacency
+    from neurec_amd.trainer import LightGCNEngine
+    tr, _ = synth.interactions("gowalla", seed=3, scale=0.1)
+    U, I = tr.shape
+    coo = tr.tocoo()
+    A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    E0 = synth.xavier_uniform(U + I, 64, np.random.RandomState(1))
+    rng = np.random.RandomState(2)
+    B = 8192
+    pick = rng.randint(0, coo.nnz, B)
+    bu, bp, bn = coo.row[pick].astype(np.int32), coo.col[pick].astype(np.int32), rng.randint(0, I, B).astype(np.int32)
+    plan = E.bpr_plan(_dev(bu), _dev(bp), _dev(bn), B, U)
+    np.testing.assert_array_equal(plan.cpu().numpy().view(np.uint64), _host_plan(bu, bp, bn, B, U))
+    outs = []
+    for given in (False, True):
+        lg = LightGCNEngine(A, U, I, E0, 3, 0.01, 1e-3, B)
+        loss = torch.zeros(2, device="cuda")
+        for _ in range(2):
+            lg.step(_dev(bu), _dev(bp), _dev(bn), loss, plan=plan if given else None)
+        outs.append((lg.E0.cpu().numpy(), loss.cpu().numpy()))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
