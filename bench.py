@@ -456,7 +456,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "data_note": "train AND test interactions are synthetic twins of the named shape (neurec_amd/synth.py); SURVEY "
-                     "8d names the reference's real dataset/gowalla.test as the test split, but /root/reference does "
+                     "8d names the reference's real dataset/gowalla.test as the test split, but the reference tree does "
                      "not exist on the GPU box and gowalla.train is absent from the reference tree altogether",
         "config": {"workload": "LightGCN on synthetic %s-shaped interactions (U=%d, I=%d, E=%d), "
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"

@@ -1,5 +1,5 @@
 """bench.py's output contract, checked on the committed bench line of the round
-(profiles/r01_bench.json) and on the argument parser — no GPU needed."""
+(profiles/r02_bench.json) and on the argument parser — no GPU needed."""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r01_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -27,11 +27,36 @@ def test_committed_bench_line_carries_every_contract_field():
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
-    assert r["traffic"] is None or r["traffic"] > r["bytes_per_launch"]      # misses re-read rows
+    assert r["traffic"] is not None and r["traffic"] > r["bytes_per_launch"]   # misses re-read rows
+    # the PMC figure belongs to the SpMM sources this tree holds (bench.py nulls a stale one)
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("spmm_blocked.hip", "spmm.hip"):
+        with open(os.path.join(ROOT, "neurec_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        assert json.load(f)["_spmm_sources_sha16"] == h.hexdigest()[:16]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+    # SURVEY 8d's three CPU legs: the step (port), the reference's own sampler and evaluator
+    assert c["sampler"]["kind"] == "reference" and c["sampler"]["unit"] == "triplets/s"
+    assert c["eval"]["kind"] == "reference" and c["eval"]["unit"] == "users/s"
+
+
+def test_committed_bench_line_says_what_was_inside_the_timed_region():
+    d = _line()
+    t = d["timed_region"]
+    assert t["steps"] == d["steps"] and t["sampler_launches"] >= 0 and t["batch_plan_launches"] >= 0
+    assert "data_note" in d and "synthetic" in d["data_note"]
+    e = d["eval"]
+    assert e["ndcg10_oracle_absdiff"] == 0.0                       # metric value pinned on the reference's evaluator
+    r = e["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert 0 < e["roofline_topk"]["frac"] < 1
+    m = d["mf"]
+    assert "lazy" in m["optimizer"] and m["ms_per_step"] < m["sweep_ms_per_step"]
 
 
 def test_bench_metric_is_the_north_star_metric():
