@@ -40,9 +40,11 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--eval-batch", type=int, default=32768)
-    ap.add_argument("--dp-mode", choices=("triplets", "allreduce", "rowshard"), default="triplets",
-                    help="N>1 exchange: all-gather the batch ids (default), all-reduce dL/dE0, or "
-                         "row-sharded tables (all-gather per hop + all-to-all lookups; config 4 path)")
+    ap.add_argument("--dp-mode", choices=("replicated", "triplets", "allreduce", "rowshard"), default="replicated",
+                    help="N>1: every rank generates the epoch stream of the GLOBAL batch itself (counter-based "
+                         "sampler: same seed, same stream — no exchange at all; default), all-gather the "
+                         "batch ids, all-reduce dL/dE0, or row-sharded tables (all-gather per hop + "
+                         "all-to-all lookups; config 4 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--eval-mode", choices=("pruned", "materialised"), default="pruned")
@@ -173,6 +175,11 @@ def main():
 
     # ---------------- workload, resident in HBM before anything is timed
     exchange = comm.active and args.dp_mode == "triplets"
+    # The sampler is a counter-based generator (seed, epoch, position): every rank can produce the
+    # whole epoch stream for 47 us, so the global batch of world x B triplets needs no id exchange —
+    # and, existing a whole epoch ahead, it gets its batch plans from the sampler like a single GPU's.
+    replicated = comm.active and args.dp_mode == "replicated"
+    global_batch = args.batch * (comm.world if (exchange or replicated) else 1)
     rowshard = args.dp_mode == "rowshard"
     config4 = args.shape == "config4"
     if config4:
@@ -210,16 +217,18 @@ def main():
             lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
         else:
             lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,        # lr, reg: conf/LightGCN.properties
-                                args.batch * (comm.world if exchange else 1))
+                                global_batch)
         trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
     # single GPU / all-reduce / row-shard modes step on the sampler's own batches: their batch plans
     # (the order of the duplicate-row gradient sums) are sorted once per epoch by the sampler; in
     # the id-exchange mode the global batch only exists after the all-gather: sorted inside the step
-    sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=args.batch, shuffle=True, seed=2018,
-                              rank=comm.rank, world=comm.world,
+    sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=global_batch if replicated else args.batch,
+                              shuffle=True, seed=2018,
+                              rank=0 if replicated else comm.rank, world=1 if replicated else comm.world,
                               plan_users=None if (exchange or rowshard) else U)
     loss2 = torch.zeros(2, device=dev)
-    grad_sync = comm.allreduce_sum_ if (comm.active and not exchange and not rowshard) else None
+    grad_sync = comm.allreduce_sum_ if (comm.active and not exchange and not rowshard and not replicated) \
+        else None
 
     def batch_stream():
         while True:
@@ -230,7 +239,7 @@ def main():
                     lg.plan_epoch(sampler._users[:sampler.n_local], sampler._pos[:sampler.n_local],
                                   sampler._neg[:sampler.n_local], args.batch)
                 b.index = k
-                if b[0].numel() == args.batch:          # fixed-size steps for the timed region
+                if b[0].numel() == sampler.batch_size:  # fixed-size steps for the timed region
                     yield b
     stream = batch_stream()
     inflight = [comm.allgather_cat_start(next(stream))] if exchange else None
@@ -462,7 +471,11 @@ def main():
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
                                % (args.shape, U, I, train_nnz, args.layers, args.dim, args.batch),
                    "global_batch": comm.world * args.batch,
-                   "parallelism": ("dp%d (replicated tables; per step one all-gather of 12 B/triplet "
+                   "parallelism": ("dp%d (replicated tables; every rank generates the same global epoch "
+                                   "stream from the shared seed and steps on the global batch of "
+                                   "%d: no exchange in training, tables bit-identical on all ranks)"
+                                   % (comm.world, global_batch) if replicated else
+                                   "dp%d (replicated tables; per step one all-gather of 12 B/triplet "
                                    "of ids, every rank steps on the global batch)" % comm.world
                                    if exchange else
                                    "rowshard%d (tables row-sharded; all-gather per hop, all-to-all "

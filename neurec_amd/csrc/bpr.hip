@@ -417,6 +417,77 @@ __device__ __forceinline__ void mf_occurrence(
   }
 }
 
+// Ordered sums over the runs of one row in the sorted occurrence list (one wave = one occurrence, its
+// NV value rows in registers).  The first occurrence of a row (the "head") adds the others in list
+// order — TF's unsorted_segment_sum order — from LDS.  A run can leave the workgroup only at its end,
+// and only the LAST run of a workgroup can: when that run's head is here, ALL waves of the workgroup
+// recompute the continuation (kOccWaves occurrences per round, every load of a round in flight at
+// once) and the head adds them in order.  (A head that recomputed the continuation alone paid one
+// dependent chain of memory round trips per occurrence: 43 us for the 24,576 occurrences of an
+// 8,192-triplet global batch, whose hub item has a run of ~30.)  Returns true on the head wave.
+template <int CPL, int NV, class F>
+__device__ __forceinline__ bool sorted_run_sum(float (&acc)[NV][CPL], float* __restrict__ s_val,
+                                               uint32_t* __restrict__ s_row, int* __restrict__ s_edge,
+                                               const uint64_t* __restrict__ skey, int n_occ, int s,
+                                               uint64_t key, uint64_t kprev, uint64_t knext, int wave,
+                                               int lane, F&& occurrence) {
+  constexpr int W = CPL * NR_WAVE;
+  const bool active = s < n_occ;
+  const uint32_t row = active ? (uint32_t)(key >> 32) : ~0u;
+  const bool follows = active && s > 0 && (uint32_t)(kprev >> 32) == row;   // not the first of its run
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) s_val[(v * kOccWaves + wave) * W + lane + c * NR_WAVE] = acc[v][c];
+  if (lane == 0) {
+    s_row[wave] = row;
+    if (wave == 0) s_edge[0] = follows;                                        // the workgroup starts mid-run
+    if (wave == kOccWaves - 1) s_edge[1] = active && s + 1 < n_occ && (uint32_t)(knext >> 32) == row;
+  }
+  __syncthreads();
+  const bool head = active && !follows;
+  if (head) {
+    for (int t = 1; wave + t < kOccWaves && s_row[wave + t] == row; ++t)
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[v][c] += s_val[(v * kOccWaves + wave + t) * W + lane + c * NR_WAVE];
+  }
+  const uint32_t lastrow = s_row[kOccWaves - 1];
+  // workgroup-uniform: the last run goes on AND began here
+  const bool overflow = s_edge[1] && !(s_edge[0] && s_row[0] == lastrow);
+  if (overflow) {
+    const bool mine = head && row == lastrow;
+    for (int base = (blockIdx.x + 1) * kOccWaves;; base += kOccWaves) {
+      __syncthreads();                             // LDS of the previous round has been consumed
+      const int idx = base + wave;
+      uint64_t k2 = ~0ull;
+      if (idx < n_occ) k2 = plan_key(skey, idx);
+      const bool m = (uint32_t)(k2 >> 32) == lastrow;
+      if (m) {
+        float more[NV][CPL];
+        occurrence((uint32_t)k2, more);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) s_val[(v * kOccWaves + wave) * W + lane + c * NR_WAVE] = more[v][c];
+      }
+      if (lane == 0) s_row[wave] = m ? lastrow : ~0u;
+      __syncthreads();
+      int cnt = 0;
+      while (cnt < kOccWaves && s_row[cnt] == lastrow) ++cnt;                  // sorted: the matches are a prefix
+      if (mine)
+        for (int t = 0; t < cnt; ++t)
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[v][c] += s_val[(v * kOccWaves + t) * W + lane + c * NR_WAVE];
+      if (cnt < kOccWaves) break;
+    }
+  }
+  return head;
+}
+
 template <int CPL, bool PAIR, bool LAZY = false>
 __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
     const float* __restrict__ P, const float* __restrict__ Q, int d, int n_users,
@@ -424,52 +495,39 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
     int batch, const uint64_t* __restrict__ skey, int n_occ, float reg, float scale, int loss_kind,
     float* __restrict__ GP, float* __restrict__ GQ, float* __restrict__ term_mf,
     float* __restrict__ term_l2, float* __restrict__ out2, unsigned* done, LazyTables lz) {
-  __shared__ float s_g[kOccWaves][CPL * NR_WAVE];
+  __shared__ float s_g[kOccWaves * CPL * NR_WAVE];
+  __shared__ uint32_t s_row[kOccWaves];
+  __shared__ int s_edge[2];
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int s = blockIdx.x * kOccWaves + wave;
-  const bool active = s < n_occ;
   uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
-  float acc[CPL];
-  if (active) {
+  float acc[1][CPL] = {};
+  if (s < n_occ) {
     key = plan_key(skey, s);
     // the neighbours in the sorted order decide "first occurrence of its row" and "another one
     // follows": requested now, with everything else, not as a dependent load after the barrier
     if (s > 0) kprev = plan_key(skey, s - 1);
     if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
     mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale, loss_kind,
-                                   (uint32_t)key, lane, acc, term_mf, term_l2, true, lz);
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) s_g[wave][lane + c * NR_WAVE] = acc[c];
+                                   (uint32_t)key, lane, acc[0], term_mf, term_l2, true, lz);
   }
-  __syncthreads();
-  if (active) {
+  const bool head = sorted_run_sum<CPL, 1>(
+      acc, s_g, s_row, s_edge, skey, n_occ, s, key, kprev, knext, wave, lane,
+      [&](uint32_t p, float (&out)[1][CPL]) {
+        mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale, loss_kind,
+                                       p, lane, out[0], term_mf, term_l2, false, lz);
+      });
+  if (head) {
     const uint32_t row = (uint32_t)(key >> 32);
-    const bool head = s == 0 || (uint32_t)(kprev >> 32) != row;
-    if (head) {
-      for (int t = 1; s + t < n_occ; ++t) {
-        const uint64_t k2 = t == 1 ? knext : plan_key(skey, s + t);
-        if ((uint32_t)(k2 >> 32) != row) break;
-        if (wave + t < kOccWaves) {
+    if constexpr (LAZY) {
+      if (lane == 0) lz.stamp[row] = lz.t;       // "in this step's batch": the optimiser launch reads it
+    }
+    float* dst = row < (uint32_t)n_users ? GP + (int64_t)row * d
+                                         : GQ + (int64_t)(row - (uint32_t)n_users) * d;
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) acc[c] += s_g[wave + t][lane + c * NR_WAVE];
-        } else {                                  // the run leaves this workgroup: recompute
-          float more[CPL];
-          mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale,
-                                         loss_kind, (uint32_t)k2, lane, more, term_mf, term_l2, false, lz);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) acc[c] += more[c];
-        }
-      }
-      if constexpr (LAZY) {
-        if (lane == 0) lz.stamp[row] = lz.t;       // "in this step's batch": the optimiser launch reads it
-      }
-      float* dst = row < (uint32_t)n_users ? GP + (int64_t)row * d
-                                           : GQ + (int64_t)(row - (uint32_t)n_users) * d;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int k = lane + c * NR_WAVE;
-        if (k < d) dst[k] = acc[c];
-      }
+    for (int c = 0; c < CPL; ++c) {
+      const int k = lane + c * NR_WAVE;
+      if (k < d) dst[k] = acc[0][c];
     }
   }
   finish_loss(term_mf, term_l2, batch, reg, out2, done);
@@ -527,57 +585,34 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
     const int32_t* __restrict__ neg, int batch, const uint64_t* __restrict__ skey, int n_occ,
     float reg, float* __restrict__ Gstar, float* __restrict__ Greg, float* __restrict__ term_mf,
     float* __restrict__ term_l2, float grad_div, float* __restrict__ out2, unsigned* done) {
-  __shared__ float s_h[kOccWaves][CPL * NR_WAVE];
-  __shared__ float s_r[kOccWaves][CPL * NR_WAVE];
+  __shared__ float s_hr[2 * kOccWaves * CPL * NR_WAVE];
+  __shared__ uint32_t s_row[kOccWaves];
+  __shared__ int s_edge[2];
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int s = blockIdx.x * kOccWaves + wave;
-  const bool active = s < n_occ;
   uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
-  float h[CPL], r[CPL];
-  if (active) {
+  float hr[2][CPL] = {};                          // [0]: dLoss/dE* row, [1]: regulariser row
+  if (s < n_occ) {
     key = plan_key(skey, s);
     if (s > 0) kprev = plan_key(skey, s - 1);      // neighbours in the sorted order: see mf_grad_sorted_kernel
     if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
     lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
-                             (uint32_t)key, lane, h, r, term_mf, term_l2, true);
+                             (uint32_t)key, lane, hr[0], hr[1], term_mf, term_l2, true);
+  }
+  const bool head = sorted_run_sum<CPL, 2>(
+      hr, s_hr, s_row, s_edge, skey, n_occ, s, key, kprev, knext, wave, lane,
+      [&](uint32_t p, float (&out)[2][CPL]) {
+        lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
+                                 p, lane, out[0], out[1], term_mf, term_l2, false);
+      });
+  if (head) {
+    const uint32_t row = (uint32_t)(key >> 32);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      s_h[wave][lane + c * NR_WAVE] = h[c];
-      s_r[wave][lane + c * NR_WAVE] = r[c];
-    }
-  }
-  __syncthreads();
-  if (active) {
-    const uint32_t row = (uint32_t)(key >> 32);
-    const bool head = s == 0 || (uint32_t)(kprev >> 32) != row;
-    if (head) {
-      for (int t = 1; s + t < n_occ; ++t) {
-        const uint64_t k2 = t == 1 ? knext : plan_key(skey, s + t);
-        if ((uint32_t)(k2 >> 32) != row) break;
-        if (wave + t < kOccWaves) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            h[c] += s_h[wave + t][lane + c * NR_WAVE];
-            r[c] += s_r[wave + t][lane + c * NR_WAVE];
-          }
-        } else {                                  // the run leaves this workgroup: recompute
-          float h2[CPL], r2[CPL];
-          lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg,
-                                   grad_div, (uint32_t)k2, lane, h2, r2, term_mf, term_l2, false);
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            h[c] += h2[c];
-            r[c] += r2[c];
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int k = lane + c * NR_WAVE;
-        if (k < d) {
-          Gstar[(int64_t)row * d + k] = h[c];
-          Greg[(int64_t)row * d + k] = r[c];
-        }
+      const int k = lane + c * NR_WAVE;
+      if (k < d) {
+        Gstar[(int64_t)row * d + k] = hr[0][c];
+        Greg[(int64_t)row * d + k] = hr[1][c];
       }
     }
   }

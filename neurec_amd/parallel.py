@@ -4,14 +4,19 @@ for the multi-process tests.
 How the hot path shards:
   * sampler    — every rank owns a contiguous slice of each epoch's triplet stream
                  (units are independent; no exchange).
-  * training   — tables replicated; the step's one exchange is either
-                 (a) "triplets" (default): every rank samples B triplets, the 12·B bytes of ids
-                     are all-gathered (prefetched one step ahead, so the collective hides behind
+  * training   — tables replicated; per step either
+                 (a) "replicated" (default): NO exchange — the sampler is a counter-based generator
+                     (seed, epoch, position), so every rank produces the same global epoch stream
+                     itself (47 us per 814 k-triplet epoch) and steps on the same world·B global
+                     batch, whose batch plans come from the sampler a whole epoch ahead;
+                 (b) "triplets": every rank samples B triplets of its own slice, the 12·B bytes of
+                     ids are all-gathered (prefetched one step ahead, so the collective hides behind
                      the previous step) and every rank runs the step on the world·B global batch —
-                     bit-identical tables on all ranks, no gradient traffic; or
-                 (b) "allreduce": each rank back-propagates its own batch and the dense dL/dE0
+                     bit-identical tables on all ranks, no gradient traffic (the plan of the
+                     global batch is then sorted inside the step); or
+                 (c) "allreduce": each rank back-propagates its own batch and the dense dL/dE0
                      ([N][d] fp32) is summed with one all-reduce before Adam.
-                 Both equal the reference run with batch_size = world * B.  The graph
+                 All equal the reference run with batch_size = world * B.  The graph
                  propagation itself is replicated (the whole gowalla-size problem is 0.03 % of
                  one GPU's HBM): its cost is per step, not per triplet, so more ranks amortise
                  it over more triplets — DESIGN.md states what that does and does not buy.
@@ -39,7 +44,12 @@ class Comm:
     def allreduce_sum_(self, t):
         """In-place SUM all-reduce (RCCL on GPU tensors, gloo on CPU tensors)."""
         if self.active:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if self.backend != "nccl" and t.is_cuda:      # gloo (tests: ranks sharing one GPU): host-staged
+                host = t.detach().cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
     def allgather_cat_start(self, parts):

@@ -65,7 +65,8 @@ def _ordered_rows(n_rows, d, idx_lists, contrib_lists):
     return out
 
 
-@pytest.mark.parametrize("d,U,I,B", [(64, 40, 30, 1024), (16, 300, 200, 512), (128, 5, 7, 333), (48, 64, 64, 64)])
+@pytest.mark.parametrize("d,U,I,B", [(64, 40, 30, 1024), (16, 300, 200, 512), (128, 5, 7, 333), (48, 64, 64, 64),
+                                     (64, 3, 2, 1000), (64, 1, 1, 16), (64, 1, 1, 17), (32, 2, 1, 48)])
 def test_mf_head_row_sums_are_the_ordered_sums_bit_for_bit(d, U, I, B):
     """Per-occurrence rows come from the kernel itself (a batch without duplicates is their
     ground truth: each row then holds exactly one occurrence), the duplicate-heavy batch must
@@ -99,11 +100,14 @@ def test_mf_head_row_sums_are_the_ordered_sums_bit_for_bit(d, U, I, B):
         np.testing.assert_array_equal(l2b.cpu().numpy(), l2.cpu().numpy())   # same terms, same order
 
 
-def test_lightgcn_head_row_sums_are_the_ordered_sums_bit_for_bit():
+@pytest.mark.parametrize("U,I,B", [(23, 31, 777), (2, 3, 1500), (1, 1, 16), (1, 2, 33), (400, 300, 4096)])
+def test_lightgcn_head_row_sums_are_the_ordered_sums_bit_for_bit(U, I, B):
+    """Runs of one row longer than a workgroup's 16 occurrences (hub items of a large global batch)
+    are continued by the whole workgroup: same ordered sums."""
     import torch
     from neurec_amd import engine as E
     rng = np.random.RandomState(9)
-    U, I, d, B, L = 23, 31, 64, 777, 3
+    d, L = 64, 3
     N = U + I
     Es = rng.randn(N, d).astype(np.float32)
     E0 = (rng.randn(N, d) * 0.1).astype(np.float32)
