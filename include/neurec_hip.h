@@ -35,7 +35,7 @@ extern "C" {
 #define NRHIP_ERR_HIP 3
 #define NRHIP_ERR_WORKSPACE 4
 
-#define NRHIP_ABI_VERSION 1
+#define NRHIP_ABI_VERSION 3
 #define NRHIP_MAX_TOPK 128 /* largest top_k the selection kernels accept */
 
 /* ---- library ------------------------------------------------------------ */
@@ -449,6 +449,10 @@ typedef struct nrhip_mf_buffers {
   /* lazy sparse Adam (nrhip_adam_sparse_tf_lazy): last != NULL selects it; needs P|Q, mP|mQ, vP|vQ,
    * GP|GQ each one [n_users + n_items][d] allocation */
   int32_t* last; int32_t* stamp; const float* alpha_tab; int alpha_len; int lazy_period;
+  /* one-launch step (nrhip_bpr_mf_step_fused): tw != NULL selects it; P / mP / vP then each hold TWO
+   * copies of the [n_users + n_items][d] array (copy 1 at + rows * d), tw = int32 [rows][2] ({0, -1} at start),
+   * inb = int32 [rows] (zero at start); last / stamp / GP / GQ are not used */
+  int32_t* tw; int32_t* inb;
 } nrhip_mf_buffers;
 int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out);
 int nrhip_mf_ctx_destroy(void* ctx);
@@ -459,6 +463,14 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
                   int batch, const uint64_t* d_plan, const uint64_t* d_next_plan, int next_batch,
                   int step_index, float alpha, float beta1, float beta2, float eps, float* d_loss2,
                   void* stream);
+/* The batch loop of MF.train_model (model/general_recommender/MF.py:95-103) over the consecutive batches of
+ * one epoch stream (n_total triplets, `batch` per step, the last one short): step k runs on triplets
+ * [k*batch, ...), plan d_plans + 3*k*batch (layout of nrhip_bpr_plan(n_total, batch); NULL: sorted per step),
+ * step index first_step_index + k, step size h_alpha[k] (HOST array), loss pair d_loss2[2k..2k+1]. */
+int nrhip_mf_steps(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                   int64_t n_total, int batch, const uint64_t* d_plans, int first_step_index,
+                   const float* h_alpha, float beta1, float beta2, float eps, float* d_loss2,
+                   void* stream);
 /* lazy mode: bring every row of both tables to step `steps_done` (no-op otherwise) */
 int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float eps, void* stream);
 
@@ -538,6 +550,21 @@ int nrhip_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* stream);
 int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
 
+/* BPR-MF step in ONE launch: the gradient of MF.py:57-72 + TF-1.12 sparse Adam (util/learner.py:9-10) by
+ * exact lazy replay, bit-identical to nrhip_bpr_mf_grad + nrhip_adam_sparse_tf.  Two copies of every table
+ * and a stamp per copy (d_tw int32 [rows][2], {0, -1} before step 1): readers of step t take the newer copy
+ * older than t, the head of a row writes the other one.  d_inb int32 [rows] (zero before step 1) marks the
+ * rows of the coming batch.  d_plan is required; batch_marked != 0 promises that the previous call (step
+ * t - 1) received exactly this plan as its d_next_plan. */
+int nrhip_bpr_mf_step_fused(float* d_W, float* d_M, float* d_V, int32_t* d_tw, int32_t* d_inb,
+                            const float* d_alpha_tab, int t, float beta1, float beta2, float eps, int d,
+                            int n_users, int n_items, const int32_t* d_users, const int32_t* d_pos,
+                            const int32_t* d_neg, int batch, float reg, float* d_work, float* d_loss2,
+                            const uint64_t* d_plan, int batch_marked, const uint64_t* d_next_plan,
+                            int n_next_occ, int period, void* stream);
+/* every row brought to step t, in copy 0 (copy 1 invalidated) */
+int nrhip_bpr_mf_fused_flush(float* d_W, float* d_M, float* d_V, int32_t* d_tw, const float* d_alpha_tab,
+                             int t, float beta1, float beta2, float eps, int d, int64_t n_rows, void* stream);
 /* ---- the other losses and optimisers of util/learner.py (MF.py:62-76 with is_pairwise /
  * loss_function / learner other than bpr + adam) ----------------------------------------------
  * Same contract as nrhip_bpr_mf_grad (dense d_GP/d_GQ zero outside the batch rows, d_work scratch of

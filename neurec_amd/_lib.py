@@ -54,7 +54,7 @@ class MFBuffers(C.Structure):
         ("n_users", C.c_int), ("n_items", C.c_int), ("d", C.c_int), ("max_batch", C.c_int),
         ("reg", C.c_float), ("last", C.c_void_p), ("stamp", C.c_void_p), ("alpha_tab", C.c_void_p),
         ("alpha_len", C.c_int),
-        ("lazy_period", C.c_int)]
+        ("lazy_period", C.c_int), ("tw", C.c_void_p), ("inb", C.c_void_p)]
 
 
 # name -> argtypes; every function returns int status except where noted.
@@ -103,6 +103,10 @@ SIGNATURES = {
     "nrhip_mf_ctx_destroy": [p],
     "nrhip_mf_step": [p, p, p, p, i32, p, p, i32, i32, f32, f32, f32, f32, p, p],
     "nrhip_mf_flush": [p, i32, f32, f32, f32, p],
+    "nrhip_mf_steps": [p, p, p, p, i64, i32, p, i32, p, f32, f32, f32, p, p],
+    "nrhip_bpr_mf_step_fused": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, i32, p, p, p, i32, f32, p, p, p,
+                                i32, p, i32, i32, p],
+    "nrhip_bpr_mf_fused_flush": [p, p, p, p, p, i32, f32, f32, f32, i32, i64, p],
     "nrhip_adam_sparse_tf_lazy": [p, p, p, p, p, p, i64, i32, p, i32, p, i32, p, i32, i32, f32, f32, f32, p],
     "nrhip_bpr_mf_grad_lazy": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, p, p, p, i32, f32, p, p, p,
                                p, p],
@@ -166,7 +170,7 @@ lib.nrhip_last_error.restype = C.c_char_p
 
 EXPORTED = sorted(list(SIGNATURES) + ["nrhip_abi_version", "nrhip_last_error"])
 
-ABI_VERSION = 2      # 2: deterministic row-gradient sums (batch plans) in the BPR heads / steps
+ABI_VERSION = 3      # 2: deterministic row-gradient sums (batch plans); 3: one-launch BPR-MF step (mf_buffers.tw)
 if lib.nrhip_abi_version() != ABI_VERSION:  # pragma: no cover
     raise ImportError("libneurec_hip.so ABI version %d, expected %d"
                       % (lib.nrhip_abi_version(), ABI_VERSION))

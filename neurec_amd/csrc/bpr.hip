@@ -89,8 +89,10 @@ __device__ __forceinline__ void load_row_lazy(const float* __restrict__ base, in
 __device__ unsigned g_done_pool[64];
 
 __device__ __forceinline__ void finish_loss(const float* term_mf, const float* term_l2, int batch,
-                                            float reg, float* __restrict__ out2, unsigned* done) {
+                                            float reg, float* __restrict__ out2, unsigned* done,
+                                            unsigned arrivers = 0) {   // 0: every workgroup of the grid
   if (out2 == nullptr) return;
+  if (arrivers == 0) arrivers = gridDim.x;
   __shared__ bool s_last;
   __shared__ double s_a[256], s_b[256];
   // The terms were stored with agent scope (write-through); waiting for their completion is all
@@ -100,7 +102,7 @@ __device__ __forceinline__ void finish_loss(const float* term_mf, const float* t
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrivers - 1;
   __syncthreads();
   if (!s_last) return;
   // the first 256 threads reduce (callers launch 256- or 1024-thread blocks): fixed partition,
@@ -533,6 +535,300 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
   finish_loss(term_mf, term_l2, batch, reg, out2, done);
 }
 
+// ---- BPR-MF step in ONE launch: gradient + exact lazy TF sparse Adam ---------------------------
+// The two-launch form (mf_grad_sorted_kernel<LAZY> then adam_lazy_kernel) needs the launch boundary
+// because the optimiser overwrites rows the gradient waves of the same step still read.  Here every
+// table (w, m, v) exists TWICE, with a stamp per copy (tw[row][copy] = the step that copy is current
+// as of): a reader of step t takes the copy with the larger stamp < t, the ONE writer of a row in
+// step t (the head of the row's run, with the summed gradient) writes the other copy and stamps it
+// t.  A reader that sees the fresh stamp ignores it (== t), one that sees the old stamp picks the
+// same copy anyway, and nobody writes the copy being read: no ordering is needed inside the launch,
+// the launch boundary orders the steps.  The gradient rows never leave LDS / registers.
+//   Rows outside the batch are maintained as in adam_lazy_kernel — the next batch's rows and the
+// scheduled rows r = t (mod period) replay their missed zero-gradient steps — by extra waves of the
+// same launch.  They must leave the rows of THIS batch to its heads: inb[row] = the latest batch the
+// row is known to be in, written one step ahead by the wave that prepares the row for the next batch
+// (or by a small pre-launch when the previous call was not given this batch's plan).  A scheduled wave
+// skips inb[row] >= t (in this batch: the head does it; in the next: the preparing wave does it), and
+// maintenance writes the other copy too, so that two roles meeting on one row store identical bytes.
+struct FusedTables {
+  float* W; float* M; float* V;        // [2][rows][d]
+  int32_t* tw;                         // [rows][2]
+  int32_t* inb;                        // [rows]
+  const float* alpha_tab;
+  int64_t rows;
+  int t;
+  float b1, b2, omb1, omb2, eps;
+};
+
+// the copy a reader of step t uses, and the first step it has not seen
+__device__ __forceinline__ int fused_pick(int2 s, int t, int& from) {
+  const int e0 = s.x < t ? s.x : -2, e1 = s.y < t ? s.y : -2;
+  const int c = e1 > e0 ? 1 : 0;
+  from = (c ? e1 : e0) + 1;
+  return c;
+}
+
+template <int CPL>
+__device__ __forceinline__ void fused_replay(float (&w)[CPL], float (&mm)[CPL], float (&vv)[CPL], int from,
+                                             int upto, float a_mine, int a_lo, int lane,
+                                             const FusedTables& ft) {
+  if (from > upto) return;
+  bool quiet = true;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
+  if (__all(quiet)) return;                       // 0·b1 = 0 and var - 0 = var: nothing moves
+  if (from >= a_lo && from >= 1) {                // the usual case: the step sizes are in the lanes already
+    for (int s2 = from; s2 <= upto; ++s2) {
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_mine), s2 - a_lo));
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) nr::adam_sparse_tf(0.f, w[c], mm[c], vv[c], a, ft.b1, ft.b2, ft.omb1, ft.omb2, ft.eps);
+    }
+  } else {
+    nr_lazy_replay<CPL>(w, mm, vv, from, upto, ft.alpha_tab, lane, ft.b1, ft.b2, ft.omb1, ft.omb2, ft.eps);
+  }
+}
+
+// Row `row` as of step t - 1.  Both copies are requested together with the stamps (one round trip
+// instead of two); WITH_MV: the moments as well (the head applies the step to this row).
+template <int CPL, bool WITH_MV>
+__device__ __forceinline__ int fused_load_row(int64_t row, int d, int lane, const FusedTables& ft,
+                                              float a_mine, int a_lo, float (&w)[CPL], float (&mm)[CPL],
+                                              float (&vv)[CPL]) {
+  const int2 s = ((const int2*)ft.tw)[row];
+  const int64_t other = ft.rows * d;
+  float w0[CPL], w1[CPL], m0[CPL], m1[CPL], v0[CPL], v1[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    const bool in = k < d;
+    w0[c] = in ? ft.W[row * d + k] : 0.f;
+    w1[c] = in ? ft.W[other + row * d + k] : 0.f;
+    if constexpr (WITH_MV) {
+      m0[c] = in ? ft.M[row * d + k] : 0.f;
+      m1[c] = in ? ft.M[other + row * d + k] : 0.f;
+      v0[c] = in ? ft.V[row * d + k] : 0.f;
+      v1[c] = in ? ft.V[other + row * d + k] : 0.f;
+    }
+  }
+  int from;
+  const int cp = __builtin_amdgcn_readfirstlane(fused_pick(s, ft.t, from));
+  from = __builtin_amdgcn_readfirstlane(from);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    w[c] = cp ? w1[c] : w0[c];
+    if constexpr (WITH_MV) {
+      mm[c] = cp ? m1[c] : m0[c];
+      vv[c] = cp ? v1[c] : v0[c];
+    }
+  }
+  if (from < ft.t) {                              // behind (the previous launch was not told this row was coming)
+    if constexpr (!WITH_MV) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int k = lane + c * NR_WAVE;
+        mm[c] = k < d ? ft.M[cp * other + row * d + k] : 0.f;
+        vv[c] = k < d ? ft.V[cp * other + row * d + k] : 0.f;
+      }
+    }
+    fused_replay<CPL>(w, mm, vv, from, ft.t - 1, a_mine, a_lo, lane, ft);
+  }
+  return cp;
+}
+
+// one occurrence's gradient row (MF.py:57-72, BPR loss); HEAD: the class row comes with its moments
+template <int CPL, bool HEAD>
+__device__ __forceinline__ int fused_occurrence(int d, int n_users, const int32_t* __restrict__ users,
+                                                const int32_t* __restrict__ pos,
+                                                const int32_t* __restrict__ neg, int batch, float reg,
+                                                uint32_t p, int lane, const FusedTables& ft, float a_mine,
+                                                int a_lo, float (&out)[CPL], float (&w)[CPL], float (&mm)[CPL],
+                                                float (&vv)[CPL], float* __restrict__ term_mf,
+                                                float* __restrict__ term_l2, bool write_terms) {
+  const int cls = (int)(p / (uint32_t)batch), b = (int)(p - (uint32_t)cls * (uint32_t)batch);
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
+  const int64_t j = (int64_t)n_users + __builtin_amdgcn_readfirstlane(neg[b]);
+  float pu[CPL], qi[CPL], qj[CPL], tm[CPL], tv[CPL];
+  int cp = 0;
+  if (HEAD && cls == 0) cp = fused_load_row<CPL, true>(u, d, lane, ft, a_mine, a_lo, pu, mm, vv);
+  else fused_load_row<CPL, false>(u, d, lane, ft, a_mine, a_lo, pu, tm, tv);
+  if (HEAD && cls == 1) cp = fused_load_row<CPL, true>(i, d, lane, ft, a_mine, a_lo, qi, mm, vv);
+  else fused_load_row<CPL, false>(i, d, lane, ft, a_mine, a_lo, qi, tm, tv);
+  if (HEAD && cls == 2) cp = fused_load_row<CPL, true>(j, d, lane, ft, a_mine, a_lo, qj, mm, vv);
+  else fused_load_row<CPL, false>(j, d, lane, ft, a_mine, a_lo, qj, tm, tv);
+  const float x = dot_rows<CPL>(pu, qi) - dot_rows<CPL>(pu, qj);      // MF.py:59,67
+  const float g = nr::pairwise_dloss((int)nr::NR_PAIR_BPR, x);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    out[c] = cls == 0 ? g * (qi[c] - qj[c]) + reg * pu[c]
+           : cls == 1 ? g * pu[c] + reg * qi[c]
+                      : -g * pu[c] + reg * qj[c];
+    if (HEAD) w[c] = cls == 0 ? pu[c] : cls == 1 ? qi[c] : qj[c];
+  }
+  if (write_terms && cls == 0) {
+    const float l2 = 0.5f * (dot_rows<CPL>(pu, pu) + dot_rows<CPL>(qj, qj) + dot_rows<CPL>(qi, qi));
+    if (lane == 0) {
+      __hip_atomic_store(&term_mf[b], nr::pairwise_loss((int)nr::NR_PAIR_BPR, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return cp;
+}
+
+template <int CPL>
+__device__ __forceinline__ void fused_store_row(int64_t row, int copy, int d, int lane, const FusedTables& ft,
+                                                const float (&w)[CPL], const float (&mm)[CPL],
+                                                const float (&vv)[CPL], int stamp) {
+  const int64_t base = copy * ft.rows * d + row * d;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    if (k < d) {
+      ft.W[base + k] = w[c];
+      ft.M[base + k] = mm[c];
+      ft.V[base + k] = vv[c];
+    }
+  }
+  if (lane == 0) ft.tw[2 * row + copy] = stamp;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
+    FusedTables ft, int d, int n_users, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int batch, const uint64_t* __restrict__ skey, int n_occ,
+    const uint64_t* __restrict__ skey_next, int n_next, int period, int occ_blocks,
+    float reg, float* __restrict__ term_mf, float* __restrict__ term_l2, float* __restrict__ out2,
+    unsigned* done) {
+  __shared__ float s_g[kOccWaves * CPL * NR_WAVE];
+  __shared__ uint32_t s_row[kOccWaves];
+  __shared__ int s_edge[2];
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int a_lo = ft.t - (NR_WAVE - 1);
+  const float a_mine = ft.alpha_tab[max(a_lo + lane, 0)]; // step sizes of the last 64 steps, lane j: step t - 63 + j
+  if ((int)blockIdx.x >= occ_blocks) {
+    // maintenance, one independent wave per row (no workgroup barrier): heads of the next batch's plan,
+    // then the scheduled rows.  Stamps, batch marks and BOTH copies of the row are requested at once.
+    const int64_t mw = (int64_t)(blockIdx.x - occ_blocks) * kOccWaves + wave;
+    int64_t row64;
+    const bool preparing = mw < n_next;
+    if (preparing) {
+      row64 = (int64_t)(skey_next[mw] >> 32);
+      if (mw > 0 && (int64_t)(skey_next[mw - 1] >> 32) == row64) return;       // a later occurrence of the row
+    } else {
+      row64 = (int64_t)(ft.t % period) + (mw - n_next) * period;
+      if (row64 >= ft.rows) return;
+    }
+    const int64_t row = __builtin_amdgcn_readfirstlane((int)row64);
+    const int2 st = ((const int2*)ft.tw)[row];
+    const int mark = ft.inb[row];
+    const int64_t other = ft.rows * d;
+    float w0[CPL], w1[CPL], m0[CPL], m1[CPL], v0[CPL], v1[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int k = lane + c * NR_WAVE;
+      const bool in = k < d;
+      w0[c] = in ? ft.W[row * d + k] : 0.f;
+      w1[c] = in ? ft.W[other + row * d + k] : 0.f;
+      m0[c] = in ? ft.M[row * d + k] : 0.f;
+      m1[c] = in ? ft.M[other + row * d + k] : 0.f;
+      v0[c] = in ? ft.V[row * d + k] : 0.f;
+      v1[c] = in ? ft.V[other + row * d + k] : 0.f;
+    }
+    if (preparing && lane == 0) ft.inb[row] = ft.t + 1;              // the next step's scheduled waves leave it alone
+    if (mark >= ft.t || st.x == ft.t || st.y == ft.t) return;         // this batch's head / another role has it
+    int from;
+    const int cp = __builtin_amdgcn_readfirstlane(fused_pick(st, ft.t, from));
+    from = __builtin_amdgcn_readfirstlane(from);
+    float w[CPL], mm[CPL], vv[CPL];
+    bool quiet = true;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      w[c] = cp ? w1[c] : w0[c];
+      mm[c] = cp ? m1[c] : m0[c];
+      vv[c] = cp ? v1[c] : v0[c];
+      quiet = quiet && mm[c] == 0.f && vv[c] == 0.f;
+    }
+    if (__all(quiet)) {
+      if (lane == 0) ft.tw[2 * row + cp] = ft.t;         // nothing to move: the copy in place is current
+    } else {
+      fused_replay<CPL>(w, mm, vv, from, ft.t, a_mine, a_lo, lane, ft);
+      fused_store_row<CPL>(row, 1 - cp, d, lane, ft, w, mm, vv, ft.t);
+    }
+    return;
+  }
+  const int s = blockIdx.x * kOccWaves + wave;
+  uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
+  float acc[1][CPL] = {}, w[CPL] = {}, mm[CPL] = {}, vv[CPL] = {};
+  int cp = 0;
+  if (s < n_occ) {
+    key = plan_key(skey, s);
+    if (s > 0) kprev = plan_key(skey, s - 1);
+    if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
+    const bool first = s == 0 || (uint32_t)(kprev >> 32) != (uint32_t)(key >> 32);   // wave-uniform
+    if (first)
+      cp = fused_occurrence<CPL, true>(d, n_users, users, pos, neg, batch, reg, (uint32_t)key, lane, ft, a_mine,
+                                       a_lo, acc[0], w, mm, vv, term_mf, term_l2, true);
+    else
+      fused_occurrence<CPL, false>(d, n_users, users, pos, neg, batch, reg, (uint32_t)key, lane, ft, a_mine,
+                                   a_lo, acc[0], w, mm, vv, term_mf, term_l2, true);
+  }
+  const bool head = sorted_run_sum<CPL, 1>(
+      acc, s_g, s_row, s_edge, skey, n_occ, s, key, kprev, knext, wave, lane,
+      [&](uint32_t p, float (&out)[1][CPL]) {
+        float w2[CPL], m2[CPL], v2[CPL];
+        fused_occurrence<CPL, false>(d, n_users, users, pos, neg, batch, reg, p, lane, ft, a_mine, a_lo, out[0],
+                                     w2, m2, v2, term_mf, term_l2, false);
+      });
+  if (head) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_mine), NR_WAVE - 1));   // alpha_tab[t]
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      nr::adam_sparse_tf(acc[0][c], w[c], mm[c], vv[c], a, ft.b1, ft.b2, ft.omb1, ft.omb2, ft.eps);
+    fused_store_row<CPL>((int64_t)(uint32_t)(key >> 32), 1 - cp, d, lane, ft, w, mm, vv, ft.t);
+  }
+  finish_loss(term_mf, term_l2, batch, reg, out2, done, (unsigned)occ_blocks);   // the occurrence workgroups only
+}
+
+// rows of a batch whose plan the previous call did not see: marked by a launch of their own
+__global__ __launch_bounds__(256) void mf_fused_mark_kernel(const uint64_t* __restrict__ skey, int n_occ,
+                                                            int32_t* __restrict__ inb, int t) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_occ) return;
+  const uint32_t row = (uint32_t)(skey[i] >> 32);
+  if (i == 0 || (uint32_t)(skey[i - 1] >> 32) != row) inb[row] = t;
+}
+
+// every row brought to step t in copy 0 (what a sweep-based run holds after t steps)
+template <int CPL>
+__global__ __launch_bounds__(256) void mf_fused_flush_kernel(FusedTables ft, int d) {
+  const int lane = nr_lane();
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= ft.rows) return;
+  const int a_lo = ft.t - (NR_WAVE - 1);
+  const float a_mine = ft.alpha_tab[max(a_lo + lane, 0)];
+  const int2 st = ((const int2*)ft.tw)[row];
+  int from;
+  const int cp = __builtin_amdgcn_readfirstlane(fused_pick(st, ft.t + 1, from));
+  from = __builtin_amdgcn_readfirstlane(from);
+  if (cp == 0 && from > ft.t) {
+    if (lane == 0) ft.tw[2 * row + 1] = -1;
+    return;
+  }
+  float w[CPL], mm[CPL], vv[CPL];
+  const int64_t base = cp * ft.rows * d + row * d;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int k = lane + c * NR_WAVE;
+    w[c] = k < d ? ft.W[base + k] : 0.f;
+    mm[c] = k < d ? ft.M[base + k] : 0.f;
+    vv[c] = k < d ? ft.V[base + k] : 0.f;
+  }
+  fused_replay<CPL>(w, mm, vv, from, ft.t, a_mine, a_lo, lane, ft);
+  fused_store_row<CPL>(row, 0, d, lane, ft, w, mm, vv, ft.t);
+  if (lane == 0) ft.tw[2 * row + 1] = -1;
+}
+
 // ---- LightGCN head -----------------------------------------------------------------------------
 template <int CPL>
 __device__ __forceinline__ void lightgcn_occurrence(
@@ -901,6 +1197,68 @@ int nrhip_bpr_mf_grad_lazy(const float* d_table, const float* d_m, const float* 
     hipLaunchKernelGGL((mf_grad_sorted_kernel<4, true, true>), grid, block, 0, st, d_P, d_Q, d, n_users,
                        d_users, d_pos, (const void*)d_neg, batch, d_plan, n_occ, reg, 1.0f,
                        (int)nr::NR_PAIR_BPR, d_GP, d_GQ, t_mf, t_l2, d_loss2, done, lz);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* BPR-MF step in one launch (mf_fused_step_kernel): gradient (MF.py:57-72) + TF-1.12 sparse Adam by
+ * exact lazy replay (util/learner.py:9-10).  d_W / d_M / d_V: TWO copies of the [n_rows = n_users +
+ * n_items][d] table / moments, copy 1 at + n_rows * d; d_tw: int32 [n_rows][2], the step each copy is
+ * current as of ({0, -1} before the first step); d_inb: int32 [n_rows], zero before the first step.
+ * d_plan: the batch's sorted occurrences (required); d_next_plan / n_next_occ: the following batch's (or
+ * NULL / 0); batch_marked != 0: the previous call (step t - 1) was given THIS batch's plan as its
+ * d_next_plan, unchanged since — its rows are marked already; 0: a small launch marks them first.
+ * d_alpha_tab[s] = lr_s (>= t + 1 entries). */
+int nrhip_bpr_mf_step_fused(float* d_W, float* d_M, float* d_V, int32_t* d_tw, int32_t* d_inb,
+                            const float* d_alpha_tab, int t, float beta1, float beta2, float eps, int d,
+                            int n_users, int n_items, const int32_t* d_users, const int32_t* d_pos,
+                            const int32_t* d_neg, int batch, float reg, float* d_work, float* d_loss2,
+                            const uint64_t* d_plan, int batch_marked, const uint64_t* d_next_plan,
+                            int n_next_occ, int period, void* stream) {
+  NR_REQUIRE(d_W && d_M && d_V && d_tw && d_inb && d_alpha_tab && d_users && d_pos && d_neg && d_work &&
+                 d_loss2 && (batch == 0 || d_plan), NR_ERR_ARG, "bpr_mf_step_fused: null pointer argument");
+  NR_REQUIRE(d >= 1 && d <= 256 && batch >= 0 && n_users >= 0 && n_items >= 0 && t >= 1 && period >= 1 &&
+                 n_next_occ >= 0 && (n_next_occ == 0 || d_next_plan), NR_ERR_ARG, "bpr_mf_step_fused: bad sizes");
+  const int64_t rows = (int64_t)n_users + n_items;
+  hipStream_t st = (hipStream_t)stream;
+  if (batch == 0) NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+  unsigned* done = next_done_counter();
+  NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
+  const FusedTables ft{d_W, d_M, d_V, d_tw, d_inb, d_alpha_tab, rows, t, beta1, beta2, 1.0f - beta1,
+                       1.0f - beta2, eps};
+  const int n_occ = 3 * batch;
+  if (n_occ > 0 && !batch_marked) {
+    hipLaunchKernelGGL(mf_fused_mark_kernel, dim3((n_occ + 255) / 256), dim3(256), 0, st, d_plan, n_occ, d_inb, t);
+    NR_LAUNCH_CHECK();
+  }
+  const int occ_blocks = (n_occ + kOccWaves - 1) / kOccWaves;
+  const int64_t maint = (int64_t)n_next_occ + (rows + period - 1) / period;
+  dim3 grid((unsigned)(occ_blocks + (maint + kOccWaves - 1) / kOccWaves)), block(kOccWaves * NR_WAVE);
+  if (grid.x == 0) return NR_OK;
+  float* loss_out = batch ? d_loss2 : nullptr;          // no batch: nothing to reduce
+#define NR_FUSED(CPL)                                                                                   \
+  hipLaunchKernelGGL(mf_fused_step_kernel<CPL>, grid, block, 0, st, ft, d, n_users, d_users, d_pos, d_neg,  \
+                     batch, d_plan, n_occ, d_next_plan, n_next_occ, period, occ_blocks, reg, d_work,        \
+                     d_work + batch, loss_out, done)
+  if (d <= 64) NR_FUSED(1); else if (d <= 128) NR_FUSED(2); else NR_FUSED(4);
+#undef NR_FUSED
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* every row of the fused step's tables brought to step t, in copy 0 */
+int nrhip_bpr_mf_fused_flush(float* d_W, float* d_M, float* d_V, int32_t* d_tw, const float* d_alpha_tab,
+                             int t, float beta1, float beta2, float eps, int d, int64_t n_rows, void* stream) {
+  NR_REQUIRE(d_W && d_M && d_V && d_tw && d_alpha_tab && d >= 1 && d <= 256 && n_rows >= 0 && t >= 0, NR_ERR_ARG,
+             "bpr_mf_fused_flush: bad arguments");
+  if (n_rows == 0) return NR_OK;
+  const FusedTables ft{d_W, d_M, d_V, d_tw, nullptr, d_alpha_tab, n_rows, t, beta1, beta2, 1.0f - beta1,
+                       1.0f - beta2, eps};
+  dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d <= 64) hipLaunchKernelGGL(mf_fused_flush_kernel<1>, grid, block, 0, st, ft, d);
+  else if (d <= 128) hipLaunchKernelGGL(mf_fused_flush_kernel<2>, grid, block, 0, st, ft, d);
+  else hipLaunchKernelGGL(mf_fused_flush_kernel<4>, grid, block, 0, st, ft, d);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

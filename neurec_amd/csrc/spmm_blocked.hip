@@ -938,14 +938,31 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
   if (by_batch) {
     for (int i = tid; i < bitmap_words; i += 16 * NR_WAVE) s_bits[i] = 0u;
     __syncthreads();
-    for (int i = tid; i < 3 * bl.batch; i += 16 * NR_WAVE) {
+    // every workgroup reads the whole batch (an 8,192-triplet global batch: 24 ids per thread): the
+    // ids of a list are requested eight at a time, not one dependent round trip per id
+    auto mark = [&](const int32_t* __restrict__ ids, int offset) {
+      for (int i0 = tid; i0 < bl.batch; i0 += 8 * 16 * NR_WAVE) {
+        int r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = i0 + j * 16 * NR_WAVE;
+          r[j] = i < bl.batch ? ids[i] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (r[j] >= 0) atomicOr(&s_bits[(offset + r[j]) >> 5], 1u << ((offset + r[j]) & 31));
+      }
+    };
+    mark(bl.users, 0);
+    mark(bl.pos, bl.n_users);
+    mark(bl.neg, bl.n_users);
+    // publishing is shared out: a contiguous piece of the 3 * batch list positions per workgroup
+    const int total = 3 * bl.batch, per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int i = wg * per + tid; i < min(total, (wg + 1) * per); i += 16 * NR_WAVE) {
       const int which = i / bl.batch, b = i - which * bl.batch;
       const int row = which == 0 ? bl.users[b] : bl.n_users + (which == 1 ? bl.pos[b] : bl.neg[b]);
-      atomicOr(&s_bits[row >> 5], 1u << (row & 31));
-      if (i % (int)gridDim.x == wg) {                              // publishing is shared out
-        bl.row_flag[row] = 1;
-        if (bl.rows_out) bl.rows_out[i] = row;
-      }
+      bl.row_flag[row] = 1;
+      if (bl.rows_out) bl.rows_out[i] = row;
     }
   }
   __syncthreads();

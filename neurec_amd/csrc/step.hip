@@ -7,6 +7,7 @@
 // No arithmetic lives here — only the order of the nrhip_* launches declared in
 // include/neurec_hip.h.
 #include "nr_common.h"
+#include <algorithm>
 #include "neurec_hip.h"
 #include <new>
 
@@ -17,6 +18,8 @@ struct LightGCNCtx {
 };
 struct MFCtx {
   nrhip_mf_buffers b;
+  const uint64_t* marked_plan = nullptr;   // one-launch step: the plan whose rows the last step marked ...
+  int marked_step = 0;                     // ... for this step index
 };
 
 }  // namespace
@@ -230,7 +233,7 @@ int nrhip_lightgcn_step_apply(void* ctx, float* d_grad, float alpha, float beta1
 int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out) {
   NR_REQUIRE(bufs && ctx_out, NR_ERR_ARG, "mf_ctx_create: null argument");
   const nrhip_mf_buffers& b = *bufs;
-  NR_REQUIRE(b.P && b.Q && b.mP && b.vP && b.mQ && b.vQ && b.GP && b.GQ && b.terms, NR_ERR_ARG,
+  NR_REQUIRE(b.P && b.Q && b.mP && b.vP && b.mQ && b.vQ && ((b.tw && b.inb) || (!b.tw && b.GP && b.GQ)) && b.terms, NR_ERR_ARG,
              "mf_ctx_create: a buffer pointer is null");
   NR_REQUIRE(b.n_users > 0 && b.n_items > 0 && b.d >= 1 && b.d <= 256 && b.max_batch > 0,
              NR_ERR_ARG, "mf_ctx_create: bad sizes");
@@ -256,7 +259,30 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
   NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG, "mf_step: batch %d outside 0..%d",
              batch, b.max_batch);
   const int64_t nu = (int64_t)b.n_users * b.d, ni = (int64_t)b.n_items * b.d;
-  const bool one_table = b.Q == b.P + nu && b.mQ == b.mP + nu && b.vQ == b.vP + nu && b.GQ == b.GP + nu;
+  const bool one_table = b.Q == b.P + nu && b.mQ == b.mP + nu && b.vQ == b.vP + nu &&
+                         (b.tw || b.GQ == b.GP + nu);        // the one-launch step keeps no gradient table
+  if (b.tw) {
+    // gradient + exact lazy Adam in one launch (bpr.hip: mf_fused_step_kernel)
+    NR_REQUIRE(one_table, NR_ERR_ARG, "mf_step: the one-launch step needs P|Q (and m, v) as one allocation");
+    NR_REQUIRE(step_index >= 1 && step_index < b.alpha_len, NR_ERR_ARG,
+               "mf_step: step %d outside the step-size table (1..%d)", step_index, b.alpha_len - 1);
+    const uint64_t* plan = d_plan;
+    if (!plan && batch > 0) {
+      uint64_t* own = (uint64_t*)(b.terms + 2 * (size_t)batch);
+      NR_TRY(nrhip_bpr_plan(d_users, d_pos, d_neg, batch, batch, b.n_users, own, stream));
+      plan = own;
+    }
+    // the rows of this batch are marked already when the previous step was handed this very plan as
+    // its next plan (the sampler's epoch buffer: one address per batch)
+    MFCtx* c = (MFCtx*)ctx;
+    const int marked = d_plan && c->marked_plan == d_plan && c->marked_step == step_index;
+    c->marked_plan = d_next_plan;
+    c->marked_step = step_index + 1;
+    return nrhip_bpr_mf_step_fused(b.P, b.mP, b.vP, b.tw, b.inb, b.alpha_tab, step_index, beta1, beta2, eps, b.d,
+                                   b.n_users, b.n_items, d_users, d_pos, d_neg, batch, b.reg, b.terms, d_loss2,
+                                   plan, marked, d_next_plan, d_next_plan ? 3 * next_batch : 0, b.lazy_period,
+                                   stream);
+  }
   if (b.last) {
     // exact lazy replay instead of the sweep: the head leaves the batch's plan (the caller's, or
     // the one it sorted into the work buffer) — the optimiser walks the same sorted occurrences
@@ -291,9 +317,39 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
   return NR_OK;
 }
 
+/* The batch loop of MF.train_model (MF.py:95-103) over consecutive batches of one epoch stream, in one
+ * call: batch k = triplets [k*batch, min((k+1)*batch, n_total)), its plan d_plans + 3*k*batch (the whole
+ * stream's plans as nrhip_bpr_plan(n_total, batch) lays them out; NULL: sorted per step), the next batch's
+ * plan handed along.  h_alpha[k] = lr_t of step first_step_index + k (HOST array); d_loss2 receives two
+ * floats per step.  A Python loop enqueues ~12 us per step — more than the one-launch step takes. */
+int nrhip_mf_steps(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                   int64_t n_total, int batch, const uint64_t* d_plans, int first_step_index,
+                   const float* h_alpha, float beta1, float beta2, float eps, float* d_loss2,
+                   void* stream) {
+  NR_REQUIRE(ctx && d_users && d_pos && d_neg && h_alpha && d_loss2, NR_ERR_ARG, "mf_steps: null argument");
+  NR_REQUIRE(n_total >= 0 && batch >= 1 && first_step_index >= 1, NR_ERR_ARG, "mf_steps: bad sizes");
+  const int64_t n_steps = (n_total + batch - 1) / batch;
+  for (int64_t k = 0; k < n_steps; ++k) {
+    const int64_t b0 = k * batch;
+    const int nb = (int)std::min<int64_t>(batch, n_total - b0);
+    const int64_t b1 = b0 + nb;
+    const int next = (int)std::min<int64_t>(batch, n_total - b1);
+    NR_TRY(nrhip_mf_step(ctx, d_users + b0, d_pos + b0, d_neg + b0, nb, d_plans ? d_plans + 3 * b0 : nullptr,
+                         (d_plans && next > 0) ? d_plans + 3 * b1 : nullptr, next, first_step_index + (int)k,
+                         h_alpha[k], beta1, beta2, eps, d_loss2 + 2 * k, stream));
+  }
+  return NR_OK;
+}
+
 int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float eps, void* stream) {
   NR_REQUIRE(ctx, NR_ERR_ARG, "mf_flush: null context");
   const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
+  if (b.tw) {
+    if (steps_done <= 0) return NR_OK;
+    NR_REQUIRE(steps_done < b.alpha_len, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
+    return nrhip_bpr_mf_fused_flush(b.P, b.mP, b.vP, b.tw, b.alpha_tab, steps_done, beta1, beta2, eps, b.d,
+                                    (int64_t)b.n_users + b.n_items, stream);
+  }
   if (!b.last || steps_done <= 0) return NR_OK;
   NR_REQUIRE(steps_done < b.alpha_len, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
   return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, nullptr, (int64_t)b.n_users + b.n_items,

@@ -88,6 +88,11 @@ class PairwiseSampler(Sampler):
                                                    plan_users=self._plan_users)
         return self._device_sampler
 
+    def epoch_stream(self):
+        """One epoch as whole-stream device tensors (users, pos, neg, batch plans or None): the
+        batches of __iter__, not cut up — for engines that run an epoch's batch loop natively."""
+        return self._device().epoch_stream()
+
     def __iter__(self):
         for batch in self._device().batches():
             if self.as_tensors:

@@ -701,14 +701,21 @@ class NativeStep:
     @staticmethod
     def for_mf(eng):
         b = _lib.MFBuffers()
-        for k in ("_P", "_Q", "mP", "vP", "mQ", "vQ", "GP", "GQ", "terms"):
+        for k in ("_P", "_Q", "terms"):
             setattr(b, k.lstrip("_"), getattr(eng, k).data_ptr())
+        for k in ("mP", "vP", "mQ", "vQ"):
+            setattr(b, k, eng._views[k].data_ptr())        # the raw views: the properties would flush
+        if not getattr(eng, "fused", False):
+            b.GP, b.GQ = eng.GP.data_ptr(), eng.GQ.data_ptr()
         b.n_users, b.n_items, b.d = eng._P.shape[0], eng._Q.shape[0], eng._P.shape[1]
         b.max_batch, b.reg = eng.max_batch, eng.reg
         if eng.lazy:
-            b.last, b.alpha_tab = eng._last.data_ptr(), eng._alpha_tab.data_ptr()
-            b.stamp = eng._stamp.data_ptr()
+            b.alpha_tab = eng._alpha_tab.data_ptr()
             b.alpha_len, b.lazy_period = eng._alpha_tab.numel(), eng.lazy_period
+            if eng.fused:
+                b.tw, b.inb = eng._tw.data_ptr(), eng._inb.data_ptr()
+            else:
+                b.last, b.stamp = eng._last.data_ptr(), eng._stamp.data_ptr()
         h = C.c_void_p(0)
         call("nrhip_mf_ctx_create", C.byref(b), C.byref(h))
         return NativeStep("mf", h, eng)
@@ -756,6 +763,18 @@ class NativeStep:
              users.numel(), self._plan(plan, 3 * users.numel()), self._plan(next_plan, 3 * n_next), n_next,
              st.t + 1, float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
              _ptr(loss2, torch.float32), _stream())
+
+    def mf_steps(self, users, pos, neg, batch, st, h_alpha, loss_steps, plans=None):
+        """the consecutive batches of an epoch stream in one native call (nrhip_mf_steps)"""
+        n = users.numel()
+        n_steps = (n + batch - 1) // batch
+        if h_alpha.dtype != np.float32 or h_alpha.size < n_steps or not h_alpha.flags["C_CONTIGUOUS"]:
+            raise TypeError("h_alpha: contiguous float32 host array of %d step sizes" % n_steps)
+        if loss_steps.numel() < 2 * n_steps:
+            raise ValueError("loss buffer holds %d floats, 2 per step = %d needed" % (loss_steps.numel(), 2 * n_steps))
+        call("nrhip_mf_steps", self.handle, self._idx(users), self._idx(pos), self._idx(neg), n, int(batch),
+             self._plan(plans, 3 * n), st.t + 1, h_alpha.ctypes.data_as(C.c_void_p), float(st.beta1),
+             float(st.beta2), float(st.eps), _ptr(loss_steps, torch.float32), _stream())
 
     def mf_flush(self, st):
         call("nrhip_mf_flush", self.handle, st.t, float(st.beta1), float(st.beta2), float(st.eps),

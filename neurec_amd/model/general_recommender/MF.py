@@ -67,7 +67,11 @@ class MF(AbstractRecommender):
         for epoch in range(1, self.num_epochs + 1):
             training_start_time = time()
             n = 0
-            for batch in data_iter:
+            if self._fast and self.engine.max_batch >= self.batch_size:
+                # conf/MF.properties as shipped: the whole batch loop of the epoch is one native call
+                users, items, negs, plans = data_iter.epoch_stream()
+                n = self.engine.run_batches(users, items, negs, self.batch_size, losses, plans)
+            for batch in (() if n else data_iter):
                 bat_users, bat_items, bat_third = batch
                 if self.is_pairwise is not True:      # host lists from the pointwise iterator
                     bat_users = torch.tensor(bat_users, dtype=torch.int32, device=dev)

@@ -77,6 +77,14 @@ class BprEpochSampler:
             E.bpr_plan(out[0], out[1], out[2], self.batch_size, self.plan_users, out=self._plan)
         return out
 
+    def epoch_stream(self):
+        """A fresh epoch as whole-stream device tensors (users, pos, neg, plans-or-None): what
+        MFEngine.run_batches consumes in one native call."""
+        users, pos, neg = self.sample_epoch()
+        n = self.n_local
+        return (users[:n], pos[:n], neg[:n * self.neg_num],
+                self._plan[:3 * n] if self.plans else None)
+
     def batches(self):
         """Yield device-tensor batches (views, no copies) for one epoch."""
         users, pos, neg = self.sample_epoch()
@@ -95,42 +103,61 @@ class MFEngine:
     """BPR-MF tables + TF-style Adam state in HBM; step() = one reference sess.run.
 
     lazy=True (default): TF-1.12's sparse Adam — which decays and moves EVERY row each step — is
-    applied by exact lazy replay (nrhip_adam_sparse_tf_lazy): a row's missed zero-gradient steps
-    are replayed in registers when the row is next touched, bit-identical to sweeping the table
-    every step (lazy=False, the checker).  lazy_period bounds how far a row may fall behind (rows
-    r = t mod period are refreshed every step).  Measured on MI355X at the gowalla shape, B = 512
-    (scripts/exp_mf_lazy.py), sweep 29.0-29.9 us/step; lazy with the sampler's next-batch plans (the
-    optimiser launch of step t brings the rows step t+1 will gather up to date, so the gradient
-    kernel replays nothing): period 4: 20.2, 8: 19.2, 16: 19.3, 32: 20.7, 64: 23.8 us; without next
-    plans the gradient kernel redoes the replay (a chain of exact fp32 sqrt + divide per missed
-    step) for every row it gathers: period 4: 22.7, 16: 27.1, 64: 48.4 us.  What is left is two
-    dependent launches of ~9-10 us, each a chain of 4-5 memory round trips.  The tables are only
-    current after flush(); the P / Q / mP / ... properties flush for you."""
+    applied by exact lazy replay: a row's missed zero-gradient steps are replayed in registers when
+    the row is next touched, bit-identical to sweeping the table every step (lazy=False, the
+    checker).  lazy_period bounds how far a row may fall behind (rows r = t mod period are
+    refreshed every step).  Two forms:
+      fused=True (default): gradient AND optimiser in ONE launch (csrc/bpr.hip: mf_fused_step_kernel).
+        Every table exists twice with a stamp per copy; readers of step t take the newer copy older
+        than t, the one writer of a row (the head of its run in the batch plan, holding the summed
+        gradient in registers) writes the other copy — no gradient table, no launch boundary.
+      fused=False: nrhip_bpr_mf_grad_lazy then nrhip_adam_sparse_tf_lazy (two dependent launches).
+    Measured on MI355X at the gowalla shape, B = 512, with the sampler's next-batch plans
+    (scripts/exp_mf_fused.py): sweep 29.0-29.9 us/step; two launches: period 4: 20.2, 8: 19.0,
+    16: 19.3, 32: 20.6; one launch: period 4: 14.6, 8: 12.8, 16: 13.0, 32: 15.8 us.  Without next
+    plans the gradient waves redo the replay (a chain of exact fp32 sqrt + divide per missed step)
+    for every row they gather (two launches: 22.7 / 27.1 / 48.4 us at period 4 / 16 / 64).
+    The tables are only current after flush(); the P / Q / mP / ... properties flush for you."""
 
     ALPHA_STEPS = 1 << 20           # step-size table: 4 MB, enough for 1 M optimiser steps
 
-    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=16):
+    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=16, fused=None):
         dev = E.require_gpu()
         ut = torch.as_tensor(user_table, dtype=torch.float32)
         it = torch.as_tensor(item_table, dtype=torch.float32)
-        nu = ut.shape[0]
+        nu, rows = ut.shape[0], ut.shape[0] + it.shape[0]
+        self.lazy, self.lazy_period = bool(lazy), int(lazy_period)
+        # fused: gradient + lazy Adam in ONE launch on double-buffered tables (csrc/bpr.hip:
+        # mf_fused_step_kernel); the two-launch lazy form stays for larger tables and as an A/B
+        self.fused = self.lazy and (True if fused is None else bool(fused))
         # user and item tables (and their moments / gradients) share one allocation each, so the
         # TF-sparse Adam update of a step is a single launch over [U+I][d]
-        self._table = torch.cat([ut, it]).contiguous().to(dev)
-        self._m, self._v, self._g = (torch.zeros_like(self._table) for _ in range(3))
+        if self.fused:
+            self._w2 = torch.empty((2, rows, ut.shape[1]), dtype=torch.float32, device=dev)
+            self._w2[0].copy_(torch.cat([ut, it]))
+            self._w2[1].zero_()
+            self._m2, self._v2 = torch.zeros_like(self._w2), torch.zeros_like(self._w2)
+            self._table, self._m, self._v, self._g = self._w2[0], self._m2[0], self._v2[0], None
+            self._tw = torch.tensor([0, -1], dtype=torch.int32, device=dev).repeat(rows, 1).contiguous()
+            self._inb = torch.zeros(rows, dtype=torch.int32, device=dev)
+            self.GP = self.GQ = None
+        else:
+            self._table = torch.cat([ut, it]).contiguous().to(dev)
+            self._m, self._v, self._g = (torch.zeros_like(self._table) for _ in range(3))
+            self.GP, self.GQ = self._g[:nu], self._g[nu:]
         self._P, self._Q = self._table[:nu], self._table[nu:]
         self._views = {"mP": self._m[:nu], "mQ": self._m[nu:], "vP": self._v[:nu], "vQ": self._v[nu:]}
-        self.GP, self.GQ = self._g[:nu], self._g[nu:]
         self.reg = float(reg)
         self.adam = E.AdamState(lr)
         self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
-        self.lazy, self.lazy_period = bool(lazy), int(lazy_period)
         self._stale = False
+        self._alpha_host = None
         if self.lazy:
-            self._last = torch.zeros(self._table.shape[0], dtype=torch.int32, device=dev)
-            self._stamp = torch.zeros(self._table.shape[0], dtype=torch.int32, device=dev)
             self._alpha_tab = torch.from_numpy(self.adam.alpha_table(self.ALPHA_STEPS)).to(dev)
+            if not self.fused:
+                self._last = torch.zeros(rows, dtype=torch.int32, device=dev)
+                self._stamp = torch.zeros(rows, dtype=torch.int32, device=dev)
         self._ctx = E.NativeStep.for_mf(self)
 
     # tables and moments as the sweep would have left them: brought up to date on access
@@ -158,6 +185,30 @@ class MFEngine:
         self._ctx.mf_step(users, pos, neg, self.adam, loss_out, plan, next_plan if self.lazy else None)
         self.adam.advance()
         self._stale = True
+
+    def run_batches(self, users, pos, neg, batch, loss_steps, plans=None):
+        """The batch loop of MF.train_model (MF.py:95-103) over the consecutive batches of an epoch
+        stream (device tensors of the whole stream, `batch` triplets per step, the last batch short)
+        in ONE native call — a Python loop enqueues ~12 us per step, more than the one-launch step
+        takes.  loss_steps: float32 device tensor, 2 per step; plans: the stream's batch plans
+        (BprEpochSampler: engine.bpr_plan over the whole stream) or None.  Returns the step count."""
+        n = users.numel()
+        n_steps = (n + batch - 1) // batch
+        if self.lazy and self.adam.t + n_steps + 1 >= self._alpha_tab.numel():
+            raise NotImplementedError("more than %d optimiser steps: enlarge MFEngine.ALPHA_STEPS" % self.ALPHA_STEPS)
+        if batch > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        if n_steps == 0:
+            return 0
+        t = self.adam.t
+        if self._alpha_host is None or self._alpha_host.size < t + n_steps + 1:
+            self._alpha_host = self.adam.alpha_table(max(2 * (t + n_steps), 4096))
+        h_alpha = np.ascontiguousarray(self._alpha_host[t + 1:t + 1 + n_steps])
+        self._ctx.mf_steps(users, pos, neg, batch, self.adam, h_alpha, loss_steps, plans)
+        for _ in range(n_steps):
+            self.adam.advance()
+        self._stale = True
+        return n_steps
 
     def step_reference(self, users, pos, neg, loss_out, plan=None):
         """The same step as individual engine calls with the sweep (what nrhip_mf_step enqueues when

@@ -192,8 +192,9 @@ def test_loss_reduction_by_the_last_block_sees_every_term():
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "two-launch"])
 @pytest.mark.parametrize("d,period,reg", [(64, 64, 0.0), (64, 5, 0.01), (128, 1000, 0.01), (20, 1, 0.0)])
-def test_lazy_sparse_adam_is_bit_identical_to_the_sweep(d, period, reg):
+def test_lazy_sparse_adam_is_bit_identical_to_the_sweep(d, period, reg, fused):
     """nrhip_adam_sparse_tf_lazy (exact lazy replay) against nrhip_adam_sparse_tf (TF's
     literal all-rows update, the checker): after 230 steps + flush the tables AND both moments are
     bit-equal — rows touched every step, rows touched once, rows never touched, with a replay bound
@@ -204,7 +205,7 @@ def test_lazy_sparse_adam_is_bit_identical_to_the_sweep(d, period, reg):
     U, I, B = 700, 900, 256
     P0 = (rng.randn(U, d) * 0.05).astype(np.float32)
     Q0 = (rng.randn(I, d) * 0.05).astype(np.float32)
-    lazy = MFEngine(P0, Q0, 0.003, reg, B, lazy=True, lazy_period=period)
+    lazy = MFEngine(P0, Q0, 0.003, reg, B, lazy=True, lazy_period=period, fused=fused)
     sweep = MFEngine(P0, Q0, 0.003, reg, B, lazy=False)
     la, lb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
     hot_u, hot_i = np.arange(40), np.arange(60)          # most traffic on a few rows, a tail touched rarely,
@@ -219,10 +220,12 @@ def test_lazy_sparse_adam_is_bit_identical_to_the_sweep(d, period, reg):
     for name in ("P", "Q", "mP", "mQ", "vP", "vQ"):
         np.testing.assert_array_equal(getattr(lazy, name).cpu().numpy(), getattr(sweep, name).cpu().numpy(), err_msg=name)
     np.testing.assert_array_equal(lazy.P.cpu().numpy()[600:], P0[600:])          # never touched: never moved
-    assert not lazy.GP.cpu().numpy().any() and not lazy.GQ.cpu().numpy().any()     # gradients re-armed
+    if not fused:                                   # (the one-launch step keeps no gradient table)
+        assert not lazy.GP.cpu().numpy().any() and not lazy.GQ.cpu().numpy().any()     # gradients re-armed
 
 
-def test_lazy_adam_with_next_batch_plans_is_bit_identical_to_the_sweep():
+@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "two-launch"])
+def test_lazy_adam_with_next_batch_plans_is_bit_identical_to_the_sweep(fused):
     """The sampler's batches carry their own plan and the next batch's: the optimiser launch of step t
     brings the rows step t+1 will gather up to date, the gradient kernel then replays nothing.  Across
     epoch boundaries (no next plan on an epoch's last batch, short last batches) the tables and moments
@@ -235,7 +238,7 @@ def test_lazy_adam_with_next_batch_plans_is_bit_identical_to_the_sweep():
     trc = E.DeviceCSR.from_scipy(tr)
     rs = np.random.RandomState(3)
     P0, Q0 = (rs.randn(U, 64) * 0.05).astype(np.float32), (rs.randn(I, 64) * 0.05).astype(np.float32)
-    lazy = MFEngine(P0, Q0, 0.002, 0.01, 2048, lazy=True, lazy_period=16)
+    lazy = MFEngine(P0, Q0, 0.002, 0.01, 2048, lazy=True, lazy_period=16, fused=fused)
     sweep = MFEngine(P0, Q0, 0.002, 0.01, 2048, lazy=False)
     sampler = BprEpochSampler(trc, I, batch_size=2048, seed=5, plan_users=U)     # 39 batches per epoch
     la, lb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
@@ -280,3 +283,33 @@ def test_global_batch_of_8192_sorts_its_plan_inside_the_step():
         outs.append((lg.E0.cpu().numpy(), loss.cpu().numpy()))
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("mode", ["one-launch", "two-launch", "sweep"])
+def test_epoch_batch_loop_in_one_native_call_equals_the_per_step_loop(mode):
+    """MFEngine.run_batches (nrhip_mf_steps: the batch loop of MF.train_model in C) against one step()
+    call per batch on the same epoch streams: per-step losses, tables and moments bit for bit, across
+    two epochs (short last batch, no next plan at the epoch's end)."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.trainer import BprEpochSampler, MFEngine
+    tr, _ = synth.interactions("ml-100k", seed=4)
+    U, I = tr.shape
+    trc = E.DeviceCSR.from_scipy(tr)
+    rs = np.random.RandomState(3)
+    P0, Q0 = (rs.randn(U, 64) * 0.05).astype(np.float32), (rs.randn(I, 64) * 0.05).astype(np.float32)
+    kw = dict(lazy=False) if mode == "sweep" else dict(lazy=True, fused=mode == "one-launch")
+    a, b = MFEngine(P0, Q0, 0.002, 0.01, 1024, **kw), MFEngine(P0, Q0, 0.002, 0.01, 1024, **kw)
+    sa = BprEpochSampler(trc, I, batch_size=1000, seed=5, plan_users=U)
+    sb = BprEpochSampler(trc, I, batch_size=1000, seed=5, plan_users=U)
+    n = len(sa)
+    la, lb = torch.zeros(n, 2, device="cuda"), torch.zeros(n, 2, device="cuda")
+    for epoch in range(2):
+        for k, bt in enumerate(sa.batches()):
+            a.step(bt[0], bt[1], bt[2], la[k], plan=bt.plan, next_plan=bt.next_plan)
+        users, pos, neg, plans = sb.epoch_stream()
+        assert users.numel() % 1000 != 0                 # the last batch is short
+        assert b.run_batches(users, pos, neg, 1000, lb, plans) == n and b.adam.t == a.adam.t
+        np.testing.assert_array_equal(la.cpu().numpy(), lb.cpu().numpy())
+    for name in ("P", "Q", "mP", "mQ", "vP", "vQ"):
+        np.testing.assert_array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), err_msg=name)
