@@ -449,6 +449,7 @@ class FullRankEvaluator:
         self._gemm = None                    # is being ranked (HBM-read bound) on a second stream
         self._scores = None
         self._side = None
+        self._flags = None                   # pruned path: per-user "ranking may depend on ties" flags of the last run
 
     def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False):
         """Returns float64 column means [n_metric*top_k] (or the fp32 np.mean when
@@ -462,6 +463,7 @@ class FullRankEvaluator:
         else:
             self._gemm.prepare(item_table)
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
+        self._flags, self.n_flagged = None, 0
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
         if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0:
@@ -497,14 +499,24 @@ class FullRankEvaluator:
                     ranked[k % 2] = side.record_event()
             main.wait_stream(side)
         if exact_mean:
+            self._redo_flagged(user_table, item_table, test_users, per_user)
             return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
-        return (E.colsum(per_user) / n).cpu().numpy()
+        # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
+        # travel together; only if some row was flagged are those rows redone and the sums retaken
+        sums = E.colsum(per_user)
+        if self._flags is None:
+            return (sums / n).cpu().numpy()
+        both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
+        self.n_flagged = int(both[-1])
+        if self.n_flagged:
+            self._redo_flagged(user_table, item_table, test_users, per_user)
+            return (E.colsum(per_user) / n).cpu().numpy()
+        return both[:-1] / n
 
     def _evaluate_pruned(self, user_table, item_table, test_users, per_user, starts):
         """Level 1: tile maxima from the scoring loop (scores never stored); level 2: rescore and
         rank the top_k+1 best tiles per user.  Rows whose ranking could depend on ties come back
         flagged and are recomputed from full score rows — same numbers as the materialised path."""
-        cols = item_table.shape[0]
         n = test_users.numel()
         flags = torch.zeros(n, dtype=torch.int32, device=test_users.device)
         self.n_flagged = 0
@@ -513,7 +525,15 @@ class FullRankEvaluator:
             M = self._gemm.tile_maxima(user_table, u, self.train)
             E.eval_tiles(M, user_table, self._gemm, u, self.train, self.test, self.metric_ids,
                          self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()])
-        redo = torch.nonzero(flags, as_tuple=False).flatten()            # one host sync per evaluation
+        self._flags = flags                        # read by evaluate_factors together with the sums
+
+    def _redo_flagged(self, user_table, item_table, test_users, per_user):
+        """Rows whose ranking could depend on ties: recomputed from full score rows."""
+        if self._flags is None:
+            return
+        cols = item_table.shape[0]
+        redo = torch.nonzero(self._flags, as_tuple=False).flatten()      # host sync: only when rows were flagged
+        self._flags = None
         self.n_flagged = int(redo.numel())
         if self.n_flagged:
             fixed = torch.empty((self.n_flagged, per_user.shape[1]), dtype=torch.float32,
