@@ -693,6 +693,20 @@ __device__ __forceinline__ void fused_store_row(int64_t row, int copy, int d, in
   if (lane == 0) ft.tw[2 * row + copy] = stamp;
 }
 
+#ifdef NR_MF_TIMELINE       // experiment builds only (scripts/exp_mf_timeline.sh): per-workgroup phase stamps
+__device__ unsigned long long g_mf_dbg[1024 * 8];
+#define NR_MF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_mf_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define NR_MF_STAMP(i)
+#endif
+
+// What bounds this launch (scripts/exp_mf_timeline.py, profiles/r02_exp_mf_timeline.txt): the eight XCDs
+// begin a kernel up to 4.3 us apart (0 / 0.4 / 1.6 / 1.6 / 3.7 / 4.2 / 2.6 / 3.1 us, the same order every
+// launch); an occurrence workgroup then takes 5-8 us (keys 0.9, rows + gradient 2.9, run sums + Adam +
+// store 1.3, loss tail 0.8-2.2), and the zero-gradient replays are real arithmetic: rows / period rows x
+// period steps = one exact sqrt + divide chain per table row per step, ~5 us of the whole chip's VALU —
+// the same arithmetic as the sweep, without its 145 MB.  One row per maintenance wave spreads it best:
+// four rows per wave (a quarter of the waves to dispatch, replays interleaved) took 19 us instead of 12.5.
 template <int CPL>
 __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
     FusedTables ft, int d, int n_users, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
@@ -706,6 +720,7 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   const int a_lo = ft.t - (NR_WAVE - 1);
   const float a_mine = ft.alpha_tab[max(a_lo + lane, 0)]; // step sizes of the last 64 steps, lane j: step t - 63 + j
+  NR_MF_STAMP(0);
   if ((int)blockIdx.x >= occ_blocks) {
     // maintenance, one independent wave per row (no workgroup barrier): heads of the next batch's plan,
     // then the scheduled rows.  Stamps, batch marks and BOTH copies of the row are requested at once.
@@ -755,6 +770,7 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
       fused_replay<CPL>(w, mm, vv, from, ft.t, a_mine, a_lo, lane, ft);
       fused_store_row<CPL>(row, 1 - cp, d, lane, ft, w, mm, vv, ft.t);
     }
+    NR_MF_STAMP(3);
     return;
   }
   const int s = blockIdx.x * kOccWaves + wave;
@@ -766,12 +782,17 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
     if (s > 0) kprev = plan_key(skey, s - 1);
     if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
     const bool first = s == 0 || (uint32_t)(kprev >> 32) != (uint32_t)(key >> 32);   // wave-uniform
+    NR_MF_STAMP(1);
     if (first)
       cp = fused_occurrence<CPL, true>(d, n_users, users, pos, neg, batch, reg, (uint32_t)key, lane, ft, a_mine,
                                        a_lo, acc[0], w, mm, vv, term_mf, term_l2, true);
     else
       fused_occurrence<CPL, false>(d, n_users, users, pos, neg, batch, reg, (uint32_t)key, lane, ft, a_mine,
                                    a_lo, acc[0], w, mm, vv, term_mf, term_l2, true);
+#ifdef NR_MF_TIMELINE
+    if (acc[0][0] == 1.2345678e-30f) return;          // (the stamp waits for the gradient)
+#endif
+    NR_MF_STAMP(2);
   }
   const bool head = sorted_run_sum<CPL, 1>(
       acc, s_g, s_row, s_edge, skey, n_occ, s, key, kprev, knext, wave, lane,
@@ -787,7 +808,9 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
       nr::adam_sparse_tf(acc[0][c], w[c], mm[c], vv[c], a, ft.b1, ft.b2, ft.omb1, ft.omb2, ft.eps);
     fused_store_row<CPL>((int64_t)(uint32_t)(key >> 32), 1 - cp, d, lane, ft, w, mm, vv, ft.t);
   }
+  NR_MF_STAMP(3);
   finish_loss(term_mf, term_l2, batch, reg, out2, done, (unsigned)occ_blocks);   // the occurrence workgroups only
+  NR_MF_STAMP(4);
 }
 
 // rows of a batch whose plan the previous call did not see: marked by a launch of their own
@@ -1245,6 +1268,14 @@ int nrhip_bpr_mf_step_fused(float* d_W, float* d_M, float* d_V, int32_t* d_tw, i
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
+
+#ifdef NR_MF_TIMELINE
+int nrhip_mf_timeline(unsigned long long* h_out) {
+  NR_CHECK_HIP(hipDeviceSynchronize());
+  NR_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_mf_dbg), sizeof(unsigned long long) * 1024 * 8));
+  return NR_OK;
+}
+#endif
 
 /* every row of the fused step's tables brought to step t, in copy 0 */
 int nrhip_bpr_mf_fused_flush(float* d_W, float* d_M, float* d_V, int32_t* d_tw, const float* d_alpha_tab,

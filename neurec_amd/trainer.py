@@ -121,15 +121,17 @@ class MFEngine:
 
     ALPHA_STEPS = 1 << 20           # step-size table: 4 MB, enough for 1 M optimiser steps
 
-    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=16, fused=None):
+    def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=None, fused=None):
         dev = E.require_gpu()
         ut = torch.as_tensor(user_table, dtype=torch.float32)
         it = torch.as_tensor(item_table, dtype=torch.float32)
         nu, rows = ut.shape[0], ut.shape[0] + it.shape[0]
-        self.lazy, self.lazy_period = bool(lazy), int(lazy_period)
+        self.lazy = bool(lazy)
         # fused: gradient + lazy Adam in ONE launch on double-buffered tables (csrc/bpr.hip:
         # mf_fused_step_kernel); the two-launch lazy form stays for larger tables and as an A/B
         self.fused = self.lazy and (True if fused is None else bool(fused))
+        # replay bound: measured best per form (12.5 us at 8 in one launch, 19.0 at 8-16 in two)
+        self.lazy_period = int(lazy_period) if lazy_period is not None else (8 if self.fused else 16)
         # user and item tables (and their moments / gradients) share one allocation each, so the
         # TF-sparse Adam update of a step is a single launch over [U+I][d]
         if self.fused:
