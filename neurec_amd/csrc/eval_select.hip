@@ -14,6 +14,8 @@
 // emulation of libstdc++'s heap partial_sort_copy (nr_core.h) so that the
 // item order is the reference's, bit for bit.
 #include "nr_common.h"
+#include <atomic>
+#include <stdlib.h>
 
 extern "C" int nrhip_score_gemm_items_kmajor(const void* d_ws, int cols, int d, const float** qt,
                                              int* ipad);   // score_gemm.hip
@@ -118,6 +120,16 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
   const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, NR_WAVE);
   return ((uint64_t)hi << 32) | lo;
 }
+// the key of lane + 1 (0 on the last lane)
+__device__ __forceinline__ uint64_t shfl_down1_u64(uint64_t v) {
+  const uint32_t lo = __shfl_down((uint32_t)v, 1, NR_WAVE);
+  const uint32_t hi = __shfl_down((uint32_t)(v >> 32), 1, NR_WAVE);
+  return nr_lane() == NR_WAVE - 1 ? 0ull : (((uint64_t)hi << 32) | lo);
+}
+// A/B knob of the short-row selection (NEUREC_SELECT_FAST=0 keeps the streaming ring for every row)
+__device__ int g_select_fast = 1;
+__device__ __forceinline__ bool select_fast_path() { return g_select_fast != 0; }
+
 // descending bitonic sort of one key per lane (0 = empty sorts last)
 __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v) {
   const int lane = nr_lane();
@@ -154,6 +166,72 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
   uint64_t* keys = s_keys[wave];
   uint64_t* top = s_top[wave];
   const float* srow = scores + (int64_t)row * ld;
+
+  // Short rows (the pruned evaluation ranks 1,282 tile maxima, then 672 rescored items per user): the whole
+  // row fits in registers and the streaming ring below — several radix refreshes of ~700 VALU instructions
+  // each, ~2,000+ per row — is the wrong tool.  The outputs depend on the exact order of the cut + 1 best
+  // keys only; the (cut+1)-th largest of the 64 LANE maxima is a lower bound of the (cut+1)-th largest
+  // score, the scores at or above it are a few dozen, and one register bitonic sort orders them.
+  // Same keys, same total order, same tie rule as the general path (a tie group too large for one key
+  // per lane falls through to it).
+  if constexpr (VEC == 4) {
+    constexpr int FR = 8;                                     // float4 registers per lane: <= 2,048 scores
+    const int need = cut + 1;
+    if (cols <= NR_WAVE * 4 * FR && need <= NR_WAVE && cut >= 1 && select_fast_path()) {
+      float v[FR][4];
+#pragma unroll
+      for (int u = 0; u < FR; ++u) {
+        const int e0 = (u * NR_WAVE + lane) * 4;
+        if (e0 + 3 < cols) {
+          const float4 t = *reinterpret_cast<const float4*>(srow + e0);
+          v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[u][c] = (e0 + c < cols) ? srow[e0 + c] : NAN;   // NaN: never a key
+        }
+      }
+      uint32_t ord[FR][4], best = 0u;                         // order words of real scores are never 0
+#pragma unroll
+      for (int u = 0; u < FR; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          ord[u][c] = v[u][c] >= -INFINITY ? nr::order_f32(v[u][c]) : 0u;
+          best = max(best, ord[u][c]);
+        }
+      const uint64_t sb = wave_sort_desc((uint64_t)best);
+      // fewer than `need` lanes hold a score: 0 — everything is a candidate
+      const uint32_t tau_ord = __builtin_amdgcn_readlane((uint32_t)sb, need - 1);
+      int c_n = 0;
+#pragma unroll
+      for (int u = 0; u < FR; ++u) {
+        const uint32_t m = max(max(ord[u][0], ord[u][1]), max(ord[u][2], ord[u][3]));
+        if (__ballot(m != 0u && m >= tau_ord) == 0) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool pass = ord[u][c] != 0u && ord[u][c] >= tau_ord;
+          const uint64_t mask = __ballot(pass);
+          if (mask) {
+            const int at = c_n + nr_mbcnt(mask);
+            if (pass && at < NR_WAVE)
+              keys[at] = ((uint64_t)ord[u][c] << 32) | (uint64_t)(0xffffffffu - (uint32_t)((u * NR_WAVE + lane) * 4 + c));
+            c_n += __popcll(mask);
+          }
+        }
+      }
+      if (c_n <= NR_WAVE) {                                   // wave-uniform
+        wave_lds_sync();
+        const uint64_t mine = wave_sort_desc(lane < c_n ? keys[lane] : 0ull);
+        const uint64_t next = shfl_down1_u64(mine);           // lane 63 and lanes past the keys: 0 = none
+        const int n_out = min(cut, min(sort_len, c_n));
+        const bool tie = lane < n_out && next != 0ull && nr::key_order(mine) == nr::key_order(next);
+        if (lane < n_out) rank[(int64_t)row * kRankStride + lane] = (int32_t)nr::key_index(mine);
+        const bool any_tie = __ballot(tie) != 0;
+        if (lane == 0) flag[row] = any_tie ? 1 : 0;
+        return;
+      }
+      wave_lds_sync();                                        // a huge tie group: the general path
+    }
+  }
 
   int cnt = 0;                        // wave-uniform
   float tau = -INFINITY;              // wave-uniform: score of the current sort_len-th best
@@ -540,8 +618,22 @@ EvalWs carve_ws(void* ws, int rows) {
   return w;
 }
 
+// NEUREC_SELECT_FAST=0 (read once per device) switches the short-row register selection off
+int select_knob_once() {
+  static std::atomic<int> done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return NR_OK;
+  if (done[dev].load(std::memory_order_acquire)) return NR_OK;
+  const char* e = getenv("NEUREC_SELECT_FAST");
+  const int v = (e && e[0] == '0') ? 0 : 1;
+  NR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_select_fast), &v, sizeof(v)));
+  done[dev].store(1, std::memory_order_release);
+  return NR_OK;
+}
+
 int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sort_len, int cut,
                   const EvalWs& w, hipStream_t st) {
+  { const int rc = select_knob_once(); if (rc != NR_OK) return rc; }
   const int blocks = (rows + kSelWaves - 1) / kSelWaves;
   NR_CHECK_HIP(hipMemsetAsync(w.n_exact, 0, sizeof(int32_t), st));
   const bool vec4 = (ld % 4 == 0) && (((uintptr_t)d_scores) % 16 == 0);
@@ -679,6 +771,7 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
   NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, top_k), NR_ERR_WORKSPACE,
              "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, top_k));
   hipStream_t st = (hipStream_t)stream;
+  { const int rc = select_knob_once(); if (rc != NR_OK) return rc; }
   const int n_keep = top_k + 1, tiles_ld = n_keep + 1;
   EvalWs w = carve_ws(d_ws, rows);
   char* p = (char*)d_ws + eval_ws_bytes(rows);
