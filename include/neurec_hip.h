@@ -618,6 +618,38 @@ int nrhip_add2d(const float* d_x, int64_t ldx, const float* d_y, int64_t ldy, fl
 int nrhip_copy2d(const float* d_x, int64_t ldx, float* d_out, int64_t ldo, int64_t rows, int cols,
                  void* stream);
 
+/* ---- NGCF: forward pass and whole training step issued natively ----------------------------------
+ * The launch sequence of NGCF._create_ngcf_embed + the BPR head + its gradient + Adam on every trainable
+ * (model/general_recommender/NGCF.py:91-110,160-202) as ONE call each: a Python loop issues the ~27
+ * launches of a step in ~270 us, more than they take on the GPU.  The context records caller-owned device
+ * pointers only.  n_layers <= NRHIP_NGCF_MAX_LAYERS; layer width d = 16. */
+#define NRHIP_NGCF_MAX_LAYERS 4
+typedef struct nrhip_ngcf_buffers {
+  const void* plan; const void* plan_t;                                     /* SpMM plans of A and A^T */
+  const int64_t* indptr;  const int32_t* indices;  const float* vals;
+  const int64_t* indptr_t; const int32_t* indices_t; const float* vals_t;
+  void* spmm_ws; size_t spmm_ws_bytes;
+  float* E0; float* mE; float* vE; float* gE0;                              /* [n_nodes][d] */
+  float* Out; float* dOut;                                                  /* [n_nodes][d * (n_layers + 1)] */
+  float* S[NRHIP_NGCF_MAX_LAYERS]; float* ego[NRHIP_NGCF_MAX_LAYERS + 1];   /* ego[0] == E0 */
+  uint8_t* mask[NRHIP_NGCF_MAX_LAYERS];
+  float* W[NRHIP_NGCF_MAX_LAYERS][4]; float* gW[NRHIP_NGCF_MAX_LAYERS][4];  /* W_gc, b_gc, W_bi, b_bi */
+  float* mW[NRHIP_NGCF_MAX_LAYERS][4]; float* vW[NRHIP_NGCF_MAX_LAYERS][4];
+  float* dS; float* dEd; float* dT1; float* dT2; float* dEgo[2];
+  float* terms; int32_t* rows; uint8_t* flag; void* ws; size_t ws_bytes;
+  int n_users; int n_nodes; int d; int n_layers; int max_batch;
+  float reg; float keep;
+} nrhip_ngcf_buffers;
+int nrhip_ngcf_ctx_create(const nrhip_ngcf_buffers* bufs, void** ctx_out);
+int nrhip_ngcf_ctx_destroy(void* ctx);
+/* Out = concat(E0, out_1 .. out_L); masks drawn from (seed, step_counter, layer) unless mask_given */
+int nrhip_ngcf_forward(void* ctx, uint64_t seed, uint64_t step_counter, int mask_given, void* stream);
+/* forward + BPR head on the rows of Out + backward + dense TF Adam on E0 and the 4 * L weights */
+int nrhip_ngcf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                    int batch, const uint64_t* d_plan, uint64_t seed, uint64_t step_counter,
+                    int mask_given, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,24 @@ class MFBuffers(C.Structure):
         ("lazy_period", C.c_int), ("tw", C.c_void_p), ("inb", C.c_void_p)]
 
 
+NGCF_MAX_LAYERS = 4
+
+
+class NGCFBuffers(C.Structure):
+    """nrhip_ngcf_buffers (include/neurec_hip.h)"""
+    _L = NGCF_MAX_LAYERS
+    _fields_ = [(n, C.c_void_p) for n in ("plan", "plan_t", "indptr", "indices", "vals", "indptr_t", "indices_t",
+                                          "vals_t", "spmm_ws")] + [("spmm_ws_bytes", C.c_size_t)] + \
+        [(n, C.c_void_p) for n in ("E0", "mE", "vE", "gE0", "Out", "dOut")] + \
+        [("S", C.c_void_p * _L), ("ego", C.c_void_p * (_L + 1)), ("mask", C.c_void_p * _L),
+         ("W", (C.c_void_p * 4) * _L), ("gW", (C.c_void_p * 4) * _L), ("mW", (C.c_void_p * 4) * _L),
+         ("vW", (C.c_void_p * 4) * _L)] + \
+        [(n, C.c_void_p) for n in ("dS", "dEd", "dT1", "dT2")] + [("dEgo", C.c_void_p * 2)] + \
+        [("terms", C.c_void_p), ("rows", C.c_void_p), ("flag", C.c_void_p), ("ws", C.c_void_p),
+         ("ws_bytes", C.c_size_t), ("n_users", C.c_int), ("n_nodes", C.c_int), ("d", C.c_int),
+         ("n_layers", C.c_int), ("max_batch", C.c_int), ("reg", C.c_float), ("keep", C.c_float)]
+
+
 # name -> argtypes; every function returns int status except where noted.
 SIGNATURES = {
     "nrhip_device_info": [C.POINTER(i32), C.POINTER(i32), psz, C.c_char_p, i32],
@@ -103,6 +121,10 @@ SIGNATURES = {
     "nrhip_mf_ctx_destroy": [p],
     "nrhip_mf_step": [p, p, p, p, i32, p, p, i32, i32, f32, f32, f32, f32, p, p],
     "nrhip_mf_flush": [p, i32, f32, f32, f32, p],
+    "nrhip_ngcf_ctx_create": [C.POINTER(NGCFBuffers), C.POINTER(p)],
+    "nrhip_ngcf_ctx_destroy": [p],
+    "nrhip_ngcf_forward": [p, C.c_uint64, C.c_uint64, i32, p],
+    "nrhip_ngcf_step": [p, p, p, p, i32, p, C.c_uint64, C.c_uint64, i32, f32, f32, f32, f32, p, p],
     "nrhip_mf_steps": [p, p, p, p, i64, i32, p, i32, p, f32, f32, f32, p, p],
     "nrhip_bpr_mf_step_fused": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, i32, p, p, p, i32, f32, p, p, p,
                                 i32, p, i32, i32, p],

@@ -16,6 +16,7 @@
 // they run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, one wave per 256-row slab) and are
 // combined over slabs in slab order (deterministic).
 #include "nr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -209,27 +210,208 @@ __global__ __launch_bounds__(kRowsPerBlock) void ngcf_layer_bwd_kernel(
   store_row<D>(dT2, r, D, g2);
 }
 
+// ---- the same two kernels with FOUR lanes per node row (D = 16) ---------------------------------
+// One thread per row holds seven 16-float rows and, fully unrolled, all 512 weights the compiler
+// hoists out of LDS: 256 VGPRs + 388-560 bytes of scratch per lane, one wave per SIMD — 29 us
+// (forward) and 37 us (backward) for 4.5 MB buffers.  Here lane q of a quad computes output columns
+// 4q..4q+3: the row's inputs are read by all four lanes (one 64-byte line), a weight row is one
+// 16-byte LDS read, whole-row quantities (the norm, the dot with the incoming gradient, the
+// transposed products) take the other lanes' values by quad shuffles and run the SAME k-ascending
+// chains as the one-thread form — bit-identical results (tests/test_ngcf_gpu.py A/B), a fifth of the time.
+constexpr int kQuadRows = 64;                      // rows per 256-thread workgroup
+
+__device__ __forceinline__ void quad_gather(const float (&mine)[4], float (&all)[16], int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) all[4 * q + c] = __shfl(mine[c], (lane & ~3) | q, NR_WAVE);
+}
+// T[4q..4q+3] = x·W[:, 4q..4q+3] + b: k-ascending chain per column, one float4 of W per k
+__device__ __forceinline__ void quad_affine(const float (&x)[16], const float* W, const float* b, int q,
+                                            float (&t)[4]) {
+  const float4 b4 = *reinterpret_cast<const float4*>(b + 4 * q);
+  t[0] = b4.x; t[1] = b4.y; t[2] = b4.z; t[3] = b4.w;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float4 w = *reinterpret_cast<const float4*>(W + k * 16 + 4 * q);
+    t[0] = fmaf(x[k], w.x, t[0]); t[1] = fmaf(x[k], w.y, t[1]);
+    t[2] = fmaf(x[k], w.z, t[2]); t[3] = fmaf(x[k], w.w, t[3]);
+  }
+}
+// y[4q..4q+3] = g·Wᵀ rows 4q..4q+3: j-ascending chain per output
+__device__ __forceinline__ void quad_affine_t(const float (&g)[16], const float* W, int q, float (&y)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float* wr = W + (4 * q + c) * 16;
+    float acc = 0.f;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const float4 w = *reinterpret_cast<const float4*>(wr + 4 * j4);
+      acc = fmaf(g[4 * j4], w.x, acc); acc = fmaf(g[4 * j4 + 1], w.y, acc);
+      acc = fmaf(g[4 * j4 + 2], w.z, acc); acc = fmaf(g[4 * j4 + 3], w.w, acc);
+    }
+    y[c] = acc;
+  }
+}
+__device__ __forceinline__ void load_row16(const float* __restrict__ p, int64_t row, int64_t ld, float (&x)[16]) {
+  load_row<16>(p, row, ld, x);
+}
+
+__global__ __launch_bounds__(4 * kQuadRows) void ngcf_layer_fwd_quad_kernel(
+    const float* __restrict__ ego, const float* __restrict__ S, const float* __restrict__ Wg,
+    const float* __restrict__ bg, const float* __restrict__ Wb, const float* __restrict__ bb,
+    int64_t n_rows, float keep, uint8_t* __restrict__ mask_io, int mask_given, uint64_t seed,
+    uint64_t step, int layer, float* __restrict__ ego_out, float* __restrict__ out, int64_t ldo) {
+  constexpr int D = 16;
+  __shared__ __attribute__((aligned(16))) float s_w[2 * D * D + 2 * D];
+  stage_weights<D>(Wg, bg, Wb, bb, s_w);
+  const int lane = threadIdx.x & 63, q = threadIdx.x & 3;
+  const int64_t r = (int64_t)blockIdx.x * kQuadRows + (threadIdx.x >> 2);
+  const bool live = r < n_rows;
+  const int64_t rr = live ? r : 0;                      // idle quads compute on row 0 (shuffles stay uniform), store nothing
+  float e[D], sv[D], bi[D], t1[4], t2[4];
+  load_row16(ego, rr, D, e);
+  load_row16(S, rr, D, sv);
+#pragma unroll
+  for (int k = 0; k < D; ++k) bi[k] = __fmul_rn(e[k], sv[k]);
+  quad_affine(sv, s_w, s_w + 2 * D * D, q, t1);
+  quad_affine(bi, s_w + D * D, s_w + 2 * D * D + D, q, t2);
+  uint32_t mw;                                           // the mask bytes of columns 4q..4q+3
+  if (mask_given) {
+    mw = *reinterpret_cast<const uint32_t*>(mask_io + rr * D + 4 * q);
+  } else {
+    const uint64_t key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull + layer));
+    const uint64_t hsh = nr::splitmix64(key ^ ((uint64_t)rr * (D / 4) + q));
+    mw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if ((float)((hsh >> (16 * i)) & 0xffffu) * (1.0f / 65536.0f) < keep) mw |= 1u << (8 * i);
+    if (live) *reinterpret_cast<uint32_t*>(mask_io + r * D + 4 * q) = mw;
+  }
+  float z[4], zall[D];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool kp = ((mw >> (8 * c)) & 0xffu) != 0;
+    const float zz = __fadd_rn(lrelu(t1[c]), lrelu(t2[c]));
+    z[c] = kp ? zz / keep : 0.f;
+  }
+  quad_gather(z, zall, lane);
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) ss = fmaf(zall[k], zall[k], ss);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, kNormEps));
+  if (!live) return;
+  *reinterpret_cast<float4*>(ego_out + r * D + 4 * q) = make_float4(z[0], z[1], z[2], z[3]);
+  *reinterpret_cast<float4*>(out + r * ldo + 4 * q) =
+      make_float4(__fmul_rn(z[0], inv), __fmul_rn(z[1], inv), __fmul_rn(z[2], inv), __fmul_rn(z[3], inv));
+}
+
+__global__ __launch_bounds__(4 * kQuadRows) void ngcf_layer_bwd_quad_kernel(
+    const float* __restrict__ ego, const float* __restrict__ S, const float* __restrict__ Wg,
+    const float* __restrict__ bg, const float* __restrict__ Wb, const float* __restrict__ bb,
+    int64_t n_rows, float keep, const uint8_t* __restrict__ mask, const float* __restrict__ d_out,
+    int64_t ldo, const float* __restrict__ d_ego_next, float* __restrict__ dS,
+    float* __restrict__ d_ego_direct, float* __restrict__ dT1, float* __restrict__ dT2) {
+  constexpr int D = 16;
+  __shared__ __attribute__((aligned(16))) float s_w[2 * D * D + 2 * D];
+  stage_weights<D>(Wg, bg, Wb, bb, s_w);
+  const int lane = threadIdx.x & 63, q = threadIdx.x & 3;
+  const int64_t r = (int64_t)blockIdx.x * kQuadRows + (threadIdx.x >> 2);
+  const bool live = r < n_rows;
+  const int64_t rr = live ? r : 0;
+  float e[D], sv[D], bi[D], t1[4], t2[4], g[D];
+  load_row16(ego, rr, D, e);
+  load_row16(S, rr, D, sv);
+  load_row16(d_out, rr, ldo, g);                         // dLoss/d out_k row
+#pragma unroll
+  for (int k = 0; k < D; ++k) bi[k] = __fmul_rn(e[k], sv[k]);
+  quad_affine(sv, s_w, s_w + 2 * D * D, q, t1);
+  quad_affine(bi, s_w + D * D, s_w + 2 * D * D + D, q, t2);
+  const uint32_t mw = *reinterpret_cast<const uint32_t*>(mask + rr * D + 4 * q);
+  float z[4], zall[D];
+  bool kp[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    kp[c] = ((mw >> (8 * c)) & 0xffu) != 0;
+    const float zz = __fadd_rn(lrelu(t1[c]), lrelu(t2[c]));
+    z[c] = kp[c] ? zz / keep : 0.f;
+  }
+  quad_gather(z, zall, lane);
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) ss = fmaf(zall[k], zall[k], ss);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, kNormEps));
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) dot = fmaf(g[k], __fmul_rn(zall[k], inv), dot);
+  float g1[4], g2[4];
+  float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d_ego_next) nxt = *reinterpret_cast<const float4*>(d_ego_next + rr * D + 4 * q);
+  const float nx[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float gk = g[4 * q + c];
+    float v = ss > kNormEps ? (gk - (z[c] * inv) * dot) * inv : gk * inv;
+    if (d_ego_next) v += nx[c];
+    const float dz = kp[c] ? v / keep : 0.f;
+    g1[c] = t1[c] > 0.f ? dz : dz * kLeaky;
+    g2[c] = t2[c] > 0.f ? dz : dz * kLeaky;
+  }
+  float g1all[D], g2all[D], y1[4], y2[4];
+  quad_gather(g1, g1all, lane);
+  quad_gather(g2, g2all, lane);
+  quad_affine_t(g1all, s_w, q, y1);                       // dT1·W_gcᵀ
+  quad_affine_t(g2all, s_w + D * D, q, y2);               // dBi = dT2·W_biᵀ
+  if (!live) return;
+  float ds[4], de[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ds[c] = y1[c] + y2[c] * e[4 * q + c];
+    de[c] = y2[c] * sv[4 * q + c];
+  }
+  *reinterpret_cast<float4*>(dS + r * D + 4 * q) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+  *reinterpret_cast<float4*>(d_ego_direct + r * D + 4 * q) = make_float4(de[0], de[1], de[2], de[3]);
+  *reinterpret_cast<float4*>(dT1 + r * D + 4 * q) = make_float4(g1[0], g1[1], g1[2], g1[3]);
+  *reinterpret_cast<float4*>(dT2 + r * D + 4 * q) = make_float4(g2[0], g2[1], g2[2], g2[3]);
+}
+
+// NEUREC_NGCF_ROW_THREAD=1 keeps the one-thread-per-row kernels (A/B)
+bool ngcf_row_thread() {
+  static const bool v = [] { const char* e = getenv("NEUREC_NGCF_ROW_THREAD"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // Weight gradients of one layer on the fp32 matrix cores (D == 16):
 //   dW_gc = Sᵀ·dT1, dW_bi = (E⊙S)ᵀ·dT2, db_gc = Σ_rows dT1, db_bi = Σ_rows dT2.
-// One wave per 256-row slab; v_mfma_f32_16x16x4_f32: lane l feeds A[i=l&15][k=l>>4] =
+// One wave per kWgradSlab-row slab; v_mfma_f32_16x16x4_f32: lane l feeds A[i=l&15][k=l>>4] =
 // X[row0+k][i] and B[k=l>>4][j=l&15] = G[row0+k][j] — four consecutive 64-byte rows per load.
+// A slab is 64 rows and ALL its 64 loads per lane are requested before the first MFMA: the first
+// version walked 256 rows per wave, four loads and two MFMAs per dependent round trip (277 waves,
+// 23 us for 18 MB).
+constexpr int kWgradSlab = 64;
 __global__ __launch_bounds__(64) void ngcf_wgrad16_kernel(
     const float* __restrict__ ego, const float* __restrict__ S, const float* __restrict__ dT1,
     const float* __restrict__ dT2, int64_t n_rows, float* __restrict__ partial) {
   const int lane = threadIdx.x, c = lane & 15, kk = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  const int64_t r0 = (int64_t)blockIdx.x * kWgradSlab;
+  constexpr int Q = kWgradSlab / 4;
+  float s[Q], e[Q], g1[Q], g2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int64_t r = r0 + q * 4 + kk;
+    const int64_t rr = r < n_rows ? r : 0;
+    const float live = r < n_rows ? 1.f : 0.f;
+    s[q] = S[rr * 16 + c] * live; e[q] = ego[rr * 16 + c];
+    g1[q] = dT1[rr * 16 + c] * live; g2[q] = dT2[rr * 16 + c] * live;
+  }
   f32x4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
   float sum1 = 0.f, sum2 = 0.f;
-  for (int q = 0; q < 64; ++q) {
-    const int64_t r = r0 + q * 4 + kk;
-    float s = 0.f, e = 0.f, g1 = 0.f, g2 = 0.f;
-    if (r < n_rows) {
-      s = S[r * 16 + c]; e = ego[r * 16 + c]; g1 = dT1[r * 16 + c]; g2 = dT2[r * 16 + c];
-    }
-    acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(s, g1, acc_g, 0, 0, 0);
-    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(__fmul_rn(e, s), g2, acc_b, 0, 0, 0);
-    sum1 += g1;
-    sum2 += g2;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(s[q], g1[q], acc_g, 0, 0, 0);
+    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(__fmul_rn(e[q], s[q]), g2[q], acc_b, 0, 0, 0);
+    sum1 += g1[q];
+    sum2 += g2[q];
   }
   sum1 += __shfl_xor(sum1, 16, 64); sum1 += __shfl_xor(sum1, 32, 64);
   sum2 += __shfl_xor(sum2, 16, 64); sum2 += __shfl_xor(sum2, 32, 64);
@@ -278,9 +460,14 @@ int nrhip_ngcf_layer_fwd(const float* d_ego, const float* d_S, const float* d_Wg
   NR_REQUIRE(ldo % 4 == 0 && ((uintptr_t)d_out % 16) == 0, NR_ERR_ARG,
              "ngcf_layer_fwd: output block must be 16-byte aligned with ldo %% 4 == 0");
   if (n_rows == 0) return NR_OK;
-  hipLaunchKernelGGL(ngcf_layer_fwd_kernel<16>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, d_ego, d_S, d_Wg, d_bg, d_Wb, d_bb, n_rows, keep, d_mask,
-                     mask_given, seed, step, layer, d_ego_out, d_out, ldo);
+  if (ngcf_row_thread())
+    hipLaunchKernelGGL(ngcf_layer_fwd_kernel<16>, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_ego, d_S, d_Wg, d_bg, d_Wb, d_bb, n_rows, keep, d_mask,
+                       mask_given, seed, step, layer, d_ego_out, d_out, ldo);
+  else
+    hipLaunchKernelGGL(ngcf_layer_fwd_quad_kernel, dim3((unsigned)((n_rows + kQuadRows - 1) / kQuadRows)),
+                       dim3(4 * kQuadRows), 0, (hipStream_t)stream, d_ego, d_S, d_Wg, d_bg, d_Wb, d_bb, n_rows,
+                       keep, d_mask, mask_given, seed, step, layer, d_ego_out, d_out, ldo);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -298,27 +485,33 @@ int nrhip_ngcf_layer_bwd(const float* d_ego, const float* d_S, const float* d_Wg
   NR_REQUIRE(d == 16, NR_ERR_UNSUPPORTED, "ngcf_layer: layer width %d not built (16)", d);
   NR_REQUIRE(ldo % 4 == 0 && ((uintptr_t)d_dout % 16) == 0, NR_ERR_ARG,
              "ngcf_layer_bwd: gradient block must be 16-byte aligned with ldo %% 4 == 0");
-  const int n_slabs = (int)((n_rows + 255) / 256);
-  NR_REQUIRE(ws_bytes >= (size_t)(n_slabs > 0 ? n_slabs : 1) * 544 * sizeof(float), NR_ERR_WORKSPACE,
+  const int n_slabs = (int)((n_rows + 255) / 256);                 // row-thread kernel's workgroups
+  const int w_slabs = (int)((n_rows + kWgradSlab - 1) / kWgradSlab);
+  NR_REQUIRE(ws_bytes >= (size_t)(w_slabs > 0 ? w_slabs : 1) * 544 * sizeof(float), NR_ERR_WORKSPACE,
              "ngcf_layer_bwd: workspace too small");
   if (n_rows == 0) return NR_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ngcf_layer_bwd_kernel<16>, dim3((unsigned)n_slabs), dim3(256), 0, st, d_ego,
-                     d_S, d_Wg, d_bg, d_Wb, d_bb, n_rows, keep, d_mask, d_dout, ldo, d_dego_next,
-                     d_dS, d_dego_direct, d_dT1, d_dT2);
+  if (ngcf_row_thread())
+    hipLaunchKernelGGL(ngcf_layer_bwd_kernel<16>, dim3((unsigned)n_slabs), dim3(256), 0, st, d_ego,
+                       d_S, d_Wg, d_bg, d_Wb, d_bb, n_rows, keep, d_mask, d_dout, ldo, d_dego_next,
+                       d_dS, d_dego_direct, d_dT1, d_dT2);
+  else
+    hipLaunchKernelGGL(ngcf_layer_bwd_quad_kernel, dim3((unsigned)((n_rows + kQuadRows - 1) / kQuadRows)),
+                       dim3(4 * kQuadRows), 0, st, d_ego, d_S, d_Wg, d_bg, d_Wb, d_bb, n_rows, keep, d_mask,
+                       d_dout, ldo, d_dego_next, d_dS, d_dego_direct, d_dT1, d_dT2);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ngcf_wgrad16_kernel, dim3((unsigned)n_slabs), dim3(64), 0, st, d_ego, d_S,
+  hipLaunchKernelGGL(ngcf_wgrad16_kernel, dim3((unsigned)w_slabs), dim3(64), 0, st, d_ego, d_S,
                      d_dT1, d_dT2, n_rows, (float*)d_ws);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(ngcf_wgrad_reduce_kernel, dim3(136), dim3(256), 0, st, (const float*)d_ws,
-                     n_slabs, d_dWg, d_dWb, d_dbg, d_dbb);
+                     w_slabs, d_dWg, d_dWb, d_dbg, d_dbb);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
 
 int nrhip_ngcf_workspace_bytes(int64_t n_rows, size_t* bytes) {
   NR_REQUIRE(bytes && n_rows >= 0, NR_ERR_ARG, "ngcf_workspace_bytes: bad arguments");
-  *bytes = (size_t)((n_rows + 255) / 256 + 1) * 544 * sizeof(float);
+  *bytes = (size_t)((n_rows + kWgradSlab - 1) / kWgradSlab + 1) * 544 * sizeof(float);
   return NR_OK;
 }
 

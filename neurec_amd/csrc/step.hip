@@ -16,6 +16,10 @@ namespace {
 struct LightGCNCtx {
   nrhip_lightgcn_buffers b;
 };
+struct NGCFCtx {
+  nrhip_ngcf_buffers b;
+};
+
 struct MFCtx {
   nrhip_mf_buffers b;
   const uint64_t* marked_plan = nullptr;   // one-launch step: the plan whose rows the last step marked ...
@@ -355,6 +359,94 @@ int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float ep
   return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, nullptr, (int64_t)b.n_users + b.n_items,
                                    b.d, nullptr, 0, nullptr, 0, b.alpha_tab, steps_done, 1, beta1, beta2, eps,
                                    stream);
+}
+
+// ---- NGCF ------------------------------------------------------------------------------------
+int nrhip_ngcf_ctx_create(const nrhip_ngcf_buffers* bufs, void** ctx_out) {
+  NR_REQUIRE(bufs && ctx_out, NR_ERR_ARG, "ngcf_ctx_create: null argument");
+  const nrhip_ngcf_buffers& b = *bufs;
+  NR_REQUIRE(b.n_layers >= 0 && b.n_layers <= NRHIP_NGCF_MAX_LAYERS && b.d == 16 && b.n_users > 0 &&
+                 b.n_nodes > b.n_users && b.max_batch > 0 && b.keep > 0.f && b.keep <= 1.f,
+             NR_ERR_ARG, "ngcf_ctx_create: bad sizes (layer width 16, at most %d layers)", NRHIP_NGCF_MAX_LAYERS);
+  bool ok = b.plan && b.plan_t && b.indptr && b.indices && b.vals && b.indptr_t && b.indices_t && b.vals_t &&
+            b.spmm_ws && b.E0 && b.mE && b.vE && b.gE0 && b.Out && b.dOut && b.dS && b.dEd && b.dT1 && b.dT2 &&
+            b.dEgo[0] && b.dEgo[1] && b.terms && b.rows && b.flag && b.ws && b.ego[0] == b.E0;
+  for (int k = 0; k < b.n_layers && ok; ++k) {
+    ok = b.S[k] && b.ego[k + 1] && b.mask[k];
+    for (int j = 0; j < 4 && ok; ++j) ok = b.W[k][j] && b.gW[k][j] && b.mW[k][j] && b.vW[k][j];
+  }
+  NR_REQUIRE(ok, NR_ERR_ARG, "ngcf_ctx_create: a buffer pointer is null (or ego[0] != E0)");
+  NGCFCtx* c = new (std::nothrow) NGCFCtx();
+  NR_REQUIRE(c, NR_ERR_ARG, "ngcf_ctx_create: out of host memory");
+  c->b = b;
+  *ctx_out = c;
+  return NR_OK;
+}
+
+int nrhip_ngcf_ctx_destroy(void* ctx) {
+  delete (NGCFCtx*)ctx;
+  return NR_OK;
+}
+
+int nrhip_ngcf_forward(void* ctx, uint64_t seed, uint64_t step_counter, int mask_given, void* stream) {
+  NR_REQUIRE(ctx, NR_ERR_ARG, "ngcf_forward: null context");
+  const nrhip_ngcf_buffers& b = ((NGCFCtx*)ctx)->b;
+  const int d = b.d, ldo = d * (b.n_layers + 1);
+  NR_TRY(nrhip_copy2d(b.E0, d, b.Out, ldo, b.n_nodes, d, stream));
+  for (int k = 0; k < b.n_layers; ++k) {
+    NR_TRY(nrhip_spmm_csr(b.plan, b.indptr, b.indices, b.vals, b.ego[k], d, b.S[k], nullptr, nullptr, nullptr,
+                          b.spmm_ws, b.spmm_ws_bytes, stream));                                  // NGCF.py:174-179
+    NR_TRY(nrhip_ngcf_layer_fwd(b.ego[k], b.S[k], b.W[k][0], b.W[k][1], b.W[k][2], b.W[k][3], b.n_nodes, d,
+                                b.keep, b.mask[k], mask_given, seed, step_counter, k, b.ego[k + 1],
+                                b.Out + (size_t)(k + 1) * d, ldo, stream));                      // NGCF.py:181-200
+  }
+  return NR_OK;
+}
+
+int nrhip_ngcf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                    int batch, const uint64_t* d_plan, uint64_t seed, uint64_t step_counter,
+                    int mask_given, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                    void* stream) {
+  NR_REQUIRE(ctx && d_users && d_pos && d_neg && d_loss2, NR_ERR_ARG, "ngcf_step: null argument");
+  const nrhip_ngcf_buffers& b = ((NGCFCtx*)ctx)->b;
+  NR_REQUIRE(batch >= 1 && batch <= b.max_batch, NR_ERR_ARG, "ngcf_step: batch %d outside 1..%d", batch, b.max_batch);
+  const int d = b.d, L = b.n_layers, ldo = d * (L + 1), U = b.n_users;
+  NR_TRY(nrhip_ngcf_forward(ctx, seed, step_counter, mask_given, stream));
+  NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, U, b.rows, b.flag, stream));
+  // the BPR head of NGCF.py:91-100 is the MF head on the rows of the concatenated output
+  NR_TRY(nrhip_bpr_mf_grad(b.Out, b.Out + (size_t)U * ldo, ldo, U, d_users, d_pos, d_neg, batch, b.reg, b.dOut,
+                           b.dOut + (size_t)U * ldo, b.terms, d_loss2, d_plan, stream));
+  const float* dego = nullptr;
+  for (int k = L - 1; k >= 0; --k) {
+    NR_TRY(nrhip_ngcf_layer_bwd(b.ego[k], b.S[k], b.W[k][0], b.W[k][1], b.W[k][2], b.W[k][3], b.n_nodes, d, b.keep,
+                                b.mask[k], b.dOut + (size_t)(k + 1) * d, ldo, dego, b.dS, b.dEd, b.dT1, b.dT2,
+                                b.gW[k][0], b.gW[k][1], b.gW[k][2], b.gW[k][3], b.ws, b.ws_bytes, stream));
+    float* nxt = b.dEgo[k % 2];
+    NR_TRY(nrhip_spmm_csr(b.plan_t, b.indptr_t, b.indices_t, b.vals_t, b.dS, d, nxt, b.dEd, nullptr, nullptr,
+                          b.spmm_ws, b.spmm_ws_bytes, stream));                                  // dE_k = dBi*S + A^T dS
+    dego = nxt;
+  }
+  if (!dego) NR_TRY(nrhip_copy2d(b.dOut, ldo, b.gE0, d, b.n_nodes, d, stream));
+  else NR_TRY(nrhip_add2d(b.dOut, ldo, dego, d, b.gE0, d, b.n_nodes, d, stream));
+  // every trainable in launches of up to 16 tensors
+  float* vars[1 + 4 * NRHIP_NGCF_MAX_LAYERS]; float* ms[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
+  float* vs[1 + 4 * NRHIP_NGCF_MAX_LAYERS]; float* gs[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
+  int64_t sizes[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
+  int32_t clear[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
+  int n = 0;
+  vars[n] = b.E0; ms[n] = b.mE; vs[n] = b.vE; gs[n] = b.gE0; sizes[n] = (int64_t)b.n_nodes * d; clear[n] = 0; ++n;
+  for (int k = 0; k < L; ++k)
+    for (int j = 0; j < 4; ++j) {
+      vars[n] = b.W[k][j]; ms[n] = b.mW[k][j]; vs[n] = b.vW[k][j]; gs[n] = b.gW[k][j];
+      sizes[n] = (j & 1) ? d : (int64_t)d * d; clear[n] = 0; ++n;
+    }
+  for (int lo = 0; lo < n; lo += 16) {
+    const int m = std::min(16, n - lo);
+    NR_TRY(nrhip_adam_dense_tf_multi(m, vars + lo, ms + lo, vs + lo, gs + lo, sizes + lo, clear + lo, alpha, beta1,
+                                     beta2, eps, stream));
+  }
+  NR_TRY(nrhip_rows_clear(b.rows, 3 * batch, ldo, b.dOut, nullptr, nullptr, nullptr, b.flag, stream));
+  return NR_OK;
 }
 
 }  // extern "C"

@@ -14,6 +14,8 @@ import torch
 from . import _lib
 from ._lib import call
 
+NGCF_MAX_LAYERS = _lib.NGCF_MAX_LAYERS
+
 METRIC_IDS = {"Precision": 1, "Recall": 2, "MAP": 3, "NDCG": 4, "MRR": 5}  # metric.h:111-117
 
 
@@ -699,6 +701,47 @@ class NativeStep:
         return ctx
 
     @staticmethod
+    def for_ngcf(eng):
+        b = _lib.NGCFBuffers()
+        eng.A.ensure_schedule(eng.d)
+        eng.At.ensure_schedule(eng.d)
+        ws = eng.A._workspace(eng.d)
+        wst = eng.At._workspace(eng.d)
+        ws = ws if ws.numel() >= wst.numel() else wst
+        b.plan, b.plan_t = eng.A.plan.value, eng.At.plan.value
+        for k, t in dict(indptr=eng.A.indptr, indices=eng.A.indices, vals=eng.A.vals, indptr_t=eng.At.indptr,
+                         indices_t=eng.At.indices, vals_t=eng.At.vals, spmm_ws=ws, E0=eng.E0, mE=eng.mE,
+                         vE=eng.vE, gE0=eng.gE0, Out=eng.Out, dOut=eng.dOut, dS=eng.dS, dEd=eng.dEd, dT1=eng.dT1,
+                         dT2=eng.dT2, terms=eng.terms, rows=eng.rows, flag=eng.flag, ws=eng.ws).items():
+            setattr(b, k, t.data_ptr())
+        b.spmm_ws_bytes, b.ws_bytes = ws.numel(), eng.ws.numel()
+        b.dEgo[0], b.dEgo[1] = eng.dEgo[0].data_ptr(), eng.dEgo[1].data_ptr()
+        for k in range(eng.L + 1):
+            b.ego[k] = eng.ego[k].data_ptr()
+        for k in range(eng.L):
+            b.S[k], b.mask[k] = eng.S[k].data_ptr(), eng.mask[k].data_ptr()
+            for j in range(4):
+                b.W[k][j], b.gW[k][j] = eng.W[k][j].data_ptr(), eng.gW[k][j].data_ptr()
+                b.mW[k][j], b.vW[k][j] = eng.mW[k][j].data_ptr(), eng.vW[k][j].data_ptr()
+        b.n_users, b.n_nodes, b.d, b.n_layers = eng.n_users, eng.N, eng.d, eng.L
+        b.max_batch, b.reg, b.keep = eng.max_batch, eng.reg, eng.keep
+        h = C.c_void_p(0)
+        call("nrhip_ngcf_ctx_create", C.byref(b), C.byref(h))
+        ctx = NativeStep("ngcf", h, eng)
+        ctx._keep = (ws,)
+        return ctx
+
+    def ngcf_forward(self, seed, step_counter, mask_given):
+        call("nrhip_ngcf_forward", self.handle, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(step_counter),
+             1 if mask_given else 0, _stream())
+
+    def ngcf_step(self, users, pos, neg, st, seed, step_counter, mask_given, loss2, plan=None):
+        call("nrhip_ngcf_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg), users.numel(),
+             self._plan(plan, 3 * users.numel()), C.c_uint64(seed & (2**64 - 1)), C.c_uint64(step_counter),
+             1 if mask_given else 0, float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
+             _ptr(loss2, torch.float32), _stream())
+
+    @staticmethod
     def for_mf(eng):
         b = _lib.MFBuffers()
         for k in ("_P", "_Q", "terms"):
@@ -723,7 +766,8 @@ class NativeStep:
     def __del__(self):
         try:
             if self.handle and self.handle.value:
-                name = "nrhip_lightgcn_ctx_destroy" if self.kind == "lightgcn" else "nrhip_mf_ctx_destroy"
+                name = {"lightgcn": "nrhip_lightgcn_ctx_destroy", "ngcf": "nrhip_ngcf_ctx_destroy"}.get(
+                    self.kind, "nrhip_mf_ctx_destroy")
                 getattr(_lib.lib, name)(self.handle)
                 self.handle = C.c_void_p(0)
         except Exception:

@@ -593,12 +593,22 @@ class NGCFEngine:
         self.flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
         self.ws = E.ngcf_workspace(self.N, dev)
         self.max_batch = max_batch
+        # the ~27 launches of a step go out in ONE native call (a Python loop issues them in ~270 us,
+        # more than they take on the GPU); contexts exist for at most E.NGCF_MAX_LAYERS layers
+        self._ctx = E.NativeStep.for_ngcf(self) if self.L <= E.NGCF_MAX_LAYERS else None
 
     def forward(self, masks=None):
         """Fills self.Out = concat(E0, out_1..out_L).  masks: optional list of uint8 [N][d] device
         tensors (tests); otherwise a fresh dropout draw per call — evaluation included, as in the
         reference (NGCF.py:193 has no training flag)."""
         d = self.d
+        if self._ctx is not None:
+            if masks is not None:
+                for k in range(self.L):
+                    self.mask[k].copy_(masks[k])
+            self._ctx.ngcf_forward(self.seed, self.t, masks is not None)
+            self.t += 1
+            return self.Out
         E.copy2d(self.E0, self.Out[:, :d])
         for k in range(self.L):
             self.A.matmul(self.ego[k], out=self.S[k])
@@ -618,6 +628,14 @@ class NGCFEngine:
         B, d = users.numel(), self.d
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
+        if self._ctx is not None:
+            if masks is not None:
+                for k in range(self.L):
+                    self.mask[k].copy_(masks[k])
+            self._ctx.ngcf_step(users, pos, neg, self.adam, self.seed, self.t, masks is not None, loss_out, plan)
+            self.t += 1
+            self.adam.advance()
+            return
         self.forward(masks)
         U = self.n_users
         rows = self.rows[:3 * B]

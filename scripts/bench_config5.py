@@ -31,11 +31,14 @@ e = get_initializer("xavier_normal", 0.01, seed=2017)
 table = np.concatenate([e([U, 16]), e([I, 16])])
 weights = [(w([16, 16]), w([1, 16]), w([16, 16]), w([1, 16])) for _ in range(2)]
 ng = NGCFEngine(A, transpose_csr(A), U, I, table, weights, 0.001, 0.0, 0.1, 512)
-sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=512, shuffle=True, seed=2018)
+sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=512, shuffle=True, seed=2018, plan_users=U)
 batches = [b for b in sampler.batches() if b[0].numel() == 512][:200]
 loss = torch.zeros(2, device=dev)
 it = iter(batches * 10)
-ms = timed(lambda: ng.step(*next(it), loss), 150, 20)
+def ngcf_step():
+    b = next(it)
+    ng.step(b[0], b[1], b[2], loss, plan=b.plan)
+ms = timed(ngcf_step, 150, 20)
 ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=16384)
 users = torch.from_numpy(np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)).to(dev)
 def ngcf_eval():
