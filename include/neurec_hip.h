@@ -514,9 +514,10 @@ int nrhip_ngcf_layer_bwd(const float* d_ego, const float* d_S, const float* d_Wg
  *                      (per CSR position, may be NULL) receives the dropped-out input value.
  *   logits             = nrhip_score_gemm(P=g1, Q=W_p1) (+ b_p1, nrhip_add_row_bias or
  *                      fused below)
- *   nrhip_vae_decoder_loss_grad   d_S holds g1·W_p1ᵀ (bias NOT added) on entry and
- *                      dLoss/dlogits on exit; writes nll[b] = -Σ_i log_softmax·x, dW_p1
- *                      ([n_items][h]), db_p1, dg1.
+ *   nrhip_vae_decoder_loss_grad   d_S holds g1·W_p1ᵀ (bias NOT added) on entry (contents on exit
+ *                      unspecified); writes nll[b] = -Σ_i log_softmax·x, dW_p1 ([n_items][h]),
+ *                      db_p1, dg1 — both products on the fp32 matrix cores, dLoss/dlogits formed in
+ *                      registers from the logits (never stored).
  *   nrhip_vae_mid_backward        the 16/32-wide layers' backward and weight gradients.
  *   nrhip_vae_dwq0     scatter of h0ᵀ·da1 into a zeroed dense [n_items][h] gradient.
  * act: 0 tanh, 1 sigmoid, 2 relu, 3 identity (util/tool.py activation_function). */

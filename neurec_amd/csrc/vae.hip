@@ -14,10 +14,15 @@
 // of it on the host per batch, MultiVAE.py:152-165).  The only dense product with a large
 // dimension on both sides is logits = g1·W_p1ᵀ ([B,32]×[32,I]): that one runs on the fp32
 // matrix cores through nrhip_score_gemm (W_p1 is stored item-major, [I][32]).  Its two
-// gradients stream the [B,I] dlogits slab once each: dW_p1 (thread per item, g1 staged in LDS)
-// and dg1 (two user rows per block against coalesced W_p1 rows).  The 16/32-wide middle
-// layers are register-resident per-row math, as in dense.hip.
+// gradients read the [B,I] logits once each and run on the matrix cores too (dLoss/dlogits is
+// formed in registers, never stored: vae_dwp1_mfma_kernel / vae_dg1_mfma_kernel; the first,
+// VALU design — dlogits in place, then one pass per gradient — stays behind
+// NEUREC_VAE_DECODER_VALU=1).  The 16/32-wide middle layers are register-resident per-row math,
+// as in dense.hip.
 #include "nr_common.h"
+#include <algorithm>
+#include <atomic>
+#include <stdlib.h>
 
 namespace {
 
@@ -425,6 +430,278 @@ __global__ __launch_bounds__(256) void vae_dg1_reduce_kernel(const float* __rest
   dG1[i] = sum;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Decoder gradient on the matrix cores.  The first design turned the logits into dLoss/dlogits in
+// place (read + write 84 MB), then streamed that slab once for dW_p1 and once for dg1 with VALU
+// FMAs: 160 us per step.  Here the logits are only READ:
+//   vae_softmax_stats_kernel   per row: the positive-item bitmap, (lse, n_b), nll
+//   vae_dwp1_mfma_kernel       dW_p1[32-item tile] = Gᵀ·g1 — G = (softmax·n_b − x)/B formed in registers
+//                              from the logits as they arrive (lanes over items: the natural, coalesced
+//                              layout IS the A operand of v_mfma_f32_32x32x2_f32), rows = contraction
+//   vae_dg1_mfma_kernel        dg1[32-row tile] += G·W_p1 over a range of item tiles — the same loads, G
+//                              transposed through a wave-local LDS tile (lanes over rows), items = contraction
+// Both without workgroup barriers in their loops (a fused kernel — 16 waves = 16 row tiles sharing each
+// item tile, dW summed across the waves in LDS per tile — spent its time at its three barriers per tile:
+// 115 us).  Partial sums meet in a fixed order: deterministic.
+// ----------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kDecTile = 32;
+constexpr int kDecTileLd = 33;                   // padded transpose tile
+constexpr int kDecWaves = 4;                     // waves per workgroup in both kernels
+constexpr int kDg1Ranges = 40;                   // item ranges of the dg1 kernel (= partial sums per output)
+
+__global__ __launch_bounds__(256) void vae_softmax_stats_kernel(
+    const float* __restrict__ S, int64_t ld, int cols, const float* __restrict__ bias,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const int32_t* __restrict__ rows, float2* __restrict__ stat_out, float* __restrict__ nll,
+    uint32_t* __restrict__ bitmap_ws, int bitmap_words) {
+  __shared__ float s_red[256];
+  __shared__ float s_lse;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* srow = S + (int64_t)r * ld;
+  const int64_t u = rows[r];
+  const int64_t b = indptr[u], e = indptr[u + 1];
+  uint32_t* bm = bitmap_ws + (int64_t)r * bitmap_words;
+  for (int w = tid; w < bitmap_words; w += 256) bm[w] = 0u;
+  __syncthreads();
+  for (int64_t t = b + tid; t < e; t += 256) atomicOr(&bm[indices[t] >> 5], 1u << (indices[t] & 31));
+  const int cols4 = cols & ~3;
+  const float4* srow4 = reinterpret_cast<const float4*>(srow);
+  const float4* bias4 = reinterpret_cast<const float4*>(bias);
+  float mx = -INFINITY, sum = 0.f;
+  auto fold = [&](float x) {
+    if (x > mx) { sum = sum * expf(mx - x) + 1.0f; mx = x; }
+    else sum += expf(x - mx);
+  };
+  constexpr int kUn = 8;                                     // independent 16-byte loads per round
+  const int n4 = cols4 / 4;
+  for (int i0 = tid; i0 < n4; i0 += 256 * kUn) {
+    float4 a[kUn], bb[kUn];
+#pragma unroll
+    for (int k = 0; k < kUn; ++k) {
+      const int i = min(i0 + k * 256, n4 - 1);
+      a[k] = srow4[i];
+      bb[k] = bias4[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kUn; ++k)
+      if (i0 + k * 256 < n4) {
+        fold(a[k].x + bb[k].x); fold(a[k].y + bb[k].y); fold(a[k].z + bb[k].z); fold(a[k].w + bb[k].w);
+      }
+  }
+  for (int i = cols4 + tid; i < cols; i += 256) fold(srow[i] + bias[i]);
+  s_red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] = fmaxf(s_red[tid], s_red[tid + s]); __syncthreads(); }
+  const float gmx = s_red[0];
+  __syncthreads();
+  s_red[tid] = (mx == -INFINITY) ? 0.f : sum * expf(mx - gmx);
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  if (tid == 0) s_lse = gmx + logf(s_red[0]);
+  __syncthreads();
+  const float lse = s_lse;
+  float ll = 0.f;                                            // Σ over the row's items of log-softmax
+  for (int64_t t = b + tid; t < e; t += 256) {
+    const int i = indices[t];
+    ll += (srow[i] + bias[i]) - lse;
+  }
+  s_red[tid] = ll;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  if (tid == 0) {
+    nll[r] = -s_red[0];
+    stat_out[r] = make_float2(lse, (float)(e - b));
+  }
+}
+
+// G of the 32 x 32 tile (rows row0.., items item0..) in the layout the loads give: lane (hlf, i), slot s
+// holds G[row0 + 2s + hlf][item0 + i]
+template <class StatOf>      // stat_of(s) = (lse, n_b) of row row0 + 2s + hlf
+__device__ __forceinline__ void vae_grad_tile(const float* __restrict__ S, int64_t ld, int batch, int cols,
+                                              int row0, int item0, int tile_index, float bias_i,
+                                              StatOf&& stat_of, const uint32_t* __restrict__ bitmap,
+                                              int bitmap_words, float inv_batch, int lane, float (&v)[16]) {
+  const int hlf = lane >> 5, i = lane & 31, item = item0 + i;
+  const bool interior = row0 + kDecTile <= batch && item0 + kDecTile <= cols;    // wave-uniform
+  float x[16];
+  if (interior) {                                    // one base address, constant strides (no clamps)
+    const float* p = S + (int64_t)(row0 + hlf) * ld + item;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) x[s] = p[(int64_t)(2 * s) * ld];    // two 128-byte row segments per instruction
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      x[s] = S[(int64_t)min(row0 + 2 * s + hlf, batch - 1) * ld + min(item, cols - 1)];
+  }
+  const int brow = row0 + i;                         // lanes j and j + 32 hold row0 + j's bitmap word of the tile
+  const uint32_t myword = brow < batch ? bitmap[(int64_t)brow * bitmap_words + tile_index] : 0u;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int row = row0 + 2 * s + hlf;
+    const uint32_t word = __shfl(myword, 2 * s + hlf, NR_WAVE);
+    const float bit = (float)((word >> i) & 1u);
+    const float2 rs = stat_of(s);
+    const float l = (x[s] + bias_i) - rs.x;          // log-softmax
+    const float g = (expf(l) * rs.y - bit) * inv_batch;
+    v[s] = (interior || (row < batch && item < cols)) ? g : 0.f;
+  }
+}
+
+// dW_p1 tile [32 items][h] and db_p1: workgroup = one item tile, wave q takes row tiles q, q+4, ...
+__global__ __launch_bounds__(kDecWaves* NR_WAVE) void vae_dwp1_mfma_kernel(
+    const float* __restrict__ S, int64_t ld, int batch, int cols, int h, const float* __restrict__ bias,
+    const float2* __restrict__ stat, float inv_batch, const uint32_t* __restrict__ bitmap, int bitmap_words,
+    const float* __restrict__ G1, float* __restrict__ dWp1, float* __restrict__ dbp1) {
+  __shared__ float s_c[kDecWaves][16 * NR_WAVE];
+  __shared__ float s_cs[kDecWaves][kDecTile];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hlf = lane >> 5, i = lane & 31;
+  const int t = blockIdx.x, item0 = t * kDecTile;
+  const float b = item0 + i < cols ? bias[item0 + i] : 0.f;
+  f32x16 c2 = {0};
+  float cs = 0.f;
+  const int n_rt = (batch + kDecTile - 1) / kDecTile;
+  for (int rt = wave; rt < n_rt; rt += kDecWaves) {
+    const int row0 = rt * kDecTile;
+    float2 st[16];
+    float hb[16];
+    if (row0 + kDecTile <= batch && h == kDecTile) {         // full row tile, full width: constant strides
+      const float2* sp = stat + row0 + hlf;
+      const float* gp = G1 + (int64_t)(row0 + hlf) * kDecTile + i;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        st[s] = sp[2 * s];
+        hb[s] = gp[2 * s * kDecTile];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int row = row0 + 2 * s + hlf;
+        st[s] = stat[min(row, batch - 1)];
+        hb[s] = (row < batch && i < h) ? G1[(int64_t)min(row, batch - 1) * h + min(i, h - 1)] : 0.f;
+      }
+    }
+    float v[16];
+    vae_grad_tile(S, ld, batch, cols, row0, item0, t, b, [&](int s2) { return st[s2]; }, bitmap, bitmap_words,
+                  inv_batch, lane, v);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      cs += v[s];
+      c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s], hb[s], c2, 0, 0, 0);   // A = G(item, row), B = g1(row, col)
+    }
+  }
+  cs += __shfl_xor(cs, 32, NR_WAVE);
+  if (hlf == 0) s_cs[wave][i] = cs;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) s_c[wave][reg * NR_WAVE + lane] = c2[reg];
+  __syncthreads();
+  for (int e = tid; e < 16 * NR_WAVE; e += kDecWaves * NR_WAVE) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < kDecWaves; ++w) sum += s_c[w][e];
+    const int reg = e >> 6, ln = e & 63;
+    const int m = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), n = ln & 31;   // C/D map: row m (item), col n
+    if (item0 + m < cols && n < h) dWp1[(int64_t)(item0 + m) * h + n] = sum;
+  }
+  if (tid < kDecTile && item0 + tid < cols) {
+    float bs = 0.f;
+#pragma unroll
+    for (int w = 0; w < kDecWaves; ++w) bs += s_cs[w][tid];
+    dbp1[item0 + tid] = bs;
+  }
+}
+
+// dg1 partial [32 rows][h] of one item range: workgroup = (row tile, item range), wave q takes the
+// range's tiles q, q+4, ...
+__global__ __launch_bounds__(kDecWaves* NR_WAVE) void vae_dg1_mfma_kernel(
+    const float* __restrict__ S, int64_t ld, int batch, int cols, int h, const float* __restrict__ bias,
+    const float2* __restrict__ stat, float inv_batch, const uint32_t* __restrict__ bitmap, int bitmap_words,
+    const float* __restrict__ Wp1, float* __restrict__ part, int tiles_per_range, int rows_pad) {
+  __shared__ float s_tile[kDecWaves][kDecTile * kDecTileLd];
+  __shared__ float s_c[kDecWaves][16 * NR_WAVE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hlf = lane >> 5, i = lane & 31;
+  const int row0 = blockIdx.x * kDecTile;
+  const int n_tiles = (cols + kDecTile - 1) / kDecTile;
+  const int t_begin = blockIdx.y * tiles_per_range, t_end = min(n_tiles, t_begin + tiles_per_range);
+  __shared__ float2 s_stat[kDecTile];                          // (lse, n_b) of the workgroup's row tile
+  if (tid < kDecTile) s_stat[tid] = stat[min(row0 + tid, batch - 1)];
+  __syncthreads();
+  float* tile = s_tile[wave];
+  f32x16 c1 = {0};
+  for (int t = t_begin + wave; t < t_end; t += kDecWaves) {
+    const int item0 = t * kDecTile;
+    const float b = item0 + i < cols ? bias[item0 + i] : 0.f;
+    float wb[16];                                   // W_p1 rows of the tile: 128-byte rows, two per instruction
+    if (item0 + kDecTile <= cols && h == kDecTile) {
+      const float* wp = Wp1 + (int64_t)(item0 + hlf) * kDecTile + i;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wb[k] = wp[2 * k * kDecTile];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int it = item0 + 2 * k + hlf;
+        wb[k] = (it < cols && i < h) ? Wp1[(int64_t)min(it, cols - 1) * h + min(i, h - 1)] : 0.f;
+      }
+    }
+    float v[16];
+    vae_grad_tile(S, ld, batch, cols, row0, item0, t, b, [&](int s2) { return s_stat[2 * s2 + hlf]; }, bitmap,
+                  bitmap_words, inv_batch, lane, v);
+    // transpose through the wave's LDS tile: lanes over rows, items become the contraction index
+#pragma unroll
+    for (int s = 0; s < 16; ++s) tile[(2 * s + hlf) * kDecTileLd + i] = v[s];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float gt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gt[k] = tile[i * kDecTileLd + 2 * k + hlf];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[k], wb[k], c1, 0, 0, 0);   // A = G(row, item), B = W(item, col)
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) s_c[wave][reg * NR_WAVE + lane] = c1[reg];
+  __syncthreads();
+  for (int e = tid; e < 16 * NR_WAVE; e += kDecWaves * NR_WAVE) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < kDecWaves; ++w) sum += s_c[w][e];
+    const int reg = e >> 6, ln = e & 63;
+    const int m = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), n = ln & 31;   // row m, col n
+    part[((int64_t)blockIdx.y * rows_pad + row0 + m) * kMaxD + n] = sum;
+  }
+}
+
+// the item ranges' partial sums added in range order; 8 loads in flight per thread
+__global__ __launch_bounds__(256) void vae_dg1_reduce_n_kernel(const float* __restrict__ part, int n_parts,
+                                                               int rows_pad, int batch, int h,
+                                                               float* __restrict__ dG1) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= batch * h) return;
+  const int r = idx / h, j = idx % h;
+  const float* p = part + (int64_t)r * kMaxD + j;
+  const int64_t stride = (int64_t)rows_pad * kMaxD;
+  float sum = 0.f;
+  for (int k0 = 0; k0 < n_parts; k0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = p[(int64_t)min(k0 + k, n_parts - 1) * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k0 + k < n_parts) sum += t[k];
+  }
+  dG1[idx] = sum;
+}
+
+// NEUREC_VAE_DECODER_VALU=1 keeps the first design (in-place dlogits + two VALU passes)
+bool vae_decoder_valu() {
+  static const bool v = [] { const char* e = getenv("NEUREC_VAE_DECODER_VALU"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // ----------------------------------------------------------------------------
 // Middle of the backward pass, one wave per batch row:
 //   da3 = dg1·act'(g1);  dz = da3·W_p0ᵀ;  dmu = dz + anneal·mu/B;
@@ -598,13 +875,17 @@ int nrhip_add_row_bias(float* d_S, int64_t ld, int batch, int cols, const float*
 int nrhip_vae_workspace_bytes(int batch, int cols, size_t* bytes) {
   NR_REQUIRE(bytes && batch >= 0 && cols >= 1, NR_ERR_ARG, "vae_workspace_bytes: bad arguments");
   const size_t rows = (size_t)(batch > 0 ? batch : 1);
-  // positive-item bit rows of the softmax gradient, then the dg1 partial sums per item range
+  // positive-item bit rows of the softmax gradient, then the dg1 partial sums (per item range: the VALU
+  // form; per workgroup: the matrix-core form) and the per-row softmax statistics
+  const size_t rows_pad = (rows + kDecTile - 1) / kDecTile * kDecTile;
+  const size_t parts = std::max((size_t)kDg1Split * rows, (size_t)kDg1Ranges * rows_pad);
   *bytes = nr_align_up(rows * (size_t)((cols + 31) / 32) * sizeof(uint32_t), 256) +
-           (size_t)kDg1Split * rows * kMaxD * sizeof(float);
+           parts * kMaxD * sizeof(float) + nr_align_up(rows * sizeof(float2), 256);
   return NR_OK;
 }
 
-/* d_S holds g1·W_p1ᵀ (no bias) on entry and dLoss/dlogits on exit. */
+/* d_S holds g1·W_p1ᵀ (no bias) on entry; its contents on exit are unspecified (the logits, or dLoss/dlogits
+ * in the VALU form). */
 int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int h,
                                 const float* d_bp1, const int64_t* d_indptr,
                                 const int32_t* d_indices, const int32_t* d_rows,
@@ -621,6 +902,32 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
              "vae_decoder_loss_grad: workspace too small");
   float* part = (float*)((char*)d_ws + bits_bytes);
   hipStream_t st = (hipStream_t)stream;
+  if (!vae_decoder_valu()) {
+    // matrix-core form: statistics, then one read of the logits per gradient
+    const int rows_pad = (batch + kDecTile - 1) / kDecTile * kDecTile;
+    const size_t parts_bytes = (size_t)kDg1Ranges * rows_pad * kMaxD * sizeof(float);
+    NR_REQUIRE(ws_bytes >= bits_bytes + parts_bytes + nr_align_up((size_t)batch * sizeof(float2), 256),
+               NR_ERR_WORKSPACE, "vae_decoder_loss_grad: workspace too small (nrhip_vae_workspace_bytes)");
+    float2* stat = (float2*)((char*)part + parts_bytes);
+    hipLaunchKernelGGL(vae_softmax_stats_kernel, dim3(batch), dim3(256), 0, st, d_S, ld, cols, d_bp1, d_indptr,
+                       d_indices, d_rows, stat, d_nll, (uint32_t*)d_ws, words);
+    NR_LAUNCH_CHECK();
+    const int n_tiles = (cols + kDecTile - 1) / kDecTile;
+    const float inv_b = 1.0f / (float)batch;
+    hipLaunchKernelGGL(vae_dwp1_mfma_kernel, dim3(n_tiles), dim3(kDecWaves * NR_WAVE), 0, st, d_S, ld, batch, cols,
+                       h, d_bp1, stat, inv_b, (const uint32_t*)d_ws, words, d_G1, d_dWp1, d_dbp1);
+    NR_LAUNCH_CHECK();
+    const int per_range = (n_tiles + kDg1Ranges - 1) / kDg1Ranges;
+    const int n_ranges = (n_tiles + per_range - 1) / per_range;
+    hipLaunchKernelGGL(vae_dg1_mfma_kernel, dim3(rows_pad / kDecTile, n_ranges), dim3(kDecWaves * NR_WAVE), 0, st,
+                       d_S, ld, batch, cols, h, d_bp1, stat, inv_b, (const uint32_t*)d_ws, words, d_Wp1, part,
+                       per_range, rows_pad);
+    NR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vae_dg1_reduce_n_kernel, dim3((batch * h + 255) / 256), dim3(256), 0, st, part, n_ranges,
+                       rows_pad, batch, h, d_dG1);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+  }
   hipLaunchKernelGGL(vae_softmax_grad_kernel, dim3(batch), dim3(256), 0, st, d_S, ld, cols, d_bp1,
                      d_indptr, d_indices, d_rows, 1.0f / (float)batch, d_nll, (uint32_t*)d_ws, words);
   NR_LAUNCH_CHECK();

@@ -179,3 +179,16 @@ def test_multivae_rejects_unbuilt_widths():
     eng = _engine(R, bad)
     with pytest.raises(NotImplementedError):
         eng.logits(_dev(np.arange(8, dtype=np.int32)))
+
+
+def test_valu_decoder_form_still_passes_this_file():
+    """NEUREC_VAE_DECODER_VALU=1 keeps the first decoder-gradient design (dlogits in place, two VALU
+    passes) as an A/B: the same oracle comparisons of this file hold for it."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NEUREC_VAE_DECODER_VALU="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p",
+                          "no:cacheprovider", "-k", "not valu_decoder_form"], env=env, capture_output=True,
+                         text=True, timeout=280, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]
