@@ -72,6 +72,7 @@ vae_eval(); torch.cuda.synchronize(); t0 = time.perf_counter(); r = vae_eval(); 
 dt = time.perf_counter() - t0
 out["multivae"] = {"ms_per_step": ms, "users_per_sec_train": 512 / ms * 1e3, "batch": 512, "p_dim": [16, 32],
                    "eval_users_per_sec": users.numel() / dt, "ndcg@10": float(r.mean(0)[2 * 20 + 9].item()),
-                   "note": "per-user inputs at evaluation (predict_accumulates_rows=False); a step streams the "
-                           "[512][I] logits slab three times (softmax/grad in place, dW_p1, dg1)"}
+                   "note": "per-user inputs at evaluation (predict_accumulates_rows=False); a step writes the "
+                           "[512][I] logits once and reads them three times (row statistics, dW_p1, dg1 — "
+                           "the two gradients on the matrix cores, dLoss/dlogits never stored)"}
 print(json.dumps(out))
