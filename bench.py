@@ -290,10 +290,15 @@ def main():
             for k in range(2 * args.layers):
                 lg.A.matmul(lg.X, out=(lg.Ya, lg.Yb)[k % 2], addend=lg.H)
             continue
-        lg.propagate()                                   # L forward launches
+        # the plain pass Y = A·X — the launch the step's full hops are (no running-sum or addend streams:
+        # the 49.6 MB of SURVEY 8d's formula are exactly its bytes), L forward + L backward operands
+        src = lg.E0
+        for k in range(args.layers):
+            lg.A.matmul(src, out=(lg.Ea, lg.Eb)[k % 2])
+            src = (lg.Ea, lg.Eb)[k % 2]
         g = lg.H
-        for k in range(args.layers):                     # L backward launches
-            lg.At.matmul(g, out=(lg.Ga, lg.Gb)[k % 2], addend=lg.H)
+        for k in range(args.layers):
+            lg.At.matmul(g, out=(lg.Ga, lg.Gb)[k % 2])
             g = (lg.Ga, lg.Gb)[k % 2]
     ev1.record(); torch.cuda.synchronize()
     spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
