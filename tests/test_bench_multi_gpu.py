@@ -37,3 +37,23 @@ def test_two_rank_bench_line(mode, port):
     if mode != "rowshard":
         assert d["eval"]["n_users"] > 0 and 0.0 <= d["eval"]["ndcg@10"] <= 1.0
     assert d["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("extra", [["--scale", "0.05", "--batch", "256"],
+                                   ["--shape", "config4", "--scale", "0.0005", "--dp-mode", "rowshard", "--dim", "128",
+                                    "--batch", "256"]], ids=["gowalla-small", "config4-small"])
+def test_one_rank_bench_line(extra):
+    """The default single-process line (training + evaluation + BPR-MF legs) and the config-4 path
+    (device-generated graph, row-sharded engine) on small shapes: contract fields present and finite."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    assert all(x == x and abs(x) < 1e9 for x in d["final_loss"])
+    if "config4" not in extra:
+        assert "ndcg10_oracle_absdiff" not in d["eval"]              # that comparison belongs to the CPU-baseline leg
+        assert d["mf"]["ms_per_step"] > 0 and d["eval"]["roofline"]["frac"] > 0
