@@ -76,13 +76,15 @@ class UniEvaluator(HIPEvaluator):
             raise TypeError("'test_user' must be a list, tuple, set or numpy array!")
         test_users = list(test_users)
         if self.user_neg_test is None and hasattr(model, "get_eval_factors"):
-            return self._format(self._evaluate_factors(model, test_users))
+            factors = model.get_eval_factors()          # None: this model state has no factor form
+            if factors is not None:
+                return self._format(self._evaluate_factors(model, test_users, factors))
         return self._format(self._evaluate_scores(model, test_users))
 
-    def _evaluate_factors(self, model, test_users):
+    def _evaluate_factors(self, model, test_users, factors=None):
         import torch
         from ....trainer import FullRankEvaluator
-        P, Q = model.get_eval_factors()
+        P, Q = factors if factors is not None else model.get_eval_factors()
         st = self._device(Q.shape[0])
         if "ranker" not in st:
             st["ranker"] = FullRankEvaluator(st["train"], st["test"], self.metrics, self.max_top,

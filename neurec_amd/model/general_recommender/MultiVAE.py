@@ -127,6 +127,15 @@ class MultiVAE(AbstractRecommender):
     def evaluate(self):
         return self.evaluator.evaluate(self)
 
+    def get_eval_factors(self):
+        """Device factor tables for the evaluator's on-GPU path ([g1(u) | 1], [W_p1 | b_p1]: their inner
+        products are predict()'s logits bit for bit) — only with per-user inputs; the reference's
+        accumulating predict rows depend on how the test users are batched, so that mode returns None and
+        is scored through predict()."""
+        if self.predict_accumulates_rows:
+            return None
+        return self.engine.eval_factors()
+
     # ------------------------------------------------------------------ inference
     def _predict_rows(self, user_ids):
         """CSR of the input rows of one predict call (see the module docstring)."""

@@ -711,6 +711,28 @@ class MultiVAEEngine:
         return (self.H1[:B], self.MU[:B], self.LOGVAR[:B], self.EPSSTD[:B], self.ZS[:B],
                 self.G1[:B], self.KLb[:B])
 
+    def eval_factors(self, csr=None):
+        """(user factors [rows][h + 1], item factors [n_items][h + 1]) whose inner products are the
+        p-network logits at is_training = 0 of every CSR row (MultiVAE.py:186-206 with per-user inputs):
+        user row = [g1(u) | 1], item row = [W_p1[i] | b_p1[i]].  The bias rides as the LAST factor
+        column, so the k-ascending fmaf chain of the scoring kernels ends with fmaf(1, b, dot) = dot + b
+        rounded once — bit for bit the `matmul + bias` of logits() — and the evaluation can take the
+        factor path (pruned: no [users][I] logits slab, no bias pass, no mask pass)."""
+        P = self.P
+        csr = self.csr if csr is None else csr
+        n, h = csr.n_rows, P["Wp1t"].shape[1]
+        dev = P["Wp1t"].device
+        z = P["Wp0"].shape[0]
+        bufs = (torch.empty((n, h), device=dev), torch.empty((n, z), device=dev), torch.empty((n, z), device=dev),
+                torch.empty((n, z), device=dev), torch.empty((n, z), device=dev), torch.empty((n, h), device=dev),
+                torch.empty(n, device=dev))
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        E.vae_encode(csr, rows, P["Wq0"], P["bq0"], P["Wq1"], P["bq1"], P["Wp0"], P["bp0"], self.act, 1.0, 0.0,
+                     self.seed, self.t, bufs)
+        users = torch.cat([bufs[5], torch.ones((n, 1), device=dev)], dim=1).contiguous()
+        items = torch.cat([P["Wp1t"], P["bp1"].reshape(-1, 1)], dim=1).contiguous()
+        return users, items
+
     def logits(self, rows, csr=None, out=None):
         """p_graph output for the given CSR rows at is_training=0, keep_prob=1 (MultiVAE.py:186-206
         feeds only input_ph).  Any number of rows (processed max_batch at a time); returns a

@@ -70,8 +70,16 @@ def vae_eval():
     return torch.cat(res)
 vae_eval(); torch.cuda.synchronize(); t0 = time.perf_counter(); r = vae_eval(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+# the same evaluation through the factor path ([g1 | 1]·[W_p1 | b_p1], pruned: no logits slab)
+def vae_eval_factors():
+    pf, qf = vae.eval_factors()
+    return ev.evaluate_factors(pf, qf, users)
+vae_eval_factors(); torch.cuda.synchronize(); t0 = time.perf_counter(); mf_ = vae_eval_factors(); torch.cuda.synchronize()
+dtf = time.perf_counter() - t0
 out["multivae"] = {"ms_per_step": ms, "users_per_sec_train": 512 / ms * 1e3, "batch": 512, "p_dim": [16, 32],
-                   "eval_users_per_sec": users.numel() / dt, "ndcg@10": float(r.mean(0)[2 * 20 + 9].item()),
+                   "eval_users_per_sec": users.numel() / dtf, "ndcg@10": float(mf_[2 * 20 + 9]),
+                   "eval_users_per_sec_logits_slab": users.numel() / dt,
+                   "ndcg@10_logits_slab": float(r.mean(0)[2 * 20 + 9].item()),
                    "note": "per-user inputs at evaluation (predict_accumulates_rows=False); a step writes the "
                            "[512][I] logits once and reads them three times (row statistics, dW_p1, dg1 — "
                            "the two gradients on the matrix cores, dLoss/dlogits never stored)"}

@@ -187,6 +187,21 @@ def test_multivae_config_drops_in(tmp_path):
     assert np.abs(solo[0] - want[0]).max() < 1e-5 and np.abs(solo[1] - want[1]).max() > 1e-4
     cand = model.predict(users, [[1, 2, 3]] * 4)
     assert np.allclose(cand[2], solo[2][[1, 2, 3]])
+    # per-user inputs have a factor form ([g1(u) | 1]·[W_p1 | b_p1] = the logits, bias as the last factor
+    # column): the evaluator's on-GPU factor path prints the same line as the predict() path, and the
+    # factor scores ARE predict()'s numbers
+    uni = model.evaluator.evaluator
+    test_users = list(uni.user_pos_test.keys())
+    Pf, Qf = model.get_eval_factors()
+    assert Pf.shape == (model.num_users, 33) and Qf.shape == (model.num_items, 33)
+    from oracle import native
+    S = native.score_gemm(Pf.cpu().numpy(), np.asarray(users, np.int32), Qf.cpu().numpy())
+    np.testing.assert_array_equal(S, solo)
+    line_factor = uni._format(uni._evaluate_factors(model, test_users))
+    line_scores = uni._format(uni._evaluate_scores(model, test_users))
+    assert line_factor == line_scores
+    model.predict_accumulates_rows = True
+    assert model.get_eval_factors() is None                  # the accumulating rows have no factor form
 
 
 def test_mf_pointwise_and_other_learners_drop_in(tmp_path):
