@@ -388,6 +388,20 @@ def main():
                                         "bandwidth-bound"},
                    "sweep_ms_per_step": sweep_dt * 1e3,
                    "sweep_GBps": 2 * 4 * (U + I) * 64 * 4 / sweep_dt / 1e9}
+        if not args.no_eval:
+            # configs[1] names the evaluator too: the BPR-MF tables through the same full-rank path
+            tu = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
+            mf_ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch,
+                                      pruned=args.eval_mode == "pruned")
+            mf_ev.evaluate_factors(mf.P, mf.Q, tu)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mm = mf_ev.evaluate_factors(mf.P, mf.Q, tu)
+            torch.cuda.synchronize()
+            mf_edt = time.perf_counter() - t0
+            mf_info["eval"] = {"users_per_sec": tu.numel() / mf_edt, "ms": mf_edt * 1e3, "n_users": int(tu.numel()),
+                               "ndcg@10": float(mm[2 * 20 + 9])}
+            del mf_ev
 
     # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)
     eval_info = None
