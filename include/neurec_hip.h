@@ -224,7 +224,7 @@ int nrhip_adam_dense_tf(float* d_var, float* d_m, float* d_v, float* d_grad, int
 int nrhip_adam_dense_tf2(float* d_var, float* d_m, float* d_v, const float* d_grad_a,
                          const float* d_grad_b, int64_t n, float alpha, float beta1, float beta2,
                          float eps, void* stream);
-/* Dense ApplyAdam on up to 16 tensors in one launch (a model's weight matrices and biases:
+/* Dense ApplyAdam on up to 32 tensors in one launch (a model's weight matrices and biases:
  * util/learner.py:9-10 applied to every trainable of NGCF.py:91-110 / MultiVAE.py:47-70).  Host
  * arrays of device pointers and lengths; clear_grad_host (optional) as in nrhip_adam_dense_tf. */
 int nrhip_adam_dense_tf_multi(int n_tensors, float* const* d_vars_host, float* const* d_ms_host,

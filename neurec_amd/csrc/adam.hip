@@ -359,7 +359,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Several dense TF-Adam updates in one launch (a model's weight matrices and biases: sixteen
 // 5-us launches per NGCF step otherwise).  blockIdx.y = tensor.
-constexpr int kMaxMulti = 16;
+constexpr int kMaxMulti = 32;        // NGCF with two layers has 17 trainables: one launch
 struct MultiAdam {
   float* var[kMaxMulti]; float* m[kMaxMulti]; float* v[kMaxMulti]; float* grad[kMaxMulti];
   int64_t n[kMaxMulti];
@@ -504,7 +504,7 @@ int nrhip_adam_dense_tf2(float* d_var, float* d_m, float* d_v, const float* d_gr
   return NR_OK;
 }
 
-/* Dense TF-1.12 ApplyAdam on up to 16 tensors in one launch (host arrays of device pointers and
+/* Dense TF-1.12 ApplyAdam on up to 32 tensors in one launch (host arrays of device pointers and
  * lengths; clear_grad[k] != 0 zeroes tensor k's gradient as nrhip_adam_dense_tf does). */
 int nrhip_adam_dense_tf_multi(int n_tensors, float* const* d_vars, float* const* d_ms,
                               float* const* d_vs, float* const* d_grads, const int64_t* sizes,

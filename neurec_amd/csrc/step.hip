@@ -428,7 +428,7 @@ int nrhip_ngcf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, con
   }
   if (!dego) NR_TRY(nrhip_copy2d(b.dOut, ldo, b.gE0, d, b.n_nodes, d, stream));
   else NR_TRY(nrhip_add2d(b.dOut, ldo, dego, d, b.gE0, d, b.n_nodes, d, stream));
-  // every trainable in launches of up to 16 tensors
+  // every trainable in one launch (up to 32 tensors per launch)
   float* vars[1 + 4 * NRHIP_NGCF_MAX_LAYERS]; float* ms[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
   float* vs[1 + 4 * NRHIP_NGCF_MAX_LAYERS]; float* gs[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
   int64_t sizes[1 + 4 * NRHIP_NGCF_MAX_LAYERS];
@@ -440,8 +440,8 @@ int nrhip_ngcf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, con
       vars[n] = b.W[k][j]; ms[n] = b.mW[k][j]; vs[n] = b.vW[k][j]; gs[n] = b.gW[k][j];
       sizes[n] = (j & 1) ? d : (int64_t)d * d; clear[n] = 0; ++n;
     }
-  for (int lo = 0; lo < n; lo += 16) {
-    const int m = std::min(16, n - lo);
+  for (int lo = 0; lo < n; lo += 32) {
+    const int m = std::min(32, n - lo);
     NR_TRY(nrhip_adam_dense_tf_multi(m, vars + lo, ms + lo, vs + lo, gs + lo, sizes + lo, clear + lo, alpha, beta1,
                                      beta2, eps, stream));
   }

@@ -329,9 +329,9 @@ def adam_dense(var, m, v, grad, st, clear_grad=True):
 
 
 def adam_dense_multi(tensors, st):
-    """Dense TF-Adam on several (var, m, v, grad[, clear_grad]) tuples in one launch (<= 16 per launch)."""
-    for lo in range(0, len(tensors), 16):
-        part = tensors[lo:lo + 16]
+    """Dense TF-Adam on several (var, m, v, grad[, clear_grad]) tuples in one launch (<= 32 per launch)."""
+    for lo in range(0, len(tensors), 32):
+        part = tensors[lo:lo + 32]
         n = len(part)
         for t in part:
             for x in t[:4]:
