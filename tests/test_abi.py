@@ -80,3 +80,19 @@ def test_no_product_import_of_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/neurec_hip.h is the boundary a C / cgo / JNI binder compiles against: it must be valid C99
+    on its own (no C++ in the signatures, every type it names declared by it or <stdint.h>/<stddef.h>)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "neurec_hip.h"\n'
+                   "int main(void) { nrhip_lightgcn_buffers a; nrhip_mf_buffers b; nrhip_ngcf_buffers c;\n"
+                   "  (void)a; (void)b; (void)c; return NRHIP_ABI_VERSION == 3 ? 0 : 1; }\n")
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                          "-o", str(tmp_path / "use_header.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
