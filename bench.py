@@ -486,7 +486,7 @@ def main():
                         "by latency, not by HBM" % (top_k + 1)}
 
     line = {
-        "metric": "BPR triplets/sec (LightGCN-gowalla)", "value": triplets_per_s,
+        "metric": "BPR triplets/sec (LightGCN-%s)" % args.shape, "value": triplets_per_s,
         "unit": "triplets/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
