@@ -167,7 +167,9 @@ int nrhip_randint_choice_batch(int high, int n_req, int64_t total, const int64_t
  *          pointwise (user, item) instances.  Batch k covers stream elements
  *          [k*batch, min((k+1)*batch, n_total)); its n_cls*len keys are written at
  *          d_plan_out + n_cls*k*batch (n_cls = 3 with d_third, else 2).  Item ids are
- *          offset by n_users in the keys.  (n_cls-1)*batch <= 16384.
+ *          offset by n_users in the keys.  Batches of up to (n_cls-1)*batch = 16384 item
+ *          occurrences are sorted by one workgroup each in one launch; larger ones by a
+ *          segmented multi-workgroup network (a few launches per call).
  *   grad:  gathers p_u,q_i,q_j; x=<p,q_i>-<p,q_j>; loss_b=softplus(-x);
  *          row gradients (duplicates summed in batch order) STORED into the rows of
  *          dense d_GP/d_GQ the batch touches (all other rows are left alone: keep them
@@ -590,7 +592,8 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_use
                             float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream);
 int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, void* stream);
 /* Ordered sums of gradient rows that arrive from other ranks (row-sharded tables): sort the
- * keys (local row << 32 | global occurrence position) — n <= 16384 per call — then every row's run
+ * keys (local row << 32 | global occurrence position; any n: one LDS workgroup up to 16384 keys, the
+ * segmented multi-workgroup network beyond), then every row's run
  * is added in key order and stored, exactly the order of the single-process head on the global batch.
  * d_index_of_pos[position] = index of that occurrence's row in d_src. */
 int nrhip_sort_u64(uint64_t* d_keys, int n, void* stream);

@@ -964,6 +964,123 @@ __global__ __launch_bounds__(kPlanThreads) void sort_u64_kernel(uint64_t* __rest
   for (int k = threadIdx.x; k < n; k += kPlanThreads) keys[k] = s_key[k];
 }
 
+// ---- batches beyond one workgroup's LDS: a segmented multi-workgroup sort -----------------------
+// Segments are the plan's (batch, side) key ranges, or one plain array.  The network is the
+// all-ascending bitonic form — a merge of size k is one "flip" (partner = mirror position inside
+// the k-block) followed by "disperse" steps (partner = i + j) — so positions >= n act as +inf
+// without being stored: a compare with a missing partner is skipped.  Steps whose partners lie
+// inside one kPlanMaxKeys-chunk run in LDS (seg_sort_local / seg_disperse_local), the others as
+// one global pass each.
+struct SegLayout {
+  int64_t n_total;      // plain: keys in the one segment; plan: triplets in the stream
+  int batch, n_cls;     // plan layout (batch == 0: plain array)
+};
+
+__device__ __forceinline__ void seg_range(const SegLayout& L, int seg, int64_t& base, int& n) {
+  if (L.batch == 0) {
+    base = 0;
+    n = (int)L.n_total;
+    return;
+  }
+  const int b = seg >> 1;
+  const int64_t first = (int64_t)b * L.batch;
+  const int nb = (int)((L.n_total - first) < (int64_t)L.batch ? (L.n_total - first) : (int64_t)L.batch);
+  base = first * L.n_cls + ((seg & 1) ? nb : 0);
+  n = (seg & 1) ? (L.n_cls - 1) * nb : nb;
+}
+
+// every occurrence's key, unsorted, at its segment's position (the small-batch kernel makes them in LDS)
+__global__ __launch_bounds__(256) void plan_fill_kernel(
+    const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+    const int32_t* __restrict__ third, int64_t n_total, int batch, int n_cls, int n_users,
+    uint64_t* __restrict__ skey) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;           // triplet index in the stream
+  if (e >= n_total) return;
+  const int64_t first = (e / batch) * batch;
+  const int nb = (int)((n_total - first) < (int64_t)batch ? (n_total - first) : (int64_t)batch);
+  const int t = (int)(e - first);
+  uint64_t* out = skey + first * n_cls;
+  out[t] = ((uint64_t)(uint32_t)users[e] << 32) | (uint32_t)t;
+  out[nb + t] = ((uint64_t)(uint32_t)(n_users + items[e]) << 32) | (uint32_t)(nb + t);
+  if (n_cls == 3) out[2 * nb + t] = ((uint64_t)(uint32_t)(n_users + third[e]) << 32) | (uint32_t)(2 * nb + t);
+}
+
+__device__ __forceinline__ void lds_cmpswap(uint64_t* s, int lo, int hi) {
+  const uint64_t a = s[lo], b = s[hi];
+  if (a > b) {
+    s[lo] = b;
+    s[hi] = a;
+  }
+}
+
+// grid (chunks, segments): FULL=true sorts each chunk (all merges up to the chunk size); FULL=false
+// runs only the disperse steps j = chunk/2 .. 1 that finish a larger merge
+template <bool FULL>
+__global__ __launch_bounds__(kPlanThreads) void seg_local_kernel(uint64_t* __restrict__ keys, SegLayout L) {
+  extern __shared__ uint64_t s_key[];
+  int64_t base;
+  int n;
+  seg_range(L, blockIdx.y, base, n);
+  const int c0 = blockIdx.x * kPlanMaxKeys;
+  if (c0 >= n) return;
+  uint64_t* seg = keys + base;
+  for (int k = threadIdx.x; k < kPlanMaxKeys; k += kPlanThreads) s_key[k] = (c0 + k < n) ? seg[c0 + k] : ~0ull;
+  __syncthreads();
+  if (FULL) {
+    for (int k = 2; k <= kPlanMaxKeys; k <<= 1) {
+      for (int i = threadIdx.x; i < (kPlanMaxKeys >> 1); i += kPlanThreads) {       // flip
+        const int q = i / (k >> 1), r = i - q * (k >> 1);
+        lds_cmpswap(s_key, q * k + r, q * k + (k - 1 - r));
+      }
+      __syncthreads();
+      for (int j = k >> 2; j > 0; j >>= 1) {                                        // disperse
+        for (int i = threadIdx.x; i < (kPlanMaxKeys >> 1); i += kPlanThreads) {
+          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+          lds_cmpswap(s_key, lo, lo | j);
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int j = kPlanMaxKeys >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (kPlanMaxKeys >> 1); i += kPlanThreads) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        lds_cmpswap(s_key, lo, lo | j);
+      }
+      __syncthreads();
+    }
+  }
+  for (int k = threadIdx.x; k < kPlanMaxKeys; k += kPlanThreads)
+    if (c0 + k < n) seg[c0 + k] = s_key[k];
+}
+
+// one global step over every segment: FLIP: partner = mirror inside the k-block; else partner = i + j
+template <bool FLIP>
+__global__ __launch_bounds__(256) void seg_global_kernel(uint64_t* __restrict__ keys, SegLayout L, int kj,
+                                                         int half_np2) {
+  int64_t base;
+  int n;
+  seg_range(L, blockIdx.y, base, n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= half_np2) return;
+  int lo, hi;
+  if (FLIP) {
+    const int q = i / (kj >> 1), r = i - q * (kj >> 1);
+    lo = q * kj + r;
+    hi = q * kj + (kj - 1 - r);
+  } else {
+    lo = ((i & ~(kj - 1)) << 1) | (i & (kj - 1));
+    hi = lo | kj;
+  }
+  if (hi >= n) return;                          // the partner is +inf: nothing moves
+  uint64_t* seg = keys + base;
+  const uint64_t a = seg[lo], b = seg[hi];
+  if (a > b) {
+    seg[lo] = b;
+    seg[hi] = a;
+  }
+}
+
 template <int CPL>
 __global__ __launch_bounds__(256) void rows_sum_sorted_kernel(const uint64_t* __restrict__ skey, int n,
                                                               const int32_t* __restrict__ index_of_pos,
@@ -1012,19 +1129,55 @@ int plan_pow2(int n) {
   return p;
 }
 
+// 128 KB of dynamic LDS: the attribute is per device (a process may drive several GPUs)
+int lds_attr_once(const void* kernel, int slot) {
+  static std::atomic<bool> set[4][64];
+  int dev = 0;
+  NR_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !set[slot][dev].load(std::memory_order_acquire)) {
+    NR_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kPlanMaxKeys * (int)sizeof(uint64_t)));
+    if (dev >= 0 && dev < 64) set[slot][dev].store(true, std::memory_order_release);
+  }
+  return NR_OK;
+}
+
+// ascending sort of every segment of `keys` (segments of at most n_max keys), any size
+int sort_segments(uint64_t* keys, SegLayout L, int n_segs, int n_max, hipStream_t st) {
+  if (n_max <= 1) return NR_OK;
+  NR_TRY(lds_attr_once((const void*)seg_local_kernel<true>, 2));
+  NR_TRY(lds_attr_once((const void*)seg_local_kernel<false>, 3));
+  const int np2 = plan_pow2(n_max);
+  const unsigned chunks = (unsigned)((n_max + kPlanMaxKeys - 1) / kPlanMaxKeys);
+  const size_t lds = (size_t)kPlanMaxKeys * sizeof(uint64_t);
+  hipLaunchKernelGGL(seg_local_kernel<true>, dim3(chunks, n_segs), dim3(kPlanThreads), lds, st, keys, L);
+  const dim3 ggrid((unsigned)((np2 / 2 + 255) / 256), n_segs);
+  for (int k = 2 * kPlanMaxKeys; k <= np2; k <<= 1) {
+    hipLaunchKernelGGL(seg_global_kernel<true>, ggrid, dim3(256), 0, st, keys, L, k, np2 / 2);
+    for (int j = k >> 2; j >= kPlanMaxKeys; j >>= 1)
+      hipLaunchKernelGGL(seg_global_kernel<false>, ggrid, dim3(256), 0, st, keys, L, j, np2 / 2);
+    hipLaunchKernelGGL(seg_local_kernel<false>, dim3(chunks, n_segs), dim3(kPlanThreads), lds, st, keys, L);
+  }
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
 int launch_plan(const int32_t* d_users, const int32_t* d_items, const int32_t* d_third,
                 int64_t n_total, int batch, int n_cls, int n_users, uint64_t* d_skey,
                 hipStream_t st) {
-  NR_REQUIRE((int64_t)(n_cls - 1) * batch <= kPlanMaxKeys, NR_ERR_UNSUPPORTED,
-             "bpr_plan: batch %d too large for the deterministic aggregation (at most %d item "
-             "occurrences per batch); NRHIP_ATOMIC_SCATTER=1 lifts the limit", batch, kPlanMaxKeys);
-  static bool attr_set = false;
-  if (!attr_set) {
-    NR_CHECK_HIP(hipFuncSetAttribute((const void*)bpr_plan_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     kPlanMaxKeys * (int)sizeof(uint64_t)));
-    attr_set = true;
+  if ((int64_t)(n_cls - 1) * batch > kPlanMaxKeys) {
+    // a batch's keys outgrow one workgroup's LDS: write them unsorted, then the segmented sort
+    NR_REQUIRE((int64_t)n_cls * batch < (1ll << 31), NR_ERR_UNSUPPORTED, "bpr_plan: batch %d too large", batch);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, d_users,
+                       d_items, d_third, n_total, batch, n_cls, n_users, d_skey);
+    NR_LAUNCH_CHECK();
+    const int64_t n_batches = (n_total + batch - 1) / batch;
+    NR_REQUIRE(2 * n_batches <= 65535, NR_ERR_UNSUPPORTED, "bpr_plan: %lld batches of %d in one call",
+               (long long)n_batches, batch);
+    const int nb_max = (int)(n_total < (int64_t)batch ? n_total : (int64_t)batch);
+    return sort_segments(d_skey, SegLayout{n_total, batch, n_cls}, (int)(2 * n_batches), (n_cls - 1) * nb_max, st);
   }
+  NR_TRY(lds_attr_once((const void*)bpr_plan_kernel, 0));
   const int nb_max = (int)(n_total < (int64_t)batch ? n_total : (int64_t)batch);
   const int np2_user = plan_pow2(nb_max), np2_item = plan_pow2((n_cls - 1) * nb_max);
   const int64_t n_batches = (n_total + batch - 1) / batch;
@@ -1079,17 +1232,13 @@ int nrhip_bpr_plan(const int32_t* d_users, const int32_t* d_items, const int32_t
                      d_plan_out, (hipStream_t)stream);
 }
 
-/* In-place ascending sort of n <= 16384 64-bit keys (one workgroup, LDS bitonic network). */
+/* In-place ascending sort of n 64-bit keys: one workgroup's LDS bitonic network up to 16384 keys, the
+ * segmented multi-workgroup network beyond. */
 int nrhip_sort_u64(uint64_t* d_keys, int n, void* stream) {
   NR_REQUIRE(d_keys && n >= 0, NR_ERR_ARG, "sort_u64: bad arguments");
-  NR_REQUIRE(n <= kPlanMaxKeys, NR_ERR_UNSUPPORTED, "sort_u64: %d keys (at most %d)", n, kPlanMaxKeys);
   if (n <= 1) return NR_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NR_CHECK_HIP(hipFuncSetAttribute((const void*)sort_u64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     kPlanMaxKeys * (int)sizeof(uint64_t)));
-    attr_set = true;
-  }
+  if (n > kPlanMaxKeys) return sort_segments(d_keys, SegLayout{n, 0, 0}, 1, n, (hipStream_t)stream);
+  NR_TRY(lds_attr_once((const void*)sort_u64_kernel, 1));
   const int np2 = plan_pow2(n);
   hipLaunchKernelGGL(sort_u64_kernel, dim3(1), dim3(kPlanThreads), (size_t)np2 * sizeof(uint64_t),
                      (hipStream_t)stream, d_keys, n, np2);

@@ -29,6 +29,11 @@ extern "C" void nrhip_set_error(const char* fmt, ...);
     }                                                                          \
   } while (0)
 
+#define NR_TRY(call)            \
+  do {                          \
+    const int rc_ = (call);     \
+    if (rc_ != NR_OK) return rc_; \
+  } while (0)
 #define NR_REQUIRE(cond, code, ...)                                            \
   do {                                                                         \
     if (!(cond)) {                                                             \

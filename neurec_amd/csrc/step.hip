@@ -22,17 +22,28 @@ struct NGCFCtx {
 
 struct MFCtx {
   nrhip_mf_buffers b;
+  bool alpha_tail_const = false;           // the last kAlphaTail step sizes are one value (see alpha_window)
   const uint64_t* marked_plan = nullptr;   // one-launch step: the plan whose rows the last step marked ...
   int marked_step = 0;                     // ... for this step index
 };
 
-}  // namespace
+constexpr int kAlphaTail = 256;
 
-#define NR_TRY(call)            \
-  do {                          \
-    int _rc = (call);           \
-    if (_rc != NR_OK) return _rc; \
-  } while (0)
+// Step sizes beyond the table.  TF's lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) stops changing once
+// both running fp32 powers vanish against 1 (t > ~17.3 k at beta2 = 0.999): from there on it is one
+// value.  A context whose table ends in kAlphaTail equal entries (checked once, at creation) serves any
+// later step from that tail: the kernels index the table with the true step numbers (a replay reaches
+// back at most lazy_period <= 64 steps, the lane-parallel load 63), so handing them the pointer moved
+// back by the excess makes every access land in the constant tail.  *out = NULL when the step cannot be
+// served (a table too short for its tail to be constant).
+const float* alpha_window(const MFCtx* c, int step_index) {
+  const nrhip_mf_buffers& b = c->b;
+  if (step_index < b.alpha_len) return b.alpha_tab;
+  if (!c->alpha_tail_const || b.lazy_period > 64) return nullptr;
+  return b.alpha_tab - (step_index - (b.alpha_len - 1));
+}
+
+}  // namespace
 
 extern "C" int nrhip_spmm_csr_adam(const void* plan, const int32_t* d_indices, const float* d_vals,
                                    const float* d_X, int d, float* d_addend, float* d_grad_b,
@@ -244,6 +255,13 @@ int nrhip_mf_ctx_create(const nrhip_mf_buffers* bufs, void** ctx_out) {
   MFCtx* c = new (std::nothrow) MFCtx();
   NR_REQUIRE(c, NR_ERR_ARG, "mf_ctx_create: out of host memory");
   c->b = b;
+  if (b.alpha_tab && b.alpha_len > kAlphaTail) {
+    float tail[kAlphaTail];
+    if (hipMemcpy(tail, b.alpha_tab + (b.alpha_len - kAlphaTail), sizeof(tail), hipMemcpyDeviceToHost) == hipSuccess) {
+      c->alpha_tail_const = true;
+      for (int k = 0; k < kAlphaTail; ++k) c->alpha_tail_const = c->alpha_tail_const && tail[k] == tail[kAlphaTail - 1];
+    }
+  }
   *ctx_out = c;
   return NR_OK;
 }
@@ -268,8 +286,10 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
   if (b.tw) {
     // gradient + exact lazy Adam in one launch (bpr.hip: mf_fused_step_kernel)
     NR_REQUIRE(one_table, NR_ERR_ARG, "mf_step: the one-launch step needs P|Q (and m, v) as one allocation");
-    NR_REQUIRE(step_index >= 1 && step_index < b.alpha_len, NR_ERR_ARG,
-               "mf_step: step %d outside the step-size table (1..%d)", step_index, b.alpha_len - 1);
+    const float* alpha_tab = alpha_window((const MFCtx*)ctx, step_index);
+    NR_REQUIRE(step_index >= 1 && alpha_tab, NR_ERR_ARG,
+               "mf_step: step %d outside the step-size table (1..%d) and the table's tail is not constant",
+               step_index, b.alpha_len - 1);
     const uint64_t* plan = d_plan;
     if (!plan && batch > 0) {
       uint64_t* own = (uint64_t*)(b.terms + 2 * (size_t)batch);
@@ -282,7 +302,7 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
     const int marked = d_plan && c->marked_plan == d_plan && c->marked_step == step_index;
     c->marked_plan = d_next_plan;
     c->marked_step = step_index + 1;
-    return nrhip_bpr_mf_step_fused(b.P, b.mP, b.vP, b.tw, b.inb, b.alpha_tab, step_index, beta1, beta2, eps, b.d,
+    return nrhip_bpr_mf_step_fused(b.P, b.mP, b.vP, b.tw, b.inb, alpha_tab, step_index, beta1, beta2, eps, b.d,
                                    b.n_users, b.n_items, d_users, d_pos, d_neg, batch, b.reg, b.terms, d_loss2,
                                    plan, marked, d_next_plan, d_next_plan ? 3 * next_batch : 0, b.lazy_period,
                                    stream);
@@ -292,8 +312,10 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
     // the one it sorted into the work buffer) — the optimiser walks the same sorted occurrences
     NR_REQUIRE(one_table && b.stamp, NR_ERR_ARG,
                "mf_step: lazy Adam needs P|Q (and m, v, G) as one allocation and a stamp array");
-    NR_REQUIRE(step_index >= 1 && step_index < b.alpha_len, NR_ERR_ARG,
-               "mf_step: step %d outside the step-size table (1..%d)", step_index, b.alpha_len - 1);
+    const float* alpha_tab = alpha_window((const MFCtx*)ctx, step_index);
+    NR_REQUIRE(step_index >= 1 && alpha_tab, NR_ERR_ARG,
+               "mf_step: step %d outside the step-size table (1..%d) and the table's tail is not constant",
+               step_index, b.alpha_len - 1);
     const uint64_t* plan = d_plan;
     if (!plan && batch > 0) {                  // no plan from the sampler: sort it into the work buffer
       uint64_t* own = (uint64_t*)(b.terms + 2 * (size_t)batch);
@@ -301,12 +323,12 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
       plan = own;
     }
     if (batch > 0)
-      NR_TRY(nrhip_bpr_mf_grad_lazy(b.P, b.mP, b.vP, b.last, b.alpha_tab, b.stamp, step_index, beta1, beta2,
+      NR_TRY(nrhip_bpr_mf_grad_lazy(b.P, b.mP, b.vP, b.last, alpha_tab, b.stamp, step_index, beta1, beta2,
                                     eps, b.d, b.n_users, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.terms,
                                     d_loss2, plan, stream));
     return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, b.stamp,
                                      (int64_t)b.n_users + b.n_items, b.d, batch ? plan : nullptr,
-                                     3 * batch, d_next_plan, d_next_plan ? 3 * next_batch : 0, b.alpha_tab,
+                                     3 * batch, d_next_plan, d_next_plan ? 3 * next_batch : 0, alpha_tab,
                                      step_index, b.lazy_period, beta1, beta2, eps, stream);
   }
   NR_TRY(nrhip_bpr_mf_grad(b.P, b.Q, b.d, b.n_users, d_users, d_pos, d_neg, batch, b.reg, b.GP, b.GQ,
@@ -350,14 +372,16 @@ int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float ep
   const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
   if (b.tw) {
     if (steps_done <= 0) return NR_OK;
-    NR_REQUIRE(steps_done < b.alpha_len, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
-    return nrhip_bpr_mf_fused_flush(b.P, b.mP, b.vP, b.tw, b.alpha_tab, steps_done, beta1, beta2, eps, b.d,
+    const float* alpha_tab = alpha_window((const MFCtx*)ctx, steps_done);
+    NR_REQUIRE(alpha_tab, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
+    return nrhip_bpr_mf_fused_flush(b.P, b.mP, b.vP, b.tw, alpha_tab, steps_done, beta1, beta2, eps, b.d,
                                     (int64_t)b.n_users + b.n_items, stream);
   }
   if (!b.last || steps_done <= 0) return NR_OK;
-  NR_REQUIRE(steps_done < b.alpha_len, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
+  const float* alpha_tab = alpha_window((const MFCtx*)ctx, steps_done);
+  NR_REQUIRE(alpha_tab, NR_ERR_ARG, "mf_flush: step %d outside the step-size table", steps_done);
   return nrhip_adam_sparse_tf_lazy(b.P, b.mP, b.vP, b.GP, b.last, nullptr, (int64_t)b.n_users + b.n_items,
-                                   b.d, nullptr, 0, nullptr, 0, b.alpha_tab, steps_done, 1, beta1, beta2, eps,
+                                   b.d, nullptr, 0, nullptr, 0, alpha_tab, steps_done, 1, beta1, beta2, eps,
                                    stream);
 }
 

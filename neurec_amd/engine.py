@@ -377,11 +377,9 @@ def rows_sum_sorted(keys, index_of_pos, src, dst):
 
 def sort_keys(keys):
     """Ascending in-place sort of int64 keys (non-negative): one LDS bitonic workgroup up to 16384
-    keys, torch.sort beyond (bookkeeping, not arithmetic)."""
-    if keys.numel() <= 16384:
-        call("nrhip_sort_u64", _ptr(keys, torch.int64), keys.numel(), _stream())
-        return keys
-    return torch.sort(keys)[0]
+    keys, the segmented multi-workgroup network beyond (csrc/bpr.hip)."""
+    call("nrhip_sort_u64", _ptr(keys, torch.int64), keys.numel(), _stream())
+    return keys
 
 
 def rows_clear(rows, d, bufs=(), flag=None):

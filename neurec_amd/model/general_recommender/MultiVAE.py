@@ -59,6 +59,11 @@ class MultiVAE(AbstractRecommender):
         if self.predict_accumulates_rows:
             self.logger.info("reference_predict_rows=True: predict() accumulates the rating row over "
                              "the users of a call, as MultiVAE.py:186-206 does")
+        else:
+            self.logger.info("reference_predict_rows=False (default): every user is scored on their OWN "
+                             "history; the reference's predict() never clears its rating row between the users "
+                             "of a call (MultiVAE.py:186-206), so its evaluation metrics differ from these — "
+                             "pass --reference_predict_rows=True to reproduce them")
 
     def build_graph(self):
         from ... import engine as E

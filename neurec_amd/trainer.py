@@ -58,7 +58,7 @@ class BprEpochSampler:
         self._pos = torch.empty(max(self.n_local, 1), dtype=torch.int32, device=dev)
         self._neg = torch.empty(max(self.n_local * self.neg_num, 1), dtype=torch.int32, device=dev)
         self.plan_users = None if plan_users is None else int(plan_users)
-        self.plans = self.plan_users is not None and self.neg_num == 1 and 2 * self.batch_size <= 16384
+        self.plans = self.plan_users is not None and self.neg_num == 1
         self._plan = (torch.empty(max(3 * self.n_local, 1), dtype=torch.int64, device=dev)
                       if self.plans else None)
 
@@ -119,7 +119,11 @@ class MFEngine:
     for every row they gather (two launches: 22.7 / 27.1 / 48.4 us at period 4 / 16 / 64).
     The tables are only current after flush(); the P / Q / mP / ... properties flush for you."""
 
-    ALPHA_STEPS = 1 << 20           # step-size table: 4 MB, enough for 1 M optimiser steps
+    # step-size table (4 MB).  Steps beyond it are served from its tail: TF's lr_t is ONE value once both
+    # running fp32 powers vanish against 1 (t > ~17.3 k at beta2 = 0.999; checked below and again by the
+    # native context), so a run of any length keeps stepping — conf/MF.properties' 300 epochs of gowalla
+    # are 475 k steps, a larger dataset passes 2^20
+    ALPHA_STEPS = 1 << 20
 
     def __init__(self, user_table, item_table, lr, reg, max_batch, lazy=True, lazy_period=None, fused=None):
         dev = E.require_gpu()
@@ -156,13 +160,21 @@ class MFEngine:
         self._stale = False
         self._alpha_host = None
         if self.lazy:
-            self._alpha_tab = torch.from_numpy(self.adam.alpha_table(self.ALPHA_STEPS)).to(dev)
+            self._alpha_np = self.adam.alpha_table(self.ALPHA_STEPS)
+            self._alpha_tail_const = bool(self._alpha_np.size > 256 and
+                                          np.all(self._alpha_np[-256:] == self._alpha_np[-1]))
+            self._alpha_tab = torch.from_numpy(self._alpha_np).to(dev)
             if not self.fused:
                 self._last = torch.zeros(rows, dtype=torch.int32, device=dev)
                 self._stamp = torch.zeros(rows, dtype=torch.int32, device=dev)
         self._ctx = E.NativeStep.for_mf(self)
 
     # tables and moments as the sweep would have left them: brought up to date on access
+    def _check_step_sizes(self, upto):
+        if self.lazy and upto >= self._alpha_tab.numel() and not self._alpha_tail_const:
+            raise NotImplementedError("step %d is beyond the step-size table (%d entries) and the table's tail "
+                                      "is not constant yet: enlarge MFEngine.ALPHA_STEPS" % (upto, self.ALPHA_STEPS))
+
     def flush(self):
         if self.lazy and self._stale:
             self._ctx.mf_flush(self.adam)
@@ -182,8 +194,7 @@ class MFEngine:
         step); next_plan: TripletBatch.next_plan — lazy mode brings the rows of the coming batch up to
         date in this step's optimiser launch, so its gradient kernel replays nothing (same results
         with or without)."""
-        if self.lazy and self.adam.t + 2 >= self._alpha_tab.numel():
-            raise NotImplementedError("more than %d optimiser steps: enlarge MFEngine.ALPHA_STEPS" % self.ALPHA_STEPS)
+        self._check_step_sizes(self.adam.t + 2)
         self._ctx.mf_step(users, pos, neg, self.adam, loss_out, plan, next_plan if self.lazy else None)
         self.adam.advance()
         self._stale = True
@@ -196,16 +207,19 @@ class MFEngine:
         (BprEpochSampler: engine.bpr_plan over the whole stream) or None.  Returns the step count."""
         n = users.numel()
         n_steps = (n + batch - 1) // batch
-        if self.lazy and self.adam.t + n_steps + 1 >= self._alpha_tab.numel():
-            raise NotImplementedError("more than %d optimiser steps: enlarge MFEngine.ALPHA_STEPS" % self.ALPHA_STEPS)
+        self._check_step_sizes(self.adam.t + n_steps + 1)
         if batch > self.max_batch:
             raise ValueError("batch larger than max_batch")
         if n_steps == 0:
             return 0
         t = self.adam.t
-        if self._alpha_host is None or self._alpha_host.size < t + n_steps + 1:
-            self._alpha_host = self.adam.alpha_table(max(2 * (t + n_steps), 4096))
-        h_alpha = np.ascontiguousarray(self._alpha_host[t + 1:t + 1 + n_steps])
+        if self.lazy:       # the device table's host twin; steps beyond it take its (constant) tail
+            idx = np.minimum(np.arange(t + 1, t + 1 + n_steps), self._alpha_np.size - 1)
+            h_alpha = np.ascontiguousarray(self._alpha_np[idx])
+        else:
+            if self._alpha_host is None or self._alpha_host.size < t + n_steps + 1:
+                self._alpha_host = self.adam.alpha_table(max(2 * (t + n_steps), 4096))
+            h_alpha = np.ascontiguousarray(self._alpha_host[t + 1:t + 1 + n_steps])
         self._ctx.mf_steps(users, pos, neg, batch, self.adam, h_alpha, loss_steps, plans)
         for _ in range(n_steps):
             self.adam.advance()

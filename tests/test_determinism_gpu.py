@@ -36,7 +36,9 @@ def _host_plan(users, items, third, batch, n_users):
     return np.concatenate(out)
 
 
-@pytest.mark.parametrize("n,batch", [(1, 1), (700, 256), (4096, 1024), (5000, 512), (9000, 4096)])
+@pytest.mark.parametrize("n,batch", [(1, 1), (700, 256), (4096, 1024), (5000, 512), (9000, 4096),
+                                     # beyond one workgroup's LDS (2 * batch > 16384): the segmented network
+                                     (8193, 8193), (50000, 20000), (70001, 33000), (300000, 150000)])
 def test_batch_plan_equals_host_sort(n, batch):
     from neurec_amd import engine as E
     rng = np.random.RandomState(n)
@@ -50,12 +52,95 @@ def test_batch_plan_equals_host_sort(n, batch):
     np.testing.assert_array_equal(got2, _host_plan(users, pos, None, batch, U))
 
 
-def test_plan_rejects_batches_beyond_the_lds_sort():
+@pytest.mark.parametrize("n", [16385, 40000, 65536, 65537, 1 << 20])
+def test_key_sort_of_any_length(n):
+    """nrhip_sort_u64 beyond 16384 keys (the row-sharded engines sort a global batch's returning rows)"""
     from neurec_amd import engine as E
-    ids = _dev(np.zeros(20000, np.int32))
-    with pytest.raises(NotImplementedError):
-        E.bpr_plan(ids, ids, ids, 8193, 5)           # 2 * 8193 item occurrences > 16384
-    E.bpr_plan(ids, ids, ids, 8192, 5)
+    rng = np.random.RandomState(n % 1000)
+    keys = (rng.randint(0, 5000, n).astype(np.int64) << 32) | rng.permutation(n).astype(np.int64)
+    got = E.sort_keys(_dev(keys)).cpu().numpy()
+    np.testing.assert_array_equal(got, np.sort(keys))
+
+
+def test_steps_on_a_batch_beyond_the_lds_sort_match_the_oracle():
+    """batch_size > 8192 used to fail in the default (lazy, fused) MF path.  One step of each
+    engine on 20,000 triplets: plan sorted inside the step by the segmented network."""
+    import torch
+    from neurec_amd.trainer import LightGCNEngine, MFEngine
+    from oracle import train as O
+    rng = np.random.RandomState(3)
+    U, I, d, B = 3000, 2000, 64, 20000
+    users = rng.randint(0, U, B).astype(np.int32)
+    pos = (rng.zipf(1.3, B) % I).astype(np.int32)                # hub items: runs of hundreds of occurrences
+    neg = rng.randint(0, I, B).astype(np.int32)
+    P0 = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q0 = (rng.randn(I, d) * 0.1).astype(np.float32)
+    for kw in (dict(), dict(fused=False), dict(lazy=False)):
+        mf = MFEngine(P0, Q0, 0.001, 0.01, B, **kw)
+        loss = torch.zeros(2, device="cuda")
+        mf.step(_dev(users), _dev(pos), _dev(neg), loss)
+        P, Q = P0.copy(), Q0.copy()
+        st = [np.zeros_like(x) for x in (P, P, Q, Q)]
+        want = O.mf_step(P, Q, st[0], st[1], st[2], st[3], users, pos, neg, 0.01, O.Adam(0.001))
+        assert abs(float(loss.sum()) - want) <= 1e-5 * want
+        assert np.abs(mf.P.cpu().numpy() - P).max() <= 1e-5 and np.abs(mf.Q.cpu().numpy() - Q).max() <= 1e-5
+    import scipy.sparse as sp
+    R = sp.csr_matrix((np.ones(B, np.float32), (users, pos)), shape=(U, I))
+    R.data[:] = 1
+    coo = R.tocoo()
+    A = O.lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    E0 = (rng.randn(U + I, d) * 0.1).astype(np.float32)
+    lg = LightGCNEngine(A, U, I, E0, 2, 0.01, 1e-3, B)
+    loss = torch.zeros(2, device="cuda")
+    lg.step(_dev(users), _dev(pos), _dev(neg), loss)
+    e, m, v = E0.copy(), np.zeros_like(E0), np.zeros_like(E0)
+    want = O.lightgcn_step(A, A, e, m, v, U, 2, users, pos, neg, 1e-3, O.Adam(0.01))
+    got = loss.cpu().numpy()
+    assert abs(got[0] - want[0]) <= 1e-5 * want[0] and abs(got[1] - want[1]) <= 1e-5 * want[1]
+    assert np.abs(lg.E0.cpu().numpy() - e).max() <= 2e-5
+
+
+def test_lazy_adam_steps_beyond_the_step_size_table():
+    """the lazy MF step read lr_t from a table of 2^20 entries and refused step 2^20.  TF's lr_t
+    is one value once both fp32 powers vanish against 1 (~17.3 k steps), so later steps are served from
+    the table's tail.  Two engines — a table that ends at step 18,000 and the full one — run 18,300 steps
+    (the batch loop in C) and must end bit-identical, in both lazy forms."""
+    import torch
+    from neurec_amd.trainer import MFEngine
+    rng = np.random.RandomState(5)
+    U, I, d, B, S = 300, 200, 64, 64, 18300
+    users = _dev(rng.randint(0, U, S * B).astype(np.int32))
+    pos = _dev(rng.randint(0, I, S * B).astype(np.int32))
+    neg = _dev(rng.randint(0, I, S * B).astype(np.int32))
+    P0 = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q0 = (rng.randn(I, d) * 0.1).astype(np.float32)
+    for fused in (True, False):
+        out = []
+        for steps in (18000, 1 << 20):
+            old = MFEngine.ALPHA_STEPS
+            MFEngine.ALPHA_STEPS = steps
+            try:
+                mf = MFEngine(P0, Q0, 0.001, 0.0, B, fused=fused)
+            finally:
+                MFEngine.ALPHA_STEPS = old
+            assert mf._alpha_tail_const
+            losses = torch.zeros(2 * S, device="cuda")
+            assert mf.run_batches(users, pos, neg, B, losses) == S
+            mf.step(users[:B], pos[:B], neg[:B], losses[:2])            # the per-step entry too
+            out.append((mf.P.cpu().numpy(), mf.Q.cpu().numpy(), mf.mP.cpu().numpy(), mf.vQ.cpu().numpy(),
+                        losses.cpu().numpy()))
+        for a, b in zip(*out):
+            np.testing.assert_array_equal(a, b)
+    # a table too short for its tail to be constant still refuses, by name
+    old = MFEngine.ALPHA_STEPS
+    MFEngine.ALPHA_STEPS = 1000
+    try:
+        mf = MFEngine(P0, Q0, 0.001, 0.0, B)
+        losses = torch.zeros(2 * 1100, device="cuda")
+        with pytest.raises(NotImplementedError, match="ALPHA_STEPS"):
+            mf.run_batches(users[:1100 * B], pos[:1100 * B], neg[:1100 * B], B, losses)
+    finally:
+        MFEngine.ALPHA_STEPS = old
 
 
 def _ordered_rows(n_rows, d, idx_lists, contrib_lists):

@@ -1,0 +1,384 @@
+"""The HIP engines against traces of the REFERENCE's own model classes (MF.py / LightGCN.py /
+NGCF.py / MultiVAE.py run unchanged under oracle/tf_shim.py; fixtures: tests/golden/tfgraph_*.npz,
+written by tests/golden/make_golden_tfgraph.py).  north_star's bar: losses and tables within 1e-5
+(fp32).  The small fixtures carry whole tables; the `big_*` fixtures are the BASELINE shapes (gowalla:
+29,858 x 40,981) with outputs sampled — the inputs are regenerated here from neurec_amd/synth.py with
+the recorded seeds.  NGCF at the gowalla shape runs against oracle.train (the reference class
+densifies the 29,858 x 40,981 train matrix, NGCF.py:40 — 9.8 GB of fp64 — and oracle.train is pinned
+to the reference graph by tests/test_tfgraph_golden.py)."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _batches(g):
+    return [tuple(np.ascontiguousarray(g["batches"][k, j, :g["batch_len"][k]]) for j in range(3))
+            for k in range(len(g["batch_len"]))]
+
+
+def _err(got, want):
+    return float(np.abs(np.asarray(got, np.float64) - want).max())
+
+
+def _rel(got, want):
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want) / np.abs(want)))
+
+
+# ------------------------------------------------------------------ BPR-MF
+@pytest.mark.parametrize("tag", ["reg0", "reg01"])
+@pytest.mark.parametrize("form", ["fused", "two-launch", "sweep"])
+def test_mf_engine_equals_the_reference_graph(tag, form):
+    import torch
+    from neurec_amd.trainer import MFEngine
+    g = load_golden("tfgraph_mf_" + tag)
+    h = json.loads(str(g["hyper"]))
+    kw = {"fused": dict(), "two-launch": dict(fused=False), "sweep": dict(lazy=False)}[form]
+    mf = MFEngine(g["P0"], g["Q0"], h["learning_rate"], h["reg_mf"], 96, **kw)
+    bs = _batches(g)
+    losses = torch.zeros(len(bs), 2, device="cuda")
+    for k, (u, p, n) in enumerate(bs):
+        mf.step(_dev(u), _dev(p), _dev(n), losses[k])
+    got = losses.cpu().numpy().astype(np.float64).sum(1)
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    P, Q = mf.P.cpu().numpy(), mf.Q.cpu().numpy()
+    bar = max(_err(g["f32_P"], g["f64_P"]), _err(g["f32_Q"], g["f64_Q"]))
+    d32 = max(_err(P, g["f32_P"]), _err(Q, g["f32_Q"]))
+    d64 = max(_err(P, g["f64_P"]), _err(Q, g["f64_Q"]))
+    print("MF %s %s: tables vs the reference graph fp32 %.1e, fp64 %.1e (its own fp32-vs-fp64 %.1e)"
+          % (tag, form, d32, d64, bar))
+    assert d32 <= TOL and d64 <= TOL + bar
+    assert _err(mf.mP.cpu().numpy(), g["f64_m_P"]) <= TOL and _err(mf.vQ.cpu().numpy(), g["f64_v_Q"]) <= TOL
+
+
+def test_mf_variants_equal_the_reference_graph():
+    import torch
+    from neurec_amd.trainer import GeneralMFEngine
+    g = load_golden("tfgraph_mf_variants")
+    reg, lr = float(g["reg"]), float(g["lr"])
+    for ci, (pairwise, loss, learner) in enumerate(json.loads(str(g["cases"]))):
+        eng = GeneralMFEngine(g["P0"], g["Q0"], lr, reg, 128, loss=loss, pairwise=pairwise, learner=learner)
+        loss2 = torch.zeros(2, device="cuda")
+        got = []
+        for s in range(5):
+            users, items, third = (g["c%d_%s" % (ci, k)][s] for k in ("users", "items", "third"))
+            eng.step(_dev(users), _dev(items), _dev(third), loss2)
+            got.append(float(loss2.cpu().numpy().astype(np.float64).sum()))
+        assert _rel(got, g["c%d_f32_loss" % ci]) <= 2e-5, (loss, learner)
+        bar = max(_err(g["c%d_f32_P" % ci], g["c%d_f64_P" % ci]), _err(g["c%d_f32_Q" % ci], g["c%d_f64_Q" % ci]))
+        d = max(_err(eng.P.cpu().numpy(), g["c%d_f32_P" % ci]), _err(eng.Q.cpu().numpy(), g["c%d_f32_Q" % ci]))
+        print("MF variant %s/%s/%s: tables vs the reference graph %.1e (its fp32-vs-fp64 %.1e)"
+              % (pairwise, loss, learner, d, bar))
+        assert d <= 2e-5 + bar
+
+
+# ------------------------------------------------------------------ LightGCN
+def _adjacency(g, adj):
+    from neurec_amd.graph import lightgcn_adjacency
+    U, I = int(g["n_users"]), int(g["n_items"])
+    R = sp.csr_matrix((np.ones(len(g["train_indices"]), np.float32), g["train_indices"], g["train_indptr"]),
+                      shape=(U, I))
+    coo = R.tocoo()
+    return U, I, R, lightgcn_adjacency(coo.row, coo.col, U, I, adj)
+
+
+@pytest.mark.parametrize("adj", ["pre", "norm"])
+def test_lightgcn_engine_equals_the_reference_graph(adj):
+    import torch
+    from neurec_amd.trainer import LightGCNEngine
+    g = load_golden("tfgraph_lightgcn_" + adj)
+    h = json.loads(str(g["hyper"]))
+    U, I, R, A = _adjacency(g, adj)
+    lg = LightGCNEngine(A, U, I, g["E0"], h["n_layers"], h["lr"], h["reg"], 128)
+    bs = _batches(g)
+    losses = torch.zeros(len(bs), 2, device="cuda")
+    for k, (u, p, n) in enumerate(bs):
+        lg.step(_dev(u), _dev(p), _dev(n), losses[k])
+    got = losses.cpu().numpy().astype(np.float64)
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL       # (mf_loss, emb_loss)
+    E = lg.E0.cpu().numpy()
+    bar = _err(g["f32_E"], g["f64_E"])
+    print("LightGCN %s: E0 vs the reference graph fp32 %.1e, fp64 %.1e (its own fp32-vs-fp64 %.1e)"
+          % (adj, _err(E, g["f32_E"]), _err(E, g["f64_E"]), bar))
+    assert _err(E, g["f32_E"]) <= TOL + bar and _err(E, g["f64_E"]) <= TOL + bar
+    assert _err(lg.m.cpu().numpy(), g["f64_m"]) <= TOL and _err(lg.v.cpu().numpy(), g["f64_v"]) <= TOL
+    # evaluate_model(): assign_opt then batch_ratings = E*_u E*_i^T (LightGCN.py:110-119,187-189)
+    eu, ei = lg.final_embeddings()
+    users = np.flatnonzero(np.diff(g["train_indptr"]) > 0)
+    S = (eu[_dev(users)].double() @ ei.double().t()).cpu().numpy()
+    assert _err(S, g["f64_ratings"]) <= TOL + 4 * bar
+
+
+def test_lightgcn_config3_equals_the_reference_graph_at_gowalla_size():
+    import torch
+    from neurec_amd import synth
+    from neurec_amd.graph import lightgcn_adjacency
+    from neurec_amd.trainer import LightGCNEngine
+    g = load_golden("tfgraph_big_lightgcn")
+    h = json.loads(str(g["hyper"]))
+    tr, _ = synth.interactions(str(g["shape"]), seed=int(g["synth_seed"]))
+    U, I = tr.shape
+    coo = tr.tocoo()
+    A = lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    assert A.nnz == int(g["adj_nnz"])
+    E0 = synth.xavier_uniform(U + I, 64, np.random.RandomState(int(g["init_seed"])))
+    lg = LightGCNEngine(A, U, I, E0, h["n_layers"], h["lr"], h["reg"], 1024)
+    bs = _batches(g)
+    losses = torch.zeros(len(bs), 2, device="cuda")
+    for k, (u, p, n) in enumerate(bs):
+        lg.step(_dev(u), _dev(p), _dev(n), losses[k])
+    got = losses.cpu().numpy().astype(np.float64)
+    rows = g["sample_rows"]
+    E = lg.E0.cpu().numpy()[rows]
+    bar = _err(g["f32_E"], g["f64_E"])
+    print("config 3 vs the reference's LightGCN class, 3 steps: loss rel err %.1e (fp32) %.1e (fp64); %d sampled "
+          "E0 rows %.1e / %.1e (reference fp32-vs-fp64 %.1e)"
+          % (_rel(got, g["f32_loss"]), _rel(got, g["f64_loss"]), len(rows), _err(E, g["f32_E"]),
+             _err(E, g["f64_E"]), bar))
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    assert _err(E, g["f32_E"]) <= TOL + bar and _err(E, g["f64_E"]) <= TOL + bar
+    eu, ei = lg.final_embeddings()
+    items = rows[rows >= U] - U
+    S = (eu[_dev(g["ratings_users"])].double() @ ei[_dev(items)].double().t()).cpu().numpy()
+    assert _err(S, g["f64_ratings"]) <= TOL
+
+
+def test_mf_config2_equals_the_reference_graph_at_gowalla_size():
+    """BASELINE configs[1]: BPR-MF on the gowalla shape, d = 64, B = 512, 20 steps through the
+    one-launch lazy step (nrhip_bpr_mf_step_fused), against MF.py's own graph and loop."""
+    import torch
+    from neurec_amd import synth
+    from neurec_amd.trainer import MFEngine
+    g = load_golden("tfgraph_big_mf")
+    h = json.loads(str(g["hyper"]))
+    tr, _ = synth.interactions(str(g["shape"]), seed=int(g["synth_seed"]))
+    U, I = tr.shape
+    rs = np.random.RandomState(int(g["init_seed"]))
+    P0 = (rs.randn(U, 64) * 0.01).astype(np.float32)
+    Q0 = (rs.randn(I, 64) * 0.01).astype(np.float32)
+    mf = MFEngine(P0, Q0, h["learning_rate"], h["reg_mf"], 512)
+    assert mf.fused
+    bs = _batches(g)
+    losses = torch.zeros(len(bs), 2, device="cuda")
+    for k, (u, p, n) in enumerate(bs):
+        mf.step(_dev(u), _dev(p), _dev(n), losses[k])
+    got = losses.cpu().numpy().astype(np.float64).sum(1)
+    rows = g["sample_rows"]
+    pu, pi = rows[rows < U], rows[rows >= U] - U
+    P, Q = mf.P.cpu().numpy(), mf.Q.cpu().numpy()
+    bar = max(_err(g["f32_P"], g["f64_P"]), _err(g["f32_Q"], g["f64_Q"]))
+    d32 = max(_err(P[pu], g["f32_P"]), _err(Q[pi], g["f32_Q"]))
+    d64 = max(_err(P[pu], g["f64_P"]), _err(Q[pi], g["f64_Q"]))
+    print("config 2 vs the reference's MF class, 20 steps: loss rel err %.1e; sampled rows %.1e (fp32) %.1e (fp64), "
+          "reference fp32-vs-fp64 %.1e" % (_rel(got, g["f64_loss"]), d32, d64, bar))
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    assert d32 <= TOL + bar and d64 <= TOL + bar
+    # untouched rows decayed with everyone else (TF's sparse Adam moves every row): the sample has both kinds
+    touched = np.zeros(U + I, bool)
+    for u, p, n in bs:
+        touched[u] = touched[U + p] = touched[U + n] = True
+    assert touched[rows].any() and (~touched[rows]).any()
+    S = P[g["ratings_users"]].astype(np.float64) @ Q[pi].astype(np.float64).T
+    assert _err(S, g["f64_ratings"]) <= TOL
+
+
+# ------------------------------------------------------------------ NGCF
+NGCF_W = ("W_gc", "b_gc", "W_bi", "b_bi")
+
+
+@pytest.mark.parametrize("tag", ["drop", "reg"])
+def test_ngcf_engine_equals_the_reference_graph(tag):
+    import torch
+    from neurec_amd.graph import ngcf_adjacency, transpose_csr
+    from neurec_amd.trainer import NGCFEngine
+    g = load_golden("tfgraph_ngcf_" + tag)
+    h = json.loads(str(g["hyper"]))
+    U, I = int(g["n_users"]), int(g["n_items"])
+    R = sp.csr_matrix((g["train_data"], g["train_indices"], g["train_indptr"]), shape=(U, I))
+    A = ngcf_adjacency(R, "norm")
+    W0 = [tuple(g["%s_%d_0" % (nm, k)] for nm in NGCF_W) for k in range(2)]
+    eng = NGCFEngine(A, transpose_csr(A), U, I, g["E0"], W0, h["learning_rate"], h["reg"],
+                     h["mess_dropout_ratio"], 128)
+    loss2 = torch.zeros(2, device="cuda")
+    got = []
+    for s, (u, p, n) in enumerate(_batches(g)):
+        eng.step(_dev(u), _dev(p), _dev(n), loss2, masks=[_dev(g["masks"][s, k]) for k in range(2)])
+        got.append(float(loss2.cpu().numpy().astype(np.float64).sum()))
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    bar = max([_err(g["f32_E"], g["f64_E"])] + [_err(g["f32_%s_%d" % (nm, k)], g["f64_%s_%d" % (nm, k)])
+                                                 for nm in NGCF_W for k in range(2)])
+    d = [_err(eng.E0.cpu().numpy(), g["f64_E"])]
+    for k in range(2):
+        for j, nm in enumerate(NGCF_W):
+            d.append(_err(eng.W[k][j].cpu().numpy().reshape(g["f64_%s_%d" % (nm, k)].shape), g["f64_%s_%d" % (nm, k)]))
+    print("NGCF %s: all parameters vs the reference graph (fp64) %.1e (its fp32-vs-fp64 %.1e)" % (tag, max(d), bar))
+    assert max(d) <= TOL + bar
+    # evaluate(): forward with the evaluation's own dropout draw (NGCF.py:140-141,193)
+    out = eng.forward([_dev(m) for m in g["eval_masks"]]).cpu().numpy()
+    assert _err(out[:U], g["f64_eval_user_emb"]) <= TOL + bar
+
+
+def test_ngcf_config5_three_steps_at_gowalla_size():
+    """BASELINE configs[4], NGCF half: gowalla shape, d = 16, layers [16, 16], B = 512, 3 steps against
+    oracle.train (pinned to the reference's NGCF class by tests/test_tfgraph_golden.py)."""
+    import torch
+    from neurec_amd import synth
+    from neurec_amd.graph import ngcf_adjacency, transpose_csr
+    from neurec_amd.trainer import NGCFEngine
+    from oracle import train as O
+    tr, _ = synth.interactions("gowalla", seed=2018)
+    U, I = tr.shape
+    A = ngcf_adjacency(tr, "norm")
+    At = transpose_csr(A)
+    rng = np.random.RandomState(2017)
+    d, B, lr, reg, drop = 16, 512, 0.001, 0.0, 0.1            # conf/NGCF.properties
+    E0 = synth.xavier_uniform(U + I, d, rng)
+    W = [tuple((rng.randn(*s) * np.sqrt(1.3 * 2 / (s[0] + s[1]))).astype(np.float32)
+               for s in ((d, d), (1, d), (d, d), (1, d))) for _ in range(2)]
+    eng = NGCFEngine(A, At, U, I, E0, W, lr, reg, drop, B)
+    coo = tr.tocoo()
+    steps = []
+    for _ in range(3):
+        pick = rng.randint(0, coo.nnz, B)
+        steps.append(((coo.row[pick].astype(np.int32), coo.col[pick].astype(np.int32),
+                       rng.randint(0, I, B).astype(np.int32)),
+                      [(rng.rand(U + I, d) < 1 - drop).astype(np.uint8) for _ in W]))
+    loss2 = torch.zeros(2, device="cuda")
+    got_loss = []
+    for (bu, bp, bn), masks in steps:
+        eng.step(_dev(bu), _dev(bp), _dev(bn), loss2, masks=[_dev(m) for m in masks])
+        got_loss.append(float(loss2.cpu().numpy().astype(np.float64).sum()))
+
+    def run(dt):
+        A_, At_ = A.astype(dt), At.astype(dt)
+        oE = E0.astype(dt)
+        oW = [[w.astype(dt) for w in ws] for ws in W]
+        params = [oE] + [w for ws in oW for w in ws]
+        ms, vs = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
+        ad = O.Adam(lr, dtype=dt)
+        losses = []
+        for (bu, bp, bn), masks in steps:
+            loss, dE, wg = O.ngcf_loss_and_grads(A_, At_, oE, [tuple(ws) for ws in oW],
+                                                 [m.astype(dt) for m in masks], 1 - drop, U, bu, bp, bn, reg)
+            for p, m, v, gg in zip(params, ms, vs, [dE] + [x for gs in wg for x in gs]):
+                ad.dense(p, m, v, gg.reshape(p.shape))
+            ad.advance()
+            losses.append(float(loss))
+        return np.asarray(losses), params
+    l32, p32 = run(np.float32)
+    l64, p64 = run(np.float64)
+    got = [eng.E0.cpu().numpy()] + [eng.W[k][j].cpu().numpy() for k in range(2) for j in range(4)]
+    d32 = max(_err(a.reshape(b.shape), b) for a, b in zip(got, p32))
+    d64 = max(_err(a.reshape(b.shape), b) for a, b in zip(got, p64))
+    bar = max(_err(a, b) for a, b in zip(p32, p64))
+    print("config 5 NGCF at the gowalla shape, 3 steps: loss rel err vs fp32 %.1e, vs fp64 %.1e; parameters vs fp32 "
+          "%.1e, vs fp64 %.1e (oracle fp32-vs-fp64 %.1e)" % (_rel(got_loss, l32), _rel(got_loss, l64), d32, d64, bar))
+    assert _rel(got_loss, l32) <= TOL and _rel(got_loss, l64) <= TOL
+    assert d32 <= TOL + bar and d64 <= TOL + bar
+
+
+# ------------------------------------------------------------------ Mult-VAE
+VAE_NAMES = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1", "bp1")
+
+
+def _vae_engine(R, g, h, B):
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import MultiVAEEngine
+    params = {k: g[k + "_0"] for k in VAE_NAMES if k != "Wp1"}
+    params["Wp1t"] = np.ascontiguousarray(g["Wp1_0"].T)
+    return MultiVAEEngine(E.DeviceCSR.from_scipy(R), R.shape[1], params, h["learning_rate"], h["reg"],
+                          h["activation"], B)
+
+
+@pytest.mark.parametrize("tag", ["tanh", "relu_reg"])
+def test_multivae_engine_equals_the_reference_graph(tag):
+    g = load_golden("tfgraph_multivae_" + tag)
+    h = json.loads(str(g["hyper"]))
+    U, I = int(g["n_users"]), int(g["n_items"])
+    R = sp.csr_matrix((np.ones(len(g["train_indices"]), np.float32), g["train_indices"], g["train_indptr"]),
+                      shape=(U, I))
+    eng = _vae_engine(R, g, h, h["batch_size"])
+    got = []
+    for s, rows in enumerate(g["rows"]):
+        drop_pos = np.ones(R.nnz, np.float32)
+        for b, u in enumerate(rows):
+            lo, hi = R.indptr[u], R.indptr[u + 1]
+            drop_pos[lo:hi] = g["drop_masks"][s][b, R.indices[lo:hi]]
+        eng.step(_dev(rows.astype(np.int32)), float(g["anneal"][s]), 0.8, drop_given=_dev(drop_pos),
+                 eps_given=_dev(g["eps"][s].astype(np.float32)))
+        got.append(eng.loss()[0])
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    bar = max(_err(g["f32_" + k], g["f64_" + k]) for k in VAE_NAMES)
+    d = []
+    for k in VAE_NAMES:
+        a = eng.P["Wp1t" if k == "Wp1" else k].cpu().numpy()
+        d.append(_err(a.T if k == "Wp1" else a, g["f64_" + k]))
+    print("Mult-VAE %s: all parameters vs the reference graph (fp64) %.1e (its fp32-vs-fp64 %.1e)" % (tag, max(d), bar))
+    assert max(d) <= TOL + bar
+
+
+def test_multivae_config5_equals_the_reference_graph_at_gowalla_size():
+    """BASELINE configs[4], Mult-VAE half: gowalla shape (I = 40,981), p_dim [16, 32], B = 512, the first 3
+    steps of MultiVAE.train_model() — losses, sampled parameter rows and sampled logits."""
+    import torch
+    from neurec_amd import synth
+    g = load_golden("tfgraph_big_multivae")
+    h = json.loads(str(g["hyper"]))
+    tr, _ = synth.interactions(str(g["shape"]), seed=int(g["synth_seed"]))
+    U, I = tr.shape
+    rs = np.random.RandomState(int(g["param_seed"]))
+    s_, hdim, z = float(g["param_scale"]), 32, 16
+    full = {"Wq0": (rs.randn(I, hdim) * s_).astype(np.float32), "bq0": (rs.randn(hdim) * 0.05).astype(np.float32),
+            "Wq1": (rs.randn(hdim, 2 * z) * s_).astype(np.float32), "bq1": (rs.randn(2 * z) * 0.05).astype(np.float32),
+            "Wp0": (rs.randn(z, hdim) * s_).astype(np.float32), "bp0": (rs.randn(hdim) * 0.05).astype(np.float32),
+            "Wp1": (rs.randn(hdim, I) * s_).astype(np.float32), "bp1": (rs.randn(I) * 0.05).astype(np.float32)}
+    fake = {k + "_0": v for k, v in full.items()}
+    eng = _vae_engine(tr, fake, h, 512)
+    items = g["sample_items"]
+    got = []
+    off = 0
+    for s, rows in enumerate(g["rows"]):
+        drop_pos = np.ones(tr.nnz, np.float32)
+        for u in rows:
+            lo, hi = tr.indptr[u], tr.indptr[u + 1]
+            drop_pos[lo:hi] = g["drop_at_positives"][off:off + hi - lo]
+            off += hi - lo
+        eng.step(_dev(rows.astype(np.int32)), float(g["anneal"][s]), 0.8, drop_given=_dev(drop_pos),
+                 eps_given=_dev(g["eps"][s].astype(np.float32)))
+        got.append(eng.loss()[0])
+    assert off == len(g["drop_at_positives"])
+    bar = max(_err(g["f32_" + k], g["f64_" + k]) for k in VAE_NAMES)
+    d = []
+    for k in VAE_NAMES:
+        a = eng.P["Wp1t" if k == "Wp1" else k].cpu().numpy()
+        a = a.T if k == "Wp1" else a
+        if a.shape[0] == I:
+            a = a[items]
+        elif a.ndim == 2 and a.shape[1] == I:
+            a = a[:, items]
+        d.append(_err(a, g["f64_" + k]))
+    print("config 5 Mult-VAE vs the reference's class at the gowalla shape, 3 steps: loss rel err %.1e; sampled "
+          "parameters %.1e (reference fp32-vs-fp64 %.1e)" % (_rel(got, g["f64_loss"]), max(d), bar))
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    assert max(d) <= TOL + bar
+    # predict() with the reference's accumulating row (MultiVAE.py:195-203): union of the users' items so far
+    acc = np.zeros(I, bool)
+    outs = []
+    for u in g["ratings_users"]:
+        acc[tr.indices[tr.indptr[u]:tr.indptr[u + 1]]] = True
+        row = sp.csr_matrix(acc.astype(np.float32)[None, :])
+        from neurec_amd import engine as E
+        S = eng.logits(torch.zeros(1, dtype=torch.int32, device="cuda"), csr=E.DeviceCSR.from_scipy(row))
+        outs.append(S.cpu().numpy()[0, :I][items])
+    assert _err(np.asarray(outs), g["f64_ratings"]) <= TOL
