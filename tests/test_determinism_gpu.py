@@ -95,9 +95,27 @@ def test_steps_on_a_batch_beyond_the_lds_sort_match_the_oracle():
     lg.step(_dev(users), _dev(pos), _dev(neg), loss)
     e, m, v = E0.copy(), np.zeros_like(E0), np.zeros_like(E0)
     want = O.lightgcn_step(A, A, e, m, v, U, 2, users, pos, neg, 1e-3, O.Adam(0.01))
+    A64 = A.astype(np.float64)
+    e64, m64, v64 = E0.astype(np.float64), np.zeros(E0.shape), np.zeros(E0.shape)
+    O.lightgcn_step(A64, A64, e64, m64, v64, U, 2, users, pos, neg, 1e-3, O.Adam(0.01, dtype=np.float64))
     got = loss.cpu().numpy()
     assert abs(got[0] - want[0]) <= 1e-5 * want[0] and abs(got[1] - want[1]) <= 1e-5 * want[1]
-    assert np.abs(lg.E0.cpu().numpy() - e).max() <= 2e-5
+    # the first-moment estimate is 0.1 * g after one step: the gradient itself, at fp32 resolution
+    # (item 1 is in ~6,000 of the 20,000 positives: its rows are 6,000-term fp32 sums — the head adds them in
+    # batch order like np.add.at, the hops cut such a row into 64-nnz segments: the sums are reassociated)
+    gscale = np.abs(m64).max()
+    gm = lg.m.cpu().numpy()
+    dm, dm32, dmo = np.abs(gm - m64).max(), np.abs(m - m64).max(), np.abs(gm - m).max()
+    print("B = 20,000: first moment abs err vs fp64 %.1e of max %.1e (the fp32 restatement's own: %.1e); vs the fp32 "
+          "restatement %.1e" % (dm, gscale, dm32, dmo))
+    assert dmo <= 1e-6 * gscale and dm <= 1e-6 * gscale + dm32        # the same ordered 6,000-term sums
+    # the table: 1e-5 of the fp64 twin wherever the gradient is resolved by fp32; where it is not (|g| within
+    # 2^-17 of the largest: lr_t * m / (sqrt(v) + 1e-8) turns its rounding noise into a fraction of a step)
+    # the fp32 restatement is just as far from its own twin — at most one step size
+    resolved = np.abs(m64) >= gscale * 2.0 ** -17
+    err = np.abs(lg.E0.cpu().numpy() - e64)
+    assert err[resolved].max() <= 1e-5 + np.abs(e - e64)[resolved].max()
+    assert err[~resolved].max() <= 0.01 and (~resolved).mean() < 0.5
 
 
 def test_lazy_adam_steps_beyond_the_step_size_table():
