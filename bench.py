@@ -50,7 +50,266 @@ def parse():
     ap.add_argument("--eval-mode", choices=("pruned", "materialised"), default="pruned")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-mf", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the NGCF / Mult-VAE legs (BASELINE configs[4])")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 slice leg (BASELINE configs[3])")
+    ap.add_argument("--config4-scale", type=float, default=1.0,
+                    help="fraction of BASELINE configs[3] (10^7 users, 10^6 items, 2*10^8 interactions) the one-GPU "
+                         "leg runs at on this one GPU; 1.0 is the full size (213 ms/step)")
     return ap.parse_args()
+
+
+def _hip_timed(fn, n, warm=3):
+    """average milliseconds of fn() over n calls, HIP events on torch's current stream (the launch stream)"""
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def _cpu_timed(step, budget=6.0, max_steps=8):
+    """(seconds per step, steps timed): one warm call, then up to max_steps inside the budget"""
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    if warm > budget:
+        return warm, 1
+    t0, n = time.perf_counter(), 0
+    while n < max_steps and time.perf_counter() - t0 < budget:
+        step()
+        n += 1
+    return (time.perf_counter() - t0) / n, n
+
+
+def leg_ngcf(train, test, trc, tec, dev, with_cpu):
+    """BASELINE configs[4], NGCF half (conf/NGCF.properties: embedding 16, layers [16, 16], B = 512, `norm`
+    adjacency, message dropout 0.1) on the run's interactions: step time, the roofline of its dominant
+    kernel (the 16-wide SpMM: four passes per step) and the oracle.train port timed on the host."""
+    import torch
+    from neurec_amd.graph import ngcf_adjacency, transpose_csr
+    from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, NGCFEngine
+    from neurec_amd.util.tool import get_initializer
+    U, I = train.shape
+    A = ngcf_adjacency(train, "norm")
+    At = transpose_csr(A)
+    w = get_initializer("xavier_normal", 0.01, seed=2018)
+    e = get_initializer("xavier_normal", 0.01, seed=2017)
+    table = np.concatenate([e([U, 16]), e([I, 16])])
+    weights = [(w([16, 16]), w([1, 16]), w([16, 16]), w([1, 16])) for _ in range(2)]
+    B, lr, reg, drop = 512, 0.001, 0.0, 0.1
+    ng = NGCFEngine(A, At, U, I, table, weights, lr, reg, drop, B)
+    sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=B, shuffle=True, seed=2018, plan_users=U)
+    batches = [b for b in sampler.batches() if b[0].numel() == B][:200]
+    loss = torch.zeros(2, device=dev)
+    it = iter(batches * 10)
+
+    def step():
+        b = next(it)
+        ng.step(b[0], b[1], b[2], loss, plan=b.plan)
+    ms = _hip_timed(step, 150, 20)
+    # dominant kernel: S = A·E at d = 16 (lane-group kernel, 4 lanes per row), 2 forward + 2 backward per step
+    x, y = ng.ego[0], ng.S[0]
+    spmm_ms = _hip_timed(lambda: ng.A.matmul(x, out=y), 40, 5)
+    spmm_bytes = ng.A.algorithmic_bytes(16)
+    users = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
+    ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=16384)
+
+    def evaluate():
+        eu, ei = ng.final_embeddings()
+        return ev.evaluate_factors(eu.contiguous(), ei.contiguous(), users)
+    evaluate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = evaluate()
+    torch.cuda.synchronize()
+    edt = time.perf_counter() - t0
+    out = {"ms_per_step": ms, "triplets_per_sec": B / ms * 1e3, "batch": B, "dim": 16, "layers": [16, 16],
+           "adjacency_nnz": int(A.nnz), "launches": "one native call per step (nrhip_ngcf_step: ~27 launches)",
+           "roofline": {"bound": "hbm", "kernel": ng.A.full_pass_kernel(16), "bytes_per_launch": spmm_bytes,
+                        "us_per_launch": spmm_ms * 1e3, "launches_per_step": 4,
+                        "achieved": spmm_bytes / spmm_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": spmm_bytes / spmm_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "nnz*8 + (N+1)*4 + 2*N*16*4 B per pass (SURVEY 8d's SpMM formula at d = 16); the "
+                                "4.5 MB operand table is L2-sized, the pass is bound by the CSR stream and latency"},
+           "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9])}}
+    if with_cpu:
+        from oracle import train as O
+        rng = np.random.RandomState(3)
+        coo = train.tocoo()
+        params = [table.copy()] + [x_.copy() for ws in weights for x_ in ws]
+        ms_, vs_ = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
+        adam = O.Adam(lr)
+
+        def cpu_step():
+            pick = rng.randint(0, coo.nnz, B)
+            masks = [(rng.rand(U + I, 16) < 1 - drop).astype(np.float32) for _ in weights]
+            Wl = [tuple(params[1 + 4 * k:5 + 4 * k]) for k in range(2)]
+            _, dE, wg = O.ngcf_loss_and_grads(A, At, params[0], Wl, masks, 1 - drop, U, coo.row[pick],
+                                              coo.col[pick], rng.randint(0, I, B), reg)
+            for p_, m_, v_, g_ in zip(params, ms_, vs_, [dE] + [x_ for gs in wg for x_ in gs]):
+                adam.dense(p_, m_, v_, g_.reshape(p_.shape))
+            adam.advance()
+        sec, n = _cpu_timed(cpu_step)
+        out["cpu_baseline"] = {"value": B / sec, "unit": "triplets/s", "cores": 1, "kind": "port",
+                               "sample": "%d NGCF steps (B=%d) of oracle.train (scipy CSR SpMM + numpy fp32, 1 thread; "
+                                         "pinned to the reference's NGCF class by tests/test_tfgraph_golden.py)" % (n, B)}
+    return out
+
+
+def leg_multivae(train, test, trc, tec, dev, with_cpu):
+    """BASELINE configs[4], Mult-VAE half (conf/MultiVAE.properties: p_dim [16, 32], B = 512, tanh, keep 0.8)."""
+    import torch
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator, MultiVAEEngine
+    from neurec_amd.util.tool import get_initializer
+    U, I = train.shape
+    wi = get_initializer("xavier_normal", 0.01, seed=2017)
+    bi = get_initializer("tnormal", 0.01, seed=2018)
+    z, h, B = 16, 32, 512
+    params = {"Wq0": wi([I, h]), "bq0": bi([h]), "Wq1": wi([h, 2 * z]), "bq1": bi([2 * z]), "Wp0": wi([z, h]),
+              "bp0": bi([h]), "Wp1t": np.ascontiguousarray(wi([h, I]).T), "bp1": bi([I])}
+    vae = MultiVAEEngine(trc, I, params, 0.001, 0.0, "tanh", B)
+    perm = torch.from_numpy(np.random.RandomState(0).permutation(U).astype(np.int32)).to(dev)
+    rows_list = [perm[k * B:(k + 1) * B].contiguous() for k in range(U // B)]
+    it = iter(rows_list * 20)
+    ms = _hip_timed(lambda: vae.step(next(it), 0.2, 0.8, want_loss=True), 150, 20)
+    # dominant kernels: the decoder gradient (row statistics + dW_p1 and dg1 on the fp32 matrix cores) reads the
+    # [B][I] logits slab three times
+    rows = rows_list[0]
+    vae.step(rows, 0.2, 0.8)
+    S = vae.gemm(vae.G1[:B], None, out=vae.S)
+
+    def decoder():
+        E.vae_decoder_loss_grad(S, I, vae.P["bp1"], vae.csr, rows, vae.G1[:B], vae.P["Wp1t"], vae.nll[:B],
+                                vae.G["Wp1t"], vae.G["bp1"], vae.dG1[:B], vae.ws)
+    dec_ms = _hip_timed(decoder, 40, 5)
+    for k in vae.G:
+        vae.G[k].zero_()
+    dec_bytes = 3 * B * I * 4
+    dec_flops = 2 * 2.0 * B * I * h                       # dW_p1 = G^T g1 and dg1 = G W_p1
+    users = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
+    ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=16384)
+
+    def evaluate():
+        pf, qf = vae.eval_factors()
+        return ev.evaluate_factors(pf, qf, users)
+    evaluate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = evaluate()
+    torch.cuda.synchronize()
+    edt = time.perf_counter() - t0
+    out = {"ms_per_step": ms, "users_per_sec_train": B / ms * 1e3, "batch": B, "p_dim": [z, h],
+           "roofline": {"bound": "hbm", "kernel": "vae_softmax_stats_kernel + vae_dwp1_mfma_kernel + vae_dg1_mfma_kernel "
+                                                  "(nrhip_vae_decoder_loss_grad)",
+                        "bytes_per_launch": dec_bytes, "us_per_launch": dec_ms * 1e3, "launches_per_step": 1,
+                        "achieved": dec_bytes / dec_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": dec_bytes / dec_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "mfma_tflops": dec_flops / dec_ms / 1e9,
+                        "note": "3*B*I*4 B: the [B][I] logits slab is read by each of the three kernels; the two "
+                                "gradients are 32-wide contractions (10.7 GFLOP), far from the MFMA roof — the slab "
+                                "reads bound them"},
+           "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9]),
+                    "design": "factor path: logits = [g1(u) | 1]·[W_p1 | b_p1] through the pruned evaluator"}}
+    if with_cpu:
+        from oracle import train as O
+        rng = np.random.RandomState(4)
+        p = {k: v.copy() for k, v in params.items()}
+        p["Wp1"] = np.ascontiguousarray(p.pop("Wp1t").T)
+        names = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1", "bp1")
+        plist = [p[k] for k in names]
+        ms_, vs_ = [np.zeros_like(x_) for x_ in plist], [np.zeros_like(x_) for x_ in plist]
+        adam = O.Adam(0.001)
+
+        def cpu_step():
+            rws = rng.choice(U, B, replace=False)
+            X = np.asarray(train[rws].todense(), dtype=np.float32)            # MultiVAE.py:152-165
+            mask = (rng.rand(B, I) < 0.8).astype(np.float32)
+            eps = (rng.randn(B, z) * 0.01).astype(np.float32)
+            _, (gWq, gbq, gWp, gbp), _ = O.multivae_loss_and_grads(
+                X, [p["Wq0"], p["Wq1"]], [p["bq0"], p["bq1"]], [p["Wp0"], p["Wp1"]], [p["bp0"], p["bp1"]],
+                mask, np.float32(0.8), eps, 0.2, 0.0, "tanh")
+            for p_, m_, v_, g_ in zip(plist, ms_, vs_, [gWq[0], gbq[0], gWq[1], gbq[1], gWp[0], gbp[0], gWp[1], gbp[1]]):
+                adam.dense(p_, m_, v_, g_.reshape(p_.shape))
+            adam.advance()
+        sec, n = _cpu_timed(cpu_step)
+        try:
+            nthreads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            nthreads = os.cpu_count() or 1
+        out["cpu_baseline"] = {"value": B / sec, "unit": "users/s", "cores": nthreads, "kind": "port",
+                               "sample": "%d Mult-VAE steps (B=%d) of oracle.train (numpy fp32; its [512 x 40981] "
+                                         "matmuls run on the BLAS threads of the box; pinned to the reference's "
+                                         "MultiVAE class by tests/test_tfgraph_golden.py)" % (n, B)}
+    return out
+
+
+def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
+    """BASELINE configs[3] (LightGCN, U = 10^7, I = 10^6, E = 2*10^8, d = 128) at `scale` on this GPU through
+    the row-sharded engine: graph generated on the device, adjacency block built on the device."""
+    import torch
+    from neurec_amd import engine as E, parallel as par, synth
+    from neurec_amd.sharded import ShardedLightGCN
+    from neurec_amd.trainer import BprEpochSampler
+    t_setup = time.perf_counter()
+    U, I, n_edges = (max(int(x * scale), 64) for x in synth.CONFIG4)
+    tr_ptr, tr_idx = synth.device_interactions(U, I, n_edges, seed=2018, device=dev)
+    n_train = int(tr_ptr[-1])
+    part = par.BipartitePartition(U, I, comm.world)
+    ur, ir = part.users_of(comm.rank), part.items_of(comm.rank)
+    rows = synth.device_lightgcn_rank_rows(tr_ptr, tr_idx, U, I, ur, ir)
+    lim = float(np.sqrt(6.0 / (U + I + dim)))
+    g = torch.Generator(device=dev)
+    g.manual_seed(2017 + comm.rank)
+    E0 = (torch.rand((ur[1] - ur[0]) + (ir[1] - ir[0]), dim, generator=g, device=dev) * 2 - 1) * lim
+    lg = ShardedLightGCN(comm, None, U, I, E0, layers, 0.01, 1e-3, batch, local_rows=rows)
+    del rows, E0
+    trc = E.DeviceCSR(tr_ptr, tr_idx, I)
+    sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=batch, shuffle=True, seed=2018, rank=comm.rank,
+                              world=comm.world, plan_users=None)
+    it = sampler.batches()
+    first = next(it)
+    lg.plan_epoch(sampler._users[:sampler.n_local], sampler._pos[:sampler.n_local], sampler._neg[:sampler.n_local],
+                  batch)
+    bs = [first] + [next(it) for _ in range(steps)]
+    lg.step(bs[0][0], bs[0][1], bs[0][2], None, batch_index=0)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+    t0 = time.perf_counter()
+    for k in range(1, steps + 1):
+        lg.step(bs[k][0], bs[k][1], bs[k][2], None, batch_index=k)
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = comm.max_float(time.perf_counter() - t0) / steps
+
+    def hops():
+        for k in range(2 * layers):
+            lg.A.matmul(lg.X, out=(lg.Ya, lg.Yb)[k % 2], addend=lg.H)
+    spmm_ms = _hip_timed(hops, 2, 1) / (2 * layers)
+    spmm_bytes = lg.A.algorithmic_bytes(dim)
+    gathered = int(lg.A.nnz) * dim * 4
+    out = {"scale": scale, "users": U, "items": I, "interactions": n_train, "dim": dim, "batch": batch,
+           "layers": layers, "steps": steps, "ms_per_step": dt * 1e3, "triplets_per_sec": comm.world * batch / dt,
+           "setup_seconds": setup_s,
+           "roofline": {"bound": "hbm", "kernel": lg.A.full_pass_kernel(dim), "bytes_per_launch": spmm_bytes,
+                        "us_per_launch": spmm_ms * 1e3, "launches_per_step": 2 * layers,
+                        "achieved": spmm_bytes / spmm_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": spmm_bytes / spmm_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "row_gather_bytes_per_launch": gathered, "row_gather_GBps": gathered / spmm_ms / 1e6,
+                        "note": "algorithmic bytes read every operand row once; a CSR pass gathers one %d-B row per "
+                                "non-zero from a table no cache holds — random row gathers run at 7.3-7.4 TB/s on "
+                                "this part whether the table sits in the Infinity Cache or in HBM (6.3 at 5 GB; "
+                                "profiles/r03_exp_gather_vs_table_size.txt), which is the rate the pass sustains"
+                                % (dim * 4)}}
+    del lg, sampler, trc, tr_ptr, tr_idx
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(train, test, E0, args, eval_tables=None, n_eval_users=1024):
@@ -277,6 +536,13 @@ def main():
                     ("one per step (sorted inside the step)" if not rowshard else 0)}
     triplets_per_s = comm.world * args.steps * args.batch / dt
     run_steps(1, loss2)                                  # untimed: loss of one more step, for the record
+    # SURVEY 8d defines the metric "sampler included" = E / epoch wall time: the per-epoch launches (sampler,
+    # batch plans) measured on their own and charged to an epoch of len(sampler) steps at the measured step time
+    epoch_ms = _hip_timed(sampler.sample_epoch, 3, 1)
+    steps_per_epoch = len(sampler)
+    n_epoch = sampler.n_local if not replicated else sampler.n_local // max(comm.world, 1)
+    timed_region["epoch_launch_ms"] = epoch_ms
+    epoch_amortised = comm.world * n_epoch / (steps_per_epoch * dt / args.steps + epoch_ms * 1e-3)
     if exchange:
         comm.allgather_cat_finish(inflight[0])           # drain the prefetched id gather
 
@@ -509,9 +775,24 @@ def main():
                                    "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()], "timed_region": timed_region,
+        "epoch_amortised": {"value": epoch_amortised, "unit": "triplets/s",
+                            "note": "one epoch = %d steps at the measured step time + the per-epoch sampler and "
+                                    "batch-plan launches (%.3f ms, HIP events): E / epoch wall time, SURVEY 8d's "
+                                    "definition of the metric" % (steps_per_epoch, epoch_ms)},
         "eval": eval_info, "mf": mf_info, "roofline": roofline,
         "device": E.device_info(),
     }
+    if comm.active:
+        import torch.distributed as dist
+        line["rccl_ranks"] = comm.world if dist.get_backend() == "nccl" else 0
+        line["dist_backend"] = dist.get_backend()
+        # what of the step is partitioned over the ranks and what every rank repeats
+        line["redundant_compute"] = {
+            "replicated": "everything: every rank runs the whole step on the global batch (no exchange)",
+            "triplets": "everything but the sampler: ids are exchanged, every rank runs the whole step",
+            "allreduce": "the propagation's full hops (batch-independent) are repeated on every rank; sampler, BPR "
+                         "head and the batch-masked hops are partitioned (each rank its B triplets)",
+            "rowshard": False}[args.dp_mode]
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         tables = None
         if eval_info is not None:
@@ -528,9 +809,29 @@ def main():
             eval_info["ndcg10_oracle_absdiff"] = abs(float(mine[2 * 20 + 9]) - cb["eval"]["ndcg@10"])
             eval_info["ndcg10_oracle_sample"] = "%d users, np.matmul scores + %s C++ evaluator" % (
                 len(sample_users), "the reference's own" if cb["eval"]["kind"] == "reference" else "the oracle's")
+            if mf_info is not None and "eval" in mf_info:
+                # the BPR-MF tables of the mf leg through the same comparison
+                from oracle import native, ref
+                P_h, Q_h = mf.P.cpu().numpy(), mf.Q.cpu().numpy()
+                truth = [test.indices[test.indptr[u]:test.indptr[u + 1]].tolist() for u in sample_users]
+                S = np.ascontiguousarray(np.matmul(P_h[sample_users], Q_h.T), dtype=np.float32)
+                native.mask_train(S, sample_users, train.indptr.astype(np.int64), train.indices)
+                fn = ref.eval_matrix if ref.available() else native.eval_matrix
+                want = float(np.mean(fn(S, truth, [1, 2, 4, 3, 5], 20, threads=8), axis=0)[2 * 20 + 9])
+                got = ev.evaluate_factors(mf.P, mf.Q, torch.from_numpy(sample_users).to(dev), exact_mean=True)
+                mf_info["ndcg10_oracle_absdiff"] = abs(float(got[2 * 20 + 9]) - want)
         line["cpu_baseline"] = cb
     else:
         line["cpu_baseline"] = None
+    # ---------------- the other BASELINE configs on this GPU (driver-visible legs)
+    if comm.rank == 0 and comm.world == 1 and not config4 and default_workload:
+        if not args.no_config5:
+            line["ngcf"] = leg_ngcf(train, test, trc, tec, dev, not args.no_cpu_baseline)
+            line["multivae"] = leg_multivae(train, test, trc, tec, dev, not args.no_cpu_baseline)
+    if comm.rank == 0 and comm.world == 1 and not config4 and default_workload and not args.no_config4:
+        ev = mf_ev = None
+        torch.cuda.empty_cache()
+        line["config4"] = leg_config4(comm, dev, args.config4_scale)
     if comm.rank == 0:
         print(json.dumps(line))
     comm.shutdown()
