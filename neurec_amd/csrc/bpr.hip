@@ -95,16 +95,20 @@ __device__ __forceinline__ void finish_loss(const float* term_mf, const float* t
   if (arrivers == 0) arrivers = gridDim.x;
   __shared__ bool s_last;
   __shared__ double s_a[256], s_b[256];
-  // The terms were stored with agent scope (write-through); waiting for their completion is all
-  // the ordering needed before the counter moves.  A full __threadfence() here costs an L2
-  // write-back per block (the row-gradient atomics leave the L2 dirty): +6 us on an MF step.
+  // Hand-off to the last arriver, by the memory model: every thread's term stores happen-before the
+  // workgroup barrier (workgroup-scope release fence + barrier), thread 0's counter increment is an
+  // agent-scope RELEASE (cumulative over what the barrier ordered before it), the winner ACQUIRES at
+  // agent scope before it reads the other workgroups' terms.  (r01/r02 used a relaxed increment
+  // behind s_waitcnt(0) — correct on gfx950 because the terms are write-through agent-scope stores,
+  // but formally a race; the release costs an L2 write-back per workgroup, measured in
+  // profiles/r03_exp_loss_handoff.txt.)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrivers - 1;
+    s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == arrivers - 1;
   __syncthreads();
   if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // the first 256 threads reduce (callers launch 256- or 1024-thread blocks): fixed partition,
   // fixed tree — the same sum whatever the block shape
   if (threadIdx.x < 256) {
