@@ -40,11 +40,12 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--eval-batch", type=int, default=32768)
-    ap.add_argument("--dp-mode", choices=("replicated", "triplets", "allreduce", "rowshard"), default="replicated",
-                    help="N>1: every rank generates the epoch stream of the GLOBAL batch itself (counter-based "
-                         "sampler: same seed, same stream — no exchange at all; default), all-gather the "
-                         "batch ids, all-reduce dL/dE0, or row-sharded tables (all-gather per hop + "
-                         "all-to-all lookups; config 4 path)")
+    ap.add_argument("--dp-mode", choices=("replicated", "triplets", "allreduce", "rowshard"), default=None,
+                    help="N>1 (default: allreduce — every rank back-propagates ITS B triplets, RCCL sums dL/dE0; the "
+                         "batch-independent full hops are repeated on every rank and labelled so).  rowshard: tables "
+                         "row-sharded, nothing repeated (all-gather per hop + all-to-all lookups; the config-4 "
+                         "path).  Opt-in, fully redundant compute: replicated (every rank generates the global "
+                         "batch itself and runs the whole step on it, no exchange) and triplets (ids all-gathered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--eval-mode", choices=("pruned", "materialised"), default="pruned")
@@ -294,9 +295,20 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
     spmm_ms = _hip_timed(hops, 2, 1) / (2 * layers)
     spmm_bytes = lg.A.algorithmic_bytes(dim)
     gathered = int(lg.A.nnz) * dim * 4
+    exchange = None
+    if comm.active:
+        comm.barrier()
+        ag_ms = _hip_timed(lambda: comm.all_gather_rows(lg.E0, lg.X), 3, 1)
+        exchange = {"all_gather_per_hop_bytes": int(lg.X.numel() * 4), "all_gather_per_hop_ms": ag_ms,
+                    "hops_per_step": 2 * layers, "received_per_rank_bytes": int(lg.X.numel() * 4 * (comm.world - 1)
+                                                                                // comm.world),
+                    "lookup_all_to_all_bytes_per_step": int(3 * batch * dim * 4 * 3),
+                    "note": "one all-gather of the [N][d] table per propagation hop (not overlapped: a row's sum must "
+                            "run in ascending column order, see neurec_amd/sharded.py), ids -> rows -> gradient rows by "
+                            "three all-to-alls"}
     out = {"scale": scale, "users": U, "items": I, "interactions": n_train, "dim": dim, "batch": batch,
            "layers": layers, "steps": steps, "ms_per_step": dt * 1e3, "triplets_per_sec": comm.world * batch / dt,
-           "setup_seconds": setup_s,
+           "setup_seconds": setup_s, "ranks": comm.world, "exchange": exchange,
            "roofline": {"bound": "hbm", "kernel": lg.A.full_pass_kernel(dim), "bytes_per_launch": spmm_bytes,
                         "us_per_launch": spmm_ms * 1e3, "launches_per_step": 2 * layers,
                         "achieved": spmm_bytes / spmm_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -426,6 +438,8 @@ def main():
     from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
 
     comm = parallel.init_from_env()
+    if args.dp_mode is None:
+        args.dp_mode = "allreduce" if comm.active else "replicated"      # one rank: the modes coincide
     if args.gpus != comm.world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, comm.world, args.gpus))
@@ -793,6 +807,32 @@ def main():
             "allreduce": "the propagation's full hops (batch-independent) are repeated on every rank; sampler, BPR "
                          "head and the batch-masked hops are partitioned (each rank its B triplets)",
             "rowshard": False}[args.dp_mode]
+    if comm.active and not rowshard and not config4:
+        # the SAME global batch stepped by ONE GPU alone (no collectives; every rank does it, rank 0 reports): what
+        # the N-GPU figure has to be read against — a full-graph LightGCN step costs the same whatever B is, so a
+        # single GPU on the N*B batch already gets most of the "scaling" of a replicated run
+        gB = comm.world * args.batch
+        lg1 = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3, gB)
+        s1 = BprEpochSampler(trc, I, neg_num=1, batch_size=gB, shuffle=True, seed=2018, plan_users=U)
+        bs1 = [b for b in s1.batches() if b[0].numel() == gB][:40]
+        it1 = iter(bs1 * 4)
+
+        def one():
+            b = next(it1)
+            lg1.step(b[0], b[1], b[2], None, plan=b.plan)
+        ms1 = _hip_timed(one, 60, 10)
+        line["same_global_batch_on_1gpu"] = {"value": gB / ms1 * 1e3, "unit": "triplets/s", "ms_per_step": ms1,
+                                             "global_batch": gB}
+        del lg1, s1, bs1
+    if comm.active and not args.no_config4 and not config4:
+        # row-sharded tables on the config-4 LAW at a fixed per-GPU slice (scale = N/8 of BASELINE configs[3]): the
+        # partitioned mode's own weak-scaling leg — every rank a slice of the users and of the items, RCCL all-gather
+        # per hop, all-to-all lookups (north_star's row-shard path); nothing is repeated across ranks
+        ev = None
+        torch.cuda.empty_cache()
+        leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0)
+        if comm.rank == 0:
+            line["rowshard_config4_law"] = leg
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         tables = None
         if eval_info is not None:

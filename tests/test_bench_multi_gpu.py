@@ -18,7 +18,7 @@ def _run(mode, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "6", "--warmup", "2", "--scale", "0.05", "--batch", "256",
-           "--no-cpu-baseline", "--no-mf", "--dp-mode", mode]
+           "--no-cpu-baseline", "--no-mf", "--config4-scale", "0.002"] + (["--dp-mode", mode] if mode else [])
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -27,9 +27,24 @@ def _run(mode, port):
 
 
 @pytest.mark.parametrize("mode,port", [("replicated", 29611), ("triplets", 29612), ("allreduce", 29613),
-                                       ("rowshard", 29614)])
+                                       ("rowshard", 29614), (None, 29615)])
 def test_two_rank_bench_line(mode, port):
     d = _run(mode, port)
+    # what of the step every rank repeats is said in the line; the default N>1 mode partitions the batch work and
+    # moves data (all-reduce of dL/dE0); the fully redundant modes are opt-in
+    assert d["dist_backend"] == "gloo" and d["rccl_ranks"] == 0          # this test box has one GPU: no RCCL here
+    if mode is None:
+        assert "one all-reduce" in d["config"]["parallelism"] and d["redundant_compute"].startswith("the propagation")
+    if mode in ("replicated", "triplets"):
+        assert d["redundant_compute"].startswith("everything")
+    if mode == "rowshard":
+        assert d["redundant_compute"] is False
+    else:
+        assert d["same_global_batch_on_1gpu"]["global_batch"] == 512 and d["same_global_batch_on_1gpu"]["value"] > 0
+    leg = d["rowshard_config4_law"]                                        # every N>1 line carries the row-shard leg
+    assert leg["ranks"] == 2 and leg["ms_per_step"] > 0 and leg["exchange"]["all_gather_per_hop_ms"] > 0
+    assert abs(leg["scale"] - 0.002 * 2 / 8) < 1e-12
+    mode = mode or "allreduce"
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 512
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert str(2) in d["config"]["parallelism"]
