@@ -478,7 +478,16 @@ def main():
         args.no_eval, args.no_mf, args.no_cpu_baseline = True, True, True
         train_nnz = n_train
     else:
-        train, test = synth.interactions(args.shape, seed=2018, scale=args.scale)
+        real_test = os.path.join(ROOT, "tests", "golden", "gowalla_test_split.npz")
+        data_test = "synthetic"
+        if args.shape == "gowalla" and args.scale == 1.0 and os.path.isfile(real_test):
+            # the test split is the reference's real dataset/gowalla.test (committed as a fixture —
+            # the reference tree does not travel); gowalla.train is absent from the reference tree, so the
+            # train side is drawn around that split (E = 810,128, the LightGCN-paper split's size)
+            train, test = synth.interactions_around_test(synth.load_test_split(real_test), 810128, seed=2018)
+            data_test = "the reference's dataset/gowalla.test (217,242 pairs)"
+        else:
+            train, test = synth.interactions(args.shape, seed=2018, scale=args.scale)
         U, I = train.shape
         train_nnz = train.nnz
         coo = train.tocoo()
@@ -770,9 +779,8 @@ def main():
         "unit": "triplets/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "data_note": "train AND test interactions are synthetic twins of the named shape (neurec_amd/synth.py); SURVEY "
-                     "8d names the reference's real dataset/gowalla.test as the test split, but the reference tree does "
-                     "not exist on the GPU box and gowalla.train is absent from the reference tree altogether",
+        "data_note": "train interactions are a synthetic twin of the named shape (neurec_amd/synth.py: gowalla.train is "
+                     "absent from the reference tree); test split: %s" % (data_test if not config4 else "none"),
         "config": {"workload": "LightGCN on synthetic %s-shaped interactions (U=%d, I=%d, E=%d), "
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
                                % (args.shape, U, I, train_nnz, args.layers, args.dim, args.batch),

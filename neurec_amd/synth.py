@@ -36,6 +36,36 @@ def _draw_unique(rng, n_items, degrees, cdf, forbid=None):
     return owner[keep].astype(np.int32), items[keep].astype(np.int32)
 
 
+def interactions_around_test(test, n_train, seed=2018):
+    """SURVEY §8d's gowalla-shaped workload: the test split is GIVEN (the reference's real
+    dataset/gowalla.test, 217,242 pairs — tests/golden/gowalla_test_split.npz) and the missing train side
+    is synthesised around it: user degrees max(8, round(LogNormal(2.9, 0.9))) rescaled to n_train
+    interactions, items drawn without replacement per user with p ∝ (rank + 10)^-0.8 over shuffled ranks,
+    never one of the user's test items.  Returns (train_csr, test_csr)."""
+    test = sp.csr_matrix(test, dtype=np.float32)
+    test.sort_indices()
+    U, I = test.shape
+    rng = np.random.RandomState(seed)
+    deg = np.maximum(8, np.round(rng.lognormal(2.9, 0.9, U))).astype(np.float64)
+    deg = np.maximum(1, np.round(deg * (n_train / deg.sum()))).astype(np.int64)
+    deg = np.minimum(deg, I // 4)
+    pop = (np.arange(I) + 10.0) ** -0.8
+    rng.shuffle(pop)
+    cdf = np.cumsum(pop / pop.sum())
+    coo = test.tocoo()
+    tu, ti = _draw_unique(rng, I, deg, cdf, forbid=np.sort(coo.row.astype(np.int64) * I + coo.col))
+    train = sp.csr_matrix((np.ones(len(tu), np.float32), (tu, ti)), shape=(U, I))
+    train.sort_indices()
+    return train, test
+
+
+def load_test_split(path):
+    """the CSR fixture written by tests/golden/make_gowalla_test_fixture.py"""
+    z = np.load(path)
+    U, I = (int(x) for x in z["shape"])
+    return sp.csr_matrix((np.ones(len(z["indices"]), np.float32), z["indices"], z["indptr"]), shape=(U, I))
+
+
 def interactions(shape="gowalla", seed=2018, scale=1.0):
     """Returns (train_csr, test_csr) scipy matrices; `scale` multiplies users/items/edges."""
     U, I, E, mean_test = SHAPES[shape]

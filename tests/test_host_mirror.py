@@ -323,3 +323,22 @@ def _try_lightgcn(cls, conf):
         cls.__init__(obj, None, types.SimpleNamespace(num_users=3, num_items=3), conf)
     finally:
         mod.AbstractRecommender.__init__ = orig
+
+
+def test_gowalla_benchmark_split_is_the_references_test_file():
+    """the gowalla workload's test split is the reference's real dataset/gowalla.test (committed
+    as a CSR fixture); the train side is synthesised around it and never contains a test pair."""
+    import os
+    from conftest import GOLDEN
+    from neurec_amd import synth
+    te = synth.load_test_split(os.path.join(GOLDEN, "gowalla_test_split.npz"))
+    assert te.shape == (29858, 40981) and te.nnz == 217242 and (np.diff(te.indptr) > 0).all()
+    src = "/root/reference/dataset/gowalla.test"
+    if os.path.isfile(src):                                   # the fixture IS the file (build container only)
+        pairs = np.loadtxt(src, delimiter=",", dtype=np.int64)
+        assert len(pairs) == te.nnz
+        assert np.array_equal(np.sort(pairs[:, 0] * 40981 + pairs[:, 1]),
+                              np.repeat(np.arange(29858), np.diff(te.indptr)) * 40981 + te.indices)
+    tr, te2 = synth.interactions_around_test(te, 810128, seed=2018)
+    assert tr.shape == te.shape and abs(tr.nnz - 810128) < 8000 and tr.multiply(te2).nnz == 0
+    assert np.diff(tr.indptr).min() >= 1
