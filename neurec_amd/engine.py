@@ -521,9 +521,12 @@ class SpmmCSR:
         return self._h_indices
 
     @staticmethod
-    def from_scipy(mat, item_rows=0, item_nnz=0, split_row=0):
+    def from_scipy(mat, item_rows=0, item_nnz=0, split_row=0, keep_order=False):
+        """keep_order: keep each row's storage order (the kernels sum a row in that order) instead of
+        sorting the columns ascending — graph.lightgcn_adjacency(..., tf_order=True)"""
         m = mat.tocsr().astype(np.float32)
-        m.sort_indices()
+        if not keep_order:
+            m.sort_indices()
         return SpmmCSR(m.indptr, m.indices, m.data, m.shape[1], item_rows, item_nnz, split_row)
 
     def __del__(self):

@@ -8,10 +8,12 @@ of fp32 (or, where the reference silently promotes through `sp.eye`, fp64) opera
 
 Pinned: tests/test_adjacency_golden.py compares every adj_type bit-for-bit with matrices made by
 the reference's own methods (tests/golden/make_golden_adjacency.py).  One order difference is
-known and stated: for LightGCN `gcmc` the reference's single scipy product leaves each row's
-columns in descending order and hands TF the COO that way; here every adjacency is canonical
-(ascending columns) — same entries, same values, the row sums of that one non-default type may
-differ from a TF-CPU run in the last ulp.
+known: for LightGCN `gcmc` the reference's single scipy product leaves each row's columns in
+DESCENDING order and hands TF the COO that way.  By default every adjacency here is canonical
+(ascending columns) — same entries, same values; `lightgcn_adjacency(..., tf_order=True)` returns the
+`gcmc` rows in the reference's descending storage order (pass `keep_order=True` on to
+LightGCNEngine / SpmmCSR.from_scipy: the SpMM kernels sum a row in its storage order), so that mode
+can be bit-faithful too.
 
 This runs once per training run on the host, exactly where the reference runs it; it is not
 on the measured path.
@@ -42,7 +44,9 @@ def bipartite_adjacency(user_idx, item_idx, n_users, n_items):
     return a
 
 
-def lightgcn_adjacency(user_idx, item_idx, n_users, n_items, adj_type="pre"):
+def lightgcn_adjacency(user_idx, item_idx, n_users, n_items, adj_type="pre", tf_order=False):
+    """tf_order=True: rows stored in the order the reference hands them to TensorFlow (differs from
+    ascending columns for `gcmc` only: descending)."""
     a = bipartite_adjacency(user_idx, item_idx, n_users, n_items)
     n = a.shape[0]
     row_of = np.repeat(np.arange(n), np.diff(a.indptr))
@@ -79,6 +83,20 @@ def lightgcn_adjacency(user_idx, item_idx, n_users, n_items, adj_type="pre"):
         raise ValueError("adj_type must be one of %s" % (ADJ_TYPES,))
     out = out.tocsr().astype(np.float32)
     out.sort_indices()
+    if tf_order and adj_type == "gcmc":
+        out = reverse_rows(out)
+    return out
+
+
+def reverse_rows(a):
+    """the same CSR with every row's entries in reverse storage order (ascending -> descending columns)"""
+    a = a.tocsr()
+    nnz = a.nnz
+    row_of = np.repeat(np.arange(a.shape[0]), np.diff(a.indptr))
+    # position p of row r (p in [lo, hi)) takes the entry at lo + hi - 1 - p
+    src = a.indptr[row_of] + a.indptr[row_of + 1] - 1 - np.arange(nnz)
+    out = sp.csr_matrix((a.data[src], a.indices[src], a.indptr.copy()), shape=a.shape)
+    out.has_sorted_indices = False
     return out
 
 

@@ -42,7 +42,9 @@ class LightGCN(AbstractRecommender):
     @timer
     def create_adj_mat(self, adj_type):
         user_list, item_list = self.dataset.get_train_interactions()
-        adj = lightgcn_adjacency(user_list, item_list, self.n_users, self.n_items, adj_type)
+        # tf_order: the rows in the order the reference hands them to TensorFlow (`gcmc`: descending columns —
+        # its single scipy product leaves them so, LightGCN.py:48); the kernels sum a row in storage order
+        adj = lightgcn_adjacency(user_list, item_list, self.n_users, self.n_items, adj_type, tf_order=True)
         print({"plain": "use the plain adjacency matrix", "norm": "use the normalized adjacency matrix",
                "gcmc": "use the gcmc adjacency matrix", "pre": "use the pre adjcency matrix"}
               .get(adj_type, "use the mean adjacency matrix"))
@@ -61,7 +63,7 @@ class LightGCN(AbstractRecommender):
         adj_t = None if is_symmetric(self.norm_adj) else transpose_csr(self.norm_adj)
         self.engine = LightGCNEngine(self.norm_adj, self.n_users, self.n_items, table,
                                      self.n_layers, self.lr, self.reg, self.batch_size,
-                                     adj_t_csr=adj_t)
+                                     adj_t_csr=adj_t, keep_order=True)
 
     def train_model(self):
         import torch

@@ -308,7 +308,9 @@ class LightGCNEngine:
     buffers all stay resident in HBM."""
 
     def __init__(self, adj_csr, n_users, n_items, embed, n_layers, lr, reg, max_batch,
-                 adj_t_csr=None):
+                 adj_t_csr=None, keep_order=False):
+        """keep_order: the forward adjacency keeps its rows' storage order (graph.lightgcn_adjacency with
+        tf_order=True: `gcmc` rows descending, as the reference hands them to TF)"""
         dev = E.require_gpu()
         self.n_users, self.n_items, self.n_layers = int(n_users), int(n_items), int(n_layers)
         self.N = self.n_users + self.n_items
@@ -316,7 +318,8 @@ class LightGCNEngine:
             from .graph import is_symmetric, transpose_csr
             if not is_symmetric(adj_csr):            # 'norm'/'gcmc'/'mean': backward needs A^T
                 adj_t_csr = transpose_csr(adj_csr)
-        self.A = adj_csr if isinstance(adj_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_csr, split_row=n_users)
+        self.A = adj_csr if isinstance(adj_csr, E.SpmmCSR) else \
+            E.SpmmCSR.from_scipy(adj_csr, split_row=n_users, keep_order=keep_order)
         if adj_t_csr is None:
             self.At = self.A
         else:

@@ -75,6 +75,40 @@ def test_spmm_matches_scipy_rowwise(eng, d):
         assert np.abs(Yn.cpu().numpy() - train.spmm_rowwise(M, X)).max() < 1e-5
 
 
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_spmm_sums_a_row_in_its_storage_order(eng, d):
+    """`gcmc` as the reference hands it to TF: every row's columns DESCENDING (graph.lightgcn_adjacency with
+    tf_order=True).  The kernels walk a row's entries as stored, so the sums are those of the descending walk —
+    bit for bit on rows that are not cut into segments — and differ in the last ulp from the ascending walk."""
+    import torch
+    from neurec_amd.graph import lightgcn_adjacency
+    rng = np.random.RandomState(d + 1)
+    U, I = 700, 500
+    ur, ic = _graph(rng, U, I, 0, 30, hubs=1)
+    A_desc = lightgcn_adjacency(ur, ic, U, I, "gcmc", tf_order=True)
+    A_asc = lightgcn_adjacency(ur, ic, U, I, "gcmc")
+    assert np.all(np.diff(A_desc.indices)[np.diff(np.repeat(np.arange(U + I), np.diff(A_desc.indptr))) == 0] < 0)
+    X = rng.randn(U + I, d).astype(np.float32)
+    csr = eng.SpmmCSR.from_scipy(A_desc, keep_order=True)
+    Y = torch.empty_like(_dev(X))
+    csr.matmul(_dev(X), out=Y)
+    got = Y.cpu().numpy()
+
+    def walk(A):                                   # sequential fp32 accumulation in storage order
+        out = np.zeros((A.shape[0], d), np.float32)
+        for r in range(A.shape[0]):
+            acc = np.zeros(d, np.float32)
+            for p in range(A.indptr[r], A.indptr[r + 1]):
+                acc = acc + A.data[p] * X[A.indices[p]]
+            out[r] = acc
+        return out
+    want_desc, want_asc = walk(A_desc), walk(A_asc)
+    short = np.diff(A_desc.indptr) <= csr.exact_row_nnz(d)
+    np.testing.assert_array_equal(got[short], want_desc[short])
+    assert (want_desc[short] != want_asc[short]).any()          # the order is observable
+    assert np.abs(got - want_asc).max() < 1e-5
+
+
 @pytest.mark.parametrize("d", [128, 256])
 def test_spmm_lane_group_kernel_wide_rows(eng, d):
     """the persistent lane-group kernel at d = 128 / 256 (2 / 1 rows per load instruction), forced:
