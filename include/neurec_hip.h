@@ -35,7 +35,7 @@ extern "C" {
 #define NRHIP_ERR_HIP 3
 #define NRHIP_ERR_WORKSPACE 4
 
-#define NRHIP_ABI_VERSION 3
+#define NRHIP_ABI_VERSION 4
 #define NRHIP_MAX_TOPK 128 /* largest top_k the selection kernels accept */
 
 /* ---- library ------------------------------------------------------------ */
@@ -468,11 +468,19 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
 /* The batch loop of MF.train_model (model/general_recommender/MF.py:95-103) over the consecutive batches of
  * one epoch stream (n_total triplets, `batch` per step, the last one short): step k runs on triplets
  * [k*batch, ...), plan d_plans + 3*k*batch (layout of nrhip_bpr_plan(n_total, batch); NULL: sorted per step),
- * step index first_step_index + k, step size h_alpha[k] (HOST array), loss pair d_loss2[2k..2k+1]. */
+ * step index first_step_index + k, step size h_alpha[k] (HOST array), loss pair d_loss2[2k..2k+1].
+ * d_terms_steps: NULL, or 2*batch floats per step — the one-launch form then leaves each step's per-triplet
+ * loss terms there and one launch after the loop (nrhip_loss_reduce_steps) produces every pair: the same sums
+ * bit for bit, no cross-workgroup hand-off inside the steps (MF.py:101 fetches the loss per step but only adds
+ * it up, :103,110). */
 int nrhip_mf_steps(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
                    int64_t n_total, int batch, const uint64_t* d_plans, int first_step_index,
                    const float* h_alpha, float beta1, float beta2, float eps, float* d_loss2,
-                   void* stream);
+                   float* d_terms_steps, void* stream);
+/* (sum of the BPR terms, reg * sum of the l2 terms) of n_steps steps from their per-triplet terms: step k's lie at
+ * d_terms + k*2*batch ([n] terms, then [n] l2 terms; n = batch, the last step n_last). */
+int nrhip_loss_reduce_steps(const float* d_terms, int n_steps, int batch, int n_last, float reg, float* d_loss2,
+                            void* stream);
 /* lazy mode: bring every row of both tables to step `steps_done` (no-op otherwise) */
 int nrhip_mf_flush(void* ctx, int steps_done, float beta1, float beta2, float eps, void* stream);
 

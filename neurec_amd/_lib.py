@@ -125,7 +125,8 @@ SIGNATURES = {
     "nrhip_ngcf_ctx_destroy": [p],
     "nrhip_ngcf_forward": [p, C.c_uint64, C.c_uint64, i32, p],
     "nrhip_ngcf_step": [p, p, p, p, i32, p, C.c_uint64, C.c_uint64, i32, f32, f32, f32, f32, p, p],
-    "nrhip_mf_steps": [p, p, p, p, i64, i32, p, i32, p, f32, f32, f32, p, p],
+    "nrhip_mf_steps": [p, p, p, p, i64, i32, p, i32, p, f32, f32, f32, p, p, p],
+    "nrhip_loss_reduce_steps": [p, i32, i32, i32, f32, p, p],
     "nrhip_bpr_mf_step_fused": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, i32, p, p, p, i32, f32, p, p, p,
                                 i32, p, i32, i32, p],
     "nrhip_bpr_mf_fused_flush": [p, p, p, p, p, i32, f32, f32, f32, i32, i64, p],
@@ -192,7 +193,8 @@ lib.nrhip_last_error.restype = C.c_char_p
 
 EXPORTED = sorted(list(SIGNATURES) + ["nrhip_abi_version", "nrhip_last_error"])
 
-ABI_VERSION = 3      # 2: deterministic row-gradient sums (batch plans); 3: one-launch BPR-MF step (mf_buffers.tw)
+ABI_VERSION = 4      # 2: deterministic row-gradient sums (batch plans); 3: one-launch BPR-MF step (mf_buffers.tw);
+                     # 4: nrhip_mf_steps takes a per-step terms buffer (one loss reduction per call)
 if lib.nrhip_abi_version() != ABI_VERSION:  # pragma: no cover
     raise ImportError("libneurec_hip.so ABI version %d, expected %d"
                       % (lib.nrhip_abi_version(), ABI_VERSION))

@@ -410,7 +410,7 @@ void nrhip_set_error(const char* fmt, ...) {
 
 const char* nrhip_last_error(void) { return g_err; }
 
-int nrhip_abi_version(void) { return 3; }
+int nrhip_abi_version(void) { return 4; }
 
 int nrhip_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, int name_len) {
   int dev = 0;

@@ -88,6 +88,46 @@ __device__ __forceinline__ void load_row_lazy(const float* __restrict__ base, in
 // 17 % of an MF step).  `done` is one of a small pool of device counters, zero between launches.
 __device__ unsigned g_done_pool[64];
 
+// out2[0] = sum mf, out2[1] = reg * sum l2 over `batch` per-triplet terms: the first 256 threads of the
+// workgroup (callers launch 256- or 1024-thread blocks) take a fixed strided partition, then a fixed tree —
+// the same sum whatever the block shape and whichever kernel runs it
+__device__ __forceinline__ void reduce_terms(const float* term_mf, const float* term_l2, int batch, float reg,
+                                             float* __restrict__ out2, double* s_a, double* s_b) {
+  if (threadIdx.x < 256) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < batch; i += 256) {   // other blocks' terms: read past the L1
+      a += (double)__hip_atomic_load(&term_mf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b += (double)__hip_atomic_load(&term_l2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
+  }
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      s_a[threadIdx.x] += s_a[threadIdx.x + s];
+      s_b[threadIdx.x] += s_b[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = (float)s_a[0];
+    out2[1] = reg * (float)s_b[0];
+  }
+}
+
+// The same reduction for many steps at once, AFTER the launches that wrote the terms (kernel boundary: no
+// hand-off inside a step at all).  Step k's terms: d_terms + k * 2 * batch ([batch] mf then [batch] l2; the
+// last step may be short: n_last).
+__global__ __launch_bounds__(256) void loss_reduce_steps_kernel(const float* __restrict__ terms, int batch,
+                                                                int n_last, float reg, float* __restrict__ out2) {
+  __shared__ double s_a[256], s_b[256];
+  const int k = blockIdx.x;
+  const int nb = k == (int)gridDim.x - 1 ? n_last : batch;
+  const float* t = terms + (int64_t)k * 2 * batch;
+  reduce_terms(t, t + nb, nb, reg, out2 + 2 * k, s_a, s_b);
+}
+
 __device__ __forceinline__ void finish_loss(const float* term_mf, const float* term_l2, int batch,
                                             float reg, float* __restrict__ out2, unsigned* done,
                                             unsigned arrivers = 0) {   // 0: every workgroup of the grid
@@ -109,30 +149,8 @@ __device__ __forceinline__ void finish_loss(const float* term_mf, const float* t
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // the first 256 threads reduce (callers launch 256- or 1024-thread blocks): fixed partition,
-  // fixed tree — the same sum whatever the block shape
-  if (threadIdx.x < 256) {
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < batch; i += 256) {   // other blocks' terms: read past the L1
-      a += (double)__hip_atomic_load(&term_mf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      b += (double)__hip_atomic_load(&term_l2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    s_a[threadIdx.x] = a;
-    s_b[threadIdx.x] = b;
-  }
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      s_a[threadIdx.x] += s_a[threadIdx.x + s];
-      s_b[threadIdx.x] += s_b[threadIdx.x + s];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    out2[0] = (float)s_a[0];
-    out2[1] = reg * (float)s_b[0];
-    *done = 0;                                       // re-armed for the next launch that draws it
-  }
+  reduce_terms(term_mf, term_l2, batch, reg, out2, s_a, s_b);
+  if (threadIdx.x == 0) *done = 0;                     // re-armed for the next launch that draws it
 }
 
 // ---- BPR-MF ------------------------------------------------------------------
@@ -1391,13 +1409,14 @@ int nrhip_bpr_mf_step_fused(float* d_W, float* d_M, float* d_V, int32_t* d_tw, i
                             const int32_t* d_neg, int batch, float reg, float* d_work, float* d_loss2,
                             const uint64_t* d_plan, int batch_marked, const uint64_t* d_next_plan,
                             int n_next_occ, int period, void* stream) {
+  // d_loss2 == NULL: the per-triplet terms stay in d_work ([batch] mf, [batch] l2) for nrhip_loss_reduce_steps
   NR_REQUIRE(d_W && d_M && d_V && d_tw && d_inb && d_alpha_tab && d_users && d_pos && d_neg && d_work &&
-                 d_loss2 && (batch == 0 || d_plan), NR_ERR_ARG, "bpr_mf_step_fused: null pointer argument");
+                 (batch == 0 || d_plan), NR_ERR_ARG, "bpr_mf_step_fused: null pointer argument");
   NR_REQUIRE(d >= 1 && d <= 256 && batch >= 0 && n_users >= 0 && n_items >= 0 && t >= 1 && period >= 1 &&
                  n_next_occ >= 0 && (n_next_occ == 0 || d_next_plan), NR_ERR_ARG, "bpr_mf_step_fused: bad sizes");
   const int64_t rows = (int64_t)n_users + n_items;
   hipStream_t st = (hipStream_t)stream;
-  if (batch == 0) NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
+  if (batch == 0 && d_loss2) NR_CHECK_HIP(hipMemsetAsync(d_loss2, 0, 2 * sizeof(float), st));
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
   const FusedTables ft{d_W, d_M, d_V, d_tw, d_inb, d_alpha_tab, rows, t, beta1, beta2, 1.0f - beta1,
@@ -1443,6 +1462,20 @@ int nrhip_bpr_mf_fused_flush(float* d_W, float* d_M, float* d_V, int32_t* d_tw, 
   if (d <= 64) hipLaunchKernelGGL(mf_fused_flush_kernel<1>, grid, block, 0, st, ft, d);
   else if (d <= 128) hipLaunchKernelGGL(mf_fused_flush_kernel<2>, grid, block, 0, st, ft, d);
   else hipLaunchKernelGGL(mf_fused_flush_kernel<4>, grid, block, 0, st, ft, d);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Loss pairs of n_steps steps whose kernels were launched with d_loss2 = NULL: step k's per-triplet terms lie at
+ * d_terms + k * 2 * batch (the last step holds n_last <= batch triplets).  The same fixed-order sums as the
+ * in-kernel reduction, bit for bit. */
+int nrhip_loss_reduce_steps(const float* d_terms, int n_steps, int batch, int n_last, float reg, float* d_loss2,
+                            void* stream) {
+  NR_REQUIRE(d_terms && d_loss2 && n_steps >= 0 && batch >= 1 && n_last >= 0 && n_last <= batch, NR_ERR_ARG,
+             "loss_reduce_steps: bad arguments");
+  if (n_steps == 0) return NR_OK;
+  hipLaunchKernelGGL(loss_reduce_steps_kernel, dim3(n_steps), dim3(256), 0, (hipStream_t)stream, d_terms, batch,
+                     n_last, reg, d_loss2);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -271,11 +271,14 @@ int nrhip_mf_ctx_destroy(void* ctx) {
   return NR_OK;
 }
 
-// One BPR-MF step = sess.run((loss, optimizer)) (MF.py:101)
-int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
-                  int batch, const uint64_t* d_plan, const uint64_t* d_next_plan, int next_batch,
-                  int step_index, float alpha, float beta1, float beta2, float eps, float* d_loss2,
-                  void* stream) {
+}  // extern "C"
+
+// d_terms != NULL (one-launch form only): the step leaves its per-triplet loss terms there ([batch] mf, [batch]
+// l2) and reduces nothing; the caller reduces many steps at once afterwards (nrhip_loss_reduce_steps)
+static int mf_step_impl(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                        int batch, const uint64_t* d_plan, const uint64_t* d_next_plan, int next_batch,
+                        int step_index, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                        float* d_terms, void* stream) {
   NR_REQUIRE(ctx && d_users && d_pos && d_neg && d_loss2, NR_ERR_ARG, "mf_step: null argument");
   const nrhip_mf_buffers& b = ((MFCtx*)ctx)->b;
   NR_REQUIRE(batch >= 0 && batch <= b.max_batch, NR_ERR_ARG, "mf_step: batch %d outside 0..%d",
@@ -303,7 +306,8 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
     c->marked_plan = d_next_plan;
     c->marked_step = step_index + 1;
     return nrhip_bpr_mf_step_fused(b.P, b.mP, b.vP, b.tw, b.inb, alpha_tab, step_index, beta1, beta2, eps, b.d,
-                                   b.n_users, b.n_items, d_users, d_pos, d_neg, batch, b.reg, b.terms, d_loss2,
+                                   b.n_users, b.n_items, d_users, d_pos, d_neg, batch, b.reg,
+                                   d_terms ? d_terms : b.terms, d_terms ? nullptr : d_loss2,
                                    plan, marked, d_next_plan, d_next_plan ? 3 * next_batch : 0, b.lazy_period,
                                    stream);
   }
@@ -343,27 +347,48 @@ int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const
   return NR_OK;
 }
 
+extern "C" {
+
+// One BPR-MF step = sess.run((loss, optimizer)) (MF.py:101)
+int nrhip_mf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                  int batch, const uint64_t* d_plan, const uint64_t* d_next_plan, int next_batch,
+                  int step_index, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                  void* stream) {
+  return mf_step_impl(ctx, d_users, d_pos, d_neg, batch, d_plan, d_next_plan, next_batch, step_index, alpha,
+                      beta1, beta2, eps, d_loss2, nullptr, stream);
+}
+
 /* The batch loop of MF.train_model (MF.py:95-103) over consecutive batches of one epoch stream, in one
  * call: batch k = triplets [k*batch, min((k+1)*batch, n_total)), its plan d_plans + 3*k*batch (the whole
  * stream's plans as nrhip_bpr_plan(n_total, batch) lays them out; NULL: sorted per step), the next batch's
  * plan handed along.  h_alpha[k] = lr_t of step first_step_index + k (HOST array); d_loss2 receives two
- * floats per step.  A Python loop enqueues ~12 us per step — more than the one-launch step takes. */
+ * floats per step.  A Python loop enqueues ~12 us per step — more than the one-launch step takes.
+ * d_terms_steps (2 * batch floats per step, or NULL): with the one-launch form the steps then only leave their
+ * per-triplet loss terms there and ONE launch after the loop reduces every step's pair — the same fixed-order
+ * sums, bit for bit, with no hand-off to a last-arriving workgroup inside the steps (whose memory-model form
+ * costs an L2 write-back per workgroup: profiles/r03_exp_loss_handoff.txt). */
 int nrhip_mf_steps(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
                    int64_t n_total, int batch, const uint64_t* d_plans, int first_step_index,
                    const float* h_alpha, float beta1, float beta2, float eps, float* d_loss2,
-                   void* stream) {
+                   float* d_terms_steps, void* stream) {
   NR_REQUIRE(ctx && d_users && d_pos && d_neg && h_alpha && d_loss2, NR_ERR_ARG, "mf_steps: null argument");
   NR_REQUIRE(n_total >= 0 && batch >= 1 && first_step_index >= 1, NR_ERR_ARG, "mf_steps: bad sizes");
   const int64_t n_steps = (n_total + batch - 1) / batch;
+  const nrhip_mf_buffers& bufs = ((MFCtx*)ctx)->b;
+  float* terms = bufs.tw ? d_terms_steps : nullptr;           // deferred reduction: the one-launch form only
   for (int64_t k = 0; k < n_steps; ++k) {
     const int64_t b0 = k * batch;
     const int nb = (int)std::min<int64_t>(batch, n_total - b0);
     const int64_t b1 = b0 + nb;
     const int next = (int)std::min<int64_t>(batch, n_total - b1);
-    NR_TRY(nrhip_mf_step(ctx, d_users + b0, d_pos + b0, d_neg + b0, nb, d_plans ? d_plans + 3 * b0 : nullptr,
-                         (d_plans && next > 0) ? d_plans + 3 * b1 : nullptr, next, first_step_index + (int)k,
-                         h_alpha[k], beta1, beta2, eps, d_loss2 + 2 * k, stream));
+    NR_TRY(mf_step_impl(ctx, d_users + b0, d_pos + b0, d_neg + b0, nb, d_plans ? d_plans + 3 * b0 : nullptr,
+                        (d_plans && next > 0) ? d_plans + 3 * b1 : nullptr, next, first_step_index + (int)k,
+                        h_alpha[k], beta1, beta2, eps, d_loss2 + 2 * k, terms ? terms + 2 * (size_t)batch * k : nullptr,
+                        stream));
   }
+  if (terms && n_steps > 0)
+    NR_TRY(nrhip_loss_reduce_steps(terms, (int)n_steps, batch, (int)(n_total - (n_steps - 1) * batch), bufs.reg,
+                                   d_loss2, stream));
   return NR_OK;
 }
 

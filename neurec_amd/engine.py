@@ -809,8 +809,9 @@ class NativeStep:
              st.t + 1, float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps),
              _ptr(loss2, torch.float32), _stream())
 
-    def mf_steps(self, users, pos, neg, batch, st, h_alpha, loss_steps, plans=None):
-        """the consecutive batches of an epoch stream in one native call (nrhip_mf_steps)"""
+    def mf_steps(self, users, pos, neg, batch, st, h_alpha, loss_steps, plans=None, terms_steps=None):
+        """the consecutive batches of an epoch stream in one native call (nrhip_mf_steps); terms_steps:
+        float32 device tensor of 2 * batch floats per step (one loss reduction launch for the whole call)"""
         n = users.numel()
         n_steps = (n + batch - 1) // batch
         if h_alpha.dtype != np.float32 or h_alpha.size < n_steps or not h_alpha.flags["C_CONTIGUOUS"]:
@@ -819,7 +820,8 @@ class NativeStep:
             raise ValueError("loss buffer holds %d floats, 2 per step = %d needed" % (loss_steps.numel(), 2 * n_steps))
         call("nrhip_mf_steps", self.handle, self._idx(users), self._idx(pos), self._idx(neg), n, int(batch),
              self._plan(plans, 3 * n), st.t + 1, h_alpha.ctypes.data_as(C.c_void_p), float(st.beta1),
-             float(st.beta2), float(st.eps), _ptr(loss_steps, torch.float32), _stream())
+             float(st.beta2), float(st.eps), _ptr(loss_steps, torch.float32),
+             _ptr(terms_steps, torch.float32, allow_none=True), _stream())
 
     def mf_flush(self, st):
         call("nrhip_mf_flush", self.handle, st.t, float(st.beta1), float(st.beta2), float(st.eps),

@@ -158,6 +158,7 @@ class MFEngine:
         self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.max_batch = max_batch
         self._stale = False
+        self._terms_steps = None
         self._alpha_host = None
         if self.lazy:
             self._alpha_np = self.adam.alpha_table(self.ALPHA_STEPS)
@@ -220,7 +221,12 @@ class MFEngine:
             if self._alpha_host is None or self._alpha_host.size < t + n_steps + 1:
                 self._alpha_host = self.adam.alpha_table(max(2 * (t + n_steps), 4096))
             h_alpha = np.ascontiguousarray(self._alpha_host[t + 1:t + 1 + n_steps])
-        self._ctx.mf_steps(users, pos, neg, batch, self.adam, h_alpha, loss_steps, plans)
+        terms = None
+        if self.fused:          # the steps leave their per-triplet terms; one launch reduces the whole call's losses
+            if self._terms_steps is None or self._terms_steps.numel() < 2 * batch * n_steps:
+                self._terms_steps = torch.empty(2 * batch * n_steps, dtype=torch.float32, device=self._table.device)
+            terms = self._terms_steps
+        self._ctx.mf_steps(users, pos, neg, batch, self.adam, h_alpha, loss_steps, plans, terms)
         for _ in range(n_steps):
             self.adam.advance()
         self._stale = True

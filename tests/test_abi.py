@@ -30,10 +30,11 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, "declared in neurec_hip.h but not exported: %s" % missing
-    # 2: batch plans (ordered row-gradient sums) in the BPR heads; 3: one-launch BPR-MF step
-    assert lib.nrhip_abi_version() == 3
+    # 2: batch plans (ordered row-gradient sums) in the BPR heads; 3: one-launch BPR-MF step;
+    # 4: nrhip_mf_steps with one loss reduction per call (per-step terms buffer)
+    assert lib.nrhip_abi_version() == 4
     with open(os.path.join(ROOT, "include", "neurec_hip.h")) as f:
-        assert "#define NRHIP_ABI_VERSION 3" in f.read()
+        assert "#define NRHIP_ABI_VERSION 4" in f.read()
 
 
 def test_library_exports_nothing_undeclared():
