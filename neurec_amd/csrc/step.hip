@@ -159,7 +159,8 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
   }
   const float* g = b.H;
   float* gping[2] = {b.Ga, b.Gb};
-  const bool fuse = adam && rearmed && L >= 2 && nrhip_spmm_plan_has_blocked(b.plan_t, d);
+  // (the ApplyAdam epilogue exists in the d = 64 lane-group kernel only)
+  const bool fuse = adam && rearmed && L >= 2 && d == 64 && nrhip_spmm_plan_has_blocked(b.plan_t, d);
   for (int k = 0; k < L; ++k) {
     if (k == L - 1 && fuse) {
       // last hop: G_0 = H + A^T G_1 is consumed row by row as the Adam gradient (+ reg rows)

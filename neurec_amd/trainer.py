@@ -330,9 +330,18 @@ class LightGCNEngine:
             self.At = self.A
         else:
             self.At = adj_t_csr if isinstance(adj_t_csr, E.SpmmCSR) else E.SpmmCSR.from_scipy(adj_t_csr, split_row=n_users)
-        self.E0 = torch.as_tensor(embed, dtype=torch.float32).contiguous().to(dev)
-        assert self.E0.shape[0] == self.N
-        self.d = self.E0.shape[1]
+        emb = torch.as_tensor(embed, dtype=torch.float32)
+        assert emb.shape[0] == self.N
+        # widths the kernels are built for; any other embed_size runs zero-padded to the next one: padded columns
+        # stay exactly zero (the propagation is column-wise, a zero gradient leaves Adam's m = v = 0 and the update
+        # 0 / (0 + eps) = 0) and add exact zeros to every dot product — the real columns see the same arithmetic
+        self.d_real = int(emb.shape[1])
+        fits = [w for w in (16, 32, 64, 128, 256) if w >= self.d_real]
+        if not fits:
+            raise NotImplementedError("LightGCN embed_size %d > 256 is not built" % self.d_real)
+        self.d = fits[0]
+        self.E0 = torch.zeros((self.N, self.d), dtype=torch.float32, device=dev)
+        self.E0[:, :self.d_real] = emb.to(dev)
         z = lambda: torch.zeros_like(self.E0)
         self.m, self.v = z(), z()
         self.Ea, self.Eb = z(), z()          # ping-pong layer buffers
@@ -367,6 +376,8 @@ class LightGCNEngine:
         self.propagate()
         Estar = torch.empty_like(self.Esum)
         E.div_scalar(self.Esum, float(self.n_layers + 1), Estar)
+        if self.d_real != self.d:
+            Estar = Estar[:, :self.d_real].contiguous()
         return Estar[:self.n_users], Estar[self.n_users:]
 
     # -- one training step = sess.run(self.opt) (LightGCN.py:178) ---------------------

@@ -208,7 +208,13 @@ def test_bpr_mf_step_tracks_oracle(eng, d):
     assert np.abs(mf.P.cpu().numpy() - oP).max() < 2e-6
 
 
-@pytest.mark.parametrize("adj_type,L,d", [("pre", 3, 64), ("pre", 1, 16), ("norm", 2, 64), ("pre", 0, 64)])
+@pytest.mark.parametrize("adj_type,L,d", [("pre", 3, 64), ("pre", 1, 16), ("norm", 2, 64), ("pre", 0, 64),
+                                          # every built width through the native step with L >= 2 (r03: the
+                                          # fused-Adam last hop was taken for any width that had a lane-group
+                                          # schedule, but exists at d = 64 only: d = 16 / 32 raised)
+                                          ("pre", 3, 16), ("pre", 2, 32), ("pre", 3, 128), ("norm", 3, 16),
+                                          # widths that are not built run zero-padded to the next one that is
+                                          ("pre", 3, 50), ("pre", 2, 20), ("norm", 2, 100)])
 def test_lightgcn_step_tracks_oracle(eng, adj_type, L, d):
     import torch
     from neurec_amd.trainer import LightGCNEngine
@@ -241,6 +247,8 @@ def test_lightgcn_step_tracks_oracle(eng, adj_type, L, d):
         assert abs(got[0] - w64[0]) <= 1e-5 * abs(w64[0]), (step, got, w32, w64)
         assert abs(got[1] - w64[1]) <= 1e-5 * max(abs(w64[1]), 1e-3)
     gotE = lg.E0.cpu().numpy()
+    assert lg.d_real == d and not gotE[:, d:].any()          # padded columns (widths that are not built) stay zero
+    gotE = gotE[:, :d]
     assert np.abs(gotE - o64).max() < 1e-5, np.abs(gotE - o64).max()
     assert np.abs(gotE - o32).max() < 1e-5
     assert not lg.Greg.cpu().numpy().any() and not lg.Gstar.cpu().numpy().any()   # buffers re-armed
