@@ -600,7 +600,9 @@ def main():
     # on (hash stamped in the file) — otherwise null
     traffic, traffic_note = None, "no PMC pass for this kernel / workload"
     here = os.path.dirname(os.path.abspath(__file__))
-    pmc_file = os.path.join(here, "profiles", "r02_pmc_traffic.json")
+    pmc_file = os.path.join(here, "profiles", "r03_pmc_traffic.json")
+    if not os.path.isfile(pmc_file):
+        pmc_file = os.path.join(here, "profiles", "r02_pmc_traffic.json")
     default_workload = (args.shape, args.scale, args.dim, args.layers) == ("gowalla", 1.0, 64, 3)
     if default_workload and os.path.isfile(pmc_file):
         import hashlib
@@ -611,13 +613,13 @@ def main():
         with open(pmc_file) as fh:
             doc = json.load(fh)
         if doc.get("_spmm_sources_sha16") != h.hexdigest()[:16]:
-            traffic_note = "stale: csrc/spmm*.hip changed since the PMC pass of profiles/r02_pmc_traffic.json"
+            traffic_note = "stale: csrc/spmm*.hip changed since the PMC pass of profiles/%s" % os.path.basename(pmc_file)
         else:
             hit = [v for k, v in doc["kernels"].items() if k.replace(" ", "") == kernel.replace(" ", "")]
             if hit:
                 traffic = hit[0]["traffic_bytes_per_launch"]
                 traffic_note = ("bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc "
-                                "passes (profiles/r02_pmc_traffic.json, sources %s)" % doc["_spmm_sources_sha16"])
+                                "passes (profiles/%s, sources %s)" % (os.path.basename(pmc_file), doc["_spmm_sources_sha16"]))
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_note": traffic_note, "bytes_per_launch": spmm_bytes,
