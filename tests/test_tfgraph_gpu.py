@@ -402,3 +402,41 @@ def test_multivae_config5_equals_the_reference_graph_at_gowalla_size():
         S = eng.logits(torch.zeros(1, dtype=torch.int32, device="cuda"), csr=E.DeviceCSR.from_scipy(row))
         outs.append(S.cpu().numpy()[0, :I][items])
     assert _err(np.asarray(outs), g["f64_ratings"]) <= TOL
+
+
+# ------------------------------------------------------------------ BASELINE configs[0], end to end
+def test_config0_epoch_on_real_ml100k_equals_the_reference_run():
+    """BASELINE configs[0]: one epoch of BPR-MF on the real ml-100k split, batches from the reference's own
+    PairwiseSampler, against the reference's MF class + predict() + C++ evaluator (all executed; see
+    golden_ml100k_epoch).  The HIP side: the epoch's batch loop in one native call (one-launch lazy steps), then
+    the pruned full-rank evaluator on the resulting tables.  Loss line and NDCG@10 within north_star's 1e-5."""
+    import torch
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator, MFEngine
+    g = load_golden("tfgraph_ml100k_mf_epoch")
+    h = json.loads(str(g["hyper"]))
+    U, I = int(g["n_users"]), int(g["n_items"])
+    rs = np.random.RandomState(int(g["init_seed"]))
+    P0 = (rs.randn(U, 64) * 0.01).astype(np.float32)
+    Q0 = (rs.randn(I, 64) * 0.01).astype(np.float32)
+    mf = MFEngine(P0, Q0, h["learning_rate"], h["reg_mf"], h["batch_size"])
+    losses = torch.zeros(2 * 157, device="cuda")
+    assert mf.run_batches(_dev(g["users"]), _dev(g["pos"]), _dev(g["neg"]), h["batch_size"], losses) == 157
+    got = losses.cpu().numpy().astype(np.float64).reshape(157, 2).sum(1)
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    logged = float(str(g["f32_log_line"]).split("loss : ")[1].split(",")[0])            # MF.py:110
+    assert abs(got.sum() / 157 - logged) <= TOL * logged
+    bar = float(g["f32_vs_f64_tables"])
+    d = max(_err(mf.P.cpu().numpy(), g["f32_P"]), _err(mf.Q.cpu().numpy(), g["f32_Q"]))
+    assert d <= TOL + bar
+    train = E.DeviceCSR(g["train_indptr"].astype(np.int64), g["train_indices"], I)
+    test = E.DeviceCSR(g["test_indptr"].astype(np.int64), g["test_indices"], I)
+    for pruned in (True, False):
+        ev = FullRankEvaluator(train, test, [1, 2, 4, 3, 5], 20, batch_rows=1024, pruned=pruned)
+        m = ev.evaluate_factors(mf.P, mf.Q, _dev(g["eval_users"]), exact_mean=True)
+        diff = np.abs(np.asarray(m, np.float64) - g["f32_metrics"]).max()
+        print("config 0 on real ml-100k (%s): loss line %.6f (reference %.6f), tables %.1e, NDCG@10 %.8f (reference "
+              "%.8f), all 100 metric columns within %.1e" % ("pruned" if pruned else "materialised", got.sum() / 157,
+                                                              logged, d, m[2 * 20 + 9], g["f32_metrics"][2 * 20 + 9], diff))
+        assert abs(m[2 * 20 + 9] - g["f32_metrics"][2 * 20 + 9]) <= TOL
+        assert diff <= 1e-4            # a near-tie crossing a cut-off moves a column by 1 / (943 k)
