@@ -605,6 +605,23 @@ int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, vo
  * is added in key order and stored, exactly the order of the single-process head on the global batch.
  * d_index_of_pos[position] = index of that occurrence's row in d_src. */
 int nrhip_sort_u64(uint64_t* d_keys, int n, void* stream);
+/* Routing of a batch's 3*batch row lookups over block-partitioned tables (neurec_amd/parallel.py:
+ * BipartitePartition — rank r owns users [r*bu, (r+1)*bu) and items [r*bi, (r+1)*bi), bu + bi rows per rank):
+ *   nrhip_route_batch   requests in owner order, stable in request order (users, then positives, then negatives):
+ *                       d_packed[i] = (row in the owner's block, occurrence code = class*code_base + position in this
+ *                       rank's batch), d_order[i] = the request (class*batch + b) routed at i, d_inv = its inverse,
+ *                       d_counts[world] (optional) = requests per owner.  d_keys: scratch for 3*batch keys.
+ *   nrhip_route_owner_keys   on the owner: sorted keys (row << 32 | position of the occurrence in the GLOBAL batch =
+ *                       class*G + d_size_off[source rank] + position) of the n rows it was asked for (ordered by
+ *                       source rank, d_recv_prefix[world+1] their offsets) and d_index_of_pos[position] = index of
+ *                       that occurrence among the n — the inputs of nrhip_rows_sum_sorted, which then adds the
+ *                       returning gradient rows in the order TF's unsorted_segment_sum walks the concatenated batch. */
+int nrhip_route_batch(const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch, int n_users,
+                      int bu, int bi, int code_base, uint64_t* d_keys, int32_t* d_packed, int32_t* d_order,
+                      int32_t* d_inv, int32_t* d_counts, int world, void* stream);
+int nrhip_route_owner_keys(const int32_t* d_rows, const int32_t* d_codes, int n, const int32_t* d_recv_prefix,
+                           const int32_t* d_size_off, int world, int global_batch, int code_base,
+                           uint64_t* d_keys_out, int32_t* d_index_of_pos, void* stream);
 int nrhip_rows_sum_sorted(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
                           const float* d_src, int64_t ld_src, float* d_dst, void* stream);
 int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
@@ -617,6 +634,8 @@ int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slo
  * d_dst[d_rows[w]] += d_src[w] (fp32 atomics, repeats summed). */
 int nrhip_rows_gather(const int32_t* d_rows, int n_listed, int d, const float* d_src, float* d_dst,
                       int64_t ld_dst, void* stream);
+int nrhip_rows_gather_ld(const int32_t* d_rows, int n_listed, int d, const float* d_src, int64_t ld_src,
+                         float* d_dst, int64_t ld_dst, void* stream);   /* d_src rows ld_src floats apart */
 int nrhip_rows_scatter_add(const int32_t* d_rows, int n_listed, int d, const float* d_src,
                            int64_t ld_src, float* d_dst, void* stream);
 

@@ -127,6 +127,8 @@ SIGNATURES = {
     "nrhip_ngcf_step": [p, p, p, p, i32, p, C.c_uint64, C.c_uint64, i32, f32, f32, f32, f32, p, p],
     "nrhip_mf_steps": [p, p, p, p, i64, i32, p, i32, p, f32, f32, f32, p, p, p],
     "nrhip_loss_reduce_steps": [p, i32, i32, i32, f32, p, p],
+    "nrhip_route_batch": [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p],
+    "nrhip_route_owner_keys": [p, p, i32, p, p, i32, i32, i32, p, p, p],
     "nrhip_bpr_mf_step_fused": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, i32, p, p, p, i32, f32, p, p, p,
                                 i32, p, i32, i32, p],
     "nrhip_bpr_mf_fused_flush": [p, p, p, p, p, i32, f32, f32, f32, i32, i64, p],
@@ -174,6 +176,7 @@ SIGNATURES = {
     "nrhip_rows_sum_sorted": [p, i32, p, i32, p, i64, p, p],
     "nrhip_optimizer_rows_tf": [i32, p, p, p, p, p, i64, i32, f32, f32, f32, f32, p],
     "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
+    "nrhip_rows_gather_ld": [p, i32, i32, p, i64, p, i64, p],
     "nrhip_rows_scatter_add": [p, i32, i32, p, i64, p, p],
     "nrhip_scale": [p, f32, p, i64, p],
     "nrhip_add": [p, p, p, i64, p],

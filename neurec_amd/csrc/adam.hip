@@ -273,12 +273,12 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(const int32_t* __restric
 // dst[w][:] = src[rows[w]][:]  /  dst[rows[w]][:] += src[w][:]  (row lookups of a sharded table)
 __global__ __launch_bounds__(256) void rows_gather_kernel(const int32_t* __restrict__ rows,
                                                           int n_listed, int d,
-                                                          const float* __restrict__ src,
+                                                          const float* __restrict__ src, int64_t ld_src,
                                                           float* __restrict__ dst, int64_t ld_dst) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= n_listed) return;
   const int64_t r = rows[w];
-  for (int k = lane; k < d; k += 64) dst[(int64_t)w * ld_dst + k] = src[r * d + k];
+  for (int k = lane; k < d; k += 64) dst[(int64_t)w * ld_dst + k] = src[r * ld_src + k];
 }
 __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int32_t* __restrict__ rows,
                                                                int n_listed, int d,
@@ -583,7 +583,19 @@ int nrhip_rows_gather(const int32_t* d_rows, int n_listed, int d, const float* d
              "rows_gather: bad arguments");
   if (n_listed == 0) return NR_OK;
   hipLaunchKernelGGL(rows_gather_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
-                     (hipStream_t)stream, d_rows, n_listed, d, d_src, d_dst, ld_dst);
+                     (hipStream_t)stream, d_rows, n_listed, d, d_src, (int64_t)d, d_dst, ld_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* the same with a source row stride: d_src may be a column block of a wider row-major buffer */
+int nrhip_rows_gather_ld(const int32_t* d_rows, int n_listed, int d, const float* d_src, int64_t ld_src,
+                         float* d_dst, int64_t ld_dst, void* stream) {
+  NR_REQUIRE(d_rows && d_src && d_dst && n_listed >= 0 && d >= 1 && ld_dst >= d && ld_src >= d, NR_ERR_ARG,
+             "rows_gather_ld: bad arguments");
+  if (n_listed == 0) return NR_OK;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, d_rows, n_listed, d, d_src, ld_src, d_dst, ld_dst);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -356,10 +356,25 @@ def rows_div(rows, src, denom, dst):
 
 
 def rows_gather(rows, src, dst):
-    """dst[w, :d] = src[rows[w]] (dst may be a column block of a wider row-major buffer)."""
+    """dst[w, :d] = src[rows[w], :d] (src and dst may be column blocks of wider row-major buffers)."""
     d = src.shape[1]
-    call("nrhip_rows_gather", _ptr(rows, torch.int32), rows.numel(), d, _ptr(src, torch.float32),
-         C.c_void_p(dst.data_ptr()), dst.stride(0), _stream())
+    call("nrhip_rows_gather_ld", _ptr(rows, torch.int32), rows.numel(), d, C.c_void_p(src.data_ptr()),
+         src.stride(0), C.c_void_p(dst.data_ptr()), dst.stride(0), _stream())
+
+
+def route_batch(users, pos, neg, n_users, bu, bi, code_base, world, keys, packed, order, inv, counts=None):
+    """requests of a batch in owner order (nrhip_route_batch); all outputs are preallocated device tensors"""
+    call("nrhip_route_batch", _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32),
+         users.numel(), int(n_users), int(bu), int(bi), int(code_base), _ptr(keys, torch.int64),
+         _ptr(packed, torch.int32), _ptr(order, torch.int32), _ptr(inv, torch.int32),
+         _ptr(counts, torch.int32, allow_none=True), int(world), _stream())
+
+
+def route_owner_keys(rows, codes, recv_prefix, size_off, world, global_batch, code_base, keys, index_of_pos):
+    """sorted (row, global position) keys of the rows this rank was asked for (nrhip_route_owner_keys)"""
+    call("nrhip_route_owner_keys", _ptr(rows, torch.int32, allow_none=True), _ptr(codes, torch.int32, allow_none=True),
+         keys.numel(), _ptr(recv_prefix, torch.int32), _ptr(size_off, torch.int32), int(world), int(global_batch),
+         int(code_base), _ptr(keys, torch.int64), _ptr(index_of_pos, torch.int32), _stream())
 
 
 def rows_scatter_add(rows, src, dst):
@@ -458,8 +473,10 @@ def lightgcn_mark_batch(users, pos, neg, n_users, rows_out, row_flag):
 
 
 def lightgcn_bpr_grad(Esum, E0, n_users, n_layers, users, pos, neg, reg, Gstar, Greg, terms, loss2,
-                      plan=None):
-    call("nrhip_lightgcn_bpr_grad", _ptr(Esum, torch.float32), _ptr(E0, torch.float32), n_users,
+                      plan=None, divided=False):
+    """divided=True (only when n_layers + 1 is a power of two): Gstar receives dLoss/dE* already divided by
+    n_layers + 1 — exact, every term divided instead of the sum (nrhip_lightgcn_bpr_grad_h)"""
+    call("nrhip_lightgcn_bpr_grad_h" if divided else "nrhip_lightgcn_bpr_grad", _ptr(Esum, torch.float32), _ptr(E0, torch.float32), n_users,
          E0.shape[1], n_layers, _ptr(users, torch.int32), _ptr(pos, torch.int32),
          _ptr(neg, torch.int32), users.numel(), float(reg), _ptr(Gstar), _ptr(Greg),
          _work(terms, users.numel()), _ptr(loss2, allow_none=True),
@@ -607,6 +624,20 @@ class SpmmCSR:
                  _ptr(sum_in, allow_none=True), _ptr(sum_out, allow_none=True), _ptr(ws),
                  ws.numel(), _stream())
         return out
+
+    def matmul_adam(self, X, addend, grad_b, var, m, v, st, row_flag=None):
+        """The last backward hop of a step with TF's ApplyAdam as its epilogue (nrhip_spmm_csr_adam): row r of
+        A @ X + addend + grad_b is consumed as var's gradient and never stored; with row_flag, rows of addend /
+        grad_b whose flag is 0 are promised zero (not read) and the consumed rows and flags are cleared.
+        Returns False when this matrix has no d = 64 lane-group schedule (the caller then runs matmul + Adam)."""
+        d = X.shape[1]
+        if d != 64 or not self.ensure_schedule(64):
+            return False
+        call("nrhip_spmm_csr_adam", self.plan, _ptr(self.indices), _ptr(self.vals), _ptr(X, torch.float32), d,
+             _ptr(addend, torch.float32), _ptr(grad_b, torch.float32), _ptr(var, torch.float32), _ptr(m), _ptr(v),
+             float(st.alpha()), float(st.beta1), float(st.beta2), float(st.eps), 1 if row_flag is not None else 0,
+             _ptr(row_flag, torch.uint8, allow_none=True), _stream())
+        return True
 
     def matmul_rows(self, X, rows, out=None, addend=None, sum_in=None, sum_out=None):
         """Only the listed rows (int32 device tensor, repeats allowed) of A @ X (+ epilogue)."""

@@ -42,14 +42,23 @@ from . import parallel
 
 
 class RowRouter:
-    """Requests for table rows by global node id -> owners and back, for block-partitioned tables."""
+    """Requests for table rows by global node id -> owners and back, for block-partitioned tables.  The index
+    bookkeeping of a step is two native calls (csrc/route.hip): `request` (requests in owner order + the inverse
+    permutation) and `ordered_keys` (the owner-side keys of the global batch order)."""
 
     CODE = 1 << 24                       # occurrence code = class * CODE + position in the rank's batch
 
-    def __init__(self, comm, part):
+    def __init__(self, comm, part, max_batch):
         self.comm, self.part = comm, part
         self.world, self.rank = comm.world, comm.rank
-        self._epoch = None               # (batch, send counts [nb][world], recv counts, sizes [nb][world])
+        self._epoch = None               # per-epoch routing tables (plan_epoch)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n = 3 * int(max_batch)
+        self._keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        self._packed = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
+        self._order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self._inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self._counts = torch.zeros(self.world, dtype=torch.int32, device=dev)
 
     # ---- per-epoch routing tables: no host sync inside the steps
     def plan_epoch(self, classes, offsets, batch):
@@ -69,7 +78,12 @@ class RowRouter:
         if nb:
             sizes[-1] = n - (nb - 1) * batch
         recv, all_sizes = self._exchange_counts(send, sizes)
-        self._epoch = (int(batch), send.cpu().tolist(), recv.cpu().tolist(), all_sizes.cpu().tolist())
+        # what the owner-side key kernel reads, for every batch of the epoch, resident on the device
+        zero = torch.zeros((nb, 1), dtype=torch.int64, device=dev)
+        recv_prefix = torch.cat([zero, torch.cumsum(recv, 1)], 1).to(torch.int32).contiguous()
+        size_off = torch.cat([zero, torch.cumsum(all_sizes, 1)[:, :-1]], 1).to(torch.int32).contiguous()
+        self._epoch = (int(batch), send.cpu().tolist(), recv.cpu().tolist(), all_sizes.cpu().tolist(),
+                       recv_prefix, size_off)
 
     def _exchange_counts(self, send, sizes):
         """send [nb][world] (what I send to r in batch k) -> recv [nb][world] (what r sends me);
@@ -98,47 +112,51 @@ class RowRouter:
         ep = self._epoch
         if ep is None or k is None or k >= len(ep[1]) or ep[3][k][self.rank] != batch_len:
             return None
-        return ep[1][k], ep[2][k], ep[3][k]
+        return ep[1][k], ep[2][k], ep[3][k], ep[4][k], ep[5][k]
 
     # ---- one batch
-    def request(self, class_ids, offsets, planned=None):
-        """ids of one batch -> (order, asked local rows, asked occurrence codes, send_counts,
-        recv_counts, sizes).  planned = epoch_counts(k, B) or None (then counted now: host sync)."""
-        B = class_ids[0].numel()
-        nodes = torch.cat([ids.long() + off for ids, off in zip(class_ids, offsets)])
-        code = torch.cat([torch.arange(B, device=nodes.device, dtype=torch.int32) + c * self.CODE
-                          for c in range(len(class_ids))])
-        owner, local = self.part.owner_local(nodes)
-        order = torch.argsort(owner, stable=True)
-        local = local[order].to(torch.int32)
-        packed = torch.stack([local, code[order]], dim=1).contiguous()          # [n][2] int32
+    def request(self, users, pos, neg, n_users, planned=None):
+        """ids of one batch -> a Route: the requests in owner order went out, `asked` / `asked_code` are what this
+        rank was asked for.  planned = epoch_counts(k, B) or None (then counted now: one host sync)."""
+        B = users.numel()
+        n = 3 * B
+        counts = None if planned is not None else self._counts
+        E.route_batch(users, pos, neg, n_users, self.part.bu, self.part.bi, self.CODE, self.world,
+                      self._keys[:n], self._packed[:n], self._order[:n], self._inv[:n], counts)
         if planned is None:
-            send_counts = torch.bincount(owner, minlength=self.world)[:self.world]
-            sizes = torch.tensor([B], dtype=torch.int64, device=nodes.device)
-            recv, all_sizes = self._exchange_counts(send_counts.view(1, -1), sizes)
-            send_counts, recv_counts = send_counts.cpu().tolist(), recv[0].cpu().tolist()
-            sizes = all_sizes[0].cpu().tolist()
+            send_counts = self._counts.cpu().tolist()
+            dev = users.device
+            sizes = torch.tensor([B], dtype=torch.int64, device=dev)
+            recv, all_sizes = self._exchange_counts(torch.tensor([send_counts], dtype=torch.int64, device=dev), sizes)
+            recv_counts, sizes = recv[0].cpu().tolist(), all_sizes[0].cpu().tolist()
+            recv_prefix = torch.tensor(np.concatenate([[0], np.cumsum(recv_counts)]), dtype=torch.int32, device=dev)
+            size_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.int32, device=dev)
         else:
-            send_counts, recv_counts, sizes = planned
-        asked, _ = self.comm.all_to_all_rows(packed, send_counts, recv_counts)
-        return order, asked[:, 0].contiguous(), asked[:, 1].contiguous(), send_counts, recv_counts, sizes
+            send_counts, recv_counts, sizes, recv_prefix, size_off = planned
+        asked, _ = self.comm.all_to_all_rows(self._packed[:n], send_counts, recv_counts)
+        return Route(self._order[:n], self._inv[:n], asked[:, 0].contiguous(), asked[:, 1].contiguous(),
+                     send_counts, recv_counts, int(sum(sizes)), recv_prefix, size_off)
 
-    def ordered_keys(self, asked_rows, asked_code, recv_counts, sizes):
-        """Sorted keys (local row << 32 | global position) of the rows received from the other ranks and
-        the index_of_pos table: global position = class * G + (offset of the source rank) + b, G = the
-        global batch length — the occurrence order of the single-process head on the concatenated batch."""
-        dev = asked_rows.device
-        n = asked_rows.numel()
-        G = int(sum(sizes))
-        off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.int64, device=dev)
-        src = torch.repeat_interleave(torch.arange(self.world, device=dev),
-                                      torch.tensor(recv_counts, dtype=torch.int64, device=dev), output_size=n)
-        cls = torch.div(asked_code, self.CODE, rounding_mode="floor").long()
-        gpos = cls * G + off[src] + (asked_code.long() - cls * self.CODE)
-        index_of_pos = torch.zeros(3 * G, dtype=torch.int32, device=dev)
-        index_of_pos[gpos] = torch.arange(n, dtype=torch.int32, device=dev)
-        keys = E.sort_keys(((asked_rows.long() << 32) | gpos).contiguous())
+    def ordered_keys(self, route):
+        """Sorted keys (local row << 32 | global position) of the rows received from the other ranks and the
+        index_of_pos table: global position = class * G + (offset of the source rank) + b, G = the global batch
+        length — the occurrence order of the single-process head on the concatenated batch."""
+        dev = route.asked.device
+        keys = torch.empty(route.asked.numel(), dtype=torch.int64, device=dev)
+        index_of_pos = torch.empty(max(3 * route.G, 1), dtype=torch.int32, device=dev)
+        E.route_owner_keys(route.asked, route.asked_code, route.recv_prefix, route.size_off, self.world, route.G,
+                           self.CODE, keys, index_of_pos)
         return keys, index_of_pos
+
+
+class Route:
+    """one batch's routing: order[i] = the request (class * B + b) that travels at position i, inv = its inverse;
+    asked / asked_code = the local rows (and occurrence codes) this rank was asked for, by source rank"""
+    __slots__ = ("order", "inv", "asked", "asked_code", "send_counts", "recv_counts", "G", "recv_prefix", "size_off")
+
+    def __init__(self, *a):
+        for k, v in zip(self.__slots__, a):
+            setattr(self, k, v)
 
 
 class ShardedLightGCN:
@@ -198,9 +216,16 @@ class ShardedLightGCN:
         self.adam = E.AdamState(lr)
         self._cu = torch.arange(self.max_batch, dtype=torch.int32, device=dev)
         self._cp = self._cu.clone()
-        self.router = RowRouter(comm, self.part)
+        self.router = RowRouter(comm, self.part, self.max_batch)
         self._offsets = (0, self.n_users, self.n_users)
         self._gidx = None
+        # rows this rank was asked for in the current step (= rows of E* the loss reads = rows that receive gradient):
+        # the last forward hop produces only those, the first backward hop skips operand rows outside them
+        self.flag = torch.zeros(self.b, dtype=torch.uint8, device=dev)
+        self.flagX = self.flag if not comm.active else torch.zeros(self.Npad, dtype=torch.uint8, device=dev)
+        self.es_buf, self.e0_buf = z(B3, self.d), z(B3, self.d)
+        self._pow2 = ((self.L + 1) & self.L) == 0
+        self._Gs = None
 
     def _from_block(self, indptr, indices, vals):
         """CSR of this rank's nu user rows followed by its ni item rows, GLOBAL node ids as columns
@@ -241,17 +266,26 @@ class ShardedLightGCN:
         self.router.plan_epoch([users, pos, neg], self._offsets, batch)
 
     # ------------------------------------------------------------------ propagation
-    def propagate(self):
-        """Esum (this rank's rows) = Σ_k E^k; returns it (E* = Esum / (L+1))."""
+    def _operand(self, local):
+        """the gathered [n_pad][d] operand of a hop: one all-gather (at one rank the block itself)"""
+        if not self.comm.active:
+            return local
+        self.comm.all_gather_rows(local, self.X)                        # exchange: one all-gather per hop
+        return self.X
+
+    def propagate(self, wanted=None):
+        """Esum (this rank's rows) = Σ_k E^k; returns it (E* = Esum / (L+1)).  wanted: uint8 [b] — the last hop
+        then produces only the flagged rows (the rows a step's loss reads; other rows of Esum are stale)."""
         if self.L == 0:
             self.Esum.copy_(self.E0)
             return self.Esum
         src, acc_in = self.E0, self.E0
         ping = (self.Ya, self.Yb)
         for k in range(self.L):
-            self.comm.all_gather_rows(src, self.X)                      # exchange: one all-gather per hop
-            out = ping[k & 1]
-            self.A.matmul(self.X, out=out, sum_in=acc_in, sum_out=self.Esum)
+            last = k == self.L - 1
+            out = None if last else ping[k & 1]                         # the last layer is only needed in the sum
+            self.A.matmul(self._operand(src), out=out, sum_in=acc_in, sum_out=self.Esum,
+                          y_row_wanted=wanted if last else None)
             src, acc_in = out, self.Esum
         return self.Esum
 
@@ -259,50 +293,72 @@ class ShardedLightGCN:
         """Full (user, item) tables on every rank (one all-gather; evaluation entrance)."""
         loc = torch.zeros_like(self.Esum)
         E.div_scalar(self.propagate(), float(self.L + 1), loc)
-        self.comm.all_gather_rows(loc, self.X)
-        return self.natural(self.X)
+        full = self.X if self.comm.active else torch.empty_like(loc)
+        self.comm.all_gather_rows(loc, full)
+        return self.natural(full)
 
     def step(self, users, pos, neg, loss_out=None, batch_index=None):
         """One optimiser step on this rank's B triplets (global batch = all ranks' triplets)."""
         B, d, dev = users.numel(), self.d, self.E0.device
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
-        esum = self.propagate()
-        # --- lookup: ids -> owners -> [Esum | E0] rows back
+        # --- routing: ids -> owners (native: requests in owner order, one all-to-all of (row, code) pairs)
         planned = self.router.epoch_counts(batch_index, B)
-        order, asked, asked_code, send_counts, recv_counts, sizes = \
-            self.router.request([users, pos, neg], self._offsets, planned)
-        rows = torch.empty((asked.numel(), 2 * d), dtype=torch.float32, device=dev)
-        E.rows_gather(asked, esum, rows[:, :d])
-        E.rows_gather(asked, self.E0, rows[:, d:])
-        got, _ = self.comm.all_to_all_rows(rows, recv_counts, send_counts)
-        req = self.req_rows[:3 * B]
-        req[order] = got                                               # back to request order (plumbing copy)
-        es = req[:, :d].contiguous()
-        e0 = req[:, d:].contiguous()
-        # --- BPR head on the compact block: "users" = rows [0,B), "items" = rows [B,3B); every
-        #     occurrence has its own row there, so gs / gr hold one gradient row per occurrence
+        rt = self.router.request(users, pos, neg, self.n_users, planned)
+        n_asked = rt.asked.numel()
+        # --- forward: the last hop only on the rows somebody asked for
+        E.mark_rows(rt.asked, self.flag)
+        esum = self.propagate(wanted=self.flag)
+        # --- lookup answers: [Esum | E0] rows back to the askers, unscattered into request order by the gather
+        rows = torch.empty((n_asked, 2 * d), dtype=torch.float32, device=dev)
+        E.rows_gather(rt.asked, esum, rows[:, :d])
+        E.rows_gather(rt.asked, self.E0, rows[:, d:])
+        got, _ = self.comm.all_to_all_rows(rows, rt.recv_counts, rt.send_counts)
+        es, e0 = self.es_buf[:3 * B], self.e0_buf[:3 * B]
+        E.rows_gather(rt.inv, got[:, :d], es)                           # es[p] = answer to request p
+        E.rows_gather(rt.inv, got[:, d:], e0)
+        # --- BPR head on the compact block: "users" = rows [0,B), "items" = rows [B,3B); every occurrence has its
+        #     own row there, so gs / gr hold one gradient row per occurrence (gs already divided by L+1 when that
+        #     is exact: L+1 a power of two)
         gs, gr = self.gc_star[:3 * B], self.gc_reg[:3 * B]
-        E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B],
-                            (self._cp[:B] + B).contiguous(), self.reg, gs, gr, self.terms, loss_out)
-        # --- gradient rows back to the owners, added there in the order of the global batch
-        back = torch.cat([gs, gr], dim=1)[order].contiguous()
-        mine, _ = self.comm.all_to_all_rows(back, send_counts, recv_counts)
-        keys, index_of_pos = self.router.ordered_keys(asked, asked_code, recv_counts, sizes)
-        E.rows_sum_sorted(keys, index_of_pos, mine[:, :d], self.Ga)     # Ga: scratch for the Gstar rows
+        E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B], (self._cp[:B] + B).contiguous(),
+                            self.reg, gs, gr, self.terms, loss_out, divided=self._pow2)
+        # --- gradient rows back to the owners (routed order), added there in the order of the global batch
+        back = torch.empty((3 * B, 2 * d), dtype=torch.float32, device=dev)
+        E.rows_gather(rt.order, gs, back[:, :d])
+        E.rows_gather(rt.order, gr, back[:, d:])
+        mine, _ = self.comm.all_to_all_rows(back, rt.send_counts, rt.recv_counts)
+        keys, index_of_pos = self.router.ordered_keys(rt)
+        if self._pow2:
+            E.rows_sum_sorted(keys, index_of_pos, mine[:, :d], self.H)
+        else:
+            if self._Gs is None:                                         # zero outside the rows of a step
+                self._Gs = torch.zeros_like(self.H)
+            E.rows_sum_sorted(keys, index_of_pos, mine[:, :d], self._Gs)
+            E.rows_div(rt.asked, self._Gs, float(self.L + 1), self.H)
+            E.rows_clear(rt.asked, d, (self._Gs,))
         E.rows_sum_sorted(keys, index_of_pos, mine[:, d:], self.Greg)
-        E.div_scalar(self.Ga, float(self.L + 1), self.H)
-        # --- backward hops: G_k = H + Aᵀ G_{k+1}
+        # --- backward hops: G_k = H + Aᵀ G_{k+1}; H is non-zero on the asked rows only (first hop skips the rest),
+        #     the last hop carries ApplyAdam as its epilogue where the lane-group schedule exists
+        if self.comm.active:
+            self.comm.all_gather_rows(self.flag, self.flagX)
         g = self.H
         ping = (self.Ga, self.Gb)
+        applied = False
         for k in range(self.L):
-            self.comm.all_gather_rows(g, self.X)
+            X = self._operand(g)
+            if k == self.L - 1 and self.L >= 2:
+                applied = self.At.matmul_adam(X, self.H, self.Greg, self.E0, self.m, self.v, self.adam,
+                                              row_flag=self.flag)
+                if applied:
+                    break
             out = ping[(k + 1) & 1]
-            self.At.matmul(self.X, out=out, addend=self.H)
+            self.At.matmul(X, out=out, addend=self.H, x_row_nonzero=self.flagX if k == 0 else None)
             g = out
-        E.adam_dense2(self.E0, self.m, self.v, g, self.Greg, self.adam)
+        if not applied:
+            E.adam_dense2(self.E0, self.m, self.v, g, self.Greg, self.adam)
+            E.rows_clear(rt.asked, d, (self.H, self.Greg), self.flag)   # rows the ordered sums stored, and the flags
         self.adam.advance()
-        self.Greg.zero_(); self.Ga.zero_()                              # rows the ordered sums stored
         return loss_out
 
 
@@ -335,10 +391,10 @@ class ShardedMF:
         self.adam = E.AdamState(lr)
         B3 = 3 * self.max_batch
         self.req = z(B3, self.d)
-        self.gP, self.gQ = z(self.max_batch, self.d), z(2 * self.max_batch, self.d)
+        self._gcat = z(B3, self.d)               # per-occurrence gradient rows: users' [B], then items' [2B]
         self.terms = z(8 * self.max_batch)
         self._ar = torch.arange(2 * self.max_batch, dtype=torch.int32, device=dev)
-        self.router = RowRouter(comm, self.part)
+        self.router = RowRouter(comm, self.part, self.max_batch)
         self._offsets = (0, self.n_users, self.n_users)
         self._gidx = None
 
@@ -350,21 +406,21 @@ class ShardedMF:
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
         planned = self.router.epoch_counts(batch_index, B)
-        order, asked, asked_code, send_counts, recv_counts, sizes = \
-            self.router.request([users, pos, neg], self._offsets, planned)      # exchange 1: ids
-        rows = torch.empty((asked.numel(), d), dtype=torch.float32, device=self.T.device)
-        E.rows_gather(asked, self.T, rows)
-        got, _ = self.comm.all_to_all_rows(rows, recv_counts, send_counts)      # exchange 2: rows
+        rt = self.router.request(users, pos, neg, self.n_users, planned)        # exchange 1: ids
+        rows = torch.empty((rt.asked.numel(), d), dtype=torch.float32, device=self.T.device)
+        E.rows_gather(rt.asked, self.T, rows)
+        got, _ = self.comm.all_to_all_rows(rows, rt.recv_counts, rt.send_counts)   # exchange 2: rows
         req = self.req[:3 * B]
-        req[order] = got
+        E.rows_gather(rt.inv, got, req)                                        # req[p] = answer to request p
         # compact tables: P' = rows [0,B) (one per triplet), Q' = rows [B,3B) (pos then neg)
         P, Q = req[:B], req[B:3 * B]
-        gP, gQ = self.gP[:B], self.gQ[:2 * B]
+        gP, gQ = self._gcat[:B], self._gcat[B:3 * B]
         E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], (self._ar[:B] + B).contiguous(), self.reg,
                       gP, gQ, self.terms, loss_out)
-        back = torch.cat([gP, gQ])[order].contiguous()
-        mine, _ = self.comm.all_to_all_rows(back, send_counts, recv_counts)     # exchange 3: gradients
-        keys, index_of_pos = self.router.ordered_keys(asked, asked_code, recv_counts, sizes)
+        back = torch.empty((3 * B, d), dtype=torch.float32, device=self.T.device)
+        E.rows_gather(rt.order, self._gcat[:3 * B], back)                       # routed order
+        mine, _ = self.comm.all_to_all_rows(back, rt.send_counts, rt.recv_counts)  # exchange 3: gradients
+        keys, index_of_pos = self.router.ordered_keys(rt)
         E.rows_sum_sorted(keys, index_of_pos, mine, self.G)
         E.adam_sparse(self.T, self.m, self.v, self.G, self.adam)                # clears G
         self.adam.advance()
