@@ -40,9 +40,13 @@ def parse():
     ap.add_argument("--layers", type=int, default=3)       # BASELINE.json configs[2]
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--eval-batch", type=int, default=32768)
-    ap.add_argument("--dp-mode", choices=("replicated", "triplets", "allreduce", "rowshard"), default=None,
-                    help="N>1 (default: allreduce — every rank back-propagates ITS B triplets, RCCL sums dL/dE0; the "
-                         "batch-independent full hops are repeated on every rank and labelled so).  rowshard: tables "
+    ap.add_argument("--dp-mode", choices=("colshard", "replicated", "triplets", "allreduce", "rowshard"), default=None,
+                    help="N>1 (default: colshard — every rank holds dim/N COLUMNS of the table for all nodes and steps "
+                         "on the whole global batch: the propagation, the gradient rows and Adam are column-wise, so the "
+                         "step's one exchange is an RCCL all-gather of the per-triplet partial inner products, 12 B per "
+                         "triplet and rank; nothing is computed twice.  allreduce: every rank back-propagates ITS B "
+                         "triplets, RCCL sums dL/dE0; the batch-independent full hops are repeated on every rank and "
+                         "labelled so).  rowshard: tables "
                          "row-sharded, nothing repeated (all-gather per hop + all-to-all lookups; the config-4 "
                          "path).  Opt-in, fully redundant compute: replicated (every rank generates the global "
                          "batch itself and runs the whole step on it, no exchange) and triplets (ids all-gathered)")
@@ -439,7 +443,8 @@ def main():
 
     comm = parallel.init_from_env()
     if args.dp_mode is None:
-        args.dp_mode = "allreduce" if comm.active else "replicated"      # one rank: the modes coincide
+        # one rank: the modes coincide.  N ranks: the column-sharded engine when the width divides
+        args.dp_mode = "replicated" if not comm.active else ("colshard" if args.dim % comm.world == 0 else "allreduce")
     if args.gpus != comm.world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, comm.world, args.gpus))
@@ -451,7 +456,9 @@ def main():
     # The sampler is a counter-based generator (seed, epoch, position): every rank can produce the
     # whole epoch stream for 47 us, so the global batch of world x B triplets needs no id exchange —
     # and, existing a whole epoch ahead, it gets its batch plans from the sampler like a single GPU's.
-    replicated = comm.active and args.dp_mode == "replicated"
+    colshard = comm.active and args.dp_mode == "colshard"
+    # (column-sharded ranks step on the same global batch, produced locally like the replicated mode's)
+    replicated = comm.active and args.dp_mode in ("replicated", "colshard")
     global_batch = args.batch * (comm.world if (exchange or replicated) else 1)
     rowshard = args.dp_mode == "rowshard"
     config4 = args.shape == "config4"
@@ -497,6 +504,9 @@ def main():
         if rowshard:
             from neurec_amd.sharded import ShardedLightGCN
             lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
+        elif colshard:
+            from neurec_amd.colshard import ColumnShardedLightGCN
+            lg = ColumnShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, global_batch)
         else:
             lg = LightGCNEngine(A, U, I, E0, args.layers, 0.01, 1e-3,        # lr, reg: conf/LightGCN.properties
                                 global_batch)
@@ -540,6 +550,9 @@ def main():
             elif rowshard:
                 b = next(stream)
                 lg.step(b[0], b[1], b[2], loss_out, batch_index=b.index)
+            elif colshard:
+                b = next(stream)
+                lg.step(b[0], b[1], b[2], loss_out, plan=b.plan)
             else:
                 b = next(stream)
                 lg.step(b[0], b[1], b[2], loss_out, grad_sync=grad_sync, plan=b.plan)
@@ -570,6 +583,10 @@ def main():
         comm.allgather_cat_finish(inflight[0])           # drain the prefetched id gather
 
     # ---------------- roofline of the dominant kernel (CSR SpMM): HIP events on the launch stream
+    full = lg                                            # what evaluation asks for the tables
+    if colshard:
+        lg = lg.local                                    # the rank's own engine: its kernels are what is profiled below
+    wdim = lg.d if colshard else args.dim                # width the rank's kernels run at (its columns, padded)
     reps = 20 if lg.A.nnz < 50_000_000 else 3
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lg.propagate(); torch.cuda.synchronize()
@@ -591,9 +608,9 @@ def main():
             g = (lg.Ga, lg.Gb)[k % 2]
     ev1.record(); torch.cuda.synchronize()
     spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
-    spmm_bytes = lg.A.algorithmic_bytes(args.dim)
+    spmm_bytes = lg.A.algorithmic_bytes(wdim)
     achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-    kernel = lg.A.full_pass_kernel(args.dim)
+    kernel = lg.A.full_pass_kernel(wdim)
     # traffic: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc passes
     # over this same command (scripts/gpu_pmc.sh -> profiles/r02_pmc_traffic.json) are reported when
     # they are for the kernel that ran, the default workload AND the SpMM sources they were measured
@@ -604,7 +621,7 @@ def main():
     if not os.path.isfile(pmc_file):
         pmc_file = os.path.join(here, "profiles", "r02_pmc_traffic.json")
     default_workload = (args.shape, args.scale, args.dim, args.layers) == ("gowalla", 1.0, 64, 3)
-    if default_workload and os.path.isfile(pmc_file):
+    if default_workload and os.path.isfile(pmc_file) and not colshard:
         import hashlib
         h = hashlib.sha256()
         for name in ("spmm_blocked.hip", "spmm.hip"):
@@ -706,7 +723,7 @@ def main():
         # summed in batch order, nothing is unordered): no re-alignment before sharded scoring
 
         def evaluate():
-            eu, ei = lg.final_embeddings()
+            eu, ei = full.final_embeddings()
             sums = ev.evaluate_factors(eu.contiguous(), ei.contiguous(), mine) * mine.numel()
             if not comm.active:                      # one rank: the sums are the totals (no round trip)
                 return np.asarray(sums, np.float64) / len(test_users)
@@ -732,7 +749,7 @@ def main():
         # rooflines of the evaluation's two halves, HIP events on the launch stream around the kernels
         # of the first batch (north_star: MFMA for the scoring matmul, HBM GB/s for the top-K)
         if args.eval_mode == "pruned" and mine.numel() > 0:
-            eu, ei = lg.final_embeddings()
+            eu, ei = full.final_embeddings()
             eu, ei = eu.contiguous(), ei.contiguous()
             ub = mine[:args.eval_batch]
             nb, d_e, top_k = ub.numel(), eu.shape[1], 20
@@ -787,16 +804,19 @@ def main():
                                "%d layers, dim %d, B=%d per GPU, adj=pre, Adam lr=0.01 reg=1e-3"
                                % (args.shape, U, I, train_nnz, args.layers, args.dim, args.batch),
                    "global_batch": comm.world * args.batch,
-                   "parallelism": ("dp%d (replicated tables; every rank generates the same global epoch "
-                                   "stream from the shared seed and steps on the global batch of "
-                                   "%d: no exchange in training, tables bit-identical on all ranks)"
-                                   % (comm.world, global_batch) if replicated else
-                                   "dp%d (replicated tables; per step one all-gather of 12 B/triplet "
-                                   "of ids, every rank steps on the global batch)" % comm.world
-                                   if exchange else
-                                   "rowshard%d (tables row-sharded; all-gather per hop, all-to-all "
-                                   "row lookups, owner-local Adam)" % comm.world if rowshard else
-                                   "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
+                   "parallelism": (
+                       "colshard%d (every rank holds %d of the %d embedding columns for all nodes and steps on the global "
+                       "batch of %d; one all-gather of the per-triplet partial inner products per step: %d B)"
+                       % (comm.world, args.dim // comm.world, args.dim, global_batch, 12 * global_batch * comm.world)
+                       if colshard else
+                       "dp%d (replicated tables; every rank generates the same global epoch stream from the shared seed "
+                       "and steps on the global batch of %d: no exchange in training, tables bit-identical on all ranks)"
+                       % (comm.world, global_batch) if replicated else
+                       "dp%d (replicated tables; per step one all-gather of 12 B/triplet of ids, every rank steps on "
+                       "the global batch)" % comm.world if exchange else
+                       "rowshard%d (tables row-sharded; all-gather per hop, all-to-all row lookups, owner-local Adam)"
+                       % comm.world if rowshard else
+                       "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()], "timed_region": timed_region,
         "epoch_amortised": {"value": epoch_amortised, "unit": "triplets/s",
@@ -816,7 +836,33 @@ def main():
             "triplets": "everything but the sampler: ids are exchanged, every rank runs the whole step",
             "allreduce": "the propagation's full hops (batch-independent) are repeated on every rank; sampler, BPR "
                          "head and the batch-masked hops are partitioned (each rank its B triplets)",
-            "rowshard": False}[args.dp_mode]
+            "rowshard": False,
+            "colshard": False}[args.dp_mode]
+        if colshard:
+            line["redundant_compute_note"] = ("nothing is computed twice: a rank gathers 1/N of every row's bytes; only the "
+                                              "CSR indices (8 B per non-zero) are read by every rank")
+    if comm.rank == 0 and comm.world == 1 and default_workload and not args.no_eval:
+        # ONE rank's share of a W-rank column-sharded job, measured on this GPU (neurec_amd/colshard.py): rank 0's dim/W
+        # columns, the global batch of W*B — what every rank of the job computes per step; the job adds ONE all-gather
+        # of 12*W*B bytes per rank to it
+        from neurec_amd.colshard import ColumnShardedLightGCN
+        shares = {}
+        for W in (2, 4, 8):
+            gB = W * args.batch
+            cs = ColumnShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, gB, rank=0, world=W)
+            sW = BprEpochSampler(trc, I, neg_num=1, batch_size=gB, shuffle=True, seed=2018, plan_users=U)
+            bsW = [b for b in sW.batches() if b[0].numel() == gB][:40]
+            itW = iter(bsW * 4)
+
+            def one_share():
+                b = next(itW)
+                cs.step(b[0], b[1], b[2], None, plan=b.plan)
+            msW = _hip_timed(one_share, 60, 10)
+            shares[str(W)] = {"ms_per_step": msW, "global_batch": gB, "columns_per_rank": args.dim // W,
+                              "kernel_width": cs.local.d, "exchange_bytes_per_rank": 12 * gB,
+                              "triplets_per_sec_if_exchange_were_free": gB / msW * 1e3}
+            del cs, sW, bsW
+        line["colshard_one_rank_share"] = shares
     if comm.active and not rowshard and not config4:
         # the SAME global batch stepped by ONE GPU alone (no collectives; every rank does it, rank 0 reports): what
         # the N-GPU figure has to be read against — a full-graph LightGCN step costs the same whatever B is, so a

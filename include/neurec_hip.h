@@ -434,6 +434,24 @@ int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
                         const int32_t* d_neg, int batch, const uint64_t* d_plan, float alpha,
                         float beta1, float beta2, float eps, float* d_loss2, void* stream);
 
+/* Column-sharded tables (LightGCN.py:132-166 when every rank holds d of the D embedding columns — the propagation,
+ * the gradient rows and ApplyAdam are column-wise, so the only quantity that needs all columns is the head's inner
+ * products): the step cut there.  _fwd: forward hops + this rank's partial products d_partials[3*batch] =
+ * (<e_u,e_i>, <e_u,e_j>, l2 term) per triplet; the caller all-gathers them, nrhip_partials_sum adds them in rank
+ * order; _bwd: head with the summed d_given, backward hops, ApplyAdam.  Every rank steps on the SAME global batch. */
+int nrhip_lightgcn_step_colshard_fwd(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                                     int batch, float* d_partials, void* stream);
+int nrhip_lightgcn_step_colshard_bwd(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                                     int batch, const uint64_t* d_plan, const float* d_given, float alpha,
+                                     float beta1, float beta2, float eps, float* d_loss2, void* stream);
+int nrhip_lightgcn_partial_dots(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
+                                const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                                float* d_out, void* stream);
+int nrhip_partials_sum(const float* d_parts, int world, int n, float* d_given, void* stream);
+int nrhip_lightgcn_bpr_grad_given(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
+                                  const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                                  float reg, float* d_Gstar, float* d_Greg, float* d_work, float* d_loss2,
+                                  const uint64_t* d_plan, const float* d_given, int divided, void* stream);
 /* The same step cut at its one exchange point (multi-GPU): _grad leaves this rank's total
  * dLoss/dE0 in d_grad_out ([n_nodes][d]); the caller sums it over ranks (RCCL all-reduce);
  * _apply runs Adam on the summed gradient. */

@@ -127,6 +127,11 @@ SIGNATURES = {
     "nrhip_ngcf_step": [p, p, p, p, i32, p, C.c_uint64, C.c_uint64, i32, f32, f32, f32, f32, p, p],
     "nrhip_mf_steps": [p, p, p, p, i64, i32, p, i32, p, f32, f32, f32, p, p, p],
     "nrhip_loss_reduce_steps": [p, i32, i32, i32, f32, p, p],
+    "nrhip_lightgcn_step_colshard_fwd": [p, p, p, p, i32, p, p],
+    "nrhip_lightgcn_step_colshard_bwd": [p, p, p, p, i32, p, p, f32, f32, f32, f32, p, p],
+    "nrhip_lightgcn_partial_dots": [p, p, i32, i32, i32, p, p, p, i32, p, p],
+    "nrhip_partials_sum": [p, i32, i32, p, p],
+    "nrhip_lightgcn_bpr_grad_given": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p, i32, p],
     "nrhip_route_batch": [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p],
     "nrhip_route_owner_keys": [p, p, i32, p, p, i32, i32, i32, p, p, p],
     "nrhip_bpr_mf_step_fused": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, i32, p, p, p, i32, f32, p, p, p,

@@ -881,7 +881,7 @@ __device__ __forceinline__ void lightgcn_occurrence(
     float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int batch, float reg, float grad_div, uint32_t p, int lane,
     float (&h)[CPL], float (&r)[CPL], float* __restrict__ term_mf, float* __restrict__ term_l2,
-    bool write_terms) {
+    bool write_terms, const float* __restrict__ given = nullptr) {
   const int cls = (int)(p / (uint32_t)batch), b = (int)(p - (uint32_t)cls * (uint32_t)batch);
   const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
   const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
@@ -897,7 +897,10 @@ __device__ __forceinline__ void lightgcn_occurrence(
     ei[c] = ei[c] / layers_p1;
     ej[c] = ej[c] / layers_p1;
   }
-  const float x = dot_rows<CPL>(eu, ei) - dot_rows<CPL>(eu, ej);     // LightGCN.py:157-158,162
+  // column-sharded tables (neurec_amd/colshard.py): this rank holds d of the D columns — the two inner
+  // products (and the regulariser's sum of squares) are the sums over the ranks' partial ones, handed in
+  const float x = given ? given[3 * b] - given[3 * b + 1]
+                        : dot_rows<CPL>(eu, ei) - dot_rows<CPL>(eu, ej);     // LightGCN.py:157-158,162
   const float g = nr::bpr_dloss(x);
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
@@ -908,10 +911,15 @@ __device__ __forceinline__ void lightgcn_occurrence(
     r[c] = reg * z[c];                             // regulariser on layer-0 rows, :160,164
   }
   if (write_terms && cls == 0) {
-    float zi[CPL], zj[CPL];
-    load_row<CPL>(E0, i, d, lane, zi);
-    load_row<CPL>(E0, j, d, lane, zj);
-    const float l2 = 0.5f * (dot_rows<CPL>(z, z) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
+    float l2;
+    if (given) {
+      l2 = given[3 * b + 2];
+    } else {
+      float zi[CPL], zj[CPL];
+      load_row<CPL>(E0, i, d, lane, zi);
+      load_row<CPL>(E0, j, d, lane, zj);
+      l2 = 0.5f * (dot_rows<CPL>(z, z) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
+    }
     if (lane == 0) {
       __hip_atomic_store(&term_mf[b], nr::bpr_loss(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -925,7 +933,8 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
     float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int batch, const uint64_t* __restrict__ skey, int n_occ,
     float reg, float* __restrict__ Gstar, float* __restrict__ Greg, float* __restrict__ term_mf,
-    float* __restrict__ term_l2, float grad_div, float* __restrict__ out2, unsigned* done) {
+    float* __restrict__ term_l2, float grad_div, float* __restrict__ out2, unsigned* done,
+    const float* __restrict__ given) {
   __shared__ float s_hr[2 * kOccWaves * CPL * NR_WAVE];
   __shared__ uint32_t s_row[kOccWaves];
   __shared__ int s_edge[2];
@@ -938,13 +947,13 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
     if (s > 0) kprev = plan_key(skey, s - 1);      // neighbours in the sorted order: see mf_grad_sorted_kernel
     if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
     lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
-                             (uint32_t)key, lane, hr[0], hr[1], term_mf, term_l2, true);
+                             (uint32_t)key, lane, hr[0], hr[1], term_mf, term_l2, true, given);
   }
   const bool head = sorted_run_sum<CPL, 2>(
       hr, s_hr, s_row, s_edge, skey, n_occ, s, key, kprev, knext, wave, lane,
       [&](uint32_t p, float (&out)[2][CPL]) {
         lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
-                                 p, lane, out[0], out[1], term_mf, term_l2, false);
+                                 p, lane, out[0], out[1], term_mf, term_l2, false, given);
       });
   if (head) {
     const uint32_t row = (uint32_t)(key >> 32);
@@ -958,6 +967,53 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
     }
   }
   finish_loss(term_mf, term_l2, batch, reg, out2, done);
+}
+
+
+// Column-sharded tables: the partial inner products of every triplet on this rank's d columns —
+// out[b] = (<e_u, e_i>, <e_u, e_j>, (|z_u|^2 + |z_i|^2 + |z_j|^2) / 2) with e = Esum / (L+1), z = E0 rows.
+template <int CPL>
+__global__ __launch_bounds__(256) void lightgcn_partial_dots_kernel(
+    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d, float layers_p1,
+    const int32_t* __restrict__ users, const int32_t* __restrict__ pos, const int32_t* __restrict__ neg,
+    int batch, float* __restrict__ out) {
+  const int lane = nr_lane();
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
+  const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
+  const int64_t j = (int64_t)n_users + __builtin_amdgcn_readfirstlane(neg[b]);
+  float eu[CPL], ei[CPL], ej[CPL], zu[CPL], zi[CPL], zj[CPL];
+  load_row<CPL>(Esum, u, d, lane, eu);
+  load_row<CPL>(Esum, i, d, lane, ei);
+  load_row<CPL>(Esum, j, d, lane, ej);
+  load_row<CPL>(E0, u, d, lane, zu);
+  load_row<CPL>(E0, i, d, lane, zi);
+  load_row<CPL>(E0, j, d, lane, zj);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    eu[c] = eu[c] / layers_p1;
+    ei[c] = ei[c] / layers_p1;
+    ej[c] = ej[c] / layers_p1;
+  }
+  const float dp = dot_rows<CPL>(eu, ei), dn = dot_rows<CPL>(eu, ej);
+  const float l2 = 0.5f * (dot_rows<CPL>(zu, zu) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
+  if (lane == 0) {
+    out[3 * b] = dp;
+    out[3 * b + 1] = dn;
+    out[3 * b + 2] = l2;
+  }
+}
+
+// given[b][c] = sum over the ranks r (ascending) of parts[r][b][c]: every rank adds the same numbers in the same
+// order, so all ranks hold bit-identical x_b and loss terms
+__global__ __launch_bounds__(256) void partials_sum_kernel(const float* __restrict__ parts, int world, int n,
+                                                           float* __restrict__ given) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  float acc = parts[k];
+  for (int r = 1; r < world; ++r) acc = acc + parts[(int64_t)r * n + k];
+  given[k] = acc;
 }
 
 
@@ -1544,7 +1600,8 @@ int nrhip_lightgcn_mark_batch(const int32_t* d_users, const int32_t* d_pos, cons
 static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
                          const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
                          int batch, float reg, float* d_Gstar, float* d_Greg, float* d_work,
-                         float* d_loss2, float grad_div, const uint64_t* d_plan, void* stream) {
+                         float* d_loss2, float grad_div, const uint64_t* d_plan, void* stream,
+                         const float* d_given = nullptr) {
   NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_Gstar && d_Greg && d_work,
              NR_ERR_ARG, "lightgcn_bpr_grad: null pointer argument");
   NR_REQUIRE(d >= 1 && d <= 256, NR_ERR_UNSUPPORTED,
@@ -1561,7 +1618,7 @@ static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, in
   const float lp1 = (float)(n_layers + 1);
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (atomic_scatter_knob()) {
+  if (atomic_scatter_knob() && !d_given) {
     dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
     NR_BY_WIDTH(lightgcn_bpr_grad_kernel, d_Esum, d_E0, n_users, d, lp1, d_users, d_pos, d_neg, batch,
                 reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
@@ -1572,7 +1629,7 @@ static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, in
     const int n_occ = 3 * batch;
     dim3 grid((n_occ + kOccWaves - 1) / kOccWaves), block(kOccWaves * NR_WAVE);
     NR_BY_WIDTH(lightgcn_grad_sorted_kernel, d_Esum, d_E0, n_users, d, lp1, d_users, d_pos, d_neg,
-                batch, plan, n_occ, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
+                batch, plan, n_occ, reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done, d_given);
   }
   NR_LAUNCH_CHECK();
   return NR_OK;
@@ -1599,6 +1656,47 @@ int nrhip_lightgcn_bpr_grad_h(const float* d_Esum, const float* d_E0, int n_user
              "lightgcn_bpr_grad_h: n_layers + 1 = %d is not a power of two", n_layers + 1);
   return lightgcn_head(d_Esum, d_E0, n_users, d, n_layers, d_users, d_pos, d_neg, batch, reg, d_H,
                        d_Greg, d_work, d_loss2, (float)(n_layers + 1), d_plan, stream);
+}
+
+/* Column-sharded tables (neurec_amd/colshard.py; LightGCN.py:157-166 when every rank holds d of the D embedding
+ * columns): the head in two halves around ONE small exchange.
+ *   nrhip_lightgcn_partial_dots   d_out[b] = (<e_u,e_i>, <e_u,e_j>, l2 term) of triplet b on this rank's columns;
+ *   nrhip_partials_sum            d_given[k] = sum over ranks r ascending of d_parts[r][k] (n = 3*batch floats per rank):
+ *                                 the same additions in the same order on every rank;
+ *   nrhip_lightgcn_bpr_grad_given the head of nrhip_lightgcn_bpr_grad(_h) with x_b and the l2 term taken from d_given
+ *                                 (divided != 0: rows already divided by n_layers + 1, a power of two). */
+int nrhip_lightgcn_partial_dots(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
+                                const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                                float* d_out, void* stream) {
+  NR_REQUIRE(d_Esum && d_E0 && d_users && d_pos && d_neg && d_out && d >= 1 && d <= 256 && batch >= 0 &&
+                 n_layers >= 0, NR_ERR_ARG, "lightgcn_partial_dots: bad arguments");
+  if (batch == 0) return NR_OK;
+  dim3 grid((batch + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  NR_BY_WIDTH(lightgcn_partial_dots_kernel, d_Esum, d_E0, n_users, d, (float)(n_layers + 1), d_users, d_pos, d_neg,
+              batch, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_partials_sum(const float* d_parts, int world, int n, float* d_given, void* stream) {
+  NR_REQUIRE(d_parts && d_given && world >= 1 && n >= 0, NR_ERR_ARG, "partials_sum: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(partials_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_parts, world,
+                     n, d_given);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_lightgcn_bpr_grad_given(const float* d_Esum, const float* d_E0, int n_users, int d, int n_layers,
+                                  const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int batch,
+                                  float reg, float* d_Gstar, float* d_Greg, float* d_work, float* d_loss2,
+                                  const uint64_t* d_plan, const float* d_given, int divided, void* stream) {
+  NR_REQUIRE(d_given, NR_ERR_ARG, "lightgcn_bpr_grad_given: null d_given");
+  NR_REQUIRE(!divided || ((n_layers + 1) & n_layers) == 0, NR_ERR_ARG,
+             "lightgcn_bpr_grad_given: divided needs n_layers + 1 = %d to be a power of two", n_layers + 1);
+  return lightgcn_head(d_Esum, d_E0, n_users, d, n_layers, d_users, d_pos, d_neg, batch, reg, d_Gstar, d_Greg,
+                       d_work, d_loss2, divided ? (float)(n_layers + 1) : 1.0f, d_plan, stream, d_given);
 }
 
 }  // extern "C"

@@ -95,22 +95,27 @@ struct AdamArgs { float alpha, beta1, beta2, eps; };
 
 // adam != nullptr: the caller wants the optimiser applied too; when the last backward hop can
 // carry it as a fused epilogue (d = 64 lane-group schedule, L >= 2) *g_out comes back NULL.
+// phase 0: the whole step.  Column-sharded tables cut it at the head's inner products (the one quantity that
+// needs all D columns): phase 1 = forward + this rank's partial products into d_partials; phase 2 = head with
+// the summed products d_given + backward.
 static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_users,
                             const int32_t* d_pos, const int32_t* d_neg, int batch,
                             const uint64_t* d_plan, float* d_loss2, void* stream,
                             const float** g_out, const AdamArgs* adam = nullptr,
-                            bool* rearmed = nullptr) {
+                            bool* rearmed = nullptr, int phase = 0, float* d_partials = nullptr,
+                            const float* d_given = nullptr) {
   const int L = b.n_layers, d = b.d;
   const bool skip = d >= 64;                 // the work-skipping variants exist for d >= 64
   // 0: no wanted-rows schedule; 1: it takes row flags; 2: it takes the batch itself and publishes
   // the flags / row list on the way (no mark_batch launch)
   const int wanted_form = (skip && L > 0) ? nrhip_spmm_plan_has_wanted(b.plan, d) : 0;
-  if (wanted_form != 2)
+  if (wanted_form != 2 && phase != 2)
     NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, b.n_users, b.batch_rows,
                                      b.row_flag, stream));
   // forward: L-1 full hops, the last one only on the batch rows
   const float* esum = b.E0;
-  if (L > 0) {
+  if (L > 0 && phase == 2) esum = b.Esum_rows;
+  if (L > 0 && phase != 2) {
     const float* src = b.E0;
     const float* acc_in = b.E0;
     float* ping[2] = {b.Ea, b.Eb};
@@ -147,14 +152,25 @@ static int lightgcn_fwd_bwd(const nrhip_lightgcn_buffers& b, const int32_t* d_us
                             b.Esum_rows, b.spmm_ws, b.spmm_ws_bytes, stream));
     esum = b.Esum_rows;
   }
+  if (phase == 1)
+    return nrhip_lightgcn_partial_dots(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, d_partials,
+                                       stream);
   // backward: H = Gstar/(L+1) on the batch rows; G_k = H + A^T G_{k+1}
   if (((L + 1) & L) == 0) {
     // L+1 a power of two (the configured L = 3): the head accumulates H directly — exact
-    NR_TRY(nrhip_lightgcn_bpr_grad_h(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch,
-                                     b.reg, b.H, b.Greg, b.terms, d_loss2, d_plan, stream));
+    if (d_given)
+      NR_TRY(nrhip_lightgcn_bpr_grad_given(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg, b.H,
+                                           b.Greg, b.terms, d_loss2, d_plan, d_given, 1, stream));
+    else
+      NR_TRY(nrhip_lightgcn_bpr_grad_h(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch,
+                                       b.reg, b.H, b.Greg, b.terms, d_loss2, d_plan, stream));
   } else {
-    NR_TRY(nrhip_lightgcn_bpr_grad(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
-                                   b.Gstar, b.Greg, b.terms, d_loss2, d_plan, stream));
+    if (d_given)
+      NR_TRY(nrhip_lightgcn_bpr_grad_given(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
+                                           b.Gstar, b.Greg, b.terms, d_loss2, d_plan, d_given, 0, stream));
+    else
+      NR_TRY(nrhip_lightgcn_bpr_grad(esum, b.E0, b.n_users, d, L, d_users, d_pos, d_neg, batch, b.reg,
+                                     b.Gstar, b.Greg, b.terms, d_loss2, d_plan, stream));
     NR_TRY(nrhip_rows_div(b.batch_rows, 3 * batch, d, b.Gstar, (float)(L + 1), b.H, stream));
   }
   const float* g = b.H;
@@ -214,6 +230,40 @@ int nrhip_lightgcn_step(void* ctx, const int32_t* d_users, const int32_t* d_pos,
   if (rearmed) return NR_OK;
   NR_TRY(nrhip_rows_clear(b.batch_rows, 3 * batch, b.d, b.Gstar, b.Greg, b.H, nullptr, b.row_flag,
                           stream));
+  return NR_OK;
+}
+
+// Column-sharded tables (every rank holds d of the D embedding columns and steps on the WHOLE global batch;
+// neurec_amd/colshard.py): the step cut at the head's inner products.  _fwd: forward hops + this rank's partial
+// products, d_partials[3*batch]; the caller all-gathers them and sums them in rank order (nrhip_partials_sum);
+// _bwd: head with those sums, backward hops, ApplyAdam — all on this rank's columns, no other exchange.
+int nrhip_lightgcn_step_colshard_fwd(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                                     int batch, float* d_partials, void* stream) {
+  NR_TRY(lightgcn_check(ctx, d_users, d_pos, d_neg, batch));
+  NR_REQUIRE(d_partials, NR_ERR_ARG, "lightgcn_step_colshard_fwd: null output");
+  if (batch == 0) return NR_OK;
+  const float* g = nullptr;
+  return lightgcn_fwd_bwd(((LightGCNCtx*)ctx)->b, d_users, d_pos, d_neg, batch, nullptr, nullptr, stream, &g,
+                          nullptr, nullptr, 1, d_partials, nullptr);
+}
+
+int nrhip_lightgcn_step_colshard_bwd(void* ctx, const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg,
+                                     int batch, const uint64_t* d_plan, const float* d_given, float alpha,
+                                     float beta1, float beta2, float eps, float* d_loss2, void* stream) {
+  NR_TRY(lightgcn_check(ctx, d_users, d_pos, d_neg, batch));
+  NR_REQUIRE(d_given, NR_ERR_ARG, "lightgcn_step_colshard_bwd: null d_given");
+  if (batch == 0) return NR_OK;
+  const nrhip_lightgcn_buffers& b = ((LightGCNCtx*)ctx)->b;
+  const float* g = nullptr;
+  const AdamArgs adam{alpha, beta1, beta2, eps};
+  bool rearmed = false;
+  NR_TRY(lightgcn_fwd_bwd(b, d_users, d_pos, d_neg, batch, d_plan, d_loss2, stream, &g, &adam, &rearmed, 2, nullptr,
+                          d_given));
+  if (g)
+    NR_TRY(nrhip_adam_dense_tf2(b.E0, b.m, b.v, g, b.Greg, (int64_t)b.n_nodes * b.d, alpha, beta1, beta2, eps,
+                                stream));
+  if (rearmed) return NR_OK;
+  NR_TRY(nrhip_rows_clear(b.batch_rows, 3 * batch, b.d, b.Gstar, b.Greg, b.H, nullptr, b.row_flag, stream));
   return NR_OK;
 }
 

@@ -362,6 +362,11 @@ def rows_gather(rows, src, dst):
          src.stride(0), C.c_void_p(dst.data_ptr()), dst.stride(0), _stream())
 
 
+def partials_sum(parts, world, n, out):
+    """out[k] = sum over ranks r ascending of parts[r][k] (nrhip_partials_sum)"""
+    call("nrhip_partials_sum", _ptr(parts, torch.float32), int(world), int(n), _ptr(out, torch.float32), _stream())
+
+
 def route_batch(users, pos, neg, n_users, bu, bi, code_base, world, keys, packed, order, inv, counts=None):
     """requests of a batch in owner order (nrhip_route_batch); all outputs are preallocated device tensors"""
     call("nrhip_route_batch", _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32),
@@ -823,6 +828,15 @@ class NativeStep:
         call("nrhip_lightgcn_step", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
              users.numel(), self._plan(plan, 3 * users.numel()), float(st.alpha()), float(st.beta1),
              float(st.beta2), float(st.eps), _ptr(loss2, allow_none=True), _stream())
+
+    def lightgcn_step_colshard_fwd(self, users, pos, neg, partials):
+        call("nrhip_lightgcn_step_colshard_fwd", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
+             users.numel(), _ptr(partials, torch.float32), _stream())
+
+    def lightgcn_step_colshard_bwd(self, users, pos, neg, st, loss2, plan, given):
+        call("nrhip_lightgcn_step_colshard_bwd", self.handle, self._idx(users), self._idx(pos), self._idx(neg),
+             users.numel(), self._plan(plan, 3 * users.numel()), _ptr(given, torch.float32), float(st.alpha()),
+             float(st.beta1), float(st.beta2), float(st.eps), _ptr(loss2, torch.float32, allow_none=True), _stream())
 
     def lightgcn_step_grad(self, users, pos, neg, loss2, grad_out, plan=None):
         call("nrhip_lightgcn_step_grad", self.handle, self._idx(users), self._idx(pos),

@@ -27,13 +27,17 @@ def _run(mode, port):
 
 
 @pytest.mark.parametrize("mode,port", [("replicated", 29611), ("triplets", 29612), ("allreduce", 29613),
-                                       ("rowshard", 29614), (None, 29615)])
+                                       ("rowshard", 29614), (None, 29615), ("colshard", 29616)])
 def test_two_rank_bench_line(mode, port):
     d = _run(mode, port)
-    # what of the step every rank repeats is said in the line; the default N>1 mode partitions the batch work and
-    # moves data (all-reduce of dL/dE0); the fully redundant modes are opt-in
+    # what of the step every rank repeats is said in the line; the default N>1 mode partitions ALL of it (column-sharded
+    # tables, one all-gather of partial inner products per step); the fully redundant modes are opt-in
     assert d["dist_backend"] == "gloo" and d["rccl_ranks"] == 0          # this test box has one GPU: no RCCL here
-    if mode is None:
+    if mode in (None, "colshard"):
+        assert d["config"]["parallelism"].startswith("colshard2 (every rank holds 32 of the 64")
+        assert d["redundant_compute"] is False and "computed twice" in d["redundant_compute_note"]
+        assert d["roofline"]["kernel"].endswith("32, false>")             # the rank's kernels run at its 32 columns
+    if mode == "allreduce":
         assert "one all-reduce" in d["config"]["parallelism"] and d["redundant_compute"].startswith("the propagation")
     if mode in ("replicated", "triplets"):
         assert d["redundant_compute"].startswith("everything")
@@ -44,7 +48,7 @@ def test_two_rank_bench_line(mode, port):
     leg = d["rowshard_config4_law"]                                        # every N>1 line carries the row-shard leg
     assert leg["ranks"] == 2 and leg["ms_per_step"] > 0 and leg["exchange"]["all_gather_per_hop_ms"] > 0
     assert abs(leg["scale"] - 0.002 * 2 / 8) < 1e-12
-    mode = mode or "allreduce"
+    mode = mode or "colshard"
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 512
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert str(2) in d["config"]["parallelism"]
