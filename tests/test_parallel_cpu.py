@@ -203,3 +203,73 @@ def test_bipartite_partition_balances_users_and_items():
         assert (gu.numpy() == pos[:U]).all() and (gi.numpy() == pos[U:]).all()
         # balance: no rank holds more than its share (+1 block rounding) of either side
         assert max(uhi - ulo for ulo, uhi in (p.users_of(r) for r in range(world))) <= p.bu
+
+
+# ------------------------------------------------------------------ column-sharded tables (neurec_amd/colshard.py)
+def _colshard_worker(rank, world, port, out):
+    """The algebra of the column-sharded step with the CPU oracle as each rank's compute: every rank holds d/W
+    columns for all nodes, steps on the SAME global batch; the one exchange is the all-gather of the per-triplet
+    partial inner products, summed in rank order (parallel.Comm.all_gather_rows, as colshard.py does it)."""
+    from oracle import train
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = parallel.init_from_env(backend="gloo")
+    A, E0, U, I = _graph()
+    At = A.T.tocsr()
+    d, L, reg = E0.shape[1], 2, 1e-3
+    dl = d // world
+    E = E0[:, rank * dl:(rank + 1) * dl].copy()                              # my columns
+    m, v = np.zeros_like(E), np.zeros_like(E)
+    adam = train.Adam(0.01, dtype=np.float64)
+    rng = np.random.RandomState(5)
+    losses = []
+    for step in range(3):
+        bu, bp, bn = rng.randint(0, U, 64), rng.randint(0, I, 64), rng.randint(0, I, 64)     # the GLOBAL batch
+        Estar, _ = train.lightgcn_propagate(A, E, L)                                          # column-wise: no exchange
+        iu, ii, ij = bu, U + bp, U + bn
+        eu, ei, ej = Estar[iu], Estar[ii], Estar[ij]
+        zu, zi, zj = E[iu], E[ii], E[ij]
+        part = np.stack([np.sum(eu * ei, 1), np.sum(eu * ej, 1),
+                         0.5 * (np.sum(zu * zu, 1) + np.sum(zi * zi, 1) + np.sum(zj * zj, 1))], 1)
+        allp = torch.empty((world,) + part.shape, dtype=torch.float64)
+        comm.all_gather_rows(torch.from_numpy(part), allp.view(world * part.shape[0], 3))      # the one exchange
+        given = allp[0].numpy().copy()
+        for r in range(1, world):
+            given = given + allp[r].numpy()                                                   # rank order
+        x = given[:, 0] - given[:, 1]
+        lb, g = train.bpr_terms(x)
+        losses.append((float(np.sum(lb)), float(reg * np.sum(given[:, 2]))))
+        Gstar = np.zeros_like(E)
+        np.add.at(Gstar, iu, g[:, None] * (ei - ej))
+        np.add.at(Gstar, ii, g[:, None] * eu)
+        np.add.at(Gstar, ij, -g[:, None] * eu)
+        H = Gstar / (L + 1)
+        G = H
+        for _ in range(L):
+            G = H + train.spmm_rowwise(At, G)                                                  # column-wise again
+        R = np.zeros_like(E)
+        np.add.at(R, iu, reg * zu)
+        np.add.at(R, ii, reg * zi)
+        np.add.at(R, ij, reg * zj)
+        adam.dense(E, m, v, G + R)
+        adam.advance()
+    np.savez(out % rank, E=E, losses=np.asarray(losses))
+    comm.shutdown()
+
+
+def test_column_sharded_step_equals_single_process(tmp_path):
+    from oracle import train
+    out = str(tmp_path / "rank%d.npz")
+    mp.start_processes(_colshard_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    r = [np.load(out % k) for k in range(2)]
+    np.testing.assert_array_equal(r[0]["losses"], r[1]["losses"])           # both ranks: the same summed products
+    A, E0, U, I = _graph()
+    m, v = np.zeros_like(E0), np.zeros_like(E0)
+    adam = train.Adam(0.01, dtype=np.float64)
+    rng = np.random.RandomState(5)
+    want = []
+    for step in range(3):
+        bu, bp, bn = rng.randint(0, U, 64), rng.randint(0, I, 64), rng.randint(0, I, 64)
+        want.append(train.lightgcn_step(A, A.T.tocsr(), E0, m, v, U, 2, bu, bp, bn, 1e-3, adam))
+    np.testing.assert_allclose(r[0]["losses"], np.asarray(want), rtol=1e-12)
+    np.testing.assert_allclose(np.concatenate([r[0]["E"], r[1]["E"]], 1), E0, atol=1e-12)
