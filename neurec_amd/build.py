@@ -29,7 +29,7 @@ HEADERS = ["nr_core.h", "nr_common.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
-         "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+         "-I", CSRC, "-I", os.path.join(ROOT, "include")] + os.environ.get("NEUREC_HIPCC_EXTRA", "").split()
 
 
 def _existing_sources():

@@ -190,6 +190,20 @@ __device__ __forceinline__ void blocked_epilogue(const float4* s_acc, int r0, in
   }
 }
 
+// per-workgroup phase stamps (experiments: build with NEUREC_HIPCC_EXTRA=-DNR_BLK_TIMELINE, scripts/exp_blk_timeline.py)
+#ifdef NR_BLK_TIMELINE
+__device__ unsigned long long g_blk_dbg[4096 * 24];
+#define NR_BLK_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_blk_dbg[blockIdx.x * 24 + (i)] = wall_clock64(); } while (0)
+#define NR_BLK_WSTAMP() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_blk_dbg[blockIdx.x * 24 + 8 + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
+extern "C" int nrhip_exp_blk_timeline(unsigned long long* h_out) {
+  if (hipDeviceSynchronize() != hipSuccess) return NR_ERR_HIP;
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_blk_dbg), sizeof(unsigned long long) * 4096 * 24) == hipSuccess ? NR_OK : NR_ERR_HIP;
+}
+#else
+#define NR_BLK_STAMP(i) do {} while (0)
+#define NR_BLK_WSTAMP() do {} while (0)
+#endif
+
 template <bool MASKED, int kWaves, int kG, int D, bool ADAM = false>
 __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_nrows,
@@ -211,9 +225,11 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & (LPR - 1), g = lane / LPR, gbase = lane & ~(LPR - 1);
   const int wg = blockIdx.x;
+  NR_BLK_STAMP(0);
   const int r0 = wg_row0[wg], nr = wg_nrows[wg];
   for (int i = tid; i < nr * LPR; i += kWaves * NR_WAVE) s_acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
+  NR_BLK_STAMP(1);
   const int32_t* eoff = wg_ent_off + (int64_t)wg * (n_phases + 1);
   const int32_t* coff = wg_cmb_off + (int64_t)wg * (n_phases + 1);
   for (int k = 0; k < n_phases; ++k) {
@@ -332,9 +348,11 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       cur_want = nxt_want;
       ei = ein;
     }
+    NR_BLK_WSTAMP();
     const int c0 = coff[k], c1 = coff[k + 1];
     if (c1 > c0) {                                  // workgroup-uniform
       __syncthreads();
+      NR_BLK_STAMP(2);
       for (int ci = c0 + wave * GPW + g; ci < c1; ci += kGroups) {
         const int4 cm = cmb[ci];
         float4 acc = s_acc[cm.x * LPR + c];
@@ -348,8 +366,10 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     }
     __syncthreads();
   }
+  NR_BLK_STAMP(3);
   blocked_epilogue<MASKED, ADAM, LPR>(s_acc, r0, nr, tid, kWaves * NR_WAVE, Y, addend, sum_in, sum_out,
                                       row_mask, ad);
+  NR_BLK_STAMP(4);
 }
 
 
