@@ -305,10 +305,10 @@ def test_unsupported_shapes_fail_early_and_by_name():
     class _Conf(dict):
         def __getattr__(self, k):
             return self[k]
-    # (since r03 every embed_size up to 256 runs — zero-padded to the next built width; beyond that: refused by name)
+    # (since r03 every embed_size up to 128 runs — zero-padded to the next built width; beyond: refused by name)
     conf = _Conf(lr=0.01, reg=1e-3, embed_size=300, batch_size=8, epochs=1, n_layers=2, adj_type="pre",
                  recommender="LightGCN")
-    with pytest.raises(NotImplementedError, match="embed_size 1..256"):
+    with pytest.raises(NotImplementedError, match="embed_size 1..128"):
         LightGCN.__init__.__wrapped__(object.__new__(LightGCN), None, None, conf) if hasattr(LightGCN.__init__, "__wrapped__") \
             else _try_lightgcn(LightGCN, conf)
 
