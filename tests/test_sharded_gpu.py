@@ -37,7 +37,7 @@ def _batches(U, I, world, B, steps):
               rng.randint(0, I, B).astype(np.int32)) for _ in range(world)] for _ in range(steps)]
 
 
-def _worker(rank, world, port, out, adj_type, d, backend="gloo"):
+def _worker(rank, world, port, out, adj_type, d, backend="gloo", L=2):
     import torch
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_DIST_BACKEND=backend)
@@ -52,10 +52,10 @@ def _worker(rank, world, port, out, adj_type, d, backend="gloo"):
         (ulo, uhi), (ilo, ihi) = part.users_of(rank), part.items_of(rank)
         blk = sp.vstack([A[ulo:uhi], A[U + ilo:U + ihi]]).tocsr()
         emb = np.concatenate([E0[ulo:uhi], E0[U + ilo:U + ihi]])
-        eng = ShardedLightGCN(comm, None, U, I, emb, 2, 0.01, 1e-3, 128,
+        eng = ShardedLightGCN(comm, None, U, I, emb, L, 0.01, 1e-3, 128,
                               local_rows=(blk.indptr, blk.indices, blk.data))
     else:
-        eng = ShardedLightGCN(comm, A, U, I, E0, 2, 0.01, 1e-3, 128)
+        eng = ShardedLightGCN(comm, A, U, I, E0, L, 0.01, 1e-3, 128)
     losses = []
     steps = _batches(U, I, world, 128, 3)
     if d == 64:
@@ -80,17 +80,20 @@ def _worker(rank, world, port, out, adj_type, d, backend="gloo"):
     comm.shutdown()
 
 
-@pytest.mark.parametrize("adj_type,d", [("pre", 64), ("norm", 64), ("pre", 128)])
-def test_sharded_lightgcn_equals_single_process(tmp_path, adj_type, d):
+@pytest.mark.parametrize("adj_type,d,L", [("pre", 64, 2), ("norm", 64, 2), ("pre", 128, 2),
+                                          # L + 1 a power of two: the head divides its rows itself (no scratch table),
+                                          # the configured depth of BASELINE configs[2] / configs[3]
+                                          ("pre", 64, 3), ("norm", 128, 3), ("pre", 64, 1)])
+def test_sharded_lightgcn_equals_single_process(tmp_path, adj_type, d, L):
     import torch
     import torch.multiprocessing as mp
     from neurec_amd.trainer import LightGCNEngine
     out = str(tmp_path / "r0.npz")
-    mp.start_processes(_worker, args=(2, _free_port(), out, adj_type, d), nprocs=2, join=True,
+    mp.start_processes(_worker, args=(2, _free_port(), out, adj_type, d, "gloo", L), nprocs=2, join=True,
                        start_method="spawn")
     got = np.load(out)
     tr, A, E0, U, I = _setup(adj_type, d)
-    lg = LightGCNEngine(A, U, I, E0, 2, 0.01, 1e-3, 256)
+    lg = LightGCNEngine(A, U, I, E0, L, 0.01, 1e-3, 256)
     want_losses = []
     for step in _batches(U, I, 2, 128, 3):
         bu, bp, bn = (torch.from_numpy(np.concatenate([s[k] for s in step])).cuda() for k in range(3))
@@ -173,3 +176,41 @@ def test_sharded_mf_equals_single_process(tmp_path):
     np.testing.assert_allclose(got["losses"], np.asarray(want_losses), rtol=1e-6)
     np.testing.assert_array_equal(got["P"], mf.P.cpu().numpy())
     np.testing.assert_array_equal(got["Q"], mf.Q.cpu().numpy())
+
+
+def test_sharded_steps_with_the_atomic_heads_knob(tmp_path):
+    """with NRHIP_ATOMIC_SCATTER=1 the heads ADD into their output rows — the sharded engines' compact
+    gradient buffers are no longer zeroed by a full memset, so they clear them themselves under the knob: three
+    steps of one rank stay within fp32 summation noise of the ordered run (they used to accumulate step over step)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from neurec_amd import graph, synth, parallel
+from neurec_amd.sharded import ShardedLightGCN, ShardedMF
+tr, _ = synth.interactions("ml-100k", seed=11)
+coo = tr.tocoo(); U, I = tr.shape
+A = graph.lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+E0 = synth.xavier_uniform(U + I, 64, np.random.RandomState(3))
+comm = parallel.Comm()
+lg = ShardedLightGCN(comm, A, U, I, E0, 3, 0.01, 1e-3, 128)
+mf = ShardedMF(comm, E0[:U], E0[U:], 0.001, 0.01, 128)
+rng = np.random.RandomState(9)
+for _ in range(3):
+    b = [torch.from_numpy(rng.randint(0, n, 128).astype(np.int32)).cuda() for n in (U, I, I)]
+    l = torch.zeros(2, device="cuda")
+    lg.step(b[0], b[1], b[2], l); mf.step(b[0], b[1], b[2], l)
+P, Q = mf.tables()
+np.savez(sys.argv[1], E=torch.cat(lg.natural(lg.E0)).cpu().numpy(), P=P.cpu().numpy(), Q=Q.cpu().numpy())
+''' % root
+    res = {}
+    for knob in ("0", "1"):
+        out = str(tmp_path / ("k%s.npz" % knob))
+        env = dict(os.environ, NRHIP_ATOMIC_SCATTER=knob)
+        r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[knob] = np.load(out)
+    for k in ("E", "P", "Q"):
+        assert np.abs(res["0"][k] - res["1"][k]).max() < 2e-4, k       # same steps up to the atomics' summation order
