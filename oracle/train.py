@@ -459,3 +459,66 @@ def multivae_loss_and_grads(X, Wq, bq, Wp, bp, drop_mask, keep, eps, anneal, reg
     gWq0 = h0.T @ da1 + dt(2 * reg) * Wq[0]
     gbq0 = da1.sum(0)
     return loss, ([gWq0, gWq1], [gbq0, gbq1], [gWp0, gWp1], [gbp0, gbp1]), (neg_ll, KL)
+
+
+def multivae_general(X, Wq, bq, Wp, bp, drop_mask, keep, eps, anneal, reg, act="tanh", is_training=1.0,
+                     want_grads=True):
+    """q_graph / p_graph / neg-ELBO of MultiVAE.py:73-135 for ANY p_dim (the reference builds
+    q_dims = reversed(p_dim + [I]) layers of arbitrary number and width, :34-36,46-71): Wq / bq the n encoder layers
+    (the last with 2z columns: [mu | logvar]), Wp / bp the n decoder layers (the last onto the I items).  Returns
+    (loss, (gWq, gbq, gWp, gbp), (neg_ll, KL), logits).  Pinned to the reference class by
+    tests/golden/tfgraph_multivae_wide_*.npz (tests/test_tfgraph_golden.py)."""
+    dt = X.dtype.type
+    B, n = X.shape[0], len(Wq)
+    ss = np.sum(X * X, axis=1, keepdims=True, dtype=dt)
+    h = X / np.sqrt(np.maximum(ss, dt(1e-12)))
+    h = h / dt(keep) * drop_mask.astype(X.dtype)
+    q_in, q_out = [], []
+    for i in range(n):
+        q_in.append(h)
+        a = h @ Wq[i] + bq[i]
+        if i != n - 1:
+            h = _act(act, a)
+            q_out.append(h)
+    z = a.shape[1] // 2
+    mu, logvar = a[:, :z], a[:, z:]
+    std = np.exp(dt(0.5) * logvar)
+    KL = np.mean(np.sum(dt(0.5) * (-logvar + np.exp(logvar) + mu * mu - dt(1)), axis=1, dtype=dt), dtype=dt)
+    zs = mu + dt(is_training) * eps * std
+    g = zs
+    p_in, p_out = [], []
+    for i in range(n):
+        p_in.append(g)
+        a3 = g @ Wp[i] + bp[i]
+        if i != n - 1:
+            g = _act(act, a3)
+            p_out.append(g)
+    logits = a3
+    mx = logits.max(axis=1, keepdims=True)
+    lse = mx + np.log(np.sum(np.exp(logits - mx), axis=1, keepdims=True, dtype=dt))
+    logsm = logits - lse
+    neg_ll = -np.mean(np.sum(logsm * X, axis=1, dtype=dt), dtype=dt)
+    reg_var = dt(reg) * sum(np.sum(w * w, dtype=dt) / dt(2) for w in list(Wq) + list(Wp))
+    loss = neg_ll + dt(anneal) * KL + dt(2) * reg_var
+    if not want_grads:
+        return loss, None, (neg_ll, KL), logits
+    nrow = np.sum(X, axis=1, keepdims=True, dtype=dt)
+    d = (np.exp(logsm) * nrow - X) / dt(B)
+    gWp, gbp = [None] * n, [None] * n
+    for i in range(n - 1, -1, -1):
+        gWp[i] = p_in[i].T @ d + dt(2 * reg) * Wp[i]
+        gbp[i] = d.sum(0)
+        d = d @ Wp[i].T
+        if i > 0:
+            d = d * _act_grad(act, p_out[i - 1], p_out[i - 1])        # (relu: y > 0 iff x > 0)
+    dz = d
+    dmu = dz + dt(anneal) * mu / dt(B)
+    dlogvar = dz * eps * std * dt(0.5) * dt(is_training) + dt(anneal) * dt(0.5) * (np.exp(logvar) - dt(1)) / dt(B)
+    d = np.concatenate([dmu, dlogvar], axis=1)
+    gWq, gbq = [None] * n, [None] * n
+    for i in range(n - 1, -1, -1):
+        gWq[i] = q_in[i].T @ d + dt(2 * reg) * Wq[i]
+        gbq[i] = d.sum(0)
+        if i > 0:
+            d = (d @ Wq[i].T) * _act_grad(act, q_out[i - 1], q_out[i - 1])
+    return loss, (gWq, gbq, gWp, gbp), (neg_ll, KL), logits

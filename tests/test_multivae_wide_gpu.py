@@ -1,0 +1,171 @@
+"""Mult-VAE at ANY p_dim on the GPU (neurec_amd/vae_wide.py; csrc/vae_wide.hip + csrc/gemm.hip) against
+  * the reference's own MultiVAE class run under oracle/tf_shim.py at two, one and three layers
+    (tests/golden/tfgraph_multivae_wide_*.npz; conf/MultiVAE.properties:3 lists [200, 600] and [200]), 1e-5;
+  * oracle.train.multivae_general (pinned to the same fixtures on the CPU) at p_dim = [200, 600];
+and the general fp32-MFMA GEMM against its own definition (the k-ascending fmaf chain) bit for bit."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _err(got, want):
+    return float(np.abs(np.asarray(got, np.float64) - want).max())
+
+
+def _rel(got, want):
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want) / np.abs(want)))
+
+
+def _drop_by_entry(R, rows, mask):
+    out = np.ones(R.nnz, np.float32)
+    for b, u in enumerate(rows):
+        lo, hi = R.indptr[u], R.indptr[u + 1]
+        out[lo:hi] = mask[b, R.indices[lo:hi]]
+    return out
+
+
+def _names(n):
+    return ["Wq%d" % i for i in range(n)] + ["bq%d" % i for i in range(n)] + \
+           ["Wp%d" % i for i in range(n)] + ["bp%d" % i for i in range(n)]
+
+
+@pytest.mark.parametrize("tag", ["24x40", "20", "8x16x24"])
+def test_wide_engine_equals_the_reference_graph(tag):
+    from neurec_amd import engine as E
+    from neurec_amd.vae_wide import MultiVAEWideEngine
+    g = load_golden("tfgraph_multivae_wide_" + tag)
+    h = json.loads(str(g["hyper"]))
+    U, I, n = int(g["n_users"]), int(g["n_items"]), int(g["n_layers"])
+    R = sp.csr_matrix((np.ones(len(g["train_indices"]), np.float32), g["train_indices"], g["train_indptr"]),
+                      shape=(U, I))
+    P = lambda k: [g["%s%d_0" % (k, i)] for i in range(n)]
+    eng = MultiVAEWideEngine(E.DeviceCSR.from_scipy(R), I, P("Wq"), P("bq"), P("Wp"), P("bp"), h["learning_rate"],
+                             h["reg"], h["activation"], h["batch_size"])
+    got, first = [], None
+    for s, rows in enumerate(g["rows"]):
+        if first is None:                                    # gradients of the first step, before Adam consumes them
+            eng.step(_dev(rows.astype(np.int32)), float(g["anneal"][s]), 0.8,
+                     drop_given=_dev(_drop_by_entry(R, rows, g["drop_masks"][s])),
+                     eps_given=_dev(g["eps"][s].astype(np.float32)), apply=False)
+            first = [x.cpu().numpy().copy() for x in eng.G]
+            eng.G[0].zero_()
+        eng.step(_dev(rows.astype(np.int32)), float(g["anneal"][s]), 0.8,
+                 drop_given=_dev(_drop_by_entry(R, rows, g["drop_masks"][s])),
+                 eps_given=_dev(g["eps"][s].astype(np.float32)))
+        got.append(eng.loss()[0])
+    assert _rel(got, g["f32_loss"]) <= TOL and _rel(got, g["f64_loss"]) <= TOL
+    names = _names(n)
+    dgrad = max(_err(a.reshape(g["f64_d" + k].shape), g["f64_d" + k]) for a, k in zip(first, names))
+    bar = max(_err(g["f32_" + k], g["f64_" + k]) for k in names)
+    d = max(_err(p.cpu().numpy().reshape(g["f64_" + k].shape), g["f64_" + k]) for p, k in zip(eng.params, names))
+    # predict(): the reference's accumulating row (MultiVAE.py:195-203) as one extra CSR
+    acc, rows_acc = set(), []
+    for u in g["ratings_users"]:
+        acc |= set(R[u].indices.tolist())
+        rows_acc.append(sorted(acc))
+    indptr = np.cumsum([0] + [len(r) for r in rows_acc])
+    Racc = sp.csr_matrix((np.ones(indptr[-1], np.float32), np.concatenate(rows_acc), indptr), shape=(len(rows_acc), I))
+    out = eng.logits(_dev(np.arange(len(rows_acc), dtype=np.int32)), E.DeviceCSR.from_scipy(Racc))
+    dr = _err(out[:, :I].cpu().numpy(), g["f64_ratings"])
+    print("wide Mult-VAE %s: first-step gradients %.1e, parameters after %d steps %.1e (reference fp32-vs-fp64 %.1e), "
+          "predict() %.1e" % (tag, dgrad, len(got), d, bar, dr))
+    assert dgrad <= TOL and d <= TOL + bar and dr <= TOL + bar
+
+
+def test_wide_engine_at_p_dim_200_600_equals_the_restatement():
+    """conf/MultiVAE.properties:3's own alternative: p_dim = [200, 600] (q: I -> 600 -> 400, p: 200 -> 600 -> I)."""
+    from neurec_amd import engine as E
+    from neurec_amd.vae_wide import MultiVAEWideEngine
+    from oracle import train as O
+    rng = np.random.RandomState(5)
+    U, I, B, z, hdim = 300, 3000, 96, 200, 600
+    R = sp.random(U, I, density=0.02, random_state=rng, format="csr", dtype=np.float32)
+    R.data[:] = 1
+    R = R[np.diff(R.indptr) > 0]
+    U = R.shape[0]
+    xav = lambda a, b: (rng.uniform(-1, 1, (a, b)) * np.sqrt(6.0 / (a + b))).astype(np.float32)
+    tn = lambda b: (rng.randn(b) * 0.001).astype(np.float32)
+    Wq, bq = [xav(I, hdim), xav(hdim, 2 * z)], [tn(hdim), tn(2 * z)]
+    Wp, bp = [xav(z, hdim), xav(hdim, I)], [tn(hdim), tn(I)]
+    lr, reg = 1e-3, 0.01
+    eng = MultiVAEWideEngine(E.DeviceCSR.from_scipy(R), I, Wq, bq, Wp, bp, lr, reg, "tanh", B)
+    for dt, tol in ((np.float64, TOL),):
+        W = [[x.astype(dt) for x in grp] for grp in (Wq, bq, Wp, bp)]
+        params = W[0] + W[1] + W[2] + W[3]
+        ms, vs = [np.zeros_like(x) for x in params], [np.zeros_like(x) for x in params]
+        adam = O.Adam(lr, dtype=dt)
+        want, got = [], []
+        for s in range(3):
+            rows = rng.choice(U, B, replace=False).astype(np.int32)
+            mask = (rng.rand(B, I) < 0.8).astype(np.float32)
+            eps = (rng.randn(B, z) * 0.01).astype(np.float32)
+            X = np.asarray(R[rows].todense(), dtype=dt)
+            loss, grads, _, _ = O.multivae_general(X, W[0], W[1], W[2], W[3], mask.astype(dt), dt(0.8), eps.astype(dt),
+                                                   0.2 * (s + 1), reg, "tanh")
+            if s == 0:
+                eng.step(_dev(rows), 0.2, 0.8, drop_given=_dev(_drop_by_entry(R, rows, mask)), eps_given=_dev(eps),
+                         apply=False)
+                flat = grads[0] + grads[1] + grads[2] + grads[3]
+                dgrad = max(_err(a.cpu().numpy().reshape(b.shape), b) / max(np.abs(b).max(), 1e-30)
+                            for a, b in zip(eng.G, flat))
+                eng.G[0].zero_()
+            for pp, m, v, gg in zip(params, ms, vs, grads[0] + grads[1] + grads[2] + grads[3]):
+                adam.dense(pp, m, v, gg.reshape(pp.shape))
+            adam.advance()
+            want.append(float(loss))
+            eng.step(_dev(rows), 0.2 * (s + 1), 0.8, drop_given=_dev(_drop_by_entry(R, rows, mask)), eps_given=_dev(eps))
+            got.append(eng.loss()[0])
+        d = max(_err(p.cpu().numpy().reshape(w.shape), w) for p, w in zip(eng.params, params))
+        print("wide Mult-VAE [200, 600]: loss %.1e, first-step gradients (relative to each one's max) %.1e, "
+              "parameters after 3 steps %.1e" % (_rel(got, want), dgrad, d))
+        assert _rel(got, want) <= tol and dgrad <= tol
+        # Adam's first steps move every coordinate by ~lr whatever |g|: coordinates whose gradient fp32 does not
+        # resolve may land on the other side ("Adam and tiny gradients"); the bulk must agree
+        assert d <= 2.5 * lr
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(64, 64, 16, 1), (100, 333, 77, 1), (512, 1000, 600, 1), (200, 600, 512, 1),
+                                          (96, 40, 5000, 8), (512, 600, 4099, 16), (1, 1, 1, 1)])
+def test_gemm_kmajor_is_the_k_ascending_fmaf_chain(M, N, K, splits):
+    import ctypes as C
+    import torch
+    from neurec_amd._lib import call
+    from neurec_amd.engine import _ptr, _stream
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(K, M).astype(np.float32)
+    Bm = rng.randn(K, N).astype(np.float32)
+    dA, dB = _dev(A), _dev(Bm)
+    out = torch.full((M, N + 3), 7.0, dtype=torch.float32, device="cuda")
+    nbytes = C.c_size_t(0)
+    call("nrhip_gemm_workspace_bytes", M, N, splits, C.byref(nbytes))
+    ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device="cuda")
+    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N + 3, 0, splits, _ptr(ws),
+         ws.numel() if splits > 1 else 0, _stream())
+    got = out.cpu().numpy()
+    assert (got[:, N:] == 7.0).all()
+    want64 = A.T.astype(np.float64) @ Bm.astype(np.float64)
+    if splits == 1:
+        from oracle import native
+        want = native.score_gemm(np.ascontiguousarray(A.T), None, np.ascontiguousarray(Bm.T))   # the true fmaf chain
+        assert np.array_equal(got[:, :N], want)
+    assert np.abs(got[:, :N] - want64).max() <= 2e-6 * np.sqrt(K) * max(1.0, np.abs(want64).max())
+    # accumulate: C += A^T B continues the chain from C
+    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N + 3, 1, splits, _ptr(ws),
+         ws.numel() if splits > 1 else 0, _stream())
+    assert np.abs(out.cpu().numpy()[:, :N] - 2 * want64).max() <= 4e-6 * np.sqrt(K) * max(1.0, np.abs(want64).max())
+    # transpose
+    T = torch.zeros((N, K + 1), dtype=torch.float32, device="cuda")
+    call("nrhip_transpose2d", _ptr(dB), N, K, N, _ptr(T), K + 1, _stream())
+    assert np.array_equal(T.cpu().numpy()[:, :K], Bm.T)

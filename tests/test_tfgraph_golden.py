@@ -300,3 +300,52 @@ def test_config0_epoch_on_real_ml100k_restated():
     # metric by 1 / (943 k)); north_star's 1e-5 is met when none does — the observed difference is printed
     print("config 0: NDCG@10 %.8f (reference run %.8f)" % (m[2 * 20 + 9], g["f32_metrics"][2 * 20 + 9]))
     assert np.abs(m - g["f32_metrics"]).max() <= 1e-4
+
+
+def _wide_params(g, dt):
+    n = int(g["n_layers"])
+    return n, ([g["Wq%d_0" % i].astype(dt) for i in range(n)], [g["bq%d_0" % i].astype(dt) for i in range(n)],
+               [g["Wp%d_0" % i].astype(dt) for i in range(n)], [g["bp%d_0" % i].astype(dt) for i in range(n)])
+
+
+@pytest.mark.parametrize("tag", ["24x40", "20", "8x16x24"])
+def test_multivae_any_p_dim_restatement_equals_the_reference_graph(tag):
+    """conf/MultiVAE.properties:3 lists other p_dim ([200, 600], [200]); MultiVAE.py builds len(p_dim) layers each
+    way.  oracle.train.multivae_general against the reference class run at two, one and three layers."""
+    g = load_golden("tfgraph_multivae_wide_" + tag)
+    h = json.loads(str(g["hyper"]))
+    U, I = int(g["n_users"]), int(g["n_items"])
+    R = sp.csr_matrix((np.ones(len(g["train_indices"])), g["train_indices"], g["train_indptr"]), shape=(U, I))
+    for w, dt, tol, tol_tab in WIDTHS:
+        n, (Wq, bq, Wp, bp) = _wide_params(g, dt)
+        params = Wq + bq + Wp + bp
+        ms, vs = [np.zeros_like(x) for x in params], [np.zeros_like(x) for x in params]
+        adam = O.Adam(h["learning_rate"], dtype=dt)
+        losses, first = [], None
+        for s, rows in enumerate(g["rows"]):
+            X = np.asarray(R[rows].todense(), dtype=dt)
+            loss, (gWq, gbq, gWp, gbp), _, _ = O.multivae_general(
+                X, Wq, bq, Wp, bp, g["drop_masks"][s].astype(dt), dt(0.8), g["eps"][s].astype(dt), g["anneal"][s],
+                h["reg"], h["activation"])
+            grads = gWq + gbq + gWp + gbp
+            if first is None:
+                first = grads
+            for pp, m, v, gg in zip(params, ms, vs, grads):
+                adam.dense(pp, m, v, gg.reshape(pp.shape))
+            adam.advance()
+            losses.append(float(loss))
+        assert _rel(losses, g[w + "_loss"]) <= tol
+        names = ["Wq%d" % i for i in range(n)] + ["bq%d" % i for i in range(n)] + \
+                ["Wp%d" % i for i in range(n)] + ["bp%d" % i for i in range(n)]
+        for a, k in zip(first, names):
+            _close(a, g["%s_d%s" % (w, k)], 3 * tol)
+        for a, k in zip(params, names):
+            _close(a, g["%s_%s" % (w, k)], tol_tab)
+        acc, outs = np.zeros((1, I), dt), []
+        for u in g["ratings_users"]:                                   # predict(): the accumulating row
+            acc[0, R[u].indices] = 1
+            _, _, _, logits = O.multivae_general(acc, Wq, bq, Wp, bp, np.ones_like(acc), 1.0,
+                                                 np.zeros((1, Wp[0].shape[0]), dt), 0.0, h["reg"], h["activation"],
+                                                 is_training=0.0, want_grads=False)
+            outs.append(logits[0])
+        _close(np.asarray(outs), g[w + "_ratings"], tol_tab)
