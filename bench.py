@@ -222,6 +222,34 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
                                 "reads bound them"},
            "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9]),
                     "design": "factor path: logits = [g1(u) | 1]·[W_p1 | b_p1] through the pruned evaluator"}}
+    # conf/MultiVAE.properties:3's alternative shape p_dim = [200, 600] on the width-generic engine
+    from neurec_amd.vae_wide import MultiVAEWideEngine
+    zw, hw = 200, 600
+    wide = MultiVAEWideEngine(trc, I, [wi([I, hw]), wi([hw, 2 * zw])], [bi([hw]), bi([2 * zw])],
+                              [wi([zw, hw]), wi([hw, I])], [bi([hw]), bi([I])], 0.001, 0.0, "tanh", B)
+    it2 = iter(rows_list * 20)
+    wide_ms = _hip_timed(lambda: wide.step(next(it2), 0.2, 0.8, want_loss=True), 60, 10)
+    wide.step(rows, 0.2, 0.8)
+
+    def item_layer():                                      # logits, dW = g^T D, dg = D W^T (the transposes included)
+        wide._transpose(wide.Gp[-1], hw, B, hw, wide.gT, wide.B)
+        wide._gemm(wide.gT, wide.B, wide.Wp[-1], I, B, I, hw, wide.S, wide.ld, bias=wide.bp[-1])
+        wide._gemm(wide.Gp[-1], hw, wide.S, wide.ld, hw, I, B, wide.G[2 * 2 + 1], I)
+        wide._transpose(wide.S, wide.ld, B, I, wide.DT, wide.B)
+        wide._transpose(wide.Wp[-1], I, hw, I, wide.WT, hw)
+        wide._gemm(wide.DT, wide.B, wide.WT, hw, B, hw, I, wide.dGp[-1], hw, splits=wide.splits)
+    item_ms = _hip_timed(item_layer, 30, 5)
+    item_flops = 3 * 2.0 * B * I * hw
+    out["wide"] = {"p_dim": [zw, hw], "batch": B, "ms_per_step": wide_ms, "users_per_sec_train": B / wide_ms * 1e3,
+                   "roofline": {"bound": "mfma", "kernel": "gemm_kmajor_kernel x3 (+ 3 transposes): the item layer's "
+                                                           "logits, dW and dg",
+                                "flops_per_step": item_flops, "us_per_step": item_ms * 1e3,
+                                "achieved": item_flops / item_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": item_flops / item_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                                "traffic": None,
+                                "note": "fp32 (the reference's dtype) on v_mfma_f32_32x32x2_f32; operands straight "
+                                        "from L2 in k-major layout, no LDS staging yet"}}
+    del wide
     if with_cpu:
         from oracle import train as O
         rng = np.random.RandomState(4)

@@ -704,10 +704,12 @@ int nrhip_ngcf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, con
  * act: 0 tanh, 1 sigmoid, 2 relu, 3 identity, -1 none.  neurec_amd/vae_wide.py strings them into a step. */
 /* C[m][n] (+)= sum_k A[k][m] * B[k][n]; A [K][lda], B [K][ldb] (contraction index slow), C [M][ldc]; every element the
  * k-ascending fmaf chain (continued from C when accumulate); splits > 1 cuts K into ranges whose partial products
- * (d_ws: nrhip_gemm_workspace_bytes) are added in order. */
+ * (d_ws: nrhip_gemm_workspace_bytes) are added in order.  Epilogue: + d_bias_n[n] (NULL: none), then `act` (-1: none) —
+ * a dense layer y = act(x W + b) is one call with A = x^T. */
 int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes);
 int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int M, int N, int K, float* d_C,
-                      int64_t ldc, int accumulate, int splits, void* d_ws, size_t ws_bytes, void* stream);
+                      int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits, void* d_ws,
+                      size_t ws_bytes, void* stream);
 int nrhip_transpose2d(const float* d_src, int64_t ld_src, int rows, int cols, float* d_dst, int64_t ld_dst,
                       void* stream);
 /* first encoder layer straight from the train CSR (tf.nn.l2_normalize + tf.nn.dropout + the first tf.matmul of
@@ -717,11 +719,7 @@ int nrhip_vae_bag_fwd(const int64_t* d_indptr, const int32_t* d_indices, const i
                       int width, const float* d_W, const float* d_bias, int act, float keep,
                       const float* d_drop_given, uint64_t seed, uint64_t step, float* d_h0val, float* d_Y,
                       void* stream);
-int nrhip_dense_fwd(const float* d_X, int64_t ldx, const float* d_W, const float* d_bias, int batch, int K, int N,
-                    int act, float* d_Y, int64_t ldy, void* stream);                 /* Y = act(X W + b) */
 int nrhip_act_bwd(const float* d_dY, const float* d_Y, int64_t n, int act, float* d_dA, void* stream);
-int nrhip_dense_bwd(const float* d_dA, int64_t lda, const float* d_X, int64_t ldx, const float* d_W, int batch,
-                    int K, int N, float* d_dX, int64_t lddx, float* d_dW, float* d_db, void* stream);
 int nrhip_vae_sample(const float* d_H2, int batch, int z, const float* d_eps_given, float is_training, uint64_t seed,
                      uint64_t step, float* d_EPSSTD, float* d_ZS, float* d_KLb, void* stream);
 int nrhip_vae_sample_bwd(const float* d_dZ, const float* d_H2, const float* d_EPSSTD, int batch, int z, float anneal,

@@ -22,75 +22,131 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kPairs = 8;        // k-pairs per unrolled step (32 loads in flight per lane)
+constexpr int KT = 16;           // k rows per LDS tile
 
-// one wave = a 64 x 64 tile of C; block = 4 waves stacked along m
-template <bool ACC>
-__global__ __launch_bounds__(256) void gemm_kmajor_kernel(
+__device__ __forceinline__ float epilogue_act(int a, float x) {
+  if (a == 0) return tanhf(x);
+  if (a == 1) return 1.0f / (1.0f + expf(-x));
+  if (a == 2) return fmaxf(x, 0.f);
+  return x;
+}
+
+// Block = 4 waves (2 x 2) over a TILE x TILE tile of C; wave tile (TILE/2)^2 = R x R MFMA 32x32 tiles.
+// Both operand tiles [KT][TILE] go global -> registers -> LDS (double-buffered: the next tile's loads are in flight
+// while the matrix cores work on the current one); an MFMA operand is then one conflict-free 32-bank row read.
+// The linear block id is dealt to the 8 XCDs so that the tiles_m blocks sharing one n-tile of B run on the SAME XCD
+// (one L2 fetch of that B tile serves all of them).
+template <int TILE, bool ACC>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int M, int N, int K,
-    int k_per_split, float* __restrict__ C, int64_t ldc, int64_t split_stride) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int k_per_split, float* __restrict__ C, int64_t ldc, int64_t split_stride, const float* __restrict__ bias_n,
+    int act, int tiles_m, int tiles_n) {
+  constexpr int R = TILE / 64;
+  constexpr int PER = KT * TILE / 256;
+  __shared__ float sA[2][KT][TILE];
+  __shared__ float sB[2][KT][TILE];
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (logical >= total) return;
+  const int m0 = (logical % tiles_m) * TILE, n0 = (logical / tiles_m) * TILE;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
-  const int m0 = (blockIdx.y * 4 + wave) * 64, n0 = blockIdx.x * 64;
-  if (m0 >= M) return;
+  const int wm = (wave & 1) * (TILE / 2), wn = (wave >> 1) * (TILE / 2);
   const int kb = blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
   C += (int64_t)blockIdx.z * split_stride;
-  // clamped operand columns (loads are unconditional; what lies outside M / N / K is multiplied by a zero)
-  const int ma = min(m0 + j, M - 1), mb = min(m0 + 32 + j, M - 1);
-  const int na = min(n0 + j, N - 1), nb = min(n0 + 32 + j, N - 1);
-  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-  if (ACC) {
+
+  f32x16 acc[R][R];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      const int ra = m0 + rr, rb = m0 + 32 + rr, ca = n0 + j, cb = n0 + 32 + j;
-      if (ra < M && ca < N) c00[reg] = C[(int64_t)ra * ldc + ca];
-      if (ra < M && cb < N) c01[reg] = C[(int64_t)ra * ldc + cb];
-      if (rb < M && ca < N) c10[reg] = C[(int64_t)rb * ldc + ca];
-      if (rb < M && cb < N) c11[reg] = C[(int64_t)rb * ldc + cb];
+  for (int x = 0; x < R; ++x)
+#pragma unroll
+    for (int y = 0; y < R; ++y) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        float v = 0.f;
+        if (ACC) {
+          const int r = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h, c = n0 + wn + 32 * y + j;
+          if (r < M && c < N) v = C[(int64_t)r * ldc + c];
+        }
+        acc[x][y][reg] = v;
+      }
     }
-  }
-  for (int k0 = kb; k0 < ke; k0 += 2 * kPairs) {
-    float a0[kPairs], a1[kPairs], b0[kPairs], b1[kPairs];
+  if (kb >= ke) return;                                   // an empty split (never launched; kept for safety)
+
+  // this thread's slots of an operand tile: element e = tid + 256 i -> row e / TILE, column e % TILE
+  const int col = tid % TILE, row0 = tid / TILE;           // rows row0 + (256 / TILE) i
+  const int64_t ca = min(m0 + col, M - 1), cb = min(n0 + col, N - 1);   // clamped: what lies outside is never stored
+  float ra[PER], rb[PER];
+  auto gload = [&](int k0) {
 #pragma unroll
-    for (int s = 0; s < kPairs; ++s) {
-      const int k = k0 + 2 * s + h;
+    for (int i = 0; i < PER; ++i) {
+      const int k = k0 + row0 + (256 / TILE) * i;
       const int kc = min(k, ke - 1);
-      const float live = k < ke ? 1.f : 0.f;            // a zero A operand removes the step exactly (x + 0*b = x)
-      a0[s] = A[(int64_t)kc * lda + ma] * live;
-      a1[s] = A[(int64_t)kc * lda + mb] * live;
-      b0[s] = B[(int64_t)kc * ldb + na];
-      b1[s] = B[(int64_t)kc * ldb + nb];
+      const float va = A[(int64_t)kc * lda + ca], vb = B[(int64_t)kc * ldb + cb];
+      ra[i] = k < ke ? va : 0.f;                            // rows past the range: exact no-ops (x + 0 * 0)
+      rb[i] = k < ke ? vb : 0.f;
     }
+  };
+  auto sstore = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < kPairs; ++s) {
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], c11, 0, 0, 0);
+    for (int i = 0; i < PER; ++i) {
+      sA[buf][row0 + (256 / TILE) * i][col] = ra[i];
+      sB[buf][row0 + (256 / TILE) * i][col] = rb[i];
     }
+  };
+  gload(kb);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += KT, buf ^= 1) {
+    const bool more = k0 + KT < ke;
+    if (more) gload(k0 + KT);
+#pragma unroll
+    for (int s = 0; s < KT / 2; ++s) {
+      float a[R], b[R];
+#pragma unroll
+      for (int x = 0; x < R; ++x) a[x] = sA[buf][2 * s + h][wm + 32 * x + j];
+#pragma unroll
+      for (int y = 0; y < R; ++y) b[y] = sB[buf][2 * s + h][wn + 32 * y + j];
+#pragma unroll
+      for (int x = 0; x < R; ++x)
+#pragma unroll
+        for (int y = 0; y < R; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
   }
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    const int ra = m0 + rr, rb = m0 + 32 + rr, ca = n0 + j, cb = n0 + 32 + j;
-    if (ra < M && ca < N) C[(int64_t)ra * ldc + ca] = c00[reg];
-    if (ra < M && cb < N) C[(int64_t)ra * ldc + cb] = c01[reg];
-    if (rb < M && ca < N) C[(int64_t)rb * ldc + ca] = c10[reg];
-    if (rb < M && cb < N) C[(int64_t)rb * ldc + cb] = c11[reg];
-  }
+  for (int x = 0; x < R; ++x)
+#pragma unroll
+    for (int y = 0; y < R; ++y) {
+      const int c = n0 + wn + 32 * y + j;
+      const float bv = (bias_n && c < N) ? bias_n[c] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = m0 + wm + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (r < M && c < N) {
+          float v = acc[x][y][reg];
+          if (bias_n) v = v + bv;
+          if (act >= 0) v = epilogue_act(act, v);
+          C[(int64_t)r * ldc + c] = v;
+        }
+      }
+    }
 }
 
 // C = (C if accumulate) + part[0] + part[1] + ... in split order
 __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ parts, int splits,
                                                                 int64_t split_stride, int M, int N, int64_t ldp,
-                                                                float* __restrict__ C, int64_t ldc, int accumulate) {
+                                                                float* __restrict__ C, int64_t ldc, int accumulate,
+                                                                const float* __restrict__ bias_n, int act) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)M * N) return;
   const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
   float acc = accumulate ? C[(int64_t)m * ldc + n] : 0.f;
   for (int s = 0; s < splits; ++s) acc = acc + parts[(int64_t)s * split_stride + (int64_t)m * ldp + n];
+  if (bias_n) acc = acc + bias_n[n];
+  if (act >= 0) acc = epilogue_act(act, acc);
   C[(int64_t)m * ldc + n] = acc;
 }
 
@@ -123,42 +179,55 @@ int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes) {
   return NR_OK;
 }
 
-/* C[m][n] (+)= sum_k A[k][m] * B[k][n] (fp32 MFMA; see the file header).  splits > 1: the contraction is cut into
- * that many ranges computed side by side into d_ws (splits*M*N floats) and added in order. */
+/* C[m][n] (+)= sum_k A[k][m] * B[k][n] (fp32 MFMA; see the file header), then + d_bias_n[n] (NULL: none) and the
+ * activation `act` (-1 none, 0 tanh, 1 sigmoid, 2 relu, 3 identity).  splits > 1: the contraction is cut into that
+ * many ranges computed side by side into d_ws (splits*M*N floats) and added in order. */
 int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int M, int N, int K, float* d_C,
-                      int64_t ldc, int accumulate, int splits, void* d_ws, size_t ws_bytes, void* stream) {
-  NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= M && ldb >= N && ldc >= N && splits >= 1,
-             NR_ERR_ARG, "gemm_kmajor: bad arguments");
+                      int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits, void* d_ws,
+                      size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= M && ldb >= N && ldc >= N && splits >= 1 &&
+                 act >= -1 && act <= 3, NR_ERR_ARG, "gemm_kmajor: bad arguments");
   if (M == 0 || N == 0) return NR_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 0) {
-    if (!accumulate)
-      for (int m = 0; m < M; ++m) NR_CHECK_HIP(hipMemsetAsync(d_C + (int64_t)m * ldc, 0, sizeof(float) * N, st));
-    return NR_OK;
-  }
   dim3 block(256);
+  if (K == 0) splits = 1;                                    // an empty contraction: C (+)= 0, then bias / activation
+  // 128 x 128 block tiles when they fill the chip, 64 x 64 otherwise (more, smaller workgroups)
+  const bool big = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits >= 256;
+  const int tile = big ? 128 : 64;
+  const int tiles_m = (M + tile - 1) / tile, tiles_n = (N + tile - 1) / tile;
+  const unsigned blocks = (unsigned)(((int64_t)tiles_m * tiles_n + 7) / 8 * 8);
+#define NR_GEMM_LAUNCH(TILE, ACCF, grid_z, per, Cptr, ldC, stride, bias, actv)                                          \
+  hipLaunchKernelGGL((gemm_lds_kernel<TILE, ACCF>), dim3(blocks, 1, grid_z), block, 0, st, d_A, lda, d_B, ldb, M, N, \
+                     K, per, Cptr, ldC, stride, bias, actv, tiles_m, tiles_n)
   if (splits == 1) {
-    dim3 grid((N + 63) / 64, (M + 255) / 256, 1);
-    if (accumulate)
-      hipLaunchKernelGGL(gemm_kmajor_kernel<true>, grid, block, 0, st, d_A, lda, d_B, ldb, M, N, K, K, d_C, ldc,
-                         (int64_t)0);
-    else
-      hipLaunchKernelGGL(gemm_kmajor_kernel<false>, grid, block, 0, st, d_A, lda, d_B, ldb, M, N, K, K, d_C, ldc,
-                         (int64_t)0);
+    if (K == 0) {
+      // no k-steps: the kernel would return early; write the epilogue of a zero product through the reduce kernel
+      hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
+                         (const float*)d_C, 0, (int64_t)0, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
+      NR_LAUNCH_CHECK();
+      return NR_OK;
+    }
+    if (big) {
+      if (accumulate) NR_GEMM_LAUNCH(128, true, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
+      else NR_GEMM_LAUNCH(128, false, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
+    } else {
+      if (accumulate) NR_GEMM_LAUNCH(64, true, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
+      else NR_GEMM_LAUNCH(64, false, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
+    }
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
   NR_REQUIRE(d_ws && ws_bytes >= (size_t)splits * M * N * sizeof(float), NR_ERR_WORKSPACE,
              "gemm_kmajor: workspace too small for %d splits", splits);
   int per = (K + splits - 1) / splits;
-  per = (per + 2 * kPairs - 1) / (2 * kPairs) * (2 * kPairs);
+  per = (per + KT - 1) / KT * KT;
   const int used = (K + per - 1) / per;
-  dim3 grid((N + 63) / 64, (M + 255) / 256, used);
-  hipLaunchKernelGGL(gemm_kmajor_kernel<false>, grid, block, 0, st, d_A, lda, d_B, ldb, M, N, K, per, (float*)d_ws,
-                     (int64_t)N, (int64_t)M * N);
+  if (big) NR_GEMM_LAUNCH(128, false, used, per, (float*)d_ws, (int64_t)N, (int64_t)M * N, (const float*)nullptr, -1);
+  else NR_GEMM_LAUNCH(64, false, used, per, (float*)d_ws, (int64_t)N, (int64_t)M * N, (const float*)nullptr, -1);
   NR_LAUNCH_CHECK();
+#undef NR_GEMM_LAUNCH
   hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
-                     (const float*)d_ws, used, (int64_t)M * N, M, N, (int64_t)N, d_C, ldc, accumulate);
+                     (const float*)d_ws, used, (int64_t)M * N, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -5,7 +5,7 @@
 // matrix cores through gemm.hip.  Same arithmetic definitions as vae.hip / oracle.train.multivae_general:
 //   first encoder layer   a = bag-sum over the user's train items of (1/sqrt(n_u) / keep * mask) * W_q0[item]  (+ b)
 //                         — the multi-hot row is never densified (the reference fills [B][I] on the host: :152-165)
-//   dense layers          y = act(x W + b), k-ascending fmaf chain per output
+//   dense layers          y = act(x W + b), k-ascending fmaf chain per output (gemm.hip, bias + activation epilogue)
 //   sampling              z = mu + is_training * eps * exp(logvar / 2); KL_b = 1/2 sum(-logvar + exp(logvar) + mu^2 - 1)
 //   decoder loss          nll_b = -sum_{i in items(b)} log_softmax(logits_b)_i;  dlogits = (softmax * n_b - x) / B
 #include "nr_common.h"
@@ -30,63 +30,55 @@ __device__ __forceinline__ float uniform01(uint64_t h) {
   return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);
 }
 
-// first encoder layer from the CSR row: one wave per batch row, lanes over 64-column chunks of the output
+// first encoder layer from the CSR row: one wave per (batch row, 64-column chunk of the output), a block = 4
+// neighbouring chunks of one row; the row's (item, value) pairs are dealt 64 at a time and walked 8 gathers at a time
 __global__ __launch_bounds__(256) void vae_bag_fwd_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const int32_t* __restrict__ rows,
     int batch, int width, const float* __restrict__ W, const float* __restrict__ bias, int act, float keep,
     const float* __restrict__ drop_given, uint64_t seed, uint64_t step, float* __restrict__ h0val,
     float* __restrict__ Y) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= batch) return;
+  const int r = blockIdx.y;
+  const int c0 = (blockIdx.x * 4 + wave) * NR_WAVE;
+  if (c0 >= width) return;
+  const int c = c0 + lane, cc = min(c, width - 1);
   const int64_t u = rows[r];
   const int64_t b = indptr[u], e = indptr[u + 1];
   const int n = (int)(e - b);
   const float inv = 1.0f / sqrtf(fmaxf((float)n, 1e-12f));      // l2_normalize of a 0/1 row
   const uint64_t drop_key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull));
-  // the row's (item, value) pairs, 64 at a time; values written out for the backward pass once
-  for (int c0 = 0; c0 < width; c0 += NR_WAVE) {
-    const int c = c0 + lane;
-    float acc = 0.f;
-    for (int64_t t0 = b; t0 < e; t0 += NR_WAVE) {
-      const int nn = (int)min((int64_t)NR_WAVE, e - t0);
-      int my_item = 0;
-      float my_val = 0.f;
-      if (lane < nn) {
-        const int64_t t = t0 + lane;
-        float kp;
-        if (drop_given) kp = drop_given[t];
-        else kp = (keep >= 1.0f || uniform01(nr::splitmix64(drop_key ^ (uint64_t)t)) < keep) ? 1.f : 0.f;
-        my_val = (inv / keep) * kp;                         // x / keep_prob * mask (tf.nn.dropout)
-        my_item = indices[t];
-        if (c0 == 0 && h0val) h0val[t] = my_val;
-      }
-      for (int s = 0; s < nn; ++s) {                        // ascending item order
-        const int item = __shfl(my_item, s, NR_WAVE);
-        const float v = __shfl(my_val, s, NR_WAVE);
-        const float w = W[(int64_t)item * width + min(c, width - 1)];
-        acc = fmaf(v, w, acc);
-      }
+  float acc = 0.f;
+  for (int64_t t0 = b; t0 < e; t0 += NR_WAVE) {
+    const int nn = (int)min((int64_t)NR_WAVE, e - t0);
+    int my_item = 0;
+    float my_val = 0.f;                                      // lanes past the row: exact no-ops below (acc + 0 * w)
+    if (lane < nn) {
+      const int64_t t = t0 + lane;
+      float kp;
+      if (drop_given) kp = drop_given[t];
+      else kp = (keep >= 1.0f || uniform01(nr::splitmix64(drop_key ^ (uint64_t)t)) < keep) ? 1.f : 0.f;
+      my_val = (inv / keep) * kp;                           // x / keep_prob * mask (tf.nn.dropout)
+      my_item = indices[t];
+      if (c0 == 0 && h0val) h0val[t] = my_val;
     }
-    if (c < width) {
-      acc = acc + bias[c];
-      Y[(int64_t)r * width + c] = act >= 0 ? act_fwd(act, acc) : acc;
+    for (int s0 = 0; s0 < nn; s0 += 8) {                    // ascending item order, 8 row gathers in flight
+      float w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int item = __shfl(my_item, min(s0 + q, nn - 1), NR_WAVE);
+        w[q] = W[(int64_t)item * width + cc];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v = __shfl(my_val, (s0 + q) & 63, NR_WAVE);
+        acc = fmaf(v, w[q], acc);
+      }
     }
   }
-}
-
-// Y[b][j] = act(sum_k X[b][k] W[k][j] + bias[j]); one thread per output
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ X, int64_t ldx,
-                                                        const float* __restrict__ W, const float* __restrict__ bias,
-                                                        int batch, int K, int N, int act, float* __restrict__ Y,
-                                                        int64_t ldy) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= (int64_t)batch * N) return;
-  const int b = (int)(o / N), j = (int)(o - (int64_t)b * N);
-  float acc = 0.f;
-  for (int k = 0; k < K; ++k) acc = fmaf(X[(int64_t)b * ldx + k], W[(int64_t)k * N + j], acc);
-  acc = acc + bias[j];
-  Y[(int64_t)b * ldy + j] = act >= 0 ? act_fwd(act, acc) : acc;
+  if (c < width) {
+    acc = acc + bias[c];
+    Y[(int64_t)r * width + c] = act >= 0 ? act_fwd(act, acc) : acc;
+  }
 }
 
 // dA[b][j] = dY[b][j] * act'(Y[b][j])
@@ -94,37 +86,6 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       int64_t n, int act, float* __restrict__ dA) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dA[i] = dY[i] * act_bwd(act, Y[i]);
-}
-
-// dX[b][k] = sum_j dA[b][j] W[k][j]
-__global__ __launch_bounds__(256) void dense_bwd_data_kernel(const float* __restrict__ dA, int64_t lda,
-                                                             const float* __restrict__ W, int batch, int K, int N,
-                                                             float* __restrict__ dX, int64_t ldx) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= (int64_t)batch * K) return;
-  const int b = (int)(o / K), k = (int)(o - (int64_t)b * K);
-  float acc = 0.f;
-  for (int j = 0; j < N; ++j) acc = fmaf(dA[(int64_t)b * lda + j], W[(int64_t)k * N + j], acc);
-  dX[(int64_t)b * ldx + k] = acc;
-}
-
-// dW[k][j] = sum_b X[b][k] dA[b][j] (b ascending); db[j] = sum_b dA[b][j]   (outputs K*N + N)
-__global__ __launch_bounds__(256) void dense_bwd_weight_kernel(const float* __restrict__ X, int64_t ldx,
-                                                               const float* __restrict__ dA, int64_t lda, int batch,
-                                                               int K, int N, float* __restrict__ dW,
-                                                               float* __restrict__ db) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= (int64_t)K * N + N) return;
-  float acc = 0.f;
-  if (o < (int64_t)K * N) {
-    const int k = (int)(o / N), j = (int)(o - (int64_t)k * N);
-    for (int b = 0; b < batch; ++b) acc = fmaf(X[(int64_t)b * ldx + k], dA[(int64_t)b * lda + j], acc);
-    dW[o] = acc;
-  } else {
-    const int j = (int)(o - (int64_t)K * N);
-    for (int b = 0; b < batch; ++b) acc = acc + dA[(int64_t)b * lda + j];
-    db[j] = acc;
-  }
 }
 
 // H2 [B][2z] = [mu | logvar]  ->  ZS, EPSSTD, KLb
@@ -170,44 +131,45 @@ __global__ __launch_bounds__(256) void vae_sample_bwd_kernel(const float* __rest
 }
 
 // one workgroup per batch row: log-sum-exp, nll of the row's items, then dLoss/dlogits in place
-__global__ __launch_bounds__(256) void vae_softmax_dlogits_kernel(float* __restrict__ S, int64_t ld, int cols,
+__global__ __launch_bounds__(1024) void vae_softmax_dlogits_kernel(float* __restrict__ S, int64_t ld, int cols,
                                                                   const int64_t* __restrict__ indptr,
                                                                   const int32_t* __restrict__ indices,
                                                                   const int32_t* __restrict__ rows, int batch,
                                                                   float* __restrict__ nll) {
-  __shared__ float s_red[256];
+  __shared__ float s_red[1024];
   const int r = blockIdx.x, tid = threadIdx.x;
   float* row = S + (int64_t)r * ld;
   float mx = -INFINITY;
-  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, row[i]);
+  for (int i = tid; i < cols; i += 1024) mx = fmaxf(mx, row[i]);
   s_red[tid] = mx;
   __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] = fmaxf(s_red[tid], s_red[tid + s]); __syncthreads(); }
+  for (int s = 512; s >= 1; s >>= 1) { if (tid < s) s_red[tid] = fmaxf(s_red[tid], s_red[tid + s]); __syncthreads(); }
   mx = s_red[0];
   __syncthreads();
   float sum = 0.f;
-  for (int i = tid; i < cols; i += 256) sum += expf(row[i] - mx);
+  for (int i = tid; i < cols; i += 1024) sum += expf(row[i] - mx);
   s_red[tid] = sum;
   __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  for (int s = 512; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
   const float lse = mx + logf(s_red[0]);
   __syncthreads();
   const int64_t u = rows[r];
   const int64_t b = indptr[u], e = indptr[u + 1];
   float ll = 0.f;
-  for (int64_t t = b + tid; t < e; t += 256) ll += row[indices[t]] - lse;
+  for (int64_t t = b + tid; t < e; t += 1024) ll += row[indices[t]] - lse;
   s_red[tid] = ll;
   __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  for (int s = 512; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
   if (tid == 0) nll[r] = -s_red[0];
   __syncthreads();
   const float nb = (float)(e - b), invB = 1.0f / (float)batch;
-  for (int i = tid; i < cols; i += 256) row[i] = expf(row[i] - lse) * nb * invB;
+  for (int i = tid; i < cols; i += 1024) row[i] = expf(row[i] - lse) * nb * invB;
   __syncthreads();
-  for (int64_t t = b + tid; t < e; t += 256) row[indices[t]] -= invB;       // distinct items: no conflict
+  for (int64_t t = b + tid; t < e; t += 1024) row[indices[t]] -= invB;       // distinct items: no conflict
 }
 
-// dW_q0[item][:] += h0val * dA1[b][:] over the batch's CSR entries (fp32 atomics, as vae.hip's scatter)
+// dW_q0[item][:] += h0val * dA1[b][:] over the batch's CSR entries (fp32 atomics, as vae.hip's scatter); one wave per
+// (batch row, 64-column chunk): the atomics of one item row are 256-byte segments, fire-and-forget
 __global__ __launch_bounds__(256) void vae_dwq0_wide_kernel(const int64_t* __restrict__ indptr,
                                                             const int32_t* __restrict__ indices,
                                                             const int32_t* __restrict__ rows, int batch, int width,
@@ -215,19 +177,13 @@ __global__ __launch_bounds__(256) void vae_dwq0_wide_kernel(const int64_t* __res
                                                             const float* __restrict__ DA1,
                                                             float* __restrict__ dWq0) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= batch) return;
+  const int r = blockIdx.y;
+  const int c = (blockIdx.x * 4 + wave) * NR_WAVE + lane;
+  if (c >= width) return;
   const int64_t u = rows[r];
   const int64_t b = indptr[u], e = indptr[u + 1];
-  for (int c0 = 0; c0 < width; c0 += NR_WAVE) {
-    const int c = c0 + lane;
-    const float g = c < width ? DA1[(int64_t)r * width + c] : 0.f;
-    for (int64_t t = b; t < e; ++t) {
-      const int item = indices[t];
-      const float val = h0val[t];
-      if (c < width) atomicAdd(&dWq0[(int64_t)item * width + c], val * g);
-    }
-  }
+  const float g = DA1[(int64_t)r * width + c];
+  for (int64_t t = b; t < e; ++t) atomicAdd(&dWq0[(int64_t)indices[t] * width + c], h0val[t] * g);
 }
 
 }  // namespace
@@ -241,19 +197,8 @@ int nrhip_vae_bag_fwd(const int64_t* d_indptr, const int32_t* d_indices, const i
   NR_REQUIRE(d_indptr && d_indices && d_rows && d_W && d_bias && d_Y && batch >= 0 && width >= 1 && act >= -1 &&
                  act <= 3 && keep > 0.f && keep <= 1.f, NR_ERR_ARG, "vae_bag_fwd: bad arguments");
   if (batch == 0) return NR_OK;
-  hipLaunchKernelGGL(vae_bag_fwd_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_indptr,
+  hipLaunchKernelGGL(vae_bag_fwd_kernel, dim3((width + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, d_indptr,
                      d_indices, d_rows, batch, width, d_W, d_bias, act, keep, d_drop_given, seed, step, d_h0val, d_Y);
-  NR_LAUNCH_CHECK();
-  return NR_OK;
-}
-
-int nrhip_dense_fwd(const float* d_X, int64_t ldx, const float* d_W, const float* d_bias, int batch, int K, int N,
-                    int act, float* d_Y, int64_t ldy, void* stream) {
-  NR_REQUIRE(d_X && d_W && d_bias && d_Y && batch >= 0 && K >= 1 && N >= 1 && ldx >= K && ldy >= N && act >= -1 &&
-                 act <= 3, NR_ERR_ARG, "dense_fwd: bad arguments");
-  if (batch == 0) return NR_OK;
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3((unsigned)(((int64_t)batch * N + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, d_X, ldx, d_W, d_bias, batch, K, N, act, d_Y, ldy);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -263,23 +208,6 @@ int nrhip_act_bwd(const float* d_dY, const float* d_Y, int64_t n, int act, float
   if (n == 0) return NR_OK;
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_dY, d_Y,
                      n, act, d_dA);
-  NR_LAUNCH_CHECK();
-  return NR_OK;
-}
-
-/* d_dX (optional) = dA W^T; d_dW = X^T dA (batch order); d_db = column sums of dA */
-int nrhip_dense_bwd(const float* d_dA, int64_t lda, const float* d_X, int64_t ldx, const float* d_W, int batch,
-                    int K, int N, float* d_dX, int64_t lddx, float* d_dW, float* d_db, void* stream) {
-  NR_REQUIRE(d_dA && d_X && d_W && d_dW && d_db && batch >= 0 && K >= 1 && N >= 1 && lda >= N && ldx >= K,
-             NR_ERR_ARG, "dense_bwd: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  if (d_dX && batch > 0) {
-    NR_REQUIRE(lddx >= K, NR_ERR_ARG, "dense_bwd: lddx");
-    hipLaunchKernelGGL(dense_bwd_data_kernel, dim3((unsigned)(((int64_t)batch * K + 255) / 256)), dim3(256), 0, st,
-                       d_dA, lda, d_W, batch, K, N, d_dX, lddx);
-  }
-  hipLaunchKernelGGL(dense_bwd_weight_kernel, dim3((unsigned)(((int64_t)K * N + N + 255) / 256)), dim3(256), 0, st,
-                     d_X, ldx, d_dA, lda, batch, K, N, d_dW, d_db);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -310,7 +238,7 @@ int nrhip_vae_softmax_dlogits(float* d_S, int64_t ld, int batch, int cols, const
   NR_REQUIRE(d_S && d_indptr && d_indices && d_rows && d_nll && batch >= 0 && cols >= 1 && ld >= cols, NR_ERR_ARG,
              "vae_softmax_dlogits: bad arguments");
   if (batch == 0) return NR_OK;
-  hipLaunchKernelGGL(vae_softmax_dlogits_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, d_S, ld, cols,
+  hipLaunchKernelGGL(vae_softmax_dlogits_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, d_S, ld, cols,
                      d_indptr, d_indices, d_rows, batch, d_nll);
   NR_LAUNCH_CHECK();
   return NR_OK;
@@ -321,7 +249,7 @@ int nrhip_vae_dwq0_wide(const int64_t* d_indptr, const int32_t* d_indices, const
   NR_REQUIRE(d_indptr && d_indices && d_rows && d_h0val && d_DA1 && d_dWq0 && batch >= 0 && width >= 1, NR_ERR_ARG,
              "vae_dwq0_wide: bad arguments");
   if (batch == 0) return NR_OK;
-  hipLaunchKernelGGL(vae_dwq0_wide_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_indptr,
+  hipLaunchKernelGGL(vae_dwq0_wide_kernel, dim3((width + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, d_indptr,
                      d_indices, d_rows, batch, width, d_h0val, d_DA1, d_dWq0);
   NR_LAUNCH_CHECK();
   return NR_OK;
@@ -330,20 +258,29 @@ int nrhip_vae_dwq0_wide(const int64_t* d_indptr, const int32_t* d_indices, const
 }  // extern "C"
 
 namespace {
-// out[c] = sum_r X[r][c], r ascending
-__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ X, int64_t ld, int rows, int cols,
-                                                          float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+// out[c] = sum_r X[r][c]: a block = 64 columns x 16 row groups; group g adds rows g, g + 16, ... in order, then the 16
+// partial sums are added in group order (a fixed association: deterministic)
+__global__ __launch_bounds__(1024) void colsum_rows_kernel(const float* __restrict__ X, int64_t ld, int rows, int cols,
+                                                           float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, cc = min(c, cols - 1);
   float acc = 0.f;
-  for (int r = 0; r < rows; ++r) acc = acc + X[(int64_t)r * ld + c];
-  out[c] = acc;
+  for (int r = g; r < rows; r += 16) acc = acc + X[(int64_t)r * ld + cc];
+  part[g][lane] = acc;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    float t = part[0][lane];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t = t + part[q][lane];
+    out[c] = t;
+  }
 }
 }  // namespace
 
 extern "C" int nrhip_colsum_rows(const float* d_X, int64_t ld, int rows, int cols, float* d_out, void* stream) {
   NR_REQUIRE(d_X && d_out && rows >= 0 && cols >= 1 && ld >= cols, NR_ERR_ARG, "colsum_rows: bad arguments");
-  hipLaunchKernelGGL(colsum_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_X, ld, rows,
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, d_X, ld, rows,
                      cols, d_out);
   NR_LAUNCH_CHECK();
   return NR_OK;

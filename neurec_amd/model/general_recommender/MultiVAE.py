@@ -16,8 +16,10 @@ What is NOT mirrored by default:
     interactions leak into every score.  Here each user is scored on their own history (the model
     that was trained).  `--reference_predict_rows=True` (or `predict_accumulates_rows = True`) is
     the explicit compatibility switch that reproduces the reference's rows; it is logged when on.
-Restriction: the kernels are built for the two-layer shape p_dim=[z, h] with h <= 32, z <= 16
-(the configured [16, 32]); other shapes raise NotImplementedError.
+Shapes: p_dim may have any number of layers and any widths (conf/MultiVAE.properties:3 lists [200, 600] and
+[200] next to the shipped [16, 32]).  The shipped two-layer shape with z <= 16, h <= 32 runs on the register-resident
+kernels (trainer.MultiVAEEngine); every other shape on the width-generic kernels + the fp32-MFMA GEMM
+(vae_wide.MultiVAEWideEngine), whose evaluation goes through predict()'s logits slab.
 """
 from time import time
 
@@ -68,30 +70,44 @@ class MultiVAE(AbstractRecommender):
     def build_graph(self):
         from ... import engine as E
         from ...trainer import MultiVAEEngine
-        if len(self.p_dims) != 3:
-            raise NotImplementedError("the HIP Mult-VAE engine implements p_dim=[z, h] (two layers)")
         if str(self.learner).lower() != "adam":
             raise NotImplementedError("the HIP Mult-VAE engine implements learner=adam")
         if self.act not in E.VAE_ACTS:
             raise NotImplementedError("activation %r is not built (tanh/sigmoid/relu/identity)" % self.act)
-        z, h, n = self.p_dims
-        if not (1 <= z <= 16 and 1 <= h <= 32):
-            raise NotImplementedError("the HIP Mult-VAE kernels are built for p_dim=[z <= 16, h <= 32] "
-                                      "(conf/MultiVAE.properties ships [16, 32]); got [%d, %d]" % (z, h))
         w_init = get_initializer(self.weight_init_method, self.stddev, seed=2017)
         b_init = get_initializer(self.bias_init_method, self.stddev, seed=2018)
-        params = {
-            "Wq0": w_init([n, h]), "bq0": b_init([h]),
-            "Wq1": w_init([h, 2 * z]), "bq1": b_init([2 * z]),
-            "Wp0": w_init([z, h]), "bp0": b_init([h]),
-            # TF variable weight_p_1to2 is [h, n]; the engine keeps it item-major
-            "Wp1t": np.ascontiguousarray(w_init([h, n]).T), "bp1": b_init([n]),
-        }
         train = self.dataset.train_matrix.tocsr().astype(np.float32)
         train.sort_indices()
         self._train_csr = train
-        self.engine = MultiVAEEngine(E.DeviceCSR.from_scipy(train), n, params, self.learning_rate,
-                                     self.reg, self.act, max(self.batch_size, 1))
+        n = self.num_items
+        narrow = len(self.p_dims) == 3 and 1 <= self.p_dims[0] <= 16 and 1 <= self.p_dims[1] <= 32
+        if narrow:
+            z, h, _ = self.p_dims
+            params = {
+                "Wq0": w_init([n, h]), "bq0": b_init([h]),
+                "Wq1": w_init([h, 2 * z]), "bq1": b_init([2 * z]),
+                "Wp0": w_init([z, h]), "bp0": b_init([h]),
+                # TF variable weight_p_1to2 is [h, n]; the engine keeps it item-major
+                "Wp1t": np.ascontiguousarray(w_init([h, n]).T), "bp1": b_init([n]),
+            }
+            self.engine = MultiVAEEngine(E.DeviceCSR.from_scipy(train), n, params, self.learning_rate,
+                                         self.reg, self.act, max(self.batch_size, 1))
+            return
+        # any other p_dim: the variables in the order the reference creates them (MultiVAE.py:46-71: all of q, then p)
+        from ...vae_wide import MultiVAEWideEngine
+        Wq, bq, Wp, bp = [], [], [], []
+        for i, (d_in, d_out) in enumerate(zip(self.q_dims[:-1], self.q_dims[1:])):
+            if i == len(self.q_dims[:-1]) - 1:
+                d_out *= 2                                     # mean and log-variance (MultiVAE.py:50-52)
+            Wq.append(w_init([d_in, d_out]))
+            bq.append(b_init([d_out]))
+        for d_in, d_out in zip(self.p_dims[:-1], self.p_dims[1:]):
+            Wp.append(w_init([d_in, d_out]))
+            bp.append(b_init([d_out]))
+        self.engine = MultiVAEWideEngine(E.DeviceCSR.from_scipy(train), n, Wq, bq, Wp, bp, self.learning_rate,
+                                         self.reg, self.act, max(self.batch_size, 1))
+        self.logger.info("p_dim=%s runs on the width-generic Mult-VAE engine (fp32 matrix-core GEMMs for the item layer)"
+                         % (list(self.p_dims[:-1]),))
 
     # ------------------------------------------------------------------ training
     def train_model(self):
@@ -137,7 +153,7 @@ class MultiVAE(AbstractRecommender):
         products are predict()'s logits bit for bit) — only with per-user inputs; the reference's
         accumulating predict rows depend on how the test users are batched, so that mode returns None and
         is scored through predict()."""
-        if self.predict_accumulates_rows:
+        if self.predict_accumulates_rows or not hasattr(self.engine, "eval_factors"):
             return None
         return self.engine.eval_factors()
 

@@ -63,18 +63,39 @@ class MultiVAEWideEngine:
         self.gT = z(self.h_last, B)                                 # feature-major copy of the last hidden layer
         self.DT = z(I, B)                                           # D^T and W_last^T for d g = D W_last^T
         self.WT = z(I, self.h_last)
-        self.splits = 16
+        self.splits = 16                                            # of the 40,981-long contraction of d g
+        mids = self.Wq[1:] + self.Wp[:-1]                            # the layers that are plain dense products
+        wmax = max([self.h_last] + [max(w.shape) for w in mids])
+        self.tX, self.tD = z(wmax, B), z(wmax, B)                   # feature-major copies of a layer's x and dLoss/dy
+        self.tW = z(max([1] + [w.numel() for w in mids]))           # W^T of the layer being differentiated
+        self.mid_splits = 4                                         # contraction cuts of the small products
         nbytes = E.C.c_size_t(0)
-        call("nrhip_gemm_workspace_bytes", B, self.h_last, self.splits, E.C.byref(nbytes))
+        call("nrhip_gemm_workspace_bytes", max(B, wmax), wmax, max(self.splits, self.mid_splits), E.C.byref(nbytes))
         self.ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
         self.stats = z(2)
         self.regsum = torch.zeros(1, dtype=torch.float64, device=dev)
         self.last_anneal = 0.0
 
     # ------------------------------------------------------------------ pieces
-    def _gemm(self, A, lda, Bm, ldb, M, N, K, Cm, ldc, splits=1):
+    def _gemm(self, A, lda, Bm, ldb, M, N, K, Cm, ldc, splits=1, bias=None, act=-1):
         call("nrhip_gemm_kmajor", _ptr(A), int(lda), _ptr(Bm), int(ldb), int(M), int(N), int(K), _ptr(Cm), int(ldc), 0,
-             int(splits), _ptr(self.ws), self.ws.numel() if splits > 1 else 0, _stream())
+             _ptr(bias, torch.float32, allow_none=True), int(act), int(splits), _ptr(self.ws),
+             self.ws.numel() if splits > 1 else 0, _stream())
+
+    def _dense_fwd(self, X, W, b, B, act, Y):
+        """Y[:B] = act(X[:B] W + b): A = X^T (feature-major), B = the TF variable as it is."""
+        K, N = W.shape
+        self._transpose(X, K, B, K, self.tX, self.B)
+        self._gemm(self.tX, self.B, W, N, B, N, K, Y, N, bias=b, act=act)
+
+    def _dense_bwd(self, dA, X, W, B, dX, dW, db):
+        """dX = dA W^T (both operands transposed first), dW = X^T dA (both k-major as stored), db = column sums."""
+        K, N = W.shape
+        self._gemm(X, K, dA, N, K, N, B, dW, N, splits=self.mid_splits if B >= 256 else 1)
+        call("nrhip_colsum_rows", _ptr(dA), N, B, N, _ptr(db), _stream())
+        self._transpose(dA, N, B, N, self.tD, self.B)
+        self._transpose(W, N, K, N, self.tW, K)
+        self._gemm(self.tD, self.B, self.tW, K, B, K, N, dX, K)
 
     def _transpose(self, src, ld_src, rows, cols, dst, ld_dst):
         call("nrhip_transpose2d", _ptr(src), int(ld_src), int(rows), int(cols), _ptr(dst), int(ld_dst), _stream())
@@ -87,21 +108,16 @@ class MultiVAEWideEngine:
              _ptr(drop_given, torch.float32, allow_none=True), self.seed, self.t,
              _ptr(self.h0val) if csr is self.csr else None, _ptr(self.Hq[0]), _stream())
         for i in range(1, n):
-            K, N = self.Wq[i].shape
-            call("nrhip_dense_fwd", _ptr(self.Hq[i - 1]), K, _ptr(self.Wq[i]), _ptr(self.bq[i]), B, K, N,
-                 _act_id(self.act, i == n - 1), _ptr(self.Hq[i]), N, _stream())
+            self._dense_fwd(self.Hq[i - 1], self.Wq[i], self.bq[i], B, _act_id(self.act, i == n - 1), self.Hq[i])
         call("nrhip_vae_sample", _ptr(self.Hq[-1]), B, self.z, _ptr(eps_given, torch.float32, allow_none=True),
              float(is_training), self.seed, self.t, _ptr(self.EPSSTD), _ptr(self.ZS), _ptr(self.KLb), _stream())
         g = self.ZS
         for i in range(n - 1):
-            K, N = self.Wp[i].shape
-            call("nrhip_dense_fwd", _ptr(g), K, _ptr(self.Wp[i]), _ptr(self.bp[i]), B, K, N, E.VAE_ACTS[self.act],
-                 _ptr(self.Gp[i]), N, _stream())
+            self._dense_fwd(g, self.Wp[i], self.bp[i], B, E.VAE_ACTS[self.act], self.Gp[i])
             g = self.Gp[i]
         h, I = self.h_last, self.n_items
         self._transpose(g, h, B, h, self.gT, self.B)                                      # g^T [h][B]
-        self._gemm(self.gT, self.B, self.Wp[-1], I, B, I, h, S, S.stride(0))              # logits on the matrix cores
-        E.add_row_bias(S[:B], I, self.bp[-1])
+        self._gemm(self.gT, self.B, self.Wp[-1], I, B, I, h, S, S.stride(0), bias=self.bp[-1])   # logits + bias
         return g
 
     def logits(self, rows, csr=None, out=None):
@@ -142,16 +158,14 @@ class MultiVAEWideEngine:
             call("nrhip_act_bwd", _ptr(dg), _ptr(self.Gp[i]), B * N, E.VAE_ACTS[self.act], _ptr(dg), _stream())
             x = self.Gp[i - 1] if i > 0 else self.ZS
             dx = self.dGp[i - 1] if i > 0 else self.dZ
-            call("nrhip_dense_bwd", _ptr(dg), N, _ptr(x), K, _ptr(self.Wp[i]), B, K, N, _ptr(dx), K,
-                 _ptr(self.G[iWp + i]), _ptr(self.G[ibp + i]), _stream())
+            self._dense_bwd(dg, x, self.Wp[i], B, dx, self.G[iWp + i], self.G[ibp + i])
             dg = dx
         call("nrhip_vae_sample_bwd", _ptr(self.dZ), _ptr(self.Hq[-1]), _ptr(self.EPSSTD), B, self.z, float(anneal),
              _ptr(self.dHq[-1]), _stream())
         d = self.dHq[-1]
         for i in range(n - 1, 0, -1):
             K, N = self.Wq[i].shape
-            call("nrhip_dense_bwd", _ptr(d), N, _ptr(self.Hq[i - 1]), K, _ptr(self.Wq[i]), B, K, N,
-                 _ptr(self.dHq[i - 1]), K, _ptr(self.G[iWq + i]), _ptr(self.G[ibq + i]), _stream())
+            self._dense_bwd(d, self.Hq[i - 1], self.Wq[i], B, self.dHq[i - 1], self.G[iWq + i], self.G[ibq + i])
             d = self.dHq[i - 1]
             call("nrhip_act_bwd", _ptr(d), _ptr(self.Hq[i - 1]), B * K, E.VAE_ACTS[self.act], _ptr(d), _stream())
         w0 = self.Wq[0].shape[1]

@@ -15,3 +15,9 @@ for k in ("ngcf","multivae","config4"):
     v = d.get(k)
     if v: print(k, "ms/step", v["ms_per_step"], "roofline frac", v["roofline"]["frac"], "us", v["roofline"]["us_per_launch"], "cpu", (v.get("cpu_baseline") or {}).get("value"), v.get("setup_seconds"))
 PY
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r03/$tag.json"))
+w=(d.get("multivae") or {}).get("wide")
+if w: print("multivae wide", w["p_dim"], "ms/step", w["ms_per_step"], "item layer us", w["roofline"]["us_per_step"], "TFLOP/s", w["roofline"]["achieved"], "frac", w["roofline"]["frac"])
+PY

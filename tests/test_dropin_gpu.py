@@ -204,6 +204,35 @@ def test_multivae_config_drops_in(tmp_path):
     assert model.get_eval_factors() is None                  # the accumulating rows have no factor form
 
 
+@pytest.mark.parametrize("p_dim", ["[200,600]", "[40]", "[8,24,48]"])
+def test_multivae_any_p_dim_drops_in(tmp_path, p_dim):
+    """conf/MultiVAE.properties:3's alternatives (p_dim = [200, 600], [200], ...) run through the same plugin on the
+    width-generic engine: log lines, loss falls, predict() equals the oracle's forward of the trained weights."""
+    from oracle import train
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=MultiVAE", "--epochs=30", "--batch_size=32", "--learning_rate=0.003",
+                            "--verbose=15", "--total_anneal_steps=50", "--p_dim=" + p_dim])
+    text = _log_text(tmp_path, "MultiVAE")
+    assert "width-generic Mult-VAE engine" in text
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 30 and float(iters[-1][1]) < float(iters[0][1])
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == [15, 30]
+    assert float(evals[-1][1].split()[5]) > 0.15
+    eng = model.engine
+    f = lambda ts: [t.cpu().numpy().astype(np.float64) for t in ts]
+    users = [5, 17, 3, 44]
+    X = np.asarray(model.dataset.train_matrix.tocsr()[users].todense(), dtype=np.float64)
+    _, _, _, want = train.multivae_general(X, f(eng.Wq), f(eng.bq), f(eng.Wp), f(eng.bp), np.ones_like(X), 1.0,
+                                           np.zeros((len(users), eng.z)), 0.0, 0.0, "tanh", is_training=0.0,
+                                           want_grads=False)
+    got = model.predict(users, None).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-5
+    cand = model.predict(users, [[1, 2, 3]] * 4)
+    assert np.allclose(cand[2], got[2][[1, 2, 3]])
+
+
 def test_mf_pointwise_and_other_learners_drop_in(tmp_path):
     """conf/MF.properties with is_pairwise=False (PointwiseSampler, sigmoid cross-entropy) and a
     non-Adam learner: runs end to end, loss falls, evaluation line printed."""

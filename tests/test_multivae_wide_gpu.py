@@ -151,7 +151,7 @@ def test_gemm_kmajor_is_the_k_ascending_fmaf_chain(M, N, K, splits):
     nbytes = C.c_size_t(0)
     call("nrhip_gemm_workspace_bytes", M, N, splits, C.byref(nbytes))
     ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device="cuda")
-    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N + 3, 0, splits, _ptr(ws),
+    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N + 3, 0, None, -1, splits, _ptr(ws),
          ws.numel() if splits > 1 else 0, _stream())
     got = out.cpu().numpy()
     assert (got[:, N:] == 7.0).all()
@@ -162,10 +162,35 @@ def test_gemm_kmajor_is_the_k_ascending_fmaf_chain(M, N, K, splits):
         assert np.array_equal(got[:, :N], want)
     assert np.abs(got[:, :N] - want64).max() <= 2e-6 * np.sqrt(K) * max(1.0, np.abs(want64).max())
     # accumulate: C += A^T B continues the chain from C
-    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N + 3, 1, splits, _ptr(ws),
+    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N + 3, 1, None, -1, splits, _ptr(ws),
          ws.numel() if splits > 1 else 0, _stream())
     assert np.abs(out.cpu().numpy()[:, :N] - 2 * want64).max() <= 4e-6 * np.sqrt(K) * max(1.0, np.abs(want64).max())
     # transpose
     T = torch.zeros((N, K + 1), dtype=torch.float32, device="cuda")
     call("nrhip_transpose2d", _ptr(dB), N, K, N, _ptr(T), K + 1, _stream())
     assert np.array_equal(T.cpu().numpy()[:, :K], Bm.T)
+
+
+@pytest.mark.parametrize("M,N,K,splits,act", [(96, 130, 50, 1, 2), (300, 700, 129, 4, 0), (512, 40981, 40, 1, -1)])
+def test_gemm_epilogue_is_bias_then_activation(M, N, K, splits, act):
+    """a dense layer y = act(x W + b) as one call (MultiVAE.py:79-84,124-129: tf.matmul + bias, then the activation)"""
+    import ctypes as C
+    import torch
+    from neurec_amd._lib import call
+    from neurec_amd.engine import _ptr, _stream
+    from oracle import native
+    rng = np.random.RandomState(M + N + K)
+    A, Bm, bias = rng.randn(K, M).astype(np.float32), rng.randn(K, N).astype(np.float32), rng.randn(N).astype(np.float32)
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    nbytes = C.c_size_t(0)
+    call("nrhip_gemm_workspace_bytes", M, N, splits, C.byref(nbytes))
+    ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device="cuda")
+    call("nrhip_gemm_kmajor", _ptr(_dev(A)), M, _ptr(_dev(Bm)), N, M, N, K, _ptr(out), N, 0, _ptr(_dev(bias)), act,
+         splits, _ptr(ws), ws.numel() if splits > 1 else 0, _stream())
+    pre = native.score_gemm(np.ascontiguousarray(A.T), None, np.ascontiguousarray(Bm.T)) + bias[None, :]
+    want = {2: np.maximum(pre, 0), 0: np.tanh(pre.astype(np.float64)), -1: pre}[act]
+    got = out.cpu().numpy()
+    if splits == 1 and act != 0:
+        assert np.array_equal(got, want)                     # the fmaf chain, one rounded add of the bias, max(., 0)
+    else:
+        assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K)
