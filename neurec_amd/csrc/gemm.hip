@@ -37,7 +37,7 @@ __device__ __forceinline__ float epilogue_act(int a, float x) {
 // The linear block id is dealt to the 8 XCDs so that the tiles_m blocks sharing one n-tile of B run on the SAME XCD
 // (one L2 fetch of that B tile serves all of them).
 template <int TILE, bool ACC>
-__global__ __launch_bounds__(256) void gemm_lds_kernel(
+__global__ __launch_bounds__(256, 3) void gemm_lds_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int M, int N, int K,
     int k_per_split, float* __restrict__ C, int64_t ldc, int64_t split_stride, const float* __restrict__ bias_n,
     int act, int tiles_m, int tiles_n) {
@@ -73,33 +73,53 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(
   if (kb >= ke) return;                                   // an empty split (never launched; kept for safety)
 
   // this thread's slots of an operand tile: element e = tid + 256 i -> row e / TILE, column e % TILE
-  const int col = tid % TILE, row0 = tid / TILE;           // rows row0 + (256 / TILE) i
-  const int64_t ca = min(m0 + col, M - 1), cb = min(n0 + col, N - 1);   // clamped: what lies outside is never stored
-  float ra[PER], rb[PER];
-  auto gload = [&](int k0) {
+  constexpr int RS = 256 / TILE;                           // rows between two slots of a thread
+  const int col = tid % TILE, row0 = tid / TILE;
+  // Operand loads are BUFFER loads: (resource = wave-uniform base of the current tile, in SGPRs) + (per-thread
+  // 32-bit byte offset, one VGPR for the whole kernel) + (uniform row offset, SGPR).  The loop carries no vector
+  // address arithmetic and no 64-bit address temporaries — with per-thread pointers the register allocator recycled
+  // the staging registers as address temporaries and had to wait for the loads in flight before issuing new ones.
+  // Clamped columns: what lies outside M / N is loaded from the last valid column and never stored.
+  const uint32_t offA = ((uint32_t)row0 * (uint32_t)lda + (uint32_t)min(m0 + col, M - 1)) * 4u;
+  const uint32_t offB = ((uint32_t)row0 * (uint32_t)ldb + (uint32_t)min(n0 + col, N - 1)) * 4u;
+  const char* uA = (const char*)(A + (int64_t)kb * lda);
+  const char* uB = (const char*)(B + (int64_t)kb * ldb);
+  const uint32_t stepA = (uint32_t)RS * (uint32_t)lda * 4u, stepB = (uint32_t)RS * (uint32_t)ldb * 4u;   // bytes
+  auto bload = [](const char* base, uint32_t voff, uint32_t soff) -> float {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
+  // Two register sets, two LDS buffers: while the matrix cores work on tile t (LDS), tile t + 1 waits in one
+  // register set and the loads of tile t + 2 are issued into the other — every load has two tile-times to land.
+  // A full tile is loaded unconditionally, so no select sits between a load and its LDS store and the wait lands
+  // behind the MFMAs; only the last, partial tile predicates its rows (zero rows: exact no-ops).
+  float ra0[PER], rb0[PER], ra1[PER], rb1[PER];
+  auto gload = [&](float (&ra)[PER], float (&rb)[PER], int k0) {
+    if (k0 + KT <= ke) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        ra[i] = bload(uA, offA, i * stepA);
+        rb[i] = bload(uB, offB, i * stepB);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const bool live = k0 + row0 + RS * i < ke;
+        ra[i] = live ? bload(uA, offA, i * stepA) : 0.f;
+        rb[i] = live ? bload(uB, offB, i * stepB) : 0.f;
+      }
+    }
+    uA += (int64_t)KT * lda * 4;
+    uB += (int64_t)KT * ldb * 4;
+  };
+  auto sstore = [&](const float (&ra)[PER], const float (&rb)[PER], int buf) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int k = k0 + row0 + (256 / TILE) * i;
-      const int kc = min(k, ke - 1);
-      const float va = A[(int64_t)kc * lda + ca], vb = B[(int64_t)kc * ldb + cb];
-      ra[i] = k < ke ? va : 0.f;                            // rows past the range: exact no-ops (x + 0 * 0)
-      rb[i] = k < ke ? vb : 0.f;
+      sA[buf][row0 + RS * i][col] = ra[i];
+      sB[buf][row0 + RS * i][col] = rb[i];
     }
   };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      sA[buf][row0 + (256 / TILE) * i][col] = ra[i];
-      sB[buf][row0 + (256 / TILE) * i][col] = rb[i];
-    }
-  };
-  gload(kb);
-  sstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kb; k0 < ke; k0 += KT, buf ^= 1) {
-    const bool more = k0 + KT < ke;
-    if (more) gload(k0 + KT);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < KT / 2; ++s) {
       float a[R], b[R];
@@ -112,7 +132,22 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(
 #pragma unroll
         for (int y = 0; y < R; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
     }
-    if (more) sstore(buf ^ 1);
+  };
+  gload(ra0, rb0, kb);
+  sstore(ra0, rb0, 0);
+  if (kb + KT < ke) gload(ra1, rb1, kb + KT);
+  __syncthreads();
+  for (int k0 = kb; k0 < ke; k0 += 2 * KT) {
+    // even tile (LDS buffer 0); set 1 holds the next tile, set 0 receives the one after
+    if (k0 + 2 * KT < ke) gload(ra0, rb0, k0 + 2 * KT);
+    compute(0);
+    if (k0 + KT < ke) sstore(ra1, rb1, 1);
+    __syncthreads();
+    if (k0 + KT >= ke) break;
+    // odd tile (LDS buffer 1)
+    if (k0 + 3 * KT < ke) gload(ra1, rb1, k0 + 3 * KT);
+    compute(1);
+    if (k0 + 2 * KT < ke) sstore(ra0, rb0, 0);
     __syncthreads();
   }
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -185,7 +220,7 @@ int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes) {
 int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int M, int N, int K, float* d_C,
                       int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits, void* d_ws,
                       size_t ws_bytes, void* stream) {
-  NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= M && ldb >= N && ldc >= N && splits >= 1 &&
+  NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= M && ldb >= N && ldc >= N && lda < (1 << 24) && ldb < (1 << 24) && splits >= 1 &&
                  act >= -1 && act <= 3, NR_ERR_ARG, "gemm_kmajor: bad arguments");
   if (M == 0 || N == 0) return NR_OK;
   hipStream_t st = (hipStream_t)stream;

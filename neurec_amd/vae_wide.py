@@ -63,7 +63,7 @@ class MultiVAEWideEngine:
         self.gT = z(self.h_last, B)                                 # feature-major copy of the last hidden layer
         self.DT = z(I, B)                                           # D^T and W_last^T for d g = D W_last^T
         self.WT = z(I, self.h_last)
-        self.splits = 16                                            # of the 40,981-long contraction of d g
+        self.splits = 32                                            # of the 40,981-long contraction of d g
         mids = self.Wq[1:] + self.Wp[:-1]                            # the layers that are plain dense products
         wmax = max([self.h_last] + [max(w.shape) for w in mids])
         self.tX, self.tD = z(wmax, B), z(wmax, B)                   # feature-major copies of a layer's x and dLoss/dy

@@ -185,7 +185,8 @@ def test_gemm_epilogue_is_bias_then_activation(M, N, K, splits, act):
     nbytes = C.c_size_t(0)
     call("nrhip_gemm_workspace_bytes", M, N, splits, C.byref(nbytes))
     ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device="cuda")
-    call("nrhip_gemm_kmajor", _ptr(_dev(A)), M, _ptr(_dev(Bm)), N, M, N, K, _ptr(out), N, 0, _ptr(_dev(bias)), act,
+    dA, dB, dbias = _dev(A), _dev(Bm), _dev(bias)
+    call("nrhip_gemm_kmajor", _ptr(dA), M, _ptr(dB), N, M, N, K, _ptr(out), N, 0, _ptr(dbias), act,
          splits, _ptr(ws), ws.numel() if splits > 1 else 0, _stream())
     pre = native.score_gemm(np.ascontiguousarray(A.T), None, np.ascontiguousarray(Bm.T)) + bias[None, :]
     want = {2: np.maximum(pre, 0), 0: np.tanh(pre.astype(np.float64)), -1: pre}[act]
