@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs (same guide, section "L2 (per XCD)")
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (same guide); v_mfma_f32_32x32x2_f32
 
 
@@ -759,15 +760,19 @@ def main():
             comm.allreduce_sum_(t)
             return (t / len(test_users)).cpu().numpy()
         evaluate()
-        torch.cuda.synchronize(); comm.barrier()
-        t0 = time.perf_counter()
-        means = evaluate()
-        torch.cuda.synchronize(); comm.barrier()
-        dte = comm.max_float(time.perf_counter() - t0)
+        runs = []
+        for _ in range(5):                           # wall clock of whole evaluations; the median is reported
+            torch.cuda.synchronize(); comm.barrier()
+            t0 = time.perf_counter()
+            means = evaluate()
+            torch.cuda.synchronize(); comm.barrier()
+            runs.append(comm.max_float(time.perf_counter() - t0))
+        dte = sorted(runs)[len(runs) // 2]
         eval_info = {"users_per_sec": len(test_users) / dte, "ms": dte * 1e3,
+                     "ms_runs": [r * 1e3 for r in runs],
                      "n_users": int(len(test_users)), "ndcg@10": float(means[2 * 20 + 9]),
                      "recall@20": float(means[1 * 20 + 19]),
-                     "design": ("pruned: tile maxima in the fp32-MFMA scoring loop (no score matrix) -> top-21 "
+                     "design": ("pruned: tile maxima in the fp32-MFMA scoring loop (no score matrix; train strikes as a planned fix-up pass) -> top-21 "
                                 "32-item tiles per user rescored + ranked; tie rows redone from full rows"
                                 if args.eval_mode == "pruned" else
                                 "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel; scoring of "
@@ -782,21 +787,30 @@ def main():
             ub = mine[:args.eval_batch]
             nb, d_e, top_k = ub.numel(), eu.shape[1], 20
             ev._gemm.prepare(ei)
-            M = ev._gemm.tile_maxima(eu, ub, trc)
+            plan = ev._plan                                                   # built by the evaluation above
+            row_of = None
+            if plan is not None:
+                row_of = torch.full((U,), -1, dtype=torch.int32, device=dev)
+                row_of[ub.long()] = torch.arange(nb, dtype=torch.int32, device=dev)
+            M = ev._gemm.tile_maxima(eu, ub, trc, plan=plan, row_of=row_of)
             per = torch.empty((nb, 5 * top_k), dtype=torch.float32, device=dev)
             flg = torch.zeros(nb, dtype=torch.int32, device=dev)
             E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg)
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            em, e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
             torch.cuda.synchronize()
+            em.record()
+            for _ in range(3):
+                M = ev._gemm.tile_maxima(eu, ub, trc)                        # strikes inside the scoring loop (r01/r02 form)
             e0.record()
             for _ in range(3):
-                M = ev._gemm.tile_maxima(eu, ub, trc)
+                M = ev._gemm.tile_maxima(eu, ub, trc, plan=plan, row_of=row_of)
             e1.record()
             for _ in range(3):
                 E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg)
             e2.record()
             torch.cuda.synchronize()
             t_score, t_rank = e0.elapsed_time(e1) / 3e3, e1.elapsed_time(e2) / 3e3       # seconds
+            t_inloop = em.elapsed_time(e0) / 3e3
             flops = 2.0 * I * d_e * nb
             tiles = 2 * ((I + 63) // 64)
             # level 2, algorithmic HBM bytes: per user its tile maxima and factor row read and M*K metrics
@@ -806,20 +820,26 @@ def main():
                 (int(train.indptr[-1]) + int(test.indptr[-1])) * 4
             rescore_l2_bytes = nb * (top_k + 1) * 64 * d_e * 4
             eval_info["roofline"] = {
-                "bound": "mfma", "kernel": "score_tilemax_kernel<32>", "users": nb,
+                "bound": "mfma", "kernel": "gather_transpose_kernel + score_tilemax_kernel<32, false> (no strikes in the "
+                                           "loop) + tilemax_fix_kernel<32> (planned (user, tile) pairs recomputed with "
+                                           "their strikes)" if plan is not None else "score_tilemax_kernel<32, true>",
+                "users": nb,
                 "achieved": flops / t_score / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / t_score / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_score * 1e3,
-                "flops_per_user": 2.0 * I * d_e}
+                "flops_per_user": 2.0 * I * d_e,
+                "strikes_in_the_loop_ms": t_inloop * 1e3,
+                "strike_plan_pairs": plan.n_pairs if plan is not None else None}
             eval_info["roofline_topk"] = {
-                "bound": "hbm", "kernel": "rescore_tiles_kernel + select_rows_kernel + metrics_kernel (nrhip_eval_tiles)",
-                "achieved": rank_bytes / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS, "ms": t_rank * 1e3,
-                "bytes": rank_bytes, "rescore_gather_bytes_from_l2": rescore_l2_bytes,
-                "rescore_gather_GBps": rescore_l2_bytes / t_rank / 1e9,
+                "bound": "l2", "kernel": "rescore_tiles_kernel + select_rows_kernel + metrics_kernel (nrhip_eval_tiles)",
+                "achieved": rescore_l2_bytes / t_rank / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                "frac": rescore_l2_bytes / t_rank / 1e9 / L2_PEAK_GBS, "ms": t_rank * 1e3,
+                "bytes": rescore_l2_bytes, "hbm_bytes": rank_bytes,
+                "hbm_GBps": rank_bytes / t_rank / 1e9, "hbm_frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS,
                 "note": "pruned design: the [users][I] score matrix is never written; the top-K works on "
                         "tile maxima and %d rescored tiles per user gathered from the L2-resident item "
-                        "copy, so its HBM bytes are small and the phase is bound by those L2 gathers and "
-                        "by latency, not by HBM" % (top_k + 1)}
+                        "copy: the phase is priced against the aggregate L2 rate those gathers are served "
+                        "at (the whole duration of the three kernels in the denominator); its HBM bytes are small "
+                        "(hbm_frac)" % (top_k + 1)}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-%s)" % args.shape, "value": triplets_per_s,

@@ -116,6 +116,19 @@ int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int 
 int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
                         int d, const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
                         float* d_M, int64_t mld, void* d_ws, size_t ws_bytes, void* stream);
+/* Level 1 in two launches (the faster form): nrhip_score_tilemax with d_tr_indptr = d_tr_indices = NULL leaves the
+ * train items IN the maxima (the scoring loop carries no cursors and no strike code), and nrhip_score_tilemax_fix
+ * recomputes — same MFMA chain, same operand roles, bit-identical values — only the (user, tile) pairs that hold a
+ * train item, from a plan built once per train matrix: pairs sorted by 32-item tile (d_tile_ptr[n_tiles32 + 1],
+ * d_plan_user[e], d_plan_mask[e]: bit r = item 32*tile + r is a train item of that user), cut into chunks of <= 32
+ * pairs of one tile (d_chunk_tile[c], d_chunk_begin[c]).  d_row_of[user] = the user's row in the evaluation order
+ * (-1: not evaluated; NULL: row = user); M holds rows [row_lo, row_lo + rows).  Afterwards M equals the one-launch
+ * form's, bit for bit (uni_evaluator.py:132-140: ranking_score[train items] = -inf, as a property of the maxima). */
+int nrhip_score_tilemax_fix(const float* d_P, int64_t ldp, int d, int cols, const int32_t* d_chunk_tile,
+                            const int64_t* d_chunk_begin, int n_chunks, const int64_t* d_tile_ptr,
+                            const int32_t* d_plan_user, const uint32_t* d_plan_mask, const int32_t* d_row_of,
+                            int row_lo, int rows, float* d_M, int64_t mld, const void* d_ws, size_t ws_bytes,
+                            void* stream);
 int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes);
 /* d_gemm_ws: the workspace nrhip_score_gemm_prepare_items filled (the rescoring reads its k-major
  * item copy, one coalesced 256-byte load per k and tile). */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "nrhip_score_gemm_workspace_bytes": [i32, i32, i32, psz],
     "nrhip_score_gemm_prepare_items": [p, i64, i32, i32, p, sz, p],
     "nrhip_score_tilemax": [p, i64, p, i32, i32, i32, p, p, p, i64, p, sz, p],
+    "nrhip_score_tilemax_fix": [p, i64, i32, i32, p, p, i32, p, p, p, p, i32, i32, p, i64, p, sz, p],
     "nrhip_eval_tiles_workspace_bytes": [i32, i32, psz],
     "nrhip_eval_tiles": [p, i64, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],

@@ -167,7 +167,9 @@ __device__ __forceinline__ float max16_except(const f32x16& c, uint32_t struck) 
   return m;
 }
 
-template <int KS>
+// MASKED = false: the strikes are left to tilemax_fix_kernel (below) — no cursors, no per-tile strike code; only the
+// pad columns of the last tile are excluded.  Every (user, tile) WITHOUT a train item already holds its final value.
+template <int KS, bool MASKED>
 __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
     const float* __restrict__ PT, int bpad, const float* __restrict__ QT, int ipad, int rows,
     int cols, const int32_t* __restrict__ users, const int64_t* __restrict__ tr_indptr,
@@ -191,9 +193,9 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
   // train-list cursors of this lane's two users (column j of user block 0 / 1)
   const int ra = u0 + j, rb = u0 + 32 + j;
   int64_t pa = 0, ea = 0, pb = 0, eb = 0;
-  if (ra < rows) { const int64_t u = users ? users[ra] : ra; pa = tr_indptr[u]; ea = tr_indptr[u + 1]; }
-  if (rb < rows) { const int64_t u = users ? users[rb] : rb; pb = tr_indptr[u]; eb = tr_indptr[u + 1]; }
-  {
+  if (MASKED && ra < rows) { const int64_t u = users ? users[ra] : ra; pa = tr_indptr[u]; ea = tr_indptr[u + 1]; }
+  if (MASKED && rb < rows) { const int64_t u = users ? users[rb] : rb; pb = tr_indptr[u]; eb = tr_indptr[u + 1]; }
+  if (MASKED) {
     // first position with item >= the chunk's first column, both users of the lane in lock step
     // (every probe is a memory round trip; the two searches one after the other were 10 % of a
     // block's time at 37 tiles per block)
@@ -208,13 +210,13 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
     pa = la;
     pb = lb;
   }
-  int na = pa < ea ? tr_indices[pa] : INT_MAX;                // next train item of each user
-  int nb = pb < eb ? tr_indices[pb] : INT_MAX;
+  int na = MASKED && pa < ea ? tr_indices[pa] : INT_MAX;      // next train item of each user
+  int nb = MASKED && pb < eb ? tr_indices[pb] : INT_MAX;
   // ... and the one after it, requested a strike ahead: 94 % of the tiles hold a train item of one
   // of the wave's 64 users, and a cursor that loads its next item when it needs it puts a memory
   // round trip (1.5 us against 3.4 us of MFMAs) into every tile
-  int na2 = pa + 1 < ea ? tr_indices[pa + 1] : INT_MAX;
-  int nb2 = pb + 1 < eb ? tr_indices[pb + 1] : INT_MAX;
+  int na2 = MASKED && pa + 1 < ea ? tr_indices[pa + 1] : INT_MAX;
+  int nb2 = MASKED && pb + 1 < eb ? tr_indices[pb + 1] : INT_MAX;
 
   float bA0[KS], bA1[KS], bB0[KS], bB1[KS];             // two B register sets (see score_gemm_kernel)
   // B operands of a tile from the operand-ordered item copy (swizzle_items_kernel): 16-byte loads,
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
     // rows of the 32x32 result held by this lane: item = it + 32*X + (reg&3) + 8*(reg>>2) + 4*h
     // struck accumulator registers of user a / b: bits 0-15 item block 0, bits 16-31 item block 1
     uint32_t ka = 0u, kb = 0u;
-    if (__ballot(na < it + 64 || nb < it + 64)) {            // a train item of some user falls in the tile
+    if (MASKED && __ballot(na < it + 64 || nb < it + 64)) {  // a train item of some user falls in the tile
       while (na < it + 64) {
         const int o = na - it, row = o & 31;
         if (((row >> 2) & 1) == h) ka |= 1u << ((row & 3) + 4 * (row >> 3) + (o < 32 ? 0 : 16));
@@ -288,6 +290,79 @@ __global__ __launch_bounds__(256, 1) void score_tilemax_kernel(
       tile(t + 1, bB0, bB1);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strikes as a separate, small pass.  The train matrix is fixed for an evaluator, so which (user, 32-item tile)
+// pairs hold a train item — and which of the tile's 32 items they are — is known once: the PLAN, sorted by tile
+// (neurec_amd/engine.py: TileStrikePlan; 1.03 M pairs at the gowalla shape against 38 M user-tiles).  The scoring
+// loop then runs without cursors and strike code (score_tilemax_kernel<KS, false>), and this kernel recomputes just
+// the planned pairs: one wave takes up to 32 planned users of ONE tile, gathers their factor rows, runs the same
+// v_mfma_f32_32x32x2_f32 chain with the same operand roles (item tile = row operand, users = column operand; bit for
+// bit the values of the scoring loop), strikes the planned items and the pad columns, and overwrites M[user][tile].
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void tilemax_fix_kernel(
+    const float* __restrict__ P, int64_t ldp, int d, const float* __restrict__ QT, int ipad, int cols,
+    const int32_t* __restrict__ chunk_tile, const int64_t* __restrict__ chunk_begin, int n_chunks,
+    const int64_t* __restrict__ tile_ptr, const int32_t* __restrict__ plan_user,
+    const uint32_t* __restrict__ plan_mask, const int32_t* __restrict__ row_of, int row_lo, int rows,
+    float* __restrict__ M, int64_t mld) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x * 4 + wave;
+  if (c >= n_chunks) return;
+  const int t = chunk_tile[c];
+  const int64_t e = chunk_begin[c] + j, e_end = min(chunk_begin[c] + 32, tile_ptr[t + 1]);
+  int u = 0, row = -1;
+  uint32_t mask = 0u;
+  if (e < e_end) {
+    u = plan_user[e];
+    mask = plan_mask[e];
+    row = (row_of ? row_of[u] : u) - row_lo;
+    if (row < 0 || row >= rows) row = -1;
+  }
+  if (!__ballot(row >= 0)) return;                             // none of these users is in this batch
+  // operands: lane (j, h) feeds k = 2 s + h of item column j (A) and of user column j (B).  The 32 factor rows are
+  // scattered: the wave fetches them one coalesced row per load (all 32 in flight) into its LDS slice and reads its
+  // k-major operand values from there (row stride 2 KS + 1: conflict-free); a lane reading its own row two floats
+  // apart made every load instruction touch 32 different lines.
+  constexpr int DP = 2 * KS;
+  __shared__ float sB[4][32][DP + 1];
+  float a[KS], b[KS];
+  const float* q = QT + (int64_t)h * ipad + (int64_t)t * 32 + j;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) a[s] = q[(int64_t)2 * s * ipad];
+  {
+    float v0[32], v1[DP > 64 ? 32 : 1];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float* pr = P + (int64_t)__shfl(u, r, 64) * ldp;
+      v0[r] = lane < d ? pr[lane] : 0.f;
+      if (DP > 64) v1[r] = lane + 64 < d ? pr[lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      if (lane < DP) sB[wave][r][lane] = v0[r];
+      if (DP > 64) sB[wave][r][lane + 64] = v1[r];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) b[s] = sB[wave][j][2 * s + h];
+  f32x16 acc = {0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  // rows of the result held by this lane: item = 32 t + (reg & 3) + 8 (reg >> 2) + 4 h
+  uint32_t struck = 0u;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (((mask >> r) & 1u) || t * 32 + r >= cols) struck |= 1u << reg;
+  }
+  float m = max16_except(acc, struck);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (h == 0 && row >= 0) M[(int64_t)row * mld + t] = m;
 }
 
 int padded_dim(int d) {
@@ -407,9 +482,10 @@ int nrhip_score_gemm_items_kmajor(const void* d_ws, int cols, int d, const float
 int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
                         int d, const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
                         float* d_M, int64_t mld, void* d_ws, size_t ws_bytes, void* stream) {
-  NR_REQUIRE(d_P && d_M && d_ws && d_tr_indptr && d_tr_indices && cols >= 1 && d >= 1 && ldp >= d &&
+  NR_REQUIRE(d_P && d_M && d_ws && (!d_tr_indptr == !d_tr_indices) && cols >= 1 && d >= 1 && ldp >= d &&
                  rows >= 0 && mld >= 2 * ((cols + 63) / 64) && mld % 2 == 0,
              NR_ERR_ARG, "score_tilemax: bad arguments (mld must be even and >= 2*ceil(cols/64))");
+  const bool masked = d_tr_indptr != nullptr;
   const int dp = padded_dim(d);
   NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_tilemax: embedding dim %d > 128 not built", d);
   if (rows == 0) return NR_OK;
@@ -428,9 +504,13 @@ int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, i
   if (tpc > n_tiles) tpc = n_tiles;
   const int by = (n_tiles + tpc - 1) / tpc;
   dim3 grid(bx, by), block(256);
-#define NR_TMAX_CASE(KS)                                                                       \
-  hipLaunchKernelGGL(score_tilemax_kernel<KS>, grid, block, 0, st, g.PT, bpad, g.QS, ipad, rows, \
-                     cols, d_users, d_tr_indptr, d_tr_indices, d_M, mld, tpc)
+#define NR_TMAX_CASE(KS)                                                                                     \
+  if (masked)                                                                                                \
+    hipLaunchKernelGGL((score_tilemax_kernel<KS, true>), grid, block, 0, st, g.PT, bpad, g.QS, ipad, rows,  \
+                       cols, d_users, d_tr_indptr, d_tr_indices, d_M, mld, tpc);                            \
+  else                                                                                                       \
+    hipLaunchKernelGGL((score_tilemax_kernel<KS, false>), grid, block, 0, st, g.PT, bpad, g.QS, ipad, rows, \
+                       cols, d_users, d_tr_indptr, d_tr_indices, d_M, mld, tpc)
   switch (dp) {
     case 16: NR_TMAX_CASE(8); break;
     case 32: NR_TMAX_CASE(16); break;
@@ -440,6 +520,45 @@ int nrhip_score_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, i
     default: NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "score_tilemax: dp=%d", dp);
   }
 #undef NR_TMAX_CASE
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Level 1, second half, when nrhip_score_tilemax ran WITHOUT the train lists (d_tr_indptr = d_tr_indices = NULL):
+ * recompute M[row][tile] for the planned (user, tile) pairs with the planned items struck.  The plan (built once
+ * per train matrix, neurec_amd/engine.py: TileStrikePlan): pairs sorted by 32-item tile — d_tile_ptr[n_tiles32 + 1],
+ * d_plan_user[e], d_plan_mask[e] (bit r: item 32*tile + r is a train item of the user) — cut into chunks of <= 32
+ * pairs of one tile (d_chunk_tile[c], d_chunk_begin[c]).  d_row_of[user] = row of the user in the evaluation order
+ * (or -1; NULL: row = user); rows [row_lo, row_lo + rows) are the batch M holds.  After this call M equals what
+ * nrhip_score_tilemax computes WITH the train lists, bit for bit. */
+int nrhip_score_tilemax_fix(const float* d_P, int64_t ldp, int d, int cols, const int32_t* d_chunk_tile,
+                            const int64_t* d_chunk_begin, int n_chunks, const int64_t* d_tile_ptr,
+                            const int32_t* d_plan_user, const uint32_t* d_plan_mask, const int32_t* d_row_of,
+                            int row_lo, int rows, float* d_M, int64_t mld, const void* d_ws, size_t ws_bytes,
+                            void* stream) {
+  NR_REQUIRE(d_P && d_M && d_ws && d_tile_ptr && cols >= 1 && d >= 1 && ldp >= d && rows >= 0 && n_chunks >= 0 &&
+                 mld >= 2 * ((cols + 63) / 64), NR_ERR_ARG, "score_tilemax_fix: bad arguments");
+  if (rows == 0 || n_chunks == 0) return NR_OK;
+  NR_REQUIRE(d_chunk_tile && d_chunk_begin && d_plan_user && d_plan_mask, NR_ERR_ARG, "score_tilemax_fix: plan");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_tilemax_fix: embedding dim %d > 128 not built", d);
+  GemmWs g = carve(const_cast<void*>(d_ws), 0, cols, dp);
+  NR_REQUIRE(ws_bytes >= g.qt_bytes, NR_ERR_WORKSPACE, "score_tilemax_fix: workspace %zu < %zu", ws_bytes, g.qt_bytes);
+  const int ipad = round_up64(cols);
+  dim3 grid((n_chunks + 3) / 4), block(256);
+#define NR_FIX_CASE(KS)                                                                                          \
+  hipLaunchKernelGGL(tilemax_fix_kernel<KS>, grid, block, 0, (hipStream_t)stream, d_P, ldp, d, g.QT, ipad, cols, \
+                     d_chunk_tile, d_chunk_begin, n_chunks, d_tile_ptr, d_plan_user, d_plan_mask, d_row_of,    \
+                     row_lo, rows, d_M, mld)
+  switch (dp) {
+    case 16: NR_FIX_CASE(8); break;
+    case 32: NR_FIX_CASE(16); break;
+    case 48: NR_FIX_CASE(24); break;
+    case 64: NR_FIX_CASE(32); break;
+    case 128: NR_FIX_CASE(64); break;
+    default: NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "score_tilemax_fix: dp=%d", dp);
+  }
+#undef NR_FIX_CASE
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

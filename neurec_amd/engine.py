@@ -210,9 +210,13 @@ class ScoreGemm:
         return out[:rows]
 
 
-    def tile_maxima(self, user_table, users, train_csr, out=None):
+    def tile_maxima(self, user_table, users, train_csr, out=None, plan=None, row_of=None, row_lo=0):
         """Pruned evaluation, level 1: M[r][t] = max admissible score of user row r over 32-item
-        tile t (train items and pad columns excluded); the scores themselves are never stored."""
+        tile t (train items and pad columns excluded); the scores themselves are never stored.
+        With a TileStrikePlan of the train matrix: the scoring loop runs without the train lists and the
+        planned (user, tile) pairs are recomputed with their strikes afterwards — same M, bit for bit.
+        `row_of` [n_users] int32 maps a user to its row in the whole evaluation order (None: row = user) and
+        `row_lo` is the first row of this batch in that order."""
         rows = user_table.shape[0] if users is None else users.numel()
         if rows > self.max_rows:
             raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
@@ -222,9 +226,52 @@ class ScoreGemm:
             out = torch.empty((rows, mld), dtype=torch.float32, device=self.ws.device)
         call("nrhip_score_tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
              _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d,
-             _ptr(train_csr.indptr), _ptr(train_csr.indices), _ptr(out, torch.float32),
+             None if plan is not None else _ptr(train_csr.indptr),
+             None if plan is not None else _ptr(train_csr.indices), _ptr(out, torch.float32),
              out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
+        if plan is not None:
+            if plan.cols != self.cols:
+                raise ValueError("strike plan built for %d items, scoring %d" % (plan.cols, self.cols))
+            call("nrhip_score_tilemax_fix", _ptr(user_table, torch.float32), user_table.stride(0), self.d, self.cols,
+                 _ptr(plan.chunk_tile, torch.int32), _ptr(plan.chunk_begin, torch.int64), plan.n_chunks,
+                 _ptr(plan.tile_ptr, torch.int64), _ptr(plan.user, torch.int32), _ptr(plan.mask, torch.int32),
+                 _ptr(row_of, torch.int32, allow_none=True), int(row_lo), rows, _ptr(out, torch.float32),
+                 out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
         return out[:rows]
+
+
+class TileStrikePlan:
+    """Which (user, 32-item tile) pairs hold a train item, and which items of the tile — built ONCE per train
+    matrix (construction-time torch ops; nothing here runs per evaluation).  Sorted by tile, then user; cut into
+    chunks of <= 32 pairs of one tile, the unit one wave of tilemax_fix_kernel recomputes (csrc/score_gemm.hip).
+    uni_evaluator.py:132-140 strikes ranking_score[u][train items of u] = -inf on the host for every batch."""
+
+    def __init__(self, train_csr, cols=None):
+        dev = train_csr.indptr.device
+        self.cols = int(train_csr.n_cols if cols is None else cols)
+        U = int(train_csr.n_rows)
+        indptr, indices = train_csr.indptr, train_csr.indices[:train_csr.nnz].to(torch.int64)
+        counts = indptr[1:] - indptr[:-1]
+        user = torch.repeat_interleave(torch.arange(U, device=dev, dtype=torch.int64), counts)
+        n_tiles = 2 * ((self.cols + 63) // 64)
+        key = (indices >> 5) * U + user
+        key, order = torch.sort(key, stable=True)
+        uniq, inverse = torch.unique_consecutive(key, return_inverse=True)
+        bits = torch.ones_like(key) << (indices[order] & 31)
+        mask = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).index_add_(0, inverse, bits)   # distinct bits: + is |
+        tile = uniq // U
+        self.user = (uniq - tile * U).to(torch.int32).contiguous()
+        self.mask = torch.where(mask >= 2**31, mask - 2**32, mask).to(torch.int32).contiguous()        # the uint32 bit pattern
+        per_tile = torch.bincount(tile, minlength=n_tiles)
+        self.tile_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
+        self.tile_ptr[1:] = torch.cumsum(per_tile, 0)
+        n_chunks = (per_tile + 31) // 32
+        self.chunk_tile = torch.repeat_interleave(torch.arange(n_tiles, device=dev, dtype=torch.int32), n_chunks).contiguous()
+        first = torch.cumsum(n_chunks, 0) - n_chunks                          # index of a tile's first chunk
+        within = torch.arange(self.chunk_tile.numel(), device=dev, dtype=torch.int64) - first[self.chunk_tile.long()]
+        self.chunk_begin = (self.tile_ptr[self.chunk_tile.long()] + 32 * within).contiguous()
+        self.n_chunks = int(self.chunk_tile.numel())
+        self.n_pairs = int(self.user.numel())
 
 
 _tiles_ws = Workspace()

@@ -475,8 +475,10 @@ class FullRankEvaluator:
                    by batch (scoring of batch b+1 overlapped with the ranking of batch b)."""
 
     def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True,
-                 pruned=True):
+                 pruned=True, strike_plan=True):
         self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
+        self.strike_plan = bool(strike_plan)  # strikes as a planned fix-up pass after an unmasked scoring loop
+        self._plan = None                    # (False: cursors + strikes inside the scoring loop; same M bit for bit)
         self.train, self.test = train_csr, test_csr
         self.metric_ids = [int(m) for m in metric_ids]
         self.top_k = int(top_k)
@@ -556,9 +558,17 @@ class FullRankEvaluator:
         n = test_users.numel()
         flags = torch.zeros(n, dtype=torch.int32, device=test_users.device)
         self.n_flagged = 0
+        plan = row_of = None
+        if self.strike_plan:
+            # test_users must be distinct (uni_evaluator.py:108: the keys of a dict): a user's row is looked up
+            if self._plan is None or self._plan.cols != item_table.shape[0]:
+                self._plan = E.TileStrikePlan(self.train, item_table.shape[0])
+            plan = self._plan
+            row_of = torch.full((self.train.n_rows,), -1, dtype=torch.int32, device=test_users.device)
+            row_of[test_users.long()] = torch.arange(n, dtype=torch.int32, device=test_users.device)
         for b in starts:
             u = test_users[b:b + self.batch_rows]
-            M = self._gemm.tile_maxima(user_table, u, self.train)
+            M = self._gemm.tile_maxima(user_table, u, self.train, plan=plan, row_of=row_of, row_lo=b)
             E.eval_tiles(M, user_table, self._gemm, u, self.train, self.test, self.metric_ids,
                          self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()])
         self._flags = flags                        # read by evaluate_factors together with the sums

@@ -245,3 +245,45 @@ def test_pruned_evaluation_equals_materialised_scores(d, ties):
         assert lean.n_flagged > 0                      # the tie rows really went through the full path
     else:
         assert lean.n_flagged <= len(users) // 20
+
+
+@pytest.mark.parametrize("d,U,I,shuffle", [(64, 700, 5000, False), (50, 300, 2500, True), (16, 900, 4133, True),
+                                           (128, 200, 1000, False)])
+def test_planned_strikes_leave_the_same_tile_maxima_as_the_in_loop_strikes(d, U, I, shuffle):
+    """nrhip_score_tilemax without the train lists + nrhip_score_tilemax_fix (the planned (user, tile) pairs
+    recomputed with their strikes) == nrhip_score_tilemax with cursors and strikes in the scoring loop, bit for bit —
+    for a user subset in any order, in batches, with users whose whole tile is train items, pad columns, d not a
+    multiple of 4."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(d + U)
+    P = (rng.randn(U, d) * 0.3).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.3).astype(np.float32)
+    tr = sp.random(U, I, 0.02, random_state=3, format="lil", dtype=np.float32)
+    tr[5, 64:96] = 1.0                                  # a whole 32-item tile struck: its maximum is -inf
+    tr[7, I - 40:I] = 1.0                               # the last, partial tile
+    tr[9, :] = 0.0                                      # a user without train items
+    tr = tr.tocsr(); tr.data[:] = 1.0; tr.sort_indices()
+    trc = E.DeviceCSR.from_scipy(tr)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    users = np.arange(U, dtype=np.int32)
+    if shuffle:
+        users = rng.permutation(U)[:U * 2 // 3].astype(np.int32)
+    ud = torch.from_numpy(users).cuda()
+    gemm = E.ScoreGemm(Qd, 256)
+    plan = E.TileStrikePlan(trc, I)
+    assert plan.n_pairs <= tr.nnz and plan.n_chunks >= 1
+    row_of = torch.full((U,), -1, dtype=torch.int32, device="cuda")
+    row_of[ud.long()] = torch.arange(len(users), dtype=torch.int32, device="cuda")
+    for b in range(0, len(users), 256):
+        u = ud[b:b + 256]
+        want = gemm.tile_maxima(Pd, u, trc).clone()
+        got = gemm.tile_maxima(Pd, u, trc, plan=plan, row_of=row_of, row_lo=b)
+        n_t = (I + 31) // 32
+        np.testing.assert_array_equal(got.cpu().numpy()[:, :n_t], want.cpu().numpy()[:, :n_t])
+    if not shuffle:                                     # row = user without a lookup table
+        want = gemm.tile_maxima(Pd[:256].contiguous(), None, trc).clone()
+        got = gemm.tile_maxima(Pd[:256].contiguous(), None, trc, plan=plan)
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+        assert np.isneginf(got.cpu().numpy()[5, 2])
