@@ -712,6 +712,21 @@ int nrhip_ngcf_step(void* ctx, const int32_t* d_users, const int32_t* d_pos, con
                     int mask_given, float alpha, float beta1, float beta2, float eps, float* d_loss2,
                     void* stream);
 
+/* ---- NGCF layers of any width (NGCF.py:31-33,271-286; csrc/ngcf_wide.hip) — the row-wise pieces a layer needs next to
+ * nrhip_spmm_csr and nrhip_gemm_kmajor; neurec_amd/ngcf_wide.py strings them (widths 1..256). */
+int nrhip_ew_mul(const float* d_a, int64_t lda, const float* d_b, int64_t ldb, int64_t rows, int cols, float* d_out,
+                 int64_t ldo, void* stream);                                            /* bi = E .* S (NGCF.py:185) */
+int nrhip_ngcf_act_fwd(const float* d_T1, const float* d_T2, int64_t ldt, int64_t n_rows, int w, int w_pad,
+                       float keep, uint8_t* d_mask_io, int mask_given, uint64_t seed, uint64_t step, int layer,
+                       float* d_ego_out, int64_t lde, float* d_out, int64_t ldo, void* stream);   /* NGCF.py:181-198 */
+int nrhip_ngcf_act_bwd(const float* d_dout, int64_t ldo, const float* d_dego_next, int64_t ldn,
+                       const float* d_ego_next, int64_t lde, const float* d_T1, const float* d_T2, int64_t ldt,
+                       const uint8_t* d_mask, int64_t n_rows, int w, float keep, float* d_dT1, float* d_dT2,
+                       void* stream);
+int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const float* d_ego, const float* d_S,
+                       int64_t lde, int64_t n_rows, int w, int w_pad, float* d_dS, float* d_dego_direct,
+                       void* stream);
+
 /* ---- Mult-VAE for any p_dim (conf/MultiVAE.properties:3: [200, 600], [200]; MultiVAE.py:46-135 builds q / p networks
  * of arbitrary depth and width) — width-generic pieces (csrc/vae_wide.hip) + a general fp32-MFMA GEMM (csrc/gemm.hip).
  * act: 0 tanh, 1 sigmoid, 2 relu, 3 identity, -1 none.  neurec_amd/vae_wide.py strings them into a step. */

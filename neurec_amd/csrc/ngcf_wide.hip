@@ -1,0 +1,184 @@
+// ngcf_wide.hip — NGCF propagation layers of ANY width (NGCF.py:31-33,271-286 take any embedding_size / layer_size;
+// conf/NGCF.properties ships 16 / [16, 16], the NGCF paper uses 64 / [64, 64, 64]).  dense.hip is the fused,
+// register-resident form for the shipped width; here a layer (NGCF.py:172-198)
+//     T1 = S W_gc + b_gc            T2 = (E .* S) W_bi + b_bi                     S = A_hat E (SpMM)
+//     Z  = leaky_relu(T1) + leaky_relu(T2)      E' = Z / keep * mask      out = E' / max(|E'|, 1e-6)  (l2_normalize)
+// is strung by neurec_amd/ngcf_wide.py from the SpMM, the general fp32-MFMA GEMM (gemm.hip: both products, their
+// weight gradients over the N rows, the transposed products of the backward pass) and the row-wise kernels below.
+// One wave per node row, lanes over the columns (<= 256): the row norm and the dot with the incoming gradient are
+// wave reductions.
+#include "nr_common.h"
+
+namespace {
+
+constexpr float kLeaky = 0.2f;
+constexpr float kNormEps = 1e-12f;
+constexpr int kMaxPer = 4;                                   // columns per lane: widths up to 256
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : __fmul_rn(x, kLeaky); }
+
+// out[r][c] = a[r][c] * b[r][c]
+__global__ __launch_bounds__(256) void ew_mul_kernel(const float* __restrict__ a, int64_t lda,
+                                                     const float* __restrict__ b, int64_t ldb, int64_t rows, int cols,
+                                                     float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int64_t r = e / cols;
+  const int c = (int)(e - r * cols);
+  out[r * ldo + c] = __fmul_rn(a[r * lda + c], b[r * ldb + c]);
+}
+
+__global__ __launch_bounds__(256) void ngcf_act_fwd_kernel(
+    const float* __restrict__ T1, const float* __restrict__ T2, int64_t ldt, int64_t n_rows, int w, int w_pad,
+    float keep, uint8_t* __restrict__ mask_io, int mask_given, uint64_t seed, uint64_t step, int layer,
+    float* __restrict__ ego_out, int64_t lde, float* __restrict__ out, int64_t ldo) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= n_rows) return;
+  const uint64_t key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull + layer));
+  float z[kMaxPer];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < kMaxPer; ++q) {
+    const int c = lane + 64 * q;
+    z[q] = 0.f;
+    if (c < w) {
+      bool kp;
+      if (mask_given) kp = mask_io[r * w + c] != 0;
+      else {
+        kp = (float)(nr::splitmix64(key ^ (uint64_t)(r * w + c)) >> 40) * (1.0f / 16777216.0f) < keep;
+        mask_io[r * w + c] = kp ? 1 : 0;
+      }
+      const float zz = __fadd_rn(lrelu(T1[r * ldt + c]), lrelu(T2[r * ldt + c]));
+      z[q] = kp ? zz / keep : 0.f;
+      ss = fmaf(z[q], z[q], ss);
+    }
+  }
+  ss = nr_wave_sum_f32(ss);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, kNormEps));
+#pragma unroll
+  for (int q = 0; q < kMaxPer; ++q) {
+    const int c = lane + 64 * q;
+    if (c < w_pad) ego_out[r * lde + c] = z[q];            // pad columns: zeros (the SpMM runs on padded rows)
+    if (c < w) out[r * ldo + c] = __fmul_rn(z[q], inv);
+  }
+}
+
+// dT1, dT2 from dLoss/d out_k (d_out), the gradient arriving through the next layer (d_ego_next, may be NULL),
+// and the forward's E' (ego_next), T1, T2, mask
+__global__ __launch_bounds__(256) void ngcf_act_bwd_kernel(
+    const float* __restrict__ d_out, int64_t ldo, const float* __restrict__ d_ego_next, int64_t ldn,
+    const float* __restrict__ ego_next, int64_t lde, const float* __restrict__ T1, const float* __restrict__ T2,
+    int64_t ldt, const uint8_t* __restrict__ mask, int64_t n_rows, int w, float keep, float* __restrict__ dT1,
+    float* __restrict__ dT2) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= n_rows) return;
+  float z[kMaxPer], g[kMaxPer];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < kMaxPer; ++q) {
+    const int c = lane + 64 * q;
+    z[q] = c < w ? ego_next[r * lde + c] : 0.f;
+    g[q] = c < w ? d_out[r * ldo + c] : 0.f;
+    ss = fmaf(z[q], z[q], ss);
+  }
+  ss = nr_wave_sum_f32(ss);
+  const float inv = 1.0f / sqrtf(fmaxf(ss, kNormEps));
+  float dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < kMaxPer; ++q) dot = fmaf(g[q], __fmul_rn(z[q], inv), dot);
+  dot = nr_wave_sum_f32(dot);
+#pragma unroll
+  for (int q = 0; q < kMaxPer; ++q) {
+    const int c = lane + 64 * q;
+    if (c >= w) continue;
+    float v = ss > kNormEps ? (g[q] - (z[q] * inv) * dot) * inv : g[q] * inv;
+    if (d_ego_next) v += d_ego_next[r * ldn + c];
+    const float dz = mask[r * w + c] ? v / keep : 0.f;
+    const float t1 = T1[r * ldt + c], t2 = T2[r * ldt + c];
+    dT1[r * ldt + c] = t1 > 0.f ? dz : dz * kLeaky;
+    dT2[r * ldt + c] = t2 > 0.f ? dz : dz * kLeaky;
+  }
+}
+
+// dS = Y1 + Y2 .* ego ;  d_ego_direct = Y2 .* S      (Y1 = dT1 W_gc^T, Y2 = dT2 W_bi^T); pad columns: zeros
+__global__ __launch_bounds__(256) void ngcf_mix_bwd_kernel(const float* __restrict__ Y1, const float* __restrict__ Y2,
+                                                           int64_t ldy, const float* __restrict__ ego,
+                                                           const float* __restrict__ S, int64_t lde, int64_t n_rows,
+                                                           int w, int w_pad, float* __restrict__ dS,
+                                                           float* __restrict__ d_ego_direct) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_rows * w_pad) return;
+  const int64_t r = e / w_pad;
+  const int c = (int)(e - r * w_pad);
+  float ds = 0.f, de = 0.f;
+  if (c < w) {
+    const float y1 = Y1[r * ldy + c], y2 = Y2[r * ldy + c];
+    ds = y1 + y2 * ego[r * lde + c];
+    de = y2 * S[r * lde + c];
+  }
+  dS[r * lde + c] = ds;
+  d_ego_direct[r * lde + c] = de;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_ew_mul(const float* d_a, int64_t lda, const float* d_b, int64_t ldb, int64_t rows, int cols, float* d_out,
+                 int64_t ldo, void* stream) {
+  NR_REQUIRE(d_a && d_b && d_out && rows >= 0 && cols >= 1 && lda >= cols && ldb >= cols && ldo >= cols, NR_ERR_ARG,
+             "ew_mul: bad arguments");
+  if (rows == 0) return NR_OK;
+  hipLaunchKernelGGL(ew_mul_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_a, lda, d_b, ldb, rows, cols, d_out, ldo);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Z = leaky_relu(T1) + leaky_relu(T2); E' = Z / keep * mask -> d_ego_out [n_rows][lde] (columns w .. w_pad-1 zeroed);
+ * l2_normalize(E') -> d_out [n_rows][ldo].  d_mask_io [n_rows][w] bytes: read when mask_given, else drawn from
+ * (seed, step, layer) and written (NGCF.py:181-198). */
+int nrhip_ngcf_act_fwd(const float* d_T1, const float* d_T2, int64_t ldt, int64_t n_rows, int w, int w_pad,
+                       float keep, uint8_t* d_mask_io, int mask_given, uint64_t seed, uint64_t step, int layer,
+                       float* d_ego_out, int64_t lde, float* d_out, int64_t ldo, void* stream) {
+  NR_REQUIRE(d_T1 && d_T2 && d_mask_io && d_ego_out && d_out && n_rows >= 0 && w >= 1 && w <= 64 * kMaxPer &&
+                 w_pad >= w && w_pad <= 64 * kMaxPer && ldt >= w && lde >= w_pad && ldo >= w && keep > 0.f &&
+                 keep <= 1.f, NR_ERR_ARG, "ngcf_act_fwd: bad arguments (widths 1..256)");
+  if (n_rows == 0) return NR_OK;
+  hipLaunchKernelGGL(ngcf_act_fwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     d_T1, d_T2, ldt, n_rows, w, w_pad, keep, d_mask_io, mask_given, seed, step, layer, d_ego_out, lde,
+                     d_out, ldo);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_ngcf_act_bwd(const float* d_dout, int64_t ldo, const float* d_dego_next, int64_t ldn,
+                       const float* d_ego_next, int64_t lde, const float* d_T1, const float* d_T2, int64_t ldt,
+                       const uint8_t* d_mask, int64_t n_rows, int w, float keep, float* d_dT1, float* d_dT2,
+                       void* stream) {
+  NR_REQUIRE(d_dout && d_ego_next && d_T1 && d_T2 && d_mask && d_dT1 && d_dT2 && n_rows >= 0 && w >= 1 &&
+                 w <= 64 * kMaxPer && ldo >= w && lde >= w && ldt >= w && (!d_dego_next || ldn >= w) && keep > 0.f,
+             NR_ERR_ARG, "ngcf_act_bwd: bad arguments (widths 1..256)");
+  if (n_rows == 0) return NR_OK;
+  hipLaunchKernelGGL(ngcf_act_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     d_dout, ldo, d_dego_next, ldn, d_ego_next, lde, d_T1, d_T2, ldt, d_mask, n_rows, w, keep, d_dT1,
+                     d_dT2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const float* d_ego, const float* d_S,
+                       int64_t lde, int64_t n_rows, int w, int w_pad, float* d_dS, float* d_dego_direct,
+                       void* stream) {
+  NR_REQUIRE(d_Y1 && d_Y2 && d_ego && d_S && d_dS && d_dego_direct && n_rows >= 0 && w >= 1 && w_pad >= w &&
+                 ldy >= w && lde >= w_pad, NR_ERR_ARG, "ngcf_mix_bwd: bad arguments");
+  if (n_rows == 0) return NR_OK;
+  hipLaunchKernelGGL(ngcf_mix_bwd_kernel, dim3((unsigned)((n_rows * w_pad + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_Y1, d_Y2, ldy, d_ego, d_S, lde, n_rows, w, w_pad, d_dS, d_dego_direct);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

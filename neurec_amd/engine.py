@@ -240,6 +240,58 @@ class ScoreGemm:
         return out[:rows]
 
 
+class ScoreGemmWide:
+    """ScoreGemm's interface for factor widths beyond the scoring loop's 128 (NGCF at the paper's 64 / [64, 64, 64]
+    concatenates to 256 columns): S = P[users] @ Q.T through the general fp32-MFMA GEMM (csrc/gemm.hip) on k-major
+    copies of both sides — the same k-ascending fmaf chain per score.  The evaluation then takes the materialised
+    path (score slab -> train mask -> select); there is no tile-maxima form at these widths."""
+
+    wide = True
+
+    def __init__(self, item_table, max_rows):
+        self.cols, self.d = item_table.shape
+        self.max_rows = int(max_rows)
+        dev = item_table.device
+        self.ld = (self.cols + 63) // 64 * 64
+        self.QT = torch.empty((self.d, self.cols), dtype=torch.float32, device=dev)
+        self.PT = torch.empty((self.d, self.max_rows), dtype=torch.float32, device=dev)
+        self.Pg = torch.empty((self.max_rows, self.d), dtype=torch.float32, device=dev)
+        self.prepare(item_table)
+
+    def prepare(self, item_table):
+        if tuple(item_table.shape) != (self.cols, self.d):
+            raise ValueError("item table shape changed")
+        call("nrhip_transpose2d", _ptr(item_table, torch.float32), item_table.stride(0), self.cols, self.d,
+             _ptr(self.QT), self.cols, _stream())
+
+    def new_score_buffer(self, rows=None):
+        rows = self.max_rows if rows is None else rows
+        return torch.empty((rows, self.ld), dtype=torch.float32, device=self.QT.device)
+
+    def __call__(self, user_table, users, out=None):
+        rows = user_table.shape[0] if users is None else users.numel()
+        if rows > self.max_rows:
+            raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
+        if out is None:
+            out = self.new_score_buffer(rows)
+        if rows == 0:
+            return out[:0]
+        src, ld = user_table, user_table.stride(0)
+        if users is not None:
+            rows_gather(users, user_table, self.Pg[:rows])
+            src, ld = self.Pg, self.d
+        call("nrhip_transpose2d", _ptr(src, torch.float32), ld, rows, self.d, _ptr(self.PT), self.max_rows, _stream())
+        call("nrhip_gemm_kmajor", _ptr(self.PT), self.max_rows, _ptr(self.QT), self.cols, rows, self.cols, self.d,
+             C.c_void_p(out.data_ptr()), out.stride(0), 0, None, -1, 1, None, 0, _stream())
+        return out[:rows]
+
+
+def score_gemm_for(item_table, max_rows):
+    """The scoring object for an item factor table: the operand-swizzled scoring loop up to 128 columns, the general
+    GEMM beyond."""
+    return (ScoreGemmWide if item_table.shape[1] > 128 else ScoreGemm)(item_table, max_rows)
+
+
 class TileStrikePlan:
     """Which (user, 32-item tile) pairs hold a train item, and which items of the tile — built ONCE per train
     matrix (construction-time torch ops; nothing here runs per evaluation).  Sorted by tile, then user; cut into

@@ -61,9 +61,9 @@ class NGCF(AbstractRecommender):
         if str(self.learner).lower() != "adam":
             raise NotImplementedError("the HIP NGCF engine implements learner=adam")
         sizes = [self.emb_dim] + list(self.weight_size)
-        if any(s != 16 for s in sizes):
-            raise NotImplementedError("NGCF layer kernels are built for width 16 "
-                                      "(embedding_size=16, layer_size=[16,...])")
+        if any(not 1 <= s <= 256 for s in sizes) or sum(sizes) > 256:
+            raise NotImplementedError("NGCF layer widths 1..256 with a concatenated width <= 256 are built "
+                                      "(embedding_size + sum(layer_size) = %d)" % sum(sizes))
         e_init = get_initializer(self.embed_init_method, self.stddev, seed=2017)
         w_init = get_initializer(self.weight_init_method, self.stddev, seed=2018)
         table = np.concatenate([e_init([self.num_users, self.emb_dim]),
@@ -73,9 +73,15 @@ class NGCF(AbstractRecommender):
         for k in range(self.n_layers):
             weights.append((w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]]),
                             w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]])))
-        self.engine = NGCFEngine(self.norm_adj, transpose_csr(self.norm_adj), self.num_users,
-                                 self.num_items, table, weights, self.learning_rate, self.reg,
-                                 self.mess_dropout_ratio, self.batch_size)
+        if all(s == 16 for s in sizes):                  # the shipped width: fused, register-resident layer kernels
+            engine = NGCFEngine
+        else:                                            # any other widths: SpMM + fp32-MFMA GEMM + row-wise kernels
+            from ...ngcf_wide import NGCFWideEngine as engine
+            self.logger.info("embedding_size=%d layer_size=%s runs on the width-generic NGCF engine"
+                             % (self.emb_dim, list(self.weight_size)))
+        self.engine = engine(self.norm_adj, transpose_csr(self.norm_adj), self.num_users,
+                             self.num_items, table, weights, self.learning_rate, self.reg,
+                             self.mess_dropout_ratio, self.batch_size)
 
     def train_model(self):
         import torch

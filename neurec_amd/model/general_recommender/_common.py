@@ -10,7 +10,7 @@ def predict_scores(user_table, item_table, user_ids, candidate_items=None):
     import torch
     from ... import engine as E
     users = torch.tensor(np.asarray(list(user_ids), dtype=np.int32), device=user_table.device)
-    gemm = E.ScoreGemm(item_table, max_rows=max(users.numel(), 1))
+    gemm = E.score_gemm_for(item_table, max(users.numel(), 1))
     ratings = gemm(user_table, users).cpu().numpy()[:, :item_table.shape[0]]
     if candidate_items is not None:
         return [rating[items] for rating, items in zip(ratings, candidate_items)]

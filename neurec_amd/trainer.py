@@ -496,7 +496,7 @@ class FullRankEvaluator:
         nm = len(self.metric_ids)
         if self._gemm is None or self._gemm.cols != item_table.shape[0] or \
                 self._gemm.d != item_table.shape[1]:
-            self._gemm = E.ScoreGemm(item_table, self.batch_rows)
+            self._gemm = E.score_gemm_for(item_table, self.batch_rows)
             self._scores = [self._gemm.new_score_buffer()]
         else:
             self._gemm.prepare(item_table)
@@ -504,7 +504,8 @@ class FullRankEvaluator:
         self._flags, self.n_flagged = None, 0
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
-        if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0:
+        if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0 and \
+                not getattr(self._gemm, "wide", False):
             self._evaluate_pruned(user_table, item_table, test_users, per_user, starts)
         elif not self.overlap or len(starts) < 2:
             for b in starts:

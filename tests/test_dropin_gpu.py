@@ -150,6 +150,26 @@ def test_ngcf_config_drops_in(tmp_path):
     assert model.get_eval_factors()[0].shape[1] == 48                        # concat of 3 blocks of 16
 
 
+@pytest.mark.parametrize("emb,layers,width", [(64, "[64,64,64]", 256), (24, "[32,8]", 64)])
+def test_ngcf_other_widths_drop_in(tmp_path, emb, layers, width):
+    """embedding_size / layer_size other than the shipped 16 / [16, 16] (64 / [64, 64, 64]: the NGCF paper's) through
+    the same plugin on the width-generic engine: log lines, loss falls, the logged evaluation line is the oracle's —
+    at 256 concatenated columns through the general-GEMM scoring (no tile-maxima form at that width)."""
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=NGCF", "--epochs=8", "--batch_size=128", "--learning_rate=0.005",
+                            "--verbose=4", "--mess_dropout_ratio=0.0", "--embedding_size=%d" % emb,
+                            "--layer_size=" + layers])
+    text = _log_text(tmp_path, "NGCF")
+    assert "width-generic NGCF engine" in text
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 8 and float(iters[-1][1]) < float(iters[0][1])
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == [4, 8]
+    assert evals[-1][1] == _oracle_line(model, model.evaluator)
+    assert model.get_eval_factors()[0].shape[1] == width
+
+
 def test_multivae_config_drops_in(tmp_path):
     """conf/MultiVAE.properties -> HIP Mult-VAE: log lines, loss falls; `predict` scores each user
     on their own history by default, and with reference_predict_rows=True on the reference's

@@ -137,30 +137,36 @@ def test_lightgcn_restatement_equals_the_reference_graph(adj):
 NGCF_W = ("W_gc", "b_gc", "W_bi", "b_bi")
 
 
-@pytest.mark.parametrize("tag", ["drop", "reg"])
+@pytest.mark.parametrize("tag", ["drop", "reg", "wide_64x3", "wide_24_32_8"])
 def test_ngcf_restatement_equals_the_reference_graph(tag):
+    """wide_*: embedding_size / layer_size other than the shipped 16 / [16, 16] (NGCF.py:31-33,271-286 take any;
+    64 / [64, 64, 64] is the NGCF paper's setting) — the reference class run at those widths."""
     g = load_golden("tfgraph_ngcf_" + tag)
     h = json.loads(str(g["hyper"]))
+    L = len(h["layer_size"])
+    step_masks = (lambda s: [g["masks_%d" % k][s] for k in range(L)]) if "masks_0" in g else \
+        (lambda s: [g["masks"][s, k] for k in range(L)])
+    eval_masks = [g["eval_masks_%d" % k] for k in range(L)] if "masks_0" in g else list(g["eval_masks"])
     U, I = int(g["n_users"]), int(g["n_items"])
     R = sp.csr_matrix((g["train_data"], g["train_indices"], g["train_indptr"]), shape=(U, I))
     A = O.ngcf_adjacency(R, "norm")
     keep = 1 - h["mess_dropout_ratio"]
     # W_mlp_* exist (NGCF.py:283-286) but the ngcf graph never reads them: no gradient, never updated
     assert sorted(g["updated"].tolist()) == sorted(["user_embedding", "item_embedding"] +
-                                                   ["%s_%d" % (n, k) for n in NGCF_W for k in range(2)])
+                                                   ["%s_%d" % (n, k) for n in NGCF_W for k in range(L)])
     assert not g["sparse_update"].any()
     for w, dt, tol, tol_tab in WIDTHS:
         A_ = A.astype(dt)
         At = A_.T.tocsr()
         At.sort_indices()
         e = g["E0"].astype(dt)
-        W = [[g["%s_%d_0" % (nm, k)].astype(dt) for nm in NGCF_W] for k in range(2)]
+        W = [[g["%s_%d_0" % (nm, k)].astype(dt) for nm in NGCF_W] for k in range(L)]
         params = [e] + [x for ws in W for x in ws]
         ms, vs = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
         adam = O.Adam(h["learning_rate"], dtype=dt)
         losses, first = [], None
         for s, (u, p, n) in enumerate(_batches(g)):
-            masks = [g["masks"][s, k].astype(dt) for k in range(2)]
+            masks = [m.astype(dt) for m in step_masks(s)]
             loss, dE, wg = O.ngcf_loss_and_grads(A_, At, e, [tuple(ws) for ws in W], masks, keep, U, u, p, n,
                                                  h["reg"])
             if first is None:
@@ -171,15 +177,20 @@ def test_ngcf_restatement_equals_the_reference_graph(tag):
             losses.append(float(loss))
         assert _rel(losses, g[w + "_loss"]) <= tol
         _close(first[0], g[w + "_dE"], tol)
-        for k in range(2):
+        for k in range(L):
             for j, nm in enumerate(NGCF_W):
                 # a weight gradient is a 288-term fp32 reduction: numpy's and torch's summation orders
                 # differ by a few ulp of the sum
                 _close(first[1][k][j], g["%s_d%s_%d" % (w, nm, k)], 3 * tol)
-                _close(W[k][j], g["%s_%s_%d" % (w, nm, k)], tol_tab)
-        _close(e, g[w + "_E"], tol_tab)
+                # Adam moves a coordinate by ~lr whatever |g|: where fp32 does not resolve the gradient the update is
+                # rounding-order dependent — the reference's own fp32-vs-fp64 gap is the bar
+                key = "%s_%d" % (nm, k)
+                bar = 2 * float(np.abs(g["f32_" + key] - g["f64_" + key]).max()) if w == "f32" else 0.0
+                _close(W[k][j], g["%s_%s" % (w, key)], tol_tab + bar)
+        bar = 2 * float(np.abs(g["f32_E"] - g["f64_E"]).max()) if w == "f32" else 0.0
+        _close(e, g[w + "_E"], tol_tab + bar)
         # evaluate(): a forward pass with fresh dropout masks (always on, NGCF.py:193), then np.matmul
-        out, _ = O.ngcf_forward(A_, e, [tuple(ws) for ws in W], [mm.astype(dt) for mm in g["eval_masks"]], keep)
+        out, _ = O.ngcf_forward(A_, e, [tuple(ws) for ws in W], [mm.astype(dt) for mm in eval_masks], keep)
         _close(out[:U], g[w + "_eval_user_emb"], tol_tab)
         users = np.flatnonzero(np.diff(g["train_indptr"]) > 0)
         _close(out[users] @ out[U:].T, g[w + "_ratings"], tol_tab)
