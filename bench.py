@@ -144,6 +144,30 @@ def leg_ngcf(train, test, trc, tec, dev, with_cpu):
                         "note": "nnz*8 + (N+1)*4 + 2*N*16*4 B per pass (SURVEY 8d's SpMM formula at d = 16); the "
                                 "4.5 MB operand table is L2-sized, the pass is bound by the CSR stream and latency"},
            "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9])}}
+    # the NGCF paper's widths (embedding 64, layers [64, 64, 64]) on the width-generic engine
+    from neurec_amd.ngcf_wide import NGCFWideEngine
+    table64 = np.concatenate([e([U, 64]), e([I, 64])])
+    weights64 = [(w([64, 64]), w([1, 64]), w([64, 64]), w([1, 64])) for _ in range(3)]
+    wide = NGCFWideEngine(A, At, U, I, table64, weights64, lr, reg, drop, B)
+    it2 = iter(batches * 10)
+
+    def wide_step():
+        b = next(it2)
+        wide.step(b[0], b[1], b[2], loss, plan=b.plan)
+    wide_ms = _hip_timed(wide_step, 40, 8)
+    x64, y64 = wide.ego[0], wide.S[0]
+    spmm64_ms = _hip_timed(lambda: wide.A.matmul(x64, out=y64), 40, 5)
+    spmm64_bytes = wide.A.algorithmic_bytes(64)
+    out["wide"] = {"dim": 64, "layers": [64, 64, 64], "batch": B, "ms_per_step": wide_ms,
+                   "triplets_per_sec": B / wide_ms * 1e3,
+                   "roofline": {"bound": "hbm", "kernel": wide.A.full_pass_kernel(64), "bytes_per_launch": spmm64_bytes,
+                                "us_per_launch": spmm64_ms * 1e3, "launches_per_step": 6,
+                                "achieved": spmm64_bytes / spmm64_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": spmm64_bytes / spmm64_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                                "note": "3 forward + 3 backward SpMM passes at d = 64 per step; the dense layer products "
+                                        "run on the fp32 matrix cores (csrc/gemm.hip), the step is strung from ~70 "
+                                        "launches issued by Python"}}
+    del wide
     if with_cpu:
         from oracle import train as O
         rng = np.random.RandomState(3)

@@ -754,7 +754,9 @@ int nrhip_vae_sample_bwd(const float* d_dZ, const float* d_H2, const float* d_EP
                          float* d_dH2, void* stream);
 int nrhip_vae_softmax_dlogits(float* d_S, int64_t ld, int batch, int cols, const int64_t* d_indptr,
                               const int32_t* d_indices, const int32_t* d_rows, float* d_nll, void* stream);
-int nrhip_colsum_rows(const float* d_X, int64_t ld, int rows, int cols, float* d_out, void* stream);   /* bias grads */
+/* d_out[c] = sum_r d_X[r][c] (bias gradients), a fixed association; rows > 2048: d_ws of ceil(rows / 512) * cols floats */
+int nrhip_colsum_rows(const float* d_X, int64_t ld, int rows, int cols, float* d_out, void* d_ws, size_t ws_bytes,
+                      void* stream);
 int nrhip_vae_dwq0_wide(const int64_t* d_indptr, const int32_t* d_indices, const int32_t* d_rows, int batch,
                         int width, const float* d_h0val, const float* d_DA1, float* d_dWq0, void* stream);
 

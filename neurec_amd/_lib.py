@@ -142,7 +142,7 @@ SIGNATURES = {
     "nrhip_vae_sample_bwd": [p, p, p, i32, i32, f32, p, p],
     "nrhip_vae_softmax_dlogits": [p, i64, i32, i32, p, p, p, p, p],
     "nrhip_vae_dwq0_wide": [p, p, p, i32, i32, p, p, p, p],
-    "nrhip_colsum_rows": [p, i64, i32, i32, p, p],
+    "nrhip_colsum_rows": [p, i64, i32, i32, p, p, sz, p],
     "nrhip_ew_mul": [p, i64, p, i64, i64, i32, p, i64, p],
     "nrhip_ngcf_act_fwd": [p, p, i64, i64, i32, i32, f32, p, i32, u64, u64, i32, p, i64, p, i64, p],
     "nrhip_ngcf_act_bwd": [p, i64, p, i64, p, i64, p, p, i64, p, i64, i32, f32, p, p, p],

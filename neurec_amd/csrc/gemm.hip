@@ -179,7 +179,16 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
   if (e >= (int64_t)M * N) return;
   const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
   float acc = accumulate ? C[(int64_t)m * ldc + n] : 0.f;
-  for (int s = 0; s < splits; ++s) acc = acc + parts[(int64_t)s * split_stride + (int64_t)m * ldp + n];
+  const float* p = parts + (int64_t)m * ldp + n;
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {                      // eight loads in flight, added in split order
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(s + q) * split_stride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = acc + v[q];
+  }
+  for (; s < splits; ++s) acc = acc + p[(int64_t)s * split_stride];
   if (bias_n) acc = acc + bias_n[n];
   if (act >= 0) acc = epilogue_act(act, acc);
   C[(int64_t)m * ldc + n] = acc;

@@ -258,30 +258,49 @@ int nrhip_vae_dwq0_wide(const int64_t* d_indptr, const int32_t* d_indices, const
 }  // extern "C"
 
 namespace {
-// out[c] = sum_r X[r][c]: a block = 64 columns x 16 row groups; group g adds rows g, g + 16, ... in order, then the 16
-// partial sums are added in group order (a fixed association: deterministic)
+// out[chunk][c] = sum over the chunk's rows of X[r][c]: a block = 64 columns x 16 row groups; group g adds rows
+// g, g + 16, ... of the chunk in order, then the 16 partial sums are added in group order (a fixed association:
+// deterministic).  Tall inputs (NGCF's [N][w] gradients: 70,839 rows) are cut into chunks of rows_per_chunk rows —
+// grid.y — whose sums a second launch of the same kernel adds in chunk order.
 __global__ __launch_bounds__(1024) void colsum_rows_kernel(const float* __restrict__ X, int64_t ld, int rows, int cols,
-                                                           float* __restrict__ out) {
+                                                           int rows_per_chunk, float* __restrict__ out) {
   __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, cc = min(c, cols - 1);
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float acc = 0.f;
-  for (int r = g; r < rows; r += 16) acc = acc + X[(int64_t)r * ld + cc];
+  for (int r = r0 + g; r < r1; r += 16) acc = acc + X[(int64_t)r * ld + cc];
   part[g][lane] = acc;
   __syncthreads();
   if (g == 0 && c < cols) {
     float t = part[0][lane];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t = t + part[q][lane];
-    out[c] = t;
+    out[(int64_t)blockIdx.y * cols + c] = t;
   }
 }
 }  // namespace
 
-extern "C" int nrhip_colsum_rows(const float* d_X, int64_t ld, int rows, int cols, float* d_out, void* stream) {
+/* d_out[c] = sum_r d_X[r][c] (bias gradients).  rows > 2048 needs d_ws of ceil(rows / 512) * cols floats. */
+extern "C" int nrhip_colsum_rows(const float* d_X, int64_t ld, int rows, int cols, float* d_out, void* d_ws,
+                                 size_t ws_bytes, void* stream) {
   NR_REQUIRE(d_X && d_out && rows >= 0 && cols >= 1 && ld >= cols, NR_ERR_ARG, "colsum_rows: bad arguments");
-  hipLaunchKernelGGL(colsum_rows_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, d_X, ld, rows,
-                     cols, d_out);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned bx = (unsigned)((cols + 63) / 64);
+  if (rows <= 2048) {
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(bx, 1), dim3(1024), 0, st, d_X, ld, rows, cols, rows > 0 ? rows : 1,
+                       d_out);
+    NR_LAUNCH_CHECK();
+    return NR_OK;
+  }
+  const int per = 512, chunks = (rows + per - 1) / per;
+  NR_REQUIRE(d_ws && ws_bytes >= (size_t)chunks * cols * sizeof(float), NR_ERR_WORKSPACE,
+             "colsum_rows: workspace %zu < %zu", ws_bytes, (size_t)chunks * cols * sizeof(float));
+  NR_REQUIRE(chunks <= 65535, NR_ERR_UNSUPPORTED, "colsum_rows: %d rows", rows);
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(bx, chunks), dim3(1024), 0, st, d_X, ld, rows, cols, per, (float*)d_ws);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(bx, 1), dim3(1024), 0, st, (const float*)d_ws, (int64_t)cols, chunks,
+                     cols, chunks, d_out);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -83,7 +83,8 @@ class NGCFWideEngine:
         self.rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
         self.flag = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.max_batch = max_batch
-        self.splits = 64                                            # cuts of the N-long contractions of dW
+        self.cs_ws = z(((N + 511) // 512) * wmax)                   # chunk sums of the bias gradients
+        self.splits = 192                                           # cuts of the N-long contractions of dW
         nbytes = C.c_size_t(0)
         call("nrhip_gemm_workspace_bytes", wmax, wmax, self.splits, C.byref(nbytes))
         self.ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
@@ -155,8 +156,8 @@ class NGCFWideEngine:
             # weight gradients: contractions over the N rows, both operands k-major as stored
             self._gemm(self.S[k], pi, self.dT1, wo, wi, wo, N, gWg, wo, splits=self.splits)
             self._gemm(self.X2[k], pi, self.dT2, wo, wi, wo, N, gWb, wo, splits=self.splits)
-            call("nrhip_colsum_rows", _ptr(self.dT1), wo, N, wo, _ptr(gbg), _stream())
-            call("nrhip_colsum_rows", _ptr(self.dT2), wo, N, wo, _ptr(gbb), _stream())
+            call("nrhip_colsum_rows", _ptr(self.dT1), wo, N, wo, _ptr(gbg), _ptr(self.cs_ws), self.cs_ws.numel() * 4, _stream())
+            call("nrhip_colsum_rows", _ptr(self.dT2), wo, N, wo, _ptr(gbb), _ptr(self.cs_ws), self.cs_ws.numel() * 4, _stream())
             # Y1 = dT1 W_gc^T, Y2 = dT2 W_bi^T
             self._transpose(self.dT1, wo, N, wo, self.tA, N)
             self._transpose(Wg, wo, wi, wo, self.tW, wi)

@@ -92,7 +92,7 @@ class MultiVAEWideEngine:
         """dX = dA W^T (both operands transposed first), dW = X^T dA (both k-major as stored), db = column sums."""
         K, N = W.shape
         self._gemm(X, K, dA, N, K, N, B, dW, N, splits=self.mid_splits if B >= 256 else 1)
-        call("nrhip_colsum_rows", _ptr(dA), N, B, N, _ptr(db), _stream())
+        call("nrhip_colsum_rows", _ptr(dA), N, B, N, _ptr(db), None, 0, _stream())
         self._transpose(dA, N, B, N, self.tD, self.B)
         self._transpose(W, N, K, N, self.tW, K)
         self._gemm(self.tD, self.B, self.tW, K, B, K, N, dX, K)
@@ -147,7 +147,7 @@ class MultiVAEWideEngine:
         iWq, ibq, iWp, ibp = 0, n, 2 * n, 3 * n                                           # offsets into params / G
         # last decoder layer on the matrix cores
         self._gemm(g_last, h, S, ld, h, I, B, self.G[iWp + n - 1], I)                      # dW = g^T D
-        call("nrhip_colsum_rows", _ptr(S), ld, B, I, _ptr(self.G[ibp + n - 1]), _stream())
+        call("nrhip_colsum_rows", _ptr(S), ld, B, I, _ptr(self.G[ibp + n - 1]), None, 0, _stream())
         self._transpose(S, ld, B, I, self.DT, self.B)
         self._transpose(self.Wp[-1], I, h, I, self.WT, h)
         dg = self.dGp[-1] if n > 1 else self.dZ
@@ -171,7 +171,7 @@ class MultiVAEWideEngine:
         w0 = self.Wq[0].shape[1]
         call("nrhip_vae_dwq0_wide", _ptr(csr.indptr), _ptr(csr.indices), _ptr(rows, torch.int32), B, w0,
              _ptr(self.h0val), _ptr(d), _ptr(self.G[iWq]), _stream())                     # G[Wq0] is zero here
-        call("nrhip_colsum_rows", _ptr(d), w0, B, w0, _ptr(self.G[ibq]), _stream())
+        call("nrhip_colsum_rows", _ptr(d), w0, B, w0, _ptr(self.G[ibq]), None, 0, _stream())
         if want_loss:
             E.mean_f32(self.nll[:B], self.stats[0:1])
             E.mean_f32(self.KLb[:B], self.stats[1:2])

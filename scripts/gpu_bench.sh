@@ -21,3 +21,9 @@ d=json.load(open("gpurun_out/r03/$tag.json"))
 w=(d.get("multivae") or {}).get("wide")
 if w: print("multivae wide", w["p_dim"], "ms/step", w["ms_per_step"], "item layer us", w["roofline"]["us_per_step"], "TFLOP/s", w["roofline"]["achieved"], "frac", w["roofline"]["frac"])
 PY
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r03/$tag.json"))
+w=(d.get("ngcf") or {}).get("wide")
+if w: print("ngcf wide", w["dim"], w["layers"], "ms/step", w["ms_per_step"], "spmm us", w["roofline"]["us_per_launch"], "frac", w["roofline"]["frac"])
+PY
