@@ -773,7 +773,11 @@ __global__ __launch_bounds__(256) void vae_small_wgrad_kernel(const float* __res
   }
 }
 
-// dW_q0[item][:] += h0[b][item]·da1[b][:] over the batch's CSR entries (scatter, fp32 atomics)
+// dW_q0[item][:] += h0[b][item]·da1[b][:] over the batch's CSR entries (scatter, fp32 atomics).
+// grid (batch row, 16 chunk slots): a wave takes 16-item chunks of ITS row, slot + 64 apart — a long row is spread over
+// up to 64 waves instead of one wave issuing its atomics one item after the other (the first form: 512 waves, the
+// longest row's ~1,000 atomics in a chain, 25.6 us) — and with h <= 32 the two wave halves take two items at a time.
+constexpr int kDwq0Chunk = 16, kDwq0SlotsY = 16;
 __global__ __launch_bounds__(256) void vae_dwq0_kernel(const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,
                                                        const int32_t* __restrict__ rows, int batch,
@@ -781,20 +785,24 @@ __global__ __launch_bounds__(256) void vae_dwq0_kernel(const int64_t* __restrict
                                                        const float* __restrict__ DA1,
                                                        float* __restrict__ dWq0) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= batch) return;
+  const int r = blockIdx.x;
   const int64_t u = rows[r];
-  const float g = lane < h ? DA1[(int64_t)r * h + lane] : 0.f;
   const int64_t b = indptr[u], e = indptr[u + 1];
-  for (int64_t t0 = b; t0 < e; t0 += NR_WAVE) {          // 64 (item, value) pairs per coalesced load
-    const int nn = (int)min((int64_t)NR_WAVE, e - t0);
+  const int n = (int)(e - b);
+  const int per = h <= 32 ? 2 : 1;                          // items per wave iteration
+  const int col = per == 2 ? (lane & 31) : lane, half = per == 2 ? (lane >> 5) : 0;
+  const float g = col < h ? DA1[(int64_t)r * h + col] : 0.f;
+  for (int c = blockIdx.y * 4 + wave; c * kDwq0Chunk < n; c += 4 * kDwq0SlotsY) {
+    const int64_t t0 = b + (int64_t)c * kDwq0Chunk;
+    const int nn = (int)min((int64_t)kDwq0Chunk, e - t0);
     int my_item = 0;
     float my_val = 0.f;
     if (lane < nn) { my_item = indices[t0 + lane]; my_val = h0val[t0 + lane]; }
-    for (int s = 0; s < nn; ++s) {
-      const int item = __builtin_amdgcn_readlane(my_item, s);
-      const float val = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), s));
-      if (lane < h) atomicAdd(&dWq0[(int64_t)item * h + lane], val * g);
+    for (int s = 0; s < nn; s += per) {
+      const int idx = s + half;
+      const int item = __shfl(my_item, idx & 63, NR_WAVE);
+      const float val = __shfl(my_val, idx & 63, NR_WAVE);
+      if (idx < nn && col < h) atomicAdd(&dWq0[(int64_t)item * h + col], val * g);
     }
   }
 }
@@ -981,7 +989,7 @@ int nrhip_vae_dwq0(const int64_t* d_indptr, const int32_t* d_indices, const int3
                  h >= 1 && h <= kMaxD,
              NR_ERR_ARG, "vae_dwq0: bad arguments");
   if (batch == 0) return NR_OK;
-  hipLaunchKernelGGL(vae_dwq0_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(vae_dwq0_kernel, dim3(batch, kDwq0SlotsY), dim3(256), 0, (hipStream_t)stream,
                      d_indptr, d_indices, d_rows, batch, h, d_h0val, d_DA1, d_dWq0);
   NR_LAUNCH_CHECK();
   return NR_OK;

@@ -232,6 +232,8 @@ class ScoreGemm:
         if plan is not None:
             if plan.cols != self.cols:
                 raise ValueError("strike plan built for %d items, scoring %d" % (plan.cols, self.cols))
+            if callable(row_of):              # built while the scoring loop already runs (the fix-up alone reads it)
+                row_of = row_of()
             call("nrhip_score_tilemax_fix", _ptr(user_table, torch.float32), user_table.stride(0), self.d, self.cols,
                  _ptr(plan.chunk_tile, torch.int32), _ptr(plan.chunk_begin, torch.int64), plan.n_chunks,
                  _ptr(plan.tile_ptr, torch.int64), _ptr(plan.user, torch.int32), _ptr(plan.mask, torch.int32),

@@ -47,6 +47,17 @@ from . import parallel
 _ATOMIC_HEADS = os.environ.get("NRHIP_ATOMIC_SCATTER", "") == "1"
 
 
+def _compact_plan(engine, B):
+    """The batch plan of the compact head block (users = rows 0..B-1, positives B..2B-1, negatives 2B..3B-1: every
+    occurrence has its own row) depends on B alone: built once per batch length instead of once per step."""
+    cache = engine.__dict__.setdefault("_compact_plans", {})
+    if B not in cache:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ar = torch.arange(B, dtype=torch.int32, device=dev)
+        cache[B] = E.bpr_plan(ar, ar, (ar + B).contiguous(), B, B).clone()
+    return cache[B]
+
+
 class RowRouter:
     """Requests for table rows by global node id -> owners and back, for block-partitioned tables.  The index
     bookkeeping of a step is two native calls (csrc/route.hip): `request` (requests in owner order + the inverse
@@ -331,7 +342,7 @@ class ShardedLightGCN:
             gs.zero_()
             gr.zero_()
         E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B], (self._cp[:B] + B).contiguous(),
-                            self.reg, gs, gr, self.terms, loss_out, divided=self._pow2)
+                            self.reg, gs, gr, self.terms, loss_out, divided=self._pow2, plan=_compact_plan(self, B))
         # --- gradient rows back to the owners (routed order), added there in the order of the global batch
         back = torch.empty((3 * B, 2 * d), dtype=torch.float32, device=dev)
         E.rows_gather(rt.order, gs, back[:, :d])
@@ -427,7 +438,7 @@ class ShardedMF:
         if _ATOMIC_HEADS:
             self._gcat[:3 * B].zero_()
         E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], (self._ar[:B] + B).contiguous(), self.reg,
-                      gP, gQ, self.terms, loss_out)
+                      gP, gQ, self.terms, loss_out, _compact_plan(self, B))
         back = torch.empty((3 * B, d), dtype=torch.float32, device=self.T.device)
         E.rows_gather(rt.order, self._gcat[:3 * B], back)                       # routed order
         mine, _ = self.comm.all_to_all_rows(back, rt.send_counts, rt.recv_counts)  # exchange 3: gradients

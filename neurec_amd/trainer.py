@@ -565,8 +565,14 @@ class FullRankEvaluator:
             if self._plan is None or self._plan.cols != item_table.shape[0]:
                 self._plan = E.TileStrikePlan(self.train, item_table.shape[0])
             plan = self._plan
-            row_of = torch.full((self.train.n_rows,), -1, dtype=torch.int32, device=test_users.device)
-            row_of[test_users.long()] = torch.arange(n, dtype=torch.int32, device=test_users.device)
+            made = []
+
+            def row_of():                     # enqueued behind the first scoring launch: the GPU is busy by then
+                if not made:
+                    t = torch.full((self.train.n_rows,), -1, dtype=torch.int32, device=test_users.device)
+                    t[test_users.long()] = torch.arange(n, dtype=torch.int32, device=test_users.device)
+                    made.append(t)
+                return made[0]
         for b in starts:
             u = test_users[b:b + self.batch_rows]
             M = self._gemm.tile_maxima(user_table, u, self.train, plan=plan, row_of=row_of, row_lo=b)
