@@ -285,5 +285,6 @@ def test_planned_strikes_leave_the_same_tile_maxima_as_the_in_loop_strikes(d, U,
     if not shuffle:                                     # row = user without a lookup table
         want = gemm.tile_maxima(Pd[:256].contiguous(), None, trc).clone()
         got = gemm.tile_maxima(Pd[:256].contiguous(), None, trc, plan=plan)
-        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy())
+        n_t = (I + 31) // 32                            # columns beyond the tiles are padding (never written)
+        np.testing.assert_array_equal(got.cpu().numpy()[:, :n_t], want.cpu().numpy()[:, :n_t])
         assert np.isneginf(got.cpu().numpy()[5, 2])
