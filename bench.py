@@ -93,6 +93,19 @@ def _cpu_timed(step, budget=6.0, max_steps=8):
     return (time.perf_counter() - t0) / n, n
 
 
+def _median_wall(fn, runs=5):
+    """(median seconds, last result) of whole host-side calls bracketed by device synchronisation"""
+    import torch
+    ts, out = [], None
+    for _ in range(runs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2], out
+
+
 def leg_ngcf(train, test, trc, tec, dev, with_cpu):
     """BASELINE configs[4], NGCF half (conf/NGCF.properties: embedding 16, layers [16, 16], B = 512, `norm`
     adjacency, message dropout 0.1) on the run's interactions: step time, the roofline of its dominant
@@ -130,11 +143,7 @@ def leg_ngcf(train, test, trc, tec, dev, with_cpu):
         eu, ei = ng.final_embeddings()
         return ev.evaluate_factors(eu.contiguous(), ei.contiguous(), users)
     evaluate()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m = evaluate()
-    torch.cuda.synchronize()
-    edt = time.perf_counter() - t0
+    edt, m = _median_wall(evaluate)
     out = {"ms_per_step": ms, "triplets_per_sec": B / ms * 1e3, "batch": B, "dim": 16, "layers": [16, 16],
            "adjacency_nnz": int(A.nnz), "launches": "one native call per step (nrhip_ngcf_step: ~27 launches)",
            "roofline": {"bound": "hbm", "kernel": ng.A.full_pass_kernel(16), "bytes_per_launch": spmm_bytes,
@@ -230,11 +239,7 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
         pf, qf = vae.eval_factors()
         return ev.evaluate_factors(pf, qf, users)
     evaluate()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m = evaluate()
-    torch.cuda.synchronize()
-    edt = time.perf_counter() - t0
+    edt, m = _median_wall(evaluate)
     out = {"ms_per_step": ms, "users_per_sec_train": B / ms * 1e3, "batch": B, "p_dim": [z, h],
            "roofline": {"bound": "hbm", "kernel": "vae_softmax_stats_kernel + vae_dwp1_mfma_kernel + vae_dg1_mfma_kernel "
                                                   "(nrhip_vae_decoder_loss_grad)",
@@ -755,11 +760,7 @@ def main():
             mf_ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch,
                                       pruned=args.eval_mode == "pruned")
             mf_ev.evaluate_factors(mf.P, mf.Q, tu)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            mm = mf_ev.evaluate_factors(mf.P, mf.Q, tu)
-            torch.cuda.synchronize()
-            mf_edt = time.perf_counter() - t0
+            mf_edt, mm = _median_wall(lambda: mf_ev.evaluate_factors(mf.P, mf.Q, tu))
             mf_info["eval"] = {"users_per_sec": tu.numel() / mf_edt, "ms": mf_edt * 1e3, "n_users": int(tu.numel()),
                                "ndcg@10": float(mm[2 * 20 + 9])}
             del mf_ev

@@ -733,7 +733,8 @@ int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const 
 /* C[m][n] (+)= sum_k A[k][m] * B[k][n]; A [K][lda], B [K][ldb] (contraction index slow), C [M][ldc]; every element the
  * k-ascending fmaf chain (continued from C when accumulate); splits > 1 cuts K into ranges whose partial products
  * (d_ws: nrhip_gemm_workspace_bytes) are added in order.  Epilogue: + d_bias_n[n] (NULL: none), then `act` (-1: none) —
- * a dense layer y = act(x W + b) is one call with A = x^T. */
+ * a dense layer y = act(x W + b) is one call with A = x^T.  lda, ldb < 2^24 elements (operand rows are addressed through
+ * buffer resources with 32-bit byte offsets); K = 0 leaves C (+)= 0 followed by the epilogue. */
 int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes);
 int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int M, int N, int K, float* d_C,
                       int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits, void* d_ws,

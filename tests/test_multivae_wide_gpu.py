@@ -195,3 +195,25 @@ def test_gemm_epilogue_is_bias_then_activation(M, N, K, splits, act):
         assert np.array_equal(got, want)                     # the fmaf chain, one rounded add of the bias, max(., 0)
     else:
         assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K)
+
+
+def test_gemm_edge_cases():
+    """empty contraction (C = bias, activation applied), empty outputs, accumulate over an empty contraction, and the
+    leading-dimension bound of the buffer-addressed operand loads"""
+    import torch
+    from neurec_amd._lib import call
+    from neurec_amd.engine import _ptr, _stream
+    A = torch.zeros((1, 8), device="cuda")
+    Bm = torch.zeros((1, 5), device="cuda")
+    bias = torch.tensor([-2.0, -1.0, 0.0, 1.0, 2.0], device="cuda")
+    out = torch.full((8, 5), 3.0, device="cuda")
+    call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 8, 5, 0, _ptr(out), 5, 0, _ptr(bias), 2, 1, None, 0, _stream())
+    assert torch.equal(out, torch.tensor([0.0, 0.0, 0.0, 1.0, 2.0], device="cuda").expand(8, 5))
+    out.fill_(3.0)
+    call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 8, 5, 0, _ptr(out), 5, 1, None, -1, 1, None, 0, _stream())
+    assert torch.equal(out, torch.full((8, 5), 3.0, device="cuda"))
+    call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 0, 5, 1, _ptr(out), 5, 0, None, -1, 1, None, 0, _stream())   # M = 0
+    with pytest.raises(ValueError):
+        call("nrhip_gemm_kmajor", _ptr(A), 1 << 24, _ptr(Bm), 5, 8, 5, 1, _ptr(out), 5, 0, None, -1, 1, None, 0, _stream())
+    with pytest.raises(Exception):                           # splits without a workspace
+        call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 8, 5, 1, _ptr(out), 5, 0, None, -1, 4, None, 0, _stream())
