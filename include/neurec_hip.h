@@ -653,8 +653,31 @@ int nrhip_route_batch(const int32_t* d_users, const int32_t* d_pos, const int32_
 int nrhip_route_owner_keys(const int32_t* d_rows, const int32_t* d_codes, int n, const int32_t* d_recv_prefix,
                            const int32_t* d_size_off, int world, int global_batch, int code_base,
                            uint64_t* d_keys_out, int32_t* d_index_of_pos, void* stream);
+/* The same two tables for EVERY batch of an epoch stream at once (the ids of an epoch are known when it starts —
+ * data/sampler.py:196-213 draws them up front): a step then issues no routing launch at all.
+ *   nrhip_sort_u64_segments        n_segs independent segments sorted in one launch (each <= 16384 keys)
+ *   nrhip_route_epoch              batch k's requests live in slot [3*batch*k, 3*batch*(k+1)) of d_keys / d_packed /
+ *                                  d_order / d_inv (d_seg_off[k] = 3*batch*k, d_seg_len[k] = 3 * that batch's length);
+ *                                  d_counts [n_batches][world]
+ *   nrhip_route_epoch_owner_keys   the received stream laid out [batch][source rank]: d_asked_off / d_asked_len per
+ *                                  batch, d_batch_of[j], per batch d_recv_prefix [world + 1], d_size_off [world],
+ *                                  d_global_len; d_index_of_pos has iop_stride entries per batch */
+int nrhip_sort_u64_segments(uint64_t* d_keys, const int64_t* d_seg_off, const int32_t* d_seg_len, int n_segs,
+                            int max_len, void* stream);
+int nrhip_route_epoch(const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int64_t n, int batch,
+                      int n_users, int bu, int bi, int code_base, int world, uint64_t* d_keys, int32_t* d_packed,
+                      int32_t* d_order, int32_t* d_inv, int32_t* d_counts, const int64_t* d_seg_off,
+                      const int32_t* d_seg_len, void* stream);
+int nrhip_route_epoch_owner_keys(const int32_t* d_rows, const int32_t* d_codes, const int32_t* d_batch_of, int64_t n,
+                                 const int64_t* d_asked_off, const int32_t* d_asked_len, int n_batches, int max_asked,
+                                 const int32_t* d_recv_prefix, const int32_t* d_size_off,
+                                 const int32_t* d_global_len, int world, int code_base, int64_t iop_stride,
+                                 uint64_t* d_keys_out, int32_t* d_index_of_pos, void* stream);
 int nrhip_rows_sum_sorted(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
                           const float* d_src, int64_t ld_src, float* d_dst, void* stream);
+int nrhip_rows_sum_sorted2(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
+                           const float* d_src_a, int64_t ld_a, float* d_dst_a, const float* d_src_b, int64_t ld_b,
+                           float* d_dst_b, void* stream);                          /* two tables, same runs, one launch */
 int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
                             uint8_t* d_row_flag, int64_t n_rows, int d, float lr, float hyper1,
                             float hyper2, float eps, void* stream);
@@ -666,7 +689,11 @@ int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slo
 int nrhip_rows_gather(const int32_t* d_rows, int n_listed, int d, const float* d_src, float* d_dst,
                       int64_t ld_dst, void* stream);
 int nrhip_rows_gather_ld(const int32_t* d_rows, int n_listed, int d, const float* d_src, int64_t ld_src,
-                         float* d_dst, int64_t ld_dst, void* stream);   /* d_src rows ld_src floats apart */
+                         float* d_dst, int64_t ld_dst, void* stream);
+/* two tables, one row list, one launch: d_dst_a[w] = d_src_a[d_rows[w]], d_dst_b[w] = d_src_b[d_rows[w]] */
+int nrhip_rows_gather2(const int32_t* d_rows, int n_listed, int d, const float* d_src_a, int64_t ld_a,
+                       const float* d_src_b, int64_t ld_b, float* d_dst_a, int64_t ldd_a, float* d_dst_b,
+                       int64_t ldd_b, void* stream);   /* d_src rows ld_src floats apart */
 int nrhip_rows_scatter_add(const int32_t* d_rows, int n_listed, int d, const float* d_src,
                            int64_t ld_src, float* d_dst, void* stream);
 

@@ -149,6 +149,9 @@ SIGNATURES = {
     "nrhip_ngcf_mix_bwd": [p, p, i64, p, p, i64, i64, i32, i32, p, p, p],
     "nrhip_route_batch": [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p],
     "nrhip_route_owner_keys": [p, p, i32, p, p, i32, i32, i32, p, p, p],
+    "nrhip_sort_u64_segments": [p, p, p, i32, i32, p],
+    "nrhip_route_epoch": [p, p, p, i64, i32, i32, i32, i32, i32, i32, p, p, p, p, p, p, p, p],
+    "nrhip_route_epoch_owner_keys": [p, p, p, i64, p, p, i32, i32, p, p, p, i32, i32, i64, p, p, p],
     "nrhip_bpr_mf_step_fused": [p, p, p, p, p, p, i32, f32, f32, f32, i32, i32, i32, p, p, p, i32, f32, p, p, p,
                                 i32, p, i32, i32, p],
     "nrhip_bpr_mf_fused_flush": [p, p, p, p, p, i32, f32, f32, f32, i32, i64, p],
@@ -194,9 +197,11 @@ SIGNATURES = {
     "nrhip_mark_rows": [p, i32, i32, p, p],
     "nrhip_sort_u64": [p, i32, p],
     "nrhip_rows_sum_sorted": [p, i32, p, i32, p, i64, p, p],
+    "nrhip_rows_sum_sorted2": [p, i32, p, i32, p, i64, p, p, i64, p, p],
     "nrhip_optimizer_rows_tf": [i32, p, p, p, p, p, i64, i32, f32, f32, f32, f32, p],
     "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
     "nrhip_rows_gather_ld": [p, i32, i32, p, i64, p, i64, p],
+    "nrhip_rows_gather2": [p, i32, i32, p, i64, p, i64, p, i64, p, i64, p],
     "nrhip_rows_scatter_add": [p, i32, i32, p, i64, p, p],
     "nrhip_scale": [p, f32, p, i64, p],
     "nrhip_add": [p, p, p, i64, p],

@@ -280,6 +280,22 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const int32_t* __restr
   const int64_t r = rows[w];
   for (int k = lane; k < d; k += 64) dst[(int64_t)w * ld_dst + k] = src[r * ld_src + k];
 }
+// the same for two tables with one row list (a row-sharded step looks its rows up in Esum AND E0, and sends two
+// gradient rows per occurrence back: one launch per pair)
+__global__ __launch_bounds__(256) void rows_gather2_kernel(const int32_t* __restrict__ rows, int n_listed, int d,
+                                                           const float* __restrict__ src_a, int64_t ld_a,
+                                                           const float* __restrict__ src_b, int64_t ld_b,
+                                                           float* __restrict__ dst_a, int64_t ldd_a,
+                                                           float* __restrict__ dst_b, int64_t ldd_b) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= n_listed) return;
+  const int64_t r = rows[w];
+  for (int k = lane; k < d; k += 64) {
+    const float a = src_a[r * ld_a + k], b = src_b[r * ld_b + k];
+    dst_a[(int64_t)w * ldd_a + k] = a;
+    dst_b[(int64_t)w * ldd_b + k] = b;
+  }
+}
 __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int32_t* __restrict__ rows,
                                                                int n_listed, int d,
                                                                const float* __restrict__ src,
@@ -596,6 +612,19 @@ int nrhip_rows_gather_ld(const int32_t* d_rows, int n_listed, int d, const float
   if (n_listed == 0) return NR_OK;
   hipLaunchKernelGGL(rows_gather_kernel, dim3((n_listed + 3) / 4), dim3(256), 0,
                      (hipStream_t)stream, d_rows, n_listed, d, d_src, ld_src, d_dst, ld_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* d_dst_a[w] = d_src_a[d_rows[w]] and d_dst_b[w] = d_src_b[d_rows[w]] in one launch (row strides as given) */
+int nrhip_rows_gather2(const int32_t* d_rows, int n_listed, int d, const float* d_src_a, int64_t ld_a,
+                       const float* d_src_b, int64_t ld_b, float* d_dst_a, int64_t ldd_a, float* d_dst_b,
+                       int64_t ldd_b, void* stream) {
+  NR_REQUIRE(d_rows && d_src_a && d_src_b && d_dst_a && d_dst_b && n_listed >= 0 && d >= 1 && ld_a >= d && ld_b >= d &&
+                 ldd_a >= d && ldd_b >= d, NR_ERR_ARG, "rows_gather2: bad arguments");
+  if (n_listed == 0) return NR_OK;
+  hipLaunchKernelGGL(rows_gather2_kernel, dim3((n_listed + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_rows,
+                     n_listed, d, d_src_a, ld_a, d_src_b, ld_b, d_dst_a, ldd_a, d_dst_b, ldd_b);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -1053,6 +1053,39 @@ __global__ __launch_bounds__(kPlanThreads) void sort_u64_kernel(uint64_t* __rest
   for (int k = threadIdx.x; k < n; k += kPlanThreads) keys[k] = s_key[k];
 }
 
+// The same network over MANY independent segments in one launch (the routing tables of a whole epoch: one segment per
+// batch): workgroup s sorts keys[off[s] .. off[s] + len[s]) in its LDS.
+__global__ __launch_bounds__(kPlanThreads) void sort_u64_segments_kernel(uint64_t* __restrict__ keys,
+                                                                         const int64_t* __restrict__ seg_off,
+                                                                         const int32_t* __restrict__ seg_len) {
+  extern __shared__ uint64_t s_key[];
+  uint64_t* k0 = keys + seg_off[blockIdx.x];
+  const int n = seg_len[blockIdx.x];
+  if (n <= 1) return;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  for (int k = threadIdx.x; k < np2; k += kPlanThreads) s_key[k] = k < n ? k0[k] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (np2 >> 1); i += kPlanThreads) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const uint64_t a = s_key[lo], b = s_key[hi];
+        if ((a > b) == ((lo & k) == 0)) {
+          s_key[lo] = b;
+          s_key[hi] = a;
+        }
+      }
+      const int j_next = j > 1 ? (j >> 1) : k;
+      if (j > NR_WAVE || j_next > NR_WAVE) __syncthreads();
+      else __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n; k += kPlanThreads) k0[k] = s_key[k];
+}
+
 // ---- batches beyond one workgroup's LDS: a segmented multi-workgroup sort -----------------------
 // Segments are the plan's (batch, side) key ranges, or one plain array.  The network is the
 // all-ascending bitonic form — a merge of size k is one "flip" (partner = mirror position inside
@@ -1170,20 +1203,24 @@ __global__ __launch_bounds__(256) void seg_global_kernel(uint64_t* __restrict__ 
   }
 }
 
+// src_b / dst_b (optional): a second table summed along the same runs in the same launch (a row-sharded LightGCN step
+// receives two gradient rows per occurrence: dLoss/dE* and the regulariser's row)
 template <int CPL>
 __global__ __launch_bounds__(256) void rows_sum_sorted_kernel(const uint64_t* __restrict__ skey, int n,
                                                               const int32_t* __restrict__ index_of_pos,
                                                               int d, const float* __restrict__ src,
-                                                              int64_t ld_src, float* __restrict__ dst) {
+                                                              int64_t ld_src, float* __restrict__ dst,
+                                                              const float* __restrict__ src_b, int64_t ld_b,
+                                                              float* __restrict__ dst_b) {
   const int lane = nr_lane();
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n) return;
   const uint64_t key = plan_key(skey, s);
   const uint32_t row = (uint32_t)(key >> 32);
   if (s > 0 && (uint32_t)(plan_key(skey, s - 1) >> 32) == row) return;
-  float acc[CPL];
+  float acc[CPL], acb[CPL];
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  for (int c = 0; c < CPL; ++c) acc[c] = acb[c] = 0.f;
   for (int t = 0; s + t < n; ++t) {
     const uint64_t k2 = t == 0 ? key : plan_key(skey, s + t);
     if ((uint32_t)(k2 >> 32) != row) break;
@@ -1191,13 +1228,19 @@ __global__ __launch_bounds__(256) void rows_sum_sorted_kernel(const uint64_t* __
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int k = lane + c * NR_WAVE;
-      if (k < d) acc[c] = t == 0 ? src[i * ld_src + k] : acc[c] + src[i * ld_src + k];
+      if (k < d) {
+        acc[c] = t == 0 ? src[i * ld_src + k] : acc[c] + src[i * ld_src + k];
+        if (src_b) acb[c] = t == 0 ? src_b[i * ld_b + k] : acb[c] + src_b[i * ld_b + k];
+      }
     }
   }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
-    if (k < d) dst[(int64_t)row * d + k] = acc[c];
+    if (k < d) {
+      dst[(int64_t)row * d + k] = acc[c];
+      if (src_b) dst_b[(int64_t)row * d + k] = acb[c];
+    }
   }
 }
 
@@ -1335,27 +1378,66 @@ int nrhip_sort_u64(uint64_t* d_keys, int n, void* stream) {
   return NR_OK;
 }
 
+/* In-place ascending sort of n_segs independent segments in ONE launch: segment s = d_keys[d_seg_off[s] ..
+ * d_seg_off[s] + d_seg_len[s]), every length <= max_len <= 16384 (one workgroup's LDS per segment). */
+int nrhip_sort_u64_segments(uint64_t* d_keys, const int64_t* d_seg_off, const int32_t* d_seg_len, int n_segs,
+                            int max_len, void* stream) {
+  NR_REQUIRE(n_segs >= 0 && max_len >= 0 && (n_segs == 0 || (d_keys && d_seg_off && d_seg_len)), NR_ERR_ARG,
+             "sort_u64_segments: bad arguments");
+  NR_REQUIRE(max_len <= kPlanMaxKeys, NR_ERR_UNSUPPORTED, "sort_u64_segments: segments of %d keys (> %d)", max_len,
+             kPlanMaxKeys);
+  if (n_segs == 0 || max_len <= 1) return NR_OK;
+  static std::atomic<bool> attr[64];
+  int dev = 0;
+  NR_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr[dev].load(std::memory_order_acquire)) {
+    NR_CHECK_HIP(hipFuncSetAttribute((const void*)sort_u64_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kPlanMaxKeys * (int)sizeof(uint64_t)));
+    if (dev >= 0 && dev < 64) attr[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(sort_u64_segments_kernel, dim3((unsigned)n_segs), dim3(kPlanThreads),
+                     (size_t)plan_pow2(max_len) * sizeof(uint64_t), (hipStream_t)stream, d_keys, d_seg_off, d_seg_len);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
 /* d_dst[row] = sum of the source rows of the row's run in the SORTED keys (row << 32 | position),
  * added in key order (the first one stored, the rest added); source row of a key =
  * d_src[d_index_of_pos[position]].  Rows of d_dst outside the keys are left alone. */
-int nrhip_rows_sum_sorted(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
-                          const float* d_src, int64_t ld_src, float* d_dst, void* stream) {
-  NR_REQUIRE(d_sorted_keys && d_index_of_pos && d_src && d_dst && n >= 0 && d >= 1 && d <= 256 &&
-                 ld_src >= d, NR_ERR_ARG, "rows_sum_sorted: bad arguments");
+static int rows_sum_sorted_launch(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
+                                  const float* d_src, int64_t ld_src, float* d_dst, const float* d_src_b, int64_t ld_b,
+                                  float* d_dst_b, void* stream) {
   if (n == 0) return NR_OK;
   dim3 grid((n + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (d <= 64)
     hipLaunchKernelGGL(rows_sum_sorted_kernel<1>, grid, block, 0, st, d_sorted_keys, n, d_index_of_pos, d,
-                       d_src, ld_src, d_dst);
+                       d_src, ld_src, d_dst, d_src_b, ld_b, d_dst_b);
   else if (d <= 128)
     hipLaunchKernelGGL(rows_sum_sorted_kernel<2>, grid, block, 0, st, d_sorted_keys, n, d_index_of_pos, d,
-                       d_src, ld_src, d_dst);
+                       d_src, ld_src, d_dst, d_src_b, ld_b, d_dst_b);
   else
     hipLaunchKernelGGL(rows_sum_sorted_kernel<4>, grid, block, 0, st, d_sorted_keys, n, d_index_of_pos, d,
-                       d_src, ld_src, d_dst);
+                       d_src, ld_src, d_dst, d_src_b, ld_b, d_dst_b);
   NR_LAUNCH_CHECK();
   return NR_OK;
+}
+
+int nrhip_rows_sum_sorted(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
+                          const float* d_src, int64_t ld_src, float* d_dst, void* stream) {
+  NR_REQUIRE(d_sorted_keys && d_index_of_pos && d_src && d_dst && n >= 0 && d >= 1 && d <= 256 &&
+                 ld_src >= d, NR_ERR_ARG, "rows_sum_sorted: bad arguments");
+  return rows_sum_sorted_launch(d_sorted_keys, n, d_index_of_pos, d, d_src, ld_src, d_dst, nullptr, 0, nullptr, stream);
+}
+
+/* two tables along the same runs in one launch: d_dst_a[row] from d_src_a, d_dst_b[row] from d_src_b */
+int nrhip_rows_sum_sorted2(const uint64_t* d_sorted_keys, int n, const int32_t* d_index_of_pos, int d,
+                           const float* d_src_a, int64_t ld_a, float* d_dst_a, const float* d_src_b, int64_t ld_b,
+                           float* d_dst_b, void* stream) {
+  NR_REQUIRE(d_sorted_keys && d_index_of_pos && d_src_a && d_dst_a && d_src_b && d_dst_b && n >= 0 && d >= 1 &&
+                 d <= 256 && ld_a >= d && ld_b >= d, NR_ERR_ARG, "rows_sum_sorted2: bad arguments");
+  return rows_sum_sorted_launch(d_sorted_keys, n, d_index_of_pos, d, d_src_a, ld_a, d_dst_a, d_src_b, ld_b, d_dst_b,
+                                stream);
 }
 
 #define NR_BY_WIDTH(KERNEL, ...)                                                          \

@@ -463,6 +463,14 @@ def rows_gather(rows, src, dst):
          src.stride(0), C.c_void_p(dst.data_ptr()), dst.stride(0), _stream())
 
 
+def rows_gather2(rows, src_a, src_b, dst_a, dst_b):
+    """dst_a[w] = src_a[rows[w]] and dst_b[w] = src_b[rows[w]] in one launch (column blocks of wider buffers allowed)"""
+    d = src_a.shape[1]
+    call("nrhip_rows_gather2", _ptr(rows, torch.int32), rows.numel(), d, C.c_void_p(src_a.data_ptr()), src_a.stride(0),
+         C.c_void_p(src_b.data_ptr()), src_b.stride(0), C.c_void_p(dst_a.data_ptr()), dst_a.stride(0),
+         C.c_void_p(dst_b.data_ptr()), dst_b.stride(0), _stream())
+
+
 def partials_sum(parts, world, n, out):
     """out[k] = sum over ranks r ascending of parts[r][k] (nrhip_partials_sum)"""
     call("nrhip_partials_sum", _ptr(parts, torch.float32), int(world), int(n), _ptr(out, torch.float32), _stream())
@@ -494,6 +502,13 @@ def rows_sum_sorted(keys, index_of_pos, src, dst):
     """dst[row] = ordered sum of src rows per run of the sorted int64 keys (row << 32 | position)."""
     call("nrhip_rows_sum_sorted", _ptr(keys, torch.int64), keys.numel(), _ptr(index_of_pos, torch.int32),
          dst.shape[1], C.c_void_p(src.data_ptr()), src.stride(0), _ptr(dst, torch.float32), _stream())
+
+
+def rows_sum_sorted2(keys, index_of_pos, src_a, dst_a, src_b, dst_b):
+    """two tables along the same runs in one launch (see rows_sum_sorted)"""
+    call("nrhip_rows_sum_sorted2", _ptr(keys, torch.int64), keys.numel(), _ptr(index_of_pos, torch.int32),
+         dst_a.shape[1], C.c_void_p(src_a.data_ptr()), src_a.stride(0), _ptr(dst_a, torch.float32),
+         C.c_void_p(src_b.data_ptr()), src_b.stride(0), _ptr(dst_b, torch.float32), _stream())
 
 
 def sort_keys(keys):

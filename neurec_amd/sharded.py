@@ -25,8 +25,10 @@ One LightGCN step (LightGCN.py:132-166,178) then has exactly these exchange poin
   * Adam is owner-local (dense TF-Adam on the rank's block): no exchange.
 Routing needs the per-destination row counts on the host (all_to_all_single takes Python lists).
 `plan_epoch` computes them for every batch of an epoch stream in one pass and ONE device→host
-copy, so the steps themselves run without host synchronisation; a step on a batch that was not
-planned falls back to counting on the spot (one sync).
+copy — and, with them, the routing itself of every batch (requests in owner order, their inverse,
+what each owner is asked for, the owner-side sorted keys: csrc/route.hip, one all-to-all of the
+epoch's ids) — so a planned step runs without host synchronisation and without a single routing
+launch; a step on a batch that was not planned routes and counts on the spot (one sync).
 Why the per-hop all-gather is not overlapped with the SpMM over the already-local columns: a
 row's sum would become (local columns) + (remote columns) instead of ascending-column order —
 a different fp32 association from the single-GPU kernel and from TF's, so rankings could no
@@ -58,6 +60,14 @@ def _compact_plan(engine, B):
     return cache[B]
 
 
+def _compact_neg(engine, B):
+    """ids B .. 2B-1: the negatives' rows of the compact head block, per batch length"""
+    cache = engine.__dict__.setdefault("_compact_negs", {})
+    if B not in cache:
+        cache[B] = torch.arange(B, 2 * B, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    return cache[B]
+
+
 class RowRouter:
     """Requests for table rows by global node id -> owners and back, for block-partitioned tables.  The index
     bookkeeping of a step is two native calls (csrc/route.hip): `request` (requests in owner order + the inverse
@@ -68,7 +78,8 @@ class RowRouter:
     def __init__(self, comm, part, max_batch):
         self.comm, self.part = comm, part
         self.world, self.rank = comm.world, comm.rank
-        self._epoch = None               # per-epoch routing tables (plan_epoch)
+        self._epoch = None               # per-epoch routing counts (plan_epoch)
+        self._tables = None              # ... and the routing itself, every batch (plan_epoch -> _build_tables)
         dev = torch.device("cuda", torch.cuda.current_device())
         n = 3 * int(max_batch)
         self._keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
@@ -78,7 +89,7 @@ class RowRouter:
         self._counts = torch.zeros(self.world, dtype=torch.int32, device=dev)
 
     # ---- per-epoch routing tables: no host sync inside the steps
-    def plan_epoch(self, classes, offsets, batch):
+    def plan_epoch(self, classes, offsets, batch, tables=True):
         """classes: list of int32 device tensors (one per id class: users, pos, neg) holding this
         rank's slice of the epoch stream; offsets: global-id offset per class.  One pass + one
         count exchange + one device->host copy for the whole epoch."""
@@ -101,6 +112,87 @@ class RowRouter:
         size_off = torch.cat([zero, torch.cumsum(all_sizes, 1)[:, :-1]], 1).to(torch.int32).contiguous()
         self._epoch = (int(batch), send.cpu().tolist(), recv.cpu().tolist(), all_sizes.cpu().tolist(),
                        recv_prefix, size_off)
+        self._tables = None
+        if tables and nb and len(classes) == 3 and tuple(offsets[1:]) == (offsets[1], offsets[1]) and offsets[0] == 0:
+            self._build_tables(classes, int(offsets[1]), int(batch), sizes, send, recv, all_sizes, recv_prefix, size_off)
+
+    def _build_tables(self, classes, n_users, batch, sizes, send, recv, all_sizes, recv_prefix, size_off):
+        """The routing of EVERY batch of the planned stream, built by a handful of launches that work on all batches
+        at once (csrc/route.hip: nrhip_route_epoch, nrhip_route_epoch_owner_keys; one all-to-all of the whole
+        epoch's (row, code) pairs): afterwards a planned step issues NO routing launch — `planned_route(k)` hands out
+        slices.  Per batch the tables equal what `request` + `ordered_keys` compute (tests/test_sharded_gpu.py)."""
+        users, pos, neg = classes
+        dev, W, B = users.device, self.world, batch
+        n, nb = users.numel(), send.shape[0]
+        max_asked = int(recv.sum(1).max())
+        if self.comm.active:                               # the decision below must be the same on every rank
+            max_asked = int(self.comm.max_float(float(max_asked)))
+        if 3 * B > 16384 or max_asked > 16384:            # one sorting workgroup per batch: routed per step instead
+            return
+        i32 = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)
+        seg_off = (torch.arange(nb, device=dev, dtype=torch.int64) * (3 * B)).contiguous()
+        seg_len = (3 * sizes).to(torch.int32).contiguous()
+        keys = torch.empty(3 * nb * B, dtype=torch.int64, device=dev)
+        packed, order, inv, cnt = i32((3 * nb * B, 2)), i32(3 * nb * B), i32(3 * nb * B), i32(nb * W)
+        E.call("nrhip_route_epoch", E._ptr(users, torch.int32), E._ptr(pos, torch.int32), E._ptr(neg, torch.int32), n, B,
+               n_users, self.part.bu, self.part.bi, self.CODE, W, E._ptr(keys), E._ptr(packed), E._ptr(order),
+               E._ptr(inv), E._ptr(cnt), E._ptr(seg_off), E._ptr(seg_len), E._stream())
+        mine = packed[:3 * n]                                 # only the LAST batch can be short: the valid slots are a prefix
+        if W == 1:
+            asked = mine
+        else:
+            # to the owners: destination-major, batches in order inside a destination
+            q = torch.arange(3 * n, device=dev, dtype=torch.int64)
+            k, o = q // (3 * B), keys[:3 * n] >> 32
+            soff = torch.cumsum(send, 1) - send               # [nb][W] first routed index of owner o inside batch k
+            kpre = torch.cumsum(send, 0) - send               # requests to o in the batches before k
+            tot_s, tot_r = send.sum(0), recv.sum(0)
+            dbase = torch.cumsum(tot_s, 0) - tot_s
+            dst = dbase[o] + kpre[k, o] + (q - 3 * B * k) - soff[k, o]
+            out = torch.empty_like(mine)
+            out[dst] = mine
+            got, _ = self.comm.all_to_all_rows(out, tot_s.cpu().tolist(), tot_r.cpu().tolist())
+            # from the sources: source-major -> [batch][source]
+            rpre = torch.cumsum(recv, 0) - recv
+            sbase = torch.cumsum(tot_r, 0) - tot_r
+            spre = torch.cumsum(recv, 1) - recv
+            per_batch = recv.sum(1)
+            aoff = torch.cumsum(per_batch, 0) - per_batch
+            src_start = (sbase.view(1, W) + rpre).reshape(-1)
+            dst_start = (aoff.view(nb, 1) + spre).reshape(-1)
+            lens = recv.reshape(-1)
+            total = int(lens.sum())
+            idx = torch.repeat_interleave(src_start - dst_start, lens) + torch.arange(total, device=dev)
+            asked = got[idx]
+        per_batch = recv.sum(1)
+        asked_off = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+        asked_off[1:] = torch.cumsum(per_batch, 0)
+        asked_len = per_batch.to(torch.int32).contiguous()
+        total = int(asked.shape[0])
+        batch_of = torch.repeat_interleave(torch.arange(nb, device=dev, dtype=torch.int32), per_batch).contiguous()
+        glen = all_sizes.sum(1).to(torch.int32).contiguous()
+        stride = 3 * int(glen.max())
+        rows, codes = asked[:, 0].contiguous(), asked[:, 1].contiguous()
+        okeys = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+        iop = i32(max(nb * stride, 1))
+        E.call("nrhip_route_epoch_owner_keys", E._ptr(rows), E._ptr(codes), E._ptr(batch_of), total,
+               E._ptr(asked_off), E._ptr(asked_len), nb, max_asked, E._ptr(recv_prefix), E._ptr(size_off),
+               E._ptr(glen), W, self.CODE, stride, E._ptr(okeys), E._ptr(iop), E._stream())
+        self._tables = (B, order, inv, rows, codes, asked_off.cpu().tolist(), okeys, iop, stride)
+
+    def planned_route(self, k, batch_len):
+        """The Route of planned batch k (slices of the epoch tables, no launch) with its owner-side keys attached,
+        or None when that batch has no tables."""
+        t, planned = self._tables, self.epoch_counts(k, batch_len)
+        if t is None or planned is None:
+            return None
+        B, order, inv, rows, codes, aoff, okeys, iop, stride = t
+        send_counts, recv_counts, sizes, recv_prefix, size_off = planned
+        s0, n3, a0, a1, G = 3 * B * k, 3 * batch_len, aoff[k], aoff[k + 1], int(sum(sizes))
+        rt = Route(order[s0:s0 + n3], inv[s0:s0 + n3], rows[a0:a1], codes[a0:a1], send_counts, recv_counts, G,
+                   recv_prefix, size_off)
+        rt.keys, rt.index_of_pos = okeys[a0:a1], iop[k * stride:k * stride + 3 * G]
+        return rt
 
     def _exchange_counts(self, send, sizes):
         """send [nb][world] (what I send to r in batch k) -> recv [nb][world] (what r sends me);
@@ -158,6 +250,8 @@ class RowRouter:
         """Sorted keys (local row << 32 | global position) of the rows received from the other ranks and the
         index_of_pos table: global position = class * G + (offset of the source rank) + b, G = the global batch
         length — the occurrence order of the single-process head on the concatenated batch."""
+        if route.keys is not None:                                  # planned with the epoch
+            return route.keys, route.index_of_pos
         dev = route.asked.device
         keys = torch.empty(route.asked.numel(), dtype=torch.int64, device=dev)
         index_of_pos = torch.empty(max(3 * route.G, 1), dtype=torch.int32, device=dev)
@@ -169,9 +263,11 @@ class RowRouter:
 class Route:
     """one batch's routing: order[i] = the request (class * B + b) that travels at position i, inv = its inverse;
     asked / asked_code = the local rows (and occurrence codes) this rank was asked for, by source rank"""
-    __slots__ = ("order", "inv", "asked", "asked_code", "send_counts", "recv_counts", "G", "recv_prefix", "size_off")
+    __slots__ = ("order", "inv", "asked", "asked_code", "send_counts", "recv_counts", "G", "recv_prefix", "size_off",
+                 "keys", "index_of_pos")
 
     def __init__(self, *a):
+        self.keys = self.index_of_pos = None
         for k, v in zip(self.__slots__, a):
             setattr(self, k, v)
 
@@ -320,20 +416,19 @@ class ShardedLightGCN:
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
         # --- routing: ids -> owners (native: requests in owner order, one all-to-all of (row, code) pairs)
-        planned = self.router.epoch_counts(batch_index, B)
-        rt = self.router.request(users, pos, neg, self.n_users, planned)
+        rt = self.router.planned_route(batch_index, B)
+        if rt is None:
+            rt = self.router.request(users, pos, neg, self.n_users, self.router.epoch_counts(batch_index, B))
         n_asked = rt.asked.numel()
         # --- forward: the last hop only on the rows somebody asked for
         E.mark_rows(rt.asked, self.flag)
         esum = self.propagate(wanted=self.flag)
         # --- lookup answers: [Esum | E0] rows back to the askers, unscattered into request order by the gather
         rows = torch.empty((n_asked, 2 * d), dtype=torch.float32, device=dev)
-        E.rows_gather(rt.asked, esum, rows[:, :d])
-        E.rows_gather(rt.asked, self.E0, rows[:, d:])
+        E.rows_gather2(rt.asked, esum, self.E0, rows[:, :d], rows[:, d:])
         got, _ = self.comm.all_to_all_rows(rows, rt.recv_counts, rt.send_counts)
         es, e0 = self.es_buf[:3 * B], self.e0_buf[:3 * B]
-        E.rows_gather(rt.inv, got[:, :d], es)                           # es[p] = answer to request p
-        E.rows_gather(rt.inv, got[:, d:], e0)
+        E.rows_gather2(rt.inv, got[:, :d], got[:, d:], es, e0)          # es[p], e0[p] = answer to request p
         # --- BPR head on the compact block: "users" = rows [0,B), "items" = rows [B,3B); every occurrence has its
         #     own row there, so gs / gr hold one gradient row per occurrence (gs already divided by L+1 when that
         #     is exact: L+1 a power of two)
@@ -341,23 +436,21 @@ class ShardedLightGCN:
         if _ATOMIC_HEADS:                  # the A/B knob's heads ADD into their rows (the ordered heads store them)
             gs.zero_()
             gr.zero_()
-        E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B], (self._cp[:B] + B).contiguous(),
+        E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B], _compact_neg(self, B),
                             self.reg, gs, gr, self.terms, loss_out, divided=self._pow2, plan=_compact_plan(self, B))
         # --- gradient rows back to the owners (routed order), added there in the order of the global batch
         back = torch.empty((3 * B, 2 * d), dtype=torch.float32, device=dev)
-        E.rows_gather(rt.order, gs, back[:, :d])
-        E.rows_gather(rt.order, gr, back[:, d:])
+        E.rows_gather2(rt.order, gs, gr, back[:, :d], back[:, d:])
         mine, _ = self.comm.all_to_all_rows(back, rt.send_counts, rt.recv_counts)
         keys, index_of_pos = self.router.ordered_keys(rt)
         if self._pow2:
-            E.rows_sum_sorted(keys, index_of_pos, mine[:, :d], self.H)
+            E.rows_sum_sorted2(keys, index_of_pos, mine[:, :d], self.H, mine[:, d:], self.Greg)
         else:
             if self._Gs is None:                                         # zero outside the rows of a step
                 self._Gs = torch.zeros_like(self.H)
-            E.rows_sum_sorted(keys, index_of_pos, mine[:, :d], self._Gs)
+            E.rows_sum_sorted2(keys, index_of_pos, mine[:, :d], self._Gs, mine[:, d:], self.Greg)
             E.rows_div(rt.asked, self._Gs, float(self.L + 1), self.H)
             E.rows_clear(rt.asked, d, (self._Gs,))
-        E.rows_sum_sorted(keys, index_of_pos, mine[:, d:], self.Greg)
         # --- backward hops: G_k = H + Aᵀ G_{k+1}; H is non-zero on the asked rows only (first hop skips the rest),
         #     the last hop carries ApplyAdam as its epilogue where the lane-group schedule exists
         if self.comm.active:
@@ -425,8 +518,9 @@ class ShardedMF:
         B, d = users.numel(), self.d
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
-        planned = self.router.epoch_counts(batch_index, B)
-        rt = self.router.request(users, pos, neg, self.n_users, planned)        # exchange 1: ids
+        rt = self.router.planned_route(batch_index, B)                          # exchange 1 (ids) done with the epoch's
+        if rt is None:
+            rt = self.router.request(users, pos, neg, self.n_users, self.router.epoch_counts(batch_index, B))
         rows = torch.empty((rt.asked.numel(), d), dtype=torch.float32, device=self.T.device)
         E.rows_gather(rt.asked, self.T, rows)
         got, _ = self.comm.all_to_all_rows(rows, rt.recv_counts, rt.send_counts)   # exchange 2: rows
@@ -437,7 +531,7 @@ class ShardedMF:
         gP, gQ = self._gcat[:B], self._gcat[B:3 * B]
         if _ATOMIC_HEADS:
             self._gcat[:3 * B].zero_()
-        E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], (self._ar[:B] + B).contiguous(), self.reg,
+        E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], _compact_neg(self, B), self.reg,
                       gP, gQ, self.terms, loss_out, _compact_plan(self, B))
         back = torch.empty((3 * B, d), dtype=torch.float32, device=self.T.device)
         E.rows_gather(rt.order, self._gcat[:3 * B], back)                       # routed order

@@ -62,6 +62,45 @@ def test_key_sort_of_any_length(n):
     np.testing.assert_array_equal(got, np.sort(keys))
 
 
+def test_many_segments_sorted_in_one_launch_and_epoch_routing_equals_per_batch_routing():
+    """nrhip_sort_u64_segments (one workgroup per segment, lengths 0 .. 16384) and the epoch-at-once routing tables
+    of the row-sharded engines (nrhip_route_epoch / nrhip_route_epoch_owner_keys) against the per-batch calls."""
+    import torch
+    from neurec_amd import engine as E, parallel
+    from neurec_amd.sharded import RowRouter
+    rng = np.random.RandomState(11)
+    lens = np.array([0, 1, 2, 63, 64, 65, 129, 1000, 3072, 4097, 16384, 5], np.int32)
+    off = np.concatenate([[0], np.cumsum(lens + 3)])[:-1].astype(np.int64)       # gaps between segments stay untouched
+    total = int(off[-1] + lens[-1] + 3)
+    keys = (rng.randint(0, 300, total).astype(np.int64) << 32) | rng.randint(0, 1 << 20, total).astype(np.int64)
+    dk, doff, dlens = _dev(keys.copy()), _dev(off), _dev(lens)       # named: the call reads them after it returns
+    E.call("nrhip_sort_u64_segments", E._ptr(dk), E._ptr(doff), E._ptr(dlens), len(lens), int(lens.max()), E._stream())
+    want = keys.copy()
+    for o, n in zip(off, lens):
+        want[o:o + n] = np.sort(keys[o:o + n])
+    np.testing.assert_array_equal(dk.cpu().numpy(), want)
+    # routing tables of a whole stream (last batch short) == the per-batch routing, batch by batch
+    U, I, B, n = 500, 700, 96, 96 * 5 + 17
+    comm = parallel.Comm()
+    part = parallel.BipartitePartition(U, I, 1)
+    users, pos, neg = (rng.randint(0, hi, n).astype(np.int32) for hi in (U, I, I))
+    du, dp, dn = _dev(users), _dev(pos), _dev(neg)
+    planned, live = RowRouter(comm, part, B), RowRouter(comm, part, B)
+    planned.plan_epoch([du, dp, dn], (0, U, U), B)
+    live.plan_epoch([du, dp, dn], (0, U, U), B, tables=False)
+    assert planned._tables is not None and live._tables is None
+    for k in range((n + B - 1) // B):
+        lo, hi = k * B, min(n, (k + 1) * B)
+        a = planned.planned_route(k, hi - lo)
+        b = live.request(du[lo:hi].contiguous(), dp[lo:hi].contiguous(), dn[lo:hi].contiguous(), U,
+                         live.epoch_counts(k, hi - lo))
+        for f in ("order", "inv", "asked", "asked_code"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), (k, f)
+        ka, ia = planned.ordered_keys(a)
+        kb, ib = live.ordered_keys(b)
+        assert torch.equal(ka, kb) and torch.equal(ia[:3 * a.G], ib[:3 * b.G])
+
+
 def test_steps_on_a_batch_beyond_the_lds_sort_match_the_oracle():
     """batch_size > 8192 used to fail in the default (lazy, fused) MF path.  One step of each
     engine on 20,000 triplets: plan sorted inside the step by the segmented network."""
