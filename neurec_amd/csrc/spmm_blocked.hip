@@ -278,21 +278,17 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
       float nxt_val[IPL];
 #pragma unroll
       for (int i = 0; i < IPL; ++i) { nxt_idx[i] = 0; nxt_val[i] = 0.f; }
+      int ch_idx[IPL];                               // the NEXT 16-entry chunk of this sub-list, requested while
+      float ch_val[IPL];                             // the current chunk's gathers are in flight
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) { ch_idx[i] = 0; ch_val[i] = 0.f; }
       for (int k0 = 0; k0 < maxlen || k0 == 0; k0 += 16) {
         int my_idx[IPL];
         float my_val[IPL];
 #pragma unroll
         for (int i = 0; i < IPL; ++i) {
-          my_idx[i] = cur_idx[i];
-          my_val[i] = cur_val[i];
-          if (k0 > 0) {                              // long sub-list: later chunks are not pipelined
-            my_idx[i] = 0;
-            my_val[i] = 0.f;
-            if (c < CL && k0 + c * IPL + i < len) {
-              my_idx[i] = indices[begin + k0 + c * IPL + i];
-              my_val[i] = vals[begin + k0 + c * IPL + i];
-            }
-          }
+          my_idx[i] = k0 == 0 ? cur_idx[i] : ch_idx[i];
+          my_val[i] = k0 == 0 ? cur_val[i] : ch_val[i];
           if constexpr (MASKED) {
             if (col_mask && c < CL && k0 + c * IPL + i < len && col_mask[my_idx[i]] == 0)
               my_idx[i] = -1;                        // X row all zero
@@ -318,6 +314,17 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
             } else {
               x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
               if (t0 + u < nn) x[u] = X[(int64_t)max(col, 0) * LPR + c];   // wave-uniform guard
+            }
+          }
+          if (t0 == 0 && k0 + 16 < maxlen) {         // a long sub-list: its next chunk (wave-uniform guard) — a chunk
+#pragma unroll                                       // used to cost index round trip + gather round trips in sequence
+            for (int i = 0; i < IPL; ++i) {
+              ch_idx[i] = 0;
+              ch_val[i] = 0.f;
+              if (c < CL && k0 + 16 + c * IPL + i < len) {
+                ch_idx[i] = indices[begin + k0 + 16 + c * IPL + i];
+                ch_val[i] = vals[begin + k0 + 16 + c * IPL + i];
+              }
             }
           }
           if (k0 == 0 && t0 == 0) {                  // prefetch for the next sub-list: first chunk, row filter
