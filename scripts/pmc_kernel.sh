@@ -29,11 +29,12 @@ for k, (n, v) in sorted(agg.items()):
 PY
   else tail -3 "$OUT/g$i.err"; fi
   rm -rf "$OUT/g$i"
-done <<'GROUPS'
+done < <(if [ -n "${PMC_GROUPS_FILE:-}" ]; then cat "$PMC_GROUPS_FILE"; else cat <<GROUPS_EOF
 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS
 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
 SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAVES
-GROUPS
+GROUPS_EOF
+fi)
