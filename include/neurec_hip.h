@@ -591,6 +591,7 @@ int nrhip_vae_dwq0(const int64_t* d_indptr, const int32_t* d_indices, const int3
 int nrhip_axpy(float a, const float* d_x, float* d_y, int64_t n, void* stream);
 int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* stream);
 int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
+int nrhip_mean2_f32(const float* d_x, const float* d_y, int n, float* d_out, void* stream);   /* out[0], out[1]: two means, one launch */
 
 /* BPR-MF step in ONE launch: the gradient of MF.py:57-72 + TF-1.12 sparse Adam (util/learner.py:9-10) by
  * exact lazy replay, bit-identical to nrhip_bpr_mf_grad + nrhip_adam_sparse_tf.  Two copies of every table

@@ -192,6 +192,7 @@ SIGNATURES = {
     "nrhip_axpy": [f32, p, p, i64, p],
     "nrhip_sumsq_accumulate": [p, i64, p, p],
     "nrhip_mean_f32": [p, i32, p, p],
+    "nrhip_mean2_f32": [p, p, i32, p, p],
     "nrhip_pairwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
     "nrhip_pointwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
     "nrhip_mark_rows": [p, i32, i32, p, p],

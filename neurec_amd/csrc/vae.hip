@@ -773,6 +773,29 @@ __global__ __launch_bounds__(256) void vae_small_wgrad_kernel(const float* __res
   }
 }
 
+// the three small weight gradients of the middle of the backward pass in ONE launch (they depend on the same
+// producer and on nothing of each other; three launches cost three boundaries for ~1,600 wave-sized jobs)
+struct SmallWgradJob { const float* X; int K; const float* G; int J; float* dW; float* db; int first_block; };
+__global__ __launch_bounds__(256) void vae_small_wgrad3_kernel(SmallWgradJob j0, SmallWgradJob j1, SmallWgradJob j2,
+                                                               int batch) {
+  const SmallWgradJob& jb = (int)blockIdx.x >= j2.first_block ? j2 : (int)blockIdx.x >= j1.first_block ? j1 : j0;
+  const int o = ((int)blockIdx.x - jb.first_block) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int K = jb.K, J = jb.J;
+  if (o >= K * J + J) return;
+  float acc = 0.f;
+  if (o < K * J) {
+    const int k = o / J, j = o % J;
+    for (int b = lane; b < batch; b += NR_WAVE) acc = fmaf(jb.X[(int64_t)b * K + k], jb.G[(int64_t)b * J + j], acc);
+    acc = nr_wave_sum_f32(acc);
+    if (lane == 0) jb.dW[o] = acc;
+  } else {
+    const int j = o - K * J;
+    for (int b = lane; b < batch; b += NR_WAVE) acc += jb.G[(int64_t)b * J + j];
+    acc = nr_wave_sum_f32(acc);
+    if (lane == 0) jb.db[j] = acc;
+  }
+}
+
 // dW_q0[item][:] += h0[b][item]·da1[b][:] over the batch's CSR entries (scatter, fp32 atomics).
 // grid (batch row, 16 chunk slots): a wave takes 16-item chunks of ITS row, slot + 64 apart — a long row is spread over
 // up to 64 waves instead of one wave issuing its atomics one item after the other (the first form: 512 waves, the
@@ -805,6 +828,19 @@ __global__ __launch_bounds__(256) void vae_dwq0_kernel(const int64_t* __restrict
       if (idx < nn && col < h) atomicAdd(&dWq0[(int64_t)item * h + col], val * g);
     }
   }
+}
+
+// block 0: mean of x -> out[0]; block 1: mean of y -> out[1] (same arithmetic as mean_kernel)
+__global__ __launch_bounds__(256) void mean2_kernel(const float* __restrict__ x, const float* __restrict__ y, int n,
+                                                    float* __restrict__ out) {
+  __shared__ double s[256];
+  const float* src = blockIdx.x == 0 ? x : y;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += (double)src[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)(s[0] / (double)n);
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n,
@@ -968,15 +1004,12 @@ int nrhip_vae_mid_backward(int batch, int h, int z, int act, float anneal, const
                      anneal, 1.0f / (float)batch, d_dG1, d_G1, d_H1, d_MU, d_LOGVAR, d_EPSSTD,
                      d_Wp0, d_Wq1, d_DA3, d_DH2, d_DA1);
   NR_LAUNCH_CHECK();
-  // dW_p0 = zsᵀ·da3 [z][h];  dW_q1 = h1ᵀ·dh2 [h][2z];  db_q0 = Σ da1
-  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((z * h + h + 3) / 4), dim3(256), 0, st, d_ZS,
-                     z, d_DA3, h, batch, d_dWp0, d_dbp0);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((h * 2 * z + 2 * z + 3) / 4), dim3(256), 0, st,
-                     d_H1, h, d_DH2, 2 * z, batch, d_dWq1, d_dbq1);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_small_wgrad_kernel, dim3((h + 3) / 4), dim3(256), 0, st, d_H1, 0, d_DA1, h, batch,
-                     (float*)nullptr, d_dbq0);
+  // dW_p0 = zsᵀ·da3 [z][h];  dW_q1 = h1ᵀ·dh2 [h][2z];  db_q0 = Σ da1 — one launch, three block ranges
+  const int b0 = (z * h + h + 3) / 4, b1 = (h * 2 * z + 2 * z + 3) / 4, b2 = (h + 3) / 4;
+  const SmallWgradJob j0{d_ZS, z, d_DA3, h, d_dWp0, d_dbp0, 0};
+  const SmallWgradJob j1{d_H1, h, d_DH2, 2 * z, d_dWq1, d_dbq1, b0};
+  const SmallWgradJob j2{d_H1, 0, d_DA1, h, nullptr, d_dbq0, b0 + b1};
+  hipLaunchKernelGGL(vae_small_wgrad3_kernel, dim3(b0 + b1 + b2), dim3(256), 0, st, j0, j1, j2, batch);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -1014,6 +1047,14 @@ int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* str
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, n,
                      d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* d_out[0] = mean(d_x[0..n)), d_out[1] = mean(d_y[0..n)) in one launch (the step's two loss terms) */
+int nrhip_mean2_f32(const float* d_x, const float* d_y, int n, float* d_out, void* stream) {
+  NR_REQUIRE(d_x && d_y && d_out && n >= 1, NR_ERR_ARG, "mean2_f32: bad arguments");
+  hipLaunchKernelGGL(mean2_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, d_x, d_y, n, d_out);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

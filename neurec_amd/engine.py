@@ -1053,5 +1053,10 @@ def sumsq_accumulate(x, out_f64):
          _stream())
 
 
+def mean2_f32(x, y, out):
+    """out[0] = mean(x), out[1] = mean(y) — one launch"""
+    call("nrhip_mean2_f32", _ptr(x, torch.float32), _ptr(y, torch.float32), x.numel(), _ptr(out, torch.float32), _stream())
+
+
 def mean_f32(x, out):
     call("nrhip_mean_f32", _ptr(x, torch.float32), x.numel(), _ptr(out, torch.float32), _stream())

@@ -822,8 +822,7 @@ class MultiVAEEngine:
                            G["bq1"], G["bq0"])
         E.vae_dwq0(self.csr, rows, self.h0val, self.DA1[:B], G["Wq0"])   # G["Wq0"] is zero here
         if want_loss:
-            E.mean_f32(self.nll[:B], self.stats[0:1])
-            E.mean_f32(self.KLb[:B], self.stats[1:2])
+            E.mean2_f32(self.nll[:B], self.KLb[:B], self.stats)
         if self.reg != 0.0:
             if want_loss:
                 self.regsum.zero_()

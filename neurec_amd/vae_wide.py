@@ -173,8 +173,7 @@ class MultiVAEWideEngine:
              _ptr(self.h0val), _ptr(d), _ptr(self.G[iWq]), _stream())                     # G[Wq0] is zero here
         call("nrhip_colsum_rows", _ptr(d), w0, B, w0, _ptr(self.G[ibq]), None, 0, _stream())
         if want_loss:
-            E.mean_f32(self.nll[:B], self.stats[0:1])
-            E.mean_f32(self.KLb[:B], self.stats[1:2])
+            E.mean2_f32(self.nll[:B], self.KLb[:B], self.stats)
         if self.reg != 0.0:
             if want_loss:
                 self.regsum.zero_()
