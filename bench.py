@@ -271,14 +271,16 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     item_ms = _hip_timed(item_layer, 30, 5)
     item_flops = 3 * 2.0 * B * I * hw
     out["wide"] = {"p_dim": [zw, hw], "batch": B, "ms_per_step": wide_ms, "users_per_sec_train": B / wide_ms * 1e3,
-                   "roofline": {"bound": "mfma", "kernel": "gemm_kmajor_kernel x3 (+ 3 transposes): the item layer's "
-                                                           "logits, dW and dg",
+                   "roofline": {"bound": "mfma", "kernel": "gemm_lds_kernel<128> x3 (+ 3 transposes, 1 split reduce): the "
+                                                           "item layer's logits, dW and dg",
                                 "flops_per_step": item_flops, "us_per_step": item_ms * 1e3,
                                 "achieved": item_flops / item_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": item_flops / item_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                                 "traffic": None,
-                                "note": "fp32 (the reference's dtype) on v_mfma_f32_32x32x2_f32; operands straight "
-                                        "from L2 in k-major layout, no LDS staging yet"}}
+                                "note": "fp32 (the reference's dtype) on v_mfma_f32_32x32x2_f32: 128 x 128 block tiles, "
+                                        "buffer-loaded k-major operand tiles double-buffered through LDS, blocks dealt to the "
+                                        "XCDs by n-tile; the vendor library on the same products: 75-108 TFLOP/s "
+                                        "(profiles/r03_exp_gemm_fp32_mfma.txt)"}}
     del wide
     if with_cpu:
         from oracle import train as O
