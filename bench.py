@@ -261,25 +261,22 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     wide_ms = _hip_timed(lambda: wide.step(next(it2), 0.2, 0.8, want_loss=True), 60, 10)
     wide.step(rows, 0.2, 0.8)
 
-    def item_layer():                                      # logits, dW = g^T D, dg = D W^T (the transposes included)
-        wide._transpose(wide.Gp[-1], hw, B, hw, wide.gT, wide.B)
-        wide._gemm(wide.gT, wide.B, wide.Wp[-1], I, B, I, hw, wide.S, wide.ld, bias=wide.bp[-1])
-        wide._gemm(wide.Gp[-1], hw, wide.S, wide.ld, hw, I, B, wide.G[2 * 2 + 1], I)
-        wide._transpose(wide.S, wide.ld, B, I, wide.DT, wide.B)
-        wide._transpose(wide.Wp[-1], I, hw, I, wide.WT, hw)
-        wide._gemm(wide.DT, wide.B, wide.WT, hw, B, hw, I, wide.dGp[-1], hw, splits=wide.splits)
+    def item_layer():                                      # logits, dW = g^T D, dg = D W^T — every operand as it lies
+        wide._gemm(wide.Gp[-1], hw, 1, wide.Wp[-1], I, 0, B, I, hw, wide.S, wide.ld, bias=wide.bp[-1])
+        wide._gemm(wide.Gp[-1], hw, 0, wide.S, wide.ld, 0, hw, I, B, wide.G[2 * 2 + 1], I)
+        wide._gemm(wide.S, wide.ld, 1, wide.Wp[-1], I, 1, B, hw, I, wide.dGp[-1], hw, splits=wide.splits)
     item_ms = _hip_timed(item_layer, 30, 5)
     item_flops = 3 * 2.0 * B * I * hw
     out["wide"] = {"p_dim": [zw, hw], "batch": B, "ms_per_step": wide_ms, "users_per_sec_train": B / wide_ms * 1e3,
-                   "roofline": {"bound": "mfma", "kernel": "gemm_lds_kernel<128> x3 (+ 3 transposes, 1 split reduce): the "
-                                                           "item layer's logits, dW and dg",
+                   "roofline": {"bound": "mfma", "kernel": "gemm_lds_kernel<128> x3 (+ 1 split reduce): the item layer's logits, dW "
+                                                           "and dg, every operand read in the layout it is stored in",
                                 "flops_per_step": item_flops, "us_per_step": item_ms * 1e3,
                                 "achieved": item_flops / item_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": item_flops / item_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                                 "traffic": None,
                                 "note": "fp32 (the reference's dtype) on v_mfma_f32_32x32x2_f32: 128 x 128 block tiles, "
-                                        "buffer-loaded k-major operand tiles double-buffered through LDS, blocks dealt to the "
-                                        "XCDs by n-tile; the vendor library on the same products: 75-108 TFLOP/s "
+                                        "buffer-loaded operand tiles (k-major or k-minor) double-buffered through LDS, blocks dealt "
+                                        "to the XCDs by n-tile; the vendor library on the same products: 75-108 TFLOP/s "
                                         "(profiles/r03_exp_gemm_fp32_mfma.txt)"}}
     del wide
     if with_cpu:

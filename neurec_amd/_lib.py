@@ -135,6 +135,7 @@ SIGNATURES = {
     "nrhip_lightgcn_bpr_grad_given": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p, i32, p],
     "nrhip_gemm_workspace_bytes": [i32, i32, i32, p],
     "nrhip_gemm_kmajor": [p, i64, p, i64, i32, i32, i32, p, i64, i32, p, i32, i32, p, sz, p],
+    "nrhip_gemm_f32": [p, i64, i32, p, i64, i32, i32, i32, i32, p, i64, i32, p, i32, i32, p, sz, p],
     "nrhip_transpose2d": [p, i64, i32, i32, p, i64, p],
     "nrhip_vae_bag_fwd": [p, p, p, i32, i32, p, p, i32, f32, p, u64, u64, p, p, p],
     "nrhip_act_bwd": [p, p, i64, i32, p, p],

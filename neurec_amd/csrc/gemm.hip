@@ -5,6 +5,10 @@
 //
 //     C[m][n] (+)= sum_k A[k][m] * B[k][n]          A: [K][lda], B: [K][ldb]  ("k-major": the contraction index is the
 //                                                    slow one), C: [M][ldc] row-major
+// Either operand may instead be given "k-minor" — A as [M][lda], B as [N][ldb], the contraction index contiguous (a
+// row-major activation block as the left factor; a TF weight [in][out] as the right factor of a product with its
+// transpose): the tile is then fetched as 64-byte row pieces and laid k-major into LDS on the way, so no caller
+// transposes anything.
 //
 // k-major on both sides is the layout in which an operand of v_mfma_f32_32x32x2_f32 — lane l feeds element
 // [row or column l & 31][k = l >> 5] — is one coalesced 128-byte segment per half-wave straight from L2 (the layout
@@ -36,15 +40,16 @@ __device__ __forceinline__ float epilogue_act(int a, float x) {
 // while the matrix cores work on the current one); an MFMA operand is then one conflict-free 32-bank row read.
 // The linear block id is dealt to the 8 XCDs so that the tiles_m blocks sharing one n-tile of B run on the SAME XCD
 // (one L2 fetch of that B tile serves all of them).
-template <int TILE, bool ACC>
+template <int TILE, bool ACC, bool AKM, bool BKM>      // AKM / BKM: operand A / B is k-major (else k-minor)
 __global__ __launch_bounds__(256, 3) void gemm_lds_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int M, int N, int K,
     int k_per_split, float* __restrict__ C, int64_t ldc, int64_t split_stride, const float* __restrict__ bias_n,
     int act, int tiles_m, int tiles_n) {
   constexpr int R = TILE / 64;
   constexpr int PER = KT * TILE / 256;
-  __shared__ float sA[2][KT][TILE];
-  __shared__ float sB[2][KT][TILE];
+  // rows padded by one float: the k-minor stores (16 lanes = 16 k of one column) then fall on 16 different banks
+  __shared__ float sA[2][KT][TILE + 1];
+  __shared__ float sB[2][KT][TILE + 1];
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
   const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (logical >= total) return;
@@ -72,18 +77,33 @@ __global__ __launch_bounds__(256, 3) void gemm_lds_kernel(
     }
   if (kb >= ke) return;                                   // an empty split (never launched; kept for safety)
 
-  // this thread's slots of an operand tile: element e = tid + 256 i -> row e / TILE, column e % TILE
-  constexpr int RS = 256 / TILE;                           // rows between two slots of a thread
-  const int col = tid % TILE, row0 = tid / TILE;
+  // this thread's slots of an operand tile [KT][TILE].  k-major operand: element e = tid + 256 i -> k = e / TILE,
+  // column e % TILE (a wave reads 64 consecutive columns of one k-row).  k-minor operand: k = e % KT, column
+  // e / KT (16 lanes read the 16 consecutive k of one column: a 64-byte piece of that row).
+  constexpr int RS = 256 / TILE;                           // k-major: k rows between two slots of a thread
+  constexpr int CS = 256 / KT;                             // k-minor: columns between two slots of a thread
+  const int col = tid % TILE, row0 = tid / TILE;           // k-major slot
+  const int kk = tid % KT, cc0 = tid / KT;                 // k-minor slot
   // Operand loads are BUFFER loads: (resource = wave-uniform base of the current tile, in SGPRs) + (per-thread
-  // 32-bit byte offset, one VGPR for the whole kernel) + (uniform row offset, SGPR).  The loop carries no vector
-  // address arithmetic and no 64-bit address temporaries — with per-thread pointers the register allocator recycled
-  // the staging registers as address temporaries and had to wait for the loads in flight before issuing new ones.
+  // 32-bit byte offset) + (uniform offset, SGPR).  The loop carries no vector address arithmetic and no 64-bit
+  // address temporaries — with per-thread pointers the register allocator recycled the staging registers as address
+  // temporaries and had to wait for the loads in flight before issuing new ones.
   // Clamped columns: what lies outside M / N is loaded from the last valid column and never stored.
-  const uint32_t offA = ((uint32_t)row0 * (uint32_t)lda + (uint32_t)min(m0 + col, M - 1)) * 4u;
-  const uint32_t offB = ((uint32_t)row0 * (uint32_t)ldb + (uint32_t)min(n0 + col, N - 1)) * 4u;
-  const char* uA = (const char*)(A + (int64_t)kb * lda);
-  const char* uB = (const char*)(B + (int64_t)kb * ldb);
+  uint32_t offA[AKM ? 1 : PER], offB[BKM ? 1 : PER];
+  if (AKM) offA[0] = ((uint32_t)row0 * (uint32_t)lda + (uint32_t)min(m0 + col, M - 1)) * 4u;
+  else {
+#pragma unroll
+    for (int i = 0; i < (AKM ? 1 : PER); ++i)
+      offA[i] = ((uint32_t)min(m0 + cc0 + CS * i, M - 1) * (uint32_t)lda + (uint32_t)kk) * 4u;
+  }
+  if (BKM) offB[0] = ((uint32_t)row0 * (uint32_t)ldb + (uint32_t)min(n0 + col, N - 1)) * 4u;
+  else {
+#pragma unroll
+    for (int i = 0; i < (BKM ? 1 : PER); ++i)
+      offB[i] = ((uint32_t)min(n0 + cc0 + CS * i, N - 1) * (uint32_t)ldb + (uint32_t)kk) * 4u;
+  }
+  const char* uA = (const char*)(AKM ? A + (int64_t)kb * lda : A + kb);
+  const char* uB = (const char*)(BKM ? B + (int64_t)kb * ldb : B + kb);
   const uint32_t stepA = (uint32_t)RS * (uint32_t)lda * 4u, stepB = (uint32_t)RS * (uint32_t)ldb * 4u;   // bytes
   auto bload = [](const char* base, uint32_t voff, uint32_t soff) -> float {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
@@ -95,28 +115,31 @@ __global__ __launch_bounds__(256, 3) void gemm_lds_kernel(
   // behind the MFMAs; only the last, partial tile predicates its rows (zero rows: exact no-ops).
   float ra0[PER], rb0[PER], ra1[PER], rb1[PER];
   auto gload = [&](float (&ra)[PER], float (&rb)[PER], int k0) {
-    if (k0 + KT <= ke) {
+    if (k0 + KT <= ke) {                                   // a full tile: no select between a load and its store
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        ra[i] = bload(uA, offA, i * stepA);
-        rb[i] = bload(uB, offB, i * stepB);
+        ra[i] = AKM ? bload(uA, offA[0], i * stepA) : bload(uA, offA[AKM ? 0 : i], 0);
+        rb[i] = BKM ? bload(uB, offB[0], i * stepB) : bload(uB, offB[BKM ? 0 : i], 0);
       }
-    } else {
+    } else {                                               // the last, partial tile: rows past the range are zeros
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const bool live = k0 + row0 + RS * i < ke;
-        ra[i] = live ? bload(uA, offA, i * stepA) : 0.f;
-        rb[i] = live ? bload(uB, offB, i * stepB) : 0.f;
+        const bool live_a = AKM ? k0 + row0 + RS * i < ke : k0 + kk < ke;
+        const bool live_b = BKM ? k0 + row0 + RS * i < ke : k0 + kk < ke;
+        ra[i] = live_a ? (AKM ? bload(uA, offA[0], i * stepA) : bload(uA, offA[AKM ? 0 : i], 0)) : 0.f;
+        rb[i] = live_b ? (BKM ? bload(uB, offB[0], i * stepB) : bload(uB, offB[BKM ? 0 : i], 0)) : 0.f;
       }
     }
-    uA += (int64_t)KT * lda * 4;
-    uB += (int64_t)KT * ldb * 4;
+    uA += AKM ? (int64_t)KT * lda * 4 : (int64_t)KT * 4;
+    uB += BKM ? (int64_t)KT * ldb * 4 : (int64_t)KT * 4;
   };
   auto sstore = [&](const float (&ra)[PER], const float (&rb)[PER], int buf) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      sA[buf][row0 + RS * i][col] = ra[i];
-      sB[buf][row0 + RS * i][col] = rb[i];
+      if (AKM) sA[buf][row0 + RS * i][col] = ra[i];
+      else sA[buf][kk][cc0 + CS * i] = ra[i];
+      if (BKM) sB[buf][row0 + RS * i][col] = rb[i];
+      else sB[buf][kk][cc0 + CS * i] = rb[i];
     }
   };
   auto compute = [&](int buf) {
@@ -223,14 +246,17 @@ int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes) {
   return NR_OK;
 }
 
-/* C[m][n] (+)= sum_k A[k][m] * B[k][n] (fp32 MFMA; see the file header), then + d_bias_n[n] (NULL: none) and the
- * activation `act` (-1 none, 0 tanh, 1 sigmoid, 2 relu, 3 identity).  splits > 1: the contraction is cut into that
- * many ranges computed side by side into d_ws (splits*M*N floats) and added in order. */
-int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int M, int N, int K, float* d_C,
-                      int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits, void* d_ws,
-                      size_t ws_bytes, void* stream) {
-  NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= M && ldb >= N && ldc >= N && lda < (1 << 24) && ldb < (1 << 24) && splits >= 1 &&
-                 act >= -1 && act <= 3, NR_ERR_ARG, "gemm_kmajor: bad arguments");
+/* C[m][n] (+)= sum_k a(k, m) * b(k, n) (fp32 MFMA; see the file header), then + d_bias_n[n] (NULL: none) and the
+ * activation `act` (-1 none, 0 tanh, 1 sigmoid, 2 relu, 3 identity).  a_kminor = 0: d_A is [K][lda] (k-major);
+ * a_kminor = 1: d_A is [M][lda] with the contraction index contiguous; b_kminor likewise for d_B ([K][ldb] / [N][ldb]).
+ * splits > 1: the contraction is cut into that many ranges computed side by side into d_ws (splits*M*N floats) and
+ * added in order. */
+int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B, int64_t ldb, int b_kminor, int M,
+                   int N, int K, float* d_C, int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits,
+                   void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= (a_kminor ? K : M) &&
+                 ldb >= (b_kminor ? K : N) && ldc >= N && lda < (1 << 24) && ldb < (1 << 24) && splits >= 1 &&
+                 act >= -1 && act <= 3, NR_ERR_ARG, "gemm_f32: bad arguments");
   if (M == 0 || N == 0) return NR_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
@@ -240,40 +266,62 @@ int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t l
   const int tile = big ? 128 : 64;
   const int tiles_m = (M + tile - 1) / tile, tiles_n = (N + tile - 1) / tile;
   const unsigned blocks = (unsigned)(((int64_t)tiles_m * tiles_n + 7) / 8 * 8);
-#define NR_GEMM_LAUNCH(TILE, ACCF, grid_z, per, Cptr, ldC, stride, bias, actv)                                          \
-  hipLaunchKernelGGL((gemm_lds_kernel<TILE, ACCF>), dim3(blocks, 1, grid_z), block, 0, st, d_A, lda, d_B, ldb, M, N, \
-                     K, per, Cptr, ldC, stride, bias, actv, tiles_m, tiles_n)
-  if (splits == 1) {
-    if (K == 0) {
-      // no k-steps: the kernel would return early; write the epilogue of a zero product through the reduce kernel
-      hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
-                         (const float*)d_C, 0, (int64_t)0, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
-      NR_LAUNCH_CHECK();
-      return NR_OK;
-    }
-    if (big) {
-      if (accumulate) NR_GEMM_LAUNCH(128, true, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
-      else NR_GEMM_LAUNCH(128, false, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
-    } else {
-      if (accumulate) NR_GEMM_LAUNCH(64, true, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
-      else NR_GEMM_LAUNCH(64, false, 1, K, d_C, ldc, (int64_t)0, d_bias_n, act);
-    }
+  if (splits == 1 && K == 0) {
+    // no k-steps: the kernel would return early; write the epilogue of a zero product through the reduce kernel
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
+                       (const float*)d_C, 0, (int64_t)0, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
-  NR_REQUIRE(d_ws && ws_bytes >= (size_t)splits * M * N * sizeof(float), NR_ERR_WORKSPACE,
-             "gemm_kmajor: workspace too small for %d splits", splits);
-  int per = (K + splits - 1) / splits;
-  per = (per + KT - 1) / KT * KT;
-  const int used = (K + per - 1) / per;
-  if (big) NR_GEMM_LAUNCH(128, false, used, per, (float*)d_ws, (int64_t)N, (int64_t)M * N, (const float*)nullptr, -1);
-  else NR_GEMM_LAUNCH(64, false, used, per, (float*)d_ws, (int64_t)N, (int64_t)M * N, (const float*)nullptr, -1);
+  int per = K, used = 1;
+  float* out = d_C;
+  int64_t ld_out = ldc, stride = 0;
+  const float* bias = d_bias_n;
+  int actv = act;
+  bool acc = accumulate != 0;
+  if (splits > 1) {
+    NR_REQUIRE(d_ws && ws_bytes >= (size_t)splits * M * N * sizeof(float), NR_ERR_WORKSPACE,
+               "gemm_f32: workspace too small for %d splits", splits);
+    per = (K + splits - 1) / splits;
+    per = (per + KT - 1) / KT * KT;
+    used = (K + per - 1) / per;
+    out = (float*)d_ws;
+    ld_out = N;
+    stride = (int64_t)M * N;
+    bias = nullptr;
+    actv = -1;
+    acc = false;
+  }
+  const dim3 grid(blocks, 1, (unsigned)used);
+#define NR_GEMM_GO(TILE, ACCF, AK, BK)                                                                                 \
+  hipLaunchKernelGGL((gemm_lds_kernel<TILE, ACCF, AK, BK>), grid, block, 0, st, d_A, lda, d_B, ldb, M, N, K, per, out, \
+                     ld_out, stride, bias, actv, tiles_m, tiles_n)
+#define NR_GEMM_LAYOUT(TILE, ACCF)                                                                \
+  do {                                                                                            \
+    if (!a_kminor && !b_kminor) NR_GEMM_GO(TILE, ACCF, true, true);                               \
+    else if (a_kminor && !b_kminor) NR_GEMM_GO(TILE, ACCF, false, true);                          \
+    else if (!a_kminor && b_kminor) NR_GEMM_GO(TILE, ACCF, true, false);                          \
+    else NR_GEMM_GO(TILE, ACCF, false, false);                                                    \
+  } while (0)
+  if (big) { if (acc) NR_GEMM_LAYOUT(128, true); else NR_GEMM_LAYOUT(128, false); }
+  else { if (acc) NR_GEMM_LAYOUT(64, true); else NR_GEMM_LAYOUT(64, false); }
+#undef NR_GEMM_LAYOUT
+#undef NR_GEMM_GO
   NR_LAUNCH_CHECK();
-#undef NR_GEMM_LAUNCH
-  hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
-                     (const float*)d_ws, used, (int64_t)M * N, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
-  NR_LAUNCH_CHECK();
+  if (splits > 1) {
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
+                       (const float*)d_ws, used, (int64_t)M * N, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
+    NR_LAUNCH_CHECK();
+  }
   return NR_OK;
+}
+
+/* the k-major / k-major form under its first name */
+int nrhip_gemm_kmajor(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, int M, int N, int K, float* d_C,
+                      int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits, void* d_ws,
+                      size_t ws_bytes, void* stream) {
+  return nrhip_gemm_f32(d_A, lda, 0, d_B, ldb, 0, M, N, K, d_C, ldc, accumulate, d_bias_n, act, splits, d_ws, ws_bytes,
+                        stream);
 }
 
 int nrhip_transpose2d(const float* d_src, int64_t ld_src, int rows, int cols, float* d_dst, int64_t ld_dst,

@@ -244,8 +244,8 @@ class ScoreGemm:
 
 class ScoreGemmWide:
     """ScoreGemm's interface for factor widths beyond the scoring loop's 128 (NGCF at the paper's 64 / [64, 64, 64]
-    concatenates to 256 columns): S = P[users] @ Q.T through the general fp32-MFMA GEMM (csrc/gemm.hip) on k-major
-    copies of both sides — the same k-ascending fmaf chain per score.  The evaluation then takes the materialised
+    concatenates to 256 columns): S = P[users] @ Q.T through the general fp32-MFMA GEMM (csrc/gemm.hip), both
+    tables read as they lie — the same k-ascending fmaf chain per score.  The evaluation then takes the materialised
     path (score slab -> train mask -> select); there is no tile-maxima form at these widths."""
 
     wide = True
@@ -255,20 +255,18 @@ class ScoreGemmWide:
         self.max_rows = int(max_rows)
         dev = item_table.device
         self.ld = (self.cols + 63) // 64 * 64
-        self.QT = torch.empty((self.d, self.cols), dtype=torch.float32, device=dev)
-        self.PT = torch.empty((self.d, self.max_rows), dtype=torch.float32, device=dev)
         self.Pg = torch.empty((self.max_rows, self.d), dtype=torch.float32, device=dev)
         self.prepare(item_table)
 
     def prepare(self, item_table):
+        """Both factor tables are read as they lie (rows = the contraction index contiguous): nothing to copy."""
         if tuple(item_table.shape) != (self.cols, self.d):
             raise ValueError("item table shape changed")
-        call("nrhip_transpose2d", _ptr(item_table, torch.float32), item_table.stride(0), self.cols, self.d,
-             _ptr(self.QT), self.cols, _stream())
+        self.Q = item_table
 
     def new_score_buffer(self, rows=None):
         rows = self.max_rows if rows is None else rows
-        return torch.empty((rows, self.ld), dtype=torch.float32, device=self.QT.device)
+        return torch.empty((rows, self.ld), dtype=torch.float32, device=self.Q.device)
 
     def __call__(self, user_table, users, out=None):
         rows = user_table.shape[0] if users is None else users.numel()
@@ -282,9 +280,8 @@ class ScoreGemmWide:
         if users is not None:
             rows_gather(users, user_table, self.Pg[:rows])
             src, ld = self.Pg, self.d
-        call("nrhip_transpose2d", _ptr(src, torch.float32), ld, rows, self.d, _ptr(self.PT), self.max_rows, _stream())
-        call("nrhip_gemm_kmajor", _ptr(self.PT), self.max_rows, _ptr(self.QT), self.cols, rows, self.cols, self.d,
-             C.c_void_p(out.data_ptr()), out.stride(0), 0, None, -1, 1, None, 0, _stream())
+        call("nrhip_gemm_f32", _ptr(src, torch.float32), ld, 1, _ptr(self.Q, torch.float32), self.Q.stride(0), 1, rows,
+             self.cols, self.d, C.c_void_p(out.data_ptr()), out.stride(0), 0, None, -1, 1, None, 0, _stream())
         return out[:rows]
 
 

@@ -4,7 +4,8 @@ build layers of whatever widths the config names; conf/NGCF.properties ships 16 
 strings the general pieces into the same step:
 
   layer forward   S = A_hat E (SpMM) -> T1 = S W_gc + b_gc, T2 = (E .* S) W_bi + b_bi on the fp32 matrix cores
-                  (csrc/gemm.hip, operands S^T / (E .* S)^T feature-major) -> leaky_relu sum, dropout, l2_normalize
+                  (csrc/gemm.hip: S and E .* S row-major, the weights [in][out], each read as it lies) -> leaky_relu sum,
+                  dropout, l2_normalize
                   (csrc/ngcf_wide.hip) -> this layer's column block of the concatenated output
   head            the BPR head of NGCF.py:91-110 on rows of the concatenated output (the BPR-MF head kernel)
   layer backward  dT1, dT2 row-wise -> dW = S^T dT1, (E .* S)^T dT2 (contractions over the N node rows, split and
@@ -65,8 +66,6 @@ class NGCFWideEngine:
         self.T2 = [z(N, self.w[k + 1]) for k in range(self.L)]
         self.mask = [torch.zeros(N, self.w[k + 1], dtype=torch.uint8, device=dev) for k in range(self.L)]
         wmax = max(self.w)
-        self.tA, self.tB = z(wmax, N), z(wmax, N)                   # feature-major copies (GEMM operands)
-        self.tW = z(wmax * wmax)
         self.dT1, self.dT2, self.Y1, self.Y2 = (z(N * wmax) for _ in range(4))
         self.dS = [z(N, p) for p in sorted(set(self.wp))]
         self.dEd = [z(N, p) for p in sorted(set(self.wp))]
@@ -97,13 +96,10 @@ class NGCFWideEngine:
     def _buf(self, group, width):
         return group[sorted(set(self.wp)).index(width)]
 
-    def _gemm(self, A, lda, Bm, ldb, M, N, K, Cm, ldc, splits=1, bias=None):
-        call("nrhip_gemm_kmajor", _ptr(A), int(lda), _ptr(Bm), int(ldb), int(M), int(N), int(K), _ptr(Cm), int(ldc), 0,
-             _ptr(bias, torch.float32, allow_none=True), -1, int(splits), _ptr(self.ws),
+    def _gemm(self, A, lda, a_kminor, Bm, ldb, b_kminor, M, N, K, Cm, ldc, splits=1, bias=None):
+        call("nrhip_gemm_f32", _ptr(A), int(lda), int(a_kminor), _ptr(Bm), int(ldb), int(b_kminor), int(M), int(N),
+             int(K), _ptr(Cm), int(ldc), 0, _ptr(bias, torch.float32, allow_none=True), -1, int(splits), _ptr(self.ws),
              self.ws.numel() if splits > 1 else 0, _stream())
-
-    def _transpose(self, src, ld_src, rows, cols, dst, ld_dst):
-        call("nrhip_transpose2d", _ptr(src), int(ld_src), int(rows), int(cols), _ptr(dst), int(ld_dst), _stream())
 
     def forward(self, masks=None):
         """Fills self.Out = concat(E0, out_1 .. out_L) (NGCF.py:160-202).  masks: optional list of uint8 [N][w_k]
@@ -116,11 +112,9 @@ class NGCFWideEngine:
             ego, S, X2 = self.ego[k], self.S[k], self.X2[k]
             self.A.matmul(ego, out=S)
             call("nrhip_ew_mul", _ptr(ego), pi, _ptr(S), pi, N, wi, _ptr(X2), pi, _stream())
-            self._transpose(S, pi, N, wi, self.tA, N)
-            self._transpose(X2, pi, N, wi, self.tB, N)
             Wg, bg, Wb, bb = self.W[k]
-            self._gemm(self.tA, N, Wg, wo, N, wo, wi, self.T1[k], wo, bias=bg)
-            self._gemm(self.tB, N, Wb, wo, N, wo, wi, self.T2[k], wo, bias=bb)
+            self._gemm(S, pi, 1, Wg, wo, 0, N, wo, wi, self.T1[k], wo, bias=bg)
+            self._gemm(X2, pi, 1, Wb, wo, 0, N, wo, wi, self.T2[k], wo, bias=bb)
             if masks is not None:
                 self.mask[k].copy_(masks[k])
             out_block = self.Out[:, self.off[k + 1]:self.off[k + 2]]
@@ -154,17 +148,13 @@ class NGCFWideEngine:
                  _ptr(self.ego[k + 1]), po, _ptr(self.T1[k]), _ptr(self.T2[k]), wo, _ptr(self.mask[k], torch.uint8), N,
                  wo, float(self.keep), _ptr(self.dT1), _ptr(self.dT2), _stream())
             # weight gradients: contractions over the N rows, both operands k-major as stored
-            self._gemm(self.S[k], pi, self.dT1, wo, wi, wo, N, gWg, wo, splits=self.splits)
-            self._gemm(self.X2[k], pi, self.dT2, wo, wi, wo, N, gWb, wo, splits=self.splits)
+            self._gemm(self.S[k], pi, 0, self.dT1, wo, 0, wi, wo, N, gWg, wo, splits=self.splits)
+            self._gemm(self.X2[k], pi, 0, self.dT2, wo, 0, wi, wo, N, gWb, wo, splits=self.splits)
             call("nrhip_colsum_rows", _ptr(self.dT1), wo, N, wo, _ptr(gbg), _ptr(self.cs_ws), self.cs_ws.numel() * 4, _stream())
             call("nrhip_colsum_rows", _ptr(self.dT2), wo, N, wo, _ptr(gbb), _ptr(self.cs_ws), self.cs_ws.numel() * 4, _stream())
-            # Y1 = dT1 W_gc^T, Y2 = dT2 W_bi^T
-            self._transpose(self.dT1, wo, N, wo, self.tA, N)
-            self._transpose(Wg, wo, wi, wo, self.tW, wi)
-            self._gemm(self.tA, N, self.tW, wi, N, wi, wo, self.Y1, wi)
-            self._transpose(self.dT2, wo, N, wo, self.tB, N)
-            self._transpose(Wb, wo, wi, wo, self.tW, wi)
-            self._gemm(self.tB, N, self.tW, wi, N, wi, wo, self.Y2, wi)
+            # Y1 = dT1 W_gc^T, Y2 = dT2 W_bi^T: both operands k-minor as stored
+            self._gemm(self.dT1, wo, 1, Wg, wo, 1, N, wi, wo, self.Y1, wi)
+            self._gemm(self.dT2, wo, 1, Wb, wo, 1, N, wi, wo, self.Y2, wi)
             dS, dEd = self._buf(self.dS, pi), self._buf(self.dEd, pi)
             call("nrhip_ngcf_mix_bwd", _ptr(self.Y1), _ptr(self.Y2), wi, _ptr(self.ego[k]), _ptr(self.S[k]), pi, N, wi,
                  pi, _ptr(dS), _ptr(dEd), _stream())

@@ -6,10 +6,11 @@ strings width-generic kernels (csrc/vae_wide.hip) and a general fp32-MFMA GEMM (
 
   forward   first encoder layer as a bag-sum over the user's CSR row (no dense [B][I] input) -> dense layers ->
             [mu | logvar] -> z = mu + eps * exp(logvar / 2) -> dense layers -> logits = g W_last + b on the matrix cores
-            (A = g^T, feature-major; B = the TF variable [h][I] as it is)
-  backward  dLoss/dlogits in place on the logits slab; dW_last = g^T D (both operands k-major as stored); d g = D W_last^T
-            (the one product that needs its two operands transposed first, split over the 40,981-long contraction);
-            dense layers back; the first encoder layer's gradient scattered along the CSR rows
+            (g row-major and the TF variable [h][I], each as it lies)
+  backward  dLoss/dlogits in place on the logits slab; dW_last = g^T D; d g = D W_last^T (split over the 40,981-long
+            contraction) — every operand read in the layout it is stored in (nrhip_gemm_f32's k-major / k-minor
+            operand forms: no transposed copies); dense layers back; the first encoder layer's gradient scattered
+            along the CSR rows
   update    TF's dense ApplyAdam on every variable (MultiVAE.py:137-139)
 
 Weights are kept in TensorFlow's layout ([in][out]).  Checked against the reference class itself at one, two and three
@@ -60,14 +61,9 @@ class MultiVAEWideEngine:
         self.h_last = self.Wp[-1].shape[0]                          # width feeding the item layer
         self.ld = (I + 63) // 64 * 64
         self.S = z(B, self.ld)                                      # logits slab, then dLoss/dlogits in place
-        self.gT = z(self.h_last, B)                                 # feature-major copy of the last hidden layer
-        self.DT = z(I, B)                                           # D^T and W_last^T for d g = D W_last^T
-        self.WT = z(I, self.h_last)
         self.splits = 32                                            # of the 40,981-long contraction of d g
         mids = self.Wq[1:] + self.Wp[:-1]                            # the layers that are plain dense products
         wmax = max([self.h_last] + [max(w.shape) for w in mids])
-        self.tX, self.tD = z(wmax, B), z(wmax, B)                   # feature-major copies of a layer's x and dLoss/dy
-        self.tW = z(max([1] + [w.numel() for w in mids]))           # W^T of the layer being differentiated
         self.mid_splits = 4                                         # contraction cuts of the small products
         nbytes = E.C.c_size_t(0)
         call("nrhip_gemm_workspace_bytes", max(B, wmax), wmax, max(self.splits, self.mid_splits), E.C.byref(nbytes))
@@ -77,28 +73,24 @@ class MultiVAEWideEngine:
         self.last_anneal = 0.0
 
     # ------------------------------------------------------------------ pieces
-    def _gemm(self, A, lda, Bm, ldb, M, N, K, Cm, ldc, splits=1, bias=None, act=-1):
-        call("nrhip_gemm_kmajor", _ptr(A), int(lda), _ptr(Bm), int(ldb), int(M), int(N), int(K), _ptr(Cm), int(ldc), 0,
-             _ptr(bias, torch.float32, allow_none=True), int(act), int(splits), _ptr(self.ws),
-             self.ws.numel() if splits > 1 else 0, _stream())
+    def _gemm(self, A, lda, a_kminor, Bm, ldb, b_kminor, M, N, K, Cm, ldc, splits=1, bias=None, act=-1):
+        """C[m][n] = sum_k a(k, m) b(k, n) (+ bias, activation); an operand is k-major ([K][ld]) or k-minor ([M|N][ld])"""
+        call("nrhip_gemm_f32", _ptr(A), int(lda), int(a_kminor), _ptr(Bm), int(ldb), int(b_kminor), int(M), int(N),
+             int(K), _ptr(Cm), int(ldc), 0, _ptr(bias, torch.float32, allow_none=True), int(act), int(splits),
+             _ptr(self.ws), self.ws.numel() if splits > 1 else 0, _stream())
 
     def _dense_fwd(self, X, W, b, B, act, Y):
-        """Y[:B] = act(X[:B] W + b): A = X^T (feature-major), B = the TF variable as it is."""
+        """Y[:B] = act(X[:B] W + b): x row-major (k-minor) and the TF variable [in][out] (k-major), as they lie."""
         K, N = W.shape
-        self._transpose(X, K, B, K, self.tX, self.B)
-        self._gemm(self.tX, self.B, W, N, B, N, K, Y, N, bias=b, act=act)
+        self._gemm(X, K, 1, W, N, 0, B, N, K, Y, N, bias=b, act=act)
 
     def _dense_bwd(self, dA, X, W, B, dX, dW, db):
-        """dX = dA W^T (both operands transposed first), dW = X^T dA (both k-major as stored), db = column sums."""
+        """dW = X^T dA (contraction over the batch rows: both k-major as stored), db = column sums, dX = dA W^T (both
+        k-minor as stored)."""
         K, N = W.shape
-        self._gemm(X, K, dA, N, K, N, B, dW, N, splits=self.mid_splits if B >= 256 else 1)
+        self._gemm(X, K, 0, dA, N, 0, K, N, B, dW, N, splits=self.mid_splits if B >= 256 else 1)
         call("nrhip_colsum_rows", _ptr(dA), N, B, N, _ptr(db), None, 0, _stream())
-        self._transpose(dA, N, B, N, self.tD, self.B)
-        self._transpose(W, N, K, N, self.tW, K)
-        self._gemm(self.tD, self.B, self.tW, K, B, K, N, dX, K)
-
-    def _transpose(self, src, ld_src, rows, cols, dst, ld_dst):
-        call("nrhip_transpose2d", _ptr(src), int(ld_src), int(rows), int(cols), _ptr(dst), int(ld_dst), _stream())
+        self._gemm(dA, N, 1, W, N, 1, B, K, N, dX, K)
 
     def _forward(self, rows, csr, keep, is_training, drop_given, eps_given, S):
         """fills Hq / ZS / Gp for the B = rows.numel() rows and the logits slab S[:B]"""
@@ -116,8 +108,7 @@ class MultiVAEWideEngine:
             self._dense_fwd(g, self.Wp[i], self.bp[i], B, E.VAE_ACTS[self.act], self.Gp[i])
             g = self.Gp[i]
         h, I = self.h_last, self.n_items
-        self._transpose(g, h, B, h, self.gT, self.B)                                      # g^T [h][B]
-        self._gemm(self.gT, self.B, self.Wp[-1], I, B, I, h, S, S.stride(0), bias=self.bp[-1])   # logits + bias
+        self._gemm(g, h, 1, self.Wp[-1], I, 0, B, I, h, S, S.stride(0), bias=self.bp[-1])   # logits + bias
         return g
 
     def logits(self, rows, csr=None, out=None):
@@ -146,12 +137,10 @@ class MultiVAEWideEngine:
              _ptr(rows, torch.int32), _ptr(self.nll), _stream())                           # S is D from here on
         iWq, ibq, iWp, ibp = 0, n, 2 * n, 3 * n                                           # offsets into params / G
         # last decoder layer on the matrix cores
-        self._gemm(g_last, h, S, ld, h, I, B, self.G[iWp + n - 1], I)                      # dW = g^T D
+        self._gemm(g_last, h, 0, S, ld, 0, h, I, B, self.G[iWp + n - 1], I)                # dW = g^T D
         call("nrhip_colsum_rows", _ptr(S), ld, B, I, _ptr(self.G[ibp + n - 1]), None, 0, _stream())
-        self._transpose(S, ld, B, I, self.DT, self.B)
-        self._transpose(self.Wp[-1], I, h, I, self.WT, h)
         dg = self.dGp[-1] if n > 1 else self.dZ
-        self._gemm(self.DT, self.B, self.WT, h, B, h, I, dg, h, splits=self.splits)        # d g = D W^T
+        self._gemm(S, ld, 1, self.Wp[-1], I, 1, B, h, I, dg, h, splits=self.splits)        # d g = D W^T
         # hidden decoder layers
         for i in range(n - 2, -1, -1):
             K, N = self.Wp[i].shape

@@ -217,3 +217,40 @@ def test_gemm_edge_cases():
         call("nrhip_gemm_kmajor", _ptr(A), 1 << 24, _ptr(Bm), 5, 8, 5, 1, _ptr(out), 5, 0, None, -1, 1, None, 0, _stream())
     with pytest.raises(Exception):                           # splits without a workspace
         call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 8, 5, 1, _ptr(out), 5, 0, None, -1, 4, None, 0, _stream())
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(100, 333, 77, 1), (512, 700, 600, 1), (130, 64, 1000, 4), (64, 64, 5000, 16),
+                                          (1, 1, 1, 1), (257, 129, 17, 1)])
+@pytest.mark.parametrize("a_kminor,b_kminor", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_operand_layouts_give_the_same_chain(M, N, K, splits, a_kminor, b_kminor):
+    """nrhip_gemm_f32: either operand k-major ([K][ld]) or k-minor ([M][ld] / [N][ld], contraction index contiguous) —
+    x W, x W^T, x^T g without transposed copies; every layout is the same k-ascending fmaf chain per element."""
+    import ctypes as C
+    import torch
+    from neurec_amd._lib import call
+    from neurec_amd.engine import _ptr, _stream
+    from oracle import native
+    rng = np.random.RandomState(M + N + K + 2 * a_kminor + b_kminor)
+    A = rng.randn(M, K).astype(np.float32)                  # a(k, m) = A[m][k]
+    Bm = rng.randn(N, K).astype(np.float32)                 # b(k, n) = Bm[n][k]
+    pad = 3
+    hA = np.zeros((M, K + pad), np.float32) if a_kminor else np.zeros((K, M + pad), np.float32)
+    hB = np.zeros((N, K + pad), np.float32) if b_kminor else np.zeros((K, N + pad), np.float32)
+    if a_kminor: hA[:, :K] = A
+    else: hA[:, :M] = A.T
+    if b_kminor: hB[:, :K] = Bm
+    else: hB[:, :N] = Bm.T
+    dA, dB = _dev(hA), _dev(hB)
+    out = torch.full((M, N + 2), 5.0, dtype=torch.float32, device="cuda")
+    nbytes = C.c_size_t(0)
+    call("nrhip_gemm_workspace_bytes", M, N, splits, C.byref(nbytes))
+    ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device="cuda")
+    call("nrhip_gemm_f32", _ptr(dA), hA.shape[1], a_kminor, _ptr(dB), hB.shape[1], b_kminor, M, N, K, _ptr(out), N + 2, 0,
+         None, -1, splits, _ptr(ws), ws.numel() if splits > 1 else 0, _stream())
+    got = out.cpu().numpy()
+    assert (got[:, N:] == 5.0).all()
+    if splits == 1:
+        np.testing.assert_array_equal(got[:, :N], native.score_gemm(A, None, Bm))
+    else:
+        want = A.astype(np.float64) @ Bm.astype(np.float64).T
+        assert np.abs(got[:, :N] - want).max() <= 2e-6 * np.sqrt(K) * max(1.0, np.abs(want).max())
