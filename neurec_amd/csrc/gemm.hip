@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256, 3) void gemm_lds_kernel(
   __shared__ float sA[2][KT][TILE + 1];
   __shared__ float sB[2][KT][TILE + 1];
   const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
-  const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  // (rotated by the split index: with fewer than 8 tiles the same x — the same XCD — would do every split's work)
+  const unsigned bx = (blockIdx.x + blockIdx.z) % gridDim.x;
+  const int logical = (bx % 8) * per_xcd + bx / 8;
   if (logical >= total) return;
   const int m0 = (logical % tiles_m) * TILE, n0 = (logical / tiles_m) * TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -217,6 +219,30 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
   C[(int64_t)m * ldc + n] = acc;
 }
 
+// many splits (a tall-skinny product: 64 x 64 outputs over 70,839 rows): first the splits of one chunk of kRedChunk
+// are added (grid.y = chunks, all of them side by side), then the chunk sums by gemm_split_reduce_kernel — the same
+// left-to-right order inside a chunk and across the chunks, so the association is fixed (deterministic)
+constexpr int kRedChunk = 32;
+__global__ __launch_bounds__(256) void gemm_split_chunks_kernel(const float* __restrict__ parts, int splits,
+                                                                int64_t split_stride, int64_t n_elems,
+                                                                float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elems) return;
+  const int s0 = blockIdx.y * kRedChunk, s1 = min(splits, s0 + kRedChunk);
+  const float* p = parts + e;
+  float acc = 0.f;
+  int s = s0;
+  for (; s + 8 <= s1; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(s + q) * split_stride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = acc + v[q];
+  }
+  for (; s < s1; ++s) acc = acc + p[(int64_t)s * split_stride];
+  out[(int64_t)blockIdx.y * n_elems + e] = acc;
+}
+
 // dst[c][r] = src[r][c]
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, int64_t ld_src, int rows,
                                                           int cols, float* __restrict__ dst, int64_t ld_dst) {
@@ -242,7 +268,8 @@ extern "C" {
 
 int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes) {
   NR_REQUIRE(bytes && M >= 0 && N >= 0 && splits >= 1, NR_ERR_ARG, "gemm_workspace_bytes: bad arguments");
-  *bytes = splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const size_t chunks = splits > 2 * kRedChunk ? (size_t)(splits + kRedChunk - 1) / kRedChunk : 0;   // second level
+  *bytes = splits > 1 ? ((size_t)splits + chunks) * (size_t)M * (size_t)N * sizeof(float) : 0;
   return NR_OK;
 }
 
@@ -262,7 +289,7 @@ int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B
   dim3 block(256);
   if (K == 0) splits = 1;                                    // an empty contraction: C (+)= 0, then bias / activation
   // 128 x 128 block tiles when they fill the chip, 64 x 64 otherwise (more, smaller workgroups)
-  const bool big = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits >= 256;
+  const bool big = (M > 64 || N > 64) && (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits >= 256;
   const int tile = big ? 128 : 64;
   const int tiles_m = (M + tile - 1) / tile, tiles_n = (N + tile - 1) / tile;
   const unsigned blocks = (unsigned)(((int64_t)tiles_m * tiles_n + 7) / 8 * 8);
@@ -280,8 +307,9 @@ int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B
   int actv = act;
   bool acc = accumulate != 0;
   if (splits > 1) {
-    NR_REQUIRE(d_ws && ws_bytes >= (size_t)splits * M * N * sizeof(float), NR_ERR_WORKSPACE,
-               "gemm_f32: workspace too small for %d splits", splits);
+    const size_t chunks_ws = splits > 2 * kRedChunk ? (size_t)(splits + kRedChunk - 1) / kRedChunk : 0;
+    NR_REQUIRE(d_ws && ws_bytes >= ((size_t)splits + chunks_ws) * M * N * sizeof(float), NR_ERR_WORKSPACE,
+               "gemm_f32: workspace too small for %d splits (nrhip_gemm_workspace_bytes)", splits);
     per = (K + splits - 1) / splits;
     per = (per + KT - 1) / KT * KT;
     used = (K + per - 1) / per;
@@ -309,8 +337,20 @@ int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B
 #undef NR_GEMM_GO
   NR_LAUNCH_CHECK();
   if (splits > 1) {
-    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), block, 0, st,
-                       (const float*)d_ws, used, (int64_t)M * N, M, N, (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
+    const float* parts = (const float*)d_ws;
+    int n_parts = used;
+    const unsigned eblocks = (unsigned)(((int64_t)M * N + 255) / 256);
+    if (splits > 2 * kRedChunk) {                          // chunk sums first, side by side
+      const int chunks = (used + kRedChunk - 1) / kRedChunk;
+      float* lvl2 = (float*)d_ws + (size_t)splits * M * N;
+      hipLaunchKernelGGL(gemm_split_chunks_kernel, dim3(eblocks, (unsigned)chunks), block, 0, st, parts, used,
+                         (int64_t)M * N, (int64_t)M * N, lvl2);
+      NR_LAUNCH_CHECK();
+      parts = lvl2;
+      n_parts = chunks;
+    }
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3(eblocks), block, 0, st, parts, n_parts, (int64_t)M * N, M, N,
+                       (int64_t)N, d_C, ldc, accumulate, d_bias_n, act);
     NR_LAUNCH_CHECK();
   }
   return NR_OK;

@@ -83,7 +83,7 @@ class NGCFWideEngine:
         self.flag = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.max_batch = max_batch
         self.cs_ws = z(((N + 511) // 512) * wmax)                   # chunk sums of the bias gradients
-        self.splits = 192                                           # cuts of the N-long contractions of dW
+        self.splits = 768                                           # cuts of the N-long contractions of dW
         nbytes = C.c_size_t(0)
         call("nrhip_gemm_workspace_bytes", wmax, wmax, self.splits, C.byref(nbytes))
         self.ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
