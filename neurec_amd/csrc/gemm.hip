@@ -289,7 +289,8 @@ int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B
   dim3 block(256);
   if (K == 0) splits = 1;                                    // an empty contraction: C (+)= 0, then bias / activation
   // 128 x 128 block tiles when they fill the chip, 64 x 64 otherwise (more, smaller workgroups)
-  const bool big = (M > 64 || N > 64) && (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits >= 256;
+  // (a dimension that fits 64 would leave half of every 128-wide tile empty)
+  const bool big = M > 64 && N > 64 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits >= 256;
   const int tile = big ? 128 : 64;
   const int tiles_m = (M + tile - 1) / tile, tiles_n = (N + tile - 1) / tile;
   const unsigned blocks = (unsigned)(((int64_t)tiles_m * tiles_n + 7) / 8 * 8);
