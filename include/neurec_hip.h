@@ -765,7 +765,8 @@ int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const 
  * buffer resources with 32-bit byte offsets); K = 0 leaves C (+)= 0 followed by the epilogue. */
 int nrhip_gemm_workspace_bytes(int M, int N, int splits, size_t* bytes);
 /* the general form: either operand k-major ([K][ld], a_kminor / b_kminor = 0) or k-minor ([M][ld] / [N][ld], the
- * contraction index contiguous, = 1) — x W, x W^T, x^T g without a transposed copy of anything */
+ * contraction index contiguous, = 1; such an operand must stay below 2 GB) — x W, x W^T, x^T g without a transposed
+ * copy of anything */
 int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B, int64_t ldb, int b_kminor, int M,
                    int N, int K, float* d_C, int64_t ldc, int accumulate, const float* d_bias_n, int act, int splits,
                    void* d_ws, size_t ws_bytes, void* stream);

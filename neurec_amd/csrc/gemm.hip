@@ -284,6 +284,10 @@ int nrhip_gemm_f32(const float* d_A, int64_t lda, int a_kminor, const float* d_B
   NR_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && lda >= (a_kminor ? K : M) &&
                  ldb >= (b_kminor ? K : N) && ldc >= N && lda < (1 << 24) && ldb < (1 << 24) && splits >= 1 &&
                  act >= -1 && act <= 3, NR_ERR_ARG, "gemm_f32: bad arguments");
+  // a k-minor operand is addressed from its first row through one buffer resource (2 GB window, 32-bit offsets)
+  NR_REQUIRE((!a_kminor || (int64_t)M * lda * 4 < (1ll << 31)) && (!b_kminor || (int64_t)N * ldb * 4 < (1ll << 31)),
+             NR_ERR_UNSUPPORTED, "gemm_f32: a k-minor operand of %lld bytes (limit 2 GB: give it k-major)",
+             (long long)((a_kminor ? (int64_t)M * lda : (int64_t)N * ldb) * 4));
   if (M == 0 || N == 0) return NR_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);

@@ -215,6 +215,9 @@ def test_gemm_edge_cases():
     call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 0, 5, 1, _ptr(out), 5, 0, None, -1, 1, None, 0, _stream())   # M = 0
     with pytest.raises(ValueError):
         call("nrhip_gemm_kmajor", _ptr(A), 1 << 24, _ptr(Bm), 5, 8, 5, 1, _ptr(out), 5, 0, None, -1, 1, None, 0, _stream())
+    with pytest.raises(NotImplementedError, match="k-minor operand"):        # 2.5 GB through one 2 GB buffer window
+        call("nrhip_gemm_f32", _ptr(A), 600, 1, _ptr(Bm), 5, 0, 1 << 20, 5, 600, _ptr(out), 5, 0, None, -1, 1, None, 0,
+             _stream())
     with pytest.raises(Exception):                           # splits without a workspace
         call("nrhip_gemm_kmajor", _ptr(A), 8, _ptr(Bm), 5, 8, 5, 1, _ptr(out), 5, 0, None, -1, 4, None, 0, _stream())
 
