@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void route_epoch_keys_kernel(const int32_t* __
   int owner, local;
   owner_local(node_of(users + b0, pos + b0, neg + b0, nbk, n_users, p), n_users, bu, bi, owner, local);
   keys[q] = ((uint64_t)(uint32_t)owner << 32) | (uint32_t)p;
-  atomicAdd(&counts[(int64_t)k * world + owner], 1);
+  if (counts) atomicAdd(&counts[(int64_t)k * world + owner], 1);      // optional: 3 * batch atomics per counter
 }
 
 __global__ __launch_bounds__(256) void route_epoch_pack_kernel(const uint64_t* __restrict__ keys,
@@ -186,19 +186,19 @@ int nrhip_route_owner_keys(const int32_t* d_rows, const int32_t* d_codes, int n,
 
 /* The routing of EVERY batch of an epoch stream (d_users / d_pos / d_neg: n triplets cut into batches of `batch`; batch
  * k's requests live in slot [3*batch*k, 3*batch*(k+1))): nrhip_route_batch's outputs for all batches in three launches.
- * d_counts [n_batches][world] (zeroed here) receives the per-destination request counts. */
+ * d_counts [n_batches][world] (optional; zeroed here) receives the per-destination request counts. */
 int nrhip_route_epoch(const int32_t* d_users, const int32_t* d_pos, const int32_t* d_neg, int64_t n, int batch,
                       int n_users, int bu, int bi, int code_base, int world, uint64_t* d_keys, int32_t* d_packed,
                       int32_t* d_order, int32_t* d_inv, int32_t* d_counts, const int64_t* d_seg_off,
                       const int32_t* d_seg_len, void* stream) {
-  NR_REQUIRE(d_users && d_pos && d_neg && d_keys && d_packed && d_order && d_inv && d_counts && d_seg_off &&
+  NR_REQUIRE(d_users && d_pos && d_neg && d_keys && d_packed && d_order && d_inv && d_seg_off &&
                  d_seg_len && n >= 0 && batch >= 1 && n_users >= 0 && bu >= 1 && bi >= 1 && code_base > batch &&
                  world >= 1, NR_ERR_ARG, "route_epoch: bad arguments");
   if (n == 0) return NR_OK;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nb = (n + batch - 1) / batch, slots = 3 * nb * batch;
   NR_REQUIRE(nb < (1ll << 31) && slots / 256 < (1ll << 31), NR_ERR_UNSUPPORTED, "route_epoch: %lld batches", (long long)nb);
-  NR_CHECK_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * nb * world, st));
+  if (d_counts) NR_CHECK_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * nb * world, st));
   const dim3 grid((unsigned)((slots + 255) / 256)), block(256);
   hipLaunchKernelGGL(route_epoch_keys_kernel, grid, block, 0, st, d_users, d_pos, d_neg, n, batch, n_users, bu, bi,
                      world, d_keys, d_counts);

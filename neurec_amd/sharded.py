@@ -133,10 +133,10 @@ class RowRouter:
         seg_off = (torch.arange(nb, device=dev, dtype=torch.int64) * (3 * B)).contiguous()
         seg_len = (3 * sizes).to(torch.int32).contiguous()
         keys = torch.empty(3 * nb * B, dtype=torch.int64, device=dev)
-        packed, order, inv, cnt = i32((3 * nb * B, 2)), i32(3 * nb * B), i32(3 * nb * B), i32(nb * W)
+        packed, order, inv = i32((3 * nb * B, 2)), i32(3 * nb * B), i32(3 * nb * B)       # (counts: plan_epoch has them)
         E.call("nrhip_route_epoch", E._ptr(users, torch.int32), E._ptr(pos, torch.int32), E._ptr(neg, torch.int32), n, B,
                n_users, self.part.bu, self.part.bi, self.CODE, W, E._ptr(keys), E._ptr(packed), E._ptr(order),
-               E._ptr(inv), E._ptr(cnt), E._ptr(seg_off), E._ptr(seg_len), E._stream())
+               E._ptr(inv), None, E._ptr(seg_off), E._ptr(seg_len), E._stream())
         mine = packed[:3 * n]                                 # only the LAST batch can be short: the valid slots are a prefix
         if W == 1:
             asked = mine
