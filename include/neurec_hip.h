@@ -157,6 +157,33 @@ int nrhip_sample_bpr_epoch(const int64_t* d_tr_indptr, const int32_t* d_tr_indic
                            int64_t out_count, int32_t* d_users_out, int32_t* d_pos_out,
                            int32_t* d_neg_out, void* stream);
 
+/* Epoch stream of training INSTANCES on the device — replaces the __iter__ of
+ * PointwiseSampler (data/sampler.py:137-149), TimeOrderPointwiseSampler
+ * (:269-282) and TimeOrderPairwiseSampler (:339-347): _sampling_negative_items
+ * (:71-90) + the Python-list layout (:131-135, :141-143, :259-266) +
+ * DataIterator(shuffle) (util/data_iterator.py:58-60,145-152), in one launch.
+ *
+ * Rows r = 0..R-1 in the iteration order of user_pos_dict; d_row_user[r] = user
+ * id; d_seq[d_seq_ptr[r]..) the row's items as the dict holds them (time order
+ * for the TimeOrder samplers); d_excl[d_excl_ptr[r]..) the same set ascending
+ * (exclusion test).  Instance t = d_inst_ptr[r] + k (k < len_r - high_order,
+ * _generative_time_order_positive_items, data/sampler.py:42-68; high_order 0:
+ * _generate_positive_items, :24-39), d_inst_row[t] = r.  pointwise == 0: slot =
+ * instance, d_items_out = positive, d_neg_out [count][neg_num].  pointwise != 0:
+ * n_inst*(neg_num+1) slots, slot s = (c = s / n_inst, t = s % n_inst), c = 0 the
+ * positive (label 1), else negative c-1 of instance t (label 0).  d_recent_out
+ * [count][high_order] (may be NULL when high_order == 0).  Output position p of
+ * the epoch carries slot perm(p); shuffle == 0: identity (the reference's list
+ * order). */
+int nrhip_sample_instances_epoch(const int64_t* d_seq_ptr, const int32_t* d_seq,
+                                 const int64_t* d_excl_ptr, const int32_t* d_excl,
+                                 const int64_t* d_inst_ptr, const int32_t* d_inst_row,
+                                 const int32_t* d_row_user, int64_t n_inst, int high_order,
+                                 int n_items, int neg_num, int pointwise, uint64_t seed,
+                                 uint64_t epoch, int shuffle, int64_t out_begin, int64_t out_count,
+                                 int32_t* d_users_out, int32_t* d_recent_out, int32_t* d_items_out,
+                                 int32_t* d_neg_out, float* d_labels_out, void* stream);
+
 /* batch_randint_choice(high, size, replace, p=None, exclusion)
  * (random_choice.pyx:64-89): request q draws size[q] =
  * d_out_offsets[q+1]-d_out_offsets[q] values into d_out[d_out_offsets[q] ..)

@@ -93,6 +93,7 @@ SIGNATURES = {
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],
     "nrhip_sample_bpr_epoch": [p, p, p, i64, i32, i32, u64, u64, i32, i64, i64, p, p, p, p],
+    "nrhip_sample_instances_epoch": [p, p, p, p, p, p, p, i64, i32, i32, i32, i32, u64, u64, i32, i64, i64, p, p, p, p, p, p],
     "nrhip_randint_choice_batch": [i32, i32, i64, p, p, p, i32, u64, u64, p, p],
     "nrhip_bpr_plan": [p, p, p, i64, i32, i32, p, p],
     "nrhip_bpr_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p],

@@ -86,6 +86,70 @@ __global__ __launch_bounds__(256) void randint_choice_kernel(
   }
 }
 
+// Training INSTANCES beyond the plain BPR triplet (data/sampler.py:93-155 PointwiseSampler,
+// :216-289 TimeOrderPointwiseSampler, :292-354 TimeOrderPairwiseSampler), one thread per slot of
+// the epoch stream, everything the reference builds with Python lists + DataIterator formed here:
+//
+//   rows      r = 0..R-1, in the iteration order of the reference's user_pos_dict; row_user[r] is
+//             the user id;  seq[seq_ptr[r] ..) the row's items in the order the dict holds them
+//             (time order for the TimeOrder samplers);  excl[excl_ptr[r] ..) the same items
+//             ascending, for the exclusion test (random_choice.pyx:50-54 keeps an unordered_set);
+//   instance  t = inst_ptr[r] + k, k < len_r - high_order: recent items seq[k .. k+high_order),
+//             positive item seq[k + high_order]  (_generative_time_order_positive_items,
+//             sampler.py:42-68; high_order = 0 is _generate_positive_items, :24-39);
+//   pairwise  slot s <-> instance s; neg_out[s][0..neg_num) drawn for instance s;
+//   pointwise slot s <-> (c = s / n_inst, t = s % n_inst): c = 0 is the positive (label 1), c >= 1
+//             the (c-1)-th negative of instance t (label 0) — the layout the reference obtains by
+//             concatenating pos_items_list with the TRANSPOSED negative array (sampler.py:141-143)
+//             and repeating users_list (neg_num + 1) times (:131);
+//   stream    output position p carries slot perm(p) (one permutation per epoch, data_iterator.py:58-60).
+// The negative of (instance t, n) comes from the same counter-based stream as the BPR kernel's:
+// key (seed, epoch, t * neg_num + n).
+struct InstanceStream {
+  const int64_t* seq_ptr; const int32_t* seq;
+  const int64_t* excl_ptr; const int32_t* excl;
+  const int64_t* inst_ptr; const int32_t* inst_row; const int32_t* row_user;
+  int64_t n_inst, n_slots;
+  int high_order, n_items, neg_num, pointwise, shuffle;
+  uint64_t seed, epoch;
+  int64_t out_begin, out_count;
+  int32_t* users_out; int32_t* recent_out; int32_t* items_out; int32_t* neg_out; float* labels_out;
+};
+
+__global__ __launch_bounds__(256) void sample_instances_kernel(const InstanceStream a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.out_count) return;
+  const int64_t p = a.out_begin + q;
+  const uint64_t perm_key = nr::splitmix64(a.seed ^ nr::splitmix64(a.epoch + 0x51ed27ull));
+  const int64_t s = a.shuffle ? (int64_t)nr::permute_index((uint64_t)p, (uint64_t)a.n_slots, perm_key) : p;
+  const int64_t t = a.pointwise ? s % a.n_inst : s;
+  const int c = a.pointwise ? (int)(s / a.n_inst) : 0;
+  const int32_t r = a.inst_row[t];
+  const int64_t at = a.seq_ptr[r] + (t - a.inst_ptr[r]);       // first recent item of the window
+  a.users_out[q] = a.row_user[r];
+  for (int h = 0; h < a.high_order; ++h) a.recent_out[q * a.high_order + h] = a.seq[at + h];
+  const int64_t eb = a.excl_ptr[r];
+  const int n_excl = (int)(a.excl_ptr[r + 1] - eb);
+  if (a.pointwise) {
+    if (c == 0) {
+      a.items_out[q] = a.seq[at + a.high_order];
+      a.labels_out[q] = 1.0f;
+    } else {
+      nr::XorShift64s g;
+      g.seed(a.seed, a.epoch, (uint64_t)t * (uint64_t)a.neg_num + (uint64_t)(c - 1));
+      a.items_out[q] = nr::draw_negative(g, a.n_items, a.excl + eb, n_excl);
+      a.labels_out[q] = 0.0f;
+    }
+  } else {
+    a.items_out[q] = a.seq[at + a.high_order];
+    for (int n = 0; n < a.neg_num; ++n) {
+      nr::XorShift64s g;
+      g.seed(a.seed, a.epoch, (uint64_t)t * (uint64_t)a.neg_num + (uint64_t)n);
+      a.neg_out[q * a.neg_num + n] = nr::draw_negative(g, a.n_items, a.excl + eb, n_excl);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -123,6 +187,36 @@ int nrhip_randint_choice_batch(int high, int n_req, int64_t total, const int64_t
   hipLaunchKernelGGL(randint_choice_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, high, n_req, d_out_offsets, d_excl_indptr, d_excl,
                      replace, seed, call_counter, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_sample_instances_epoch(const int64_t* d_seq_ptr, const int32_t* d_seq,
+                                 const int64_t* d_excl_ptr, const int32_t* d_excl,
+                                 const int64_t* d_inst_ptr, const int32_t* d_inst_row,
+                                 const int32_t* d_row_user, int64_t n_inst, int high_order,
+                                 int n_items, int neg_num, int pointwise, uint64_t seed,
+                                 uint64_t epoch, int shuffle, int64_t out_begin, int64_t out_count,
+                                 int32_t* d_users_out, int32_t* d_recent_out, int32_t* d_items_out,
+                                 int32_t* d_neg_out, float* d_labels_out, void* stream) {
+  NR_REQUIRE(d_seq_ptr && d_seq && d_excl_ptr && d_excl && d_inst_ptr && d_inst_row && d_row_user &&
+                 d_users_out && d_items_out,
+             NR_ERR_ARG, "sample_instances_epoch: null pointer argument");
+  NR_REQUIRE(neg_num >= 1, NR_ERR_ARG, "'neg_num' must be a positive integer.");
+  NR_REQUIRE(high_order >= 0, NR_ERR_ARG, "'high_order' must be a positive integer.");
+  NR_REQUIRE(high_order == 0 || d_recent_out, NR_ERR_ARG, "sample_instances_epoch: no buffer for the recent items");
+  NR_REQUIRE(pointwise ? d_labels_out != nullptr : d_neg_out != nullptr, NR_ERR_ARG,
+             "sample_instances_epoch: %s", pointwise ? "no label buffer" : "no negative buffer");
+  const int64_t n_slots = pointwise ? n_inst * ((int64_t)neg_num + 1) : n_inst;
+  NR_REQUIRE(n_items >= 1 && n_inst >= 0 && out_begin >= 0 && out_count >= 0 && out_begin + out_count <= n_slots,
+             NR_ERR_ARG, "sample_instances_epoch: bad range [%lld,+%lld) of %lld", (long long)out_begin,
+             (long long)out_count, (long long)n_slots);
+  if (out_count == 0) return NR_OK;
+  InstanceStream a{d_seq_ptr, d_seq, d_excl_ptr, d_excl, d_inst_ptr, d_inst_row, d_row_user, n_inst, n_slots,
+                   high_order, n_items, neg_num, pointwise ? 1 : 0, shuffle ? 1 : 0, seed, epoch, out_begin,
+                   out_count, d_users_out, d_recent_out, d_items_out, d_neg_out, d_labels_out};
+  hipLaunchKernelGGL(sample_instances_kernel, dim3((unsigned)((out_count + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

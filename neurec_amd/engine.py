@@ -367,6 +367,17 @@ def sample_bpr_epoch(train_csr, row_of, n_items, neg_num, seed, epoch, shuffle=T
     return users[:count], pos[:count], neg[:count * neg_num]
 
 
+def sample_instances_epoch(rows, n_items, neg_num, pointwise, seed, epoch, shuffle, begin, count, out):
+    """One epoch (or a slice) of the instance stream of InstanceRows `rows` (nrhip_sample_instances_epoch):
+    out = (users, recent-or-None, items, neg-or-None, labels-or-None) device buffers, filled in place."""
+    users, recent, items, neg, labels = out
+    call("nrhip_sample_instances_epoch", _ptr(rows.seq_ptr), _ptr(rows.seq), _ptr(rows.excl_ptr), _ptr(rows.excl),
+         _ptr(rows.inst_ptr), _ptr(rows.inst_row), _ptr(rows.row_user), rows.n_inst, rows.high_order, n_items,
+         neg_num, 1 if pointwise else 0, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(epoch), 1 if shuffle else 0,
+         begin, count, _ptr(users), _ptr(recent, allow_none=True), _ptr(items), _ptr(neg, allow_none=True),
+         _ptr(labels, torch.float32, allow_none=True), _stream())
+
+
 def randint_choice_batch(high, sizes, exclusion_csr, replace, seed, counter):
     """Device half of batch_randint_choice: returns an int32 tensor of sum(sizes) draws."""
     dev = require_gpu()

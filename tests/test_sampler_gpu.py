@@ -186,3 +186,75 @@ def test_time_order_and_pointwise_samplers(eng):
         TimeOrderPairwiseSampler(ds, high_order=1, neg_num=0)
     with pytest.raises(ValueError):
         TimeOrderPointwiseSampler(ds, high_order=0)                  # _generative_time_order_positive_items
+
+
+def test_instance_streams_are_the_reference_layout_formed_on_the_device(eng, hostcheck):
+    """data/streams.py + sample_instances_kernel against the reference's list construction: with shuffle=False
+    the stream IS the list layout (positives, then the transposed negative block; users / recent repeated);
+    with shuffle=True it is a permutation of it (same key as the BPR stream); negatives replay on the host from
+    the same per-thread code; device batches (`as_tensors=True`) equal the list batches."""
+    from neurec_amd.data import PointwiseSampler, TimeOrderPairwiseSampler, TimeOrderPointwiseSampler
+    from neurec_amd.data.streams import InstanceEpochStream, InstanceRows
+    rng = np.random.RandomState(12)
+    n_items = 90
+    seqs = {int(u): rng.choice(n_items, rng.randint(1, 15), replace=False).tolist()
+            for u in rng.permutation(70)[:50]}                           # user ids not contiguous, dict order not sorted
+    ds = _SeqDataset(seqs, n_items)
+    h, neg_num, seed = 2, 3, 2018
+    rows = InstanceRows(ds.get_user_train_dict(by_time=True), h, n_items)
+    n_inst = rows.n_inst
+    assert n_inst == sum(max(len(s) - h, 0) for s in seqs.values())
+    # --- pointwise, shuffle=False: the concatenated lists of sampler.py:259-266,269-276
+    st = InstanceEpochStream(rows, n_items, neg_num, True, 64, False, False, seed=seed)
+    users, recent, items, _, labels = [None if f is None else f.cpu().numpy() for f in st.sample_epoch()]
+    assert len(users) == n_inst * (neg_num + 1) and recent.shape == (len(users), h)
+    np.testing.assert_array_equal(users, np.tile(rows.users(), neg_num + 1))
+    np.testing.assert_array_equal(recent, np.tile(rows.recents(), (neg_num + 1, 1)))
+    np.testing.assert_array_equal(items[:n_inst], rows.positives())
+    np.testing.assert_array_equal(labels, np.r_[np.ones(n_inst), np.zeros(n_inst * neg_num)].astype(np.float32))
+    excl = {u: np.sort(np.asarray(s, np.int32)) for u, s in seqs.items()}
+    for t in range(0, n_inst, 7):
+        for c in range(neg_num):                                         # block c of the transposed negative array
+            ex = np.ascontiguousarray(excl[int(users[t])])
+            want = hostcheck.hc_draw_negative(seed, 0, t * neg_num + c, n_items, ex, len(ex))
+            assert items[(c + 1) * n_inst + t] == want and want not in seqs[int(users[t])]
+    # --- shuffle=True: position p carries slot perm(p)
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9e3779b97f4a7c15) & M
+        x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & M
+        x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & M
+        return x ^ (x >> 31)
+    st2 = InstanceEpochStream(rows, n_items, neg_num, True, 64, True, False, seed=seed)
+    u2, r2, i2, _, l2 = [None if f is None else f.cpu().numpy() for f in st2.sample_epoch()]
+    key = sm(seed ^ sm(0x51ed27))
+    perm = np.array([hostcheck.hc_permute_index(p, len(users), key) for p in range(len(users))])
+    assert np.array_equal(np.sort(perm), np.arange(len(users)))
+    np.testing.assert_array_equal(u2, users[perm]); np.testing.assert_array_equal(i2, items[perm])
+    np.testing.assert_array_equal(l2, labels[perm]); np.testing.assert_array_equal(r2, recent[perm])
+    u3 = st2.sample_epoch()[0].cpu().numpy()                             # next epoch: another permutation
+    assert not np.array_equal(u3, u2) and np.array_equal(np.sort(u3), np.sort(u2))
+    # --- pairwise stream: negatives [n_inst][neg_num], the BPR kernel's counter stream
+    sp = InstanceEpochStream(rows, n_items, neg_num, False, 64, False, False, seed=seed)
+    pu, pr, pp, pn, pl = sp.sample_epoch()
+    assert pl is None and tuple(pn.shape) == (n_inst, neg_num)
+    np.testing.assert_array_equal(pp.cpu().numpy(), rows.positives())
+    np.testing.assert_array_equal(pn.cpu().numpy().T.reshape(-1), items[n_inst:])   # the same draws, untransposed
+    # --- front ends: list batches == device batches; len(); short last batch; drop_last
+    for cls, kw in ((PointwiseSampler, {}), (TimeOrderPointwiseSampler, {"high_order": 1}),
+                    (TimeOrderPairwiseSampler, {"high_order": 3})):
+        a = cls(ds, neg_num=2, batch_size=37, shuffle=True, **kw)
+        b = cls(ds, neg_num=2, batch_size=37, shuffle=True, as_tensors=True, **kw)
+        la, lb = list(a), list(b)
+        assert len(la) == len(a) == len(lb) and all(len(f) == len(la[0][0]) for f in la[0])
+        for x, y in zip(la, lb):
+            for fx, fy in zip(x, y):
+                assert fx == fy.cpu().tolist()
+        assert sum(len(x[0]) for x in la) == a.stream.n_slots and len(la[-1][0]) == a.stream.n_slots % 37
+        d = cls(ds, neg_num=2, batch_size=37, shuffle=True, drop_last=True, **kw)
+        assert len(list(d)) == len(d) == a.stream.n_slots // 37
+    # a user with as many items as there are: the reference's rejection loop refuses while iterating
+    full = _SeqDataset({0: list(range(5)), 1: [1, 2]}, 5)
+    with pytest.raises(ValueError):
+        next(iter(PointwiseSampler(full)))
