@@ -218,20 +218,24 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     rows_list = [perm[k * B:(k + 1) * B].contiguous() for k in range(U // B)]
     it = iter(rows_list * 20)
     ms = _hip_timed(lambda: vae.step(next(it), 0.2, 0.8, want_loss=True), 150, 20)
-    # dominant kernels: the decoder gradient (row statistics + dW_p1 and dg1 on the fp32 matrix cores) reads the
-    # [B][I] logits slab three times
+    # dominant kernels: the decoder's loss + gradients with NO [B][I] buffer (csrc/vae_fused.hip): logits tiles are
+    # recomputed on the fp32 matrix cores in two passes (statistics; gradients)
     rows = rows_list[0]
     vae.step(rows, 0.2, 0.8)
-    S = vae.gemm(vae.G1[:B], None, out=vae.S)
 
     def decoder():
-        E.vae_decoder_loss_grad(S, I, vae.P["bp1"], vae.csr, rows, vae.G1[:B], vae.P["Wp1t"], vae.nll[:B],
-                                vae.G["Wp1t"], vae.G["bp1"], vae.dG1[:B], vae.ws)
+        E.vae_decoder_fused(I, vae.P["bp1"], vae.csr, rows, vae.G1[:B], vae.P["Wp1t"], vae.nll[:B],
+                            vae.G["Wp1t"], vae.G["bp1"], vae.dG1[:B], vae.ws)
     dec_ms = _hip_timed(decoder, 40, 5)
     for k in vae.G:
         vae.G[k].zero_()
-    dec_bytes = 3 * B * I * 4
-    dec_flops = 2 * 2.0 * B * I * h                       # dW_p1 = G^T g1 and dg1 = G W_p1
+    nnz_b = int((vae.csr.h_indptr[rows.cpu().numpy().astype(np.int64) + 1]
+                 - vae.csr.h_indptr[rows.cpu().numpy().astype(np.int64)]).sum())
+    # algorithmic bytes: W_p1 + b_p1 read, dW_p1 + db_p1 written, g1 read, dg1 + nll written, the batch's CSR rows
+    dec_bytes = 2 * (I * h + I) * 4 + (2 * B * h + B) * 4 + nnz_b * 4 + 2 * B * 8
+    # flops issued: the logits twice (K = h + the bias step, 17 MFMA steps of 2) and the two gradients once each
+    dec_flops = 2.0 * B * I * (2 * (h + 2) + 2 * h)
+    dec_flops_min = 3 * 2.0 * B * I * h                    # logits, dW_p1 = G^T g1, dg1 = G W_p1 once each
     users = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
     ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=16384)
 
@@ -241,15 +245,19 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     evaluate()
     edt, m = _median_wall(evaluate)
     out = {"ms_per_step": ms, "users_per_sec_train": B / ms * 1e3, "batch": B, "p_dim": [z, h],
-           "roofline": {"bound": "hbm", "kernel": "vae_softmax_stats_kernel + vae_dwp1_mfma_kernel + vae_dg1_mfma_kernel "
-                                                  "(nrhip_vae_decoder_loss_grad)",
-                        "bytes_per_launch": dec_bytes, "us_per_launch": dec_ms * 1e3, "launches_per_step": 1,
-                        "achieved": dec_bytes / dec_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": dec_bytes / dec_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                        "mfma_tflops": dec_flops / dec_ms / 1e9,
-                        "note": "3*B*I*4 B: the [B][I] logits slab is read by each of the three kernels; the two "
-                                "gradients are 32-wide contractions (10.7 GFLOP), far from the MFMA roof — the slab "
-                                "reads bound them"},
+           "roofline": {"bound": "mfma", "kernel": "vae_dec_stats_kernel + vae_dec_grad_kernel<2> (+ rows / stat / dg1-reduce: "
+                                                   "nrhip_vae_decoder_fused)",
+                        "flops_per_launch": dec_flops, "us_per_launch": dec_ms * 1e3, "launches_per_step": 1,
+                        "achieved": dec_flops / dec_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": dec_flops / dec_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                        "frac_of_minimal_flops": dec_flops_min / dec_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                        "algorithmic_bytes": dec_bytes, "hbm_frac_on_algorithmic_bytes": dec_bytes / dec_ms / 1e6 / HBM_PEAK_GBS,
+                        "traffic": None,
+                        "note": "no [B][I] logits slab any more: the 32-deep logits product is recomputed tile by tile in both "
+                                "passes (4 GEMM-equivalents of 2·B·I·h issued where 3 are the minimum), so the bound is the fp32 "
+                                "matrix pipe, not HBM: algorithmic bytes are W_p1 + dW_p1 + the batch rows (10.6 MB, ~1.3 us at "
+                                "8 TB/s).  frac = issued flops / time / dense fp32 MFMA peak; frac_of_minimal_flops counts the "
+                                "recomputation as waste.  The slab form it replaces moved 336 MB (profiles/r04_narrow_vae_*)"},
            "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9]),
                     "design": "factor path: logits = [g1(u) | 1]·[W_p1 | b_p1] through the pruned evaluator"}}
     # conf/MultiVAE.properties:3's alternative shape p_dim = [200, 600] on the width-generic engine

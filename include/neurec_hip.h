@@ -605,6 +605,15 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
                                 const float* d_G1, const float* d_Wp1, float* d_nll,
                                 float* d_dWp1, float* d_dbp1, float* d_dG1, void* d_ws,
                                 size_t ws_bytes, void* stream);
+/* The decoder's loss and gradients with NO [batch][cols] buffer (csrc/vae_fused.hip; MultiVAE.py:104-124):
+ * logits tiles are recomputed by MFMA in two passes (statistics; gradients) and never leave the registers.
+ * Same arguments as nrhip_vae_decoder_loss_grad minus the slab; d_G1 [batch][h], d_Wp1 [cols][h] item-major.
+ * d_dbg_logits: NULL, or (tests) a [batch][cols] buffer that receives pass 1's logits (bias included). */
+int nrhip_vae_decoder_fused_workspace_bytes(int batch, int cols, size_t* bytes);
+int nrhip_vae_decoder_fused(int batch, int cols, int h, const float* d_G1, const float* d_Wp1,
+                            const float* d_bp1, const int64_t* d_indptr, const int32_t* d_indices,
+                            const int32_t* d_rows, float* d_nll, float* d_dWp1, float* d_dbp1,
+                            float* d_dG1, void* d_ws, size_t ws_bytes, float* d_dbg_logits, void* stream);
 int nrhip_vae_mid_backward(int batch, int h, int z, int act, float anneal, const float* d_dG1,
                            const float* d_G1, const float* d_H1, const float* d_MU,
                            const float* d_LOGVAR, const float* d_EPSSTD, const float* d_ZS,

@@ -188,6 +188,8 @@ SIGNATURES = {
     "nrhip_add_row_bias": [p, i64, i32, i32, p, p],
     "nrhip_vae_workspace_bytes": [i32, i32, psz],
     "nrhip_vae_decoder_loss_grad": [p, i64, i32, i32, i32, p, p, p, p, p, p, p, p, p, p, p, sz, p],
+    "nrhip_vae_decoder_fused_workspace_bytes": [i32, i32, psz],
+    "nrhip_vae_decoder_fused": [i32, i32, i32, p, p, p, p, p, p, p, p, p, p, p, sz, p, p],
     "nrhip_vae_mid_backward": [i32, i32, i32, i32, f32, p, p, p, p, p, p, p, p, p, p, p, p, p, p,
                                p, p, p, p],
     "nrhip_vae_dwq0": [p, p, p, i32, i32, p, p, p, p],

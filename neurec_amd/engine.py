@@ -1039,6 +1039,19 @@ def vae_decoder_loss_grad(S, cols, bp1, csr, rows, G1, Wp1, nll, dWp1, dbp1, dG1
          _stream())
 
 
+def vae_fused_workspace(batch, cols, device):
+    nbytes = C.c_size_t(0)
+    call("nrhip_vae_decoder_fused_workspace_bytes", batch, cols, C.byref(nbytes))
+    return torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+
+
+def vae_decoder_fused(cols, bp1, csr, rows, G1, Wp1, nll, dWp1, dbp1, dG1, ws, dbg_logits=None):
+    """nrhip_vae_decoder_fused: loss + gradients of the Mult-VAE decoder, logits never stored"""
+    call("nrhip_vae_decoder_fused", rows.numel(), cols, G1.shape[1], _ptr(G1, torch.float32), _ptr(Wp1, torch.float32),
+         _ptr(bp1), _ptr(csr.indptr), _ptr(csr.indices), _ptr(rows, torch.int32), _ptr(nll), _ptr(dWp1), _ptr(dbp1),
+         _ptr(dG1), _ptr(ws), ws.numel(), _ptr(dbg_logits, torch.float32, allow_none=True), _stream())
+
+
 def vae_mid_backward(batch, act, anneal, dG1, G1, H1, MU, LOGVAR, EPSSTD, ZS, Wp0, Wq1, DA3, DH2,
                      DA1, dWp0, dbp0, dWq1, dbq1, dbq0):
     z, h = Wp0.shape

@@ -720,14 +720,21 @@ class MultiVAEEngine:
 
     Parameters live on the GPU as W_q0 [I][h], b_q0 [h], W_q1 [h][2z], b_q1 [2z], W_p0 [z][h],
     b_p0 [h], W_p1ᵀ [I][h] (item-major — the transpose of the TF variable), b_p1 [I].
-    A step = encode (bag-sum over each user's CSR row; no dense [B][I] input) -> logits on the
-    matrix cores -> softmax/neg-ELBO gradient in place -> the two wide weight gradients -> the
+    A step = encode (bag-sum over each user's CSR row; no dense [B][I] input) -> the decoder's loss and
+    gradients with the logits recomputed tile by tile on the matrix cores, never stored (csrc/vae_fused.hip;
+    `decoder="slab"` keeps the first form: one [B][I] logits slab written once, read three times) -> the
     narrow layers -> dense TF-Adam on all eight variables (MultiVAE.py:126-139)."""
 
     NAMES = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1t", "bp1")
 
-    def __init__(self, train_csr, n_items, params, lr, reg, act, max_batch, seed=2017):
+    def __init__(self, train_csr, n_items, params, lr, reg, act, max_batch, seed=2017, decoder=None):
         dev = E.require_gpu()
+        if decoder is None:                      # A/B switch for tests and profiles; the product default is "fused"
+            import os
+            decoder = os.environ.get("NEUREC_VAE_DECODER", "fused")
+        if decoder not in ("fused", "slab"):
+            raise ValueError("decoder must be 'fused' or 'slab'")
+        self.decoder = decoder
         self.csr, self.n_items = train_csr, int(n_items)
         f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
         self.P = {k: f(params[k]) for k in self.NAMES}
@@ -749,10 +756,17 @@ class MultiVAEEngine:
         self.KLb, self.nll = zf(B), zf(B)
         self.h0val = zf(max(train_csr.nnz, 1))
         self.gemm = E.ScoreGemm(self.P["Wp1t"], B)
-        self.S = self.gemm.new_score_buffer(B)
-        self.ws = E.vae_workspace(B, self.n_items, dev)
+        self._S = None                             # the [B][I] slab exists only where somebody asks for logits
+        self.ws = (E.vae_fused_workspace(B, self.n_items, dev) if decoder == "fused"
+                   else E.vae_workspace(B, self.n_items, dev))
         self.stats = zf(2)                         # [neg_ll, KL] of the last step
         self.regsum = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    @property
+    def S(self):
+        if self._S is None:
+            self._S = self.gemm.new_score_buffer(self.max_batch)
+        return self._S
 
     def gemm_out(self, rows):
         """a fresh [rows][ld] score slab (predict hands its result to the evaluator)"""
@@ -812,10 +826,14 @@ class MultiVAEEngine:
         E.vae_encode(self.csr, rows, P["Wq0"], P["bq0"], P["Wq1"], P["bq1"], P["Wp0"], P["bp0"],
                      self.act, keep, 1.0, self.seed, self.t, self._fwd_bufs(B),
                      drop_given=drop_given, eps_given=eps_given, h0val=self.h0val)
-        self.gemm.prepare(P["Wp1t"])
-        S = self.gemm(self.G1[:B], None, out=self.S)
-        E.vae_decoder_loss_grad(S, self.n_items, P["bp1"], self.csr, rows, self.G1[:B], P["Wp1t"],
-                                self.nll[:B], G["Wp1t"], G["bp1"], self.dG1[:B], self.ws)
+        if self.decoder == "fused":
+            E.vae_decoder_fused(self.n_items, P["bp1"], self.csr, rows, self.G1[:B], P["Wp1t"], self.nll[:B],
+                                G["Wp1t"], G["bp1"], self.dG1[:B], self.ws)
+        else:
+            self.gemm.prepare(P["Wp1t"])
+            S = self.gemm(self.G1[:B], None, out=self.S)
+            E.vae_decoder_loss_grad(S, self.n_items, P["bp1"], self.csr, rows, self.G1[:B], P["Wp1t"],
+                                    self.nll[:B], G["Wp1t"], G["bp1"], self.dG1[:B], self.ws)
         E.vae_mid_backward(B, self.act, anneal, self.dG1[:B], self.G1[:B], self.H1[:B], self.MU[:B],
                            self.LOGVAR[:B], self.EPSSTD[:B], self.ZS[:B], P["Wp0"], P["Wq1"],
                            self.DA3[:B], self.DH2[:B], self.DA1[:B], G["Wp0"], G["bp0"], G["Wq1"],

@@ -68,6 +68,9 @@ class MultiVAEWideEngine:
         nbytes = E.C.c_size_t(0)
         call("nrhip_gemm_workspace_bytes", max(B, wmax), wmax, max(self.splits, self.mid_splits), E.C.byref(nbytes))
         self.ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
+        # column sums over more than 2,048 rows go through ceil(rows / 512) partial rows (nrhip_colsum_rows)
+        widths = [I, self.h_last] + [w.shape[1] for w in mids] + [self.Wq[0].shape[1]]
+        self.cs_ws = z(max((B + 511) // 512 * max(widths), 64)) if B > 2048 else None
         self.stats = z(2)
         self.regsum = torch.zeros(1, dtype=torch.float64, device=dev)
         self.last_anneal = 0.0
@@ -79,6 +82,11 @@ class MultiVAEWideEngine:
              int(K), _ptr(Cm), int(ldc), 0, _ptr(bias, torch.float32, allow_none=True), int(act), int(splits),
              _ptr(self.ws), self.ws.numel() if splits > 1 else 0, _stream())
 
+    def _colsum(self, X, ld, rows, cols, out):
+        ws = self.cs_ws
+        call("nrhip_colsum_rows", _ptr(X), int(ld), int(rows), int(cols), _ptr(out),
+             _ptr(ws, allow_none=True), 0 if ws is None else ws.numel() * 4, _stream())
+
     def _dense_fwd(self, X, W, b, B, act, Y):
         """Y[:B] = act(X[:B] W + b): x row-major (k-minor) and the TF variable [in][out] (k-major), as they lie."""
         K, N = W.shape
@@ -89,7 +97,7 @@ class MultiVAEWideEngine:
         k-minor as stored)."""
         K, N = W.shape
         self._gemm(X, K, 0, dA, N, 0, K, N, B, dW, N, splits=self.mid_splits if B >= 256 else 1)
-        call("nrhip_colsum_rows", _ptr(dA), N, B, N, _ptr(db), None, 0, _stream())
+        self._colsum(dA, N, B, N, db)
         self._gemm(dA, N, 1, W, N, 1, B, K, N, dX, K)
 
     def _forward(self, rows, csr, keep, is_training, drop_given, eps_given, S):
@@ -138,7 +146,7 @@ class MultiVAEWideEngine:
         iWq, ibq, iWp, ibp = 0, n, 2 * n, 3 * n                                           # offsets into params / G
         # last decoder layer on the matrix cores
         self._gemm(g_last, h, 0, S, ld, 0, h, I, B, self.G[iWp + n - 1], I)                # dW = g^T D
-        call("nrhip_colsum_rows", _ptr(S), ld, B, I, _ptr(self.G[ibp + n - 1]), None, 0, _stream())
+        self._colsum(S, ld, B, I, self.G[ibp + n - 1])
         dg = self.dGp[-1] if n > 1 else self.dZ
         self._gemm(S, ld, 1, self.Wp[-1], I, 1, B, h, I, dg, h, splits=self.splits)        # d g = D W^T
         # hidden decoder layers
@@ -160,7 +168,7 @@ class MultiVAEWideEngine:
         w0 = self.Wq[0].shape[1]
         call("nrhip_vae_dwq0_wide", _ptr(csr.indptr), _ptr(csr.indices), _ptr(rows, torch.int32), B, w0,
              _ptr(self.h0val), _ptr(d), _ptr(self.G[iWq]), _stream())                     # G[Wq0] is zero here
-        call("nrhip_colsum_rows", _ptr(d), w0, B, w0, _ptr(self.G[ibq]), None, 0, _stream())
+        self._colsum(d, w0, B, w0, self.G[ibq])
         if want_loss:
             E.mean2_f32(self.nll[:B], self.KLb[:B], self.stats)
         if self.reg != 0.0:

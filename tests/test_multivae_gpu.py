@@ -181,14 +181,54 @@ def test_multivae_rejects_unbuilt_widths():
         eng.logits(_dev(np.arange(8, dtype=np.int32)))
 
 
-def test_valu_decoder_form_still_passes_this_file():
-    """NEUREC_VAE_DECODER_VALU=1 keeps the first decoder-gradient design (dlogits in place, two VALU
-    passes) as an A/B: the same oracle comparisons of this file hold for it."""
+@pytest.mark.parametrize("B,I,h", [(512, 4099, 32), (300, 1000, 32), (700, 2050, 20), (33, 31, 32), (1, 77, 5)])
+def test_fused_decoder_equals_the_slab_form(B, I, h):
+    """csrc/vae_fused.hip (no [B][I] buffer) against the slab form it replaces: pass 1's logits are bit for bit
+    the slab's (score GEMM chain + bias), nll / dW_p1 / db_p1 / dg1 agree to fp32 rounding of the differently
+    associated sums; ragged sizes: rows beyond one 512-row chunk, tiles cut by the batch, the item count and h."""
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(B + I)
+    R = sp.random(B + 7, I, min(0.5, 30.0 / I), random_state=1, format="csr", dtype=np.float32)
+    R.data[:] = 1.0
+    R.sort_indices()
+    csr = E.DeviceCSR.from_scipy(R)
+    rows = _dev(rng.permutation(B + 7)[:B].astype(np.int32))
+    G1 = _dev((rng.randn(B, h) * 0.7).astype(np.float32))
+    W = _dev((rng.randn(I, h) * 0.5).astype(np.float32))
+    b = _dev((rng.randn(I) * 0.3).astype(np.float32))
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device="cuda")
+    out_f = (z(B), z(I, h), z(I), z(B, h))
+    dbg = torch.full((B, I), float("nan"), device="cuda")
+    E.vae_decoder_fused(I, b, csr, rows, G1, W, *out_f, E.vae_fused_workspace(B, I, "cuda"), dbg_logits=dbg)
+    gemm = E.ScoreGemm(W, B)
+    gemm.prepare(W)
+    S = gemm(G1, None, out=gemm.new_score_buffer(B))
+    logits = S[:, :I] + b[None, :]
+    assert torch.equal(dbg, logits)
+    out_s = (z(B), z(I, h), z(I), z(B, h))
+    E.vae_decoder_loss_grad(S, I, b, csr, rows, G1, W, *out_s, E.vae_workspace(B, I, "cuda"))
+    # both against the fp64 statement of the same formulas
+    L = logits.double()
+    X = torch.from_numpy(np.asarray(R.todense())).cuda()[rows.long()].double()
+    lsm = L - torch.logsumexp(L, 1, keepdim=True)
+    Gd = (torch.exp(lsm) * X.sum(1, keepdim=True) - X) / B
+    want = (-(lsm * X).sum(1), Gd.T @ G1.double(), Gd.sum(0), Gd @ W.double())
+    for name, f, s_, w in zip(("nll", "dWp1", "dbp1", "dg1"), out_f, out_s, want):
+        scale = max(float(w.abs().max()), 1e-6)
+        ef, es = float((f.double() - w).abs().max()) / scale, float((s_.double() - w).abs().max()) / scale
+        assert ef < 2e-6 and ef <= max(4 * es, 5e-7), (name, ef, es)
+
+
+def test_slab_and_valu_decoder_forms_still_pass_this_file():
+    """NEUREC_VAE_DECODER=slab keeps the first decoder (one [B][I] logits slab; NEUREC_VAE_DECODER_VALU=1: its
+    VALU gradient passes) as an A/B: the same oracle comparisons of this file hold for both."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, NEUREC_VAE_DECODER_VALU="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p",
-                          "no:cacheprovider", "-k", "not valu_decoder_form"], env=env, capture_output=True,
-                         text=True, timeout=280, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert out.returncode == 0, out.stdout[-3000:]
+    for extra in ({}, {"NEUREC_VAE_DECODER_VALU": "1"}):
+        env = dict(os.environ, NEUREC_VAE_DECODER="slab", **extra)
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p",
+                              "no:cacheprovider", "-k", "not decoder_form"], env=env, capture_output=True,
+                             text=True, timeout=280, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, out.stdout[-3000:]

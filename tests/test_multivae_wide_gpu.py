@@ -136,6 +136,39 @@ def test_wide_engine_at_p_dim_200_600_equals_the_restatement():
         assert d <= 2.5 * lr
 
 
+def test_wide_engine_steps_a_batch_beyond_2048_rows():
+    """the column sums of a batch of more than 2,048 rows go through a workspace (nrhip_colsum_rows'
+    chunked form) — the engine owns one; first-step gradients against the restatement at B = 2,304."""
+    from neurec_amd import engine as E
+    from neurec_amd.vae_wide import MultiVAEWideEngine
+    from oracle import train as O
+    rng = np.random.RandomState(9)
+    U, I, B, z, hdim = 2400, 500, 2304, 12, 40
+    R = sp.random(U, I, density=0.03, random_state=rng, format="csr", dtype=np.float32)
+    R.data[:] = 1
+    R = R[np.diff(R.indptr) > 0]
+    U = R.shape[0]
+    B = min(B, U)
+    assert B > 2048
+    xav = lambda a, b: (rng.uniform(-1, 1, (a, b)) * np.sqrt(6.0 / (a + b))).astype(np.float32)
+    tn = lambda b: (rng.randn(b) * 0.001).astype(np.float32)
+    Wq, bq = [xav(I, hdim), xav(hdim, 2 * z)], [tn(hdim), tn(2 * z)]
+    Wp, bp = [xav(z, hdim), xav(hdim, I)], [tn(hdim), tn(I)]
+    eng = MultiVAEWideEngine(E.DeviceCSR.from_scipy(R), I, Wq, bq, Wp, bp, 1e-3, 0.0, "tanh", B)
+    rows = rng.choice(U, B, replace=False).astype(np.int32)
+    mask = (rng.rand(B, I) < 0.8).astype(np.float32)
+    eps = (rng.randn(B, z) * 0.01).astype(np.float32)
+    dt = np.float64
+    W = [[x.astype(dt) for x in grp] for grp in (Wq, bq, Wp, bp)]
+    X = np.asarray(R[rows].todense(), dtype=dt)
+    loss, grads, _, _ = O.multivae_general(X, W[0], W[1], W[2], W[3], mask.astype(dt), dt(0.8), eps.astype(dt), 0.2, 0.0,
+                                           "tanh")
+    eng.step(_dev(rows), 0.2, 0.8, drop_given=_dev(_drop_by_entry(R, rows, mask)), eps_given=_dev(eps), apply=False)
+    flat = grads[0] + grads[1] + grads[2] + grads[3]
+    dgrad = max(_err(a.cpu().numpy().reshape(b.shape), b) / max(np.abs(b).max(), 1e-30) for a, b in zip(eng.G, flat))
+    assert abs(eng.loss()[0] - float(loss)) <= TOL * abs(float(loss)) and dgrad <= TOL, (eng.loss()[0], float(loss), dgrad)
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(64, 64, 16, 1), (100, 333, 77, 1), (512, 1000, 600, 1), (200, 600, 512, 1),
                                           (96, 40, 5000, 8), (512, 600, 4099, 16), (1, 1, 1, 1)])
 def test_gemm_kmajor_is_the_k_ascending_fmaf_chain(M, N, K, splits):
