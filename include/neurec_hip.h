@@ -410,6 +410,18 @@ int nrhip_spmm_blocked_wanted_batch(const void* plan, const int32_t* d_indices, 
 int nrhip_spmm_plan_has_wanted(const void* plan, int d);
 int nrhip_spmm_blocked_has_wanted(const void* blocked_plan);
 
+/* Chunked propagation hop of the row-sharded engine (neurec_amd/sharded.py; LightGCN.py:132-149 with the operand
+ * arriving in rank-ordered chunks — SURVEY 8e "overlap layer-k comm with layer-k local SpMM").  One launch per
+ * operand chunk (columns < x_split: the rank's own block d_X; the rest: the received chunk d_X2) carries every
+ * (virtual) row's accumulator on, so a row's sum stays ONE ascending-column chain; the
+ * finish pass combines a hub row's 256-non-zero segments in segment order and applies nrhip_spmm_csr's epilogue. */
+int nrhip_spmm_csr_carry(const void* plan, const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
+                         const float* d_X, const float* d_X2, int x_split, int d, float* d_Yv, int has_carry,
+                         const uint8_t* d_row_mask, void* stream);
+int nrhip_spmm_chunks_finish(const int32_t* d_first_vrow, int64_t n_rows, const float* d_Yv, int d, float* d_Y,
+                             const float* d_addend, const float* d_sum_in, float* d_sum_out,
+                             const uint8_t* d_row_mask, void* stream);
+
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,
                         const float* d_addend, const float* d_sum_in, float* d_sum_out,
@@ -667,6 +679,8 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_use
                             int batch, float reg, int loss_kind, float* d_GP, float* d_GQ,
                             float* d_work, float* d_loss2, const uint64_t* d_plan, void* stream);
 int nrhip_mark_rows(const int32_t* d_ids, int n, int offset, uint8_t* d_flag, void* stream);
+/* d_dst[i] = d_src[d_index[i]]: a row flag per VIRTUAL row of the chunked hop (nrhip_spmm_csr_carry) */
+int nrhip_gather_u8(const uint8_t* d_src, const int32_t* d_index, int64_t n, uint8_t* d_dst, void* stream);
 /* Ordered sums of gradient rows that arrive from other ranks (row-sharded tables): sort the
  * keys (local row << 32 | global occurrence position; any n: one LDS workgroup up to 16384 keys, the
  * segmented multi-workgroup network beyond), then every row's run

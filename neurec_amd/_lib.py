@@ -110,6 +110,8 @@ SIGNATURES = {
     "nrhip_spmm_workspace_bytes": [p, i32, psz],
     "nrhip_spmm_csr": [p, p, p, p, p, i32, p, p, p, p, p, sz, p],
     "nrhip_spmm_csr_masked": [p, p, p, p, p, p, p, i32, p, p, p, p, p, sz, p],
+    "nrhip_spmm_csr_carry": [p, p, p, p, p, p, i32, i32, p, i32, p, p],
+    "nrhip_spmm_chunks_finish": [p, i64, p, i32, p, p, p, p, p, p],
     "nrhip_spmm_csr_rows": [p, p, p, p, i32, p, i32, p, p, p, p, p],
     "nrhip_lightgcn_mark_batch": [p, p, p, i32, i32, p, p, p],
     "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p],
@@ -199,6 +201,7 @@ SIGNATURES = {
     "nrhip_mean2_f32": [p, p, i32, p, p],
     "nrhip_pairwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
     "nrhip_pointwise_mf_grad": [p, p, i32, i32, p, p, p, i32, f32, i32, p, p, p, p, p, p],
+    "nrhip_gather_u8": [p, p, i64, p, p],
     "nrhip_mark_rows": [p, i32, i32, p, p],
     "nrhip_sort_u64": [p, i32, p],
     "nrhip_rows_sum_sorted": [p, i32, p, i32, p, i64, p, p],

@@ -415,6 +415,14 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MultiAdam t, float alph
 
 }  // namespace
 
+// dst[i] = src[index[i]] (row flags of the chunked hop's virtual rows: neurec_amd/sharded.py)
+__global__ __launch_bounds__(256) static void gather_u8_kernel(const uint8_t* __restrict__ src,
+                                                               const int32_t* __restrict__ index, int64_t n,
+                                                               uint8_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[index[i]];
+}
+
 extern "C" {
 
 void nrhip_set_error(const char* fmt, ...) {
@@ -554,6 +562,15 @@ int nrhip_rows_div(const int32_t* d_rows, int n_listed, int d, const float* d_sr
   if (n_listed == 0) return NR_OK;
   hipLaunchKernelGGL(rows_div_kernel, dim3((n_listed + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      d_rows, n_listed, d, d_src, denom, d_dst);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_gather_u8(const uint8_t* d_src, const int32_t* d_index, int64_t n, uint8_t* d_dst, void* stream) {
+  NR_REQUIRE(d_src && d_index && d_dst && n >= 0, NR_ERR_ARG, "gather_u8: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(gather_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src,
+                     d_index, n, d_dst);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -255,7 +255,13 @@ __device__ __forceinline__ void hub_row_block(int row, float (*part)[D],
 //   col_mask[c] == 0  promises X[c][:] == 0            -> term skipped
 //   row_mask[r] == 0  says output row r is not needed   -> row left untouched
 // ----------------------------------------------------------------------------
-template <int D, int WPB, int TR, int G, bool MASKED>
+// CARRY: a row's accumulator starts from carry[row] instead of 0 — the chunked (pipelined all-gather) hop of the
+// row-sharded engine walks a row's non-zeros in several launches, one per operand chunk, and the sum must stay
+// ONE ascending chain ((carry + a1·x1) + a2·x2 ...).  The carried rows are requested together with the item's first
+// indices (same round trip), parked in the LDS tile and picked up at every row boundary.
+// CHUNK: 0 = the one-launch hop; 1 = first chunk of a chunked hop; 2 = a later chunk (CARRY).  Chunk launches read
+// the operand from TWO buffers: columns < x_split index X (this rank's own block), the others X2 (the received chunk).
+template <int D, int WPB, int TR, int G, bool MASKED, int CHUNK = 0>
 __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
     const int32_t* __restrict__ item_row0, const int32_t* __restrict__ item_nrows,
     const int64_t* __restrict__ item_begin, const int32_t* __restrict__ item_len,
@@ -264,8 +270,10 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float* __restrict__ X, float* __restrict__ Y, const float* __restrict__ addend,
     const float* sum_in, float* sum_out, const uint8_t* __restrict__ col_mask,
-    const uint8_t* __restrict__ row_mask) {
+    const uint8_t* __restrict__ row_mask, const float* carry = nullptr, const float* X2 = nullptr,
+    int x_split = 0) {
   constexpr int CPL = D / NR_WAVE;
+  constexpr bool CARRY = CHUNK == 2;
   __shared__ float s_tile[WPB][TR][D];
   const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
   // Item order is [hub segments | class A | class B].  Classes are a locality hint: in a
@@ -339,6 +347,25 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
     nxt_idx = indices[b + lane];
     nxt_val = vals[b + lane];
   }
+  if constexpr (CARRY) {                        // behind the index loads: the same memory round trip
+    for (int i0 = 0; i0 < nr; i0 += 8) {
+      float cv[8][CPL];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t row = (int64_t)r0 + min(i0 + i, nr - 1);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) cv[i][c] = carry[row * D + lane + c * NR_WAVE];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i0 + i < nr) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) tile[i0 + i][lane + c * NR_WAVE] = cv[i][c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = tile[0][lane + c * NR_WAVE];   // a lane reads what it wrote itself
+  }
   for (int k0 = 0; k0 < len; k0 += NR_WAVE) {
     const int n = min(NR_WAVE, len - k0);
     const int my_idx = nxt_idx;
@@ -357,7 +384,8 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
           const int col = __builtin_amdgcn_readlane(my_idx, tt);
           a[u] = __builtin_bit_cast(
               float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), tt));
-          const float* xr = X + (int64_t)col * D + lane;
+          const float* xr = ((CHUNK != 0 && col >= x_split) ? X2 + (int64_t)(col - x_split) * D
+                                                                : X + (int64_t)col * D) + lane;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) x[u][c] = xr[c * NR_WAVE];
         }
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
 #pragma unroll
               for (int c = 0; c < CPL; ++c) {
                 tile[cur][lane + c * NR_WAVE] = acc[c];
-                acc[c] = 0.f;
+                acc[c] = (CARRY && cur + 1 < nr) ? tile[cur + 1][lane + c * NR_WAVE] : 0.f;
               }
               ++cur;
               cur_end = cur < nr ? __builtin_amdgcn_readlane(my_end, cur) : INT_MAX;
@@ -409,7 +437,8 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
         const int col = __builtin_amdgcn_readlane(my_idx, pos);
         a[u] = __builtin_bit_cast(float,
                                   __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_val), pos));
-        const float* xr = X + (int64_t)col * D + lane;
+        const float* xr = ((CHUNK != 0 && col >= x_split) ? X2 + (int64_t)(col - x_split) * D
+                                                                : X + (int64_t)col * D) + lane;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) x[u][c] = xr[c * NR_WAVE];
       }
@@ -421,7 +450,7 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
               tile[cur][lane + c * NR_WAVE] = acc[c];
-              acc[c] = 0.f;
+              acc[c] = (CARRY && cur + 1 < nr) ? tile[cur + 1][lane + c * NR_WAVE] : 0.f;
             }
             ++cur;
             cur_end = cur < nr ? __builtin_amdgcn_readlane(my_end, cur) : INT_MAX;
@@ -436,7 +465,7 @@ __global__ __launch_bounds__(WPB* NR_WAVE) void spmm_item_kernel(
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       tile[cur][lane + c * NR_WAVE] = acc[c];
-      acc[c] = 0.f;
+      acc[c] = (CARRY && cur + 1 < nr) ? tile[cur + 1][lane + c * NR_WAVE] : 0.f;
     }
     ++cur;
   }
@@ -622,6 +651,65 @@ int launch_segs(const SpmmPlan* p, const int32_t* indices, const float* vals, co
     NR_LAUNCH_CHECK();
   }
   return launch_fix<D>(p, Y, addend, sum_in, sum_out, partial, nullptr, st);
+}
+
+
+// ----------------------------------------------------------------------------
+// Chunked hop, last act: the virtual rows (a real row's 256-non-zero segments, each summed as its own row over
+// all chunk launches) combined in segment order — the association of spmm_fix_kernel — and the fused epilogue.
+// ----------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kLegacyWaves* NR_WAVE) void spmm_chunks_finish_kernel(
+    const int32_t* __restrict__ first_vrow, int64_t n_rows, const float* __restrict__ Yv, float* __restrict__ Y,
+    const float* __restrict__ addend, const float* sum_in, float* sum_out, const uint8_t* __restrict__ row_mask) {
+  constexpr int CPL = D / NR_WAVE;
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int64_t row = (int64_t)blockIdx.x * kLegacyWaves + wave;
+  if (row >= n_rows) return;
+  if (row_mask && row_mask[row] == 0) return;
+  const int v0 = first_vrow[row], v1 = first_vrow[row + 1];
+  float acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = Yv[(int64_t)v0 * D + lane + c * NR_WAVE];
+  for (int v = v0 + 1; v < v1; ++v) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = __fadd_rn(acc[c], Yv[(int64_t)v * D + lane + c * NR_WAVE]);
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int64_t o = row * D + lane + c * NR_WAVE;
+    float y = acc[c];
+    if (addend) y = __fadd_rn(y, addend[o]);
+    if (Y) Y[o] = y;
+    if (sum_out) sum_out[o] = __fadd_rn(sum_in[o], y);
+  }
+}
+
+template <int D, int WPB>
+int launch_items_carry(const SpmmPlan* p, const int64_t* indptr, const int32_t* indices, const float* vals,
+                       const float* X, const float* X2, int x_split, float* Yv, bool has_carry,
+                       const uint8_t* row_mask, hipStream_t st) {
+  const int64_t ba = (p->n_a_items + WPB - 1) / WPB, bb = (p->n_b_items + WPB - 1) / WPB;
+  const int64_t blocks = p->n_b_items == 0 ? ba : 8 * ((std::max(ba, bb) + 3) / 4);
+  if (p->n_items == 0) return NR_OK;
+  dim3 grid((unsigned)blocks), block(WPB * NR_WAVE);
+#define NR_CARRY_LAUNCH(TR, M, CY)                                                                            \
+  hipLaunchKernelGGL((spmm_item_kernel<D, WPB, TR, kGather, M, CY>), grid, block, 0, st, p->item_row0,        \
+                     p->item_nrows, p->item_begin, p->item_len, p->item_slot, (float*)nullptr, 0,             \
+                     (int)p->n_a_items, (int)p->n_b_items, indptr, indices, vals, X, Yv, (const float*)nullptr, \
+                     (const float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr, row_mask,               \
+                     (const float*)Yv, X2, x_split)
+  const bool small = p->item_rows <= 16;
+  if (row_mask) {
+    if (has_carry) { if (small) NR_CARRY_LAUNCH(16, true, 2); else NR_CARRY_LAUNCH(32, true, 2); }
+    else { if (small) NR_CARRY_LAUNCH(16, true, 1); else NR_CARRY_LAUNCH(32, true, 1); }
+  } else {
+    if (has_carry) { if (small) NR_CARRY_LAUNCH(16, false, 2); else NR_CARRY_LAUNCH(32, false, 2); }
+    else { if (small) NR_CARRY_LAUNCH(16, false, 1); else NR_CARRY_LAUNCH(32, false, 1); }
+  }
+#undef NR_CARRY_LAUNCH
+  NR_LAUNCH_CHECK();
+  return NR_OK;
 }
 
 }  // namespace
@@ -919,6 +1007,52 @@ int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const
     case 256: hipLaunchKernelGGL(spmm_rows_kernel<256>, grid, block, 0, st, d_rows, d_indptr, d_indices, d_vals, d_X, d_Y, d_addend, d_sum_in, d_sum_out); break;
     default:
       NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "spmm_csr_rows: embedding dim %d not built (64, 128, 256)", d);
+  }
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* One chunk of a chunked hop (neurec_amd/sharded.py: the row-sharded propagation with the all-gather received in
+ * rank-ordered chunks): Yv[v] = (has_carry ? Yv[v] : 0) + Σ_j a_j·X[col_j] over the non-zeros this chunk's CSR holds
+ * for virtual row v, ONE ascending chain across the launches of a hop.  Column c < x_split is row c of d_X (the
+ * rank's own block), any other column row c - x_split of d_X2 (the received chunk).  The CSR must not contain a row
+ * of more than 256 non-zeros (virtual rows: a real row's 256-non-zero segments).  d_row_mask (optional, per virtual row): 0 =
+ * row not wanted, left untouched. */
+int nrhip_spmm_csr_carry(const void* plan, const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
+                         const float* d_X, const float* d_X2, int x_split, int d, float* d_Yv, int has_carry,
+                         const uint8_t* d_row_mask, void* stream) {
+  NR_REQUIRE(plan && d_indptr && d_indices && d_vals && d_X && d_X2 && d_Yv && x_split >= 0, NR_ERR_ARG,
+             "spmm_csr_carry: null pointer argument");
+  const SpmmPlan* p = (const SpmmPlan*)plan;
+  NR_REQUIRE(p->n_multi_seg == 0 && p->n_hub_items == 0, NR_ERR_UNSUPPORTED,
+             "spmm_csr_carry: a row of more than 256 non-zeros (chunk CSRs hold virtual rows)");
+  hipStream_t st = (hipStream_t)stream;
+  switch (d) {
+    case 64: return launch_items_carry<64, 4>(p, d_indptr, d_indices, d_vals, d_X, d_X2, x_split, d_Yv, has_carry != 0, d_row_mask, st);
+    case 128: return launch_items_carry<128, 2>(p, d_indptr, d_indices, d_vals, d_X, d_X2, x_split, d_Yv, has_carry != 0, d_row_mask, st);
+    case 256: return launch_items_carry<256, 1>(p, d_indptr, d_indices, d_vals, d_X, d_X2, x_split, d_Yv, has_carry != 0, d_row_mask, st);
+    default:
+      NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "spmm_csr_carry: embedding dim %d not built (64, 128, 256)", d);
+  }
+  return NR_OK;
+}
+
+/* After the last chunk: y[r] = Yv[first_vrow[r]] + Yv[first_vrow[r]+1] + ... (segment order), then the fused
+ * epilogue of nrhip_spmm_csr (y += addend; sum_out = sum_in + y); d_row_mask per REAL row (0: row left untouched). */
+int nrhip_spmm_chunks_finish(const int32_t* d_first_vrow, int64_t n_rows, const float* d_Yv, int d, float* d_Y,
+                             const float* d_addend, const float* d_sum_in, float* d_sum_out,
+                             const uint8_t* d_row_mask, void* stream) {
+  NR_REQUIRE(d_first_vrow && d_Yv && (d_Y || d_sum_out) && n_rows >= 0, NR_ERR_ARG, "spmm_chunks_finish: bad arguments");
+  NR_REQUIRE((d_sum_out == nullptr) || (d_sum_in != nullptr), NR_ERR_ARG, "spmm_chunks_finish: sum_out needs sum_in");
+  if (n_rows == 0) return NR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((n_rows + kLegacyWaves - 1) / kLegacyWaves)), block(kLegacyWaves * NR_WAVE);
+  switch (d) {
+    case 64: hipLaunchKernelGGL(spmm_chunks_finish_kernel<64>, grid, block, 0, st, d_first_vrow, n_rows, d_Yv, d_Y, d_addend, d_sum_in, d_sum_out, d_row_mask); break;
+    case 128: hipLaunchKernelGGL(spmm_chunks_finish_kernel<128>, grid, block, 0, st, d_first_vrow, n_rows, d_Yv, d_Y, d_addend, d_sum_in, d_sum_out, d_row_mask); break;
+    case 256: hipLaunchKernelGGL(spmm_chunks_finish_kernel<256>, grid, block, 0, st, d_first_vrow, n_rows, d_Yv, d_Y, d_addend, d_sum_in, d_sum_out, d_row_mask); break;
+    default:
+      NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "spmm_chunks_finish: embedding dim %d not built (64, 128, 256)", d);
   }
   NR_LAUNCH_CHECK();
   return NR_OK;

@@ -581,6 +581,12 @@ def pointwise_mf_grad(P, Q, users, items, labels, reg, loss, GP, GQ, terms, loss
          _work(terms, users.numel()), _ptr(loss2), _ptr(plan, torch.int64, allow_none=True), _stream())
 
 
+def gather_u8(src, index, dst):
+    """dst[i] = src[index[i]] (uint8)"""
+    call("nrhip_gather_u8", _ptr(src, torch.uint8), _ptr(index, torch.int32), index.numel(), _ptr(dst, torch.uint8),
+         _stream())
+
+
 def mark_rows(ids, flag, offset=0):
     call("nrhip_mark_rows", _ptr(ids, torch.int32), ids.numel(), int(offset), _ptr(flag, torch.uint8),
          _stream())

@@ -94,6 +94,26 @@ class Comm:
         out.copy_(host.reshape(out.shape))
         return out
 
+    def bcast_rows_start(self, buf, src):
+        """Begin broadcasting rank `src`'s `buf` into every other rank's `buf` (one chunk of a chunked all-gather:
+        neurec_amd/sharded.py).  RCCL: asynchronous on the collective stream, ordered behind the work already
+        enqueued on the current stream (so a receive slot is not overwritten under the kernel that still reads it);
+        returns a token for bcast_rows_finish.  gloo: host-staged, done when this returns."""
+        if not self.active:
+            return None
+        if self.backend == "nccl":
+            return dist.broadcast(buf, src=src, async_op=True)
+        host = buf.detach().cpu().contiguous() if self.rank == src else torch.empty(tuple(buf.shape), dtype=buf.dtype)
+        dist.broadcast(host, src=src)
+        if self.rank != src:
+            buf.copy_(host)
+        return None
+
+    def bcast_rows_finish(self, token):
+        """the current stream waits for the chunk (no host synchronisation)"""
+        if token is not None:
+            token.wait()
+
     def all_to_all_rows(self, send, send_counts, recv_counts=None):
         """Variable all-to-all of rows: `send` [n][...] is ordered by destination rank,
         `send_counts[r]` rows go to rank r.  Returns (recv [m][...], recv_counts) ordered by

@@ -29,10 +29,15 @@ copy — and, with them, the routing itself of every batch (requests in owner or
 what each owner is asked for, the owner-side sorted keys: csrc/route.hip, one all-to-all of the
 epoch's ids) — so a planned step runs without host synchronisation and without a single routing
 launch; a step on a batch that was not planned routes and counts on the spot (one sync).
-Why the per-hop all-gather is not overlapped with the SpMM over the already-local columns: a
-row's sum would become (local columns) + (remote columns) instead of ascending-column order —
-a different fp32 association from the single-GPU kernel and from TF's, so rankings could no
-longer be called identical.  The exact form is kept; the hop's communication is exposed.
+The per-hop all-gather is PIPELINED with the local SpMM without changing a single rounding (`ChunkedHop`,
+r04).  Splitting a row into (local columns) + (remote columns) would re-associate its sum; but with this
+partition a user row's columns are items and an item row's are users, so ascending column id IS ascending
+owner rank: the operand is received in rank order, one chunk per rank (a broadcast each, two receive slots),
+and launch r adds the non-zeros owned by rank r to the row accumulators carried from launch r-1 — the same
+ascending chain, cut where the owners change — while chunk r+1 is on the links.  (`norm`'s self loop is the
+first term of a user row and the last of an item row, and always local.)  It also drops the [world·b][d]
+gathered operand: a hop holds two [b][d] receive slots.  NEUREC_ROWSHARD_PIPELINE=0 keeps the one-all-gather
+form (bit-identical; tests/test_sharded_gpu.py runs both).
 All arithmetic is the same HIP kernels as the replicated engine; the collectives are
 torch.distributed plumbing (`parallel.Comm`).
 """
@@ -272,15 +277,102 @@ class Route:
             setattr(self, k, v)
 
 
+class ChunkedHop:
+    """A rank's row block of Â re-cut for the chunked hop: CSR r holds, for every VIRTUAL row, the non-zeros whose
+    column is owned by rank r (in storage order), columns addressed as (own block row | b + row of the received
+    chunk).  Virtual rows: a real row of more than `seg_len` non-zeros is cut by position into seg_len-segments, each
+    summed as a row of its own and added in segment order at the end — the association of the one-launch kernels
+    (seg_len = SpmmCSR.exact_row_nnz(d): 256 for the work-item kernel, 64 where the lane-group schedule runs)."""
+
+    def __init__(self, part, rank, indptr, cols_global, vals, seg_len, device):
+        t = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device, dt)
+        ip, cg, va = t(indptr, torch.int64), t(cols_global, torch.int64), t(vals, torch.float32)
+        self.world, self.rank, self.b = part.world, int(rank), part.b
+        b, W, nnz = part.b, part.world, int(cg.numel())
+        assert ip.numel() == b + 1
+        lens = ip[1:] - ip[:-1]
+        n_v = torch.clamp((lens + seg_len - 1) // seg_len, min=1)                # virtual rows of every real row
+        first = torch.zeros(b + 1, dtype=torch.int64, device=device)
+        first[1:] = torch.cumsum(n_v, 0)
+        self.n_virtual = int(first[-1])
+        self.first_vrow = first.to(torch.int32).contiguous()
+        row_of = torch.repeat_interleave(torch.arange(b, device=device), lens, output_size=nnz)
+        pos = torch.arange(nnz, device=device) - ip[row_of]
+        vrow = first[row_of] + pos // seg_len
+        owner, local = part.owner_local(cg)
+        # launch of every non-zero = the owner of its column; a column on the ROW'S OWN side of the graph (`norm`'s self
+        # loop) is local and sits first in a user row, last in an item row
+        user_row = row_of < part.bu
+        same_side = (cg < part.U) == user_row
+        if bool((same_side & (owner != self.rank)).any()):
+            raise NotImplementedError("chunked hop: a same-side edge to another rank (not a bipartite graph + self loops)")
+        launch = torch.where(same_side, torch.where(user_row, 0, W - 1), owner)
+        inside = row_of[1:] == row_of[:-1]
+        if bool((inside & (launch[1:] < launch[:-1])).any()):
+            raise NotImplementedError("chunked hop: a row's owners are not ascending in storage order")
+        col = torch.where(owner == self.rank, local, b + local).to(torch.int32)
+        self.chunks = []
+        for r in range(W):
+            sel = launch == r
+            cnt = torch.bincount(vrow[sel], minlength=self.n_virtual)
+            ipr = torch.zeros(self.n_virtual + 1, dtype=torch.int64, device=device)
+            ipr[1:] = torch.cumsum(cnt, 0)
+            self.chunks.append(E.SpmmCSR(ipr, col[sel], va[sel], n_cols=2 * b))
+            assert self.chunks[-1].n_split_rows == 0
+        self.real_of_vrow = torch.repeat_interleave(torch.arange(b, device=device), n_v,
+                                                    output_size=self.n_virtual).to(torch.int32)
+        self._Yv = {}
+        self._slots = {}
+        self._vmask = torch.zeros(self.n_virtual, dtype=torch.uint8, device=device)
+
+    def buffers(self, d, device):
+        if d not in self._Yv:
+            self._Yv[d] = torch.empty((self.n_virtual, d), dtype=torch.float32, device=device)
+            self._slots[d] = [torch.empty((self.b, d), dtype=torch.float32, device=device) for _ in range(2)]
+        return self._Yv[d], self._slots[d]
+
+    def matmul(self, comm, local, out=None, addend=None, sum_in=None, sum_out=None, y_row_wanted=None):
+        """out = Â_block · (all ranks' `local` blocks) (+ addend); sum_out = sum_in + out — nrhip_spmm_csr's contract,
+        with the other ranks' blocks arriving chunk by chunk under the launches."""
+        d, W = local.shape[1], self.world
+        Yv, slots = self.buffers(d, local.device)
+        vmask = None
+        if y_row_wanted is not None:
+            E.gather_u8(y_row_wanted, self.real_of_vrow, self._vmask)
+            vmask = self._vmask
+        bufs = [local if r == self.rank else slots[r & 1] for r in range(W)]
+        tokens = [None] * W
+        for r in range(min(2, W)):
+            tokens[r] = comm.bcast_rows_start(bufs[r], r)
+        for r in range(W):
+            comm.bcast_rows_finish(tokens[r])
+            ch = self.chunks[r]
+            E.call("nrhip_spmm_csr_carry", ch.plan, E._ptr(ch.indptr), E._ptr(ch.indices), E._ptr(ch.vals),
+                   E._ptr(local, torch.float32), E._ptr(bufs[r], torch.float32), self.b, d, E._ptr(Yv),
+                   1 if r > 0 else 0, E._ptr(vmask, allow_none=True), E._stream())
+            if r + 2 < W:                                  # its slot is free once launch r has been enqueued
+                tokens[r + 2] = comm.bcast_rows_start(bufs[r + 2], r + 2)
+        E.call("nrhip_spmm_chunks_finish", E._ptr(self.first_vrow), self.b, E._ptr(Yv), d,
+               E._ptr(out, torch.float32, allow_none=True), E._ptr(addend, allow_none=True),
+               E._ptr(sum_in, allow_none=True), E._ptr(sum_out, allow_none=True),
+               E._ptr(y_row_wanted, allow_none=True), E._stream())
+        return out
+
+
 class ShardedLightGCN:
     def __init__(self, comm, adj_csr, n_users, n_items, embed, n_layers, lr, reg, max_batch,
-                 symmetric=None, local_rows=None, local_rows_t=None):
+                 symmetric=None, local_rows=None, local_rows_t=None, pipeline=None):
         """adj_csr: the full [N][N] scipy adjacency (each rank slices its block), or None with
         local_rows = (indptr, indices, vals) of this rank's row block only (global column ids;
         local_rows_t for Âᵀ when Â is not symmetric).  embed: the full [N][d] table or just this
-        rank's [n_loc][d] rows."""
+        rank's [n_loc][d] rows.  pipeline: the chunked hop (None: on when there is more than one rank,
+        unless NEUREC_ROWSHARD_PIPELINE=0)."""
         dev = E.require_gpu()
         self.comm, self.rank, self.world = comm, comm.rank, comm.world
+        if pipeline is None:
+            pipeline = self.world > 1 and os.environ.get("NEUREC_ROWSHARD_PIPELINE", "1") != "0"
+        self.pipeline = bool(pipeline)
+        self._d_hint = int(embed.shape[1])
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.N = self.n_users + self.n_items
         self.L, self.reg, self.max_batch = int(n_layers), float(reg), int(max_batch)
@@ -319,7 +411,8 @@ class ShardedLightGCN:
         self.E0[:self.nu] = src_u
         self.E0[self.part.bu:self.part.bu + self.ni] = src_i
         self.m, self.v = z(self.b, self.d), z(self.b, self.d)
-        self.X = z(self.Npad, self.d)                       # gathered operand of the local SpMM
+        # gathered operand of the one-all-gather hop; the chunked hop holds two [b][d] receive slots instead
+        self._X = None
         self.Ya, self.Yb, self.Esum = (z(self.b, self.d) for _ in range(3))
         self.H, self.Greg, self.Ga, self.Gb = (z(self.b, self.d) for _ in range(4))
         B3 = 3 * self.max_batch
@@ -335,7 +428,8 @@ class ShardedLightGCN:
         # rows this rank was asked for in the current step (= rows of E* the loss reads = rows that receive gradient):
         # the last forward hop produces only those, the first backward hop skips operand rows outside them
         self.flag = torch.zeros(self.b, dtype=torch.uint8, device=dev)
-        self.flagX = self.flag if not comm.active else torch.zeros(self.Npad, dtype=torch.uint8, device=dev)
+        self.flagX = self.flag if (not comm.active or self.pipeline) else \
+            torch.zeros(self.Npad, dtype=torch.uint8, device=dev)
         self.es_buf, self.e0_buf = z(B3, self.d), z(B3, self.d)
         self._pow2 = ((self.L + 1) & self.L) == 0
         self._Gs = None
@@ -352,7 +446,7 @@ class ShardedLightGCN:
             ip[bu + 1:bu + self.ni + 1] = indptr[self.nu + 1:self.nu + self.ni + 1]
             ip[bu + self.ni + 1:] = indptr[self.nu + self.ni]
             cols = self.part.position(indices.long()).to(torch.int32)
-            return E.SpmmCSR(ip, cols, vals, n_cols=self.Npad)
+            return self._with_chunks(E.SpmmCSR(ip, cols, vals, n_cols=self.Npad), ip, indices, vals)
         indptr = np.asarray(indptr, dtype=np.int64)
         ip = np.zeros(self.b + 1, dtype=np.int64)
         ip[1:self.nu + 1] = indptr[1:self.nu + 1]
@@ -360,12 +454,26 @@ class ShardedLightGCN:
         ip[bu + 1:bu + self.ni + 1] = indptr[self.nu + 1:self.nu + self.ni + 1]
         ip[bu + self.ni + 1:] = indptr[self.nu + self.ni]
         cols = self.part.position(np.asarray(indices, dtype=np.int64)).astype(np.int32)
-        return E.SpmmCSR(ip, cols, np.asarray(vals, np.float32), n_cols=self.Npad)
+        return self._with_chunks(E.SpmmCSR(ip, cols, np.asarray(vals, np.float32), n_cols=self.Npad), ip, indices, vals)
+
+    def _with_chunks(self, A, ip, cols_global, vals):
+        """attach the chunked (pipelined) form of the block (ChunkedHop) where the hop is pipelined"""
+        A.chunked = None
+        if self.pipeline and self._d_hint in (64, 128, 256):
+            A.chunked = ChunkedHop(self.part, self.rank, ip, cols_global, vals, A.exact_row_nnz(self._d_hint),
+                                   A.indices.device)
+        return A
 
     def _local_rows(self, a):
         import scipy.sparse as sp
         blk = sp.vstack([a[self.ulo:self.uhi], a[self.n_users + self.ilo:self.n_users + self.ihi]]).tocsr()
         return self._from_block(blk.indptr, blk.indices, blk.data)
+
+    @property
+    def X(self):
+        if self._X is None:
+            self._X = torch.zeros((self.Npad, self.d), dtype=torch.float32, device=self.E0.device)
+        return self._X
 
     def natural(self, gathered):
         """[n_pad][d] gathered (rank-major) table -> (user rows [U][d], item rows [I][d]) in id order"""
@@ -397,8 +505,12 @@ class ShardedLightGCN:
         for k in range(self.L):
             last = k == self.L - 1
             out = None if last else ping[k & 1]                         # the last layer is only needed in the sum
-            self.A.matmul(self._operand(src), out=out, sum_in=acc_in, sum_out=self.Esum,
-                          y_row_wanted=wanted if last else None)
+            if self.A.chunked is not None:
+                self.A.chunked.matmul(self.comm, src, out=out, sum_in=acc_in, sum_out=self.Esum,
+                                      y_row_wanted=wanted if last else None)
+            else:
+                self.A.matmul(self._operand(src), out=out, sum_in=acc_in, sum_out=self.Esum,
+                              y_row_wanted=wanted if last else None)
             src, acc_in = out, self.Esum
         return self.Esum
 
@@ -453,12 +565,18 @@ class ShardedLightGCN:
             E.rows_clear(rt.asked, d, (self._Gs,))
         # --- backward hops: G_k = H + Aᵀ G_{k+1}; H is non-zero on the asked rows only (first hop skips the rest),
         #     the last hop carries ApplyAdam as its epilogue where the lane-group schedule exists
-        if self.comm.active:
+        chunked = self.At.chunked is not None
+        if self.comm.active and not chunked:
             self.comm.all_gather_rows(self.flag, self.flagX)
         g = self.H
         ping = (self.Ga, self.Gb)
         applied = False
         for k in range(self.L):
+            if chunked:                                 # the operand arrives chunk by chunk under the launches
+                out = ping[(k + 1) & 1]
+                self.At.chunked.matmul(self.comm, g, out=out, addend=self.H)
+                g = out
+                continue
             X = self._operand(g)
             if k == self.L - 1 and self.L >= 2:
                 applied = self.At.matmul_adam(X, self.H, self.Greg, self.E0, self.m, self.v, self.adam,

@@ -37,10 +37,11 @@ def _batches(U, I, world, B, steps):
               rng.randint(0, I, B).astype(np.int32)) for _ in range(world)] for _ in range(steps)]
 
 
-def _worker(rank, world, port, out, adj_type, d, backend="gloo", L=2):
+def _worker(rank, world, port, out, adj_type, d, backend="gloo", L=2, pipeline="1"):
     import torch
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_DIST_BACKEND=backend)
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_DIST_BACKEND=backend,
+                      NEUREC_ROWSHARD_PIPELINE=pipeline)
     from neurec_amd import parallel
     from neurec_amd.sharded import ShardedLightGCN
     comm = parallel.init_from_env()
@@ -56,6 +57,7 @@ def _worker(rank, world, port, out, adj_type, d, backend="gloo", L=2):
                               local_rows=(blk.indptr, blk.indices, blk.data))
     else:
         eng = ShardedLightGCN(comm, A, U, I, E0, L, 0.01, 1e-3, 128)
+    assert eng.pipeline == (pipeline == "1") and (eng.A.chunked is not None) == eng.pipeline
     losses = []
     steps = _batches(U, I, world, 128, 3)
     if d == 64:
@@ -80,16 +82,20 @@ def _worker(rank, world, port, out, adj_type, d, backend="gloo", L=2):
     comm.shutdown()
 
 
-@pytest.mark.parametrize("adj_type,d,L", [("pre", 64, 2), ("norm", 64, 2), ("pre", 128, 2),
-                                          # L + 1 a power of two: the head divides its rows itself (no scratch table),
-                                          # the configured depth of BASELINE configs[2] / configs[3]
-                                          ("pre", 64, 3), ("norm", 128, 3), ("pre", 64, 1)])
-def test_sharded_lightgcn_equals_single_process(tmp_path, adj_type, d, L):
+@pytest.mark.parametrize("adj_type,d,L,pipeline",
+                         [("pre", 64, 2, "1"), ("norm", 64, 2, "1"), ("pre", 128, 2, "1"),
+                          # L + 1 a power of two: the head divides its rows itself (no scratch table),
+                          # the configured depth of BASELINE configs[2] / configs[3]
+                          ("pre", 64, 3, "1"), ("norm", 128, 3, "1"), ("pre", 64, 1, "1"),
+                          # the one-all-gather hop (no chunking) stays a selectable, equally exact form
+                          ("norm", 64, 3, "0"), ("pre", 128, 2, "0")])
+def test_sharded_lightgcn_equals_single_process(tmp_path, adj_type, d, L, pipeline):
+    """pipeline "1": every hop's operand arrives in rank-ordered chunks under the launches (ChunkedHop)"""
     import torch
     import torch.multiprocessing as mp
     from neurec_amd.trainer import LightGCNEngine
     out = str(tmp_path / "r0.npz")
-    mp.start_processes(_worker, args=(2, _free_port(), out, adj_type, d, "gloo", L), nprocs=2, join=True,
+    mp.start_processes(_worker, args=(2, _free_port(), out, adj_type, d, "gloo", L, pipeline), nprocs=2, join=True,
                        start_method="spawn")
     got = np.load(out)
     tr, A, E0, U, I = _setup(adj_type, d)
@@ -214,3 +220,82 @@ np.savez(sys.argv[1], E=torch.cat(lg.natural(lg.E0)).cpu().numpy(), P=P.cpu().nu
         res[knob] = np.load(out)
     for k in ("E", "P", "Q"):
         assert np.abs(res["0"][k] - res["1"][k]).max() < 2e-4, k       # same steps up to the atomics' summation order
+
+
+class _Blocks:
+    """stands in for parallel.Comm in a one-process check of ChunkedHop: rank `src`'s block is copied on request"""
+    active, backend = True, "fake"
+
+    def __init__(self, rank, world, blocks):
+        self.rank, self.world, self.blocks = rank, world, blocks
+
+    def bcast_rows_start(self, buf, src):
+        if src != self.rank:
+            buf.copy_(self.blocks[src])
+
+    def bcast_rows_finish(self, token):
+        pass
+
+
+@pytest.mark.parametrize("adj_type,d,world", [("pre", 64, 3), ("norm", 64, 2), ("norm", 128, 3), ("pre", 128, 4),
+                                              ("gcmc", 128, 3)])
+def test_chunked_hop_is_the_one_launch_hop_bit_for_bit(adj_type, d, world):
+    """The pipelined form of the row-sharded hop (operand received rank by rank, row accumulators carried from
+    launch to launch, hub rows as virtual segment rows) against the one-all-gather hop on the same block: equal
+    bits with every epilogue option and with a wanted-rows mask — user rows, item rows, `norm`'s self loops (first
+    term of a user row, last of an item row), hub rows beyond 64 / 256 non-zeros, uneven last blocks."""
+    import scipy.sparse as sp
+    import torch
+    from neurec_amd import engine as E, parallel
+    from neurec_amd.sharded import ChunkedHop
+    tr, A, E0, U, I = _setup(adj_type, d)
+    A = A.tocsr().astype(np.float32)
+    A.sort_indices()
+    assert np.diff(A.indptr).max() > 256
+    part = parallel.BipartitePartition(U, I, world)
+    rng = np.random.RandomState(5)
+    X = (rng.randn(U + I, d) * 0.3).astype(np.float32)
+    b = part.b
+
+    def block_of(table, r):
+        (ulo, uhi), (ilo, ihi) = part.users_of(r), part.items_of(r)
+        out = np.zeros((b,) + table.shape[1:], table.dtype)
+        out[:uhi - ulo] = table[ulo:uhi]
+        out[part.bu:part.bu + ihi - ilo] = table[U + ilo:U + ihi]
+        return out
+    blocks = [torch.from_numpy(block_of(X, r)).cuda() for r in range(world)]
+    gathered = torch.cat(blocks)
+    for rank in range(world):
+        (ulo, uhi), (ilo, ihi) = part.users_of(rank), part.items_of(rank)
+        blk = sp.vstack([A[ulo:uhi], A[U + ilo:U + ihi]]).tocsr()
+        nu, ni = uhi - ulo, ihi - ilo
+        ip = np.zeros(b + 1, np.int64)
+        ip[1:nu + 1] = blk.indptr[1:nu + 1]
+        ip[nu + 1:part.bu + 1] = blk.indptr[nu]
+        ip[part.bu + 1:part.bu + ni + 1] = blk.indptr[nu + 1:nu + ni + 1]
+        ip[part.bu + ni + 1:] = blk.indptr[nu + ni]
+        one = E.SpmmCSR(ip, part.position(blk.indices.astype(np.int64)).astype(np.int32), blk.data, n_cols=part.n_pad)
+        seg = one.exact_row_nnz(d)
+        hop = ChunkedHop(part, rank, ip, blk.indices.astype(np.int64), blk.data, seg, "cuda")
+        assert hop.n_virtual > b                                        # hub rows were cut
+        comm = _Blocks(rank, world, blocks)
+        z = lambda: torch.zeros(b, d, device="cuda")
+        addend = torch.from_numpy((rng.randn(b, d) * 0.1).astype(np.float32)).cuda()
+        sum_in = torch.from_numpy((rng.randn(b, d) * 0.1).astype(np.float32)).cuda()
+        wanted = torch.from_numpy((rng.rand(b) < 0.3).astype(np.uint8)).cuda()
+        for kw in ({}, {"addend": addend}, {"sum_in": sum_in, "sum_out": "new"}, {"sum_in": sum_in, "sum_out": "only"},
+                   {"sum_in": sum_in, "sum_out": "only", "y_row_wanted": wanted}):
+            outs = []
+            for which in ("one", "chunked"):
+                k = dict(kw)
+                out = None if k.get("sum_out") == "only" else z()
+                if "sum_out" in k:
+                    k["sum_out"] = torch.full((b, d), 7.0, device="cuda")     # unwanted rows must stay untouched
+                if which == "one":
+                    one.matmul(gathered, out=out, **k)
+                else:
+                    hop.matmul(comm, blocks[rank], out=out, **k)
+                outs.append((out, k.get("sum_out")))
+            for x, y in zip(outs[0], outs[1]):
+                if x is not None:
+                    assert torch.equal(x, y), (adj_type, d, rank, sorted(kw))
