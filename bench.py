@@ -393,6 +393,124 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
     return out
 
 
+def leg_config4_partitions(dev, scale, which="both", W=8, dim=128, L=3, B=8192):
+    """BASELINE configs[3] on ONE GPU: what ONE rank of a W-rank job computes per step under the two partitions, at the
+    config-4 law —
+      rowshard_rank0_of_W  1/W of the users and of the items, all `dim` columns; per hop the other blocks arrive in
+                           rank-ordered chunks under the launches (sharded.ChunkedHop) — here the chunk buffers are
+                           resident and nothing is exchanged: the compute side of the hop, chunked and one-launch;
+      colshard_rank0_of_W  all nodes, dim/W columns, the global batch of W·B (colshard.py): no per-hop exchange."""
+    import torch
+    from neurec_amd import engine as E, parallel as par, synth
+    U, I, n_edges = (max(int(x * scale), 64) for x in synth.CONFIG4)
+    tr_ptr, tr_idx = synth.device_interactions(U, I, n_edges, seed=2018, device=dev)
+    out = {"scale": scale, "users": U, "items": I, "interactions": int(tr_ptr[-1]), "dim": dim, "ranks_modelled": W}
+
+    class Share(par.Comm):
+        """rank 0 of W with every exchange a no-op: the compute share of one rank on one GPU"""
+        def __init__(self):
+            super().__init__(0, W, 0, "none")
+
+        def barrier(self):
+            pass
+
+        def bcast_rows_start(self, buf, src):
+            return None
+
+        def bcast_rows_finish(self, token):
+            pass
+
+        def all_gather_rows(self, local, out_):
+            return out_
+
+    if which in ("rows", "both"):
+        from neurec_amd.sharded import ShardedLightGCN
+        part = par.BipartitePartition(U, I, W)
+        ur, ir = part.users_of(0), part.items_of(0)
+        rows = synth.device_lightgcn_rank_rows(tr_ptr, tr_idx, U, I, ur, ir)
+        lim = float(np.sqrt(6.0 / (U + I + dim)))
+        E0 = (torch.rand((ur[1] - ur[0]) + (ir[1] - ir[0]), dim, device=dev) * 2 - 1) * lim
+        t0 = time.perf_counter()
+        lg = ShardedLightGCN(Share(), None, U, I, E0, L, 0.01, 1e-3, B, local_rows=rows, pipeline=True)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        del rows, E0
+        ch, comm, b = lg.A.chunked, lg.comm, part.b
+        ms_ch = _hip_timed(lambda: ch.matmul(comm, lg.E0, out=lg.Ya, addend=lg.H), 3, 1)
+        X = lg.X                                           # [W·b][d] gathered operand of the one-launch form
+        X.uniform_(-lim, lim)
+        ms_one = _hip_timed(lambda: lg.A.matmul(X, out=lg.Ya, addend=lg.H), 3, 1)
+        Yv, slots = ch.buffers(dim, dev)
+        per = []
+        for r in range(W):                                  # the chunk launches one by one
+            c = ch.chunks[r]
+            per.append(_hip_timed(lambda: E.call("nrhip_spmm_csr_carry", c.plan, E._ptr(c.indptr), E._ptr(c.indices),
+                                                 E._ptr(c.vals), E._ptr(lg.E0), E._ptr(slots[r & 1]), b, dim, E._ptr(Yv),
+                                                 1 if r else 0, E._ptr(None, allow_none=True), E._stream()), 3, 1))
+        nnz = int(lg.A.nnz)
+        out["rowshard_rank0_of_%d" % W] = {
+            "rows_per_rank": b, "nnz_per_rank": nnz, "virtual_rows": ch.n_virtual, "build_seconds": build_s,
+            "hop_ms_chunked_%d_launches_plus_finish" % W: ms_ch, "hop_ms_one_launch": ms_one, "chunk_launch_ms": per,
+            "row_gather_bytes_per_hop": nnz * dim * 4, "row_gather_GBps_chunked": nnz * dim * 4 / ms_ch / 1e6,
+            "row_gather_GBps_one_launch": nnz * dim * 4 / ms_one / 1e6,
+            "received_bytes_per_hop": (W - 1) * b * dim * 4, "hops_per_step": 2 * L,
+            "operand_buffers_bytes": {"chunked_two_slots": 2 * b * dim * 4, "one_launch_gathered": W * b * dim * 4}}
+        del lg, ch, X, Yv, slots
+        torch.cuda.empty_cache()
+    if which in ("cols", "both"):
+        from neurec_amd.trainer import LightGCNEngine
+        N = U + I
+        t0 = time.perf_counter()
+        ip, idx, val = synth.device_lightgcn_rank_rows(tr_ptr, tr_idx, U, I, (0, U), (0, I))   # every row, natural ids
+        A = E.SpmmCSR(ip, idx, val, n_cols=N, split_row=U)
+        del ip, idx, val
+        gB, dl = W * B, dim // W
+        lim = float(np.sqrt(6.0 / (N + dim)))
+        emb = (torch.rand(N, dl, device=dev) * 2 - 1) * lim           # rank 0's columns
+        lgc = LightGCNEngine(A, U, I, emb, L, 0.01, 1e-3, gB)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        trc = E.DeviceCSR(tr_ptr, tr_idx, I)
+        n_b = 3
+        users, pos, neg = E.sample_bpr_epoch(trc, trc.row_of(), I, 1, 2018, 0, True, begin=0, count=n_b * gB)
+        parts = torch.zeros(3 * gB, device=dev)
+        ctx, k = lgc._ctx, [0]
+
+        def step():
+            j = k[0] % n_b
+            k[0] += 1
+            bu, bp, bn = (t[j * gB:(j + 1) * gB] for t in (users, pos, neg))
+            ctx.lightgcn_step_colshard_fwd(bu, bp, bn, parts)
+            ctx.lightgcn_step_colshard_bwd(bu, bp, bn, lgc.adam, None, None, parts)
+            lgc.adam.advance()
+        ms = _hip_timed(step, 3, 1)
+        ms_hop = _hip_timed(lambda: lgc.A.matmul(lgc.E0, out=lgc.Ea, addend=lgc.H), 3, 1)
+        out["colshard_rank0_of_%d" % W] = {
+            "columns_per_rank": dl, "kernel_width": lgc.d, "global_batch": gB, "build_seconds": build_s, "ms_per_step": ms,
+            "hop_ms": ms_hop, "kernel": lgc.A.full_pass_kernel(lgc.d), "nnz": int(A.nnz),
+            "row_gather_bytes_per_hop": int(A.nnz) * dl * 4, "row_gather_GBps": int(A.nnz) * dl * 4 / ms_hop / 1e6,
+            "exchange_bytes_per_rank_per_step": 12 * gB, "triplets_per_sec_if_exchange_were_free": gB / ms * 1e3}
+        del lgc, A, trc
+        torch.cuda.empty_cache()
+    # what the measured compute sides mean at W ranks over xGMI (7 links x 76.8 GB/s per direction into a GPU)
+    link_in = 7 * 76.8e9
+    rs, cs = out.get("rowshard_rank0_of_%d" % W), out.get("colshard_rank0_of_%d" % W)
+    model = {"link_in_bytes_per_s": link_in, "assumed": "every collective keeps all 7 incoming links busy (multi-ring)"}
+    if rs:
+        comm_ms = rs["received_bytes_per_hop"] / link_in * 1e3
+        model["rowshard_hop_ms_allgather_then_one_launch"] = comm_ms + rs["hop_ms_one_launch"]
+        model["rowshard_hop_ms_chunked_pipelined"] = max(comm_ms, sum(rs["chunk_launch_ms"])) + \
+            rs["chunk_launch_ms"][-1] + (rs["hop_ms_chunked_%d_launches_plus_finish" % W] - sum(rs["chunk_launch_ms"]))
+        model["rowshard_hop_ms_chunked_direct_links_only"] = (W - 1) * (rs["received_bytes_per_hop"] / (W - 1)) / 76.8e9 \
+            * 1e3 + rs["chunk_launch_ms"][-1]
+        model["rowshard_step_ms_pipelined"] = 2 * L * model["rowshard_hop_ms_chunked_pipelined"]
+        model["rowshard_step_ms_unpipelined"] = 2 * L * model["rowshard_hop_ms_allgather_then_one_launch"]
+    if cs:
+        model["colshard_step_ms"] = cs["ms_per_step"]
+    out["model_at_%d_ranks" % W] = model
+    return out
+
+
 def cpu_baseline(train, test, E0, args, eval_tables=None, n_eval_users=1024):
     """SURVEY §8d's CPU legs, timed on this box's host cores on bounded samples of the same workload:
       (i)   the reference's own PairwiseSampler epoch (data/sampler.py + util/data_iterator.py +
@@ -497,6 +615,80 @@ def cpu_baseline(train, test, E0, args, eval_tables=None, n_eval_users=1024):
                    "sample": "%d users, np.matmul + C++ evaluator, num_thread=8, batch 128" % len(users),
                    "ndcg@10": float(np.mean(np.concatenate(res), axis=0)[2 * 20 + 9]),
                    "users": users}
+    return out
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(line):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` with the
+    secondary legs' headline numbers as FLAT numeric keys (the driver's parser keeps those objects key by key and
+    truncates anything long), no prose.  The full objects — every leg with its kernel names, notes and sample
+    descriptions — go to bench_full.json (committed per round as profiles/rNN_bench.json)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "rccl_ranks", "dist_backend")
+    out = {k: line[k] for k in keep if k in line}
+    short = lambda d: {k: v for k, v in (d or {}).items()
+                       if isinstance(v, (int, float, bool)) or v is None or (isinstance(v, str) and len(v) <= 96)}
+    roof = short(line.get("roofline"))
+    legs = {
+        "epoch_amortised_triplets_per_sec": _get(line, "epoch_amortised", "value"),
+        "eval_users_per_sec": _get(line, "eval", "users_per_sec"), "eval_ms": _get(line, "eval", "ms"),
+        "eval_ndcg10": _get(line, "eval", "ndcg@10"),
+        "eval_ndcg10_oracle_absdiff": _get(line, "eval", "ndcg10_oracle_absdiff"),
+        "eval_mfma_tflops": _get(line, "eval", "roofline", "achieved"),
+        "eval_mfma_frac": _get(line, "eval", "roofline", "frac"),
+        "eval_plan_build_ms": _get(line, "eval", "strike_plan_build_ms"),
+        "mf_triplets_per_sec": _get(line, "mf", "triplets_per_sec"),
+        "mf_us_per_step": None if _get(line, "mf", "ms_per_step") is None else _get(line, "mf", "ms_per_step") * 1e3,
+        "mf_hbm_frac": _get(line, "mf", "roofline", "frac"),
+        "mf_eval_users_per_sec": _get(line, "mf", "eval", "users_per_sec"),
+        "ngcf_ms_per_step": _get(line, "ngcf", "ms_per_step"),
+        "ngcf_triplets_per_sec": _get(line, "ngcf", "triplets_per_sec"),
+        "ngcf_spmm_hbm_frac": _get(line, "ngcf", "roofline", "frac"),
+        "ngcf_wide_ms_per_step": _get(line, "ngcf", "wide", "ms_per_step"),
+        "multivae_ms_per_step": _get(line, "multivae", "ms_per_step"),
+        "multivae_users_per_sec": _get(line, "multivae", "users_per_sec_train"),
+        "multivae_decoder_us": _get(line, "multivae", "roofline", "us_per_launch"),
+        "multivae_decoder_mfma_frac": _get(line, "multivae", "roofline", "frac"),
+        "multivae_wide_ms_per_step": _get(line, "multivae", "wide", "ms_per_step"),
+        "multivae_wide_mfma_frac": _get(line, "multivae", "wide", "roofline", "frac"),
+        "config4_ms_per_step": _get(line, "config4", "ms_per_step"),
+        "config4_triplets_per_sec": _get(line, "config4", "triplets_per_sec"),
+        "config4_spmm_hbm_frac": _get(line, "config4", "roofline", "frac"),
+        "config4_row_gather_GBps": _get(line, "config4", "roofline", "row_gather_GBps"),
+        "config4_rowshard_rank0of8_hop_ms": _get(line, "config4", "partitions", "rowshard_rank0_of_8",
+                                                 "hop_ms_chunked_8_launches_plus_finish"),
+        "config4_colshard_rank0of8_step_ms": _get(line, "config4", "partitions", "colshard_rank0_of_8", "ms_per_step"),
+    }
+    for w in ("2", "4", "8"):
+        legs["colshard_share_ms_%s" % w] = _get(line, "colshard_one_rank_share", w, "ms_per_step")
+    legs["same_global_batch_on_1gpu_triplets_per_sec"] = _get(line, "same_global_batch_on_1gpu", "value")
+    legs["exchange_ms_per_step"] = _get(line, "exchange_measured", "ms_per_step")
+    roof.update({k: v for k, v in legs.items() if v is not None})
+    out["roofline"] = roof
+    cb = line.get("cpu_baseline")
+    if cb is not None:
+        c = short(cb)
+        for k, path in (("sampler_triplets_per_sec", ("sampler", "value")), ("eval_users_per_sec", ("eval", "value")),
+                        ("eval_ndcg10", ("eval", "ndcg@10"))):
+            v = _get(cb, *path)
+            if v is not None:
+                c[k] = v
+        for leg, unit in (("ngcf", "triplets_per_sec"), ("multivae", "users_per_sec")):
+            v = _get(line, leg, "cpu_baseline", "value")
+            if v is not None:
+                c["%s_%s" % (leg, unit)] = v
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = None
+    out["full_line"] = "bench_full.json next to bench.py / in gpurun_out (committed per round as profiles/rNN_bench.json)"
     return out
 
 
@@ -1008,8 +1200,19 @@ def main():
         ev = mf_ev = None
         torch.cuda.empty_cache()
         line["config4"] = leg_config4(comm, dev, args.config4_scale)
+        try:
+            line["config4"]["partitions"] = leg_config4_partitions(dev, args.config4_scale)
+        except Exception as e:                                # a measurement leg must not take the headline down
+            line["config4"]["partitions"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if comm.rank == 0:
-        print(json.dumps(line))
+        full = os.environ.get("NEUREC_BENCH_FULL") or os.path.join(
+            ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "bench_full.json")
+        try:
+            with open(full, "w") as f:
+                json.dump(line, f)
+        except OSError:
+            pass
+        print(json.dumps(compact_line(line)))
     comm.shutdown()
 
 

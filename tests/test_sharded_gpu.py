@@ -299,3 +299,76 @@ def test_chunked_hop_is_the_one_launch_hop_bit_for_bit(adj_type, d, world):
             for x, y in zip(outs[0], outs[1]):
                 if x is not None:
                     assert torch.equal(x, y), (adj_type, d, rank, sorted(kw))
+
+
+def _config4_law(scale):
+    """the config-4 interaction law (synth.device_interactions) at a small scale, as host arrays"""
+    import torch
+    from neurec_amd import graph, synth
+    U, I, n_edges = (max(int(x * scale), 64) for x in synth.CONFIG4)
+    ptr, idx = synth.device_interactions(U, I, n_edges, seed=2018, device=torch.device("cuda", 0))
+    ptr, idx = ptr.cpu().numpy(), idx.cpu().numpy()
+    users = np.repeat(np.arange(U), np.diff(ptr))
+    A = graph.lightgcn_adjacency(users, idx, U, I, "pre")
+    E0 = (np.random.RandomState(4).rand(U + I, 128).astype(np.float32) * 2 - 1) * np.float32(np.sqrt(6.0 / (U + I + 128)))
+    return ptr, idx, A, E0, U, I
+
+
+def _config4_batches(U, I, world, B, steps):
+    rng = np.random.RandomState(31)
+    return [[(rng.randint(0, U, B).astype(np.int32), rng.randint(0, I, B).astype(np.int32),
+              rng.randint(0, I, B).astype(np.int32)) for _ in range(world)] for _ in range(steps)]
+
+
+def _config4_worker(rank, world, port, out, pipeline):
+    import torch
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), NEUREC_DIST_BACKEND="gloo", NEUREC_ROWSHARD_PIPELINE=pipeline)
+    from neurec_amd import parallel, synth
+    from neurec_amd.sharded import ShardedLightGCN
+    comm = parallel.init_from_env()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    U, I, n_edges = (max(int(x * 0.002), 64) for x in synth.CONFIG4)
+    ptr, idx = synth.device_interactions(U, I, n_edges, seed=2018, device=dev)
+    part = parallel.BipartitePartition(U, I, world)
+    ur, ir = part.users_of(rank), part.items_of(rank)
+    rows = synth.device_lightgcn_rank_rows(ptr, idx, U, I, ur, ir)        # the rank's rows alone, built on the device
+    E0 = _config4_law(0.002)[3]
+    emb = np.concatenate([E0[ur[0]:ur[1]], E0[U + ir[0]:U + ir[1]]])
+    B = 8192
+    eng = ShardedLightGCN(comm, None, U, I, emb, 3, 0.01, 1e-3, B, local_rows=rows)
+    steps = _config4_batches(U, I, world, B, 2)
+    eng.plan_epoch(*(torch.from_numpy(np.concatenate([st[rank][k] for st in steps])).to(dev) for k in range(3)), B)
+    # 3 x 8,192 requests per rank outgrow the one-workgroup key sort of the per-epoch routing tables: the step routes on the spot
+    assert eng.router.planned_route(0, B) is None and eng.router.epoch_counts(0, B) is not None
+    for k, step in enumerate(steps):
+        bu, bp, bn = (torch.from_numpy(x).to(dev) for x in step[rank])
+        eng.step(bu, bp, bn, None, batch_index=k)
+    table = torch.zeros(eng.Npad, 128, device=dev)
+    comm.all_gather_rows(eng.E0, table)
+    if rank == 0:
+        tu, ti = eng.natural(table)
+        np.save(out, torch.cat([tu, ti]).cpu().numpy())
+    comm.barrier()
+    comm.shutdown()
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_config4_law_two_ranks_equal_the_single_engine(tmp_path, pipeline):
+    """BASELINE configs[3]'s own law (device-generated graph, hub items of thousands of interactions,
+    d = 128, L = 3, B = 8,192 per rank) at scale 0.002 on two ranks — each built from its own rows alone, stepping
+    through the per-step routing fallback that only this batch size hits — against the single engine on the
+    concatenated batches: identical bits, with the chunked hop and with the one-all-gather hop."""
+    import torch
+    import torch.multiprocessing as mp
+    from neurec_amd.trainer import LightGCNEngine
+    out = str(tmp_path / "t.npy")
+    mp.start_processes(_config4_worker, args=(2, _free_port(), out, pipeline), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    ptr, idx, A, E0, U, I = _config4_law(0.002)
+    assert np.diff(A.tocsr().indptr).max() > 1000                       # hub rows: segments combined in order
+    lg = LightGCNEngine(A, U, I, E0, 3, 0.01, 1e-3, 2 * 8192)
+    for step in _config4_batches(U, I, 2, 8192, 2):
+        bu, bp, bn = (torch.from_numpy(np.concatenate([s[k] for s in step])).cuda() for k in range(3))
+        lg.step(bu, bp, bn, None)
+    np.testing.assert_array_equal(got, lg.E0.cpu().numpy())
