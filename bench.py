@@ -1098,6 +1098,26 @@ def main():
         "eval": eval_info, "mf": mf_info, "roofline": roofline,
         "device": E.device_info(),
     }
+    if colshard:
+        # the step's ONE exchange measured on its own (not asserted): all-gather of the per-triplet
+        # partial products + the rank-order sums, wall clock between device synchronisations, median of 20
+        n3 = 3 * global_batch
+        parts = torch.rand(n3, device=dev)
+        allp = torch.empty((comm.world, n3), dtype=torch.float32, device=dev)
+        given = torch.empty(n3, dtype=torch.float32, device=dev)
+        ts = []
+        for _ in range(25):
+            torch.cuda.synchronize(); comm.barrier()
+            t1 = time.perf_counter()
+            comm.all_gather_rows(parts, allp)
+            E.partials_sum(allp, comm.world, n3, given)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        ex_ms = comm.max_float(float(np.median(ts[5:])) * 1e3)
+        line["exchange_measured"] = {"ms_per_step": ex_ms, "bytes_per_rank": 4 * n3, "backend": comm.backend,
+                                     "share_of_step": ex_ms / (dt / args.steps * 1e3),
+                                     "note": "inside the timed step already; gloo stages through the host (two ranks on "
+                                             "one GPU in the tests): only backend nccl is the xGMI figure"}
     if comm.active:
         import torch.distributed as dist
         line["rccl_ranks"] = comm.world if dist.get_backend() == "nccl" else 0

@@ -528,3 +528,48 @@ extern "C" int nrhip_exp_mfma_peak(int blocks, int waves_per_simd, int iters, fl
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Micro-benchmark (scripts/exp_grid_barrier.py): what does a device-wide barrier cost on this part?  The BPR-MF
+// step is one launch per step (12 us, 4.3 us of it the XCDs' launch skew); a persistent epoch kernel would trade the
+// launch for a grid barrier per step.  `n_wg` resident workgroups of 256 threads cross `iters` barriers:
+//   mode 0  one global counter: thread 0 of every workgroup adds 1 (release), spins until it reads iter·n_wg (acquire)
+//   mode 1  two levels: a counter per XCD (blockIdx % 8), the last arriver of an XCD adds 1 to the global one; all
+//           spin on the global counter
+// `work` = dependent fma steps per thread between barriers (0: the bare barrier).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void exp_grid_barrier_kernel(unsigned* cnt, int n_wg, int iters, int mode, int work,
+                                                               float* out) {
+  const int wg = blockIdx.x, xcd = wg & 7;
+  const int per_xcd = (n_wg - xcd + 7) / 8;
+  float x = threadIdx.x * 1e-3f;
+  for (int it = 1; it <= iters; ++it) {
+    for (int k = 0; k < work; ++k) x = __builtin_fmaf(x, 1.0000001f, 1e-7f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (mode == 0) {
+        atomicAdd(&cnt[0], 1u);
+        while (__hip_atomic_load(&cnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it * n_wg) {}
+      } else {
+        const unsigned prev = atomicAdd(&cnt[16 * (1 + xcd)], 1u);
+        if (prev + 1 == (unsigned)it * per_xcd) atomicAdd(&cnt[0], 1u);
+        while (__hip_atomic_load(&cnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it * 8u) {}
+      }
+    }
+    __syncthreads();
+  }
+  if (x == 12345.f) out[wg] = x;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_grid_barrier(unsigned* d_cnt, int n_wg, int iters, int mode, int work, float* d_out,
+                                      void* stream) {
+  NR_REQUIRE(d_cnt && d_out && n_wg >= 8 && iters >= 1, NR_ERR_ARG, "exp_grid_barrier: bad arguments");
+  NR_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 16 * 9 * sizeof(unsigned), (hipStream_t)stream));
+  hipLaunchKernelGGL(exp_grid_barrier_kernel, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, d_cnt, n_wg, iters, mode,
+                     work, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}

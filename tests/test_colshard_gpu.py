@@ -113,3 +113,42 @@ def test_two_ranks_equal_one_gpu_within_inner_product_rounding(tmp_path, d, L):
     assert np.abs(full - got).max() <= 2e-4 and np.mean(np.abs(full - got) > 1e-6) < 0.01
     fu, fi = lg.final_embeddings()
     assert np.abs(r[0]["eu"] - fu.cpu().numpy()).max() <= 2e-4
+
+
+def test_one_rank_share_of_8_costs_no_more_than_1p2x_the_share_of_4():
+    """the default `--gpus 8` path steps on the global batch of 8 x 1,024 with 8 of the 64 columns; its
+    one-rank step (no exchange) must stay within 1.2x of the 4-rank share's (16 columns, 4 x 1,024) at the gowalla
+    shape — HIP events, best of three, NOT under a profiler (kernel tracing made this host-bound loop read 0.41 ms
+    where the untraced run reads 0.157: profiles/r03_bench.json vs BENCH_r03.json)."""
+    import torch
+    from neurec_amd import engine as E, graph, parallel, synth
+    from neurec_amd.colshard import ColumnShardedLightGCN
+    from neurec_amd.trainer import BprEpochSampler
+    tr, _ = synth.interactions("gowalla", seed=2018)
+    U, I = tr.shape
+    coo = tr.tocoo()
+    A = graph.lightgcn_adjacency(coo.row, coo.col, U, I, "pre")
+    E0 = synth.xavier_uniform(U + I, 64, np.random.RandomState(2017))
+    trc = E.DeviceCSR.from_scipy(tr)
+    ms = {}
+    for W in (4, 8):
+        gB = W * 1024
+        cs = ColumnShardedLightGCN(parallel.Comm(), A, U, I, E0, 3, 0.01, 1e-3, gB, rank=0, world=W)
+        s = BprEpochSampler(trc, I, batch_size=gB, seed=2018, plan_users=U)
+        bs = [b for b in s.batches() if b[0].numel() == gB][:30]
+        best = 1e9
+        for _ in range(3):
+            for b in bs[:10]:
+                cs.step(b[0], b[1], b[2], None, plan=b.plan)
+            torch.cuda.synchronize()
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for b in bs:
+                cs.step(b[0], b[1], b[2], None, plan=b.plan)
+            e.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(e) / len(bs))
+        ms[W] = best
+        del cs, s, bs
+    print("one-rank share: W=4 %.4f ms, W=8 %.4f ms" % (ms[4], ms[8]))
+    assert ms[8] <= 1.2 * ms[4], ms
