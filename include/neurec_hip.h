@@ -75,6 +75,15 @@ int nrhip_eval_scores(const float* d_scores, int64_t ld, int rows, int cols,
                       int n_metric, int top_k, float* d_out, int32_t* d_topk_out,
                       int32_t* d_n_exact, void* d_ws, size_t ws_bytes, void* stream);
 
+/* nrhip_eval_scores without the top_k <= 128 limit (cpp_evaluate_matrix / eval_one_user take any K:
+ * evaluator/backend/cpp/include/evaluate.h:23-50): one thread per row replays std::partial_sort_copy and the metric
+ * loops sequentially.  Same arguments, same output layout; its own workspace query. */
+int nrhip_eval_any_k_workspace_bytes(int rows, int cols, int top_k, size_t* bytes);
+int nrhip_eval_scores_any_k(const float* d_scores, int64_t ld, int rows, int cols, const int32_t* d_users,
+                            const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                            const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
+                            int32_t* d_topk_out, void* d_ws, size_t ws_bytes, void* stream);
+
 /* Per row arg-top-K with std::partial_sort_copy(K) semantics
  * (arg_topk.h:15-25): d_out[rows][top_k] int32. */
 int nrhip_arg_topk(const float* d_scores, int64_t ld, int rows, int cols, int top_k,

@@ -81,6 +81,8 @@ SIGNATURES = {
     "nrhip_eval_workspace_bytes": [i32, i32, psz],
     "nrhip_mask_train": [p, i64, p, i32, i32, p, p, p],
     "nrhip_eval_scores": [p, i64, i32, i32, p, p, p, C.POINTER(i32), i32, i32, p, p, p, p, sz, p],
+    "nrhip_eval_any_k_workspace_bytes": [i32, i32, i32, psz],
+    "nrhip_eval_scores_any_k": [p, i64, i32, i32, p, p, p, C.POINTER(i32), i32, i32, p, p, p, sz, p],
     "nrhip_arg_topk": [p, i64, i32, i32, i32, p, p, p, sz, p],
     "nrhip_colsum_workspace_bytes": [i32, i32, psz],
     "nrhip_colsum_f64": [p, i64, i32, i32, p, p, sz, p],

@@ -14,6 +14,7 @@
 // emulation of libstdc++'s heap partial_sort_copy (nr_core.h) so that the
 // item order is the reference's, bit for bit.
 #include "nr_common.h"
+#include <vector>
 #include <atomic>
 #include <stdlib.h>
 
@@ -713,6 +714,34 @@ int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sor
   return NR_OK;
 }
 
+// ----------------------------------------------------------------------------
+// Any top_k (the reference's evaluate.h:23-50 takes any K; the selection kernels above are built for K <= 128):
+// one thread per score row runs the libstdc++ partial_sort_copy replay itself (nr::partial_sort_copy_emul — the
+// definition the parallel selection is checked against) over its row, heap in global memory, then the metrics with
+// the reference's float / double sequence (nr::metric_eval).  Slow and simple: a row is ~cols + 2K·ln(cols/2K)·log2K
+// sequential steps; the common cut-offs (<= 128) never come here.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void eval_bigk_kernel(
+    const float* __restrict__ S, int64_t ld, int rows, int cols, int sort_len, int top_k,
+    const int32_t* __restrict__ users, const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices,
+    MetricIds mids, const double* __restrict__ inv_log2, float* __restrict__ heap_val, int* __restrict__ heap_idx,
+    float* __restrict__ out, int32_t* __restrict__ topk_out) {
+  const int row = blockIdx.x * 64 + threadIdx.x;
+  if (row >= rows) return;
+  float* hv = heap_val + (int64_t)row * sort_len;
+  int* hi = heap_idx + (int64_t)row * sort_len;
+  nr::partial_sort_copy_emul(S + (int64_t)row * ld, cols, sort_len, hv, hi);
+  const int64_t t = users ? (int64_t)users[row] : (int64_t)row;
+  const int64_t tb = t_indptr[t];
+  const int T = (int)(t_indptr[t + 1] - tb);
+  if (topk_out)
+    for (int k = 0; k < top_k; ++k) topk_out[(int64_t)row * top_k + k] = hi[k];
+  for (int m = 0; m < mids.n; ++m)
+    nr::metric_eval(mids.id[m], [&](int k) { return nr::sorted_contains(t_indices + tb, T, hi[k]); }, top_k, T,
+                    inv_log2, out + ((int64_t)row * mids.n + m) * top_k);
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -777,6 +806,56 @@ int nrhip_eval_scores(const float* d_scores, int64_t ld, int rows, int cols,
   NR_LAUNCH_CHECK();
   if (d_n_exact)
     NR_CHECK_HIP(hipMemcpyAsync(d_n_exact, w.n_exact, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return NR_OK;
+}
+
+/* nrhip_eval_scores for ANY top_k (evaluate.h:23-50 has no limit): same arguments and output; workspace =
+ * nrhip_eval_any_k_workspace_bytes.  One thread per row (see eval_bigk_kernel). */
+static size_t eval_any_k_ws(int rows, int cols, int top_k) {
+  const int sort_len = (2 * top_k < cols) ? 2 * top_k : cols;
+  const size_t r = (size_t)(rows > 0 ? rows : 1);
+  return nr_align_up((size_t)top_k * sizeof(double), 256) + 2 * nr_align_up(r * (size_t)sort_len * 4, 256);
+}
+
+int nrhip_eval_any_k_workspace_bytes(int rows, int cols, int top_k, size_t* bytes) {
+  NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && top_k >= 1, NR_ERR_ARG, "eval_any_k_workspace_bytes: bad arguments");
+  *bytes = eval_any_k_ws(rows, cols, top_k);
+  return NR_OK;
+}
+
+int nrhip_eval_scores_any_k(const float* d_scores, int64_t ld, int rows, int cols, const int32_t* d_users,
+                            const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                            const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
+                            int32_t* d_topk_out, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_scores && d_truth_indptr && d_truth_indices && metric_ids_host && d_out && d_ws, NR_ERR_ARG,
+             "eval_scores_any_k: null pointer argument");
+  NR_REQUIRE(top_k >= 1 && cols >= top_k, NR_ERR_ARG,
+             "eval_scores_any_k: %d columns < top_k=%d (the reference reads past its buffer here)", cols, top_k);
+  NR_REQUIRE(n_metric >= 1 && n_metric <= 8, NR_ERR_ARG, "eval_scores_any_k: n_metric=%d outside 1..8", n_metric);
+  NR_REQUIRE(ld >= cols && rows >= 0, NR_ERR_ARG, "eval_scores_any_k: ld=%lld < cols=%d", (long long)ld, cols);
+  MetricIds mids;
+  mids.n = n_metric;
+  for (int i = 0; i < n_metric; ++i) {
+    NR_REQUIRE(metric_ids_host[i] >= 1 && metric_ids_host[i] <= 5, NR_ERR_ARG,
+               "eval_scores_any_k: metric id %d is not one of 1..5", metric_ids_host[i]);
+    mids.id[i] = metric_ids_host[i];
+  }
+  if (rows == 0) return NR_OK;
+  NR_REQUIRE(ws_bytes >= eval_any_k_ws(rows, cols, top_k), NR_ERR_WORKSPACE, "eval_scores_any_k: workspace %zu < %zu",
+             ws_bytes, eval_any_k_ws(rows, cols, top_k));
+  hipStream_t st = (hipStream_t)stream;
+  const int sort_len = (2 * top_k < cols) ? 2 * top_k : cols;   // evaluate.h:37
+  char* ws = (char*)d_ws;
+  double* tbl = (double*)ws;
+  float* hv = (float*)(ws + nr_align_up((size_t)top_k * sizeof(double), 256));
+  int* hi = (int*)((char*)hv + nr_align_up((size_t)rows * sort_len * 4, 256));
+  std::vector<double> h((size_t)top_k);
+  for (int i = 0; i < top_k; ++i) h[(size_t)i] = 1.0 / log2((double)(unsigned)(i + 2));           // metric.h:78
+  NR_CHECK_HIP(hipMemcpyAsync(tbl, h.data(), (size_t)top_k * sizeof(double), hipMemcpyHostToDevice, st));
+  NR_CHECK_HIP(hipStreamSynchronize(st));                       // the host table goes out of scope
+  hipLaunchKernelGGL(eval_bigk_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_scores, ld, rows, cols, sort_len,
+                     top_k, d_users, d_truth_indptr, d_truth_indices, mids, tbl, hv, hi, d_out, d_topk_out);
+  NR_LAUNCH_CHECK();
   return NR_OK;
 }
 

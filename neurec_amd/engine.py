@@ -134,9 +134,19 @@ def eval_scores(scores, truth_csr, metric_ids, top_k, users=None, cols=None, out
     topk = torch.empty((rows, top_k), dtype=torch.int32, device=dev) if want_topk else None
     nex = torch.zeros(1, dtype=torch.int32, device=dev) if want_exact_count else None
     nbytes = C.c_size_t(0)
+    ids = (C.c_int * nm)(*[int(m) for m in metric_ids])
+    if top_k > 128:                 # beyond the parallel selection's cut-off: the sequential replay, any K
+        call("nrhip_eval_any_k_workspace_bytes", rows, cols, top_k, C.byref(nbytes))
+        ws = _eval_ws.get(nbytes.value)
+        call("nrhip_eval_scores_any_k", C.c_void_p(scores.data_ptr()), scores.stride(0), rows, cols,
+             _ptr(users, torch.int32, allow_none=True), _ptr(truth_csr.indptr), _ptr(truth_csr.indices), ids, nm,
+             top_k, _ptr(out, torch.float32), _ptr(topk, allow_none=True), _ptr(ws), ws.numel(), _stream())
+        if nex is not None:
+            nex.fill_(rows)          # every row took the exact replay
+        res = [out] + ([topk] if want_topk else []) + ([nex] if want_exact_count else [])
+        return res[0] if len(res) == 1 else tuple(res)
     call("nrhip_eval_workspace_bytes", rows, top_k, C.byref(nbytes))
     ws = _eval_ws.get(nbytes.value)
-    ids = (C.c_int * nm)(*[int(m) for m in metric_ids])
     call("nrhip_eval_scores", C.c_void_p(scores.data_ptr()), scores.stride(0), rows, cols,
          _ptr(users, torch.int32, allow_none=True), _ptr(truth_csr.indptr),
          _ptr(truth_csr.indices), ids, nm, top_k, _ptr(out, torch.float32),

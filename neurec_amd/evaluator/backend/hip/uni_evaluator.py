@@ -42,8 +42,8 @@ class UniEvaluator(HIPEvaluator):
         self.num_thread = num_thread
         self.batch_size = batch_size
         self.max_top = top_k if isinstance(top_k, int) else max(top_k)
-        if self.max_top > 128:
-            raise NotImplementedError("the HIP top-K kernels rank at most 128 items per user; top_k=%r" % (top_k,))
+        # (any top_k, as the reference's evaluate.h:23-50: cut-offs beyond 128 take the one-thread-per-row replay,
+        # engine.eval_scores -> nrhip_eval_scores_any_k)
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._device_state = None
 

@@ -23,12 +23,12 @@ class LightGCN(AbstractRecommender):
         self.lr = config["lr"]
         self.reg = config["reg"]
         self.emb_dim = config["embed_size"]
-        if not (isinstance(self.emb_dim, int) and 1 <= self.emb_dim <= 128):
+        if not (isinstance(self.emb_dim, int) and 1 <= self.emb_dim <= 256):
             # fail here, by name, not as an opaque context error inside the native step.  Widths other than
-            # 16 / 32 / 64 / 128 run zero-padded to the next built one (trainer.LightGCNEngine, which itself goes to
-            # 256); the evaluator's fp32-MFMA scoring loop is built up to 128 columns, so the plugin stops there
-            raise NotImplementedError("the HIP LightGCN plugin is built for embed_size 1..128 (training kernels: up to "
-                                      "256; evaluation scoring: up to 128); got %r" % (self.emb_dim,))
+            # 16 / 32 / 64 / 128 / 256 run zero-padded to the next built one (trainer.LightGCNEngine); beyond 128 columns
+            # the evaluation scores through the general fp32-MFMA GEMM (engine.ScoreGemmWide: the same k-ascending
+            # chain per score, materialised path) instead of the tile-maxima scoring loop
+            raise NotImplementedError("the HIP LightGCN plugin is built for embed_size 1..256; got %r" % (self.emb_dim,))
         self.batch_size = config["batch_size"]
         self.epochs = config["epochs"]
         self.n_layers = config["n_layers"]

@@ -106,6 +106,20 @@ def test_lightgcn_config_drops_in(tmp_path):
     assert evals[-1][1] == _oracle_line(model, model.evaluator)
 
 
+def test_lightgcn_embed_size_beyond_the_scoring_loop(tmp_path):
+    """embed_size 160: the table runs zero-padded at 256 columns and the evaluation scores through the
+    wide GEMM (engine.ScoreGemmWide) — the logged line equals the CPU restatement of the reference evaluator."""
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=LightGCN", "--epochs=2", "--batch_size=256", "--embed_size=160",
+                            "--n_layers=2", "--topk=[5,10]", "--metric=[\"Recall\",\"NDCG\"]"])
+    assert model.engine.d == 256 and model.engine.d_real == 160
+    evals = re.findall(r"epoch (\d+):\t(.+)", _log_text(tmp_path, "LightGCN"))
+    assert [int(e[0]) for e in evals] == [0, 1]
+    model._final = None
+    assert evals[-1][1] == _oracle_line(model, model.evaluator)
+
+
 def test_candidate_negative_mode_and_groups(tmp_path):
     """rec.evaluate.neg > 0 (leave-one-out protocol) and group_view go through the same kernels."""
     _write_dataset(str(tmp_path))

@@ -99,8 +99,28 @@ def test_eval_argument_errors(eng):
         eng.eval_scores(s, truth, [1], 9)              # top_k > columns
     with pytest.raises(ValueError):
         eng.eval_scores(s, truth, [7], 2)              # unknown metric id
-    with pytest.raises(NotImplementedError):
-        eng.eval_scores(s, truth, [1], 129, cols=8)    # beyond the built top_k range
+    with pytest.raises(ValueError):
+        eng.eval_scores(s, truth, [1], 129, cols=8)    # top_k > columns on the any-K path as well
+
+
+@pytest.mark.parametrize("rows,cols,k,ties", [(70, 900, 129, False), (33, 700, 300, True), (5, 260, 250, True),
+                                              (64, 2000, 512, False)])
+def test_any_top_k_matches_the_reference_evaluator(eng, rows, cols, k, ties):
+    """evaluate.h:23-50 takes any K: beyond the parallel selection's 128 a thread per row replays
+    std::partial_sort_copy (2K of cols, heap tie order) and the metric loops — equal bits to the C++ restatement,
+    with ties straddling the cut-off, -inf (masked) entries and truth lists longer than K."""
+    from oracle import native
+    rng = np.random.RandomState(rows + k)
+    s = rng.randn(rows, cols).astype(np.float32)
+    if ties:
+        s = np.round(s * 4) / 4
+    s[rng.rand(rows, cols) < 0.05] = -np.inf
+    test_lists = [np.sort(rng.choice(cols, rng.randint(1, min(cols, 2 * k)), replace=False)).tolist() for _ in range(rows)]
+    mids = [1, 2, 3, 4, 5]
+    want = native.eval_matrix(s, test_lists, mids, k)
+    got, topk = eng.eval_scores(_dev(s), _csr(eng, test_lists, cols), mids, k, want_topk=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert topk.shape == (rows, k)
 
 
 def test_mask_train_matches_reference_loop(eng):

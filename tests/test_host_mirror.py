@@ -298,17 +298,17 @@ def test_unsupported_shapes_fail_early_and_by_name():
     """shapes the kernels are not built for are refused in the Python constructors with a
     message that lists what is supported (no opaque native error later)."""
     from neurec_amd.evaluator.backend.hip.uni_evaluator import UniEvaluator
-    with pytest.raises(NotImplementedError, match="at most 128"):
-        UniEvaluator({0: [1]}, {0: [2]}, top_k=200)
+    assert UniEvaluator({0: [1]}, {0: [2]}, top_k=200).max_top == 200      # any top_k (evaluate.h:23-50), since r04
     from neurec_amd.model.general_recommender.LightGCN import LightGCN
 
     class _Conf(dict):
         def __getattr__(self, k):
             return self[k]
-    # (since r03 every embed_size up to 128 runs — zero-padded to the next built width; beyond: refused by name)
+    # (every embed_size up to 256 runs — zero-padded to the next built width, scored through the wide GEMM beyond 128;
+    # beyond 256: refused by name)
     conf = _Conf(lr=0.01, reg=1e-3, embed_size=300, batch_size=8, epochs=1, n_layers=2, adj_type="pre",
                  recommender="LightGCN")
-    with pytest.raises(NotImplementedError, match="embed_size 1..128"):
+    with pytest.raises(NotImplementedError, match="embed_size 1..256"):
         LightGCN.__init__.__wrapped__(object.__new__(LightGCN), None, None, conf) if hasattr(LightGCN.__init__, "__wrapped__") \
             else _try_lightgcn(LightGCN, conf)
 
