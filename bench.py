@@ -1053,6 +1053,13 @@ def main():
                 "flops_per_user": 2.0 * I * d_e,
                 "strikes_in_the_loop_ms": t_inloop * 1e3,
                 "strike_plan_pairs": plan.n_pairs if plan is not None else None}
+            if plan is not None:
+                # the plan is built once per train matrix, outside every evaluation: its one-off cost
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                E.TileStrikePlan(trc, I)
+                torch.cuda.synchronize()
+                eval_info["strike_plan_build_ms"] = (time.perf_counter() - tp) * 1e3
             eval_info["roofline_topk"] = {
                 "bound": "l2", "kernel": "rescore_tiles_kernel + select_rows_kernel + metrics_kernel (nrhip_eval_tiles)",
                 "achieved": rescore_l2_bytes / t_rank / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",

@@ -315,10 +315,12 @@ class TileStrikePlan:
         counts = indptr[1:] - indptr[:-1]
         user = torch.repeat_interleave(torch.arange(U, device=dev, dtype=torch.int64), counts)
         n_tiles = 2 * ((self.cols + 63) // 64)
-        key = (indices >> 5) * U + user
-        key, order = torch.sort(key, stable=True)
+        # one entry per distinct (tile, user, item): a CSR assembled by hand may repeat an item, and a repeated bit
+        # would carry into its neighbour under the + below
+        full = torch.unique(((indices >> 5) * U + user) * 32 + (indices & 31))
+        key = full >> 5
         uniq, inverse = torch.unique_consecutive(key, return_inverse=True)
-        bits = torch.ones_like(key) << (indices[order] & 31)
+        bits = torch.ones_like(key) << (full & 31)
         mask = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).index_add_(0, inverse, bits)   # distinct bits: + is |
         tile = uniq // U
         self.user = (uniq - tile * U).to(torch.int32).contiguous()

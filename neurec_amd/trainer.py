@@ -560,8 +560,17 @@ class FullRankEvaluator:
         flags = torch.zeros(n, dtype=torch.int32, device=test_users.device)
         self.n_flagged = 0
         plan = row_of = None
-        if self.strike_plan:
-            # test_users must be distinct (uni_evaluator.py:108: the keys of a dict): a user's row is looked up
+        use_plan = self.strike_plan
+        if use_plan:
+            # the planned strikes look a user's row up: test_users must be distinct (uni_evaluator.py:108 hands over
+            # the keys of a dict).  Checked once per user list (one count, one host read), not per evaluation; a list
+            # with repeats takes the in-loop strikes, which have no such precondition.
+            tag = (test_users.data_ptr(), n)
+            if getattr(self, "_distinct_tag", None) != tag:
+                self._distinct_tag = tag
+                self._distinct = int(torch.unique(test_users).numel()) == n
+            use_plan = self._distinct
+        if use_plan:
             if self._plan is None or self._plan.cols != item_table.shape[0]:
                 self._plan = E.TileStrikePlan(self.train, item_table.shape[0])
             plan = self._plan
