@@ -174,8 +174,8 @@ def leg_ngcf(train, test, trc, tec, dev, with_cpu):
                                 "achieved": spmm64_bytes / spmm64_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": spmm64_bytes / spmm64_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
                                 "note": "3 forward + 3 backward SpMM passes at d = 64 per step; the dense layer products "
-                                        "run on the fp32 matrix cores (csrc/gemm.hip), the step is strung from ~70 "
-                                        "launches issued by Python"}}
+                                        "run on the fp32 matrix cores (csrc/gemm.hip); one native call per step "
+                                        "(nrhip_ngcf_wide_step: ~70 launches; r03 issued them from Python: 1.02 ms)"}}
     del wide
     if with_cpu:
         from oracle import train as O

@@ -814,6 +814,42 @@ int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const 
                        int64_t lde, int64_t n_rows, int w, int w_pad, float* d_dS, float* d_dego_direct,
                        void* stream);
 
+/* The width-generic NGCF forward pass and training step as ONE call each (neurec_amd/ngcf_wide.py strung them from
+ * ~70 Python-issued launches: 1.0 ms a step at 64 / [64, 64, 64], of which the GPU was busy 0.45).  The struct
+ * records caller-owned device pointers; per layer k: widths w[k] -> w[k+1] (wp = padded to the SpMM's row widths),
+ * off[k] = first column of layer k's block in the concatenated output. */
+#define NRHIP_NGCF_WIDE_MAX_LAYERS 8
+typedef struct {
+  const void* plan; const int64_t* indptr; const int32_t* indices; const float* vals;           /* A_hat */
+  const void* plan_t; const int64_t* indptr_t; const int32_t* indices_t; const float* vals_t;   /* A_hat^T */
+  void* ws_fwd[NRHIP_NGCF_WIDE_MAX_LAYERS]; size_t ws_fwd_bytes[NRHIP_NGCF_WIDE_MAX_LAYERS];     /* SpMM scratch per layer */
+  void* ws_bwd[NRHIP_NGCF_WIDE_MAX_LAYERS]; size_t ws_bwd_bytes[NRHIP_NGCF_WIDE_MAX_LAYERS];
+  int n_users, n_nodes, n_layers, max_batch, dsum, splits;
+  int w[NRHIP_NGCF_WIDE_MAX_LAYERS + 1], wp[NRHIP_NGCF_WIDE_MAX_LAYERS + 1], off[NRHIP_NGCF_WIDE_MAX_LAYERS + 2];
+  float *E0p, *mE, *vE, *gE0, *Out, *dOut;
+  float* ego[NRHIP_NGCF_WIDE_MAX_LAYERS + 1];
+  float *S[NRHIP_NGCF_WIDE_MAX_LAYERS], *X2[NRHIP_NGCF_WIDE_MAX_LAYERS], *T1[NRHIP_NGCF_WIDE_MAX_LAYERS],
+      *T2[NRHIP_NGCF_WIDE_MAX_LAYERS];
+  uint8_t* mask[NRHIP_NGCF_WIDE_MAX_LAYERS];
+  float *W[NRHIP_NGCF_WIDE_MAX_LAYERS][4], *gW[NRHIP_NGCF_WIDE_MAX_LAYERS][4], *mW[NRHIP_NGCF_WIDE_MAX_LAYERS][4],
+      *vW[NRHIP_NGCF_WIDE_MAX_LAYERS][4];
+  float *dS[NRHIP_NGCF_WIDE_MAX_LAYERS], *dEd[NRHIP_NGCF_WIDE_MAX_LAYERS], *dEgo[NRHIP_NGCF_WIDE_MAX_LAYERS];
+  float *dT1, *dT2, *Y1, *Y2, *terms, *cs_ws;
+  size_t cs_ws_bytes;
+  int32_t* rows; uint8_t* flag;
+  void* gemm_ws; size_t gemm_ws_bytes;
+  float reg, keep;
+} nrhip_ngcf_wide_buffers;
+/* forward (NGCF.py:160-202): fills Out; masks_given != 0: mask[k] hold the dropout masks, else they are drawn
+ * from (seed, step) and stored there */
+int nrhip_ngcf_wide_forward(const nrhip_ngcf_wide_buffers* b, int masks_given, uint64_t seed, uint64_t step,
+                            void* stream);
+/* forward + BPR head (NGCF.py:91-110) + backward + dense TF-Adam on the ego table and every layer weight */
+int nrhip_ngcf_wide_step(const nrhip_ngcf_wide_buffers* b, const int32_t* d_users, const int32_t* d_pos,
+                         const int32_t* d_neg, int batch, const uint64_t* d_plan, int masks_given, uint64_t seed,
+                         uint64_t step, float alpha, float beta1, float beta2, float eps, float* d_loss2,
+                         void* stream);
+
 /* ---- Mult-VAE for any p_dim (conf/MultiVAE.properties:3: [200, 600], [200]; MultiVAE.py:46-135 builds q / p networks
  * of arbitrary depth and width) — width-generic pieces (csrc/vae_wide.hip) + a general fp32-MFMA GEMM (csrc/gemm.hip).
  * act: 0 tanh, 1 sigmoid, 2 relu, 3 identity, -1 none.  neurec_amd/vae_wide.py strings them into a step. */

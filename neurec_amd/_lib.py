@@ -75,6 +75,29 @@ class NGCFBuffers(C.Structure):
          ("n_layers", C.c_int), ("max_batch", C.c_int), ("reg", C.c_float), ("keep", C.c_float)]
 
 
+NGCF_WIDE_MAX_LAYERS = 8
+
+
+class NGCFWideBuffers(C.Structure):
+    """nrhip_ngcf_wide_buffers (include/neurec_hip.h)"""
+    _L = NGCF_WIDE_MAX_LAYERS
+    _fields_ = [(n, C.c_void_p) for n in ("plan", "indptr", "indices", "vals", "plan_t", "indptr_t", "indices_t",
+                                          "vals_t")] + \
+        [("ws_fwd", C.c_void_p * _L), ("ws_fwd_bytes", C.c_size_t * _L), ("ws_bwd", C.c_void_p * _L),
+         ("ws_bwd_bytes", C.c_size_t * _L)] + \
+        [(n, C.c_int) for n in ("n_users", "n_nodes", "n_layers", "max_batch", "dsum", "splits")] + \
+        [("w", C.c_int * (_L + 1)), ("wp", C.c_int * (_L + 1)), ("off", C.c_int * (_L + 2))] + \
+        [(n, C.c_void_p) for n in ("E0p", "mE", "vE", "gE0", "Out", "dOut")] + \
+        [("ego", C.c_void_p * (_L + 1)), ("S", C.c_void_p * _L), ("X2", C.c_void_p * _L), ("T1", C.c_void_p * _L),
+         ("T2", C.c_void_p * _L), ("mask", C.c_void_p * _L),
+         ("W", (C.c_void_p * 4) * _L), ("gW", (C.c_void_p * 4) * _L), ("mW", (C.c_void_p * 4) * _L),
+         ("vW", (C.c_void_p * 4) * _L),
+         ("dS", C.c_void_p * _L), ("dEd", C.c_void_p * _L), ("dEgo", C.c_void_p * _L)] + \
+        [(n, C.c_void_p) for n in ("dT1", "dT2", "Y1", "Y2", "terms", "cs_ws")] + \
+        [("cs_ws_bytes", C.c_size_t), ("rows", C.c_void_p), ("flag", C.c_void_p), ("gemm_ws", C.c_void_p),
+         ("gemm_ws_bytes", C.c_size_t), ("reg", C.c_float), ("keep", C.c_float)]
+
+
 # name -> argtypes; every function returns int status except where noted.
 SIGNATURES = {
     "nrhip_device_info": [C.POINTER(i32), C.POINTER(i32), psz, C.c_char_p, i32],
@@ -142,6 +165,8 @@ SIGNATURES = {
     "nrhip_gemm_kmajor": [p, i64, p, i64, i32, i32, i32, p, i64, i32, p, i32, i32, p, sz, p],
     "nrhip_gemm_f32": [p, i64, i32, p, i64, i32, i32, i32, i32, p, i64, i32, p, i32, i32, p, sz, p],
     "nrhip_transpose2d": [p, i64, i32, i32, p, i64, p],
+    "nrhip_ngcf_wide_forward": [C.POINTER(NGCFWideBuffers), i32, u64, u64, p],
+    "nrhip_ngcf_wide_step": [C.POINTER(NGCFWideBuffers), p, p, p, i32, p, i32, u64, u64, f32, f32, f32, f32, p, p],
     "nrhip_vae_bag_fwd": [p, p, p, i32, i32, p, p, i32, f32, p, u64, u64, p, p, p],
     "nrhip_act_bwd": [p, p, i64, i32, p, p],
     "nrhip_vae_sample": [p, i32, i32, p, f32, u64, u64, p, p, p, p],

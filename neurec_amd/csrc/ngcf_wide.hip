@@ -8,6 +8,7 @@
 // One wave per node row, lanes over the columns (<= 256): the row norm and the dot with the incoming gradient are
 // wave reductions.
 #include "nr_common.h"
+#include "neurec_hip.h"
 
 namespace {
 
@@ -182,3 +183,97 @@ int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The step as ONE native call: the launch sequence neurec_amd/ngcf_wide.py issued from Python.
+// ---------------------------------------------------------------------------------------------------------------
+static int ngcf_wide_check(const nrhip_ngcf_wide_buffers* b, const char* who) {
+  NR_REQUIRE(b && b->plan && b->plan_t && b->E0p && b->Out && b->dOut, NR_ERR_ARG, "%s: null buffers", who);
+  NR_REQUIRE(b->n_layers >= 0 && b->n_layers <= NRHIP_NGCF_WIDE_MAX_LAYERS, NR_ERR_UNSUPPORTED,
+             "%s: %d layers (at most %d)", who, b->n_layers, NRHIP_NGCF_WIDE_MAX_LAYERS);
+  NR_REQUIRE(b->dsum >= 1 && b->dsum <= 256, NR_ERR_UNSUPPORTED, "%s: concatenated width %d outside 1..256", who, b->dsum);
+  return NR_OK;
+}
+
+extern "C" int nrhip_ngcf_wide_forward(const nrhip_ngcf_wide_buffers* b, int masks_given, uint64_t seed, uint64_t step,
+                                       void* stream) {
+  NR_TRY(ngcf_wide_check(b, "ngcf_wide_forward"));
+  const int64_t N = b->n_nodes;
+  NR_TRY(nrhip_copy2d(b->E0p, b->wp[0], b->Out, b->dsum, N, b->w[0], stream));
+  for (int k = 0; k < b->n_layers; ++k) {
+    const int wi = b->w[k], wo = b->w[k + 1], pi = b->wp[k], po = b->wp[k + 1];
+    NR_TRY(nrhip_spmm_csr(b->plan, b->indptr, b->indices, b->vals, b->ego[k], pi, b->S[k], nullptr, nullptr, nullptr,
+                          b->ws_fwd[k], b->ws_fwd_bytes[k], stream));
+    NR_TRY(nrhip_ew_mul(b->ego[k], pi, b->S[k], pi, N, wi, b->X2[k], pi, stream));
+    NR_TRY(nrhip_gemm_f32(b->S[k], pi, 1, b->W[k][0], wo, 0, (int)N, wo, wi, b->T1[k], wo, 0, b->W[k][1], -1, 1,
+                          b->gemm_ws, 0, stream));
+    NR_TRY(nrhip_gemm_f32(b->X2[k], pi, 1, b->W[k][2], wo, 0, (int)N, wo, wi, b->T2[k], wo, 0, b->W[k][3], -1, 1,
+                          b->gemm_ws, 0, stream));
+    NR_TRY(nrhip_ngcf_act_fwd(b->T1[k], b->T2[k], wo, N, wo, po, b->keep, b->mask[k], masks_given, seed, step, k,
+                              b->ego[k + 1], po, b->Out + b->off[k + 1], b->dsum, stream));
+  }
+  return NR_OK;
+}
+
+extern "C" int nrhip_ngcf_wide_step(const nrhip_ngcf_wide_buffers* b, const int32_t* d_users, const int32_t* d_pos,
+                                    const int32_t* d_neg, int batch, const uint64_t* d_plan, int masks_given,
+                                    uint64_t seed, uint64_t step, float alpha, float beta1, float beta2, float eps,
+                                    float* d_loss2, void* stream) {
+  NR_TRY(ngcf_wide_check(b, "ngcf_wide_step"));
+  NR_REQUIRE(d_users && d_pos && d_neg && batch >= 1 && batch <= b->max_batch, NR_ERR_ARG,
+             "ngcf_wide_step: batch %d outside [1, %d]", batch, b->max_batch);
+  const int64_t N = b->n_nodes;
+  const int U = b->n_users, L = b->n_layers, dsum = b->dsum;
+  NR_TRY(nrhip_ngcf_wide_forward(b, masks_given, seed, step, stream));
+  NR_TRY(nrhip_lightgcn_mark_batch(d_users, d_pos, d_neg, batch, U, b->rows, b->flag, stream));
+  NR_TRY(nrhip_bpr_mf_grad(b->Out, b->Out + (int64_t)U * dsum, dsum, U, d_users, d_pos, d_neg, batch, b->reg, b->dOut,
+                           b->dOut + (int64_t)U * dsum, b->terms, d_loss2, d_plan, stream));
+  const float* dego = nullptr;
+  int dego_ld = 0;
+  for (int k = L - 1; k >= 0; --k) {
+    const int wi = b->w[k], wo = b->w[k + 1], pi = b->wp[k], po = b->wp[k + 1];
+    NR_TRY(nrhip_ngcf_act_bwd(b->dOut + b->off[k + 1], dsum, dego, po, b->ego[k + 1], po, b->T1[k], b->T2[k], wo,
+                              b->mask[k], N, wo, b->keep, b->dT1, b->dT2, stream));
+    // weight gradients: contractions over the N rows, both operands k-major as stored
+    NR_TRY(nrhip_gemm_f32(b->S[k], pi, 0, b->dT1, wo, 0, wi, wo, (int)N, b->gW[k][0], wo, 0, nullptr, -1, b->splits,
+                          b->gemm_ws, b->gemm_ws_bytes, stream));
+    NR_TRY(nrhip_gemm_f32(b->X2[k], pi, 0, b->dT2, wo, 0, wi, wo, (int)N, b->gW[k][2], wo, 0, nullptr, -1, b->splits,
+                          b->gemm_ws, b->gemm_ws_bytes, stream));
+    NR_TRY(nrhip_colsum_rows(b->dT1, wo, (int)N, wo, b->gW[k][1], b->cs_ws, b->cs_ws_bytes, stream));
+    NR_TRY(nrhip_colsum_rows(b->dT2, wo, (int)N, wo, b->gW[k][3], b->cs_ws, b->cs_ws_bytes, stream));
+    // Y1 = dT1 W_gc^T, Y2 = dT2 W_bi^T: both operands k-minor as stored
+    NR_TRY(nrhip_gemm_f32(b->dT1, wo, 1, b->W[k][0], wo, 1, (int)N, wi, wo, b->Y1, wi, 0, nullptr, -1, 1, b->gemm_ws, 0,
+                          stream));
+    NR_TRY(nrhip_gemm_f32(b->dT2, wo, 1, b->W[k][2], wo, 1, (int)N, wi, wo, b->Y2, wi, 0, nullptr, -1, 1, b->gemm_ws, 0,
+                          stream));
+    NR_TRY(nrhip_ngcf_mix_bwd(b->Y1, b->Y2, wi, b->ego[k], b->S[k], pi, N, wi, pi, b->dS[k], b->dEd[k], stream));
+    NR_TRY(nrhip_spmm_csr(b->plan_t, b->indptr_t, b->indices_t, b->vals_t, b->dS[k], pi, b->dEgo[k], b->dEd[k], nullptr,
+                          nullptr, b->ws_bwd[k], b->ws_bwd_bytes[k], stream));       // dE_k = dBi .* S + A_hat^T dS
+    dego = b->dEgo[k];
+    dego_ld = pi;
+  }
+  const int w0 = b->w[0], p0 = b->wp[0];
+  if (!dego) NR_TRY(nrhip_copy2d(b->dOut, dsum, b->gE0, p0, N, w0, stream));
+  else NR_TRY(nrhip_add2d(b->dOut, dsum, dego, dego_ld, b->gE0, p0, N, w0, stream));
+  float* vars[1 + 4 * NRHIP_NGCF_WIDE_MAX_LAYERS];
+  float* ms[1 + 4 * NRHIP_NGCF_WIDE_MAX_LAYERS];
+  float* vs[1 + 4 * NRHIP_NGCF_WIDE_MAX_LAYERS];
+  float* gs[1 + 4 * NRHIP_NGCF_WIDE_MAX_LAYERS];
+  int64_t sizes[1 + 4 * NRHIP_NGCF_WIDE_MAX_LAYERS];
+  int32_t clear[1 + 4 * NRHIP_NGCF_WIDE_MAX_LAYERS];
+  int n = 0;
+  vars[n] = b->E0p; ms[n] = b->mE; vs[n] = b->vE; gs[n] = b->gE0; sizes[n] = N * p0; clear[n] = 0; ++n;
+  for (int k = 0; k < L; ++k)
+    for (int j = 0; j < 4; ++j) {
+      vars[n] = b->W[k][j]; ms[n] = b->mW[k][j]; vs[n] = b->vW[k][j]; gs[n] = b->gW[k][j];
+      sizes[n] = (j % 2) ? b->w[k + 1] : (int64_t)b->w[k] * b->w[k + 1];
+      clear[n] = 0;
+      ++n;
+    }
+  for (int lo = 0; lo < n; lo += 32) {
+    const int m = n - lo < 32 ? n - lo : 32;
+    NR_TRY(nrhip_adam_dense_tf_multi(m, vars + lo, ms + lo, vs + lo, gs + lo, sizes + lo, clear + lo, alpha, beta1, beta2,
+                                     eps, stream));
+  }
+  return nrhip_rows_clear(b->rows, 3 * batch, dsum, b->dOut, nullptr, nullptr, nullptr, b->flag, stream);
+}

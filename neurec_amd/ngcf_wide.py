@@ -20,6 +20,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from . import _lib
 from . import engine as E
 from ._lib import call
 from .engine import _ptr, _stream
@@ -83,10 +84,46 @@ class NGCFWideEngine:
         self.flag = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.max_batch = max_batch
         self.cs_ws = z(((N + 511) // 512) * wmax)                   # chunk sums of the bias gradients
-        self.splits = 768                                           # cuts of the N-long contractions of dW
+        self.splits = max(1, min(768, (N + 255) // 256))             # cuts of the N-long contractions of dW: from N
         nbytes = C.c_size_t(0)
         call("nrhip_gemm_workspace_bytes", wmax, wmax, self.splits, C.byref(nbytes))
         self.ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
+        self._native = self._native_buffers() if self.L <= _lib.NGCF_WIDE_MAX_LAYERS else None
+
+    def _native_buffers(self):
+        """nrhip_ngcf_wide_buffers: every pointer the native step needs, recorded once (the buffers never move)"""
+        b = _lib.NGCFWideBuffers()
+        ptr = lambda t: t.data_ptr()
+        for A, sfx, ws_name in ((self.A, "", "ws_fwd"), (self.At, "_t", "ws_bwd")):
+            setattr(b, "plan" + sfx, A.plan.value)
+            setattr(b, "indptr" + sfx, ptr(A.indptr))
+            setattr(b, "indices" + sfx, ptr(A.indices))
+            setattr(b, "vals" + sfx, ptr(A.vals))
+            for k in range(self.L):
+                A.ensure_schedule(self.wp[k])                        # the lane-group schedule of this width, attached once
+                ws = A._workspace(self.wp[k])
+                getattr(b, ws_name)[k] = ptr(ws)
+                getattr(b, ws_name + "_bytes")[k] = ws.numel()
+        b.n_users, b.n_nodes, b.n_layers, b.max_batch, b.dsum, b.splits = \
+            self.n_users, self.N, self.L, self.max_batch, self.dsum, self.splits
+        for k in range(self.L + 1):
+            b.w[k], b.wp[k] = self.w[k], self.wp[k]
+            b.ego[k] = ptr(self.ego[k])
+        for k in range(self.L + 2):
+            b.off[k] = int(self.off[k])
+        for name in ("E0p", "mE", "vE", "gE0", "Out", "dOut", "dT1", "dT2", "Y1", "Y2", "terms", "cs_ws", "rows", "flag"):
+            setattr(b, name, ptr(getattr(self, name)))
+        b.cs_ws_bytes = self.cs_ws.numel() * 4
+        b.gemm_ws, b.gemm_ws_bytes = ptr(self.ws), self.ws.numel()
+        for k in range(self.L):
+            b.S[k], b.X2[k], b.T1[k], b.T2[k], b.mask[k] = (ptr(x[k]) for x in (self.S, self.X2, self.T1, self.T2, self.mask))
+            pi = self.wp[k]
+            b.dS[k], b.dEd[k] = ptr(self._buf(self.dS, pi)), ptr(self._buf(self.dEd, pi))
+            b.dEgo[k] = ptr(self._buf(self.dEgo[k % 2], pi))
+            for j in range(4):
+                b.W[k][j], b.gW[k][j], b.mW[k][j], b.vW[k][j] = (ptr(x[k][j]) for x in (self.W, self.gW, self.mW, self.vW))
+        b.reg, b.keep = self.reg, self.keep
+        return b
 
     # the trainable ego table as the caller sees it (real width)
     @property
@@ -104,7 +141,19 @@ class NGCFWideEngine:
     def forward(self, masks=None):
         """Fills self.Out = concat(E0, out_1 .. out_L) (NGCF.py:160-202).  masks: optional list of uint8 [N][w_k]
         device tensors (tests); otherwise a fresh dropout draw per call — evaluation included, as in the reference
-        (NGCF.py:193 has no training flag)."""
+        (NGCF.py:193 has no training flag).  One native call (nrhip_ngcf_wide_forward); forward_reference is the same
+        launch sequence issued from Python."""
+        if self._native is None:
+            return self.forward_reference(masks)
+        if masks is not None:
+            for k in range(self.L):
+                self.mask[k].copy_(masks[k])
+        call("nrhip_ngcf_wide_forward", C.byref(self._native), 1 if masks is not None else 0,
+             C.c_uint64(self.seed & (2**64 - 1)), C.c_uint64(self.t), _stream())
+        self.t += 1
+        return self.Out
+
+    def forward_reference(self, masks=None):
         N = self.N
         E.copy2d(self.E0, self.Out[:, :self.w[0]])
         for k in range(self.L):
@@ -130,10 +179,29 @@ class NGCFWideEngine:
         return out[:self.n_users], out[self.n_users:]
 
     def step(self, users, pos, neg, loss_out, masks=None, plan=None):
+        """One optimiser step: ONE native call (nrhip_ngcf_wide_step enqueues the ~25 + 15 L launches; issued from
+        Python they cost more host time than GPU time).  step_reference spells the sequence out."""
+        if self._native is None:
+            return self.step_reference(users, pos, neg, loss_out, masks, plan)
+        B = users.numel()
+        if B > self.max_batch:
+            raise ValueError("batch larger than max_batch")
+        if masks is not None:
+            for k in range(self.L):
+                self.mask[k].copy_(masks[k])
+        st = self.adam
+        call("nrhip_ngcf_wide_step", C.byref(self._native), _ptr(users, torch.int32), _ptr(pos, torch.int32),
+             _ptr(neg, torch.int32), B, _ptr(plan, torch.int64, allow_none=True), 1 if masks is not None else 0,
+             C.c_uint64(self.seed & (2**64 - 1)), C.c_uint64(self.t), st.alpha(), st.beta1, st.beta2, st.eps,
+             _ptr(loss_out, torch.float32, allow_none=True), _stream())
+        self.t += 1
+        self.adam.advance()
+
+    def step_reference(self, users, pos, neg, loss_out, masks=None, plan=None):
         B, N, U = users.numel(), self.N, self.n_users
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
-        self.forward(masks)
+        self.forward_reference(masks)
         rows = self.rows[:3 * B]
         E.lightgcn_mark_batch(users, pos, neg, U, rows, self.flag)
         E.bpr_mf_grad(self.Out[:U], self.Out[U:], users, pos, neg, self.reg, self.dOut[:U], self.dOut[U:], self.terms,

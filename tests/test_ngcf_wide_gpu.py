@@ -88,3 +88,34 @@ def test_score_gemm_wide_is_the_k_ascending_chain():
     np.testing.assert_array_equal(got, native.score_gemm(P, users, Q))
     got = gemm(_dev(P[:150]), None).cpu().numpy()[:, :1000]
     np.testing.assert_array_equal(got, native.score_gemm(P[:150], None, Q))
+
+
+def test_native_wide_step_is_the_python_launch_sequence_bit_for_bit():
+    """nrhip_ngcf_wide_step / _forward (one native call each) against step_reference / forward_reference (the same
+    launches issued from Python): identical tables, weights, losses and device-drawn dropout masks."""
+    import torch
+    from neurec_amd.graph import ngcf_adjacency, transpose_csr
+    from neurec_amd.ngcf_wide import NGCFWideEngine
+    g = load_golden("tfgraph_ngcf_wide_24_32_8")
+    h = json.loads(str(g["hyper"]))
+    L = len(h["layer_size"])
+    U, I = int(g["n_users"]), int(g["n_items"])
+    R = sp.csr_matrix((g["train_data"], g["train_indices"], g["train_indptr"]), shape=(U, I))
+    A = ngcf_adjacency(R, "norm")
+    W0 = [tuple(g["%s_%d_0" % (nm, k)] for nm in NGCF_W) for k in range(L)]
+    mk = lambda: NGCFWideEngine(A, transpose_csr(A), U, I, g["E0"], W0, h["learning_rate"], 1e-3, 0.1, 128)
+    a, b = mk(), mk()
+    assert a._native is not None
+    la, lb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    for s, (u, p, n) in enumerate(_batches(g)):
+        masks = [_dev(g["masks_%d" % k][s]) for k in range(L)] if s % 2 == 0 else None      # given / drawn on the device
+        a.step(_dev(u), _dev(p), _dev(n), la, masks=masks)
+        b.step_reference(_dev(u), _dev(p), _dev(n), lb, masks=masks)
+        assert torch.equal(la, lb)
+        for k in range(L):
+            assert torch.equal(a.mask[k], b.mask[k])
+    assert torch.equal(a.E0p, b.E0p) and torch.equal(a.mE, b.mE)
+    for k in range(L):
+        for j in range(4):
+            assert torch.equal(a.W[k][j], b.W[k][j])
+    assert torch.equal(a.forward(), b.forward_reference())
