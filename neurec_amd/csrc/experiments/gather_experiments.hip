@@ -573,3 +573,52 @@ extern "C" int nrhip_exp_grid_barrier(unsigned* d_cnt, int n_wg, int iters, int 
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Micro-benchmark (scripts/exp_mfma_valu_overlap.py): do fp32 MFMAs of one wave and VALU work of ANOTHER wave of the
+// same SIMD overlap?  (csrc/vae_fused.hip: MFMA time and exp time ADD.)  A workgroup = 8 waves = 2 per SIMD; waves
+// 0-3 take role A, waves 4-7 role B:   role 1 = `iters` x 16 dependent v_mfma_f32_32x32x2_f32 (one accumulator);
+// role 2 = `iters` x 256 dependent v_fma_f32; role 3 = `iters` x 64 dependent v_exp_f32 (+ 1 fma each); role 0 = idle.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float exp_role_work(int role, int iters, float seed) {
+  float r = seed;
+  if (role == 1) {
+    exp_f32x16 c = {0};
+    float a = seed, b = seed * 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += c[i];
+  } else if (role == 2) {
+    float x = seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 256; ++s) x = __builtin_fmaf(x, 1.0000001f, 1e-9f);
+    }
+    r = x;
+  } else if (role == 3) {
+    float x = seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 64; ++s) x = __builtin_fmaf(__builtin_amdgcn_exp2f(x), 1e-3f, -0.5f);
+    }
+    r = x;
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(512, 1) void exp_overlap_kernel(int role_a, int role_b, int iters, float* out) {
+  const int wave = threadIdx.x >> 6;
+  const float r = exp_role_work(wave < 4 ? role_a : role_b, iters, 1.0f + threadIdx.x * 1e-4f);
+  if (r == 12345.678f) out[blockIdx.x * 512 + threadIdx.x] = r;
+}
+}  // namespace
+
+extern "C" int nrhip_exp_overlap(int blocks, int role_a, int role_b, int iters, float* d_out, void* stream) {
+  hipLaunchKernelGGL(exp_overlap_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, role_a, role_b, iters, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
