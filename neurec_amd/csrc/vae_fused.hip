@@ -63,7 +63,7 @@ __device__ __forceinline__ float exp_nonpos(float x) {
   return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
 }
 
-// Σ exp of pass 1: v_exp_f32 on one fma, e^(x - ref) = 2^(x·log2e - ref·log2e).  The single rounding of the
+// e^(x - ref) = 2^(x·log2e - ref·log2e): v_exp_f32 on one fma (both passes).  Pass 1's Σ exp:  The single rounding of the
 // exponent costs a term a relative error of 6e-8·|x - ref|·log2e — weighted by the term itself, |t|·e^t <= 1/e, so
 // the SUM (>= 1: the maximum's own term) keeps a relative error under 1e-7 and lse an absolute one under 1e-7; the
 // full-precision form above costs 11 instructions per logit against 2, and MFMA and VALU time add up here.
@@ -78,6 +78,8 @@ struct FusedArgs {
   const float* bp1;       // [cols]
   const uint32_t* bitmap; // [batch][words]   positives of every batch row (pass 2)
   int batch, cols, h, words, n_tiles, tiles_per_wg, rows_pad;
+  int main_tiles, n_rem, groups_per_tile;   // whole tiles dealt to workgroups; left-over tiles cut by rows (see pass 2)
+  float* xpart;                             // [n_rem·groups_per_tile][kScratch] partial dW tiles of the left-over tiles
   // pass 1 out: per-workgroup partial statistics, SoA [wg][2][rows_pad]
   float* pstat;
   // pass 2 in
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 2) void vae_dec_stats_kernel(const FusedA
   const int row = (blockIdx.y * kWaves + wave) * kT + j32;
   const bool active = row - j32 < a.rows_pad;                  // wave-uniform
   const int t_begin = blockIdx.x * a.tiles_per_wg;
-  const int t_end = min(a.n_tiles, t_begin + a.tiles_per_wg);
+  const int t_end = min(a.main_tiles, t_begin + a.tiles_per_wg);
   float gA[17];                                                // logits' B operand: lane = row, k = 2·step + hlf
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
@@ -186,43 +188,51 @@ __global__ __launch_bounds__(kThreads, 2) void vae_dec_stats_kernel(const FusedA
   }
   gA[16] = hlf == 0 ? 1.0f : 0.f;                              // step 16: bias · 1
   float mx = -INFINITY, sm = 0.f;
+  auto fold_tile = [&](const float* W, int t) {
+    float wA[17];                                              // A operand: lane = item, k = 2·step + hlf
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wA[s] = W[j32 * kLd + 2 * s + hlf];
+    wA[16] = hlf == 0 ? W[j32 * kLd + 32] : 0.f;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 17; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[s], gA[s], c, 0, 0, 0);
+    // c[j] = logit(row, item 32·t + c_row(j, hlf)), bias included
+    if (MODE == 2 && row < a.batch) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int it = t * kT + c_row(j, hlf);
+        if (it < a.cols) a.dbg_logits[(int64_t)row * a.cols + it] = c[j];
+      }
+    }
+    float m16 = c[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) m16 = fmaxf(m16, c[j]);
+    const float mnew = fmaxf(mx, m16);
+    const float ref = mnew == -INFINITY ? 0.f : mnew;
+    const float nref = -ref * kLog2e;
+    float s16 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s16 += exp2_scaled(__builtin_fmaf(c[j], kLog2e, nref));
+    sm = sm * exp_nonpos(mx - ref) + s16;
+    mx = mnew;
+  };
   for (int g0 = t_begin; g0 < t_end; g0 += kGroup1) {
     const int n = min(kGroup1, t_end - g0);
     __syncthreads();                                           // the previous group's readers are done
     stage_w_tiles<kGroup1, 16>(a, g0, n, Wt, tid);
     __syncthreads();
     if (!active) continue;
-    for (int tt = 0; tt < n; ++tt) {
-      const float* W = Wt + tt * kScratch;
-      float wA[17];                                            // A operand: lane = item, k = 2·step + hlf
-#pragma unroll
-      for (int s = 0; s < 16; ++s) wA[s] = W[j32 * kLd + 2 * s + hlf];
-      wA[16] = hlf == 0 ? W[j32 * kLd + 32] : 0.f;
-      f32x16 c;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 17; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[s], gA[s], c, 0, 0, 0);
-      // c[j] = logit(row, item 32·t + c_row(j, hlf)), bias included
-      if (MODE == 2 && row < a.batch) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int it = (g0 + tt) * kT + c_row(j, hlf);
-          if (it < a.cols) a.dbg_logits[(int64_t)row * a.cols + it] = c[j];
-        }
-      }
-      float m16 = c[0];
-#pragma unroll
-      for (int j = 1; j < 16; ++j) m16 = fmaxf(m16, c[j]);
-      const float mnew = fmaxf(mx, m16);
-      const float ref = mnew == -INFINITY ? 0.f : mnew;
-      const float nref = -ref * kLog2e;
-      float s16 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s16 += exp2_scaled(__builtin_fmaf(c[j], kLog2e, nref));
-      sm = sm * exp_nonpos(mx - ref) + s16;
-      mx = mnew;
-    }
+    for (int tt = 0; tt < n; ++tt) fold_tile(Wt + tt * kScratch, g0 + tt);
+  }
+  // the left-over tiles (see pass 2): the (tile, this workgroup's 8 row tiles) groups dealt round robin over x
+  for (int j = 0; j < a.n_rem; ++j) {
+    if ((j * (int)gridDim.y + (int)blockIdx.y) % (int)gridDim.x != (int)blockIdx.x) continue;
+    __syncthreads();
+    stage_w_tiles<kGroup1, 16>(a, a.main_tiles + j, 1, Wt, tid);
+    __syncthreads();
+    if (active) fold_tile(Wt, a.main_tiles + j);
   }
   if (!active) return;
   const float omx = __shfl_xor(mx, 32, NR_WAVE), osm = __shfl_xor(sm, 32, NR_WAVE);
@@ -239,6 +249,13 @@ __global__ __launch_bounds__(kThreads, 2) void vae_dec_stats_kernel(const FusedA
 // ---------------------------------------------------------------------------------------------------------------
 // Pass 2: the gradients.  8 waves x RT row tiles = a chunk of 256·RT rows; one barrier per item tile (the exchange
 // of the waves' partial dW tiles).
+//
+// Tail.  I = 40,981 is 1,280.7 item tiles = 5.003 per CU: with whole tiles dealt to whole workgroups every one ran
+// SIX tile steps (the ceiling), a sixth of the kernel for 0.06 % of the work.  So every workgroup takes
+// floor(n_tiles / n_wg) tiles and the R tiles left over are cut by ROWS into groups of 8 row tiles (one per wave) dealt
+// round robin: a group is one wave-tile per wave, its dW partial goes to a small buffer (xpart) that
+// vae_dec_xreduce (the last blocks of the dg1 reduce launch) adds over the groups of a tile, in row order.  dg1 needs nothing extra: the group's
+// contribution lands in the wave's accumulators like any other tile's.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kGroup2 = 6;
 template <int RT>
@@ -250,9 +267,9 @@ __global__ __launch_bounds__(kThreads, 1) void vae_dec_grad_kernel(const FusedAr
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int hlf = lane >> 5, j32 = lane & 31;
   const int t_begin = blockIdx.x * a.tiles_per_wg;
-  const int t_end = min(a.n_tiles, t_begin + a.tiles_per_wg);
-  if (t_begin >= t_end) return;
+  const int t_end = min(a.main_tiles, t_begin + a.tiles_per_wg);
   constexpr int kChunk = RT * kWaves * kT;
+  int nbar = 0;                                      // tile steps so far: the parity of the scratch buffers
 
   for (int chunk0 = 0; chunk0 < a.batch; chunk0 += kChunk) {
     __syncthreads();                                 // the previous chunk's readers of gS are done
@@ -271,116 +288,167 @@ __global__ __launch_bounds__(kThreads, 1) void vae_dec_grad_kernel(const FusedAr
     }
     __syncthreads();
 
-    // loop-invariant per wave: the logits' B operand of its row tiles (lane = row, k = 2·step + hlf; step 16 = 1 | 0)
-    float gA[RT][17];
+    // per wave and row tile: its rows' statistics and the dg1 accumulators (the logits' B operand — lane = row,
+    // k = 2·step + hlf — is read from gS at every tile: 17 LDS reads against 34 registers held for the whole kernel,
+    // which spilled; measured 54.8 us against 57.2 at five tiles)
     int row[RT];
-    float lse[RT], nb[RT], invb[RT];
-    uint32_t word[RT];
+    float nlse[RT], nbi[RT], invb[RT];
     f32x16 c1[RT];
+    const float one_or_zero = hlf == 0 ? 1.0f : 0.f;             // step 16: bias · 1
 #pragma unroll
     for (int q = 0; q < RT; ++q) {
       const int lr0 = (wave + kWaves * q) * kT;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) gA[q][s] = gS[(lr0 + j32) * kLd + 2 * s + hlf];
-      gA[q][16] = hlf == 0 ? 1.0f : 0.f;
       row[q] = chunk0 + lr0 + j32;
       const float2 st = a.stat[min(row[q], a.batch - 1)];
-      lse[q] = st.x; nb[q] = st.y;
+      nlse[q] = -st.x * kLog2e;
       invb[q] = row[q] < a.batch ? a.inv_batch : 0.f;           // rows beyond the batch: G = 0
-      word[q] = a.bitmap[(int64_t)min(row[q], a.batch - 1) * a.words + t_begin];
+      nbi[q] = st.y * invb[q];
 #pragma unroll
       for (int r = 0; r < 16; ++r) c1[q][r] = 0.f;
     }
 
-    for (int g0 = t_begin; g0 < t_end; g0 += kGroup2) {
-      const int n = min(kGroup2, t_end - g0);
-      if (g0 != t_begin) __syncthreads();            // the previous group's W readers are done
-      stage_w_tiles<kGroup2, 4>(a, g0, n, Wt, tid);
-      __syncthreads();
-      for (int tt = 0; tt < n; ++tt) {
-        const int t = g0 + tt, par = (t - t_begin) & 1;
-        const float* W = Wt + tt * kScratch;
-        float* my = scratch + (par * kWaves + wave) * kScratch;
-        uint32_t wnext[RT];                          // the next tile's positives: a tile ahead of their use
+    // one tile step: logits -> G -> dg1 / dW MFMAs of the row tiles `only` (-1: all RT), the 8 waves' partial dW tiles
+    // exchanged behind ONE barrier and added in wave order into dWp1 / dbp1 (xdst == NULL) or into xdst
+    auto tile_step = [&](const float* W, int t, int only, const uint32_t (&word)[RT], float* xdst) {
+      const int par = nbar & 1;
+      ++nbar;
+      float* my = scratch + (par * kWaves + wave) * kScratch;
+      float wA[17];                                  // logits' A operand: lane = item, k = 2·step + hlf
 #pragma unroll
-        for (int q = 0; q < RT; ++q)
-          wnext[q] = a.bitmap[(int64_t)min(row[q], a.batch - 1) * a.words + min(t + 1, t_end - 1)];
-        float wA[17];                                // logits' A operand: lane = item, k = 2·step + hlf
+      for (int s = 0; s < 16; ++s) wA[s] = W[j32 * kLd + 2 * s + hlf];
+      wA[16] = hlf == 0 ? W[j32 * kLd + 32] : 0.f;
+      f32x16 c2;
+      float cs = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wA[s] = W[j32 * kLd + 2 * s + hlf];
-        wA[16] = hlf == 0 ? W[j32 * kLd + 32] : 0.f;
-        f32x16 c2;
-        float cs = 0.f;
+      for (int r = 0; r < 16; ++r) c2[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+      for (int q = 0; q < RT; ++q) {
+        if (only >= 0 && only != q) continue;         // workgroup-uniform
+        const int lr0 = (wave + kWaves * q) * kT;
+        f32x16 c;
 #pragma unroll
-        for (int q = 0; q < RT; ++q) {
-          f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        for (int s = 0; s < 16; ++s)
+          c = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[s], gS[(lr0 + j32) * kLd + 2 * s + hlf], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[16], one_or_zero, c, 0, 0, 0);
+        // c[j] = logit(row = lane & 31, item = 32·t + c_row(j, hlf)), bias included.
+        // G = (softmax · n_b − x) / B with softmax = 2^(logit·log2e − lse·log2e): one fma + v_exp_f32 per logit.
+        // (MFMA time and VALU time ADD on this part — profiles/r04_exp_mfma_valu_overlap.txt — so the 11-instruction
+        // full-precision exp cost a tenth of the kernel; the single rounding of the exponent leaves a relative
+        // error of 6e-8·|l|·log2e in a probability e^l: 2e-7 at l = -2, and the elements with large |l| are the
+        // ones that carry no gradient.)  g = softmax·(n_b/B) − x/B as ONE fma: the addend is -1/B where the
+        // positives' bit is set (the bit field sign-extended to a mask over the bits of -1/B), else 0
+        float g[16];
 #pragma unroll
-          for (int s = 0; s < 17; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[s], gA[q][s], c, 0, 0, 0);
-          // c[j] = logit(row = lane & 31, item = 32·t + c_row(j, hlf)), bias included
-          float g[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float bit = (float)((word[q] >> c_row(j, hlf)) & 1u);
-            const float l = fminf(c[j] - lse[q], 0.f);              // log-softmax (<= 0 up to the rounding of lse)
-            g[j] = (exp_nonpos(l) * nb[q] - bit) * invb[q];
-          }
-          // dg1[row][col] += Σ_item G[row][item] · W[item][col]: register j IS contraction step j
-#pragma unroll
-          for (int s = 0; s < 16; ++s)
-            c1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], W[c_row(s, hlf) * kLd + j32], c1[q], 0, 0, 0);
-          // transpose through the wave's LDS tile: lanes over items, rows become the contraction index
-#pragma unroll
-          for (int j = 0; j < 16; ++j) my[c_row(j, hlf) * kLd + j32] = g[j];
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          float gt[16];
-#pragma unroll
-          for (int s = 0; s < 16; ++s) gt[s] = my[j32 * kLd + 2 * s + hlf];
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          const int lr0 = (wave + kWaves * q) * kT;
-#pragma unroll
-          for (int s = 0; s < 16; ++s) {
-            cs += gt[s];
-            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[s], gS[(lr0 + 2 * s + hlf) * kLd + j32], c2, 0, 0, 0);
-          }
-          word[q] = wnext[q];
+        for (int j = 0; j < 16; ++j) {
+          const int m = __builtin_amdgcn_sbfe((int)word[q], c_row(j, hlf), 1);            // 0 or -1
+          const float sub = __int_as_float(m & __float_as_int(-invb[q]));
+          const float pr = exp2_scaled(__builtin_fmaf(c[j], kLog2e, nlse[q]));
+          g[j] = __builtin_fmaf(pr, nbi[q], sub);
         }
-        // this wave's partial dW tile + column sums
+        // dg1[row][col] += Σ_item G[row][item] · W[item][col]: register j IS contraction step j
 #pragma unroll
-        for (int r = 0; r < 16; ++r) my[r * NR_WAVE + lane] = c2[r];
-        cs += __shfl_xor(cs, 32, NR_WAVE);
-        if (hlf == 0) my[16 * NR_WAVE + j32] = cs;
-        __syncthreads();
-        // the 8 partial tiles added in wave order — every wave takes two of the 16 accumulator registers (the
-        // scratch of this parity is next written two tiles on, behind the next barrier); later chunks add to
-        // what is there
-        const float* base = scratch + par * kWaves * kScratch;
-        const int item0 = t * kT;
+        for (int s = 0; s < 16; ++s)
+          c1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], W[c_row(s, hlf) * kLd + j32], c1[q], 0, 0, 0);
+        // transpose through the wave's LDS tile: lanes over items, rows become the contraction index
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int r = 2 * wave + rr;
-          float sum = 0.f;
+        for (int j = 0; j < 16; ++j) my[c_row(j, hlf) * kLd + j32] = g[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float gt[16];
 #pragma unroll
-          for (int w = 0; w < kWaves; ++w) sum += base[w * kScratch + r * NR_WAVE + lane];
+        for (int s = 0; s < 16; ++s) gt[s] = my[j32 * kLd + 2 * s + hlf];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          cs += gt[s];
+          c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[s], gS[(lr0 + 2 * s + hlf) * kLd + j32], c2, 0, 0, 0);
+        }
+      }
+      // this wave's partial dW tile + column sums
+#pragma unroll
+      for (int r = 0; r < 16; ++r) my[r * NR_WAVE + lane] = c2[r];
+      cs += __shfl_xor(cs, 32, NR_WAVE);
+      if (hlf == 0) my[16 * NR_WAVE + j32] = cs;
+      __syncthreads();
+      // the 8 partial tiles added in wave order — every wave takes two of the 16 accumulator registers (the scratch
+      // of this parity is next written two tile steps on, behind the next barrier)
+      const float* base = scratch + par * kWaves * kScratch;
+      const int item0 = t * kT;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + rr;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) sum += base[w * kScratch + r * NR_WAVE + lane];
+        if (xdst) xdst[r * NR_WAVE + lane] = sum;
+        else {
           const int it = item0 + c_row(r, hlf);
           if (it < a.cols && j32 < a.h) {
             float* o = a.dWp1 + (int64_t)it * a.h + j32;
-            *o = chunk0 ? *o + sum : sum;
+            *o = chunk0 ? *o + sum : sum;            // later chunks add to what is there
           }
         }
-        if (wave == 0 && hlf == 0 && item0 + j32 < a.cols) {
-          float sum = 0.f;
+      }
+      if (wave == 0 && hlf == 0) {
+        float sum = 0.f;
 #pragma unroll
-          for (int w = 0; w < kWaves; ++w) sum += base[w * kScratch + 16 * NR_WAVE + j32];
+        for (int w = 0; w < kWaves; ++w) sum += base[w * kScratch + 16 * NR_WAVE + j32];
+        if (xdst) xdst[16 * NR_WAVE + j32] = sum;
+        else if (item0 + j32 < a.cols) {
           float* o = a.dbp1 + item0 + j32;
           *o = chunk0 ? *o + sum : sum;
         }
       }
+    };
+
+    // the workgroup's steps of this chunk: its whole tiles (W staged kGroup2 tiles at a time), then its share of the
+    // left-over tiles — groups (tile, 8 row tiles) dealt round robin, those whose rows lie in this chunk.  ONE loop
+    // (one inlined copy of the tile step: two copies cost 40 spilled registers).
+    const int n_main = max(t_end - t_begin, 0);
+    int n_extra = 0;
+    for (int gi = blockIdx.x; gi < a.n_rem * a.groups_per_tile; gi += gridDim.x)
+      n_extra += ((gi % a.groups_per_tile) * kWaves * kT / kChunk == chunk0 / kChunk) ? 1 : 0;
+    int gi_next = blockIdx.x;                        // cursor over this workgroup's groups
+    auto next_group = [&]() {                        // the next group of this chunk (workgroup-uniform)
+      while ((gi_next % a.groups_per_tile) * kWaves * kT / kChunk != chunk0 / kChunk) gi_next += gridDim.x;
+      const int gi = gi_next;
+      gi_next += gridDim.x;
+      return gi;
+    };
+    int gi_cur = n_main == 0 && n_extra > 0 ? next_group() : -1;
+    auto tile_of = [&](int it, int gi) { return it < n_main ? t_begin + it : a.main_tiles + gi / a.groups_per_tile; };
+    uint32_t word[RT];
+    if (n_main + n_extra > 0) {
+      const int t0 = tile_of(0, gi_cur);
+#pragma unroll
+      for (int q = 0; q < RT; ++q) word[q] = a.bitmap[(int64_t)min(row[q], a.batch - 1) * a.words + t0];
+    }
+    for (int it = 0; it < n_main + n_extra; ++it) {
+      const bool main_step = it < n_main;
+      const int tt = main_step ? it % kGroup2 : 0;
+      if (!main_step || tt == 0) {
+        __syncthreads();                             // the previous group's W readers are done
+        if (main_step) stage_w_tiles<kGroup2, 4>(a, t_begin + it, min(kGroup2, n_main - it), Wt, tid);
+        else stage_w_tiles<kGroup2, 4>(a, tile_of(it, gi_cur), 1, Wt, tid);
+        __syncthreads();
+      }
+      const int t = tile_of(it, gi_cur);
+      const int only = main_step ? -1 : ((gi_cur % a.groups_per_tile)) % RT;
+      float* xdst = main_step ? nullptr : a.xpart + (int64_t)gi_cur * kScratch;
+      // the next step's positives: a tile ahead of their use
+      int gi_after = gi_cur;
+      if (it + 1 >= n_main && it + 1 < n_main + n_extra) gi_after = next_group();
+      uint32_t wnext[RT];
+      const int t_after = it + 1 < n_main + n_extra ? tile_of(it + 1, gi_after) : t;
+#pragma unroll
+      for (int q = 0; q < RT; ++q) wnext[q] = a.bitmap[(int64_t)min(row[q], a.batch - 1) * a.words + t_after];
+      tile_step(Wt + tt * kScratch, t, only, word, xdst);
+#pragma unroll
+      for (int q = 0; q < RT; ++q) word[q] = wnext[q];
+      gi_cur = gi_after;
     }
 
     // the chunk's rows leave: dg1 partials of this workgroup
@@ -392,6 +460,23 @@ __global__ __launch_bounds__(kThreads, 1) void vae_dec_grad_kernel(const FusedAr
         for (int r = 0; r < 16; ++r)
           a.part[((int64_t)blockIdx.x * a.rows_pad + lr0 + c_row(r, hlf)) * kT + j32] = c1[q][r];
       }
+    }
+  }
+}
+
+// the left-over tiles: dW_p1 / db_p1 = the groups' partial tiles added in row order (group 0 = row tiles 0-7, ...);
+// runs as the last blocks of vae_dg1_reduce_wg_kernel's launch
+__device__ __forceinline__ void vae_dec_xreduce(const FusedArgs& a, int j) {
+  const int t = a.main_tiles + j;
+  for (int e = threadIdx.x; e < kScratch; e += 256) {
+    float sum = 0.f;
+    for (int g = 0; g < a.groups_per_tile; ++g) sum += a.xpart[((int64_t)j * a.groups_per_tile + g) * kScratch + e];
+    if (e < 16 * NR_WAVE) {
+      const int r = e >> 6, ln = e & 63, it = t * kT + c_row(r, ln >> 5), col = ln & 31;
+      if (it < a.cols && col < a.h) a.dWp1[(int64_t)it * a.h + col] = sum;
+    } else {
+      const int it = t * kT + (e - 16 * NR_WAVE);
+      if (it < a.cols) a.dbp1[it] = sum;
     }
   }
 }
@@ -430,8 +515,13 @@ __global__ __launch_bounds__(256) void vae_dec_stat_kernel(const float* __restri
 // the quarters are added in order
 __global__ __launch_bounds__(256) void vae_dg1_reduce_wg_kernel(const float* __restrict__ part, int n_wg,
                                                                 int rows_pad, int batch, int h,
-                                                                float* __restrict__ dG1) {
+                                                                float* __restrict__ dG1, const FusedArgs a,
+                                                                int n_dg1_blocks) {
   __shared__ float s_q[4][64];
+  if ((int)blockIdx.x >= n_dg1_blocks) {             // workgroup-uniform: the left-over item tiles' dW / db
+    vae_dec_xreduce(a, (int)blockIdx.x - n_dg1_blocks);
+    return;
+  }
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;                     // over batch x 32 (padded width)
   const int r = idx >> 5, j = idx & 31;
@@ -463,8 +553,8 @@ int fused_workgroups() {
 }
 
 struct FusedLayout {
-  size_t bitmap, pstat, stat, posll, part, total;
-  int words, n_tiles, n_wg, tiles_per_wg, rows_pad;
+  size_t bitmap, pstat, stat, posll, part, xpart, total;
+  int words, n_tiles, n_wg, tiles_per_wg, rows_pad, main_tiles, n_rem, groups_per_tile;
 };
 
 FusedLayout fused_layout(int batch, int cols) {
@@ -472,15 +562,19 @@ FusedLayout fused_layout(int batch, int cols) {
   L.words = (cols + 31) / 32;
   L.n_tiles = L.words;
   const int want = fused_workgroups();                       // one workgroup per CU, contiguous item ranges
-  L.tiles_per_wg = (L.n_tiles + want - 1) / want;
-  L.n_wg = (L.n_tiles + L.tiles_per_wg - 1) / L.tiles_per_wg;
+  L.n_wg = L.n_tiles < want ? L.n_tiles : want;
+  L.tiles_per_wg = L.n_tiles / L.n_wg;                       // whole tiles per workgroup (floor) ...
+  L.main_tiles = L.n_wg * L.tiles_per_wg;
+  L.n_rem = L.n_tiles - L.main_tiles;                        // ... and the left-over tiles, cut by rows
   L.rows_pad = (batch + kT - 1) / kT * kT;
+  L.groups_per_tile = (L.rows_pad / kT + kWaves - 1) / kWaves;
   size_t off = 0;
   L.bitmap = off; off += nr_align_up((size_t)batch * L.words * sizeof(uint32_t), 256);
   L.pstat = off; off += nr_align_up((size_t)L.n_wg * 2 * L.rows_pad * sizeof(float), 256);
   L.stat = off; off += nr_align_up((size_t)batch * sizeof(float2), 256);
   L.posll = off; off += nr_align_up((size_t)batch * sizeof(float), 256);
   L.part = off; off += nr_align_up((size_t)L.n_wg * L.rows_pad * kT * sizeof(float), 256);
+  L.xpart = off; off += nr_align_up((size_t)(L.n_rem * L.groups_per_tile + 1) * kScratch * sizeof(float), 256);
   L.total = off;
   return L;
 }
@@ -529,6 +623,8 @@ int nrhip_vae_decoder_fused(int batch, int cols, int h, const float* d_G1, const
   a.G1 = d_G1; a.Wp1 = d_Wp1; a.bp1 = d_bp1; a.bitmap = (const uint32_t*)(ws + L.bitmap);
   a.batch = batch; a.cols = cols; a.h = h; a.words = L.words; a.n_tiles = L.n_tiles;
   a.tiles_per_wg = L.tiles_per_wg; a.rows_pad = L.rows_pad;
+  a.main_tiles = L.main_tiles; a.n_rem = L.n_rem; a.groups_per_tile = L.groups_per_tile;
+  a.xpart = (float*)(ws + L.xpart);
   a.pstat = (float*)(ws + L.pstat); a.stat = (const float2*)(ws + L.stat);
   a.inv_batch = 1.0f / (float)batch;
   a.dWp1 = d_dWp1; a.dbp1 = d_dbp1; a.part = (float*)(ws + L.part);
@@ -547,8 +643,9 @@ int nrhip_vae_decoder_fused(int batch, int cols, int h, const float* d_G1, const
                      batch, d_indptr, d_rows, (const float*)(ws + L.posll), (float2*)(ws + L.stat), d_nll);
   NR_LAUNCH_CHECK();
   NR_TRY(one ? launch_grad<1>(a, L.n_wg, st) : launch_grad<2>(a, L.n_wg, st));
-  hipLaunchKernelGGL(vae_dg1_reduce_wg_kernel, dim3((batch * kT + 63) / 64), dim3(256), 0, st, a.part, L.n_wg,
-                     L.rows_pad, batch, h, d_dG1);
+  const int n_dg1_blocks = (batch * kT + 63) / 64;
+  hipLaunchKernelGGL(vae_dg1_reduce_wg_kernel, dim3(n_dg1_blocks + L.n_rem), dim3(256), 0, st, a.part, L.n_wg,
+                     L.rows_pad, batch, h, d_dG1, a, n_dg1_blocks);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

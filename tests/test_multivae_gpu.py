@@ -181,7 +181,9 @@ def test_multivae_rejects_unbuilt_widths():
         eng.logits(_dev(np.arange(8, dtype=np.int32)))
 
 
-@pytest.mark.parametrize("B,I,h", [(512, 4099, 32), (300, 1000, 32), (700, 2050, 20), (33, 31, 32), (1, 77, 5)])
+@pytest.mark.parametrize("B,I,h", [(512, 4099, 32), (300, 1000, 32), (700, 2050, 20), (33, 31, 32), (1, 77, 5),
+                                   # more item tiles than workgroups: whole tiles per workgroup + left-over tiles cut by rows
+                                   (512, 8300, 32), (700, 8521, 32), (100, 16500, 24)])
 def test_fused_decoder_equals_the_slab_form(B, I, h):
     """csrc/vae_fused.hip (no [B][I] buffer) against the slab form it replaces: pass 1's logits are bit for bit
     the slab's (score GEMM chain + bias), nll / dW_p1 / db_p1 / dg1 agree to fp32 rounding of the differently
