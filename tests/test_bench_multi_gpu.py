@@ -18,7 +18,7 @@ def _run(mode, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "6", "--warmup", "2", "--scale", "0.05", "--batch", "256",
-           "--no-cpu-baseline", "--no-mf", "--config4-scale", "0.002"] + (["--dp-mode", mode] if mode else [])
+           "--no-cpu-baseline", "--no-mf", "--config4-scale", "0.002", "--full-line"] + (["--dp-mode", mode] if mode else [])
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -65,7 +65,7 @@ def test_one_rank_bench_line(extra):
     """The default single-process line (training + evaluation + BPR-MF legs) and the config-4 path
     (device-generated graph, row-sharded engine) on small shapes: contract fields present and finite."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-           "--no-cpu-baseline"] + extra
+           "--no-cpu-baseline", "--full-line"] + extra
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -76,3 +76,25 @@ def test_one_rank_bench_line(extra):
     if "config4" not in extra:
         assert "ndcg10_oracle_absdiff" not in d["eval"]              # that comparison belongs to the CPU-baseline leg
         assert d["mf"]["ms_per_step"] > 0 and d["eval"]["roofline"]["frac"] > 0
+
+
+def test_default_line_is_the_compact_one():
+    """Without --full-line the printed line is the compact form the driver's parser keeps whole: the
+    contract keys, `roofline` with the secondary legs as flat numbers, no prose; the full line goes to a file."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline", "--scale", "0.05", "--batch", "256", "--no-config4", "--no-config5"]
+    full = os.path.join(ROOT, "gpurun_out", "test_full_line.json")
+    os.makedirs(os.path.dirname(full), exist_ok=True)
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280, env=dict(os.environ, NEUREC_BENCH_FULL=full))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4000
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    r = d["roofline"]
+    assert r["eval_users_per_sec"] > 0 and r["mf_triplets_per_sec"] > 0 and 0 < r["frac"] < 1
+    assert all(not isinstance(v, (dict, list)) for v in r.values())
+    with open(full) as f:
+        assert json.load(f)["eval"]["roofline"]["kernel"]              # the full objects live in the file
