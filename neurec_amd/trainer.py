@@ -221,14 +221,22 @@ class MFEngine:
             if self._alpha_host is None or self._alpha_host.size < t + n_steps + 1:
                 self._alpha_host = self.adam.alpha_table(max(2 * (t + n_steps), 4096))
             h_alpha = np.ascontiguousarray(self._alpha_host[t + 1:t + 1 + n_steps])
-        terms = None
-        if self.fused:          # the steps leave their per-triplet terms; one launch reduces the whole call's losses
-            if self._terms_steps is None or self._terms_steps.numel() < 2 * batch * n_steps:
-                self._terms_steps = torch.empty(2 * batch * n_steps, dtype=torch.float32, device=self._table.device)
-            terms = self._terms_steps
-        self._ctx.mf_steps(users, pos, neg, batch, self.adam, h_alpha, loss_steps, plans, terms)
-        for _ in range(n_steps):
-            self.adam.advance()
+        # the fused steps leave their per-triplet terms for ONE reduction launch per native call: run the stream in
+        # groups of kGroup steps so that buffer stays bounded (2 * batch * 4096 floats) whatever the epoch's length
+        kGroup = 4096
+        for s0 in range(0, n_steps, kGroup):
+            ns = min(kGroup, n_steps - s0)
+            lo, hi = s0 * batch, min((s0 + ns) * batch, n)
+            terms = None
+            if self.fused:
+                if self._terms_steps is None or self._terms_steps.numel() < 2 * batch * ns:
+                    self._terms_steps = torch.empty(2 * batch * ns, dtype=torch.float32, device=self._table.device)
+                terms = self._terms_steps
+            self._ctx.mf_steps(users[lo:hi], pos[lo:hi], neg[lo:hi], batch, self.adam,
+                               np.ascontiguousarray(h_alpha[s0:s0 + ns]), loss_steps[2 * s0:2 * (s0 + ns)],
+                               None if plans is None else plans[3 * lo:3 * hi], terms)
+            for _ in range(ns):
+                self.adam.advance()
         self._stale = True
         return n_steps
 
