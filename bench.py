@@ -1223,7 +1223,10 @@ def main():
         # per hop, all-to-all lookups (north_star's row-shard path); nothing is repeated across ranks
         ev = None
         torch.cuda.empty_cache()
-        leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0)
+        try:
+            leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0)
+        except Exception as e:          # a secondary leg must not take the headline (already measured above) down
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
         if comm.rank == 0:
             line["rowshard_config4_law"] = leg
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
