@@ -258,3 +258,49 @@ def test_instance_streams_are_the_reference_layout_formed_on_the_device(eng, hos
     full = _SeqDataset({0: list(range(5)), 1: [1, 2]}, 5)
     with pytest.raises(ValueError):
         next(iter(PointwiseSampler(full)))
+
+
+def test_instance_stream_edge_cases(eng):
+    """windows longer than a sequence (the user contributes nothing), a single instance, neg_num > 1 in both kinds,
+    batch sizes that do not divide the stream, stream slices (multi-GPU sharding of the epoch) and the error behaviour
+    of the reference's constructors."""
+    from neurec_amd.data import PointwiseSampler, TimeOrderPairwiseSampler, TimeOrderPointwiseSampler
+    from neurec_amd.data.streams import InstanceEpochStream, InstanceRows
+    seqs = {3: [5, 1, 7], 9: [2], 4: [8, 0, 6, 4, 3]}                    # user 9: shorter than any window
+    ds = _SeqDataset(seqs, 12)
+    pw = TimeOrderPairwiseSampler(ds, high_order=2, neg_num=3, batch_size=2, shuffle=False)
+    got = list(pw)
+    assert len(got) == len(pw) == 2                                      # 1 + 3 instances in batches of 2
+    users = [u for b in got for u in b[0]]
+    recent = [r for b in got for r in b[1]]
+    nxt = [p for b in got for p in b[2]]
+    negs = [n for b in got for n in b[3]]
+    assert users == [3, 4, 4, 4] and recent == [[5, 1], [8, 0], [0, 6], [6, 4]] and nxt == [7, 6, 4, 3]
+    assert all(len(n) == 3 and not set(n) & set(seqs[u]) for n, u in zip(negs, users))
+    one = TimeOrderPointwiseSampler(_SeqDataset({0: [1, 2]}, 5), high_order=1, neg_num=2, batch_size=10, shuffle=True)
+    (bu, br, bi, bl), = list(one)
+    assert sorted(zip(bi, bl), key=lambda x: -x[1])[0] == (2, 1.0) and bu == [0, 0, 0] and br == [1, 1, 1]
+    assert sum(bl) == 1.0 and all(i not in (1, 2) for i, l in zip(bi, bl) if l == 0.0)
+    with pytest.raises(ValueError):
+        PointwiseSampler(ds, neg_num=0)
+    with pytest.raises(ValueError):
+        TimeOrderPairwiseSampler(ds, high_order=-1)
+    with pytest.raises(ValueError):
+        InstanceRows({}, 0)
+    with pytest.raises(TypeError):
+        InstanceRows([1, 2], 0)
+    # no user has a window: an empty stream, zero batches
+    none = TimeOrderPairwiseSampler(_SeqDataset({0: [1], 1: [2]}, 5), high_order=3)
+    assert len(none) == 0 and list(none) == []
+    # a slice of the stream equals the same slice of the whole (the epoch's rank slices)
+    rows = InstanceRows(ds.get_user_train_dict(by_time=True), 1, 12).to_device()
+    st = InstanceEpochStream(rows, 12, 2, True, 4, True, False, seed=5)
+    whole = [f.cpu().numpy() for f in st.sample_epoch() if f is not None]
+    import torch
+    n = st.n_slots
+    out = (torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"),
+           torch.empty(n, dtype=torch.int32, device="cuda"), None, torch.empty(n, dtype=torch.float32, device="cuda"))
+    eng.sample_instances_epoch(rows, 12, 2, True, 5, 0, True, 3, 7, out)
+    np.testing.assert_array_equal(out[0][:7].cpu().numpy(), whole[0][3:10])
+    np.testing.assert_array_equal(out[2][:7].cpu().numpy(), whole[2][3:10])
+    np.testing.assert_array_equal(out[4][:7].cpu().numpy(), whole[3][3:10])
