@@ -23,6 +23,10 @@ def _load():
         raise ImportError(
             "libneurec_hip.so is not built (expected at %s). Run `python -m neurec_amd.build` "
             "(needs hipcc; the engine has no CPU fallback)." % LIB_PATH)
+    if os.path.isfile(_build.STAMP) and not _build.is_current() and not os.environ.get("NEUREC_ALLOW_STALE_LIB"):
+        raise ImportError(
+            "libneurec_hip.so was built from other sources than neurec_amd/csrc now holds (digest in %s differs). "
+            "Run `python -m neurec_amd.build`; NEUREC_ALLOW_STALE_LIB=1 loads it anyway." % _build.STAMP)
     try:
         return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:  # pragma: no cover - depends on the box

@@ -44,7 +44,8 @@ def _digest():
             h.update(f.read())
     with open(os.path.join(ROOT, "include", "neurec_hip.h"), "rb") as f:
         h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    # the flags without the checkout's absolute paths: the same tree digests the same wherever it lies
+    h.update(" ".join(f.replace(ROOT, "<root>") for f in FLAGS).encode())
     return h.hexdigest()
 
 

@@ -97,3 +97,28 @@ def test_header_is_plain_c(tmp_path):
     out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                           "-o", str(tmp_path / "use_header.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_a_library_built_from_other_sources_is_refused(monkeypatch):
+    """A .so older than the kernels next to it must not be measured or tested by accident: the loader
+    compares the build's source digest and raises (NEUREC_ALLOW_STALE_LIB=1 overrides)."""
+    from neurec_amd import build
+    build.build_extension()
+    from neurec_amd import _lib
+    assert not _lib.is_stale()
+    monkeypatch.setattr(build, "is_current", lambda: False)
+    monkeypatch.delenv("NEUREC_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(ImportError, match="other sources"):
+        _lib._load()
+    monkeypatch.setenv("NEUREC_ALLOW_STALE_LIB", "1")
+    assert _lib._load() is not None
+
+
+def test_the_source_digest_does_not_depend_on_the_checkout_path(monkeypatch):
+    from neurec_amd import build
+    d0 = build._digest()
+    monkeypatch.setattr(build, "FLAGS", [f.replace(build.ROOT, "/somewhere/else") for f in build.FLAGS])
+    monkeypatch.setattr(build, "ROOT", "/somewhere/else")
+    # (ROOT is also where include/neurec_hip.h is read from: keep the header readable)
+    monkeypatch.setattr(build.os.path, "join", lambda *a, _j=build.os.path.join: _j(*a).replace("/somewhere/else", os.path.dirname(build.HERE)))
+    assert build._digest() == d0
