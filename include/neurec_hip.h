@@ -138,6 +138,21 @@ int nrhip_score_tilemax_fix(const float* d_P, int64_t ldp, int d, int cols, cons
                             const int32_t* d_plan_user, const uint32_t* d_plan_mask, const int32_t* d_row_of,
                             int row_lo, int rows, float* d_M, int64_t mld, const void* d_ws, size_t ws_bytes,
                             void* stream);
+/* Level 1 as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip; d <= 64).  The fp32 chain stays the
+ * definition of every score that is ranked: this only SEARCHES for the tiles worth rescoring, 4-5x faster than the
+ * fp32 MFMA loop.  x = hi + lo + r with hi, lo bf16 (round to nearest even), u.i ~= sum_k uh*ih + uh*il + ul*ih in
+ * fp32 accumulators, and |approx - chain| <= kappa(d) * ||u|| * max_i ||i|| = d_eps[row] (kappa: nrhip_score_filter_kappa;
+ * the derivation stands at the top of score_bf16.hip).  nrhip_score_filter_prepare_items splits the item table once
+ * per evaluation (it replaces np.matmul's operand, MF.py:120-122); nrhip_score_filter_tilemax fills d_M like
+ * nrhip_score_tilemax without train lists (nrhip_score_tilemax_fix must follow: it writes exact fp32 maxima, error 0)
+ * and d_eps[rows].  nrhip_eval_tiles_bounded then certifies each row against its bound or flags it. */
+int nrhip_score_filter_workspace_bytes(int rows, int cols, int d, size_t* bytes);
+int nrhip_score_filter_kappa(int d, float* kappa);
+int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws, size_t ws_bytes,
+                                     int max_rows, void* stream);
+int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols, int d,
+                               float* d_M, int64_t mld, float* d_eps, void* d_ws, size_t ws_bytes, int max_rows,
+                               void* stream);
 int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes);
 /* d_gemm_ws: the workspace nrhip_score_gemm_prepare_items filled (the rescoring reads its k-major
  * item copy, one coalesced 256-byte load per k and tile). */
@@ -148,6 +163,18 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
                      const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
                      const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
                      int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream);
+/* Level 2 for BOUNDED maxima (nrhip_score_filter_tilemax, then nrhip_score_tilemax_fix): the n_keep best tiles
+ * (top_k + 1 <= n_keep <= 63) are rescored with the fp32 chain and ranked as in nrhip_eval_tiles; a row stands when its
+ * top_k-th rescored score exceeds the largest maximum among the tiles NOT rescored by more than d_eps[row] — no item
+ * outside the rescored tiles can then reach or tie the kept set in the fp32 chain — otherwise d_flag_out[row] = 1 and
+ * the caller recomputes the row from a full fp32 score row (as for ties).  evaluate.h:23-50 stays the definition. */
+int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int top_k, int n_keep, size_t* bytes);
+int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, int n_keep, const float* d_P,
+                             int64_t ldp, const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
+                             const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                             const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                             const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
+                             int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---- sampler ------------------------------------------------------------
  * Replaces: PairwiseSampler.__iter__ = _sampling_negative_items +

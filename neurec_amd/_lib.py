@@ -117,8 +117,14 @@ SIGNATURES = {
     "nrhip_score_gemm_prepare_items": [p, i64, i32, i32, p, sz, p],
     "nrhip_score_tilemax": [p, i64, p, i32, i32, i32, p, p, p, i64, p, sz, p],
     "nrhip_score_tilemax_fix": [p, i64, i32, i32, p, p, i32, p, p, p, p, i32, i32, p, i64, p, sz, p],
+    "nrhip_score_filter_workspace_bytes": [i32, i32, i32, psz],
+    "nrhip_score_filter_kappa": [i32, p],
+    "nrhip_score_filter_prepare_items": [p, i64, i32, i32, p, sz, i32, p],
+    "nrhip_score_filter_tilemax": [p, i64, p, i32, i32, i32, p, i64, p, p, sz, i32, p],
     "nrhip_eval_tiles_workspace_bytes": [i32, i32, psz],
     "nrhip_eval_tiles": [p, i64, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
+    "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, psz],
+    "nrhip_eval_tiles_bounded": [p, i64, p, i32, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],
     "nrhip_sample_bpr_epoch": [p, p, p, i64, i32, i32, u64, u64, i32, i64, i64, p, p, p, p],

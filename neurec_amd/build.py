@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(HERE, "libneurec_hip.so")
 STAMP = os.path.join(OBJ_DIR, "sources.sha256")
 
 SOURCES = ["eval_select.hip", "score_gemm.hip", "sampler.hip", "spmm.hip", "bpr.hip", "adam.hip",
-           "step.hip", "dense.hip", "vae.hip", "spmm_blocked.hip", "route.hip", "gemm.hip", "vae_wide.hip", "ngcf_wide.hip", "vae_fused.hip"]
+           "step.hip", "dense.hip", "vae.hip", "spmm_blocked.hip", "route.hip", "gemm.hip", "vae_wide.hip", "ngcf_wide.hip", "vae_fused.hip",
+           "score_bf16.hip"]
 # micro-benchmarks behind the design decisions in DESIGN.md (scripts/exp_*.py): their own library,
 # nothing of it is linked into the product
 EXP_SOURCES = ["experiments/gather_experiments.hip"]

@@ -617,9 +617,12 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
                                                          const int32_t* __restrict__ tiles,
                                                          int tiles_ld, const float* __restrict__ M,
                                                          int64_t mld, int rows, int n_keep, int cut,
+                                                         const float* __restrict__ C, int64_t cld,
+                                                         const float* __restrict__ eps,
                                                          int32_t* __restrict__ flag_out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
+  const int col_k = rank[(int64_t)row * kRankStride + cut - 1];       // compact column of the cut-th best (read before the remap)
   for (int k = lane; k < cut; k += NR_WAVE) {
     const int col = rank[(int64_t)row * kRankStride + k];
     rank[(int64_t)row * kRankStride + k] =
@@ -628,7 +631,14 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
   if (lane == 0) {
     const float inside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep - 1]];
     const float outside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep]];
-    flag_out[row] = (sel_flag[row] != 0 || !(inside > outside)) ? 1 : 0;
+    if (eps) {
+      // bounded maxima (nrhip_score_filter_tilemax): every item of a tile that was not rescored scores at most
+      // outside + eps[row] in the fp32 chain; the row stands only if its cut-th rescored score is strictly above
+      const float s_k = C[(int64_t)row * cld + col_k];
+      flag_out[row] = (sel_flag[row] != 0 || !(s_k > outside + eps[row])) ? 1 : 0;
+    } else {
+      flag_out[row] = (sel_flag[row] != 0 || !(inside > outside)) ? 1 : 0;
+    }
   }
 }
 
@@ -860,9 +870,8 @@ int nrhip_eval_scores_any_k(const float* d_scores, int64_t ld, int rows, int col
 }
 
 /* Workspace of nrhip_eval_tiles for `rows` rows (includes the selection scratch). */
-static size_t eval_tiles_ws_bytes(int rows, int top_k) {
+static size_t eval_tiles_ws_bytes(int rows, int n_keep) {
   const size_t r = (size_t)(rows > 0 ? rows : 1);
-  const int n_keep = top_k + 1;
   return eval_ws_bytes((int)r) + nr_align_up(r * (size_t)(n_keep + 1) * 4, 256) +
          nr_align_up(r * (size_t)n_keep * 4, 256) +
          nr_align_up(r * (size_t)n_keep * kTileItems * sizeof(float), 256);
@@ -871,7 +880,14 @@ static size_t eval_tiles_ws_bytes(int rows, int top_k) {
 int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes) {
   NR_REQUIRE(bytes && rows >= 0 && top_k >= 1 && top_k <= 62, NR_ERR_ARG,
              "eval_tiles_workspace_bytes: rows=%d top_k=%d (1..62)", rows, top_k);
-  *bytes = eval_tiles_ws_bytes(rows, top_k);
+  *bytes = eval_tiles_ws_bytes(rows, top_k + 1);
+  return NR_OK;
+}
+
+int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int top_k, int n_keep, size_t* bytes) {
+  NR_REQUIRE(bytes && rows >= 0 && top_k >= 1 && n_keep >= top_k + 1 && n_keep <= 63, NR_ERR_ARG,
+             "eval_tiles_bounded_workspace_bytes: rows=%d top_k=%d n_keep=%d (top_k + 1 .. 63)", rows, top_k, n_keep);
+  *bytes = eval_tiles_ws_bytes(rows, n_keep);
   return NR_OK;
 }
 
@@ -880,12 +896,13 @@ int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes) {
  * d_flag_out[r] = 1 for the rows whose ranking may depend on ties — those rows of d_out are
  * provisional and must be recomputed from a full score row (nrhip_score_gemm + nrhip_mask_train +
  * nrhip_eval_scores).  Needs ceil(cols/64) >= top_k + 2 tiles. */
-int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ldp,
-                     const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
-                     const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
-                     const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
-                     const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
-                     int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream) {
+static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int64_t ldp,
+                           const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
+                           const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                           const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                           const int32_t* metric_ids_host, int n_metric, int top_k, int n_keep,
+                           const float* d_eps, float* d_out, int32_t* d_flag_out, void* d_ws, size_t ws_bytes,
+                           void* stream) {
   NR_REQUIRE(d_M && d_P && d_gemm_ws && d_tr_indptr && d_tr_indices && d_truth_indptr && d_truth_indices &&
                  metric_ids_host && d_out && d_flag_out && d_ws,
              NR_ERR_ARG, "eval_tiles: null pointer argument");
@@ -899,8 +916,9 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
     if (rc0 != NR_OK) return rc0;
   }
   const int n_tiles = 2 * ((cols + 63) / 64);      // 32-item tiles, as nrhip_score_tilemax writes them
-  NR_REQUIRE(n_tiles >= top_k + 2 && mld >= n_tiles, NR_ERR_ARG,
-             "eval_tiles: %d tiles < top_k + 2 (use the full score path)", n_tiles);
+  NR_REQUIRE(n_keep >= top_k + 1 && n_keep <= 63, NR_ERR_ARG, "eval_tiles: n_keep=%d outside top_k + 1 .. 63", n_keep);
+  NR_REQUIRE(n_tiles >= n_keep + 1 && mld >= n_tiles, NR_ERR_ARG,
+             "eval_tiles: %d tiles < n_keep + 1 (use the full score path)", n_tiles);
   NR_REQUIRE(n_metric >= 1 && n_metric <= 8 && rows >= 0, NR_ERR_ARG, "eval_tiles: bad sizes");
   MetricIds mids;
   mids.n = n_metric;
@@ -910,11 +928,11 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
     mids.id[i] = metric_ids_host[i];
   }
   if (rows == 0) return NR_OK;
-  NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, top_k), NR_ERR_WORKSPACE,
-             "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, top_k));
+  NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, n_keep), NR_ERR_WORKSPACE,
+             "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, n_keep));
   hipStream_t st = (hipStream_t)stream;
   { const int rc = select_knob_once(); if (rc != NR_OK) return rc; }
-  const int n_keep = top_k + 1, tiles_ld = n_keep + 1;
+  const int tiles_ld = n_keep + 1;
   EvalWs w = carve_ws(d_ws, rows);
   char* p = (char*)d_ws + eval_ws_bytes(rows);
   int32_t* tiles = (int32_t*)p;   p += nr_align_up((size_t)rows * tiles_ld * 4, 256);
@@ -949,7 +967,7 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
   NR_LAUNCH_CHECK();
   // 4. columns -> item ids, boundary check, flags
   hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
-                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k, d_flag_out);
+                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k, C, cld, d_eps, d_flag_out);
   NR_LAUNCH_CHECK();
   // 5. metrics
   InvLog2Table tbl;
@@ -959,6 +977,32 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
                      (int32_t*)nullptr);
   NR_LAUNCH_CHECK();
   return NR_OK;
+}
+
+int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ldp,
+                     const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
+                     const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                     const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                     const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
+                     int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream) {
+  return eval_tiles_impl(d_M, mld, d_P, ldp, d_gemm_ws, d, d_users, rows, cols, d_tr_indptr, d_tr_indices,
+                         d_truth_indptr, d_truth_indices, metric_ids_host, n_metric, top_k, top_k + 1, nullptr,
+                         d_out, d_flag_out, d_ws, ws_bytes, stream);
+}
+
+/* nrhip_eval_tiles for maxima that are only bounded (nrhip_score_filter_tilemax + nrhip_score_tilemax_fix):
+ * the n_keep (>= top_k + 1) best tiles are rescored with the fp32 chain; a row stands when its top_k-th rescored
+ * score exceeds the largest maximum among the other tiles by more than d_eps[row], else it is flagged. */
+int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, int n_keep, const float* d_P,
+                             int64_t ldp, const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
+                             const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
+                             const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
+                             const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
+                             int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_eps, NR_ERR_ARG, "eval_tiles_bounded: null bound");
+  return eval_tiles_impl(d_M, mld, d_P, ldp, d_gemm_ws, d, d_users, rows, cols, d_tr_indptr, d_tr_indices,
+                         d_truth_indptr, d_truth_indices, metric_ids_host, n_metric, top_k, n_keep, d_eps, d_out,
+                         d_flag_out, d_ws, ws_bytes, stream);
 }
 
 int nrhip_arg_topk(const float* d_scores, int64_t ld, int rows, int cols, int top_k,

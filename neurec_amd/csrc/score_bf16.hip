@@ -1,0 +1,322 @@
+// score_bf16.hip — level 1 of the pruned evaluation as a BOUNDED FILTER on the bf16 matrix cores.
+//
+// The evaluation's answer is defined by the fp32 k-ascending fmaf chain of every (user, item) score
+// (score_gemm.hip; MF.py:120-122, LightGCN.py:187-189) and stays that: the chosen tiles are rescored with that
+// chain and ranked from those values (eval_select.hip, nrhip_eval_tiles_bounded).  What this file replaces is only
+// the SEARCH for the tiles worth rescoring: v_mfma_f32_32x32x2_f32 issues 64 FLOP / clk / SIMD, the bf16 MFMA 1,024,
+// so the tile maxima are taken over a three-term bf16 expansion of the same products
+//     x = hi + lo + r,   hi = bf16_rne(x),  lo = bf16_rne(x - hi),  |r| <= 2^-18 |x|
+//     u·i ~= Σ_k  uh·ih + uh·il + ul·ih                     (48 MFMAs of 32 clk per 64 x 64 tile instead of 128 of 64)
+// and every maximum comes with a bound on its distance from the fp32 chain's value:
+//     |approx(u, i) - chain(u, i)| <= kappa(d) · ||u||₂ · max_i ||i||₂ = eps[u]
+//     kappa(d) = 1.5 · (3.2 · 2^-18  +  3 d · 2^-23  +  d · 2^-24)
+//       dropped terms (ul·il, r·x, x·r)   products of bf16 are exact in fp32; <= 192 fp32 accumulations,   the chain's
+//                                          each within 2^-23 of its partial sum (truncation allowed)        own rounding
+//     with Σ_k |u_k i_k| <= ||u||₂ ||i||₂.  tests/test_eval_gpu.py measures the left side against this bound.
+// The ranking kernel accepts a row only if its K-th rescored (exact) score exceeds the largest approximate maximum
+// among the tiles it did NOT rescore by more than eps[u]; any other row is flagged and redone from a full fp32 score
+// row, exactly as rows with ties are.  No reduced-precision value reaches a ranking or a metric.
+//
+// Operand layout (built by split_rows_kernel, items once per evaluation, users per batch): for a block b of 32 rows,
+// term (0 = hi, 1 = lo), k-step s (16 k each) the wave's 64 lanes read ONE uint4 each — lane 32·g + j holds
+// row 32·b + j, k = 16·s + 8·g .. +7 — i.e. exactly its v_mfma_f32_32x32x16_bf16 operand: 1 KB coalesced per load.
+// Train items: the planned (user, tile) pairs are recomputed in fp32 by nrhip_score_tilemax_fix afterwards (error 0).
+#include "nr_common.h"
+#include <limits.h>
+#include <math.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
+  const uint32_t b = __float_as_uint(x);
+  if ((b & 0x7fffffffu) > 0x7f800000u) return (b >> 16) | 0x40u;        // NaN stays NaN
+  return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+
+// dst[((b·2 + term)·KS16 + s)·64 + lane] = the 8 bf16 of row 32·b + (lane & 31), k = 16·s + 8·(lane >> 5) .. +7;
+// norm[row] = ||row||₂ (fp32, rounded up by the caller's factor); *max_norm = max over rows (optional)
+__global__ void split_rows_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ ids, int n,
+                                  int d, int ks16, uint4* __restrict__ dst, float* __restrict__ norm,
+                                  float* __restrict__ max_norm) {
+  __shared__ float s_sq[8][64];
+  const int lane = threadIdx.x, s = threadIdx.y, b = blockIdx.x;
+  const int r = b * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+  float x[8];
+  const bool have = r < n;
+  const float* p = src + (have ? (ids ? (int64_t)ids[r] : (int64_t)r) : 0) * ld;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = (have && k0 + e < d) ? p[k0 + e] : 0.f;
+  uint32_t hi[8], lo[8];
+  float sq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = bf16_rne_bits(x[e]);
+    lo[e] = bf16_rne_bits(x[e] - __uint_as_float(hi[e] << 16));       // x - hi is exact in fp32
+    sq = fmaf(x[e], x[e], sq);
+  }
+  uint4 vh, vl;
+  vh.x = hi[0] | (hi[1] << 16); vh.y = hi[2] | (hi[3] << 16); vh.z = hi[4] | (hi[5] << 16); vh.w = hi[6] | (hi[7] << 16);
+  vl.x = lo[0] | (lo[1] << 16); vl.y = lo[2] | (lo[3] << 16); vl.z = lo[4] | (lo[5] << 16); vl.w = lo[6] | (lo[7] << 16);
+  dst[(((int64_t)b * 2 + 0) * ks16 + s) * 64 + lane] = vh;
+  dst[(((int64_t)b * 2 + 1) * ks16 + s) * 64 + lane] = vl;
+  s_sq[s][lane] = sq;
+  __syncthreads();
+  if (s == 0 && lane < 32) {
+    float t = 0.f;
+    for (int q = 0; q < ks16; ++q) t += s_sq[q][lane] + s_sq[q][lane + 32];
+    const float nv = sqrtf(t);
+    if (have && norm) norm[r] = nv;
+    if (have && max_norm) atomicMax(reinterpret_cast<int*>(max_norm), __float_as_int(nv));   // nv >= 0 (or NaN: stays)
+  }
+}
+
+__global__ void row_eps_kernel(const float* __restrict__ norm, const float* __restrict__ max_norm, int rows,
+                               float kappa, float* __restrict__ eps) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) eps[r] = kappa * norm[r] * max_norm[0];
+}
+
+__device__ __forceinline__ float max16(const f32x16& c) {
+  float m = c[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, c[i]);
+  return m;
+}
+__device__ __forceinline__ float max16_skip(const f32x16& c, uint32_t skip) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = ((skip >> i) & 1u) ? m : fmaxf(m, c[i]);
+  return m;
+}
+// max over the two lane halves (rows (reg&3) + 8 (reg>>2) + 4 h of the same 32-row block)
+__device__ __forceinline__ float max_halves(float m) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int KS16>
+struct BSet {
+  uint4 v[2][2][KS16];                                        // [item block X][term][k-step]
+};
+
+// One wave: 64 users (two 32-user column blocks, operands in registers for the whole chunk) against the chunk's
+// 64-item tiles; the four waves of a workgroup take four user panels against the same tiles (shared in L1 / L2).
+// Three B register sets: the loads of tile t + 2 are issued before tile t's MFMAs (a tile is ~0.75 us).
+template <int KS16>
+__global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __restrict__ PB,
+                                                              const uint4* __restrict__ QB, int bpad, int rows,
+                                                              int cols, int n_tiles, float* __restrict__ M,
+                                                              int64_t mld, int tiles_per_chunk) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int ub0 = (blockIdx.x * 4 + wave) * 2;
+  if (ub0 * 32 >= bpad) return;
+  const int t_begin = blockIdx.y * tiles_per_chunk;
+  const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+  if (t_begin >= t_end) return;
+
+  bf16x8 ah[2][KS16], al[2][KS16];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int s = 0; s < KS16; ++s) {
+      ah[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 0) * KS16 + s) * 64 + lane]);
+      al[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 1) * KS16 + s) * 64 + lane]);
+    }
+  const int ra = ub0 * 32 + j, rb = ra + 32;
+
+  auto load_b = [&](int t, BSet<KS16>& b) {
+    const uint4* q = QB + (int64_t)min(t, t_end - 1) * (4 * KS16 * 64) + lane;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int term = 0; term < 2; ++term)
+#pragma unroll
+        for (int s = 0; s < KS16; ++s) b.v[x][term][s] = q[((x * 2 + term) * KS16 + s) * 64];
+  };
+  auto tile = [&](int t, const BSet<KS16>& b) {
+    f32x16 c[2][2];                                           // [item block X (rows)][user block Y (columns)]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[x][y][i] = 0.f;
+    // the small terms first; the four accumulators interleaved (independent chains)
+#pragma unroll
+    for (int s = 0; s < KS16; ++s)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][1][s]), ah[y][s],
+                                                            c[x][y], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS16; ++s)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), al[y][s],
+                                                            c[x][y], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS16; ++s)
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), ah[y][s],
+                                                            c[x][y], 0, 0, 0);
+    float m[2][2];
+    const int it = t * 64;
+    if (it + 64 > cols) {                                     // the last tile: pad columns score 0, not -inf
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        uint32_t skip = 0u;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (it + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h >= cols) skip |= 1u << reg;
+        m[x][0] = max16_skip(c[x][0], skip);
+        m[x][1] = max16_skip(c[x][1], skip);
+      }
+    } else {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) { m[x][0] = max16(c[x][0]); m[x][1] = max16(c[x][1]); }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { m[x][0] = max_halves(m[x][0]); m[x][1] = max_halves(m[x][1]); }
+    if (h == 0 && t < t_end) {
+      if (ra < rows) *reinterpret_cast<float2*>(M + (int64_t)ra * mld + 2 * t) = make_float2(m[0][0], m[1][0]);
+      if (rb < rows) *reinterpret_cast<float2*>(M + (int64_t)rb * mld + 2 * t) = make_float2(m[0][1], m[1][1]);
+    }
+  };
+
+  BSet<KS16> b0, b1, b2;
+  load_b(t_begin, b0);
+  load_b(t_begin + 1, b1);
+  // (tiles past the chunk's end are recomputed from the clamped loads and not stored: no branch around a load)
+  for (int t = t_begin; t < t_end; t += 3) {
+    load_b(t + 2, b2);
+    tile(t, b0);
+    load_b(t + 3, b0);
+    tile(t + 1, b1);
+    load_b(t + 4, b1);
+    tile(t + 2, b2);
+  }
+}
+
+inline int padded_dim16(int d) {                              // widths the bf16 filter is built for
+  const int opts[4] = {16, 32, 48, 64};
+  for (int i = 0; i < 4; ++i)
+    if (d <= opts[i]) return opts[i];
+  return -1;
+}
+inline int round_up64(int x) { return (x + 63) / 64 * 64; }
+
+struct FilterWs {
+  uint4* QB;
+  uint4* PB;
+  float* unorm;
+  float* inorm_max;
+  size_t q_bytes, p_bytes, n_bytes, total;
+};
+FilterWs carve(void* ws, int rows, int cols, int dp) {
+  FilterWs f;
+  f.q_bytes = nr_align_up((size_t)round_up64(cols) * dp * 4, 256);          // hi + lo bf16 = 4 bytes per element
+  f.p_bytes = nr_align_up((size_t)round_up64(rows > 0 ? rows : 1) * dp * 4, 256);
+  f.n_bytes = nr_align_up((size_t)round_up64(rows > 0 ? rows : 1) * 4, 256);
+  f.QB = (uint4*)ws;
+  f.PB = (uint4*)((char*)ws + f.q_bytes);
+  f.unorm = (float*)((char*)ws + f.q_bytes + f.p_bytes);
+  f.inorm_max = (float*)((char*)ws + f.q_bytes + f.p_bytes + f.n_bytes);
+  f.total = f.q_bytes + f.p_bytes + f.n_bytes + 256;
+  return f;
+}
+inline float kappa_of(int dp) {
+  return 1.5f * (3.2f * 3.814697265625e-06f + 3.0f * dp * 1.1920928955078125e-07f + dp * 5.9604644775390625e-08f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrhip_score_filter_workspace_bytes(int rows, int cols, int d, size_t* bytes) {
+  NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && d >= 1, NR_ERR_ARG, "score_filter_workspace_bytes: bad arguments");
+  const int dp = padded_dim16(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built (use nrhip_score_tilemax)", d);
+  *bytes = carve(nullptr, rows, cols, dp).total;
+  return NR_OK;
+}
+
+int nrhip_score_filter_kappa(int d, float* kappa) {
+  NR_REQUIRE(kappa && d >= 1, NR_ERR_ARG, "score_filter_kappa: bad arguments");
+  const int dp = padded_dim16(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built", d);
+  *kappa = kappa_of(dp);
+  return NR_OK;
+}
+
+int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws, size_t ws_bytes,
+                                     int max_rows, void* stream) {
+  NR_REQUIRE(d_Q && d_ws && cols >= 1 && d >= 1 && ldq >= d && max_rows >= 0, NR_ERR_ARG,
+             "score_filter_prepare_items: bad arguments");
+  const int dp = padded_dim16(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built", d);
+  FilterWs f = carve(d_ws, max_rows, cols, dp);
+  NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_prepare_items: workspace %zu < %zu", ws_bytes,
+             f.total);
+  hipStream_t st = (hipStream_t)stream;
+  NR_CHECK_HIP(hipMemsetAsync(f.inorm_max, 0, sizeof(float), st));
+  const int ks16 = dp / 16;
+  hipLaunchKernelGGL(split_rows_kernel, dim3(round_up64(cols) / 32), dim3(64, ks16), 0, st, d_Q, ldq,
+                     (const int32_t*)nullptr, cols, d, ks16, f.QB, (float*)nullptr, f.inorm_max);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* Approximate tile maxima M[rows][2*ceil(cols/64)] (32-item tiles, pad columns excluded, train items NOT struck:
+ * nrhip_score_tilemax_fix follows) and d_eps[rows]: |M[r][t] - (fp32 chain maximum of that tile)| <= d_eps[r].
+ * nrhip_score_filter_prepare_items with the same workspace, cols, d and max_rows >= rows must have run. */
+int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols, int d,
+                               float* d_M, int64_t mld, float* d_eps, void* d_ws, size_t ws_bytes, int max_rows,
+                               void* stream) {
+  NR_REQUIRE(d_P && d_M && d_eps && d_ws && cols >= 1 && d >= 1 && ldp >= d && rows >= 0 && max_rows >= rows &&
+                 mld >= 2 * ((cols + 63) / 64) && mld % 2 == 0,
+             NR_ERR_ARG, "score_filter_tilemax: bad arguments (mld must be even and >= 2*ceil(cols/64))");
+  const int dp = padded_dim16(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built", d);
+  if (rows == 0) return NR_OK;
+  FilterWs f = carve(d_ws, max_rows, cols, dp);
+  NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_tilemax: workspace %zu < %zu", ws_bytes, f.total);
+  hipStream_t st = (hipStream_t)stream;
+  const int ks16 = dp / 16, bpad = round_up64(rows);
+  hipLaunchKernelGGL(split_rows_kernel, dim3(bpad / 32), dim3(64, ks16), 0, st, d_P, ldp, d_users, rows, d, ks16,
+                     f.PB, f.unorm, (float*)nullptr);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(row_eps_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, f.unorm, f.inorm_max, rows,
+                     kappa_of(dp), d_eps);
+  NR_LAUNCH_CHECK();
+  const int bx = (bpad / 64 + 3) / 4;
+  const int n_tiles = round_up64(cols) / 64;
+  int tpc = (int)(((int64_t)n_tiles * bx + 2047) / 2048);
+  tpc = (tpc + 2) / 3 * 3;
+  if (tpc < 6) tpc = 6;
+  const int by = (n_tiles + tpc - 1) / tpc;
+  dim3 grid(bx, by), block(256);
+#define NR_FILTER_CASE(K)                                                                                       \
+  hipLaunchKernelGGL(tilemax_bf16_kernel<K>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld, tpc)
+  switch (ks16) {
+    case 1: NR_FILTER_CASE(1); break;
+    case 2: NR_FILTER_CASE(2); break;
+    case 3: NR_FILTER_CASE(3); break;
+    default: NR_FILTER_CASE(4); break;
+  }
+#undef NR_FILTER_CASE
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+}  // extern "C"

@@ -220,13 +220,16 @@ class ScoreGemm:
         return out[:rows]
 
 
-    def tile_maxima(self, user_table, users, train_csr, out=None, plan=None, row_of=None, row_lo=0):
+    def tile_maxima(self, user_table, users, train_csr, out=None, plan=None, row_of=None, row_lo=0, filt=None):
         """Pruned evaluation, level 1: M[r][t] = max admissible score of user row r over 32-item
         tile t (train items and pad columns excluded); the scores themselves are never stored.
         With a TileStrikePlan of the train matrix: the scoring loop runs without the train lists and the
         planned (user, tile) pairs are recomputed with their strikes afterwards — same M, bit for bit.
         `row_of` [n_users] int32 maps a user to its row in the whole evaluation order (None: row = user) and
-        `row_lo` is the first row of this batch in that order."""
+        `row_lo` is the first row of this batch in that order.
+        With `filt` (a ScoreFilter of the same item table; needs `plan`) the scoring loop is the bf16 bounded filter
+        and the return value is (M, eps): |M[r][t] - the fp32 chain's maximum| <= eps[r] (the planned pairs are
+        recomputed in fp32: error 0)."""
         rows = user_table.shape[0] if users is None else users.numel()
         if rows > self.max_rows:
             raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
@@ -234,11 +237,17 @@ class ScoreGemm:
         mld = (n_tiles + 3) // 4 * 4
         if out is None:
             out = torch.empty((rows, mld), dtype=torch.float32, device=self.ws.device)
-        call("nrhip_score_tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
-             _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d,
-             None if plan is not None else _ptr(train_csr.indptr),
-             None if plan is not None else _ptr(train_csr.indices), _ptr(out, torch.float32),
-             out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
+        eps = None
+        if filt is not None:
+            if plan is None:
+                raise ValueError("the bounded filter leaves the train items to the planned fix-up: pass the plan")
+            _, eps = filt.tile_maxima(user_table, users, out=out)
+        else:
+            call("nrhip_score_tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
+                 _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d,
+                 None if plan is not None else _ptr(train_csr.indptr),
+                 None if plan is not None else _ptr(train_csr.indices), _ptr(out, torch.float32),
+                 out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
         if plan is not None:
             if plan.cols != self.cols:
                 raise ValueError("strike plan built for %d items, scoring %d" % (plan.cols, self.cols))
@@ -249,7 +258,54 @@ class ScoreGemm:
                  _ptr(plan.tile_ptr, torch.int64), _ptr(plan.user, torch.int32), _ptr(plan.mask, torch.int32),
                  _ptr(row_of, torch.int32, allow_none=True), int(row_lo), rows, _ptr(out, torch.float32),
                  out.stride(0), _ptr(self.ws), self.ws.numel(), _stream())
-        return out[:rows]
+        return out[:rows] if filt is None else (out[:rows], eps)
+
+
+class ScoreFilter:
+    """Level 1 of the pruned evaluation as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip): tile
+    maxima over a three-term bf16 expansion of the fp32 products, each within eps[row] of the fp32 chain's value.
+    Nothing here is ranked: nrhip_eval_tiles_bounded rescores the chosen tiles with the fp32 chain and accepts a row
+    only if its bound certifies the choice.  Built for d <= 64 (`ScoreFilter.supports`)."""
+
+    @staticmethod
+    def supports(d):
+        return int(d) <= 64
+
+    def __init__(self, item_table, max_rows):
+        self.cols, self.d = item_table.shape
+        self.max_rows = int(max_rows)
+        nbytes = C.c_size_t(0)
+        call("nrhip_score_filter_workspace_bytes", self.max_rows, self.cols, self.d, C.byref(nbytes))
+        self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=item_table.device)
+        k = C.c_float(0)
+        call("nrhip_score_filter_kappa", self.d, C.byref(k))
+        self.kappa = float(k.value)
+        self.prepare(item_table)
+
+    def prepare(self, item_table):
+        if tuple(item_table.shape) != (self.cols, self.d):
+            raise ValueError("item table %s, prepared for %s" % (tuple(item_table.shape), (self.cols, self.d)))
+        if item_table.stride(1) != 1:
+            item_table = item_table.contiguous()
+        call("nrhip_score_filter_prepare_items", C.c_void_p(item_table.data_ptr()), item_table.stride(0), self.cols,
+             self.d, _ptr(self.ws), self.ws.numel(), self.max_rows, _stream())
+
+    def tile_maxima(self, user_table, users, out=None, eps=None):
+        """(M, eps): M[r][t] ~ max score of row r over 32-item tile t (pad columns excluded, train items NOT struck),
+        |M[r][t] - fp32 chain maximum| <= eps[r]."""
+        rows = user_table.shape[0] if users is None else users.numel()
+        if rows > self.max_rows:
+            raise ValueError("batch of %d rows > prepared max_rows=%d" % (rows, self.max_rows))
+        n_tiles = 2 * ((self.cols + 63) // 64)
+        mld = (n_tiles + 3) // 4 * 4
+        if out is None:
+            out = torch.empty((rows, mld), dtype=torch.float32, device=self.ws.device)
+        if eps is None:
+            eps = torch.empty(rows, dtype=torch.float32, device=self.ws.device)
+        call("nrhip_score_filter_tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
+             _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d, _ptr(out, torch.float32),
+             out.stride(0), _ptr(eps, torch.float32), _ptr(self.ws), self.ws.numel(), self.max_rows, _stream())
+        return out[:rows], eps[:rows]
 
 
 class ScoreGemmWide:
@@ -340,16 +396,30 @@ class TileStrikePlan:
 _tiles_ws = Workspace()
 
 
-def eval_tiles(M, user_table, gemm, users, train_csr, truth_csr, metric_ids, top_k, out, flags):
+def eval_tiles(M, user_table, gemm, users, train_csr, truth_csr, metric_ids, top_k, out, flags, eps=None,
+               n_keep=None):
     """Pruned evaluation, level 2 (nrhip_eval_tiles): metric rows into `out`, tie flags into
     `flags` (int32 per row; flagged rows must be recomputed from full score rows).  `gemm` is the
-    ScoreGemm whose prepared (k-major) item copy the rescoring reads."""
+    ScoreGemm whose prepared (k-major) item copy the rescoring reads.  With `eps` (ScoreFilter.tile_maxima) the maxima
+    are bounded, not exact: `n_keep` tiles are rescored and a row stands only if its bound certifies the choice
+    (nrhip_eval_tiles_bounded)."""
     rows = M.shape[0]
     nbytes = C.c_size_t(0)
-    call("nrhip_eval_tiles_workspace_bytes", rows, top_k, C.byref(nbytes))
-    ws = _tiles_ws.get(nbytes.value)
     nm = len(metric_ids)
     ids = (C.c_int * nm)(*[int(m) for m in metric_ids])
+    if eps is not None:
+        n_keep = int(top_k + 1 if n_keep is None else n_keep)
+        call("nrhip_eval_tiles_bounded_workspace_bytes", rows, top_k, n_keep, C.byref(nbytes))
+        ws = _tiles_ws.get(nbytes.value)
+        call("nrhip_eval_tiles_bounded", C.c_void_p(M.data_ptr()), M.stride(0), _ptr(eps, torch.float32), n_keep,
+             _ptr(user_table, torch.float32), user_table.stride(0), _ptr(gemm.ws), gemm.d,
+             _ptr(users, torch.int32, allow_none=True), rows, gemm.cols,
+             _ptr(train_csr.indptr), _ptr(train_csr.indices), _ptr(truth_csr.indptr),
+             _ptr(truth_csr.indices), ids, nm, top_k, _ptr(out, torch.float32),
+             _ptr(flags, torch.int32), _ptr(ws), ws.numel(), _stream())
+        return out
+    call("nrhip_eval_tiles_workspace_bytes", rows, top_k, C.byref(nbytes))
+    ws = _tiles_ws.get(nbytes.value)
     call("nrhip_eval_tiles", C.c_void_p(M.data_ptr()), M.stride(0), _ptr(user_table, torch.float32),
          user_table.stride(0), _ptr(gemm.ws), gemm.d,
          _ptr(users, torch.int32, allow_none=True), rows, gemm.cols,

@@ -10,6 +10,7 @@ and bench.py drive.
   LightGCNEngine    LightGCN.build_graph + sess.run model/general_recommender/LightGCN.py:80-149,178
   FullRankEvaluator UniEvaluator.evaluate           evaluator/backend/cpp/uni_evaluator.py:101-157
 """
+import os
 import numpy as np
 import torch
 
@@ -483,7 +484,15 @@ class FullRankEvaluator:
                    by batch (scoring of batch b+1 overlapped with the ranking of batch b)."""
 
     def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True,
-                 pruned=True, strike_plan=True):
+                 pruned=True, strike_plan=True, search=None, extra_tiles=2):
+        # how the pruned path FINDS the tiles it rescores: "bf16" = the bounded filter on the bf16 matrix cores
+        # (csrc/score_bf16.hip; every row certified against its error bound or redone from fp32 rows), "fp32" = the
+        # fp32 MFMA loop (exact maxima).  The ranked scores are the fp32 chain's either way.  NEUREC_EVAL_SEARCH overrides.
+        self.search = str(search or os.environ.get("NEUREC_EVAL_SEARCH", "bf16"))
+        if self.search not in ("bf16", "fp32"):
+            raise ValueError("search must be 'bf16' or 'fp32', got %r" % (self.search,))
+        self.extra_tiles = int(extra_tiles)  # bounded search: tiles rescored beyond top_k + 1 (room for the bound)
+        self._filter = None
         self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
         self.strike_plan = bool(strike_plan)  # strikes as a planned fix-up pass after an unmasked scoring loop
         self._plan = None                    # (False: cursors + strikes inside the scoring loop; same M bit for bit)
@@ -506,6 +515,7 @@ class FullRankEvaluator:
                 self._gemm.d != item_table.shape[1]:
             self._gemm = E.score_gemm_for(item_table, self.batch_rows)
             self._scores = [self._gemm.new_score_buffer()]
+            self._filter = None
         else:
             self._gemm.prepare(item_table)
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
@@ -590,11 +600,26 @@ class FullRankEvaluator:
                     t[test_users.long()] = torch.arange(n, dtype=torch.int32, device=test_users.device)
                     made.append(t)
                 return made[0]
+        filt = None
+        n_keep = min(self.top_k + 1 + self.extra_tiles, 63, 2 * ((item_table.shape[0] + 63) // 64) - 1)
+        if self.search == "bf16" and use_plan and E.ScoreFilter.supports(item_table.shape[1]) and n_keep > self.top_k:
+            if self._filter is None:
+                self._filter = E.ScoreFilter(item_table, self.batch_rows)
+            else:
+                self._filter.prepare(item_table)
+            filt = self._filter
+        self.search_used = "bf16" if filt is not None else "fp32"
         for b in starts:
             u = test_users[b:b + self.batch_rows]
-            M = self._gemm.tile_maxima(user_table, u, self.train, plan=plan, row_of=row_of, row_lo=b)
-            E.eval_tiles(M, user_table, self._gemm, u, self.train, self.test, self.metric_ids,
-                         self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()])
+            if filt is None:
+                M = self._gemm.tile_maxima(user_table, u, self.train, plan=plan, row_of=row_of, row_lo=b)
+                E.eval_tiles(M, user_table, self._gemm, u, self.train, self.test, self.metric_ids,
+                             self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()])
+            else:
+                M, eps = self._gemm.tile_maxima(user_table, u, self.train, plan=plan, row_of=row_of, row_lo=b,
+                                                filt=filt)
+                E.eval_tiles(M, user_table, self._gemm, u, self.train, self.test, self.metric_ids,
+                             self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()], eps=eps, n_keep=n_keep)
         self._flags = flags                        # read by evaluate_factors together with the sums
 
     def _redo_flagged(self, user_table, item_table, test_users, per_user):

@@ -308,3 +308,118 @@ def test_planned_strikes_leave_the_same_tile_maxima_as_the_in_loop_strikes(d, U,
         n_t = (I + 31) // 32                            # columns beyond the tiles are padding (never written)
         np.testing.assert_array_equal(got.cpu().numpy()[:, :n_t], want.cpu().numpy()[:, :n_t])
         assert np.isneginf(got.cpu().numpy()[5, 2])
+
+
+def _spread_tables(rng, U, I, d, kind):
+    """Factor tables that stress the bf16 expansion: plain gaussians at three scales, and entries whose exponents
+    are spread over 2^-20 .. 2^6 (the high / low parts of different coordinates then differ by many binades)."""
+    if kind == "wide":
+        P = (rng.randn(U, d) * np.exp2(rng.randint(-20, 7, size=(U, d)))).astype(np.float32)
+        Q = (rng.randn(I, d) * np.exp2(rng.randint(-20, 7, size=(I, d)))).astype(np.float32)
+    else:
+        P = (rng.randn(U, d) * kind).astype(np.float32)
+        Q = (rng.randn(I, d) * kind).astype(np.float32)
+    return P, Q
+
+
+@pytest.mark.parametrize("d", [8, 16, 24, 32, 48, 50, 64])
+@pytest.mark.parametrize("kind", [0.01, 1.0, 300.0, "wide"])
+def test_bounded_filter_stays_within_its_bound(d, kind):
+    """csrc/score_bf16.hip: every approximate tile maximum lies within eps[row] = kappa(d)·||u||·max||i|| of the fp32
+    chain's maximum (nrhip_score_tilemax without train lists: exact).  kappa carries a factor 1.5 over the derivation,
+    so no error may exceed 2/3 of the bound; measured: 0.07 (d = 64) to 0.30 (d = 8, where Cauchy-Schwarz is tight).  Pad tiles agree (-inf), user subsets and partial batches included."""
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(d * 7 + (11 if kind == "wide" else int(kind * 100)))
+    U, I = 333, 4133
+    P, Q = _spread_tables(rng, U, I, d, kind)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    users = torch.from_numpy(rng.permutation(U)[:300].astype(np.int32)).cuda()
+    gemm, filt = E.ScoreGemm(Qd, 512), E.ScoreFilter(Qd, 512)
+    n_t = 2 * ((I + 63) // 64)
+    mld = (n_t + 3) // 4 * 4
+    exact = torch.empty((300, mld), dtype=torch.float32, device="cuda")
+    E.call("nrhip_score_tilemax", E._ptr(Pd), Pd.stride(0), E._ptr(users), 300, I, d, None, None, E._ptr(exact),
+           exact.stride(0), E._ptr(gemm.ws), gemm.ws.numel(), E._stream())
+    M, eps = filt.tile_maxima(Pd, users)
+    a, b, e = exact.cpu().numpy()[:, :n_t], M.cpu().numpy()[:, :n_t], eps.cpu().numpy()
+    assert np.array_equal(np.isneginf(a), np.isneginf(b))
+    assert np.isneginf(a[:, (I + 31) // 32:]).all() and np.isfinite(a[:, :(I + 31) // 32]).all()
+    fin = np.isfinite(a)
+    err = np.where(fin, np.abs(np.where(fin, a, 0) - np.where(fin, b, 0)), 0.0)
+    un = np.linalg.norm(P[users.cpu().numpy()].astype(np.float64), axis=1)
+    imax = np.linalg.norm(Q.astype(np.float64), axis=1).max()
+    np.testing.assert_allclose(e, filt.kappa * un * imax, rtol=1e-5)
+    assert (err <= 0.6 * e[:, None]).all(), "worst error / bound = %.3f" % (err / e[:, None]).max()
+
+
+@pytest.mark.parametrize("d,clustered,extra", [(64, False, 2), (50, False, 0), (16, True, 2), (32, True, 1)])
+def test_bounded_search_ranks_exactly_what_the_fp32_search_ranks(d, clustered, extra):
+    """FullRankEvaluator(search='bf16') == search='fp32' == the materialised path, per-user metric rows bit for bit.
+    `clustered`: items that are tiny perturbations of each other, spread over many tiles — the gaps between the best
+    scores fall below the bound, the certificate fails, the rows are redone from fp32 rows (n_flagged > 0)."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(d + 5)
+    U, I = 600, 6000
+    P = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.1).astype(np.float32)
+    if clustered:
+        base = Q[:60].copy()
+        for c in range(100):                               # 100 near-copies of 60 items, scattered over the tiles
+            Q[c * 60:(c + 1) * 60] = base * (1.0 + rng.randn(60, 1).astype(np.float32) * 1e-7)
+        Q = Q[rng.permutation(I)]
+    tr = sp.random(U, I, 0.01, random_state=1, format="lil", dtype=np.float32)
+    for u in range(0, U, 3):
+        tr[u, np.argsort(-(P[u] @ Q.T))[:rng.randint(1, 30)]] = 1.0
+    tr = tr.tocsr(); tr.data[:] = 1.0; tr.sort_indices()
+    te = sp.random(U, I, 0.004, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    users = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    ud = torch.from_numpy(users).cuda()
+    full = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, pruned=False)
+    exact = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, search="fp32")
+    fast = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, search="bf16", extra_tiles=extra)
+    a = full.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    b = exact.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    c = fast.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    assert exact.search_used == "fp32" and fast.search_used == "bf16"
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    if clustered:
+        assert fast.n_flagged > 0
+    else:
+        assert fast.n_flagged <= len(users) // 20
+    # the float64 means (one device->host copy, flagged rows redone on demand) agree as well
+    np.testing.assert_array_equal(exact.evaluate_factors(Pd, Qd, ud), fast.evaluate_factors(Pd, Qd, ud))
+
+
+def test_bounded_search_falls_back_where_it_is_not_built():
+    """d > 64 and evaluations without a strike plan (repeated users) take the fp32 search; an unknown name is refused."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(3)
+    U, I, d = 100, 3000, 96
+    P, Q = (rng.randn(U, d) * 0.1).astype(np.float32), (rng.randn(I, d) * 0.1).astype(np.float32)
+    tr = sp.random(U, I, 0.01, random_state=1, format="csr", dtype=np.float32); tr.data[:] = 1.0
+    te = sp.random(U, I, 0.01, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    users = torch.from_numpy(np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)).cuda()
+    ev = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=64)
+    ref = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=64, pruned=False)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    np.testing.assert_array_equal(ev.evaluate_factors(Pd, Qd, users, exact_mean=True),
+                                  ref.evaluate_factors(Pd, Qd, users, exact_mean=True))
+    assert ev.search_used == "fp32"
+    assert not E.ScoreFilter.supports(96) and E.ScoreFilter.supports(64)
+    with pytest.raises(ValueError, match="search"):
+        FullRankEvaluator(trc, tec, [1], 10, search="fp16")
+    with pytest.raises(NotImplementedError):
+        E.ScoreFilter(Qd, 64)
