@@ -167,8 +167,11 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
  * (top_k + 1 <= n_keep <= 63) are rescored with the fp32 chain and ranked as in nrhip_eval_tiles; a row stands when its
  * top_k-th rescored score exceeds the largest maximum among the tiles NOT rescored by more than d_eps[row] — no item
  * outside the rescored tiles can then reach or tie the kept set in the fp32 chain — otherwise d_flag_out[row] = 1 and
- * the caller recomputes the row from a full fp32 score row (as for ties).  evaluate.h:23-50 stays the definition. */
-int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int top_k, int n_keep, size_t* bytes);
+ * the caller recomputes the row from a full fp32 score row (as for ties).  evaluate.h:23-50 stays the definition.
+ * d_eps = NULL: the maxima are exact (nrhip_score_tilemax), n_keep = top_k + 1, nrhip_eval_tiles' rule.  The rescoring
+ * runs grouped by tile (32 users of one tile per wave on the fp32 matrix cores: the item tile is read once per 32
+ * users, not once per user) where the shape allows; same scores bit for bit. */
+int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int cols, int top_k, int n_keep, size_t* bytes);
 int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, int n_keep, const float* d_P,
                              int64_t ldp, const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
                              const int64_t* d_tr_indptr, const int32_t* d_tr_indices,

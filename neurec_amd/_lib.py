@@ -123,7 +123,7 @@ SIGNATURES = {
     "nrhip_score_filter_tilemax": [p, i64, p, i32, i32, i32, p, i64, p, p, sz, i32, p],
     "nrhip_eval_tiles_workspace_bytes": [i32, i32, psz],
     "nrhip_eval_tiles": [p, i64, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
-    "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, psz],
+    "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, i32, psz],
     "nrhip_eval_tiles_bounded": [p, i64, p, i32, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],

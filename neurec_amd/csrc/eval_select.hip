@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
   wave_lds_sync();
   // the scan is a chain of dependent loads unless the row is fetched ahead: 8 groups of 64 scores
   // in flight, offered to the heap in index order
-  constexpr int kAhead = 8;
+  constexpr int kAhead = 32;                                   // (8: 320 us for a 41 k row, one round trip per 512 scores)
   for (int base0 = m; base0 < cols; base0 += kAhead * NR_WAVE) {
     float vv[kAhead];
 #pragma unroll
@@ -610,6 +610,171 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Rescoring grouped by TILE (the form nrhip_eval_tiles_bounded runs).  rescore_tiles_kernel above reads, per user,
+// n_keep item tiles of 8 KB each from the L2s — 5.6 GB at the gowalla shape, the largest kernel of an evaluation
+// (0.43 ms) although the arithmetic is 2.8 GFLOP.  Here the (row, tile) pairs are bucketed by tile first and a wave
+// takes 32 pairs of ONE tile: the item tile is loaded once per 32 users and the scores come from the same
+// v_mfma_f32_32x32x2_f32 chain as the scoring loop (bit for bit the k-ascending fmaf chain, as tilemax_fix_kernel).
+//   tile_pairs_kernel     the (row, slot) pairs counted per tile in LDS, ONE global reservation per (workgroup, tile)
+//                         — a tile that every user chose costs a workgroup one atomic, not one per row — then
+//                         written to the tile's bucket as (row << 6 | slot)
+//   chunk_scan / _list    buckets cut into chunks of <= 32 pairs
+//   rescore_pairs_kernel  wave per chunk: gather the 32 user rows, 32 x 32 scores, float4 stores into C[row][slot]
+//   strike_compact_kernel train items of the row -> -inf (uni_evaluator.py:140-143)
+// The order of the pairs inside a bucket depends on the atomics; no result does (every pair is independent).
+// ----------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kPairRows = 256;                                 // rows per workgroup of tile_pairs_kernel
+constexpr int kMaxGroupedTiles = 12288;                        // LDS histogram: 4 bytes per 32-item tile
+
+// A thread per (row, slot) pair; slot = the tile's place in the selection's order (descending maxima).  The compact
+// row C[row][slot][32] is therefore NOT in item order — which only matters for the index tie-break of the second
+// selection, and every row with a tie among its cut + 1 best compact scores is flagged and redone from a full row.
+// (Measured on the way: a wave per row with the slots sorted by tile id: 57 us at 64 rows per workgroup — 600 k global
+// reservations — and 99 us at 256 — 64 dependent iterations per wave; this form: one reservation per (workgroup, tile).)
+__global__ __launch_bounds__(256) void tile_pairs_kernel(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep,
+                                                         int rows, int n_tiles, int32_t* __restrict__ tilemap,
+                                                         int32_t* __restrict__ gcnt, uint32_t* __restrict__ bucket) {
+  extern __shared__ int32_t s_hist[];                          // [n_tiles]: counts, then the bucket cursors
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n_tiles; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  const int r0 = blockIdx.x * kPairRows;
+  const int n_pairs = min(kPairRows, rows - r0) * n_keep;
+  for (int p = tid; p < n_pairs; p += 256) {
+    int t = tiles[(int64_t)(r0 + p / n_keep) * tiles_ld + p % n_keep];
+    if ((unsigned)t >= (unsigned)n_tiles) t = 0;               // NaN tables: garbage ids stay in range
+    atomicAdd(&s_hist[t], 1);
+  }
+  __syncthreads();
+  for (int t = tid; t < n_tiles; t += 256) {
+    const int c = s_hist[t];
+    if (c) s_hist[t] = atomicAdd(&gcnt[t], c);                 // ONE reservation per (workgroup, tile)
+  }
+  __syncthreads();
+  for (int p = tid; p < n_pairs; p += 256) {
+    const int row = r0 + p / n_keep, slot = p % n_keep;
+    int t = tiles[(int64_t)row * tiles_ld + slot];
+    if ((unsigned)t >= (unsigned)n_tiles) t = 0;
+    tilemap[(int64_t)row * n_keep + slot] = t;
+    const int at = atomicAdd(&s_hist[t], 1);
+    bucket[(int64_t)t * rows + at] = ((uint32_t)row << 6) | (uint32_t)slot;
+  }
+}
+
+// chunk_begin[t] = sum over t' < t of ceil(cnt[t'] / 32); chunk_begin[n_tiles] = the number of chunks.  One workgroup.
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(const int32_t* __restrict__ gcnt, int n_tiles,
+                                                          int32_t* __restrict__ chunk_begin) {
+  __shared__ int32_t s_sum[1024];
+  const int tid = threadIdx.x;
+  const int per = (n_tiles + 1023) / 1024;
+  const int b = tid * per, e = min(n_tiles, b + per);
+  int local = 0;
+  for (int t = b; t < e; ++t) local += (gcnt[t] + 31) >> 5;
+  s_sum[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? s_sum[tid - off] : 0;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  int run = s_sum[tid] - local;
+  for (int t = b; t < e; ++t) { chunk_begin[t] = run; run += (gcnt[t] + 31) >> 5; }
+  if (tid == 1023) chunk_begin[n_tiles] = s_sum[1023];
+}
+__global__ __launch_bounds__(256) void chunk_list_kernel(const int32_t* __restrict__ gcnt,
+                                                         const int32_t* __restrict__ chunk_begin, int n_tiles,
+                                                         int2* __restrict__ chunks) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_tiles) return;
+  const int n = (gcnt[t] + 31) >> 5, base = chunk_begin[t];
+  for (int c = lane; c < n; c += 64) chunks[base + c] = make_int2(t, 32 * c);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void rescore_pairs_kernel(
+    const float* __restrict__ P, int64_t ldp, int d, const float* __restrict__ QT, int64_t ipad, int cols,
+    const int32_t* __restrict__ users, int rows, const int32_t* __restrict__ gcnt,
+    const int32_t* __restrict__ chunk_begin, int n_tiles, const int2* __restrict__ chunks,
+    const uint32_t* __restrict__ bucket, float* __restrict__ C, int64_t cld) {
+  constexpr int DP = 2 * KS;
+  __shared__ float sB[4][32][DP + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x * 4 + wave;
+  if (c >= chunk_begin[n_tiles]) return;
+  const int2 ck = chunks[c];
+  const int t = ck.x;
+  const int n = min(32, gcnt[t] - ck.y);
+  uint32_t pair = 0u;
+  if (j < n) pair = bucket[(int64_t)t * rows + ck.y + j];
+  const int row = (int)(pair >> 6), slot = (int)(pair & 63u);
+  const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
+  float a[KS], b[KS];
+  const float* q = QT + (int64_t)h * ipad + (int64_t)t * 32 + j;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) a[s] = q[(int64_t)2 * s * ipad];
+  {
+    // the 32 factor rows, one coalesced row per load, all in flight, into this wave's LDS slice
+    float v0[32], v1[DP > 64 ? 32 : 1];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float* pr = P + __shfl(u, r, 64) * ldp;
+      v0[r] = lane < d ? pr[lane] : 0.f;
+      if (DP > 64) v1[r] = lane + 64 < d ? pr[lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      if (lane < DP) sB[wave][r][lane] = v0[r];
+      if (DP > 64) sB[wave][r][lane + 64] = v1[r];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wave_lds_sync();
+#pragma unroll
+  for (int s = 0; s < KS; ++s) b[s] = sB[wave][j][2 * s + h];
+  f32x16 acc = {0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  if (j >= n) return;
+  // items of this lane: 32 t + 8 g + 4 h + 0..3 for g = 0..3 (accumulator registers 4 g .. 4 g + 3)
+  float* crow = C + (int64_t)row * cld + slot * kTileItems + 4 * h;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int item = t * kTileItems + 8 * g + 4 * h;
+    float4 v;
+    v.x = item + 0 < cols ? acc[4 * g + 0] : -INFINITY;
+    v.y = item + 1 < cols ? acc[4 * g + 1] : -INFINITY;
+    v.z = item + 2 < cols ? acc[4 * g + 2] : -INFINITY;
+    v.w = item + 3 < cols ? acc[4 * g + 3] : -INFINITY;
+    *reinterpret_cast<float4*>(crow + 8 * g) = v;
+  }
+}
+
+// the user's train items that fall in a rescored tile -> -inf (one wave per row)
+__global__ __launch_bounds__(256) void strike_compact_kernel(const int32_t* __restrict__ users, int rows, int n_keep,
+                                                             const int32_t* __restrict__ tilemap,
+                                                             const int64_t* __restrict__ tr_indptr,
+                                                             const int32_t* __restrict__ tr_indices,
+                                                             float* __restrict__ C, int64_t cld) {
+  __shared__ int32_t s_map[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  if (lane < n_keep) s_map[wave][lane] = tilemap[(int64_t)row * n_keep + lane];
+  wave_lds_sync();
+  const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
+  float* crow = C + (int64_t)row * cld;
+  const int64_t tb = tr_indptr[u], te = tr_indptr[u + 1];
+  for (int64_t t = tb + lane; t < te; t += NR_WAVE) {
+    const int item = tr_indices[t], tile = item / kTileItems;
+    for (int k = 0; k < n_keep; ++k)                           // (slots are in selection order, not sorted)
+      if (s_map[wave][k] == tile) crow[k * kTileItems + (item % kTileItems)] = -INFINITY;
+  }
+}
+
 // compact column -> item id; boundary check on the tile maxima; flag_out |= select's tie flag
 __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ rank,
                                                          const int32_t* __restrict__ sel_flag,
@@ -668,7 +833,15 @@ __global__ void colsum_stage2(const double* __restrict__ partial, int n_slabs, i
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   double acc = 0.0;
-  for (int s = 0; s < n_slabs; ++s) acc += partial[(int64_t)s * cols + c];
+  int s = 0;
+  for (; s + 16 <= n_slabs; s += 16) {             // 16 loads in flight, added in slab order (one load per add was
+    double v[16];                                  // a chain of n_slabs memory round trips: 29 us for 117 slabs)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = partial[(int64_t)(s + i) * cols + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += v[i];
+  }
+  for (; s < n_slabs; ++s) acc += partial[(int64_t)s * cols + c];
   out[c] = acc;
 }
 
@@ -870,6 +1043,26 @@ int nrhip_eval_scores_any_k(const float* d_scores, int64_t ld, int rows, int col
 }
 
 /* Workspace of nrhip_eval_tiles for `rows` rows (includes the selection scratch). */
+// tile-grouped rescoring (rescore_pairs_kernel): extra workspace behind the per-row form's; 0 = not used at this shape
+// (more tiles than the LDS histogram holds, or buckets beyond 1 GB: the per-row kernel runs)
+static int g_rescore_grouped = -1;
+static bool rescore_grouped_enabled() {
+  if (g_rescore_grouped < 0) {
+    const char* e = getenv("NEUREC_RESCORE_GROUPED");
+    g_rescore_grouped = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_rescore_grouped != 0;
+}
+static size_t grouped_extra_bytes(int rows, int cols, int n_keep) {
+  const size_t r = (size_t)(rows > 0 ? rows : 1);
+  const size_t n_tiles = 2 * (((size_t)cols + 63) / 64);
+  if (!rescore_grouped_enabled() || n_tiles > (size_t)kMaxGroupedTiles || n_tiles * r * 4 > ((size_t)1 << 30) ||
+      r >= ((size_t)1 << 26))
+    return 0;
+  const size_t max_chunks = r * (size_t)n_keep / 32 + n_tiles + 1;
+  return nr_align_up(n_tiles * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
+         nr_align_up(n_tiles * r * 4, 256);
+}
 static size_t eval_tiles_ws_bytes(int rows, int n_keep) {
   const size_t r = (size_t)(rows > 0 ? rows : 1);
   return eval_ws_bytes((int)r) + nr_align_up(r * (size_t)(n_keep + 1) * 4, 256) +
@@ -884,10 +1077,11 @@ int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes) {
   return NR_OK;
 }
 
-int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int top_k, int n_keep, size_t* bytes) {
-  NR_REQUIRE(bytes && rows >= 0 && top_k >= 1 && n_keep >= top_k + 1 && n_keep <= 63, NR_ERR_ARG,
-             "eval_tiles_bounded_workspace_bytes: rows=%d top_k=%d n_keep=%d (top_k + 1 .. 63)", rows, top_k, n_keep);
-  *bytes = eval_tiles_ws_bytes(rows, n_keep);
+int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int cols, int top_k, int n_keep, size_t* bytes) {
+  NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && top_k >= 1 && n_keep >= top_k + 1 && n_keep <= 63, NR_ERR_ARG,
+             "eval_tiles_bounded_workspace_bytes: rows=%d cols=%d top_k=%d n_keep=%d (top_k + 1 .. 63)", rows, cols,
+             top_k, n_keep);
+  *bytes = eval_tiles_ws_bytes(rows, n_keep) + grouped_extra_bytes(rows, cols, n_keep);
   return NR_OK;
 }
 
@@ -901,8 +1095,8 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
                            const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
                            const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
                            const int32_t* metric_ids_host, int n_metric, int top_k, int n_keep,
-                           const float* d_eps, float* d_out, int32_t* d_flag_out, void* d_ws, size_t ws_bytes,
-                           void* stream) {
+                           const float* d_eps, bool grouped, float* d_out, int32_t* d_flag_out, void* d_ws,
+                           size_t ws_bytes, void* stream) {
   NR_REQUIRE(d_M && d_P && d_gemm_ws && d_tr_indptr && d_tr_indices && d_truth_indptr && d_truth_indices &&
                  metric_ids_host && d_out && d_flag_out && d_ws,
              NR_ERR_ARG, "eval_tiles: null pointer argument");
@@ -928,8 +1122,9 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     mids.id[i] = metric_ids_host[i];
   }
   if (rows == 0) return NR_OK;
-  NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, n_keep), NR_ERR_WORKSPACE,
-             "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, n_keep));
+  const size_t extra = grouped ? grouped_extra_bytes(rows, cols, n_keep) : 0;
+  NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, n_keep) + extra, NR_ERR_WORKSPACE,
+             "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, n_keep) + extra);
   hipStream_t st = (hipStream_t)stream;
   { const int rc = select_knob_once(); if (rc != NR_OK) return rc; }
   const int tiles_ld = n_keep + 1;
@@ -954,11 +1149,48 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
                        rows, tiles_ld, tiles);
     NR_LAUNCH_CHECK();
   }
-  // 2. rescore the top_k + 1 chosen tiles, train items struck out
-  hipLaunchKernelGGL(rescore_tiles_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_P, ldp,
-                     qt, (int64_t)ipad, d, d_users, rows, cols, tiles, tiles_ld, n_keep, d_tr_indptr,
-                     d_tr_indices, C, cld, tilemap);
-  NR_LAUNCH_CHECK();
+  // 2. rescore the chosen tiles, train items struck out
+  if (extra) {
+    char* x = (char*)d_ws + eval_tiles_ws_bytes(rows, n_keep);
+    int32_t* gcnt = (int32_t*)x;        x += nr_align_up((size_t)n_tiles * 4, 256);
+    int32_t* chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
+    int2* chunks = (int2*)x;
+    const size_t max_chunks = (size_t)rows * n_keep / 32 + n_tiles + 1;
+    x += nr_align_up(max_chunks * 8, 256);
+    uint32_t* bucket = (uint32_t*)x;
+    NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, (size_t)n_tiles * 4, st));
+    hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
+                       (size_t)n_tiles * 4, st, tiles, tiles_ld, n_keep, rows, n_tiles, tilemap,
+                       gcnt, bucket);
+    NR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, gcnt, n_tiles, chunk_begin);
+    NR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_list_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, gcnt, chunk_begin, n_tiles,
+                       chunks);
+    NR_LAUNCH_CHECK();
+    const dim3 pgrid((unsigned)((max_chunks + 3) / 4));
+    const int dp = d <= 16 ? 16 : d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : 128;
+#define NR_PAIRS_CASE(KS)                                                                                        \
+  hipLaunchKernelGGL(rescore_pairs_kernel<KS>, pgrid, dim3(256), 0, st, d_P, ldp, d, qt, (int64_t)ipad, cols,     \
+                     d_users, rows, gcnt, chunk_begin, n_tiles, chunks, bucket, C, cld)
+    switch (dp) {
+      case 16: NR_PAIRS_CASE(8); break;
+      case 32: NR_PAIRS_CASE(16); break;
+      case 48: NR_PAIRS_CASE(24); break;
+      case 64: NR_PAIRS_CASE(32); break;
+      default: NR_PAIRS_CASE(64); break;
+    }
+#undef NR_PAIRS_CASE
+    NR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(strike_compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, d_users, rows, n_keep, tilemap,
+                       d_tr_indptr, d_tr_indices, C, cld);
+    NR_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(rescore_tiles_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_P, ldp,
+                       qt, (int64_t)ipad, d, d_users, rows, cols, tiles, tiles_ld, n_keep, d_tr_indptr,
+                       d_tr_indices, C, cld, tilemap);
+    NR_LAUNCH_CHECK();
+  }
   // 3. rank the compact rows (no in-place exact path: a tie needs the full row)
   const int ccols = (int)cld;
   const int sort_len = (2 * top_k < ccols) ? 2 * top_k : ccols;
@@ -987,22 +1219,25 @@ int nrhip_eval_tiles(const float* d_M, int64_t mld, const float* d_P, int64_t ld
                      int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream) {
   return eval_tiles_impl(d_M, mld, d_P, ldp, d_gemm_ws, d, d_users, rows, cols, d_tr_indptr, d_tr_indices,
                          d_truth_indptr, d_truth_indices, metric_ids_host, n_metric, top_k, top_k + 1, nullptr,
-                         d_out, d_flag_out, d_ws, ws_bytes, stream);
+                         false, d_out, d_flag_out, d_ws, ws_bytes, stream);
 }
 
 /* nrhip_eval_tiles for maxima that are only bounded (nrhip_score_filter_tilemax + nrhip_score_tilemax_fix):
  * the n_keep (>= top_k + 1) best tiles are rescored with the fp32 chain; a row stands when its top_k-th rescored
- * score exceeds the largest maximum among the other tiles by more than d_eps[row], else it is flagged. */
+ * score exceeds the largest maximum among the other tiles by more than d_eps[row], else it is flagged.
+ * d_eps = NULL: exact maxima (nrhip_score_tilemax), nrhip_eval_tiles' rule, n_keep = top_k + 1.  Either way the
+ * rescoring runs grouped by tile (rescore_pairs_kernel) where the shape allows. */
 int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, int n_keep, const float* d_P,
                              int64_t ldp, const void* d_gemm_ws, int d, const int32_t* d_users, int rows, int cols,
                              const int64_t* d_tr_indptr, const int32_t* d_tr_indices,
                              const int64_t* d_truth_indptr, const int32_t* d_truth_indices,
                              const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
                              int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream) {
-  NR_REQUIRE(d_eps, NR_ERR_ARG, "eval_tiles_bounded: null bound");
+  NR_REQUIRE(d_eps || n_keep == top_k + 1, NR_ERR_ARG,
+             "eval_tiles_bounded: without a bound the maxima are exact and n_keep is top_k + 1");
   return eval_tiles_impl(d_M, mld, d_P, ldp, d_gemm_ws, d, d_users, rows, cols, d_tr_indptr, d_tr_indices,
-                         d_truth_indptr, d_truth_indices, metric_ids_host, n_metric, top_k, n_keep, d_eps, d_out,
-                         d_flag_out, d_ws, ws_bytes, stream);
+                         d_truth_indptr, d_truth_indices, metric_ids_host, n_metric, top_k, n_keep, d_eps, true,
+                         d_out, d_flag_out, d_ws, ws_bytes, stream);
 }
 
 int nrhip_arg_topk(const float* d_scores, int64_t ld, int rows, int cols, int top_k,

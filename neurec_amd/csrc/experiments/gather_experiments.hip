@@ -606,6 +606,38 @@ __device__ __forceinline__ float exp_role_work(int role, int iters, float seed) 
       for (int s = 0; s < 64; ++s) x = __builtin_fmaf(__builtin_amdgcn_exp2f(x), 1e-3f, -0.5f);
     }
     r = x;
+  } else if (role == 4 || role == 5) {
+    // 16 bf16 MFMAs 32x32x16 over four independent accumulators; role 5: four independent fmas after every MFMA,
+    // issued by the SAME wave (does a wave's VALU work run in the shadow of its own MFMAs?)
+    typedef __attribute__((ext_vector_type(8))) __bf16 exp_bf16x8;
+    exp_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    uint4 ua = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    ua.x += (uint32_t)(seed * 3.f);
+    const exp_bf16x8 a = __builtin_bit_cast(exp_bf16x8, ua), b = a;
+    float x0 = seed, x1 = seed + 1.f, x2 = seed + 2.f, x3 = seed + 3.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        if (role == 5) { x0 = __builtin_fmaf(x0, 1.0000001f, 1e-9f); x1 = __builtin_fmaf(x1, 1.0000001f, 1e-9f); x2 = __builtin_fmaf(x2, 1.0000001f, 1e-9f); x3 = __builtin_fmaf(x3, 1.0000001f, 1e-9f); }
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        if (role == 5) { x0 = __builtin_fmaf(x0, 1.0000001f, 1e-9f); x1 = __builtin_fmaf(x1, 1.0000001f, 1e-9f); x2 = __builtin_fmaf(x2, 1.0000001f, 1e-9f); x3 = __builtin_fmaf(x3, 1.0000001f, 1e-9f); }
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+        if (role == 5) { x0 = __builtin_fmaf(x0, 1.0000001f, 1e-9f); x1 = __builtin_fmaf(x1, 1.0000001f, 1e-9f); x2 = __builtin_fmaf(x2, 1.0000001f, 1e-9f); x3 = __builtin_fmaf(x3, 1.0000001f, 1e-9f); }
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+        if (role == 5) { x0 = __builtin_fmaf(x0, 1.0000001f, 1e-9f); x1 = __builtin_fmaf(x1, 1.0000001f, 1e-9f); x2 = __builtin_fmaf(x2, 1.0000001f, 1e-9f); x3 = __builtin_fmaf(x3, 1.0000001f, 1e-9f); }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += c0[i] + c1[i] + c2[i] + c3[i];
+    r += x0 + x1 + x2 + x3;
+  } else if (role == 6) {
+    float x0 = seed, x1 = seed + 1.f, x2 = seed + 2.f, x3 = seed + 3.f;   // the 64 fmas of role 5 alone
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { x0 = __builtin_fmaf(x0, 1.0000001f, 1e-9f); x1 = __builtin_fmaf(x1, 1.0000001f, 1e-9f); x2 = __builtin_fmaf(x2, 1.0000001f, 1e-9f); x3 = __builtin_fmaf(x3, 1.0000001f, 1e-9f); }
+    }
+    r = x0 + x1 + x2 + x3;
   }
   return r;
 }

@@ -104,12 +104,18 @@ struct BSet {
 
 // One wave: 64 users (two 32-user column blocks, operands in registers for the whole chunk) against the chunk's
 // 64-item tiles; the four waves of a workgroup take four user panels against the same tiles (shared in L1 / L2).
-// Three B register sets: the loads of tile t + 2 are issued before tile t's MFMAs (a tile is ~0.75 us).
+// Software pipeline, branch-free: while the 48 MFMAs of tile t + 1 run into one accumulator set, the VALU reduces the
+// other set (tile t: 64 accumulator reads, the maxima, the half exchange) and stores it — a wave issues its VALU work
+// in the shadow of its own MFMAs (32 clk each), there is no second wave on the SIMD to do it.  Three B register sets
+// (loads of tile t + 2 issued before tile t's MFMAs), two accumulator sets: the body is unrolled over 6 phases.
+// Stores without a branch: every lane stores one float2 (half 0: user block 0, half 1: user block 1), rows / tiles
+// that do not exist go to a per-lane sink.  The partial last tile (pad columns) runs after the loop, unpipelined.
 template <int KS16>
 __global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __restrict__ PB,
                                                               const uint4* __restrict__ QB, int bpad, int rows,
                                                               int cols, int n_tiles, float* __restrict__ M,
-                                                              int64_t mld, int tiles_per_chunk) {
+                                                              int64_t mld, int tiles_per_chunk,
+                                                              float* __restrict__ sink) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int ub0 = (blockIdx.x * 4 + wave) * 2;
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __res
   const int t_begin = blockIdx.y * tiles_per_chunk;
   const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
   if (t_begin >= t_end) return;
+  const int t_stop = min(t_end, cols / 64);                   // full tiles: the pipelined loop
 
   bf16x8 ah[2][KS16], al[2][KS16];
 #pragma unroll
@@ -126,7 +133,10 @@ __global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __res
       ah[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 0) * KS16 + s) * 64 + lane]);
       al[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 1) * KS16 + s) * 64 + lane]);
     }
-  const int ra = ub0 * 32 + j, rb = ra + 32;
+  const int my_row = ub0 * 32 + 32 * h + j;                   // the row this lane stores
+  float* const my_sink = sink + 2 * lane;
+  float* const my_M = M + (int64_t)my_row * mld;
+  const bool row_ok = my_row < rows;
 
   auto load_b = [&](int t, BSet<KS16>& b) {
     const uint4* q = QB + (int64_t)min(t, t_end - 1) * (4 * KS16 * 64) + lane;
@@ -137,74 +147,79 @@ __global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __res
 #pragma unroll
         for (int s = 0; s < KS16; ++s) b.v[x][term][s] = q[((x * 2 + term) * KS16 + s) * 64];
   };
-  auto tile = [&](int t, const BSet<KS16>& b) {
-    f32x16 c[2][2];                                           // [item block X (rows)][user block Y (columns)]
+  // MFMA group g of a tile (g = 0 .. 3 KS16 - 1): the four accumulators, one k-step of one term; small terms first
+  auto mfma_group = [&](int g, const BSet<KS16>& b, f32x16 (&c)[2][2]) {
+    const int term = g / KS16, s = g % KS16;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        if (term == 0)
+          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][1][s]), ah[y][s], c[x][y], 0, 0, 0);
+        else if (term == 1)
+          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), al[y][s], c[x][y], 0, 0, 0);
+        else
+          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), ah[y][s], c[x][y], 0, 0, 0);
+      }
+  };
+  auto zero = [&](f32x16 (&c)[2][2]) {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int y = 0; y < 2; ++y)
 #pragma unroll
         for (int i = 0; i < 16; ++i) c[x][y][i] = 0.f;
-    // the small terms first; the four accumulators interleaved (independent chains)
-#pragma unroll
-    for (int s = 0; s < KS16; ++s)
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][1][s]), ah[y][s],
-                                                            c[x][y], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS16; ++s)
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), al[y][s],
-                                                            c[x][y], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS16; ++s)
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-          c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), ah[y][s],
-                                                            c[x][y], 0, 0, 0);
-    float m[2][2];
-    const int it = t * 64;
-    if (it + 64 > cols) {                                     // the last tile: pad columns score 0, not -inf
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        uint32_t skip = 0u;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-          if (it + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h >= cols) skip |= 1u << reg;
-        m[x][0] = max16_skip(c[x][0], skip);
-        m[x][1] = max16_skip(c[x][1], skip);
-      }
-    } else {
-#pragma unroll
-      for (int x = 0; x < 2; ++x) { m[x][0] = max16(c[x][0]); m[x][1] = max16(c[x][1]); }
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x) { m[x][0] = max_halves(m[x][0]); m[x][1] = max_halves(m[x][1]); }
-    if (h == 0 && t < t_end) {
-      if (ra < rows) *reinterpret_cast<float2*>(M + (int64_t)ra * mld + 2 * t) = make_float2(m[0][0], m[1][0]);
-      if (rb < rows) *reinterpret_cast<float2*>(M + (int64_t)rb * mld + 2 * t) = make_float2(m[0][1], m[1][1]);
-    }
+  };
+  // the finished accumulator set of tile t: maxima, half exchange, store
+  auto reduce_store = [&](int t, const f32x16 (&c)[2][2]) {
+    float m00 = max_halves(max16(c[0][0])), m10 = max_halves(max16(c[1][0]));
+    float m01 = max_halves(max16(c[0][1])), m11 = max_halves(max16(c[1][1]));
+    const float2 v = h ? make_float2(m01, m11) : make_float2(m00, m10);
+    float* dst = (row_ok && t < t_stop) ? my_M + 2 * t : my_sink;
+    *reinterpret_cast<float2*>(dst) = v;
   };
 
-  BSet<KS16> b0, b1, b2;
-  load_b(t_begin, b0);
-  load_b(t_begin + 1, b1);
-  // (tiles past the chunk's end are recomputed from the clamped loads and not stored: no branch around a load)
-  for (int t = t_begin; t < t_end; t += 3) {
-    load_b(t + 2, b2);
-    tile(t, b0);
-    load_b(t + 3, b0);
-    tile(t + 1, b1);
-    load_b(t + 4, b1);
-    tile(t + 2, b2);
+  if (t_begin < t_stop) {
+    BSet<KS16> b[3];
+    f32x16 c[2][2][2];
+    load_b(t_begin, b[0]);
+    load_b(t_begin + 1, b[1]);
+    load_b(t_begin + 2, b[2]);
+    zero(c[0]);
+#pragma unroll
+    for (int g = 0; g < 3 * KS16; ++g) mfma_group(g, b[0], c[0]);
+    // phase ph: tile t + ph is finished in c[ph & 1]; tile t + ph + 1 is computed from b[(ph + 1) % 3] into the
+    // other set while this one is reduced; b[ph % 3] is free again and takes tile t + ph + 3
+    for (int t = t_begin; t < t_stop; t += 6) {
+#pragma unroll
+      for (int ph = 0; ph < 6; ++ph) {
+        load_b(t + ph + 3, b[ph % 3]);
+        zero(c[(ph + 1) & 1]);
+#pragma unroll
+        for (int g = 0; g < 3 * KS16; ++g) mfma_group(g, b[(ph + 1) % 3], c[(ph + 1) & 1]);
+        reduce_store(t + ph, c[ph & 1]);
+      }
+    }
+  }
+  if (t_stop < t_end) {                                       // the partial last tile: pad columns excluded
+    const int t = t_stop, it = t * 64;
+    BSet<KS16> b;
+    f32x16 c[2][2];
+    load_b(t, b);
+    zero(c);
+#pragma unroll
+    for (int g = 0; g < 3 * KS16; ++g) mfma_group(g, b, c);
+    float m[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      uint32_t skip = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if (it + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h >= cols) skip |= 1u << reg;
+      m[x][0] = max_halves(max16_skip(c[x][0], skip));
+      m[x][1] = max_halves(max16_skip(c[x][1], skip));
+    }
+    if (row_ok) *reinterpret_cast<float2*>(my_M + 2 * t) = h ? make_float2(m[0][1], m[1][1]) : make_float2(m[0][0], m[1][0]);
   }
 }
 
@@ -221,6 +236,7 @@ struct FilterWs {
   uint4* PB;
   float* unorm;
   float* inorm_max;
+  float* sink;                                                // 64 float2: where stores of rows / tiles that do not exist go
   size_t q_bytes, p_bytes, n_bytes, total;
 };
 FilterWs carve(void* ws, int rows, int cols, int dp) {
@@ -232,7 +248,8 @@ FilterWs carve(void* ws, int rows, int cols, int dp) {
   f.PB = (uint4*)((char*)ws + f.q_bytes);
   f.unorm = (float*)((char*)ws + f.q_bytes + f.p_bytes);
   f.inorm_max = (float*)((char*)ws + f.q_bytes + f.p_bytes + f.n_bytes);
-  f.total = f.q_bytes + f.p_bytes + f.n_bytes + 256;
+  f.sink = f.inorm_max + 64;
+  f.total = f.q_bytes + f.p_bytes + f.n_bytes + 256 + 512;
   return f;
 }
 inline float kappa_of(int dp) {
@@ -302,12 +319,12 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
   const int bx = (bpad / 64 + 3) / 4;
   const int n_tiles = round_up64(cols) / 64;
   int tpc = (int)(((int64_t)n_tiles * bx + 2047) / 2048);
-  tpc = (tpc + 2) / 3 * 3;
-  if (tpc < 6) tpc = 6;
+  tpc = (tpc + 5) / 6 * 6;                                    // the pipelined body covers 6 tiles
   const int by = (n_tiles + tpc - 1) / tpc;
   dim3 grid(bx, by), block(256);
 #define NR_FILTER_CASE(K)                                                                                       \
-  hipLaunchKernelGGL(tilemax_bf16_kernel<K>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld, tpc)
+  hipLaunchKernelGGL(tilemax_bf16_kernel<K>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld, tpc, \
+                     f.sink)
   switch (ks16) {
     case 1: NR_FILTER_CASE(1); break;
     case 2: NR_FILTER_CASE(2); break;

@@ -397,21 +397,23 @@ _tiles_ws = Workspace()
 
 
 def eval_tiles(M, user_table, gemm, users, train_csr, truth_csr, metric_ids, top_k, out, flags, eps=None,
-               n_keep=None):
+               n_keep=None, grouped=True):
     """Pruned evaluation, level 2 (nrhip_eval_tiles): metric rows into `out`, tie flags into
     `flags` (int32 per row; flagged rows must be recomputed from full score rows).  `gemm` is the
     ScoreGemm whose prepared (k-major) item copy the rescoring reads.  With `eps` (ScoreFilter.tile_maxima) the maxima
     are bounded, not exact: `n_keep` tiles are rescored and a row stands only if its bound certifies the choice
-    (nrhip_eval_tiles_bounded)."""
+    (nrhip_eval_tiles_bounded).  `grouped`: the rescoring bucketed by tile (same scores; False = nrhip_eval_tiles'
+    per-row kernel, exact maxima only)."""
     rows = M.shape[0]
     nbytes = C.c_size_t(0)
     nm = len(metric_ids)
     ids = (C.c_int * nm)(*[int(m) for m in metric_ids])
-    if eps is not None:
-        n_keep = int(top_k + 1 if n_keep is None else n_keep)
-        call("nrhip_eval_tiles_bounded_workspace_bytes", rows, top_k, n_keep, C.byref(nbytes))
+    if eps is not None or grouped:
+        n_keep = int(top_k + 1 if n_keep is None or eps is None else n_keep)
+        call("nrhip_eval_tiles_bounded_workspace_bytes", rows, gemm.cols, top_k, n_keep, C.byref(nbytes))
         ws = _tiles_ws.get(nbytes.value)
-        call("nrhip_eval_tiles_bounded", C.c_void_p(M.data_ptr()), M.stride(0), _ptr(eps, torch.float32), n_keep,
+        call("nrhip_eval_tiles_bounded", C.c_void_p(M.data_ptr()), M.stride(0),
+             _ptr(eps, torch.float32, allow_none=True), n_keep,
              _ptr(user_table, torch.float32), user_table.stride(0), _ptr(gemm.ws), gemm.d,
              _ptr(users, torch.int32, allow_none=True), rows, gemm.cols,
              _ptr(train_csr.indptr), _ptr(train_csr.indices), _ptr(truth_csr.indptr),

@@ -15,7 +15,7 @@ fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 fn.restype = C.c_int
 out = torch.zeros(256 * 512, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-NAMES = {0: "idle", 1: "mfma x16", 2: "fma x256", 3: "exp x64"}
+NAMES = {0: "idle", 1: "mfma x16", 2: "fma x256", 3: "exp x64", 4: "bf16mfma x16", 5: "bf16mfma x16 + 64 fma (one wave)", 6: "fma x64 (4 chains)"}
 
 
 def timed(a, b, iters=2000):
@@ -32,3 +32,7 @@ def timed(a, b, iters=2000):
 print("us per iteration (one iteration = 16 dependent MFMA 32x32x2 f32 | 256 dependent fma | 64 dependent exp+fma)")
 for a, b in ((1, 0), (0, 2), (0, 3), (1, 1), (2, 2), (3, 3), (1, 2), (1, 3), (2, 3)):
     print("  waves 0-3: %-9s waves 4-7: %-9s  %.3f us" % (NAMES[a], NAMES[b], timed(a, b)))
+
+print("bf16 MFMA 32x32x16 (16 per iteration over four accumulators) and VALU")
+for a, b in ((4, 0), (0, 6), (5, 0), (4, 6), (4, 4), (5, 5), (4, 2)):
+    print("  waves 0-3: %-34s waves 4-7: %-18s  %.3f us" % (NAMES[a], NAMES[b], timed(a, b)))

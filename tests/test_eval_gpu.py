@@ -423,3 +423,40 @@ def test_bounded_search_falls_back_where_it_is_not_built():
         FullRankEvaluator(trc, tec, [1], 10, search="fp16")
     with pytest.raises(NotImplementedError):
         E.ScoreFilter(Qd, 64)
+
+
+@pytest.mark.parametrize("d,U,I", [(64, 700, 5000), (50, 300, 2500), (16, 257, 4133), (128, 130, 1000), (24, 90, 500)])
+def test_tile_grouped_rescoring_equals_the_per_row_kernel(d, U, I):
+    """nrhip_eval_tiles_bounded rescoring bucketed by tile (32 users of one tile per wave, fp32 MFMA chain) ==
+    nrhip_eval_tiles' one-wave-per-user fmaf chain: metric rows and flags identical — popular tiles that every user
+    picks (one bucket holding all rows), the partial last tile, users without train items."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(d + U)
+    P = (rng.randn(U, d) * 0.3).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.3).astype(np.float32)
+    Q[40:60] += 3.0 * P.mean(0) / max(np.linalg.norm(P.mean(0)), 1e-6)       # items most users rank high
+    P += 0.5 * P.mean(0)
+    tr = sp.random(U, I, 0.02, random_state=3, format="lil", dtype=np.float32)
+    tr[7, I - 40:I] = 1.0
+    tr[9, :] = 0.0
+    tr = tr.tocsr(); tr.data[:] = 1.0; tr.sort_indices()
+    te = sp.random(U, I, 0.01, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    users = torch.from_numpy(rng.permutation(U).astype(np.int32)).cuda()
+    gemm = E.ScoreGemm(Qd, U)
+    M = gemm.tile_maxima(Pd, users, trc)
+    k = 10
+    outs = []
+    for grouped in (False, True):
+        out = torch.zeros((U, 3 * k), dtype=torch.float32, device="cuda")
+        flags = torch.full((U,), -1, dtype=torch.int32, device="cuda")
+        E.eval_tiles(M, Pd, gemm, users, trc, tec, [1, 3, 5], k, out, flags, grouped=grouped)
+        outs.append((out.cpu().numpy(), flags.cpu().numpy()))
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    keep = outs[0][1] == 0
+    np.testing.assert_array_equal(outs[0][0][keep], outs[1][0][keep])
+    assert keep.sum() > U // 2
