@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs (same guide, section "L2 (per XCD)")
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (same guide); v_mfma_f32_32x32x2_f32
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide; AMD's 2:1-sparse headline figure is not used)
 
 
 def parse():
@@ -660,6 +661,12 @@ def compact_line(line):
         "eval_ndcg10_oracle_absdiff": _get(line, "eval", "ndcg10_oracle_absdiff"),
         "eval_mfma_tflops": _get(line, "eval", "roofline", "achieved"),
         "eval_mfma_frac": _get(line, "eval", "roofline", "frac"),
+        "eval_search": _get(line, "eval", "search"),
+        "eval_search_frac_of_sustained_bf16": _get(line, "eval", "roofline", "frac_of_sustained"),
+        "eval_fp32_loop_ms": _get(line, "eval", "roofline", "fp32_mfma_loop_ms"),
+        "eval_search_ms": _get(line, "eval", "roofline", "ms"),
+        "eval_rank_ms": _get(line, "eval", "roofline_topk", "ms"),
+        "eval_rows_redone": _get(line, "eval", "rows_redone_for_ties"),
         "eval_plan_build_ms": _get(line, "eval", "strike_plan_build_ms"),
         "mf_triplets_per_sec": _get(line, "mf", "triplets_per_sec"),
         "mf_us_per_step": None if _get(line, "mf", "ms_per_step") is None else _get(line, "mf", "ms_per_step") * 1e3,
@@ -1034,8 +1041,11 @@ def main():
                      "ms_runs": [r * 1e3 for r in runs],
                      "n_users": int(len(test_users)), "ndcg@10": float(means[2 * 20 + 9]),
                      "recall@20": float(means[1 * 20 + 19]),
-                     "design": ("pruned: tile maxima in the fp32-MFMA scoring loop (no score matrix; train strikes as a planned fix-up pass) -> top-21 "
-                                "32-item tiles per user rescored + ranked; tie rows redone from full rows"
+                     "search": getattr(ev, "search_used", None),
+                     "design": ("pruned: tile maxima from a bounded bf16-MFMA filter (no score matrix; three-term bf16 expansion, per-row "
+                                "error bound; train strikes as a planned fp32 fix-up pass) -> the best 23 32-item tiles per user "
+                                "rescored with the fp32 chain (bucketed by tile, fp32 MFMA) + ranked; each row certified against "
+                                "its bound; tie / uncertified rows redone from full fp32 rows"
                                 if args.eval_mode == "pruned" else
                                 "materialised scores: fp32-MFMA GEMM -> HBM -> select kernel; scoring of "
                                 "batch b+1 overlaps ranking of batch b (two streams, two slabs)"),
@@ -1054,43 +1064,85 @@ def main():
             if plan is not None:
                 row_of = torch.full((U,), -1, dtype=torch.int32, device=dev)
                 row_of[ub.long()] = torch.arange(nb, dtype=torch.int32, device=dev)
-            M = ev._gemm.tile_maxima(eu, ub, trc, plan=plan, row_of=row_of)
+            filt = ev._filter if getattr(ev, "search_used", "fp32") == "bf16" else None
+            n_keep = min(top_k + 1 + ev.extra_tiles, 63) if filt is not None else top_k + 1
             per = torch.empty((nb, 5 * top_k), dtype=torch.float32, device=dev)
             flg = torch.zeros(nb, dtype=torch.int32, device=dev)
-            E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg)
-            em, e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+
+            def level1_fp32():
+                return ev._gemm.tile_maxima(eu, ub, trc, plan=plan, row_of=row_of)
+
+            def level1_search():
+                return ev._gemm.tile_maxima(eu, ub, trc, plan=plan, row_of=row_of, filt=filt)
+
+            def level2(M, eps=None):
+                E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg, eps=eps,
+                             n_keep=n_keep if eps is not None else None)
+            if filt is not None:
+                filt.prepare(ei)
+                M, eps = level1_search()
+            else:
+                M, eps = level1_fp32(), None
+            level2(M, eps)
+            ev_ = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             torch.cuda.synchronize()
-            em.record()
+            ev_[0].record()
             for _ in range(3):
-                M = ev._gemm.tile_maxima(eu, ub, trc)                        # strikes inside the scoring loop (r01/r02 form)
-            e0.record()
+                ev._gemm.tile_maxima(eu, ub, trc)                            # strikes inside the scoring loop (r01/r02 form)
+            ev_[1].record()
             for _ in range(3):
-                M = ev._gemm.tile_maxima(eu, ub, trc, plan=plan, row_of=row_of)
-            e1.record()
+                M32 = level1_fp32()                                          # fp32 MFMA loop + planned fix-up (r03 form)
+            ev_[2].record()
             for _ in range(3):
-                E.eval_tiles(M, eu, ev._gemm, ub, trc, tec, [1, 2, 4, 3, 5], top_k, per, flg)
-            e2.record()
+                if filt is not None:
+                    M, eps = level1_search()                                 # bf16 bounded filter + the same fix-up (r04)
+            ev_[3].record()
+            if filt is None:
+                M = M32
+            for _ in range(3):
+                level2(M, eps)
+            ev_[4].record()
             torch.cuda.synchronize()
-            t_score, t_rank = e0.elapsed_time(e1) / 3e3, e1.elapsed_time(e2) / 3e3       # seconds
-            t_inloop = em.elapsed_time(e0) / 3e3
+            t_inloop, t_fp32, t_filter, t_rank = (ev_[i].elapsed_time(ev_[i + 1]) / 3e3 for i in range(4))   # seconds
+            t_score = t_filter if filt is not None else t_fp32
             flops = 2.0 * I * d_e * nb
             tiles = 2 * ((I + 63) // 64)
             # level 2, algorithmic HBM bytes: per user its tile maxima and factor row read and M*K metrics
-            # written; the k-major item copy and the train/test lists read once.  (The top_k+1 rescored
-            # tiles per user are gathers from that L2-resident item copy: reported apart, not HBM bytes.)
+            # written; the k-major item copy and the train/test lists read once.
             rank_bytes = nb * (tiles * 4 + d_e * 4 + 5 * top_k * 4) + I * d_e * 4 + \
                 (int(train.indptr[-1]) + int(test.indptr[-1])) * 4
-            rescore_l2_bytes = nb * (top_k + 1) * 64 * d_e * 4
-            eval_info["roofline"] = {
-                "bound": "mfma", "kernel": "gather_transpose_kernel + score_tilemax_kernel<32, false> (no strikes in the "
-                                           "loop) + tilemax_fix_kernel<32> (planned (user, tile) pairs recomputed with "
-                                           "their strikes)" if plan is not None else "score_tilemax_kernel<32, true>",
-                "users": nb,
-                "achieved": flops / t_score / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / t_score / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_score * 1e3,
-                "flops_per_user": 2.0 * I * d_e,
-                "strikes_in_the_loop_ms": t_inloop * 1e3,
-                "strike_plan_pairs": plan.n_pairs if plan is not None else None}
+            rescore_flops = 2.0 * nb * n_keep * 32 * d_e
+            if filt is not None:
+                eval_info["roofline"] = {
+                    "bound": "mfma", "kernel": "split_rows_kernel + tilemax_bf16_kernel<%d> (bounded filter: three bf16 MFMA "
+                                               "terms per product, fp32 accumulate) + tilemax_fix_kernel<32> (planned "
+                                               "(user, tile) pairs in fp32)" % ((d_e + 15) // 16),
+                    "users": nb, "ms": t_filter * 1e3,
+                    "achieved": 3.0 * flops / t_filter / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 3.0 * flops / t_filter / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "achieved_note": "bf16 flops ISSUED (3 x 2·I·d per user) over the filter + fix-up time; the dense bf16 "
+                                     "MFMA rate this chip sustains with every CU busy was measured at 1,490 TFLOP/s "
+                                     "(profiles/r04_exp_mfma_valu_overlap.txt: 54 clk per 32x32x16 at the 2.4 GHz nominal "
+                                     "clock), frac_of_sustained prices against that",
+                    "frac_of_sustained": 3.0 * flops / t_filter / 1e12 / 1490.0,
+                    "scores_per_s_as_fp32_tflops": flops / t_filter / 1e12,
+                    "fp32_mfma_loop_ms": t_fp32 * 1e3, "fp32_mfma_loop_frac": flops / t_fp32 / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "flops_per_user": 2.0 * I * d_e, "kappa": filt.kappa, "tiles_rescored_per_user": n_keep,
+                    "strikes_in_the_loop_ms": t_inloop * 1e3,
+                    "strike_plan_pairs": plan.n_pairs if plan is not None else None,
+                    "exactness": "the filter only chooses the tiles; every ranked score is the fp32 fmaf chain's, each row is "
+                                 "certified against its error bound or redone from fp32 rows (rows_redone_for_ties)"}
+            else:
+                eval_info["roofline"] = {
+                    "bound": "mfma", "kernel": "gather_transpose_kernel + score_tilemax_kernel<32, false> (no strikes in the "
+                                               "loop) + tilemax_fix_kernel<32> (planned (user, tile) pairs recomputed with "
+                                               "their strikes)" if plan is not None else "score_tilemax_kernel<32, true>",
+                    "users": nb,
+                    "achieved": flops / t_score / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / t_score / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_score * 1e3,
+                    "flops_per_user": 2.0 * I * d_e,
+                    "strikes_in_the_loop_ms": t_inloop * 1e3,
+                    "strike_plan_pairs": plan.n_pairs if plan is not None else None}
             if plan is not None:
                 # the plan is built once per train matrix, outside every evaluation: its one-off cost
                 torch.cuda.synchronize()
@@ -1099,16 +1151,16 @@ def main():
                 torch.cuda.synchronize()
                 eval_info["strike_plan_build_ms"] = (time.perf_counter() - tp) * 1e3
             eval_info["roofline_topk"] = {
-                "bound": "l2", "kernel": "rescore_tiles_kernel + select_rows_kernel + metrics_kernel (nrhip_eval_tiles)",
-                "achieved": rescore_l2_bytes / t_rank / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                "frac": rescore_l2_bytes / t_rank / 1e9 / L2_PEAK_GBS, "ms": t_rank * 1e3,
-                "bytes": rescore_l2_bytes, "hbm_bytes": rank_bytes,
-                "hbm_GBps": rank_bytes / t_rank / 1e9, "hbm_frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS,
-                "note": "pruned design: the [users][I] score matrix is never written; the top-K works on "
-                        "tile maxima and %d rescored tiles per user gathered from the L2-resident item "
-                        "copy: the phase is priced against the aggregate L2 rate those gathers are served "
-                        "at (the whole duration of the three kernels in the denominator); its HBM bytes are small "
-                        "(hbm_frac)" % (top_k + 1)}
+                "bound": "hbm", "kernel": "select_rows_kernel (tile maxima) + tile_pairs / chunk kernels + rescore_pairs_kernel "
+                                          "(fp32 MFMA chain, 32 users of one tile per wave) + strike_compact + "
+                                          "select_rows_kernel + remap + metrics_kernel (nrhip_eval_tiles_bounded)",
+                "achieved": rank_bytes / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS, "ms": t_rank * 1e3,
+                "bytes": rank_bytes, "rescore_gflop": rescore_flops / 1e9,
+                "note": "pruned design: the [users][I] score matrix is never written; the top-K works on the tile maxima "
+                        "(%d floats per user, the phase's HBM stream) and %d rescored 32-item tiles per user; the "
+                        "rescoring is bucketed by tile, so an item tile is read once per 32 users (r03: once per user, "
+                        "5.6 GB through the L2s, 0.43 ms); the phase is a chain of eight short launches" % (tiles, n_keep)}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-%s)" % args.shape, "value": triplets_per_s,

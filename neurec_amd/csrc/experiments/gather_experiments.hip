@@ -613,7 +613,9 @@ __device__ __forceinline__ float exp_role_work(int role, int iters, float seed) 
     exp_f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     uint4 ua = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
     ua.x += (uint32_t)(seed * 3.f);
-    const exp_bf16x8 a = __builtin_bit_cast(exp_bf16x8, ua), b = a;
+    uint4 ub = make_uint4(0x3f003f00u, 0x3f003f00u, 0x3f003f00u, 0x3f003f00u);
+    ub.y += (uint32_t)(seed * 5.f);
+    const exp_bf16x8 a = __builtin_bit_cast(exp_bf16x8, ua), b = __builtin_bit_cast(exp_bf16x8, ub);   // distinct registers
     float x0 = seed, x1 = seed + 1.f, x2 = seed + 2.f, x3 = seed + 3.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -631,6 +633,23 @@ __device__ __forceinline__ float exp_role_work(int role, int iters, float seed) 
 #pragma unroll
     for (int i = 0; i < 16; ++i) r += c0[i] + c1[i] + c2[i] + c3[i];
     r += x0 + x1 + x2 + x3;
+  } else if (role == 7) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 exp_bf16x8;
+    typedef __attribute__((ext_vector_type(4))) float exp_f32x4;
+    exp_f32x4 c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = exp_f32x4{0, 0, 0, 0};
+    uint4 ua = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), ub = make_uint4(0x3f003f00u, 0x3f003f00u, 0x3f003f00u, 0x3f003f00u);
+    ua.x += (uint32_t)(seed * 3.f); ub.y += (uint32_t)(seed * 5.f);
+    const exp_bf16x8 a = __builtin_bit_cast(exp_bf16x8, ua), b = __builtin_bit_cast(exp_bf16x8, ub);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += c[i][0] + c[i][1] + c[i][2] + c[i][3];
   } else if (role == 6) {
     float x0 = seed, x1 = seed + 1.f, x2 = seed + 2.f, x3 = seed + 3.f;   // the 64 fmas of role 5 alone
     for (int it = 0; it < iters; ++it) {

@@ -79,11 +79,23 @@ __global__ void row_eps_kernel(const float* __restrict__ norm, const float* __re
   if (r < rows) eps[r] = kappa * norm[r] * max_norm[0];
 }
 
+// fmaxf() costs two instructions per call here (v_max_f32 x, x, x to quiet a possible signalling NaN, then the max).
+// The bare instructions; a NaN score is dropped by v_max (IEEE mode returns the other operand) as fmaxf would drop it.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float max16(const f32x16& c) {
-  float m = c[0];
+  float m = vmax3(c[0], c[1], c[2]);
 #pragma unroll
-  for (int i = 1; i < 16; ++i) m = fmaxf(m, c[i]);
-  return m;
+  for (int i = 3; i < 15; i += 2) m = vmax3(m, c[i], c[i + 1]);
+  return vmax(m, c[15]);
 }
 __device__ __forceinline__ float max16_skip(const f32x16& c, uint32_t skip) {
   float m = -INFINITY;
@@ -94,7 +106,7 @@ __device__ __forceinline__ float max16_skip(const f32x16& c, uint32_t skip) {
 // max over the two lane halves (rows (reg&3) + 8 (reg>>2) + 4 h of the same 32-row block)
 __device__ __forceinline__ float max_halves(float m) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 template <int KS16>
@@ -318,9 +330,21 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
   NR_LAUNCH_CHECK();
   const int bx = (bpad / 64 + 3) / 4;
   const int n_tiles = round_up64(cols) / 64;
-  int tpc = (int)(((int64_t)n_tiles * bx + 2047) / 2048);
-  tpc = (tpc + 5) / 6 * 6;                                    // the pipelined body covers 6 tiles
-  const int by = (n_tiles + tpc - 1) / tpc;
+  // chunks per user panel: a workgroup's start (64 operand registers per lane + the first tiles: ~3 tile times) and the
+  // last, partly filled round of workgroups are what a launch loses; pick the split that minimises
+  // rounds x (tiles per chunk + 3) over the 256 CUs (one workgroup per CU).  2,048 small workgroups cost 13 %.
+  int by = 1, tpc = 0;
+  {
+    int64_t best = -1;
+    for (int cand = 1; cand <= 64 && cand <= n_tiles; ++cand) {
+      int t = (n_tiles + cand - 1) / cand;
+      t = (t + 5) / 6 * 6;                                    // the pipelined body covers 6 tiles
+      const int chunks = (n_tiles + t - 1) / t;
+      const int64_t rounds = ((int64_t)bx * chunks + 255) / 256;
+      const int64_t cost = rounds * (t + 3);
+      if (best < 0 || cost < best) { best = cost; by = chunks; tpc = t; }
+    }
+  }
   dim3 grid(bx, by), block(256);
 #define NR_FILTER_CASE(K)                                                                                       \
   hipLaunchKernelGGL(tilemax_bf16_kernel<K>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld, tpc, \

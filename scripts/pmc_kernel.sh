@@ -5,7 +5,7 @@ set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 KSUB=$1; TAG=$2; shift 3
-OUT=$R/gpurun_out/r03/pmc_$TAG
+OUT=$R/gpurun_out/r04/pmc_$TAG
 mkdir -p "$OUT"
 i=0
 while read -r group; do
