@@ -366,6 +366,24 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
 // every lane executes the (uniform) heap code; lanes only differ while
 // scanning the row 64 scores at a time for elements that beat the heap root.
 // ----------------------------------------------------------------------------
+// The heap of a sort length <= 64, one slot per lane: slot reads are v_readlane with a scalar index, slot writes
+// a lane compare + select — no LDS round trip in the sift chains (the LDS heap made a flagged 41 k-column row cost 0.31 ms, most
+// of it waiting for one dependent LDS access after the other).  Every lane runs the same (uniform) control flow.
+struct RegHeap {
+  float v;      // this lane's slot: score
+  int id;       //                   item
+  __device__ __forceinline__ float gv(int i) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+  }
+  __device__ __forceinline__ int gi(int i) const { return __builtin_amdgcn_readlane(id, i); }
+  __device__ __forceinline__ void set(int i, float nv, int nid) {
+    const bool me = (int)nr_lane() == i;                       // (no v_writelane builtin here: compare + select)
+    v = me ? nv : v;
+    id = me ? nid : id;
+  }
+  __device__ __forceinline__ void mov(int dst, int src) { set(dst, gv(src), gi(src)); }
+};
+
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
     const float* __restrict__ scores, int64_t ld, int rows, int cols, int sort_len, int cut,
     int32_t* __restrict__ rank, const int32_t* __restrict__ flag, int32_t* __restrict__ n_exact) {
@@ -377,8 +395,41 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
   if (row >= rows || flag[row] == 0) return;
 
   const float* srow = scores + (int64_t)row * ld;
-  nr::HeapView h{s_val[wave], s_idx[wave]};
   const int m = sort_len < cols ? sort_len : cols;
+  if (m <= NR_WAVE) {                                          // wave-uniform: the register heap
+    RegHeap h{lane < m ? srow[lane] : 0.f, lane};
+    nr::heap_make(h, m);
+    constexpr int kAheadR = 16;
+    for (int base0 = m; base0 < cols; base0 += kAheadR * NR_WAVE) {
+      float vv[kAheadR];
+#pragma unroll
+      for (int g = 0; g < kAheadR; ++g) {
+        const int e = base0 + g * NR_WAVE + lane;
+        vv[g] = e < cols ? srow[e] : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < kAheadR; ++g) {
+        const int base = base0 + g * NR_WAVE;
+        if (base >= cols) break;
+        bool live = base + lane < cols;
+        const float v = vv[g];
+        for (;;) {
+          const float root = h.gv(0);
+          const uint64_t mask = __ballot(live && v > root);
+          if (!mask) break;
+          const int t = __builtin_ctzll(mask);
+          const float vt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+          nr::heap_adjust(h, 0, m, vt, base + t);
+          live = live && lane > t;
+        }
+      }
+    }
+    nr::heap_sort(h, m);
+    if (lane < cut && lane < m) rank[(int64_t)row * kRankStride + lane] = h.id;
+    if (lane == 0 && n_exact) atomicAdd(n_exact, 1);
+    return;
+  }
+  nr::HeapView h{s_val[wave], s_idx[wave]};
   for (int i = lane; i < m; i += NR_WAVE) { h.val[i] = srow[i]; h.idx[i] = i; }
   wave_lds_sync();
   nr::heap_make(h, m);

@@ -60,48 +60,54 @@ NR_HD uint32_t key_order(uint64_t k) { return (uint32_t)(k >> 32); }
 // The routines mirror GCC 11 bits/stl_heap.h (__adjust_heap / __push_heap /
 // __make_heap / __sort_heap) and bits/stl_algo.h (__partial_sort_copy) [EXT].
 // ----------------------------------------------------------------------------
+// The heap routines are written against a small view interface — gv(i) / gi(i): score / item of slot i; set(i, v,
+// id); mov(dst, src) — so that the same statement sequence runs on a heap in memory (HeapView: host checks, the
+// LDS heap of long sort lengths) and on a heap held one slot per lane in registers (eval_select.hip: RegHeap).
 struct HeapView {
   float* val;   // heap scores
   int*   idx;   // heap item indices
+  NR_HD float gv(int i) const { return val[i]; }
+  NR_HD int gi(int i) const { return idx[i]; }
+  NR_HD void set(int i, float v, int id) { val[i] = v; idx[i] = id; }
+  NR_HD void mov(int dst, int src) { val[dst] = val[src]; idx[dst] = idx[src]; }
 };
 
-NR_HD void heap_push(HeapView h, int hole, int top, float v, int id) {
+template <class H>
+NR_HD void heap_push(H& h, int hole, int top, float v, int id) {
   int parent = (hole - 1) / 2;
-  while (hole > top && h.val[parent] > v) {          // comp(parent, value)
-    h.val[hole] = h.val[parent];
-    h.idx[hole] = h.idx[parent];
+  while (hole > top && h.gv(parent) > v) {           // comp(parent, value)
+    h.mov(hole, parent);
     hole = parent;
     parent = (hole - 1) / 2;
   }
-  h.val[hole] = v;
-  h.idx[hole] = id;
+  h.set(hole, v, id);
 }
 
-NR_HD void heap_adjust(HeapView h, int hole, int len, float v, int id) {
+template <class H>
+NR_HD void heap_adjust(H& h, int hole, int len, float v, int id) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (h.val[child] > h.val[child - 1]) child--;     // comp(child, child-1)
-    h.val[hole] = h.val[child];
-    h.idx[hole] = h.idx[child];
+    if (h.gv(child) > h.gv(child - 1)) child--;       // comp(child, child-1)
+    h.mov(hole, child);
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    h.val[hole] = h.val[child - 1];
-    h.idx[hole] = h.idx[child - 1];
+    h.mov(hole, child - 1);
     hole = child - 1;
   }
   heap_push(h, hole, top, v, id);
 }
 
-NR_HD void heap_make(HeapView h, int len) {
+template <class H>
+NR_HD void heap_make(H& h, int len) {
   if (len < 2) return;
   int parent = (len - 2) / 2;
   while (true) {
-    float v = h.val[parent];
-    int id = h.idx[parent];
+    float v = h.gv(parent);
+    int id = h.gi(parent);
     heap_adjust(h, parent, len, v, id);
     if (parent == 0) return;
     parent--;
@@ -110,19 +116,20 @@ NR_HD void heap_make(HeapView h, int len) {
 
 // Offer element (v,id) of the input stream to a full heap: replaces the heap
 // root iff comp(element, root), i.e. v > root score (strictly).
-NR_HD bool heap_offer(HeapView h, int len, float v, int id) {
-  if (v > h.val[0]) { heap_adjust(h, 0, len, v, id); return true; }
+template <class H>
+NR_HD bool heap_offer(H& h, int len, float v, int id) {
+  if (v > h.gv(0)) { heap_adjust(h, 0, len, v, id); return true; }
   return false;
 }
 
-NR_HD void heap_sort(HeapView h, int len) {
+template <class H>
+NR_HD void heap_sort(H& h, int len) {
   int last = len;
   while (last > 1) {
     --last;
-    float v = h.val[last];
-    int id = h.idx[last];
-    h.val[last] = h.val[0];
-    h.idx[last] = h.idx[0];
+    float v = h.gv(last);
+    int id = h.gi(last);
+    h.mov(last, 0);
     heap_adjust(h, 0, last, v, id);
   }
 }
