@@ -156,7 +156,9 @@ __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v) {
 template <int VEC>
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
     const float* __restrict__ scores, int64_t ld, int rows, int cols, int sort_len, int cut,
-    int32_t* __restrict__ rank, int32_t* __restrict__ flag) {
+    int32_t* __restrict__ rank, int32_t* __restrict__ flag, uint64_t* __restrict__ tie_mask) {
+  // tie_mask (optional): bit k <=> the scores at ranks k and k + 1 are equal, k < cut (bit cut - 1 = the pair that
+  // straddles the cut); all ones when only "some tie" is known (the streaming path)
   __shared__ uint64_t s_keys[kSelWaves][kSelSlots];
   __shared__ uint64_t s_top[kSelWaves][kMaxSort];
   const int wave = threadIdx.x / NR_WAVE;
@@ -226,8 +228,11 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
         const int n_out = min(cut, min(sort_len, c_n));
         const bool tie = lane < n_out && next != 0ull && nr::key_order(mine) == nr::key_order(next);
         if (lane < n_out) rank[(int64_t)row * kRankStride + lane] = (int32_t)nr::key_index(mine);
-        const bool any_tie = __ballot(tie) != 0;
-        if (lane == 0) flag[row] = any_tie ? 1 : 0;
+        const uint64_t tmask = __ballot(tie);
+        if (lane == 0) {
+          flag[row] = tmask ? 1 : 0;
+          if (tie_mask) tie_mask[row] = tmask;
+        }
         return;
       }
       wave_lds_sync();                                        // a huge tie group: the general path
@@ -357,7 +362,10 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
   }
   if (btie && take >= cut && cut >= 1 && nr::key_order(top[cut - 1]) == btie_order) tie = true;
   const bool any_tie = __ballot(tie) != 0;
-  if (lane == 0) flag[row] = any_tie ? 1 : 0;
+  if (lane == 0) {
+    flag[row] = any_tie ? 1 : 0;
+    if (tie_mask) tie_mask[row] = any_tie ? ~0ull : 0ull;
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -478,7 +486,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
     const int32_t* __restrict__ rank, int rows, int top_k, const int32_t* __restrict__ users,
     const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices, MetricIds mids,
-    InvLog2Table tbl, float* __restrict__ out, int32_t* __restrict__ topk_out) {
+    InvLog2Table tbl, float* __restrict__ out, int32_t* __restrict__ topk_out,
+    const uint64_t* __restrict__ tie_mask, int32_t* __restrict__ flag_io) {
   __shared__ unsigned char s_hit[kSelWaves][128];
   __shared__ float s_pre[kSelWaves][128];
   const int wave = threadIdx.x / NR_WAVE;
@@ -488,12 +497,24 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
   const int64_t t = users ? (int64_t)users[row] : (int64_t)row;
   const int64_t tb = t_indptr[t], te = t_indptr[t + 1];
   const int T = (int)(te - tb);
-  for (int k = lane; k < top_k; k += NR_WAVE) {
+  for (int k = lane; k < top_k + (tie_mask ? 1 : 0); k += NR_WAVE) {    // (with tie masks: the first item outside too)
     const int32_t item = rank[(int64_t)row * kRankStride + k];
     s_hit[wave][k] = nr::sorted_contains(t_indices + tb, T, item) ? 1 : 0;
-    if (topk_out) topk_out[(int64_t)row * top_k + k] = item;
+    if (topk_out && k < top_k) topk_out[(int64_t)row * top_k + k] = item;
   }
   wave_lds_sync();
+  if (tie_mask) {
+    // Equal scores at neighbouring ranks: the reference's order among them is its heap's history (exact_rows_kernel
+    // replays it from a full row).  Every metric here is a function of the hit / miss sequence over the ranks alone,
+    // so a tie between two items that are both test items or both not cannot change any of them — the pair across
+    // the cut included (rank holds top_k + 1 items here).  Only a tie whose two sides differ needs the replay, and a
+    // tie group that runs on beyond the first item outside (its other members are not known here).
+    const uint64_t tm = tie_mask[row];
+    bool bad = false;
+    if (lane < top_k && ((tm >> lane) & 1ull) && s_hit[wave][lane] != s_hit[wave][lane + 1]) bad = true;
+    if (((tm >> (top_k - 1)) & 1ull) && ((tm >> top_k) & 1ull)) bad = true;
+    if (__ballot(bad) != 0 && lane == 0) flag_io[row] = 1;
+  }
   // nr::metric_eval (the float / double sequence of metric.h) with the lanes across the cut-offs k
   // instead of across the metrics: the running quantities (hit count, DCG, IDCG, the sum of the
   // precisions at the hits) are order-dependent float recurrences — every lane steps through them and
@@ -826,19 +847,19 @@ __global__ __launch_bounds__(256) void strike_compact_kernel(const int32_t* __re
   }
 }
 
-// compact column -> item id; boundary check on the tile maxima; flag_out |= select's tie flag
+// compact column -> item id; boundary check on the tile maxima -> flag_out
 __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ rank,
                                                          const int32_t* __restrict__ sel_flag,
                                                          const int32_t* __restrict__ tilemap,
                                                          const int32_t* __restrict__ tiles,
                                                          int tiles_ld, const float* __restrict__ M,
-                                                         int64_t mld, int rows, int n_keep, int cut,
+                                                         int64_t mld, int rows, int n_keep, int cut, int top_k,
                                                          const float* __restrict__ C, int64_t cld,
                                                          const float* __restrict__ eps,
                                                          int32_t* __restrict__ flag_out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const int col_k = rank[(int64_t)row * kRankStride + cut - 1];       // compact column of the cut-th best (read before the remap)
+  const int col_k = rank[(int64_t)row * kRankStride + top_k - 1];     // compact column of the top_k-th best (read before the remap)
   for (int k = lane; k < cut; k += NR_WAVE) {
     const int col = rank[(int64_t)row * kRankStride + k];
     rank[(int64_t)row * kRankStride + k] =
@@ -851,10 +872,11 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
       // bounded maxima (nrhip_score_filter_tilemax): every item of a tile that was not rescored scores at most
       // outside + eps[row] in the fp32 chain; the row stands only if its cut-th rescored score is strictly above
       const float s_k = C[(int64_t)row * cld + col_k];
-      flag_out[row] = (sel_flag[row] != 0 || !(s_k > outside + eps[row])) ? 1 : 0;
+      flag_out[row] = !(s_k > outside + eps[row]) ? 1 : 0;
     } else {
-      flag_out[row] = (sel_flag[row] != 0 || !(inside > outside)) ? 1 : 0;
+      flag_out[row] = !(inside > outside) ? 1 : 0;
     }
+    // (ties inside the compact row: metrics_kernel decides from the tie mask whether they can change a metric)
   }
 }
 
@@ -937,10 +959,10 @@ int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sor
   const bool vec4 = (ld % 4 == 0) && (((uintptr_t)d_scores) % 16 == 0);
   if (vec4)
     hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st,
-                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag);
+                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag, (uint64_t*)nullptr);
   else
     hipLaunchKernelGGL(select_rows_kernel<1>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st,
-                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag);
+                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag, (uint64_t*)nullptr);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(exact_rows_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_scores,
                      ld, rows, cols, sort_len, cut, w.rank, w.flag, w.n_exact);
@@ -1036,7 +1058,8 @@ int nrhip_eval_scores(const float* d_scores, int64_t ld, int rows, int cols,
   for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));  // metric.h:78
   hipLaunchKernelGGL(metrics_kernel, dim3((rows + kSelWaves - 1) / kSelWaves),
                      dim3(kSelWaves * NR_WAVE), 0, st, w.rank, rows, top_k, d_users,
-                     d_truth_indptr, d_truth_indices, mids, tbl, d_out, d_topk_out);
+                     d_truth_indptr, d_truth_indices, mids, tbl, d_out, d_topk_out, (const uint64_t*)nullptr,
+                     (int32_t*)nullptr);
   NR_LAUNCH_CHECK();
   if (d_n_exact)
     NR_CHECK_HIP(hipMemcpyAsync(d_n_exact, w.n_exact, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -1116,9 +1139,10 @@ static size_t grouped_extra_bytes(int rows, int cols, int n_keep) {
 }
 static size_t eval_tiles_ws_bytes(int rows, int n_keep) {
   const size_t r = (size_t)(rows > 0 ? rows : 1);
+  // (+ the tie masks of the compact selection, 8 bytes per row, behind the compact rows)
   return eval_ws_bytes((int)r) + nr_align_up(r * (size_t)(n_keep + 1) * 4, 256) +
          nr_align_up(r * (size_t)n_keep * 4, 256) +
-         nr_align_up(r * (size_t)n_keep * kTileItems * sizeof(float), 256);
+         nr_align_up(r * (size_t)n_keep * kTileItems * sizeof(float), 256) + nr_align_up(r * 8, 256);
 }
 
 int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes) {
@@ -1183,16 +1207,17 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   char* p = (char*)d_ws + eval_ws_bytes(rows);
   int32_t* tiles = (int32_t*)p;   p += nr_align_up((size_t)rows * tiles_ld * 4, 256);
   int32_t* tilemap = (int32_t*)p; p += nr_align_up((size_t)rows * n_keep * 4, 256);
-  float* C = (float*)p;
+  float* C = (float*)p;           p += nr_align_up((size_t)rows * n_keep * kTileItems * sizeof(float), 256);
+  uint64_t* tmask = (uint64_t*)p;
   const int64_t cld = (int64_t)n_keep * kTileItems;
   // 1. the top_k + 2 largest tile maxima per user (their order among equal maxima is irrelevant)
   const int blocks = (rows + kSelWaves - 1) / kSelWaves;
   if ((mld % 4 == 0) && (((uintptr_t)d_M) % 16 == 0))
     hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
-                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag);
+                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag, (uint64_t*)nullptr);
   else
     hipLaunchKernelGGL(select_rows_kernel<1>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
-                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag);
+                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag, (uint64_t*)nullptr);
   NR_LAUNCH_CHECK();
   {
     const int64_t n = (int64_t)rows * tiles_ld;
@@ -1246,18 +1271,18 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   const int ccols = (int)cld;
   const int sort_len = (2 * top_k < ccols) ? 2 * top_k : ccols;
   hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld,
-                     rows, ccols, sort_len, top_k, w.rank, w.flag);
+                     rows, ccols, sort_len, top_k + 1, w.rank, w.flag, tmask);   // (one item beyond the cut: the tie rule)
   NR_LAUNCH_CHECK();
   // 4. columns -> item ids, boundary check, flags
   hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
-                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k, C, cld, d_eps, d_flag_out);
+                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k + 1, top_k, C, cld, d_eps, d_flag_out);
   NR_LAUNCH_CHECK();
   // 5. metrics
   InvLog2Table tbl;
   for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));
   hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, w.rank, rows,
                      top_k, d_users, d_truth_indptr, d_truth_indices, mids, tbl, d_out,
-                     (int32_t*)nullptr);
+                     (int32_t*)nullptr, tmask, d_flag_out);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

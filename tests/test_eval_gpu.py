@@ -460,3 +460,34 @@ def test_tile_grouped_rescoring_equals_the_per_row_kernel(d, U, I):
     keep = outs[0][1] == 0
     np.testing.assert_array_equal(outs[0][0][keep], outs[1][0][keep])
     assert keep.sum() > U // 2
+
+
+def test_ties_that_cannot_change_a_metric_do_not_send_a_row_to_the_replay():
+    """Two equal scores at neighbouring ranks matter only if one is a test item and the other is not, or if the pair
+    straddles the cut: every metric is a function of the hit / miss sequence alone.  Duplicate item rows make exact
+    ties for every user; the pruned evaluation still equals the materialised one (which replays the reference's heap
+    for every tie) and flags only the rows whose ties could matter."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(11)
+    U, I, d = 500, 4000, 32
+    P = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.1).astype(np.float32)
+    Q[1000:2000] = Q[:1000]                             # every item of the first thousand has an exact duplicate
+    tr = sp.random(U, I, 0.005, random_state=1, format="csr", dtype=np.float32); tr.data[:] = 1.0
+    te = sp.random(U, I, 0.004, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    users = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    Pd, Qd, ud = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda(), torch.from_numpy(users).cuda()
+    full = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, pruned=False)
+    a = full.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    for search in ("bf16", "fp32"):
+        lean = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, search=search)
+        b = lean.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+        np.testing.assert_array_equal(a, b)
+        # nearly every user has a tied pair among its 20 best (half of the top items are duplicated); few of those
+        # pairs involve a test item or the cut
+        assert 0 < lean.n_flagged < len(users) // 3, lean.n_flagged
