@@ -179,6 +179,35 @@ int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, 
                              const int32_t* metric_ids_host, int n_metric, int top_k, float* d_out,
                              int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream);
 
+/* The pruned evaluation of a whole user list as one call: the batch loop of UniEvaluator.evaluate
+ * (evaluator/backend/cpp/uni_evaluator.py:101-157) over nrhip_score_filter_tilemax (use_filter) or nrhip_score_tilemax,
+ * nrhip_score_tilemax_fix and nrhip_eval_tiles_bounded, then (d_sums != NULL) the fp64 column sums of d_out and the
+ * number of flagged rows in d_sums[n_metric*top_k] — one device->host copy brings the means and says whether any row
+ * must be redone.  Pointers are device pointers except metric_ids (host). */
+typedef struct nrhip_eval_pruned_args {
+  const float* d_P; int64_t ldp;                 /* user factors [n_table_users][ldp] */
+  const float* d_Q; int64_t ldq;                 /* item factors [cols][ldq] */
+  int d, cols;
+  const int32_t* d_users; int n_users, batch_rows;
+  const int64_t* d_tr_indptr; const int32_t* d_tr_indices;          /* train CSR (struck items) */
+  const int64_t* d_truth_indptr; const int32_t* d_truth_indices;    /* test CSR */
+  const int32_t* d_chunk_tile; const int64_t* d_chunk_begin; int n_chunks;   /* strike plan (nrhip_score_tilemax_fix) */
+  const int64_t* d_tile_ptr; const int32_t* d_plan_user; const uint32_t* d_plan_mask;
+  const int32_t* d_row_of;                       /* user -> evaluation row (-1: not evaluated) */
+  const int32_t* metric_ids; int n_metric, top_k, n_keep;
+  int use_filter, prepare_items;                 /* bf16 bounded search / (re)build the item-side copies first */
+  void* d_gemm_ws; size_t gemm_ws_bytes;         /* nrhip_score_gemm_workspace_bytes(batch_rows, cols, d) */
+  void* d_filter_ws; size_t filter_ws_bytes;     /* nrhip_score_filter_workspace_bytes(batch_rows, cols, d) */
+  void* d_tiles_ws; size_t tiles_ws_bytes;       /* nrhip_eval_tiles_bounded_workspace_bytes(batch_rows, cols, top_k, n_keep) */
+  float* d_M; int64_t mld;                       /* [batch_rows][mld] tile maxima */
+  float* d_eps;                                  /* [batch_rows] */
+  float* d_out;                                  /* [n_users][n_metric*top_k] */
+  int32_t* d_flags;                              /* [n_users] */
+  double* d_sums;                                /* [n_metric*top_k + 1] or NULL */
+  void* d_colsum_ws; size_t colsum_ws_bytes;     /* nrhip_colsum_workspace_bytes(n_users, n_metric*top_k) */
+} NrhipEvalPruned;
+int nrhip_eval_pruned(const NrhipEvalPruned* args, void* stream);
+
 /* ---- sampler ------------------------------------------------------------
  * Replaces: PairwiseSampler.__iter__ = _sampling_negative_items +
  *           DataIterator(shuffle) (data/sampler.py:71-90,198-206;

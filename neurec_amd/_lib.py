@@ -102,6 +102,21 @@ class NGCFWideBuffers(C.Structure):
          ("gemm_ws_bytes", C.c_size_t), ("reg", C.c_float), ("keep", C.c_float)]
 
 
+class EvalPrunedArgs(C.Structure):
+    """nrhip_eval_pruned_args (include/neurec_hip.h)"""
+    _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("Q", C.c_void_p), ("ldq", C.c_int64), ("d", C.c_int),
+                ("cols", C.c_int), ("users", C.c_void_p), ("n_users", C.c_int), ("batch_rows", C.c_int),
+                ("tr_indptr", C.c_void_p), ("tr_indices", C.c_void_p), ("truth_indptr", C.c_void_p),
+                ("truth_indices", C.c_void_p), ("chunk_tile", C.c_void_p), ("chunk_begin", C.c_void_p),
+                ("n_chunks", C.c_int), ("tile_ptr", C.c_void_p), ("plan_user", C.c_void_p), ("plan_mask", C.c_void_p),
+                ("row_of", C.c_void_p), ("metric_ids", C.POINTER(C.c_int)), ("n_metric", C.c_int), ("top_k", C.c_int),
+                ("n_keep", C.c_int), ("use_filter", C.c_int), ("prepare_items", C.c_int),
+                ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("filter_ws", C.c_void_p),
+                ("filter_ws_bytes", C.c_size_t), ("tiles_ws", C.c_void_p), ("tiles_ws_bytes", C.c_size_t),
+                ("M", C.c_void_p), ("mld", C.c_int64), ("eps", C.c_void_p), ("out", C.c_void_p), ("flags", C.c_void_p),
+                ("sums", C.c_void_p), ("colsum_ws", C.c_void_p), ("colsum_ws_bytes", C.c_size_t)]
+
+
 # name -> argtypes; every function returns int status except where noted.
 SIGNATURES = {
     "nrhip_device_info": [C.POINTER(i32), C.POINTER(i32), psz, C.c_char_p, i32],
@@ -125,6 +140,7 @@ SIGNATURES = {
     "nrhip_eval_tiles": [p, i64, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, i32, psz],
     "nrhip_eval_tiles_bounded": [p, i64, p, i32, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
+    "nrhip_eval_pruned": [C.POINTER(EvalPrunedArgs), p],
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],
     "nrhip_sample_bpr_epoch": [p, p, p, i64, i32, i32, u64, u64, i32, i64, i64, p, p, p, p],

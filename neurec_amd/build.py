@@ -20,7 +20,7 @@ STAMP = os.path.join(OBJ_DIR, "sources.sha256")
 
 SOURCES = ["eval_select.hip", "score_gemm.hip", "sampler.hip", "spmm.hip", "bpr.hip", "adam.hip",
            "step.hip", "dense.hip", "vae.hip", "spmm_blocked.hip", "route.hip", "gemm.hip", "vae_wide.hip", "ngcf_wide.hip", "vae_fused.hip",
-           "score_bf16.hip"]
+           "score_bf16.hip", "eval_pipeline.hip"]
 # micro-benchmarks behind the design decisions in DESIGN.md (scripts/exp_*.py): their own library,
 # nothing of it is linked into the product
 EXP_SOURCES = ["experiments/gather_experiments.hip"]

@@ -431,6 +431,64 @@ def eval_tiles(M, user_table, gemm, users, train_csr, truth_csr, metric_ids, top
     return out
 
 
+class PrunedEvaluation:
+    """nrhip_eval_pruned: the pruned evaluation of a whole user list in one native call (tile search, planned train
+    strikes, fp32 rescoring + ranking + certificate + metrics per batch, then the column sums and the flagged-row
+    count).  Holds the per-evaluator buffers; `run` returns (per_user [n][M*K] float32, flags [n] int32,
+    sums [M*K + 1] float64 — the last entry is the number of flagged rows)."""
+
+    def __init__(self, gemm, filt, plan, train_csr, truth_csr, metric_ids, top_k, n_keep, batch_rows):
+        from ._lib import EvalPrunedArgs
+        self.gemm, self.filt, self.plan = gemm, filt, plan
+        self.train, self.truth = train_csr, truth_csr
+        self.top_k, self.n_keep, self.batch_rows = int(top_k), int(n_keep), int(batch_rows)
+        self.nm = len(metric_ids)
+        self.ids = (C.c_int * self.nm)(*[int(m) for m in metric_ids])
+        dev = gemm.ws.device
+        n_tiles = 2 * ((gemm.cols + 63) // 64)
+        self.mld = (n_tiles + 3) // 4 * 4
+        self.M = torch.empty((self.batch_rows, self.mld), dtype=torch.float32, device=dev)
+        self.eps = torch.empty(self.batch_rows, dtype=torch.float32, device=dev)
+        nb = C.c_size_t(0)
+        call("nrhip_eval_tiles_bounded_workspace_bytes", self.batch_rows, gemm.cols, self.top_k, self.n_keep, C.byref(nb))
+        self.tiles_ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        self.sums = torch.empty(self.nm * self.top_k + 1, dtype=torch.float64, device=dev)
+        self.cs_ws = None
+        self.args = EvalPrunedArgs()
+
+    def run(self, user_table, item_table, users, row_of, per_user, flags, prepare_items=True):
+        a, g, f, pl = self.args, self.gemm, self.filt, self.plan
+        n = users.numel()
+        nb = C.c_size_t(0)
+        call("nrhip_colsum_workspace_bytes", max(n, 1), self.nm * self.top_k, C.byref(nb))
+        if self.cs_ws is None or self.cs_ws.numel() < nb.value:
+            self.cs_ws = torch.empty(max(nb.value, 256), dtype=torch.uint8, device=g.ws.device)
+        if item_table.stride(1) != 1:
+            item_table = item_table.contiguous()
+        ptr = lambda t: t.data_ptr()
+        a.P, a.ldp, a.Q, a.ldq, a.d, a.cols = ptr(user_table), user_table.stride(0), ptr(item_table), item_table.stride(0), g.d, g.cols
+        a.users, a.n_users, a.batch_rows = ptr(users), n, self.batch_rows
+        a.tr_indptr, a.tr_indices = ptr(self.train.indptr), ptr(self.train.indices)
+        a.truth_indptr, a.truth_indices = ptr(self.truth.indptr), ptr(self.truth.indices)
+        a.chunk_tile, a.chunk_begin, a.n_chunks = ptr(pl.chunk_tile), ptr(pl.chunk_begin), pl.n_chunks
+        a.tile_ptr, a.plan_user, a.plan_mask, a.row_of = ptr(pl.tile_ptr), ptr(pl.user), ptr(pl.mask), ptr(row_of)
+        a.metric_ids, a.n_metric, a.top_k, a.n_keep = self.ids, self.nm, self.top_k, self.n_keep
+        a.use_filter, a.prepare_items = (1 if f is not None else 0), (1 if prepare_items else 0)
+        a.gemm_ws, a.gemm_ws_bytes = ptr(g.ws), g.ws.numel()
+        a.filter_ws, a.filter_ws_bytes = (ptr(f.ws), f.ws.numel()) if f is not None else (None, 0)
+        a.tiles_ws, a.tiles_ws_bytes = ptr(self.tiles_ws), self.tiles_ws.numel()
+        a.M, a.mld, a.eps = ptr(self.M), self.mld, ptr(self.eps)
+        a.out, a.flags, a.sums = ptr(per_user), ptr(flags), ptr(self.sums)
+        a.colsum_ws, a.colsum_ws_bytes = ptr(self.cs_ws), self.cs_ws.numel()
+        if user_table.dtype != torch.float32 or item_table.dtype != torch.float32 or users.dtype != torch.int32 or \
+                per_user.dtype != torch.float32 or flags.dtype != torch.int32 or row_of.dtype != torch.int32:
+            raise TypeError("nrhip_eval_pruned: float32 tables / output, int32 users / flags / row table")
+        if not (user_table.stride(1) == 1 and users.is_contiguous() and per_user.is_contiguous() and flags.is_contiguous()):
+            raise ValueError("nrhip_eval_pruned: contiguous arguments")
+        call("nrhip_eval_pruned", C.byref(a), _stream())
+        return per_user, flags, self.sums
+
+
 # ----------------------------------------------------------------------------- sampler
 def sample_bpr_epoch(train_csr, row_of, n_items, neg_num, seed, epoch, shuffle=True, begin=0,
                      count=None, out=None):

@@ -493,6 +493,8 @@ class FullRankEvaluator:
             raise ValueError("search must be 'bf16' or 'fp32', got %r" % (self.search,))
         self.extra_tiles = int(extra_tiles)  # bounded search: tiles rescored beyond top_k + 1 (room for the bound)
         self._filter = None
+        self.native_loop = os.environ.get("NEUREC_EVAL_NATIVE_LOOP", "1") != "0"   # nrhip_eval_pruned (0: the Python batch loop)
+        self._native_sums = None
         self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
         self.strike_plan = bool(strike_plan)  # strikes as a planned fix-up pass after an unmasked scoring loop
         self._plan = None                    # (False: cursors + strikes inside the scoring loop; same M bit for bit)
@@ -519,7 +521,7 @@ class FullRankEvaluator:
         else:
             self._gemm.prepare(item_table)
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
-        self._flags, self.n_flagged = None, 0
+        self._flags, self.n_flagged, self._native_sums = None, 0, None
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
         if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0 and \
@@ -560,10 +562,14 @@ class FullRankEvaluator:
             return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
         # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
         # travel together; only if some row was flagged are those rows redone and the sums retaken
-        sums = E.colsum(per_user)
-        if self._flags is None:
-            return (sums / n).cpu().numpy()
-        both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
+        if self._native_sums is not None:                 # nrhip_eval_pruned left the sums and the flag count together
+            both = self._native_sums.cpu().numpy()
+            self._native_sums = None
+        else:
+            sums = E.colsum(per_user)
+            if self._flags is None:
+                return (sums / n).cpu().numpy()
+            both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
         self.n_flagged = int(both[-1])
         if self.n_flagged:
             self._redo_flagged(user_table, item_table, test_users, per_user)
@@ -583,23 +589,21 @@ class FullRankEvaluator:
             # the planned strikes look a user's row up: test_users must be distinct (uni_evaluator.py:108 hands over
             # the keys of a dict).  Checked once per user list (one count, one host read), not per evaluation; a list
             # with repeats takes the in-loop strikes, which have no such precondition.
-            tag = (test_users.data_ptr(), n)
+            # (keyed by the tensor object — held, so its address cannot be reused — and its in-place version counter)
+            tag = (id(test_users), test_users._version, n)
             if getattr(self, "_distinct_tag", None) != tag:
-                self._distinct_tag = tag
+                self._distinct_tag, self._users_ref = tag, test_users
                 self._distinct = int(torch.unique(test_users).numel()) == n
             use_plan = self._distinct
         if use_plan:
             if self._plan is None or self._plan.cols != item_table.shape[0]:
                 self._plan = E.TileStrikePlan(self.train, item_table.shape[0])
             plan = self._plan
-            made = []
-
-            def row_of():                     # enqueued behind the first scoring launch: the GPU is busy by then
-                if not made:
-                    t = torch.full((self.train.n_rows,), -1, dtype=torch.int32, device=test_users.device)
-                    t[test_users.long()] = torch.arange(n, dtype=torch.int32, device=test_users.device)
-                    made.append(t)
-                return made[0]
+            if getattr(self, "_row_of_tag", None) != tag:     # the user -> evaluation row table, once per user list
+                t = torch.full((self.train.n_rows,), -1, dtype=torch.int32, device=test_users.device)
+                t[test_users.long()] = torch.arange(n, dtype=torch.int32, device=test_users.device)
+                self._row_of_tag, self._row_of = tag, t
+            row_of = self._row_of
         filt = None
         n_keep = min(self.top_k + 1 + self.extra_tiles, 63, 2 * ((item_table.shape[0] + 63) // 64) - 1)
         if self.search == "bf16" and use_plan and E.ScoreFilter.supports(item_table.shape[1]) and n_keep > self.top_k:
@@ -609,6 +613,19 @@ class FullRankEvaluator:
                 self._filter.prepare(item_table)
             filt = self._filter
         self.search_used = "bf16" if filt is not None else "fp32"
+        if use_plan and self.native_loop:
+            # the whole batch loop, the column sums and the flagged-row count in one native call (nrhip_eval_pruned)
+            keep = n_keep if filt is not None else self.top_k + 1
+            key = (id(self._gemm), id(filt), id(plan), keep)
+            if getattr(self, "_native_key", None) != key:
+                self._native = E.PrunedEvaluation(self._gemm, filt, plan, self.train, self.test, self.metric_ids,
+                                                  self.top_k, keep, self.batch_rows)
+                self._native_key = key
+            _, _, self._native_sums = self._native.run(user_table, item_table, test_users, row_of, per_user, flags,
+                                                       prepare_items=False)
+            self._flags = flags
+            return
+        self._native_sums = None
         for b in starts:
             u = test_users[b:b + self.batch_rows]
             if filt is None:

@@ -491,3 +491,34 @@ def test_ties_that_cannot_change_a_metric_do_not_send_a_row_to_the_replay():
         # nearly every user has a tied pair among its 20 best (half of the top items are duplicated); few of those
         # pairs involve a test item or the cut
         assert 0 < lean.n_flagged < len(users) // 3, lean.n_flagged
+
+
+@pytest.mark.parametrize("search", ["bf16", "fp32"])
+def test_the_native_batch_loop_equals_the_python_batch_loop(search):
+    """nrhip_eval_pruned (the batch loop, the column sums and the flagged-row count in one call) == the same entry points
+    issued from Python batch by batch: per-user rows, flags, the float64 means; several batches, a short last one,
+    a shuffled user subset, a second evaluation with other tables through the same evaluator."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(21)
+    U, I, d = 700, 3000, 48
+    tr = sp.random(U, I, 0.01, random_state=1, format="csr", dtype=np.float32); tr.data[:] = 1.0
+    te = sp.random(U, I, 0.005, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    users = rng.permutation(np.flatnonzero(np.diff(te.indptr) > 0))[:611].astype(np.int32)
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    ud = torch.from_numpy(users).cuda()
+    a = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, search=search)
+    b = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, search=search)
+    a.native_loop, b.native_loop = True, False
+    for seed in (0, 1):
+        r2 = np.random.RandomState(seed)
+        Pd = torch.from_numpy((r2.randn(U, d) * 0.1).astype(np.float32)).cuda()
+        Qd = torch.from_numpy((r2.randn(I, d) * 0.1).astype(np.float32)).cuda()
+        np.testing.assert_array_equal(a.evaluate_factors(Pd, Qd, ud), b.evaluate_factors(Pd, Qd, ud))
+        assert a.n_flagged == b.n_flagged
+        np.testing.assert_array_equal(a.evaluate_factors(Pd, Qd, ud, exact_mean=True),
+                                      b.evaluate_factors(Pd, Qd, ud, exact_mean=True))
+    assert a._native is not None and getattr(b, "_native", None) is None
