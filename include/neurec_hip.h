@@ -709,6 +709,26 @@ int nrhip_sumsq_accumulate(const float* d_x, int64_t n, double* d_out, void* str
 int nrhip_mean_f32(const float* d_x, int n, float* d_out, void* stream);
 int nrhip_mean2_f32(const float* d_x, const float* d_y, int n, float* d_out, void* stream);   /* out[0], out[1]: two means, one launch */
 
+/* The narrow Mult-VAE step (one sess.run((loss, optimizer)) of MultiVAE.py:73-139) as one call: nrhip_vae_encode,
+ * nrhip_vae_decoder_fused, nrhip_vae_mid_backward, nrhip_vae_dwq0, [nrhip_mean2_f32 -> d_stats = (neg_ll, KL); the L2
+ * terms into d_regsum] and nrhip_adam_dense_tf_multi issued back to back.  P / G / M / V / sizes: the eight variables in
+ * the order W_q0, b_q0, W_q1, b_q1, W_p0, b_p0, W_p1^T (item-major), b_p1 (host arrays of device pointers).  The
+ * per-batch buffers hold max_batch rows; d_drop_given / d_eps_given (tests) may be NULL. */
+typedef struct nrhip_vae_step_args {
+  const int64_t* d_indptr; const int32_t* d_indices;   /* train CSR: the users' rows are the network's input */
+  int n_items, h, z, act;
+  float* P[8]; float* G[8]; float* M[8]; float* V[8]; int64_t sizes[8];
+  float *d_H1, *d_MU, *d_LOGVAR, *d_EPSSTD, *d_ZS, *d_G1, *d_KLb, *d_h0val;
+  float *d_nll, *d_dG1, *d_DA3, *d_DH2, *d_DA1;
+  float* d_stats; double* d_regsum;
+  void* d_ws; size_t ws_bytes;                        /* nrhip_vae_decoder_fused_workspace_bytes(max_batch, n_items) */
+  const float* d_drop_given; const float* d_eps_given;
+  float reg, beta1, beta2, adam_eps;
+  uint64_t seed;
+} NrhipVaeStep;
+int nrhip_vae_step(const NrhipVaeStep* args, const int32_t* d_rows, int batch, float anneal, float keep,
+                   float adam_alpha, uint64_t step, int want_loss, int apply, void* stream);
+
 /* BPR-MF step in ONE launch: the gradient of MF.py:57-72 + TF-1.12 sparse Adam (util/learner.py:9-10) by
  * exact lazy replay, bit-identical to nrhip_bpr_mf_grad + nrhip_adam_sparse_tf.  Two copies of every table
  * and a stamp per copy (d_tw int32 [rows][2], {0, -1} before step 1): readers of step t take the newer copy

@@ -102,6 +102,17 @@ class NGCFWideBuffers(C.Structure):
          ("gemm_ws_bytes", C.c_size_t), ("reg", C.c_float), ("keep", C.c_float)]
 
 
+class VaeStepArgs(C.Structure):
+    """nrhip_vae_step_args (include/neurec_hip.h)"""
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("n_items", C.c_int), ("h", C.c_int), ("z", C.c_int),
+                ("act", C.c_int), ("P", C.c_void_p * 8), ("G", C.c_void_p * 8), ("M", C.c_void_p * 8),
+                ("V", C.c_void_p * 8), ("sizes", C.c_int64 * 8)] + \
+        [(n, C.c_void_p) for n in ("H1", "MU", "LOGVAR", "EPSSTD", "ZS", "G1", "KLb", "h0val", "nll", "dG1", "DA3",
+                                   "DH2", "DA1", "stats", "regsum", "ws")] + \
+        [("ws_bytes", C.c_size_t), ("drop_given", C.c_void_p), ("eps_given", C.c_void_p), ("reg", C.c_float),
+         ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("seed", C.c_uint64)]
+
+
 class EvalPrunedArgs(C.Structure):
     """nrhip_eval_pruned_args (include/neurec_hip.h)"""
     _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("Q", C.c_void_p), ("ldq", C.c_int64), ("d", C.c_int),
@@ -141,6 +152,7 @@ SIGNATURES = {
     "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, i32, psz],
     "nrhip_eval_tiles_bounded": [p, i64, p, i32, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_eval_pruned": [C.POINTER(EvalPrunedArgs), p],
+    "nrhip_vae_step": [C.POINTER(VaeStepArgs), p, i32, f32, f32, f32, u64, i32, i32, p],
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],
     "nrhip_sample_bpr_epoch": [p, p, p, i64, i32, i32, u64, u64, i32, i64, i64, p, p, p, p],

@@ -1169,6 +1169,39 @@ def vae_encode(csr, rows, Wq0, bq0, Wq1, bq1, Wp0, bp0, act, keep, is_training, 
          *[_ptr(b, torch.float32) for b in bufs], _stream())
 
 
+def vae_step_native(eng, rows, anneal, keep, drop_given, eps_given, want_loss, apply):
+    """nrhip_vae_step: one native call for the narrow Mult-VAE step of `eng` (trainer.MultiVAEEngine); the argument
+    block is filled once per engine (its buffers never move), the per-call values travel as arguments."""
+    from ._lib import VaeStepArgs
+    a = eng._step_args
+    key = tuple(id(t) for d in (eng.P, eng.G, eng.M, eng.V) for t in d.values())      # a replaced tensor refills the block
+    if a is None or eng._step_key != key:
+        eng._step_key = key
+        a = VaeStepArgs()
+        names = eng.NAMES
+        for t in list(eng.P.values()) + list(eng.G.values()) + list(eng.M.values()) + list(eng.V.values()):
+            _ptr(t, torch.float32)
+        a.indptr, a.indices = eng.csr.indptr.data_ptr(), eng.csr.indices.data_ptr()
+        a.n_items, a.h, a.z, a.act = eng.n_items, eng.h, eng.z, VAE_ACTS[eng.act]
+        for k, n in enumerate(names):
+            a.P[k], a.G[k], a.M[k], a.V[k] = (d[n].data_ptr() for d in (eng.P, eng.G, eng.M, eng.V))
+            a.sizes[k] = eng.P[n].numel()
+        for f in ("H1", "MU", "LOGVAR", "EPSSTD", "ZS", "G1", "KLb", "h0val", "nll", "dG1", "DA3", "DH2", "DA1", "stats",
+                  "regsum", "ws"):
+            setattr(a, f, getattr(eng, f).data_ptr())
+        a.ws_bytes = eng.ws.numel()
+        a.reg, a.beta1, a.beta2, a.adam_eps, a.seed = eng.reg, eng.adam.beta1, eng.adam.beta2, eng.adam.eps, eng.seed & (2**64 - 1)
+        eng._step_args = a
+    B = rows.numel()
+    for g in (drop_given, eps_given):
+        if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda):
+            raise ValueError("given dropout / noise tensors: contiguous float32 device tensors")
+    a.drop_given = drop_given.data_ptr() if drop_given is not None else None
+    a.eps_given = eps_given.data_ptr() if eps_given is not None else None
+    call("nrhip_vae_step", C.byref(a), _ptr(rows, torch.int32), B, float(anneal), float(keep), float(eng.adam.alpha()),
+         C.c_uint64(eng.t), 1 if want_loss else 0, 1 if apply else 0, _stream())
+
+
 def add_row_bias(S, cols, bias):
     call("nrhip_add_row_bias", _ptr(S, torch.float32), S.stride(0), S.shape[0], cols, _ptr(bias),
          _stream())

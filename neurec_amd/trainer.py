@@ -820,6 +820,9 @@ class MultiVAEEngine:
                    else E.vae_workspace(B, self.n_items, dev))
         self.stats = zf(2)                         # [neg_ll, KL] of the last step
         self.regsum = torch.zeros(1, dtype=torch.float64, device=dev)
+        # the whole step as one native call (nrhip_vae_step; NEUREC_VAE_NATIVE_STEP=0: the same entry points from Python)
+        self.native_step = decoder == "fused" and os.environ.get("NEUREC_VAE_NATIVE_STEP", "1") != "0"
+        self._step_args, self._step_key = None, None
 
     @property
     def S(self):
@@ -882,6 +885,13 @@ class MultiVAEEngine:
         P, G, B = self.P, self.G, rows.numel()
         if B > self.max_batch or B < 1:
             raise ValueError("batch size %d outside [1, %d]" % (B, self.max_batch))
+        if self.native_step:
+            E.vae_step_native(self, rows, anneal, keep, drop_given, eps_given, want_loss, apply)
+            self.last_anneal = float(anneal)
+            if apply:
+                self.adam.advance()
+                self.t += 1
+            return
         E.vae_encode(self.csr, rows, P["Wq0"], P["bq0"], P["Wq1"], P["bq1"], P["Wp0"], P["bp0"],
                      self.act, keep, 1.0, self.seed, self.t, self._fwd_bufs(B),
                      drop_given=drop_given, eps_given=eps_given, h0val=self.h0val)
