@@ -707,7 +707,8 @@ constexpr int kMaxGroupedTiles = 12288;                        // LDS histogram:
 // reservations — and 99 us at 256 — 64 dependent iterations per wave; this form: one reservation per (workgroup, tile).)
 __global__ __launch_bounds__(256) void tile_pairs_kernel(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep,
                                                          int rows, int n_tiles, int32_t* __restrict__ tilemap,
-                                                         int32_t* __restrict__ gcnt, uint32_t* __restrict__ bucket) {
+                                                         int32_t* __restrict__ gcnt, uint32_t* __restrict__ bucket,
+                                                         int32_t* __restrict__ overflow) {
   extern __shared__ int32_t s_hist[];                          // [n_tiles]: counts, then the bucket cursors
   const int tid = threadIdx.x;
   for (int i = tid; i < n_tiles; i += 256) s_hist[i] = 0;
@@ -731,19 +732,22 @@ __global__ __launch_bounds__(256) void tile_pairs_kernel(const int32_t* __restri
     if ((unsigned)t >= (unsigned)n_tiles) t = 0;
     tilemap[(int64_t)row * n_keep + slot] = t;
     const int at = atomicAdd(&s_hist[t], 1);
-    bucket[(int64_t)t * rows + at] = ((uint32_t)row << 6) | (uint32_t)slot;
+    // a bucket holds one pair per row; only rows with garbage tile ids (NaN tables: the same tile several times) can
+    // ask for more — a pair that does not fit is dropped and its row flagged (redone from a full score row)
+    if (at < rows) bucket[(int64_t)t * rows + at] = ((uint32_t)row << 6) | (uint32_t)slot;
+    else overflow[row] = 1;
   }
 }
 
 // chunk_begin[t] = sum over t' < t of ceil(cnt[t'] / 32); chunk_begin[n_tiles] = the number of chunks.  One workgroup.
-__global__ __launch_bounds__(1024) void chunk_scan_kernel(const int32_t* __restrict__ gcnt, int n_tiles,
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(int32_t* __restrict__ gcnt, int n_tiles, int cap,
                                                           int32_t* __restrict__ chunk_begin) {
   __shared__ int32_t s_sum[1024];
   const int tid = threadIdx.x;
   const int per = (n_tiles + 1023) / 1024;
   const int b = tid * per, e = min(n_tiles, b + per);
   int local = 0;
-  for (int t = b; t < e; ++t) local += (gcnt[t] + 31) >> 5;
+  for (int t = b; t < e; ++t) local += (min(gcnt[t], cap) + 31) >> 5;
   s_sum[tid] = local;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -753,8 +757,10 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const int32_t* __restr
     __syncthreads();
   }
   int run = s_sum[tid] - local;
-  for (int t = b; t < e; ++t) { chunk_begin[t] = run; run += (gcnt[t] + 31) >> 5; }
+  for (int t = b; t < e; ++t) { chunk_begin[t] = run; run += (min(gcnt[t], cap) + 31) >> 5; }
   if (tid == 1023) chunk_begin[n_tiles] = s_sum[1023];
+  __syncthreads();
+  for (int t = b; t < e; ++t) gcnt[t] = min(gcnt[t], cap);     // (the later kernels read the clamped counts)
 }
 __global__ __launch_bounds__(256) void chunk_list_kernel(const int32_t* __restrict__ gcnt,
                                                          const int32_t* __restrict__ chunk_begin, int n_tiles,
@@ -856,6 +862,7 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
                                                          int64_t mld, int rows, int n_keep, int cut, int top_k,
                                                          const float* __restrict__ C, int64_t cld,
                                                          const float* __restrict__ eps,
+                                                         const int32_t* __restrict__ overflow,
                                                          int32_t* __restrict__ flag_out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -876,6 +883,7 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
     } else {
       flag_out[row] = !(inside > outside) ? 1 : 0;
     }
+    if (overflow && overflow[row]) flag_out[row] = 1;          // a pair of this row did not fit its tile's bucket
     // (ties inside the compact row: metrics_kernel decides from the tie mask whether they can change a metric)
   }
 }
@@ -1134,8 +1142,8 @@ static size_t grouped_extra_bytes(int rows, int cols, int n_keep) {
       r >= ((size_t)1 << 26))
     return 0;
   const size_t max_chunks = r * (size_t)n_keep / 32 + n_tiles + 1;
-  return nr_align_up(n_tiles * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
-         nr_align_up(n_tiles * r * 4, 256);
+  return nr_align_up((n_tiles + r) * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
+         nr_align_up(n_tiles * r * 4, 256);                     // counts + overflow flags | chunk starts | chunks | buckets
 }
 static size_t eval_tiles_ws_bytes(int rows, int n_keep) {
   const size_t r = (size_t)(rows > 0 ? rows : 1);
@@ -1226,20 +1234,22 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     NR_LAUNCH_CHECK();
   }
   // 2. rescore the chosen tiles, train items struck out
+  int32_t* overflow = nullptr;
   if (extra) {
     char* x = (char*)d_ws + eval_tiles_ws_bytes(rows, n_keep);
-    int32_t* gcnt = (int32_t*)x;        x += nr_align_up((size_t)n_tiles * 4, 256);
+    int32_t* gcnt = (int32_t*)x;        x += nr_align_up(((size_t)n_tiles + rows) * 4, 256);
+    overflow = gcnt + n_tiles;
     int32_t* chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
     int2* chunks = (int2*)x;
     const size_t max_chunks = (size_t)rows * n_keep / 32 + n_tiles + 1;
     x += nr_align_up(max_chunks * 8, 256);
     uint32_t* bucket = (uint32_t*)x;
-    NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, (size_t)n_tiles * 4, st));
+    NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, ((size_t)n_tiles + rows) * 4, st));
     hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
                        (size_t)n_tiles * 4, st, tiles, tiles_ld, n_keep, rows, n_tiles, tilemap,
-                       gcnt, bucket);
+                       gcnt, bucket, overflow);
     NR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, gcnt, n_tiles, chunk_begin);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, gcnt, n_tiles, rows, chunk_begin);
     NR_LAUNCH_CHECK();
     hipLaunchKernelGGL(chunk_list_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, gcnt, chunk_begin, n_tiles,
                        chunks);
@@ -1275,7 +1285,8 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   NR_LAUNCH_CHECK();
   // 4. columns -> item ids, boundary check, flags
   hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
-                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k + 1, top_k, C, cld, d_eps, d_flag_out);
+                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k + 1, top_k, C, cld, d_eps, overflow,
+                     d_flag_out);
   NR_LAUNCH_CHECK();
   // 5. metrics
   InvLog2Table tbl;

@@ -522,3 +522,33 @@ def test_the_native_batch_loop_equals_the_python_batch_loop(search):
         np.testing.assert_array_equal(a.evaluate_factors(Pd, Qd, ud, exact_mean=True),
                                       b.evaluate_factors(Pd, Qd, ud, exact_mean=True))
     assert a._native is not None and getattr(b, "_native", None) is None
+
+
+def test_nan_user_rows_do_not_disturb_the_other_users():
+    """User factor rows full of NaN (a diverged model) leave garbage tile ids behind the selection; the tile buckets
+    take one pair per row, anything beyond is dropped and the row flagged — no fault, and the other users' rows are
+    what the materialised path computes for them."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(5)
+    U, I, d = 400, 3000, 32
+    P = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.1).astype(np.float32)
+    bad = rng.choice(U, 40, replace=False)
+    P[bad] = np.nan
+    tr = sp.random(U, I, 0.01, random_state=1, format="csr", dtype=np.float32); tr.data[:] = 1.0
+    te = sp.random(U, I, 0.01, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    everyone = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
+    good = np.setdiff1d(everyone, bad).astype(np.int32)
+    lean = FullRankEvaluator(trc, tec, [1, 3, 5], 10, batch_rows=128)
+    full = FullRankEvaluator(trc, tec, [1, 3, 5], 10, batch_rows=128, pruned=False)
+    lean.evaluate_factors(Pd, Qd, torch.from_numpy(everyone).cuda())          # must not fault
+    torch.cuda.synchronize()
+    g = torch.from_numpy(good).cuda()
+    np.testing.assert_array_equal(lean.evaluate_factors(Pd, Qd, g, exact_mean=True),
+                                  full.evaluate_factors(Pd, Qd, g, exact_mean=True))
