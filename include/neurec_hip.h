@@ -138,7 +138,7 @@ int nrhip_score_tilemax_fix(const float* d_P, int64_t ldp, int d, int cols, cons
                             const int32_t* d_plan_user, const uint32_t* d_plan_mask, const int32_t* d_row_of,
                             int row_lo, int rows, float* d_M, int64_t mld, const void* d_ws, size_t ws_bytes,
                             void* stream);
-/* Level 1 as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip; d <= 64).  The fp32 chain stays the
+/* Level 1 as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip; d <= 128).  The fp32 chain stays the
  * definition of every score that is ranked: this only SEARCHES for the tiles worth rescoring, 4-5x faster than the
  * fp32 MFMA loop.  x = hi + lo + r with hi, lo bf16 (round to nearest even), u.i ~= sum_k uh*ih + uh*il + ul*ih in
  * fp32 accumulators, and |approx - chain| <= kappa(d) * ||u|| * max_i ||i|| = d_eps[row] (kappa: nrhip_score_filter_kappa;

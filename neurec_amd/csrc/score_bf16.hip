@@ -235,9 +235,128 @@ __global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __res
   }
 }
 
-inline int padded_dim16(int d) {                              // widths the bf16 filter is built for
-  const int opts[4] = {16, 32, 48, 64};
-  for (int i = 0; i < 4; ++i)
+// 64 < d <= 128: the same loop with the k range of a tile in TWO halves ("units": (tile, half)), so that the operand
+// sets keep the size of the d = 64 kernel — 128 user-operand registers stay resident, an item set is 64.  A tile's
+// accumulators are zeroed before its first unit and reduced after its second, while the first unit of the next tile
+// runs into the other set.  Two item sets (the next unit is loaded while this one runs), unrolled over 4 units.
+__global__ __launch_bounds__(256, 1) void tilemax_bf16_wide_kernel(const uint4* __restrict__ PB,
+                                                                   const uint4* __restrict__ QB, int bpad, int rows,
+                                                                   int cols, int n_tiles, float* __restrict__ M,
+                                                                   int64_t mld, int tiles_per_chunk,
+                                                                   float* __restrict__ sink) {
+  constexpr int KS = 4, KT = 8;                               // k-steps of 16 per unit / per tile
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int ub0 = (blockIdx.x * 4 + wave) * 2;
+  if (ub0 * 32 >= bpad) return;
+  const int t_begin = blockIdx.y * tiles_per_chunk;
+  const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+  if (t_begin >= t_end) return;
+  const int t_stop = min(t_end, cols / 64);
+
+  bf16x8 ah[2][KT], al[2][KT];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int s = 0; s < KT; ++s) {
+      ah[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 0) * KT + s) * 64 + lane]);
+      al[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 1) * KT + s) * 64 + lane]);
+    }
+  const int my_row = ub0 * 32 + 32 * h + j;
+  float* const my_sink = sink + 2 * lane;
+  float* const my_M = M + (int64_t)my_row * mld;
+  const bool row_ok = my_row < rows;
+
+  // unit q of the chunk = (tile t_begin + q / 2, k half q & 1)
+  auto load_u = [&](int q, BSet<KS>& b) __attribute__((always_inline)) {
+    const uint4* p = QB + (int64_t)min(t_begin + (q >> 1), t_end - 1) * (4 * KT * 64) + lane;
+    const int kh = q & 1;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int term = 0; term < 2; ++term)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b.v[x][term][s] = p[((x * 2 + term) * KT + kh * KS + s) * 64];
+  };
+  auto mfma_unit = [&](int kh, const BSet<KS>& b, f32x16 (&c)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            if (term == 0)
+              c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][1][s]), ah[y][kh * KS + s], c[x][y], 0, 0, 0);
+            else if (term == 1)
+              c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), al[y][kh * KS + s], c[x][y], 0, 0, 0);
+            else
+              c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), ah[y][kh * KS + s], c[x][y], 0, 0, 0);
+          }
+  };
+  auto zero = [&](f32x16 (&c)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[x][y][i] = 0.f;
+  };
+  auto reduce_store = [&](int t, const f32x16 (&c)[2][2]) __attribute__((always_inline)) {
+    float m00 = max_halves(max16(c[0][0])), m10 = max_halves(max16(c[1][0]));
+    float m01 = max_halves(max16(c[0][1])), m11 = max_halves(max16(c[1][1]));
+    const float2 v = h ? make_float2(m01, m11) : make_float2(m00, m10);
+    float* dst = (row_ok && t < t_stop) ? my_M + 2 * t : my_sink;
+    *reinterpret_cast<float2*>(dst) = v;
+  };
+
+  if (t_begin < t_stop) {
+    BSet<KS> b[2];                                            // (three sets spilled: 128 user + 192 item registers)
+    f32x16 c[2][2][2];
+    load_u(0, b[0]);
+    load_u(1, b[1]);
+    zero(c[0]);
+    mfma_unit(0, b[0], c[0]);
+    const int n_units = 2 * (t_stop - t_begin);
+    // phase ph: unit q = q0 + ph is done; unit q + 1 runs from b[(ph + 1) & 1]; if q closed its tile (odd), that
+    // tile is reduced meanwhile; b[ph & 1] takes unit q + 2.  q0 is a multiple of 4: every index below is static.
+    for (int q0 = 0; q0 < n_units; q0 += 4) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        load_u(q0 + ph + 2, b[ph & 1]);
+        if (((ph + 1) & 1) == 0) zero(c[((ph + 1) >> 1) & 1]);
+        mfma_unit((ph + 1) & 1, b[(ph + 1) & 1], c[((ph + 1) >> 1) & 1]);
+        if (ph & 1) reduce_store(t_begin + ((q0 + ph) >> 1), c[(ph >> 1) & 1]);
+      }
+    }
+  }
+  if (t_stop < t_end) {                                       // the partial last tile: pad columns excluded
+    const int t = t_stop, it = t * 64;
+    BSet<KS> b;
+    f32x16 c[2][2];
+    zero(c);
+    load_u(2 * (t - t_begin), b);
+    mfma_unit(0, b, c);
+    load_u(2 * (t - t_begin) + 1, b);
+    mfma_unit(1, b, c);
+    float m[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      uint32_t skip = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if (it + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h >= cols) skip |= 1u << reg;
+      m[x][0] = max_halves(max16_skip(c[x][0], skip));
+      m[x][1] = max_halves(max16_skip(c[x][1], skip));
+    }
+    if (row_ok) *reinterpret_cast<float2*>(my_M + 2 * t) = h ? make_float2(m[0][1], m[1][1]) : make_float2(m[0][0], m[1][0]);
+  }
+}
+
+inline int padded_dim16(int d) {                              // widths the bf16 filter is built for (128: two k halves)
+  const int opts[5] = {16, 32, 48, 64, 128};
+  for (int i = 0; i < 5; ++i)
     if (d <= opts[i]) return opts[i];
   return -1;
 }
@@ -275,7 +394,7 @@ extern "C" {
 int nrhip_score_filter_workspace_bytes(int rows, int cols, int d, size_t* bytes) {
   NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && d >= 1, NR_ERR_ARG, "score_filter_workspace_bytes: bad arguments");
   const int dp = padded_dim16(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built (use nrhip_score_tilemax)", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 128 not built (use nrhip_score_tilemax)", d);
   *bytes = carve(nullptr, rows, cols, dp).total;
   return NR_OK;
 }
@@ -283,7 +402,7 @@ int nrhip_score_filter_workspace_bytes(int rows, int cols, int d, size_t* bytes)
 int nrhip_score_filter_kappa(int d, float* kappa) {
   NR_REQUIRE(kappa && d >= 1, NR_ERR_ARG, "score_filter_kappa: bad arguments");
   const int dp = padded_dim16(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 128 not built", d);
   *kappa = kappa_of(dp);
   return NR_OK;
 }
@@ -293,7 +412,7 @@ int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, in
   NR_REQUIRE(d_Q && d_ws && cols >= 1 && d >= 1 && ldq >= d && max_rows >= 0, NR_ERR_ARG,
              "score_filter_prepare_items: bad arguments");
   const int dp = padded_dim16(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 128 not built", d);
   FilterWs f = carve(d_ws, max_rows, cols, dp);
   NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_prepare_items: workspace %zu < %zu", ws_bytes,
              f.total);
@@ -316,7 +435,7 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
                  mld >= 2 * ((cols + 63) / 64) && mld % 2 == 0,
              NR_ERR_ARG, "score_filter_tilemax: bad arguments (mld must be even and >= 2*ceil(cols/64))");
   const int dp = padded_dim16(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 64 not built", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter: embedding dim %d > 128 not built", d);
   if (rows == 0) return NR_OK;
   FilterWs f = carve(d_ws, max_rows, cols, dp);
   NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_tilemax: workspace %zu < %zu", ws_bytes, f.total);
@@ -353,7 +472,10 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
     case 1: NR_FILTER_CASE(1); break;
     case 2: NR_FILTER_CASE(2); break;
     case 3: NR_FILTER_CASE(3); break;
-    default: NR_FILTER_CASE(4); break;
+    case 4: NR_FILTER_CASE(4); break;
+    default:
+      hipLaunchKernelGGL(tilemax_bf16_wide_kernel, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld,
+                         tpc, f.sink);
   }
 #undef NR_FILTER_CASE
   NR_LAUNCH_CHECK();

@@ -265,11 +265,11 @@ class ScoreFilter:
     """Level 1 of the pruned evaluation as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip): tile
     maxima over a three-term bf16 expansion of the fp32 products, each within eps[row] of the fp32 chain's value.
     Nothing here is ranked: nrhip_eval_tiles_bounded rescores the chosen tiles with the fp32 chain and accepts a row
-    only if its bound certifies the choice.  Built for d <= 64 (`ScoreFilter.supports`)."""
+    only if its bound certifies the choice.  Built for d <= 128 (`ScoreFilter.supports`)."""
 
     @staticmethod
     def supports(d):
-        return int(d) <= 64
+        return int(d) <= 128
 
     def __init__(self, item_table, max_rows):
         self.cols, self.d = item_table.shape

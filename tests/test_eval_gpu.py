@@ -322,7 +322,7 @@ def _spread_tables(rng, U, I, d, kind):
     return P, Q
 
 
-@pytest.mark.parametrize("d", [8, 16, 24, 32, 48, 50, 64])
+@pytest.mark.parametrize("d", [8, 16, 24, 32, 48, 50, 64, 96, 100, 128])
 @pytest.mark.parametrize("kind", [0.01, 1.0, 300.0, "wide"])
 def test_bounded_filter_stays_within_its_bound(d, kind):
     """csrc/score_bf16.hip: every approximate tile maximum lies within eps[row] = kappa(d)·||u||·max||i|| of the fp32
@@ -353,7 +353,8 @@ def test_bounded_filter_stays_within_its_bound(d, kind):
     assert (err <= 0.6 * e[:, None]).all(), "worst error / bound = %.3f" % (err / e[:, None]).max()
 
 
-@pytest.mark.parametrize("d,clustered,extra", [(64, False, 2), (50, False, 0), (16, True, 2), (32, True, 1)])
+@pytest.mark.parametrize("d,clustered,extra", [(64, False, 2), (50, False, 0), (16, True, 2), (32, True, 1), (128, False, 2),
+                                               (100, True, 2)])
 def test_bounded_search_ranks_exactly_what_the_fp32_search_ranks(d, clustered, extra):
     """FullRankEvaluator(search='bf16') == search='fp32' == the materialised path, per-user metric rows bit for bit.
     `clustered`: items that are tiny perturbations of each other, spread over many tiles — the gaps between the best
@@ -399,7 +400,8 @@ def test_bounded_search_ranks_exactly_what_the_fp32_search_ranks(d, clustered, e
 
 
 def test_bounded_search_falls_back_where_it_is_not_built():
-    """d > 64 and evaluations without a strike plan (repeated users) take the fp32 search; an unknown name is refused."""
+    """A user list with repeats has no strike plan and takes the fp32 search with in-loop strikes; an unknown search
+    name is refused; the filter itself is built up to 128 columns."""
     import torch
     import scipy.sparse as sp
     from neurec_amd import engine as E
@@ -411,18 +413,21 @@ def test_bounded_search_falls_back_where_it_is_not_built():
     te = sp.random(U, I, 0.01, random_state=2, format="csr", dtype=np.float32)
     te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
     trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
-    users = torch.from_numpy(np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)).cuda()
+    u = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
+    users = torch.from_numpy(np.concatenate([u, u[:7]])).cuda()               # seven users twice
     ev = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=64)
     ref = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=64, pruned=False)
     Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
     np.testing.assert_array_equal(ev.evaluate_factors(Pd, Qd, users, exact_mean=True),
                                   ref.evaluate_factors(Pd, Qd, users, exact_mean=True))
     assert ev.search_used == "fp32"
-    assert not E.ScoreFilter.supports(96) and E.ScoreFilter.supports(64)
+    ev.evaluate_factors(Pd, Qd, torch.from_numpy(u).cuda())
+    assert ev.search_used == "bf16"
+    assert not E.ScoreFilter.supports(129) and E.ScoreFilter.supports(128)
     with pytest.raises(ValueError, match="search"):
         FullRankEvaluator(trc, tec, [1], 10, search="fp16")
     with pytest.raises(NotImplementedError):
-        E.ScoreFilter(Qd, 64)
+        E.ScoreFilter(torch.zeros((I, 160), device="cuda"), 64)
 
 
 @pytest.mark.parametrize("d,U,I", [(64, 700, 5000), (50, 300, 2500), (16, 257, 4133), (128, 130, 1000), (24, 90, 500)])
