@@ -497,9 +497,20 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
   const int64_t t = users ? (int64_t)users[row] : (int64_t)row;
   const int64_t tb = t_indptr[t], te = t_indptr[t + 1];
   const int T = (int)(te - tb);
-  for (int k = lane; k < top_k + (tie_mask ? 1 : 0); k += NR_WAVE) {    // (with tie masks: the first item outside too)
-    const int32_t item = rank[(int64_t)row * kRankStride + k];
-    s_hit[wave][k] = nr::sorted_contains(t_indices + tb, T, item) ? 1 : 0;
+  // the user's test list into LDS (one coalesced load, in flight together with the ranks) and the membership searches
+  // there: a binary search in global memory was ~5 dependent round trips per row, 46 us for 29,858 users
+  constexpr int kTruthLds = 256;
+  __shared__ int32_t s_truth[kSelWaves][kTruthLds];
+  const int n_rank = top_k + (tie_mask ? 1 : 0);               // (with tie masks: the first item outside too)
+  const int32_t item0 = lane < n_rank ? rank[(int64_t)row * kRankStride + lane] : 0;
+  const bool in_lds = T <= kTruthLds;                          // wave-uniform
+  if (in_lds)
+    for (int i = lane; i < T; i += NR_WAVE) s_truth[wave][i] = t_indices[tb + i];
+  wave_lds_sync();
+  const int32_t* truth = in_lds ? s_truth[wave] : t_indices + tb;
+  for (int k = lane; k < n_rank; k += NR_WAVE) {
+    const int32_t item = k == lane ? item0 : rank[(int64_t)row * kRankStride + k];
+    s_hit[wave][k] = nr::sorted_contains(truth, T, item) ? 1 : 0;
     if (topk_out && k < top_k) topk_out[(int64_t)row * top_k + k] = item;
   }
   wave_lds_sync();

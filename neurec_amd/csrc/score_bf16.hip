@@ -37,10 +37,11 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
 }
 
 // dst[((b·2 + term)·KS16 + s)·64 + lane] = the 8 bf16 of row 32·b + (lane & 31), k = 16·s + 8·(lane >> 5) .. +7;
-// norm[row] = ||row||₂ (fp32, rounded up by the caller's factor); *max_norm = max over rows (optional)
+// norm[row] = ||row||₂ (fp32); *max_norm = max over rows (optional); eps[row] = kappa · norm[row] · *other_max (optional)
 __global__ void split_rows_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ ids, int n,
                                   int d, int ks16, uint4* __restrict__ dst, float* __restrict__ norm,
-                                  float* __restrict__ max_norm) {
+                                  float* __restrict__ max_norm, const float* __restrict__ other_max, float kappa,
+                                  float* __restrict__ eps) {
   __shared__ float s_sq[8][64];
   const int lane = threadIdx.x, s = threadIdx.y, b = blockIdx.x;
   const int r = b * 32 + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
@@ -69,14 +70,9 @@ __global__ void split_rows_kernel(const float* __restrict__ src, int64_t ld, con
     for (int q = 0; q < ks16; ++q) t += s_sq[q][lane] + s_sq[q][lane + 32];
     const float nv = sqrtf(t);
     if (have && norm) norm[r] = nv;
+    if (have && eps) eps[r] = kappa * nv * other_max[0];        // the row's bound: kappa ||u|| max ||i||
     if (have && max_norm) atomicMax(reinterpret_cast<int*>(max_norm), __float_as_int(nv));   // nv >= 0 (or NaN: stays)
   }
-}
-
-__global__ void row_eps_kernel(const float* __restrict__ norm, const float* __restrict__ max_norm, int rows,
-                               float kappa, float* __restrict__ eps) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < rows) eps[r] = kappa * norm[r] * max_norm[0];
 }
 
 // fmaxf() costs two instructions per call here (v_max_f32 x, x, x to quiet a possible signalling NaN, then the max).
@@ -420,7 +416,8 @@ int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, in
   NR_CHECK_HIP(hipMemsetAsync(f.inorm_max, 0, sizeof(float), st));
   const int ks16 = dp / 16;
   hipLaunchKernelGGL(split_rows_kernel, dim3(round_up64(cols) / 32), dim3(64, ks16), 0, st, d_Q, ldq,
-                     (const int32_t*)nullptr, cols, d, ks16, f.QB, (float*)nullptr, f.inorm_max);
+                     (const int32_t*)nullptr, cols, d, ks16, f.QB, (float*)nullptr, f.inorm_max, (const float*)nullptr,
+                     0.f, (float*)nullptr);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -442,10 +439,7 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
   hipStream_t st = (hipStream_t)stream;
   const int ks16 = dp / 16, bpad = round_up64(rows);
   hipLaunchKernelGGL(split_rows_kernel, dim3(bpad / 32), dim3(64, ks16), 0, st, d_P, ldp, d_users, rows, d, ks16,
-                     f.PB, f.unorm, (float*)nullptr);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(row_eps_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, f.unorm, f.inorm_max, rows,
-                     kappa_of(dp), d_eps);
+                     f.PB, f.unorm, (float*)nullptr, f.inorm_max, kappa_of(dp), d_eps);
   NR_LAUNCH_CHECK();
   const int bx = (bpad / 64 + 3) / 4;
   const int n_tiles = round_up64(cols) / 64;
