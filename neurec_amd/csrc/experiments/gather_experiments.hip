@@ -615,6 +615,11 @@ __device__ __forceinline__ float exp_role_work(int role, int iters, float seed) 
     ua.x += (uint32_t)(seed * 3.f);
     uint4 ub = make_uint4(0x3f003f00u, 0x3f003f00u, 0x3f003f00u, 0x3f003f00u);
     ub.y += (uint32_t)(seed * 5.f);
+    if (iters & 1) {                                           // odd iteration count: operands with random mantissa / sign bits
+      uint32_t hsh = (uint32_t)(seed * 1e4f) * 2654435761u + threadIdx.x * 40503u;
+      auto nxt = [&]() { hsh ^= hsh << 13; hsh ^= hsh >> 17; hsh ^= hsh << 5; return (hsh & 0x807f807fu) | 0x3f003f00u; };
+      ua = make_uint4(nxt(), nxt(), nxt(), nxt()); ub = make_uint4(nxt(), nxt(), nxt(), nxt());
+    }
     const exp_bf16x8 a = __builtin_bit_cast(exp_bf16x8, ua), b = __builtin_bit_cast(exp_bf16x8, ub);   // distinct registers
     float x0 = seed, x1 = seed + 1.f, x2 = seed + 2.f, x3 = seed + 3.f;
     for (int it = 0; it < iters; ++it) {
@@ -641,6 +646,11 @@ __device__ __forceinline__ float exp_role_work(int role, int iters, float seed) 
     for (int i = 0; i < 8; ++i) c[i] = exp_f32x4{0, 0, 0, 0};
     uint4 ua = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), ub = make_uint4(0x3f003f00u, 0x3f003f00u, 0x3f003f00u, 0x3f003f00u);
     ua.x += (uint32_t)(seed * 3.f); ub.y += (uint32_t)(seed * 5.f);
+    if (iters & 1) {                                           // odd iteration count: operands with random mantissa / sign bits
+      uint32_t hsh = (uint32_t)(seed * 1e4f) * 2654435761u + threadIdx.x * 40503u;
+      auto nxt = [&]() { hsh ^= hsh << 13; hsh ^= hsh >> 17; hsh ^= hsh << 5; return (hsh & 0x807f807fu) | 0x3f003f00u; };
+      ua = make_uint4(nxt(), nxt(), nxt(), nxt()); ub = make_uint4(nxt(), nxt(), nxt(), nxt());
+    }
     const exp_bf16x8 a = __builtin_bit_cast(exp_bf16x8, ua), b = __builtin_bit_cast(exp_bf16x8, ub);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll

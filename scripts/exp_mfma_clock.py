@@ -16,3 +16,8 @@ for blocks in (8, 32, 64, 128, 256):
     t7 = timed(blocks, 7, 0)
     print("blocks %3d: 32 bf16 MFMA 16x16x32 per wave (same flops): %.3f us -> %.1f clk each" % (blocks, t7, t7 * 2400 / 32))
     print("blocks %3d: 16 bf16 MFMA 32x32x16 per wave: %.3f us -> %.1f clk each at 2.4 GHz; fp32 mfma x16: %.3f us" % (blocks, t, t * 2400 / 16, timed(blocks, 1, 0)))
+
+print("the same with operands of random sign / mantissa bits (data-dependent power: does the cadence hold?)")
+for blocks in (8, 256):
+    t4, t7 = timed(blocks, 4, 0, 4001), timed(blocks, 7, 0, 4001)
+    print("blocks %3d: 32x32x16 %.1f clk each, 16x16x32 %.1f clk each (at 2.4 GHz)" % (blocks, t4 * 2400 / 16, t7 * 2400 / 32))
