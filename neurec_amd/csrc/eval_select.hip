@@ -526,6 +526,17 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
     if (((tm >> (top_k - 1)) & 1ull) && ((tm >> top_k) & 1ull)) bad = true;
     if (__ballot(bad) != 0 && lane == 0) flag_io[row] = 1;
   }
+  // A row without a test item among its top_k (most rows: hits are rare) has every metric 0 at every cut-off as long as
+  // the user has test items at all (0 / T, 0 / idcg with idcg > 0, no reciprocal rank): written directly, the float /
+  // double recurrences below are skipped.  (They are ~800 VALU instructions a row: 47 -> ~15 us for 29,858 users.)
+  {
+    bool h = false;
+    for (int k = lane; k < top_k; k += NR_WAVE) h = h || s_hit[wave][k] != 0;
+    if (T > 0 && __ballot(h) == 0) {
+      for (int e = lane; e < mids.n * top_k; e += NR_WAVE) out[(int64_t)row * mids.n * top_k + e] = 0.f;
+      return;
+    }
+  }
   // nr::metric_eval (the float / double sequence of metric.h) with the lanes across the cut-offs k
   // instead of across the metrics: the running quantities (hit count, DCG, IDCG, the sum of the
   // precisions at the hits) are order-dependent float recurrences — every lane steps through them and
