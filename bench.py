@@ -141,7 +141,7 @@ def leg_ngcf(train, test, trc, tec, dev, with_cpu):
     spmm_ms = _hip_timed(lambda: ng.A.matmul(x, out=y), 40, 5)
     spmm_bytes = ng.A.algorithmic_bytes(16)
     users = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
-    ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=16384)
+    ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=32768)   # (as the headline leg: --eval-batch default)
 
     def evaluate():
         eu, ei = ng.final_embeddings()
@@ -241,7 +241,7 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     dec_flops = 2.0 * B * I * (2 * (h + 2) + 2 * h)
     dec_flops_min = 3 * 2.0 * B * I * h                    # logits, dW_p1 = G^T g1, dg1 = G W_p1 once each
     users = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
-    ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=16384)
+    ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=32768)   # (as the headline leg: --eval-batch default)
 
     def evaluate():
         pf, qf = vae.eval_factors()
