@@ -156,7 +156,8 @@ def leg_ngcf(train, test, trc, tec, dev, with_cpu):
                         "frac": spmm_bytes / spmm_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
                         "note": "nnz*8 + (N+1)*4 + 2*N*16*4 B per pass (SURVEY 8d's SpMM formula at d = 16); the "
                                 "4.5 MB operand table is L2-sized, the pass is bound by the CSR stream and latency"},
-           "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9])}}
+           "eval": {"users_per_sec": users.numel() / edt, "ms": edt * 1e3, "ndcg@10": float(m[2 * 20 + 9]),
+                    "rows_redone": int(getattr(ev, "n_flagged", 0)), "search": getattr(ev, "search_used", None)}}
     # the NGCF paper's widths (embedding 64, layers [64, 64, 64]) on the width-generic engine
     from neurec_amd.ngcf_wide import NGCFWideEngine
     table64 = np.concatenate([e([U, 64]), e([I, 64])])
