@@ -660,6 +660,44 @@ __device__ __forceinline__ float exp_role_work(int role, int iters, float seed) 
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) r += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+  } else if (role == 8 || role == 9) {
+    // int8 MFMAs: role 8 = 16 x v_mfma_i32_32x32x32_i8 over four accumulators, role 9 = 32 x v_mfma_i32_16x16x64_i8
+    // over eight (twice the MACs of roles 4 / 7 per iteration); operands with random bits when iters is odd
+    typedef __attribute__((ext_vector_type(4))) int exp_i32x4;
+    typedef __attribute__((ext_vector_type(16))) int exp_i32x16;
+    exp_i32x4 a = {0x01020304, 0x05060708, 0x090a0b0c, 0x0d0e0f10}, b = {0x11121314, 0x15161718, 0x191a1b1c, 0x1d1e1f20};
+    a[0] += (int)(seed * 3.f); b[1] += (int)(seed * 5.f);
+    if (iters & 1) {
+      uint32_t hsh = (uint32_t)(seed * 1e4f) * 2654435761u + threadIdx.x * 40503u;
+      auto nxt = [&]() { hsh ^= hsh << 13; hsh ^= hsh >> 17; hsh ^= hsh << 5; return (int)hsh; };
+      a = exp_i32x4{nxt(), nxt(), nxt(), nxt()}; b = exp_i32x4{nxt(), nxt(), nxt(), nxt()};
+    }
+    if (role == 8) {
+      exp_i32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c2, 0, 0, 0);
+          c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c3, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += (float)(c0[i] + c1[i] + c2[i] + c3[i]);
+    } else {
+      exp_i32x4 c[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c[i] = exp_i32x4{0, 0, 0, 0};
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r += (float)(c[i][0] + c[i][1] + c[i][2] + c[i][3]);
+    }
   } else if (role == 6) {
     float x0 = seed, x1 = seed + 1.f, x2 = seed + 2.f, x3 = seed + 3.f;   // the 64 fmas of role 5 alone
     for (int it = 0; it < iters; ++it) {

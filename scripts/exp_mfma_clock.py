@@ -21,3 +21,8 @@ print("the same with operands of random sign / mantissa bits (data-dependent pow
 for blocks in (8, 256):
     t4, t7 = timed(blocks, 4, 0, 4001), timed(blocks, 7, 0, 4001)
     print("blocks %3d: 32x32x16 %.1f clk each, 16x16x32 %.1f clk each (at 2.4 GHz)" % (blocks, t4 * 2400 / 16, t7 * 2400 / 32))
+
+print("int8 MFMAs (twice the MACs per instruction of the bf16 forms), random operand bits")
+for blocks in (8, 256):
+    t8, t9 = timed(blocks, 8, 0, 4001), timed(blocks, 9, 0, 4001)
+    print("blocks %3d: i32_32x32x32_i8 %.1f clk each, i32_16x16x64_i8 %.1f clk each (at 2.4 GHz)" % (blocks, t8 * 2400 / 16, t9 * 2400 / 32))
