@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,3 +123,25 @@ def test_the_source_digest_does_not_depend_on_the_checkout_path(monkeypatch):
     # (ROOT is also where include/neurec_hip.h is read from: keep the header readable)
     monkeypatch.setattr(build.os.path, "join", lambda *a, _j=build.os.path.join: _j(*a).replace("/somewhere/else", os.path.dirname(build.HERE)))
     assert build._digest() == d0
+
+
+def test_the_filter_bound_constant_is_the_documented_formula():
+    """kappa(d) of the bounded bf16 search (host code of the library, no GPU needed): 1.5 x (dropped terms 3.2 x 2^-18 +
+    3 d' accumulations at 2^-23 + the fp32 chain's d' roundings at 2^-24), d' = d padded to the kernel's width; the
+    workspace grows with rows, columns and width; widths beyond 128 are refused by name."""
+    import ctypes as C
+    from neurec_amd import _lib
+    for d, dp in ((1, 16), (16, 16), (17, 32), (48, 48), (50, 64), (64, 64), (65, 128), (128, 128)):
+        k = C.c_float(0)
+        _lib.call("nrhip_score_filter_kappa", d, C.byref(k))
+        want = np.float32(1.5) * (np.float32(3.2 * 2.0 ** -18) + np.float32(3.0 * dp) * np.float32(2.0 ** -23) +
+                                  np.float32(dp) * np.float32(2.0 ** -24))
+        assert abs(k.value - float(want)) <= 1e-6 * float(want), (d, k.value, float(want))
+    sizes = []
+    for rows, cols, d in ((1024, 5000, 64), (2048, 5000, 64), (2048, 50000, 64), (2048, 50000, 128)):
+        n = C.c_size_t(0)
+        _lib.call("nrhip_score_filter_workspace_bytes", rows, cols, d, C.byref(n))
+        sizes.append(n.value)
+    assert sizes == sorted(sizes) and sizes[0] > 0
+    with pytest.raises(NotImplementedError, match="128"):
+        _lib.call("nrhip_score_filter_kappa", 129, C.byref(C.c_float(0)))
