@@ -722,8 +722,45 @@ def compact_line(line):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a plain shell (no launcher, WORLD_SIZE unset): start the N ranks here — one
+    process per GPU, the environment torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT on 127.0.0.1, a free port), the same command line — and wait for them.  Rank 0's stdout (the ONE JSON
+    line) is this process's stdout.  If a rank fails the others are stopped (exactly the PIDs started here) and its
+    exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_BENCH_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     from neurec_amd import engine as E, parallel, synth
     from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
@@ -733,8 +770,9 @@ def main():
         # one rank: the modes coincide.  N ranks: the column-sharded engine when the width divides
         args.dp_mode = "replicated" if not comm.active else ("colshard" if args.dim % comm.world == 0 else "allreduce")
     if args.gpus != comm.world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
-                         "--nproc-per-node %d" % (args.gpus, comm.world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node and --gpus must agree "
+                         "(a plain `python bench.py --gpus %d` starts its own ranks)"
+                         % (args.gpus, comm.world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dev = torch.device("cuda", torch.cuda.current_device())
 

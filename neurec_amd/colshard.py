@@ -63,7 +63,7 @@ class ColumnShardedLightGCN:
             raise ValueError("batch larger than max_batch")
         ctx, n = self.local._ctx, 3 * B
         ctx.lightgcn_step_colshard_fwd(users, pos, neg, self._parts)
-        if self.comm.active and self.world == self.comm.world:
+        if self.comm.live and self.world == self.comm.world:
             allp = torch.empty((self.world, n), dtype=torch.float32, device=self._parts.device)
             self.comm.all_gather_rows(self._parts[:n], allp)            # the step's ONE exchange: 12 B per triplet and rank
             E.partials_sum(allp, self.world, n, self._given)
@@ -77,7 +77,7 @@ class ColumnShardedLightGCN:
     def final_embeddings(self):
         """Full (user, item) E* tables on every rank: one all-gather of the column slices (evaluation entrance)."""
         eu, ei = self.local.final_embeddings()
-        if not (self.comm.active and self.world == self.comm.world):
+        if not (self.comm.live and self.world == self.comm.world):
             return eu, ei
         loc = torch.cat([eu, ei]).contiguous()                           # [N][d_loc]
         allc = torch.empty((self.world,) + tuple(loc.shape), dtype=loc.dtype, device=loc.device)

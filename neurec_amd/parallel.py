@@ -30,33 +30,71 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, rank=0, world=1, local_rank=0, backend=None):
+    """Collectives of the hot path.  STREAM CONTRACT (backend "nccl" = RCCL): every kernel of this package is
+    launched through ctypes on torch's CURRENT stream (engine._stream()); ProcessGroupNCCL runs a collective on its
+    own stream, ordered behind the work enqueued on the current stream when the collective is issued.  Every
+    method below therefore returns only after `work.wait()` has made the CURRENT stream wait for the collective
+    (a stream-side dependency, no host synchronisation) — or hands out the work object as a token whose
+    `*_finish` does that — so the next ctypes launch reads what the collective wrote.  NEUREC_DIST_DEBUG_SYNC=1
+    brackets every collective with torch.cuda.synchronize(): a run must give the same bits with and without it
+    (tests/test_rccl_gpu.py), which is how a missing dependency would show."""
+
+    def __init__(self, rank=0, world=1, local_rank=0, backend=None, force=False):
         self.rank, self.world, self.local_rank, self.backend = rank, world, local_rank, backend
+        # force: run the collectives through the process group even at world size 1 (the one-GPU RCCL test: the
+        # library loads, every call signature / dtype / split argument is accepted)
+        self.force = bool(force)
+        self.debug_sync = os.environ.get("NEUREC_DIST_DEBUG_SYNC", "") == "1"
+        self.calls = {}                                      # collective name -> times issued (tests, bench line)
 
     @property
     def active(self):
+        """more than one rank: what the ENGINES ask when they choose a mode"""
         return self.world > 1
 
+    @property
+    def live(self):
+        """collectives go through torch.distributed (more than one rank, or forced at one)"""
+        return self.world > 1 or self.force
+
+    def _enter(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+        if self.debug_sync and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def _done(self, work=None):
+        """the current stream waits for the collective (see the class docstring)"""
+        if work is not None:
+            work.wait()
+        if self.debug_sync and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
     def barrier(self):
-        if self.active:
-            dist.barrier()
+        if self.live:
+            if self.backend == "nccl":
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
 
     def allreduce_sum_(self, t):
         """In-place SUM all-reduce (RCCL on GPU tensors, gloo on CPU tensors)."""
-        if self.active:
+        if self.live:
+            self._enter("all_reduce")
             if self.backend != "nccl" and t.is_cuda:      # gloo (tests: ranks sharing one GPU): host-staged
                 host = t.detach().cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
                 t.copy_(host)
+                self._done()
             else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                self._done(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         return t
 
     def allgather_cat_start(self, parts):
         """Begin all-gathering equal-length 1-D tensors (e.g. a batch's users/pos/neg ids).
         Returns a token for allgather_cat_finish; the collective runs asynchronously."""
-        if not self.active:
+        if not self.live:
             return (list(parts), None, None)
+        self._enter("all_gather_ids")
         packed = torch.stack([p.contiguous() for p in parts]).contiguous()        # [P][k]
         out = torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype,
                           device=packed.device)
@@ -74,7 +112,7 @@ class Comm:
         parts, out, work = token
         if work is None:
             return parts
-        work.wait()
+        self._done(work)
         if parts is not None:                      # gloo path: `parts` holds the target device
             out = out.to(parts)
         return [out[:, i, :].reshape(-1).contiguous() for i in range(out.shape[1])]
@@ -83,24 +121,45 @@ class Comm:
     def all_gather_rows(self, local, out):
         """out[world·n][...] = rank-major concatenation of every rank's `local` [n][...]
         (identical shape on all ranks).  RCCL all-gather; gloo stages through the host."""
-        if not self.active:
+        if not self.live:
             out.copy_(local)
             return out
+        self._enter("all_gather")
         if self.backend == "nccl":
-            dist.all_gather_into_tensor(out, local.contiguous())
+            self._done(dist.all_gather_into_tensor(out, local.contiguous(), async_op=True))
             return out
         host = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype)
         dist.all_gather([host[r] for r in range(self.world)], local.detach().cpu().contiguous())
         out.copy_(host.reshape(out.shape))
+        self._done()
         return out
+
+    def all_gather_rows_start(self, local, out):
+        """all_gather_rows without the wait: -> token for all_gather_rows_finish.  RCCL: the collective runs on the
+        process group's stream behind what the current stream holds NOW; kernels enqueued after this call overlap it
+        (the column-sliced hop of neurec_amd/sharded.py).  gloo: done when this returns."""
+        if not self.live:
+            out.copy_(local)
+            return None
+        self._enter("all_gather_async")
+        if self.backend == "nccl":
+            return dist.all_gather_into_tensor(out, local.contiguous(), async_op=True)
+        host = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype)
+        dist.all_gather([host[r] for r in range(self.world)], local.detach().cpu().contiguous())
+        out.copy_(host.reshape(out.shape))
+        return None
+
+    def all_gather_rows_finish(self, token):
+        self._done(token)
 
     def bcast_rows_start(self, buf, src):
         """Begin broadcasting rank `src`'s `buf` into every other rank's `buf` (one chunk of a chunked all-gather:
         neurec_amd/sharded.py).  RCCL: asynchronous on the collective stream, ordered behind the work already
         enqueued on the current stream (so a receive slot is not overwritten under the kernel that still reads it);
         returns a token for bcast_rows_finish.  gloo: host-staged, done when this returns."""
-        if not self.active:
+        if not self.live:
             return None
+        self._enter("broadcast")
         if self.backend == "nccl":
             return dist.broadcast(buf, src=src, async_op=True)
         host = buf.detach().cpu().contiguous() if self.rank == src else torch.empty(tuple(buf.shape), dtype=buf.dtype)
@@ -111,8 +170,7 @@ class Comm:
 
     def bcast_rows_finish(self, token):
         """the current stream waits for the chunk (no host synchronisation)"""
-        if token is not None:
-            token.wait()
+        self._done(token)
 
     def all_to_all_rows(self, send, send_counts, recv_counts=None):
         """Variable all-to-all of rows: `send` [n][...] is ordered by destination rank,
@@ -122,18 +180,19 @@ class Comm:
         exchanged first (one host synchronisation).  RCCL all_to_all_single over xGMI; gloo:
         host-staged point-to-point."""
         send_counts = [int(c) for c in send_counts]
-        if not self.active:
+        if not self.live:
             return send, send_counts
+        self._enter("all_to_all")
         tail = tuple(send.shape[1:])
         if self.backend == "nccl":
             if recv_counts is None:
                 sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
                 rc = torch.empty_like(sc)
-                dist.all_to_all_single(rc, sc)
+                self._done(dist.all_to_all_single(rc, sc, async_op=True))
                 recv_counts = [int(c) for c in rc.cpu()]
             recv_counts = [int(c) for c in recv_counts]
             recv = torch.empty((sum(recv_counts),) + tail, dtype=send.dtype, device=send.device)
-            dist.all_to_all_single(recv, send.contiguous(), recv_counts, send_counts)
+            self._done(dist.all_to_all_single(recv, send.contiguous(), recv_counts, send_counts, async_op=True))
             return recv, recv_counts
         if recv_counts is None:
             mat = torch.empty((self.world, self.world), dtype=torch.int64)
@@ -157,17 +216,25 @@ class Comm:
             ro += recv_counts[r]
         for q in reqs:
             q.wait()
+        self._done()
         return host_recv.to(send.device), recv_counts
 
     def broadcast_(self, t, src=0):
         """In-place broadcast from rank `src` (used to re-align replicas whose scatter atomics
         summed in different orders)."""
-        if self.active:
-            dist.broadcast(t, src=src)
+        if self.live:
+            self._enter("broadcast")
+            if self.backend != "nccl" and t.is_cuda:
+                host = t.detach().cpu()
+                dist.broadcast(host, src=src)
+                t.copy_(host)
+                self._done()
+            else:
+                self._done(dist.broadcast(t, src=src, async_op=True))
         return t
 
     def max_float(self, x):
-        if not self.active:
+        if not self.live:
             return float(x)
         dev = "cuda" if (self.backend == "nccl" and torch.cuda.is_available()) else "cpu"
         t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
@@ -175,28 +242,33 @@ class Comm:
         return float(t.item())
 
     def shutdown(self):
-        if self.active and dist.is_initialized():
+        if self.live and dist.is_initialized():
             dist.destroy_process_group()
 
 
-def init_from_env(backend=None):
-    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (set by torch.distributed.run)."""
+def init_from_env(backend=None, force=None):
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (set by torch.distributed.run, or by bench.py when it starts
+    its own ranks).  Backend: NEUREC_DIST_BACKEND, else "nccl" (= RCCL) when every rank has a GPU of its own, else
+    "gloo" — RCCL cannot put two ranks on one device, so on a box with fewer GPUs than ranks the ranks share devices
+    round-robin and exchange through the host (the line then says dist_backend gloo, rccl_ranks 0).
+    force (or NEUREC_DIST_FORCE_GROUP=1): create the process group even at world size 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if force is None:
+        force = os.environ.get("NEUREC_DIST_FORCE_GROUP", "") == "1"
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if backend is None:
-        backend = os.environ.get("NEUREC_DIST_BACKEND") or \
-            ("nccl" if torch.cuda.is_available() else "gloo")
-    if torch.cuda.is_available():
-        # one process per GPU; with fewer GPUs than ranks (tests: 2 ranks on one GPU over gloo)
-        # ranks share devices round-robin
-        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-    if world > 1:
+        backend = os.environ.get("NEUREC_DIST_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+    if n_dev:
+        torch.cuda.set_device(local_rank % n_dev)
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return Comm(rank, world, local_rank, backend)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return Comm(rank, world, local_rank, backend, force=force)
 
 
 class BipartitePartition:

@@ -130,7 +130,7 @@ class RowRouter:
         dev, W, B = users.device, self.world, batch
         n, nb = users.numel(), send.shape[0]
         max_asked = int(recv.sum(1).max())
-        if self.comm.active:                               # the decision below must be the same on every rank
+        if self.comm.live:                                 # the decision below must be the same on every rank
             max_asked = int(self.comm.max_float(float(max_asked)))
         if 3 * B > 16384 or max_asked > 16384:            # one sorting workgroup per batch: routed per step instead
             return
@@ -202,7 +202,7 @@ class RowRouter:
     def _exchange_counts(self, send, sizes):
         """send [nb][world] (what I send to r in batch k) -> recv [nb][world] (what r sends me);
         sizes [nb] -> [nb][world] batch length of every rank."""
-        if not self.comm.active:
+        if not self.comm.live:
             return send.clone(), sizes.view(-1, 1).clone()
         import torch.distributed as dist
         nb = send.shape[0]
@@ -428,7 +428,7 @@ class ShardedLightGCN:
         # rows this rank was asked for in the current step (= rows of E* the loss reads = rows that receive gradient):
         # the last forward hop produces only those, the first backward hop skips operand rows outside them
         self.flag = torch.zeros(self.b, dtype=torch.uint8, device=dev)
-        self.flagX = self.flag if (not comm.active or self.pipeline) else \
+        self.flagX = self.flag if (not comm.live or self.pipeline) else \
             torch.zeros(self.Npad, dtype=torch.uint8, device=dev)
         self.es_buf, self.e0_buf = z(B3, self.d), z(B3, self.d)
         self._pow2 = ((self.L + 1) & self.L) == 0
@@ -489,7 +489,7 @@ class ShardedLightGCN:
     # ------------------------------------------------------------------ propagation
     def _operand(self, local):
         """the gathered [n_pad][d] operand of a hop: one all-gather (at one rank the block itself)"""
-        if not self.comm.active:
+        if not self.comm.live:
             return local
         self.comm.all_gather_rows(local, self.X)                        # exchange: one all-gather per hop
         return self.X
@@ -518,7 +518,7 @@ class ShardedLightGCN:
         """Full (user, item) tables on every rank (one all-gather; evaluation entrance)."""
         loc = torch.zeros_like(self.Esum)
         E.div_scalar(self.propagate(), float(self.L + 1), loc)
-        full = self.X if self.comm.active else torch.empty_like(loc)
+        full = self.X if self.comm.live else torch.empty_like(loc)
         self.comm.all_gather_rows(loc, full)
         return self.natural(full)
 
@@ -566,7 +566,7 @@ class ShardedLightGCN:
         # --- backward hops: G_k = H + Aᵀ G_{k+1}; H is non-zero on the asked rows only (first hop skips the rest),
         #     the last hop carries ApplyAdam as its epilogue where the lane-group schedule exists
         chunked = self.At.chunked is not None
-        if self.comm.active and not chunked:
+        if self.comm.live and not chunked:
             self.comm.all_gather_rows(self.flag, self.flagX)
         g = self.H
         ping = (self.Ga, self.Gb)
