@@ -52,6 +52,11 @@ def parse():
                          "row-sharded, nothing repeated (all-gather per hop + all-to-all lookups; the config-4 "
                          "path).  Opt-in, fully redundant compute: replicated (every rank generates the global "
                          "batch itself and runs the whole step on it, no exchange) and triplets (ids all-gathered)")
+    ap.add_argument("--rowshard-hop", choices=("sliced", "allgather", "chunked", "reduce"), default=None,
+                    help="--dp-mode rowshard: how a propagation hop gets the other ranks' rows (neurec_amd/sharded.py; "
+                         "default: sliced — column slabs all-gathered under the one-launch SpMM of the previous slab, "
+                         "exact; reduce — item rows as per-rank partials + all-to-all, 5x fewer bytes at config 4, "
+                         "within fp32 rounding)")
     ap.add_argument("--full-line", action="store_true",
                     help="print the full line (every leg with kernels, notes and samples) instead of the compact one the "
                          "driver parses; the full line always goes to bench_full.json as well")
@@ -325,9 +330,10 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     return out
 
 
-def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
+def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=None):
     """BASELINE configs[3] (LightGCN, U = 10^7, I = 10^6, E = 2*10^8, d = 128) at `scale` on this GPU through
-    the row-sharded engine: graph generated on the device, adjacency block built on the device."""
+    the row-sharded engine: graph generated on the device, adjacency block built on the device.  hop: the form of the
+    per-hop exchange (sharded.ShardedLightGCN: sliced / allgather / chunked / reduce; None = the engine's default)."""
     import torch
     from neurec_amd import engine as E, parallel as par, synth
     from neurec_amd.sharded import ShardedLightGCN
@@ -343,7 +349,7 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
     g = torch.Generator(device=dev)
     g.manual_seed(2017 + comm.rank)
     E0 = (torch.rand((ur[1] - ur[0]) + (ir[1] - ir[0]), dim, generator=g, device=dev) * 2 - 1) * lim
-    lg = ShardedLightGCN(comm, None, U, I, E0, layers, 0.01, 1e-3, batch, local_rows=rows)
+    lg = ShardedLightGCN(comm, None, U, I, E0, layers, 0.01, 1e-3, batch, local_rows=rows, hop=hop)
     del rows, E0
     trc = E.DeviceCSR(tr_ptr, tr_idx, I)
     sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=batch, shuffle=True, seed=2018, rank=comm.rank,
@@ -356,6 +362,7 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
     lg.step(bs[0][0], bs[0][1], bs[0][2], None, batch_index=0)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
+    comm.barrier()
     t0 = time.perf_counter()
     for k in range(1, steps + 1):
         lg.step(bs[k][0], bs[k][1], bs[k][2], None, batch_index=k)
@@ -363,49 +370,44 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3):
     comm.barrier()
     dt = comm.max_float(time.perf_counter() - t0) / steps
 
-    Xg = lg.X                                            # the gathered operand of the one-launch hop
-
     def hops():
         for k in range(2 * layers):
-            lg.A.matmul(Xg, out=(lg.Ya, lg.Yb)[k % 2], addend=lg.H)
-    spmm_ms = _hip_timed(hops, 2, 1) / (2 * layers)
+            lg.local_pass(k)
+    spmm_ms = _hip_timed(hops, 2, 1) / (2 * layers)          # per HOP: every launch of the form, no collective
     spmm_bytes = lg.A.algorithmic_bytes(dim)
     gathered = int(lg.A.nnz) * dim * 4
     exchange = None
-    if comm.active:
+    if comm.live:
+        # one whole hop with the run's own collectives (the form's exchange overlapped the way the step overlaps it)
         comm.barrier()
-        ag_ms = _hip_timed(lambda: comm.all_gather_rows(lg.E0, lg.X), 3, 1)
-        # the whole hop both ways, with the real collectives of this run (pick by evidence):
-        # (a) one all-gather, then the one-launch SpMM; (b) the operand in rank-ordered chunks under the launches
-        comm.barrier()
-        hop_a = _hip_timed(lambda: (comm.all_gather_rows(lg.E0, lg.X), lg.A.matmul(lg.X, out=lg.Ya, addend=lg.H)), 3, 1)
-        hop_b = None
-        if getattr(lg.A, "chunked", None) is not None:
-            comm.barrier()
-            hop_b = _hip_timed(lambda: lg.A.chunked.matmul(comm, lg.E0, out=lg.Ya, addend=lg.H), 3, 1)
-        exchange = {"all_gather_per_hop_bytes": int(lg.X.numel() * 4), "all_gather_per_hop_ms": ag_ms,
-                    "hop_ms_allgather_then_one_launch": hop_a, "hop_ms_chunked": hop_b,
-                    "hop_form_in_the_step": "chunked" if getattr(lg.A, "chunked", None) is not None else "all-gather",
-                    "hops_per_step": 2 * layers, "received_per_rank_bytes": int(lg.X.numel() * 4 * (comm.world - 1)
-                                                                                // comm.world),
-                    "lookup_all_to_all_bytes_per_step": int(3 * batch * dim * 4 * 3),
-                    "note": "per propagation hop the other ranks' [b][d] blocks arrive in rank-ordered chunks under the "
-                            "SpMM launches (sharded.ChunkedHop: a row's sum stays one ascending-column chain) or, with "
-                            "NEUREC_ROWSHARD_PIPELINE=0, by one all-gather before a one-launch SpMM; ids -> rows -> "
-                            "gradient rows by three all-to-alls"}
+        hop_ms = _hip_timed(lambda: lg._hops((lg.A, lg.R), [dict(src=lg.E0, out=lg.Ya, addend=lg.H),
+                                                             dict(src=lg.Ya, out=lg.Yb, addend=lg.H)]), 3, 1) / 2
+        recv = (comm.world - 1) * 4 * dim * (2 * part.bi if lg.hop == "reduce" else part.b)
+        exchange = {"hop_form": lg.hop, "column_slabs": lg.S, "hop_ms": comm.max_float(hop_ms),
+                    "hop_compute_only_ms": spmm_ms, "hops_per_step": 2 * layers,
+                    "received_per_rank_bytes_per_hop": int(recv),
+                    "lookup_all_to_all_bytes_per_step": int(3 * batch * dim * 4 * 3), "backend": comm.backend,
+                    "note": {"sliced": "the table lives as column slabs; slab s+1 is all-gathered (every link busy) under "
+                                       "the one-launch SpMM of slab s, across hop boundaries too; exact",
+                             "allgather": "one all-gather of the [b][d] blocks, then the one-launch SpMM; exact",
+                             "chunked": "r04: W rank-ordered broadcasts under W carry launches; exact",
+                             "reduce": "user rows: all-gather of the item blocks only; item rows: per-rank partials over "
+                                       "the rank's own user rows, equal-split all-to-all, rank-ordered sums at the "
+                                       "owners; within fp32 rounding of the exact forms"}[lg.hop] +
+                            "; ids -> rows -> gradient rows by three all-to-alls"}
     out = {"scale": scale, "users": U, "items": I, "interactions": n_train, "dim": dim, "batch": batch,
            "layers": layers, "steps": steps, "ms_per_step": dt * 1e3, "triplets_per_sec": comm.world * batch / dt,
-           "setup_seconds": setup_s, "ranks": comm.world, "exchange": exchange,
-           "roofline": {"bound": "hbm", "kernel": lg.A.full_pass_kernel(dim), "bytes_per_launch": spmm_bytes,
+           "setup_seconds": setup_s, "ranks": comm.world, "hop": lg.hop, "exchange": exchange,
+           "roofline": {"bound": "hbm", "kernel": lg.A.full_pass_kernel(lg.w), "bytes_per_launch": spmm_bytes,
                         "us_per_launch": spmm_ms * 1e3, "launches_per_step": 2 * layers,
                         "achieved": spmm_bytes / spmm_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": spmm_bytes / spmm_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
                         "row_gather_bytes_per_launch": gathered, "row_gather_GBps": gathered / spmm_ms / 1e6,
-                        "note": "algorithmic bytes read every operand row once; a CSR pass gathers one %d-B row per "
-                                "non-zero from a table no cache holds — random row gathers run at 7.3-7.4 TB/s on "
-                                "this part whether the table sits in the Infinity Cache or in HBM (6.3 at 5 GB; "
-                                "profiles/r03_exp_gather_vs_table_size.txt), which is the rate the pass sustains"
-                                % (dim * 4)}}
+                        "note": "per hop (all %d slab launches); algorithmic bytes read every operand row once; a CSR "
+                                "pass gathers one %d-B row per non-zero from a table no cache holds — random row "
+                                "gathers run at 7.3-7.4 TB/s on this part whether the table sits in the Infinity "
+                                "Cache or in HBM (6.3 at 5 GB; profiles/r03_exp_gather_vs_table_size.txt), which is "
+                                "the rate the pass sustains" % (lg.S, lg.w * 4)}}
     del lg, sampler, trc, tr_ptr, tr_idx
     torch.cuda.empty_cache()
     return out
@@ -435,11 +437,17 @@ def leg_config4_partitions(dev, scale, which="both", W=8, dim=128, L=3, B=8192):
         def bcast_rows_start(self, buf, src):
             return None
 
-        def bcast_rows_finish(self, token):
-            pass
-
         def all_gather_rows(self, local, out_):
             return out_
+
+        def all_gather_rows_start(self, local, out_):
+            return None
+
+        def all_to_all_equal_start(self, send, recv):
+            return None
+
+        def _done(self, work=None):
+            pass
 
     if which in ("rows", "both"):
         from neurec_amd.sharded import ShardedLightGCN
@@ -448,32 +456,51 @@ def leg_config4_partitions(dev, scale, which="both", W=8, dim=128, L=3, B=8192):
         rows = synth.device_lightgcn_rank_rows(tr_ptr, tr_idx, U, I, ur, ir)
         lim = float(np.sqrt(6.0 / (U + I + dim)))
         E0 = (torch.rand((ur[1] - ur[0]) + (ir[1] - ir[0]), dim, device=dev) * 2 - 1) * lim
-        t0 = time.perf_counter()
-        lg = ShardedLightGCN(Share(), None, U, I, E0, L, 0.01, 1e-3, B, local_rows=rows, pipeline=True)
-        torch.cuda.synchronize()
-        build_s = time.perf_counter() - t0
+        b, forms = part.b, {}
+        nnz = None
+        for name, kw in (("allgather", dict(hop="allgather")), ("sliced2", dict(hop="sliced", col_slices=2)),
+                         ("sliced4", dict(hop="sliced", col_slices=4)), ("reduce", dict(hop="reduce")),
+                         ("chunked", dict(hop="chunked"))):
+            t0 = time.perf_counter()
+            lg = ShardedLightGCN(Share(), None, U, I, E0, L, 0.01, 1e-3, B, local_rows=rows, **kw)
+            torch.cuda.synchronize()
+            build_s = time.perf_counter() - t0
+            nnz = int(lg.A.nnz)
+            for k in range(min(lg.S, 2)):
+                lg._xbuf(k).uniform_(-lim, lim)             # what the (skipped) all-gather would have delivered
+            hop = [dict(src=lg.E0, out=lg.Ya, addend=lg.H)]
+            f = {"build_seconds": build_s, "column_slabs": lg.S, "slab_bytes_per_row": lg.w * 4,
+                 "hop_compute_ms": _hip_timed(lambda: lg._hops((lg.A, lg.R), hop), 3, 1),
+                 "kernel": lg.A.full_pass_kernel(lg.w),
+                 "received_bytes_per_hop": (W - 1) * 4 * dim * (2 * part.bi if name == "reduce" else b)}
+            if name == "reduce":
+                Mu, Mp = lg.R
+                lg._Z.uniform_(-lim, lim)
+                bu = part.bu
+                f["partial_product_ms"] = _hip_timed(lambda: Mp.matmul(lg.E0[0], out=lg._P), 3, 1)
+                f["user_rows_ms"] = _hip_timed(lambda: Mu.matmul(lg._Z, out=lg.Ya[0][:bu], addend=lg.H[0][:bu]), 3, 1)
+                f["ordered_sum_of_%d_partials_ms" % W] = _hip_timed(
+                    lambda: E.partials_sum_rows(lg._Rv.view(W, b - bu, dim), W, out=lg.Ya[0][bu:], addend=lg.H[0][bu:]), 3, 1)
+                f["nnz_user_rows"], f["nnz_partial"] = int(Mu.nnz), int(Mp.nnz)
+            if name == "chunked":
+                ch = lg.A.chunked
+                Yv, slots = ch.buffers(dim, dev)
+                per = []
+                for r in range(W):                          # the chunk launches one by one
+                    c = ch.chunks[r]
+                    per.append(_hip_timed(lambda: E.call("nrhip_spmm_csr_carry", c.plan, E._ptr(c.indptr), E._ptr(c.indices),
+                                                         E._ptr(c.vals), E._ptr(lg.E0[0]), E._ptr(slots[r & 1]), b, dim,
+                                                         E._ptr(Yv), 1 if r else 0, E._ptr(None, allow_none=True),
+                                                         E._stream()), 3, 1))
+                f["chunk_launch_ms"], f["virtual_rows"] = per, ch.n_virtual
+                del ch, Yv, slots
+            f["row_gather_GBps"] = nnz * dim * 4 / f["hop_compute_ms"] / 1e6
+            forms[name] = f
+            del lg
+            torch.cuda.empty_cache()
+        out["rowshard_rank0_of_%d" % W] = {"rows_per_rank": b, "nnz_per_rank": nnz, "row_gather_bytes_per_hop": nnz * dim * 4,
+                                           "hops_per_step": 2 * L, "forms": forms}
         del rows, E0
-        ch, comm, b = lg.A.chunked, lg.comm, part.b
-        ms_ch = _hip_timed(lambda: ch.matmul(comm, lg.E0, out=lg.Ya, addend=lg.H), 3, 1)
-        X = lg.X                                           # [W·b][d] gathered operand of the one-launch form
-        X.uniform_(-lim, lim)
-        ms_one = _hip_timed(lambda: lg.A.matmul(X, out=lg.Ya, addend=lg.H), 3, 1)
-        Yv, slots = ch.buffers(dim, dev)
-        per = []
-        for r in range(W):                                  # the chunk launches one by one
-            c = ch.chunks[r]
-            per.append(_hip_timed(lambda: E.call("nrhip_spmm_csr_carry", c.plan, E._ptr(c.indptr), E._ptr(c.indices),
-                                                 E._ptr(c.vals), E._ptr(lg.E0), E._ptr(slots[r & 1]), b, dim, E._ptr(Yv),
-                                                 1 if r else 0, E._ptr(None, allow_none=True), E._stream()), 3, 1))
-        nnz = int(lg.A.nnz)
-        out["rowshard_rank0_of_%d" % W] = {
-            "rows_per_rank": b, "nnz_per_rank": nnz, "virtual_rows": ch.n_virtual, "build_seconds": build_s,
-            "hop_ms_chunked_%d_launches_plus_finish" % W: ms_ch, "hop_ms_one_launch": ms_one, "chunk_launch_ms": per,
-            "row_gather_bytes_per_hop": nnz * dim * 4, "row_gather_GBps_chunked": nnz * dim * 4 / ms_ch / 1e6,
-            "row_gather_GBps_one_launch": nnz * dim * 4 / ms_one / 1e6,
-            "received_bytes_per_hop": (W - 1) * b * dim * 4, "hops_per_step": 2 * L,
-            "operand_buffers_bytes": {"chunked_two_slots": 2 * b * dim * 4, "one_launch_gathered": W * b * dim * 4}}
-        del lg, ch, X, Yv, slots
         torch.cuda.empty_cache()
     if which in ("cols", "both"):
         from neurec_amd.trainer import LightGCNEngine
@@ -510,19 +537,32 @@ def leg_config4_partitions(dev, scale, which="both", W=8, dim=128, L=3, B=8192):
             "exchange_bytes_per_rank_per_step": 12 * gB, "triplets_per_sec_if_exchange_were_free": gB / ms * 1e3}
         del lgc, A, trc
         torch.cuda.empty_cache()
-    # what the measured compute sides mean at W ranks over xGMI (7 links x 76.8 GB/s per direction into a GPU)
+    # what the measured compute sides mean at W ranks over xGMI (7 links x 76.8 GB/s per direction into a GPU) — ONE
+    # number per form, under ONE stated assumption; the chunked form's second number is there because its
+    # collective is W one-source broadcasts and nothing measured here says they use more than the direct link
     link_in = 7 * 76.8e9
     rs, cs = out.get("rowshard_rank0_of_%d" % W), out.get("colshard_rank0_of_%d" % W)
-    model = {"link_in_bytes_per_s": link_in, "assumed": "every collective keeps all 7 incoming links busy (multi-ring)"}
+    model = {"link_in_bytes_per_s": link_in,
+             "assumed": "all_gather_into_tensor / all_to_all_single keep all 7 incoming links busy; steady state of a "
+                        "chain of hops (the first slab of a step's first hop is exposed once)"}
     if rs:
-        comm_ms = rs["received_bytes_per_hop"] / link_in * 1e3
-        model["rowshard_hop_ms_allgather_then_one_launch"] = comm_ms + rs["hop_ms_one_launch"]
-        model["rowshard_hop_ms_chunked_pipelined"] = max(comm_ms, sum(rs["chunk_launch_ms"])) + \
-            rs["chunk_launch_ms"][-1] + (rs["hop_ms_chunked_%d_launches_plus_finish" % W] - sum(rs["chunk_launch_ms"]))
-        model["rowshard_hop_ms_chunked_direct_links_only"] = (W - 1) * (rs["received_bytes_per_hop"] / (W - 1)) / 76.8e9 \
-            * 1e3 + rs["chunk_launch_ms"][-1]
-        model["rowshard_step_ms_pipelined"] = 2 * L * model["rowshard_hop_ms_chunked_pipelined"]
-        model["rowshard_step_ms_unpipelined"] = 2 * L * model["rowshard_hop_ms_allgather_then_one_launch"]
+        fm = rs["forms"]
+        ms = lambda f: f["received_bytes_per_hop"] / link_in * 1e3
+        model["hop_ms"] = {
+            "allgather": ms(fm["allgather"]) + fm["allgather"]["hop_compute_ms"],
+            "sliced2": max(ms(fm["sliced2"]), fm["sliced2"]["hop_compute_ms"]),
+            "sliced4": max(ms(fm["sliced4"]), fm["sliced4"]["hop_compute_ms"]),
+            "reduce": max(ms(fm["reduce"]) / 2, fm["reduce"]["partial_product_ms"]) +
+            max(ms(fm["reduce"]) / 2, fm["reduce"]["user_rows_ms"]) + fm["reduce"]["ordered_sum_of_%d_partials_ms" % W],
+            "chunked": max(ms(fm["chunked"]), sum(fm["chunked"]["chunk_launch_ms"])) + fm["chunked"]["chunk_launch_ms"][-1] +
+            (fm["chunked"]["hop_compute_ms"] - sum(fm["chunked"]["chunk_launch_ms"])),
+            "chunked_if_broadcasts_use_one_link": fm["chunked"]["received_bytes_per_hop"] / 76.8e9 * 1e3 +
+            fm["chunked"]["chunk_launch_ms"][-1]}
+        model["hop_bound_by"] = {k: ("links" if ms(fm[k]) > fm[k]["hop_compute_ms"] else "compute")
+                                 for k in ("sliced2", "sliced4")}
+        model["hop_bound_by"]["reduce"] = "links" if ms(fm["reduce"]) / 2 > min(fm["reduce"]["partial_product_ms"],
+                                                                                 fm["reduce"]["user_rows_ms"]) else "compute"
+        model["step_ms"] = {k: 2 * L * v for k, v in model["hop_ms"].items()}
     if cs:
         model["colshard_step_ms"] = cs["ms_per_step"]
     out["model_at_%d_ranks" % W] = model
@@ -687,8 +727,14 @@ def compact_line(line):
         "config4_triplets_per_sec": _get(line, "config4", "triplets_per_sec"),
         "config4_spmm_hbm_frac": _get(line, "config4", "roofline", "frac"),
         "config4_row_gather_GBps": _get(line, "config4", "roofline", "row_gather_GBps"),
-        "config4_rowshard_rank0of8_hop_ms": _get(line, "config4", "partitions", "rowshard_rank0_of_8",
-                                                 "hop_ms_chunked_8_launches_plus_finish"),
+        "config4_rank0of8_hop_ms_allgather": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "allgather"),
+        "config4_rank0of8_hop_ms_sliced2": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "sliced2"),
+        "config4_rank0of8_hop_ms_sliced4": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "sliced4"),
+        "config4_rank0of8_hop_ms_reduce": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "reduce"),
+        "config4_rank0of8_hop_compute_ms_sliced2": _get(line, "config4", "partitions", "rowshard_rank0_of_8", "forms",
+                                                        "sliced2", "hop_compute_ms"),
+        "config4_rank0of8_hop_compute_ms_reduce": _get(line, "config4", "partitions", "rowshard_rank0_of_8", "forms",
+                                                       "reduce", "hop_compute_ms"),
         "config4_colshard_rank0of8_step_ms": _get(line, "config4", "partitions", "colshard_rank0_of_8", "ms_per_step"),
     }
     for w in ("2", "4", "8"):
@@ -696,11 +742,10 @@ def compact_line(line):
     legs["same_global_batch_on_1gpu_triplets_per_sec"] = _get(line, "same_global_batch_on_1gpu", "value")
     legs["exchange_ms_per_step"] = _get(line, "exchange_measured", "ms_per_step")
     legs["rowshard_config4_law_ms_per_step"] = _get(line, "rowshard_config4_law", "ms_per_step")
-    legs["rowshard_config4_law_all_gather_per_hop_ms"] = _get(line, "rowshard_config4_law", "exchange",
-                                                              "all_gather_per_hop_ms")
-    legs["rowshard_config4_law_hop_ms_chunked"] = _get(line, "rowshard_config4_law", "exchange", "hop_ms_chunked")
-    legs["rowshard_config4_law_hop_ms_allgather_one_launch"] = _get(line, "rowshard_config4_law", "exchange",
-                                                                    "hop_ms_allgather_then_one_launch")
+    legs["rowshard_config4_law_hop"] = _get(line, "rowshard_config4_law", "hop")
+    legs["rowshard_config4_law_hop_ms"] = _get(line, "rowshard_config4_law", "exchange", "hop_ms")
+    legs["rowshard_config4_law_reduce_ms_per_step"] = _get(line, "rowshard_config4_law_reduce", "ms_per_step")
+    legs["rowshard_config4_law_reduce_hop_ms"] = _get(line, "rowshard_config4_law_reduce", "exchange", "hop_ms")
     roof.update({k: v for k, v in legs.items() if v is not None})
     out["roofline"] = roof
     cb = line.get("cpu_baseline")
@@ -804,7 +849,8 @@ def main():
         lim = float(np.sqrt(6.0 / (U + I + args.dim)))
         g = torch.Generator(device=dev); g.manual_seed(2017 + comm.rank)
         E0 = (torch.rand((ur[1] - ur[0]) + (ir[1] - ir[0]), args.dim, generator=g, device=dev) * 2 - 1) * lim
-        lg = ShardedLightGCN(comm, None, U, I, E0, args.layers, 0.01, 1e-3, args.batch, local_rows=rows)
+        lg = ShardedLightGCN(comm, None, U, I, E0, args.layers, 0.01, 1e-3, args.batch, local_rows=rows,
+                             hop=args.rowshard_hop)
         del rows
         trc, tec, train, test = E.DeviceCSR(tr_ptr, tr_idx, I), None, None, None
         args.no_eval, args.no_mf, args.no_cpu_baseline = True, True, True
@@ -828,7 +874,7 @@ def main():
         E0 = synth.xavier_uniform(U + I, args.dim, np.random.RandomState(2017))
         if rowshard:
             from neurec_amd.sharded import ShardedLightGCN
-            lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
+            lg = ShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch, hop=args.rowshard_hop)
         elif colshard:
             from neurec_amd.colshard import ColumnShardedLightGCN
             lg = ColumnShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, global_batch)
@@ -911,7 +957,7 @@ def main():
     full = lg                                            # what evaluation asks for the tables
     if colshard:
         lg = lg.local                                    # the rank's own engine: its kernels are what is profiled below
-    wdim = lg.d if colshard else args.dim                # width the rank's kernels run at (its columns, padded)
+    wdim = lg.d if colshard else (lg.w if rowshard else args.dim)   # width the rank's kernels run at (its columns / slab)
     reps = 20 if lg.A.nnz < 50_000_000 else 3
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lg.propagate(); torch.cuda.synchronize()
@@ -919,7 +965,7 @@ def main():
     for _ in range(reps):
         if rowshard:                                     # local SpMM launches only (no collectives)
             for k in range(2 * args.layers):
-                lg.A.matmul(lg.X, out=(lg.Ya, lg.Yb)[k % 2], addend=lg.H)
+                lg.local_pass(k)
             continue
         # the plain pass Y = A·X — the launch the step's full hops are (no running-sum or addend streams:
         # the 49.6 MB of SURVEY 8d's formula are exactly its bytes), L forward + L backward operands
@@ -932,8 +978,8 @@ def main():
             lg.At.matmul(g, out=(lg.Ga, lg.Gb)[k % 2])
             g = (lg.Ga, lg.Gb)[k % 2]
     ev1.record(); torch.cuda.synchronize()
-    spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))
-    spmm_bytes = lg.A.algorithmic_bytes(wdim)
+    spmm_ms = ev0.elapsed_time(ev1) / (reps * 2 * max(args.layers, 1))     # row-sharded: per hop (all its slab launches)
+    spmm_bytes = lg.A.algorithmic_bytes(args.dim if rowshard else wdim)
     achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
     kernel = lg.A.full_pass_kernel(wdim)
     # traffic: PMC counters cannot be read inside this process; the committed rocprofv3 --pmc passes
@@ -1222,8 +1268,8 @@ def main():
                        % (comm.world, global_batch) if replicated else
                        "dp%d (replicated tables; per step one all-gather of 12 B/triplet of ids, every rank steps on "
                        "the global batch)" % comm.world if exchange else
-                       "rowshard%d (tables row-sharded; all-gather per hop, all-to-all row lookups, owner-local Adam)"
-                       % comm.world if rowshard else
+                       "rowshard%d (tables row-sharded; %s hop, all-to-all row lookups, owner-local Adam)"
+                       % (comm.world, lg.hop) if rowshard else
                        "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()], "timed_region": timed_region,
@@ -1314,12 +1360,13 @@ def main():
         # per hop, all-to-all lookups (north_star's row-shard path); nothing is repeated across ranks
         ev = None
         torch.cuda.empty_cache()
-        try:
-            leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0)
-        except Exception as e:          # a secondary leg must not take the headline (already measured above) down
-            leg = {"error": "%s: %s" % (type(e).__name__, e)}
-        if comm.rank == 0:
-            line["rowshard_config4_law"] = leg
+        for key, hop in (("rowshard_config4_law", None), ("rowshard_config4_law_reduce", "reduce")):
+            try:
+                leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0, hop=hop)
+            except Exception as e:      # a secondary leg must not take the headline (already measured above) down
+                leg = {"error": "%s: %s" % (type(e).__name__, e)}
+            if comm.rank == 0:
+                line[key] = leg
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         tables = None
         if eval_info is not None:

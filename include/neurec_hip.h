@@ -490,6 +490,14 @@ int nrhip_spmm_chunks_finish(const int32_t* d_first_vrow, int64_t n_rows, const 
                              const float* d_addend, const float* d_sum_in, float* d_sum_out,
                              const uint8_t* d_row_mask, void* stream);
 
+/* Reduced-exchange hop of the row-sharded engine (neurec_amd/sharded.py hop="reduce"; LightGCN.py:132-149 with the
+ * item rows' sums formed as per-rank partials over each rank's OWN user rows): d_parts[world][n_rows][d]
+ * holds the partial rows an owner received, rank-major; Y[r] = parts[0][r] + parts[1][r] + ... in rank order (one
+ * fixed association), then nrhip_spmm_csr's epilogue (addend, running sum).  d_row_mask (optional): 0 = row left
+ * untouched.  d a multiple of 4. */
+int nrhip_partials_sum_rows(const float* d_parts, int world, int64_t n_rows, int d, float* d_Y, const float* d_addend,
+                            const float* d_sum_in, float* d_sum_out, const uint8_t* d_row_mask, void* stream);
+
 int nrhip_spmm_csr_rows(const int64_t* d_indptr, const int32_t* d_indices, const float* d_vals,
                         const float* d_X, int d, const int32_t* d_rows, int n_listed, float* d_Y,
                         const float* d_addend, const float* d_sum_in, float* d_sum_out,

@@ -175,6 +175,7 @@ SIGNATURES = {
     "nrhip_spmm_csr_masked": [p, p, p, p, p, p, p, i32, p, p, p, p, p, sz, p],
     "nrhip_spmm_csr_carry": [p, p, p, p, p, p, i32, i32, p, i32, p, p],
     "nrhip_spmm_chunks_finish": [p, i64, p, i32, p, p, p, p, p, p],
+    "nrhip_partials_sum_rows": [p, i32, i64, i32, p, p, p, p, p, p],
     "nrhip_spmm_csr_rows": [p, p, p, p, i32, p, i32, p, p, p, p, p],
     "nrhip_lightgcn_mark_batch": [p, p, p, i32, i32, p, p, p],
     "nrhip_lightgcn_bpr_grad": [p, p, i32, i32, i32, p, p, p, i32, f32, p, p, p, p, p, p],

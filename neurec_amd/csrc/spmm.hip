@@ -685,6 +685,36 @@ __global__ __launch_bounds__(kLegacyWaves* NR_WAVE) void spmm_chunks_finish_kern
   }
 }
 
+// Reduced-exchange hop of the row-sharded engine (neurec_amd/sharded.py, hop="reduce"): every rank multiplied ITS
+// user rows into partial item rows; the owner of an item block has received the W partials of its rows
+// (parts[q][row][*], rank-major) and adds them in RANK ORDER — one fixed association, the same on every run —
+// then the fused epilogue of nrhip_spmm_csr.  Streams: W + 2..4 reads and 1..2 writes of [n_rows][d] fp32; float4 lanes.
+__global__ __launch_bounds__(256) void partials_sum_rows_kernel(
+    const float4* __restrict__ parts, int world, int64_t n_rows, int d4, float4* __restrict__ Y,
+    const float4* __restrict__ addend, const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ row_mask) {
+  const int64_t n4 = n_rows * d4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    if (row_mask && row_mask[i / d4] == 0) continue;
+    float4 acc = parts[i];
+    for (int q = 1; q < world; ++q) {
+      const float4 t = parts[(int64_t)q * n4 + i];
+      acc.x = __fadd_rn(acc.x, t.x); acc.y = __fadd_rn(acc.y, t.y);
+      acc.z = __fadd_rn(acc.z, t.z); acc.w = __fadd_rn(acc.w, t.w);
+    }
+    if (addend) {
+      const float4 a = addend[i];
+      acc.x = __fadd_rn(acc.x, a.x); acc.y = __fadd_rn(acc.y, a.y);
+      acc.z = __fadd_rn(acc.z, a.z); acc.w = __fadd_rn(acc.w, a.w);
+    }
+    if (Y) Y[i] = acc;
+    if (sum_out) {
+      const float4 s = sum_in[i];
+      sum_out[i] = make_float4(__fadd_rn(s.x, acc.x), __fadd_rn(s.y, acc.y), __fadd_rn(s.z, acc.z),
+                               __fadd_rn(s.w, acc.w));
+    }
+  }
+}
+
 template <int D, int WPB>
 int launch_items_carry(const SpmmPlan* p, const int64_t* indptr, const int32_t* indices, const float* vals,
                        const float* X, const float* X2, int x_split, float* Yv, bool has_carry,
@@ -1054,6 +1084,22 @@ int nrhip_spmm_chunks_finish(const int32_t* d_first_vrow, int64_t n_rows, const 
     default:
       NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "spmm_chunks_finish: embedding dim %d not built (64, 128, 256)", d);
   }
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_partials_sum_rows(const float* d_parts, int world, int64_t n_rows, int d, float* d_Y, const float* d_addend,
+                            const float* d_sum_in, float* d_sum_out, const uint8_t* d_row_mask, void* stream) {
+  NR_REQUIRE(d_parts && (d_Y || d_sum_out) && world >= 1 && n_rows >= 0, NR_ERR_ARG,
+             "partials_sum_rows: null pointer / bad count");
+  NR_REQUIRE((d_sum_out == nullptr) || (d_sum_in != nullptr), NR_ERR_ARG, "partials_sum_rows: sum_out needs sum_in");
+  NR_REQUIRE(d > 0 && d % 4 == 0, NR_ERR_UNSUPPORTED, "partials_sum_rows: width %d is not a multiple of 4", d);
+  if (n_rows == 0) return NR_OK;
+  const int64_t n4 = n_rows * (d / 4);
+  const int64_t blocks = std::min<int64_t>((n4 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(partials_sum_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)d_parts, world, n_rows, d / 4, (float4*)d_Y, (const float4*)d_addend,
+                     (const float4*)d_sum_in, (float4*)d_sum_out, d_row_mask);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -626,6 +626,16 @@ def partials_sum(parts, world, n, out):
     call("nrhip_partials_sum", _ptr(parts, torch.float32), int(world), int(n), _ptr(out, torch.float32), _stream())
 
 
+def partials_sum_rows(parts, world, out=None, addend=None, sum_in=None, sum_out=None, row_mask=None):
+    """out[r] = parts[0][r] + parts[1][r] + ... (rank order) (+ addend); sum_out = sum_in + out — the owner's half of
+    the reduced-exchange hop (nrhip_partials_sum_rows); parts is [world][n_rows][d] contiguous."""
+    n_rows, d = parts.shape[-2], parts.shape[-1]
+    call("nrhip_partials_sum_rows", _ptr(parts, torch.float32), int(world), int(n_rows), int(d),
+         _ptr(out, torch.float32, allow_none=True), _ptr(addend, allow_none=True), _ptr(sum_in, allow_none=True),
+         _ptr(sum_out, allow_none=True), _ptr(row_mask, torch.uint8, allow_none=True), _stream())
+    return out
+
+
 def route_batch(users, pos, neg, n_users, bu, bi, code_base, world, keys, packed, order, inv, counts=None):
     """requests of a batch in owner order (nrhip_route_batch); all outputs are preallocated device tensors"""
     call("nrhip_route_batch", _ptr(users, torch.int32), _ptr(pos, torch.int32), _ptr(neg, torch.int32),
@@ -795,6 +805,9 @@ class SpmmCSR:
         self.nnz = int(self.h_indptr[-1])
         self.n_cols = self.n_rows if n_cols is None else n_cols
         self.split_row = int(split_row)
+        # False: never attach the lane-group schedule (the sharded engine's column slices of a d >= 128 table keep the
+        # work-item kernel's 256-non-zero segments, i.e. the single-GPU engine's association at that d)
+        self.lane_group = True
         self.blocked = None               # lane-group schedule of the last dim asked for
         self._blocked = {}                # d -> (plan handle | None, buffer), built on first use
         nbytes = C.c_size_t(0)
@@ -843,7 +856,7 @@ class SpmmCSR:
         up to 256 non-zeros in strict order, so 128 / 256 are attached only with force=True.
         Matrices the schedule does not fit keep the work-item kernel.  NEUREC_SPMM_BLOCKED=0
         disables it (A/B measurements)."""
-        if d not in (16, 32, 64, 128, 256) or \
+        if d not in (16, 32, 64, 128, 256) or not self.lane_group or \
                 (d in (128, 256) and not force and d not in self._blocked):
             return False
         if d not in self._blocked:

@@ -219,6 +219,25 @@ class Comm:
         self._done()
         return host_recv.to(send.device), recv_counts
 
+    def all_to_all_equal_start(self, send, recv):
+        """Equal-split all-to-all of row blocks: send [world·n][...] holds n rows for every rank (destination-major),
+        recv [world·n][...] receives n rows from every rank (source-major).  -> token for all_to_all_equal_finish.
+        RCCL: asynchronous on the process group's stream (every link carries one block at the same time); gloo:
+        host-staged point-to-point, done when this returns."""
+        if not self.live:
+            recv.copy_(send)
+            return None
+        self._enter("all_to_all_equal")
+        if self.backend == "nccl":
+            return dist.all_to_all_single(recv, send, async_op=True)
+        n = send.shape[0] // self.world
+        got, _ = self.all_to_all_rows(send, [n] * self.world, [n] * self.world)
+        recv.copy_(got.reshape(recv.shape))
+        return None
+
+    def all_to_all_equal_finish(self, token):
+        self._done(token)
+
     def broadcast_(self, t, src=0):
         """In-place broadcast from rank `src` (used to re-align replicas whose scatter atomics
         summed in different orders)."""

@@ -360,19 +360,52 @@ class ChunkedHop:
 
 
 class ShardedLightGCN:
+    """hop (how a propagation hop gets the other ranks' rows; NEUREC_ROWSHARD_HOP, default "sliced" where there is
+    something to exchange and the width allows it, else "allgather"):
+      "allgather"  one all-gather of the [b][d] blocks, then the one-launch SpMM (exact);
+      "sliced"     the table lives as `col_slices` COLUMN SLABS [S][b][d/S]; SpMM column c depends on operand column c
+                   only, so slab s+1 is all-gathered (all_gather_into_tensor: every xGMI link busy) while the
+                   one-launch kernel runs on slab s, across hop boundaries too — no carry kernel, no rank order, and
+                   not a single sum re-associated: every output element is the same chain over the same non-zeros
+                   (exact; a d >= 128 table's 64-column slabs keep the work-item kernel and its 256-non-zero
+                   segments, the single-GPU engine's association at that d);
+      "chunked"    r04's form, kept for A/B: the operand in W rank-ordered broadcasts under W carry launches (exact;
+                   whether RCCL's one-source broadcasts keep more than one link busy is not known);
+      "reduce"     the reduced-exchange hop: user rows need item rows (all-gather of the item blocks only), item
+                   rows are formed as per-rank PARTIALS over each rank's OWN user rows (the transpose of its user-row
+                   block times its own block, no operand exchange) which an equal-split all-to-all delivers to the
+                   owners, added there in rank order (nrhip_partials_sum_rows).  At config 4 a rank receives 0.9 GB
+                   per hop instead of 4.9 GB, and both exchanges run under a local product.  NOT bitwise the single
+                   engine (a sum of W per-rank partial sums) — deterministic, within fp32 rounding (tests: 1e-5)."""
+
+    HOPS = ("allgather", "sliced", "chunked", "reduce")
+
     def __init__(self, comm, adj_csr, n_users, n_items, embed, n_layers, lr, reg, max_batch,
-                 symmetric=None, local_rows=None, local_rows_t=None, pipeline=None):
+                 symmetric=None, local_rows=None, local_rows_t=None, hop=None, col_slices=None):
         """adj_csr: the full [N][N] scipy adjacency (each rank slices its block), or None with
         local_rows = (indptr, indices, vals) of this rank's row block only (global column ids;
         local_rows_t for Âᵀ when Â is not symmetric).  embed: the full [N][d] table or just this
-        rank's [n_loc][d] rows.  pipeline: the chunked hop (None: on when there is more than one rank,
-        unless NEUREC_ROWSHARD_PIPELINE=0)."""
+        rank's [n_loc][d] rows."""
         dev = E.require_gpu()
         self.comm, self.rank, self.world = comm, comm.rank, comm.world
-        if pipeline is None:
-            pipeline = self.world > 1 and os.environ.get("NEUREC_ROWSHARD_PIPELINE", "1") != "0"
-        self.pipeline = bool(pipeline)
-        self._d_hint = int(embed.shape[1])
+        self.d = d = int(embed.shape[1])
+        if hop is None:
+            hop = os.environ.get("NEUREC_ROWSHARD_HOP") or ("sliced" if comm.live and d in (64, 128, 256) else "allgather")
+        if hop not in self.HOPS:
+            raise ValueError("hop must be one of %s" % (self.HOPS,))
+        if hop == "chunked" and d not in (64, 128, 256):
+            raise NotImplementedError("chunked hop: widths 64 / 128 / 256")
+        if hop == "reduce" and d not in (64, 128, 256):
+            raise NotImplementedError("reduce hop: widths 64 / 128 / 256 (masked one-launch kernels)")
+        self.hop = hop
+        if col_slices is None:
+            col_slices = int(os.environ.get("NEUREC_ROWSHARD_SLICES", "2")) if hop == "sliced" else 1
+        self.S = S = int(col_slices)
+        if hop != "sliced" and S != 1:
+            raise ValueError("col_slices > 1 needs hop='sliced'")
+        if d % S or (d // S) not in (16, 32, 64, 128, 256):
+            raise ValueError("embed_size %d in %d column slices: slab width %s is not a built SpMM width" % (d, S, d / S))
+        self.w = w = d // S
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.N = self.n_users + self.n_items
         self.L, self.reg, self.max_batch = int(n_layers), float(reg), int(max_batch)
@@ -382,42 +415,48 @@ class ShardedLightGCN:
         self.ilo, self.ihi = self.part.items_of(self.rank)
         self.nu, self.ni = self.uhi - self.ulo, self.ihi - self.ilo
         if local_rows is not None:
-            self.A = self._from_block(*local_rows)
-            self.At = self.A if local_rows_t is None else self._from_block(*local_rows_t)
+            blk = self._block_arrays(*local_rows)
+            blk_t = blk if local_rows_t is None else self._block_arrays(*local_rows_t)
         else:
             a = adj_csr.tocsr().astype(np.float32)
             a.sort_indices()
             if symmetric is None:
                 symmetric = (a != a.T).nnz == 0
-            self.A = self._local_rows(a)
-            self.At = self.A if symmetric else self._local_rows(a.T.tocsr())
+            blk = self._block_arrays(*self._slice_rows(a))
+            blk_t = blk if symmetric else self._block_arrays(*self._slice_rows(a.T.tocsr()))
+        self.A = self._gathered_matrix(*blk)
+        self.At = self.A if blk_t is blk else self._gathered_matrix(*blk_t)
+        self.R = self.Rt = None                            # (user-row matrix, partial matrix) of the reduce hop
+        if hop == "reduce":
+            self.R = self._reduce_matrices(blk, blk_t)
+            self.Rt = self.R if blk_t is blk else self._reduce_matrices(blk_t, blk)
+        del blk, blk_t
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         if isinstance(embed, torch.Tensor):             # this rank's rows (users then items) or the full table
-            self.d = embed.shape[1]
             src_u, src_i = ((embed[:self.nu], embed[self.nu:self.nu + self.ni])
                             if embed.shape[0] == self.nu + self.ni and embed.shape[0] != self.N else
                             (embed[self.ulo:self.uhi], embed[self.n_users + self.ilo:self.n_users + self.ihi]))
             src_u, src_i = src_u.to(dev), src_i.to(dev)
         else:
             embed = np.asarray(embed, dtype=np.float32)
-            self.d = embed.shape[1]
             if embed.shape[0] == self.nu + self.ni and embed.shape[0] != self.N:
                 hu, hi_ = embed[:self.nu], embed[self.nu:]
             else:
                 hu, hi_ = embed[self.ulo:self.uhi], embed[self.n_users + self.ilo:self.n_users + self.ihi]
             src_u = torch.from_numpy(np.ascontiguousarray(hu)).to(dev)
             src_i = torch.from_numpy(np.ascontiguousarray(hi_)).to(dev)
-        self.E0 = z(self.b, self.d)
-        self.E0[:self.nu] = src_u
-        self.E0[self.part.bu:self.part.bu + self.ni] = src_i
-        self.m, self.v = z(self.b, self.d), z(self.b, self.d)
-        # gathered operand of the one-all-gather hop; the chunked hop holds two [b][d] receive slots instead
-        self._X = None
-        self.Ya, self.Yb, self.Esum = (z(self.b, self.d) for _ in range(3))
-        self.H, self.Greg, self.Ga, self.Gb = (z(self.b, self.d) for _ in range(4))
+        # every [b][d] resident is S column slabs [S][b][w] (S = 1: the row-major block itself)
+        b, bu = self.b, self.part.bu
+        self.E0 = z(S, b, w)
+        for s in range(S):
+            self.E0[s, :self.nu] = src_u[:, s * w:(s + 1) * w]
+            self.E0[s, bu:bu + self.ni] = src_i[:, s * w:(s + 1) * w]
+        self.m, self.v = z(S, b, w), z(S, b, w)
+        self.Ya, self.Yb, self.Esum = (z(S, b, w) for _ in range(3))
+        self.H, self.Greg, self.Ga, self.Gb = (z(S, b, w) for _ in range(4))
+        self._Xs = []                                       # receive buffers [n_pad][w] of the all-gathered operand
         B3 = 3 * self.max_batch
-        self.req_rows = z(B3, 2 * self.d)                   # [Esum | E0] rows of my triplets
-        self.gc_star, self.gc_reg = z(B3, self.d), z(B3, self.d)
+        self.gc_star, self.gc_reg = z(B3, d), z(B3, d)
         self.terms = z(8 * self.max_batch)
         self.adam = E.AdamState(lr)
         self._cu = torch.arange(self.max_batch, dtype=torch.int32, device=dev)
@@ -427,56 +466,115 @@ class ShardedLightGCN:
         self._gidx = None
         # rows this rank was asked for in the current step (= rows of E* the loss reads = rows that receive gradient):
         # the last forward hop produces only those, the first backward hop skips operand rows outside them
-        self.flag = torch.zeros(self.b, dtype=torch.uint8, device=dev)
-        self.flagX = self.flag if (not comm.live or self.pipeline) else \
+        self.flag = torch.zeros(b, dtype=torch.uint8, device=dev)
+        self.flagX = self.flag if (not comm.live or hop in ("chunked", "reduce")) else \
             torch.zeros(self.Npad, dtype=torch.uint8, device=dev)
-        self.es_buf, self.e0_buf = z(B3, self.d), z(B3, self.d)
+        self.es_buf, self.e0_buf = z(B3, d), z(B3, d)
         self._pow2 = ((self.L + 1) & self.L) == 0
         self._Gs = None
+        # the one-launch kernels skip work by row flags at every width they have a lane-group schedule for, and at
+        # 64 columns and more without one
+        self._masks_ok = w >= 64 or (self.A.ensure_schedule(w) and self.At.ensure_schedule(w))
+        if hop == "reduce":
+            self._ipad = self.part.bi * self.world
+            self._Z = z(bu + self._ipad, d)                 # operand of the user rows: [own users ; every item row]
+            self._P = z(self._ipad, d)                      # my partial of every item row
+            self._Rv = z(self._ipad, d)                     # the W partials of MY item rows, rank-major
+            self.flagZ = torch.zeros(bu + self._ipad, dtype=torch.uint8, device=dev)
 
-    def _from_block(self, indptr, indices, vals):
-        """CSR of this rank's nu user rows followed by its ni item rows, GLOBAL node ids as columns
-        (numpy or device tensors) -> the padded [b]-row local block whose columns are positions in the
-        gathered layout; a row keeps its storage order (ascending node id)."""
+    # ------------------------------------------------------------------ this rank's rows of the adjacency
+    def _slice_rows(self, a):
+        import scipy.sparse as sp
+        blk = sp.vstack([a[self.ulo:self.uhi], a[self.n_users + self.ilo:self.n_users + self.ihi]]).tocsr()
+        return blk.indptr, blk.indices, blk.data
+
+    def _block_arrays(self, indptr, indices, vals):
+        """CSR of this rank's nu user rows followed by its ni item rows, GLOBAL node ids as columns (numpy or device
+        tensors) -> device tensors (indptr padded to the [b]-row block, global columns int64, values); a row keeps
+        its storage order (ascending node id)."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda a_, dt: (a_ if isinstance(a_, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a_))).to(dev, dt)
+        indptr, cg, va = t(indptr, torch.int64), t(indices, torch.int64), t(vals, torch.float32)
         bu = self.part.bu
-        if isinstance(indices, torch.Tensor):
-            ip = torch.zeros(self.b + 1, dtype=torch.int64, device=indices.device)
-            ip[1:self.nu + 1] = indptr[1:self.nu + 1]
-            ip[self.nu + 1:bu + 1] = indptr[self.nu]
-            ip[bu + 1:bu + self.ni + 1] = indptr[self.nu + 1:self.nu + self.ni + 1]
-            ip[bu + self.ni + 1:] = indptr[self.nu + self.ni]
-            cols = self.part.position(indices.long()).to(torch.int32)
-            return self._with_chunks(E.SpmmCSR(ip, cols, vals, n_cols=self.Npad), ip, indices, vals)
-        indptr = np.asarray(indptr, dtype=np.int64)
-        ip = np.zeros(self.b + 1, dtype=np.int64)
+        ip = torch.zeros(self.b + 1, dtype=torch.int64, device=dev)
         ip[1:self.nu + 1] = indptr[1:self.nu + 1]
         ip[self.nu + 1:bu + 1] = indptr[self.nu]
         ip[bu + 1:bu + self.ni + 1] = indptr[self.nu + 1:self.nu + self.ni + 1]
         ip[bu + self.ni + 1:] = indptr[self.nu + self.ni]
-        cols = self.part.position(np.asarray(indices, dtype=np.int64)).astype(np.int32)
-        return self._with_chunks(E.SpmmCSR(ip, cols, np.asarray(vals, np.float32), n_cols=self.Npad), ip, indices, vals)
+        return ip, cg, va
 
-    def _with_chunks(self, A, ip, cols_global, vals):
-        """attach the chunked (pipelined) form of the block (ChunkedHop) where the hop is pipelined"""
+    def _gathered_matrix(self, ip, cg, va):
+        """the block as the one-launch hop multiplies it: columns = positions in the rank-major gathered layout"""
+        A = E.SpmmCSR(ip, self.part.position(cg).to(torch.int32), va, n_cols=self.Npad)
+        # column slabs of a d >= 128 table run at 64 columns: keep the work-item kernel (256-non-zero segments) so the
+        # association stays the single-GPU engine's at that d
+        A.lane_group = not (self.S > 1 and self.d >= 128)
         A.chunked = None
-        if self.pipeline and self._d_hint in (64, 128, 256):
-            A.chunked = ChunkedHop(self.part, self.rank, ip, cols_global, vals, A.exact_row_nnz(self._d_hint),
-                                   A.indices.device)
+        if self.hop == "chunked":
+            A.chunked = ChunkedHop(self.part, self.rank, ip, cg, va, A.exact_row_nnz(self.d), A.indices.device)
         return A
 
-    def _local_rows(self, a):
-        import scipy.sparse as sp
-        blk = sp.vstack([a[self.ulo:self.uhi], a[self.n_users + self.ilo:self.n_users + self.ihi]]).tocsr()
-        return self._from_block(blk.indptr, blk.indices, blk.data)
+    def _reduce_matrices(self, blk, blk_t):
+        """(Mu, Mp) of the reduced-exchange hop Y = M·X for the matrix M whose rows of this rank are `blk` and whose
+        TRANSPOSE's rows of this rank are `blk_t` (the same arrays when M is symmetric).
+          Mu [bu] x [bu + I_pad]: my user rows; a user column (norm's self loop: my own row) -> that row of the
+             operand's first bu rows, item i -> row bu + i (the all-gathered item blocks ARE the item table in id order);
+          Mp [I_pad] x [b]: row i holds M[i][u] for MY users u (= the transpose of my user rows of Mᵀ, users ascending)
+             and, for my own items, the same-side entries of the row (the self loop, last): the partial a rank forms
+             from its own block alone."""
+        ip, cg, va = blk
+        ip_t, cg_t, va_t = blk_t
+        part, U, W = self.part, self.n_users, self.world
+        bu, bi, b, dev = part.bu, part.bi, self.b, cg.device
+        ipad = bi * W
+        n_u = int(ip[bu])
+        cu = cg[:n_u]
+        same = cu < U
+        if bool((same & ((cu < self.ulo) | (cu >= self.uhi))).any()):
+            raise NotImplementedError("reduce hop: a user-user edge to another rank (not a bipartite graph + self loops)")
+        col_u = torch.where(same, cu - self.ulo, bu + (cu - U)).to(torch.int32)
+        Mu = E.SpmmCSR(ip[:bu + 1].clone(), col_u, va[:n_u].clone(), n_cols=bu + ipad)
+        n_t = int(ip_t[bu])
+        ct, vt = cg_t[:n_t], va_t[:n_t]
+        row_u = torch.repeat_interleave(torch.arange(bu, device=dev), ip_t[1:bu + 1] - ip_t[:bu], output_size=n_t)
+        keep = ct >= U
+        i0, i1 = int(ip[bu]), int(ip[b])
+        ci, vi = cg[i0:i1], va[i0:i1]
+        row_i = torch.repeat_interleave(torch.arange(bi, device=dev), ip[bu + 1:b + 1] - ip[bu:b], output_size=i1 - i0)
+        ss = ci >= U
+        loc = ci[ss] - U - self.ilo
+        if bool(((loc < 0) | (loc >= bi)).any()):
+            raise NotImplementedError("reduce hop: an item-item edge to another rank (not a bipartite graph + self loops)")
+        rows = torch.cat([ct[keep] - U, self.ilo + row_i[ss]])
+        cols = torch.cat([row_u[keep], bu + loc])
+        vals = torch.cat([vt[keep], vi[ss]])
+        order = torch.sort(rows, stable=True).indices        # inside an item: my users ascending, then the self loop
+        ipp = torch.zeros(ipad + 1, dtype=torch.int64, device=dev)
+        ipp[1:] = torch.cumsum(torch.bincount(rows, minlength=ipad), 0)
+        Mp = E.SpmmCSR(ipp, cols[order].to(torch.int32), vals[order], n_cols=b)
+        return Mu, Mp
+
+    # ------------------------------------------------------------------ layouts
+    def _xbuf(self, k):
+        while len(self._Xs) <= k:
+            self._Xs.append(torch.zeros((self.Npad, self.w), dtype=torch.float32, device=self.E0.device))
+        return self._Xs[k]
 
     @property
     def X(self):
-        if self._X is None:
-            self._X = torch.zeros((self.Npad, self.d), dtype=torch.float32, device=self.E0.device)
-        return self._X
+        """the gathered [n_pad][w] operand buffer of a hop (w = d with one slab)"""
+        return self._xbuf(0)
+
+    def rows_of(self, slabs):
+        """[S][b][w] column slabs -> the [b][d] row-major block (a view when S = 1)"""
+        return slabs[0] if self.S == 1 else torch.cat([slabs[s] for s in range(self.S)], dim=1)
+
+    def table_rows(self):
+        """this rank's [b][d] block of E0 (users first, then items), row-major"""
+        return self.rows_of(self.E0)
 
     def natural(self, gathered):
-        """[n_pad][d] gathered (rank-major) table -> (user rows [U][d], item rows [I][d]) in id order"""
+        """[n_pad][*] gathered (rank-major) table -> (user rows [U][*], item rows [I][*]) in id order"""
         if self._gidx is None:
             self._gidx = self.part.gathered_index(gathered.device)
         return gathered[self._gidx[0]], gathered[self._gidx[1]]
@@ -487,46 +585,149 @@ class ShardedLightGCN:
         self.router.plan_epoch([users, pos, neg], self._offsets, batch)
 
     # ------------------------------------------------------------------ propagation
-    def _operand(self, local):
-        """the gathered [n_pad][d] operand of a hop: one all-gather (at one rank the block itself)"""
-        if not self.comm.live:
-            return local
-        self.comm.all_gather_rows(local, self.X)                        # exchange: one all-gather per hop
-        return self.X
+    def _hops(self, mats, hops):
+        """Run a chain of hops Y_h = M·X_h (+ epilogue).  mats = (M in gathered-column form, its reduce pair);
+        hops: dicts with src (slabs), out / addend / sum_in / sum_out (slabs or None), wanted (produce flagged rows
+        only), nonzero (operand is zero outside flagged rows), adam (last backward hop: ApplyAdam as the epilogue
+        where the d = 64 lane-group schedule exists).  Returns True when the last hop applied Adam itself."""
+        M, red = mats
+        comm, S = self.comm, self.S
+        sl = lambda t, s: None if t is None else t[s]
+        if self.hop == "reduce":
+            for hp in hops:
+                self._hop_reduce(red, hp)
+            return False
+        if M.chunked is not None:
+            for hp in hops:
+                M.chunked.matmul(comm, hp["src"][0], out=sl(hp.get("out"), 0), addend=sl(hp.get("addend"), 0),
+                                 sum_in=sl(hp.get("sum_in"), 0), sum_out=sl(hp.get("sum_out"), 0),
+                                 y_row_wanted=self.flag if hp.get("wanted") else None)
+            return False
+        tasks = [(h, s) for h in range(len(hops)) for s in range(S)]
+        live = comm.live
+        # task j's all-gather may be issued once the launches that produce its source slab (task j - S) and that
+        # still read its receive buffer (task j - lag) have been enqueued: with two slabs or more the gather of the
+        # next slab — of the next hop, too — is on the links while the current launch runs
+        lag = min(S, 2)
+        tok = {}
+
+        def start(j):
+            h, s = tasks[j]
+            tok[j] = comm.all_gather_rows_start(hops[h]["src"][s], self._xbuf(j % lag))
+        if live:
+            for j in range(min(lag, len(tasks))):
+                start(j)
+        applied = False
+        for j, (h, s) in enumerate(tasks):
+            hp = hops[h]
+            if live:
+                comm.all_gather_rows_finish(tok.pop(j))
+                X = self._xbuf(j % lag)
+            else:
+                X = hp["src"][s]
+            masks = self._masks_ok
+            if hp.get("adam") and S == 1 and M.matmul_adam(X, self.H[0], self.Greg[0], self.E0[0], self.m[0], self.v[0],
+                                                           self.adam, row_flag=self.flag):
+                applied = True
+            else:
+                M.matmul(X, out=sl(hp.get("out"), s), addend=sl(hp.get("addend"), s), sum_in=sl(hp.get("sum_in"), s),
+                         sum_out=sl(hp.get("sum_out"), s),
+                         x_row_nonzero=self.flagX if (hp.get("nonzero") and masks) else None,
+                         y_row_wanted=self.flag if (hp.get("wanted") and masks) else None)
+            if live and j + lag < len(tasks):
+                start(j + lag)
+        return applied
+
+    def _hop_reduce(self, red, hp):
+        """One reduced-exchange hop (class docstring).  Order of issue: all-gather of the item blocks ‖ my partial of
+        every item row (own block only) -> all-to-all of the partials ‖ my user rows (gathered items) -> the owners'
+        rank-ordered sums with the hop's epilogue."""
+        Mu, Mp = red
+        comm, bu, b, W = self.comm, self.part.bu, self.b, self.world
+        src = hp["src"][0]
+        row = lambda key, lo, hi: None if hp.get(key) is None else hp[key][0][lo:hi]
+        wanted, nonzero = hp.get("wanted"), hp.get("nonzero")
+        tok = comm.all_gather_rows_start(src[bu:b], self._Z[bu:])
+        Mp.matmul(src, out=self._P, y_row_wanted=self.flagZ[bu:] if wanted else None,
+                  x_row_nonzero=self.flag if nonzero else None)
+        comm.all_gather_rows_finish(tok)
+        tok = comm.all_to_all_equal_start(self._P, self._Rv)
+        if self._same_side_users(Mu):
+            E.copy2d(src[:bu], self._Z[:bu])
+        if Mu.n_rows:
+            Mu.matmul(self._Z, out=row("out", 0, bu), addend=row("addend", 0, bu), sum_in=row("sum_in", 0, bu),
+                      sum_out=row("sum_out", 0, bu), y_row_wanted=self.flag[:bu] if wanted else None,
+                      x_row_nonzero=self.flagZ if nonzero else None)
+        comm.all_to_all_equal_finish(tok)
+        E.partials_sum_rows(self._Rv.view(W, b - bu, self.d), W, out=row("out", bu, b), addend=row("addend", bu, b),
+                            sum_in=row("sum_in", bu, b), sum_out=row("sum_out", bu, b),
+                            row_mask=self.flag[bu:] if wanted else None)
+
+    def _same_side_users(self, Mu):
+        """does a user row of this matrix read a user row (norm's self loop)?  Decided once per matrix."""
+        if not hasattr(Mu, "_same_side"):
+            Mu._same_side = bool((Mu.indices[:Mu.nnz] < self.part.bu).any()) if Mu.nnz else False
+        return Mu._same_side
+
+    def _publish_flags(self):
+        """the step's row flags where the masked hops of this form read them"""
+        if self.hop == "reduce":
+            bu = self.part.bu
+            self.flagZ[:bu].copy_(self.flag[:bu])
+            self.comm.all_gather_rows(self.flag[bu:], self.flagZ[bu:])
+        elif self.flagX is not self.flag:
+            self.comm.all_gather_rows(self.flag, self.flagX)
 
     def propagate(self, wanted=None):
-        """Esum (this rank's rows) = Σ_k E^k; returns it (E* = Esum / (L+1)).  wanted: uint8 [b] — the last hop
-        then produces only the flagged rows (the rows a step's loss reads; other rows of Esum are stale)."""
+        """Esum (this rank's rows, column slabs) = Σ_k E^k; returns it (E* = Esum / (L+1)).  wanted: True — the last
+        hop then produces only the rows flagged in self.flag (the rows a step's loss reads; other rows of Esum are
+        stale)."""
         if self.L == 0:
             self.Esum.copy_(self.E0)
             return self.Esum
-        src, acc_in = self.E0, self.E0
+        hops, src, acc_in = [], self.E0, self.E0
         ping = (self.Ya, self.Yb)
         for k in range(self.L):
             last = k == self.L - 1
             out = None if last else ping[k & 1]                         # the last layer is only needed in the sum
-            if self.A.chunked is not None:
-                self.A.chunked.matmul(self.comm, src, out=out, sum_in=acc_in, sum_out=self.Esum,
-                                      y_row_wanted=wanted if last else None)
-            else:
-                self.A.matmul(self._operand(src), out=out, sum_in=acc_in, sum_out=self.Esum,
-                              y_row_wanted=wanted if last else None)
+            hops.append(dict(src=src, out=out, sum_in=acc_in, sum_out=self.Esum, wanted=bool(wanted) and last))
             src, acc_in = out, self.Esum
+        self._hops((self.A, self.R), hops)
         return self.Esum
 
+    def local_pass(self, k=0):
+        """one LOCAL full pass over this rank's rows (no collective): what bench.py times as the hop's kernel"""
+        out = (self.Ya, self.Yb)[k & 1]
+        if self.hop == "reduce":
+            Mu, Mp = self.R
+            Mp.matmul(self.E0[0], out=self._P)
+            Mu.matmul(self._Z, out=out[0][:self.part.bu], addend=self.H[0][:self.part.bu])
+            E.partials_sum_rows(self._Rv.view(self.world, self.b - self.part.bu, self.d), self.world,
+                                out=out[0][self.part.bu:], addend=self.H[0][self.part.bu:])
+            return
+        for s in range(self.S):
+            self.A.matmul(self._xbuf(0) if self.comm.live else self.E0[s], out=out[s], addend=self.H[s])
+
     def final_embeddings(self):
-        """Full (user, item) tables on every rank (one all-gather; evaluation entrance)."""
-        loc = torch.zeros_like(self.Esum)
-        E.div_scalar(self.propagate(), float(self.L + 1), loc)
-        full = self.X if self.comm.live else torch.empty_like(loc)
-        self.comm.all_gather_rows(loc, full)
-        return self.natural(full)
+        """Full (user, item) tables on every rank (one all-gather per slab; evaluation entrance)."""
+        esum = self.propagate()
+        loc = torch.empty((self.b, self.w), dtype=torch.float32, device=esum.device)
+        us, its = [], []
+        for s in range(self.S):
+            E.div_scalar(esum[s], float(self.L + 1), loc)
+            full = self._xbuf(0) if self.comm.live else torch.empty_like(loc)
+            self.comm.all_gather_rows(loc, full)
+            u, i = self.natural(full)
+            us.append(u)
+            its.append(i)
+        return (us[0], its[0]) if self.S == 1 else (torch.cat(us, 1), torch.cat(its, 1))
 
     def step(self, users, pos, neg, loss_out=None, batch_index=None):
         """One optimiser step on this rank's B triplets (global batch = all ranks' triplets)."""
-        B, d, dev = users.numel(), self.d, self.E0.device
+        B, d, w, S, dev = users.numel(), self.d, self.w, self.S, self.E0.device
         if B > self.max_batch:
             raise ValueError("batch larger than max_batch")
+        cols = lambda t, s: t[:, s * w:(s + 1) * w]
         # --- routing: ids -> owners (native: requests in owner order, one all-to-all of (row, code) pairs)
         rt = self.router.planned_route(batch_index, B)
         if rt is None:
@@ -534,10 +735,13 @@ class ShardedLightGCN:
         n_asked = rt.asked.numel()
         # --- forward: the last hop only on the rows somebody asked for
         E.mark_rows(rt.asked, self.flag)
-        esum = self.propagate(wanted=self.flag)
+        if self.hop == "reduce":
+            self._publish_flags()                          # its item rows are produced where they are NOT owned
+        esum = self.propagate(wanted=True)
         # --- lookup answers: [Esum | E0] rows back to the askers, unscattered into request order by the gather
         rows = torch.empty((n_asked, 2 * d), dtype=torch.float32, device=dev)
-        E.rows_gather2(rt.asked, esum, self.E0, rows[:, :d], rows[:, d:])
+        for s in range(S):
+            E.rows_gather2(rt.asked, esum[s], self.E0[s], cols(rows, s), cols(rows[:, d:], s))
         got, _ = self.comm.all_to_all_rows(rows, rt.recv_counts, rt.send_counts)
         es, e0 = self.es_buf[:3 * B], self.e0_buf[:3 * B]
         E.rows_gather2(rt.inv, got[:, :d], got[:, d:], es, e0)          # es[p], e0[p] = answer to request p
@@ -555,40 +759,31 @@ class ShardedLightGCN:
         E.rows_gather2(rt.order, gs, gr, back[:, :d], back[:, d:])
         mine, _ = self.comm.all_to_all_rows(back, rt.send_counts, rt.recv_counts)
         keys, index_of_pos = self.router.ordered_keys(rt)
-        if self._pow2:
-            E.rows_sum_sorted2(keys, index_of_pos, mine[:, :d], self.H, mine[:, d:], self.Greg)
-        else:
-            if self._Gs is None:                                         # zero outside the rows of a step
-                self._Gs = torch.zeros_like(self.H)
-            E.rows_sum_sorted2(keys, index_of_pos, mine[:, :d], self._Gs, mine[:, d:], self.Greg)
-            E.rows_div(rt.asked, self._Gs, float(self.L + 1), self.H)
-            E.rows_clear(rt.asked, d, (self._Gs,))
+        if not self._pow2 and self._Gs is None:                         # zero outside the rows of a step
+            self._Gs = torch.zeros_like(self.H)
+        for s in range(S):
+            if self._pow2:
+                E.rows_sum_sorted2(keys, index_of_pos, cols(mine, s), self.H[s], cols(mine[:, d:], s), self.Greg[s])
+            else:
+                E.rows_sum_sorted2(keys, index_of_pos, cols(mine, s), self._Gs[s], cols(mine[:, d:], s), self.Greg[s])
+                E.rows_div(rt.asked, self._Gs[s], float(self.L + 1), self.H[s])
+                E.rows_clear(rt.asked, w, (self._Gs[s],))
         # --- backward hops: G_k = H + Aᵀ G_{k+1}; H is non-zero on the asked rows only (first hop skips the rest),
         #     the last hop carries ApplyAdam as its epilogue where the lane-group schedule exists
-        chunked = self.At.chunked is not None
-        if self.comm.live and not chunked:
-            self.comm.all_gather_rows(self.flag, self.flagX)
-        g = self.H
+        if self.hop != "reduce":
+            self._publish_flags()
+        hops, g = [], self.H
         ping = (self.Ga, self.Gb)
-        applied = False
         for k in range(self.L):
-            if chunked:                                 # the operand arrives chunk by chunk under the launches
-                out = ping[(k + 1) & 1]
-                self.At.chunked.matmul(self.comm, g, out=out, addend=self.H)
-                g = out
-                continue
-            X = self._operand(g)
-            if k == self.L - 1 and self.L >= 2:
-                applied = self.At.matmul_adam(X, self.H, self.Greg, self.E0, self.m, self.v, self.adam,
-                                              row_flag=self.flag)
-                if applied:
-                    break
             out = ping[(k + 1) & 1]
-            self.At.matmul(X, out=out, addend=self.H, x_row_nonzero=self.flagX if k == 0 else None)
+            hops.append(dict(src=g, out=out, addend=self.H, nonzero=k == 0,
+                             adam=(k == self.L - 1 and self.L >= 2)))
             g = out
+        applied = self._hops((self.At, self.Rt), hops)
         if not applied:
             E.adam_dense2(self.E0, self.m, self.v, g, self.Greg, self.adam)
-            E.rows_clear(rt.asked, d, (self.H, self.Greg), self.flag)   # rows the ordered sums stored, and the flags
+            for s in range(S):                                          # rows the ordered sums stored, and the flags
+                E.rows_clear(rt.asked, w, (self.H[s], self.Greg[s]), self.flag if s == S - 1 else None)
         self.adam.advance()
         return loss_out
 

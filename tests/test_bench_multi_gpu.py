@@ -46,7 +46,10 @@ def test_two_rank_bench_line(mode, port):
     else:
         assert d["same_global_batch_on_1gpu"]["global_batch"] == 512 and d["same_global_batch_on_1gpu"]["value"] > 0
     leg = d["rowshard_config4_law"]                                        # every N>1 line carries the row-shard leg
-    assert leg["ranks"] == 2 and leg["ms_per_step"] > 0 and leg["exchange"]["all_gather_per_hop_ms"] > 0
+    assert leg["ranks"] == 2 and leg["ms_per_step"] > 0 and leg["hop"] == "sliced" and leg["exchange"]["hop_ms"] > 0
+    red = d["rowshard_config4_law_reduce"]                                 # ... and its reduced-exchange form
+    assert red["hop"] == "reduce" and red["ms_per_step"] > 0
+    assert red["exchange"]["received_per_rank_bytes_per_hop"] < leg["exchange"]["received_per_rank_bytes_per_hop"]
     assert abs(leg["scale"] - 0.002 * 2 / 8) < 1e-12
     mode = mode or "colshard"
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 512
