@@ -901,7 +901,8 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
       // bounded maxima (nrhip_score_filter_tilemax): every item of a tile that was not rescored scores at most
       // outside + eps[row] in the fp32 chain; the row stands only if its cut-th rescored score is strictly above
       const float s_k = C[(int64_t)row * cld + col_k];
-      flag_out[row] = !(s_k > outside + eps[row]) ? 1 : 0;
+      // (the sum rounded UP: the comparison itself must not eat into the bound; a NaN anywhere flags the row)
+      flag_out[row] = !(s_k > nr_add_up(outside, eps[row])) ? 1 : 0;
     } else {
       flag_out[row] = !(inside > outside) ? 1 : 0;
     }
@@ -1186,7 +1187,13 @@ int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int cols, int top_k, int 
   NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && top_k >= 1 && n_keep >= top_k + 1 && n_keep <= 63, NR_ERR_ARG,
              "eval_tiles_bounded_workspace_bytes: rows=%d cols=%d top_k=%d n_keep=%d (top_k + 1 .. 63)", rows, cols,
              top_k, n_keep);
-  *bytes = eval_tiles_ws_bytes(rows, n_keep) + grouped_extra_bytes(rows, cols, n_keep);
+  // a workspace sized for `rows` serves every batch of up to `rows` rows (a loop sizes it once for its
+  // full batches and a SHORT last batch may take the tile-grouped path the full ones were too large for): the
+  // grouped part is the largest any row count up to `rows` can ask for
+  const size_t n_tiles = 2 * (((size_t)cols + 63) / 64);
+  const size_t r_group = std::min<size_t>((size_t)(rows > 0 ? rows : 1),
+                                          std::min<size_t>(((size_t)1 << 30) / (n_tiles * 4), ((size_t)1 << 26) - 1));
+  *bytes = eval_tiles_ws_bytes(rows, n_keep) + (r_group ? grouped_extra_bytes((int)r_group, cols, n_keep) : 0);
   return NR_OK;
 }
 
@@ -1227,7 +1234,9 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     mids.id[i] = metric_ids_host[i];
   }
   if (rows == 0) return NR_OK;
-  const size_t extra = grouped ? grouped_extra_bytes(rows, cols, n_keep) : 0;
+  size_t extra = grouped ? grouped_extra_bytes(rows, cols, n_keep) : 0;
+  // a workspace without room for the tile buckets runs the per-row rescoring (same results) instead of failing
+  if (extra && ws_bytes < eval_tiles_ws_bytes(rows, n_keep) + extra) extra = 0;
   NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, n_keep) + extra, NR_ERR_WORKSPACE,
              "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, n_keep) + extra);
   hipStream_t st = (hipStream_t)stream;

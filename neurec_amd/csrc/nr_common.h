@@ -57,6 +57,17 @@ static inline size_t nr_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 // ---- wave-level helpers (wave64) -------------------------------------------
 __device__ __forceinline__ int nr_lane() { return threadIdx.x & (NR_WAVE - 1); }
 
+// Upward-rounded fp32 sum / product for error BOUNDS (gfx950 has no per-instruction rounding mode in HIP): the
+// round-to-nearest result moved one ulp towards +inf is >= the exact value.  NaN / +inf pass through.
+__device__ __forceinline__ float nr_next_up(float s) {
+  if (!(s < __builtin_huge_valf())) return s;                       // NaN, +inf
+  if (s == 0.f) return __uint_as_float(1u);                         // smallest sub-normal
+  const uint32_t b = __float_as_uint(s);
+  return __uint_as_float(s > 0.f ? b + 1u : b - 1u);
+}
+__device__ __forceinline__ float nr_add_up(float a, float b) { return nr_next_up(__fadd_rn(a, b)); }
+__device__ __forceinline__ float nr_mul_up(float a, float b) { return nr_next_up(__fmul_rn(a, b)); }
+
 __device__ __forceinline__ uint64_t nr_shfl_xor_u64(uint64_t x, int m) {
   uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
   lo = __shfl_xor(lo, m, NR_WAVE);

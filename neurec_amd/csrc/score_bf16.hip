@@ -13,6 +13,10 @@
 //       dropped terms (ul·il, r·x, x·r)   products of bf16 are exact in fp32; <= 192 fp32 accumulations,   the chain's
 //                                          each within 2^-23 of its partial sum (truncation allowed)        own rounding
 //     with Σ_k |u_k i_k| <= ||u||₂ ||i||₂.  tests/test_eval_gpu.py measures the left side against this bound.
+//     ASSUMED MODEL of the matrix pipe (the one thing here that is measured, not derived): each of the <= 3 d
+//     accumulate steps of v_mfma_f32_*_bf16 leaves its partial sum within 2^-23 relative (round-to-nearest or
+//     truncation of an exact product-sum) — the 1.5 and the tests' 0.6-of-the-bound ceiling are its margin; values
+//     below 2^-126 may flush, which the absolute term of eps covers (r05).
 // The ranking kernel accepts a row only if its K-th rescored (exact) score exceeds the largest approximate maximum
 // among the tiles it did NOT rescore by more than eps[u]; any other row is flagged and redone from a full fp32 score
 // row, exactly as rows with ties are.  No reduced-precision value reaches a ranking or a metric.
@@ -75,7 +79,14 @@ __global__ void split_rows_kernel(const float* __restrict__ src, int64_t ld, con
       for (int g = 0; g < kgroups; ++g) t += s_sq[q][lane + brows * g];
     const float nv = sqrtf(t);
     if (have && norm) norm[r] = nv;
-    if (have && eps) eps[r] = kappa * nv * other_max[0];        // the row's bound: kappa ||u|| max ||i||
+    // the row's bound: kappa ||u|| max ||i||, rounded UP, plus an absolute term for what a relative bound cannot
+    // cover — operands / products / partial sums below 2^-126 (a bf16 `lo` part of |x| < 2^-117, a product of two
+    // tiny entries) may be flushed to zero by the matrix pipe: each of the <= 6 d flushed quantities is below
+    // 2^-126 (times an operand magnitude <= the norms), so 2^-110 · d · (1 + ||u|| + max ||i||) is a generous
+    // ceiling; rows of such magnitude cannot be certified against it and take the fp32 path, as they should
+    if (have && eps)
+      eps[r] = nr_add_up(nr_mul_up(nr_mul_up(kappa, nv), other_max[0]),
+                         nr_mul_up(7.70371978e-34f * (float)d, nr_add_up(1.0f, nr_add_up(nv, other_max[0]))));
     if (have && max_norm) atomicMax(reinterpret_cast<int*>(max_norm), __float_as_int(nv));   // nv >= 0 (or NaN: stays)
   }
 }

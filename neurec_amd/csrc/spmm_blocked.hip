@@ -29,6 +29,9 @@
 #include <algorithm>
 #include <new>
 #include <cstdlib>
+#include <queue>
+#include <functional>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -43,12 +46,22 @@ struct BlockedPlan {
   int64_t n_rows, nnz, n_ent, n_cmb;
   int n_wg, n_phases;
   int seg, r_max, p_max, waves, d;
-  int32_t* wg_row0;
+  int32_t* wg_row0;      // first position of the workgroup's rows in row_of (== the first row when rows are not dealt)
   int32_t* wg_nrows;
+  // r05: the rows of a workgroup are a LIST, not a run: row_of[wg_row0[w] + slot] (see "dealt rows" at the plan
+  // builder) — and the plan owns the (column, value) pairs in that order, so a workgroup's pairs stay one
+  // contiguous slice (the staged masked kernel reads it in bulk).  ent[].z / wg_nnz index the packed arrays.
+  int32_t* row_of;       // [n_rows]
+  uint32_t* pk_src;      // [n_rows] first CSR position of row_of[k]
+  uint32_t* pk_dst;      // [n_rows + 1] first packed position of row_of[k]
+  int32_t* pk_idx;       // [nnz]
+  float* pk_val;         // [nnz]
+  const int32_t* pk_from_idx;   // the CSR arrays the packed copy was made from (nullptr: not yet)
+  const float* pk_from_val;
   int32_t* wg_ent_off;   // [n_wg][n_phases + 1]
   int32_t* wg_cmb_off;   // [n_wg][n_phases + 1]
-  int4* ent;             // {accumulator slot, length, first non-zero, owning row slot}
-  int4* cmb;             // {row slot, first partial slot, segments, 0}
+  int4* ent;             // {accumulator slot, length, first non-zero (packed), owning row (global id)}
+  int4* cmb;             // {row slot, first partial slot, segments, row (global id)}
   // masked hops of a training step (d = 64, one phase): dedicated kernels below
   uint32_t* wg_nnz;      // [n_wg][2] first non-zero of the workgroup's rows, count
   int nnz_cap, ent_cap;  // largest slice / descriptor list of a workgroup
@@ -120,7 +133,8 @@ size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
   const size_t ww = 3 * nr_align_up((wg + 1) * 4, 256) + nr_align_up(ww_ents * 16 + 16, 256) +
                     nr_align_up(ww_seg * 4 + 4, 256) + 2 * nr_align_up(max_cmb * 16 + 16, 256) +
                     nr_align_up(ww_seg * 256 + 256, 256) + nr_align_up(max_cmb * 4 + 4, 256);
-  return ww + nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
+  const size_t dealt = 3 * nr_align_up(((size_t)n_rows + 1) * 4, 256) + 2 * nr_align_up((size_t)nnz * 4 + 4, 256);
+  return ww + dealt + nr_align_up(max_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) +
          3 * nr_align_up(wg * 8, 256) + 2 * nr_align_up(wg * (kMaxPhases + 1) * 4, 256) +
          nr_align_up(w_ent * 16, 256) + nr_align_up(max_cmb * 16, 256) + 2 * nr_align_up(wg * 8, 256);
 }
@@ -138,15 +152,18 @@ struct AdamEpilogue {
 
 
 // Epilogue shared by the full-pass kernels: the workgroup's finished row sums sit in LDS
-// (s_acc[slot][LPR], slot = row - r0); y += addend, then either the ApplyAdam epilogue or the
-// stores of y and of the running layer sum — coalesced over the row run.
+// (s_acc[slot][LPR]); y += addend, then either the ApplyAdam epilogue or the stores of y and of the
+// running layer sum — a row is LPR lanes x 16 B (whole cache lines at d >= 32), so a row LIST
+// streams as well as a row run.
 template <bool MASKED, bool ADAM, int LPR>
 __device__ __forceinline__ void blocked_epilogue(const float4* s_acc, int r0, int nr, int tid, int nthreads,
                                                  float4* __restrict__ Y, const float4* __restrict__ addend,
                                                  const float4* sum_in, float4* sum_out,
-                                                 const uint8_t* __restrict__ row_mask, const AdamEpilogue& ad) {
+                                                 const uint8_t* __restrict__ row_mask, const AdamEpilogue& ad,
+                                                 const int32_t* s_rows = nullptr) {
   for (int i = tid; i < nr * LPR; i += nthreads) {
-    const int row = r0 + i / LPR;
+    // s_rows: the workgroup's row list (LDS; dealt rows), else its rows are the run [r0, r0 + nr)
+    const int row = s_rows ? s_rows[i / LPR] : r0 + i / LPR;
     if constexpr (MASKED) {
       if (row_mask && row_mask[row] == 0) continue;
     }
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     const int32_t* __restrict__ indices, const float* __restrict__ vals,
     const float4* __restrict__ X, float4* __restrict__ Y, const float4* __restrict__ addend,
     const float4* sum_in, float4* sum_out, const uint8_t* __restrict__ col_mask,
-    const uint8_t* __restrict__ row_mask, int kRMax, AdamEpilogue ad) {
+    const uint8_t* __restrict__ row_mask, int kRMax, AdamEpilogue ad, const int32_t* __restrict__ row_of,
+    int kPMax) {
   constexpr int LPR = D / 4;                   // lanes per row: 16-byte pieces of a d-float row
   constexpr int GPW = NR_WAVE / LPR;           // lane groups (rows in flight) per wave: 4 / 2 / 1
   constexpr int kGroups = kWaves * GPW;
@@ -221,12 +239,14 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
   constexpr int CL = LPR < 16 ? LPR : 16;
   constexpr int IPL = 16 / CL;
   static_assert(kG % IPL == 0, "broadcast component must be a compile-time index");
-  extern __shared__ float4 s_acc[];          // [(r_max + p_max)][LPR]
+  extern __shared__ float4 s_acc[];          // [(r_max + p_max)][LPR], then the row list [r_max]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & (LPR - 1), g = lane / LPR, gbase = lane & ~(LPR - 1);
   const int wg = blockIdx.x;
   NR_BLK_STAMP(0);
   const int r0 = wg_row0[wg], nr = wg_nrows[wg];
+  int32_t* s_rows = (int32_t*)(s_acc + (size_t)(kRMax + kPMax) * LPR);
+  for (int i = tid; i < nr; i += kWaves * NR_WAVE) s_rows[i] = row_of[r0 + i];   // read back in the epilogue
   for (int i = tid; i < nr * LPR; i += kWaves * NR_WAVE) s_acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   NR_BLK_STAMP(1);
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
     }
     int cur_want = 1;                                // row filter of the current entry (prefetched)
     if constexpr (MASKED) {
-      if (row_mask && ei < e1) cur_want = row_mask[r0 + cur.w];
+      if (row_mask && ei < e1) cur_want = row_mask[cur.w];
     }
     for (int base = e0 + wave * GPW; base < e1; base += kGroups) {
       const bool live = ei < e1;
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
                 nxt_val[i] = vals[(uint32_t)nxt.z + c * IPL + i];
               }
             if constexpr (MASKED) {
-              if (row_mask && ein < e1) nxt_want = row_mask[r0 + nxt.w];
+              if (row_mask && ein < e1) nxt_want = row_mask[nxt.w];
             }
           }
 #pragma unroll
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
   }
   NR_BLK_STAMP(3);
   blocked_epilogue<MASKED, ADAM, LPR>(s_acc, r0, nr, tid, kWaves * NR_WAVE, Y, addend, sum_in, sum_out,
-                                      row_mask, ad);
+                                      row_mask, ad, s_rows);
   NR_BLK_STAMP(4);
 }
 
@@ -697,7 +717,6 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & (LPR - 1), g = lane / LPR;
   const int wg = blockIdx.x;
-  const int r0 = wg_row0[wg];
   const uint32_t nz0 = wg_nnz[2 * wg];
   const int nz = (int)wg_nnz[2 * wg + 1];
   const int e0 = wg_ent_off[2 * wg], ne = wg_ent_off[2 * wg + 1] - e0;
@@ -738,12 +757,12 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
       e.z = (int)((uint32_t)e.z - nz0);                            // offset inside the staged slice
       // bit 30 of the owner: the addend row of this output row may be non-zero;
       // bit 29: the output row is not wanted (nothing is gathered, nothing is written)
-      const int owner = e.w;
+      const int owner = e.w;                                       // the row itself (global id < 2^24)
       bool addend_on = true;
-      if constexpr (COLMASK) addend_on = !addend_masked || col_mask[r0 + owner] != 0;
+      if constexpr (COLMASK) addend_on = !addend_masked || col_mask[owner] != 0;
       if (addend_on) e.w |= 1 << 30;
       if constexpr (ROWMASK) {
-        if (row_mask[r0 + owner] == 0) {
+        if (row_mask[owner] == 0) {
           e.y = 0;
           e.w |= 1 << 29;
         }
@@ -774,13 +793,13 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
     }
     if (ei < ne && c == 0) s_ent[ei].y = w;
   }
-  staged_walk(s_ent, s_iv, ne, r0, X, Y, addend, sum_in, sum_out, s_part, kRMax, wave, g, c);
+  staged_walk(s_ent, s_iv, ne, 0, X, Y, addend, sum_in, sum_out, s_part, kRMax, wave, g, c);
   if (c1 > c0) {                                           // workgroup-uniform
     __syncthreads();
     for (int ci = c0 + wave * GPW + g; ci < c1; ci += kGroups) {
       const int4 cm = cmb[ci];
       if constexpr (ROWMASK) {
-        if (row_mask[r0 + cm.x] == 0) continue;
+        if (row_mask[cm.w] == 0) continue;
       }
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int sgm = 0; sgm < cm.z; ++sgm) {
@@ -789,8 +808,8 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_staged_masked_kernel(
         acc.z = __fadd_rn(acc.z, q.z); acc.w = __fadd_rn(acc.w, q.w);
       }
       bool addend_on = true;
-      if constexpr (COLMASK) addend_on = !addend_masked || col_mask[r0 + cm.x] != 0;
-      masked_row_out(acc, ((int64_t)r0 + cm.x) * RS + c, addend, addend_on, Y, sum_in, sum_out);
+      if constexpr (COLMASK) addend_on = !addend_masked || col_mask[cm.w] != 0;
+      masked_row_out(acc, (int64_t)cm.w * RS + c, addend, addend_on, Y, sum_in, sum_out);
     }
   }
 }
@@ -1314,6 +1333,22 @@ void build_affinity(const int64_t* h_indptr, const int32_t* h_indices, int64_t n
   out.ok = true;
 }
 
+// (column, value) pairs copied into the plan's row order: row k of the order is CSR positions
+// [src[k], src[k] + dst[k+1] - dst[k]) -> packed positions [dst[k], dst[k+1]).  Once per matrix.
+__global__ __launch_bounds__(256) void row_order_pack_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst,
+                                                             int64_t n_rows, const int32_t* __restrict__ indices,
+                                                             const float* __restrict__ vals, int32_t* __restrict__ pk_idx,
+                                                             float* __restrict__ pk_val) {
+  const int c = threadIdx.x & 15;
+  for (int64_t k = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); k < n_rows; k += (int64_t)gridDim.x * 16) {
+    const uint32_t s0 = src[k], d0 = dst[k], len = dst[k + 1] - d0;
+    for (uint32_t j = c; j < len; j += 16) {
+      pk_idx[d0 + j] = indices[s0 + j];
+      pk_val[d0 + j] = vals[s0 + j];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1337,7 +1372,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   NR_REQUIRE(d == 16 || d == 32 || d == 64 || d == 128 || d == 256, NR_ERR_UNSUPPORTED,
              "spmm_blocked: embedding dim %d not built (16, 32, 64, 128, 256)", d);
   NR_REQUIRE(kWaves == 16 || kWaves == 8, NR_ERR_UNSUPPORTED, "spmm_blocked: waves per workgroup %d (8, 16)", kWaves);
-  NR_REQUIRE(kSeg >= 16 && (size_t)(kRMax + kPMax) * kD * 4 <= (size_t)kMaxLdsBytes, NR_ERR_UNSUPPORTED,
+  NR_REQUIRE(kSeg >= 16 && (size_t)(kRMax + kPMax) * kD * 4 + (size_t)kRMax * 4 <= (size_t)kMaxLdsBytes, NR_ERR_UNSUPPORTED,
              "spmm_blocked: seg %d / accumulators %d+%d do not fit", kSeg, kRMax, kPMax);
   NR_REQUIRE(h_indptr && h_indices && d_plan_buf && plan_out && n_rows > 0, NR_ERR_ARG,
              "spmm_blocked_plan_create: bad arguments");
@@ -1379,10 +1414,10 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   int ent_cost = 6;
   if (const char* e = getenv("NEUREC_SPMM_ENTCOST")) ent_cost = atoi(e);
   auto row_cost = [&](int64_t l) { return l + (int64_t)ent_cost * std::max<int64_t>(1, (l + kSeg - 1) / kSeg); };
-  struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; };
+  struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; int32_t cmin; int64_t width, K; };
   std::vector<ClassDesc> classes;
   if (split_row) {
-    ClassDesc a{0, split_row, {}}, b{split_row, n_rows, {}};
+    ClassDesc a{0, split_row, {}, 0, 1, 1}, b{split_row, n_rows, {}, 0, 1, 1};
     // workgroups per class in proportion to the class's cost; class A fills XCDs 0.. first
     // (workgroup w runs on XCD w % 8), so at most one XCD serves both halves of the table
     int64_t cost_a = 0, cost_b = 0;
@@ -1405,7 +1440,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     classes.push_back(a);
     classes.push_back(b);
   } else {
-    ClassDesc a{0, n_rows, {}};
+    ClassDesc a{0, n_rows, {}, 0, 1, 1};
     for (int w = 0; w < n_wg; ++w) a.wgs.push_back(w);
     classes.push_back(a);
   }
@@ -1413,7 +1448,10 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   std::vector<std::vector<std::vector<HostEnt>>> wg_ent(n_wg);     // [wg][phase][entries]
   std::vector<std::vector<std::vector<int4>>> wg_cmb(n_wg);
   int n_phases = 1;
-  for (const ClassDesc& cl : classes) {
+  std::vector<std::vector<int32_t>> wg_rows((size_t)n_wg);         // [wg] its rows, slot order
+  bool dealt = !aff_enabled();
+  if (const char* e = getenv("NEUREC_SPMM_DEAL")) dealt = dealt && e[0] != '0';
+  for (ClassDesc& cl : classes) {
     const int64_t cb = h_indptr[cl.ra], ce = h_indptr[cl.rb];
     int32_t cmin = INT32_MAX, cmax = -1;
     for (int64_t t = cb; t < ce; ++t) {
@@ -1429,38 +1467,114 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
                "use the work-item kernel", (long long)span, (long long)K, kMaxPhases);
     const int64_t width = (span + K - 1) / K;
     n_phases = std::max<int>(n_phases, (int)K);
-    // contiguous row runs, balanced by cost, at most kRMax rows each
-    int64_t r = cl.ra, left = 0;
-    for (int64_t q = cl.ra; q < cl.rb; ++q) left += row_cost(h_indptr[q + 1] - h_indptr[q]);
+    cl.cmin = cmin; cl.width = width; cl.K = K;
+    // Which rows a workgroup owns.  r01-r04: contiguous runs balanced by cost — fine while a row's length is
+    // independent of its id (the first synthetic twin shuffled the popularity ranks), but in real interaction data
+    // (and in the r05 twin, whose item popularity follows the real test split) popular items cluster in id: the
+    // run of hub rows then holds few rows and the runs of tail rows hit the accumulator cap (kRMax rows of ~8
+    // non-zeros = 0.7 of the cost target), which pushes the excess onto the other runs — the slowest workgroup of
+    // the item class carried 1.9x the mean cost and the pass took 50 us instead of 34.  r05: rows are DEALT —
+    // sorted by cost, each to the least-loaded workgroup that still has an accumulator (LPT) — so every
+    // workgroup gets the same cost whatever the numbering; the plan lists a workgroup's rows (row_of) and owns
+    // the (column, value) pairs in that order.  NEUREC_SPMM_DEAL=0 (A/B) and the affinity schedule keep runs.
+    const int64_t n_cl = cl.rb - cl.ra;
+    const int64_t nw = (int64_t)cl.wgs.size();
+    std::vector<std::vector<int32_t>> lists((size_t)nw);
+    if (dealt) {
+      NR_REQUIRE(n_cl <= nw * (int64_t)kRMax, NR_ERR_UNSUPPORTED,
+                 "spmm_blocked: %lld rows do not fit %zu workgroups x %d accumulators — use the work-item kernel",
+                 (long long)n_cl, cl.wgs.size(), kRMax);
+      std::vector<int32_t> by_cost((size_t)n_cl);
+      for (int64_t q = 0; q < n_cl; ++q) by_cost[(size_t)q] = (int32_t)(cl.ra + q);
+      std::stable_sort(by_cost.begin(), by_cost.end(), [&](int32_t x, int32_t y) {
+        return h_indptr[x + 1] - h_indptr[x] > h_indptr[y + 1] - h_indptr[y];
+      });
+      // min-heap of (cost so far, workgroup); a workgroup whose accumulators are all taken leaves the heap
+      typedef std::pair<int64_t, int> Load;
+      std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+      for (int i = 0; i < (int)nw; ++i) heap.push(Load(0, i));
+      // rows that cannot be placed freely any more (as many rows left as free accumulators) are not an issue:
+      // every workgroup in the heap has a free accumulator and n_cl <= nw * kRMax
+      for (int32_t row : by_cost) {
+        Load top = heap.top();
+        heap.pop();
+        lists[(size_t)top.second].push_back(row);
+        top.first += row_cost(h_indptr[row + 1] - h_indptr[row]);
+        if ((int64_t)lists[(size_t)top.second].size() < kRMax) heap.push(top);
+      }
+    } else {
+      int64_t r = cl.ra, left = 0;
+      for (int64_t q = cl.ra; q < cl.rb; ++q) left += row_cost(h_indptr[q + 1] - h_indptr[q]);
+      for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
+        const int64_t wgs_left = (int64_t)cl.wgs.size() - (int64_t)wi;
+        const int64_t target = (left + wgs_left - 1) / wgs_left;
+        const int64_t rstart = r;
+        int64_t got = 0;
+        while (r < cl.rb && (r - rstart) < kRMax) {
+          const int64_t l = row_cost(h_indptr[r + 1] - h_indptr[r]);
+          // stop at the cost target unless the rows left would overflow the later workgroups
+          const bool must_take = (cl.rb - r) > (wgs_left - 1) * (int64_t)kRMax;
+          if (!must_take && wgs_left > 1 && got > 0 && got + l / 2 > target) break;
+          got += l;
+          ++r;
+        }
+        if (wgs_left == 1)
+          NR_REQUIRE(r == cl.rb, NR_ERR_UNSUPPORTED,
+                     "spmm_blocked: %lld rows do not fit %zu workgroups x %d accumulators — use the "
+                     "work-item kernel", (long long)(cl.rb - cl.ra), cl.wgs.size(), kRMax);
+        left -= got;
+        for (int64_t row = rstart; row < r; ++row) lists[wi].push_back((int32_t)row);
+      }
+    }
     for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
       const int w = cl.wgs[wi];
-      const int64_t wgs_left = (int64_t)cl.wgs.size() - (int64_t)wi;
-      const int64_t target = (left + wgs_left - 1) / wgs_left;
-      const int64_t rstart = r;
-      int64_t got = 0;
-      while (r < cl.rb && (r - rstart) < kRMax) {
-        const int64_t l = row_cost(h_indptr[r + 1] - h_indptr[r]);
-        // stop at the cost target unless the rows left would overflow the later workgroups
-        const bool must_take = (cl.rb - r) > (wgs_left - 1) * (int64_t)kRMax;
-        if (!must_take && wgs_left > 1 && got > 0 && got + l / 2 > target) break;
-        got += l;
-        ++r;
+      wg_rows[(size_t)w].swap(lists[wi]);
+    }
+  }
+  // run order: workgroup by workgroup; the packed (column, value) arrays follow it
+  std::vector<int32_t> row_of((size_t)n_rows);
+  std::vector<uint32_t> pk_src((size_t)n_rows), pk_dst((size_t)n_rows + 1, 0);
+  {
+    // workgroups in the order of their first row when rows are runs (position == row id: the affinity kernel
+    // addresses rows as wg_row0 + slot), in id order when rows are dealt
+    std::vector<int> wg_order((size_t)n_wg);
+    for (int w = 0; w < n_wg; ++w) wg_order[(size_t)w] = w;
+    if (!dealt)
+      std::stable_sort(wg_order.begin(), wg_order.end(), [&](int x, int y) {
+        const int64_t fx = wg_rows[(size_t)x].empty() ? n_rows : wg_rows[(size_t)x][0];
+        const int64_t fy = wg_rows[(size_t)y].empty() ? n_rows : wg_rows[(size_t)y][0];
+        return fx < fy;
+      });
+    int64_t k = 0;
+    for (int w : wg_order) {
+      wg_row0[(size_t)w] = (int32_t)k;
+      wg_nrows[(size_t)w] = (int32_t)wg_rows[(size_t)w].size();
+      for (int32_t row : wg_rows[(size_t)w]) {
+        row_of[(size_t)k] = row;
+        pk_src[(size_t)k] = (uint32_t)h_indptr[row];
+        pk_dst[(size_t)k + 1] = pk_dst[(size_t)k] + (uint32_t)(h_indptr[row + 1] - h_indptr[row]);
+        ++k;
       }
-      if (wgs_left == 1)
-        NR_REQUIRE(r == cl.rb, NR_ERR_UNSUPPORTED,
-                   "spmm_blocked: %lld rows do not fit %zu workgroups x %d accumulators — use the "
-                   "work-item kernel", (long long)(cl.rb - cl.ra), cl.wgs.size(), kRMax);
-      left -= got;
-      wg_row0[w] = (int32_t)rstart;
-      wg_nrows[w] = (int32_t)(r - rstart);
+    }
+    NR_REQUIRE(k == n_rows, NR_ERR_ARG, "spmm_blocked: internal: %lld of %lld rows scheduled", (long long)k,
+               (long long)n_rows);
+  }
+  for (const ClassDesc& cl : classes) {
+    const int32_t cmin = cl.cmin;
+    const int64_t width = cl.width, K = cl.K;
+    for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
+      const int w = cl.wgs[wi];
       wg_ent[w].assign((size_t)K, {});
       wg_cmb[w].assign((size_t)K, {});
       std::vector<int> pcount((size_t)K, 0);
-      for (int64_t row = rstart; row < r; ++row) {
-        const int32_t slot = (int32_t)(row - rstart);
+      for (size_t si = 0; si < wg_rows[(size_t)w].size(); ++si) {
+        const int64_t row = wg_rows[(size_t)w][si];
+        const int32_t slot = (int32_t)si;
+        // position of the row's first pair in the packed arrays
+        const int64_t shift = (int64_t)pk_dst[(size_t)wg_row0[(size_t)w] + si] - h_indptr[row];
         int64_t t = h_indptr[row];
         const int64_t te = h_indptr[row + 1];
-        if (t == te) wg_ent[w][0].push_back(HostEnt{slot, 0, (uint32_t)t, slot});   // empty row
+        if (t == te) wg_ent[w][0].push_back(HostEnt{slot, 0, (uint32_t)(t + shift), (int32_t)row});   // empty row
         while (t < te) {
           const int64_t k = ((int64_t)h_indices[t] - cmin) / width;
           int64_t t2 = t + 1;
@@ -1468,18 +1582,18 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
           while (t2 < te && h_indices[t2] < col_end) ++t2;
           const int64_t len = t2 - t;
           if (len <= kSeg) {
-            wg_ent[w][(size_t)k].push_back(HostEnt{slot, (int32_t)len, (uint32_t)t, slot});
+            wg_ent[w][(size_t)k].push_back(HostEnt{slot, (int32_t)len, (uint32_t)(t + shift), (int32_t)row});
           } else {
             const int ns = (int)((len + kSeg - 1) / kSeg);
             NR_REQUIRE(pcount[(size_t)k] + ns <= kPMax, NR_ERR_UNSUPPORTED,
                        "spmm_blocked: more than %d hub segments in one workgroup phase — use the "
                        "work-item kernel", kPMax);
             const int first = kRMax + pcount[(size_t)k];
-            for (int s = 0; s < ns; ++s)
+            for (int sg = 0; sg < ns; ++sg)
               wg_ent[w][(size_t)k].push_back(
-                  HostEnt{first + s, (int32_t)std::min<int64_t>(kSeg, len - (int64_t)s * kSeg),
-                          (uint32_t)(t + (int64_t)s * kSeg), slot});
-            wg_cmb[w][(size_t)k].push_back(make_int4(slot, first, ns, 0));
+                  HostEnt{first + sg, (int32_t)std::min<int64_t>(kSeg, len - (int64_t)sg * kSeg),
+                          (uint32_t)(t + shift + (int64_t)sg * kSeg), (int32_t)row});
+            wg_cmb[w][(size_t)k].push_back(make_int4(slot, first, ns, (int)row));
             pcount[(size_t)k] += ns;
           }
           t = t2;
@@ -1506,7 +1620,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   std::vector<uint32_t> wg_nnz((size_t)n_wg * 2, 0);
   int64_t nnz_cap = 0, ent_cap = 0;
   for (int w = 0; w < n_wg; ++w) {
-    const int64_t b = h_indptr[wg_row0[w]], en = h_indptr[(int64_t)wg_row0[w] + wg_nrows[w]];
+    const int64_t b = pk_dst[(size_t)wg_row0[w]], en = pk_dst[(size_t)wg_row0[w] + (size_t)wg_nrows[w]];
     wg_nnz[2 * (size_t)w] = (uint32_t)b;
     wg_nnz[2 * (size_t)w + 1] = (uint32_t)(en - b);
     nnz_cap = std::max(nnz_cap, en - b);
@@ -1521,7 +1635,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     const char* off = getenv("NEUREC_SPMM_MASKED_FAST");     // "0": A/B against the general kernel
     const bool on = d == 64 && kWaves == 16 && n_phases == 1 && !(off && off[0] == '0');
     const size_t base = (size_t)kPMax * 256 + (size_t)p->ent_cap * 16;
-    p->colmask_ok = on && nnz_cap < ((int64_t)1 << 24) && base + (size_t)nnz_cap * 8 <= (size_t)kMaxLdsBytes;
+    p->colmask_ok = on && nnz_cap < ((int64_t)1 << 24) && n_rows < ((int64_t)1 << 24) &&
+                    base + (size_t)nnz_cap * 8 <= (size_t)kMaxLdsBytes;
     p->wanted_ok = on && kSeg <= 255 && n_rows < ((int64_t)1 << 24);
   }
   std::vector<int4> w_ent, w_cmb;
@@ -1687,6 +1802,13 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   p->cmb = (int4*)carve(cmb.size() * 16 + 16);
   p->wg_row0 = (int32_t*)carve((size_t)n_wg * 4);
   p->wg_nrows = (int32_t*)carve((size_t)n_wg * 4);
+  p->row_of = (int32_t*)carve(row_of.size() * 4);
+  p->pk_src = (uint32_t*)carve(pk_src.size() * 4);
+  p->pk_dst = (uint32_t*)carve(pk_dst.size() * 4);
+  p->pk_idx = (int32_t*)carve((size_t)nnz * 4 + 4);
+  p->pk_val = (float*)carve((size_t)nnz * 4 + 4);
+  p->pk_from_idx = nullptr;
+  p->pk_from_val = nullptr;
   p->wg_ent_off = (int32_t*)carve(ent_off.size() * 4);
   p->wg_cmb_off = (int32_t*)carve(cmb_off.size() * 4);
   p->wg_nnz = (uint32_t*)carve(wg_nnz.size() * 4);
@@ -1735,6 +1857,9 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   up(p->cmb, cmb.data(), cmb.size() * 16);
   up(p->wg_row0, wg_row0.data(), wg_row0.size() * 4);
   up(p->wg_nrows, wg_nrows.data(), wg_nrows.size() * 4);
+  up(p->row_of, row_of.data(), row_of.size() * 4);
+  up(p->pk_src, pk_src.data(), pk_src.size() * 4);
+  up(p->pk_dst, pk_dst.data(), pk_dst.size() * 4);
   up(p->wg_ent_off, ent_off.data(), ent_off.size() * 4);
   up(p->wg_cmb_off, cmb_off.data(), cmb_off.size() * 4);
   up(p->wg_nnz, wg_nnz.data(), wg_nnz.size() * 4);
@@ -1765,7 +1890,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     up(p->a_perm, aff.perm.data(), aff.perm.size() * 4);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  const int lds = (kRMax + kPMax) * kD * 4;
+  const int lds = (kRMax + kPMax) * kD * 4 + kRMax * 4;           // accumulators + the workgroup's row list
   auto allow = [&](const void* fn) {
     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   };
@@ -1810,6 +1935,15 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
 int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d_vals, void* stream) {
   NR_REQUIRE(plan && d_indices && d_vals, NR_ERR_ARG, "spmm_blocked_pack: null pointer argument");
   BlockedPlan* p = (BlockedPlan*)plan;
+  if (p->nnz > 0) {
+    // the (column, value) pairs in the plan's row order: a 16-lane group per row
+    const unsigned blocks = (unsigned)std::min<int64_t>((p->n_rows + 15) / 16, 8192);
+    hipLaunchKernelGGL(row_order_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->pk_src, p->pk_dst,
+                       p->n_rows, d_indices, d_vals, p->pk_idx, p->pk_val);
+    NR_LAUNCH_CHECK();
+  }
+  p->pk_from_idx = d_indices;
+  p->pk_from_val = d_vals;
   if (!p->aff_ok) return NR_OK;
   const int64_t n = p->aff_rounds * 4;
   if (n > 0) {
@@ -1822,6 +1956,13 @@ int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d
   p->aff_indices = d_indices;
   p->aff_vals = d_vals;
   return NR_OK;
+}
+
+// The kernels that walk the plan's own schedule read the plan's packed pairs; a call that hands in other CSR
+// arrays than the ones packed (or none packed yet) packs first, on the caller's stream.
+static int ensure_packed(const BlockedPlan* p, const int32_t* d_indices, const float* d_vals, void* stream) {
+  if (p->pk_from_idx == d_indices && p->pk_from_val == d_vals) return NR_OK;
+  return nrhip_spmm_blocked_pack((void*)p, d_indices, d_vals, stream);
 }
 
 /* 0: the full pass runs spmm_blocked_kernel; K > 0: it runs spmm_affinity_kernel over K column
@@ -1875,7 +2016,7 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
   const BlockedPlan* p = (const BlockedPlan*)plan;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)p->n_wg), block(p->waves * NR_WAVE);
-  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;
+  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4 + (size_t)p->r_max * 4;
   const bool masked = d_x_row_nonzero || d_y_row_wanted;
   const int gif = s_gathers_in_flight;
   if (p->ww_ok && d_y_row_wanted && !d_x_row_nonzero)
@@ -1890,13 +2031,14 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
+  NR_TRY(ensure_packed(p, d_indices, d_vals, stream));
   if (p->colmask_ok && masked) {
     // an addend that is the operand itself shares its promise (zero rows where the mask is 0)
     const int addend_masked = d_x_row_nonzero && d_addend == d_X ? 1 : 0;
 #define NR_STAGED(CM, RM)                                                                          \
   hipLaunchKernelGGL((spmm_staged_masked_kernel<CM, RM>), grid, block, colmask_lds_bytes(p), st,   \
-                     p->wg_row0, p->wg_ent_off, p->wg_cmb_off, p->wg_nnz, p->ent, p->cmb, d_indices, \
-                     d_vals, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,             \
+                     p->wg_row0, p->wg_ent_off, p->wg_cmb_off, p->wg_nnz, p->ent, p->cmb, p->pk_idx, \
+                     p->pk_val, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,          \
                      (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,  \
                      addend_masked, p->r_max, p->p_max, p->ent_cap)
     if (d_x_row_nonzero && d_y_row_wanted) NR_STAGED(true, true);
@@ -1917,9 +2059,9 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
 #define NR_BLK(M, W, GG, DD)                                                                       \
   hipLaunchKernelGGL((spmm_blocked_kernel<M, W, GG, DD>), grid, block, lds, st, p->wg_row0,        \
                      p->wg_nrows, p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases,        \
-                     d_indices, d_vals, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,  \
+                     p->pk_idx, p->pk_val, (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend, \
                      (const float4*)d_sum_in, (float4*)d_sum_out, d_x_row_nonzero, d_y_row_wanted,  \
-                     p->r_max, AdamEpilogue{})
+                     p->r_max, AdamEpilogue{}, p->row_of, p->p_max)
 #define NR_BLK_D(DD)                                                                               \
   if (p->waves == 16) {                                                                            \
     if (masked) { if (gif == 4) NR_BLK(true, 16, 4, DD); else NR_BLK(true, 16, 8, DD); }           \
@@ -2018,7 +2160,8 @@ int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const fl
   NR_REQUIRE(p->d == 64 && p->waves == 16, NR_ERR_UNSUPPORTED,
              "spmm_blocked_adam: built for d = 64 schedules with 16 waves");
   NR_REQUIRE(d_X != d_var, NR_ERR_ARG, "spmm_blocked_adam: the operand must not be the updated table");
-  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4;   // allowed at plan creation
+  const size_t lds = (size_t)(p->r_max + p->p_max) * p->d * 4 + (size_t)p->r_max * 4;   // allowed at plan creation
+  NR_TRY(ensure_packed(p, d_indices, d_vals, stream));
   NR_REQUIRE(!clear_consumed || d_addend, NR_ERR_ARG, "spmm_blocked_adam: clear_consumed needs an addend");
   AdamEpilogue ad{(float4*)d_var, (float4*)d_m, (float4*)d_v, (const float4*)d_grad_b,
                   alpha, 1.0f - beta1, 1.0f - beta2, eps,
@@ -2034,10 +2177,10 @@ int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const fl
   }
   hipLaunchKernelGGL((spmm_blocked_kernel<false, 16, 8, 64, true>), dim3((unsigned)p->n_wg),
                      dim3(16 * NR_WAVE), lds, (hipStream_t)stream, p->wg_row0, p->wg_nrows,
-                     p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, d_indices, d_vals,
+                     p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, p->pk_idx, p->pk_val,
                      (const float4*)d_X, (float4*)nullptr, (const float4*)d_addend,
                      (const float4*)nullptr, (float4*)nullptr, (const uint8_t*)nullptr,
-                     (const uint8_t*)nullptr, p->r_max, ad);
+                     (const uint8_t*)nullptr, p->r_max, ad, p->row_of, p->p_max);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -103,7 +103,6 @@ class InstanceEpochStream:
         self.shuffle, self.drop_last = bool(shuffle), bool(drop_last)
         self.seed, self.epoch = int(seed), 0
         self.n_slots = rows.n_inst * (self.neg_num + 1 if self.pointwise else 1)
-        self._out = None
 
     def __len__(self):
         if self.drop_last:
@@ -111,14 +110,16 @@ class InstanceEpochStream:
         return (self.n_slots + self.batch_size - 1) // self.batch_size
 
     def _buffers(self):
-        if self._out is None:
-            dev = self.rows.to_device()._dev
-            n, h = max(self.n_slots, 1), self.rows.high_order
-            i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)
-            self._out = (i32(n), i32(n * h) if h else None, i32(n),
-                         None if self.pointwise else i32(n * self.neg_num),
-                         torch.empty(n, dtype=torch.float32, device=dev) if self.pointwise else None)
-        return self._out
+        """FRESH output buffers for every epoch: the batches handed out are views of them, and the
+        reference yields new lists each epoch (data/sampler.py:110-124) — a batch kept past the next __iter__, or a
+        second live iterator, must not see the newer epoch's data.  torch's caching allocator makes this a pointer
+        bump; the buffers of an epoch are released with its last view."""
+        dev = self.rows.to_device()._dev
+        n, h = max(self.n_slots, 1), self.rows.high_order
+        i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)
+        return (i32(n), i32(n * h) if h else None, i32(n),
+                None if self.pointwise else i32(n * self.neg_num),
+                torch.empty(n, dtype=torch.float32, device=dev) if self.pointwise else None)
 
     def sample_epoch(self):
         """(users, recent, items, neg, labels) of a fresh epoch — device tensors (None where the kind has none)."""

@@ -1187,7 +1187,12 @@ def vae_step_native(eng, rows, anneal, keep, drop_given, eps_given, want_loss, a
     block is filled once per engine (its buffers never move), the per-call values travel as arguments."""
     from ._lib import VaeStepArgs
     a = eng._step_args
-    key = tuple(id(t) for d in (eng.P, eng.G, eng.M, eng.V) for t in d.values())      # a replaced tensor refills the block
+    # the block holds raw device pointers: keyed on the data_ptr() of EVERY tensor in it (ADVICE r4: id() misses a
+    # storage swapped in place and can be reused by a new tensor) — a moved or replaced buffer refills the block
+    bufs = ("H1", "MU", "LOGVAR", "EPSSTD", "ZS", "G1", "KLb", "h0val", "nll", "dG1", "DA3", "DH2", "DA1", "stats",
+            "regsum", "ws")
+    key = tuple(t.data_ptr() for d in (eng.P, eng.G, eng.M, eng.V) for t in d.values()) + \
+        tuple(getattr(eng, f).data_ptr() for f in bufs) + (eng.csr.indptr.data_ptr(), eng.csr.indices.data_ptr())
     if a is None or eng._step_key != key:
         eng._step_key = key
         a = VaeStepArgs()
@@ -1199,8 +1204,7 @@ def vae_step_native(eng, rows, anneal, keep, drop_given, eps_given, want_loss, a
         for k, n in enumerate(names):
             a.P[k], a.G[k], a.M[k], a.V[k] = (d[n].data_ptr() for d in (eng.P, eng.G, eng.M, eng.V))
             a.sizes[k] = eng.P[n].numel()
-        for f in ("H1", "MU", "LOGVAR", "EPSSTD", "ZS", "G1", "KLb", "h0val", "nll", "dG1", "DA3", "DH2", "DA1", "stats",
-                  "regsum", "ws"):
+        for f in bufs:
             setattr(a, f, getattr(eng, f).data_ptr())
         a.ws_bytes = eng.ws.numel()
         a.reg, a.beta1, a.beta2, a.adam_eps, a.seed = eng.reg, eng.adam.beta1, eng.adam.beta2, eng.adam.eps, eng.seed & (2**64 - 1)

@@ -40,8 +40,12 @@ def interactions_around_test(test, n_train, seed=2018):
     """SURVEY §8d's gowalla-shaped workload: the test split is GIVEN (the reference's real
     dataset/gowalla.test, 217,242 pairs — tests/golden/gowalla_test_split.npz) and the missing train side
     is synthesised around it: user degrees max(8, round(LogNormal(2.9, 0.9))) rescaled to n_train
-    interactions, items drawn without replacement per user with p ∝ (rank + 10)^-0.8 over shuffled ranks,
-    never one of the user's test items.  Returns (train_csr, test_csr)."""
+    interactions, items drawn without replacement per user with p ∝ (rank + 10)^-0.8, never one of the user's
+    test items.  An item's rank is its POPULARITY RANK IN THE GIVEN TEST SPLIT (ties in shuffled order): as in a
+    real dataset the train and test popularities go together, so a trained model has something to find and the
+    run's NDCG@10 is a number about ranking, not about noise (r04: ranks were shuffled — independent of the test
+    split — and NDCG@10 stayed at chance).  The multiset of popularities, hence the degree law and the hub
+    rows, is the same as before.  Returns (train_csr, test_csr)."""
     test = sp.csr_matrix(test, dtype=np.float32)
     test.sort_indices()
     U, I = test.shape
@@ -49,10 +53,12 @@ def interactions_around_test(test, n_train, seed=2018):
     deg = np.maximum(8, np.round(rng.lognormal(2.9, 0.9, U))).astype(np.float64)
     deg = np.maximum(1, np.round(deg * (n_train / deg.sum()))).astype(np.int64)
     deg = np.minimum(deg, I // 4)
-    pop = (np.arange(I) + 10.0) ** -0.8
-    rng.shuffle(pop)
-    cdf = np.cumsum(pop / pop.sum())
     coo = test.tocoo()
+    shuffled = rng.permutation(I)
+    by_test_count = shuffled[np.argsort(-np.bincount(coo.col, minlength=I)[shuffled], kind="stable")]
+    pop = np.empty(I)
+    pop[by_test_count] = (np.arange(I) + 10.0) ** -0.8           # the most tested item is the most popular
+    cdf = np.cumsum(pop / pop.sum())
     tu, ti = _draw_unique(rng, I, deg, cdf, forbid=np.sort(coo.row.astype(np.int64) * I + coo.col))
     train = sp.csr_matrix((np.ones(len(tu), np.float32), (tu, ti)), shape=(U, I))
     train.sort_indices()

@@ -508,9 +508,11 @@ class FullRankEvaluator:
         self._side = None
         self._flags = None                   # pruned path: per-user "ranking may depend on ties" flags of the last run
 
-    def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False):
+    def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False, per_user=False):
         """Returns float64 column means [n_metric*top_k] (or the fp32 np.mean when
-        exact_mean) over `test_users` (int32 device tensor)."""
+        exact_mean) over `test_users` (int32 device tensor); per_user: the [n][n_metric*top_k] fp32
+        matrix cpp_evaluate_matrix returns (evaluate.h:53-72), one row per test user."""
+        want_rows = per_user
         n = test_users.numel()
         nm = len(self.metric_ids)
         if self._gemm is None or self._gemm.cols != item_table.shape[0] or \
@@ -557,9 +559,10 @@ class FullRankEvaluator:
                                   out=per_user[b:b + u.numel()])
                     ranked[k % 2] = side.record_event()
             main.wait_stream(side)
-        if exact_mean:
+        if exact_mean or want_rows:
             self._redo_flagged(user_table, item_table, test_users, per_user)
-            return np.mean(per_user.cpu().numpy(), axis=0)     # uni_evaluator.py:150-151
+            rows = per_user.cpu().numpy()
+            return rows if want_rows else np.mean(rows, axis=0)   # uni_evaluator.py:150-151
         # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
         # travel together; only if some row was flagged are those rows redone and the sums retaken
         if self._native_sums is not None:                 # nrhip_eval_pruned left the sums and the flag count together
@@ -793,11 +796,16 @@ class MultiVAEEngine:
             decoder = os.environ.get("NEUREC_VAE_DECODER", "fused")
         if decoder not in ("fused", "slab"):
             raise ValueError("decoder must be 'fused' or 'slab'")
-        self.decoder = decoder
         self.csr, self.n_items = train_csr, int(n_items)
         f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
         self.P = {k: f(params[k]) for k in self.NAMES}
         self.h, self.z = self.P["Wp0"].shape[1], self.P["Wp0"].shape[0]
+        if self.h > 32 or 2 * self.z > 32:
+            # every kernel of this engine (csrc/vae.hip, vae_fused.hip) is written for hidden <= 32 and latent <= 16;
+            # said here, not by an opaque NR_ERR_UNSUPPORTED at the first step
+            raise ValueError("MultiVAEEngine: hidden width %d / latent %d outside the narrow engine's range (h <= 32, "
+                             "z <= 16): use vae_wide.MultiVAEWideEngine, as the MultiVAE plugin does" % (self.h, self.z))
+        self.decoder = decoder
         assert self.P["Wq0"].shape == (self.n_items, self.h)
         assert self.P["Wq1"].shape == (self.h, 2 * self.z)
         assert self.P["Wp1t"].shape == (self.n_items, self.h)

@@ -10,14 +10,16 @@ import torch
 
 
 class TorchLightGCN:
-    def __init__(self, A_csr, E0, n_users, n_layers, lr, reg, threads):
+    def __init__(self, A_csr, E0, n_users, n_layers, lr, reg, threads, dtype=np.float32):
+        """dtype=np.float64: the fp64 twin of the same graph (the error bar of long parity runs, where the
+        one-thread scipy restatement would take minutes)"""
         torch.set_num_threads(int(threads))
-        a = A_csr.tocsr().astype(np.float32)
+        a = A_csr.tocsr().astype(dtype)
         a.sort_indices()
         self.A = torch.sparse_csr_tensor(torch.from_numpy(a.indptr.astype(np.int64)),
                                          torch.from_numpy(a.indices.astype(np.int64)),
                                          torch.from_numpy(a.data), size=a.shape)
-        self.E = torch.from_numpy(np.array(E0, dtype=np.float32))
+        self.E = torch.from_numpy(np.array(E0, dtype=dtype))
         self.m, self.v = torch.zeros_like(self.E), torch.zeros_like(self.E)
         self.U, self.L, self.lr, self.reg = int(n_users), int(n_layers), float(lr), float(reg)
         self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8

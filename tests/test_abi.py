@@ -145,3 +145,19 @@ def test_the_filter_bound_constant_is_the_documented_formula():
     assert sizes == sorted(sizes) and sizes[0] > 0
     with pytest.raises(NotImplementedError, match="128"):
         _lib.call("nrhip_score_filter_kappa", 129, C.byref(C.c_float(0)))
+
+
+def test_the_pruned_evaluation_workspace_serves_every_shorter_batch():
+    """nrhip_eval_pruned sizes its level-2 workspace ONCE for batch_rows; a shorter last batch may
+    take the tile-grouped rescoring the full batches were too large for (buckets beyond 1 GiB).  The size query is
+    therefore monotone in rows — what it returns for the capacity covers every row count below it (host side; the
+    kernels also fall back to the per-row rescoring when the buckets do not fit)."""
+    import ctypes as C
+    from neurec_amd import _lib
+    q = lambda rows, cols: (_lib.call("nrhip_eval_tiles_bounded_workspace_bytes", rows, cols, 20, 23, C.byref(n)), n.value)[1]
+    n = C.c_size_t(0)
+    for cols in (40981, 262144, 300000, 393216, 1000000):
+        sizes = [q(r, cols) for r in (1, 100, 2048, 8192, 16384, 20000, 32768, 65536)]
+        assert all(a <= b for a, b in zip(sizes, sizes[1:])), (cols, sizes)
+    # the case of the finding: ~300 k items at batch_rows 32,768 — full batches too large to group, a 20,000-row tail not
+    assert q(32768, 300000) >= q(20000, 300000) > q(20000, 300000) - 1
