@@ -705,6 +705,7 @@ def compact_line(line):
         "eval_search": _get(line, "eval", "search"),
         "eval_search_frac_of_sustained_bf16": _get(line, "eval", "roofline", "frac_of_sustained"),
         "eval_fp32_loop_ms": _get(line, "eval", "roofline", "fp32_mfma_loop_ms"),
+        "eval_fp32_roof_ratio": _get(line, "eval", "fp32_roof_ratio"),
         "eval_search_ms": _get(line, "eval", "roofline", "ms"),
         "eval_rank_ms": _get(line, "eval", "roofline_topk", "ms"),
         "eval_rows_redone": _get(line, "eval", "rows_redone_for_ties"),
@@ -1000,11 +1001,8 @@ def main():
     # on (hash stamped in the file) — otherwise null
     traffic, traffic_note = None, "no PMC pass for this kernel / workload"
     here = os.path.dirname(os.path.abspath(__file__))
-    pmc_file = os.path.join(here, "profiles", "r04_pmc_traffic.json")
-    if not os.path.isfile(pmc_file):
-        pmc_file = os.path.join(here, "profiles", "r03_pmc_traffic.json")
-    if not os.path.isfile(pmc_file):
-        pmc_file = os.path.join(here, "profiles", "r02_pmc_traffic.json")
+    pmc_file = next((f for f in (os.path.join(here, "profiles", "r0%d_pmc_traffic.json" % r) for r in (5, 4, 3, 2))
+                     if os.path.isfile(f)), "")
     default_workload = (args.shape, args.scale, args.dim, args.layers) == ("gowalla", 1.0, 64, 3)
     if default_workload and os.path.isfile(pmc_file) and not colshard:
         import hashlib
@@ -1030,7 +1028,7 @@ def main():
                 "step_bytes_survey_8d": lg.step_bytes_survey() if hasattr(lg, "step_bytes_survey") else None}
     # the same kernel's average in the committed rocprofv3 --kernel-trace --stats table of this command (it cannot be
     # collected from inside; VERDICT r3 weak #13: both clocks in the line, not the favourable one)
-    for rr in ("r04", "r03"):
+    for rr in ("r05", "r04", "r03"):
         stats = os.path.join(here, "profiles", "%s_bench_kernel_stats.csv" % rr)
         if default_workload and os.path.isfile(stats):
             import csv
@@ -1149,6 +1147,13 @@ def main():
                                 "batch b+1 overlaps ranking of batch b (two streams, two slabs)"),
                      "rows_redone_for_ties": getattr(ev, "n_flagged", 0) if args.eval_mode == "pruned" else None}
 
+        # SURVEY 8d prices the evaluation against the fp32 matrix peak ("fp32 is mandatory"): every RANKED score is the
+        # fp32 fmaf chain's, but the tile SEARCH runs on the bf16 matrix cores, so the whole evaluation can (and does)
+        # exceed that roof — said here as a ratio, next to eval_search / eval_rows_redone / eval_fp32_loop_ms
+        eval_info["fp32_roof_ratio"] = 2.0 * I * args.dim * len(test_users) / dte / 1e12 / MFMA_F32_PEAK_TFLOPS
+        eval_info["fp32_roof_note"] = ("2·I·d flop per user / whole evaluation time / %.1f TFLOP/s fp32-MFMA peak; > 1 is "
+                                       "possible because only the ranked scores are fp32 (certified bf16 search)"
+                                       % MFMA_F32_PEAK_TFLOPS)
         # rooflines of the evaluation's two halves, HIP events on the launch stream around the kernels
         # of the first batch (north_star: MFMA for the scoring matmul, HBM GB/s for the top-K)
         if args.eval_mode == "pruned" and mine.numel() > 0:

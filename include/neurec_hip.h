@@ -138,6 +138,15 @@ int nrhip_score_tilemax_fix(const float* d_P, int64_t ldp, int d, int cols, cons
                             const int32_t* d_plan_user, const uint32_t* d_plan_mask, const int32_t* d_row_of,
                             int row_lo, int rows, float* d_M, int64_t mld, const void* d_ws, size_t ws_bytes,
                             void* stream);
+
+/* The strike plan itself, built on the device (r05: was construction-time torch code): pairs (user, 32-item tile) that
+ * hold a train item of the user — uni_evaluator.py:132-140 strikes those items of every batch on the host — grouped by
+ * tile, chunks of <= 32 pairs.  Capacities: d_plan_user / d_plan_mask nnz entries; d_tile_ptr n_tiles + 1 with
+ * n_tiles = 2 * ceil(cols / 64); d_chunk_tile / d_chunk_begin nnz / 32 + n_tiles + 1; d_counts[2] = {pairs, chunks};
+ * d_ws 8 * n_tiles bytes.  The order of the pairs inside a tile is unspecified (each pair is independent). */
+int nrhip_tile_strike_plan(const int64_t* d_indptr, const int32_t* d_indices, int n_users, int cols,
+                           int32_t* d_plan_user, uint32_t* d_plan_mask, int64_t* d_tile_ptr, int32_t* d_chunk_tile,
+                           int64_t* d_chunk_begin, int32_t* d_counts, void* d_ws, size_t ws_bytes, void* stream);
 /* Level 1 as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip; d <= 128).  The fp32 chain stays the
  * definition of every score that is ranked: this only SEARCHES for the tiles worth rescoring, 4-5x faster than the
  * fp32 MFMA loop.  x = hi + lo + r with hi, lo bf16 (round to nearest even), u.i ~= sum_k uh*ih + uh*il + ul*ih in
@@ -828,6 +837,12 @@ int nrhip_rows_sum_sorted2(const uint64_t* d_sorted_keys, int n, const int32_t* 
 int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad,
                             uint8_t* d_row_flag, int64_t n_rows, int d, float lr, float hyper1,
                             float hyper2, float eps, void* stream);
+/* The DENSE updates of learner.py:2-17 — a variable with a consumer that is not a gather (NGCF's and Mult-VAE's
+ * tables and weights) gets TF-1.12's Apply* kernels (training_ops.cc): kinds, slots and hyper-parameters as above
+ * (rmsprop in ApplyRMSProp's form: ms += (g² - ms)(1 - rho); mom = mom·momentum + g·lr / sqrt(eps + ms)).
+ * clear_grad: zero the gradient once consumed. */
+int nrhip_optimizer_dense_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad, int64_t n,
+                             float lr, float hyper1, float hyper2, float eps, int clear_grad, void* stream);
 
 /* Row lookups of a row-sharded table (BASELINE config 4; the reference's tf.nn.embedding_lookup of
  * LightGCN.py:99-104 and its IndexedSlices gradient when the rows live on another rank):

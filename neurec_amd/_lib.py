@@ -142,6 +142,7 @@ SIGNATURES = {
     "nrhip_score_gemm_workspace_bytes": [i32, i32, i32, psz],
     "nrhip_score_gemm_prepare_items": [p, i64, i32, i32, p, sz, p],
     "nrhip_score_tilemax": [p, i64, p, i32, i32, i32, p, p, p, i64, p, sz, p],
+    "nrhip_tile_strike_plan": [p, p, i32, i32, p, p, p, p, p, p, p, sz, p],
     "nrhip_score_tilemax_fix": [p, i64, i32, i32, p, p, i32, p, p, p, p, i32, i32, p, i64, p, sz, p],
     "nrhip_score_filter_workspace_bytes": [i32, i32, i32, psz],
     "nrhip_score_filter_kappa": [i32, p],
@@ -273,6 +274,7 @@ SIGNATURES = {
     "nrhip_rows_sum_sorted": [p, i32, p, i32, p, i64, p, p],
     "nrhip_rows_sum_sorted2": [p, i32, p, i32, p, i64, p, p, i64, p, p],
     "nrhip_optimizer_rows_tf": [i32, p, p, p, p, p, i64, i32, f32, f32, f32, f32, p],
+    "nrhip_optimizer_dense_tf": [i32, p, p, p, p, i64, f32, f32, f32, f32, i32, p],
     "nrhip_rows_gather": [p, i32, i32, p, p, i64, p],
     "nrhip_rows_gather_ld": [p, i32, i32, p, i64, p, i64, p],
     "nrhip_rows_gather2": [p, i32, i32, p, i64, p, i64, p, i64, p, i64, p],

@@ -264,6 +264,44 @@ __global__ __launch_bounds__(256) void optimizer_rows_kernel(float* __restrict__
   }
 }
 
+// The DENSE updates of util/learner.py:2-17 (a variable whose consumers are not all gathers gets TF-1.12's Apply*
+// kernels, core/kernels/training_ops.cc [EXT]; NGCF's and Mult-VAE's tables and weights):
+//   gd        var -= g * lr
+//   adagrad   accum += g * g;                          var -= (g * lr) * rsqrt(accum)
+//   rmsprop   ms += (g * g - ms) * (1 - rho);          mom = mom * momentum + (g * lr) / sqrt(eps + ms);  var -= mom
+//   momentum  accum = accum * momentum + g;            var -= accum * lr
+// (ApplyRMSProp's arithmetic is not SparseApplyRMSProp's above: the moving average is an increment, the step a division.)
+template <int KIND>
+__global__ __launch_bounds__(256) void optimizer_dense_kernel(float* __restrict__ var, float* __restrict__ s0,
+                                                              float* __restrict__ s1, float* __restrict__ grad,
+                                                              int64_t n, float lr, float h1, float h2, float eps,
+                                                              int clear_grad) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
+    const float g = grad[o];
+    float v = var[o];
+    if (KIND == OPT_GD) {
+      v = __fsub_rn(v, __fmul_rn(g, lr));
+    } else if (KIND == OPT_ADAGRAD) {
+      const float a = __fadd_rn(s0[o], __fmul_rn(g, g));
+      s0[o] = a;
+      v = __fsub_rn(v, __fmul_rn(__fmul_rn(g, lr), 1.0f / sqrtf(a)));
+    } else if (KIND == OPT_RMSPROP) {
+      const float ms0 = s0[o];
+      const float ms = __fadd_rn(ms0, __fmul_rn(__fsub_rn(__fmul_rn(g, g), ms0), 1.0f - h1));
+      s0[o] = ms;
+      const float mom = __fadd_rn(__fmul_rn(s1[o], h2), __fdiv_rn(__fmul_rn(g, lr), sqrtf(__fadd_rn(eps, ms))));
+      s1[o] = mom;
+      v = __fsub_rn(v, mom);
+    } else {
+      const float a = __fadd_rn(__fmul_rn(s0[o], h1), g);
+      s0[o] = a;
+      v = __fsub_rn(v, __fmul_rn(a, lr));
+    }
+    var[o] = v;
+    if (clear_grad) grad[o] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void mark_rows_kernel(const int32_t* __restrict__ ids, int n,
                                                         int offset, uint8_t* __restrict__ flag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -606,6 +644,30 @@ int nrhip_optimizer_rows_tf(int kind, float* d_var, float* d_slot0, float* d_slo
   else if (kind == OPT_RMSPROP) NR_OPT(OPT_RMSPROP);
   else NR_OPT(OPT_MOMENTUM);
 #undef NR_OPT
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_optimizer_dense_tf(int kind, float* d_var, float* d_slot0, float* d_slot1, float* d_grad, int64_t n,
+                             float lr, float hyper1, float hyper2, float eps, int clear_grad, void* stream) {
+  NR_REQUIRE(d_var && d_grad && n >= 0, NR_ERR_ARG, "optimizer_dense_tf: bad arguments");
+  NR_REQUIRE(kind >= OPT_GD && kind <= OPT_MOMENTUM, NR_ERR_ARG,
+             "optimizer_dense_tf: unknown optimiser %d (0 gd, 1 adagrad, 2 rmsprop, 3 momentum)", kind);
+  NR_REQUIRE(kind == OPT_GD || d_slot0, NR_ERR_ARG, "optimizer_dense_tf: slot buffer missing");
+  NR_REQUIRE(kind != OPT_RMSPROP || d_slot1, NR_ERR_ARG, "optimizer_dense_tf: rmsprop needs two slots");
+  if (n == 0) return NR_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define NR_OPTD(K)                                                                                          \
+  hipLaunchKernelGGL(optimizer_dense_kernel<K>, grid, block, 0, st, d_var, d_slot0, d_slot1, d_grad, n, lr, \
+                     hyper1, hyper2, eps, clear_grad)
+  if (kind == OPT_GD) NR_OPTD(OPT_GD);
+  else if (kind == OPT_ADAGRAD) NR_OPTD(OPT_ADAGRAD);
+  else if (kind == OPT_RMSPROP) NR_OPTD(OPT_RMSPROP);
+  else NR_OPTD(OPT_MOMENTUM);
+#undef NR_OPTD
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

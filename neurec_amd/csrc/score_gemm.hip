@@ -19,6 +19,7 @@
 // L1.  The kernel is bound by the HBM write of S (4·I bytes per user), not by
 // the matrix pipe: d is only 16..128.
 #include "nr_common.h"
+#include <algorithm>
 #include <limits.h>
 
 namespace {
@@ -390,6 +391,94 @@ GemmWs carve(void* ws, int rows, int cols, int dp) {
   return g;
 }
 
+// ---- the strike plan, built on the device (r05; was construction-time torch unique / bincount / cumsum) -------------
+// A pair = (user, 32-item tile) holding at least one train item of the user.  CSR rows are sorted by item, so a
+// user's entries of one tile are consecutive: the FIRST of them (the "head") stands for the pair.  Three launches:
+// count heads per tile (LDS pre-aggregated histogram) -> one workgroup scans the tiles and lays out the chunk table
+// (chunks of <= 32 pairs of one tile: the unit a wave of tilemax_fix_kernel recomputes) -> every head reserves a slot
+// in its tile and writes (user, OR of its items' bits).  The order of the pairs inside a tile is whatever the atomics
+// give — every pair is independent in the fix-up pass, so M does not depend on it.
+__global__ __launch_bounds__(256) void strike_plan_count_kernel(const int64_t* __restrict__ indptr,
+                                                                const int32_t* __restrict__ indices, int n_users,
+                                                                int32_t* __restrict__ per_tile) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * 256) >> 6;
+  for (int u = wave; u < n_users; u += n_waves) {
+    const int64_t b = indptr[u], e = indptr[u + 1];
+    for (int64_t t = b + lane; t < e; t += NR_WAVE) {
+      const int tile = indices[t] >> 5;
+      if (t == b || (indices[t - 1] >> 5) != tile) atomicAdd(&per_tile[tile], 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void strike_plan_layout_kernel(const int32_t* __restrict__ per_tile, int n_tiles,
+                                                                  int64_t* __restrict__ tile_ptr,
+                                                                  int32_t* __restrict__ cursor,
+                                                                  int32_t* __restrict__ chunk_tile,
+                                                                  int64_t* __restrict__ chunk_begin,
+                                                                  int32_t* __restrict__ counts) {
+  __shared__ int64_t s_pairs[1024];
+  __shared__ int32_t s_chunks[1024];
+  const int tid = threadIdx.x;
+  const int per = (n_tiles + 1023) / 1024, t0 = tid * per, t1 = min(t0 + per, n_tiles);
+  int64_t pairs = 0;
+  int32_t chunks = 0;
+  for (int t = t0; t < t1; ++t) {
+    pairs += per_tile[t];
+    chunks += (per_tile[t] + 31) >> 5;
+  }
+  s_pairs[tid] = pairs;
+  s_chunks[tid] = chunks;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {                       // inclusive scan of the per-thread totals
+    const int64_t a = tid >= off ? s_pairs[tid - off] : 0;
+    const int32_t c = tid >= off ? s_chunks[tid - off] : 0;
+    __syncthreads();
+    s_pairs[tid] += a;
+    s_chunks[tid] += c;
+    __syncthreads();
+  }
+  int64_t pbase = s_pairs[tid] - pairs;
+  int32_t cbase = s_chunks[tid] - chunks;
+  for (int t = t0; t < t1; ++t) {
+    const int32_t n = per_tile[t];
+    tile_ptr[t] = pbase;
+    cursor[t] = 0;
+    for (int c = 0; c < ((n + 31) >> 5); ++c) {
+      chunk_tile[cbase + c] = t;
+      chunk_begin[cbase + c] = pbase + 32 * (int64_t)c;
+    }
+    pbase += n;
+    cbase += (n + 31) >> 5;
+  }
+  if (tid == 1023) {
+    tile_ptr[n_tiles] = s_pairs[1023];
+    counts[0] = (int32_t)s_pairs[1023];
+    counts[1] = s_chunks[1023];
+  }
+}
+
+__global__ __launch_bounds__(256) void strike_plan_fill_kernel(const int64_t* __restrict__ indptr,
+                                                               const int32_t* __restrict__ indices, int n_users,
+                                                               const int64_t* __restrict__ tile_ptr,
+                                                               int32_t* __restrict__ cursor,
+                                                               int32_t* __restrict__ plan_user,
+                                                               uint32_t* __restrict__ plan_mask) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * 256) >> 6;
+  for (int u = wave; u < n_users; u += n_waves) {
+    const int64_t b = indptr[u], e = indptr[u + 1];
+    for (int64_t t = b + lane; t < e; t += NR_WAVE) {
+      const int item = indices[t], tile = item >> 5;
+      if (t != b && (indices[t - 1] >> 5) == tile) continue;     // not the head of its pair
+      uint32_t m = 1u << (item & 31);
+      for (int64_t q = t + 1; q < e && (indices[q] >> 5) == tile; ++q) m |= 1u << (indices[q] & 31);   // <= 31 more
+      const int64_t slot = tile_ptr[tile] + atomicAdd(&cursor[tile], 1);
+      plan_user[slot] = u;
+      plan_mask[slot] = m;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -559,6 +648,35 @@ int nrhip_score_tilemax_fix(const float* d_P, int64_t ldp, int d, int cols, cons
     default: NR_REQUIRE(false, NR_ERR_UNSUPPORTED, "score_tilemax_fix: dp=%d", dp);
   }
 #undef NR_FIX_CASE
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+/* The strike plan of a train matrix (engine.TileStrikePlan; uni_evaluator.py:132-140 strikes the train items of every
+ * batch on the host): which (user, 32-item tile) pairs hold a train item and which items of the tile, grouped by
+ * tile and cut into chunks of <= 32 pairs — the arguments of nrhip_score_tilemax_fix.  Capacities: d_plan_user /
+ * d_plan_mask nnz entries, d_tile_ptr n_tiles + 1 (n_tiles = 2 * ceil(cols / 64)), d_chunk_tile / d_chunk_begin
+ * nnz / 32 + n_tiles + 1, d_counts[2] = {pairs, chunks}, d_ws 2 * n_tiles int32.  Built once per train matrix. */
+int nrhip_tile_strike_plan(const int64_t* d_indptr, const int32_t* d_indices, int n_users, int cols,
+                           int32_t* d_plan_user, uint32_t* d_plan_mask, int64_t* d_tile_ptr, int32_t* d_chunk_tile,
+                           int64_t* d_chunk_begin, int32_t* d_counts, void* d_ws, size_t ws_bytes, void* stream) {
+  NR_REQUIRE(d_indptr && d_indices && d_plan_user && d_plan_mask && d_tile_ptr && d_chunk_tile && d_chunk_begin &&
+                 d_counts && d_ws && n_users >= 0 && cols >= 1, NR_ERR_ARG, "tile_strike_plan: bad arguments");
+  const int n_tiles = 2 * ((cols + 63) / 64);
+  NR_REQUIRE(ws_bytes >= (size_t)n_tiles * 8, NR_ERR_WORKSPACE, "tile_strike_plan: workspace %zu < %zu", ws_bytes,
+             (size_t)n_tiles * 8);
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* per_tile = (int32_t*)d_ws;
+  int32_t* cursor = per_tile + n_tiles;
+  NR_CHECK_HIP(hipMemsetAsync(per_tile, 0, (size_t)n_tiles * 4, st));
+  const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)n_users + 3) / 4 + 1, 4096);
+  hipLaunchKernelGGL(strike_plan_count_kernel, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users, per_tile);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(strike_plan_layout_kernel, dim3(1), dim3(1024), 0, st, per_tile, n_tiles, d_tile_ptr, cursor,
+                     d_chunk_tile, d_chunk_begin, d_counts);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(strike_plan_fill_kernel, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users, d_tile_ptr,
+                     cursor, d_plan_user, d_plan_mask);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

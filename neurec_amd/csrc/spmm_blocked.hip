@@ -1411,7 +1411,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   // cost of a row for balancing: its non-zeros plus a fixed cost per sub-list (descriptor, first
   // index chunk and the short last gather round; fitted on the per-workgroup timeline,
   // profiles/r01_exp_spmm_timeline.txt)
-  int ent_cost = 6;
+  int ent_cost = 4;     // r05 (rows dealt): 0 .. 16 all within 1 us of each other, 2-4 best (profiles/r05_exp_entcost.txt)
   if (const char* e = getenv("NEUREC_SPMM_ENTCOST")) ent_cost = atoi(e);
   auto row_cost = [&](int64_t l) { return l + (int64_t)ent_cost * std::max<int64_t>(1, (l + kSeg - 1) / kSeg); };
   struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; int32_t cmin; int64_t width, K; };

@@ -359,38 +359,30 @@ def score_gemm_for(item_table, max_rows):
 
 class TileStrikePlan:
     """Which (user, 32-item tile) pairs hold a train item, and which items of the tile — built ONCE per train
-    matrix (construction-time torch ops; nothing here runs per evaluation).  Sorted by tile, then user; cut into
-    chunks of <= 32 pairs of one tile, the unit one wave of tilemax_fix_kernel recomputes (csrc/score_gemm.hip).
+    matrix by three native launches (nrhip_tile_strike_plan: head count per tile, layout, fill; r05 — it was
+    construction-time torch unique / bincount / cumsum).  Grouped by tile, cut into chunks of <= 32 pairs of one
+    tile, the unit one wave of tilemax_fix_kernel recomputes (csrc/score_gemm.hip); the order of the pairs inside a
+    tile is unspecified (every pair is independent in the fix-up pass).
     uni_evaluator.py:132-140 strikes ranking_score[u][train items of u] = -inf on the host for every batch."""
 
     def __init__(self, train_csr, cols=None):
         dev = train_csr.indptr.device
         self.cols = int(train_csr.n_cols if cols is None else cols)
-        U = int(train_csr.n_rows)
-        indptr, indices = train_csr.indptr, train_csr.indices[:train_csr.nnz].to(torch.int64)
-        counts = indptr[1:] - indptr[:-1]
-        user = torch.repeat_interleave(torch.arange(U, device=dev, dtype=torch.int64), counts)
+        U, nnz = int(train_csr.n_rows), int(train_csr.nnz)
         n_tiles = 2 * ((self.cols + 63) // 64)
-        # one entry per distinct (tile, user, item): a CSR assembled by hand may repeat an item, and a repeated bit
-        # would carry into its neighbour under the + below (ADVICE r3)
-        full = torch.unique(((indices >> 5) * U + user) * 32 + (indices & 31))
-        key = full >> 5
-        uniq, inverse = torch.unique_consecutive(key, return_inverse=True)
-        bits = torch.ones_like(key) << (full & 31)
-        mask = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).index_add_(0, inverse, bits)   # distinct bits: + is |
-        tile = uniq // U
-        self.user = (uniq - tile * U).to(torch.int32).contiguous()
-        self.mask = torch.where(mask >= 2**31, mask - 2**32, mask).to(torch.int32).contiguous()        # the uint32 bit pattern
-        per_tile = torch.bincount(tile, minlength=n_tiles)
-        self.tile_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
-        self.tile_ptr[1:] = torch.cumsum(per_tile, 0)
-        n_chunks = (per_tile + 31) // 32
-        self.chunk_tile = torch.repeat_interleave(torch.arange(n_tiles, device=dev, dtype=torch.int32), n_chunks).contiguous()
-        first = torch.cumsum(n_chunks, 0) - n_chunks                          # index of a tile's first chunk
-        within = torch.arange(self.chunk_tile.numel(), device=dev, dtype=torch.int64) - first[self.chunk_tile.long()]
-        self.chunk_begin = (self.tile_ptr[self.chunk_tile.long()] + 32 * within).contiguous()
-        self.n_chunks = int(self.chunk_tile.numel())
-        self.n_pairs = int(self.user.numel())
+        i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+        i64 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int64, device=dev)
+        user, mask = i32(nnz), i32(nnz)
+        self.tile_ptr = i64(n_tiles + 1)
+        cap = nnz // 32 + n_tiles + 1
+        chunk_tile, chunk_begin = i32(cap), i64(cap)
+        counts, ws = i32(2), i32(2 * n_tiles)
+        call("nrhip_tile_strike_plan", _ptr(train_csr.indptr, torch.int64), _ptr(train_csr.indices, torch.int32), U,
+             self.cols, _ptr(user), _ptr(mask), _ptr(self.tile_ptr), _ptr(chunk_tile), _ptr(chunk_begin), _ptr(counts),
+             _ptr(ws), ws.numel() * 4, _stream())
+        self.n_pairs, self.n_chunks = (int(x) for x in counts.cpu())      # the one host round trip of the build
+        self.user, self.mask = user[:max(self.n_pairs, 1)], mask[:max(self.n_pairs, 1)]
+        self.chunk_tile, self.chunk_begin = chunk_tile[:max(self.n_chunks, 1)], chunk_begin[:max(self.n_chunks, 1)]
 
 
 _tiles_ws = Workspace()
@@ -750,6 +742,46 @@ def optimizer_rows(kind, var, slot0, slot1, grad, flag, lr, hyper1=0.0, hyper2=0
          _ptr(slot0, torch.float32, allow_none=True), _ptr(slot1, torch.float32, allow_none=True),
          _ptr(grad, torch.float32), _ptr(flag, torch.uint8), var.shape[0], var.shape[1], float(lr),
          float(hyper1), float(hyper2), float(eps), _stream())
+
+
+class DenseLearner:
+    """util/learner.py:2-17 for DENSE variables (NGCF / Mult-VAE: every trainable feeds a dense op, so TF applies
+    its Apply* kernels): gd, adagrad (initial_accumulator_value 1e-8, learner.py:5-6), rmsprop
+    (tf.train.RMSPropOptimizer(lr): decay 0.9, momentum 0, epsilon 1e-10; `rms` starts at ones), momentum
+    (learner.py:13-14, 0.9).  The engines hand in their Adam moment buffers as slots — `init_slots` gives them the
+    optimiser's initial values; Adam itself stays on its own kernels."""
+
+    KINDS = ("gd", "adagrad", "rmsprop", "momentum")
+
+    def __init__(self, kind, lr, momentum=0.9):
+        kind = str(kind).lower()
+        if kind not in self.KINDS:
+            raise ValueError("please select a suitable optimizer")            # learner.py:15-16
+        self.kind, self.lr, self.momentum = kind, float(lr), float(momentum)
+
+    def init_slots(self, slot0, slot1):
+        """slot tensors (any iterable each) set to what TF creates them with"""
+        v0 = {"gd": 0.0, "adagrad": 1e-8, "rmsprop": 1.0, "momentum": 0.0}[self.kind]
+        for t in slot0:
+            t.fill_(v0)
+        for t in slot1:
+            t.zero_()
+
+    def apply(self, tensors):
+        """tensors: (var, slot0, slot1, grad[, clear_grad]) tuples, as adam_dense_multi takes them"""
+        h1, h2, eps = {"gd": (0.0, 0.0, 0.0), "adagrad": (0.0, 0.0, 0.0), "rmsprop": (0.9, 0.0, 1e-10),
+                       "momentum": (self.momentum, 0.0, 0.0)}[self.kind]
+        for t in tensors:
+            var, s0, s1, grad = t[:4]
+            call("nrhip_optimizer_dense_tf", ROW_OPTIMIZERS[self.kind], _ptr(var, torch.float32),
+                 _ptr(s0, torch.float32, allow_none=True), _ptr(s1, torch.float32, allow_none=True),
+                 _ptr(grad, torch.float32), var.numel(), self.lr, h1, h2, eps, 1 if (len(t) > 4 and t[4]) else 0,
+                 _stream())
+
+
+def make_learner(learner, lr):
+    """None for adam (the engines' own kernels), a DenseLearner for the other learners of learner.py"""
+    return None if str(learner).lower() == "adam" else DenseLearner(learner, lr)
 
 
 def lightgcn_mark_batch(users, pos, neg, n_users, rows_out, row_flag):

@@ -70,8 +70,8 @@ class MultiVAE(AbstractRecommender):
     def build_graph(self):
         from ... import engine as E
         from ...trainer import MultiVAEEngine
-        if str(self.learner).lower() != "adam":
-            raise NotImplementedError("the HIP Mult-VAE engine implements learner=adam")
+        if str(self.learner).lower() not in ("adam",) + E.DenseLearner.KINDS:
+            raise ValueError("please select a suitable optimizer")               # util/learner.py:15-16
         if self.act not in E.VAE_ACTS:
             raise NotImplementedError("activation %r is not built (tanh/sigmoid/relu/identity)" % self.act)
         w_init = get_initializer(self.weight_init_method, self.stddev, seed=2017)
@@ -91,7 +91,7 @@ class MultiVAE(AbstractRecommender):
                 "Wp1t": np.ascontiguousarray(w_init([h, n]).T), "bp1": b_init([n]),
             }
             self.engine = MultiVAEEngine(E.DeviceCSR.from_scipy(train), n, params, self.learning_rate,
-                                         self.reg, self.act, max(self.batch_size, 1))
+                                         self.reg, self.act, max(self.batch_size, 1), learner=self.learner)
             return
         # any other p_dim: the variables in the order the reference creates them (MultiVAE.py:46-71: all of q, then p)
         from ...vae_wide import MultiVAEWideEngine
@@ -105,7 +105,7 @@ class MultiVAE(AbstractRecommender):
             Wp.append(w_init([d_in, d_out]))
             bp.append(b_init([d_out]))
         self.engine = MultiVAEWideEngine(E.DeviceCSR.from_scipy(train), n, Wq, bq, Wp, bp, self.learning_rate,
-                                         self.reg, self.act, max(self.batch_size, 1))
+                                         self.reg, self.act, max(self.batch_size, 1), learner=self.learner)
         self.logger.info("p_dim=%s runs on the width-generic Mult-VAE engine (fp32 matrix-core GEMMs for the item layer)"
                          % (list(self.p_dims[:-1]),))
 

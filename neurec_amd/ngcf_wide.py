@@ -36,7 +36,8 @@ def _pad(w):
 
 
 class NGCFWideEngine:
-    def __init__(self, adj, adj_t, n_users, n_items, embed, weights, lr, reg, mess_dropout, max_batch, seed=2017):
+    def __init__(self, adj, adj_t, n_users, n_items, embed, weights, lr, reg, mess_dropout, max_batch, seed=2017,
+                 learner="adam"):
         dev = E.require_gpu()
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.N = N = self.n_users + self.n_items
@@ -88,7 +89,11 @@ class NGCFWideEngine:
         nbytes = C.c_size_t(0)
         call("nrhip_gemm_workspace_bytes", wmax, wmax, self.splits, C.byref(nbytes))
         self.ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
-        self._native = self._native_buffers() if self.L <= _lib.NGCF_WIDE_MAX_LAYERS else None
+        # learner.py:2-17: adam inside the native step; the other learners after the spelled-out step's gradients
+        self.learner = E.make_learner(learner, lr)
+        if self.learner is not None:
+            self.learner.init_slots([self.mE] + [m for ms in self.mW for m in ms], [self.vE] + [v for vs in self.vW for v in vs])
+        self._native = self._native_buffers() if (self.L <= _lib.NGCF_WIDE_MAX_LAYERS and self.learner is None) else None
 
     def _native_buffers(self):
         """nrhip_ngcf_wide_buffers: every pointer the native step needs, recorded once (the buffers never move)"""
@@ -234,8 +239,11 @@ class NGCFWideEngine:
             E.copy2d(self.dOut[:, :w0], self.gE0[:, :w0])
         else:
             E.add2d(self.dOut[:, :w0], dego[:, :w0], self.gE0[:, :w0])
-        E.adam_dense_multi([(self.E0p, self.mE, self.vE, self.gE0)] +
-                           [(w, m, v, g) for k in range(self.L)
-                            for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k])], self.adam)
+        tensors = [(self.E0p, self.mE, self.vE, self.gE0)] + \
+            [(w, m, v, g) for k in range(self.L) for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k])]
+        if self.learner is None:
+            E.adam_dense_multi(tensors, self.adam)
+        else:
+            self.learner.apply(tensors)
         E.rows_clear(rows, self.dsum, (self.dOut,), self.flag)
         self.adam.advance()

@@ -571,12 +571,13 @@ class FullRankEvaluator:
         else:
             sums = E.colsum(per_user)
             if self._flags is None:
-                return (sums / n).cpu().numpy()
+                return sums.cpu().numpy() / n      # every mean is the fp64 column sum divided ON THE HOST (a device-side
+                #                                    scalar division may be a reciprocal multiply: last-ulp differences)
             both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
         self.n_flagged = int(both[-1])
         if self.n_flagged:
             self._redo_flagged(user_table, item_table, test_users, per_user)
-            return (E.colsum(per_user) / n).cpu().numpy()
+            return E.colsum(per_user).cpu().numpy() / n
         return both[:-1] / n
 
     def _evaluate_pruned(self, user_table, item_table, test_users, per_user, starts):
@@ -671,7 +672,7 @@ class NGCFEngine:
     (model/general_recommender/NGCF.py:91-110,160-202)."""
 
     def __init__(self, adj, adj_t, n_users, n_items, embed, weights, lr, reg, mess_dropout,
-                 max_batch, seed=2017):
+                 max_batch, seed=2017, learner="adam"):
         dev = E.require_gpu()
         self.n_users, self.n_items = int(n_users), int(n_items)
         self.N = self.n_users + self.n_items
@@ -701,6 +702,11 @@ class NGCFEngine:
         self.keep = 1.0 - float(mess_dropout)
         self.reg, self.seed, self.t = float(reg), int(seed), 0
         self.adam = E.AdamState(lr)
+        # learner.py:2-17: adam runs on the engine's own kernels (and inside the native step); the other four are
+        # applied tensor by tensor after the gradients of the spelled-out step (their slots live in the moment buffers)
+        self.learner = E.make_learner(learner, lr)
+        if self.learner is not None:
+            self.learner.init_slots([self.mE] + [m for ms in self.mW for m in ms], [self.vE] + [v for vs in self.vW for v in vs])
         self.terms = torch.empty(8 * max_batch, dtype=torch.float32, device=dev)
         self.rows = torch.zeros(3 * max_batch, dtype=torch.int32, device=dev)
         self.flag = torch.zeros(self.N, dtype=torch.uint8, device=dev)
@@ -708,7 +714,7 @@ class NGCFEngine:
         self.max_batch = max_batch
         # the ~27 launches of a step go out in ONE native call (a Python loop issues them in ~270 us,
         # more than they take on the GPU); contexts exist for at most E.NGCF_MAX_LAYERS layers
-        self._ctx = E.NativeStep.for_ngcf(self) if self.L <= E.NGCF_MAX_LAYERS else None
+        self._ctx = E.NativeStep.for_ngcf(self) if (self.L <= E.NGCF_MAX_LAYERS and self.learner is None) else None
 
     def forward(self, masks=None):
         """Fills self.Out = concat(E0, out_1..out_L).  masks: optional list of uint8 [N][d] device
@@ -769,9 +775,12 @@ class NGCFEngine:
         else:
             E.add2d(self.dOut[:, :d], dego, self.gE0)
         # every trainable in one launch (17 tensors = 2 launches; they were 17)
-        E.adam_dense_multi([(self.E0, self.mE, self.vE, self.gE0)] +
-                           [(w, m, v, g) for k in range(self.L)
-                            for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k])], self.adam)
+        tensors = [(self.E0, self.mE, self.vE, self.gE0)] + \
+            [(w, m, v, g) for k in range(self.L) for w, m, v, g in zip(self.W[k], self.mW[k], self.vW[k], self.gW[k])]
+        if self.learner is None:
+            E.adam_dense_multi(tensors, self.adam)
+        else:
+            self.learner.apply(tensors)
         E.rows_clear(rows, self.dsum, (self.dOut,), self.flag)
         self.adam.advance()
 
@@ -789,7 +798,7 @@ class MultiVAEEngine:
 
     NAMES = ("Wq0", "bq0", "Wq1", "bq1", "Wp0", "bp0", "Wp1t", "bp1")
 
-    def __init__(self, train_csr, n_items, params, lr, reg, act, max_batch, seed=2017, decoder=None):
+    def __init__(self, train_csr, n_items, params, lr, reg, act, max_batch, seed=2017, decoder=None, learner="adam"):
         dev = E.require_gpu()
         if decoder is None:                      # A/B switch for tests and profiles; the product default is "fused"
             import os
@@ -831,6 +840,9 @@ class MultiVAEEngine:
         # the whole step as one native call (nrhip_vae_step; NEUREC_VAE_NATIVE_STEP=0: the same entry points from Python)
         self.native_step = decoder == "fused" and os.environ.get("NEUREC_VAE_NATIVE_STEP", "1") != "0"
         self._step_args, self._step_key = None, None
+        self.learner = E.make_learner(learner, lr)          # learner.py:2-17; None: adam (the engine's own kernels)
+        if self.learner is not None:
+            self.learner.init_slots(self.M.values(), self.V.values())
 
     @property
     def S(self):
@@ -894,9 +906,12 @@ class MultiVAEEngine:
         if B > self.max_batch or B < 1:
             raise ValueError("batch size %d outside [1, %d]" % (B, self.max_batch))
         if self.native_step:
-            E.vae_step_native(self, rows, anneal, keep, drop_given, eps_given, want_loss, apply)
+            # another learner than adam: the native call stops after the gradients, the update follows tensor by tensor
+            E.vae_step_native(self, rows, anneal, keep, drop_given, eps_given, want_loss, apply and self.learner is None)
             self.last_anneal = float(anneal)
             if apply:
+                if self.learner is not None:
+                    self.learner.apply([(P[k], self.M[k], self.V[k], G[k], k == "Wq0") for k in self.NAMES])
                 self.adam.advance()
                 self.t += 1
             return
@@ -928,7 +943,11 @@ class MultiVAEEngine:
         self.last_anneal = float(anneal)
         if not apply:
             return
-        E.adam_dense_multi([(P[k], self.M[k], self.V[k], G[k], k == "Wq0") for k in self.NAMES], self.adam)
+        tensors = [(P[k], self.M[k], self.V[k], G[k], k == "Wq0") for k in self.NAMES]
+        if self.learner is None:
+            E.adam_dense_multi(tensors, self.adam)
+        else:
+            self.learner.apply(tensors)
         self.adam.advance()
         self.t += 1
 

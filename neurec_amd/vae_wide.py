@@ -29,7 +29,7 @@ def _act_id(act, last):
 
 
 class MultiVAEWideEngine:
-    def __init__(self, train_csr, n_items, Wq, bq, Wp, bp, lr, reg, act, max_batch, seed=2017):
+    def __init__(self, train_csr, n_items, Wq, bq, Wp, bp, lr, reg, act, max_batch, seed=2017, learner="adam"):
         dev = E.require_gpu()
         self.csr, self.n_items = train_csr, int(n_items)
         f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)
@@ -51,6 +51,9 @@ class MultiVAEWideEngine:
         self.G = [torch.zeros_like(p) for p in self.params]
         self.M = [torch.zeros_like(p) for p in self.params]
         self.V = [torch.zeros_like(p) for p in self.params]
+        self.learner = E.make_learner(learner, lr)          # learner.py:2-17; None: adam
+        if self.learner is not None:
+            self.learner.init_slots(self.M, self.V)
         self.Hq = [z(B, w.shape[1]) for w in self.Wq]              # encoder layer outputs (the last: [mu | logvar])
         self.Gp = [z(B, w.shape[1]) for w in self.Wp[:-1]]         # decoder hidden outputs
         self.dHq = [z(B, w.shape[1]) for w in self.Wq]
@@ -181,8 +184,11 @@ class MultiVAEWideEngine:
         self.last_anneal = float(anneal)
         if not apply:
             return
-        E.adam_dense_multi([(self.params[k], self.M[k], self.V[k], self.G[k], k == iWq)
-                            for k in range(len(self.params))], self.adam)
+        tensors = [(self.params[k], self.M[k], self.V[k], self.G[k], k == iWq) for k in range(len(self.params))]
+        if self.learner is None:
+            E.adam_dense_multi(tensors, self.adam)
+        else:
+            self.learner.apply(tensors)
         self.adam.advance()
         self.t += 1
 

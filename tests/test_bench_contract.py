@@ -1,5 +1,5 @@
 """bench.py's output contract, checked on the committed bench line of the round
-(profiles/r04_bench.json) and on the argument parser — no GPU needed."""
+(profiles/r05_bench.json) and on the argument parser — no GPU needed."""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -34,7 +34,7 @@ def test_committed_bench_line_carries_every_contract_field():
     for name in ("spmm_blocked.hip", "spmm.hip"):
         with open(os.path.join(ROOT, "neurec_amd", "csrc", name), "rb") as f:
             h.update(f.read())
-    with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
         assert json.load(f)["_spmm_sources_sha16"] == h.hexdigest()[:16]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

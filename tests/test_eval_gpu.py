@@ -580,3 +580,46 @@ def test_nan_user_rows_do_not_disturb_the_other_users():
     g = torch.from_numpy(good).cuda()
     np.testing.assert_array_equal(lean.evaluate_factors(Pd, Qd, g, exact_mean=True),
                                   full.evaluate_factors(Pd, Qd, g, exact_mean=True))
+
+
+@pytest.mark.parametrize("shape", [(300, 1000, 0.02), (1, 40, 0.5), (64, 33, 0.3), (500, 70001, 0.0005)])
+def test_native_strike_plan_lists_every_user_tile_pair_once(shape):
+    """engine.TileStrikePlan (nrhip_tile_strike_plan, r05: no torch ops): the (user, tile) pairs, their item bits,
+    the per-tile pointers and the chunk table against a numpy construction — as SETS per tile (the order inside a
+    tile is unspecified), duplicate items in a hand-made CSR included."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    U, I, dens = shape
+    tr = sp.random(U, I, dens, random_state=U + I, format="csr", dtype=np.float32)
+    tr.sort_indices()
+    indptr, indices = tr.indptr.astype(np.int64), tr.indices.astype(np.int32)
+    if len(indices) > 3:                                   # a repeated item (a CSR assembled by hand may hold one)
+        r = int(np.flatnonzero(np.diff(indptr) >= 2)[0]) if (np.diff(indptr) >= 2).any() else None
+        if r is not None:
+            indices[indptr[r] + 1] = indices[indptr[r]]
+    csr = E.DeviceCSR(indptr, indices, I)
+    plan = E.TileStrikePlan(csr, I)
+    n_tiles = 2 * ((I + 63) // 64)
+    want = {}
+    for u in range(U):
+        for i in indices[indptr[u]:indptr[u + 1]]:
+            want[(int(i) >> 5, u)] = want.get((int(i) >> 5, u), 0) | (1 << (int(i) & 31))
+    assert plan.n_pairs == len(want)
+    tp = plan.tile_ptr.cpu().numpy()
+    user, mask = plan.user.cpu().numpy(), plan.mask.cpu().numpy().view(np.uint32)
+    assert tp[0] == 0 and tp[-1] == len(want) and len(tp) == n_tiles + 1 and (np.diff(tp) >= 0).all()
+    got = {}
+    for t in range(n_tiles):
+        for k in range(tp[t], tp[t + 1]):
+            assert (t, int(user[k])) not in got
+            got[(t, int(user[k]))] = int(mask[k])
+    assert got == want
+    ct, cb = plan.chunk_tile.cpu().numpy()[:plan.n_chunks], plan.chunk_begin.cpu().numpy()[:plan.n_chunks]
+    assert plan.n_chunks == int(((np.diff(tp) + 31) // 32).sum())
+    covered = np.zeros(len(want), bool)
+    for t, b in zip(ct, cb):
+        e = min(b + 32, tp[t + 1])
+        assert tp[t] <= b < e and not covered[b:e].any()
+        covered[b:e] = True
+    assert covered.all()

@@ -176,9 +176,9 @@ def test_multivae_rejects_unbuilt_widths():
     bad["bq0"] = np.zeros(64, np.float32); bad["bp0"] = np.zeros(64, np.float32)
     bad["Wq1"] = np.zeros((64, 32), np.float32)
     bad["Wp1t"] = np.zeros((R.shape[1], 64), np.float32)
-    eng = _engine(R, bad)
-    with pytest.raises(NotImplementedError):
-        eng.logits(_dev(np.arange(8, dtype=np.int32)))
+    # said at construction (it used to surface as an opaque native error at the first step)
+    with pytest.raises(ValueError, match="MultiVAEWideEngine"):
+        _engine(R, bad)
 
 
 @pytest.mark.parametrize("B,I,h", [(512, 4099, 32), (300, 1000, 32), (700, 2050, 20), (33, 31, 32), (1, 77, 5),
