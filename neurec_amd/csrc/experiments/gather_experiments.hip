@@ -721,3 +721,78 @@ extern "C" int nrhip_exp_overlap(int blocks, int role_a, int role_b, int iters, 
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// r05: a persistent BPR-MF epoch kernel confined to ONE XCD — what would its per-step barrier
+// cost, and how long does the step's WORK take on an eighth of the chip?  (scripts/exp_one_xcd.py)
+//   nrhip_exp_xcd_barrier   8·G blocks are launched; only those that find themselves on XCD `xcd` (HW_REG_XCC_ID)
+//                           take part, the others return at once: G workgroups of one XCD cross `iters` barriers
+//                           on one counter (release add, acquire spin).  us per barrier = kernel time / iters.
+//   nrhip_exp_xcc_histogram which XCD do the blocks of a launch run on (d_hist[8]) — reads back what a CU-masked
+//                           stream (hipExtStreamCreateWithCUMask) really selects
+//   nrhip_exp_cumask_stream_create / _destroy: a stream whose kernels run on the masked CUs only
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int exp_xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15;
+}
+__global__ __launch_bounds__(256) void exp_xcd_barrier_kernel(unsigned* cnt, int xcd, int group, int iters, float* out) {
+  if (exp_xcc_id() != xcd) return;
+  __shared__ int s_member;
+  if (threadIdx.x == 0) s_member = (int)atomicAdd(&cnt[1], 1u);           // the first `group` arrivals take part
+  __syncthreads();
+  if (s_member >= group) return;
+  float x = threadIdx.x * 1e-3f;
+  for (int it = 1; it <= iters; ++it) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      atomicAdd(&cnt[0], 1u);
+      // (bounded spin: if fewer than `group` blocks landed on this XCD the kernel must end, not hang the box;
+      //  cnt[2] != 0 afterwards says the numbers are void)
+      long spins = 0;
+      while (__hip_atomic_load(&cnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it * group)
+        if (++spins > (1L << 22)) { cnt[2] = 1u; break; }
+      if (cnt[2]) it = iters;
+    }
+    __syncthreads();
+  }
+  if (x == 12345.f) out[blockIdx.x] = x;
+}
+__global__ void exp_xcc_histogram_kernel(int* hist) {
+  if (threadIdx.x == 0) atomicAdd(&hist[exp_xcc_id() & 7], 1);
+}
+}  // namespace
+
+extern "C" int nrhip_exp_xcd_barrier(unsigned* d_cnt, int xcd, int group, int iters, float* d_out, void* stream) {
+  NR_REQUIRE(d_cnt && d_out && xcd >= 0 && xcd < 8 && group >= 1 && group <= 32 && iters >= 1, NR_ERR_ARG,
+             "exp_xcd_barrier: bad arguments (group <= 32: one workgroup per CU of the XCD)");
+  NR_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 16 * sizeof(unsigned), (hipStream_t)stream));
+  hipLaunchKernelGGL(exp_xcd_barrier_kernel, dim3(8 * group), dim3(256), 0, (hipStream_t)stream, d_cnt, xcd, group, iters,
+                     d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+extern "C" int nrhip_exp_xcc_histogram(int n_blocks, int* d_hist, void* stream) {
+  NR_REQUIRE(d_hist && n_blocks >= 1, NR_ERR_ARG, "exp_xcc_histogram: bad arguments");
+  NR_CHECK_HIP(hipMemsetAsync(d_hist, 0, 8 * sizeof(int), (hipStream_t)stream));
+  hipLaunchKernelGGL(exp_xcc_histogram_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, d_hist);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+extern "C" int nrhip_exp_cumask_stream_create(const uint32_t* mask, int words, void** stream_out) {
+  NR_REQUIRE(mask && words >= 1 && stream_out, NR_ERR_ARG, "exp_cumask_stream_create: bad arguments");
+  hipStream_t s = nullptr;
+  NR_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream_out = (void*)s;
+  return NR_OK;
+}
+
+extern "C" int nrhip_exp_cumask_stream_destroy(void* stream) {
+  if (stream) NR_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return NR_OK;
+}
