@@ -916,6 +916,25 @@ int nrhip_ngcf_mix_bwd(const float* d_Y1, const float* d_Y2, int64_t ldy, const 
                        int64_t lde, int64_t n_rows, int w, int w_pad, float* d_dS, float* d_dego_direct,
                        void* stream);
 
+/* NGCF's other conf-surface branches (r05): alg_type = gcn / gcmc (NGCF.py:204-248 — a layer is leaky_relu(S W_gc + b_gc)
+ * with message dropout, gcmc adds a dense layer on top and concatenates only those) and node dropout of the adjacency
+ * (NGCF.py:162-164,334-362).  The products are nrhip_spmm_csr / nrhip_gemm_f32; these are the element-wise pieces:
+ *   nrhip_lrelu_drop_fwd   y = (flags & 1 ? leaky_relu(T) : T); (flags & 2): y = mask ? y / keep : 0 (mask read when
+ *                          mask_given, else drawn from (seed, step, layer) and written); d_out_a [n_rows][lda] padded with
+ *                          zeros to w_pad (the next hop's operand), d_out_b [n_rows][ldb] the w real columns; either NULL
+ *   nrhip_lrelu_drop_bwd   dT[n_rows][w] = (d_a + d_b) through the same ops backwards (d_b optional)
+ *   nrhip_edge_dropout     out[e] = keep_e ? vals[e] * (1 / keep) : 0 over the stored entries (sparse_retain + scale);
+ *                          keep_e read (given) or drawn from (seed, step) and written
+ *   nrhip_gather_f32       dst[e] = src[index[e]] (the transposed matrix takes the same draw) */
+int nrhip_lrelu_drop_fwd(const float* d_T, int64_t ldt, int64_t n_rows, int w, int w_pad, float keep, uint8_t* d_mask_io,
+                         int mask_given, uint64_t seed, uint64_t step, int layer, int flags, float* d_out_a, int64_t lda,
+                         float* d_out_b, int64_t ldb, void* stream);
+int nrhip_lrelu_drop_bwd(const float* d_da, int64_t lda, const float* d_db, int64_t ldb, const float* d_T, int64_t ldt,
+                         const uint8_t* d_mask, int64_t n_rows, int w, float keep, int flags, float* d_dT, void* stream);
+int nrhip_edge_dropout(const float* d_vals, int64_t n, float keep, uint8_t* d_keep_io, int given, uint64_t seed,
+                       uint64_t step, float* d_out, void* stream);
+int nrhip_gather_f32(const float* d_src, const int32_t* d_index, int64_t n, float* d_dst, void* stream);
+
 /* The width-generic NGCF forward pass and training step as ONE call each (neurec_amd/ngcf_wide.py strung them from
  * ~70 Python-issued launches: 1.0 ms a step at 64 / [64, 64, 64], of which the GPU was busy 0.45).  The struct
  * records caller-owned device pointers; per layer k: widths w[k] -> w[k+1] (wp = padded to the SpMM's row widths),

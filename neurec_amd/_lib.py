@@ -217,6 +217,10 @@ SIGNATURES = {
     "nrhip_ew_mul": [p, i64, p, i64, i64, i32, p, i64, p],
     "nrhip_ngcf_act_fwd": [p, p, i64, i64, i32, i32, f32, p, i32, u64, u64, i32, p, i64, p, i64, p],
     "nrhip_ngcf_act_bwd": [p, i64, p, i64, p, i64, p, p, i64, p, i64, i32, f32, p, p, p],
+    "nrhip_lrelu_drop_fwd": [p, i64, i64, i32, i32, f32, p, i32, u64, u64, i32, i32, p, i64, p, i64, p],
+    "nrhip_lrelu_drop_bwd": [p, i64, p, i64, p, i64, p, i64, i32, f32, i32, p, p],
+    "nrhip_edge_dropout": [p, i64, f32, p, i32, u64, u64, p, p],
+    "nrhip_gather_f32": [p, p, i64, p, p],
     "nrhip_ngcf_mix_bwd": [p, p, i64, p, p, i64, i64, i32, i32, p, p, p],
     "nrhip_route_batch": [p, p, p, i32, i32, i32, i32, i32, p, p, p, p, p, i32, p],
     "nrhip_route_owner_keys": [p, p, i32, p, p, i32, i32, i32, p, p, p],

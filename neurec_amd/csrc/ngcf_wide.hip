@@ -123,6 +123,78 @@ __global__ __launch_bounds__(256) void ngcf_mix_bwd_kernel(const float* __restri
   d_ego_direct[r * lde + c] = de;
 }
 
+// ---- alg_type = gcn / gcmc (NGCF.py:204-248) and node dropout (NGCF.py:334-362): the element-wise pieces -----------
+// y = (flags & 1 ? leaky_relu(T) : T);  (flags & 2): y = mask ? y / keep : 0, the mask read (mask_given) or drawn from
+// (seed, step, layer) with the hash ngcf_act_fwd uses.  out_a gets the row padded with zeros to w_pad (the next SpMM's
+// operand), out_b the w real columns (a column block of the concatenated output); either may be NULL.
+__global__ __launch_bounds__(256) void lrelu_drop_fwd_kernel(const float* __restrict__ T, int64_t ldt, int64_t n_rows,
+                                                             int w, int w_pad, float keep, uint8_t* __restrict__ mask_io,
+                                                             int mask_given, uint64_t seed, uint64_t step, int layer,
+                                                             int flags, float* __restrict__ out_a, int64_t lda,
+                                                             float* __restrict__ out_b, int64_t ldb) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_rows * w_pad) return;
+  const int64_t r = e / w_pad;
+  const int c = (int)(e - r * w_pad);
+  float y = 0.f;
+  if (c < w) {
+    y = T[r * ldt + c];
+    if (flags & 1) y = lrelu(y);
+    if (flags & 2) {
+      bool kp;
+      if (mask_given) kp = mask_io[r * w + c] != 0;
+      else {
+        const uint64_t key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull + layer));
+        kp = (float)(nr::splitmix64(key ^ (uint64_t)(r * w + c)) >> 40) * (1.0f / 16777216.0f) < keep;
+        mask_io[r * w + c] = kp ? 1 : 0;
+      }
+      y = kp ? y / keep : 0.f;
+    }
+    if (out_b) out_b[r * ldb + c] = y;
+  }
+  if (out_a) out_a[r * lda + c] = y;
+}
+
+// dT = (d_a + d_b) through the same ops backwards: (flags & 2) mask ? g / keep : 0, (flags & 1) times leaky_relu'(T)
+__global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __restrict__ d_a, int64_t lda,
+                                                             const float* __restrict__ d_b, int64_t ldb,
+                                                             const float* __restrict__ T, int64_t ldt,
+                                                             const uint8_t* __restrict__ mask, int64_t n_rows, int w,
+                                                             float keep, int flags, float* __restrict__ dT) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_rows * w) return;
+  const int64_t r = e / w;
+  const int c = (int)(e - r * w);
+  float g = d_a[r * lda + c];
+  if (d_b) g += d_b[r * ldb + c];
+  if (flags & 2) g = mask[r * w + c] ? g / keep : 0.f;
+  if (flags & 1) g = T[r * ldt + c] > 0.f ? g : g * kLeaky;
+  dT[r * (int64_t)w + c] = g;
+}
+
+// node dropout of the adjacency's stored entries: out[e] = keep_e ? vals[e] * (1 / keep) : 0 (NGCF.py:352-362:
+// sparse_retain(X, floor(keep + uniform)) * (1 / keep)); keep_e read (given) or drawn from (seed, step) and written
+__global__ __launch_bounds__(256) void edge_dropout_kernel(const float* __restrict__ vals, int64_t n, float keep,
+                                                           uint8_t* __restrict__ keep_io, int given, uint64_t seed,
+                                                           uint64_t step, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  bool kp;
+  if (given) kp = keep_io[e] != 0;
+  else {
+    const uint64_t key = nr::splitmix64(seed ^ (step * 0x9e3779b97f4a7c15ull + 0x6e6f6465ull));
+    kp = (float)(nr::splitmix64(key ^ (uint64_t)e) >> 40) * (1.0f / 16777216.0f) < keep;
+    keep_io[e] = kp ? 1 : 0;
+  }
+  out[e] = kp ? __fmul_rn(vals[e], __fdiv_rn(1.0f, keep)) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                         int64_t n, float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) dst[e] = src[idx[e]];
+}
+
 }  // namespace
 
 extern "C" {
@@ -166,6 +238,50 @@ int nrhip_ngcf_act_bwd(const float* d_dout, int64_t ldo, const float* d_dego_nex
   hipLaunchKernelGGL(ngcf_act_bwd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      d_dout, ldo, d_dego_next, ldn, d_ego_next, lde, d_T1, d_T2, ldt, d_mask, n_rows, w, keep, d_dT1,
                      d_dT2);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_lrelu_drop_fwd(const float* d_T, int64_t ldt, int64_t n_rows, int w, int w_pad, float keep, uint8_t* d_mask_io,
+                         int mask_given, uint64_t seed, uint64_t step, int layer, int flags, float* d_out_a, int64_t lda,
+                         float* d_out_b, int64_t ldb, void* stream) {
+  NR_REQUIRE(d_T && (d_out_a || d_out_b) && n_rows >= 0 && w >= 1 && w_pad >= w && ldt >= w && (!d_out_a || lda >= w_pad) &&
+                 (!d_out_b || ldb >= w) && (!(flags & 2) || (d_mask_io && keep > 0.f && keep <= 1.f)), NR_ERR_ARG,
+             "lrelu_drop_fwd: bad arguments");
+  if (n_rows == 0) return NR_OK;
+  hipLaunchKernelGGL(lrelu_drop_fwd_kernel, dim3((unsigned)((n_rows * w_pad + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_T, ldt, n_rows, w, w_pad, keep, d_mask_io, mask_given, seed, step, layer, flags,
+                     d_out_a, lda, d_out_b, ldb);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_lrelu_drop_bwd(const float* d_da, int64_t lda, const float* d_db, int64_t ldb, const float* d_T, int64_t ldt,
+                         const uint8_t* d_mask, int64_t n_rows, int w, float keep, int flags, float* d_dT, void* stream) {
+  NR_REQUIRE(d_da && d_dT && n_rows >= 0 && w >= 1 && lda >= w && (!d_db || ldb >= w) && (!(flags & 1) || (d_T && ldt >= w)) &&
+                 (!(flags & 2) || (d_mask && keep > 0.f)), NR_ERR_ARG, "lrelu_drop_bwd: bad arguments");
+  if (n_rows == 0) return NR_OK;
+  hipLaunchKernelGGL(lrelu_drop_bwd_kernel, dim3((unsigned)((n_rows * w + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_da, lda, d_db, ldb, d_T, ldt, d_mask, n_rows, w, keep, flags, d_dT);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_edge_dropout(const float* d_vals, int64_t n, float keep, uint8_t* d_keep_io, int given, uint64_t seed,
+                       uint64_t step, float* d_out, void* stream) {
+  NR_REQUIRE(d_vals && d_keep_io && d_out && n >= 0 && keep > 0.f && keep <= 1.f, NR_ERR_ARG, "edge_dropout: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(edge_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_vals, n,
+                     keep, d_keep_io, given, seed, step, d_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+
+int nrhip_gather_f32(const float* d_src, const int32_t* d_index, int64_t n, float* d_dst, void* stream) {
+  NR_REQUIRE(d_src && d_index && d_dst && n >= 0, NR_ERR_ARG, "gather_f32: bad arguments");
+  if (n == 0) return NR_OK;
+  hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_src,
+                     d_index, n, d_dst);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

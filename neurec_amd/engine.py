@@ -911,6 +911,13 @@ class SpmmCSR:
         self.blocked = self._blocked[d][0]
         return self.blocked is not None
 
+    def values_changed(self):
+        """`vals` was rewritten in place (NGCF's node dropout): the lane-group schedules hold their own copy of the
+        (column, value) pairs in schedule order and must re-read it"""
+        for plan, _buf in self._blocked.values():
+            if plan is not None and plan.value:
+                call("nrhip_spmm_blocked_pack", plan, _ptr(self.indices), _ptr(self.vals), _stream())
+
     def exact_row_nnz(self, d):
         """Rows with at most this many non-zeros are summed strictly in ascending column order."""
         return 64 if self.ensure_schedule(d) else 256

@@ -6,7 +6,9 @@ constructor, config keys (conf/NGCF.properties), training loop and log lines.  D
 the reference are limited to what SURVEY.md H6 lists as its quirks and are stated, not hidden:
   * the adjacency is built sparsely (the reference densifies the U×I train matrix first);
   * message dropout stays active at evaluation, as in the reference (no training flag there);
-  * only alg_type=ngcf without node dropout is implemented (the configured defaults).
+  * alg_type ngcf / gcn / gcmc, node dropout and every learner of util/learner.py are built (r05); the shipped
+    defaults (ngcf, adam, 16 / [16, 16], no node dropout) run on the fused register-resident engine, everything else on
+    the width-generic one.
 """
 from time import time
 
@@ -54,14 +56,15 @@ class NGCF(AbstractRecommender):
         self._final = None
 
     def build_graph(self):
+        from ... import engine as E
         from ...trainer import NGCFEngine
-        if self.alg_type not in ("ngcf",) or self.node_dropout_flag is True:
-            raise NotImplementedError("the HIP NGCF engine implements alg_type=ngcf with "
-                                      "node_dropout_flag=False (the reference defaults)")
-        if str(self.learner).lower() != "adam":
-            raise NotImplementedError("the HIP NGCF engine implements learner=adam")
+        if self.alg_type not in ("ngcf", "gcn", "gcmc"):
+            raise ValueError("alg_type must be ngcf, gcn or gcmc")            # NGCF.py:67-74 silently builds nothing
+        if str(self.learner).lower() not in ("adam",) + E.DenseLearner.KINDS:
+            raise ValueError("please select a suitable optimizer")             # util/learner.py:15-16
         sizes = [self.emb_dim] + list(self.weight_size)
-        if any(not 1 <= s <= 256 for s in sizes) or sum(sizes) > 256:
+        blocks = sizes[1:] if self.alg_type == "gcmc" else sizes               # gcmc concatenates the dense layers only
+        if any(not 1 <= s <= 256 for s in sizes) or sum(blocks) > 256:
             raise NotImplementedError("NGCF layer widths 1..256 with a concatenated width <= 256 are built "
                                       "(embedding_size + sum(layer_size) = %d)" % sum(sizes))
         e_init = get_initializer(self.embed_init_method, self.stddev, seed=2017)
@@ -71,17 +74,24 @@ class NGCF(AbstractRecommender):
         self.logger.info("using xavier initialization")
         weights = []
         for k in range(self.n_layers):
-            weights.append((w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]]),
-                            w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]])))
-        if all(s == 16 for s in sizes):                  # the shipped width: fused, register-resident layer kernels
-            engine = NGCFEngine
-        else:                                            # any other widths: SpMM + fp32-MFMA GEMM + row-wise kernels
-            from ...ngcf_wide import NGCFWideEngine as engine
-            self.logger.info("embedding_size=%d layer_size=%s runs on the width-generic NGCF engine"
-                             % (self.emb_dim, list(self.weight_size)))
-        self.engine = engine(self.norm_adj, transpose_csr(self.norm_adj), self.num_users,
-                             self.num_items, table, weights, self.learning_rate, self.reg,
-                             self.mess_dropout_ratio, self.batch_size)
+            layer = [w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]]),
+                     w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]])]     # W_gc, b_gc, W_bi, b_bi (NGCF.py:271-279)
+            if self.alg_type == "gcmc":                                               # W_mlp, b_mlp (NGCF.py:281-284)
+                layer[2:] = [w_init([sizes[k], sizes[k + 1]]), w_init([1, sizes[k + 1]])]
+            weights.append(tuple(layer))
+        node_dropout = float(self.node_dropout_ratio) if (self.node_dropout_flag is True and self.alg_type == "ngcf") else 0.0
+        args = (self.norm_adj, transpose_csr(self.norm_adj), self.num_users, self.num_items, table, weights,
+                self.learning_rate, self.reg, self.mess_dropout_ratio, self.batch_size)
+        if all(s == 16 for s in sizes) and self.alg_type == "ngcf" and node_dropout == 0.0:
+            # the shipped configuration: fused, register-resident layer kernels
+            self.engine = NGCFEngine(*args, learner=self.learner)
+            return
+        # any other widths / alg_type / node dropout: SpMM + fp32-MFMA GEMM + row-wise kernels
+        from ...ngcf_wide import NGCFWideEngine
+        self.logger.info("embedding_size=%d layer_size=%s alg_type=%s%s runs on the width-generic NGCF engine"
+                         % (self.emb_dim, list(self.weight_size), self.alg_type,
+                            " node_dropout=%g" % node_dropout if node_dropout else ""))
+        self.engine = NGCFWideEngine(*args, learner=self.learner, alg_type=self.alg_type, node_dropout=node_dropout)
 
     def train_model(self):
         import torch

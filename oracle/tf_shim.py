@@ -419,9 +419,52 @@ class SparseTensor:
         return self._cache[dt]
 
 
+class _DynSparse:
+    """A SparseTensor whose VALUES are a graph tensor: what tf.sparse_retain / `sparse * scalar` produce in
+    NGCF.py:352-362 (`_dropout_sparse`: node dropout of the adjacency).  A dropped entry keeps its slot with
+    value 0: in sparse_tensor_dense_matmul it adds an exact +0, which is what removing it does [EXT:
+    sparse_ops.sparse_retain keeps the entries whose mask is True; SparseTensor.__mul__ scales the values]."""
+
+    def __init__(self, indices, values, dense_shape):
+        self.indices, self.values, self.dense_shape = indices, values, tuple(int(x) for x in dense_shape)
+
+    def __mul__(self, o):
+        return _DynSparse(self.indices, multiply(self.values, o), self.dense_shape)
+    __rmul__ = __mul__
+
+
+def _sparse_mul(self, o):
+    base = Tensor(lambda: torch.from_numpy(np.ascontiguousarray(self.values)).to(_FLOAT["t"]), [])
+    return _DynSparse(self.indices, multiply(base, o), self.dense_shape)
+
+
+SparseTensor.__mul__ = _sparse_mul
+SparseTensor.__rmul__ = _sparse_mul
+
+
+def sparse_retain(sp_input, to_retain, name=None):
+    vals = sp_input.values
+    if not isinstance(vals, Tensor):
+        host = np.ascontiguousarray(sp_input.values)
+        vals = Tensor(lambda: torch.from_numpy(host).to(_FLOAT["t"]), [])
+    kept = Tensor(lambda v, m: v * m.to(v.dtype), [vals, to_retain])
+    return _DynSparse(sp_input.indices, kept, sp_input.dense_shape)
+
+
 def sparse_tensor_dense_matmul(sp_a, b, name=None, **_):
     """sparse_ops.sparse_tensor_dense_matmul: out[r] = sum over the stored entries of row r of
     value * b[col]; the derivative with respect to b is left to torch.autograd."""
+    if isinstance(sp_a, _DynSparse):
+        rows = torch.from_numpy(np.ascontiguousarray(sp_a.indices[:, 0]))
+        cols = torch.from_numpy(np.ascontiguousarray(sp_a.indices[:, 1]))
+        crow = torch.zeros(sp_a.dense_shape[0] + 1, dtype=torch.int64)
+        crow[1:] = torch.cumsum(torch.bincount(rows, minlength=sp_a.dense_shape[0]), 0)
+        assert (rows[1:] >= rows[:-1]).all().item(), "row-major entries expected (scipy COO of a CSR slice)"
+
+        def f(v, x):
+            a = torch.sparse_csr_tensor(crow, cols, v.detach(), size=sp_a.dense_shape)   # the adjacency is a constant
+            return torch.sparse.mm(a, x)
+        return Tensor(f, [sp_a.values, b])
     return Tensor(lambda x: torch.sparse.mm(sp_a.torch(), x), [b])
 
 

@@ -314,22 +314,27 @@ def test_unsupported_shapes_fail_early_and_by_name():
 
 
 def test_ngcf_and_multivae_plugins_refuse_what_is_not_built_by_name():
-    """r03: NGCF runs at any widths whose concatenation fits 256 columns and Mult-VAE at any p_dim; what is still not
-    built (wider concatenations, other alg_types / learners / activations) is refused before any engine is created."""
+    """r05: every alg_type / learner / node-dropout setting of conf/NGCF.properties and every learner of
+    conf/MultiVAE.properties is built; what is still refused (concatenations beyond 256 columns, unknown names — which
+    the reference rejects too, util/learner.py:15-16 — and activations TF has but the kernels do not) is refused by
+    name before any engine is created."""
     from neurec_amd.model.general_recommender.NGCF import NGCF
     from neurec_amd.model.general_recommender.MultiVAE import MultiVAE
     ng = object.__new__(NGCF)
     ng.alg_type, ng.node_dropout_flag, ng.learner, ng.emb_dim, ng.weight_size = "ngcf", False, "adam", 128, [128, 128]
     with pytest.raises(NotImplementedError, match="concatenated width <= 256"):
         ng.build_graph()
-    ng.emb_dim, ng.weight_size, ng.alg_type = 16, [16, 16], "gcn"
-    with pytest.raises(NotImplementedError, match="alg_type=ngcf"):
+    ng.emb_dim, ng.weight_size, ng.alg_type = 16, [16, 16], "gat"
+    with pytest.raises(ValueError, match="alg_type must be ngcf, gcn or gcmc"):
+        ng.build_graph()
+    ng.alg_type, ng.learner = "gcn", "sgd"
+    with pytest.raises(ValueError, match="please select a suitable optimizer"):
         ng.build_graph()
     vae = object.__new__(MultiVAE)
     vae.learner, vae.act, vae.p_dims = "sgd", "tanh", [200, 600, 1000]
-    with pytest.raises(NotImplementedError, match="learner=adam"):
+    with pytest.raises(ValueError, match="please select a suitable optimizer"):
         vae.build_graph()
-    vae.learner, vae.act = "adam", "elu"
+    vae.learner, vae.act = "rmsprop", "elu"
     with pytest.raises(NotImplementedError, match="activation 'elu' is not built"):
         vae.build_graph()
 

@@ -348,6 +348,52 @@ def test_multivae_engine_equals_the_reference_graph(tag):
     assert max(d) <= TOL + bar
 
 
+@pytest.mark.parametrize("learner", ["adagrad", "rmsprop", "gd", "momentum"])
+@pytest.mark.parametrize("engine_kind", ["narrow", "wide"])
+def test_multivae_other_learners_equal_the_reference_graph(learner, engine_kind):
+    """conf/MultiVAE.properties' learner beyond adam (util/learner.py:2-17): the reference class's own
+    epoch per learner (tests/golden/make_golden_tfgraph.py golden_multivae_learners) against both Mult-VAE engines —
+    the narrow one steps natively up to the gradients and applies the update tensor by tensor."""
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import MultiVAEEngine
+    from neurec_amd.vae_wide import MultiVAEWideEngine
+    g = load_golden("tfgraph_multivae_learners")
+    c = {k[len(learner) + 1:]: v for k, v in g.items() if k.startswith(learner + "/")}
+    h = json.loads(str(c["hyper"]))
+    assert h["learner"] == learner
+    U, I = int(g["n_users"]), int(g["n_items"])
+    R = sp.csr_matrix((np.ones(len(g["train_indices"]), np.float32), g["train_indices"], g["train_indptr"]),
+                      shape=(U, I))
+    csr = E.DeviceCSR.from_scipy(R)
+    if engine_kind == "narrow":
+        params = {k: g[k + "_0"] for k in VAE_NAMES if k != "Wp1"}
+        params["Wp1t"] = np.ascontiguousarray(g["Wp1_0"].T)
+        eng = MultiVAEEngine(csr, I, params, h["learning_rate"], h["reg"], h["activation"], h["batch_size"],
+                             learner=learner)
+        value = lambda k: (eng.P["Wp1t"].cpu().numpy().T if k == "Wp1" else eng.P[k].cpu().numpy())
+    else:
+        eng = MultiVAEWideEngine(csr, I, [g["Wq0_0"], g["Wq1_0"]], [g["bq0_0"], g["bq1_0"]], [g["Wp0_0"], g["Wp1_0"]],
+                                 [g["bp0_0"], g["bp1_0"]], h["learning_rate"], h["reg"], h["activation"],
+                                 h["batch_size"], learner=learner)
+        where = {"Wq0": 0, "Wq1": 1, "bq0": 2, "bq1": 3, "Wp0": 4, "Wp1": 5, "bp0": 6, "bp1": 7}
+        value = lambda k: eng.params[where[k]].cpu().numpy()
+    got = []
+    for s, rows in enumerate(c["rows"]):
+        drop_pos = np.ones(R.nnz, np.float32)
+        for b, u in enumerate(rows):
+            lo, hi = R.indptr[u], R.indptr[u + 1]
+            drop_pos[lo:hi] = c["drop_masks"][s][b, R.indices[lo:hi]]
+        eng.step(_dev(rows.astype(np.int32)), float(c["anneal"][s]), 0.8, drop_given=_dev(drop_pos),
+                 eps_given=_dev(c["eps"][s].astype(np.float32)))
+        got.append(eng.loss()[0])
+    assert _rel(got, c["f32_loss"]) <= TOL and _rel(got, c["f64_loss"]) <= TOL
+    bar = max(_err(c["f32_" + k], c["f64_" + k]) for k in VAE_NAMES)
+    d = [_err(value(k).reshape(c["f64_" + k].shape), c["f64_" + k]) for k in VAE_NAMES]
+    print("Mult-VAE %s (%s engine): all parameters vs the reference graph (fp64) %.1e (its fp32-vs-fp64 %.1e)"
+          % (learner, engine_kind, max(d), bar))
+    assert max(d) <= TOL + bar
+
+
 def test_multivae_config5_equals_the_reference_graph_at_gowalla_size():
     """BASELINE configs[4], Mult-VAE half: gowalla shape (I = 40,981), p_dim [16, 32], B = 512, the first 3
     steps of MultiVAE.train_model() — losses, sampled parameter rows and sampled logits."""
