@@ -398,16 +398,34 @@ GemmWs carve(void* ws, int rows, int cols, int dp) {
 // (chunks of <= 32 pairs of one tile: the unit a wave of tilemax_fix_kernel recomputes) -> every head reserves a slot
 // in its tile and writes (user, OR of its items' bits).  The order of the pairs inside a tile is whatever the atomics
 // give — every pair is independent in the fix-up pass, so M does not depend on it.
+// (a popular tile receives tens of thousands of heads: one global atomic each serialises — 0.31 ms at gowalla; a
+// workgroup therefore counts its users' heads per tile in LDS first and publishes one atomic per (workgroup, tile))
+constexpr int kPlanLdsTiles = 8192;             // tiles an LDS histogram holds (262,144 items); beyond: global atomics
+
+template <bool LDS>
 __global__ __launch_bounds__(256) void strike_plan_count_kernel(const int64_t* __restrict__ indptr,
                                                                 const int32_t* __restrict__ indices, int n_users,
-                                                                int32_t* __restrict__ per_tile) {
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * 256) >> 6;
-  for (int u = wave; u < n_users; u += n_waves) {
+                                                                int n_tiles, int32_t* __restrict__ per_tile) {
+  __shared__ int32_t s_cnt[LDS ? kPlanLdsTiles : 1];
+  if (LDS) {
+    for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+  }
+  // a workgroup owns a contiguous run of users (the fill kernel must see the same runs)
+  const int per = (n_users + gridDim.x - 1) / gridDim.x;
+  const int u0 = blockIdx.x * per, u1 = min(u0 + per, n_users);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int u = u0 + wave; u < u1; u += 4) {
     const int64_t b = indptr[u], e = indptr[u + 1];
     for (int64_t t = b + lane; t < e; t += NR_WAVE) {
       const int tile = indices[t] >> 5;
-      if (t == b || (indices[t - 1] >> 5) != tile) atomicAdd(&per_tile[tile], 1);
+      if (t == b || (indices[t - 1] >> 5) != tile) atomicAdd(LDS ? &s_cnt[tile] : &per_tile[tile], 1);
     }
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += 256)
+      if (s_cnt[t]) atomicAdd(&per_tile[t], s_cnt[t]);
   }
 }
 
@@ -458,21 +476,45 @@ __global__ __launch_bounds__(1024) void strike_plan_layout_kernel(const int32_t*
   }
 }
 
+template <bool LDS>
 __global__ __launch_bounds__(256) void strike_plan_fill_kernel(const int64_t* __restrict__ indptr,
                                                                const int32_t* __restrict__ indices, int n_users,
-                                                               const int64_t* __restrict__ tile_ptr,
+                                                               int n_tiles, const int64_t* __restrict__ tile_ptr,
                                                                int32_t* __restrict__ cursor,
                                                                int32_t* __restrict__ plan_user,
                                                                uint32_t* __restrict__ plan_mask) {
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * 256) >> 6;
-  for (int u = wave; u < n_users; u += n_waves) {
+  // LDS: pass 1 counts this workgroup's heads per tile, one global atomic per (workgroup, tile) reserves its slots
+  // in the tile (s_base), pass 2 hands them out with LDS atomics
+  __shared__ int32_t s_cnt[LDS ? kPlanLdsTiles : 1];
+  __shared__ int32_t s_base[LDS ? kPlanLdsTiles : 1];
+  const int per = (n_users + gridDim.x - 1) / gridDim.x;
+  const int u0 = blockIdx.x * per, u1 = min(u0 + per, n_users);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (LDS) {
+    for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+    for (int u = u0 + wave; u < u1; u += 4) {
+      const int64_t b = indptr[u], e = indptr[u + 1];
+      for (int64_t t = b + lane; t < e; t += NR_WAVE) {
+        const int tile = indices[t] >> 5;
+        if (t == b || (indices[t - 1] >> 5) != tile) atomicAdd(&s_cnt[tile], 1);
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += 256) {
+      s_base[t] = s_cnt[t] ? atomicAdd(&cursor[t], s_cnt[t]) : 0;
+      s_cnt[t] = 0;
+    }
+    __syncthreads();
+  }
+  for (int u = u0 + wave; u < u1; u += 4) {
     const int64_t b = indptr[u], e = indptr[u + 1];
     for (int64_t t = b + lane; t < e; t += NR_WAVE) {
       const int item = indices[t], tile = item >> 5;
       if (t != b && (indices[t - 1] >> 5) == tile) continue;     // not the head of its pair
       uint32_t m = 1u << (item & 31);
       for (int64_t q = t + 1; q < e && (indices[q] >> 5) == tile; ++q) m |= 1u << (indices[q] & 31);   // <= 31 more
-      const int64_t slot = tile_ptr[tile] + atomicAdd(&cursor[tile], 1);
+      const int64_t slot = tile_ptr[tile] + (LDS ? s_base[tile] + atomicAdd(&s_cnt[tile], 1) : atomicAdd(&cursor[tile], 1));
       plan_user[slot] = u;
       plan_mask[slot] = m;
     }
@@ -669,14 +711,25 @@ int nrhip_tile_strike_plan(const int64_t* d_indptr, const int32_t* d_indices, in
   int32_t* per_tile = (int32_t*)d_ws;
   int32_t* cursor = per_tile + n_tiles;
   NR_CHECK_HIP(hipMemsetAsync(per_tile, 0, (size_t)n_tiles * 4, st));
-  const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)n_users + 3) / 4 + 1, 4096);
-  hipLaunchKernelGGL(strike_plan_count_kernel, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users, per_tile);
+  // both passes cut the users into the same contiguous runs, one per workgroup (two resident per CU)
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n_users + 15) / 16, 512));
+  const bool lds = n_tiles <= kPlanLdsTiles;
+  if (lds)
+    hipLaunchKernelGGL(strike_plan_count_kernel<true>, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users,
+                       n_tiles, per_tile);
+  else
+    hipLaunchKernelGGL(strike_plan_count_kernel<false>, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users,
+                       n_tiles, per_tile);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(strike_plan_layout_kernel, dim3(1), dim3(1024), 0, st, per_tile, n_tiles, d_tile_ptr, cursor,
                      d_chunk_tile, d_chunk_begin, d_counts);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(strike_plan_fill_kernel, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users, d_tile_ptr,
-                     cursor, d_plan_user, d_plan_mask);
+  if (lds)
+    hipLaunchKernelGGL(strike_plan_fill_kernel<true>, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users,
+                       n_tiles, d_tile_ptr, cursor, d_plan_user, d_plan_mask);
+  else
+    hipLaunchKernelGGL(strike_plan_fill_kernel<false>, dim3(blocks), dim3(256), 0, st, d_indptr, d_indices, n_users,
+                       n_tiles, d_tile_ptr, cursor, d_plan_user, d_plan_mask);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
