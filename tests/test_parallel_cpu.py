@@ -273,3 +273,74 @@ def test_column_sharded_step_equals_single_process(tmp_path):
         want.append(train.lightgcn_step(A, A.T.tocsr(), E0, m, v, U, 2, bu, bp, bn, 1e-3, adam))
     np.testing.assert_allclose(r[0]["losses"], np.asarray(want), rtol=1e-12)
     np.testing.assert_allclose(np.concatenate([r[0]["E"], r[1]["E"]], 1), E0, atol=1e-12)
+
+
+def _hop_worker(rank, world, port, out):
+    """The two r05 forms of the row-sharded hop, their algebra on CPU (scipy plays the SpMM kernels): the column-sliced
+    all-gather (`all_gather_rows_start/finish` per slab) and the reduced exchange (item blocks all-gathered, per-rank
+    partials of the item rows through `all_to_all_equal_start/finish`, added in rank order)."""
+    import scipy.sparse as sp
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = parallel.init_from_env(backend="gloo")
+    A, E0, U, I = _graph()
+    A = A.tocsr()
+    d = E0.shape[1]
+    part = parallel.BipartitePartition(U, I, world)
+    bu, bi, b = part.bu, part.bi, part.b
+    (ulo, uhi), (ilo, ihi) = part.users_of(rank), part.items_of(rank)
+
+    def block(table):
+        blk = np.zeros((b, table.shape[1]))
+        blk[:uhi - ulo] = table[ulo:uhi]
+        blk[bu:bu + ihi - ilo] = table[U + ilo:U + ihi]
+        return blk
+    X = np.random.RandomState(3).randn(U + I, d)
+    local = torch.from_numpy(block(X))
+    # this rank's rows of A, columns as positions in the rank-major gathered layout
+    rows = sp.vstack([A[ulo:uhi], sp.csr_matrix((bu - (uhi - ulo), U + I)), A[U + ilo:U + ihi],
+                      sp.csr_matrix((bi - (ihi - ilo), U + I))]).tocoo()
+    pos = part.position(rows.col.astype(np.int64))
+    A_blk = sp.csr_matrix((rows.data, (rows.row, pos)), shape=(b, part.n_pad))
+    # --- column-sliced: slab s + 1 is gathered while slab s is multiplied
+    S, w = 2, d // 2
+    Y = np.zeros((b, d))
+    bufs = [torch.zeros(part.n_pad, w, dtype=torch.float64) for _ in range(2)]
+    toks = [comm.all_gather_rows_start(local[:, :w].contiguous(), bufs[0]), None]
+    for s in range(S):
+        if s + 1 < S:
+            toks[(s + 1) % 2] = comm.all_gather_rows_start(local[:, (s + 1) * w:(s + 2) * w].contiguous(), bufs[(s + 1) % 2])
+        comm.all_gather_rows_finish(toks[s % 2])
+        Y[:, s * w:(s + 1) * w] = A_blk @ bufs[s % 2].numpy()
+    # --- reduced exchange: items all-gathered, item rows as per-rank partials
+    Z = torch.zeros(world * bi, d, dtype=torch.float64)
+    tok = comm.all_gather_rows_start(local[bu:].contiguous(), Z)
+    At = A.T.tocsr()                                          # (A is symmetric here; written for the general case)
+    mine_t = At[ulo:uhi][:, U:].tocoo()                       # my user rows of A^T, item columns: (u, i) = A[i][u]
+    Mp = sp.csr_matrix((mine_t.data, (mine_t.col, mine_t.row)), shape=(world * bi, b))
+    P = torch.from_numpy(Mp @ local.numpy())
+    comm.all_gather_rows_finish(tok)
+    R = torch.zeros(world * bi, d, dtype=torch.float64)
+    tok = comm.all_to_all_equal_start(P.contiguous(), R)
+    mu = A[ulo:uhi][:, U:]                                    # my user rows x every item (id order == gathered order)
+    Mu = sp.hstack([mu, sp.csr_matrix((uhi - ulo, world * bi - I))]).tocsr()
+    Yr = np.zeros((b, d))
+    Yr[:uhi - ulo] = Mu @ Z.numpy()
+    comm.all_to_all_equal_finish(tok)
+    acc = R.view(world, bi, d)[0].clone()
+    for q in range(1, world):
+        acc += R.view(world, bi, d)[q]                        # rank order
+    Yr[bu:] = acc.numpy()
+    want = block(A @ X)
+    np.savez(out % rank, sliced=np.abs(Y - want).max(), reduce=np.abs(Yr - want).max(), calls=str(dict(comm.calls)))
+    comm.barrier()
+    comm.shutdown()
+
+
+def test_row_sharded_hop_forms_two_ranks(tmp_path):
+    out = str(tmp_path / "hop%d.npz")
+    mp.start_processes(_hop_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    for r in range(2):
+        got = np.load(out % r)
+        assert got["sliced"] < 1e-12 and got["reduce"] < 1e-12, (r, got["sliced"], got["reduce"])
+        assert "all_gather_async" in str(got["calls"]) and "all_to_all_equal" in str(got["calls"])
