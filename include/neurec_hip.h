@@ -401,8 +401,11 @@ int nrhip_spmm_csr_masked(const void* plan, const int64_t* d_indptr, const int32
                           void* stream);
 /* Only the listed rows of A·X (+ epilogue) are produced; other rows of the outputs are left
  * untouched.  d_rows may repeat; d_sum_out must not alias d_sum_in.  d in {64,128,256}. */
-/* Persistent lane-group schedule for d = 64 / 128 / 256 (spmm_blocked.hip): one workgroup per CU
- * owns a run of rows (4·d-byte accumulators in LDS), a d/4-lane group walks one row with 16-byte
+/* Persistent lane-group schedule for d = 16 / 32 / 64 (128 / 256 on request) (spmm_blocked.hip): one workgroup per CU
+ * owns a LIST of rows (4·d-byte accumulators in LDS) — since r05 the rows are dealt to the workgroups by cost
+ * (longest first, each to the least-loaded workgroup with a free accumulator), so the balance does not depend on how
+ * the nodes are numbered (contiguous runs — r01-r04, NEUREC_SPMM_DEAL=0 — carried 1.9x the mean cost in their
+ * slowest workgroup when popular items cluster in id); a d/4-lane group walks one row with 16-byte
  * loads, so a load instruction moves 4 / 2 / 1 rows; sub-lists longer than seg_len are cut into segments whose
  * partials are added in segment order.  Optional column blocking (block_bytes) cuts the gathered
  * table into L2-sized windows walked phase by phase.  Same contract and masks as nrhip_spmm_csr /
@@ -421,10 +424,13 @@ int nrhip_spmm_blocked_plan_destroy(void* plan);
 int nrhip_spmm_blocked_plan_info(const void* plan, int* n_workgroups, int* n_phases,
                                  int64_t* n_entries, int64_t* n_split);
 int nrhip_spmm_blocked_tune(int gathers_in_flight);
-/* d = 64 plans also carry the *affinity schedule* of the full pass (cache-blocked by column windows,
- * no phase barriers: csrc/spmm_blocked.hip); it reads a plan-owned (column, value) stream that
- * nrhip_spmm_blocked_pack fills from the matrix's CSR arrays — once per matrix, again if the values
- * change.  Calls that pass those same arrays then run it; results keep the contract of
+/* The plan OWNS a copy of the matrix's (column, value) pairs in its own row order (a workgroup's pairs are one
+ * contiguous slice): nrhip_spmm_blocked_pack fills it from the CSR arrays — once per matrix, again whenever the
+ * values change (NGCF's node dropout rewrites them every step); a product call that hands in arrays that were not
+ * packed packs them first, on its stream.
+ * d = 64 plans built with NEUREC_SPMM_AFFINITY=1 also carry the *affinity schedule* of the full pass (cache-blocked
+ * by column windows, no phase barriers: csrc/spmm_blocked.hip; it keeps contiguous row runs), whose stream the same
+ * call fills.  Calls that pass those same arrays then run it; results keep the contract of
  * nrhip_spmm_csr (rows of <= 64 non-zeros in strict ascending-column order).
  * nrhip_spmm_blocked_affinity: number of column windows in use (0 = base schedule), not a status. */
 int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d_vals, void* stream);
