@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from neurec_amd import engine as E, synth
 from neurec_amd.trainer import FullRankEvaluator
 
-train, test = synth.interactions("gowalla", seed=2018)
+train, test = synth.interactions_around_test(synth.load_test_split(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "gowalla_test_split.npz")), 810128, seed=2018)   # the bench workload
 U, I = train.shape
 rng = np.random.RandomState(0)
 P = torch.from_numpy(synth.xavier_uniform(U, 64, rng)).cuda()

@@ -21,3 +21,6 @@ echo "== config 5 kernel table"
 bash scripts/prof_config5.sh 2>&1 | tail -45 > $OUT/config5_kernels.txt
 f=$(find gpurun_out/config5/p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/config5_kernel_stats.csv
 tail -5 $OUT/config5_kernels.txt
+echo "== evaluation-only kernel table (no torch / rocPRIM kernel may appear between the evaluator's first and last launch)"
+bash scripts/prof_py.sh eval scripts/exp_eval_time.py 2>&1 | tail -30 > $OUT/eval_kernels.txt
+tail -25 $OUT/eval_kernels.txt
