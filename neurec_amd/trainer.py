@@ -585,7 +585,9 @@ class FullRankEvaluator:
         rank the top_k+1 best tiles per user.  Rows whose ranking could depend on ties come back
         flagged and are recomputed from full score rows — same numbers as the materialised path."""
         n = test_users.numel()
-        flags = torch.zeros(n, dtype=torch.int32, device=test_users.device)
+        # (every row's flag is WRITTEN by level 2 — remap_rank_kernel — so no fill: in steady state an evaluation
+        #  launches nothing but this package's kernels; `torch.unique` / the user -> row table below run once per user list)
+        flags = torch.empty(n, dtype=torch.int32, device=test_users.device)
         self.n_flagged = 0
         plan = row_of = None
         use_plan = self.strike_plan
