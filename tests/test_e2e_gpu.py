@@ -127,3 +127,63 @@ def test_lightgcn_gowalla_train_then_evaluate_matches_the_reference_pipeline():
         assert abs(nd["hip/hip"] - nd["cpu32"]) <= max(1e-5, 2.0 * abs(nd["cpu32"] - nd["cpu64"]))
         assert d32 <= max(1e-5, 2.0 * bar)
     assert nd["hip/hip"] > 5e-3                                                # the model learned something to rank
+
+
+def test_bprmf_gowalla_train_then_evaluate_matches_the_reference_pipeline():
+    """BASELINE configs[1] end to end (BPR-MF on gowalla, d = 64, B = 512, conf/MF.properties: lr 0.001, reg 0): 300
+    steps of MF.py:85-113 on the HIP engine — the epoch's batch loop in one native call, one-launch lazy TF-sparse-Adam
+    steps — and on oracle.train.mf_step (fp32, the pinned restatement with TF's all-rows sparse update, and an fp64
+    twin) from the same triplet stream; then MF.predict's scores (MF.py:115-128) through the reference's own C++
+    evaluator for all test users, the HIP tables also through the HIP evaluator."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, MFEngine
+    from oracle import ref, train as O
+    train, test = synth.interactions_around_test(
+        synth.load_test_split(os.path.join(ROOT, "tests", "golden", "gowalla_test_split.npz")), 810128, seed=2018)
+    U, I = train.shape
+    d, B, lr, reg, K = 64, 512, 0.001, 0.0, 300
+    rs = np.random.RandomState(2017)
+    P0 = (rs.randn(U, d) * 0.01).astype(np.float32)
+    Q0 = (rs.randn(I, d) * 0.01).astype(np.float32)
+    trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
+    mf = MFEngine(P0, Q0, lr, reg, B)
+    sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=B, shuffle=True, seed=2018, plan_users=U)
+    mu, mp_, mn, plans = sampler.epoch_stream()
+    n = K * B
+    losses = torch.zeros(K, 2, device="cuda")
+    mf.run_batches(mu[:n], mp_[:n], mn[:n], B, losses, plans[:3 * n])
+    hu, hp, hn = (t[:n].cpu().numpy() for t in (mu, mp_, mn))
+
+    def run(dt):
+        P, Q = P0.astype(dt), Q0.astype(dt)
+        mP, vP, mQ, vQ = (np.zeros(a.shape, dt) for a in (P, P, Q, Q))
+        adam = O.Adam(lr, dtype=dt)
+        out = [O.mf_step(P, Q, mP, vP, mQ, vQ, hu[k * B:(k + 1) * B], hp[k * B:(k + 1) * B], hn[k * B:(k + 1) * B],
+                         reg, adam) for k in range(K)]
+        return np.asarray(out, np.float64), P, Q
+    l32, P32, Q32 = run(np.float32)
+    l64, P64, Q64 = run(np.float64)
+    got_l = losses.cpu().numpy().astype(np.float64).sum(1)
+    gP, gQ = mf.P.cpu().numpy(), mf.Q.cpu().numpy()
+    d32 = max(np.abs(gP - P32).max(), np.abs(gQ - Q32).max())
+    bar = max(np.abs(P32 - P64).max(), np.abs(Q32 - Q64).max())
+    users = np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)
+    ev = FullRankEvaluator(trc, tec, METRICS, TOPK)
+    hip_rows = ev.evaluate_factors(mf.P, mf.Q, torch.from_numpy(users).cuda(), per_user=True)
+    ref_chain, _ = _reference_eval(gP, gQ, train, test, users, chain=True)
+    assert np.array_equal(hip_rows, ref_chain)
+    nd = {}
+    for name, (p, q) in (("hip", (gP, gQ)), ("cpu32", (P32, Q32)), ("cpu64", (P64.astype(np.float32), Q64.astype(np.float32)))):
+        rows, _ = _reference_eval(p, q, train, test, users, chain=False)
+        nd[name] = float(np.mean(rows.astype(np.float64), axis=0)[NDCG10])
+    nd["hip/hip"] = float(np.mean(hip_rows.astype(np.float64), axis=0)[NDCG10])
+    print("config 2 end to end, %d steps (%s evaluator): epoch-loss rel err vs fp32 oracle %.1e; tables max abs diff HIP vs "
+          "fp32 oracle %.2e (oracle fp32-vs-fp64 %.2e); NDCG@10 HIP tables %.8f (HIP evaluator) / %.8f (reference C++, "
+          "np.matmul) | fp32 oracle %.8f | fp64 twin %.8f"
+          % (K, "the reference's own C++" if ref.available() else "the oracle's C++",
+             abs(got_l.sum() - l32.sum()) / abs(l32.sum()), d32, bar, nd["hip/hip"], nd["hip"], nd["cpu32"], nd["cpu64"]))
+    assert abs(got_l.sum() - l32.sum()) <= 1e-5 * abs(l32.sum())                  # MF.py:110: the epoch's logged loss
+    assert d32 <= max(1e-5, 2.0 * bar)
+    assert abs(nd["hip/hip"] - nd["hip"]) <= 1e-5
+    assert abs(nd["hip/hip"] - nd["cpu32"]) <= max(1e-5, 2.0 * abs(nd["cpu32"] - nd["cpu64"]))
