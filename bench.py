@@ -929,6 +929,17 @@ def main():
                 b = next(stream)
                 lg.step(b[0], b[1], b[2], loss_out, grad_sync=grad_sync, plan=b.plan)
 
+    # The host-side setup above (graph, adjacency, schedules: seconds) left the device idle and clocked down; a short
+    # run (the driver's --steps 20 --warmup 5 is 5 ms of device work) would time the clock ramp, not the step: 0.210 ms
+    # per step against 0.199 after 300 warmup steps (profiles/r05_exp_short_window.txt).  Untimed, state-free device
+    # work first — the evaluation's propagation of the tables (scratch buffers only), the same count on every rank.
+    prop = (lg.local if colshard else lg).propagate
+    n_spin = max(2, min(200, int(3e8 / max(int((lg.local if colshard else lg).A.nnz), 1))))
+    t_spin = time.perf_counter()
+    for _ in range(n_spin):
+        prop()
+    torch.cuda.synchronize()
+    spin_ms = (time.perf_counter() - t_spin) * 1e3
     run_steps(args.warmup)
     torch.cuda.synchronize(); comm.barrier()
     epochs_before = sampler.epoch
@@ -939,6 +950,9 @@ def main():
     # what the timed region held: the sampler (+ batch-plan) launch happens once per epoch of
     # len(sampler) steps, so a short run may contain none — said here rather than implied
     timed_region = {"steps": args.steps, "steps_per_epoch": len(sampler),
+                    "device_spin_up_before_warmup": {"propagations": n_spin, "ms": spin_ms,
+                                                     "note": "untimed, state-free (scratch buffers): brings the device to "
+                                                             "its running clocks after seconds of host-side setup"},
                     "sampler_launches": sampler.epoch - epochs_before,
                     "batch_plan_launches": (sampler.epoch - epochs_before) if sampler.plans else
                     ("one per step (sorted inside the step)" if not rowshard else 0)}
