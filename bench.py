@@ -934,7 +934,7 @@ def main():
     # per step against 0.199 after 300 warmup steps (profiles/r05_exp_short_window.txt).  Untimed, state-free device
     # work first — the evaluation's propagation of the tables (scratch buffers only), the same count on every rank.
     prop = (lg.local if colshard else lg).propagate
-    n_spin = max(2, min(200, int(3e8 / max(int((lg.local if colshard else lg).A.nnz), 1))))
+    n_spin = max(2, min(200, int(3e8 / max(2 * int(train_nnz), 1))))     # from the GLOBAL graph: every rank the same count
     t_spin = time.perf_counter()
     for _ in range(n_spin):
         prop()
