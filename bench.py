@@ -961,7 +961,9 @@ def main():
     # SURVEY 8d defines the metric "sampler included" = E / epoch wall time: the per-epoch launches (sampler,
     # batch plans) measured on their own and charged to an epoch of len(sampler) steps at the measured step time
     epoch_ms = _hip_timed(sampler.sample_epoch, 3, 1)
-    steps_per_epoch = len(sampler)
+    # (the same number on every rank: a rank's slice of the stream may hold one batch more or less than another's, and the
+    #  untimed training before the eval leg below runs `f(steps_per_epoch)` steps with collectives inside)
+    steps_per_epoch = int(comm.max_float(float(len(sampler))))
     n_epoch = sampler.n_local if not replicated else sampler.n_local // max(comm.world, 1)
     timed_region["epoch_launch_ms"] = epoch_ms
     epoch_amortised = comm.world * n_epoch / (steps_per_epoch * dt / args.steps + epoch_ms * 1e-3)
