@@ -286,7 +286,22 @@ def init_from_env(backend=None, force=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if not dist.is_initialized():
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "gloo":
+                # gloo's C++ side announces "[Gloo] Rank r is connected to n peer ranks" on STDOUT when the mesh
+                # connects; rank 0's stdout is the bench's one JSON line, so that chatter goes to stderr
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                    dist.barrier()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return Comm(rank, world, local_rank, backend, force=force)
 
 
