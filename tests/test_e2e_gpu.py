@@ -187,3 +187,80 @@ def test_bprmf_gowalla_train_then_evaluate_matches_the_reference_pipeline():
     assert d32 <= max(1e-5, 2.0 * bar)
     assert abs(nd["hip/hip"] - nd["hip"]) <= 1e-5
     assert abs(nd["hip/hip"] - nd["cpu32"]) <= max(1e-5, 2.0 * abs(nd["cpu32"] - nd["cpu64"]))
+
+
+def test_ngcf_gowalla_train_then_evaluate_matches_the_restated_pipeline():
+    """BASELINE configs[4], NGCF half, end to end at the gowalla shape (d = 16, layers [16, 16], B = 512, lr 0.001,
+    mess_dropout 0.1 — conf/NGCF.properties): 40 steps on the HIP engine and on oracle.train (fp32 and fp64; pinned to
+    the reference's NGCF class on the small fixtures — the class itself densifies the 29,858 x 40,981 train matrix,
+    NGCF.py:40, and cannot run at this size), dropout masks carried as data, then the evaluation forward (its own
+    dropout draw, NGCF.py:140-141) and NGCF.predict's scores through the reference's C++ evaluator."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.graph import ngcf_adjacency, transpose_csr
+    from neurec_amd.trainer import FullRankEvaluator, NGCFEngine
+    from oracle import ref, train as O
+    train, test = synth.interactions_around_test(
+        synth.load_test_split(os.path.join(ROOT, "tests", "golden", "gowalla_test_split.npz")), 810128, seed=2018)
+    U, I = train.shape
+    A = ngcf_adjacency(train, "norm")
+    At = transpose_csr(A)
+    rng = np.random.RandomState(2017)
+    d, B, lr, reg, drop, K = 16, 512, 0.001, 0.0, 0.1, 40
+    E0 = synth.xavier_uniform(U + I, d, rng)
+    W = [tuple((rng.randn(*s) * np.sqrt(1.3 * 2 / (s[0] + s[1]))).astype(np.float32)
+               for s in ((d, d), (1, d), (d, d), (1, d))) for _ in range(2)]
+    eng = NGCFEngine(A, At, U, I, E0, W, lr, reg, drop, B)
+    coo = train.tocoo()
+    steps = []
+    for _ in range(K):
+        pick = rng.randint(0, coo.nnz, B)
+        steps.append(((coo.row[pick].astype(np.int32), coo.col[pick].astype(np.int32), rng.randint(0, I, B).astype(np.int32)),
+                      [(rng.rand(U + I, d) < 1 - drop).astype(np.uint8) for _ in W]))
+    eval_masks = [(rng.rand(U + I, d) < 1 - drop).astype(np.uint8) for _ in W]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    loss2 = torch.zeros(2, device="cuda")
+    for (bu, bp, bn), masks in steps:
+        eng.step(dev(bu), dev(bp), dev(bn), loss2, masks=[dev(m) for m in masks])
+    out = eng.forward([dev(m) for m in eval_masks])
+    eu_t, ei_t = out[:U].contiguous(), out[U:].contiguous()
+
+    def run(dt):
+        A_, At_ = A.astype(dt), At.astype(dt)
+        oE = E0.astype(dt)
+        oW = [[w.astype(dt) for w in ws] for ws in W]
+        params = [oE] + [w for ws in oW for w in ws]
+        ms, vs = [np.zeros_like(p) for p in params], [np.zeros_like(p) for p in params]
+        ad = O.Adam(lr, dtype=dt)
+        for (bu, bp, bn), masks in steps:
+            _, dE, wg = O.ngcf_loss_and_grads(A_, At_, oE, [tuple(ws) for ws in oW], [m.astype(dt) for m in masks],
+                                              1 - drop, U, bu, bp, bn, reg)
+            for p, m, v, gg in zip(params, ms, vs, [dE] + [x for gs in wg for x in gs]):
+                ad.dense(p, m, v, gg.reshape(p.shape))
+            ad.advance()
+        o, _ = O.ngcf_forward(A_, oE, [tuple(ws) for ws in oW], [m.astype(dt) for m in eval_masks], 1 - drop)
+        return o.astype(np.float32)
+    o32, o64 = run(np.float32), run(np.float64)
+    users = np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)
+    trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
+    ev = FullRankEvaluator(trc, tec, METRICS, TOPK)
+    hip_rows = ev.evaluate_factors(eu_t, ei_t, torch.from_numpy(users).cuda(), per_user=True)
+    eu, ei = eu_t.cpu().numpy(), ei_t.cpu().numpy()
+    ref_chain, _ = _reference_eval(eu, ei, train, test, users, chain=True)
+    assert np.array_equal(hip_rows, ref_chain)
+    nd = {"hip/hip": float(np.mean(hip_rows.astype(np.float64), axis=0)[NDCG10])}
+    for name, o in (("hip", np.concatenate([eu, ei])), ("cpu32", o32), ("cpu64", o64)):
+        rows, _ = _reference_eval(np.ascontiguousarray(o[:U]), np.ascontiguousarray(o[U:]), train, test, users, chain=False)
+        nd[name] = float(np.mean(rows.astype(np.float64), axis=0)[NDCG10])
+    d32, bar = np.abs(np.concatenate([eu, ei]) - o32).max(), np.abs(o32 - o64).max()
+    print("config 5 (NGCF) end to end, %d steps (%s evaluator): evaluation embeddings max abs diff HIP vs fp32 oracle %.2e "
+          "(oracle fp32-vs-fp64 %.2e); NDCG@10 HIP tables %.8f (HIP evaluator) / %.8f (reference C++, np.matmul) | fp32 "
+          "oracle %.8f | fp64 twin %.8f" % (K, "the reference's own C++" if ref.available() else "the oracle's C++", d32, bar,
+                                            nd["hip/hip"], nd["hip"], nd["cpu32"], nd["cpu64"]))
+    # the embeddings: TF's Adam moves a coordinate whose gradient is at fp32 rounding level by up to a step size whichever
+    # way the rounding falls (tests/test_tfgraph_gpu.py::test_ngcf_config5_three_steps_at_gowalla_size spells this out):
+    # 40 steps of lr = 1e-3 leave a handful of such coordinates a few 1e-5 apart in ANY two fp32 runs — the restatement is
+    # `bar` from its own fp64 twin — so the table bar is 5 x that; what the pipeline PRINTS, NDCG@10, is held to 1e-5
+    assert d32 <= max(1e-5, 5.0 * bar)
+    assert abs(nd["hip/hip"] - nd["hip"]) <= 1e-5
+    assert abs(nd["hip/hip"] - nd["cpu32"]) <= max(1e-5, 2.0 * abs(nd["cpu32"] - nd["cpu64"]))
