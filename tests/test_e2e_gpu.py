@@ -264,3 +264,84 @@ def test_ngcf_gowalla_train_then_evaluate_matches_the_restated_pipeline():
     assert d32 <= max(1e-5, 5.0 * bar)
     assert abs(nd["hip/hip"] - nd["hip"]) <= 1e-5
     assert abs(nd["hip/hip"] - nd["cpu32"]) <= max(1e-5, 2.0 * abs(nd["cpu32"] - nd["cpu64"]))
+
+
+def test_multivae_gowalla_train_then_evaluate_matches_the_restated_pipeline():
+    """BASELINE configs[4], Mult-VAE half, end to end at the gowalla shape (p_dim [16, 32], B = 512, lr 0.001, reg 0,
+    tanh; conf/MultiVAE.properties at the narrow widths): 20 steps on the HIP engine (one native call per step, the
+    decoder without a [B][I] logits buffer) and on oracle.train.multivae_loss_and_grads (fp32 / fp64; pinned to the
+    reference's MultiVAE class, also at I = 40,981: tfgraph_big_multivae.npz), dropout masks and noise as data; then every
+    test user scored on their own history at is_training = 0 (this package's documented default for predict) — logits as
+    inner products of [g1(u) | 1] and [W_p1 | b_p1] — through the reference's C++ evaluator."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.trainer import FullRankEvaluator, MultiVAEEngine
+    from oracle import ref, train as O
+    train, test = synth.interactions_around_test(
+        synth.load_test_split(os.path.join(ROOT, "tests", "golden", "gowalla_test_split.npz")), 810128, seed=2018)
+    train.data[:] = 1.0
+    U, I = train.shape
+    z, h, B, lr, keep, K = 16, 32, 512, 0.001, 0.5, 20
+    rs = np.random.RandomState(2017)
+    s_ = 0.05
+    params = {"Wq0": (rs.randn(I, h) * s_).astype(np.float32), "bq0": (rs.randn(h) * 0.01).astype(np.float32),
+              "Wq1": (rs.randn(h, 2 * z) * s_).astype(np.float32), "bq1": (rs.randn(2 * z) * 0.01).astype(np.float32),
+              "Wp0": (rs.randn(z, h) * s_).astype(np.float32), "bp0": (rs.randn(h) * 0.01).astype(np.float32),
+              "Wp1t": (rs.randn(I, h) * s_).astype(np.float32), "bp1": (rs.randn(I) * 0.01).astype(np.float32)}
+    trc, tec = E.DeviceCSR.from_scipy(train), E.DeviceCSR.from_scipy(test)
+    eng = MultiVAEEngine(trc, I, params, lr, 0.0, "tanh", B)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    steps = []
+    for k in range(K):
+        rows = rs.choice(U, B, replace=False).astype(np.int32)
+        drop_pos = (rs.rand(train.nnz) < keep).astype(np.float32)
+        eps = (rs.randn(B, z) * 0.01).astype(np.float32)
+        steps.append((rows, drop_pos, eps, min(0.2, k / 200.0)))
+    for rows, drop_pos, eps, anneal in steps:
+        eng.step(dev(rows), anneal, keep, drop_given=dev(drop_pos), eps_given=dev(eps), want_loss=False)
+    pf, qf = eng.eval_factors()
+    users = np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)
+    ev = FullRankEvaluator(trc, tec, METRICS, TOPK)
+    hip_rows = ev.evaluate_factors(pf, qf, torch.from_numpy(users).cuda(), per_user=True)
+
+    def run(dt):
+        p = {k: v.astype(dt) for k, v in params.items()}
+        Wq, bq, Wp, bp = [p["Wq0"], p["Wq1"]], [p["bq0"], p["bq1"]], [p["Wp0"], p["Wp1t"].T.copy()], [p["bp0"], p["bp1"]]
+        flat = Wq + bq + Wp + bp
+        ms, vs = [np.zeros_like(x) for x in flat], [np.zeros_like(x) for x in flat]
+        ad = O.Adam(lr, dtype=dt)
+        for rows, drop_pos, eps, anneal in steps:
+            X = np.asarray(train[rows].todense(), dtype=dt)
+            D = np.ones_like(X)
+            for b, u in enumerate(rows):
+                lo, hi = train.indptr[u], train.indptr[u + 1]
+                D[b, train.indices[lo:hi]] = drop_pos[lo:hi]
+            _, (gWq, gbq, gWp, gbp), _ = O.multivae_loss_and_grads(X, Wq, bq, Wp, bp, D, keep, eps.astype(dt), anneal, 0.0, "tanh")
+            for x, m, v, g in zip(flat, ms, vs, list(gWq) + list(gbq) + list(gWp) + list(gbp)):
+                ad.dense(x, m, v, g.astype(dt).reshape(x.shape))
+            ad.advance()
+        # evaluation factors: g1(u) at is_training = 0 for every user, chunk by chunk
+        G1 = np.zeros((U, h), np.float32)
+        for lo in range(0, U, 2048):
+            X = np.asarray(train[lo:lo + 2048].todense(), dtype=dt)
+            _, _, _, cache = O.multivae_forward(X, Wq, bq, Wp, bp, np.ones_like(X), 1.0, np.zeros((X.shape[0], z), dt), 0.0, "tanh")
+            G1[lo:lo + 2048] = cache[-1].astype(np.float32)
+        return (np.concatenate([G1, np.ones((U, 1), np.float32)], 1),
+                np.concatenate([Wp[1].T.astype(np.float32), bp[1].astype(np.float32)[:, None]], 1))
+    f32, f64 = run(np.float32), run(np.float64)
+    gp, gq = pf.cpu().numpy(), qf.cpu().numpy()
+    ref_chain, _ = _reference_eval(gp, gq, train, test, users, chain=True)
+    assert np.array_equal(hip_rows, ref_chain)
+    nd = {"hip/hip": float(np.mean(hip_rows.astype(np.float64), axis=0)[NDCG10])}
+    for name, (p_, q_) in (("hip", (gp, gq)), ("cpu32", f32), ("cpu64", f64)):
+        rows_, _ = _reference_eval(np.ascontiguousarray(p_), np.ascontiguousarray(q_), train, test, users, chain=False)
+        nd[name] = float(np.mean(rows_.astype(np.float64), axis=0)[NDCG10])
+    d32 = max(np.abs(gp - f32[0]).max(), np.abs(gq - f32[1]).max())
+    bar = max(np.abs(f32[0] - f64[0]).max(), np.abs(f32[1] - f64[1]).max())
+    print("config 5 (Mult-VAE) end to end, %d steps (%s evaluator): evaluation factors max abs diff HIP vs fp32 oracle %.2e "
+          "(oracle fp32-vs-fp64 %.2e); NDCG@10 HIP %.8f (HIP evaluator) / %.8f (reference C++, np.matmul) | fp32 oracle %.8f "
+          "| fp64 twin %.8f" % (K, "the reference's own C++" if ref.available() else "the oracle's C++", d32, bar,
+                                nd["hip/hip"], nd["hip"], nd["cpu32"], nd["cpu64"]))
+    assert d32 <= max(1e-5, 5.0 * bar)
+    assert abs(nd["hip/hip"] - nd["hip"]) <= 1e-5
+    assert abs(nd["hip/hip"] - nd["cpu32"]) <= max(1e-5, 2.0 * abs(nd["cpu32"] - nd["cpu64"]))
