@@ -932,12 +932,15 @@ def main():
     # The host-side setup above (graph, adjacency, schedules: seconds) left the device idle and clocked down; a short
     # run (the driver's --steps 20 --warmup 5 is 5 ms of device work) would time the clock ramp, not the step: 0.210 ms
     # per step against 0.199 after 300 warmup steps (profiles/r05_exp_short_window.txt).  Untimed, state-free device
-    # work first — the evaluation's propagation of the tables (scratch buffers only), the same count on every rank.
-    prop = (lg.local if colshard else lg).propagate
-    n_spin = max(2, min(200, int(3e8 / max(2 * int(train_nnz), 1))))     # from the GLOBAL graph: every rank the same count
+    # work first — plain propagation passes into a scratch buffer.
+    # (the PLAIN pass Y = A·X into a scratch layer buffer — the launch the step's full hops are, so the per-kernel
+    #  averages of a rocprofv3 / PMC pass over this command stay those of that launch; no collective inside)
+    eng0 = lg.local if colshard else lg
+    spin = (lambda: eng0.local_pass(0)) if rowshard else (lambda: eng0.A.matmul(eng0.E0, out=eng0.Ea))
+    n_spin = max(2, min(600, int(9e8 / max(2 * int(train_nnz), 1))))
     t_spin = time.perf_counter()
     for _ in range(n_spin):
-        prop()
+        spin()
     torch.cuda.synchronize()
     spin_ms = (time.perf_counter() - t_spin) * 1e3
     run_steps(args.warmup)
@@ -950,7 +953,7 @@ def main():
     # what the timed region held: the sampler (+ batch-plan) launch happens once per epoch of
     # len(sampler) steps, so a short run may contain none — said here rather than implied
     timed_region = {"steps": args.steps, "steps_per_epoch": len(sampler),
-                    "device_spin_up_before_warmup": {"propagations": n_spin, "ms": spin_ms,
+                    "device_spin_up_before_warmup": {"plain_passes": n_spin, "ms": spin_ms,
                                                      "note": "untimed, state-free (scratch buffers): brings the device to "
                                                              "its running clocks after seconds of host-side setup"},
                     "sampler_launches": sampler.epoch - epochs_before,
