@@ -184,6 +184,42 @@ def test_ngcf_other_widths_drop_in(tmp_path, emb, layers, width):
     assert model.get_eval_factors()[0].shape[1] == width
 
 
+@pytest.mark.parametrize("extra,width", [(["--alg_type=gcn", "--learner=rmsprop", "--learning_rate=0.002"], 48),
+                                         (["--alg_type=gcmc", "--learner=adagrad", "--learning_rate=0.05"], 32),
+                                         (["--node_dropout_flag=True", "--node_dropout_ratio=0.2", "--learner=momentum",
+                                           "--learning_rate=0.002"], 48),
+                                         (["--learner=gd", "--learning_rate=0.01"], 48)])
+def test_ngcf_conf_surface_drops_in(tmp_path, extra, width):
+    """r05: conf/NGCF.properties' other settings through the plugin — alg_type gcn / gcmc, node dropout, the other
+    learners of util/learner.py (the shipped width stays on the fused engine for a plain learner change; everything
+    else runs on the width-generic engine): log lines, the loss falls, evaluation lines are printed; gcmc concatenates
+    its dense layers only (NGCF.py:226-248: 2 x 16 columns)."""
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    model = _run(tmp_path, ["--recommender=NGCF", "--epochs=8", "--batch_size=128", "--verbose=4",
+                            "--mess_dropout_ratio=0.0"] + extra)
+    text = _log_text(tmp_path, "NGCF")
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 8 and float(iters[-1][1]) < float(iters[0][1])
+    evals = re.findall(r"epoch (\d+):\t(.+)", text)
+    assert [int(e[0]) for e in evals] == [4, 8]
+    assert ("width-generic NGCF engine" in text) == (extra[0] != "--learner=gd")
+    assert model.get_eval_factors()[0].shape[1] == width
+    if "--node_dropout_flag=True" not in extra:              # (node dropout draws again at evaluation, NGCF.py:140-141)
+        assert evals[-1][1] == _oracle_line(model, model.evaluator)
+
+
+@pytest.mark.parametrize("learner,lr", [("rmsprop", "0.001"), ("momentum", "0.01")])
+def test_multivae_other_learners_drop_in(tmp_path, learner, lr):
+    _write_dataset(str(tmp_path))
+    np.random.seed(2018)
+    _run(tmp_path, ["--recommender=MultiVAE", "--epochs=30", "--batch_size=32", "--learning_rate=" + lr,
+                    "--verbose=30", "--learner=" + learner])
+    text = _log_text(tmp_path, "MultiVAE")
+    iters = re.findall(r"\[iter (\d+) : loss : ([0-9.]+), time: ([0-9.]+)\]", text)
+    assert len(iters) == 30 and float(iters[-1][1]) < float(iters[0][1])
+
+
 def test_multivae_config_drops_in(tmp_path):
     """conf/MultiVAE.properties -> HIP Mult-VAE: log lines, loss falls; `predict` scores each user
     on their own history by default, and with reference_predict_rows=True on the reference's
