@@ -27,6 +27,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs (same guide, section "L2 (per XCD)")
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (same guide); v_mfma_f32_32x32x2_f32
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide; AMD's 2:1-sparse headline figure is not used)
+MFMA_I8_PEAK_TOPS = 5000.0      # dense int8 matrix rate: the guide gives no spec row, "~2x the bf16 rate" (ubench >= 3,944)
 
 
 def parse():
@@ -703,7 +704,8 @@ def compact_line(line):
         "eval_mfma_tflops": _get(line, "eval", "roofline", "achieved"),
         "eval_mfma_frac": _get(line, "eval", "roofline", "frac"),
         "eval_search": _get(line, "eval", "search"),
-        "eval_search_frac_of_sustained_bf16": _get(line, "eval", "roofline", "frac_of_sustained"),
+        "eval_search_frac_of_sustained": _get(line, "eval", "roofline", "frac_of_sustained"),
+        "eval_search_unit": _get(line, "eval", "roofline", "unit"),
         "eval_fp32_loop_ms": _get(line, "eval", "roofline", "fp32_mfma_loop_ms"),
         "eval_fp32_roof_ratio": _get(line, "eval", "fp32_roof_ratio"),
         "eval_search_ms": _get(line, "eval", "roofline", "ms"),
@@ -1157,7 +1159,8 @@ def main():
                      "trained_steps": eval_pretrain_steps + args.warmup + args.steps + 1,
                      "recall@20": float(means[1 * 20 + 19]),
                      "search": getattr(ev, "search_used", None),
-                     "design": ("pruned: tile maxima from a bounded bf16-MFMA filter (no score matrix; three-term bf16 expansion, per-row "
+                     "design": ("pruned: tile maxima from a bounded matrix-core filter (no score matrix; `search` names its arithmetic: "
+                                "int8 = 15-bit fixed point in exact integer accumulators, bf16 = three-term bf16 expansion; per-row "
                                 "error bound; train strikes as a planned fp32 fix-up pass) -> the best 23 32-item tiles per user "
                                 "rescored with the fp32 chain (bucketed by tile, fp32 MFMA) + ranked; each row certified against "
                                 "its bound; tie / uncertified rows redone from full fp32 rows"
@@ -1167,11 +1170,11 @@ def main():
                      "rows_redone_for_ties": getattr(ev, "n_flagged", 0) if args.eval_mode == "pruned" else None}
 
         # SURVEY 8d prices the evaluation against the fp32 matrix peak ("fp32 is mandatory"): every RANKED score is the
-        # fp32 fmaf chain's, but the tile SEARCH runs on the bf16 matrix cores, so the whole evaluation can (and does)
+        # fp32 fmaf chain's, but the tile SEARCH runs on the int8 / bf16 matrix cores, so the whole evaluation can (and does)
         # exceed that roof — said here as a ratio, next to eval_search / eval_rows_redone / eval_fp32_loop_ms
         eval_info["fp32_roof_ratio"] = 2.0 * I * args.dim * len(test_users) / dte / 1e12 / MFMA_F32_PEAK_TFLOPS
         eval_info["fp32_roof_note"] = ("2·I·d flop per user / whole evaluation time / %.1f TFLOP/s fp32-MFMA peak; > 1 is "
-                                       "possible because only the ranked scores are fp32 (certified bf16 search)"
+                                       "possible because only the ranked scores are fp32 (certified reduced-precision search)"
                                        % MFMA_F32_PEAK_TFLOPS)
         # rooflines of the evaluation's two halves, HIP events on the launch stream around the kernels
         # of the first batch (north_star: MFMA for the scoring matmul, HBM GB/s for the top-K)
@@ -1186,7 +1189,7 @@ def main():
             if plan is not None:
                 row_of = torch.full((U,), -1, dtype=torch.int32, device=dev)
                 row_of[ub.long()] = torch.arange(nb, dtype=torch.int32, device=dev)
-            filt = ev._filter if getattr(ev, "search_used", "fp32") == "bf16" else None
+            filt = ev._filter if getattr(ev, "search_used", "fp32") in ("bf16", "int8") else None
             n_keep = min(top_k + 1 + ev.extra_tiles, 63) if filt is not None else top_k + 1
             per = torch.empty((nb, 5 * top_k), dtype=torch.float32, device=dev)
             flg = torch.zeros(nb, dtype=torch.int32, device=dev)
@@ -1235,18 +1238,31 @@ def main():
                 (int(train.indptr[-1]) + int(test.indptr[-1])) * 4
             rescore_flops = 2.0 * nb * n_keep * 32 * d_e
             if filt is not None:
+                i8 = filt.arith == "int8"
+                peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TFLOPS
+                sustained = 3500.0 if i8 else 1300.0
                 eval_info["roofline"] = {
-                    "bound": "mfma", "kernel": "split_rows_kernel + tilemax_bf16_kernel<%d> (bounded filter: three bf16 MFMA "
-                                               "terms per product, fp32 accumulate) + tilemax_fix_kernel<32> (planned "
-                                               "(user, tile) pairs in fp32)" % ((d_e + 15) // 16),
-                    "users": nb, "ms": t_filter * 1e3,
-                    "achieved": 3.0 * flops / t_filter / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": 3.0 * flops / t_filter / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                    "achieved_note": "bf16 flops ISSUED (3 x 2·I·d per user) over the split + filter + fix-up time; back-to-back "
-                                     "v_mfma_f32_32x32x16_bf16 on every CU with random operand bits sustain 1,300 TFLOP/s "
-                                     "(60 clk each at the nominal 2.4 GHz instead of 32; 55 with constant operands; "
-                                     "profiles/r04_exp_mfma_valu_overlap.txt), frac_of_sustained prices against that",
-                    "frac_of_sustained": 3.0 * flops / t_filter / 1e12 / 1300.0,
+                    "bound": "mfma",
+                    "kernel": ("split_rows_i8_kernel + tilemax_i8_kernel<%d> (bounded filter: 15-bit fixed point, three int8 "
+                               "MFMA products per score in exact int32 accumulators, the bound derived from the "
+                               "quantisation) + tilemax_fix_kernel<32> (planned (user, tile) pairs in fp32)"
+                               % ((d_e + 31) // 32) if i8 else
+                               "split_rows_kernel + tilemax_bf16_kernel<%d> (bounded filter: three bf16 MFMA "
+                               "terms per product, fp32 accumulate) + tilemax_fix_kernel<32> (planned "
+                               "(user, tile) pairs in fp32)" % ((d_e + 15) // 16)),
+                    "users": nb, "ms": t_filter * 1e3, "arith": filt.arith,
+                    "achieved": 3.0 * flops / t_filter / 1e12, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
+                    "frac": 3.0 * flops / t_filter / 1e12 / peak,
+                    "achieved_note": ("int8 operations ISSUED (3 x 2·I·d per user) over the split + filter + fix-up time; peak = "
+                                      "2 x the bf16 dense rate (the guide has no int8 spec row; its micro-benchmark ceiling is "
+                                      "3,944); back-to-back v_mfma_i32_32x32x32_i8 on every CU with random operand bits "
+                                      "sustain 3,500 (46 clk each: profiles/r04_exp_mfma_valu_overlap.txt), "
+                                      "frac_of_sustained prices against that" if i8 else
+                                      "bf16 flops ISSUED (3 x 2·I·d per user) over the split + filter + fix-up time; back-to-back "
+                                      "v_mfma_f32_32x32x16_bf16 on every CU with random operand bits sustain 1,300 TFLOP/s "
+                                      "(60 clk each at the nominal 2.4 GHz instead of 32; 55 with constant operands; "
+                                      "profiles/r04_exp_mfma_valu_overlap.txt), frac_of_sustained prices against that"),
+                    "frac_of_sustained": 3.0 * flops / t_filter / 1e12 / sustained,
                     "scores_per_s_as_fp32_tflops": flops / t_filter / 1e12,
                     "fp32_mfma_loop_ms": t_fp32 * 1e3, "fp32_mfma_loop_frac": flops / t_fp32 / 1e12 / MFMA_F32_PEAK_TFLOPS,
                     "flops_per_user": 2.0 * I * d_e, "kappa": filt.kappa, "tiles_rescored_per_user": n_keep,

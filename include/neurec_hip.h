@@ -162,6 +162,20 @@ int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, in
 int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols, int d,
                                float* d_M, int64_t mld, float* d_eps, void* d_ws, size_t ws_bytes, int max_rows,
                                void* stream);
+/* The same bounded filter on the int8 matrix cores (csrc/score_i8.hip; d <= 64): 15-bit fixed point — one scale per
+ * user row, one for the whole item table, two int8 planes per entry, three v_mfma_i32_32x32x32_i8 products in exact
+ * integer accumulators, the tile maximum taken on the integers.  Same outputs and the same contract as
+ * nrhip_score_filter_tilemax: |d_M[r][t] - fp32 chain maximum| <= d_eps[r], the bound DERIVED from the quantisation
+ * (su*sI*[0.52*(sum|qu| + max_i sum|qi|) + 0.27*d + 64*sum|lu|] + the chain's own rounding; top of score_i8.hip) —
+ * no model of the matrix pipe is assumed.  d_eps[r] = NaN for rows (or item tables) whose largest magnitude lies
+ * outside [2^-40, 2^40] or is not finite: every certificate fails for them and the caller's fp32 path takes the row.
+ * It replaces the same reference lines (np.matmul's operand, MF.py:120-122; LightGCN.py:187-189). */
+int nrhip_score_filter_i8_workspace_bytes(int rows, int cols, int d, size_t* bytes);
+int nrhip_score_filter_i8_prepare_items(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws, size_t ws_bytes,
+                                        int max_rows, void* stream);
+int nrhip_score_filter_i8_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols, int d,
+                                  float* d_M, int64_t mld, float* d_eps, void* d_ws, size_t ws_bytes, int max_rows,
+                                  void* stream);
 int nrhip_eval_tiles_workspace_bytes(int rows, int top_k, size_t* bytes);
 /* d_gemm_ws: the workspace nrhip_score_gemm_prepare_items filled (the rescoring reads its k-major
  * item copy, one coalesced 256-byte load per k and tile). */
@@ -189,7 +203,8 @@ int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, 
                              int32_t* d_flag_out, void* d_ws, size_t ws_bytes, void* stream);
 
 /* The pruned evaluation of a whole user list as one call: the batch loop of UniEvaluator.evaluate
- * (evaluator/backend/cpp/uni_evaluator.py:101-157) over nrhip_score_filter_tilemax (use_filter) or nrhip_score_tilemax,
+ * (evaluator/backend/cpp/uni_evaluator.py:101-157) over nrhip_score_filter_tilemax / nrhip_score_filter_i8_tilemax
+ * (use_filter = 1 / 2) or nrhip_score_tilemax,
  * nrhip_score_tilemax_fix and nrhip_eval_tiles_bounded, then (d_sums != NULL) the fp64 column sums of d_out and the
  * number of flagged rows in d_sums[n_metric*top_k] — one device->host copy brings the means and says whether any row
  * must be redone.  Pointers are device pointers except metric_ids (host). */
@@ -204,7 +219,7 @@ typedef struct nrhip_eval_pruned_args {
   const int64_t* d_tile_ptr; const int32_t* d_plan_user; const uint32_t* d_plan_mask;
   const int32_t* d_row_of;                       /* user -> evaluation row (-1: not evaluated) */
   const int32_t* metric_ids; int n_metric, top_k, n_keep;
-  int use_filter, prepare_items;                 /* bf16 bounded search / (re)build the item-side copies first */
+  int use_filter, prepare_items;                 /* bounded search: 0 none, 1 bf16, 2 int8 (d_filter_ws of that form) / (re)build the item-side copies first */
   void* d_gemm_ws; size_t gemm_ws_bytes;         /* nrhip_score_gemm_workspace_bytes(batch_rows, cols, d) */
   void* d_filter_ws; size_t filter_ws_bytes;     /* nrhip_score_filter_workspace_bytes(batch_rows, cols, d) */
   void* d_tiles_ws; size_t tiles_ws_bytes;       /* nrhip_eval_tiles_bounded_workspace_bytes(batch_rows, cols, top_k, n_keep) */

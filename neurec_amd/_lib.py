@@ -148,6 +148,9 @@ SIGNATURES = {
     "nrhip_score_filter_kappa": [i32, p],
     "nrhip_score_filter_prepare_items": [p, i64, i32, i32, p, sz, i32, p],
     "nrhip_score_filter_tilemax": [p, i64, p, i32, i32, i32, p, i64, p, p, sz, i32, p],
+    "nrhip_score_filter_i8_workspace_bytes": [i32, i32, i32, psz],
+    "nrhip_score_filter_i8_prepare_items": [p, i64, i32, i32, p, sz, i32, p],
+    "nrhip_score_filter_i8_tilemax": [p, i64, p, i32, i32, i32, p, i64, p, p, sz, i32, p],
     "nrhip_eval_tiles_workspace_bytes": [i32, i32, psz],
     "nrhip_eval_tiles": [p, i64, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, i32, psz],

@@ -20,7 +20,10 @@ STAMP = os.path.join(OBJ_DIR, "sources.sha256")
 
 SOURCES = ["eval_select.hip", "score_gemm.hip", "sampler.hip", "spmm.hip", "bpr.hip", "adam.hip",
            "step.hip", "dense.hip", "vae.hip", "spmm_blocked.hip", "route.hip", "gemm.hip", "vae_wide.hip", "ngcf_wide.hip", "vae_fused.hip",
-           "score_bf16.hip", "eval_pipeline.hip"]
+           "score_bf16.hip", "score_i8.hip", "eval_pipeline.hip"]
+# per-file flags.  score_i8.hip: MFMA results in the unified VGPR file instead of AGPRs — its epilogue reads every
+# accumulator of two sets per tile, and v_accvgpr_read per element doubled its VALU work (896 -> 78 reads in the loop)
+FILE_FLAGS = {"score_i8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # micro-benchmarks behind the design decisions in DESIGN.md (scripts/exp_*.py): their own library,
 # nothing of it is linked into the product
 EXP_SOURCES = ["experiments/gather_experiments.hip"]
@@ -47,6 +50,7 @@ def _digest():
         h.update(f.read())
     # the flags without the checkout's absolute paths: the same tree digests the same wherever it lies
     h.update(" ".join(f.replace(ROOT, "<root>") for f in FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -66,7 +70,7 @@ def build_extension(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, obj, r
 

@@ -45,11 +45,15 @@ int nrhip_eval_pruned(const NrhipEvalPruned* a, void* stream) {
   NR_REQUIRE(a->d_users && a->d_tile_ptr && a->d_row_of, NR_ERR_ARG,
              "eval_pruned: the user list, the strike plan and the user -> row table are part of this form");
   NR_REQUIRE(!a->use_filter || (a->d_filter_ws && a->d_eps), NR_ERR_ARG, "eval_pruned: the filter needs its workspace");
+  NR_REQUIRE(a->use_filter >= 0 && a->use_filter <= 2, NR_ERR_ARG, "eval_pruned: use_filter is 0 (exact maxima), 1 (bf16) or 2 (int8)");
   NR_REQUIRE(a->use_filter || a->n_keep == a->top_k + 1, NR_ERR_ARG,
              "eval_pruned: exact maxima take n_keep = top_k + 1");
   if (a->prepare_items) {
     NR_TRY(nrhip_score_gemm_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_gemm_ws, a->gemm_ws_bytes, stream));
-    if (a->use_filter)
+    if (a->use_filter == 2)
+      NR_TRY(nrhip_score_filter_i8_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_filter_ws, a->filter_ws_bytes,
+                                                 a->batch_rows, stream));
+    else if (a->use_filter)
       NR_TRY(nrhip_score_filter_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_filter_ws, a->filter_ws_bytes,
                                               a->batch_rows, stream));
   }
@@ -58,7 +62,10 @@ int nrhip_eval_pruned(const NrhipEvalPruned* a, void* stream) {
     const int rows = a->n_users - b < a->batch_rows ? a->n_users - b : a->batch_rows;
     const int32_t* users = a->d_users + b;
     const float* P = a->d_P;
-    if (a->use_filter)
+    if (a->use_filter == 2)
+      NR_TRY(nrhip_score_filter_i8_tilemax(P, a->ldp, users, rows, a->cols, a->d, a->d_M, a->mld, a->d_eps,
+                                           a->d_filter_ws, a->filter_ws_bytes, a->batch_rows, stream));
+    else if (a->use_filter)
       NR_TRY(nrhip_score_filter_tilemax(P, a->ldp, users, rows, a->cols, a->d, a->d_M, a->mld, a->d_eps,
                                         a->d_filter_ws, a->filter_ws_bytes, a->batch_rows, stream));
     else

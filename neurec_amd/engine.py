@@ -262,24 +262,34 @@ class ScoreGemm:
 
 
 class ScoreFilter:
-    """Level 1 of the pruned evaluation as a bounded filter on the bf16 matrix cores (csrc/score_bf16.hip): tile
-    maxima over a three-term bf16 expansion of the fp32 products, each within eps[row] of the fp32 chain's value.
-    Nothing here is ranked: nrhip_eval_tiles_bounded rescores the chosen tiles with the fp32 chain and accepts a row
-    only if its bound certifies the choice.  Built for d <= 128 (`ScoreFilter.supports`)."""
+    """Level 1 of the pruned evaluation as a bounded filter on the matrix cores: tile maxima, each within eps[row]
+    of the fp32 chain's value.  arith="bf16" (csrc/score_bf16.hip, d <= 128): a three-term bf16 expansion of the fp32
+    products; arith="int8" (csrc/score_i8.hip, d <= 64): 15-bit fixed point in exact integer accumulators, the bound
+    derived from the quantisation (eps = NaN for rows it cannot bound).  Nothing here is ranked:
+    nrhip_eval_tiles_bounded rescores the chosen tiles with the fp32 chain and accepts a row only if its bound
+    certifies the choice."""
+
+    ARITH = {"bf16": ("nrhip_score_filter_", 128, 1), "int8": ("nrhip_score_filter_i8_", 64, 2)}
 
     @staticmethod
-    def supports(d):
-        return int(d) <= 128
+    def supports(d, arith="bf16"):
+        return int(d) <= ScoreFilter.ARITH[arith][1]
 
-    def __init__(self, item_table, max_rows):
+    def __init__(self, item_table, max_rows, arith="bf16"):
+        if arith not in self.ARITH:
+            raise ValueError("arith must be one of %s, got %r" % (sorted(self.ARITH), arith))
+        self.arith = arith
+        self._prefix, _, self.use_filter = self.ARITH[arith]      # use_filter: nrhip_eval_pruned's selector
         self.cols, self.d = item_table.shape
         self.max_rows = int(max_rows)
         nbytes = C.c_size_t(0)
-        call("nrhip_score_filter_workspace_bytes", self.max_rows, self.cols, self.d, C.byref(nbytes))
+        call(self._prefix + "workspace_bytes", self.max_rows, self.cols, self.d, C.byref(nbytes))
         self.ws = torch.empty(nbytes.value, dtype=torch.uint8, device=item_table.device)
-        k = C.c_float(0)
-        call("nrhip_score_filter_kappa", self.d, C.byref(k))
-        self.kappa = float(k.value)
+        self.kappa = None
+        if arith == "bf16":
+            k = C.c_float(0)
+            call("nrhip_score_filter_kappa", self.d, C.byref(k))
+            self.kappa = float(k.value)
         self.prepare(item_table)
 
     def prepare(self, item_table):
@@ -287,7 +297,7 @@ class ScoreFilter:
             raise ValueError("item table %s, prepared for %s" % (tuple(item_table.shape), (self.cols, self.d)))
         if item_table.stride(1) != 1:
             item_table = item_table.contiguous()
-        call("nrhip_score_filter_prepare_items", C.c_void_p(item_table.data_ptr()), item_table.stride(0), self.cols,
+        call(self._prefix + "prepare_items", C.c_void_p(item_table.data_ptr()), item_table.stride(0), self.cols,
              self.d, _ptr(self.ws), self.ws.numel(), self.max_rows, _stream())
 
     def tile_maxima(self, user_table, users, out=None, eps=None):
@@ -302,7 +312,7 @@ class ScoreFilter:
             out = torch.empty((rows, mld), dtype=torch.float32, device=self.ws.device)
         if eps is None:
             eps = torch.empty(rows, dtype=torch.float32, device=self.ws.device)
-        call("nrhip_score_filter_tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
+        call(self._prefix + "tilemax", _ptr(user_table, torch.float32), user_table.stride(0),
              _ptr(users, torch.int32, allow_none=True), rows, self.cols, self.d, _ptr(out, torch.float32),
              out.stride(0), _ptr(eps, torch.float32), _ptr(self.ws), self.ws.numel(), self.max_rows, _stream())
         return out[:rows], eps[:rows]
@@ -465,7 +475,7 @@ class PrunedEvaluation:
         a.chunk_tile, a.chunk_begin, a.n_chunks = ptr(pl.chunk_tile), ptr(pl.chunk_begin), pl.n_chunks
         a.tile_ptr, a.plan_user, a.plan_mask, a.row_of = ptr(pl.tile_ptr), ptr(pl.user), ptr(pl.mask), ptr(row_of)
         a.metric_ids, a.n_metric, a.top_k, a.n_keep = self.ids, self.nm, self.top_k, self.n_keep
-        a.use_filter, a.prepare_items = (1 if f is not None else 0), (1 if prepare_items else 0)
+        a.use_filter, a.prepare_items = (f.use_filter if f is not None else 0), (1 if prepare_items else 0)
         a.gemm_ws, a.gemm_ws_bytes = ptr(g.ws), g.ws.numel()
         a.filter_ws, a.filter_ws_bytes = (ptr(f.ws), f.ws.numel()) if f is not None else (None, 0)
         a.tiles_ws, a.tiles_ws_bytes = ptr(self.tiles_ws), self.tiles_ws.numel()

@@ -485,12 +485,15 @@ class FullRankEvaluator:
 
     def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True,
                  pruned=True, strike_plan=True, search=None, extra_tiles=2):
-        # how the pruned path FINDS the tiles it rescores: "bf16" = the bounded filter on the bf16 matrix cores
-        # (csrc/score_bf16.hip; every row certified against its error bound or redone from fp32 rows), "fp32" = the
-        # fp32 MFMA loop (exact maxima).  The ranked scores are the fp32 chain's either way.  NEUREC_EVAL_SEARCH overrides.
-        self.search = str(search or os.environ.get("NEUREC_EVAL_SEARCH", "bf16"))
-        if self.search not in ("bf16", "fp32"):
-            raise ValueError("search must be 'bf16' or 'fp32', got %r" % (self.search,))
+        # how the pruned path FINDS the tiles it rescores: "int8" (the default; tables of <= 64 columns, wider ones take
+        # "bf16") = the bounded filter on the int8 matrix cores (csrc/score_i8.hip: 15-bit fixed point, exact integer
+        # accumulators, the bound derived from the quantisation), "bf16" = the same on the bf16 matrix cores
+        # (csrc/score_bf16.hip, d <= 128) — either way every row is certified against its error bound or redone from
+        # fp32 rows — and "fp32" = the fp32 MFMA loop (exact maxima).  The ranked scores are the fp32 chain's in all
+        # three.  NEUREC_EVAL_SEARCH overrides the default.
+        self.search = str(search or os.environ.get("NEUREC_EVAL_SEARCH", "int8"))
+        if self.search not in ("bf16", "int8", "fp32"):
+            raise ValueError("search must be 'bf16', 'int8' or 'fp32', got %r" % (self.search,))
         self.extra_tiles = int(extra_tiles)  # bounded search: tiles rescored beyond top_k + 1 (room for the bound)
         self._filter = None
         self.native_loop = os.environ.get("NEUREC_EVAL_NATIVE_LOOP", "1") != "0"   # nrhip_eval_pruned (0: the Python batch loop)
@@ -612,13 +615,16 @@ class FullRankEvaluator:
             row_of = self._row_of
         filt = None
         n_keep = min(self.top_k + 1 + self.extra_tiles, 63, 2 * ((item_table.shape[0] + 63) // 64) - 1)
-        if self.search == "bf16" and use_plan and E.ScoreFilter.supports(item_table.shape[1]) and n_keep > self.top_k:
-            if self._filter is None:
-                self._filter = E.ScoreFilter(item_table, self.batch_rows)
+        arith = self.search
+        if arith == "int8" and not E.ScoreFilter.supports(item_table.shape[1], "int8"):
+            arith = "bf16"                                    # the int8 form is built for d <= 64
+        if arith != "fp32" and use_plan and E.ScoreFilter.supports(item_table.shape[1], arith) and n_keep > self.top_k:
+            if self._filter is None or self._filter.arith != arith:
+                self._filter = E.ScoreFilter(item_table, self.batch_rows, arith)
             else:
                 self._filter.prepare(item_table)
             filt = self._filter
-        self.search_used = "bf16" if filt is not None else "fp32"
+        self.search_used = filt.arith if filt is not None else "fp32"
         if use_plan and self.native_loop:
             # the whole batch loop, the column sums and the flagged-row count in one native call (nrhip_eval_pruned)
             keep = n_keep if filt is not None else self.top_k + 1

@@ -1,0 +1,181 @@
+"""csrc/score_i8.hip: the bounded search on the int8 matrix cores (d <= 64).  Same contract as the bf16 filter: its
+tile maxima are never ranked, every one carries a bound on its distance from the fp32 chain's value, and
+FullRankEvaluator(search="int8") returns exactly the rows the fp32 search and the materialised path return
+(evaluator/backend/cpp/src/evaluate.h:23-50 stays the definition; MF.py:120-122 the scores)."""
+import numpy as np
+import pytest
+
+from test_eval_gpu import _spread_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixed_point_bound(P, Q, d):
+    """score_i8.hip's derivation restated in float64 numpy: the quantisation part of eps (without the chain's own
+    rounding term), from the same integers the split kernel forms."""
+    aI = np.abs(Q).max()
+    sI = np.float32(aI) / np.float32(16256)
+    qi = np.clip(np.rint((Q * (np.float32(16256) / np.float32(aI))).astype(np.float32)), -16256, 16256)
+    au = np.abs(P).max(1)
+    su = (au / np.float32(16256)).astype(np.float32)
+    qu = np.clip(np.rint((P * (np.float32(16256) / au)[:, None]).astype(np.float32)), -16256, 16256)
+    lu = qu - 128 * np.floor((qu + 64) / 128)
+    return su.astype(np.float64) * float(sI) * (0.52 * (np.abs(qu).sum(1) + np.abs(qi).sum(1).max()) + 0.27 * d +
+                                                 64 * np.abs(lu).sum(1))
+
+
+@pytest.mark.parametrize("d", [8, 16, 24, 32, 48, 50, 64])
+@pytest.mark.parametrize("kind", [0.01, 1.0, 300.0, "wide", "cancel", "norm-spread"])
+def test_int8_filter_stays_within_its_derived_bound(d, kind):
+    """Every approximate tile maximum lies within eps[row] of the fp32 chain's maximum (nrhip_score_tilemax without
+    train lists: exact), for gaussians at three scales, exponents spread over 26 binades, heavy cancellation and norms
+    spread over 20 binades.  The integer accumulators are exact, so the bound is the derivation itself (no safety
+    factor over a measured model): the test holds errors to <= 1.0 of it, and the bound to what the derivation gives."""
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(d * 7 + (11 + len(kind) if isinstance(kind, str) else int(kind * 100)))
+    U, I = 333, 4133
+    P, Q = _spread_tables(rng, U, I, d, kind)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    users_h = rng.permutation(U)[:300].astype(np.int32)
+    users = torch.from_numpy(users_h).cuda()
+    gemm, filt = E.ScoreGemm(Qd, 512), E.ScoreFilter(Qd, 512, "int8")
+    n_t = 2 * ((I + 63) // 64)
+    mld = (n_t + 3) // 4 * 4
+    exact = torch.empty((300, mld), dtype=torch.float32, device="cuda")
+    E.call("nrhip_score_tilemax", E._ptr(Pd), Pd.stride(0), E._ptr(users), 300, I, d, None, None, E._ptr(exact),
+           exact.stride(0), E._ptr(gemm.ws), gemm.ws.numel(), E._stream())
+    M, eps = filt.tile_maxima(Pd, users)
+    a, b, e = exact.cpu().numpy()[:, :n_t], M.cpu().numpy()[:, :n_t], eps.cpu().numpy().astype(np.float64)
+    assert np.array_equal(np.isneginf(a), np.isneginf(b))
+    assert np.isneginf(a[:, (I + 31) // 32:]).all() and np.isfinite(a[:, :(I + 31) // 32]).all()
+    assert np.isfinite(e).all()
+    fin = np.isfinite(a)
+    err = np.where(fin, np.abs(np.where(fin, a, 0).astype(np.float64) - np.where(fin, b, 0)), 0.0)
+    assert (err <= e[:, None]).all(), "worst error / bound = %.3f" % (err / e[:, None]).max()
+    # the bound is the one the header derives: quantisation part + 1.5 d 2^-24 ||u|| max||i|| (+ the absolute term)
+    un = np.linalg.norm(P[users_h].astype(np.float64), axis=1)
+    imax = np.linalg.norm(Q.astype(np.float64), axis=1).max()
+    want = _fixed_point_bound(P[users_h], Q, d) + 1.5 * d * 2.0 ** -24 * un * imax
+    ab = 2.0 ** -110 * d * (1.0 + un + imax)
+    assert (e >= want * (1 - 1e-5)).all() and (e <= (want + ab) * (1 + 1e-5) + 1e-44).all()
+    # and it is a useful one: a small multiple of the bf16 form's (4-6x measured)
+    kappa = E.ScoreFilter(Qd, 512).kappa
+    assert (e <= 12.0 * kappa * un * imax + ab).all()
+
+
+@pytest.mark.parametrize("kind", ["tiny", "underflow-edge", "nan-user", "inf-item", "zero-user"])
+def test_int8_filter_refuses_to_bound_what_fixed_point_cannot_hold(kind):
+    """Magnitudes outside 2^-40 .. 2^40 and non-finite entries: eps = NaN (every certificate fails, the caller's fp32
+    path ranks the row); rows of zeros are exact with a bound of (almost) zero."""
+    import torch
+    from neurec_amd import engine as E
+    rng = np.random.RandomState(17)
+    U, I, d = 70, 1000, 32
+    if kind in ("tiny", "underflow-edge"):
+        P, Q = _spread_tables(rng, U, I, d, kind)
+    else:
+        P, Q = (rng.randn(U, d) * 0.1).astype(np.float32), (rng.randn(I, d) * 0.1).astype(np.float32)
+    if kind == "nan-user":
+        P[3, 5] = np.nan
+        P[9, 0] = np.inf
+    if kind == "inf-item":
+        Q[77, 1] = np.inf
+    if kind == "zero-user":
+        P[4] = 0.0
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    M, eps = E.ScoreFilter(Qd, 128, "int8").tile_maxima(Pd, None)
+    e, m = eps.cpu().numpy(), M.cpu().numpy()
+    if kind in ("tiny", "underflow-edge", "inf-item"):
+        assert np.isnan(e).all()
+    elif kind == "nan-user":
+        assert np.isnan(e[[3, 9]]).all() and np.isfinite(np.delete(e, [3, 9])).all()
+    else:
+        assert np.isfinite(e).all() and e[4] < 1e-30
+        assert (m[4, :(I + 31) // 32] == 0.0).all()
+    assert not np.isnan(m[:, :(I + 31) // 32]).any()
+
+
+@pytest.mark.parametrize("d,clustered,extra", [(64, False, 2), (50, False, 0), (16, True, 2), (32, True, 1), (8, False, 2),
+                                               (64, "tiny", 2), (48, "underflow-edge", 2)])
+def test_int8_search_ranks_exactly_what_the_fp32_search_ranks(d, clustered, extra):
+    """FullRankEvaluator(search='int8') == search='fp32' == the materialised path, per-user metric rows bit for bit;
+    near-duplicate items (the certificate fails) and magnitudes the fixed point cannot hold (eps = NaN) take the fp32
+    path and come out the same."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(d + 5)
+    U, I = 600, 6000
+    P = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.1).astype(np.float32)
+    if isinstance(clustered, str):
+        P, Q = _spread_tables(rng, U, I, d, clustered)
+    elif clustered:
+        base = Q[:60].copy()
+        for c in range(100):
+            Q[c * 60:(c + 1) * 60] = base * (1.0 + rng.randn(60, 1).astype(np.float32) * 1e-7)
+        Q = Q[rng.permutation(I)]
+    tr = sp.random(U, I, 0.01, random_state=1, format="lil", dtype=np.float32)
+    for u in range(0, U, 3):
+        tr[u, np.argsort(-(P[u] @ Q.T))[:rng.randint(1, 30)]] = 1.0
+    tr = tr.tocsr(); tr.data[:] = 1.0; tr.sort_indices()
+    te = sp.random(U, I, 0.004, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    users = np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    ud = torch.from_numpy(users).cuda()
+    full = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, pruned=False)
+    exact = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, search="fp32")
+    fast = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=256, search="int8", extra_tiles=extra)
+    a = full.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    b = exact.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    c = fast.evaluate_factors(Pd, Qd, ud, exact_mean=True)
+    assert exact.search_used == "fp32" and fast.search_used == "int8"
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    if isinstance(clustered, str):
+        assert fast.n_flagged == len(users)                  # nothing is certified on a NaN bound
+    elif clustered:
+        assert fast.n_flagged > 0
+    else:
+        assert fast.n_flagged <= len(users) // 20
+    np.testing.assert_array_equal(exact.evaluate_factors(Pd, Qd, ud), fast.evaluate_factors(Pd, Qd, ud))
+
+
+def test_int8_search_native_loop_python_loop_and_width_fallback():
+    """The one-call batch loop (nrhip_eval_pruned, use_filter = 2) equals the Python batch loop; beyond 64 columns the
+    int8 request takes the bf16 filter (built up to 128); the int8 entry points refuse d > 64 by name."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(9)
+    U, I, d = 500, 5000, 64
+    P, Q = (rng.randn(U, d) * 0.1).astype(np.float32), (rng.randn(I, d) * 0.1).astype(np.float32)
+    tr = sp.random(U, I, 0.01, random_state=1, format="csr", dtype=np.float32); tr.data[:] = 1.0
+    te = sp.random(U, I, 0.005, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr); te.eliminate_zeros(); te.sort_indices()
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    users = torch.from_numpy(np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)).cuda()
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    a = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, search="int8")
+    b = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, search="int8")
+    a.native_loop, b.native_loop = True, False
+    ref = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, pruned=False)
+    ra = a.evaluate_factors(Pd, Qd, users, per_user=True)
+    rb = b.evaluate_factors(Pd, Qd, users, per_user=True)
+    rr = ref.evaluate_factors(Pd, Qd, users, per_user=True)
+    assert a.search_used == "int8" and b.search_used == "int8"
+    np.testing.assert_array_equal(np.asarray(ra), np.asarray(rb))
+    np.testing.assert_array_equal(np.asarray(ra), np.asarray(rr))
+    # wider tables: the request falls to the bf16 form
+    P2, Q2 = (rng.randn(U, 96) * 0.1).astype(np.float32), (rng.randn(I, 96) * 0.1).astype(np.float32)
+    w = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=128, search="int8")
+    w.evaluate_factors(torch.from_numpy(P2).cuda(), torch.from_numpy(Q2).cuda(), users)
+    assert w.search_used == "bf16"
+    assert E.ScoreFilter.supports(64, "int8") and not E.ScoreFilter.supports(65, "int8")
+    with pytest.raises(NotImplementedError):
+        E.ScoreFilter(torch.zeros((I, 96), device="cuda"), 64, "int8")
