@@ -1122,7 +1122,8 @@ def main():
             mf_ev.evaluate_factors(mf.P, mf.Q, tu)
             mf_edt, mm = _median_wall(lambda: mf_ev.evaluate_factors(mf.P, mf.Q, tu))
             mf_info["eval"] = {"users_per_sec": tu.numel() / mf_edt, "ms": mf_edt * 1e3, "n_users": int(tu.numel()),
-                               "ndcg@10": float(mm[2 * 20 + 9])}
+                               "ndcg@10": float(mm[2 * 20 + 9]), "search": getattr(mf_ev, "search_used", None),
+                               "rows_redone": int(getattr(mf_ev, "n_flagged", 0))}
             del mf_ev
 
     # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)

@@ -164,12 +164,15 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
                                void* stream);
 /* The same bounded filter on the int8 matrix cores (csrc/score_i8.hip; d <= 64): 15-bit fixed point — one scale per
  * user row, one for the whole item table, two int8 planes per entry, three v_mfma_i32_32x32x32_i8 products in exact
- * integer accumulators, the tile maximum taken on the integers.  Same outputs and the same contract as
- * nrhip_score_filter_tilemax: |d_M[r][t] - fp32 chain maximum| <= d_eps[r], the bound DERIVED from the quantisation
- * (su*sI*[0.52*(sum|qu| + max_i sum|qi|) + 0.27*d + 64*sum|lu|] + the chain's own rounding; top of score_i8.hip) —
- * no model of the matrix pipe is assumed.  d_eps[r] = NaN for rows (or item tables) whose largest magnitude lies
- * outside [2^-40, 2^40] or is not finite: every certificate fails for them and the caller's fp32 path takes the row.
- * It replaces the same reference lines (np.matmul's operand, MF.py:120-122; LightGCN.py:187-189). */
+ * integer accumulators, the tile maximum taken on the integers.  Same outputs as nrhip_score_filter_tilemax, with a
+ * ONE-SIDED contract (what nrhip_eval_tiles_bounded's certificate needs): d_M[r][t] is an upper-bound maximum — the
+ * approximate maximum plus the tile's own share of the quantisation error, 0.525*su*sI*max_{i in t} sum|qi| — and
+ * fp32 chain maximum of tile t <= d_M[r][t] + d_eps[r],   d_M[r][t] - that maximum <= d_eps[r] + 2 x the tile's share,
+ * with d_eps[r] = su*sI*[0.525*sum|qu| + 0.27*d + 64*sum|lu|] + the chain's own rounding, DERIVED from the
+ * quantisation (top of score_i8.hip) — no model of the matrix pipe is assumed.  d_eps[r] = NaN for rows (or item
+ * tables) whose largest magnitude lies outside [2^-40, 2^40] or is not finite: every certificate fails for them and
+ * the caller's fp32 path takes the row.  It replaces the same reference lines (np.matmul's operand, MF.py:120-122;
+ * LightGCN.py:187-189). */
 int nrhip_score_filter_i8_workspace_bytes(int rows, int cols, int d, size_t* bytes);
 int nrhip_score_filter_i8_prepare_items(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws, size_t ws_bytes,
                                         int max_rows, void* stream);

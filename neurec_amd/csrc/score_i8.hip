@@ -12,16 +12,21 @@
 //     i_k = sI (qi_k + di_k),  sI = max over the WHOLE item table / 16256                           (one scale for all items)
 //     q = 128 h + l,  h in [-127, 127],  l in [-64, 63]        (two int8 planes)
 //     approx(u, i) = su sI 128 · V,   V = 128 Σ hu hi + Σ (hu li + lu hi)      (three int8 products; Σ lu li dropped)
-// One item scale, because eps[u] has to hold for the worst item anyway and then the maximum over a tile's items can be
-// taken on the INTEGERS V (v_max3_i32 on the accumulators) with one conversion and one multiply per stored maximum.
-// The integer matrix pipe is exact, so the bound is derived, not measured:
+// One item scale, so that the maximum over a tile's items can be taken on the INTEGERS V (v_max3_i32 on the
+// accumulators) with one conversion and one fused multiply-add per stored maximum.
+// The integer matrix pipe is exact, so the bound is derived, not measured.  For user u and item i
 //     |approx - exact dot| <= su sI [ 0.503 Σ|qu| + 0.503 Σ|qi| + 0.2531 d + 64 Σ|lu| ] + 3·2^-24 |approx|
-//                          <= su sI [ 0.52 (Qu1 + max_i Qi1) + 0.27 d + 64 Lu1 ]
 //       (|du|, |di| <= 0.5 + 16256·3·2^-24: the quotient is formed as x · fl(16256 / max);  |lu li| <= 64 |lu|;
 //        Qu1 = Σ|qu|, Lu1 = Σ|lu|, Qi1 = Σ|qi| are integers formed while splitting; the int -> float conversion of V,
-//        the rounding of su sI and of the final product are the 3·2^-24 and sit inside the 0.52)
+//        the rounding of su sI and of the final product are the 3·2^-24)
 //     |exact dot - fp32 chain| <= 1.5 · d · 2^-24 · ||u||₂ · max_i ||i||₂        (the chain's own rounding, as score_bf16)
-//     plus score_bf16's absolute term for products below 2^-126.
+// and the item-dependent part goes INTO the stored maximum, per 32-item tile (item norms are heavy-tailed: the
+// table-wide max of Qi1 is 4-5 x a typical tile's, and the tiles that decide a certificate are the unpopular ones):
+//     M[u][t]  = su sI 128 · max_{i in t} V(u, i)  +  0.525 su sI · max_{i in t} Qi1(i)       an UPPER-bound maximum
+//     eps[u]   = su sI [ 0.525 Qu1 + 0.27 d + 64 Lu1 ] + 1.5 d 2^-24 ||u|| max||i|| + score_bf16's absolute term
+//     =>  fp32 chain(u, i) <= M[u][t] + eps[u] for every item i of tile t        (what the certificate needs), and
+//         M[u][t] - (chain's tile maximum) <= eps[u] + 1.05 su sI max_{i in t} Qi1(i)         (how loose it can be)
+//     (0.525 - 0.503 covers the three float roundings of M.)
 // Rows (or an item table) whose largest magnitude is outside [2^-40, 2^40], or not finite, get eps = NaN: the
 // certificate fails and they take the fp32 path, as rows with ties do.
 //
@@ -42,9 +47,8 @@ typedef __attribute__((ext_vector_type(16))) int i32x16;
 constexpr int kQMax = 16256;                                  // 127 · 128
 constexpr uint32_t kBitsLo = 0x2B800000u;                     // 2^-40
 constexpr uint32_t kBitsHi = 0x53800000u;                     // 2^40
-// scalars of an item table (uint32 slots of the workspace): [0] bits of max |entry|, [1] max_i Σ_k |qi_k|,
-// [2] bits of max_i ||i||₂
-constexpr int kScAmax = 0, kScQ1 = 1, kScNorm = 2;
+// scalars of an item table (uint32 slots of the workspace): [0] bits of max |entry|, [2] bits of max_i ||i||₂
+constexpr int kScAmax = 0, kScNorm = 2;
 
 // max |entry| of a table as float bits (NaN / inf sort above every finite value).  flat != 0: the rows lie back to
 // back (ld == d) on a 16-byte boundary and n·d is a multiple of 4 — one float4 per thread and step, no index arithmetic.
@@ -83,12 +87,14 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
 __device__ __forceinline__ bool scale_bad(uint32_t bits) { return bits != 0u && (bits < kBitsLo || bits > kBitsHi); }
 
 // dst[((b·2 + plane)·KS + s)·64 + lane] = the 16 int8 of row 32·b + (lane & 31), k = 32·s + 16·(lane >> 5) .. +15.
-// items (sc_items == nullptr is not allowed; is_items != 0): the scale is the table's (sc[kScAmax], formed before);
-//   sc[kScQ1], sc[kScNorm] take the row maxima.
-// users: per-row scale; cu[r] = su·sI·128 (0 for rows that cannot be bounded), eps[r] = the bound (NaN for those).
+// items (is_items != 0): the scale is the table's (sc[kScAmax], formed before); qblk[b] = max over the block's rows of
+//   Σ_k |q_k| (as a float: an integer below 2^21), sc[kScNorm] takes the largest row norm.
+// users: per-row scale; cu[2r] = su·sI·128, cu[2r + 1] = 0.525·su·sI rounded up (both 0 for rows that cannot be
+//   bounded), eps[r] = the user-side bound (NaN for those).
 __global__ void split_rows_i8_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ ids, int n,
                                      int d, int ks32, uint4* __restrict__ dst, uint32_t* __restrict__ sc,
-                                     float* __restrict__ cu, float* __restrict__ eps, int is_items) {
+                                     float* __restrict__ qblk, float* __restrict__ cu, float* __restrict__ eps,
+                                     int is_items) {
   __shared__ uint32_t s_max[2][64];
   __shared__ int s_q1[2][64], s_l1[2][64];
   __shared__ float s_sq[2][64];
@@ -154,17 +160,17 @@ __global__ void split_rows_i8_kernel(const float* __restrict__ src, int64_t ld, 
   }
   const float nv = sqrtf(SQ);
   if (is_items) {
-    // one pair of atomics per block, not per row (40,981 same-address atomics were 0.1 ms of the item pass)
+    // the block's maxima: Σ|q| to its own slot, the norm through ONE atomic per block, not per row (same-address
+    // atomics were 0.1 ms of the item pass)
     int mq = have ? Q1 : 0, mn = have ? __float_as_int(nv) : 0;                  // nv >= 0 (or NaN: stays on top)
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
       mq = max(mq, __shfl_xor(mq, o, NR_WAVE));
       mn = max(mn, __shfl_xor(mn, o, NR_WAVE));
     }
-    if (lane == 0) {                                          // (only if it can raise the maximum: see absmax_bits_kernel)
-      int* q1p = reinterpret_cast<int*>(&sc[kScQ1]);
-      int* nmp = reinterpret_cast<int*>(&sc[kScNorm]);
-      if (mq > __hip_atomic_load(q1p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q1p, mq);
+    if (lane == 0) {
+      qblk[b] = (float)mq;
+      int* nmp = reinterpret_cast<int*>(&sc[kScNorm]);        // (only if it can raise the maximum: see absmax_bits_kernel)
       if (mn > __hip_atomic_load(nmp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nmp, mn);
     }
     return;
@@ -173,16 +179,18 @@ __global__ void split_rows_i8_kernel(const float* __restrict__ src, int64_t ld, 
   const uint32_t ibits = sc[kScAmax];
   const float inorm = __uint_as_float(sc[kScNorm]);
   if (bad || scale_bad(ibits) || !(nv < __builtin_huge_valf()) || !(inorm < __builtin_huge_valf())) {
-    cu[r] = 0.f;
+    cu[2 * r] = 0.f;
+    cu[2 * r + 1] = 0.f;
     eps[r] = __builtin_nanf("");
     return;
   }
   const float su = bits ? amax / (float)kQMax : 0.f;
   const float sI = ibits ? __uint_as_float(ibits) / (float)kQMax : 0.f;
-  cu[r] = su * sI * 128.f;
-  const float bracket = nr_add_up(nr_add_up(nr_mul_up(0.52f, (float)(Q1 + (int)sc[kScQ1])), 0.27f * (float)d),
-                                  64.f * (float)L1);
-  const float e_fixed = nr_mul_up(nr_mul_up(su, sI), bracket);
+  const float susi = nr_mul_up(su, sI);
+  cu[2 * r] = su * sI * 128.f;
+  cu[2 * r + 1] = nr_mul_up(0.525f, susi);
+  const float bracket = nr_add_up(nr_add_up(nr_mul_up(0.525f, (float)Q1), 0.27f * (float)d), 64.f * (float)L1);
+  const float e_fixed = nr_mul_up(susi, bracket);
   const float e_chain = nr_mul_up(nr_mul_up(1.5f * (float)d * 5.9604644775390625e-08f, nv), inorm);
   const float e_abs = nr_mul_up(7.70371978e-34f * (float)d, nr_add_up(1.0f, nr_add_up(nv, inorm)));
   eps[r] = nr_add_up(nr_add_up(e_fixed, e_chain), e_abs);
@@ -220,7 +228,8 @@ struct BSetI8 {
 // slower: 0.139 against 0.117 ms per 16,384 users (profiles/r05_exp_filter_i8.txt).
 template <int KS>
 __global__ __launch_bounds__(256, 1) void tilemax_i8_kernel(const uint4* __restrict__ PB, const uint4* __restrict__ QB,
-                                                            const float* __restrict__ cu, int bpad, int rows, int cols,
+                                                            const float* __restrict__ cu,
+                                                            const float* __restrict__ qblk, int bpad, int rows, int cols,
                                                             int n_tiles, float* __restrict__ M, int64_t mld,
                                                             int tiles_per_chunk, float* __restrict__ sink) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -242,7 +251,8 @@ __global__ __launch_bounds__(256, 1) void tilemax_i8_kernel(const uint4* __restr
     }
   const int my_row = ub0 * 32 + 32 * h + j;                   // the row this lane stores
   const bool row_ok = my_row < rows;
-  const float my_scale = row_ok ? cu[my_row] : 0.f;
+  const float my_scale = row_ok ? cu[2 * my_row] : 0.f;       // su sI 128
+  const float my_tile = row_ok ? cu[2 * my_row + 1] : 0.f;    // 0.525 su sI: times the tile's largest Σ|qi|
   float* const my_sink = sink + 2 * lane;
   float* const my_M = M + (int64_t)(row_ok ? my_row : 0) * mld;
 
@@ -286,7 +296,9 @@ __global__ __launch_bounds__(256, 1) void tilemax_i8_kernel(const uint4* __restr
   auto reduce_store = [&](int t, const i32x16 (&hh)[2][2], const i32x16 (&xx)[2][2]) __attribute__((always_inline)) {
     const int m00 = max_halves_i(vmax16(hh[0][0], xx[0][0])), m10 = max_halves_i(vmax16(hh[1][0], xx[1][0]));
     const int m01 = max_halves_i(vmax16(hh[0][1], xx[0][1])), m11 = max_halves_i(vmax16(hh[1][1], xx[1][1]));
-    const float2 v = make_float2((float)(h ? m01 : m00) * my_scale, (float)(h ? m11 : m10) * my_scale);
+    const int tq = min(t, n_tiles - 1);                        // (tiles past the end are computed into the sink)
+    const float2 v = make_float2(fmaf(qblk[2 * tq], my_tile, (float)(h ? m01 : m00) * my_scale),
+                                 fmaf(qblk[2 * tq + 1], my_tile, (float)(h ? m11 : m10) * my_scale));
     float* dst = (row_ok && t < t_stop) ? my_M + 2 * t : my_sink;
     *reinterpret_cast<float2*>(dst) = v;
   };
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void tilemax_i8_kernel(const uint4* __restr
 #pragma unroll
       for (int y = 0; y < 2; ++y) {
         const int mi = max_halves_i(vmax16_skip(hh[x][y], xx[x][y], skip));
-        m[x][y] = mi == INT_MIN ? -INFINITY : (float)mi * my_scale;      // a block of pad columns only
+        m[x][y] = mi == INT_MIN ? -INFINITY : fmaf(qblk[2 * t + x], my_tile, (float)mi * my_scale);   // (-inf: pad columns only)
       }
     }
     if (row_ok) *reinterpret_cast<float2*>(my_M + 2 * t) = h ? make_float2(m[0][1], m[1][1]) : make_float2(m[0][0], m[1][0]);
@@ -339,7 +351,8 @@ inline int round_up64(int x) { return (x + 63) / 64 * 64; }
 struct FilterWsI8 {
   uint4* QB;
   uint4* PB;
-  float* cu;
+  float* cu;                                                  // [rows][2]
+  float* qblk;                                                // [item blocks of 32]
   uint32_t* sc;
   float* sink;                                                // 64 float2: where stores of rows / tiles that do not exist go
   size_t q_bytes, p_bytes, n_bytes, total;
@@ -348,13 +361,15 @@ FilterWsI8 carve(void* ws, int rows, int cols, int dp) {
   FilterWsI8 f;
   f.q_bytes = nr_align_up((size_t)round_up64(cols) * dp * 2, 256);          // h + l planes = 2 bytes per element
   f.p_bytes = nr_align_up((size_t)round_up64(rows > 0 ? rows : 1) * dp * 2, 256);
-  f.n_bytes = nr_align_up((size_t)round_up64(rows > 0 ? rows : 1) * 4, 256);
+  f.n_bytes = nr_align_up((size_t)round_up64(rows > 0 ? rows : 1) * 8, 256);
+  const size_t b_bytes = nr_align_up((size_t)(round_up64(cols) / 32) * 4, 256);
   f.QB = (uint4*)ws;
   f.PB = (uint4*)((char*)ws + f.q_bytes);
   f.cu = (float*)((char*)ws + f.q_bytes + f.p_bytes);
-  f.sc = (uint32_t*)((char*)ws + f.q_bytes + f.p_bytes + f.n_bytes);
+  f.qblk = (float*)((char*)ws + f.q_bytes + f.p_bytes + f.n_bytes);
+  f.sc = (uint32_t*)((char*)ws + f.q_bytes + f.p_bytes + f.n_bytes + b_bytes);
   f.sink = (float*)(f.sc + 64);
-  f.total = f.q_bytes + f.p_bytes + f.n_bytes + 256 + 512;
+  f.total = f.q_bytes + f.p_bytes + f.n_bytes + b_bytes + 256 + 512;
   return f;
 }
 
@@ -388,7 +403,7 @@ int nrhip_score_filter_i8_prepare_items(const float* d_Q, int64_t ldq, int cols,
   hipLaunchKernelGGL(absmax_bits_kernel, dim3(blocks), dim3(256), 0, st, d_Q, ldq, cols, d, flat, f.sc + kScAmax);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(split_rows_i8_kernel, dim3(round_up64(cols) / 32), dim3(64, dp / 32), 0, st, d_Q, ldq,
-                     (const int32_t*)nullptr, cols, d, dp / 32, f.QB, f.sc, (float*)nullptr, (float*)nullptr, 1);
+                     (const int32_t*)nullptr, cols, d, dp / 32, f.QB, f.sc, f.qblk, (float*)nullptr, (float*)nullptr, 1);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -412,7 +427,7 @@ int nrhip_score_filter_i8_tilemax(const float* d_P, int64_t ldp, const int32_t* 
   hipStream_t st = (hipStream_t)stream;
   const int ks = dp / 32, bpad = round_up64(rows);
   hipLaunchKernelGGL(split_rows_i8_kernel, dim3(bpad / 32), dim3(64, ks), 0, st, d_P, ldp, d_users, rows, d, ks, f.PB,
-                     f.sc, f.cu, d_eps, 0);
+                     f.sc, (float*)nullptr, f.cu, d_eps, 0);
   NR_LAUNCH_CHECK();
   const int bx = (bpad / 64 + 3) / 4;
   const int n_tiles = round_up64(cols) / 64;
@@ -431,10 +446,10 @@ int nrhip_score_filter_i8_tilemax(const float* d_P, int64_t ldp, const int32_t* 
   }
   dim3 grid(bx, by), block(256);
   if (ks == 1)
-    hipLaunchKernelGGL(tilemax_i8_kernel<1>, grid, block, 0, st, f.PB, f.QB, f.cu, bpad, rows, cols, n_tiles, d_M, mld,
+    hipLaunchKernelGGL(tilemax_i8_kernel<1>, grid, block, 0, st, f.PB, f.QB, f.cu, f.qblk, bpad, rows, cols, n_tiles, d_M, mld,
                        tpc, f.sink);
   else
-    hipLaunchKernelGGL(tilemax_i8_kernel<2>, grid, block, 0, st, f.PB, f.QB, f.cu, bpad, rows, cols, n_tiles, d_M, mld,
+    hipLaunchKernelGGL(tilemax_i8_kernel<2>, grid, block, 0, st, f.PB, f.QB, f.cu, f.qblk, bpad, rows, cols, n_tiles, d_M, mld,
                        tpc, f.sink);
   NR_LAUNCH_CHECK();
   return NR_OK;

@@ -495,7 +495,16 @@ class FullRankEvaluator:
         if self.search not in ("bf16", "int8", "fp32"):
             raise ValueError("search must be 'bf16', 'int8' or 'fp32', got %r" % (self.search,))
         self.extra_tiles = int(extra_tiles)  # bounded search: tiles rescored beyond top_k + 1 (room for the bound)
-        self._filter = None
+        self._filter, self._filters = None, {}
+        # the int8 bound is 2-4 x the bf16 form's: where scores crowd together (an untrained NGCF: a third of the rows)
+        # its certificate fails row after row and every such row costs a full fp32 row.  An evaluation that had to
+        # redo rows under int8 sends the next `int8_retry` evaluations through bf16 before int8 is tried again.
+        self.int8_retry = 8
+        self._int8_pause = 0
+        # ... and the int8 certificate gets more rescored tiles to stand on: with 23 tiles 1-3 of 29,858 rows of plain
+        # gaussian tables stay uncertified (each costs a full fp32 row: 0.87 instead of 0.67 ms), with 25 none; four
+        # more tiles cost 0.01 ms (profiles/r05_exp_filter_i8.txt)
+        self.int8_extra_tiles = int(os.environ.get("NEUREC_EVAL_I8_EXTRA_TILES", "4"))
         self.native_loop = os.environ.get("NEUREC_EVAL_NATIVE_LOOP", "1") != "0"   # nrhip_eval_pruned (0: the Python batch loop)
         self._native_sums = None
         self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
@@ -564,6 +573,7 @@ class FullRankEvaluator:
             main.wait_stream(side)
         if exact_mean or want_rows:
             self._redo_flagged(user_table, item_table, test_users, per_user)
+            self._note_flags()
             rows = per_user.cpu().numpy()
             return rows if want_rows else np.mean(rows, axis=0)   # uni_evaluator.py:150-151
         # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
@@ -578,10 +588,15 @@ class FullRankEvaluator:
                 #                                    scalar division may be a reciprocal multiply: last-ulp differences)
             both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
         self.n_flagged = int(both[-1])
+        self._note_flags()
         if self.n_flagged:
             self._redo_flagged(user_table, item_table, test_users, per_user)
             return E.colsum(per_user).cpu().numpy() / n
         return both[:-1] / n
+
+    def _note_flags(self):
+        if getattr(self, "search_used", None) == "int8" and self.n_flagged > 0 and self.search == "int8":
+            self._int8_pause = self.int8_retry
 
     def _evaluate_pruned(self, user_table, item_table, test_users, per_user, starts):
         """Level 1: tile maxima from the scoring loop (scores never stored); level 2: rescore and
@@ -614,25 +629,36 @@ class FullRankEvaluator:
                 self._row_of_tag, self._row_of = tag, t
             row_of = self._row_of
         filt = None
-        n_keep = min(self.top_k + 1 + self.extra_tiles, 63, 2 * ((item_table.shape[0] + 63) // 64) - 1)
         arith = self.search
         if arith == "int8" and not E.ScoreFilter.supports(item_table.shape[1], "int8"):
             arith = "bf16"                                    # the int8 form is built for d <= 64
+        if arith == "int8" and self._int8_pause > 0:
+            self._int8_pause -= 1
+            arith = "bf16"                                    # the last int8 evaluation left rows uncertified
+        # the int8 bound is wider: its certificate gets more rescored tiles to stand on (int8_extra_tiles more)
+        extra = self.extra_tiles + (self.int8_extra_tiles if arith == "int8" else 0)
+        n_keep = min(self.top_k + 1 + extra, 63, 2 * ((item_table.shape[0] + 63) // 64) - 1)
         if arith != "fp32" and use_plan and E.ScoreFilter.supports(item_table.shape[1], arith) and n_keep > self.top_k:
-            if self._filter is None or self._filter.arith != arith:
-                self._filter = E.ScoreFilter(item_table, self.batch_rows, arith)
+            if self._filter is None:
+                self._filters = {}                            # (a new scoring engine: new table shape)
+            if arith not in self._filters:                    # both forms stay built: a paused int8 comes back
+                self._filters[arith] = E.ScoreFilter(item_table, self.batch_rows, arith)
             else:
-                self._filter.prepare(item_table)
-            filt = self._filter
+                self._filters[arith].prepare(item_table)
+            filt = self._filter = self._filters[arith]
         self.search_used = filt.arith if filt is not None else "fp32"
         if use_plan and self.native_loop:
             # the whole batch loop, the column sums and the flagged-row count in one native call (nrhip_eval_pruned)
             keep = n_keep if filt is not None else self.top_k + 1
             key = (id(self._gemm), id(filt), id(plan), keep)
             if getattr(self, "_native_key", None) != key:
-                self._native = E.PrunedEvaluation(self._gemm, filt, plan, self.train, self.test, self.metric_ids,
-                                                  self.top_k, keep, self.batch_rows)
-                self._native_key = key
+                cache = getattr(self, "_natives", None)
+                if cache is None or cache[0] is not self._gemm:
+                    cache = self._natives = (self._gemm, {})
+                if key not in cache[1]:
+                    cache[1][key] = E.PrunedEvaluation(self._gemm, filt, plan, self.train, self.test, self.metric_ids,
+                                                       self.top_k, keep, self.batch_rows)
+                self._native, self._native_key = cache[1][key], key
             _, _, self._native_sums = self._native.run(user_table, item_table, test_users, row_of, per_user, flags,
                                                        prepare_items=False)
             self._flags = flags
