@@ -408,11 +408,12 @@ int nrhip_score_filter_i8_prepare_items(const float* d_Q, int64_t ldq, int cols,
   return NR_OK;
 }
 
-/* nrhip_score_filter_tilemax on the int8 matrix cores: M[rows][2*ceil(cols/64)] approximate tile maxima (32-item
- * tiles, pad columns excluded, train items NOT struck) and d_eps[rows] with |M[r][t] - (fp32 chain maximum of that
- * tile)| <= d_eps[r]; d_eps[r] is NaN for a row the fixed-point form cannot bound (magnitudes outside 2^-40 .. 2^40,
- * non-finite entries) — such rows fail every certificate.  nrhip_score_filter_i8_prepare_items with the same
- * workspace, cols, d and max_rows >= rows must have run. */
+/* nrhip_score_filter_tilemax on the int8 matrix cores: M[rows][2*ceil(cols/64)] UPPER-bound tile maxima (32-item
+ * tiles, pad columns excluded, train items NOT struck; the tile's share of the quantisation error is inside) and
+ * d_eps[rows] with  fp32 chain maximum of tile t <= M[r][t] + d_eps[r]  and  M[r][t] - that maximum <= d_eps[r] +
+ * 2 x the tile's share (top of this file); d_eps[r] is NaN for a row the fixed-point form cannot bound (magnitudes
+ * outside 2^-40 .. 2^40, non-finite entries) — such rows fail every certificate.
+ * nrhip_score_filter_i8_prepare_items with the same workspace, cols, d and max_rows >= rows must have run. */
 int nrhip_score_filter_i8_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols, int d,
                                   float* d_M, int64_t mld, float* d_eps, void* d_ws, size_t ws_bytes, int max_rows,
                                   void* stream) {
