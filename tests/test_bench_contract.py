@@ -55,6 +55,14 @@ def test_committed_bench_line_says_what_was_inside_the_timed_region():
     r = e["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     assert 0 < e["roofline_topk"]["frac"] < 1
+    # the search arithmetic is named, and it certified every row (a redone row would be a full fp32 row in the timing)
+    assert e["search"] in ("int8", "bf16", "fp32") and r.get("arith", e["search"]) == e["search"]
+    assert e["rows_redone_for_ties"] == 0 and r["unit"] == ("TOP/s" if e["search"] == "int8" else "TFLOP/s")
+    with open(os.path.join(ROOT, "profiles", "r05_bench_driver_line.json")) as f:
+        compact = json.loads(f.read().strip().splitlines()[-1])["roofline"]
+    for k in ("eval_search", "eval_search_unit", "eval_fp32_roof_ratio", "eval_fp32_loop_ms", "eval_rows_redone", "eval_rank_ms"):
+        assert k in compact, k
+    assert compact["eval_search"] == e["search"] and compact["eval_ndcg10_oracle_absdiff"] == 0.0
     m = d["mf"]
     assert "lazy" in m["optimizer"] and m["ms_per_step"] < m["sweep_ms_per_step"]
 
