@@ -1,5 +1,5 @@
-"""Power and shader clock while the bf16 filter (and, for comparison, the fp32 loop and an idle GPU) runs back to back
-for ~2.5 s each: rocm-smi sampled from a side thread."""
+"""Power and shader clock while the bf16 filter, the int8 filter (and, for comparison, the fp32 loop and an idle GPU)
+run back to back for ~2.5 s each: rocm-smi sampled from a side thread."""
 import os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,7 @@ P = (torch.randn(U, d, device=dev) * 0.01).contiguous()
 Q = (torch.randn(I, d, device=dev) * 0.01).contiguous()
 users = torch.arange(U, dtype=torch.int32, device=dev)
 g, f = E.ScoreGemm(Q, U), E.ScoreFilter(Q, U)
+f8 = E.ScoreFilter(Q, U, "int8")
 n_tiles = 2 * ((I + 63) // 64)
 M = torch.empty((U, (n_tiles + 3) // 4 * 4), dtype=torch.float32, device=dev)
 eps = torch.empty(U, dtype=torch.float32, device=dev)
@@ -49,4 +50,5 @@ def run(name, fn, seconds=2.5):
 
 run("idle", None)
 run("bf16 filter", lambda: f.tile_maxima(P, users, out=M, eps=eps))
+run("int8 filter", lambda: f8.tile_maxima(P, users, out=M, eps=eps))
 run("fp32 MFMA loop", fp32)
