@@ -116,6 +116,127 @@ def _median_wall(fn, runs=5):
     return sorted(ts)[len(ts) // 2], out
 
 
+def leg_mf(train, test, trc, tec, dev, eval_batch, eval_mode, with_eval, with_cpu, label="gowalla"):
+    """BPR-MF (MF.py:45-113 with conf/MF.properties: d = 64, B = 512, lr 0.001, reg 0, N(0, 0.01) tables) on the given
+    interactions: BASELINE configs[1] at the gowalla shape, configs[0] at the ml-100k shape (the reference's own
+    CPU-runnable case).  A step = ONE launch: gather, BPR forward/backward, the batch's duplicate-row sums, TF-1.12 sparse
+    Adam by exact lazy replay (bit-identical to the all-rows sweep).  One whole epoch is timed (sampler and
+    batch plans inside, the short last batch too) next to a window of full steps.  -> (info, engine)"""
+    import torch
+    from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, MFEngine
+    U, I = train.shape
+    B, d = 512, 64
+    rs = np.random.RandomState(2017)
+    P0, Q0 = (rs.randn(U, d) * 0.01).astype(np.float32), (rs.randn(I, d) * 0.01).astype(np.float32)
+    mf = MFEngine(P0, Q0, 0.001, 0.0, B)                                      # conf/MF.properties
+    mf_sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=B, shuffle=True, seed=2018, plan_users=U)
+    # the batch loop of MF.train_model runs natively (MFEngine.run_batches -> nrhip_mf_steps): a
+    # Python loop enqueues ~12 us per step, about what the one-launch step takes on the GPU
+    mu, mp, mn, mplans = mf_sampler.epoch_stream()
+    avail = mu.numel() // B
+    w_steps = min(50, avail // 4)
+    t_steps = max(min(400, avail - w_steps), 1)
+    n_warm, n_timed = w_steps * B, t_steps * B
+    mf_loss = torch.zeros(max(avail + 1, 1), 2, device=dev)
+    cut = lambda lo, hi: (mu[lo:hi], mp[lo:hi], mn[lo:hi])
+    mf.run_batches(*cut(0, n_warm), B, mf_loss, mplans[:3 * n_warm])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mf.run_batches(*cut(n_warm, n_warm + n_timed), B, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
+    torch.cuda.synchronize()
+    mf_dt = (time.perf_counter() - t0) / t_steps
+    # ONE WHOLE EPOCH as MF.train_model runs it (MF.py:95-103): the sampler's launch, the batch plans, every batch of
+    # the permuted stream including the short last one — E / epoch wall time, SURVEY 8d's metric
+    ep = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eu_, ep_, en_, epl = mf_sampler.epoch_stream()
+        mf.run_batches(eu_, ep_, en_, B, mf_loss, epl)
+        torch.cuda.synchronize()
+        ep.append(time.perf_counter() - t0)
+    epoch_s = sorted(ep)[1]
+    n_epoch = int(mu.numel())
+    # the same steps with TF's literal all-rows sweep (the checker) for the record
+    mf_sweep = MFEngine(P0, Q0, 0.001, 0.0, B, lazy=False)
+    mf_sweep.run_batches(*cut(0, n_warm), B, mf_loss, mplans[:3 * n_warm])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mf_sweep.run_batches(*cut(n_warm, n_warm + n_timed), B, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
+    torch.cuda.synchronize()
+    sweep_dt = (time.perf_counter() - t0) / t_steps
+    del mf_sweep
+    touched = B * (72 * d + 12)              # SURVEY 8d: 3 rows x (read + write of p, m, v) + ids, per triplet
+    info = {"shape": label, "users": U, "items": I, "interactions": int(train.nnz),
+            "triplets_per_sec": B / mf_dt, "ms_per_step": mf_dt * 1e3, "batch": B, "dim": d, "steps_timed": t_steps,
+            "epoch": {"triplets_per_sec": n_epoch / epoch_s, "ms": epoch_s * 1e3, "triplets": n_epoch,
+                      "steps": (n_epoch + B - 1) // B, "runs_ms": [x * 1e3 for x in ep],
+                      "note": "sampler launch + batch plans + every batch (short last one included), wall clock between "
+                              "device synchronisations, median of 3"},
+            "optimizer": "TF-1.12 sparse Adam by exact lazy replay (bit-identical to the all-rows sweep), "
+                         "gradient + optimiser in one launch on double-buffered tables",
+            "roofline": {"bound": "hbm", "bytes_per_step": touched, "unit": "GB/s",
+                         "achieved": touched / mf_dt / 1e9, "peak": HBM_PEAK_GBS,
+                         "frac": touched / mf_dt / 1e9 / HBM_PEAK_GBS,
+                         "epoch_frac": n_epoch * (72 * d + 12) / epoch_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "SURVEY 8d bound (72 d + 12) B per triplet; one launch whose critical path is a "
+                                 "chain of ~5 dependent memory round trips (plan key -> ids -> stamps + rows -> "
+                                 "ordered row sums -> Adam -> store -> loss reduction): latency-bound, not "
+                                 "bandwidth-bound"},
+            "sweep_ms_per_step": sweep_dt * 1e3,
+            "sweep_GBps": 2 * 4 * (U + I) * d * 4 / sweep_dt / 1e9}
+    tu = None
+    if with_eval:
+        # configs[0] / [1] name the evaluator too: the BPR-MF tables through the same full-rank path
+        tu = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
+        mf_ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=eval_batch, pruned=eval_mode == "pruned")
+        mf_ev.evaluate_factors(mf.P, mf.Q, tu)
+        mf_edt, mm = _median_wall(lambda: mf_ev.evaluate_factors(mf.P, mf.Q, tu))
+        info["eval"] = {"users_per_sec": tu.numel() / mf_edt, "ms": mf_edt * 1e3, "n_users": int(tu.numel()),
+                        "ndcg@10": float(mm[2 * 20 + 9]), "search": getattr(mf_ev, "search_used", None),
+                        "rows_redone": int(getattr(mf_ev, "n_flagged", 0)),
+                        "mfma_fp32_roof_ratio": 2.0 * I * d * tu.numel() / mf_edt / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    if with_cpu:
+        # the CPU side of configs[0]: the restated MF step (oracle.train.mf_step: numpy gathers + TF's all-rows sparse
+        # Adam, 1 thread — TF-CPU itself is not installable here) and the reference's own C++ evaluator fed by
+        # np.matmul as MF.py:120-122 does, on the GPU run's tables and users
+        from oracle import native, ref, train as otrain
+        Pc, Qc = P0.copy(), Q0.copy()
+        mP, vP, mQ, vQ = (np.zeros_like(x) for x in (Pc, Pc, Qc, Qc))
+        adam = otrain.Adam(0.001)
+        hu, hp, hn = (x.cpu().numpy() for x in (mu, mp, mn))
+        t0, n = time.perf_counter(), 0
+        while n < avail and time.perf_counter() - t0 < 6.0:
+            sl = slice(n * B, (n + 1) * B)
+            otrain.mf_step(Pc, Qc, mP, vP, mQ, vQ, hu[sl], hp[sl], hn[sl], 0.0, adam)
+            n += 1
+        cpu_step = (time.perf_counter() - t0) / max(n, 1)
+        cb = {"value": B / cpu_step, "unit": "triplets/s", "cores": 1, "kind": "port",
+              "sample": "%d BPR-MF steps (B = %d, d = %d) of the same stream: oracle.train.mf_step, numpy fp32, the "
+                        "all-rows sparse Adam of TF 1.12" % (n, B, d)}
+        if tu is not None:
+            users = tu.cpu().numpy()[:1024]
+            Ph, Qh = mf.P.cpu().numpy(), mf.Q.cpu().numpy()
+            truth = [test.indices[test.indptr[u]:test.indptr[u + 1]].tolist() for u in users]
+            fn = ref.eval_matrix if ref.available() else native.eval_matrix
+            res = []
+            t0 = time.perf_counter()
+            for b in range(0, len(users), 128):               # test_batch_size=128, NeuRec.properties:40
+                ub = users[b:b + 128]
+                S = np.ascontiguousarray(np.matmul(Ph[ub], Qh.T), dtype=np.float32)
+                native.mask_train(S, ub, train.indptr.astype(np.int64), train.indices)
+                res.append(fn(S, truth[b:b + 128], [1, 2, 4, 3, 5], 20, threads=8))
+            dte = time.perf_counter() - t0
+            want = float(np.mean(np.concatenate(res), axis=0)[2 * 20 + 9])
+            got = mf_ev.evaluate_factors(mf.P, mf.Q, torch.from_numpy(users).to(dev), exact_mean=True)
+            cb["eval"] = {"value": len(users) / dte, "unit": "users/s", "cores": 8,
+                          "kind": "reference" if ref.available() else "port", "ndcg@10": want,
+                          "sample": "%d users, np.matmul + C++ evaluator, num_thread=8, batch 128" % len(users)}
+            info["ndcg10_oracle_absdiff"] = abs(float(got[2 * 20 + 9]) - want)
+        info["cpu_baseline"] = cb
+    return info, mf
+
+
 def leg_ngcf(train, test, trc, tec, dev, with_cpu):
     """BASELINE configs[4], NGCF half (conf/NGCF.properties: embedding 16, layers [16, 16], B = 512, `norm`
     adjacency, message dropout 0.1) on the run's interactions: step time, the roofline of its dominant
@@ -331,7 +452,7 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     return out
 
 
-def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=None):
+def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=None, eval_users=0):
     """BASELINE configs[3] (LightGCN, U = 10^7, I = 10^6, E = 2*10^8, d = 128) at `scale` on this GPU through
     the row-sharded engine: graph generated on the device, adjacency block built on the device.  hop: the form of the
     per-hop exchange (sharded.ShardedLightGCN: sliced / allgather / chunked / reduce; None = the engine's default)."""
@@ -409,8 +530,96 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=No
                                 "gathers run at 7.3-7.4 TB/s on this part whether the table sits in the Infinity "
                                 "Cache or in HBM (6.3 at 5 GB; profiles/r03_exp_gather_vs_table_size.txt), which is "
                                 "the rate the pass sustains" % (lg.S, lg.w * 4)}}
+    if eval_users:
+        try:
+            out["eval"] = _config4_eval(lg, comm, trc, I, dim, dev, eval_users)
+        except Exception as e:                                # a secondary leg must not take the headline down
+            out["eval"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del lg, sampler, trc, tr_ptr, tr_idx
     torch.cuda.empty_cache()
+    return out
+
+
+def _config4_eval(lg, comm, trc, I, dim, dev, n_eval, batch_rows=8192, top_k=20):
+    """The evaluation half of BASELINE's metric at the config-4 shape (uni_evaluator.py:101-157 on LightGCN.py:183-192):
+    every rank ranks ITS users against the whole item table — ShardedLightGCN.eval_factors all-gathers the item blocks
+    only — and the metric sums are added over the ranks (sharded.ShardedEvaluator).  Timed on a BOUNDED block of each
+    rank's users (the first n_eval of them: ranking is per user, the rate does not depend on which), the propagation
+    that precedes an evaluation timed on its own (it is per evaluation, not per user)."""
+    import torch
+    from neurec_amd import engine as E, synth
+    from neurec_amd.sharded import ShardedEvaluator
+    mids = [1, 2, 4, 3, 5]
+    n = min(int(n_eval), lg.nu)
+    train_rows = trc.rows(lg.ulo, lg.ulo + n)
+    test_rows = synth.device_test_rows(train_rows, I, per_user=2, seed=2019 + comm.rank)
+    ev = ShardedEvaluator(comm, train_rows, test_rows, mids, top_k, batch_rows=batch_rows)
+    torch.cuda.synchronize(); comm.barrier()
+    t0 = time.perf_counter()
+    eu, items = lg.eval_factors()
+    torch.cuda.synchronize(); comm.barrier()
+    factors_s = comm.max_float(time.perf_counter() - t0)
+    eu = eu[:n]
+    t0 = time.perf_counter()
+    ev.evaluate_factors(eu, items)                            # first call: strike plan, filter operands, buffers
+    torch.cuda.synchronize()
+    first_s = time.perf_counter() - t0
+    runs = []
+    for _ in range(3):
+        torch.cuda.synchronize(); comm.barrier()
+        t0 = time.perf_counter()
+        means = ev.evaluate_factors(eu, items)
+        torch.cuda.synchronize(); comm.barrier()
+        runs.append(comm.max_float(time.perf_counter() - t0))
+    dt = sorted(runs)[1]
+    fe = ev.ev
+    out = {"users_per_sec": ev.n_total / dt, "ms": dt * 1e3, "ms_runs": [r * 1e3 for r in runs], "n_users": ev.n_total,
+           "users_per_rank": ev.n_local, "items": I, "dim": dim, "batch_rows": batch_rows,
+           "ndcg@10": float(means[2 * top_k + 9]), "search": fe.search_used, "rows_redone": ev.rows_redone,
+           "first_call_ms": first_s * 1e3, "factors_ms": factors_s * 1e3,
+           "whole_population_seconds": factors_s + lg.n_users / (ev.n_total / dt),
+           "sample": "the first %d users of every rank with a synthetic test split (2 uniform draws per user outside the "
+                     "train row); factors_ms = the L hops + the all-gather of the item blocks that precede an "
+                     "evaluation (per evaluation, not per user); whole_population_seconds = factors + U / users_per_sec; "
+                     "the model is %d steps from Xavier noise: NDCG@10 is at chance, the leg measures the rate" % (n, 4)}
+    # roofline of the search (the dominant kernel) and of the ranking phase, first batch, HIP events on the launch stream
+    ub = ev.users[:batch_rows]
+    nb = ub.numel()
+    filt = fe._filter if fe.search_used in ("bf16", "int8") else None
+    if nb and fe._plan is not None:
+        n_keep = min(top_k + 1 + fe.extra_tiles + (fe.int8_extra_tiles if fe.search_used == "int8" else 0), 63) \
+            if filt is not None else top_k + 1
+        level1 = lambda: fe._gemm.tile_maxima(eu, ub, train_rows, plan=fe._plan, row_of=fe._row_of, filt=filt)
+        r1 = level1()
+        M, eps = r1 if filt is not None else (r1, None)
+        per = torch.empty((nb, len(mids) * top_k), dtype=torch.float32, device=dev)
+        flg = torch.zeros(nb, dtype=torch.int32, device=dev)
+        level2 = lambda: E.eval_tiles(M, eu, fe._gemm, ub, train_rows, test_rows, mids, top_k, per, flg, eps=eps,
+                                      n_keep=n_keep if eps is not None else None)
+        t1 = _hip_timed(level1, 3, 1) * 1e-3
+        t2 = _hip_timed(level2, 3, 1) * 1e-3
+        flops = 2.0 * I * dim * nb
+        if filt is not None:
+            i8 = filt.arith == "int8"
+            peak, sustained = (MFMA_I8_PEAK_TOPS, 3500.0) if i8 else (MFMA_BF16_PEAK_TFLOPS, 1300.0)
+            out["roofline"] = {"bound": "mfma", "arith": filt.arith, "users": nb, "ms": t1 * 1e3,
+                               "kernel": "tilemax_i8_kernel" if i8 else ("tilemax_bf16_wide_kernel" if dim > 64 else "tilemax_bf16_kernel"),
+                               "achieved": 3.0 * flops / t1 / 1e12, "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
+                               "frac": 3.0 * flops / t1 / 1e12 / peak, "frac_of_sustained": 3.0 * flops / t1 / 1e12 / sustained,
+                               "note": "operations ISSUED (3 products of 2·I·d per user) over split + filter + planned fix-up"}
+        else:
+            out["roofline"] = {"bound": "mfma", "arith": "fp32", "users": nb, "ms": t1 * 1e3, "kernel": "score_tilemax_kernel",
+                               "achieved": flops / t1 / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": flops / t1 / 1e12 / MFMA_F32_PEAK_TFLOPS}
+        tiles = 2 * ((I + 63) // 64)
+        # level 2, algorithmic HBM bytes: per user its tile maxima read once, its factor row, M·K metrics; the rescored
+        # item tiles read once per 32 (user, tile) pairs of a bucket chunk
+        rank_bytes = nb * (tiles * 4 + dim * 4 + len(mids) * top_k * 4) + nb * n_keep * 32 * dim * 4 // 32
+        out["roofline_topk"] = {"bound": "hbm", "ms": t2 * 1e3, "bytes": rank_bytes, "achieved": rank_bytes / t2 / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_bytes / t2 / 1e9 / HBM_PEAK_GBS,
+                                "tile_maxima_per_user": tiles, "tiles_rescored_per_user": n_keep,
+                                "kernel": "select_rows_kernel (streaming ring over %d maxima) + tile_count / tile_fill "
+                                          "(packed buckets) + rescore_pairs_kernel + select_rows + remap + metrics" % tiles}
     return out
 
 
@@ -693,6 +902,12 @@ def compact_line(line):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "rccl_ranks", "dist_backend", "redundant_compute", "final_loss")
     out = {k: line[k] for k in keep if k in line}
+    # the metric as SURVEY 8d defines it — one whole timed epoch, sampler and short last batch inside — next to the
+    # contract's K-step window
+    out["value_epoch"] = _get(line, "epoch_timed", "value")
+    out["epoch_ms"] = _get(line, "epoch_timed", "ms")
+    out["epoch_steps"] = _get(line, "epoch_timed", "steps")
+    out["epoch_vs_steps_window"] = _get(line, "epoch_timed", "vs_steps_window")
     short = lambda d: {k: v for k, v in (d or {}).items()
                        if isinstance(v, (int, float, bool)) or v is None or (isinstance(v, str) and len(v) <= 96)}
     roof = short(line.get("roofline"))
@@ -716,6 +931,16 @@ def compact_line(line):
         "mf_us_per_step": None if _get(line, "mf", "ms_per_step") is None else _get(line, "mf", "ms_per_step") * 1e3,
         "mf_hbm_frac": _get(line, "mf", "roofline", "frac"),
         "mf_eval_users_per_sec": _get(line, "mf", "eval", "users_per_sec"),
+        "mf_epoch_triplets_per_sec": _get(line, "mf", "epoch", "triplets_per_sec"),
+        "ml100k_mf_triplets_per_sec": _get(line, "ml100k", "epoch", "triplets_per_sec"),
+        "ml100k_mf_window_triplets_per_sec": _get(line, "ml100k", "triplets_per_sec"),
+        "ml100k_mf_us_per_step": None if _get(line, "ml100k", "ms_per_step") is None else _get(line, "ml100k", "ms_per_step") * 1e3,
+        "ml100k_mf_hbm_frac": _get(line, "ml100k", "roofline", "frac"),
+        "ml100k_eval_users_per_sec": _get(line, "ml100k", "eval", "users_per_sec"),
+        "ml100k_eval_ms": _get(line, "ml100k", "eval", "ms"),
+        "ml100k_eval_ndcg10": _get(line, "ml100k", "eval", "ndcg@10"),
+        "ml100k_eval_fp32_roof_ratio": _get(line, "ml100k", "eval", "mfma_fp32_roof_ratio"),
+        "ml100k_ndcg10_oracle_absdiff": _get(line, "ml100k", "ndcg10_oracle_absdiff"),
         "ngcf_ms_per_step": _get(line, "ngcf", "ms_per_step"),
         "ngcf_triplets_per_sec": _get(line, "ngcf", "triplets_per_sec"),
         "ngcf_spmm_hbm_frac": _get(line, "ngcf", "roofline", "frac"),
@@ -730,6 +955,18 @@ def compact_line(line):
         "config4_triplets_per_sec": _get(line, "config4", "triplets_per_sec"),
         "config4_spmm_hbm_frac": _get(line, "config4", "roofline", "frac"),
         "config4_row_gather_GBps": _get(line, "config4", "roofline", "row_gather_GBps"),
+        "config4_eval_users_per_sec": _get(line, "config4", "eval", "users_per_sec"),
+        "config4_eval_n_users": _get(line, "config4", "eval", "n_users"),
+        "config4_eval_search": _get(line, "config4", "eval", "search"),
+        "config4_eval_rows_redone": _get(line, "config4", "eval", "rows_redone"),
+        "config4_eval_factors_ms": _get(line, "config4", "eval", "factors_ms"),
+        "config4_eval_whole_population_s": _get(line, "config4", "eval", "whole_population_seconds"),
+        "config4_eval_mfma_tflops": _get(line, "config4", "eval", "roofline", "achieved"),
+        "config4_eval_mfma_frac": _get(line, "config4", "eval", "roofline", "frac"),
+        "config4_eval_mfma_frac_of_sustained": _get(line, "config4", "eval", "roofline", "frac_of_sustained"),
+        "config4_eval_search_ms": _get(line, "config4", "eval", "roofline", "ms"),
+        "config4_eval_rank_ms": _get(line, "config4", "eval", "roofline_topk", "ms"),
+        "config4_eval_rank_hbm_frac": _get(line, "config4", "eval", "roofline_topk", "frac"),
         "config4_rank0of8_hop_ms_allgather": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "allgather"),
         "config4_rank0of8_hop_ms_sliced2": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "sliced2"),
         "config4_rank0of8_hop_ms_sliced4": _get(line, "config4", "partitions", "model_at_8_ranks", "hop_ms", "sliced4"),
@@ -749,6 +986,8 @@ def compact_line(line):
     legs["rowshard_config4_law_hop_ms"] = _get(line, "rowshard_config4_law", "exchange", "hop_ms")
     legs["rowshard_config4_law_reduce_ms_per_step"] = _get(line, "rowshard_config4_law_reduce", "ms_per_step")
     legs["rowshard_config4_law_reduce_hop_ms"] = _get(line, "rowshard_config4_law_reduce", "exchange", "hop_ms")
+    legs["rowshard_config4_law_eval_users_per_sec"] = _get(line, "rowshard_config4_law", "eval", "users_per_sec")
+    legs["rowshard_config4_law_eval_factors_ms"] = _get(line, "rowshard_config4_law", "eval", "factors_ms")
     roof.update({k: v for k, v in legs.items() if v is not None})
     out["roofline"] = roof
     cb = line.get("cpu_baseline")
@@ -757,6 +996,12 @@ def compact_line(line):
         for k, path in (("sampler_triplets_per_sec", ("sampler", "value")), ("eval_users_per_sec", ("eval", "value")),
                         ("eval_ndcg10", ("eval", "ndcg@10"))):
             v = _get(cb, *path)
+            if v is not None:
+                c[k] = v
+        for k, path in (("ml100k_mf_triplets_per_sec", ("ml100k", "cpu_baseline", "value")),
+                        ("ml100k_eval_users_per_sec", ("ml100k", "cpu_baseline", "eval", "value")),
+                        ("ml100k_eval_ndcg10", ("ml100k", "cpu_baseline", "eval", "ndcg@10"))):
+            v = _get(line, *path)
             if v is not None:
                 c[k] = v
         for leg, unit in (("ngcf", "triplets_per_sec"), ("multivae", "users_per_sec")):
@@ -814,6 +1059,7 @@ def main():
     from neurec_amd.trainer import BprEpochSampler, FullRankEvaluator, LightGCNEngine
 
     comm = parallel.init_from_env()
+    no_eval_legs = args.no_eval
     if args.dp_mode is None:
         # one rank: the modes coincide.  N ranks: the column-sharded engine when the width divides
         args.dp_mode = "replicated" if not comm.active else ("colshard" if args.dim % comm.world == 0 else "allreduce")
@@ -856,6 +1102,7 @@ def main():
                              hop=args.rowshard_hop)
         del rows
         trc, tec, train, test = E.DeviceCSR(tr_ptr, tr_idx, I), None, None, None
+        config4_eval = not args.no_eval                      # its own evaluation leg (_config4_eval), after the timed steps
         args.no_eval, args.no_mf, args.no_cpu_baseline = True, True, True
         train_nnz = n_train
     else:
@@ -963,6 +1210,44 @@ def main():
                     ("one per step (sorted inside the step)" if not rowshard else 0)}
     triplets_per_s = comm.world * args.steps * args.batch / dt
     run_steps(1, loss2)                                  # untimed: loss of one more step, for the record
+    # ONE WHOLE EPOCH, timed (the metric is E / epoch wall time, sampler included): the
+    # sampler's launch, the batch plans and EVERY batch of the permuted stream, the short last one too
+    # (LightGCN.py:168-180 with data_iterator.py's drop_last=False) — whatever --steps is.  Where the ranks step in
+    # lock-step on their OWN slices (all-reduce / row-shard with N > 1: a collective per step, a rank's slice may hold
+    # one batch more than another's) the epoch is its full batches.  Skipped when an epoch would take more than ~5 s
+    # (config 4 at full size: 24 k steps of 0.14 s).
+    epoch_timed = None
+    n_full = int(comm.max_float(float(len(sampler))))
+    if not exchange and n_full * dt / args.steps < 5.0:
+        lockstep = comm.active and not replicated
+        torch.cuda.synchronize(); comm.barrier()
+        e_before = sampler.epoch
+        t0 = time.perf_counter()
+        n_tr, n_st = 0, 0
+        if lockstep:
+            n_st = int(-comm.max_float(-float(sampler.n_local // sampler.batch_size)))     # full batches every rank has
+            run_steps(n_st)
+            n_tr = comm.world * n_st * args.batch
+        else:
+            for k, b in enumerate(sampler.batches()):
+                if k == 0 and rowshard:
+                    lg.plan_epoch(sampler._users[:sampler.n_local], sampler._pos[:sampler.n_local],
+                                  sampler._neg[:sampler.n_local], args.batch)
+                if rowshard:
+                    lg.step(b[0], b[1], b[2], None, batch_index=k)
+                elif colshard:
+                    lg.step(b[0], b[1], b[2], None, plan=b.plan)
+                else:
+                    lg.step(b[0], b[1], b[2], None, grad_sync=grad_sync, plan=b.plan)
+                n_tr += b[0].numel()
+                n_st += 1
+        torch.cuda.synchronize(); comm.barrier()
+        dt_e = comm.max_float(time.perf_counter() - t0)
+        epoch_timed = {"value": n_tr / dt_e, "unit": "triplets/s", "ms": dt_e * 1e3, "steps": n_st, "triplets": n_tr,
+                       "sampler_launches": sampler.epoch - e_before, "short_last_batch": (not lockstep) and n_tr % (
+                           sampler.batch_size) != 0,
+                       "vs_steps_window": (n_tr / dt_e) / triplets_per_s,
+                       "agrees_with_steps_window_within_2pct": abs((n_tr / dt_e) / triplets_per_s - 1.0) <= 0.02}
     # SURVEY 8d defines the metric "sampler included" = E / epoch wall time: the per-epoch launches (sampler,
     # batch plans) measured on their own and charged to an epoch of len(sampler) steps at the measured step time
     epoch_ms = _hip_timed(sampler.sample_epoch, 3, 1)
@@ -1067,64 +1352,10 @@ def main():
         roofline["step_frac_survey_8d"] = roofline["step_bytes_survey_8d"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS
 
     # ---------------- BPR-MF on the same interactions (BASELINE configs[1]: d=64, B=512) — reported
-    # next to the headline, not instead of it.  A step = fused gather/BPR/scatter kernel + the two
-    # TF-sparse Adam sweeps (every row of both tables decays each step).
-    mf_info = None
+    # next to the headline, not instead of it (leg_mf)
+    mf_info = mf = None
     if comm.rank == 0 and not args.no_mf:
-        from neurec_amd.trainer import MFEngine
-        rs = np.random.RandomState(2017)
-        mf = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32),
-                      0.001, 0.0, 512)                                   # conf/MF.properties
-        mf_sampler = BprEpochSampler(trc, I, neg_num=1, batch_size=512, shuffle=True, seed=2018,
-                                     plan_users=U)
-        # the batch loop of MF.train_model runs natively (MFEngine.run_batches -> nrhip_mf_steps): a
-        # Python loop enqueues ~12 us per step, about what the one-launch step takes on the GPU
-        mu, mp, mn, mplans = mf_sampler.epoch_stream()
-        avail = mu.numel() // 512
-        w_steps = min(50, avail // 4)
-        t_steps = max(min(400, avail - w_steps), 1)
-        n_warm, n_timed = w_steps * 512, t_steps * 512
-        mf_loss = torch.zeros(max(t_steps, w_steps, 1), 2, device=dev)
-        cut = lambda lo, hi: (mu[lo:hi], mp[lo:hi], mn[lo:hi])
-        mf.run_batches(*cut(0, n_warm), 512, mf_loss, mplans[:3 * n_warm])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        mf.run_batches(*cut(n_warm, n_warm + n_timed), 512, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
-        torch.cuda.synchronize()
-        mf_dt = (time.perf_counter() - t0) / t_steps
-        # the same steps with TF's literal all-rows sweep (the checker) for the record
-        mf_sweep = MFEngine((rs.randn(U, 64) * 0.01).astype(np.float32), (rs.randn(I, 64) * 0.01).astype(np.float32),
-                            0.001, 0.0, 512, lazy=False)
-        mf_sweep.run_batches(*cut(0, n_warm), 512, mf_loss, mplans[:3 * n_warm])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        mf_sweep.run_batches(*cut(n_warm, n_warm + n_timed), 512, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
-        torch.cuda.synchronize()
-        sweep_dt = (time.perf_counter() - t0) / t_steps
-        touched = 512 * (72 * 64 + 12)           # 3 rows x (read + write of p, m, v) + ids, per triplet
-        mf_info = {"triplets_per_sec": 512 / mf_dt, "ms_per_step": mf_dt * 1e3, "batch": 512, "dim": 64,
-                   "optimizer": "TF-1.12 sparse Adam by exact lazy replay (bit-identical to the all-rows sweep), "
-                                "gradient + optimiser in one launch on double-buffered tables",
-                   "roofline": {"bound": "hbm", "bytes_per_step": touched, "unit": "GB/s",
-                                "achieved": touched / mf_dt / 1e9, "peak": HBM_PEAK_GBS,
-                                "frac": touched / mf_dt / 1e9 / HBM_PEAK_GBS,
-                                "note": "SURVEY 8d bound (72 d + 12) B per triplet; one launch whose critical path is a "
-                                        "chain of ~5 dependent memory round trips (plan key -> ids -> stamps + rows -> "
-                                        "ordered row sums -> Adam -> store -> loss reduction): latency-bound, not "
-                                        "bandwidth-bound"},
-                   "sweep_ms_per_step": sweep_dt * 1e3,
-                   "sweep_GBps": 2 * 4 * (U + I) * 64 * 4 / sweep_dt / 1e9}
-        if not args.no_eval:
-            # configs[1] names the evaluator too: the BPR-MF tables through the same full-rank path
-            tu = torch.from_numpy(np.flatnonzero(np.diff(test.indptr) > 0).astype(np.int32)).to(dev)
-            mf_ev = FullRankEvaluator(trc, tec, [1, 2, 4, 3, 5], 20, batch_rows=args.eval_batch,
-                                      pruned=args.eval_mode == "pruned")
-            mf_ev.evaluate_factors(mf.P, mf.Q, tu)
-            mf_edt, mm = _median_wall(lambda: mf_ev.evaluate_factors(mf.P, mf.Q, tu))
-            mf_info["eval"] = {"users_per_sec": tu.numel() / mf_edt, "ms": mf_edt * 1e3, "n_users": int(tu.numel()),
-                               "ndcg@10": float(mm[2 * 20 + 9]), "search": getattr(mf_ev, "search_used", None),
-                               "rows_redone": int(getattr(mf_ev, "n_flagged", 0))}
-            del mf_ev
+        mf_info, mf = leg_mf(train, test, trc, tec, dev, args.eval_batch, args.eval_mode, not args.no_eval, False)
 
     # ---------------- evaluation leg: users/sec + NDCG@10 (full rank, all users with test items)
     eval_info = None
@@ -1327,6 +1558,7 @@ def main():
                        "dp%d (replicated tables, one all-reduce of dL/dE0 per step)" % comm.world)
                    if comm.active else "single GPU"},
         "final_loss": [float(x) for x in loss2.cpu().numpy()], "timed_region": timed_region,
+        "epoch_timed": epoch_timed,
         "epoch_amortised": {"value": epoch_amortised, "unit": "triplets/s",
                             "note": "one epoch = %d steps at the measured step time + the per-epoch sampler and "
                                     "batch-plan launches (%.3f ms, HIP events): E / epoch wall time, SURVEY 8d's "
@@ -1334,6 +1566,12 @@ def main():
         "eval": eval_info, "mf": mf_info, "roofline": roofline,
         "device": E.device_info(),
     }
+    if config4 and config4_eval:
+        try:
+            ev4 = _config4_eval(full, comm, trc, I, args.dim, dev, 65536)
+        except Exception as e:
+            ev4 = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["eval"] = ev4
     if colshard:
         # the step's ONE exchange measured on its own (not asserted): all-gather of the per-triplet
         # partial products + the rank-order sums, wall clock between device synchronisations, median of 20
@@ -1416,7 +1654,8 @@ def main():
         torch.cuda.empty_cache()
         for key, hop in (("rowshard_config4_law", None), ("rowshard_config4_law_reduce", "reduce")):
             try:
-                leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0, hop=hop)
+                leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0, hop=hop,
+                                  eval_users=65536 if (hop is None and not no_eval_legs) else 0)
             except Exception as e:      # a secondary leg must not take the headline (already measured above) down
                 leg = {"error": "%s: %s" % (type(e).__name__, e)}
             if comm.rank == 0:
@@ -1456,10 +1695,32 @@ def main():
         if not args.no_config5:
             line["ngcf"] = leg_ngcf(train, test, trc, tec, dev, not args.no_cpu_baseline)
             line["multivae"] = leg_multivae(train, test, trc, tec, dev, not args.no_cpu_baseline)
+    if comm.rank == 0 and comm.world == 1 and not config4 and default_workload and not args.no_mf:
+        # BASELINE configs[0] (conf/MF.properties on ml-100k, the reference's own CPU-runnable case): the real split of
+        # dataset/ml-100k.rating under the default NeuRec.properties (ratio 0.8) as committed with the golden epoch
+        # (tests/golden/tfgraph_ml100k_mf_epoch.npz — the reference tree does not travel), else the synthetic twin
+        import scipy.sparse as sp
+        fx = os.path.join(ROOT, "tests", "golden", "tfgraph_ml100k_mf_epoch.npz")
+        if os.path.isfile(fx):
+            z = np.load(fx)
+            shp = (int(z["n_users"]), int(z["n_items"]))
+            csr = lambda ptr, idx: sp.csr_matrix((np.ones(len(idx), np.float32), idx, ptr), shape=shp)
+            tr1, te1 = csr(z["train_indptr"], z["train_indices"]), csr(z["test_indptr"], z["test_indices"])
+            src = "the reference's real ml-100k split (80,367 train / 19,633 test pairs; fixture of the golden epoch)"
+        else:
+            tr1, te1 = synth.interactions("ml-100k", seed=2018)
+            src = "synthetic ml-100k-shaped twin (neurec_amd/synth.py)"
+        try:
+            line["ml100k"], _ = leg_mf(tr1, te1, E.DeviceCSR.from_scipy(tr1), E.DeviceCSR.from_scipy(te1), dev,
+                                       args.eval_batch, args.eval_mode, not args.no_eval, not args.no_cpu_baseline,
+                                       label="ml-100k")
+            line["ml100k"]["data"] = src
+        except Exception as e:                                # a secondary leg must not take the headline down
+            line["ml100k"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if comm.rank == 0 and comm.world == 1 and not config4 and default_workload and not args.no_config4:
         ev = mf_ev = None
         torch.cuda.empty_cache()
-        line["config4"] = leg_config4(comm, dev, args.config4_scale)
+        line["config4"] = leg_config4(comm, dev, args.config4_scale, eval_users=0 if args.no_eval else 65536)
         try:
             line["config4"]["partitions"] = leg_config4_partitions(dev, args.config4_scale)
         except Exception as e:                                # a measurement leg must not take the headline down

@@ -762,25 +762,44 @@ __global__ __launch_bounds__(256) void tile_pairs_kernel(const int32_t* __restri
 }
 
 // chunk_begin[t] = sum over t' < t of ceil(cnt[t'] / 32); chunk_begin[n_tiles] = the number of chunks.  One workgroup.
+// pair_begin (the compact form): the packed bucket starts, pair_begin[t] = sum over t' < t of cnt[t'].
 __global__ __launch_bounds__(1024) void chunk_scan_kernel(int32_t* __restrict__ gcnt, int n_tiles, int cap,
-                                                          int32_t* __restrict__ chunk_begin) {
+                                                          int32_t* __restrict__ chunk_begin,
+                                                          int32_t* __restrict__ pair_begin) {
   __shared__ int32_t s_sum[1024];
+  __shared__ int32_t s_pairs[1024];
   const int tid = threadIdx.x;
   const int per = (n_tiles + 1023) / 1024;
   const int b = tid * per, e = min(n_tiles, b + per);
-  int local = 0;
-  for (int t = b; t < e; ++t) local += (min(gcnt[t], cap) + 31) >> 5;
+  int local = 0, pairs = 0;
+  for (int t = b; t < e; ++t) {
+    const int c = min(gcnt[t], cap);
+    local += (c + 31) >> 5;
+    pairs += c;
+  }
   s_sum[tid] = local;
+  s_pairs[tid] = pairs;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
     const int v = tid >= off ? s_sum[tid - off] : 0;
+    const int q = tid >= off ? s_pairs[tid - off] : 0;
     __syncthreads();
     s_sum[tid] += v;
+    s_pairs[tid] += q;
     __syncthreads();
   }
-  int run = s_sum[tid] - local;
-  for (int t = b; t < e; ++t) { chunk_begin[t] = run; run += (min(gcnt[t], cap) + 31) >> 5; }
-  if (tid == 1023) chunk_begin[n_tiles] = s_sum[1023];
+  int run = s_sum[tid] - local, prun = s_pairs[tid] - pairs;
+  for (int t = b; t < e; ++t) {
+    const int c = min(gcnt[t], cap);
+    chunk_begin[t] = run;
+    run += (c + 31) >> 5;
+    if (pair_begin) pair_begin[t] = prun;
+    prun += c;
+  }
+  if (tid == 1023) {
+    chunk_begin[n_tiles] = s_sum[1023];
+    if (pair_begin) pair_begin[n_tiles] = s_pairs[1023];
+  }
   __syncthreads();
   for (int t = b; t < e; ++t) gcnt[t] = min(gcnt[t], cap);     // (the later kernels read the clamped counts)
 }
@@ -793,12 +812,83 @@ __global__ __launch_bounds__(256) void chunk_list_kernel(const int32_t* __restri
   for (int c = lane; c < n; c += 64) chunks[base + c] = make_int2(t, 32 * c);
 }
 
+// ---- the COMPACT bucket form: any number of tiles (r06; BASELINE configs[3] has 31,250 32-item tiles) -------------
+// The strided form above gives every tile a bucket of `rows` slots (n_tiles x rows x 4 bytes: 153 MB at gowalla, 4 GB
+// at 10^6 items x 32,768 rows) and an LDS histogram of all tiles.  Here the buckets are packed (rows x n_keep slots in
+// all) and the LDS histogram covers a WINDOW of kPairWindow tiles at a time, so nothing depends on the item count:
+//   tile_count_kernel     pairs per tile (per window: LDS counts, one global atomic per (workgroup, tile))
+//   chunk_scan_kernel<1>  pair_begin[t] = packed bucket starts next to chunk_begin[t]
+//   tile_fill_kernel      the same windows again: one reservation per (workgroup, tile) in the tile's bucket, LDS
+//                         cursors hand the slots out
+// The order of the pairs inside a bucket depends on the atomics; no result does (every pair is independent).
+constexpr int kPairWindow = 12288;                             // tiles per LDS window (48 KB)
+
+__device__ __forceinline__ int pair_tile(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep, int r0, int p,
+                                         int n_tiles) {
+  const int t = tiles[(int64_t)(r0 + p / n_keep) * tiles_ld + p % n_keep];
+  return (unsigned)t >= (unsigned)n_tiles ? 0 : t;             // NaN tables: garbage ids stay in range
+}
+
+__global__ __launch_bounds__(256) void tile_count_kernel(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep,
+                                                         int rows, int n_tiles, int32_t* __restrict__ gcnt) {
+  __shared__ int32_t s_hist[kPairWindow];
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * kPairRows;
+  const int n_pairs = min(kPairRows, rows - r0) * n_keep;
+  for (int w0 = 0; w0 < n_tiles; w0 += kPairWindow) {
+    const int wn = min(kPairWindow, n_tiles - w0);
+    for (int i = tid; i < wn; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < n_pairs; p += 256) {
+      const int t = pair_tile(tiles, tiles_ld, n_keep, r0, p, n_tiles) - w0;
+      if ((unsigned)t < (unsigned)wn) atomicAdd(&s_hist[t], 1);
+    }
+    __syncthreads();
+    for (int t = tid; t < wn; t += 256)
+      if (s_hist[t]) atomicAdd(&gcnt[w0 + t], s_hist[t]);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_fill_kernel(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep,
+                                                        int rows, int n_tiles, const int32_t* __restrict__ pair_begin,
+                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ tilemap,
+                                                        uint32_t* __restrict__ bucket) {
+  __shared__ int32_t s_hist[kPairWindow];                      // counts, then the bucket cursors
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * kPairRows;
+  const int n_pairs = min(kPairRows, rows - r0) * n_keep;
+  for (int p = tid; p < n_pairs; p += 256)
+    tilemap[(int64_t)(r0 + p / n_keep) * n_keep + p % n_keep] = pair_tile(tiles, tiles_ld, n_keep, r0, p, n_tiles);
+  for (int w0 = 0; w0 < n_tiles; w0 += kPairWindow) {
+    const int wn = min(kPairWindow, n_tiles - w0);
+    for (int i = tid; i < wn; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < n_pairs; p += 256) {
+      const int t = pair_tile(tiles, tiles_ld, n_keep, r0, p, n_tiles) - w0;
+      if ((unsigned)t < (unsigned)wn) atomicAdd(&s_hist[t], 1);
+    }
+    __syncthreads();
+    for (int t = tid; t < wn; t += 256) {
+      const int c = s_hist[t];
+      if (c) s_hist[t] = pair_begin[w0 + t] + atomicAdd(&cursor[w0 + t], c);   // ONE reservation per (workgroup, tile)
+    }
+    __syncthreads();
+    for (int p = tid; p < n_pairs; p += 256) {
+      const int t = pair_tile(tiles, tiles_ld, n_keep, r0, p, n_tiles) - w0;
+      if ((unsigned)t < (unsigned)wn)
+        bucket[atomicAdd(&s_hist[t], 1)] = ((uint32_t)(r0 + p / n_keep) << 6) | (uint32_t)(p % n_keep);
+    }
+    __syncthreads();
+  }
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void rescore_pairs_kernel(
     const float* __restrict__ P, int64_t ldp, int d, const float* __restrict__ QT, int64_t ipad, int cols,
     const int32_t* __restrict__ users, int rows, const int32_t* __restrict__ gcnt,
     const int32_t* __restrict__ chunk_begin, int n_tiles, const int2* __restrict__ chunks,
-    const uint32_t* __restrict__ bucket, float* __restrict__ C, int64_t cld) {
+    const uint32_t* __restrict__ bucket, const int32_t* __restrict__ pair_begin, float* __restrict__ C, int64_t cld) {
   constexpr int DP = 2 * KS;
   __shared__ float sB[4][32][DP + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -809,7 +899,7 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(
   const int t = ck.x;
   const int n = min(32, gcnt[t] - ck.y);
   uint32_t pair = 0u;
-  if (j < n) pair = bucket[(int64_t)t * rows + ck.y + j];
+  if (j < n) pair = bucket[(pair_begin ? (int64_t)pair_begin[t] : (int64_t)t * rows) + ck.y + j];   // packed / strided buckets
   const int row = (int)(pair >> 6), slot = (int)(pair & 63u);
   const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
   float a[KS], b[KS];
@@ -1151,22 +1241,41 @@ int nrhip_eval_scores_any_k(const float* d_scores, int64_t ld, int rows, int col
 // tile-grouped rescoring (rescore_pairs_kernel): extra workspace behind the per-row form's; 0 = not used at this shape
 // (more tiles than the LDS histogram holds, or buckets beyond 1 GB: the per-row kernel runs)
 static int g_rescore_grouped = -1;
-static bool rescore_grouped_enabled() {
+// NEUREC_RESCORE_GROUPED: 0 = the per-row rescoring kernel, 2 = the compact bucket form at every shape (tests: the form
+// large item counts take, exercised on small ones); default: strided buckets where they fit, compact buckets beyond
+static int rescore_grouped_mode() {
   if (g_rescore_grouped < 0) {
     const char* e = getenv("NEUREC_RESCORE_GROUPED");
-    g_rescore_grouped = (e && e[0] == '0') ? 0 : 1;
+    g_rescore_grouped = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
   }
-  return g_rescore_grouped != 0;
+  return g_rescore_grouped;
 }
-static size_t grouped_extra_bytes(int rows, int cols, int n_keep) {
+enum GroupedForm { kGroupedNone = 0, kGroupedStrided = 1, kGroupedCompact = 2 };
+static size_t grouped_form_bytes(int form, int rows, int cols, int n_keep) {
   const size_t r = (size_t)(rows > 0 ? rows : 1);
   const size_t n_tiles = 2 * (((size_t)cols + 63) / 64);
-  if (!rescore_grouped_enabled() || n_tiles > (size_t)kMaxGroupedTiles || n_tiles * r * 4 > ((size_t)1 << 30) ||
-      r >= ((size_t)1 << 26))
-    return 0;
   const size_t max_chunks = r * (size_t)n_keep / 32 + n_tiles + 1;
-  return nr_align_up((n_tiles + r) * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
-         nr_align_up(n_tiles * r * 4, 256);                     // counts + overflow flags | chunk starts | chunks | buckets
+  if (form == kGroupedStrided) {
+    if (n_tiles > (size_t)kMaxGroupedTiles || n_tiles * r * 4 > ((size_t)1 << 30) || r >= ((size_t)1 << 26)) return 0;
+    return nr_align_up((n_tiles + r) * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
+           nr_align_up(n_tiles * r * 4, 256);                   // counts + overflow flags | chunk starts | chunks | buckets
+  }
+  if (form == kGroupedCompact) {
+    if (r >= ((size_t)1 << 26) || r * (size_t)n_keep >= ((size_t)1 << 31)) return 0;
+    // counts + bucket cursors | chunk starts | bucket starts | chunks | packed buckets
+    return nr_align_up(2 * n_tiles * 4, 256) + 2 * nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
+           nr_align_up(r * (size_t)n_keep * 4, 256);
+  }
+  return 0;
+}
+// the form a batch of `rows` rows takes (0: the per-row kernel) and its workspace behind the per-row form's
+static int grouped_form(int rows, int cols, int n_keep, size_t* bytes) {
+  const int mode = rescore_grouped_mode();
+  *bytes = 0;
+  if (mode == 0) return kGroupedNone;
+  if (mode == 1 && (*bytes = grouped_form_bytes(kGroupedStrided, rows, cols, n_keep)) != 0) return kGroupedStrided;
+  if ((*bytes = grouped_form_bytes(kGroupedCompact, rows, cols, n_keep)) != 0) return kGroupedCompact;
+  return kGroupedNone;
 }
 static size_t eval_tiles_ws_bytes(int rows, int n_keep) {
   const size_t r = (size_t)(rows > 0 ? rows : 1);
@@ -1190,10 +1299,16 @@ int nrhip_eval_tiles_bounded_workspace_bytes(int rows, int cols, int top_k, int 
   // a workspace sized for `rows` serves every batch of up to `rows` rows (a loop sizes it once for its
   // full batches and a SHORT last batch may take the tile-grouped path the full ones were too large for): the
   // grouped part is the largest any row count up to `rows` can ask for
+  // the strided form serves row counts up to r_group (its buckets grow with rows x tiles), the compact form any
   const size_t n_tiles = 2 * (((size_t)cols + 63) / 64);
   const size_t r_group = std::min<size_t>((size_t)(rows > 0 ? rows : 1),
                                           std::min<size_t>(((size_t)1 << 30) / (n_tiles * 4), ((size_t)1 << 26) - 1));
-  *bytes = eval_tiles_ws_bytes(rows, n_keep) + (r_group ? grouped_extra_bytes((int)r_group, cols, n_keep) : 0);
+  size_t extra = 0;
+  if (rescore_grouped_mode() != 0) {
+    if (r_group) extra = grouped_form_bytes(kGroupedStrided, (int)r_group, cols, n_keep);
+    extra = std::max(extra, grouped_form_bytes(kGroupedCompact, rows, cols, n_keep));
+  }
+  *bytes = eval_tiles_ws_bytes(rows, n_keep) + extra;
   return NR_OK;
 }
 
@@ -1234,9 +1349,14 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     mids.id[i] = metric_ids_host[i];
   }
   if (rows == 0) return NR_OK;
-  size_t extra = grouped ? grouped_extra_bytes(rows, cols, n_keep) : 0;
-  // a workspace without room for the tile buckets runs the per-row rescoring (same results) instead of failing
-  if (extra && ws_bytes < eval_tiles_ws_bytes(rows, n_keep) + extra) extra = 0;
+  size_t extra = 0;
+  int form = grouped ? grouped_form(rows, cols, n_keep, &extra) : kGroupedNone;
+  // a workspace without room for the form's buckets takes the packed form, then the per-row rescoring (same results)
+  if (form == kGroupedStrided && ws_bytes < eval_tiles_ws_bytes(rows, n_keep) + extra) {
+    extra = grouped_form_bytes(kGroupedCompact, rows, cols, n_keep);
+    form = extra ? kGroupedCompact : kGroupedNone;
+  }
+  if (form != kGroupedNone && ws_bytes < eval_tiles_ws_bytes(rows, n_keep) + extra) { form = kGroupedNone; extra = 0; }
   NR_REQUIRE(ws_bytes >= eval_tiles_ws_bytes(rows, n_keep) + extra, NR_ERR_WORKSPACE,
              "eval_tiles: workspace %zu < %zu bytes", ws_bytes, eval_tiles_ws_bytes(rows, n_keep) + extra);
   hipStream_t st = (hipStream_t)stream;
@@ -1266,22 +1386,44 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   }
   // 2. rescore the chosen tiles, train items struck out
   int32_t* overflow = nullptr;
-  if (extra) {
+  if (form != kGroupedNone) {
     char* x = (char*)d_ws + eval_tiles_ws_bytes(rows, n_keep);
-    int32_t* gcnt = (int32_t*)x;        x += nr_align_up(((size_t)n_tiles + rows) * 4, 256);
-    overflow = gcnt + n_tiles;
-    int32_t* chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
-    int2* chunks = (int2*)x;
     const size_t max_chunks = (size_t)rows * n_keep / 32 + n_tiles + 1;
-    x += nr_align_up(max_chunks * 8, 256);
-    uint32_t* bucket = (uint32_t*)x;
-    NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, ((size_t)n_tiles + rows) * 4, st));
-    hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
-                       (size_t)n_tiles * 4, st, tiles, tiles_ld, n_keep, rows, n_tiles, tilemap,
-                       gcnt, bucket, overflow);
-    NR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, gcnt, n_tiles, rows, chunk_begin);
-    NR_LAUNCH_CHECK();
+    int32_t *gcnt, *chunk_begin, *pair_begin = nullptr;
+    int2* chunks;
+    uint32_t* bucket;
+    if (form == kGroupedStrided) {
+      gcnt = (int32_t*)x;        x += nr_align_up(((size_t)n_tiles + rows) * 4, 256);
+      overflow = gcnt + n_tiles;
+      chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
+      chunks = (int2*)x;         x += nr_align_up(max_chunks * 8, 256);
+      bucket = (uint32_t*)x;
+      NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, ((size_t)n_tiles + rows) * 4, st));
+      hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
+                         (size_t)n_tiles * 4, st, tiles, tiles_ld, n_keep, rows, n_tiles, tilemap,
+                         gcnt, bucket, overflow);
+      NR_LAUNCH_CHECK();
+      hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, gcnt, n_tiles, rows, chunk_begin,
+                         (int32_t*)nullptr);
+      NR_LAUNCH_CHECK();
+    } else {
+      gcnt = (int32_t*)x;        x += nr_align_up(2 * (size_t)n_tiles * 4, 256);
+      int32_t* cursor = gcnt + n_tiles;
+      chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
+      pair_begin = (int32_t*)x;  x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
+      chunks = (int2*)x;         x += nr_align_up(max_chunks * 8, 256);
+      bucket = (uint32_t*)x;
+      const dim3 wg((rows + kPairRows - 1) / kPairRows);
+      NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, 2 * (size_t)n_tiles * 4, st));
+      hipLaunchKernelGGL(tile_count_kernel, wg, dim3(256), 0, st, tiles, tiles_ld, n_keep, rows, n_tiles, gcnt);
+      NR_LAUNCH_CHECK();
+      // (a packed bucket holds every pair of its tile: no cap, no overflow rows)
+      hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, st, gcnt, n_tiles, INT_MAX, chunk_begin, pair_begin);
+      NR_LAUNCH_CHECK();
+      hipLaunchKernelGGL(tile_fill_kernel, wg, dim3(256), 0, st, tiles, tiles_ld, n_keep, rows, n_tiles, pair_begin,
+                         cursor, tilemap, bucket);
+      NR_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(chunk_list_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, gcnt, chunk_begin, n_tiles,
                        chunks);
     NR_LAUNCH_CHECK();
@@ -1289,7 +1431,7 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     const int dp = d <= 16 ? 16 : d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : 128;
 #define NR_PAIRS_CASE(KS)                                                                                        \
   hipLaunchKernelGGL(rescore_pairs_kernel<KS>, pgrid, dim3(256), 0, st, d_P, ldp, d, qt, (int64_t)ipad, cols,     \
-                     d_users, rows, gcnt, chunk_begin, n_tiles, chunks, bucket, C, cld)
+                     d_users, rows, gcnt, chunk_begin, n_tiles, chunks, bucket, pair_begin, C, cld)
     switch (dp) {
       case 16: NR_PAIRS_CASE(8); break;
       case 32: NR_PAIRS_CASE(16); break;

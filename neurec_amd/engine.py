@@ -95,6 +95,30 @@ class DeviceCSR:
             indices[b:b + len(items)] = np.sort(np.asarray(items, dtype=np.int32))
         return DeviceCSR(indptr, indices, n_cols)
 
+    def rows(self, lo, hi):
+        """rows [lo, hi) as a CSR of their own (row r = row lo + r here; the columns stay): a rank's users of a
+        row-sharded evaluation (sharded.ShardedEvaluator)"""
+        lo, hi = int(lo), int(hi)
+        b, e = int(self.h_indptr[lo]), int(self.h_indptr[hi])
+        idx = self.indices[b:e] if e > b else torch.zeros(1, dtype=torch.int32, device=self.indices.device)
+        return DeviceCSR(self.indptr[lo:hi + 1] - b, idx, self.n_cols)
+
+    def check_sorted(self, n_cols=None):
+        """Raises ValueError unless every row's indices ascend strictly and lie in [0, n_cols): what the planned
+        strikes of the pruned evaluation assume of a train matrix (one device pass, one host read)."""
+        n_cols = self.n_cols if n_cols is None else int(n_cols)
+        if self.nnz == 0:
+            return
+        idx = self.indices[:self.nnz].long()
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= n_cols:
+            raise ValueError("CSR column ids span [%d, %d], outside [0, %d)" % (lo, hi, n_cols))
+        if self.nnz > 1:
+            key = self.row_of().long() * n_cols + idx
+            if bool((key[1:] <= key[:-1]).any()):
+                raise ValueError("CSR rows must hold strictly ascending column ids (sort and de-duplicate the rows: "
+                                 "DeviceCSR.from_scipy does)")
+
     def row_of(self):
         """User id of every CSR position (users_list of data/sampler.py:24-39)."""
         if self.nnz == 0:
@@ -378,6 +402,8 @@ class TileStrikePlan:
     def __init__(self, train_csr, cols=None):
         dev = train_csr.indptr.device
         self.cols = int(train_csr.n_cols if cols is None else cols)
+        # the head-of-pair rule of the native build needs ascending rows, its histograms ids below cols
+        train_csr.check_sorted(self.cols)
         U, nnz = int(train_csr.n_rows), int(train_csr.nnz)
         n_tiles = 2 * ((self.cols + 63) // 64)
         i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)

@@ -708,8 +708,29 @@ class ShardedLightGCN:
         for s in range(self.S):
             self.A.matmul(self._xbuf(0) if self.comm.live else self.E0[s], out=out[s], addend=self.H[s])
 
+    def eval_factors(self):
+        """The evaluation entrance of a row-sharded run: (this rank's user rows of E* [nu][d], the WHOLE item table of
+        E* [I][d]).  uni_evaluator.py:101-157 scores a batch of users against every item, so a rank needs all item rows
+        but only ITS users: the item blocks are all-gathered (config 4: 0.5 GB arrive per rank), the 5.1 GB user
+        table never moves.  Same bits as the rows final_embeddings() returns."""
+        esum = self.propagate()
+        dev, d, w = esum.device, self.d, self.w
+        bu, bi = self.part.bu, self.part.bi
+        users = torch.empty((self.nu, d), dtype=torch.float32, device=dev)
+        block = torch.zeros((bi, d), dtype=torch.float32, device=dev)        # my items, padded to the block
+        loc = torch.empty((self.b, w), dtype=torch.float32, device=dev)
+        for s in range(self.S):
+            E.div_scalar(esum[s], float(self.L + 1), loc)
+            users[:, s * w:(s + 1) * w] = loc[:self.nu]
+            block[:self.ni, s * w:(s + 1) * w] = loc[bu:bu + self.ni]
+        del loc
+        items = torch.empty((self.world * bi, d), dtype=torch.float32, device=dev)
+        self.comm.all_gather_rows(block, items)      # item blocks in rank order ARE the item table in id order
+        return users, items[:self.n_items]
+
     def final_embeddings(self):
-        """Full (user, item) tables on every rank (one all-gather per slab; evaluation entrance)."""
+        """Full (user, item) tables on every rank (one all-gather per slab).  Small models and tests; an evaluation
+        takes eval_factors() — only the item table travels."""
         esum = self.propagate()
         loc = torch.empty((self.b, self.w), dtype=torch.float32, device=esum.device)
         us, its = [], []
@@ -861,3 +882,48 @@ class ShardedMF:
         if self._gidx is None:
             self._gidx = self.part.gathered_index(full.device)
         return full[self._gidx[0]], full[self._gidx[1]]
+
+
+class ShardedEvaluator:
+    """Full-rank evaluation of a row-sharded model (SURVEY 8e "Evaluator"; uni_evaluator.py:101-157 on one process):
+    users are independent units, so every rank ranks ITS users — rows [ulo, uhi) of the BipartitePartition — against
+    the whole item table and the M·K metric sums are added over the ranks once (one all-reduce of M·K + 1 doubles).
+    Nothing but the item table (ShardedLightGCN.eval_factors) and those sums is exchanged.
+
+    train_rows / test_rows: DeviceCSR of this rank's users ONLY (row r = user ulo + r, global item ids) — e.g.
+    DeviceCSR.rows(ulo, uhi) of the whole matrices; the strike plan and the user -> row table of the pruned path
+    are then built over the rank's users, not over all 10^7."""
+
+    def __init__(self, comm, train_rows, test_rows, metric_ids, top_k, batch_rows=8192, **evaluator_args):
+        from .trainer import FullRankEvaluator
+        if train_rows.n_rows != test_rows.n_rows:
+            raise ValueError("train and test rows of a rank cover the same users")
+        self.comm = comm
+        self.ev = FullRankEvaluator(train_rows, test_rows, metric_ids, top_k, batch_rows=batch_rows, **evaluator_args)
+        dev = test_rows.indptr.device
+        has = (test_rows.indptr[1:] - test_rows.indptr[:-1]) > 0          # tool.py:63: users without test items are skipped
+        self.users = torch.nonzero(has, as_tuple=False).flatten().to(torch.int32)
+        self.n_local = int(self.users.numel())
+        self.n_out = len(self.ev.metric_ids) * self.ev.top_k
+        t = torch.tensor([float(self.n_local)], dtype=torch.float64, device=dev)
+        comm.allreduce_sum_(t)
+        self.n_total = int(t.item())
+
+    def evaluate_factors(self, user_rows, item_table):
+        """user_rows [nu][d]: this rank's rows of the user factors; item_table [I][d].  -> fp64 means [M·K] over ALL
+        ranks' test users (the same numbers on every rank)."""
+        dev = item_table.device
+        both = torch.zeros(self.n_out + 1, dtype=torch.float64, device=dev)
+        if self.n_local:
+            sums = self.ev.evaluate_factors(user_rows, item_table, self.users, column_sums=True)
+            both[:self.n_out] = torch.from_numpy(np.asarray(sums, np.float64)).to(dev)
+            both[self.n_out] = float(self.ev.n_flagged)
+        self.comm.allreduce_sum_(both)
+        host = both.cpu().numpy()
+        self.rows_redone = int(host[-1])
+        return host[:-1] / max(self.n_total, 1)
+
+    def evaluate(self, engine):
+        """engine: ShardedLightGCN (anything with eval_factors())."""
+        eu, items = engine.eval_factors()
+        return self.evaluate_factors(eu, items)

@@ -185,3 +185,30 @@ def device_lightgcn_rank_rows(indptr, indices, n_users, n_items, user_range, ite
     pi, ii, vi = device_lightgcn_adjacency(indptr, indices, n_users, n_items, n_users + item_range[0],
                                            n_users + item_range[1])
     return torch.cat([pu, pi[1:] + pu[-1]]), torch.cat([iu, ii]), torch.cat([vu, vi])
+
+
+def device_test_rows(train_rows, n_items, per_user=2, seed=2019):
+    """A synthetic test split for a block of users of a device-generated graph (the config-4 evaluation leg):
+    `per_user` uniform item draws per user, duplicates and the user's TRAIN items dropped (dataset.py's splits are
+    disjoint) — so a few users end up with fewer, or no, test items and are skipped like tool.py:63 skips them.
+    train_rows: engine.DeviceCSR of those users.  Returns an engine.DeviceCSR with the same rows."""
+    import torch
+    from . import engine as E
+    dev = train_rows.indptr.device
+    n = train_rows.n_rows
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    owner = torch.arange(n, device=dev).repeat_interleave(per_user)
+    items = torch.randint(0, n_items, (owner.numel(),), generator=g, device=dev)
+    key = torch.unique(owner * n_items + items)
+    if train_rows.nnz:
+        tkey = train_rows.row_of().long() * n_items + train_rows.indices[:train_rows.nnz].long()   # ascending
+        pos = torch.searchsorted(tkey, key).clamp_(max=tkey.numel() - 1)
+        key = key[tkey[pos] != key]
+    users = torch.div(key, n_items, rounding_mode="floor")
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(users, minlength=n), 0)
+    idx = (key - users * n_items).to(torch.int32)
+    if idx.numel() == 0:
+        idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    return E.DeviceCSR(indptr, idx, n_items)

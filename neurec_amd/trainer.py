@@ -520,17 +520,21 @@ class FullRankEvaluator:
         self._side = None
         self._flags = None                   # pruned path: per-user "ranking may depend on ties" flags of the last run
 
-    def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False, per_user=False):
+    def evaluate_factors(self, user_table, item_table, test_users, exact_mean=False, per_user=False, column_sums=False):
         """Returns float64 column means [n_metric*top_k] (or the fp32 np.mean when
         exact_mean) over `test_users` (int32 device tensor); per_user: the [n][n_metric*top_k] fp32
-        matrix cpp_evaluate_matrix returns (evaluate.h:53-72), one row per test user."""
+        matrix cpp_evaluate_matrix returns (evaluate.h:53-72), one row per test user; column_sums: the fp64 column
+        SUMS, undivided (a rank's share of a sharded evaluation: the ranks' sums are added, then divided once)."""
         want_rows = per_user
         n = test_users.numel()
         nm = len(self.metric_ids)
         if self._gemm is None or self._gemm.cols != item_table.shape[0] or \
                 self._gemm.d != item_table.shape[1]:
             self._gemm = E.score_gemm_for(item_table, self.batch_rows)
-            self._scores = [self._gemm.new_score_buffer()]
+            # score slabs [slab_rows][I]: the materialised path's batch, the pruned path's redo rows — made when first
+            # needed, and never wider than 1 GiB (at 10^6 items a batch_rows slab would be 32 GB for rows that are
+            # almost never redone)
+            self._scores = []
             self._filter = None
         else:
             self._gemm.prepare(item_table)
@@ -544,15 +548,15 @@ class FullRankEvaluator:
         elif not self.overlap or len(starts) < 2:
             for b in starts:
                 u = test_users[b:b + self.batch_rows]
-                S = self._gemm(user_table, u, out=self._scores[0])
+                S = self._gemm(user_table, u, out=self._slab(0, self.batch_rows))
                 E.mask_train(S, u, self.train, cols=cols)
                 E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
                               out=per_user[b:b + u.numel()])
         else:
             # two score slabs, two HIP streams: GEMM + mask of batch b+1 on the current stream,
             # top-K + metrics of batch b on the side stream; events order the slab hand-offs
-            if len(self._scores) < 2:
-                self._scores.append(self._gemm.new_score_buffer())
+            self._slab(0, self.batch_rows)
+            self._slab(1, self.batch_rows)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=test_users.device)
             main, side = torch.cuda.current_stream(), self._side
@@ -576,6 +580,7 @@ class FullRankEvaluator:
             self._note_flags()
             rows = per_user.cpu().numpy()
             return rows if want_rows else np.mean(rows, axis=0)   # uni_evaluator.py:150-151
+        div = 1 if column_sums else n
         # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
         # travel together; only if some row was flagged are those rows redone and the sums retaken
         if self._native_sums is not None:                 # nrhip_eval_pruned left the sums and the flag count together
@@ -584,15 +589,24 @@ class FullRankEvaluator:
         else:
             sums = E.colsum(per_user)
             if self._flags is None:
-                return sums.cpu().numpy() / n      # every mean is the fp64 column sum divided ON THE HOST (a device-side
+                return sums.cpu().numpy() / div    # every mean is the fp64 column sum divided ON THE HOST (a device-side
                 #                                    scalar division may be a reciprocal multiply: last-ulp differences)
             both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
         self.n_flagged = int(both[-1])
         self._note_flags()
         if self.n_flagged:
             self._redo_flagged(user_table, item_table, test_users, per_user)
-            return E.colsum(per_user).cpu().numpy() / n
-        return both[:-1] / n
+            return E.colsum(per_user).cpu().numpy() / div
+        return both[:-1] / div
+
+    def _slab(self, k, rows):
+        """score slab k with room for `rows` rows"""
+        while len(self._scores) <= k:
+            self._scores.append(None)
+        if self._scores[k] is None or self._scores[k].shape[0] < rows:
+            self._scores[k] = None
+            self._scores[k] = self._gemm.new_score_buffer(rows)
+        return self._scores[k]
 
     def _note_flags(self):
         if getattr(self, "search_used", None) == "int8" and self.n_flagged > 0 and self.search == "int8":
@@ -688,10 +702,12 @@ class FullRankEvaluator:
         if self.n_flagged:
             fixed = torch.empty((self.n_flagged, per_user.shape[1]), dtype=torch.float32,
                                 device=per_user.device)
-            for lo in range(0, self.n_flagged, self.batch_rows):
-                idx = redo[lo:lo + self.batch_rows]
+            # full fp32 rows, at most 1 GiB of them at a time
+            step = max(1, min(self.batch_rows, (1 << 28) // max(self._gemm.ld, 1)))
+            for lo in range(0, self.n_flagged, step):
+                idx = redo[lo:lo + step]
                 u = test_users[idx].contiguous()
-                S = self._gemm(user_table, u, out=self._scores[0])
+                S = self._gemm(user_table, u, out=self._slab(0, min(step, self.n_flagged)))
                 E.mask_train(S, u, self.train, cols=cols)
                 E.eval_scores(S, self.test, self.metric_ids, self.top_k, users=u, cols=cols,
                               out=fixed[lo:lo + u.numel()])
