@@ -606,12 +606,16 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
   }
 }
 
+// limit > 0: ids outside [0, limit) become 0.  The pruned evaluation's tile ids: a row without a single comparable
+// score (a NaN factor row) leaves its rank slots as the workspace held them — whatever a previous call wrote there,
+// item ids of another table included — and every later kernel indexes M / the item copy / the buckets with them.
 __global__ void copy_rank_kernel(const int32_t* __restrict__ rank, int rows, int top_k,
-                                 int32_t* __restrict__ out) {
+                                 int32_t* __restrict__ out, int limit) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)rows * top_k) return;
   const int r = (int)(i / top_k), k = (int)(i % top_k);
-  out[i] = rank[(int64_t)r * kRankStride + k];
+  const int v = rank[(int64_t)r * kRankStride + k];
+  out[i] = (limit > 0 && (unsigned)v >= (unsigned)limit) ? 0 : v;
 }
 
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void mask_train_kernel(
@@ -659,7 +663,10 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
   // ascending tile order keeps "compact column order == item id order" (ties are broken by index)
   const int mine = lane < n_keep ? tiles[(int64_t)row * tiles_ld + lane] : INT_MAX;
   int pos = 0;
-  for (int i = 0; i < n_keep; ++i) pos += (__builtin_amdgcn_readlane(mine, i) < mine) ? 1 : 0;
+  for (int i = 0; i < n_keep; ++i) {                           // (equal ids — a NaN row's clamped garbage — keep lane order:
+    const int o = __builtin_amdgcn_readlane(mine, i);          //  every slot of s_map is written)
+    pos += (o < mine || (o == mine && i < lane)) ? 1 : 0;
+  }
   if (lane < n_keep) { s_map[wave][pos] = mine; tilemap[(int64_t)row * n_keep + pos] = mine; }
   for (int k = lane; k < d; k += NR_WAVE) s_p[wave][k] = P[u * ldp + k];
   wave_lds_sync();
@@ -1381,7 +1388,7 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   {
     const int64_t n = (int64_t)rows * tiles_ld;
     hipLaunchKernelGGL(copy_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.rank,
-                       rows, tiles_ld, tiles);
+                       rows, tiles_ld, tiles, n_tiles);
     NR_LAUNCH_CHECK();
   }
   // 2. rescore the chosen tiles, train items struck out
@@ -1516,7 +1523,7 @@ int nrhip_arg_topk(const float* d_scores, int64_t ld, int rows, int cols, int to
   if (rc != NR_OK) return rc;
   const int64_t n = (int64_t)rows * top_k;
   hipLaunchKernelGGL(copy_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.rank,
-                     rows, top_k, d_out);
+                     rows, top_k, d_out, 0);
   NR_LAUNCH_CHECK();
   if (d_n_exact)
     NR_CHECK_HIP(hipMemcpyAsync(d_n_exact, w.n_exact, sizeof(int32_t), hipMemcpyDeviceToDevice, st));

@@ -104,8 +104,9 @@ class DeviceCSR:
         return DeviceCSR(self.indptr[lo:hi + 1] - b, idx, self.n_cols)
 
     def check_sorted(self, n_cols=None):
-        """Raises ValueError unless every row's indices ascend strictly and lie in [0, n_cols): what the planned
-        strikes of the pruned evaluation assume of a train matrix (one device pass, one host read)."""
+        """Raises ValueError unless every row's indices ascend (a repeated id is tolerated: repeats are neighbours then)
+        and lie in [0, n_cols): what the planned strikes of the pruned evaluation assume of a train matrix (one device
+        pass, one host read)."""
         n_cols = self.n_cols if n_cols is None else int(n_cols)
         if self.nnz == 0:
             return
@@ -115,9 +116,8 @@ class DeviceCSR:
             raise ValueError("CSR column ids span [%d, %d], outside [0, %d)" % (lo, hi, n_cols))
         if self.nnz > 1:
             key = self.row_of().long() * n_cols + idx
-            if bool((key[1:] <= key[:-1]).any()):
-                raise ValueError("CSR rows must hold strictly ascending column ids (sort and de-duplicate the rows: "
-                                 "DeviceCSR.from_scipy does)")
+            if bool((key[1:] < key[:-1]).any()):
+                raise ValueError("CSR rows must hold ascending column ids (sort the rows: DeviceCSR.from_scipy does)")
 
     def row_of(self):
         """User id of every CSR position (users_list of data/sampler.py:24-39)."""

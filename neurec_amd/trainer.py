@@ -991,9 +991,20 @@ class MultiVAEEngine:
                     E.sumsq_accumulate(P[k], self.regsum)
                 E.axpy(2.0 * self.reg, P[k], G[k])
         self.last_anneal = float(anneal)
-        if not apply:
-            return
-        tensors = [(P[k], self.M[k], self.V[k], G[k], k == "Wq0") for k in self.NAMES]
+        if apply:
+            self.apply_gradients()
+
+    def gradient_tensors(self):
+        """the gradients of the last step(apply=False), in NAMES order (replicas.MultiVAEReplicas sums them over ranks)"""
+        return [self.G[k] for k in self.NAMES]
+
+    def set_gradient_tensors(self, tensors):
+        for k, t in zip(self.NAMES, tensors):
+            self.G[k] = t
+
+    def apply_gradients(self):
+        """the update half of a step: the learner on self.G (dW_q0, accumulated by row, is cleared behind it)"""
+        tensors = [(self.P[k], self.M[k], self.V[k], self.G[k], k == "Wq0") for k in self.NAMES]
         if self.learner is None:
             E.adam_dense_multi(tensors, self.adam)
         else:

@@ -182,9 +182,19 @@ class MultiVAEWideEngine:
                     E.sumsq_accumulate(self.params[k], self.regsum)
                 E.axpy(2.0 * self.reg, self.params[k], self.G[k])
         self.last_anneal = float(anneal)
-        if not apply:
-            return
-        tensors = [(self.params[k], self.M[k], self.V[k], self.G[k], k == iWq) for k in range(len(self.params))]
+        if apply:
+            self.apply_gradients()
+
+    def gradient_tensors(self):
+        """the gradients of the last step(apply=False) (replicas.MultiVAEReplicas sums them over ranks)"""
+        return list(self.G)
+
+    def set_gradient_tensors(self, tensors):
+        self.G = list(tensors)
+
+    def apply_gradients(self):
+        """the update half of a step: the learner on self.G (dW_q0, accumulated by row, is cleared behind it)"""
+        tensors = [(self.params[k], self.M[k], self.V[k], self.G[k], k == 0) for k in range(len(self.params))]
         if self.learner is None:
             E.adam_dense_multi(tensors, self.adam)
         else:
