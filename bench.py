@@ -575,7 +575,7 @@ def _config4_eval(lg, comm, trc, I, dim, dev, n_eval, batch_rows=8192, top_k=20)
     fe = ev.ev
     out = {"users_per_sec": ev.n_total / dt, "ms": dt * 1e3, "ms_runs": [r * 1e3 for r in runs], "n_users": ev.n_total,
            "users_per_rank": ev.n_local, "items": I, "dim": dim, "batch_rows": batch_rows,
-           "ndcg@10": float(means[2 * top_k + 9]), "search": fe.search_used, "rows_redone": ev.rows_redone,
+           "ndcg@10": float(means[2 * top_k + 9]), "search": getattr(fe, "search_used", None), "rows_redone": ev.rows_redone,
            "first_call_ms": first_s * 1e3, "factors_ms": factors_s * 1e3,
            "whole_population_seconds": factors_s + lg.n_users / (ev.n_total / dt),
            "sample": "the first %d users of every rank with a synthetic test split (2 uniform draws per user outside the "
@@ -585,9 +585,10 @@ def _config4_eval(lg, comm, trc, I, dim, dev, n_eval, batch_rows=8192, top_k=20)
     # roofline of the search (the dominant kernel) and of the ranking phase, first batch, HIP events on the launch stream
     ub = ev.users[:batch_rows]
     nb = ub.numel()
-    filt = fe._filter if fe.search_used in ("bf16", "int8") else None
-    if nb and fe._plan is not None:
-        n_keep = min(top_k + 1 + fe.extra_tiles + (fe.int8_extra_tiles if fe.search_used == "int8" else 0), 63) \
+    search = getattr(fe, "search_used", None)                  # None: too few tiles for the pruned path (tiny tables)
+    filt = fe._filter if search in ("bf16", "int8") else None
+    if nb and search is not None and fe._plan is not None:
+        n_keep = min(top_k + 1 + fe.extra_tiles + (fe.int8_extra_tiles if search == "int8" else 0), 63) \
             if filt is not None else top_k + 1
         level1 = lambda: fe._gemm.tile_maxima(eu, ub, train_rows, plan=fe._plan, row_of=fe._row_of, filt=filt)
         r1 = level1()
@@ -981,6 +982,8 @@ def compact_line(line):
         legs["colshard_share_ms_%s" % w] = _get(line, "colshard_one_rank_share", w, "ms_per_step")
     legs["same_global_batch_on_1gpu_triplets_per_sec"] = _get(line, "same_global_batch_on_1gpu", "value")
     legs["exchange_ms_per_step"] = _get(line, "exchange_measured", "ms_per_step")
+    legs["strong_scaling_triplets_per_sec"] = _get(line, "strong_scaling", "value")
+    legs["strong_scaling_ms_per_step"] = _get(line, "strong_scaling", "ms_per_step")
     legs["rowshard_config4_law_ms_per_step"] = _get(line, "rowshard_config4_law", "ms_per_step")
     legs["rowshard_config4_law_hop"] = _get(line, "rowshard_config4_law", "hop")
     legs["rowshard_config4_law_hop_ms"] = _get(line, "rowshard_config4_law", "exchange", "hop_ms")
@@ -1017,19 +1020,18 @@ def compact_line(line):
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` from a plain shell (no launcher, WORLD_SIZE unset): start the N ranks here — one
-    process per GPU, the environment torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
-    MASTER_PORT on 127.0.0.1, a free port), the same command line — and wait for them.  Rank 0's stdout (the ONE JSON
+    process per GPU, the environment torch.distributed.run would set (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE),
+    a file-store rendezvous instead of a port, the same command line — and wait for them.  Rank 0's stdout (the ONE JSON
     line) is this process's stdout.  If a rank fails the others are stopped (exactly the PIDs started here) and its
     exit code is returned."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import tempfile
+    # rendezvous through a file store (parallel._rendezvous): no port is picked here and lost before the ranks bind it
+    store = os.path.join(tempfile.mkdtemp(prefix="neurec_bench_"), "store")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUREC_BENCH_SELF_SPAWNED="1")
+                   MASTER_ADDR="127.0.0.1", NEUREC_DIST_INIT_FILE=store, NEUREC_BENCH_SELF_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -1646,6 +1648,32 @@ def main():
         line["same_global_batch_on_1gpu"] = {"value": gB / ms1 * 1e3, "unit": "triplets/s", "ms_per_step": ms1,
                                              "global_batch": gB}
         del lg1, s1, bs1
+    if comm.active and colshard and not config4:
+        # STRONG scaling next to the weak figure: the global batch FIXED at B — exactly the step one
+        # GPU runs, its columns split over the N ranks.  A full-graph LightGCN step costs the same whatever B is, so the
+        # weak figure above grows with N by construction; this one says what N GPUs buy on the SAME work.
+        from neurec_amd.colshard import ColumnShardedLightGCN
+        lgs = ColumnShardedLightGCN(comm, A, U, I, E0, args.layers, 0.01, 1e-3, args.batch)
+        ssm = BprEpochSampler(trc, I, neg_num=1, batch_size=args.batch, shuffle=True, seed=2018, plan_users=U)
+        bss = [b for b in ssm.batches() if b[0].numel() == args.batch][:64]
+        for b in bss[:12]:
+            lgs.step(b[0], b[1], b[2], None, plan=b.plan)
+        torch.cuda.synchronize(); comm.barrier()
+        t0 = time.perf_counter()
+        for b in bss[12:]:
+            lgs.step(b[0], b[1], b[2], None, plan=b.plan)
+        torch.cuda.synchronize(); comm.barrier()
+        dts = comm.max_float(time.perf_counter() - t0) / max(len(bss) - 12, 1)
+        line["strong_scaling"] = {"value": args.batch / dts, "unit": "triplets/s", "ms_per_step": dts * 1e3,
+                                  "global_batch": args.batch, "steps": len(bss) - 12, "partition": "colshard%d" % comm.world,
+                                  "note": "global batch fixed at %d (the 1-GPU step's work split over %d ranks by columns); "
+                                          "compare with the 1-GPU value of the same command line" % (args.batch, comm.world)}
+        del lgs, ssm, bss
+    if comm.active:
+        line["north_star_partition"] = ("north_star names ROW-sharded tables with all-to-all lookups: --dp-mode rowshard "
+                                        "(sharded.ShardedLightGCN), measured here as the rowshard_config4_law* legs; the "
+                                        "headline of an N-rank run is colshard because at the gowalla shape (18 MB of "
+                                        "tables) a per-hop exchange of rows costs more than the hop")
     if comm.active and not args.no_config4 and not config4:
         # row-sharded tables on the config-4 LAW at a fixed per-GPU slice (scale = N/8 of BASELINE configs[3]): the
         # partitioned mode's own weak-scaling leg — every rank a slice of the users and of the items, RCCL all-gather

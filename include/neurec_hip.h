@@ -162,7 +162,7 @@ int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, in
 int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols, int d,
                                float* d_M, int64_t mld, float* d_eps, void* d_ws, size_t ws_bytes, int max_rows,
                                void* stream);
-/* The same bounded filter on the int8 matrix cores (csrc/score_i8.hip; d <= 64): 15-bit fixed point — one scale per
+/* The same bounded filter on the int8 matrix cores (csrc/score_i8.hip; d <= 128): 15-bit fixed point — one scale per
  * user row, one for the whole item table, two int8 planes per entry, three v_mfma_i32_32x32x32_i8 products in exact
  * integer accumulators, the tile maximum taken on the integers.  Same outputs as nrhip_score_filter_tilemax, with a
  * ONE-SIDED contract (what nrhip_eval_tiles_bounded's certificate needs): d_M[r][t] is an upper-bound maximum — the
@@ -209,7 +209,8 @@ int nrhip_eval_tiles_bounded(const float* d_M, int64_t mld, const float* d_eps, 
  * (evaluator/backend/cpp/uni_evaluator.py:101-157) over nrhip_score_filter_tilemax / nrhip_score_filter_i8_tilemax
  * (use_filter = 1 / 2) or nrhip_score_tilemax,
  * nrhip_score_tilemax_fix and nrhip_eval_tiles_bounded, then (d_sums != NULL) the fp64 column sums of d_out and the
- * number of flagged rows in d_sums[n_metric*top_k] — one device->host copy brings the means and says whether any row
+ * number of flagged rows in d_sums[n_metric*top_k] (and, behind it, how many of them failed their certificate: flag
+ * bit 1; bit 0 = ties / bucket overflow) — one device->host copy brings the means and says whether any row
  * must be redone.  Pointers are device pointers except metric_ids (host). */
 typedef struct nrhip_eval_pruned_args {
   const float* d_P; int64_t ldp;                 /* user factors [n_table_users][ldp] */
@@ -230,7 +231,7 @@ typedef struct nrhip_eval_pruned_args {
   float* d_eps;                                  /* [batch_rows] */
   float* d_out;                                  /* [n_users][n_metric*top_k] */
   int32_t* d_flags;                              /* [n_users] */
-  double* d_sums;                                /* [n_metric*top_k + 1] or NULL */
+  double* d_sums;                                /* [n_metric*top_k + 2] or NULL */
   void* d_colsum_ws; size_t colsum_ws_bytes;     /* nrhip_colsum_workspace_bytes(n_users, n_metric*top_k) */
 } NrhipEvalPruned;
 int nrhip_eval_pruned(const NrhipEvalPruned* args, void* stream);

@@ -72,6 +72,14 @@ def build_extension(force=False, verbose=True):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 and FILE_FLAGS.get(src):
+            # the per-file flags are compiler-internal options: a hipcc that does not know one still builds the file
+            # without it (same results, a slower kernel) instead of failing the whole library
+            r2 = subprocess.run([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+            if r2.returncode == 0:
+                sys.stderr.write("neurec_amd.build: %s compiled WITHOUT %s (not accepted by this hipcc)\n"
+                                 % (src, " ".join(FILE_FLAGS[src])))
+                r = r2
         return src, obj, r
 
     objs = []

@@ -9,25 +9,27 @@
 
 namespace {
 
-// sums[n_cols] <- the flagged-row count (as a double, next to the column sums: one device->host copy brings both)
+// out[0] <- the flagged-row count, out[1] <- the rows among them whose certificate failed (flag bit 1), as doubles next
+// to the column sums: one device->host copy brings all of it
 __global__ __launch_bounds__(1024) void count_flags_kernel(const int32_t* __restrict__ flags, int n,
                                                            double* __restrict__ out) {
-  __shared__ int s_part[1024];
-  int c = 0;
+  __shared__ int s_part[1024], s_cert[1024];
+  int c = 0, k = 0;
   for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {         // 8 loads in flight per thread (one after the other: 20 us)
     int v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < n ? flags[i0 + u * 1024] : 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) c += v[u] != 0 ? 1 : 0;
+    for (int u = 0; u < 8; ++u) { c += v[u] != 0 ? 1 : 0; k += (v[u] & 2) ? 1 : 0; }
   }
   s_part[threadIdx.x] = c;
+  s_cert[threadIdx.x] = k;
   __syncthreads();
   for (int st = 512; st >= 1; st >>= 1) {
-    if ((int)threadIdx.x < st) s_part[threadIdx.x] += s_part[threadIdx.x + st];
+    if ((int)threadIdx.x < st) { s_part[threadIdx.x] += s_part[threadIdx.x + st]; s_cert[threadIdx.x] += s_cert[threadIdx.x + st]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = (double)s_part[0];
+  if (threadIdx.x == 0) { out[0] = (double)s_part[0]; out[1] = (double)s_cert[0]; }
 }
 
 }  // namespace

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
     bool bad = false;
     if (lane < top_k && ((tm >> lane) & 1ull) && s_hit[wave][lane] != s_hit[wave][lane + 1]) bad = true;
     if (((tm >> (top_k - 1)) & 1ull) && ((tm >> top_k) & 1ull)) bad = true;
-    if (__ballot(bad) != 0 && lane == 0) flag_io[row] = 1;
+    if (__ballot(bad) != 0 && lane == 0) flag_io[row] |= 1;    // (bit 1 of a pruned row: its certificate failed)
   }
   // A row without a test item among its top_k (most rows: hits are rare) has every metric 0 at every cut-off as long as
   // the user has test items at all (0 / T, 0 / idcg with idcg > 0, no reciprocal rank): written directly, the float /
@@ -999,11 +999,12 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
       // outside + eps[row] in the fp32 chain; the row stands only if its cut-th rescored score is strictly above
       const float s_k = C[(int64_t)row * cld + col_k];
       // (the sum rounded UP: the comparison itself must not eat into the bound; a NaN anywhere flags the row)
-      flag_out[row] = !(s_k > nr_add_up(outside, eps[row])) ? 1 : 0;
+      // (2: the bound did not certify the row — what a search arithmetic can be blamed for; 1: ties, bucket overflow)
+      flag_out[row] = !(s_k > nr_add_up(outside, eps[row])) ? 2 : 0;
     } else {
       flag_out[row] = !(inside > outside) ? 1 : 0;
     }
-    if (overflow && overflow[row]) flag_out[row] = 1;          // a pair of this row did not fit its tile's bucket
+    if (overflow && overflow[row]) flag_out[row] |= 1;         // a pair of this row did not fit its tile's bucket
     // (ties inside the compact row: metrics_kernel decides from the tie mask whether they can change a metric)
   }
 }

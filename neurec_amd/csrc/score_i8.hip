@@ -1,4 +1,4 @@
-// score_i8.hip — level 1 of the pruned evaluation as a BOUNDED FILTER on the int8 matrix cores (d <= 64).
+// score_i8.hip — level 1 of the pruned evaluation as a BOUNDED FILTER on the int8 matrix cores (d <= 128).
 //
 // Same contract as score_bf16.hip: the evaluation's answer is the fp32 k-ascending fmaf chain of every (user, item)
 // score (score_gemm.hip; MF.py:120-122, LightGCN.py:187-189); this file only SEARCHES for the tiles worth rescoring
@@ -95,9 +95,9 @@ __global__ void split_rows_i8_kernel(const float* __restrict__ src, int64_t ld, 
                                      int d, int ks32, uint4* __restrict__ dst, uint32_t* __restrict__ sc,
                                      float* __restrict__ qblk, float* __restrict__ cu, float* __restrict__ eps,
                                      int is_items) {
-  __shared__ uint32_t s_max[2][64];
-  __shared__ int s_q1[2][64], s_l1[2][64];
-  __shared__ float s_sq[2][64];
+  __shared__ uint32_t s_max[4][64];                           // (ks32 <= 4 k-steps of 32: d <= 128)
+  __shared__ int s_q1[4][64], s_l1[4][64];
+  __shared__ float s_sq[4][64];
   const int lane = threadIdx.x, s = threadIdx.y, b = blockIdx.x;
   const int j = lane & 31, g = lane >> 5;
   const int r = b * 32 + j, k0 = 32 * s + 16 * g;
@@ -304,19 +304,21 @@ __global__ __launch_bounds__(256, 1) void tilemax_i8_kernel(const uint4* __restr
   };
 
   if (t_begin < t_stop) {
-    BSetI8<KS> b[3];
+    constexpr int NB = 3;                                     // item sets in flight
+    BSetI8<KS> b[NB];
     i32x16 hh[2][2][2], xx[2][2][2];
-    load_b(t_begin, b[0]);
-    load_b(t_begin + 1, b[1]);
-    load_b(t_begin + 2, b[2]);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) load_b(t_begin + k, b[k]);
     zero(hh[0], xx[0]);
     mfma_tile(b[0], hh[0], xx[0]);
+    // phase ph: tile t + ph is finished in set ph & 1; tile t + ph + 1 is computed from b[(ph + 1) % NB] into the other
+    // set while this one is reduced; b[ph % NB] is free again and takes tile t + ph + NB
     for (int t = t_begin; t < t_stop; t += 6) {
 #pragma unroll
       for (int ph = 0; ph < 6; ++ph) {
-        load_b(t + ph + 3, b[ph % 3]);
+        load_b(t + ph + NB, b[ph % NB]);
         zero(hh[(ph + 1) & 1], xx[(ph + 1) & 1]);
-        mfma_tile(b[(ph + 1) % 3], hh[(ph + 1) & 1], xx[(ph + 1) & 1]);
+        mfma_tile(b[(ph + 1) % NB], hh[(ph + 1) & 1], xx[(ph + 1) & 1]);
         reduce_store(t + ph, hh[ph & 1], xx[ph & 1]);
       }
     }
@@ -345,7 +347,136 @@ __global__ __launch_bounds__(256, 1) void tilemax_i8_kernel(const uint4* __restr
   }
 }
 
-inline int padded_dim32(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : -1); }
+// 64 < d <= 128: the k range of a tile in TWO halves ("units": (tile, half)), as tilemax_bf16_wide_kernel — the user
+// operands (64 registers) and two accumulator sets (256) stay resident, an item set is one unit's 32 registers; with
+// whole-tile item sets the KS = 4 form spilled (three sets: 119 registers, two: 69).  A tile's accumulators are zeroed
+// before its first unit and reduced after its second, while the first unit of the next tile runs into the other set.
+__global__ __launch_bounds__(256, 1) void tilemax_i8_wide_kernel(const uint4* __restrict__ PB, const uint4* __restrict__ QB,
+                                                                 const float* __restrict__ cu,
+                                                                 const float* __restrict__ qblk, int bpad, int rows,
+                                                                 int cols, int n_tiles, float* __restrict__ M, int64_t mld,
+                                                                 int tiles_per_chunk, float* __restrict__ sink) {
+  constexpr int KS = 2, KT = 4;                               // k-steps of 32 per unit / per tile
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int ub0 = (blockIdx.x * 4 + wave) * 2;
+  if (ub0 * 32 >= bpad) return;
+  const int t_begin = blockIdx.y * tiles_per_chunk;
+  const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+  if (t_begin >= t_end) return;
+  const int t_stop = min(t_end, cols / 64);
+
+  i32x4 ah[2][KT], al[2][KT];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int s = 0; s < KT; ++s) {
+      ah[y][s] = __builtin_bit_cast(i32x4, PB[(((int64_t)(ub0 + y) * 2 + 0) * KT + s) * 64 + lane]);
+      al[y][s] = __builtin_bit_cast(i32x4, PB[(((int64_t)(ub0 + y) * 2 + 1) * KT + s) * 64 + lane]);
+    }
+  const int my_row = ub0 * 32 + 32 * h + j;
+  const bool row_ok = my_row < rows;
+  const float my_scale = row_ok ? cu[2 * my_row] : 0.f;
+  const float my_tile = row_ok ? cu[2 * my_row + 1] : 0.f;
+  float* const my_sink = sink + 2 * lane;
+  float* const my_M = M + (int64_t)(row_ok ? my_row : 0) * mld;
+
+  // unit q of the chunk = (tile t_begin + q / 2, k half q & 1)
+  auto load_u = [&](int q, BSetI8<KS>& b) __attribute__((always_inline)) {
+    const uint4* p = QB + (int64_t)min(t_begin + (q >> 1), t_end - 1) * (4 * KT * 64) + lane;
+    const int kh = q & 1;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b.v[x][pl][s] = __builtin_bit_cast(i32x4, p[((x * 2 + pl) * KT + kh * KS + s) * 64]);
+  };
+  auto mfma_unit = [&](int kh, const BSetI8<KS>& b, i32x16 (&hh)[2][2], i32x16 (&xx)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          xx[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.v[x][1][s], ah[y][kh * KS + s], xx[x][y], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          hh[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.v[x][0][s], ah[y][kh * KS + s], hh[x][y], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+          xx[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b.v[x][0][s], al[y][kh * KS + s], xx[x][y], 0, 0, 0);
+    }
+  };
+  auto zero = [&](i32x16 (&hh)[2][2], i32x16 (&xx)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hh[x][y][i] = 0; xx[x][y][i] = 0; }
+  };
+  auto reduce_store = [&](int t, const i32x16 (&hh)[2][2], const i32x16 (&xx)[2][2]) __attribute__((always_inline)) {
+    const int m00 = max_halves_i(vmax16(hh[0][0], xx[0][0])), m10 = max_halves_i(vmax16(hh[1][0], xx[1][0]));
+    const int m01 = max_halves_i(vmax16(hh[0][1], xx[0][1])), m11 = max_halves_i(vmax16(hh[1][1], xx[1][1]));
+    const int tq = min(t, n_tiles - 1);
+    const float2 v = make_float2(fmaf(qblk[2 * tq], my_tile, (float)(h ? m01 : m00) * my_scale),
+                                 fmaf(qblk[2 * tq + 1], my_tile, (float)(h ? m11 : m10) * my_scale));
+    float* dst = (row_ok && t < t_stop) ? my_M + 2 * t : my_sink;
+    *reinterpret_cast<float2*>(dst) = v;
+  };
+
+  if (t_begin < t_stop) {
+    BSetI8<KS> b[2];
+    i32x16 hh[2][2][2], xx[2][2][2];
+    load_u(0, b[0]);
+    load_u(1, b[1]);
+    zero(hh[0], xx[0]);
+    mfma_unit(0, b[0], hh[0], xx[0]);
+    const int n_units = 2 * (t_stop - t_begin);
+    // phase ph: unit q = q0 + ph is done; unit q + 1 runs from b[(ph + 1) & 1]; if q closed its tile (odd), that tile
+    // is reduced meanwhile; b[ph & 1] takes unit q + 2.  q0 is a multiple of 4: every index below is static.
+    for (int q0 = 0; q0 < n_units; q0 += 4) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        load_u(q0 + ph + 2, b[ph & 1]);
+        if (((ph + 1) & 1) == 0) zero(hh[((ph + 1) >> 1) & 1], xx[((ph + 1) >> 1) & 1]);
+        mfma_unit((ph + 1) & 1, b[(ph + 1) & 1], hh[((ph + 1) >> 1) & 1], xx[((ph + 1) >> 1) & 1]);
+        if (ph & 1) reduce_store(t_begin + ((q0 + ph) >> 1), hh[(ph >> 1) & 1], xx[(ph >> 1) & 1]);
+      }
+    }
+  }
+  if (t_stop < t_end) {                                       // the partial last tile: pad columns excluded
+    const int t = t_stop, it = t * 64;
+    BSetI8<KS> b;
+    i32x16 hh[2][2], xx[2][2];
+    zero(hh, xx);
+    load_u(2 * (t - t_begin), b);
+    mfma_unit(0, b, hh, xx);
+    load_u(2 * (t - t_begin) + 1, b);
+    mfma_unit(1, b, hh, xx);
+    float m[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      uint32_t skip = 0u;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if (it + 32 * x + (reg & 3) + 8 * (reg >> 2) + 4 * h >= cols) skip |= 1u << reg;
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        const int mi = max_halves_i(vmax16_skip(hh[x][y], xx[x][y], skip));
+        m[x][y] = mi == INT_MIN ? -INFINITY : fmaf(qblk[2 * t + x], my_tile, (float)mi * my_scale);
+      }
+    }
+    if (row_ok) *reinterpret_cast<float2*>(my_M + 2 * t) = h ? make_float2(m[0][1], m[1][1]) : make_float2(m[0][0], m[1][0]);
+  }
+}
+
+inline int padded_dim32(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 128 ? 128 : -1)); }
 inline int round_up64(int x) { return (x + 63) / 64 * 64; }
 
 struct FilterWsI8 {
@@ -380,7 +511,7 @@ extern "C" {
 int nrhip_score_filter_i8_workspace_bytes(int rows, int cols, int d, size_t* bytes) {
   NR_REQUIRE(bytes && rows >= 0 && cols >= 1 && d >= 1, NR_ERR_ARG, "score_filter_i8_workspace_bytes: bad arguments");
   const int dp = padded_dim32(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter_i8: embedding dim %d > 64 not built (use nrhip_score_filter_*)", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter_i8: embedding dim %d > 128 not built (use nrhip_score_tilemax)", d);
   *bytes = carve(nullptr, rows, cols, dp).total;
   return NR_OK;
 }
@@ -390,7 +521,7 @@ int nrhip_score_filter_i8_prepare_items(const float* d_Q, int64_t ldq, int cols,
   NR_REQUIRE(d_Q && d_ws && cols >= 1 && d >= 1 && ldq >= d && max_rows >= 0, NR_ERR_ARG,
              "score_filter_i8_prepare_items: bad arguments");
   const int dp = padded_dim32(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter_i8: embedding dim %d > 64 not built", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter_i8: embedding dim %d > 128 not built", d);
   FilterWsI8 f = carve(d_ws, max_rows, cols, dp);
   NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_i8_prepare_items: workspace %zu < %zu", ws_bytes,
              f.total);
@@ -421,7 +552,7 @@ int nrhip_score_filter_i8_tilemax(const float* d_P, int64_t ldp, const int32_t* 
                  mld >= 2 * ((cols + 63) / 64) && mld % 2 == 0,
              NR_ERR_ARG, "score_filter_i8_tilemax: bad arguments (mld must be even and >= 2*ceil(cols/64))");
   const int dp = padded_dim32(d);
-  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter_i8: embedding dim %d > 64 not built", d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_filter_i8: embedding dim %d > 128 not built", d);
   if (rows == 0) return NR_OK;
   FilterWsI8 f = carve(d_ws, max_rows, cols, dp);
   NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_i8_tilemax: workspace %zu < %zu", ws_bytes, f.total);
@@ -449,9 +580,12 @@ int nrhip_score_filter_i8_tilemax(const float* d_P, int64_t ldp, const int32_t* 
   if (ks == 1)
     hipLaunchKernelGGL(tilemax_i8_kernel<1>, grid, block, 0, st, f.PB, f.QB, f.cu, f.qblk, bpad, rows, cols, n_tiles, d_M, mld,
                        tpc, f.sink);
-  else
+  else if (ks == 2)
     hipLaunchKernelGGL(tilemax_i8_kernel<2>, grid, block, 0, st, f.PB, f.QB, f.cu, f.qblk, bpad, rows, cols, n_tiles, d_M, mld,
                        tpc, f.sink);
+  else
+    hipLaunchKernelGGL(tilemax_i8_wide_kernel, grid, block, 0, st, f.PB, f.QB, f.cu, f.qblk, bpad, rows, cols, n_tiles, d_M,
+                       mld, tpc, f.sink);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }

@@ -288,12 +288,12 @@ class ScoreGemm:
 class ScoreFilter:
     """Level 1 of the pruned evaluation as a bounded filter on the matrix cores: tile maxima, each within eps[row]
     of the fp32 chain's value.  arith="bf16" (csrc/score_bf16.hip, d <= 128): a three-term bf16 expansion of the fp32
-    products; arith="int8" (csrc/score_i8.hip, d <= 64): 15-bit fixed point in exact integer accumulators, the bound
+    products; arith="int8" (csrc/score_i8.hip, d <= 128): 15-bit fixed point in exact integer accumulators, the bound
     derived from the quantisation (eps = NaN for rows it cannot bound).  Nothing here is ranked:
     nrhip_eval_tiles_bounded rescores the chosen tiles with the fp32 chain and accepts a row only if its bound
     certifies the choice."""
 
-    ARITH = {"bf16": ("nrhip_score_filter_", 128, 1), "int8": ("nrhip_score_filter_i8_", 64, 2)}
+    ARITH = {"bf16": ("nrhip_score_filter_", 128, 1), "int8": ("nrhip_score_filter_i8_", 128, 2)}
 
     @staticmethod
     def supports(d, arith="bf16"):
@@ -463,7 +463,8 @@ class PrunedEvaluation:
     """nrhip_eval_pruned: the pruned evaluation of a whole user list in one native call (tile search, planned train
     strikes, fp32 rescoring + ranking + certificate + metrics per batch, then the column sums and the flagged-row
     count).  Holds the per-evaluator buffers; `run` returns (per_user [n][M*K] float32, flags [n] int32,
-    sums [M*K + 1] float64 — the last entry is the number of flagged rows)."""
+    sums [M*K + 2] float64 — the last two entries are the number of flagged rows and, among them, of rows whose
+    certificate failed)."""
 
     def __init__(self, gemm, filt, plan, train_csr, truth_csr, metric_ids, top_k, n_keep, batch_rows):
         from ._lib import EvalPrunedArgs
@@ -480,7 +481,7 @@ class PrunedEvaluation:
         nb = C.c_size_t(0)
         call("nrhip_eval_tiles_bounded_workspace_bytes", self.batch_rows, gemm.cols, self.top_k, self.n_keep, C.byref(nb))
         self.tiles_ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-        self.sums = torch.empty(self.nm * self.top_k + 1, dtype=torch.float64, device=dev)
+        self.sums = torch.empty(self.nm * self.top_k + 2, dtype=torch.float64, device=dev)
         self.cs_ws = None
         self.args = EvalPrunedArgs()
 

@@ -266,8 +266,8 @@ class Comm:
 
 
 def init_from_env(backend=None, force=None):
-    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (set by torch.distributed.run, or by bench.py when it starts
-    its own ranks).  Backend: NEUREC_DIST_BACKEND, else "nccl" (= RCCL) when every rank has a GPU of its own, else
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / LOCAL_WORLD_SIZE / MASTER_* (set by torch.distributed.run, or by bench.py
+    when it starts its own ranks).  Backend: NEUREC_DIST_BACKEND, else "nccl" (= RCCL) when every rank OF THIS NODE has a GPU of its own, else
     "gloo" — RCCL cannot put two ranks on one device, so on a box with fewer GPUs than ranks the ranks share devices
     round-robin and exchange through the host (the line then says dist_backend gloo, rccl_ranks 0).
     force (or NEUREC_DIST_FORCE_GROUP=1): create the process group even at world size 1."""
@@ -277,8 +277,10 @@ def init_from_env(backend=None, force=None):
     if force is None:
         force = os.environ.get("NEUREC_DIST_FORCE_GROUP", "") == "1"
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    # ranks on THIS node (torch.distributed.run sets LOCAL_WORLD_SIZE; a 2 x 8 launch has world 16, 8 per node)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if backend is None:
-        backend = os.environ.get("NEUREC_DIST_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+        backend = os.environ.get("NEUREC_DIST_BACKEND") or ("nccl" if n_dev >= local_world else "gloo")
     if n_dev:
         torch.cuda.set_device(local_rank % n_dev)
     if world > 1 or force:
@@ -294,15 +296,22 @@ def init_from_env(backend=None, force=None):
                 saved = os.dup(1)
                 os.dup2(2, 1)
                 try:
-                    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                    dist.init_process_group(backend=backend, rank=rank, world_size=world, **_rendezvous())
                     dist.barrier()
                 finally:
                     sys.stdout.flush()
                     os.dup2(saved, 1)
                     os.close(saved)
             else:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, **_rendezvous())
     return Comm(rank, world, local_rank, backend, force=force)
+
+
+def _rendezvous():
+    """NEUREC_DIST_INIT_FILE (bench.py's self-started ranks): a file store instead of MASTER_ADDR / MASTER_PORT — no
+    port to pick before the ranks exist, hence none to lose to another process in between."""
+    path = os.environ.get("NEUREC_DIST_INIT_FILE")
+    return {"init_method": "file://" + path} if path else {}
 
 
 class BipartitePartition:

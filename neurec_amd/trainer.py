@@ -485,7 +485,7 @@ class FullRankEvaluator:
 
     def __init__(self, train_csr, test_csr, metric_ids, top_k, batch_rows=2048, overlap=True,
                  pruned=True, strike_plan=True, search=None, extra_tiles=2):
-        # how the pruned path FINDS the tiles it rescores: "int8" (the default; tables of <= 64 columns, wider ones take
+        # how the pruned path FINDS the tiles it rescores: "int8" (the default; tables of <= 128 columns, wider ones take
         # "bf16") = the bounded filter on the int8 matrix cores (csrc/score_i8.hip: 15-bit fixed point, exact integer
         # accumulators, the bound derived from the quantisation), "bf16" = the same on the bf16 matrix cores
         # (csrc/score_bf16.hip, d <= 128) — either way every row is certified against its error bound or redone from
@@ -539,7 +539,7 @@ class FullRankEvaluator:
         else:
             self._gemm.prepare(item_table)
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
-        self._flags, self.n_flagged, self._native_sums = None, 0, None
+        self._flags, self.n_flagged, self.n_uncertified, self._native_sums = None, 0, 0, None
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
         if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0 and \
@@ -591,13 +591,14 @@ class FullRankEvaluator:
             if self._flags is None:
                 return sums.cpu().numpy() / div    # every mean is the fp64 column sum divided ON THE HOST (a device-side
                 #                                    scalar division may be a reciprocal multiply: last-ulp differences)
-            both = torch.cat([sums.reshape(-1), self._flags.sum().to(sums.dtype).reshape(1)]).cpu().numpy()
-        self.n_flagged = int(both[-1])
+            both = torch.cat([sums.reshape(-1), (self._flags != 0).sum().to(sums.dtype).reshape(1),
+                              ((self._flags & 2) != 0).sum().to(sums.dtype).reshape(1)]).cpu().numpy()
+        self.n_flagged, self.n_uncertified = int(both[-2]), int(both[-1])
         self._note_flags()
         if self.n_flagged:
             self._redo_flagged(user_table, item_table, test_users, per_user)
             return E.colsum(per_user).cpu().numpy() / div
-        return both[:-1] / div
+        return both[:-2] / div
 
     def _slab(self, k, rows):
         """score slab k with room for `rows` rows"""
@@ -609,7 +610,9 @@ class FullRankEvaluator:
         return self._scores[k]
 
     def _note_flags(self):
-        if getattr(self, "search_used", None) == "int8" and self.n_flagged > 0 and self.search == "int8":
+        # only rows whose CERTIFICATE failed (flag bit 1) say something about the int8 bound; rows flagged for ties or a
+        # full bucket would be flagged under any search (a dataset with tied rows must not lose int8 for good)
+        if getattr(self, "search_used", None) == "int8" and self.n_uncertified > 0 and self.search == "int8":
             self._int8_pause = self.int8_retry
 
     def _evaluate_pruned(self, user_table, item_table, test_users, per_user, starts):
@@ -645,7 +648,7 @@ class FullRankEvaluator:
         filt = None
         arith = self.search
         if arith == "int8" and not E.ScoreFilter.supports(item_table.shape[1], "int8"):
-            arith = "bf16"                                    # the int8 form is built for d <= 64
+            arith = "bf16"                                    # (both forms are built for d <= 128)
         if arith == "int8" and self._int8_pause > 0:
             self._int8_pause -= 1
             arith = "bf16"                                    # the last int8 evaluation left rows uncertified
@@ -697,6 +700,7 @@ class FullRankEvaluator:
             return
         cols = item_table.shape[0]
         redo = torch.nonzero(self._flags, as_tuple=False).flatten()      # host sync: only when rows were flagged
+        self.n_uncertified = int(((self._flags & 2) != 0).sum()) if redo.numel() else 0
         self._flags = None
         self.n_flagged = int(redo.numel())
         if self.n_flagged:

@@ -159,5 +159,9 @@ def test_the_pruned_evaluation_workspace_serves_every_shorter_batch():
     for cols in (40981, 262144, 300000, 393216, 1000000):
         sizes = [q(r, cols) for r in (1, 100, 2048, 8192, 16384, 20000, 32768, 65536)]
         assert all(a <= b for a, b in zip(sizes, sizes[1:])), (cols, sizes)
-    # the case of the finding: ~300 k items at batch_rows 32,768 — full batches too large to group, a 20,000-row tail not
-    assert q(32768, 300000) >= q(20000, 300000) > q(20000, 300000) - 1
+    # the case of the finding: ~300 k items at batch_rows 32,768 — its full batches take the packed buckets (r06), a
+    # 20,000-row tail the strided ones: the capacity's workspace covers the tail's strided buckets (tiles x rows x 4 B)
+    strided_tail = 2 * ((300000 + 63) // 64) * 20000 * 4
+    assert q(32768, 300000) >= q(20000, 300000) > strided_tail
+    # a million items: no strided form at all (31,250 tiles > the LDS histogram), the packed buckets are rows x n_keep
+    assert q(8192, 1000000) - q(8192, 1000000 - 64) < (1 << 20)

@@ -47,6 +47,10 @@ def test_two_rank_bench_line(mode, port):
         assert d["same_global_batch_on_1gpu"]["global_batch"] == 512 and d["same_global_batch_on_1gpu"]["value"] > 0
     leg = d["rowshard_config4_law"]                                        # every N>1 line carries the row-shard leg
     assert leg["ranks"] == 2 and leg["ms_per_step"] > 0 and leg["hop"] == "sliced" and leg["exchange"]["hop_ms"] > 0
+    assert leg["eval"]["users_per_sec"] > 0 and leg["eval"]["n_users"] > 0   # ... with its sharded evaluation (r06)
+    if mode in (None, "colshard"):                                         # strong scaling next to the weak figure
+        assert d["strong_scaling"]["global_batch"] == 256 and d["strong_scaling"]["value"] > 0
+        assert "rowshard" in d["north_star_partition"]
     red = d["rowshard_config4_law_reduce"]                                 # ... and its reduced-exchange form
     assert red["hop"] == "reduce" and red["ms_per_step"] > 0
     assert red["exchange"]["received_per_rank_bytes_per_hop"] < leg["exchange"]["received_per_rank_bytes_per_hop"]
@@ -79,6 +83,12 @@ def test_one_rank_bench_line(extra):
     if "config4" not in extra:
         assert "ndcg10_oracle_absdiff" not in d["eval"]              # that comparison belongs to the CPU-baseline leg
         assert d["mf"]["ms_per_step"] > 0 and d["eval"]["roofline"]["frac"] > 0
+        assert d["mf"]["epoch"]["triplets"] == d["mf"]["interactions"]          # a whole epoch, short last batch inside
+        # the headline's whole timed epoch: every triplet of the stream, the sampler's launch inside
+        assert d["epoch_timed"]["triplets"] == d["mf"]["interactions"] and d["epoch_timed"]["sampler_launches"] == 1
+        assert d["epoch_timed"]["short_last_batch"] and d["epoch_timed"]["value"] > 0
+    else:
+        assert d["eval"]["users_per_sec"] > 0 and d["eval"]["n_users"] > 0       # config 4 has an evaluation leg (r06)
 
 
 def test_default_line_is_the_compact_one():

@@ -445,7 +445,7 @@ def test_bounded_search_falls_back_where_it_is_not_built():
                                   ref.evaluate_factors(Pd, Qd, users, exact_mean=True))
     assert ev.search_used == "fp32"
     ev.evaluate_factors(Pd, Qd, torch.from_numpy(u).cuda())
-    assert ev.search_used == "bf16"
+    assert ev.search_used == "int8"                                           # (the default search, built up to 128 columns)
     assert not E.ScoreFilter.supports(129) and E.ScoreFilter.supports(128)
     with pytest.raises(ValueError, match="search"):
         FullRankEvaluator(trc, tec, [1], 10, search="fp16")

@@ -75,9 +75,9 @@ def test_pruned_evaluation_beyond_the_strided_buckets_equals_the_reference_evalu
     mids, k = [1, 2, 3, 4, 5], 20
     # 2 * ceil(I / 64) tiles: more than the strided buckets' LDS histogram holds
     assert 2 * ((I + 63) // 64) > 12288
-    fast = FullRankEvaluator(trc, tec, mids, k, batch_rows=1024)             # the default search: int8 (d <= 64) / bf16
+    fast = FullRankEvaluator(trc, tec, mids, k, batch_rows=1024)             # the default search: int8
     rows = np.asarray(fast.evaluate_factors(Pd, Qd, ud, per_user=True))
-    assert fast.search_used == ("int8" if d <= 64 else "bf16")
+    assert fast.search_used == "int8"
     assert fast.n_flagged <= len(users) // 10                                # the bound certifies: not a redo-everything run
     # the reference's evaluator on sampled users, the fmaf-chain scores as its input: identical metric rows
     rng = np.random.RandomState(1)
@@ -89,6 +89,10 @@ def test_pruned_evaluation_beyond_the_strided_buckets_equals_the_reference_evalu
     # every user: the exact (fp32) tile search gives the same rows, and so do the means in one call
     exact = FullRankEvaluator(trc, tec, mids, k, batch_rows=1024, search="fp32")
     np.testing.assert_array_equal(np.asarray(exact.evaluate_factors(Pd, Qd, ud, per_user=True)), rows)
+    if d > 64:                                                               # ... and the bf16 search (config 4's form in r05)
+        bf = FullRankEvaluator(trc, tec, mids, k, batch_rows=1024, search="bf16")
+        np.testing.assert_array_equal(np.asarray(bf.evaluate_factors(Pd, Qd, ud, per_user=True)), rows)
+        assert bf.search_used == "bf16"
     means = fast.evaluate_factors(Pd, Qd, ud)
     np.testing.assert_allclose(means, rows.astype(np.float64).sum(0) / len(users), rtol=0, atol=1e-12)
 

@@ -1,4 +1,5 @@
-"""csrc/score_i8.hip: the bounded search on the int8 matrix cores (d <= 64).  Same contract as the bf16 filter: its
+"""csrc/score_i8.hip: the bounded search on the int8 matrix cores (d <= 128; beyond 64 columns a tile's k range
+runs in two halves).  Same contract as the bf16 filter: its
 tile maxima are never ranked, every one carries a bound on its distance from the fp32 chain's value, and
 FullRankEvaluator(search="int8") returns exactly the rows the fp32 search and the materialised path return
 (evaluator/backend/cpp/src/evaluate.h:23-50 stays the definition; MF.py:120-122 the scores)."""
@@ -31,7 +32,7 @@ def _fixed_point_bound(P, Q, d):
     return user, tile
 
 
-@pytest.mark.parametrize("d", [8, 16, 24, 32, 48, 50, 64])
+@pytest.mark.parametrize("d", [8, 16, 24, 32, 48, 50, 64, 96, 100, 128])
 @pytest.mark.parametrize("kind", [0.01, 1.0, 300.0, "wide", "cancel", "norm-spread"])
 def test_int8_filter_stays_within_its_derived_bound(d, kind):
     """The filter's tile maxima are UPPER-bound maxima: fp32 chain maximum of the tile (nrhip_score_tilemax without
@@ -109,7 +110,8 @@ def test_int8_filter_refuses_to_bound_what_fixed_point_cannot_hold(kind):
 
 
 @pytest.mark.parametrize("d,clustered,extra", [(64, False, 2), (50, False, 0), (16, True, 2), (32, True, 1), (8, False, 2),
-                                               (64, "tiny", 2), (48, "underflow-edge", 2)])
+                                               (64, "tiny", 2), (48, "underflow-edge", 2), (128, False, 2), (96, False, 0),
+                                               (128, True, 2), (100, "tiny", 2)])
 def test_int8_search_ranks_exactly_what_the_fp32_search_ranks(d, clustered, extra):
     """FullRankEvaluator(search='int8') == search='fp32' == the materialised path, per-user metric rows bit for bit;
     near-duplicate items (the certificate fails) and magnitudes the fixed point cannot hold (eps = NaN) take the fp32
@@ -158,8 +160,8 @@ def test_int8_search_ranks_exactly_what_the_fp32_search_ranks(d, clustered, extr
 
 
 def test_int8_search_native_loop_python_loop_and_width_fallback():
-    """The one-call batch loop (nrhip_eval_pruned, use_filter = 2) equals the Python batch loop; beyond 64 columns the
-    int8 request takes the bf16 filter (built up to 128); the int8 entry points refuse d > 64 by name."""
+    """The one-call batch loop (nrhip_eval_pruned, use_filter = 2) equals the Python batch loop; 65 .. 128 columns run
+    the two-half kernel; the int8 entry points refuse d > 128 by name."""
     import torch
     import scipy.sparse as sp
     from neurec_amd import engine as E
@@ -183,14 +185,17 @@ def test_int8_search_native_loop_python_loop_and_width_fallback():
     assert a.search_used == "int8" and b.search_used == "int8"
     np.testing.assert_array_equal(np.asarray(ra), np.asarray(rb))
     np.testing.assert_array_equal(np.asarray(ra), np.asarray(rr))
-    # wider tables: the request falls to the bf16 form
+    # tables of 65 .. 128 columns: the same search, a tile's k range in two halves (r06; r05 fell to the bf16 form)
     P2, Q2 = (rng.randn(U, 96) * 0.1).astype(np.float32), (rng.randn(I, 96) * 0.1).astype(np.float32)
     w = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=128, search="int8")
-    w.evaluate_factors(torch.from_numpy(P2).cuda(), torch.from_numpy(Q2).cuda(), users)
-    assert w.search_used == "bf16"
-    assert E.ScoreFilter.supports(64, "int8") and not E.ScoreFilter.supports(65, "int8")
+    rw = w.evaluate_factors(torch.from_numpy(P2).cuda(), torch.from_numpy(Q2).cuda(), users, per_user=True)
+    assert w.search_used == "int8"
+    rr = FullRankEvaluator(trc, tec, [1, 3], 10, batch_rows=128, pruned=False).evaluate_factors(
+        torch.from_numpy(P2).cuda(), torch.from_numpy(Q2).cuda(), users, per_user=True)
+    np.testing.assert_array_equal(np.asarray(rw), np.asarray(rr))
+    assert E.ScoreFilter.supports(128, "int8") and not E.ScoreFilter.supports(129, "int8")
     with pytest.raises(NotImplementedError):
-        E.ScoreFilter(torch.zeros((I, 96), device="cuda"), 64, "int8")
+        E.ScoreFilter(torch.zeros((I, 160), device="cuda"), 64, "int8")
 
 
 def test_an_int8_evaluation_that_redid_rows_pauses_int8_for_the_next_ones():
@@ -232,3 +237,36 @@ def test_an_int8_evaluation_that_redid_rows_pauses_int8_for_the_next_ones():
         assert ev2.search_used == ("int8" if clean else "bf16")
         clean = clean and ev2.n_flagged == 0
     assert clean                                            # gaussian tables: gaps of tens of bounds
+
+
+def test_rows_flagged_for_ties_do_not_cost_the_int8_search():
+    """exact duplicates among a user's best items flag the row for its TIE (bit 0: redone from a full row so
+    that the reference's heap order decides) — that says nothing about the int8 bound, whose certificate (bit 1)
+    passed, so the next evaluation still searches in int8."""
+    import torch
+    import scipy.sparse as sp
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    rng = np.random.RandomState(31)
+    U, I, d = 300, 6000, 32
+    P = (rng.randn(U, d) * 0.1).astype(np.float32)
+    Q = (rng.randn(I, d) * 0.1).astype(np.float32)
+    Q[:20] *= 5.0                                           # twenty long items lead most rankings ...
+    Q[3000:3020] = Q[:20]                                   # ... and each exists twice, in another tile
+    tr = sp.random(U, I, 0.01, random_state=1, format="csr", dtype=np.float32); tr.data[:] = 1.0
+    te = sp.random(U, I, 0.005, random_state=2, format="csr", dtype=np.float32)
+    te = te - te.multiply(tr)
+    tr, te = tr.tolil(), te.tolil()
+    for u in range(0, 120):                                 # one copy of a pair is a test item, the other is not:
+        tr[u, 5] = tr[u, 3005] = te[u, 3005] = 0            # where the pair makes the top 20 its order decides metrics
+        te[u, 5] = 1.0
+    tr, te = tr.tocsr(), te.tocsr()
+    tr.eliminate_zeros(); te.eliminate_zeros(); tr.sort_indices(); te.sort_indices()
+    trc, tec = E.DeviceCSR.from_scipy(tr), E.DeviceCSR.from_scipy(te)
+    users = torch.from_numpy(np.flatnonzero(np.diff(te.indptr) > 0).astype(np.int32)).cuda()
+    Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    ev = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, search="int8")
+    ref = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, pruned=False).evaluate_factors(Pd, Qd, users)
+    for _ in range(3):
+        np.testing.assert_array_equal(ev.evaluate_factors(Pd, Qd, users), ref)
+        assert ev.search_used == "int8" and ev.n_flagged > 0 and ev.n_uncertified == 0
