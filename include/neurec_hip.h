@@ -314,8 +314,6 @@ int nrhip_randint_choice_batch(int high, int n_req, int64_t total, const int64_t
  *          of an nrhip_bpr_plan output, or NULL: the plan is then sorted on the spot
  *          (one more launch); d_loss2[0] = sum_b loss_b, d_loss2[1] = reg * sum_b l2_b,
  *          the two addends of MF.py:68-69 (the fetched loss is their sum).
- *          NRHIP_ATOMIC_SCATTER=1 in the environment selects the former kernels that
- *          scatter with fp32 atomics (order of the sums arbitrary; an A/B knob).
  *   adam:  TF-1.12 sparse Adam = all rows swept (see nr_core.h), and the
  *          gradient buffer is cleared for the next step.               */
 int nrhip_bpr_plan(const int32_t* d_users, const int32_t* d_items, const int32_t* d_third,
@@ -423,8 +421,8 @@ int nrhip_spmm_csr_masked(const void* plan, const int64_t* d_indptr, const int32
 /* Persistent lane-group schedule for d = 16 / 32 / 64 (128 / 256 on request) (spmm_blocked.hip): one workgroup per CU
  * owns a LIST of rows (4·d-byte accumulators in LDS) — since r05 the rows are dealt to the workgroups by cost
  * (longest first, each to the least-loaded workgroup with a free accumulator), so the balance does not depend on how
- * the nodes are numbered (contiguous runs — r01-r04, NEUREC_SPMM_DEAL=0 — carried 1.9x the mean cost in their
- * slowest workgroup when popular items cluster in id); a d/4-lane group walks one row with 16-byte
+ * the nodes are numbered (r01-r04's contiguous runs carried 1.9x the mean cost in their slowest workgroup when
+ * popular items cluster in id); a d/4-lane group walks one row with 16-byte
  * loads, so a load instruction moves 4 / 2 / 1 rows; sub-lists longer than seg_len are cut into segments whose
  * partials are added in segment order.  Optional column blocking (block_bytes) cuts the gathered
  * table into L2-sized windows walked phase by phase.  Same contract and masks as nrhip_spmm_csr /
@@ -446,14 +444,10 @@ int nrhip_spmm_blocked_tune(int gathers_in_flight);
 /* The plan OWNS a copy of the matrix's (column, value) pairs in its own row order (a workgroup's pairs are one
  * contiguous slice): nrhip_spmm_blocked_pack fills it from the CSR arrays — once per matrix, again whenever the
  * values change (NGCF's node dropout rewrites them every step); a product call that hands in arrays that were not
- * packed packs them first, on its stream.
- * d = 64 plans built with NEUREC_SPMM_AFFINITY=1 also carry the *affinity schedule* of the full pass (cache-blocked
- * by column windows, no phase barriers: csrc/spmm_blocked.hip; it keeps contiguous row runs), whose stream the same
- * call fills.  Calls that pass those same arrays then run it; results keep the contract of
- * nrhip_spmm_csr (rows of <= 64 non-zeros in strict ascending-column order).
- * nrhip_spmm_blocked_affinity: number of column windows in use (0 = base schedule), not a status. */
+ * packed packs them first, on its stream.  CONTRACT: freshness is decided by the identity of the two pointers — a
+ * caller that rewrites d_vals IN PLACE must call nrhip_spmm_blocked_pack again before the next product
+ * (engine.SpmmCSR.values_changed does; NGCF's node dropout is the one such caller). */
 int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d_vals, void* stream);
-int nrhip_spmm_blocked_affinity(const void* plan, int* windows_b);
 int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* d_vals,
                        const float* d_X, float* d_Y, const float* d_addend, const float* d_sum_in,
                        float* d_sum_out, const uint8_t* d_x_row_nonzero,

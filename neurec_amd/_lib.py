@@ -242,7 +242,6 @@ SIGNATURES = {
                              p, sz, p],
     "nrhip_spmm_blocked_plan_bytes": [i64, i64, i32, psz],
     "nrhip_spmm_blocked_pack": [p, p, p, p],
-    "nrhip_spmm_blocked_affinity": [p, C.POINTER(i32)],
     "nrhip_spmm_blocked_plan_create": [p, p, i64, i64, i32, i64, i32, i32, i32, i32, i32, p, sz, p,
                                        C.POINTER(p)],
     "nrhip_spmm_blocked_plan_destroy": [p],

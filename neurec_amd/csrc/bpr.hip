@@ -17,15 +17,14 @@
 // shuffles and leaves its occurrence's gradient row in LDS; the wave of the FIRST occurrence
 // of a row then adds the following occurrences in order (from LDS while they are in its
 // workgroup, recomputed beyond) and stores the row — no atomics, bit-identical run to run
-// and to np.add.at in the oracle.  The former one-wave-per-triplet kernels that scatter with
-// fp32 hardware atomics stay as an A/B knob (NRHIP_ATOMIC_SCATTER=1).  Per-triplet loss terms
+// and to np.add.at in the oracle.  (r01's one-wave-per-triplet kernels that scattered with fp32
+// hardware atomics — 5.0 us against 7.2 at B = 1,024, sums in arbitrary order — left the product
+// in r06.)  Per-triplet loss terms
 // are written out and reduced in a fixed order by the block that finishes last (finish_loss).
 #include "nr_common.h"
 #include <atomic>
 
 namespace {
-
-constexpr int kWavesPerBlock = 4;
 
 template <int CPL>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int d,
@@ -151,164 +150,6 @@ __device__ __forceinline__ void finish_loss(const float* term_mf, const float* t
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   reduce_terms(term_mf, term_l2, batch, reg, out2, s_a, s_b);
   if (threadIdx.x == 0) *done = 0;                     // re-armed for the next launch that draws it
-}
-
-// ---- BPR-MF ------------------------------------------------------------------
-template <int CPL>
-__device__ __forceinline__ void bpr_mf_grad_body(
-    const float* __restrict__ P, const float* __restrict__ Q, int d,
-    const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
-    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ GP,
-    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
-    int loss_kind) {
-  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
-  const int b = blockIdx.x * kWavesPerBlock + wave;
-  if (b >= batch) return;
-  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
-  const int64_t i = __builtin_amdgcn_readfirstlane(pos[b]);
-  const int64_t j = __builtin_amdgcn_readfirstlane(neg[b]);
-  float p[CPL], qi[CPL], qj[CPL];
-  load_row<CPL>(P, u, d, lane, p);
-  load_row<CPL>(Q, i, d, lane, qi);
-  load_row<CPL>(Q, j, d, lane, qj);
-  const float x = dot_rows<CPL>(p, qi) - dot_rows<CPL>(p, qj);      // MF.py:59,67
-  const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(qj, qj) + dot_rows<CPL>(qi, qi));
-  const float g = nr::pairwise_dloss(loss_kind, x);
-  if (lane == 0) {
-    // agent-scope stores: written through to where the block that finishes last reads them
-    __hip_atomic_store(&term_mf[b], nr::pairwise_loss(loss_kind, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int k = lane + c * NR_WAVE;
-    if (k < d) {
-      atomicAdd(&GP[u * d + k], g * (qi[c] - qj[c]) + reg * p[c]);
-      atomicAdd(&GQ[i * d + k], g * p[c] + reg * qi[c]);
-      atomicAdd(&GQ[j * d + k], -g * p[c] + reg * qj[c]);
-    }
-  }
-}
-
-template <int CPL>
-__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void bpr_mf_grad_kernel(
-    const float* __restrict__ P, const float* __restrict__ Q, int d,
-    const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
-    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ GP,
-    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
-    int loss_kind,
-    float* __restrict__ out2, unsigned* done) {
-  bpr_mf_grad_body<CPL>(P, Q, d, users, pos, neg, batch, reg, GP, GQ, term_mf, term_l2, loss_kind);
-  finish_loss(term_mf, term_l2, batch, reg, out2, done);
-}
-
-// ---- pointwise MF (is_pairwise=False, MF.py:70-72): (user, item, label) instances ---------------
-template <int CPL>
-__device__ __forceinline__ void pointwise_mf_grad_body(
-    const float* __restrict__ P, const float* __restrict__ Q, int d,
-    const int32_t* __restrict__ users, const int32_t* __restrict__ items,
-    const float* __restrict__ labels, int batch, float reg, float scale, float* __restrict__ GP,
-    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
-    int loss_kind) {
-  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
-  const int b = blockIdx.x * kWavesPerBlock + wave;
-  if (b >= batch) return;
-  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
-  const int64_t i = __builtin_amdgcn_readfirstlane(items[b]);
-  const float z = labels[b];
-  float p[CPL], q[CPL];
-  load_row<CPL>(P, u, d, lane, p);
-  load_row<CPL>(Q, i, d, lane, q);
-  const float x = dot_rows<CPL>(p, q);                               // MF.py:59
-  const float l2 = 0.5f * (dot_rows<CPL>(p, p) + dot_rows<CPL>(q, q));
-  const float g = nr::pointwise_dloss(loss_kind, z, x) * scale;
-  if (lane == 0) {
-    // agent-scope stores: written through to where the block that finishes last reads them
-    __hip_atomic_store(&term_mf[b], nr::pointwise_loss(loss_kind, z, x) * scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int k = lane + c * NR_WAVE;
-    if (k < d) {
-      atomicAdd(&GP[u * d + k], g * q[c] + reg * p[c]);
-      atomicAdd(&GQ[i * d + k], g * p[c] + reg * q[c]);
-    }
-  }
-}
-
-template <int CPL>
-__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void pointwise_mf_grad_kernel(
-    const float* __restrict__ P, const float* __restrict__ Q, int d,
-    const int32_t* __restrict__ users, const int32_t* __restrict__ items,
-    const float* __restrict__ labels, int batch, float reg, float scale, float* __restrict__ GP,
-    float* __restrict__ GQ, float* __restrict__ term_mf, float* __restrict__ term_l2,
-    int loss_kind,
-    float* __restrict__ out2, unsigned* done) {
-  pointwise_mf_grad_body<CPL>(P, Q, d, users, items, labels, batch, reg, scale, GP, GQ, term_mf, term_l2, loss_kind);
-  finish_loss(term_mf, term_l2, batch, reg, out2, done);
-}
-
-// ---- LightGCN head --------------------------------------------------------------
-template <int CPL>
-__device__ __forceinline__ void lightgcn_bpr_grad_body(
-    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
-    float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
-    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ Gstar,
-    float* __restrict__ Greg, float* __restrict__ term_mf, float* __restrict__ term_l2,
-    float grad_div) {
-  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
-  const int b = blockIdx.x * kWavesPerBlock + wave;
-  if (b >= batch) return;
-  const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
-  const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
-  const int64_t j = (int64_t)n_users + __builtin_amdgcn_readfirstlane(neg[b]);
-  float eu[CPL], ei[CPL], ej[CPL], zu[CPL], zi[CPL], zj[CPL];
-  load_row<CPL>(Esum, u, d, lane, eu);
-  load_row<CPL>(Esum, i, d, lane, ei);
-  load_row<CPL>(Esum, j, d, lane, ej);
-  load_row<CPL>(E0, u, d, lane, zu);
-  load_row<CPL>(E0, i, d, lane, zi);
-  load_row<CPL>(E0, j, d, lane, zj);
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {   // E* = mean over layers = sum / (L+1), LightGCN.py:146-147
-    eu[c] = eu[c] / layers_p1;
-    ei[c] = ei[c] / layers_p1;
-    ej[c] = ej[c] / layers_p1;
-  }
-  const float x = dot_rows<CPL>(eu, ei) - dot_rows<CPL>(eu, ej);     // LightGCN.py:157-158,162
-  const float l2 = 0.5f * (dot_rows<CPL>(zu, zu) + dot_rows<CPL>(zi, zi) + dot_rows<CPL>(zj, zj));
-  const float g = nr::bpr_dloss(x);
-  if (lane == 0) {
-    // agent-scope stores: written through to where the block that finishes last reads them
-    __hip_atomic_store(&term_mf[b], nr::bpr_loss(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&term_l2[b], l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int k = lane + c * NR_WAVE;
-    if (k < d) {
-      // grad_div is 1 or a power of two: dividing each term is then exactly dividing the sum
-      atomicAdd(&Gstar[u * d + k], (g * (ei[c] - ej[c])) / grad_div);
-      atomicAdd(&Gstar[i * d + k], (g * eu[c]) / grad_div);
-      atomicAdd(&Gstar[j * d + k], (-g * eu[c]) / grad_div);
-      atomicAdd(&Greg[u * d + k], reg * zu[c]);    // regulariser on layer-0 rows, :160,164
-      atomicAdd(&Greg[i * d + k], reg * zi[c]);
-      atomicAdd(&Greg[j * d + k], reg * zj[c]);
-    }
-  }
-}
-
-template <int CPL>
-__global__ __launch_bounds__(kWavesPerBlock* NR_WAVE) void lightgcn_bpr_grad_kernel(
-    const float* __restrict__ Esum, const float* __restrict__ E0, int n_users, int d,
-    float layers_p1, const int32_t* __restrict__ users, const int32_t* __restrict__ pos,
-    const int32_t* __restrict__ neg, int batch, float reg, float* __restrict__ Gstar,
-    float* __restrict__ Greg, float* __restrict__ term_mf, float* __restrict__ term_l2,
-    float grad_div,
-    float* __restrict__ out2, unsigned* done) {
-  lightgcn_bpr_grad_body<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, Gstar, Greg, term_mf, term_l2, grad_div);
-  finish_loss(term_mf, term_l2, batch, reg, out2, done);
 }
 
 __global__ __launch_bounds__(256) void mark_batch_kernel(const int32_t* __restrict__ users,
@@ -1244,16 +1085,6 @@ __global__ __launch_bounds__(256) void rows_sum_sorted_kernel(const uint64_t* __
   }
 }
 
-// NRHIP_ATOMIC_SCATTER=1: the former one-wave-per-triplet kernels (fp32 hardware atomics, row sums
-// in arbitrary order) — an A/B knob for measurements, not a product path.
-bool atomic_scatter_knob() {
-  static const bool on = [] {
-    const char* e = getenv("NRHIP_ATOMIC_SCATTER");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
-
 // np2 >= n, a power of two, at least 2
 int plan_pow2(int n) {
   int p = 2;
@@ -1472,11 +1303,7 @@ static int pairwise_mf_grad(const char* who, const float* d_P, const float* d_Q,
   float* t_l2 = d_work + batch;
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (atomic_scatter_knob()) {
-    dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
-    NR_BY_WIDTH(bpr_mf_grad_kernel, d_P, d_Q, d, d_users, d_pos, d_neg, batch, reg, d_GP, d_GQ, t_mf,
-                t_l2, loss_kind, d_loss2, done);
-  } else {
+  {
     const uint64_t* plan = nullptr;
     int rc = resolve_plan(d_plan, d_users, d_pos, d_neg, batch, 3, n_users, d_work, st, &plan);
     if (rc != NR_OK) return rc;
@@ -1659,11 +1486,7 @@ int nrhip_pointwise_mf_grad(const float* d_P, const float* d_Q, int d, int n_use
   const float scale = loss_kind == nr::NR_POINT_CROSS_ENTROPY ? 1.0f / (float)batch : 1.0f;
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (atomic_scatter_knob()) {
-    dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
-    NR_BY_WIDTH(pointwise_mf_grad_kernel, d_P, d_Q, d, d_users, d_items, d_labels, batch, reg, scale,
-                d_GP, d_GQ, t_mf, t_l2, loss_kind, d_loss2, done);
-  } else {
+  {
     const uint64_t* plan = nullptr;
     int rc = resolve_plan(d_plan, d_users, d_items, nullptr, batch, 2, n_users, d_work, st, &plan);
     if (rc != NR_OK) return rc;
@@ -1711,11 +1534,7 @@ static int lightgcn_head(const float* d_Esum, const float* d_E0, int n_users, in
   const float lp1 = (float)(n_layers + 1);
   unsigned* done = next_done_counter();
   NR_REQUIRE(done, NR_ERR_HIP, "loss reduction: device counter pool unavailable");
-  if (atomic_scatter_knob() && !d_given) {
-    dim3 grid((batch + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * NR_WAVE);
-    NR_BY_WIDTH(lightgcn_bpr_grad_kernel, d_Esum, d_E0, n_users, d, lp1, d_users, d_pos, d_neg, batch,
-                reg, d_Gstar, d_Greg, t_mf, t_l2, grad_div, d_loss2, done);
-  } else {
+  {
     const uint64_t* plan = nullptr;
     int rc = resolve_plan(d_plan, d_users, d_pos, d_neg, batch, 3, n_users, d_work, st, &plan);
     if (rc != NR_OK) return rc;

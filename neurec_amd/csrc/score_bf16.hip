@@ -41,17 +41,16 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {
   return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
 }
 
-// dst[((b·2 + term)·KS + s)·64 + lane] = the 8 bf16 of row 32·b + (lane & 31), k = 16·s + 8·(lane >> 5) .. +7
-// (or, rows_log2 = 4: row 16·b + (lane & 15), k = 32·s + 8·(lane >> 4) .. +7);
+// dst[((b·2 + term)·KS + s)·64 + lane] = the 8 bf16 of row 32·b + (lane & 31), k = 16·s + 8·(lane >> 5) .. +7;
 // norm[row] = ||row||₂ (fp32); *max_norm = max over rows (optional); eps[row] = kappa · norm[row] · *other_max (optional)
 __global__ void split_rows_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ ids, int n,
                                   int d, int ks16, uint4* __restrict__ dst, float* __restrict__ norm,
                                   float* __restrict__ max_norm, const float* __restrict__ other_max, float kappa,
-                                  float* __restrict__ eps, int rows_log2) {
+                                  float* __restrict__ eps) {
   __shared__ float s_sq[8][64];
   const int lane = threadIdx.x, s = threadIdx.y, b = blockIdx.x;
-  // rows_log2 = 5: blocks of 32 rows, k-steps of 16 (v_mfma_f32_32x32x16_bf16 operands); 4: 16 rows, 32 k (16x16x32)
-  const int brows = 1 << rows_log2, kgroups = 64 >> rows_log2;
+  // blocks of 32 rows, k-steps of 16: the operands of v_mfma_f32_32x32x16_bf16
+  constexpr int brows = 32, kgroups = 2, rows_log2 = 5;
   const int r = b * brows + (lane & (brows - 1)), k0 = 8 * kgroups * s + 8 * (lane >> rows_log2);
   float x[8];
   const bool have = r < n;
@@ -247,138 +246,6 @@ __global__ __launch_bounds__(256, 1) void tilemax_bf16_kernel(const uint4* __res
   }
 }
 
-// d = 32 / 64 on v_mfma_f32_16x16x32_bf16 (A/B form, NEUREC_FILTER_K32=1; not the default — see use_k32): four chains
-// of the 32x32x16 form issue one MFMA per ~50 clk on this part (32 nominal), the 16x16x32 form runs at its 16
-// (scripts/exp_mfma_clock.py).  Same structure as tilemax_bf16_kernel: per-wave operand loads, three item sets, two accumulator sets, the reduction
-// of tile t under the MFMAs of tile t + 1, branch-free stores.  A wave: 64 users = four 16-user column blocks; a
-// 64-item tile = four 16-item row blocks; c[x][y][reg] = score of item 16 x + 4 (lane >> 4) + reg, user 16 y + (lane & 15).
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-template <int KS32>
-struct BSet16 {
-  uint4 v[4][2][KS32];                                        // [16-item block][term][k-step of 32]
-};
-// max over the four lane groups (lanes j, j + 16, j + 32, j + 48 hold different rows of the same 16-row block)
-__device__ __forceinline__ float max_groups(float m) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-  const float a = vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
-  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
-  return vmax(__uint_as_float(q[0]), __uint_as_float(q[1]));
-}
-template <int KS32>
-__global__ __launch_bounds__(256, 1) void tilemax_bf16_k32_kernel(const uint4* __restrict__ PB,
-                                                                  const uint4* __restrict__ QB, int bpad, int rows,
-                                                                  int cols, int n_tiles, float* __restrict__ M,
-                                                                  int64_t mld, int tiles_per_chunk,
-                                                                  float* __restrict__ sink) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = lane & 15, grp = lane >> 4;
-  const int ub0 = (blockIdx.x * 4 + wave) * 4;                // first 16-user block of this wave
-  if (ub0 * 16 >= bpad) return;
-  const int t_begin = blockIdx.y * tiles_per_chunk;
-  const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
-  if (t_begin >= t_end) return;
-  const int t_stop = min(t_end, cols / 64);
-
-  bf16x8 ah[4][KS32], al[4][KS32];
-#pragma unroll
-  for (int y = 0; y < 4; ++y)
-#pragma unroll
-    for (int s = 0; s < KS32; ++s) {
-      ah[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 0) * KS32 + s) * 64 + lane]);
-      al[y][s] = __builtin_bit_cast(bf16x8, PB[(((int64_t)(ub0 + y) * 2 + 1) * KS32 + s) * 64 + lane]);
-    }
-  const int my_row = ub0 * 16 + 16 * grp + j;                 // lane group g stores user block g
-  float* const my_sink = sink + 2 * lane;
-  const bool row_ok = my_row < rows;
-  float* const my_M = M + (int64_t)(row_ok ? my_row : 0) * mld;
-
-  auto load_b = [&](int t, BSet16<KS32>& b) __attribute__((always_inline)) {
-    const uint4* q = QB + (int64_t)min(t, t_end - 1) * (8 * KS32 * 64) + lane;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int term = 0; term < 2; ++term)
-#pragma unroll
-        for (int s = 0; s < KS32; ++s) b.v[x][term][s] = q[((x * 2 + term) * KS32 + s) * 64];
-  };
-  auto mfma_tile = [&](const BSet16<KS32>& b, f32x4 (&c)[4][4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int term = 0; term < 3; ++term)                      // item lo x user hi, item hi x user lo, hi x hi
-#pragma unroll
-      for (int s = 0; s < KS32; ++s)
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 4; ++y) {
-            if (term == 0)
-              c[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b.v[x][1][s]), ah[y][s], c[x][y], 0, 0, 0);
-            else if (term == 1)
-              c[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), al[y][s], c[x][y], 0, 0, 0);
-            else
-              c[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b.v[x][0][s]), ah[y][s], c[x][y], 0, 0, 0);
-          }
-  };
-  auto zero = [&](f32x4 (&c)[4][4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) c[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto half_max = [&](const f32x4 (&c)[4][4], int hf, int y) __attribute__((always_inline)) {
-    const f32x4 &p = c[2 * hf][y], &q = c[2 * hf + 1][y];
-    return max_groups(vmax(vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], q[0]), q[1], q[2]), q[3]));
-  };
-  auto pick = [&](const float (&m)[4]) __attribute__((always_inline)) {   // user block grp's value (selects, no switch)
-    return (grp & 2) ? ((grp & 1) ? m[3] : m[2]) : ((grp & 1) ? m[1] : m[0]);
-  };
-  auto reduce_store = [&](int t, const f32x4 (&c)[4][4]) __attribute__((always_inline)) {
-    float m0[4], m1[4];
-#pragma unroll
-    for (int y = 0; y < 4; ++y) { m0[y] = half_max(c, 0, y); m1[y] = half_max(c, 1, y); }
-    const bool ok = row_ok & (t < t_stop);
-    float* dst = ok ? my_M + 2 * t : my_sink;
-    *reinterpret_cast<float2*>(dst) = make_float2(pick(m0), pick(m1));
-  };
-
-  if (t_begin < t_stop) {
-    BSet16<KS32> b[3];
-    f32x4 c[2][4][4];
-    load_b(t_begin, b[0]);
-    load_b(t_begin + 1, b[1]);
-    load_b(t_begin + 2, b[2]);
-    zero(c[0]);
-    mfma_tile(b[0], c[0]);
-    for (int t = t_begin; t < t_stop; t += 6) {
-#pragma unroll
-      for (int ph = 0; ph < 6; ++ph) {
-        load_b(t + ph + 3, b[ph % 3]);
-        zero(c[(ph + 1) & 1]);
-        mfma_tile(b[(ph + 1) % 3], c[(ph + 1) & 1]);
-        reduce_store(t + ph, c[ph & 1]);
-      }
-    }
-  }
-  if (t_stop < t_end) {                                       // the partial last tile: pad columns excluded
-    const int t = t_stop, it = t * 64;
-    BSet16<KS32> b;
-    f32x4 c[4][4];
-    load_b(t, b);
-    zero(c);
-    mfma_tile(b, c);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          if (it + 16 * x + 4 * grp + reg >= cols) c[x][y][reg] = -INFINITY;
-    float m0[4], m1[4];
-#pragma unroll
-    for (int y = 0; y < 4; ++y) { m0[y] = half_max(c, 0, y); m1[y] = half_max(c, 1, y); }
-    if (row_ok) *reinterpret_cast<float2*>(my_M + 2 * t) = make_float2(pick(m0), pick(m1));
-  }
-}
-
 // 64 < d <= 128: the same loop with the k range of a tile in TWO halves ("units": (tile, half)), so that the operand
 // sets keep the size of the d = 64 kernel — 128 user-operand registers stay resident, an item set is 64.  A tile's
 // accumulators are zeroed before its first unit and reduced after its second, while the first unit of the next tile
@@ -527,17 +394,6 @@ FilterWs carve(void* ws, int rows, int cols, int dp) {
   f.total = f.q_bytes + f.p_bytes + f.n_bytes + 256 + 512;
   return f;
 }
-// NEUREC_FILTER_K32=1 (A/B only): d = 32 / 64 in the 16-row / 32-k operand layout on the 16x16x32 kernel.  Measured
-// slower than the 32x32x16 kernel although its MFMAs issue at the nominal rate: 0.225 vs 0.211 ms (d = 64), 0.150 vs
-// 0.124 (d = 32) per 16,384 users — the loop is not bound by the MFMA cadence (profiles/r04_exp_score_filter.txt).
-static int g_filter_k32 = -1;
-inline bool use_k32(int dp) {
-  if (g_filter_k32 < 0) {
-    const char* e = getenv("NEUREC_FILTER_K32");
-    g_filter_k32 = (e && e[0] == '1') ? 1 : 0;
-  }
-  return g_filter_k32 != 0 && (dp == 32 || dp == 64);
-}
 inline float kappa_of(int dp) {
   return 1.5f * (3.2f * 3.814697265625e-06f + 3.0f * dp * 1.1920928955078125e-07f + dp * 5.9604644775390625e-08f);
 }
@@ -573,11 +429,10 @@ int nrhip_score_filter_prepare_items(const float* d_Q, int64_t ldq, int cols, in
              f.total);
   hipStream_t st = (hipStream_t)stream;
   NR_CHECK_HIP(hipMemsetAsync(f.inorm_max, 0, sizeof(float), st));
-  const bool k32 = use_k32(dp);
-  const int ks = k32 ? dp / 32 : dp / 16;
-  hipLaunchKernelGGL(split_rows_kernel, dim3(round_up64(cols) / (k32 ? 16 : 32)), dim3(64, ks), 0, st, d_Q, ldq,
+  const int ks = dp / 16;
+  hipLaunchKernelGGL(split_rows_kernel, dim3(round_up64(cols) / 32), dim3(64, ks), 0, st, d_Q, ldq,
                      (const int32_t*)nullptr, cols, d, ks, f.QB, (float*)nullptr, f.inorm_max, (const float*)nullptr,
-                     0.f, (float*)nullptr, k32 ? 4 : 5);
+                     0.f, (float*)nullptr);
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
@@ -597,11 +452,9 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
   FilterWs f = carve(d_ws, max_rows, cols, dp);
   NR_REQUIRE(ws_bytes >= f.total, NR_ERR_WORKSPACE, "score_filter_tilemax: workspace %zu < %zu", ws_bytes, f.total);
   hipStream_t st = (hipStream_t)stream;
-  const bool k32 = use_k32(dp);
   const int ks16 = dp / 16, bpad = round_up64(rows);
-  hipLaunchKernelGGL(split_rows_kernel, dim3(bpad / (k32 ? 16 : 32)), dim3(64, k32 ? dp / 32 : ks16), 0, st, d_P, ldp,
-                     d_users, rows, d, k32 ? dp / 32 : ks16, f.PB, f.unorm, (float*)nullptr, f.inorm_max, kappa_of(dp),
-                     d_eps, k32 ? 4 : 5);
+  hipLaunchKernelGGL(split_rows_kernel, dim3(bpad / 32), dim3(64, ks16), 0, st, d_P, ldp,
+                     d_users, rows, d, ks16, f.PB, f.unorm, (float*)nullptr, f.inorm_max, kappa_of(dp), d_eps);
   NR_LAUNCH_CHECK();
   const int bx = (bpad / 64 + 3) / 4;
   const int n_tiles = round_up64(cols) / 64;
@@ -624,14 +477,6 @@ int nrhip_score_filter_tilemax(const float* d_P, int64_t ldp, const int32_t* d_u
 #define NR_FILTER_CASE(K)                                                                                       \
   hipLaunchKernelGGL(tilemax_bf16_kernel<K>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld, tpc, \
                      f.sink)
-  if (k32) {
-    if (dp == 32)
-      hipLaunchKernelGGL(tilemax_bf16_k32_kernel<1>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld,
-                         tpc, f.sink);
-    else
-      hipLaunchKernelGGL(tilemax_bf16_k32_kernel<2>, grid, block, 0, st, f.PB, f.QB, bpad, rows, cols, n_tiles, d_M, mld,
-                         tpc, f.sink);
-  } else
   switch (ks16) {
     case 1: NR_FILTER_CASE(1); break;
     case 2: NR_FILTER_CASE(2); break;

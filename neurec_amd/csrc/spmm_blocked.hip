@@ -46,7 +46,7 @@ struct BlockedPlan {
   int64_t n_rows, nnz, n_ent, n_cmb;
   int n_wg, n_phases;
   int seg, r_max, p_max, waves, d;
-  int32_t* wg_row0;      // first position of the workgroup's rows in row_of (== the first row when rows are not dealt)
+  int32_t* wg_row0;      // first position of the workgroup's rows in row_of
   int32_t* wg_nrows;
   // r05: the rows of a workgroup are a LIST, not a run: row_of[wg_row0[w] + slot] (see "dealt rows" at the plan
   // builder) — and the plan owns the (column, value) pairs in that order, so a workgroup's pairs stay one
@@ -87,41 +87,7 @@ struct BlockedPlan {
   int ww_lds_slots;      // LDS partial slots per workgroup
   float* ww_part;        // [segments of multi-chunk rows][64]
   unsigned* ww_cnt;      // [multi-chunk rows] chunks finished (zero between launches)
-  // affinity schedule (d = 64 full pass, cache-blocked without phase barriers): per lane group a
-  // stream of rounds of four (column, value) pairs, phase-major
-  int aff_ok, aff_packed, aff_phases_a, aff_phases_b;
-  int64_t aff_rounds;
-  int32_t* a_goff;       // [n_wg][65] first round of each lane group
-  int32_t* a_npart;      // [n_wg] partial slots in use
-  int32_t* a_cmb_off;    // [n_wg + 1]
-  int4* a_cmb;           // {row slot, first partial slot, segments, 0}
-  uint32_t* a_rd;        // [rounds] valid pairs | new sub-list << 3 | accumulator slot << 4
-  int32_t* a_perm;       // [rounds][4] CSR position of each pair, -1 = padding
-  int4* a_iv;            // [rounds][2] {col0..col3}, {val0..val3 as bits} (packed on device)
-  const int32_t* aff_indices;   // the CSR arrays the stream was packed from
-  const float* aff_vals;
 };
-
-constexpr int kAffMaxPhases = 8;
-constexpr int kAffSlackRounds = 96;      // idle rounds of the last lane groups read past their stream
-
-size_t aff_rounds_bound(int64_t n_rows, int64_t nnz) {
-  return (size_t)(nnz / 4) + (size_t)std::min<int64_t>(nnz, n_rows * (int64_t)kAffMaxPhases) +
-         (size_t)(nnz / 32) + 128 + kAffSlackRounds;
-}
-
-bool aff_enabled() {
-  const char* on = getenv("NEUREC_SPMM_AFFINITY");
-  return on && on[0] == '1';
-}
-
-size_t aff_plan_bytes(int64_t n_rows, int64_t nnz) {
-  const size_t wg = 4096 + (size_t)(n_rows / 32);
-  const size_t rounds = aff_rounds_bound(n_rows, nnz);
-  return nr_align_up(rounds * 32, 256) + nr_align_up(rounds * 16, 256) + nr_align_up(rounds * 4, 256) +
-         nr_align_up(wg * 65 * 4, 256) + 2 * nr_align_up((wg + 1) * 4, 256) +
-         nr_align_up(((size_t)(nnz / 16) + 64) * 16, 256);
-}
 
 size_t blocked_plan_bytes(int64_t n_rows, int64_t nnz) {
   const size_t max_ent = (size_t)std::min<int64_t>(nnz, n_rows * (int64_t)kMaxPhases) + (size_t)(nnz / 16) + 64;
@@ -399,149 +365,6 @@ __global__ __launch_bounds__(kWaves* NR_WAVE) void spmm_blocked_kernel(
   NR_BLK_STAMP(4);
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Affinity schedule: the cache-blocked full pass without phase barriers (d = 64).
-//
-// Column blocking keeps an XCD's gathers inside a window of the table its 4 MB L2 can hold, but in
-// spmm_blocked_kernel every phase ends in a workgroup barrier plus the longest sub-list chain of
-// that phase, which costs more than the hits save.  Here the barriers are gone: a
-// row belongs to ONE 16-lane group for the whole pass (its accumulator slot in LDS is private to
-// that group), and the group walks its own stream — the window-0 sub-lists of its rows, then the
-// window-1 sub-lists, ... — at its own pace.  The groups of an XCD carry equal work, so they cross
-// the windows at about the same time without being told to.  The stream is plan-owned memory:
-// rounds of four (column, value) pairs (a sub-list is padded to whole rounds) plus one descriptor
-// word per round {valid pairs, "new sub-list", accumulator slot}, so a group reads 36 contiguous
-// bytes per round and no CSR arrays.  Three rounds of four row gathers are in flight per group;
-// every round issues the same seven loads unconditionally (see staged_walk on why), the stream
-// words three rounds ahead of their use.  Sub-lists longer than 64 are segments with partial slots,
-// dealt to other groups and added in (window, segment) order after the walk — as before, only such
-// hub rows leave the strict ascending-column order.
-template <bool ADAM>
-__global__ __launch_bounds__(16 * NR_WAVE) void spmm_affinity_kernel(
-    const int32_t* __restrict__ wg_row0, const int32_t* __restrict__ wg_nrows,
-    const int32_t* __restrict__ a_goff, const int32_t* __restrict__ a_npart,
-    const int32_t* __restrict__ a_cmb_off, const int4* __restrict__ a_cmb,
-    const int4* __restrict__ a_iv, const uint32_t* __restrict__ a_rd, const float4* __restrict__ X,
-    float4* __restrict__ Y, const float4* __restrict__ addend, const float4* sum_in,
-    float4* sum_out, int kRMax, AdamEpilogue ad) {
-  // a_iv[2r] = the four columns of round r, a_iv[2r + 1] = its four values (float bits)
-  constexpr int LPR = 16, GPW = 4, kQ = 4, kGroups = 64;
-  extern __shared__ float4 s_acc[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & (LPR - 1), g = lane / LPR;
-  const int wg = blockIdx.x;
-  const int r0 = wg_row0[wg], nr = wg_nrows[wg], np = a_npart[wg];
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < nr * LPR; i += 16 * NR_WAVE) s_acc[i] = zero;
-  for (int i = tid; i < np * LPR; i += 16 * NR_WAVE) s_acc[kRMax * LPR + i] = zero;
-  __syncthreads();
-  const int q = wave * GPW + g;
-  const int rb = a_goff[wg * (kGroups + 1) + q];
-  const int nrounds = a_goff[wg * (kGroups + 1) + q + 1] - rb;
-  int wmax = nrounds;
-  wmax = max(wmax, __shfl_xor(wmax, 16, NR_WAVE));
-  wmax = max(wmax, __shfl_xor(wmax, 32, NR_WAVE));
-  wmax = __builtin_amdgcn_readfirstlane(wmax);
-
-  // the four columns of a round are needed when it is issued (fetched three rounds ahead); its
-  // values and descriptor word only when it retires: they travel with the round's own gathers
-  struct Round { float4 x[kQ]; int4 v; uint32_t rd; };
-  auto fetch = [&](int t, int4& cols) { cols = a_iv[2 * ((int64_t)rb + t)]; };
-  auto issue = [&](int t, int4& cols, Round& R) {
-    const int col[kQ] = {cols.x, cols.y, cols.z, cols.w};
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) R.x[u] = X[(int64_t)col[u] * LPR + c];
-    R.v = a_iv[2 * ((int64_t)rb + t) + 1];
-    R.rd = a_rd[(int64_t)rb + t];              // not touched before the round retires (no early wait)
-    // last, into the registers the gathers just consumed (a fresh register would have to be copied
-    // back on the loop's back edge, and a copy waits for the load): these columns are needed when
-    // this ring slot issues again, right after this round has retired — which covers them
-    fetch(t + 3, cols);
-  };
-  float4 acc = zero;
-  int cur = 0;
-  bool have = false;
-  auto retire = [&](const Round& R, int t) {
-    const uint32_t rd = (t >= 0 && t < nrounds) ? R.rd : 0u;   // outside the group's stream: ignored
-    const int n = (int)(rd & 7u);
-    if ((rd >> 3) & 1u) {                      // a new sub-list: park the running sum, take the slot's
-      if (have) s_acc[cur * LPR + c] = acc;
-      cur = (int)(rd >> 4);
-      acc = s_acc[cur * LPR + c];
-      have = true;
-    }
-    const float v[kQ] = {__int_as_float(R.v.x), __int_as_float(R.v.y), __int_as_float(R.v.z),
-                         __int_as_float(R.v.w)};
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const float4 t = make_float4(__fadd_rn(acc.x, __fmul_rn(v[u], R.x[u].x)),
-                                   __fadd_rn(acc.y, __fmul_rn(v[u], R.x[u].y)),
-                                   __fadd_rn(acc.z, __fmul_rn(v[u], R.x[u].z)),
-                                   __fadd_rn(acc.w, __fmul_rn(v[u], R.x[u].w)));
-      if (u < n) acc = t;
-    }
-  };
-  // Ring slots: q2 takes rounds 0, 3, 6, ..., q0 rounds 1, 4, ..., q1 rounds 2, 5, ...; d* = the columns
-  // of the slot's next round.  The loop starts two rounds "early" (t = -2: its first two retirements
-  // are of rounds that do not exist) so that the prologue holds no gathers: only the three column
-  // fetches, landed before the loop is entered.  Every s_waitcnt inside the loop is computed for
-  // the worse of the ways into its block; with loads in flight at loop entry the compiler is free to
-  // order the prologue so that this worst case is vmcnt(0..8) on every iteration (seen in the ISA).
-  int4 d0, d1, d2;
-  Round q0, q1, q2;
-  q0.rd = q1.rd = 0u;
-  q0.v = q1.v = make_int4(0, 0, 0, 0);
-#pragma unroll
-  for (int u = 0; u < kQ; ++u) q0.x[u] = q1.x[u] = zero;
-  fetch(0, d2);
-  fetch(1, d0);
-  fetch(2, d1);
-  asm volatile("" : "+v"(d0.x), "+v"(d0.y), "+v"(d0.z), "+v"(d0.w));
-  asm volatile("" : "+v"(d1.x), "+v"(d1.y), "+v"(d1.z), "+v"(d1.w));
-  asm volatile("" : "+v"(d2.x), "+v"(d2.y), "+v"(d2.z), "+v"(d2.w));
-  int t_first = -2;
-  asm volatile("" : "+s"(t_first));            // opaque: the loop must not be peeled into a prologue
-  for (int t = t_first; t < wmax; t += 3) {
-    issue(t + 2, d2, q2);
-    retire(q0, t);
-    issue(t + 3, d0, q0);
-    retire(q1, t + 1);
-    issue(t + 4, d1, q1);
-    retire(q2, t + 2);
-  }
-  if (have) s_acc[cur * LPR + c] = acc;
-  __syncthreads();
-  const int c0 = a_cmb_off[wg], c1 = a_cmb_off[wg + 1];
-  if (c1 > c0) {                                  // workgroup-uniform
-    for (int ci = c0 + q; ci < c1; ci += kGroups) {
-      const int4 cm = a_cmb[ci];
-      float4 a = s_acc[cm.x * LPR + c];
-      for (int sgm = 0; sgm < cm.z; ++sgm) {
-        const float4 pz = s_acc[(cm.y + sgm) * LPR + c];
-        a.x = __fadd_rn(a.x, pz.x); a.y = __fadd_rn(a.y, pz.y);
-        a.z = __fadd_rn(a.z, pz.z); a.w = __fadd_rn(a.w, pz.w);
-      }
-      s_acc[cm.x * LPR + c] = a;
-    }
-    __syncthreads();
-  }
-  blocked_epilogue<false, ADAM, LPR>(s_acc, r0, nr, tid, 16 * NR_WAVE, Y, addend, sum_in, sum_out,
-                                     (const uint8_t*)nullptr, ad);
-}
-
-// stream words from the CSR arrays: pair e of the stream = (indices[perm[e]], vals[perm[e]])
-__global__ __launch_bounds__(256) void aff_pack_kernel(const int32_t* __restrict__ perm, int64_t n,
-                                                       const int32_t* __restrict__ indices,
-                                                       const float* __restrict__ vals,
-                                                       int32_t* __restrict__ iv) {
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int32_t pz = perm[e];
-    const int64_t r = e >> 2, u = e & 3;           // round, pair: columns at [8r + u], values at [8r + 4 + u]
-    iv[8 * r + u] = pz >= 0 ? indices[pz] : 0;
-    iv[8 * r + 4 + u] = pz >= 0 ? __float_as_int(vals[pz]) : 0;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // The masked hops of a LightGCN step (d = 64).  Column-masked (first backward hop): only columns of
@@ -1213,126 +1036,6 @@ int launch_wanted_wave(const BlockedPlan* p, const int32_t* d_indices, const flo
 struct HostEnt { int32_t slot, len; uint32_t begin; int32_t owner; };
 int s_gathers_in_flight = 8;     // tuning knob (nrhip_spmm_blocked_tune)
 
-// ---- affinity schedule (host) -------------------------------------------------------------------
-struct AffSub { int phase; int slot; int64_t begin; int len; };
-struct AffItem { int64_t cost; std::vector<AffSub> subs; };
-struct AffHost {
-  std::vector<int32_t> goff, npart, cmb_off, perm;
-  std::vector<int4> cmb;
-  std::vector<uint32_t> rd;
-  int phases_a = 1, phases_b = 1;
-  bool ok = false;
-};
-
-// rows of workgroup w are [row0[w], row0[w] + nrows[w]); classes as in the base schedule
-void build_affinity(const int64_t* h_indptr, const int32_t* h_indices, int64_t n_rows, int64_t split_row,
-                    int n_wg, const std::vector<int32_t>& row0, const std::vector<int32_t>& nrows,
-                    int kSeg, int kRMax, int kPMax, int64_t block_bytes, AffHost& out) {
-  constexpr int kGroups = 64, kQ = 4;
-  const int sub_cost = 3;                         // accumulator switch + the short last round
-  auto phases_of = [&](int64_t ra, int64_t rb, int32_t& cmin, int64_t& width) {
-    int32_t lo = INT32_MAX, hi = -1;
-    for (int64_t t = h_indptr[ra]; t < h_indptr[rb]; ++t) {
-      lo = std::min(lo, h_indices[t]);
-      hi = std::max(hi, h_indices[t]);
-    }
-    if (hi < lo) { lo = 0; hi = 0; }
-    const int64_t span = (int64_t)hi + 1 - lo;
-    int64_t K = (span * 256 + block_bytes - 1) / block_bytes;
-    K = std::min<int64_t>(std::max<int64_t>(K, 1), kAffMaxPhases);
-    cmin = lo;
-    width = (span + K - 1) / K;
-    return (int)K;
-  };
-  int32_t cmin_a = 0, cmin_b = 0;
-  int64_t width_a = 1, width_b = 1;
-  const int64_t sr = split_row ? split_row : n_rows;
-  out.phases_a = phases_of(0, sr, cmin_a, width_a);
-  out.phases_b = split_row ? phases_of(split_row, n_rows, cmin_b, width_b) : out.phases_a;
-  out.goff.assign((size_t)n_wg * (kGroups + 1), 0);
-  out.npart.assign((size_t)n_wg, 0);
-  out.cmb_off.assign((size_t)n_wg + 1, 0);
-  int64_t round_no = 0;
-  std::vector<AffItem> items;
-  std::vector<std::vector<int>> of_group(kGroups);
-  for (int w = 0; w < n_wg; ++w) {
-    out.cmb_off[(size_t)w] = (int32_t)out.cmb.size();
-    const int64_t ra = row0[(size_t)w], rb = ra + nrows[(size_t)w];
-    const bool class_b = split_row && ra >= split_row;
-    const int K = class_b ? out.phases_b : out.phases_a;
-    const int32_t cmin = class_b ? cmin_b : cmin_a;
-    const int64_t width = class_b ? width_b : width_a;
-    if (rb - ra > kRMax) return;
-    items.clear();
-    int npart = 0;
-    for (int64_t row = ra; row < rb; ++row) {
-      const int slot = (int)(row - ra);
-      AffItem direct{0, {}};
-      int first_part = -1, nseg = 0;
-      int64_t t = h_indptr[row];
-      const int64_t te = h_indptr[row + 1];
-      while (t < te) {
-        const int64_t k = std::min<int64_t>(((int64_t)h_indices[t] - cmin) / width, K - 1);
-        const int64_t col_end = (int64_t)cmin + (k + 1) * width;
-        int64_t t2 = t + 1;
-        while (t2 < te && (k == K - 1 || h_indices[t2] < col_end)) ++t2;
-        const int64_t len = t2 - t;
-        if (len <= kSeg) {
-          direct.subs.push_back(AffSub{(int)k, slot, t, (int)len});
-          direct.cost += (len + kQ - 1) / kQ * kQ + sub_cost;
-        } else {
-          const int ns = (int)((len + kSeg - 1) / kSeg);
-          if (npart + ns > kPMax) return;           // too many hub segments: base schedule stays
-          if (first_part < 0) first_part = kRMax + npart;
-          for (int sg = 0; sg < ns; ++sg) {
-            const int64_t l = std::min<int64_t>(kSeg, len - (int64_t)sg * kSeg);
-            items.push_back(AffItem{(l + kQ - 1) / kQ * kQ + sub_cost,
-                                    {AffSub{(int)k, kRMax + npart + sg, t + (int64_t)sg * kSeg, (int)l}}});
-          }
-          npart += ns;
-          nseg += ns;
-        }
-        t = t2;
-      }
-      if (!direct.subs.empty()) items.push_back(std::move(direct));
-      if (nseg) out.cmb.push_back(make_int4(slot, first_part, nseg, 0));
-    }
-    out.npart[(size_t)w] = npart;
-    // longest-processing-time dealing of the items to the 64 lane groups
-    std::vector<int> order(items.size());
-    for (size_t i = 0; i < items.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[(size_t)a].cost > items[(size_t)b].cost; });
-    int64_t load[kGroups] = {0};
-    for (auto& v : of_group) v.clear();
-    for (int i : order) {
-      int best = 0;
-      for (int qg = 1; qg < kGroups; ++qg)
-        if (load[qg] < load[best]) best = qg;
-      load[best] += items[(size_t)i].cost;
-      of_group[(size_t)best].push_back(i);
-    }
-    // streams: window-major per group
-    for (int qg = 0; qg < kGroups; ++qg) {
-      out.goff[(size_t)w * (kGroups + 1) + qg] = (int32_t)round_no;
-      for (int k = 0; k < K; ++k)
-        for (int i : of_group[(size_t)qg])
-          for (const AffSub& sb : items[(size_t)i].subs) {
-            if (sb.phase != k) continue;
-            for (int o = 0; o < sb.len; o += kQ) {
-              const int n = std::min(kQ, sb.len - o);
-              out.rd.push_back((uint32_t)n | ((o == 0 ? 1u : 0u) << 3) | ((uint32_t)sb.slot << 4));
-              for (int u = 0; u < kQ; ++u) out.perm.push_back(u < n ? (int32_t)(sb.begin + o + u) : -1);
-              ++round_no;
-            }
-          }
-    }
-    out.goff[(size_t)w * (kGroups + 1) + kGroups] = (int32_t)round_no;
-    if (round_no > (int64_t)INT32_MAX - 4096) return;
-  }
-  out.cmb_off[(size_t)n_wg] = (int32_t)out.cmb.size();
-  out.ok = true;
-}
-
 // (column, value) pairs copied into the plan's row order: row k of the order is CSR positions
 // [src[k], src[k] + dst[k+1] - dst[k]) -> packed positions [dst[k], dst[k+1]).  Once per matrix.
 __global__ __launch_bounds__(256) void row_order_pack_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst,
@@ -1355,7 +1058,8 @@ extern "C" {
 
 int nrhip_spmm_blocked_plan_bytes(int64_t n_rows, int64_t nnz, int d, size_t* bytes) {
   NR_REQUIRE(bytes && n_rows >= 0 && nnz >= 0, NR_ERR_ARG, "spmm_blocked_plan_bytes: bad arguments");
-  *bytes = blocked_plan_bytes(n_rows, nnz) + (d == 64 && aff_enabled() ? aff_plan_bytes(n_rows, nnz) : 0);
+  (void)d;
+  *bytes = blocked_plan_bytes(n_rows, nnz);
   return NR_OK;
 }
 
@@ -1379,11 +1083,9 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   const int64_t nnz = h_indptr[n_rows] - h_indptr[0];
   NR_REQUIRE(h_indptr[0] == 0 && nnz < ((int64_t)1 << 32), NR_ERR_UNSUPPORTED,
              "spmm_blocked: indptr must start at 0 and hold < 2^32 non-zeros");
-  const size_t need_bytes = blocked_plan_bytes(n_rows, nnz) + (d == 64 && aff_enabled() ? aff_plan_bytes(n_rows, nnz) : 0);
+  const size_t need_bytes = blocked_plan_bytes(n_rows, nnz);
   NR_REQUIRE(plan_bytes >= need_bytes, NR_ERR_WORKSPACE,
              "spmm_blocked_plan_create: plan buffer %zu < %zu bytes", plan_bytes, need_bytes);
-  if (block_bytes <= 0)
-    if (const char* e0 = getenv("NEUREC_SPMM_BLOCK_BYTES")) block_bytes = atoll(e0);   // experiments
   if (block_bytes <= 0) block_bytes = (int64_t)1 << 40;     // measured: phases cost more than they save
   if (split_row <= 0 || split_row >= n_rows) split_row = 0;
   int n_wg = n_workgroups;
@@ -1411,8 +1113,7 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   // cost of a row for balancing: its non-zeros plus a fixed cost per sub-list (descriptor, first
   // index chunk and the short last gather round; fitted on the per-workgroup timeline,
   // profiles/r01_exp_spmm_timeline.txt)
-  int ent_cost = 4;     // r05 (rows dealt): 0 .. 16 all within 1 us of each other, 2-4 best (profiles/r05_exp_entcost.txt)
-  if (const char* e = getenv("NEUREC_SPMM_ENTCOST")) ent_cost = atoi(e);
+  const int ent_cost = 4;     // r05 (rows dealt): 0 .. 16 all within 1 us of each other, 2-4 best (profiles/r05_exp_entcost.txt)
   auto row_cost = [&](int64_t l) { return l + (int64_t)ent_cost * std::max<int64_t>(1, (l + kSeg - 1) / kSeg); };
   struct ClassDesc { int64_t ra, rb; std::vector<int> wgs; int32_t cmin; int64_t width, K; };
   std::vector<ClassDesc> classes;
@@ -1449,8 +1150,6 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   std::vector<std::vector<std::vector<int4>>> wg_cmb(n_wg);
   int n_phases = 1;
   std::vector<std::vector<int32_t>> wg_rows((size_t)n_wg);         // [wg] its rows, slot order
-  bool dealt = !aff_enabled();
-  if (const char* e = getenv("NEUREC_SPMM_DEAL")) dealt = dealt && e[0] != '0';
   for (ClassDesc& cl : classes) {
     const int64_t cb = h_indptr[cl.ra], ce = h_indptr[cl.rb];
     int32_t cmin = INT32_MAX, cmax = -1;
@@ -1476,11 +1175,12 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     // the item class carried 1.9x the mean cost and the pass took 50 us instead of 34.  r05: rows are DEALT —
     // sorted by cost, each to the least-loaded workgroup that still has an accumulator (LPT) — so every
     // workgroup gets the same cost whatever the numbering; the plan lists a workgroup's rows (row_of) and owns
-    // the (column, value) pairs in that order.  NEUREC_SPMM_DEAL=0 (A/B) and the affinity schedule keep runs.
+    // the (column, value) pairs in that order.  (The r01-r04 contiguous runs left the product in r06:
+    // profiles/r05_exp_entcost.txt has the A/B.)
     const int64_t n_cl = cl.rb - cl.ra;
     const int64_t nw = (int64_t)cl.wgs.size();
     std::vector<std::vector<int32_t>> lists((size_t)nw);
-    if (dealt) {
+    {
       NR_REQUIRE(n_cl <= nw * (int64_t)kRMax, NR_ERR_UNSUPPORTED,
                  "spmm_blocked: %lld rows do not fit %zu workgroups x %d accumulators — use the work-item kernel",
                  (long long)n_cl, cl.wgs.size(), kRMax);
@@ -1502,29 +1202,6 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
         top.first += row_cost(h_indptr[row + 1] - h_indptr[row]);
         if ((int64_t)lists[(size_t)top.second].size() < kRMax) heap.push(top);
       }
-    } else {
-      int64_t r = cl.ra, left = 0;
-      for (int64_t q = cl.ra; q < cl.rb; ++q) left += row_cost(h_indptr[q + 1] - h_indptr[q]);
-      for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
-        const int64_t wgs_left = (int64_t)cl.wgs.size() - (int64_t)wi;
-        const int64_t target = (left + wgs_left - 1) / wgs_left;
-        const int64_t rstart = r;
-        int64_t got = 0;
-        while (r < cl.rb && (r - rstart) < kRMax) {
-          const int64_t l = row_cost(h_indptr[r + 1] - h_indptr[r]);
-          // stop at the cost target unless the rows left would overflow the later workgroups
-          const bool must_take = (cl.rb - r) > (wgs_left - 1) * (int64_t)kRMax;
-          if (!must_take && wgs_left > 1 && got > 0 && got + l / 2 > target) break;
-          got += l;
-          ++r;
-        }
-        if (wgs_left == 1)
-          NR_REQUIRE(r == cl.rb, NR_ERR_UNSUPPORTED,
-                     "spmm_blocked: %lld rows do not fit %zu workgroups x %d accumulators — use the "
-                     "work-item kernel", (long long)(cl.rb - cl.ra), cl.wgs.size(), kRMax);
-        left -= got;
-        for (int64_t row = rstart; row < r; ++row) lists[wi].push_back((int32_t)row);
-      }
     }
     for (size_t wi = 0; wi < cl.wgs.size(); ++wi) {
       const int w = cl.wgs[wi];
@@ -1535,18 +1212,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   std::vector<int32_t> row_of((size_t)n_rows);
   std::vector<uint32_t> pk_src((size_t)n_rows), pk_dst((size_t)n_rows + 1, 0);
   {
-    // workgroups in the order of their first row when rows are runs (position == row id: the affinity kernel
-    // addresses rows as wg_row0 + slot), in id order when rows are dealt
-    std::vector<int> wg_order((size_t)n_wg);
-    for (int w = 0; w < n_wg; ++w) wg_order[(size_t)w] = w;
-    if (!dealt)
-      std::stable_sort(wg_order.begin(), wg_order.end(), [&](int x, int y) {
-        const int64_t fx = wg_rows[(size_t)x].empty() ? n_rows : wg_rows[(size_t)x][0];
-        const int64_t fy = wg_rows[(size_t)y].empty() ? n_rows : wg_rows[(size_t)y][0];
-        return fx < fy;
-      });
     int64_t k = 0;
-    for (int w : wg_order) {
+    for (int w = 0; w < n_wg; ++w) {
       wg_row0[(size_t)w] = (int32_t)k;
       wg_nrows[(size_t)w] = (int32_t)wg_rows[(size_t)w].size();
       for (int32_t row : wg_rows[(size_t)w]) {
@@ -1771,28 +1438,6 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
                          (size_t)((n_rows + 127) / 128 * 16) + 1024 <= (size_t)kMaxLdsBytes;
     }
   }
-  AffHost aff;
-  {
-    // cache-blocked full pass without phase barriers (spmm_affinity_kernel): its own schedule on
-    // the same row runs.  OFF by default — measured on MI355X (profiles/r02_exp_affinity.txt): the
-    // groups of an XCD drift apart within a handful of rounds, the L2 miss count does not move
-    // (1.69 M per pass with one window, 1.61 M with five) and the pass is 36-41 us against the base
-    // kernel's 34 us.  NEUREC_SPMM_AFFINITY=1 builds and uses it (A/B runs, tests);
-    // NEUREC_SPMM_AFF_BLOCK = the window of the gathered table in bytes.
-    int64_t win = 5 * 512 * 1024;
-    if (const char* e2 = getenv("NEUREC_SPMM_AFF_BLOCK")) win = std::max<int64_t>(atoll(e2), 64 * 1024);
-    if (d == 64 && kWaves == 16 && n_phases == 1 && aff_enabled())
-      build_affinity(h_indptr, h_indices, n_rows, split_row, n_wg, wg_row0, wg_nrows, kSeg, kRMax, kPMax,
-                     win, aff);
-    if (aff.ok && aff.rd.size() + kAffSlackRounds > aff_rounds_bound(n_rows, nnz)) aff.ok = false;
-  }
-  p->aff_ok = aff.ok ? 1 : 0;
-  p->aff_packed = 0;
-  p->aff_indices = nullptr;
-  p->aff_vals = nullptr;
-  p->aff_rounds = aff.ok ? (int64_t)aff.rd.size() : 0;
-  p->aff_phases_a = aff.phases_a;
-  p->aff_phases_b = aff.phases_b;
   p->n_rows = n_rows; p->nnz = nnz; p->n_wg = n_wg; p->n_phases = n_phases;
   p->seg = kSeg; p->r_max = kRMax; p->p_max = kPMax; p->waves = kWaves; p->d = d;
   p->n_ent = (int64_t)ent.size(); p->n_cmb = (int64_t)cmb.size();
@@ -1829,19 +1474,6 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     p->ww_part = (float*)carve((size_t)ww_segments * 256 + 256);
     p->ww_cnt = (unsigned*)carve(ww_hub.size() * 4 + 4);
   }
-  p->a_goff = p->a_npart = p->a_cmb_off = p->a_perm = nullptr;
-  p->a_cmb = p->a_iv = nullptr;
-  p->a_rd = nullptr;
-  if (p->aff_ok) {
-    const size_t rounds = aff.rd.size() + kAffSlackRounds;
-    p->a_goff = (int32_t*)carve(aff.goff.size() * 4);
-    p->a_npart = (int32_t*)carve(aff.npart.size() * 4);
-    p->a_cmb_off = (int32_t*)carve(aff.cmb_off.size() * 4);
-    p->a_cmb = (int4*)carve(aff.cmb.size() * 16 + 16);
-    p->a_rd = (uint32_t*)carve(rounds * 4);
-    p->a_perm = (int32_t*)carve(rounds * 16);
-    p->a_iv = (int4*)carve(rounds * 32);
-  }
   if ((size_t)(q - (char*)d_plan_buf) > plan_bytes) {
     delete p;
     nrhip_set_error("spmm_blocked_plan_create: plan needs %zu bytes, buffer has %zu",
@@ -1877,18 +1509,6 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
     up(p->ww_lcmb, ww_lcmb.data(), ww_lcmb.size() * 16);
     if (e == hipSuccess) e = hipMemsetAsync(p->ww_cnt, 0, ww_hub.size() * 4 + 4, st);
   }
-  if (p->aff_ok) {
-    const size_t rounds = aff.rd.size() + kAffSlackRounds;
-    if (e == hipSuccess) e = hipMemsetAsync(p->a_rd, 0, rounds * 4, st);       // slack rounds: ignored words
-    if (e == hipSuccess) e = hipMemsetAsync(p->a_perm, 0xFF, rounds * 16, st); // ... of padding pairs
-    if (e == hipSuccess) e = hipMemsetAsync(p->a_iv, 0, rounds * 32, st);
-    up(p->a_goff, aff.goff.data(), aff.goff.size() * 4);
-    up(p->a_npart, aff.npart.data(), aff.npart.size() * 4);
-    up(p->a_cmb_off, aff.cmb_off.data(), aff.cmb_off.size() * 4);
-    up(p->a_cmb, aff.cmb.data(), aff.cmb.size() * 16);
-    up(p->a_rd, aff.rd.data(), aff.rd.size() * 4);
-    up(p->a_perm, aff.perm.data(), aff.perm.size() * 4);
-  }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   const int lds = (kRMax + kPMax) * kD * 4 + kRMax * 4;           // accumulators + the workgroup's row list
   auto allow = [&](const void* fn) {
@@ -1903,8 +1523,6 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   else if (d == 64) {
     NR_ALLOW(64);
     allow((const void*)spmm_blocked_kernel<false, 16, 8, 64, true>);
-    allow((const void*)spmm_affinity_kernel<false>);
-    allow((const void*)spmm_affinity_kernel<true>);
   }
   else if (d == 128) { NR_ALLOW(128); } else { NR_ALLOW(256); }
 #undef NR_ALLOW
@@ -1929,9 +1547,8 @@ int nrhip_spmm_blocked_plan_create(const int64_t* h_indptr, const int32_t* h_ind
   return NR_OK;
 }
 
-/* Fill the affinity schedule's (column, value) stream from the matrix's CSR arrays (once per matrix;
- * again if the values change).  Until then — and for calls that pass other arrays — the full pass
- * runs on the base schedule.  No-op for plans without an affinity schedule. */
+/* Copy the matrix's (column, value) pairs into the plan's row order (once per matrix; again if the values change:
+ * engine.SpmmCSR.values_changed).  The lane-group kernels read this private copy. */
 int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d_vals, void* stream) {
   NR_REQUIRE(plan && d_indices && d_vals, NR_ERR_ARG, "spmm_blocked_pack: null pointer argument");
   BlockedPlan* p = (BlockedPlan*)plan;
@@ -1944,17 +1561,6 @@ int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d
   }
   p->pk_from_idx = d_indices;
   p->pk_from_val = d_vals;
-  if (!p->aff_ok) return NR_OK;
-  const int64_t n = p->aff_rounds * 4;
-  if (n > 0) {
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(aff_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->a_perm, n,
-                       d_indices, d_vals, (int32_t*)p->a_iv);
-    NR_LAUNCH_CHECK();
-  }
-  p->aff_packed = 1;
-  p->aff_indices = d_indices;
-  p->aff_vals = d_vals;
   return NR_OK;
 }
 
@@ -1963,15 +1569,6 @@ int nrhip_spmm_blocked_pack(void* plan, const int32_t* d_indices, const float* d
 static int ensure_packed(const BlockedPlan* p, const int32_t* d_indices, const float* d_vals, void* stream) {
   if (p->pk_from_idx == d_indices && p->pk_from_val == d_vals) return NR_OK;
   return nrhip_spmm_blocked_pack((void*)p, d_indices, d_vals, stream);
-}
-
-/* 0: the full pass runs spmm_blocked_kernel; K > 0: it runs spmm_affinity_kernel over K column
- * windows for the first row class (K_b for the second, when the matrix is split). */
-int nrhip_spmm_blocked_affinity(const void* plan, int* windows_b) {
-  if (!plan) return 0;
-  const BlockedPlan* p = (const BlockedPlan*)plan;
-  if (windows_b) *windows_b = p->aff_ok && p->aff_packed ? p->aff_phases_b : 0;
-  return p->aff_ok && p->aff_packed ? p->aff_phases_a : 0;
 }
 
 #ifdef NR_WW_TIMELINE
@@ -2045,14 +1642,6 @@ int nrhip_spmm_blocked(const void* plan, const int32_t* d_indices, const float* 
     else if (d_x_row_nonzero) NR_STAGED(true, false);
     else NR_STAGED(false, true);
 #undef NR_STAGED
-    NR_LAUNCH_CHECK();
-    return NR_OK;
-  }
-  if (!masked && p->aff_ok && p->aff_packed && p->aff_indices == d_indices && p->aff_vals == d_vals) {
-    hipLaunchKernelGGL(spmm_affinity_kernel<false>, grid, block, lds, st, p->wg_row0, p->wg_nrows,
-                       p->a_goff, p->a_npart, p->a_cmb_off, p->a_cmb, p->a_iv, p->a_rd,
-                       (const float4*)d_X, (float4*)d_Y, (const float4*)d_addend,
-                       (const float4*)d_sum_in, (float4*)d_sum_out, p->r_max, AdamEpilogue{});
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
@@ -2167,14 +1756,6 @@ int nrhip_spmm_blocked_adam(const void* plan, const int32_t* d_indices, const fl
                   alpha, 1.0f - beta1, 1.0f - beta2, eps,
                   clear_consumed ? (float4*)d_addend : nullptr,
                   clear_consumed ? (float4*)d_grad_b : nullptr, clear_consumed ? d_row_flag : nullptr};
-  if (p->aff_ok && p->aff_packed && p->aff_indices == d_indices && p->aff_vals == d_vals) {
-    hipLaunchKernelGGL(spmm_affinity_kernel<true>, dim3((unsigned)p->n_wg), dim3(16 * NR_WAVE), lds,
-                       (hipStream_t)stream, p->wg_row0, p->wg_nrows, p->a_goff, p->a_npart,
-                       p->a_cmb_off, p->a_cmb, p->a_iv, p->a_rd, (const float4*)d_X, (float4*)nullptr,
-                       (const float4*)d_addend, (const float4*)nullptr, (float4*)nullptr, p->r_max, ad);
-    NR_LAUNCH_CHECK();
-    return NR_OK;
-  }
   hipLaunchKernelGGL((spmm_blocked_kernel<false, 16, 8, 64, true>), dim3((unsigned)p->n_wg),
                      dim3(16 * NR_WAVE), lds, (hipStream_t)stream, p->wg_row0, p->wg_nrows,
                      p->wg_ent_off, p->wg_cmb_off, p->ent, p->cmb, p->n_phases, p->pk_idx, p->pk_val,

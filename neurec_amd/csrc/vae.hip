@@ -15,9 +15,8 @@
 // dimension on both sides is logits = g1·W_p1ᵀ ([B,32]×[32,I]): that one runs on the fp32
 // matrix cores through nrhip_score_gemm (W_p1 is stored item-major, [I][32]).  Its two
 // gradients read the [B,I] logits once each and run on the matrix cores too (dLoss/dlogits is
-// formed in registers, never stored: vae_dwp1_mfma_kernel / vae_dg1_mfma_kernel; the first,
-// VALU design — dlogits in place, then one pass per gradient — stays behind
-// NEUREC_VAE_DECODER_VALU=1).  The 16/32-wide middle layers are register-resident per-row math,
+// formed in registers, never stored: vae_dwp1_mfma_kernel / vae_dg1_mfma_kernel; r01's VALU
+// design — dlogits in place, then one pass per gradient, 160 us per step — left the product in r06).  The 16/32-wide middle layers are register-resident per-row math,
 // as in dense.hip.
 #include "nr_common.h"
 #include <algorithm>
@@ -180,273 +179,6 @@ __global__ __launch_bounds__(256) void add_row_bias_kernel(float* __restrict__ S
     const int c = (int)(i - r * cols);
     S[r * ld + c] += bias[c];
   }
-}
-
-// ----------------------------------------------------------------------------
-// log-softmax + multinomial likelihood + dlogits, one block per batch row, in place:
-//   S[b][i] <- (softmax_i · n_b − x_bi) / B ;  nll[b] = −Σ_{i∈x_b} (l_i − lse)
-// (l_i = S[b][i] + bias[i]).  x_b is kept as a bitmap in LDS.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vae_softmax_grad_kernel(
-    float* __restrict__ S, int64_t ld, int cols, const float* __restrict__ bias,
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-    const int32_t* __restrict__ rows, float inv_batch, float* __restrict__ nll,
-    uint32_t* __restrict__ bitmap_ws, int bitmap_words) {
-  __shared__ float s_red[256];
-  __shared__ float s_lse;
-  const int r = blockIdx.x, tid = threadIdx.x;
-  float* srow = S + (int64_t)r * ld;
-  const int64_t u = rows[r];
-  const int64_t b = indptr[u], e = indptr[u + 1];
-  uint32_t* bm = bitmap_ws + (int64_t)r * bitmap_words;
-  for (int w = tid; w < bitmap_words; w += 256) bm[w] = 0u;
-  __syncthreads();
-  for (int64_t t = b + tid; t < e; t += 256) atomicOr(&bm[indices[t] >> 5], 1u << (indices[t] & 31));
-  // pass A: online (max, sum of exp) over the row, 16-byte loads; pass B: gradient in place
-  const int cols4 = cols & ~3;
-  const float4* srow4 = reinterpret_cast<const float4*>(srow);
-  const float4* bias4 = reinterpret_cast<const float4*>(bias);
-  float mx = -INFINITY, sum = 0.f;
-  auto fold = [&](float x) {
-    if (x > mx) { sum = sum * expf(mx - x) + 1.0f; mx = x; }
-    else sum += expf(x - mx);
-  };
-  // kUn independent 16-byte loads per thread and round (unconditional, clamped): the folds below
-  // branch, so the compiler will not overlap one iteration's loads with the next one's — 40 rounds
-  // of one memory round trip each were most of this kernel's 60 us
-  constexpr int kUn = 4;
-  const int n4 = cols4 / 4;
-  for (int i0 = tid; i0 < n4; i0 += 256 * kUn) {
-    float4 a[kUn], bb[kUn];
-#pragma unroll
-    for (int k = 0; k < kUn; ++k) {
-      const int i = min(i0 + k * 256, n4 - 1);
-      a[k] = srow4[i];
-      bb[k] = bias4[i];
-    }
-#pragma unroll
-    for (int k = 0; k < kUn; ++k)
-      if (i0 + k * 256 < n4) {
-        fold(a[k].x + bb[k].x); fold(a[k].y + bb[k].y); fold(a[k].z + bb[k].z); fold(a[k].w + bb[k].w);
-      }
-  }
-  for (int i = cols4 + tid; i < cols; i += 256) fold(srow[i] + bias[i]);
-  s_red[tid] = mx;
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] = fmaxf(s_red[tid], s_red[tid + s]); __syncthreads(); }
-  const float gmx = s_red[0];
-  __syncthreads();
-  s_red[tid] = (mx == -INFINITY) ? 0.f : sum * expf(mx - gmx);
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-  if (tid == 0) s_lse = gmx + logf(s_red[0]);
-  __syncthreads();
-  const float lse = s_lse;
-  const float nb = (float)(e - b);
-  float ll = 0.f;
-  auto grad = [&](float xv, bool x) {
-    const float l = xv - lse;                                  // log-softmax
-    if (x) ll += l;
-    return (expf(l) * nb - (x ? 1.f : 0.f)) * inv_batch;
-  };
-  float4* srow4w = reinterpret_cast<float4*>(srow);
-  for (int i0 = tid; i0 < n4; i0 += 256 * kUn) {
-    float4 a[kUn], bb[kUn];
-    uint32_t bits[kUn];                                      // 4 consecutive items share a bitmap word
-#pragma unroll
-    for (int k = 0; k < kUn; ++k) {
-      const int i = min(i0 + k * 256, n4 - 1);
-      a[k] = srow4[i];
-      bb[k] = bias4[i];
-      bits[k] = bm[i >> 3] >> ((4 * i) & 31);
-    }
-#pragma unroll
-    for (int k = 0; k < kUn; ++k) {
-      const int i = i0 + k * 256;
-      if (i < n4) {
-        float4 o;
-        o.x = grad(a[k].x + bb[k].x, bits[k] & 1u); o.y = grad(a[k].y + bb[k].y, (bits[k] >> 1) & 1u);
-        o.z = grad(a[k].z + bb[k].z, (bits[k] >> 2) & 1u); o.w = grad(a[k].w + bb[k].w, (bits[k] >> 3) & 1u);
-        srow4w[i] = o;
-      }
-    }
-  }
-  for (int i = cols4 + tid; i < cols; i += 256)
-    srow[i] = grad(srow[i] + bias[i], ((bm[i >> 5] >> (i & 31)) & 1u) != 0u);
-  s_red[tid] = ll;
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-  if (tid == 0) nll[r] = -s_red[0];
-}
-
-// ----------------------------------------------------------------------------
-// dW_p1[i][:] = Σ_b dlogits[b][i]·g1[b][:],  db_p1[i] = Σ_b dlogits[b][i].
-// A block = 64 items x 4 waves; wave q takes every 4th group of 64 batch rows of the staged slab
-// (the lanes of a wave read 64 consecutive items of a row: one 256-byte load), 16 loads in flight
-// per lane, and the four partial sums meet in LDS.  The first version gave an item to a thread
-// for all batch rows: 640 waves on 1,024 SIMDs, each a chain of batch/8 memory round trips (1.5 us
-// each on this part) — 89 us for 84 MB.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vae_dwp1_kernel(const float* __restrict__ dlogits,
-                                                       int64_t ld, int batch, int cols, int h,
-                                                       const float* __restrict__ G1,
-                                                       float* __restrict__ dWp1,
-                                                       float* __restrict__ dbp1) {
-  constexpr int kSlab = 256;                                       // batch rows staged per round
-  constexpr int kInFlight = 16;
-  __shared__ __attribute__((aligned(16))) float s_g1[kSlab * kMaxD];   // 32 KB; reused for the reduction
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int item = blockIdx.x * 64 + lane;
-  const int item_c = min(item, cols - 1);                          // idle lanes read a valid column
-  float acc[kMaxD];
-#pragma unroll
-  for (int j = 0; j < kMaxD; ++j) acc[j] = 0.f;
-  float bsum = 0.f;
-  for (int b0 = 0; b0 < batch; b0 += kSlab) {
-    const int nb = min(kSlab, batch - b0);
-    __syncthreads();
-    // g1 rows staged zero-padded to kMaxD columns: the inner product below needs no h predicate
-    for (int i = threadIdx.x; i < kSlab * kMaxD; i += 256) {
-      const int bb = i / kMaxD, j = i % kMaxD;
-      s_g1[i] = (bb < nb && j < h) ? G1[(int64_t)(b0 + bb) * h + j] : 0.f;
-    }
-    __syncthreads();
-    for (int bb = q * 64; bb < nb; bb += 4 * 64) {                 // this wave's 64-row groups
-      for (int u0 = 0; u0 < 64; u0 += kInFlight) {
-        float g[kInFlight];
-#pragma unroll
-        for (int u = 0; u < kInFlight; ++u)                        // rows past the slab: row 0, weight 0 (zero g1)
-          g[u] = dlogits[(int64_t)(b0 + min(bb + u0 + u, nb - 1)) * ld + item_c];
-#pragma unroll
-        for (int u = 0; u < kInFlight; ++u) {
-          const bool in = bb + u0 + u < nb;
-          const float gv = in ? g[u] : 0.f;
-          bsum += gv;
-          const float4* gr = reinterpret_cast<const float4*>(s_g1 + min(bb + u0 + u, nb - 1) * kMaxD);
-#pragma unroll
-          for (int j4 = 0; j4 < kMaxD / 4; ++j4) {
-            const float4 w = gr[j4];               // wave-uniform address: LDS broadcast
-            acc[4 * j4] = fmaf(gv, w.x, acc[4 * j4]);
-            acc[4 * j4 + 1] = fmaf(gv, w.y, acc[4 * j4 + 1]);
-            acc[4 * j4 + 2] = fmaf(gv, w.z, acc[4 * j4 + 2]);
-            acc[4 * j4 + 3] = fmaf(gv, w.w, acc[4 * j4 + 3]);
-          }
-        }
-      }
-    }
-  }
-  // waves 1..3 hand their partial sums to wave 0 through LDS ([3][33][64], lane-contiguous)
-  __syncthreads();
-  float* s_red = s_g1;
-  if (q > 0) {
-#pragma unroll
-    for (int j = 0; j < kMaxD; ++j) s_red[((q - 1) * (kMaxD + 1) + j) * 64 + lane] = acc[j];
-    s_red[((q - 1) * (kMaxD + 1) + kMaxD) * 64 + lane] = bsum;
-  }
-  __syncthreads();
-  if (q != 0 || item >= cols) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-#pragma unroll
-    for (int j = 0; j < kMaxD; ++j) acc[j] += s_red[(w * (kMaxD + 1) + j) * 64 + lane];
-    bsum += s_red[(w * (kMaxD + 1) + kMaxD) * 64 + lane];
-  }
-#pragma unroll
-  for (int j = 0; j < kMaxD; ++j)
-    if (j < h) dWp1[(int64_t)item * h + j] = acc[j];
-  dbp1[item] = bsum;
-}
-
-// dg1[b][:] = Σ_i dlogits[b][i]·W_p1[i][:].  A block of 8 waves takes kDg1Rows batch rows against
-// one of kDg1Split item ranges: W_p1 is then streamed batch/16 times instead of batch/2 times (the
-// first version: 1.3 GB through the L2s, 189 us).  A wave takes every 8th 64-item chunk of the
-// range: each row's dlogits of the chunk are one coalesced load, a lane owns a column quad
-// (q = lane & 7 -> columns 4q..4q+3) of item (lane >> 3) of each 8-item step, so a 16-byte load per
-// lane brings eight W_p1 rows per instruction.  Partial sums per item range go to the workspace and
-// are added in range order by vae_dg1_reduce_kernel (deterministic).
-constexpr int kDg1Waves = 8;
-constexpr int kDg1Rows = 16;
-constexpr int kDg1Split = 8;
-__global__ __launch_bounds__(kDg1Waves* NR_WAVE) void vae_dg1_kernel(
-    const float* __restrict__ dlogits, int64_t ld, int batch, int cols, int h,
-    const float* __restrict__ Wp1, float* __restrict__ part) {
-  __shared__ float s_red[kDg1Waves][kDg1Rows][kMaxD];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int q = lane & 7, t = lane >> 3;
-  const int r0 = blockIdx.x * kDg1Rows;
-  const int chunks = (cols + NR_WAVE - 1) / NR_WAVE;
-  const int per = (chunks + kDg1Split - 1) / kDg1Split;
-  const int ch0 = blockIdx.y * per, ch1 = min(chunks, ch0 + per);
-  const int hq = (h + 3) / 4;                      // column quads in use (h <= 32 -> <= 8)
-  float4 a[kDg1Rows];
-#pragma unroll
-  for (int r = 0; r < kDg1Rows; ++r) a[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int ch = ch0 + wave; ch < ch1; ch += kDg1Waves) {
-    const int c0 = ch * NR_WAVE;
-    const int nn = min(NR_WAVE, cols - c0);
-    float dv[kDg1Rows];
-#pragma unroll
-    for (int r = 0; r < kDg1Rows; ++r)            // unconditional loads (clamped), zeroed afterwards
-      dv[r] = dlogits[(int64_t)min(r0 + r, batch - 1) * ld + c0 + min(lane, nn - 1)];
-    float4 w[8];
-#pragma unroll
-    for (int sI = 0; sI < 8; ++sI) {
-      const int it = min(8 * sI + t, nn - 1);
-      const float* wp = Wp1 + (int64_t)(c0 + it) * h + 4 * min(q, hq - 1);
-      if ((h & 3) == 0) w[sI] = *(const float4*)wp;
-      else {
-        w[sI].x = wp[0];
-        w[sI].y = 4 * q + 1 < h ? wp[1] : 0.f;
-        w[sI].z = 4 * q + 2 < h ? wp[2] : 0.f;
-        w[sI].w = 4 * q + 3 < h ? wp[3] : 0.f;
-      }
-      if (8 * sI + t >= nn || q >= hq) w[sI] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int r = 0; r < kDg1Rows; ++r) {
-      const float d = (lane < nn && r0 + r < batch) ? dv[r] : 0.f;
-#pragma unroll
-      for (int sI = 0; sI < 8; ++sI) {
-        const float gv = __shfl(d, 8 * sI + t, NR_WAVE);
-        a[r].x = fmaf(gv, w[sI].x, a[r].x); a[r].y = fmaf(gv, w[sI].y, a[r].y);
-        a[r].z = fmaf(gv, w[sI].z, a[r].z); a[r].w = fmaf(gv, w[sI].w, a[r].w);
-      }
-    }
-  }
-  // sum the eight item lanes (t) of every column quad, then the waves
-#pragma unroll
-  for (int r = 0; r < kDg1Rows; ++r) {
-#pragma unroll
-    for (int m = 8; m < NR_WAVE; m <<= 1) {
-      a[r].x += __shfl_xor(a[r].x, m, NR_WAVE); a[r].y += __shfl_xor(a[r].y, m, NR_WAVE);
-      a[r].z += __shfl_xor(a[r].z, m, NR_WAVE); a[r].w += __shfl_xor(a[r].w, m, NR_WAVE);
-    }
-    if (t == 0) {
-      s_red[wave][r][4 * q] = a[r].x; s_red[wave][r][4 * q + 1] = a[r].y;
-      s_red[wave][r][4 * q + 2] = a[r].z; s_red[wave][r][4 * q + 3] = a[r].w;
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < kDg1Rows * kMaxD; i += kDg1Waves * NR_WAVE) {
-    const int r = i / kMaxD, j = i % kMaxD;
-    if (r0 + r < batch && j < h) {
-      float sum = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < kDg1Waves; ++w2) sum += s_red[w2][r][j];
-      part[((int64_t)blockIdx.y * batch + r0 + r) * kMaxD + j] = sum;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void vae_dg1_reduce_kernel(const float* __restrict__ part, int batch,
-                                                             int h, float* __restrict__ dG1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= batch * h) return;
-  const int r = i / h, j = i % h;
-  float sum = 0.f;
-#pragma unroll
-  for (int k = 0; k < kDg1Split; ++k) sum += part[((int64_t)k * batch + r) * kMaxD + j];
-  dG1[i] = sum;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -715,12 +447,6 @@ __global__ __launch_bounds__(256) void vae_dg1_reduce_n_kernel(const float* __re
   dG1[idx] = sum;
 }
 
-// NEUREC_VAE_DECODER_VALU=1 keeps the first design (in-place dlogits + two VALU passes)
-bool vae_decoder_valu() {
-  static const bool v = [] { const char* e = getenv("NEUREC_VAE_DECODER_VALU"); return e && e[0] == '1'; }();
-  return v;
-}
-
 // ----------------------------------------------------------------------------
 // Middle of the backward pass, one wave per batch row:
 //   da3 = dg1·act'(g1);  dz = da3·W_p0ᵀ;  dmu = dz + anneal·mu/B;
@@ -938,17 +664,16 @@ int nrhip_add_row_bias(float* d_S, int64_t ld, int batch, int cols, const float*
 int nrhip_vae_workspace_bytes(int batch, int cols, size_t* bytes) {
   NR_REQUIRE(bytes && batch >= 0 && cols >= 1, NR_ERR_ARG, "vae_workspace_bytes: bad arguments");
   const size_t rows = (size_t)(batch > 0 ? batch : 1);
-  // positive-item bit rows of the softmax gradient, then the dg1 partial sums (per item range: the VALU
-  // form; per workgroup: the matrix-core form) and the per-row softmax statistics
+  // positive-item bit rows of the softmax gradient, then the dg1 partial sums (per item range) and the per-row
+  // softmax statistics
   const size_t rows_pad = (rows + kDecTile - 1) / kDecTile * kDecTile;
-  const size_t parts = std::max((size_t)kDg1Split * rows, (size_t)kDg1Ranges * rows_pad);
+  const size_t parts = (size_t)kDg1Ranges * rows_pad;
   *bytes = nr_align_up(rows * (size_t)((cols + 31) / 32) * sizeof(uint32_t), 256) +
            parts * kMaxD * sizeof(float) + nr_align_up(rows * sizeof(float2), 256);
   return NR_OK;
 }
 
-/* d_S holds g1·W_p1ᵀ (no bias) on entry; its contents on exit are unspecified (the logits, or dLoss/dlogits
- * in the VALU form). */
+/* d_S holds g1·W_p1ᵀ (no bias) on entry and is only read. */
 int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int h,
                                 const float* d_bp1, const int64_t* d_indptr,
                                 const int32_t* d_indices, const int32_t* d_rows,
@@ -961,12 +686,10 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
   NR_REQUIRE(h >= 1 && h <= kMaxD, NR_ERR_UNSUPPORTED, "vae_decoder: hidden %d > 32", h);
   const int words = (cols + 31) / 32;
   const size_t bits_bytes = nr_align_up((size_t)batch * words * sizeof(uint32_t), 256);
-  NR_REQUIRE(ws_bytes >= bits_bytes + (size_t)kDg1Split * batch * kMaxD * sizeof(float), NR_ERR_WORKSPACE,
-             "vae_decoder_loss_grad: workspace too small");
   float* part = (float*)((char*)d_ws + bits_bytes);
   hipStream_t st = (hipStream_t)stream;
-  if (!vae_decoder_valu()) {
-    // matrix-core form: statistics, then one read of the logits per gradient
+  {
+    // statistics, then one read of the logits per gradient
     const int rows_pad = (batch + kDecTile - 1) / kDecTile * kDecTile;
     const size_t parts_bytes = (size_t)kDg1Ranges * rows_pad * kMaxD * sizeof(float);
     NR_REQUIRE(ws_bytes >= bits_bytes + parts_bytes + nr_align_up((size_t)batch * sizeof(float2), 256),
@@ -991,19 +714,6 @@ int nrhip_vae_decoder_loss_grad(float* d_S, int64_t ld, int batch, int cols, int
     NR_LAUNCH_CHECK();
     return NR_OK;
   }
-  hipLaunchKernelGGL(vae_softmax_grad_kernel, dim3(batch), dim3(256), 0, st, d_S, ld, cols, d_bp1,
-                     d_indptr, d_indices, d_rows, 1.0f / (float)batch, d_nll, (uint32_t*)d_ws, words);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dwp1_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, d_S, ld, batch,
-                     cols, h, d_G1, d_dWp1, d_dbp1);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dg1_kernel, dim3((batch + kDg1Rows - 1) / kDg1Rows, kDg1Split),
-                     dim3(kDg1Waves * NR_WAVE), 0, st, d_S, ld, batch, cols, h, d_Wp1, part);
-  NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vae_dg1_reduce_kernel, dim3((batch * h + 255) / 256), dim3(256), 0, st, part, batch, h,
-                     d_dG1);
-  NR_LAUNCH_CHECK();
-  return NR_OK;
 }
 
 int nrhip_vae_mid_backward(int batch, int h, int z, int act, float anneal, const float* d_dG1,

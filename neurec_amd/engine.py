@@ -940,7 +940,7 @@ class SpmmCSR:
                          self.h_indices.ctypes.data_as(C.c_void_p), self.n_rows, self.split_row, d,
                          0, 0, 0, 0, 0, 0, _ptr(buf), buf.numel(), _stream(), C.byref(plan))
                     call("nrhip_spmm_plan_attach_blocked", self.plan, plan, d)
-                    # the affinity schedule's (column, value) stream (d = 64): filled once
+                    # the plan's own copy of the (column, value) pairs, in its row order: filled once
                     call("nrhip_spmm_blocked_pack", plan, _ptr(self.indices), _ptr(self.vals), _stream())
                     self._blocked[d] = (plan, buf)
                 except NotImplementedError:
@@ -1026,9 +1026,6 @@ class SpmmCSR:
     def full_pass_kernel(self, d):
         """Name (as rocprofv3 prints it) of the kernel an unmasked matmul at width d launches."""
         if self.ensure_schedule(d):
-            wb = C.c_int(0)
-            if _lib.lib.nrhip_spmm_blocked_affinity(self.blocked, C.byref(wb)) > 0:
-                return "spmm_affinity_kernel<false>"
             return "spmm_blocked_kernel<false, 16, 8, %d, false>" % d
         return "spmm_item_kernel<%d, ...>" % d
 

@@ -49,9 +49,6 @@ import os
 from . import engine as E
 from . import parallel
 
-# NRHIP_ATOMIC_SCATTER=1 (A/B knob, read once per process by the library): the one-wave-per-triplet heads
-# accumulate with fp32 atomics instead of storing ordered sums, so their compact output rows must start from zero
-_ATOMIC_HEADS = os.environ.get("NRHIP_ATOMIC_SCATTER", "") == "1"
 
 
 def _compact_plan(engine, B):
@@ -770,9 +767,6 @@ class ShardedLightGCN:
         #     own row there, so gs / gr hold one gradient row per occurrence (gs already divided by L+1 when that
         #     is exact: L+1 a power of two)
         gs, gr = self.gc_star[:3 * B], self.gc_reg[:3 * B]
-        if _ATOMIC_HEADS:                  # the A/B knob's heads ADD into their rows (the ordered heads store them)
-            gs.zero_()
-            gr.zero_()
         E.lightgcn_bpr_grad(es, e0, B, self.L, self._cu[:B], self._cp[:B], _compact_neg(self, B),
                             self.reg, gs, gr, self.terms, loss_out, divided=self._pow2, plan=_compact_plan(self, B))
         # --- gradient rows back to the owners (routed order), added there in the order of the global batch
@@ -863,8 +857,6 @@ class ShardedMF:
         # compact tables: P' = rows [0,B) (one per triplet), Q' = rows [B,3B) (pos then neg)
         P, Q = req[:B], req[B:3 * B]
         gP, gQ = self._gcat[:B], self._gcat[B:3 * B]
-        if _ATOMIC_HEADS:
-            self._gcat[:3 * B].zero_()
         E.bpr_mf_grad(P, Q, self._ar[:B], self._ar[:B], _compact_neg(self, B), self.reg,
                       gP, gQ, self.terms, loss_out, _compact_plan(self, B))
         back = torch.empty((3 * B, d), dtype=torch.float32, device=self.T.device)

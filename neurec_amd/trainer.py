@@ -504,8 +504,8 @@ class FullRankEvaluator:
         # ... and the int8 certificate gets more rescored tiles to stand on: with 23 tiles 1-3 of 29,858 rows of plain
         # gaussian tables stay uncertified (each costs a full fp32 row: 0.87 instead of 0.67 ms), with 25 none; four
         # more tiles cost 0.01 ms (profiles/r05_exp_filter_i8.txt)
-        self.int8_extra_tiles = int(os.environ.get("NEUREC_EVAL_I8_EXTRA_TILES", "4"))
-        self.native_loop = os.environ.get("NEUREC_EVAL_NATIVE_LOOP", "1") != "0"   # nrhip_eval_pruned (0: the Python batch loop)
+        self.int8_extra_tiles = 4
+        self.native_loop = True              # nrhip_eval_pruned (False, tests: the same entry points issued batch by batch)
         self._native_sums = None
         self.pruned = bool(pruned)           # tile-pruned path: no score matrix (see _evaluate_pruned)
         self.strike_plan = bool(strike_plan)  # strikes as a planned fix-up pass after an unmasked scoring loop
@@ -540,6 +540,7 @@ class FullRankEvaluator:
             self._gemm.prepare(item_table)
         per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
         self._flags, self.n_flagged, self.n_uncertified, self._native_sums = None, 0, 0, None
+        self._n_rows, self._search_macs = n, float(n) * item_table.shape[0] * item_table.shape[1]
         cols = item_table.shape[0]
         starts = list(range(0, n, self.batch_rows))
         if self.pruned and 2 * ((cols + 63) // 64) >= self.top_k + 2 and self.top_k <= 62 and n > 0 and \
@@ -612,8 +613,13 @@ class FullRankEvaluator:
     def _note_flags(self):
         # only rows whose CERTIFICATE failed (flag bit 1) say something about the int8 bound; rows flagged for ties or a
         # full bucket would be flagged under any search (a dataset with tied rows must not lose int8 for good)
-        if getattr(self, "search_used", None) == "int8" and self.n_uncertified > 0 and self.search == "int8":
-            self._int8_pause = self.int8_retry
+        # ... and what a redone row costs is a fixed ~0.2 ms (a host round trip, three launches) plus one fp32 row: at the
+        # gowalla shape that is more than int8 saves over bf16 (0.1 ms), at a search of tens of milliseconds (config 4:
+        # 8,192 users x 10^6 items x 128) it is nothing — there only a run that fails every hundredth row pauses int8
+        if getattr(self, "search_used", None) == "int8" and self.search == "int8":
+            big = self._search_macs > 4e12
+            if self.n_uncertified > (self._n_rows // 100 if big else 0):
+                self._int8_pause = self.int8_retry
 
     def _evaluate_pruned(self, user_table, item_table, test_users, per_user, starts):
         """Level 1: tile maxima from the scoring loop (scores never stored); level 2: rescore and
@@ -891,8 +897,8 @@ class MultiVAEEngine:
                    else E.vae_workspace(B, self.n_items, dev))
         self.stats = zf(2)                         # [neg_ll, KL] of the last step
         self.regsum = torch.zeros(1, dtype=torch.float64, device=dev)
-        # the whole step as one native call (nrhip_vae_step; NEUREC_VAE_NATIVE_STEP=0: the same entry points from Python)
-        self.native_step = decoder == "fused" and os.environ.get("NEUREC_VAE_NATIVE_STEP", "1") != "0"
+        # the whole step as one native call (nrhip_vae_step; False, tests: the same entry points issued from Python)
+        self.native_step = decoder == "fused"
         self._step_args, self._step_key = None, None
         self.learner = E.make_learner(learner, lr)          # learner.py:2-17; None: adam (the engine's own kernels)
         if self.learner is not None:

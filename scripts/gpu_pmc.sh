@@ -9,8 +9,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc
 mkdir -p "$OUT"
+export C4SCALE=${C4SCALE:-0.25}
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/$c" -o b -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-eval --no-mf --no-config5 --config4-scale ${C4SCALE:-0.25} > /dev/null 2> "$OLDPWD/$OUT/$c.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/$OUT/$c" -o b -- python "$OLDPWD/bench.py" --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-eval --no-mf --no-config5 --config4-scale ${C4SCALE:-0.25} > /dev/null 2> "$OLDPWD/$OUT/$c.err" )
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, hashlib, json, os, sys
@@ -37,7 +38,8 @@ for name in ("spmm_blocked.hip", "spmm.hip"):
     with open(os.path.join("neurec_amd", "csrc", name), "rb") as f:
         h.update(f.read())
 doc = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel-trace only) over "
-               "`python bench.py --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-eval --no-mf --no-config5 --config4-scale 0.25` "
+               "`python bench.py --gpus 1 --steps 20 --warmup 2 --no-cpu-baseline --no-eval --no-mf --no-config5 --config4-scale "
+               + os.environ.get("C4SCALE", "0.25") + "` "
                "(scripts/gpu_pmc.sh); per-launch averages; FETCH_SIZE doubled (gfx950 tallies 128-B requests at "
                "64 B: guide + profiles/r01_pmc_calibration_gather.txt), WRITE_SIZE as reported. Counts L2->fabric "
                "requests, Infinity-Cache hits included: an upper bound on HBM bytes.",

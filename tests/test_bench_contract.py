@@ -1,5 +1,5 @@
 """bench.py's output contract, checked on the committed bench line of the round
-(profiles/r05_bench.json) and on the argument parser — no GPU needed."""
+(profiles/r06_bench.json) and on the argument parser — no GPU needed."""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -34,7 +34,7 @@ def test_committed_bench_line_carries_every_contract_field():
     for name in ("spmm_blocked.hip", "spmm.hip"):
         with open(os.path.join(ROOT, "neurec_amd", "csrc", name), "rb") as f:
             h.update(f.read())
-    with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")) as f:
         assert json.load(f)["_spmm_sources_sha16"] == h.hexdigest()[:16]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
@@ -58,7 +58,7 @@ def test_committed_bench_line_says_what_was_inside_the_timed_region():
     # the search arithmetic is named, and it certified every row (a redone row would be a full fp32 row in the timing)
     assert e["search"] in ("int8", "bf16", "fp32") and r.get("arith", e["search"]) == e["search"]
     assert e["rows_redone_for_ties"] == 0 and r["unit"] == ("TOP/s" if e["search"] == "int8" else "TFLOP/s")
-    with open(os.path.join(ROOT, "profiles", "r05_bench_driver_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_bench_driver_line.json")) as f:
         compact = json.loads(f.read().strip().splitlines()[-1])["roofline"]
     for k in ("eval_search", "eval_search_unit", "eval_fp32_roof_ratio", "eval_fp32_loop_ms", "eval_rows_redone", "eval_rank_ms"):
         assert k in compact, k

@@ -222,18 +222,17 @@ def test_fused_decoder_equals_the_slab_form(B, I, h):
         assert ef < 2e-6 and ef <= max(4 * es, 5e-7), (name, ef, es)
 
 
-def test_slab_and_valu_decoder_forms_still_pass_this_file():
-    """NEUREC_VAE_DECODER=slab keeps the first decoder (one [B][I] logits slab; NEUREC_VAE_DECODER_VALU=1: its
-    VALU gradient passes) as an A/B: the same oracle comparisons of this file hold for both."""
+def test_slab_decoder_form_still_passes_this_file():
+    """NEUREC_VAE_DECODER=slab keeps the decoder that materialises one [B][I] logits slab (its gradients on the matrix
+    cores) as an A/B: the same oracle comparisons of this file hold for it."""
     import os
     import subprocess
     import sys
-    for extra in ({}, {"NEUREC_VAE_DECODER_VALU": "1"}):
-        env = dict(os.environ, NEUREC_VAE_DECODER="slab", **extra)
-        out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p",
-                              "no:cacheprovider", "-k", "not decoder_form"], env=env, capture_output=True,
-                             text=True, timeout=280, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert out.returncode == 0, out.stdout[-3000:]
+    env = dict(os.environ, NEUREC_VAE_DECODER="slab")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p",
+                          "no:cacheprovider", "-k", "not decoder_form"], env=env, capture_output=True,
+                         text=True, timeout=280, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]
 
 
 @pytest.mark.parametrize("reg", [0.0, 1e-3])

@@ -102,59 +102,6 @@ def test_ngcf_steps_track_oracle(reg, drop):
     assert not eng.dOut.cpu().numpy().any() and not eng.flag.cpu().numpy().any()
 
 
-_AB_CHILD = r'''
-import hashlib, json, sys
-import numpy as np, torch
-sys.path.insert(0, %r)
-from neurec_amd import engine as E
-out = {}
-for n in (1, 63, 64, 65, 1000, 70839):
-    rng = np.random.RandomState(n)
-    dev = "cuda"
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    ego, S = t(rng.randn(n, 16) * 0.3), t(rng.randn(n, 16) * 0.3)
-    W = (t(rng.randn(16, 16) * 0.3), t(rng.randn(1, 16) * 0.1), t(rng.randn(16, 16) * 0.3), t(rng.randn(1, 16) * 0.1))
-    mask = torch.zeros(n, 16, dtype=torch.uint8, device=dev)
-    ego_out = torch.zeros(n, 16, device=dev)
-    cat = torch.zeros(n, 48, device=dev)
-    E.ngcf_layer_fwd(ego, S, W, 0.9, mask, False, 2017, 5, 1, ego_out, cat[:, 16:32])
-    mask2 = mask.clone()
-    ego_out2, cat2 = torch.zeros_like(ego_out), torch.zeros_like(cat)
-    E.ngcf_layer_fwd(ego, S, W, 0.9, mask2, True, 0, 0, 0, ego_out2, cat2[:, 16:32])     # mask given: same values
-    assert torch.equal(ego_out, ego_out2) and torch.equal(cat, cat2)
-    dcat = t(rng.randn(n, 48))
-    for nxt in (None, t(rng.randn(n, 16))):
-        dS, de, d1, d2 = (torch.zeros(n, 16, device=dev) for _ in range(4))
-        dW = (torch.zeros(16, 16, device=dev), torch.zeros(1, 16, device=dev), torch.zeros(16, 16, device=dev),
-              torch.zeros(1, 16, device=dev))
-        E.ngcf_layer_bwd(ego, S, W, 0.9, mask, dcat[:, 16:32], nxt, dS, de, d1, d2, dW, E.ngcf_workspace(n, dev))
-        h = hashlib.sha256()
-        for x in (mask, ego_out, cat, dS, de, d1, d2) + dW:
-            h.update(x.cpu().numpy().tobytes())
-        out["%%d/%%s" %% (n, nxt is not None)] = h.hexdigest()
-print(json.dumps(out))
-'''
-
-
-def test_quad_per_row_layer_kernels_equal_the_one_thread_per_row_kernels_bit_for_bit():
-    """The NGCF layer kernels with four lanes per node row (default) against the one-thread-per-row
-    kernels they replace (NEUREC_NGCF_ROW_THREAD=1): drawn masks, forward outputs, all backward
-    outputs and the weight gradients hash equal, row counts around the workgroup size."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for knob in ("0", "1"):
-        env = dict(os.environ, NEUREC_NGCF_ROW_THREAD=knob)
-        out = subprocess.run([sys.executable, "-c", _AB_CHILD % root], env=env, capture_output=True, text=True,
-                             timeout=280)
-        assert out.returncode == 0, out.stderr[-3000:]
-        res.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert res[0] == res[1] and len(res[0]) == 12
-
-
 def test_native_step_equals_the_spelled_out_launch_sequence():
     """nrhip_ngcf_step (one call) against NGCFEngine's Python launch sequence (what runs with more than
     NGCF_MAX_LAYERS layers): given masks and device-drawn ones, three steps, every trainable and both

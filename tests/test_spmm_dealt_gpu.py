@@ -1,9 +1,11 @@
 """The lane-group SpMM schedule deals rows to workgroups by cost (r05, csrc/spmm_blocked.hip) instead of cutting the row
 range into contiguous runs: a workgroup's cost no longer depends on how the nodes are numbered.  Guarded here:
-  * bit-identical results to the run schedule (NEUREC_SPMM_DEAL=0) and to the oracle's ascending-column row sums, full
-    pass and both masked hops, d = 16 / 32 / 64, on a graph whose items are numbered by DESCENDING degree (the worst case
-    for runs: all hub rows first, then thousands of short rows);
-  * the pass time on that numbering stays within 10 % of the time on a shuffled numbering (the run schedule: 1.4-1.5x).
+  * the oracle's ascending-column row sums, bit for bit on rows of <= 64 non-zeros, and the work-item kernel's results
+    (SpmmCSR.lane_group = False), full pass and both masked hops, d = 16 / 32 / 64, on a graph whose items are numbered
+    by DESCENDING degree (the worst case for contiguous runs — r01-r04's schedule, which left the product in r06: all
+    hub rows first, then thousands of short rows);
+  * the pass time on that numbering stays within 10 % of the time on a shuffled numbering (runs: 1.4-1.5x,
+    profiles/r05_exp_entcost.txt).
 LightGCN.py:132-149 (what a hop computes) is numbering-invariant; so is its cost now."""
 import os
 
@@ -31,14 +33,15 @@ def _graph(order):
     return lightgcn_adjacency(coo.row, new_of[coo.col], U, I, "pre"), U, I
 
 
-def _csr(A, U, deal, monkeypatch):
+def _csr(A, U, lane_group=True):
     from neurec_amd import engine as E
-    monkeypatch.setenv("NEUREC_SPMM_DEAL", "1" if deal else "0")
-    return E.SpmmCSR.from_scipy(A, split_row=U)
+    csr = E.SpmmCSR.from_scipy(A, split_row=U)
+    csr.lane_group = lane_group
+    return csr
 
 
 @pytest.mark.parametrize("d", [16, 32, 64])
-def test_dealt_rows_give_the_run_schedule_bits(d, monkeypatch):
+def test_dealt_rows_give_the_ascending_column_sums(d):
     import torch
     from oracle import train as O
     A, U, I = _graph("degree")
@@ -50,13 +53,11 @@ def test_dealt_rows_give_the_run_schedule_bits(d, monkeypatch):
     nonzero = (rng.rand(N) < 0.05).astype(np.uint8)
     Xs = X * nonzero[:, None]
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    outs, fits = {}, {}
-    for deal in (True, False):
-        csr = _csr(A, U, deal, monkeypatch)
-        fits[deal] = csr.ensure_schedule(d)
-        # dealing always fits; the RUN schedule may not on such ids (a run of hub rows needs more segment partials
-        # than a workgroup has: the matrix then falls back to the work-item kernel, whose hub rows are cut at 256)
-        assert fits[deal] or not deal
+    outs = {}
+    for lane_group in (True, False):
+        csr = _csr(A, U, lane_group)
+        if lane_group:
+            assert csr.ensure_schedule(d)                                         # dealing always fits
         res = []
         Y, S = torch.empty(N, d, device="cuda"), torch.empty(N, d, device="cuda")
         csr.matmul(dev(X), out=Y, addend=dev(add), sum_in=dev(acc), sum_out=S)
@@ -67,41 +68,34 @@ def test_dealt_rows_give_the_run_schedule_bits(d, monkeypatch):
         Y3 = torch.empty(N, d, device="cuda")
         csr.matmul(dev(Xs), out=Y3, addend=dev(add), x_row_nonzero=dev(nonzero))  # column-masked hop
         res.append(Y3.cpu().numpy())
-        outs[deal] = res
+        outs[lane_group] = res
     short = np.diff(A.indptr) <= 64                                               # strict ascending-column rows
-    for a, b in zip(outs[True], outs[False]):
-        if fits[False]:
-            np.testing.assert_array_equal(a, b)
-        else:
-            np.testing.assert_array_equal(a[short], b[short])
-            assert np.abs(a - b).max() < 1e-5
-    print("d = %d: run schedule %s on degree-ordered ids" % (d, "fits" if fits[False] else "does NOT fit (work-item fallback)"))
+    for a, b in zip(outs[True], outs[False]):                                     # (hub rows: segments of 64 vs 256)
+        np.testing.assert_array_equal(a[short], b[short])
+        assert np.abs(a - b).max() < 1e-5
     want = O.spmm_rowwise(A, X) + add
     np.testing.assert_array_equal(outs[True][0][short], want[short])
     assert np.abs(outs[True][0] - want).max() < 1e-5
     assert (outs[True][2][wanted == 0] == 7.0).all()
 
 
-def test_pass_time_does_not_depend_on_the_numbering(monkeypatch):
+def test_pass_time_does_not_depend_on_the_numbering():
     import torch
     times = {}
     for order in ("degree", "shuffled"):
         A, U, I = _graph(order)
         X = torch.randn(U + I, 64, device="cuda")
         Y = torch.empty_like(X)
-        for deal in (True, False):
-            csr = _csr(A, U, deal, monkeypatch)
-            for _ in range(5):
-                csr.matmul(X, out=Y)
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(50):
-                csr.matmul(X, out=Y)
-            b.record()
-            torch.cuda.synchronize()
-            times[(order, deal)] = a.elapsed_time(b) / 50 * 1e3
-    print("SpMM pass, d = 64, us: " + ", ".join("%s ids / %s: %.1f" % (o, "dealt" if dl else "runs", t)
-                                                for (o, dl), t in sorted(times.items())))
-    assert times[("degree", True)] <= 1.10 * times[("shuffled", True)]
-    assert times[("degree", True)] <= 0.85 * times[("degree", False)]              # what dealing buys on such ids
+        csr = _csr(A, U)
+        for _ in range(5):
+            csr.matmul(X, out=Y)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(50):
+            csr.matmul(X, out=Y)
+        b.record()
+        torch.cuda.synchronize()
+        times[order] = a.elapsed_time(b) / 50 * 1e3
+    print("SpMM pass, d = 64, us: " + ", ".join("%s ids: %.1f" % (o, t) for o, t in sorted(times.items())))
+    assert times["degree"] <= 1.10 * times["shuffled"]
