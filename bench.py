@@ -620,7 +620,7 @@ def _config4_eval(lg, comm, trc, I, dim, dev, n_eval, batch_rows=8192, top_k=20)
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_bytes / t2 / 1e9 / HBM_PEAK_GBS,
                                 "tile_maxima_per_user": tiles, "tiles_rescored_per_user": n_keep,
                                 "kernel": "select_rows_kernel (streaming ring over %d maxima) + tile_count / tile_fill "
-                                          "(packed buckets) + rescore_pairs_kernel + select_rows + remap + metrics" % tiles}
+                                          "(packed buckets) + rescore_pairs_kernel + rank_compact_kernel + metrics_kernel" % tiles}
     return out
 
 
@@ -1524,15 +1524,15 @@ def main():
                 eval_info["strike_plan_build_ms"] = (time.perf_counter() - tp) * 1e3
             eval_info["roofline_topk"] = {
                 "bound": "hbm", "kernel": "select_rows_kernel (tile maxima) + tile_pairs / chunk kernels + rescore_pairs_kernel "
-                                          "(fp32 MFMA chain, 32 users of one tile per wave) + strike_compact + "
-                                          "select_rows_kernel + remap + metrics_kernel (nrhip_eval_tiles_bounded)",
+                                          "(fp32 MFMA chain, 32 users of one tile per wave) + rank_compact_kernel (strikes, "
+                                          "ranking, item ids, certificate) + metrics_kernel (nrhip_eval_tiles_bounded)",
                 "achieved": rank_bytes / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS, "ms": t_rank * 1e3,
                 "bytes": rank_bytes, "rescore_gflop": rescore_flops / 1e9,
                 "note": "pruned design: the [users][I] score matrix is never written; the top-K works on the tile maxima "
                         "(%d floats per user, the phase's HBM stream) and %d rescored 32-item tiles per user; the "
                         "rescoring is bucketed by tile, so an item tile is read once per 32 users (r03: once per user, "
-                        "5.6 GB through the L2s, 0.43 ms); the phase is a chain of eight short launches" % (tiles, n_keep)}
+                        "5.6 GB through the L2s, 0.43 ms); the phase is a chain of seven short launches" % (tiles, n_keep)}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-%s)" % args.shape, "value": triplets_per_s,

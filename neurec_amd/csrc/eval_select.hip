@@ -722,7 +722,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
 //                         written to the tile's bucket as (row << 6 | slot)
 //   chunk_scan / _list    buckets cut into chunks of <= 32 pairs
 //   rescore_pairs_kernel  wave per chunk: gather the 32 user rows, 32 x 32 scores, float4 stores into C[row][slot]
-//   strike_compact_kernel train items of the row -> -inf (uni_evaluator.py:140-143)
+//   rank_compact_kernel   strikes (uni_evaluator.py:140-143), ranking, item ids, certificate: one wave per row
 // The order of the pairs inside a bucket depends on the atomics; no result does (every pair is independent).
 // ----------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -950,28 +950,6 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(
   }
 }
 
-// the user's train items that fall in a rescored tile -> -inf (one wave per row)
-__global__ __launch_bounds__(256) void strike_compact_kernel(const int32_t* __restrict__ users, int rows, int n_keep,
-                                                             const int32_t* __restrict__ tilemap,
-                                                             const int64_t* __restrict__ tr_indptr,
-                                                             const int32_t* __restrict__ tr_indices,
-                                                             float* __restrict__ C, int64_t cld) {
-  __shared__ int32_t s_map[4][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= rows) return;
-  if (lane < n_keep) s_map[wave][lane] = tilemap[(int64_t)row * n_keep + lane];
-  wave_lds_sync();
-  const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
-  float* crow = C + (int64_t)row * cld;
-  const int64_t tb = tr_indptr[u], te = tr_indptr[u + 1];
-  for (int64_t t = tb + lane; t < te; t += NR_WAVE) {
-    const int item = tr_indices[t], tile = item / kTileItems;
-    for (int k = 0; k < n_keep; ++k)                           // (slots are in selection order, not sorted)
-      if (s_map[wave][k] == tile) crow[k * kTileItems + (item % kTileItems)] = -INFINITY;
-  }
-}
-
 // compact column -> item id; boundary check on the tile maxima -> flag_out
 __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ rank,
                                                          const int32_t* __restrict__ sel_flag,
@@ -1006,6 +984,122 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
     }
     if (overflow && overflow[row]) flag_out[row] |= 1;         // a pair of this row did not fit its tile's bucket
     // (ties inside the compact row: metrics_kernel decides from the tie mask whether they can change a metric)
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Level 2, the ranking of a compact row as ONE launch (r06; the grouped forms): what strike_compact_kernel +
+// select_rows_kernel<4> + remap_rank_kernel did in three passes over C (103 MB at gowalla) and two launch gaps.  One
+// wave per row:
+//   * the user's train items that fall in a rescored tile become bits of an LDS bitmap over the compact row
+//     (uni_evaluator.py:140-143's strikes) — C itself is only read;
+//   * the whole row (<= 63 x 32 scores) sits in registers, struck entries become -inf as they arrive, and the
+//     selection is select_rows_kernel's short-row path: same keys (ordered score, -compact column), same total order,
+//     same tie mask;
+//   * compact columns -> item ids, and the boundary certificate on the tile maxima, as remap_rank_kernel.
+// A tie group too large for one key per lane (that path falls back to the streaming ring in select_rows_kernel) flags
+// the row here: it is then ranked from a full score row, which is exact whatever the cause.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
+    const float* __restrict__ C, int64_t cld, int rows, int n_keep, int top_k, const int32_t* __restrict__ users,
+    const int64_t* __restrict__ tr_indptr, const int32_t* __restrict__ tr_indices,
+    const int32_t* __restrict__ tilemap, const int32_t* __restrict__ tiles, int tiles_ld,
+    const float* __restrict__ M, int64_t mld, const float* __restrict__ eps, const int32_t* __restrict__ overflow,
+    int32_t* __restrict__ rank, uint64_t* __restrict__ tie_mask, int32_t* __restrict__ flag_out) {
+  __shared__ int32_t s_map[kSelWaves][NR_WAVE];
+  __shared__ uint32_t s_strike[kSelWaves][NR_WAVE];
+  __shared__ uint64_t s_keys[kSelWaves][NR_WAVE];
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  s_map[wave][lane] = lane < n_keep ? tilemap[(int64_t)row * n_keep + lane] : -1;
+  s_strike[wave][lane] = 0u;
+  constexpr int FR = 8;                                       // float4 registers per lane: <= 2,048 scores
+  const int cols = n_keep * kTileItems, cut = top_k + 1, need = cut + 1;
+  const float* srow = C + (int64_t)row * cld;
+  float v[FR][4];
+#pragma unroll
+  for (int u = 0; u < FR; ++u) {                              // the row is requested before the train list is walked
+    const int e0 = (u * NR_WAVE + lane) * 4;
+    if (e0 < cols) {
+      const float4 t = *reinterpret_cast<const float4*>(srow + e0);
+      v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+    } else {
+      v[u][0] = v[u][1] = v[u][2] = v[u][3] = NAN;            // NaN: never a key
+    }
+  }
+  wave_lds_sync();
+  const int64_t usr = users ? (int64_t)users[row] : (int64_t)row;
+  const int64_t tb = tr_indptr[usr], te = tr_indptr[usr + 1];
+  for (int64_t t = tb + lane; t < te; t += NR_WAVE) {
+    const int item = tr_indices[t], tile = item / kTileItems;
+    for (int k = 0; k < n_keep; ++k)                           // (slots are in selection order, not sorted)
+      if (s_map[wave][k] == tile) atomicOr(&s_strike[wave][k], 1u << (item % kTileItems));
+  }
+  wave_lds_sync();
+  uint32_t ord[FR][4], best = 0u;                             // order words of real scores are never 0
+#pragma unroll
+  for (int u = 0; u < FR; ++u) {
+    const int e0 = (u * NR_WAVE + lane) * 4;
+    const uint32_t nib = e0 < cols ? (s_strike[wave][e0 / kTileItems] >> (e0 % kTileItems)) & 0xFu : 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = ((nib >> c) & 1u) ? -INFINITY : v[u][c];
+      ord[u][c] = x >= -INFINITY ? nr::order_f32(x) : 0u;
+      best = max(best, ord[u][c]);
+    }
+  }
+  const uint64_t sb = wave_sort_desc((uint64_t)best);
+  const uint32_t tau_ord = __builtin_amdgcn_readlane((uint32_t)sb, need - 1);   // fewer than `need` lanes with a score: 0
+  uint64_t* keys = s_keys[wave];
+  int c_n = 0;
+#pragma unroll
+  for (int u = 0; u < FR; ++u) {
+    const uint32_t m = max(max(ord[u][0], ord[u][1]), max(ord[u][2], ord[u][3]));
+    if (__ballot(m != 0u && m >= tau_ord) == 0) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool pass = ord[u][c] != 0u && ord[u][c] >= tau_ord;
+      const uint64_t mask = __ballot(pass);
+      if (mask) {
+        const int at = c_n + nr_mbcnt(mask);
+        if (pass && at < NR_WAVE)
+          keys[at] = ((uint64_t)ord[u][c] << 32) | (uint64_t)(0xffffffffu - (uint32_t)((u * NR_WAVE + lane) * 4 + c));
+        c_n += __popcll(mask);
+      }
+    }
+  }
+  if (c_n > NR_WAVE) {                                        // wave-uniform: a tie group beyond one key per lane
+    if (lane == 0) { flag_out[row] = 1; tie_mask[row] = ~0ull; }
+    return;
+  }
+  wave_lds_sync();
+  const uint64_t mine = wave_sort_desc(lane < c_n ? keys[lane] : 0ull);
+  const uint64_t next = shfl_down1_u64(mine);                 // lane 63 and lanes past the keys: 0 = none
+  const int n_out = min(cut, c_n);
+  const bool tie = lane < n_out && next != 0ull && nr::key_order(mine) == nr::key_order(next);
+  const uint64_t tmask = __ballot(tie);
+  if (lane < n_out) {
+    const int col = (int)nr::key_index(mine);
+    rank[(int64_t)row * kRankStride + lane] = s_map[wave][col / kTileItems] * kTileItems + col % kTileItems;
+  }
+  // the score of the top_k-th best, from its key (the order word is a bijection on the scores; -0 reads as +0)
+  const uint32_t ok_lo = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), top_k - 1);
+  if (lane == 0) {
+    tie_mask[row] = tmask;
+    const float inside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep - 1]];
+    const float outside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep]];
+    int flag;
+    if (n_out < top_k) {
+      flag = 1;                                               // fewer than top_k rankable scores in the rescored tiles
+    } else if (eps) {
+      const float s_k = nr::unorder_f32(ok_lo);
+      flag = !(s_k > nr_add_up(outside, eps[row])) ? 2 : 0;   // (2: the bound did not certify the row; see remap_rank_kernel)
+    } else {
+      flag = !(inside > outside) ? 1 : 0;
+    }
+    if (overflow && overflow[row]) flag |= 1;
+    flag_out[row] = flag;
   }
 }
 
@@ -1449,26 +1543,31 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     }
 #undef NR_PAIRS_CASE
     NR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(strike_compact_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, d_users, rows, n_keep, tilemap,
-                       d_tr_indptr, d_tr_indices, C, cld);
-    NR_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(rescore_tiles_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_P, ldp,
                        qt, (int64_t)ipad, d, d_users, rows, cols, tiles, tiles_ld, n_keep, d_tr_indptr,
                        d_tr_indices, C, cld, tilemap);
     NR_LAUNCH_CHECK();
   }
-  // 3. rank the compact rows (no in-place exact path: a tie needs the full row)
-  const int ccols = (int)cld;
-  const int sort_len = (2 * top_k < ccols) ? 2 * top_k : ccols;
-  hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld,
-                     rows, ccols, sort_len, top_k + 1, w.rank, w.flag, tmask);   // (one item beyond the cut: the tie rule)
-  NR_LAUNCH_CHECK();
-  // 4. columns -> item ids, boundary check, flags
-  hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
-                     tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k + 1, top_k, C, cld, d_eps, overflow,
-                     d_flag_out);
-  NR_LAUNCH_CHECK();
+  if (form != kGroupedNone) {
+    // 3 + 4 in one launch: strikes, ranking of the compact rows, columns -> item ids, boundary check, flags
+    hipLaunchKernelGGL(rank_compact_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld, rows, n_keep, top_k,
+                       d_users, d_tr_indptr, d_tr_indices, tilemap, tiles, tiles_ld, d_M, mld, d_eps, overflow, w.rank,
+                       tmask, d_flag_out);
+    NR_LAUNCH_CHECK();
+  } else {
+    // 3. rank the compact rows (no in-place exact path: a tie needs the full row)
+    const int ccols = (int)cld;
+    const int sort_len = (2 * top_k < ccols) ? 2 * top_k : ccols;
+    hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld,
+                       rows, ccols, sort_len, top_k + 1, w.rank, w.flag, tmask);   // (one item beyond the cut: the tie rule)
+    NR_LAUNCH_CHECK();
+    // 4. columns -> item ids, boundary check, flags
+    hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
+                       tilemap, tiles, tiles_ld, d_M, mld, rows, n_keep, top_k + 1, top_k, C, cld, d_eps, overflow,
+                       d_flag_out);
+    NR_LAUNCH_CHECK();
+  }
   // 5. metrics
   InvLog2Table tbl;
   for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));

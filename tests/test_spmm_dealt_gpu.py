@@ -62,12 +62,13 @@ def test_dealt_rows_give_the_ascending_column_sums(d):
         Y, S = torch.empty(N, d, device="cuda"), torch.empty(N, d, device="cuda")
         csr.matmul(dev(X), out=Y, addend=dev(add), sum_in=dev(acc), sum_out=S)
         res += [Y.cpu().numpy(), S.cpu().numpy()]
-        Y2 = torch.full((N, d), 7.0, device="cuda")
-        csr.matmul(dev(X), out=Y2, y_row_wanted=dev(wanted))                      # row-masked hop: other rows untouched
-        res.append(Y2.cpu().numpy())
-        Y3 = torch.empty(N, d, device="cuda")
-        csr.matmul(dev(Xs), out=Y3, addend=dev(add), x_row_nonzero=dev(nonzero))  # column-masked hop
-        res.append(Y3.cpu().numpy())
+        if lane_group or d >= 64:                                                 # (the work-item kernel masks rows at d >= 64 only)
+            Y2 = torch.full((N, d), 7.0, device="cuda")
+            csr.matmul(dev(X), out=Y2, y_row_wanted=dev(wanted))                  # row-masked hop: other rows untouched
+            res.append(Y2.cpu().numpy())
+            Y3 = torch.empty(N, d, device="cuda")
+            csr.matmul(dev(Xs), out=Y3, addend=dev(add), x_row_nonzero=dev(nonzero))  # column-masked hop
+            res.append(Y3.cpu().numpy())
         outs[lane_group] = res
     short = np.diff(A.indptr) <= 64                                               # strict ascending-column rows
     for a, b in zip(outs[True], outs[False]):                                     # (hub rows: segments of 64 vs 256)
@@ -77,6 +78,13 @@ def test_dealt_rows_give_the_ascending_column_sums(d):
     np.testing.assert_array_equal(outs[True][0][short], want[short])
     assert np.abs(outs[True][0] - want).max() < 1e-5
     assert (outs[True][2][wanted == 0] == 7.0).all()
+    # the masked hops against the oracle's row sums (they are what the work-item comparison cannot cover below d = 64)
+    full = O.spmm_rowwise(A, X)
+    np.testing.assert_array_equal(outs[True][2][(wanted == 1) & short], full[(wanted == 1) & short])
+    assert np.abs(outs[True][2][wanted == 1] - full[wanted == 1]).max() < 1e-5
+    want3 = O.spmm_rowwise(A, Xs) + add
+    np.testing.assert_array_equal(outs[True][3][short], want3[short])
+    assert np.abs(outs[True][3] - want3).max() < 1e-5
 
 
 def test_pass_time_does_not_depend_on_the_numbering():
