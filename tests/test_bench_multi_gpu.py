@@ -111,3 +111,20 @@ def test_default_line_is_the_compact_one():
     assert all(not isinstance(v, (dict, list)) for v in r.values())
     with open(full) as f:
         assert json.load(f)["eval"]["roofline"]["kernel"]              # the full objects live in the file
+
+
+def test_plain_shell_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset): bench.spawn_ranks starts the ranks itself —
+    one process per rank, a FILE-STORE rendezvous (no port is picked and lost before the ranks bind it) — and
+    rank 0's stdout is the ONE line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NEUREC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--scale", "0.05",
+           "--batch", "256", "--no-cpu-baseline", "--no-mf", "--no-config4", "--no-config5", "--full-line"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["config"]["global_batch"] == 512
+    assert d["strong_scaling"]["global_batch"] == 256 and d["value"] > 0
