@@ -623,3 +623,27 @@ def test_native_strike_plan_lists_every_user_tile_pair_once(shape):
         assert tp[t] <= b < e and not covered[b:e].any()
         covered[b:e] = True
     assert covered.all()
+
+
+def test_strike_plan_refuses_a_train_matrix_it_cannot_plan():
+    """the native plan build takes the first entry of a (user, tile) run as the pair's head — a row whose
+    items do not ascend would give one pair two heads with partial masks (two different maxima for one M slot, no
+    flag) — and indexes its histograms with the item ids.  Both preconditions are checked once, at plan build: an
+    unsorted row or an item id >= cols raises instead; a repeated item (neighbours in an ascending row) is fine."""
+    import torch
+    from neurec_amd import engine as E
+    I = 500
+    ptr = np.asarray([0, 3, 6], np.int64)
+    ok = E.DeviceCSR(ptr, np.asarray([5, 40, 41, 7, 7, 300], np.int32), I)            # ascending, one repeat
+    assert E.TileStrikePlan(ok, I).n_pairs == 4                                        # user 0: tiles 0, 1 (40 and 41 share it); user 1: tiles 0 (7 twice), 9
+    with pytest.raises(ValueError, match="ascending"):
+        E.TileStrikePlan(E.DeviceCSR(ptr, np.asarray([40, 5, 41, 7, 8, 300], np.int32), I), I)
+    with pytest.raises(ValueError, match="outside"):
+        E.TileStrikePlan(E.DeviceCSR(ptr, np.asarray([5, 40, 41, 7, 8, 500], np.int32), I), I)
+    # the evaluator on an unsorted hand-made CSR says so as well (it builds the plan on first use)
+    from neurec_amd.trainer import FullRankEvaluator
+    bad = E.DeviceCSR(ptr, np.asarray([40, 5, 41, 7, 8, 300], np.int32), I)
+    te = E.DeviceCSR(ptr, np.asarray([1, 2, 3, 4, 5, 6], np.int32), I)
+    P, Q = torch.randn(2, 16, device="cuda"), torch.randn(I, 16, device="cuda")
+    with pytest.raises(ValueError, match="ascending"):
+        FullRankEvaluator(bad, te, [1], 5, batch_rows=64).evaluate_factors(P, Q, torch.arange(2, dtype=torch.int32, device="cuda"))
