@@ -32,7 +32,7 @@ from .trainer import LightGCNEngine
 
 class ColumnShardedLightGCN:
     def __init__(self, comm, adj_csr, n_users, n_items, embed, n_layers, lr, reg, max_batch, adj_t_csr=None,
-                 rank=None, world=None):
+                 rank=None, world=None, keep_order=False):
         """embed: the full [N][d] table (each rank keeps its columns).  rank / world override comm's (a one-GPU run
         of ONE rank's share of a W-rank job: the measurement bench.py reports next to the single-GPU step)."""
         self.comm = comm
@@ -45,7 +45,7 @@ class ColumnShardedLightGCN:
         self.d_loc = self.d // self.world
         lo = self.rank * self.d_loc
         self.local = LightGCNEngine(adj_csr, n_users, n_items, emb[:, lo:lo + self.d_loc], n_layers, lr, reg,
-                                    max_batch, adj_t_csr=adj_t_csr)
+                                    max_batch, adj_t_csr=adj_t_csr, keep_order=keep_order)
         dev = self.local.E0.device
         self.max_batch = int(max_batch)
         self._parts = torch.zeros(3 * self.max_batch, dtype=torch.float32, device=dev)

@@ -83,14 +83,59 @@ class UniEvaluator(HIPEvaluator):
 
     def _evaluate_factors(self, model, test_users, factors=None):
         import torch
+        from .... import parallel
         from ....trainer import FullRankEvaluator
         P, Q = factors if factors is not None else model.get_eval_factors()
         st = self._device(Q.shape[0])
+        comm = parallel.get_comm()
+        if comm.active:
+            return self._evaluate_factors_sharded(comm, model, test_users, P, Q, st)
         if "ranker" not in st:
             st["ranker"] = FullRankEvaluator(st["train"], st["test"], self.metrics, self.max_top,
                                              batch_rows=max(int(self.batch_size), 2048))
         users = torch.tensor(np.asarray(test_users, dtype=np.int32), device=P.device)
         return st["ranker"].evaluate_factors(P, Q, users, exact_mean=True)
+
+    def _evaluate_factors_sharded(self, comm, model, test_users, P, Q, st):
+        """One rank of several (SURVEY 8e "Evaluator"): users are independent units, every rank ranks ITS share and the
+        per-user metric rows (M·K floats each) are gathered, so that the mean is the float32 np.mean over the same rows
+        in the same order as on one GPU (uni_evaluator.py:150-151) — the printed line does not depend on the number of
+        ranks.  A model whose user table is row-sharded says which users its rows are (`eval_user_range()` -> (lo, hi):
+        P row r = user lo + r; LightGCN's row-sharded engine); otherwise P holds every user and the test users are cut
+        into contiguous shares."""
+        import torch
+        from .... import parallel
+        from ....trainer import FullRankEvaluator
+        users_all = np.asarray(test_users, dtype=np.int32)
+        rng = model.eval_user_range() if hasattr(model, "eval_user_range") else None
+        if rng is not None:
+            lo, hi = int(rng[0]), min(int(rng[1]), st["train"].n_rows)     # (users past the last one with data have no rows)
+            lo = min(lo, hi)
+            mine = users_all[(users_all >= lo) & (users_all < hi)]
+            key = ("ranker", lo, hi)
+            if key not in st:
+                st[key] = FullRankEvaluator(st["train"].rows(lo, hi), st["test"].rows(lo, hi), self.metrics, self.max_top,
+                                            batch_rows=max(int(self.batch_size), 2048))
+            ranker, local = st[key], mine - lo
+        else:
+            mine = parallel.shard_users(users_all, comm.rank, comm.world)
+            if "ranker" not in st:
+                st["ranker"] = FullRankEvaluator(st["train"], st["test"], self.metrics, self.max_top,
+                                                 batch_rows=max(int(self.batch_size), 2048))
+            ranker, local = st["ranker"], mine
+        dev = Q.device
+        width = self.metrics_num * self.max_top
+        if len(mine):
+            rows = ranker.evaluate_factors(P, Q, torch.from_numpy(np.ascontiguousarray(local)).to(dev), per_user=True)
+            rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(dev)
+        else:
+            rows = torch.zeros((0, width), dtype=torch.float32, device=dev)
+        got_u, got_r = parallel.gather_rows_by_user(comm, torch.from_numpy(np.ascontiguousarray(mine)).to(dev), rows, dev)
+        got_u, got_r = got_u.cpu().numpy(), got_r.cpu().numpy()
+        # back into the order of `test_users` (the order the reference's batches run in)
+        pos = {int(u): k for k, u in enumerate(got_u)}
+        order = np.asarray([pos[int(u)] for u in users_all], dtype=np.int64)
+        return np.mean(got_r[order], axis=0)
 
     def _evaluate_scores(self, model, test_users):
         import torch

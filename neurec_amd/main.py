@@ -33,7 +33,14 @@ def main(argv=None, properties="NeuRec.properties"):
     np.random.seed(2018)
     random.seed(2018)
     conf = Configurator(properties, default_section="hyperparameters", argv=argv)
-    os.environ["HIP_VISIBLE_DEVICES"] = str(conf["gpu_id"])     # main.py:17-18 (CUDA_VISIBLE_DEVICES)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one rank of several (python -m torch.distributed.run --nproc-per-node N -m neurec_amd.main ...): every rank
+        # takes the GPU of its LOCAL_RANK (parallel.init_from_env), `gpu_id` names a single device and is not used;
+        # the plugins that have a multi-GPU form (LightGCN) ask parallel.get_comm() for the partition
+        from . import parallel
+        parallel.get_comm()
+    else:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(conf["gpu_id"])     # main.py:17-18 (CUDA_VISIBLE_DEVICES)
     dataset = Dataset(conf)
     model = find_recommender(conf["recommender"])(None, dataset, conf)
     model.build_graph()

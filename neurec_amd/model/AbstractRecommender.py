@@ -21,6 +21,12 @@ def _create_logger(config, data_name):
     return Logger(os.path.join(log_dir, run_id + ".log"))
 
 
+class _Silent(object):
+    """the logger of ranks > 0 of a multi-GPU run"""
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
 class AbstractRecommender(object):
     def __init__(self, dataset, conf):
         self.evaluator = ProxyEvaluator(dataset.get_user_train_dict(),
@@ -31,7 +37,9 @@ class AbstractRecommender(object):
                                         top_k=conf["topk"],
                                         batch_size=conf["test_batch_size"],
                                         num_thread=conf["num_thread"])
-        self.logger = _create_logger(conf, dataset.dataset_name)
+        # one rank of several (parallel.get_comm): rank 0 writes the run's log, the others only compute
+        rank = int(os.environ.get("RANK", "0")) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0
+        self.logger = _create_logger(conf, dataset.dataset_name) if rank == 0 else _Silent()
         self.logger.info(dataset)
         self.logger.info(conf)
 

@@ -36,6 +36,8 @@ class LightGCN(AbstractRecommender):
         self.n_users, self.n_items = self.dataset.num_users, self.dataset.num_items
         self.user_pos_train = self.dataset.get_user_train_dict(by_time=False)
         self.all_users = list(self.user_pos_train.keys())
+        self.adj_type = config["adj_type"]
+        self.dp_mode_conf = config["dp_mode"] if "dp_mode" in config else None     # multi-GPU runs only (build_graph)
         self.norm_adj = self.create_adj_mat(config["adj_type"])
         self.sess = sess                      # unused: there is no TensorFlow session
         self.engine = None
@@ -63,6 +65,32 @@ class LightGCN(AbstractRecommender):
         table[:self.n_users] = rng.uniform(-lim_u, lim_u, (self.n_users, self.emb_dim))
         table[self.n_users:] = rng.uniform(-lim_i, lim_i, (self.n_items, self.emb_dim))
         adj_t = None if is_symmetric(self.norm_adj) else transpose_csr(self.norm_adj)
+        from ... import parallel
+        self.comm = comm = parallel.get_comm()
+        self.dp_mode = None
+        if comm.active:
+            # one rank of several: `batch_size` stays the GLOBAL batch of a step (the run is the one-GPU run of the same
+            # configuration, partitioned).  --dp_mode=colshard (default where embed_size divides by the ranks): every
+            # rank holds embed_size / N columns of every row and steps on the whole batch, one all-gather of 12 B per
+            # triplet per step (colshard.py); --dp_mode=rowshard: tables row-sharded, a rank steps on its slice of the
+            # batch, rows travel by all-to-all (sharded.py: north_star's partition, the form for tables one GPU
+            # cannot hold) — bit-identical to the one-GPU run
+            mode = self.dp_mode_conf or ("colshard" if self.emb_dim % comm.world == 0 else "rowshard")
+            if mode not in ("colshard", "rowshard"):
+                raise ValueError("dp_mode must be 'colshard' or 'rowshard', got %r" % (mode,))
+            self.dp_mode = mode
+            if mode == "colshard":
+                from ...colshard import ColumnShardedLightGCN
+                self.engine = ColumnShardedLightGCN(comm, self.norm_adj, self.n_users, self.n_items, table, self.n_layers,
+                                                    self.lr, self.reg, self.batch_size, adj_t_csr=adj_t, keep_order=True)
+            else:
+                from ...sharded import ShardedLightGCN
+                if self.adj_type == "gcmc":
+                    raise NotImplementedError("dp_mode=rowshard sums a row in ascending column order; adj_type=gcmc's "
+                                              "descending order is the one-GPU / colshard engines'")
+                self.engine = ShardedLightGCN(comm, self.norm_adj, self.n_users, self.n_items, table, self.n_layers,
+                                              self.lr, self.reg, self.batch_size)
+            return
         self.engine = LightGCNEngine(self.norm_adj, self.n_users, self.n_items, table,
                                      self.n_layers, self.lr, self.reg, self.batch_size,
                                      adj_t_csr=adj_t, keep_order=True)
@@ -71,27 +99,49 @@ class LightGCN(AbstractRecommender):
         import torch
         data_iter = PairwiseSampler(self.dataset, neg_num=1, batch_size=self.batch_size,
                                     shuffle=True, as_tensors=True)
-        loss2 = torch.zeros(2, device=self.engine.E0.device)
+        loss2 = torch.zeros(2, device="cuda")
         self.logger.info(self.evaluator.metrics_info())
+        comm = self.comm
         for epoch in range(self.epochs):
             for batch in data_iter:
                 bat_users, bat_pos_items, bat_neg_items = batch
-                self.engine.step(bat_users, bat_pos_items, bat_neg_items, loss2, plan=batch.plan)
+                if self.dp_mode == "rowshard":
+                    # every rank draws the same epoch stream (a counter-based generator: same seed, same triplets) and
+                    # steps on ITS contiguous slice of each global batch; the owners add the gradient rows in the
+                    # global batch's order: the one-GPU step on the whole batch, bit for bit
+                    n = bat_users.numel()
+                    lo, hi = (n * comm.rank) // comm.world, (n * (comm.rank + 1)) // comm.world
+                    self.engine.step(bat_users[lo:hi], bat_pos_items[lo:hi], bat_neg_items[lo:hi], loss2)
+                else:
+                    self.engine.step(bat_users, bat_pos_items, bat_neg_items, loss2, plan=batch.plan)
             result = self.evaluate_model()
             self.logger.info("epoch %d:\t%s" % (epoch, result))
 
-    def evaluate_model(self):
-        # the reference's assign_opt: snapshot the propagated tables once per evaluation
-        eu, ei = self.engine.final_embeddings()
+    def _snapshot(self):
+        # the reference's assign_opt: snapshot the propagated tables once per evaluation.  Row-sharded: a rank keeps
+        # ITS user rows and gets the whole item table (one all-gather of the item blocks)
+        if self.dp_mode == "rowshard":
+            eu, ei = self.engine.eval_factors()
+        else:
+            eu, ei = self.engine.final_embeddings()
         self._final = (eu.contiguous(), ei.contiguous())
+
+    def evaluate_model(self):
+        self._snapshot()
         return self.evaluator.evaluate(self)
 
     def get_eval_factors(self):
         if self._final is None:
-            eu, ei = self.engine.final_embeddings()
-            self._final = (eu.contiguous(), ei.contiguous())
+            self._snapshot()
         return self._final
 
+    def eval_user_range(self):
+        """row-sharded run: the users whose rows get_eval_factors()[0] holds (row r = user lo + r); else None"""
+        return (self.engine.ulo, self.engine.uhi) if self.dp_mode == "rowshard" else None
+
     def predict(self, users, candidate_items=None):
+        if self.dp_mode == "rowshard":
+            eu, ei = self.engine.final_embeddings()       # the plugin contract scores ANY user: the whole table, gathered
+            return predict_scores(eu.contiguous(), ei.contiguous(), users, candidate_items)
         eu, ei = self.get_eval_factors()
         return predict_scores(eu, ei, users, candidate_items)

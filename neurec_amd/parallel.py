@@ -378,3 +378,40 @@ def partition(n, rank, world):
 def shard_users(user_ids, rank, world):
     lo, hi = partition(len(user_ids), rank, world)
     return user_ids[lo:hi]
+
+
+_process_comm = None
+
+
+def get_comm():
+    """The process's communicator: created from the launcher's environment on first use (world size 1 without one:
+    an inactive Comm, every collective a no-op).  The drop-in entry point (`python -m torch.distributed.run
+    --nproc-per-node N -m neurec_amd.main ...`) and the plugins ask here whether they are one rank of several."""
+    global _process_comm
+    if _process_comm is None:
+        _process_comm = init_from_env()
+    return _process_comm
+
+
+def gather_rows_by_user(comm, users_local, rows_local, device):
+    """Every rank's (user ids int32 [n_r], per-user rows float32 [n_r][w]) -> (users [n], rows [n][w]) on every rank,
+    rank-major.  The sharded drop-in evaluation gathers the per-user METRIC ROWS (M·K floats per user) so that the
+    mean over users is the reference's float32 np.mean over the same rows in the same order
+    (uni_evaluator.py:150-151), whatever the number of ranks."""
+    import numpy as np
+    n = torch.tensor([int(users_local.numel())], dtype=torch.int64, device=device)
+    counts = torch.zeros(comm.world, dtype=torch.int64, device=device)
+    comm.all_gather_rows(n, counts)
+    counts = [int(c) for c in counts.cpu()]
+    cap, w = max(counts + [1]), int(rows_local.shape[1])
+    pad_u = torch.zeros(cap, dtype=torch.int32, device=device)
+    pad_r = torch.zeros((cap, w), dtype=torch.float32, device=device)
+    pad_u[:users_local.numel()] = users_local
+    pad_r[:rows_local.shape[0]] = rows_local
+    all_u = torch.empty(comm.world * cap, dtype=torch.int32, device=device)
+    all_r = torch.empty((comm.world * cap, w), dtype=torch.float32, device=device)
+    comm.all_gather_rows(pad_u, all_u)
+    comm.all_gather_rows(pad_r, all_r)
+    keep = np.concatenate([np.arange(r * cap, r * cap + c) for r, c in enumerate(counts)]) if sum(counts) else np.zeros(0, np.int64)
+    keep = torch.from_numpy(keep.astype(np.int64)).to(device)
+    return all_u[keep], all_r[keep]

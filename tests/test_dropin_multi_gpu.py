@@ -1,0 +1,68 @@
+"""The drop-in entry point as one rank of several (north_star: "existing configs drop in ... tables row-shard across
+the GPUs"): `python -m torch.distributed.run --nproc-per-node 2 -m neurec_amd.main --recommender=LightGCN ...` in a
+directory with NeuRec.properties + conf/ + a .rating file, two ranks sharing the one visible GPU over gloo, against
+the same command line on one process.  `batch_size` stays the GLOBAL batch, so the N-rank run IS the one-GPU run,
+partitioned:
+  * --dp_mode=rowshard (tables row-sharded, all-to-all lookups, a rank evaluates ITS users against the gathered item
+    table): every epoch's metric line identical to the one-GPU log, character for character;
+  * --dp_mode=colshard (the default: every rank holds embed_size / N columns): the inner products are sums of per-rank
+    partial dots, so the lines agree to north_star's 1e-5.
+Rank 0 writes the one log; the per-user metric rows are gathered so that the mean is the reference's float32 mean."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from neurec_amd import defaults
+from test_dropin_gpu import _write_dataset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+ARGS = ["--recommender=LightGCN", "--epochs=4", "--batch_size=256", "--embed_size=64", "--n_layers=2", "--lr=0.01"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(folder, ranks, extra):
+    os.makedirs(folder, exist_ok=True)
+    _write_dataset(folder, n_users=230, n_items=150)
+    defaults.write_default_configs(folder, overrides={"data.input.path": os.path.join(folder, "dataset"),
+                                                      "data.input.dataset": "toy", "test_batch_size": "64"})
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), NEUREC_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if ranks == 1:
+        cmd = [sys.executable, "-m", "neurec_amd.main"] + ARGS + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "neurec_amd.main"] + ARGS + extra
+    out = subprocess.run(cmd, cwd=folder, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    logs = os.path.join(folder, "log", "toy", "LightGCN")
+    files = os.listdir(logs)
+    assert len(files) == 1, files                                  # rank 0 writes the run's one log
+    with open(os.path.join(logs, files[0])) as f:
+        return re.findall(r"epoch (\d+):\t(.+)", f.read())
+
+
+def test_two_rank_lightgcn_drop_in_equals_the_one_gpu_run(tmp_path):
+    one = _run(str(tmp_path / "one"), 1, [])
+    rows = _run(str(tmp_path / "rows"), 2, ["--dp_mode=rowshard"])
+    cols = _run(str(tmp_path / "cols"), 2, [])
+    assert [e[0] for e in one] == [e[0] for e in rows] == [e[0] for e in cols] == ["0", "1", "2", "3"]
+    for a, b in zip(one, rows):
+        assert a[1] == b[1], (a, b)                                # row-sharded: the same line, to the last digit
+    va = np.asarray([[float(x) for x in e[1].split("\t")] for e in one])
+    vc = np.asarray([[float(x) for x in e[1].split("\t")] for e in cols])
+    assert np.abs(va - vc).max() <= 1e-5 and va[-1].max() > 0.05   # column-sharded: 1e-5; and the model has learnt
