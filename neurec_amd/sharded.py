@@ -867,8 +867,17 @@ class ShardedMF:
         E.adam_sparse(self.T, self.m, self.v, self.G, self.adam)                # clears G
         self.adam.advance()
 
+    def eval_factors(self):
+        """The evaluation entrance of a row-sharded run: (this rank's user rows [nu][d], the WHOLE item table [I][d]) —
+        only the item blocks are all-gathered (cf. ShardedLightGCN.eval_factors)."""
+        bu, bi = self.part.bu, self.part.bi
+        ulo, uhi = self.part.users_of(self.rank)
+        items = torch.empty((self.world * bi, self.d), dtype=torch.float32, device=self.T.device)
+        self.comm.all_gather_rows(self.T[bu:bu + bi].contiguous(), items)
+        return self.T[:uhi - ulo], items[:self.n_items]
+
     def tables(self):
-        """Full (P, Q) on every rank (one all-gather; evaluation entrance)."""
+        """Full (P, Q) on every rank (one all-gather; tests and the plugin's predict())."""
         full = torch.empty(self.b * self.world, self.d, dtype=torch.float32, device=self.T.device)
         self.comm.all_gather_rows(self.T, full)
         if self._gidx is None:

@@ -23,6 +23,7 @@ from test_dropin_gpu import _write_dataset
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 ARGS = ["--recommender=LightGCN", "--epochs=4", "--batch_size=256", "--embed_size=64", "--n_layers=2", "--lr=0.01"]
+MF_ARGS = ["--recommender=MF", "--epochs=6", "--batch_size=128", "--learning_rate=0.01", "--reg_mf=0.001", "--verbose=2"]
 
 
 def _free_port():
@@ -33,7 +34,8 @@ def _free_port():
     return port
 
 
-def _run(folder, ranks, extra):
+def _run(folder, ranks, extra, args=None, model="LightGCN", raw=False):
+    args = ARGS if args is None else args
     os.makedirs(folder, exist_ok=True)
     _write_dataset(folder, n_users=230, n_items=150)
     defaults.write_default_configs(folder, overrides={"data.input.path": os.path.join(folder, "dataset"),
@@ -43,17 +45,18 @@ def _run(folder, ranks, extra):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     if ranks == 1:
-        cmd = [sys.executable, "-m", "neurec_amd.main"] + ARGS + extra
+        cmd = [sys.executable, "-m", "neurec_amd.main"] + args + extra
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "neurec_amd.main"] + ARGS + extra
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "neurec_amd.main"] + args + extra
     out = subprocess.run(cmd, cwd=folder, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
-    logs = os.path.join(folder, "log", "toy", "LightGCN")
+    logs = os.path.join(folder, "log", "toy", model)
     files = os.listdir(logs)
     assert len(files) == 1, files                                  # rank 0 writes the run's one log
     with open(os.path.join(logs, files[0])) as f:
-        return re.findall(r"epoch (\d+):\t(.+)", f.read())
+        text = f.read()
+    return text if raw else re.findall(r"epoch (\d+):\t(.+)", text)
 
 
 def test_two_rank_lightgcn_drop_in_equals_the_one_gpu_run(tmp_path):
@@ -66,3 +69,17 @@ def test_two_rank_lightgcn_drop_in_equals_the_one_gpu_run(tmp_path):
     va = np.asarray([[float(x) for x in e[1].split("\t")] for e in one])
     vc = np.asarray([[float(x) for x in e[1].split("\t")] for e in cols])
     assert np.abs(va - vc).max() <= 1e-5 and va[-1].max() > 0.05   # column-sharded: 1e-5; and the model has learnt
+
+
+def test_two_rank_mf_drop_in_equals_the_one_gpu_run(tmp_path):
+    """conf/MF.properties as shipped (BPR, adam) on two ranks: both tables row-sharded with their Adam moments
+    (sharded.ShardedMF — north_star's "row-shard ... with all-to-all for cross-shard lookups"), a rank evaluates ITS
+    users against the gathered item table: the metric lines of the log are the one-GPU run's character for character
+    (the tables are bit-identical), the logged epoch losses agree to fp32 rounding (two per-rank sums added)."""
+    one = _run(str(tmp_path / "one"), 1, [], MF_ARGS, "MF", raw=True)
+    two = _run(str(tmp_path / "two"), 2, [], MF_ARGS, "MF", raw=True)
+    ev = lambda t: re.findall(r"epoch (\d+):\t(.+)", t)
+    assert [e[0] for e in ev(one)] == ["2", "4", "6"] and ev(one) == ev(two)
+    lo = lambda t: [float(x) for x in re.findall(r"\[iter \d+ : loss : ([0-9.]+),", t)]
+    assert len(lo(one)) == 6 and np.allclose(lo(one), lo(two), rtol=1e-5, atol=0)
+    assert lo(one)[-1] < lo(one)[0]
