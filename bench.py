@@ -68,6 +68,11 @@ def parse():
     ap.add_argument("--no-mf", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the NGCF / Mult-VAE legs (BASELINE configs[4])")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 slice leg (BASELINE configs[3])")
+    ap.add_argument("--config4-eval-batch", type=int, default=65536,
+                    help="users per batch of the config-4 evaluation leg (tile maxima: 4 B x 31,250 tiles per user = 8 GB "
+                         "at 65,536; measured 2.04 / 2.19 / 2.31 / 2.38 M users/s at 8,192 / 16,384 / 32,768 / 65,536: "
+                         "the planned strikes and the tile buckets of level 2 fill their 32-pair chunks only when a "
+                         "batch brings >= 32 pairs per tile)")
     ap.add_argument("--config4-scale", type=float, default=1.0,
                     help="fraction of BASELINE configs[3] (10^7 users, 10^6 items, 2*10^8 interactions) the one-GPU "
                          "leg runs at on this one GPU; 1.0 is the full size (213 ms/step)")
@@ -452,7 +457,7 @@ def leg_multivae(train, test, trc, tec, dev, with_cpu):
     return out
 
 
-def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=None, eval_users=0):
+def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=None, eval_users=0, eval_batch=65536):
     """BASELINE configs[3] (LightGCN, U = 10^7, I = 10^6, E = 2*10^8, d = 128) at `scale` on this GPU through
     the row-sharded engine: graph generated on the device, adjacency block built on the device.  hop: the form of the
     per-hop exchange (sharded.ShardedLightGCN: sliced / allgather / chunked / reduce; None = the engine's default)."""
@@ -532,7 +537,7 @@ def leg_config4(comm, dev, scale, batch=8192, dim=128, layers=3, steps=3, hop=No
                                 "the rate the pass sustains" % (lg.S, lg.w * 4)}}
     if eval_users:
         try:
-            out["eval"] = _config4_eval(lg, comm, trc, I, dim, dev, eval_users)
+            out["eval"] = _config4_eval(lg, comm, trc, I, dim, dev, eval_users, batch_rows=eval_batch)
         except Exception as e:                                # a secondary leg must not take the headline down
             out["eval"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del lg, sampler, trc, tr_ptr, tr_idx
@@ -1570,7 +1575,7 @@ def main():
     }
     if config4 and config4_eval:
         try:
-            ev4 = _config4_eval(full, comm, trc, I, args.dim, dev, 65536)
+            ev4 = _config4_eval(full, comm, trc, I, args.dim, dev, 65536, batch_rows=args.config4_eval_batch)
         except Exception as e:
             ev4 = {"error": "%s: %s" % (type(e).__name__, e)}
         line["eval"] = ev4
@@ -1683,7 +1688,8 @@ def main():
         for key, hop in (("rowshard_config4_law", None), ("rowshard_config4_law_reduce", "reduce")):
             try:
                 leg = leg_config4(comm, dev, args.config4_scale * comm.world / 8.0, hop=hop,
-                                  eval_users=65536 if (hop is None and not no_eval_legs) else 0)
+                                  eval_users=65536 if (hop is None and not no_eval_legs) else 0,
+                                  eval_batch=args.config4_eval_batch)
             except Exception as e:      # a secondary leg must not take the headline (already measured above) down
                 leg = {"error": "%s: %s" % (type(e).__name__, e)}
             if comm.rank == 0:
@@ -1748,7 +1754,8 @@ def main():
     if comm.rank == 0 and comm.world == 1 and not config4 and default_workload and not args.no_config4:
         ev = mf_ev = None
         torch.cuda.empty_cache()
-        line["config4"] = leg_config4(comm, dev, args.config4_scale, eval_users=0 if args.no_eval else 65536)
+        line["config4"] = leg_config4(comm, dev, args.config4_scale, eval_users=0 if args.no_eval else 65536,
+                                      eval_batch=args.config4_eval_batch)
         try:
             line["config4"]["partitions"] = leg_config4_partitions(dev, args.config4_scale)
         except Exception as e:                                # a measurement leg must not take the headline down

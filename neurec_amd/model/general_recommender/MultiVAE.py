@@ -112,9 +112,19 @@ class MultiVAE(AbstractRecommender):
     # ------------------------------------------------------------------ training
     def train_model(self):
         import torch
+        from ... import parallel
         update_count = 0.0
         self.logger.info(self.evaluator.metrics_info())
         dev = self.engine.stats.device
+        comm = parallel.get_comm()
+        replicas = None
+        if comm.active and self.batch_size % comm.world == 0:
+            # one rank of several: data-parallel replicas — every rank encodes / decodes ITS share of each
+            # global batch of `batch_size` users, one all-reduce of the flat gradient buffer per step, the same dense
+            # update everywhere (replicas.MultiVAEReplicas); the permutation below is the same on every rank (numpy
+            # seed 2018, main.py:10).  A batch size the ranks do not divide trains the whole batch on every rank
+            from ...replicas import MultiVAEReplicas
+            replicas = MultiVAEReplicas(comm, self.engine, decorrelate=True)
         n_batches = int(self.num_users / self.batch_size)
         for epoch in range(1, self.num_epochs + 1):
             random_perm_doc_idx = np.random.permutation(self.num_users).astype(np.int32)
@@ -129,13 +139,19 @@ class MultiVAE(AbstractRecommender):
                     anneal = min(self.anneal_cap, 1. * update_count / self.total_anneal_steps)
                 else:
                     anneal = self.anneal_cap
-                self.engine.step(rows.contiguous(), anneal, keep=0.8)
+                if replicas is not None:
+                    replicas.step(rows.contiguous(), anneal, keep=0.8)
+                else:
+                    self.engine.step(rows.contiguous(), anneal, keep=0.8)
                 stats[num_batch].copy_(self.engine.stats)
                 if self.reg != 0.0:                    # 2·reg_var term (host read; reg defaults to 0)
                     loss, neg_ll, kl = self.engine.loss()
                     reg_total += loss - neg_ll - anneal * kl
                 anneals.append(anneal)
                 update_count += 1
+            if replicas is not None:                   # the ranks' batch means averaged: the global batch's means
+                comm.allreduce_sum_(stats)
+                stats /= comm.world
             total_loss = reg_total
             for (neg_ll, kl), anneal in zip(stats[:len(anneals)].cpu().numpy(), anneals):
                 total_loss += float(neg_ll) + anneal * float(kl)

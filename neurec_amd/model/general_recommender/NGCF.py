@@ -82,6 +82,17 @@ class NGCF(AbstractRecommender):
         node_dropout = float(self.node_dropout_ratio) if (self.node_dropout_flag is True and self.alg_type == "ngcf") else 0.0
         args = (self.norm_adj, transpose_csr(self.norm_adj), self.num_users, self.num_items, table, weights,
                 self.learning_rate, self.reg, self.mess_dropout_ratio, self.batch_size)
+        from ... import parallel
+        self.comm = parallel.get_comm()
+        self.dp_mode = None
+        if self.comm.active and self.alg_type == "ngcf" and node_dropout == 0.0 and str(self.learner).lower() == "adam":
+            # one rank of several (python -m torch.distributed.run -m neurec_amd.main): node rows sharded over the ranks,
+            # the tiny layer weights replicated, `batch_size` = the GLOBAL batch (sharded_ngcf.ShardedNGCF).  The other
+            # alg_types / learners / node dropout train the whole model on every rank (same seeds, same tables)
+            from ...sharded_ngcf import ShardedNGCF
+            self.dp_mode = "rowshard"
+            self.engine = ShardedNGCF(self.comm, *args)
+            return
         if all(s == 16 for s in sizes) and self.alg_type == "ngcf" and node_dropout == 0.0:
             # the shipped configuration: fused, register-resident layer kernels
             self.engine = NGCFEngine(*args, learner=self.learner)
@@ -98,15 +109,23 @@ class NGCF(AbstractRecommender):
         self.logger.info(self.evaluator.metrics_info())
         data_iter = PairwiseSampler(self.dataset, neg_num=1, batch_size=self.batch_size,
                                     shuffle=True, as_tensors=True)
-        losses = torch.zeros((max(len(data_iter), 1), 2), device=self.engine.E0.device)
+        losses = torch.zeros((max(len(data_iter), 1), 2), device="cuda")
+        comm = self.comm
         for epoch in range(1, self.num_epochs + 1):
             training_start_time = time()
             num_training_instances = len(data_iter)
             n = 0
             for batch in data_iter:
                 bat_users, bat_items_pos, bat_items_neg = batch
-                self.engine.step(bat_users, bat_items_pos, bat_items_neg, losses[n], plan=batch.plan)
+                if self.dp_mode == "rowshard":           # this rank's slice of the global batch (every rank draws the same stream)
+                    nb = bat_users.numel()
+                    lo, hi = (nb * comm.rank) // comm.world, (nb * (comm.rank + 1)) // comm.world
+                    self.engine.step(bat_users[lo:hi], bat_items_pos[lo:hi], bat_items_neg[lo:hi], losses[n])
+                else:
+                    self.engine.step(bat_users, bat_items_pos, bat_items_neg, losses[n], plan=batch.plan)
                 n += 1
+            if self.dp_mode == "rowshard":
+                comm.allreduce_sum_(losses)               # the ranks' per-step sums added: the global batch's loss
             total_loss = 0.0
             for a, b in losses[:n].cpu().numpy():
                 total_loss += np.float32(a) + np.float32(b)

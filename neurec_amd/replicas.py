@@ -22,8 +22,14 @@ class MultiVAEReplicas:
     """engine: trainer.MultiVAEEngine or vae_wide.MultiVAEWideEngine, built identically on every rank (same
     parameters, same train CSR)."""
 
-    def __init__(self, comm, engine):
+    def __init__(self, comm, engine, decorrelate=False):
+        """decorrelate: give every rank its own noise / dropout seed (the sampling noise is keyed by a row's place in its
+        rank's batch: without this rank r's row j would draw rank 0's row j's eps)."""
         self.comm, self.eng = comm, engine
+        if decorrelate and comm.rank:
+            engine.seed = (int(engine.seed) + 0x9E3779B97F4A7C15 * comm.rank) & (2 ** 63 - 1)
+            if hasattr(engine, "_step_args"):
+                engine._step_args = None               # (the native step's argument block holds the seed)
         gs = engine.gradient_tensors()
         self.flat = torch.zeros(sum(g.numel() for g in gs), dtype=torch.float32, device=gs[0].device)
         views, off = [], 0

@@ -895,7 +895,11 @@ class ShardedEvaluator:
     DeviceCSR.rows(ulo, uhi) of the whole matrices; the strike plan and the user -> row table of the pruned path
     are then built over the rank's users, not over all 10^7."""
 
-    def __init__(self, comm, train_rows, test_rows, metric_ids, top_k, batch_rows=8192, **evaluator_args):
+    def __init__(self, comm, train_rows, test_rows, metric_ids, top_k, batch_rows=32768, **evaluator_args):
+        # batch_rows: the tile maxima of a batch are 4 B x 2·ceil(I / 64) per user (10^6 items: 4 GB at 32,768 users);
+        # large batches matter at large I — the planned strikes and level 2's tile buckets work in 32-pair chunks of
+        # ONE tile, which a batch fills only if it brings >= 32 pairs per tile (config 4: 2.04 M users/s at 8,192,
+        # 2.38 M at 65,536)
         from .trainer import FullRankEvaluator
         if train_rows.n_rows != test_rows.n_rows:
             raise ValueError("train and test rows of a rank cover the same users")

@@ -83,3 +83,36 @@ def test_two_rank_mf_drop_in_equals_the_one_gpu_run(tmp_path):
     lo = lambda t: [float(x) for x in re.findall(r"\[iter \d+ : loss : ([0-9.]+),", t)]
     assert len(lo(one)) == 6 and np.allclose(lo(one), lo(two), rtol=1e-5, atol=0)
     assert lo(one)[-1] < lo(one)[0]
+
+
+def test_two_rank_ngcf_drop_in_tracks_the_one_gpu_run(tmp_path):
+    """conf/NGCF.properties (ngcf, adam) on two ranks: node rows sharded, the layer weights replicated and their
+    gradients all-reduced (sharded_ngcf.ShardedNGCF).  With message dropout off the run is deterministic and differs
+    from one GPU only by the association of the weight-gradient sums: metric lines and epoch losses agree to 1e-5."""
+    args = ["--recommender=NGCF", "--epochs=4", "--batch_size=128", "--learning_rate=0.005", "--mess_dropout_ratio=0.0",
+            "--verbose=2"]
+    one = _run(str(tmp_path / "one"), 1, [], args, "NGCF", raw=True)
+    two = _run(str(tmp_path / "two"), 2, [], args, "NGCF", raw=True)
+    ev = lambda t: np.asarray([[float(x) for x in e[1].split("\t")] for e in re.findall(r"epoch (\d+):\t(.+)", t)])
+    lo = lambda t: [float(x) for x in re.findall(r"\[iter \d+ : loss : ([0-9.]+),", t)]
+    assert ev(one).shape == (2, 10) and np.abs(ev(one) - ev(two)).max() <= 1e-5
+    assert len(lo(one)) == 4 and np.allclose(lo(one), lo(two), rtol=1e-5, atol=0) and lo(one)[-1] < lo(one)[0]
+
+
+def test_two_rank_multivae_drop_in_trains_as_replicas(tmp_path):
+    """conf/MultiVAE.properties on two ranks: data-parallel replicas (each rank its share of every global batch, one
+    all-reduce of the gradients per step).  The sampling noise of a replica run is a different, equally distributed draw
+    than one process's, so the check is the run itself: one log, the loss falls, the evaluation (sharded over users)
+    prints a line of the reference's format with a model that has learnt."""
+    args = ["--recommender=MultiVAE", "--epochs=12", "--batch_size=64", "--learning_rate=0.01", "--verbose=6"]
+    one = _run(str(tmp_path / "one"), 1, [], args, "MultiVAE", raw=True)
+    two = _run(str(tmp_path / "two"), 2, [], args, "MultiVAE", raw=True)
+    for text in (one, two):
+        lo = [float(x) for x in re.findall(r"\[iter \d+ : loss : ([0-9.]+),", text)]
+        ev = re.findall(r"epoch (\d+):\t(.+)", text)
+        assert len(lo) == 12 and lo[-1] < lo[0] and [e[0] for e in ev] == ["6", "12"]
+        vals = [float(x) for x in ev[-1][1].split("\t")]
+        assert len(vals) == 10 and max(vals) > 0.05
+    l1 = [float(x) for x in re.findall(r"\[iter \d+ : loss : ([0-9.]+),", one)]
+    l2 = [float(x) for x in re.findall(r"\[iter \d+ : loss : ([0-9.]+),", two)]
+    assert abs(l1[-1] - l2[-1]) <= 0.1 * abs(l1[-1])               # the same model, another draw of the noise
