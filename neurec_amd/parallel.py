@@ -29,6 +29,63 @@ import torch
 import torch.distributed as dist
 
 
+class _RcclDirect:
+    """ncclAllGather issued on torch's CURRENT stream through librccl's C API (r06, VERDICT r5 #7b).
+
+    ProcessGroupNCCL runs a collective on its own stream: an event recorded on the compute stream, a wait on the
+    collective stream, the collective, an event back — measured at +34 us on the device timeline of the column-sharded
+    step before a byte moves (profiles/r05_exp_colshard_nccl_overhead.txt), 17 % of that step.  The step's ONE exchange
+    (12 B per triplet and rank) has nothing to overlap with, so it is issued where the kernels around it are: one more
+    launch on the compute stream, ordered like them.  A second RCCL communicator next to torch's, created from a unique
+    id that rank 0 broadcasts through the process group.  Anything that fails here leaves the torch path in charge."""
+
+    DTYPES = {torch.int8: 0, torch.uint8: 1, torch.int32: 2, torch.int64: 4, torch.float16: 6, torch.float32: 7,
+              torch.float64: 8}
+
+    def __init__(self, rank, world):
+        import ctypes as C
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        self._C = C
+        self.lib = lib = C.CDLL(os.environ.get("NEUREC_RCCL_LIB", "librccl.so"))
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = UniqueId()
+        if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().cuda()
+        dist.broadcast(raw, src=0)                                # (the process group exists: backend nccl)
+        C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        rc = lib.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank))
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed with %d" % rc)
+
+    def all_gather(self, local, out):
+        C = self._C
+        rc = self.lib.ncclAllGather(C.c_void_p(local.data_ptr()), C.c_void_p(out.data_ptr()), C.c_size_t(local.numel()),
+                                    self.DTYPES[local.dtype], self.comm, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError("ncclAllGather failed with %d" % rc)
+
+    def all_reduce_sum(self, t):
+        C = self._C
+        rc = self.lib.ncclAllReduce(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), C.c_size_t(t.numel()),
+                                    self.DTYPES[t.dtype], 0, self.comm,                     # 0 = ncclSum; in place
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError("ncclAllReduce failed with %d" % rc)
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 class Comm:
     """Collectives of the hot path.  STREAM CONTRACT (backend "nccl" = RCCL): every kernel of this package is
     launched through ctypes on torch's CURRENT stream (engine._stream()); ProcessGroupNCCL runs a collective on its
@@ -46,6 +103,20 @@ class Comm:
         self.force = bool(force)
         self.debug_sync = os.environ.get("NEUREC_DIST_DEBUG_SYNC", "") == "1"
         self.calls = {}                                      # collective name -> times issued (tests, bench line)
+        self._direct, self._direct_tried = None, False       # the RCCL communicator of all_gather_rows (made on first use)
+
+    def _rccl_direct(self):
+        """librccl on the compute stream for the blocking all-gather (backend nccl; NEUREC_RCCL_DIRECT=0: torch's)"""
+        if not self._direct_tried:
+            self._direct_tried = True
+            if self.backend == "nccl" and os.environ.get("NEUREC_RCCL_DIRECT", "1") != "0" and dist.is_initialized():
+                try:
+                    self._direct = _RcclDirect(self.rank, self.world)
+                except Exception as e:                       # torch.distributed stays in charge
+                    import sys
+                    sys.stderr.write("neurec_amd.parallel: direct RCCL all-gather unavailable (%s: %s), using "
+                                     "torch.distributed\n" % (type(e).__name__, e))
+        return self._direct
 
     @property
     def active(self):
@@ -86,7 +157,12 @@ class Comm:
                 t.copy_(host)
                 self._done()
             else:
-                self._done(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+                direct = self._rccl_direct() if t.is_cuda else None
+                if direct is not None and t.dtype in direct.DTYPES and t.is_contiguous():
+                    direct.all_reduce_sum(t)              # on the current stream, as all_gather_rows
+                    self._done()
+                else:
+                    self._done(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         return t
 
     def allgather_cat_start(self, parts):
@@ -126,6 +202,12 @@ class Comm:
             return out
         self._enter("all_gather")
         if self.backend == "nccl":
+            direct = self._rccl_direct()
+            if direct is not None and local.dtype in direct.DTYPES and out.is_contiguous():
+                # on the CURRENT stream: ordered behind the kernels already enqueued and before the next ones
+                direct.all_gather(local.contiguous(), out)
+                self._done()
+                return out
             self._done(dist.all_gather_into_tensor(out, local.contiguous(), async_op=True))
             return out
         host = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype)
@@ -261,6 +343,11 @@ class Comm:
         return float(t.item())
 
     def shutdown(self):
+        if self._direct is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self._direct.close()
+            self._direct = None
         if self.live and dist.is_initialized():
             dist.destroy_process_group()
 

@@ -97,6 +97,17 @@ def _worker(rank, port, out_path):
     _comm_methods(comm, torch)
     _comm_methods(synced, torch)
     report["comm_calls"] = dict(comm.calls)
+    # r06: the blocking all-gather goes through librccl's C API on the CURRENT stream (parallel._RcclDirect); the
+    # process group's own collective is the fallback and gives the same bits
+    report["direct_all_gather"] = comm._direct is not None
+    os.environ["NEUREC_RCCL_DIRECT"] = "0"
+    via_torch = parallel.Comm(0, 1, 0, "nccl", force=True)
+    x = torch.rand(257, 12, device="cuda")
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    comm.all_gather_rows(x, a)
+    via_torch.all_gather_rows(x, b)
+    report["direct_equals_process_group"] = bool(torch.equal(a, b) and torch.equal(a, x)) and via_torch._direct is None
+    del os.environ["NEUREC_RCCL_DIRECT"]
 
     cuda = lambda b: tuple(torch.from_numpy(x).cuda() for x in b)
 
@@ -183,6 +194,7 @@ def test_every_collective_and_every_sharded_engine_over_rccl_at_world_size_one(t
         rep = json.load(f)
     print("RCCL at world size 1:", json.dumps(rep))
     assert rep["backend"] == "nccl"
+    assert rep["direct_all_gather"] and rep["direct_equals_process_group"]
     for name in ("all_gather", "all_gather_async", "broadcast", "all_to_all", "all_gather_ids", "all_reduce"):
         assert rep["comm_calls"].get(name, 0) > 0, name
     for name, r in rep["engines"].items():
