@@ -53,6 +53,8 @@ class _RcclDirect:
         lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
         uid = UniqueId()
         if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
@@ -79,6 +81,26 @@ class _RcclDirect:
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise RuntimeError("ncclAllReduce failed with %d" % rc)
+
+    def all_to_all_rows(self, send, send_counts, recv, recv_counts):
+        """rows [n][...] ordered by destination -> rows ordered by source: one group of ncclSend / ncclRecv pairs"""
+        C, lib = self._C, self.lib
+        row = 1
+        for x in send.shape[1:]:
+            row *= int(x)
+        esz, dt, st = send.element_size(), self.DTYPES[send.dtype], C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        sp, rp, so, ro = send.data_ptr(), recv.data_ptr(), 0, 0
+        rc = lib.ncclGroupStart()
+        for r in range(len(send_counts)):
+            if send_counts[r] and rc == 0:
+                rc = lib.ncclSend(C.c_void_p(sp + so * row * esz), C.c_size_t(send_counts[r] * row), dt, r, self.comm, st)
+            if recv_counts[r] and rc == 0:
+                rc = lib.ncclRecv(C.c_void_p(rp + ro * row * esz), C.c_size_t(recv_counts[r] * row), dt, r, self.comm, st)
+            so += send_counts[r]
+            ro += recv_counts[r]
+        rc2 = lib.ncclGroupEnd()
+        if rc != 0 or rc2 != 0:
+            raise RuntimeError("ncclSend / ncclRecv group failed with %d / %d" % (rc, rc2))
 
     def close(self):
         if self.comm:
@@ -274,6 +296,12 @@ class Comm:
                 recv_counts = [int(c) for c in rc.cpu()]
             recv_counts = [int(c) for c in recv_counts]
             recv = torch.empty((sum(recv_counts),) + tail, dtype=send.dtype, device=send.device)
+            direct = self._rccl_direct()
+            if direct is not None and send.dtype in direct.DTYPES:
+                # on the current stream (see all_gather_rows): the row-sharded step's three exchanges are blocking ones
+                direct.all_to_all_rows(send.contiguous(), send_counts, recv, recv_counts)
+                self._done()
+                return recv, recv_counts
             self._done(dist.all_to_all_single(recv, send.contiguous(), recv_counts, send_counts, async_op=True))
             return recv, recv_counts
         if recv_counts is None:
