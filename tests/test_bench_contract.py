@@ -83,5 +83,10 @@ def test_bench_cli_has_the_contract_flags_and_safe_defaults():
         assert re.search(r'add_argument\(\s*"%s"' % flag, src), flag
     m = re.search(r'add_argument\(\s*"--gpus"[^)]*default=(\d+)', src)
     assert m and int(m.group(1)) == 1
-    # nothing measured may touch the reference tree or the oracle outside the cpu_baseline leg
-    assert "/root/reference" not in src
+    # nothing measured may touch the reference tree or the oracle outside the cpu_baseline legs (bench_legs.py holds them)
+    with open(os.path.join(ROOT, "bench_legs.py")) as f:
+        legs = f.read()
+    assert "/root/reference" not in src and "/root/reference" not in legs
+    # `oracle` is imported inside the CPU-baseline code only: never at module level of either file
+    for text in (src, legs):
+        assert not any(l.startswith(("import oracle", "from oracle")) for l in text.splitlines())
