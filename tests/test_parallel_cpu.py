@@ -344,3 +344,35 @@ def test_row_sharded_hop_forms_two_ranks(tmp_path):
         got = np.load(out % r)
         assert got["sliced"] < 1e-12 and got["reduce"] < 1e-12, (r, got["sliced"], got["reduce"])
         assert "all_gather_async" in str(got["calls"]) and "all_to_all_equal" in str(got["calls"])
+
+
+def _row_gather_worker(rank, world, store, out):
+    """file-store rendezvous (no MASTER_PORT at all) + the per-user row gather of the sharded drop-in evaluation"""
+    for k in ("MASTER_PORT",):
+        os.environ.pop(k, None)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      NEUREC_DIST_INIT_FILE=store)
+    comm = parallel.init_from_env(backend="gloo")
+    assert comm.active and comm.world == world
+    n = (5, 0, 3)[rank]                                                     # unequal shares, an empty one
+    users = torch.arange(n, dtype=torch.int32) + 100 * rank
+    rows = (torch.arange(n * 4, dtype=torch.float32).view(n, 4) + 1000 * rank)
+    got_u, got_r = parallel.gather_rows_by_user(comm, users, rows, torch.device("cpu"))
+    if rank == 0:
+        np.savez(out, users=got_u.numpy(), rows=got_r.numpy())
+    comm.barrier()
+    comm.shutdown()
+
+
+def test_file_store_rendezvous_and_row_gather_over_three_ranks(tmp_path):
+    """bench.py's self-started ranks and `-m neurec_amd.main` under a launcher meet through parallel.init_from_env;
+    NEUREC_DIST_INIT_FILE replaces MASTER_ADDR / MASTER_PORT by a file store (no port to lose).  The sharded
+    drop-in evaluation gathers (user, metric row) pairs of unequal shares rank-major: every rank then means the same rows
+    in the same order as one process does (uni_evaluator.py:150-151)."""
+    out = str(tmp_path / "g.npz")
+    mp.start_processes(_row_gather_worker, args=(3, str(tmp_path / "store"), out), nprocs=3, join=True, start_method="spawn")
+    got = np.load(out)
+    want_u = np.concatenate([np.arange(5), 200 + np.arange(3)]).astype(np.int32)
+    want_r = np.concatenate([np.arange(20, dtype=np.float32).reshape(5, 4), 2000 + np.arange(12, dtype=np.float32).reshape(3, 4)])
+    np.testing.assert_array_equal(got["users"], want_u)
+    np.testing.assert_array_equal(got["rows"], want_r)
