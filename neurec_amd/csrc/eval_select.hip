@@ -810,13 +810,20 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(int32_t* __restrict__ 
   __syncthreads();
   for (int t = b; t < e; ++t) gcnt[t] = min(gcnt[t], cap);     // (the later kernels read the clamped counts)
 }
+// chunks[c] = {tile, first bucket entry of the chunk (absolute), pairs in the chunk, 0}: everything rescore_pairs_kernel
+// needs besides the entries themselves in ONE load (r06: it read chunks -> gcnt / pair_begin -> bucket in sequence)
 __global__ __launch_bounds__(256) void chunk_list_kernel(const int32_t* __restrict__ gcnt,
                                                          const int32_t* __restrict__ chunk_begin, int n_tiles,
-                                                         int2* __restrict__ chunks) {
+                                                         const int32_t* __restrict__ pair_begin, int rows,
+                                                         int4* __restrict__ chunks) {
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= n_tiles) return;
-  const int n = (gcnt[t] + 31) >> 5, base = chunk_begin[t];
-  for (int c = lane; c < n; c += 64) chunks[base + c] = make_int2(t, 32 * c);
+  const int cnt = gcnt[t], n = (cnt + 31) >> 5, base = chunk_begin[t];
+  const int64_t first = pair_begin ? (int64_t)pair_begin[t] : (int64_t)t * rows;      // packed / strided buckets
+  for (int c = lane; c < n; c += 64) {
+    const int64_t at = first + 32 * c;
+    chunks[base + c] = make_int4(t, (int)(at & 0xffffffff), min(32, cnt - 32 * c), (int)(at >> 32));
+  }
 }
 
 // ---- the COMPACT bucket form: any number of tiles (r06; BASELINE configs[3] has 31,250 32-item tiles) -------------
@@ -893,20 +900,18 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const int32_t* __restric
 template <int KS>
 __global__ __launch_bounds__(256) void rescore_pairs_kernel(
     const float* __restrict__ P, int64_t ldp, int d, const float* __restrict__ QT, int64_t ipad, int cols,
-    const int32_t* __restrict__ users, int rows, const int32_t* __restrict__ gcnt,
-    const int32_t* __restrict__ chunk_begin, int n_tiles, const int2* __restrict__ chunks,
-    const uint32_t* __restrict__ bucket, const int32_t* __restrict__ pair_begin, float* __restrict__ C, int64_t cld) {
+    const int32_t* __restrict__ users, int rows, const int32_t* __restrict__ chunk_begin, int n_tiles,
+    const int4* __restrict__ chunks, const uint32_t* __restrict__ bucket, float* __restrict__ C, int64_t cld) {
   constexpr int DP = 2 * KS;
   __shared__ float sB[4][32][DP + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int c = blockIdx.x * 4 + wave;
   if (c >= chunk_begin[n_tiles]) return;
-  const int2 ck = chunks[c];
-  const int t = ck.x;
-  const int n = min(32, gcnt[t] - ck.y);
+  const int4 ck = chunks[c];
+  const int t = ck.x, n = ck.z;
   uint32_t pair = 0u;
-  if (j < n) pair = bucket[(pair_begin ? (int64_t)pair_begin[t] : (int64_t)t * rows) + ck.y + j];   // packed / strided buckets
+  if (j < n) pair = bucket[(((int64_t)ck.w << 32) | (uint32_t)ck.y) + j];
   const int row = (int)(pair >> 6), slot = (int)(pair & 63u);
   const int64_t u = users ? (int64_t)users[row] : (int64_t)row;
   float a[KS], b[KS];
@@ -1367,13 +1372,13 @@ static size_t grouped_form_bytes(int form, int rows, int cols, int n_keep) {
   const size_t max_chunks = r * (size_t)n_keep / 32 + n_tiles + 1;
   if (form == kGroupedStrided) {
     if (n_tiles > (size_t)kMaxGroupedTiles || n_tiles * r * 4 > ((size_t)1 << 30) || r >= ((size_t)1 << 26)) return 0;
-    return nr_align_up((n_tiles + r) * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
+    return nr_align_up((n_tiles + r) * 4, 256) + nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 16, 256) +
            nr_align_up(n_tiles * r * 4, 256);                   // counts + overflow flags | chunk starts | chunks | buckets
   }
   if (form == kGroupedCompact) {
     if (r >= ((size_t)1 << 26) || r * (size_t)n_keep >= ((size_t)1 << 31)) return 0;
     // counts + bucket cursors | chunk starts | bucket starts | chunks | packed buckets
-    return nr_align_up(2 * n_tiles * 4, 256) + 2 * nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 8, 256) +
+    return nr_align_up(2 * n_tiles * 4, 256) + 2 * nr_align_up((n_tiles + 1) * 4, 256) + nr_align_up(max_chunks * 16, 256) +
            nr_align_up(r * (size_t)n_keep * 4, 256);
   }
   return 0;
@@ -1500,13 +1505,13 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     char* x = (char*)d_ws + eval_tiles_ws_bytes(rows, n_keep);
     const size_t max_chunks = (size_t)rows * n_keep / 32 + n_tiles + 1;
     int32_t *gcnt, *chunk_begin, *pair_begin = nullptr;
-    int2* chunks;
+    int4* chunks;
     uint32_t* bucket;
     if (form == kGroupedStrided) {
       gcnt = (int32_t*)x;        x += nr_align_up(((size_t)n_tiles + rows) * 4, 256);
       overflow = gcnt + n_tiles;
       chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
-      chunks = (int2*)x;         x += nr_align_up(max_chunks * 8, 256);
+      chunks = (int4*)x;         x += nr_align_up(max_chunks * 16, 256);
       bucket = (uint32_t*)x;
       NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, ((size_t)n_tiles + rows) * 4, st));
       hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
@@ -1521,7 +1526,7 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
       int32_t* cursor = gcnt + n_tiles;
       chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
       pair_begin = (int32_t*)x;  x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
-      chunks = (int2*)x;         x += nr_align_up(max_chunks * 8, 256);
+      chunks = (int4*)x;         x += nr_align_up(max_chunks * 16, 256);
       bucket = (uint32_t*)x;
       const dim3 wg((rows + kPairRows - 1) / kPairRows);
       NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, 2 * (size_t)n_tiles * 4, st));
@@ -1535,13 +1540,13 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
       NR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(chunk_list_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, st, gcnt, chunk_begin, n_tiles,
-                       chunks);
+                       pair_begin, rows, chunks);
     NR_LAUNCH_CHECK();
     const dim3 pgrid((unsigned)((max_chunks + 3) / 4));
     const int dp = d <= 16 ? 16 : d <= 32 ? 32 : d <= 48 ? 48 : d <= 64 ? 64 : 128;
 #define NR_PAIRS_CASE(KS)                                                                                        \
   hipLaunchKernelGGL(rescore_pairs_kernel<KS>, pgrid, dim3(256), 0, st, d_P, ldp, d, qt, (int64_t)ipad, cols,     \
-                     d_users, rows, gcnt, chunk_begin, n_tiles, chunks, bucket, pair_begin, C, cld)
+                     d_users, rows, chunk_begin, n_tiles, chunks, bucket, C, cld)
     switch (dp) {
       case 16: NR_PAIRS_CASE(8); break;
       case 32: NR_PAIRS_CASE(16); break;
