@@ -7,32 +7,10 @@
 #include "nr_common.h"
 #include "neurec_hip.h"
 
-namespace {
-
-// out[0] <- the flagged-row count, out[1] <- the rows among them whose certificate failed (flag bit 1), as doubles next
-// to the column sums: one device->host copy brings all of it
-__global__ __launch_bounds__(1024) void count_flags_kernel(const int32_t* __restrict__ flags, int n,
-                                                           double* __restrict__ out) {
-  __shared__ int s_part[1024], s_cert[1024];
-  int c = 0, k = 0;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {         // 8 loads in flight per thread (one after the other: 20 us)
-    int v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < n ? flags[i0 + u * 1024] : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { c += v[u] != 0 ? 1 : 0; k += (v[u] & 2) ? 1 : 0; }
-  }
-  s_part[threadIdx.x] = c;
-  s_cert[threadIdx.x] = k;
-  __syncthreads();
-  for (int st = 512; st >= 1; st >>= 1) {
-    if ((int)threadIdx.x < st) { s_part[threadIdx.x] += s_part[threadIdx.x + st]; s_cert[threadIdx.x] += s_cert[threadIdx.x + st]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { out[0] = (double)s_part[0]; out[1] = (double)s_cert[0]; }
-}
-
-}  // namespace
+// eval_select.hip: the column sums with the flagged-row counts formed in their second launch — out[cols] <- rows with
+// a flag, out[cols + 1] <- the rows among them whose certificate failed (flag bit 1), as doubles next to the sums
+int nr_colsum_f64_flags(const float* d_mat, int64_t ld, int rows, int cols, double* d_out, void* d_ws, size_t ws_bytes,
+                        const int32_t* d_flags, double* d_flag_out, void* stream);
 
 extern "C" {
 
@@ -85,10 +63,8 @@ int nrhip_eval_pruned(const NrhipEvalPruned* a, void* stream) {
   }
   if (a->d_sums && a->n_users > 0) {
     NR_REQUIRE(a->d_colsum_ws, NR_ERR_ARG, "eval_pruned: column sums need their workspace");
-    NR_TRY(nrhip_colsum_f64(a->d_out, out_ld, a->n_users, out_ld, a->d_sums, a->d_colsum_ws, a->colsum_ws_bytes, stream));
-    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a->d_flags, a->n_users,
-                       a->d_sums + out_ld);
-    NR_LAUNCH_CHECK();
+    NR_TRY(nr_colsum_f64_flags(a->d_out, out_ld, a->n_users, out_ld, a->d_sums, a->d_colsum_ws, a->colsum_ws_bytes,
+                               a->d_flags, a->d_sums + out_ld, stream));
   }
   return NR_OK;
 }

@@ -156,7 +156,15 @@ __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t v) {
 template <int VEC>
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
     const float* __restrict__ scores, int64_t ld, int rows, int cols, int sort_len, int cut,
-    int32_t* __restrict__ rank, int32_t* __restrict__ flag, uint64_t* __restrict__ tie_mask) {
+    int32_t* __restrict__ rank, int32_t* __restrict__ flag, uint64_t* __restrict__ tie_mask, int64_t rank_ld, int fill,
+    int32_t* __restrict__ zero, int zero_n) {
+  // zero (optional): zero_n words the NEXT kernel wants cleared (the tile counters of the bucket pass) — the grid
+  // clears them on its way in instead of a hipMemsetAsync launch between the two kernels
+  if (zero)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x) zero[i] = 0;
+  // rank_ld: the stride of `rank`'s rows.  fill != 0: the slots [ranks written, cut) of the row are set to 0 — the
+  // pruned evaluation's tile lists: a row without `cut` comparable scores (a NaN factor row) would otherwise keep what
+  // a previous call left in the workspace, and every later kernel indexes M / the item copy / the buckets with them.
   // tie_mask (optional): bit k <=> the scores at ranks k and k + 1 are equal, k < cut (bit cut - 1 = the pair that
   // straddles the cut); all ones when only "some tie" is known (the streaming path)
   __shared__ uint64_t s_keys[kSelWaves][kSelSlots];
@@ -227,7 +235,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
         const uint64_t next = shfl_down1_u64(mine);           // lane 63 and lanes past the keys: 0 = none
         const int n_out = min(cut, min(sort_len, c_n));
         const bool tie = lane < n_out && next != 0ull && nr::key_order(mine) == nr::key_order(next);
-        if (lane < n_out) rank[(int64_t)row * kRankStride + lane] = (int32_t)nr::key_index(mine);
+        if (lane < n_out) rank[(int64_t)row * rank_ld + lane] = (int32_t)nr::key_index(mine);
+        else if (fill && lane < cut) rank[(int64_t)row * rank_ld + lane] = 0;
         const uint64_t tmask = __ballot(tie);
         if (lane == 0) {
           flag[row] = tmask ? 1 : 0;
@@ -358,8 +367,10 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
     const uint64_t a = top[r];
     const uint64_t b = (r + 1 < take) ? top[r + 1] : nb;
     if (b != 0 && nr::key_order(a) == nr::key_order(b)) tie = true;
-    rank[(int64_t)row * kRankStride + r] = (int32_t)nr::key_index(a);
+    rank[(int64_t)row * rank_ld + r] = (int32_t)nr::key_index(a);
   }
+  if (fill)
+    for (int r = max(0, min(cut, take)) + lane; r < cut; r += NR_WAVE) rank[(int64_t)row * rank_ld + r] = 0;
   if (btie && take >= cut && cut >= 1 && nr::key_order(top[cut - 1]) == btie_order) tie = true;
   const bool any_tie = __ballot(tie) != 0;
   if (lane == 0) {
@@ -483,46 +494,41 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void exact_rows_kernel(
 // test list, then lane m evaluates metric m sequentially over k (the float /
 // double sequence of metric.h, see nr::metric_eval).
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
-    const int32_t* __restrict__ rank, int rows, int top_k, const int32_t* __restrict__ users,
-    const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices, MetricIds mids,
-    InvLog2Table tbl, float* __restrict__ out, int32_t* __restrict__ topk_out,
-    const uint64_t* __restrict__ tie_mask, int32_t* __restrict__ flag_io) {
-  __shared__ unsigned char s_hit[kSelWaves][128];
-  __shared__ float s_pre[kSelWaves][128];
-  const int wave = threadIdx.x / NR_WAVE;
-  const int lane = nr_lane();
-  const int row = blockIdx.x * kSelWaves + wave;
-  if (row >= rows) return;
+// One row's metrics by one wave (metrics_kernel's body; rank_compact_kernel ends with it).  item0 = the item at rank
+// `lane` (lanes >= the number of ranks: anything); rank_row = the row's ranks in memory for cut-offs beyond one per lane
+// (may be null when top_k + 1 <= 64).  s_hit / s_pre [128], s_truth [kMetricsTruthLds]: the wave's LDS.
+constexpr int kMetricsTruthLds = 256;
+__device__ __forceinline__ void metrics_row(
+    const int32_t* __restrict__ rank_row, int32_t item0, int row, int lane, int top_k, bool with_tie, uint64_t tm,
+    const int32_t* __restrict__ users, const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices,
+    const MetricIds& mids, const InvLog2Table& tbl, float* __restrict__ out, int32_t* __restrict__ topk_out,
+    int32_t* __restrict__ flag_io, unsigned char* s_hit, float* s_pre, int32_t* s_truth) {
   const int64_t t = users ? (int64_t)users[row] : (int64_t)row;
   const int64_t tb = t_indptr[t], te = t_indptr[t + 1];
   const int T = (int)(te - tb);
   // the user's test list into LDS (one coalesced load, in flight together with the ranks) and the membership searches
   // there: a binary search in global memory was ~5 dependent round trips per row, 46 us for 29,858 users
-  constexpr int kTruthLds = 256;
-  __shared__ int32_t s_truth[kSelWaves][kTruthLds];
-  const int n_rank = top_k + (tie_mask ? 1 : 0);               // (with tie masks: the first item outside too)
-  const int32_t item0 = lane < n_rank ? rank[(int64_t)row * kRankStride + lane] : 0;
+  constexpr int kTruthLds = kMetricsTruthLds;
+  const int n_rank = top_k + (with_tie ? 1 : 0);               // (with tie masks: the first item outside too)
   const bool in_lds = T <= kTruthLds;                          // wave-uniform
   if (in_lds)
-    for (int i = lane; i < T; i += NR_WAVE) s_truth[wave][i] = t_indices[tb + i];
+    for (int i = lane; i < T; i += NR_WAVE) s_truth[i] = t_indices[tb + i];
   wave_lds_sync();
-  const int32_t* truth = in_lds ? s_truth[wave] : t_indices + tb;
+  const int32_t* truth = in_lds ? s_truth : t_indices + tb;
   for (int k = lane; k < n_rank; k += NR_WAVE) {
-    const int32_t item = k == lane ? item0 : rank[(int64_t)row * kRankStride + k];
-    s_hit[wave][k] = nr::sorted_contains(truth, T, item) ? 1 : 0;
+    const int32_t item = k == lane ? item0 : rank_row[k];      // (item0 only: n_rank <= 64, rank_row may be null)
+    s_hit[k] = nr::sorted_contains(truth, T, item) ? 1 : 0;
     if (topk_out && k < top_k) topk_out[(int64_t)row * top_k + k] = item;
   }
   wave_lds_sync();
-  if (tie_mask) {
+  if (with_tie) {
     // Equal scores at neighbouring ranks: the reference's order among them is its heap's history (exact_rows_kernel
     // replays it from a full row).  Every metric here is a function of the hit / miss sequence over the ranks alone,
     // so a tie between two items that are both test items or both not cannot change any of them — the pair across
     // the cut included (rank holds top_k + 1 items here).  Only a tie whose two sides differ needs the replay, and a
     // tie group that runs on beyond the first item outside (its other members are not known here).
-    const uint64_t tm = tie_mask[row];
     bool bad = false;
-    if (lane < top_k && ((tm >> lane) & 1ull) && s_hit[wave][lane] != s_hit[wave][lane + 1]) bad = true;
+    if (lane < top_k && ((tm >> lane) & 1ull) && s_hit[lane] != s_hit[lane + 1]) bad = true;
     if (((tm >> (top_k - 1)) & 1ull) && ((tm >> top_k) & 1ull)) bad = true;
     if (__ballot(bad) != 0 && lane == 0) flag_io[row] |= 1;    // (bit 1 of a pruned row: its certificate failed)
   }
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
   // double recurrences below are skipped.  (They are ~800 VALU instructions a row: 47 -> ~15 us for 29,858 users.)
   {
     bool h = false;
-    for (int k = lane; k < top_k; k += NR_WAVE) h = h || s_hit[wave][k] != 0;
+    for (int k = lane; k < top_k; k += NR_WAVE) h = h || s_hit[k] != 0;
     if (T > 0 && __ballot(h) == 0) {
       for (int e = lane; e < mids.n * top_k; e += NR_WAVE) out[(int64_t)row * mids.n * top_k + e] = 0.f;
       return;
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
   // keeps the state at its own k — and the divisions, which are most of the instructions, are done for
   // all k at once.  (One lane per metric ran five divergent 20-step loops of fp64 divisions one after
   // the other: ~1,800 instructions a row, 88 us for 29,858 users.)  top_k <= 128: two cut-offs per lane.
-  const unsigned char* hit = s_hit[wave];
+  const unsigned char* hit = s_hit;
   int hits = 0, first = -1;
   float dcg = 0.f, idcg = 0.f;
   int hits_k[2] = {0, 0};
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
   for (int j = 0; j < 2; ++j) {
     const int k = lane + NR_WAVE * j;
     pre_k[j] = (float)(1.0 * hits_k[j] / (double)(unsigned)(k + 1));   // precision, metric.h:17-28
-    if (k < top_k) s_pre[wave][k] = pre_k[j];
+    if (k < top_k) s_pre[k] = pre_k[j];
   }
   bool want_ap = false;
   for (int m = 0; m < mids.n; ++m) want_ap = want_ap || mids.id[m] == 3;
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
     wave_lds_sync();
     float sum_pre = 0.f;
     for (int i = 0; i < top_k; ++i) {
-      if (hit[i] != 0) sum_pre += s_pre[wave][i];
+      if (hit[i] != 0) sum_pre += s_pre[i];
       if ((i & (NR_WAVE - 1)) == lane) sum_k[i >> 6] = sum_pre;
     }
   }
@@ -604,6 +610,26 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
       o[k] = val;
     }
   }
+}
+
+
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void metrics_kernel(
+    const int32_t* __restrict__ rank, int rows, int top_k, const int32_t* __restrict__ users,
+    const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices, MetricIds mids,
+    InvLog2Table tbl, float* __restrict__ out, int32_t* __restrict__ topk_out,
+    const uint64_t* __restrict__ tie_mask, int32_t* __restrict__ flag_io) {
+  __shared__ unsigned char s_hit[kSelWaves][128];
+  __shared__ float s_pre[kSelWaves][128];
+  __shared__ int32_t s_truth[kSelWaves][kMetricsTruthLds];
+  const int wave = threadIdx.x / NR_WAVE;
+  const int lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  const int n_rank = top_k + (tie_mask ? 1 : 0);
+  const int32_t* rank_row = rank + (int64_t)row * kRankStride;
+  const int32_t item0 = lane < n_rank ? rank_row[lane] : 0;
+  metrics_row(rank_row, item0, row, lane, top_k, tie_mask != nullptr, tie_mask ? tie_mask[row] : 0ull, users, t_indptr,
+              t_indices, mids, tbl, out, topk_out, flag_io, s_hit[wave], s_pre[wave], s_truth[wave]);
 }
 
 // limit > 0: ids outside [0, limit) become 0.  The pruned evaluation's tile ids: a row without a single comparable
@@ -1010,7 +1036,12 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
     const int64_t* __restrict__ tr_indptr, const int32_t* __restrict__ tr_indices,
     const int32_t* __restrict__ tilemap, const int32_t* __restrict__ tiles, int tiles_ld,
     const float* __restrict__ M, int64_t mld, const float* __restrict__ eps, const int32_t* __restrict__ overflow,
-    int32_t* __restrict__ rank, uint64_t* __restrict__ tie_mask, int32_t* __restrict__ flag_out) {
+    int32_t* __restrict__ flag_out, const int64_t* __restrict__ t_indptr, const int32_t* __restrict__ t_indices,
+    MetricIds mids, InvLog2Table tbl, float* __restrict__ out) {
+  // (the ranks and the tie mask never leave the wave: the row's metrics are formed here, metrics_row)
+  __shared__ unsigned char s_hit[kSelWaves][128];
+  __shared__ float s_pre[kSelWaves][128];
+  __shared__ int32_t s_truth[kSelWaves][kMetricsTruthLds];
   __shared__ int32_t s_map[kSelWaves][NR_WAVE];
   __shared__ uint32_t s_strike[kSelWaves][NR_WAVE];
   __shared__ uint64_t s_keys[kSelWaves][NR_WAVE];
@@ -1083,7 +1114,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
     }
   }
   if (c_n > NR_WAVE) {                                        // wave-uniform: a tie group beyond one key per lane
-    if (lane == 0) { flag_out[row] = 1; tie_mask[row] = ~0ull; }
+    if (lane == 0) flag_out[row] = 1;                         // (the row is redone from a full score row)
+    for (int e = lane; e < mids.n * top_k; e += NR_WAVE) out[(int64_t)row * mids.n * top_k + e] = 0.f;
     return;
   }
   wave_lds_sync();
@@ -1092,14 +1124,14 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
   const int n_out = min(cut, c_n);
   const bool tie = lane < n_out && next != 0ull && nr::key_order(mine) == nr::key_order(next);
   const uint64_t tmask = __ballot(tie);
+  int32_t item = -1;                                          // (no item: never a test item)
   if (lane < n_out) {
     const int col = (int)nr::key_index(mine);
-    rank[(int64_t)row * kRankStride + lane] = s_map[wave][col / kTileItems] * kTileItems + col % kTileItems;
+    item = s_map[wave][col / kTileItems] * kTileItems + col % kTileItems;
   }
   // the score of the top_k-th best, from its key (the order word is a bijection on the scores; -0 reads as +0)
   const uint32_t ok_lo = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), top_k - 1);
   if (lane == 0) {
-    tie_mask[row] = tmask;
     const float inside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep - 1]];
     const float outside = M[(int64_t)row * mld + tiles[(int64_t)row * tiles_ld + n_keep]];
     int flag;
@@ -1114,6 +1146,9 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
     if (overflow && overflow[row]) flag |= 1;
     flag_out[row] = flag;
   }
+  // 5. the metrics of the row (lane 0 ORs bit 0 into the flag it has just written when a tie could change one)
+  metrics_row(nullptr, item, row, lane, top_k, true, tmask, users, t_indptr, t_indices, mids, tbl, out, nullptr,
+              flag_out, s_hit[wave], s_pre[wave], s_truth[wave]);
 }
 
 // column sums in fp64: stage 1 sums 256-row slabs, stage 2 adds the slabs in
@@ -1152,6 +1187,47 @@ __global__ void colsum_stage2(const double* __restrict__ partial, int n_slabs, i
   }
   for (; s < n_slabs; ++s) acc += partial[(int64_t)s * cols + c];
   out[c] = acc;
+}
+
+// colsum_stage2 with one more workgroup (the last) that counts the flagged rows next to the sums: flag_out[0] <- rows
+// with a flag, flag_out[1] <- rows among them whose certificate failed (flag bit 1), as doubles — one device->host copy
+// brings sums and counts (r06: a count_flags launch did this after the sums, 6 us + a launch gap)
+__global__ __launch_bounds__(256) void colsum_stage2_flags(const double* __restrict__ partial, int n_slabs, int cols,
+                                                           double* __restrict__ out, const int32_t* __restrict__ flags,
+                                                           int n, double* __restrict__ flag_out) {
+  if (blockIdx.x + 1 < gridDim.x) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double acc = 0.0;
+    int s = 0;
+    for (; s + 16 <= n_slabs; s += 16) {             // (colsum_stage2's order: slab after slab)
+      double v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = partial[(int64_t)(s + i) * cols + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc += v[i];
+    }
+    for (; s < n_slabs; ++s) acc += partial[(int64_t)s * cols + c];
+    out[c] = acc;
+    return;
+  }
+  __shared__ int s_part[256], s_cert[256];
+  int c = 0, k = 0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {          // 8 loads in flight per thread
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < n ? flags[i0 + u * 256] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { c += v[u] != 0 ? 1 : 0; k += (v[u] & 2) ? 1 : 0; }
+  }
+  s_part[threadIdx.x] = c;
+  s_cert[threadIdx.x] = k;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) { s_part[threadIdx.x] += s_part[threadIdx.x + st]; s_cert[threadIdx.x] += s_cert[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { flag_out[0] = (double)s_part[0]; flag_out[1] = (double)s_cert[0]; }
 }
 
 struct EvalWs {
@@ -1195,10 +1271,12 @@ int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sor
   const bool vec4 = (ld % 4 == 0) && (((uintptr_t)d_scores) % 16 == 0);
   if (vec4)
     hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st,
-                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag, (uint64_t*)nullptr);
+                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag, (uint64_t*)nullptr,
+                       (int64_t)kRankStride, 0, (int32_t*)nullptr, 0);
   else
     hipLaunchKernelGGL(select_rows_kernel<1>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st,
-                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag, (uint64_t*)nullptr);
+                       d_scores, ld, rows, cols, sort_len, cut, w.rank, w.flag, (uint64_t*)nullptr,
+                       (int64_t)kRankStride, 0, (int32_t*)nullptr, 0);
   NR_LAUNCH_CHECK();
   hipLaunchKernelGGL(exact_rows_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_scores,
                      ld, rows, cols, sort_len, cut, w.rank, w.flag, w.n_exact);
@@ -1486,19 +1564,19 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   const int64_t cld = (int64_t)n_keep * kTileItems;
   // 1. the top_k + 2 largest tile maxima per user (their order among equal maxima is irrelevant)
   const int blocks = (rows + kSelWaves - 1) / kSelWaves;
+  // (the grouped forms' tile counters lead their part of the workspace: this launch clears them on its way in)
+  int32_t* const gcnt0 = form != kGroupedNone ? (int32_t*)((char*)d_ws + eval_tiles_ws_bytes(rows, n_keep)) : nullptr;
+  const int gcnt0_n = form == kGroupedStrided ? n_tiles + rows : form == kGroupedCompact ? 2 * n_tiles : 0;
   if ((mld % 4 == 0) && (((uintptr_t)d_M) % 16 == 0))
     hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
-                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag, (uint64_t*)nullptr);
+                       mld, rows, n_tiles, tiles_ld, tiles_ld, tiles, w.flag, (uint64_t*)nullptr, (int64_t)tiles_ld, 1,
+                       gcnt0, gcnt0_n);
   else
     hipLaunchKernelGGL(select_rows_kernel<1>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
-                       mld, rows, n_tiles, tiles_ld, tiles_ld, w.rank, w.flag, (uint64_t*)nullptr);
+                       mld, rows, n_tiles, tiles_ld, tiles_ld, tiles, w.flag, (uint64_t*)nullptr, (int64_t)tiles_ld, 1,
+                       gcnt0, gcnt0_n);
   NR_LAUNCH_CHECK();
-  {
-    const int64_t n = (int64_t)rows * tiles_ld;
-    hipLaunchKernelGGL(copy_rank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.rank,
-                       rows, tiles_ld, tiles, n_tiles);
-    NR_LAUNCH_CHECK();
-  }
+  // (straight into the tile lists, unfilled slots zeroed: r06 — a copy_rank launch did both before)
   // 2. rescore the chosen tiles, train items struck out
   int32_t* overflow = nullptr;
   if (form != kGroupedNone) {
@@ -1513,7 +1591,6 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
       chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
       chunks = (int4*)x;         x += nr_align_up(max_chunks * 16, 256);
       bucket = (uint32_t*)x;
-      NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, ((size_t)n_tiles + rows) * 4, st));
       hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
                          (size_t)n_tiles * 4, st, tiles, tiles_ld, n_keep, rows, n_tiles, tilemap,
                          gcnt, bucket, overflow);
@@ -1529,7 +1606,6 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
       chunks = (int4*)x;         x += nr_align_up(max_chunks * 16, 256);
       bucket = (uint32_t*)x;
       const dim3 wg((rows + kPairRows - 1) / kPairRows);
-      NR_CHECK_HIP(hipMemsetAsync(gcnt, 0, 2 * (size_t)n_tiles * 4, st));
       hipLaunchKernelGGL(tile_count_kernel, wg, dim3(256), 0, st, tiles, tiles_ld, n_keep, rows, n_tiles, gcnt);
       NR_LAUNCH_CHECK();
       // (a packed bucket holds every pair of its tile: no cap, no overflow rows)
@@ -1562,18 +1638,23 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
                        d_tr_indices, C, cld, tilemap);
     NR_LAUNCH_CHECK();
   }
+  InvLog2Table tbl;
+  for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));
   if (form != kGroupedNone) {
-    // 3 + 4 in one launch: strikes, ranking of the compact rows, columns -> item ids, boundary check, flags
+    // 3 + 4 + 5 in one launch: strikes, ranking of the compact rows, columns -> item ids, boundary check, flags, and the
+    // metrics from the ranks while they are still in the wave's registers (r06: metrics_kernel was 21 us + a launch gap)
     hipLaunchKernelGGL(rank_compact_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld, rows, n_keep, top_k,
-                       d_users, d_tr_indptr, d_tr_indices, tilemap, tiles, tiles_ld, d_M, mld, d_eps, overflow, w.rank,
-                       tmask, d_flag_out);
+                       d_users, d_tr_indptr, d_tr_indices, tilemap, tiles, tiles_ld, d_M, mld, d_eps, overflow,
+                       d_flag_out, d_truth_indptr, d_truth_indices, mids, tbl, d_out);
     NR_LAUNCH_CHECK();
+    return NR_OK;
   } else {
     // 3. rank the compact rows (no in-place exact path: a tie needs the full row)
     const int ccols = (int)cld;
     const int sort_len = (2 * top_k < ccols) ? 2 * top_k : ccols;
     hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld,
-                       rows, ccols, sort_len, top_k + 1, w.rank, w.flag, tmask);   // (one item beyond the cut: the tie rule)
+                       rows, ccols, sort_len, top_k + 1, w.rank, w.flag, tmask,    // (one item beyond the cut: the tie rule)
+                       (int64_t)kRankStride, 1, (int32_t*)nullptr, 0);    // (unranked slots: column 0, a NaN row's)
     NR_LAUNCH_CHECK();
     // 4. columns -> item ids, boundary check, flags
     hipLaunchKernelGGL(remap_rank_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, w.rank, w.flag,
@@ -1582,8 +1663,6 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
     NR_LAUNCH_CHECK();
   }
   // 5. metrics
-  InvLog2Table tbl;
-  for (int i = 0; i < 128; ++i) tbl.v[i] = 1.0 / log2((double)(unsigned)(i + 2));
   hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, w.rank, rows,
                      top_k, d_users, d_truth_indptr, d_truth_indices, mids, tbl, d_out,
                      (int32_t*)nullptr, tmask, d_flag_out);
@@ -1670,3 +1749,23 @@ int nrhip_colsum_f64(const float* d_mat, int64_t ld, int rows, int cols, double*
 }
 
 }  // extern "C"
+
+// nrhip_colsum_f64 + the flagged-row counts of the pruned evaluation in its second launch (eval_pipeline.hip)
+__attribute__((visibility("hidden"))) int nr_colsum_f64_flags(const float* d_mat, int64_t ld, int rows, int cols,
+                                                              double* d_out, void* d_ws, size_t ws_bytes,
+                                                              const int32_t* d_flags, double* d_flag_out, void* stream) {
+  NR_REQUIRE(d_mat && d_out && d_ws && ld >= cols && rows >= 1 && cols >= 1 && d_flags && d_flag_out, NR_ERR_ARG,
+             "colsum_f64_flags: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int n_slabs = (rows + kSlabRows - 1) / kSlabRows;
+  NR_REQUIRE(ws_bytes >= (size_t)n_slabs * cols * sizeof(double), NR_ERR_WORKSPACE,
+             "colsum_f64_flags: workspace too small");
+  hipLaunchKernelGGL(colsum_stage1, dim3((cols + 63) / 64, n_slabs), dim3(256), 0, st, d_mat, ld, rows, cols,
+                     (double*)d_ws);
+  NR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_stage2_flags, dim3((cols + 255) / 256 + 1), dim3(256), 0, st, (const double*)d_ws, n_slabs,
+                     cols, d_out, d_flags, rows, d_flag_out);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+

@@ -43,11 +43,14 @@ class _RcclDirect:
               torch.float64: 8}
 
     def __init__(self, rank, world):
+        """loads librccl and, on rank 0, draws the unique id: LOCAL work only — connect() holds the collective part, so
+        that Comm._rccl_direct can make every rank agree on the outcome of each half (a rank that fell back to the
+        process group while the others issue on this communicator would hang the job)"""
         import ctypes as C
 
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_char * 128)]
-        self._C = C
+        self._C, self.rank, self.world, self.comm = C, int(rank), int(world), None
         self.lib = lib = C.CDLL(os.environ.get("NEUREC_RCCL_LIB", "librccl.so"))
         lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
         lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
@@ -56,16 +59,39 @@ class _RcclDirect:
         lib.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
-        uid = UniqueId()
-        if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+        self._uid = UniqueId()
+        if self.rank == 0 and lib.ncclGetUniqueId(C.byref(self._uid)) != 0:
             raise RuntimeError("ncclGetUniqueId failed")
-        raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().cuda()
-        dist.broadcast(raw, src=0)                                # (the process group exists: backend nccl)
-        C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+
+    def uid_bytes(self):
+        return bytes(self._uid)
+
+    def connect(self, uid_bytes):
+        """collective: every rank calls it with rank 0's id"""
+        C = self._C
+        C.memmove(C.byref(self._uid), uid_bytes, 128)
         self.comm = C.c_void_p()
-        rc = lib.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank))
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), self.world, self._uid, self.rank)
         if rc != 0:
+            self.comm = None
             raise RuntimeError("ncclCommInitRank failed with %d" % rc)
+
+    def self_check(self):
+        """one tiny call of each entry point against the answer it must give (the dtype codes, the argument order and
+        the in-place form are this file's reading of rccl.h: a library that disagrees shows here, not in a table)"""
+        w, r, dev = self.world, self.rank, torch.device("cuda", torch.cuda.current_device())
+        got = torch.empty(w, dtype=torch.int32, device=dev)
+        self.all_gather(torch.full((1,), r, dtype=torch.int32, device=dev), got)
+        s64 = torch.full((3,), float(r + 1), dtype=torch.float64, device=dev)
+        self.all_reduce_sum(s64)
+        send = (torch.arange(w, dtype=torch.float32, device=dev) + r * w).reshape(w, 1).repeat(1, 4).contiguous()
+        recv = torch.empty_like(send)
+        self.all_to_all_rows(send, [1] * w, recv, [1] * w)
+        torch.cuda.current_stream().synchronize()
+        want = torch.arange(w, dtype=torch.float32) * w + r
+        if not (got.cpu().tolist() == list(range(w)) and s64.cpu().tolist() == [w * (w + 1) / 2.0] * 3
+                and torch.equal(recv.cpu(), want.reshape(w, 1).repeat(1, 4))):
+            raise RuntimeError("the direct communicator's self-check returned wrong values")
 
     def all_gather(self, local, out):
         C = self._C
@@ -128,16 +154,41 @@ class Comm:
         self._direct, self._direct_tried = None, False       # the RCCL communicator of all_gather_rows (made on first use)
 
     def _rccl_direct(self):
-        """librccl on the compute stream for the blocking all-gather (backend nccl; NEUREC_RCCL_DIRECT=0: torch's)"""
+        """librccl on the compute stream for the blocking collectives (backend nccl; NEUREC_RCCL_DIRECT=0: torch's).
+        COLLECTIVE on first use: after each half of the set-up (library loaded / communicator connected and its
+        self-check passed) the ranks take the minimum of their outcomes through the process group, so that either every
+        rank issues on the direct communicator or none does."""
         if not self._direct_tried:
             self._direct_tried = True
             if self.backend == "nccl" and os.environ.get("NEUREC_RCCL_DIRECT", "1") != "0" and dist.is_initialized():
+                import sys
+                dev = torch.device("cuda", torch.cuda.current_device())
+
+                def agreed(ok):
+                    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    return bool(flag.item())
+                d, why = None, ""
                 try:
-                    self._direct = _RcclDirect(self.rank, self.world)
-                except Exception as e:                       # torch.distributed stays in charge
-                    import sys
-                    sys.stderr.write("neurec_amd.parallel: direct RCCL all-gather unavailable (%s: %s), using "
-                                     "torch.distributed\n" % (type(e).__name__, e))
+                    d = _RcclDirect(self.rank, self.world)
+                except Exception as e:
+                    why = "%s: %s" % (type(e).__name__, e)
+                if agreed(d is not None):
+                    raw = torch.frombuffer(bytearray(d.uid_bytes()), dtype=torch.uint8).clone().to(dev)
+                    dist.broadcast(raw, src=0)
+                    ok = True
+                    try:
+                        d.connect(raw.cpu().numpy().tobytes())
+                        d.self_check()
+                    except Exception as e:
+                        ok, why = False, "%s: %s" % (type(e).__name__, e)
+                    if agreed(ok):
+                        self._direct = d
+                    else:
+                        d.close()
+                if self._direct is None:                     # torch.distributed stays in charge
+                    sys.stderr.write("neurec_amd.parallel: direct RCCL collectives unavailable (%s), using "
+                                     "torch.distributed\n" % (why or "another rank could not set them up"))
         return self._direct
 
     @property
