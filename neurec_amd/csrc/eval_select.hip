@@ -1164,7 +1164,14 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ m
   const int r1 = min(rows, r0 + kSlabRows);
   double acc = 0.0;
   if (c < cols)
-    for (int r = r0 + g; r < r1; r += 4) acc += (double)mat[(int64_t)r * ld + c];
+    for (int r = r0 + g; r < r1; r += 4 * 8) {       // 8 rows in flight, added in row order (one load per add was a
+      float v[8];                                    // chain of 64 memory round trips: 17.5 us for 29,858 x 100)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = r + 4 * i < r1 ? mat[(int64_t)(r + 4 * i) * ld + c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (r + 4 * i < r1) acc += (double)v[i];
+    }
   s_part[g][threadIdx.x & 63] = acc;
   __syncthreads();
   if (g == 0 && c < cols)
@@ -1192,9 +1199,9 @@ __global__ void colsum_stage2(const double* __restrict__ partial, int n_slabs, i
 // colsum_stage2 with one more workgroup (the last) that counts the flagged rows next to the sums: flag_out[0] <- rows
 // with a flag, flag_out[1] <- rows among them whose certificate failed (flag bit 1), as doubles — one device->host copy
 // brings sums and counts (r06: a count_flags launch did this after the sums, 6 us + a launch gap)
-__global__ __launch_bounds__(256) void colsum_stage2_flags(const double* __restrict__ partial, int n_slabs, int cols,
-                                                           double* __restrict__ out, const int32_t* __restrict__ flags,
-                                                           int n, double* __restrict__ flag_out) {
+__global__ __launch_bounds__(1024) void colsum_stage2_flags(const double* __restrict__ partial, int n_slabs, int cols,
+                                                            double* __restrict__ out, const int32_t* __restrict__ flags,
+                                                            int n, double* __restrict__ flag_out) {
   if (blockIdx.x + 1 < gridDim.x) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
@@ -1211,19 +1218,19 @@ __global__ __launch_bounds__(256) void colsum_stage2_flags(const double* __restr
     out[c] = acc;
     return;
   }
-  __shared__ int s_part[256], s_cert[256];
+  __shared__ int s_part[1024], s_cert[1024];
   int c = 0, k = 0;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {          // 8 loads in flight per thread
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {         // 8 loads in flight per thread
     int v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < n ? flags[i0 + u * 256] : 0;
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < n ? flags[i0 + u * 1024] : 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) { c += v[u] != 0 ? 1 : 0; k += (v[u] & 2) ? 1 : 0; }
   }
   s_part[threadIdx.x] = c;
   s_cert[threadIdx.x] = k;
   __syncthreads();
-  for (int st = 128; st >= 1; st >>= 1) {
+  for (int st = 512; st >= 1; st >>= 1) {
     if ((int)threadIdx.x < st) { s_part[threadIdx.x] += s_part[threadIdx.x + st]; s_cert[threadIdx.x] += s_cert[threadIdx.x + st]; }
     __syncthreads();
   }
@@ -1763,7 +1770,7 @@ __attribute__((visibility("hidden"))) int nr_colsum_f64_flags(const float* d_mat
   hipLaunchKernelGGL(colsum_stage1, dim3((cols + 63) / 64, n_slabs), dim3(256), 0, st, d_mat, ld, rows, cols,
                      (double*)d_ws);
   NR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_stage2_flags, dim3((cols + 255) / 256 + 1), dim3(256), 0, st, (const double*)d_ws, n_slabs,
+  hipLaunchKernelGGL(colsum_stage2_flags, dim3((cols + 1023) / 1024 + 1), dim3(1024), 0, st, (const double*)d_ws, n_slabs,
                      cols, d_out, d_flags, rows, d_flag_out);
   NR_LAUNCH_CHECK();
   return NR_OK;

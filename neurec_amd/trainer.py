@@ -530,15 +530,25 @@ class FullRankEvaluator:
         nm = len(self.metric_ids)
         if self._gemm is None or self._gemm.cols != item_table.shape[0] or \
                 self._gemm.d != item_table.shape[1]:
-            self._gemm = E.score_gemm_for(item_table, self.batch_rows)
+            self._gemm = E.score_gemm_for(item_table, self.batch_rows)       # (loads the item side itself)
             # score slabs [slab_rows][I]: the materialised path's batch, the pruned path's redo rows — made when first
             # needed, and never wider than 1 GiB (at 10^6 items a batch_rows slab would be 32 GB for rows that are
             # almost never redone)
             self._scores = []
             self._filter = None
+            self._gemm_stale = False
         else:
-            self._gemm.prepare(item_table)
-        per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
+            # the scoring engine still holds the previous table's item copies: reloaded by whoever scores first — the
+            # native pruned evaluation does it inside its one call (r06: a Python-level launch here, another for the
+            # filter, then the native call left the device idle between them: 0.71 ms where the launches take 0.64)
+            self._gemm_stale = True
+        if want_rows or exact_mean or getattr(self, "_rows_buf", None) is None or \
+                self._rows_buf.shape != (n, nm * self.top_k) or self._rows_buf.device != test_users.device:
+            per_user = torch.empty((n, nm * self.top_k), dtype=torch.float32, device=test_users.device)
+            if not (want_rows or exact_mean):
+                self._rows_buf = per_user                 # (the sums-only form: the rows never leave this object)
+        else:
+            per_user = self._rows_buf
         self._flags, self.n_flagged, self.n_uncertified, self._native_sums = None, 0, 0, None
         self._n_rows, self._search_macs = n, float(n) * item_table.shape[0] * item_table.shape[1]
         cols = item_table.shape[0]
@@ -547,6 +557,7 @@ class FullRankEvaluator:
                 not getattr(self._gemm, "wide", False):
             self._evaluate_pruned(user_table, item_table, test_users, per_user, starts)
         elif not self.overlap or len(starts) < 2:
+            self._reload_items(item_table)
             for b in starts:
                 u = test_users[b:b + self.batch_rows]
                 S = self._gemm(user_table, u, out=self._slab(0, self.batch_rows))
@@ -556,6 +567,7 @@ class FullRankEvaluator:
         else:
             # two score slabs, two HIP streams: GEMM + mask of batch b+1 on the current stream,
             # top-K + metrics of batch b on the side stream; events order the slab hand-offs
+            self._reload_items(item_table)
             self._slab(0, self.batch_rows)
             self._slab(1, self.batch_rows)
             if self._side is None:
@@ -585,7 +597,13 @@ class FullRankEvaluator:
         # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
         # travel together; only if some row was flagged are those rows redone and the sums retaken
         if self._native_sums is not None:                 # nrhip_eval_pruned left the sums and the flag count together
-            both = self._native_sums.cpu().numpy()
+            host = getattr(self, "_sums_host", None)
+            if host is None or host.shape != self._native_sums.shape:
+                host = self._sums_host = torch.empty(self._native_sums.shape, dtype=self._native_sums.dtype,
+                                                     pin_memory=True)
+            host.copy_(self._native_sums, non_blocking=True)     # (pinned: no staging copy behind the device's)
+            torch.cuda.current_stream().synchronize()
+            both = host.numpy().copy()
             self._native_sums = None
         else:
             sums = E.colsum(per_user)
@@ -600,6 +618,12 @@ class FullRankEvaluator:
             self._redo_flagged(user_table, item_table, test_users, per_user)
             return E.colsum(per_user).cpu().numpy() / div
         return both[:-2] / div
+
+    def _reload_items(self, item_table):
+        """the scoring engine's item copies, if they are still the previous table's"""
+        if getattr(self, "_gemm_stale", False):
+            self._gemm.prepare(item_table)
+            self._gemm_stale = False
 
     def _slab(self, k, rows):
         """score slab k with room for `rows` rows"""
@@ -664,12 +688,20 @@ class FullRankEvaluator:
         if arith != "fp32" and use_plan and E.ScoreFilter.supports(item_table.shape[1], arith) and n_keep > self.top_k:
             if self._filter is None:
                 self._filters = {}                            # (a new scoring engine: new table shape)
-            if arith not in self._filters:                    # both forms stay built: a paused int8 comes back
-                self._filters[arith] = E.ScoreFilter(item_table, self.batch_rows, arith)
-            else:
-                self._filters[arith].prepare(item_table)
+            filt_stale = arith in self._filters               # both forms stay built: a paused int8 comes back
+            if not filt_stale:
+                self._filters[arith] = E.ScoreFilter(item_table, self.batch_rows, arith)     # (loads the item side itself)
             filt = self._filter = self._filters[arith]
+        else:
+            filt_stale = False
         self.search_used = filt.arith if filt is not None else "fp32"
+        # the item side of both engines inside the native call when both are stale (the steady state); else from here
+        native = use_plan and self.native_loop
+        inside = native and self._gemm_stale and (filt is None or filt_stale)
+        if not inside:
+            self._reload_items(item_table)
+            if filt is not None and filt_stale:
+                filt.prepare(item_table)
         if use_plan and self.native_loop:
             # the whole batch loop, the column sums and the flagged-row count in one native call (nrhip_eval_pruned)
             keep = n_keep if filt is not None else self.top_k + 1
@@ -683,7 +715,8 @@ class FullRankEvaluator:
                                                        self.top_k, keep, self.batch_rows)
                 self._native, self._native_key = cache[1][key], key
             _, _, self._native_sums = self._native.run(user_table, item_table, test_users, row_of, per_user, flags,
-                                                       prepare_items=False)
+                                                       prepare_items=inside)
+            self._gemm_stale = False
             self._flags = flags
             return
         self._native_sums = None
@@ -704,6 +737,7 @@ class FullRankEvaluator:
         """Rows whose ranking could depend on ties: recomputed from full score rows."""
         if self._flags is None:
             return
+        self._reload_items(item_table)
         cols = item_table.shape[0]
         redo = torch.nonzero(self._flags, as_tuple=False).flatten()      # host sync: only when rows were flagged
         self.n_uncertified = int(((self._flags & 2) != 0).sum()) if redo.numel() else 0
