@@ -223,7 +223,9 @@ typedef struct nrhip_eval_pruned_args {
   const int64_t* d_tile_ptr; const int32_t* d_plan_user; const uint32_t* d_plan_mask;
   const int32_t* d_row_of;                       /* user -> evaluation row (-1: not evaluated) */
   const int32_t* metric_ids; int n_metric, top_k, n_keep;
-  int use_filter, prepare_items;                 /* bounded search: 0 none, 1 bf16, 2 int8 (d_filter_ws of that form) / (re)build the item-side copies first */
+  int use_filter, prepare_items;                 /* bounded search: 0 none, 1 bf16, 2 int8 (d_filter_ws of that form) / (re)build the item-side copies first:
+                                                  * 1 all of them; 2 (with a filter) all but the fp32 scoring loop's operand copy, which this call does not read —
+                                                  * nrhip_score_gemm_prepare_items must run before nrhip_score_gemm / nrhip_score_tilemax use that workspace */
   void* d_gemm_ws; size_t gemm_ws_bytes;         /* nrhip_score_gemm_workspace_bytes(batch_rows, cols, d) */
   void* d_filter_ws; size_t filter_ws_bytes;     /* nrhip_score_filter_workspace_bytes(batch_rows, cols, d) */
   void* d_tiles_ws; size_t tiles_ws_bytes;       /* nrhip_eval_tiles_bounded_workspace_bytes(batch_rows, cols, top_k, n_keep) */

@@ -9,6 +9,8 @@
 
 // eval_select.hip: the column sums with the flagged-row counts formed in their second launch — out[cols] <- rows with
 // a flag, out[cols + 1] <- the rows among them whose certificate failed (flag bit 1), as doubles next to the sums
+int nr_score_gemm_prepare_items_kmajor(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws, size_t ws_bytes,
+                                       void* stream);                                           // score_gemm.hip
 int nr_colsum_f64_flags(const float* d_mat, int64_t ld, int rows, int cols, double* d_out, void* d_ws, size_t ws_bytes,
                         const int32_t* d_flags, double* d_flag_out, void* stream);
 
@@ -28,8 +30,14 @@ int nrhip_eval_pruned(const NrhipEvalPruned* a, void* stream) {
   NR_REQUIRE(a->use_filter >= 0 && a->use_filter <= 2, NR_ERR_ARG, "eval_pruned: use_filter is 0 (exact maxima), 1 (bf16) or 2 (int8)");
   NR_REQUIRE(a->use_filter || a->n_keep == a->top_k + 1, NR_ERR_ARG,
              "eval_pruned: exact maxima take n_keep = top_k + 1");
+  NR_REQUIRE(a->prepare_items >= 0 && a->prepare_items <= 2 && (a->prepare_items != 2 || a->use_filter), NR_ERR_ARG,
+             "eval_pruned: prepare_items is 0, 1, or 2 (2 with a filter only)");
   if (a->prepare_items) {
-    NR_TRY(nrhip_score_gemm_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_gemm_ws, a->gemm_ws_bytes, stream));
+    // 2: without the fp32 scoring loop's operand copy — nothing in this call reads it when a filter searches
+    if (a->prepare_items == 2)
+      NR_TRY(nr_score_gemm_prepare_items_kmajor(a->d_Q, a->ldq, a->cols, a->d, a->d_gemm_ws, a->gemm_ws_bytes, stream));
+    else
+      NR_TRY(nrhip_score_gemm_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_gemm_ws, a->gemm_ws_bytes, stream));
     if (a->use_filter == 2)
       NR_TRY(nrhip_score_filter_i8_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_filter_ws, a->filter_ws_bytes,
                                                  a->batch_rows, stream));

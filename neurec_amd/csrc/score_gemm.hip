@@ -555,6 +555,26 @@ int nrhip_score_gemm_prepare_items(const float* d_Q, int64_t ldq, int cols, int 
   return NR_OK;
 }
 
+}  // extern "C"
+// nrhip_score_gemm_prepare_items without the scoring loop's operand-ordered copy: the k-major copy is all the pruned
+// evaluation reads when a bounded filter does the search (the fix-up and the rescoring; eval_pipeline.hip) — whoever
+// scores with the fp32 loop afterwards (rows redone from full score rows) reloads the item side in full first
+__attribute__((visibility("hidden"))) int nr_score_gemm_prepare_items_kmajor(const float* d_Q, int64_t ldq, int cols,
+                                                                             int d, void* d_ws, size_t ws_bytes,
+                                                                             void* stream) {
+  NR_REQUIRE(d_Q && d_ws && cols >= 1 && d >= 1 && ldq >= d, NR_ERR_ARG, "score_gemm_prepare_items: bad arguments");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_gemm: embedding dim %d > 128 not built", d);
+  GemmWs g = carve(d_ws, 0, cols, dp);
+  NR_REQUIRE(ws_bytes >= g.qt_bytes, NR_ERR_WORKSPACE, "score_gemm_prepare_items: workspace small");
+  const int ipad = round_up64(cols);
+  hipLaunchKernelGGL(gather_transpose_kernel, dim3(ipad / 64, (dp + 63) / 64), dim3(256), 0, (hipStream_t)stream, d_Q,
+                     ldq, (const int32_t*)nullptr, cols, d, g.QT, ipad, dp);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
+extern "C" {
+
 int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,
                      int d, float* d_S, int64_t lds, void* d_ws, size_t ws_bytes, void* stream) {
   NR_REQUIRE(d_P && d_S && d_ws && cols >= 1 && d >= 1 && ldp >= d && lds >= cols && rows >= 0,

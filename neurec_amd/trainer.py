@@ -652,7 +652,9 @@ class FullRankEvaluator:
         n = test_users.numel()
         # (every row's flag is WRITTEN by level 2 — remap_rank_kernel — so no fill: in steady state an evaluation
         #  launches nothing but this package's kernels; `torch.unique` / the user -> row table below run once per user list)
-        flags = torch.empty(n, dtype=torch.int32, device=test_users.device)
+        flags = getattr(self, "_flags_buf", None)             # (read back before the next evaluation writes it)
+        if flags is None or flags.numel() != n or flags.device != test_users.device:
+            flags = self._flags_buf = torch.empty(n, dtype=torch.int32, device=test_users.device)
         self.n_flagged = 0
         plan = row_of = None
         use_plan = self.strike_plan
@@ -714,9 +716,12 @@ class FullRankEvaluator:
                     cache[1][key] = E.PrunedEvaluation(self._gemm, filt, plan, self.train, self.test, self.metric_ids,
                                                        self.top_k, keep, self.batch_rows)
                 self._native, self._native_key = cache[1][key], key
+            # (with a filter the call leaves the fp32 scoring loop's operand copy alone — 2 — and the engine stays
+            #  stale: rows redone from full score rows reload it first, _reload_items)
             _, _, self._native_sums = self._native.run(user_table, item_table, test_users, row_of, per_user, flags,
-                                                       prepare_items=inside)
-            self._gemm_stale = False
+                                                       prepare_items=(2 if filt is not None else 1) if inside else 0)
+            if not (inside and filt is not None):
+                self._gemm_stale = False
             self._flags = flags
             return
         self._native_sums = None
