@@ -238,6 +238,26 @@ typedef struct nrhip_eval_pruned_args {
 } NrhipEvalPruned;
 int nrhip_eval_pruned(const NrhipEvalPruned* args, void* stream);
 
+/* The rows nrhip_eval_pruned flagged (ties that could change a metric, a certificate that did not hold, a full bucket),
+ * ranked again from full fp32 score rows — nrhip_score_gemm + nrhip_mask_train + nrhip_eval_scores, the materialised
+ * path, exact whatever the cause (uni_evaluator.py:132-151 -> evaluate.h:23-72) — and written over their rows of
+ * ev->d_out, then (ev->d_sums != NULL) the column sums again: one call, no host round trip inside.  n_flagged is the
+ * count nrhip_eval_pruned left in d_sums[n_metric*top_k] (the caller has read it); ev is that call's argument block,
+ * unchanged.  The rows are collected in whatever order the device finds them (every row is independent). */
+typedef struct nrhip_eval_redo_args {
+  const NrhipEvalPruned* ev;
+  int n_flagged;
+  int reload_items;                              /* the fp32 scoring loop's item side first: 1 nrhip_score_gemm_prepare_items; 2 its operand
+                                                  * copy only (ev ran with prepare_items = 2 on this table: the k-major copy stands) */
+  float* d_scores; int64_t lds; int slab_rows;   /* score slab [slab_rows][lds], lds >= roundup(cols, 64), slab_rows <= ev->batch_rows */
+  int32_t* d_rows;                               /* [n_flagged] out: the flagged rows */
+  int32_t* d_row_users;                          /* [n_flagged] out: their users */
+  int32_t* d_count;                              /* one word */
+  float* d_fixed;                                /* [slab_rows][n_metric*top_k] */
+  void* d_ws; size_t ws_bytes;                   /* nrhip_eval_workspace_bytes(slab_rows, top_k) */
+} NrhipEvalRedo;
+int nrhip_eval_redo(const NrhipEvalRedo* args, void* stream);
+
 /* ---- sampler ------------------------------------------------------------
  * Replaces: PairwiseSampler.__iter__ = _sampling_negative_items +
  *           DataIterator(shuffle) (data/sampler.py:71-90,198-206;

@@ -128,6 +128,14 @@ class EvalPrunedArgs(C.Structure):
                 ("sums", C.c_void_p), ("colsum_ws", C.c_void_p), ("colsum_ws_bytes", C.c_size_t)]
 
 
+class EvalRedoArgs(C.Structure):
+    """nrhip_eval_redo_args (include/neurec_hip.h)"""
+    _fields_ = [("ev", C.POINTER(EvalPrunedArgs)), ("n_flagged", C.c_int), ("reload_items", C.c_int),
+                ("scores", C.c_void_p), ("lds", C.c_int64), ("slab_rows", C.c_int), ("rows", C.c_void_p),
+                ("row_users", C.c_void_p), ("count", C.c_void_p), ("fixed", C.c_void_p), ("ws", C.c_void_p),
+                ("ws_bytes", C.c_size_t)]
+
+
 # name -> argtypes; every function returns int status except where noted.
 SIGNATURES = {
     "nrhip_device_info": [C.POINTER(i32), C.POINTER(i32), psz, C.c_char_p, i32],
@@ -156,6 +164,7 @@ SIGNATURES = {
     "nrhip_eval_tiles_bounded_workspace_bytes": [i32, i32, i32, i32, psz],
     "nrhip_eval_tiles_bounded": [p, i64, p, i32, p, i64, p, i32, p, i32, i32, p, p, p, p, p, i32, i32, p, p, p, sz, p],
     "nrhip_eval_pruned": [C.POINTER(EvalPrunedArgs), p],
+    "nrhip_eval_redo": [C.POINTER(EvalRedoArgs), p],
     "nrhip_vae_step": [C.POINTER(VaeStepArgs), p, i32, f32, f32, f32, u64, i32, i32, p],
     "nrhip_score_gemm_items_kmajor": [p, i32, i32, p, p],
     "nrhip_score_gemm": [p, i64, p, i32, i32, i32, p, i64, p, sz, p],

@@ -11,10 +11,90 @@
 // a flag, out[cols + 1] <- the rows among them whose certificate failed (flag bit 1), as doubles next to the sums
 int nr_score_gemm_prepare_items_kmajor(const float* d_Q, int64_t ldq, int cols, int d, void* d_ws, size_t ws_bytes,
                                        void* stream);                                           // score_gemm.hip
+int nr_score_gemm_swizzle_items(int cols, int d, void* d_ws, size_t ws_bytes, void* stream);   // score_gemm.hip
 int nr_colsum_f64_flags(const float* d_mat, int64_t ld, int rows, int cols, double* d_out, void* d_ws, size_t ws_bytes,
                         const int32_t* d_flags, double* d_flag_out, void* stream);
 
+namespace {
+
+// the flagged rows and their users, in whatever order the waves arrive (every row is redone independently)
+__global__ __launch_bounds__(256) void flagged_rows_kernel(const int32_t* __restrict__ flags,
+                                                           const int32_t* __restrict__ users, int n, int cap,
+                                                           int32_t* __restrict__ count, int32_t* __restrict__ rows_out,
+                                                           int32_t* __restrict__ users_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool f = i < n && flags[i] != 0;
+  const unsigned long long m = __ballot(f);
+  if (!m) return;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(count, __popcll(m));   // one reservation per wave
+  base = __shfl(base, leader, 64);
+  if (f) {
+    const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (at < cap) { rows_out[at] = i; users_out[at] = users[i]; }
+  }
+}
+
+// out[rows_idx[r]][:] = fixed[r][:]
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ fixed, int cols,
+                                                           const int32_t* __restrict__ rows_idx, int rows,
+                                                           float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  out[(int64_t)rows_idx[r] * cols + c] = fixed[i];
+}
+
+}  // namespace
+
 extern "C" {
+
+int nrhip_eval_redo(const NrhipEvalRedo* r, void* stream) {
+  NR_REQUIRE(r && r->ev, NR_ERR_ARG, "eval_redo: null argument block");
+  const NrhipEvalPruned* a = r->ev;
+  NR_REQUIRE(a->d_P && a->d_Q && a->d_out && a->d_flags && a->d_users && a->d_gemm_ws && a->d_tr_indptr &&
+                 a->d_tr_indices && a->d_truth_indptr && a->d_truth_indices && a->metric_ids,
+             NR_ERR_ARG, "eval_redo: the evaluation's argument block is incomplete");
+  NR_REQUIRE(r->n_flagged >= 0 && r->n_flagged <= a->n_users, NR_ERR_ARG, "eval_redo: n_flagged=%d outside 0..%d",
+             r->n_flagged, a->n_users);
+  if (r->n_flagged == 0) return NR_OK;
+  NR_REQUIRE(r->d_scores && r->d_rows && r->d_row_users && r->d_count && r->d_fixed && r->d_ws, NR_ERR_ARG,
+             "eval_redo: null buffer");
+  NR_REQUIRE(r->slab_rows >= 1 && r->slab_rows <= a->batch_rows && r->lds >= (a->cols + 63) / 64 * 64, NR_ERR_ARG,
+             "eval_redo: slab of %d rows x %lld (1..%d rows, >= %d columns)", r->slab_rows, (long long)r->lds,
+             a->batch_rows, (a->cols + 63) / 64 * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (r->reload_items == 2)      // the k-major copy is this table's (ev ran with prepare_items = 2): the operand copy only
+    NR_TRY(nr_score_gemm_swizzle_items(a->cols, a->d, a->d_gemm_ws, a->gemm_ws_bytes, stream));
+  else if (r->reload_items)
+    NR_TRY(nrhip_score_gemm_prepare_items(a->d_Q, a->ldq, a->cols, a->d, a->d_gemm_ws, a->gemm_ws_bytes, stream));
+  NR_CHECK_HIP(hipMemsetAsync(r->d_count, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(flagged_rows_kernel, dim3((a->n_users + 255) / 256), dim3(256), 0, st, a->d_flags, a->d_users,
+                     a->n_users, r->n_flagged, r->d_count, r->d_rows, r->d_row_users);
+  NR_LAUNCH_CHECK();
+  const int out_ld = a->n_metric * a->top_k;
+  for (int lo = 0; lo < r->n_flagged; lo += r->slab_rows) {
+    const int rows = r->n_flagged - lo < r->slab_rows ? r->n_flagged - lo : r->slab_rows;
+    const int32_t* users = r->d_row_users + lo;
+    NR_TRY(nrhip_score_gemm(a->d_P, a->ldp, users, rows, a->cols, a->d, r->d_scores, r->lds, a->d_gemm_ws,
+                            a->gemm_ws_bytes, stream));
+    NR_TRY(nrhip_mask_train(r->d_scores, r->lds, users, rows, a->cols, a->d_tr_indptr, a->d_tr_indices, stream));
+    NR_TRY(nrhip_eval_scores(r->d_scores, r->lds, rows, a->cols, users, a->d_truth_indptr, a->d_truth_indices,
+                             a->metric_ids, a->n_metric, a->top_k, r->d_fixed, nullptr, nullptr, r->d_ws, r->ws_bytes,
+                             stream));
+    const int64_t n = (int64_t)rows * out_ld;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r->d_fixed, out_ld,
+                       r->d_rows + lo, rows, a->d_out);
+    NR_LAUNCH_CHECK();
+  }
+  if (a->d_sums) {
+    NR_REQUIRE(a->d_colsum_ws, NR_ERR_ARG, "eval_redo: column sums need their workspace");
+    NR_TRY(nr_colsum_f64_flags(a->d_out, out_ld, a->n_users, out_ld, a->d_sums, a->d_colsum_ws, a->colsum_ws_bytes,
+                               a->d_flags, a->d_sums + out_ld, stream));
+  }
+  return NR_OK;
+}
 
 int nrhip_eval_pruned(const NrhipEvalPruned* a, void* stream) {
   NR_REQUIRE(a, NR_ERR_ARG, "eval_pruned: null argument block");

@@ -573,6 +573,22 @@ __attribute__((visibility("hidden"))) int nr_score_gemm_prepare_items_kmajor(con
   NR_LAUNCH_CHECK();
   return NR_OK;
 }
+// ... and the other half: the operand-ordered copy from a k-major copy that is already this table's (nrhip_eval_redo
+// behind an evaluation that ran with prepare_items = 2)
+__attribute__((visibility("hidden"))) int nr_score_gemm_swizzle_items(int cols, int d, void* d_ws, size_t ws_bytes,
+                                                                      void* stream) {
+  NR_REQUIRE(d_ws && cols >= 1 && d >= 1, NR_ERR_ARG, "score_gemm_swizzle_items: bad arguments");
+  const int dp = padded_dim(d);
+  NR_REQUIRE(dp > 0, NR_ERR_UNSUPPORTED, "score_gemm: embedding dim %d > 128 not built", d);
+  GemmWs g = carve(d_ws, 0, cols, dp);
+  NR_REQUIRE(ws_bytes >= g.qt_bytes, NR_ERR_WORKSPACE, "score_gemm_swizzle_items: workspace small");
+  const int ipad = round_up64(cols);
+  const int64_t n_vec = (int64_t)(ipad / 64) * 2 * (dp / 8) * 64;
+  hipLaunchKernelGGL(swizzle_items_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     g.QT, ipad, dp / 2, (float4*)g.QS, n_vec);
+  NR_LAUNCH_CHECK();
+  return NR_OK;
+}
 extern "C" {
 
 int nrhip_score_gemm(const float* d_P, int64_t ldp, const int32_t* d_users, int rows, int cols,

@@ -488,13 +488,15 @@ class PrunedEvaluation:
     def run(self, user_table, item_table, users, row_of, per_user, flags, prepare_items=True):
         a, g, f, pl = self.args, self.gemm, self.filt, self.plan
         n = users.numel()
-        # the argument block of the previous call stands when it was made from the same objects (held here, so an id
-        # cannot be reused; a tensor keeps its storage pointer unless resized): an evaluation per epoch hands over the
-        # same tables, user list and buffers every time, and filling ~40 fields costs more than a small launch
-        same = getattr(self, "_last", None)
-        now = (user_table, item_table, users, row_of, per_user, flags)
-        if same is not None and all(x is y for x, y in zip(same[0], now)) and same[1] == (n, user_table.stride(0),
-                                                                                        item_table.stride(0)):
+        # the argument block of the previous call stands when the six tensors lie where they lay (the block holds nothing
+        # of them but pointers, strides and counts; everything else in it belongs to this object): an evaluation per
+        # epoch hands over the same tables, user list and buffers every time, and filling ~40 fields costs more than a
+        # small launch
+        key = (user_table.data_ptr(), user_table.stride(0), item_table.data_ptr(), item_table.stride(0), item_table.stride(1),
+               users.data_ptr(), n, row_of.data_ptr(), per_user.data_ptr(), flags.data_ptr(), user_table.dtype,
+               item_table.dtype, users.dtype, per_user.dtype, flags.dtype, row_of.dtype, user_table.stride(1),
+               per_user.is_contiguous())
+        if getattr(self, "_last", None) == key:
             a.prepare_items = int(prepare_items)
             call("nrhip_eval_pruned", C.byref(a), _stream())
             return per_user, flags, self.sums
@@ -506,7 +508,7 @@ class PrunedEvaluation:
             self._cs_n = n
         if item_table.stride(1) != 1:
             item_table = item_table.contiguous()
-            now = None                                       # (a temporary copy: nothing to remember)
+            key = None                                       # (a temporary copy: nothing to remember)
         ptr = lambda t: t.data_ptr()
         a.P, a.ldp, a.Q, a.ldq, a.d, a.cols = ptr(user_table), user_table.stride(0), ptr(item_table), item_table.stride(0), g.d, g.cols
         a.users, a.n_users, a.batch_rows = ptr(users), n, self.batch_rows
@@ -529,8 +531,40 @@ class PrunedEvaluation:
         if not (user_table.stride(1) == 1 and users.is_contiguous() and per_user.is_contiguous() and flags.is_contiguous()):
             raise ValueError("nrhip_eval_pruned: contiguous arguments")
         call("nrhip_eval_pruned", C.byref(a), _stream())
-        self._last = None if now is None else (now, (n, user_table.stride(0), item_table.stride(0)))
+        self._last = key
         return per_user, flags, self.sums
+
+    def redo(self, n_flagged, slab, reload_items):
+        """nrhip_eval_redo behind run(): the n_flagged rows run() flagged (the count it left behind the sums, read by
+        the caller) ranked again from full fp32 score rows in `slab` [rows][ld] and written over their rows of run()'s
+        per_user; the sums retaken.  reload_items: the scoring engine's item side first — 2: run() ran with
+        prepare_items = 2 on this table (only the operand copy is missing), 1: all of it.  Returns the sums tensor."""
+        from ._lib import EvalRedoArgs
+        n_flagged = int(n_flagged)
+        rows = min(int(slab.shape[0]), self.batch_rows)
+        dev = slab.device
+        r = getattr(self, "_redo_args", None)
+        if r is None:
+            r = self._redo_args = EvalRedoArgs()
+            self._redo_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._redo_rows = self._redo_fixed = self._redo_ws = None
+        if self._redo_rows is None or self._redo_rows.shape[1] < n_flagged:
+            self._redo_rows = torch.empty((2, max(n_flagged, 256)), dtype=torch.int32, device=dev)
+        if self._redo_fixed is None or self._redo_fixed.shape[0] < rows:
+            self._redo_fixed = torch.empty((rows, self.nm * self.top_k), dtype=torch.float32, device=dev)
+            nb = C.c_size_t(0)
+            call("nrhip_eval_workspace_bytes", rows, self.top_k, C.byref(nb))
+            self._redo_ws = torch.empty(max(nb.value, 256), dtype=torch.uint8, device=dev)
+        if slab.dtype != torch.float32 or slab.stride(1) != 1:
+            raise TypeError("nrhip_eval_redo: a float32 score slab with contiguous rows")
+        r.ev = C.pointer(self.args)
+        r.n_flagged, r.reload_items = n_flagged, int(reload_items)
+        r.scores, r.lds, r.slab_rows = slab.data_ptr(), slab.stride(0), rows
+        r.rows, r.row_users = self._redo_rows[0].data_ptr(), self._redo_rows[1].data_ptr()
+        r.count, r.fixed = self._redo_count.data_ptr(), self._redo_fixed.data_ptr()
+        r.ws, r.ws_bytes = self._redo_ws.data_ptr(), self._redo_ws.numel()
+        call("nrhip_eval_redo", C.byref(r), _stream())
+        return self.sums
 
 
 # ----------------------------------------------------------------------------- sampler

@@ -589,7 +589,14 @@ class FullRankEvaluator:
                     ranked[k % 2] = side.record_event()
             main.wait_stream(side)
         if exact_mean or want_rows:
-            self._redo_flagged(user_table, item_table, test_users, per_user)
+            if self._native_sums is not None:             # the counts lie behind the sums: the redo needs no host sync of its own
+                both = self._read_native_sums()
+                self.n_flagged, self.n_uncertified = int(both[-2]), int(both[-1])
+                if self.n_flagged:
+                    self._redo_native(item_table)
+                self._flags = None
+            else:
+                self._redo_flagged(user_table, item_table, test_users, per_user)
             self._note_flags()
             rows = per_user.cpu().numpy()
             return rows if want_rows else np.mean(rows, axis=0)   # uni_evaluator.py:150-151
@@ -597,14 +604,16 @@ class FullRankEvaluator:
         # ONE device->host copy per evaluation: the column sums and the number of rows flagged for ties
         # travel together; only if some row was flagged are those rows redone and the sums retaken
         if self._native_sums is not None:                 # nrhip_eval_pruned left the sums and the flag count together
-            host = getattr(self, "_sums_host", None)
-            if host is None or host.shape != self._native_sums.shape:
-                host = self._sums_host = torch.empty(self._native_sums.shape, dtype=self._native_sums.dtype,
-                                                     pin_memory=True)
-            host.copy_(self._native_sums, non_blocking=True)     # (pinned: no staging copy behind the device's)
-            torch.cuda.current_stream().synchronize()
-            both = host.numpy().copy()
-            self._native_sums = None
+            both = self._read_native_sums()
+            self.n_flagged, self.n_uncertified = int(both[-2]), int(both[-1])
+            self._note_flags()
+            if self.n_flagged:
+                # the flagged rows again from full score rows and the sums retaken, in one native call (r06: the
+                # Python-level redo — index, GEMM, mask, rank, scatter, sums — cost 0.31 ms whatever the count)
+                self._redo_native(item_table)
+                both = self._read_native_sums()
+                self._flags = None
+            return both[:-2] / div
         else:
             sums = E.colsum(per_user)
             if self._flags is None:
@@ -615,9 +624,29 @@ class FullRankEvaluator:
         self.n_flagged, self.n_uncertified = int(both[-2]), int(both[-1])
         self._note_flags()
         if self.n_flagged:
-            self._redo_flagged(user_table, item_table, test_users, per_user)
+            # (both counts are known: the redo below runs without a host round trip of its own)
+            self._redo_flagged(user_table, item_table, test_users, per_user, known=(self.n_flagged, self.n_uncertified))
             return E.colsum(per_user).cpu().numpy() / div
         return both[:-2] / div
+
+    def _read_native_sums(self):
+        """[column sums | flagged rows | rows among them whose certificate failed] of the native evaluation, on the host"""
+        host = getattr(self, "_sums_host", None)
+        if host is None or host.shape != self._native_sums.shape:
+            host = self._sums_host = torch.empty(self._native_sums.shape, dtype=self._native_sums.dtype, pin_memory=True)
+        host.copy_(self._native_sums, non_blocking=True)         # (pinned: no staging copy behind the device's)
+        torch.cuda.current_stream().synchronize()
+        self._native_sums = None
+        return host.numpy().copy()
+
+    def _redo_native(self, item_table):
+        """nrhip_eval_redo: the rows the native evaluation flagged, from full fp32 score rows (at most 1 GiB of them at a
+        time), over their rows of its output; leaves the retaken sums for _read_native_sums"""
+        step = max(1, min(self.batch_rows, (1 << 28) // max(self._gemm.ld, 1)))
+        slab = self._slab(0, min(step, self.n_flagged))
+        stale = getattr(self, "_gemm_stale", False)
+        self._native_sums = self._native.redo(self.n_flagged, slab, reload_items=2 if stale == "operand copy" else 1 if stale else 0)
+        self._gemm_stale = False
 
     def _reload_items(self, item_table):
         """the scoring engine's item copies, if they are still the previous table's"""
@@ -722,6 +751,8 @@ class FullRankEvaluator:
                                                        prepare_items=(2 if filt is not None else 1) if inside else 0)
             if not (inside and filt is not None):
                 self._gemm_stale = False
+            else:
+                self._gemm_stale = "operand copy"             # (the k-major copy is this table's)
             self._flags = flags
             return
         self._native_sums = None
@@ -738,14 +769,24 @@ class FullRankEvaluator:
                              self.top_k, per_user[b:b + u.numel()], flags[b:b + u.numel()], eps=eps, n_keep=n_keep)
         self._flags = flags                        # read by evaluate_factors together with the sums
 
-    def _redo_flagged(self, user_table, item_table, test_users, per_user):
-        """Rows whose ranking could depend on ties: recomputed from full score rows."""
+    def _redo_flagged(self, user_table, item_table, test_users, per_user, known=None):
+        """Rows whose ranking could depend on ties: recomputed from full score rows.  known = (flagged rows, rows among
+        them whose certificate failed) when the caller has read the counts already (they come back with the column
+        sums): the row list is then formed on the device without a host round trip."""
         if self._flags is None:
             return
         self._reload_items(item_table)
         cols = item_table.shape[0]
-        redo = torch.nonzero(self._flags, as_tuple=False).flatten()      # host sync: only when rows were flagged
-        self.n_uncertified = int(((self._flags & 2) != 0).sum()) if redo.numel() else 0
+        redo = None
+        if known is not None and known[0] > 0:
+            try:
+                redo = torch.nonzero_static(self._flags, size=int(known[0])).flatten()
+                self.n_uncertified = int(known[1])
+            except (RuntimeError, NotImplementedError):      # (a build without the static form on this device)
+                redo = None
+        if redo is None:
+            redo = torch.nonzero(self._flags, as_tuple=False).flatten()      # host sync: only when rows were flagged
+            self.n_uncertified = int(((self._flags & 2) != 0).sum()) if redo.numel() else 0
         self._flags = None
         self.n_flagged = int(redo.numel())
         if self.n_flagged:

@@ -168,3 +168,48 @@ def test_packed_tile_buckets_equal_the_strided_buckets_and_the_per_row_kernel():
         assert packed[key][1] == strided[key][1] == per_row[key][1], key
         np.testing.assert_array_equal(np.asarray(packed[key][0]), np.asarray(strided[key][0]), err_msg=key)
         np.testing.assert_array_equal(np.asarray(packed[key][0]), np.asarray(per_row[key][0]), err_msg=key)
+
+
+@pytest.mark.parametrize("I,d", [(5000, 64), (70_000, 128)])
+def test_native_redo_of_any_row_reproduces_the_pruned_rows(I, d):
+    """nrhip_eval_redo ranks a flagged row again from a full fp32 score row — the materialised path, exact whatever
+    made the search give up.  So marking rows the search had certified must change nothing: the same per-user metric
+    rows bit for bit (and the reference evaluator's on sampled users), the same column sums, the marked count reported.
+    Slabs shorter than the marked count (several passes) included."""
+    import torch
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    U = 900
+    P, Q, Pd, Qd, tr_lists, te_lists = _workload(U, I, d, seed=I % 97)
+    trc, tec = _csr(E, tr_lists, I), _csr(E, te_lists, I)
+    users_np = np.asarray([u for u in range(U) if te_lists[u]], np.int32)
+    users = torch.from_numpy(users_np).cuda()
+    n = len(users_np)
+    clean = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=512)
+    want_rows = np.asarray(clean.evaluate_factors(Pd, Qd, users, per_user=True))
+    want_sums = clean.evaluate_factors(Pd, Qd, users, column_sums=True)
+    assert clean.n_flagged == 0
+    for k, batch_rows in ((1, 512), (n // 7, 512), (n // 3, 64)):          # (64-row slabs: n // 3 rows take several)
+        ev = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=batch_rows)
+        marked = torch.from_numpy(np.random.RandomState(k).choice(n, k, replace=False)).cuda()
+        read = ev._read_native_sums
+        state = {"mark": True}
+
+        def patched():
+            both = read()
+            if state["mark"]:                                  # behind the search: as if these certificates had failed
+                ev._flags_buf[marked] = 2
+                both[-2] += k
+                both[-1] += k
+                state["mark"] = False
+            return both
+        ev._read_native_sums = patched
+        rows = np.asarray(ev.evaluate_factors(Pd, Qd, users, per_user=True))
+        assert ev.n_flagged == k and ev.n_uncertified == k
+        np.testing.assert_array_equal(rows.view(np.uint32), want_rows.view(np.uint32))
+        state["mark"] = True
+        sums = ev.evaluate_factors(Pd, Qd, users, column_sums=True)
+        assert ev.n_flagged == k
+        np.testing.assert_array_equal(sums, want_sums)
+    pick = np.arange(0, n, 11)
+    np.testing.assert_array_equal(want_rows[pick], _reference_rows(P, Q, users_np[pick], tr_lists, te_lists, [1, 2, 3, 4, 5], 20))
