@@ -580,16 +580,17 @@ def main():
                 torch.cuda.synchronize()
                 eval_info["strike_plan_build_ms"] = (time.perf_counter() - tp) * 1e3
             eval_info["roofline_topk"] = {
-                "bound": "hbm", "kernel": "select_rows_kernel (tile maxima) + tile_pairs / chunk kernels + rescore_pairs_kernel "
-                                          "(fp32 MFMA chain, 32 users of one tile per wave) + rank_compact_kernel (strikes, "
-                                          "ranking, item ids, certificate) + metrics_kernel (nrhip_eval_tiles_bounded)",
+                "bound": "hbm", "kernel": "select_rows_kernel (tile maxima -> tile lists) + tile_pairs / chunk kernels + "
+                                          "rescore_pairs_kernel (fp32 MFMA chain, 32 users of one tile per wave) + "
+                                          "rank_compact_kernel (strikes, ranking, item ids, certificate, metrics) "
+                                          "(nrhip_eval_tiles_bounded)",
                 "achieved": rank_bytes / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rank_bytes / t_rank / 1e9 / HBM_PEAK_GBS, "ms": t_rank * 1e3,
                 "bytes": rank_bytes, "rescore_gflop": rescore_flops / 1e9,
                 "note": "pruned design: the [users][I] score matrix is never written; the top-K works on the tile maxima "
                         "(%d floats per user, the phase's HBM stream) and %d rescored 32-item tiles per user; the "
                         "rescoring is bucketed by tile, so an item tile is read once per 32 users (r03: once per user, "
-                        "5.6 GB through the L2s, 0.43 ms); the phase is a chain of seven short launches" % (tiles, n_keep)}
+                        "5.6 GB through the L2s, 0.43 ms); the phase is a chain of six short launches" % (tiles, n_keep)}
 
     line = {
         "metric": "BPR triplets/sec (LightGCN-%s)" % args.shape, "value": triplets_per_s,

@@ -568,7 +568,7 @@ def _config4_eval(lg, comm, trc, I, dim, dev, n_eval, batch_rows=8192, top_k=20)
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_bytes / t2 / 1e9 / HBM_PEAK_GBS,
                                 "tile_maxima_per_user": tiles, "tiles_rescored_per_user": n_keep,
                                 "kernel": "select_rows_kernel (streaming ring over %d maxima) + tile_count / tile_fill "
-                                          "(packed buckets) + rescore_pairs_kernel + rank_compact_kernel + metrics_kernel" % tiles}
+                                          "(packed buckets) + rescore_pairs_kernel + rank_compact_kernel (ranking, certificate, metrics)" % tiles}
     return out
 
 
