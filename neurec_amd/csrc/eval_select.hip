@@ -380,6 +380,94 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
 }
 
 // ----------------------------------------------------------------------------
+// The pruned evaluation's FIRST selection as a kernel of its own (r06): the `cut` largest of a row of <= 256 FR tile
+// maxima, written straight into the row's tile list.  select_rows_kernel's short-row path, word for word — same keys
+// (ordered score, -column), same total order — without the streaming ring next to it: that path's registers (94) held
+// the launch at 5 waves per SIMD, and the kernel is one round trip for the row plus two register sorts, so the waves
+// in flight are its throughput (54-64 registers: 8 waves).  Ties among maxima do not matter here (no flag is kept):
+// a tie group beyond one key per lane — a zero factor row: every maximum equal — is ranked by repeated maximum
+// extraction over the registers instead of the ring.  Slots beyond the comparable maxima (a NaN row) are set to 0.
+// ----------------------------------------------------------------------------
+template <int FR>
+__global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_tiles_kernel(
+    const float* __restrict__ scores, int64_t ld, int rows, int cols, int cut, int32_t* __restrict__ out, int64_t out_ld,
+    int32_t* __restrict__ zero, int zero_n) {
+  __shared__ uint64_t s_keys[kSelWaves][NR_WAVE];
+  if (zero)                                                    // (the bucket pass's counters: see select_rows_kernel)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += gridDim.x * blockDim.x) zero[i] = 0;
+  const int wave = threadIdx.x / NR_WAVE, lane = nr_lane();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  const float* srow = scores + (int64_t)row * ld;
+  uint32_t ord[FR][4], best = 0u;                              // order words of real scores are never 0
+#pragma unroll
+  for (int u = 0; u < FR; ++u) {
+    const int e0 = (u * NR_WAVE + lane) * 4;
+    float v[4];
+    if (e0 + 3 < cols) {
+      const float4 t = *reinterpret_cast<const float4*>(srow + e0);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = (e0 + c < cols) ? srow[e0 + c] : NAN;      // NaN: never a key
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ord[u][c] = v[c] >= -INFINITY ? nr::order_f32(v[c]) : 0u;
+      best = max(best, ord[u][c]);
+    }
+  }
+  const int need = cut + 1;
+  const uint64_t sb = wave_sort_desc((uint64_t)best);
+  const uint32_t tau_ord = __builtin_amdgcn_readlane((uint32_t)sb, need - 1);     // fewer than `need` lanes with a score: 0
+  uint64_t* keys = s_keys[wave];
+  int c_n = 0;
+#pragma unroll
+  for (int u = 0; u < FR; ++u) {
+    const uint32_t m = max(max(ord[u][0], ord[u][1]), max(ord[u][2], ord[u][3]));
+    if (__ballot(m != 0u && m >= tau_ord) == 0) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool pass = ord[u][c] != 0u && ord[u][c] >= tau_ord;
+      const uint64_t mask = __ballot(pass);
+      if (mask) {
+        const int at = c_n + nr_mbcnt(mask);
+        if (pass && at < NR_WAVE)
+          keys[at] = ((uint64_t)ord[u][c] << 32) | (uint64_t)(0xffffffffu - (uint32_t)((u * NR_WAVE + lane) * 4 + c));
+        c_n += __popcll(mask);
+      }
+    }
+  }
+  int32_t* orow = out + (int64_t)row * out_ld;
+  if (c_n <= NR_WAVE) {                                        // wave-uniform
+    wave_lds_sync();
+    const uint64_t mine = wave_sort_desc(lane < c_n ? keys[lane] : 0ull);
+    const int n_out = min(cut, c_n);
+    if (lane < cut) orow[lane] = lane < n_out ? (int32_t)nr::key_index(mine) : 0;
+    return;
+  }
+  // more than 64 candidates at or above the threshold (equal maxima): the `cut` best keys one after the other
+  uint64_t last = ~0ull;                                       // every key is below it
+  for (int k = 0; k < cut; ++k) {
+    uint64_t m = 0ull;
+#pragma unroll
+    for (int u = 0; u < FR; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint64_t key = ord[u][c] ? ((uint64_t)ord[u][c] << 32) | (uint64_t)(0xffffffffu - (uint32_t)((u * NR_WAVE + lane) * 4 + c)) : 0ull;
+        if (key < last && key > m) m = key;
+      }
+#pragma unroll
+    for (int sh = 1; sh < NR_WAVE; sh <<= 1) {
+      const uint64_t o = shfl_xor_u64(m, sh);
+      m = o > m ? o : m;
+    }
+    if (lane == 0) orow[k] = m ? (int32_t)nr::key_index(m) : 0;
+    last = m ? m : 0ull;                                       // (no key left: the remaining slots take 0)
+  }
+}
+
+// ----------------------------------------------------------------------------
 // Exact path for flagged rows: wave-cooperative replay of
 // std::partial_sort_copy's heap (see nr_core.h).  The heap lives in LDS and
 // every lane executes the (uniform) heap code; lanes only differ while
@@ -753,6 +841,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rescore_tiles_kernel(
 // ----------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kPairRows = 256;                                 // rows per workgroup of tile_pairs_kernel
+constexpr int kPairThreads = 1024;                             // ... and its threads: the launch is rows / 256 workgroups (117 at gowalla, half
+                                                               // the CUs) of dependent LDS / global atomics — 16 waves each hide what 4 could not
 constexpr int kMaxGroupedTiles = 12288;                        // LDS histogram: 4 bytes per 32-item tile
 
 // A thread per (row, slot) pair; slot = the tile's place in the selection's order (descending maxima).  The compact
@@ -760,28 +850,28 @@ constexpr int kMaxGroupedTiles = 12288;                        // LDS histogram:
 // selection, and every row with a tie among its cut + 1 best compact scores is flagged and redone from a full row.
 // (Measured on the way: a wave per row with the slots sorted by tile id: 57 us at 64 rows per workgroup — 600 k global
 // reservations — and 99 us at 256 — 64 dependent iterations per wave; this form: one reservation per (workgroup, tile).)
-__global__ __launch_bounds__(256) void tile_pairs_kernel(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep,
+__global__ __launch_bounds__(kPairThreads) void tile_pairs_kernel(const int32_t* __restrict__ tiles, int tiles_ld, int n_keep,
                                                          int rows, int n_tiles, int32_t* __restrict__ tilemap,
                                                          int32_t* __restrict__ gcnt, uint32_t* __restrict__ bucket,
                                                          int32_t* __restrict__ overflow) {
   extern __shared__ int32_t s_hist[];                          // [n_tiles]: counts, then the bucket cursors
   const int tid = threadIdx.x;
-  for (int i = tid; i < n_tiles; i += 256) s_hist[i] = 0;
+  for (int i = tid; i < n_tiles; i += kPairThreads) s_hist[i] = 0;
   __syncthreads();
   const int r0 = blockIdx.x * kPairRows;
   const int n_pairs = min(kPairRows, rows - r0) * n_keep;
-  for (int p = tid; p < n_pairs; p += 256) {
+  for (int p = tid; p < n_pairs; p += kPairThreads) {
     int t = tiles[(int64_t)(r0 + p / n_keep) * tiles_ld + p % n_keep];
     if ((unsigned)t >= (unsigned)n_tiles) t = 0;               // NaN tables: garbage ids stay in range
     atomicAdd(&s_hist[t], 1);
   }
   __syncthreads();
-  for (int t = tid; t < n_tiles; t += 256) {
+  for (int t = tid; t < n_tiles; t += kPairThreads) {
     const int c = s_hist[t];
     if (c) s_hist[t] = atomicAdd(&gcnt[t], c);                 // ONE reservation per (workgroup, tile)
   }
   __syncthreads();
-  for (int p = tid; p < n_pairs; p += 256) {
+  for (int p = tid; p < n_pairs; p += kPairThreads) {
     const int row = r0 + p / n_keep, slot = p % n_keep;
     int t = tiles[(int64_t)row * tiles_ld + slot];
     if ((unsigned)t >= (unsigned)n_tiles) t = 0;
@@ -1031,6 +1121,7 @@ __global__ __launch_bounds__(256) void remap_rank_kernel(int32_t* __restrict__ r
 // A tie group too large for one key per lane (that path falls back to the streaming ring in select_rows_kernel) flags
 // the row here: it is then ranked from a full score row, which is exact whatever the cause.
 // ----------------------------------------------------------------------------------------------
+template <int FR>                                              // float4 registers per lane: the compact row holds <= 256 FR scores
 __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
     const float* __restrict__ C, int64_t cld, int rows, int n_keep, int top_k, const int32_t* __restrict__ users,
     const int64_t* __restrict__ tr_indptr, const int32_t* __restrict__ tr_indices,
@@ -1053,7 +1144,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
   s_map[wave][lane] = my_tile;
   s_strike[wave][lane] = 0u;
   s_bits[wave][lane] = 0u;
-  constexpr int FR = 8;                                       // float4 registers per lane: <= 2,048 scores
+  // (FR = 4 for n_keep <= 32 — the usual 22-27 tiles: half the registers of the 2,048-score form, 8 waves per SIMD
+  //  instead of 5 in a kernel that is nothing but dependent round trips: 85 -> us per 29,858 rows)
   const int cols = n_keep * kTileItems, cut = top_k + 1, need = cut + 1;
   const float* srow = C + (int64_t)row * cld;
   float v[FR][4];
@@ -1163,15 +1255,20 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ m
   const int r0 = blockIdx.y * kSlabRows;
   const int r1 = min(rows, r0 + kSlabRows);
   double acc = 0.0;
-  if (c < cols)
-    for (int r = r0 + g; r < r1; r += 4 * 8) {       // 8 rows in flight, added in row order (one load per add was a
-      float v[8];                                    // chain of 64 memory round trips: 17.5 us for 29,858 x 100)
+  if (c < cols) {
+    // the thread's 64 rows (r0 + g, + 4, ...) requested at once, added in row order: 936 waves is all this launch has,
+    // and with 8 loads in flight each it was eight memory round trips long (18 us for 29,858 x 100; one load per add: 64)
+    constexpr int kMine = kSlabRows / 4;
+    float v[kMine];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = r + 4 * i < r1 ? mat[(int64_t)(r + 4 * i) * ld + c] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (r + 4 * i < r1) acc += (double)v[i];
+    for (int i = 0; i < kMine; ++i) {
+      const int r = r0 + g + 4 * i;
+      v[i] = r < r1 ? mat[(int64_t)r * ld + c] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < kMine; ++i)
+      if (r0 + g + 4 * i < r1) acc += (double)v[i];
+  }
   s_part[g][threadIdx.x & 63] = acc;
   __syncthreads();
   if (g == 0 && c < cols)
@@ -1268,6 +1365,12 @@ int select_knob_once() {
   NR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_select_fast), &v, sizeof(v)));
   done[dev].store(1, std::memory_order_release);
   return NR_OK;
+}
+
+// the same knob on the host: NEUREC_SELECT_FAST=0 also keeps the pruned evaluation's first selection on the general kernel
+static bool select_fast_host() {
+  static const int v = [] { const char* e = getenv("NEUREC_SELECT_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v != 0;
 }
 
 int run_selection(const float* d_scores, int64_t ld, int rows, int cols, int sort_len, int cut,
@@ -1574,7 +1677,18 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   // (the grouped forms' tile counters lead their part of the workspace: this launch clears them on its way in)
   int32_t* const gcnt0 = form != kGroupedNone ? (int32_t*)((char*)d_ws + eval_tiles_ws_bytes(rows, n_keep)) : nullptr;
   const int gcnt0_n = form == kGroupedStrided ? n_tiles + rows : form == kGroupedCompact ? 2 * n_tiles : 0;
-  if ((mld % 4 == 0) && (((uintptr_t)d_M) % 16 == 0))
+  const bool vec4 = (mld % 4 == 0) && (((uintptr_t)d_M) % 16 == 0);
+  if (vec4 && n_tiles <= 2048 && tiles_ld + 1 <= NR_WAVE && select_fast_host()) {
+    const int fr = (n_tiles + 255) / 256;                       // float4 registers per lane
+#define NR_TILES_CASE(FR)                                                                                         \
+  hipLaunchKernelGGL(select_tiles_kernel<FR>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M, mld, rows, n_tiles, \
+                     tiles_ld, tiles, (int64_t)tiles_ld, gcnt0, gcnt0_n)
+    if (fr <= 2) NR_TILES_CASE(2);
+    else if (fr <= 4) NR_TILES_CASE(4);
+    else if (fr <= 6) NR_TILES_CASE(6);
+    else NR_TILES_CASE(8);
+#undef NR_TILES_CASE
+  } else if (vec4)
     hipLaunchKernelGGL(select_rows_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, d_M,
                        mld, rows, n_tiles, tiles_ld, tiles_ld, tiles, w.flag, (uint64_t*)nullptr, (int64_t)tiles_ld, 1,
                        gcnt0, gcnt0_n);
@@ -1598,7 +1712,7 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
       chunk_begin = (int32_t*)x; x += nr_align_up(((size_t)n_tiles + 1) * 4, 256);
       chunks = (int4*)x;         x += nr_align_up(max_chunks * 16, 256);
       bucket = (uint32_t*)x;
-      hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(256),
+      hipLaunchKernelGGL(tile_pairs_kernel, dim3((rows + kPairRows - 1) / kPairRows), dim3(kPairThreads),
                          (size_t)n_tiles * 4, st, tiles, tiles_ld, n_keep, rows, n_tiles, tilemap,
                          gcnt, bucket, overflow);
       NR_LAUNCH_CHECK();
@@ -1650,9 +1764,14 @@ static int eval_tiles_impl(const float* d_M, int64_t mld, const float* d_P, int6
   if (form != kGroupedNone) {
     // 3 + 4 + 5 in one launch: strikes, ranking of the compact rows, columns -> item ids, boundary check, flags, and the
     // metrics from the ranks while they are still in the wave's registers (r06: metrics_kernel was 21 us + a launch gap)
-    hipLaunchKernelGGL(rank_compact_kernel, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld, rows, n_keep, top_k,
-                       d_users, d_tr_indptr, d_tr_indices, tilemap, tiles, tiles_ld, d_M, mld, d_eps, overflow,
-                       d_flag_out, d_truth_indptr, d_truth_indices, mids, tbl, d_out);
+    if (n_keep * kTileItems <= 1024)
+      hipLaunchKernelGGL(rank_compact_kernel<4>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld, rows, n_keep,
+                         top_k, d_users, d_tr_indptr, d_tr_indices, tilemap, tiles, tiles_ld, d_M, mld, d_eps, overflow,
+                         d_flag_out, d_truth_indptr, d_truth_indices, mids, tbl, d_out);
+    else
+      hipLaunchKernelGGL(rank_compact_kernel<8>, dim3(blocks), dim3(kSelWaves * NR_WAVE), 0, st, C, cld, rows, n_keep,
+                         top_k, d_users, d_tr_indptr, d_tr_indices, tilemap, tiles, tiles_ld, d_M, mld, d_eps, overflow,
+                         d_flag_out, d_truth_indptr, d_truth_indices, mids, tbl, d_out);
     NR_LAUNCH_CHECK();
     return NR_OK;
   } else {

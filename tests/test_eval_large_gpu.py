@@ -213,3 +213,29 @@ def test_native_redo_of_any_row_reproduces_the_pruned_rows(I, d):
         np.testing.assert_array_equal(sums, want_sums)
     pick = np.arange(0, n, 11)
     np.testing.assert_array_equal(want_rows[pick], _reference_rows(P, Q, users_np[pick], tr_lists, te_lists, [1, 2, 3, 4, 5], 20))
+
+
+@pytest.mark.parametrize("I,d", [(40_981, 32), (9_000, 64)])
+def test_zero_factor_rows_take_the_equal_maxima_path_of_the_first_selection(I, d):
+    """a zero user row scores 0 everywhere: every tile maximum is equal, more candidates than a wave has lanes — the
+    first selection (select_tiles_kernel) ranks them by repeated maximum extraction; the row is then flagged for its
+    ties and redone, and comes out as the materialised path's, like its neighbours"""
+    import torch
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    U = 260
+    P, Q, Pd, Qd, tr_lists, te_lists = _workload(U, I, d, seed=5)
+    P[::5] = 0.0
+    Pd = torch.from_numpy(P).cuda()
+    trc, tec = _csr(E, tr_lists, I), _csr(E, te_lists, I)
+    users = torch.from_numpy(np.asarray([u for u in range(U) if te_lists[u]], np.int32)).cuda()
+    got, flagged = {}, {}
+    for search in ("int8", "bf16", "fp32"):
+        ev = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, search=search)
+        got[search] = np.asarray(ev.evaluate_factors(Pd, Qd, users, per_user=True))
+        flagged[search] = ev.n_flagged
+    want = np.asarray(FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], 20, batch_rows=128, pruned=False)
+                      .evaluate_factors(Pd, Qd, users, per_user=True))
+    for search in got:
+        assert flagged[search] >= int((P[users.cpu().numpy()] == 0).all(1).sum()), search
+        np.testing.assert_array_equal(got[search].view(np.uint32), want.view(np.uint32), err_msg=search)
