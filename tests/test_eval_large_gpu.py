@@ -239,3 +239,29 @@ def test_zero_factor_rows_take_the_equal_maxima_path_of_the_first_selection(I, d
     for search in got:
         assert flagged[search] >= int((P[users.cpu().numpy()] == 0).all(1).sum()), search
         np.testing.assert_array_equal(got[search].view(np.uint32), want.view(np.uint32), err_msg=search)
+
+
+@pytest.mark.parametrize("top_k", [1, 5, 31, 40, 62])
+def test_pruned_evaluation_at_other_cut_offs_equals_the_materialised_path(top_k):
+    """K = 20 is the configured cut-off (NeuRec.properties); the kernels are sized by it — rank_compact_kernel<4> up to
+    32 rescored tiles, <8> beyond, the first selection in registers while K + extra + 2 <= 64, the streaming ring at
+    K = 62 — so every size class is run here against the materialised path, per-user rows bit for bit, and against
+    the reference evaluator on sampled users"""
+    import torch
+    from neurec_amd import engine as E
+    from neurec_amd.trainer import FullRankEvaluator
+    U, I, d = 420, 12_000, 64
+    P, Q, Pd, Qd, tr_lists, te_lists = _workload(U, I, d, seed=top_k)
+    trc, tec = _csr(E, tr_lists, I), _csr(E, te_lists, I)
+    users_np = np.asarray([u for u in range(U) if te_lists[u]], np.int32)
+    users = torch.from_numpy(users_np).cuda()
+    want = np.asarray(FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], top_k, batch_rows=160, pruned=False)
+                      .evaluate_factors(Pd, Qd, users, per_user=True))
+    for search in ("int8", "bf16", "fp32"):
+        ev = FullRankEvaluator(trc, tec, [1, 2, 3, 4, 5], top_k, batch_rows=160, search=search)
+        got = np.asarray(ev.evaluate_factors(Pd, Qd, users, per_user=True))
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg="%s K=%d" % (search, top_k))
+        sums = ev.evaluate_factors(Pd, Qd, users, column_sums=True)
+        np.testing.assert_allclose(sums, want.astype(np.float64).sum(0), rtol=1e-12)
+    pick = np.arange(0, len(users_np), 9)
+    np.testing.assert_array_equal(want[pick], _reference_rows(P, Q, users_np[pick], tr_lists, te_lists, [1, 2, 3, 4, 5], top_k))
