@@ -202,12 +202,14 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
         }
       }
       uint32_t ord[FR][4], best = 0u;                         // order words of real scores are never 0
+      bool has_nan = false;                                   // a NaN among the row's own columns (see the flag below)
 #pragma unroll
       for (int u = 0; u < FR; ++u)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           ord[u][c] = v[u][c] >= -INFINITY ? nr::order_f32(v[u][c]) : 0u;
           best = max(best, ord[u][c]);
+          has_nan = has_nan || (ord[u][c] == 0u && (u * NR_WAVE + lane) * 4 + c < cols);
         }
       const uint64_t sb = wave_sort_desc((uint64_t)best);
       // fewer than `need` lanes hold a score: 0 — everything is a candidate
@@ -238,9 +240,14 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
         if (lane < n_out) rank[(int64_t)row * rank_ld + lane] = (int32_t)nr::key_index(mine);
         else if (fill && lane < cut) rank[(int64_t)row * rank_ld + lane] = 0;
         const uint64_t tmask = __ballot(tie);
+        // A NaN score is no key here, but in the reference it sits in the heap like any other value and every
+        // comparison with it is false: what std::partial_sort_copy then returns is a function of the row's whole
+        // history.  Such a row is flagged — exact_rows_kernel replays that heap, NaNs included — instead of ranking
+        // the comparable scores only (and leaving the slots beyond them as the workspace held them).
+        const bool nan_any = __ballot(has_nan) != 0;
         if (lane == 0) {
-          flag[row] = tmask ? 1 : 0;
-          if (tie_mask) tie_mask[row] = tmask;
+          flag[row] = (tmask || nan_any) ? 1 : 0;
+          if (tie_mask) tie_mask[row] = nan_any ? ~0ull : tmask;
         }
         return;
       }
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
   constexpr int UNIT_ELEMS = NR_WAVE * VEC;
   const int step = UNITS * UNIT_ELEMS;
 
+  bool nan_seen = false;                          // a NaN among the row's own columns: the row is flagged (see the short-row path)
   for (int base = 0; base < cols; base += step) {
     float v[UNITS][VEC];
     if (base + step <= cols) {                 // interior of the row: unconditional back-to-back loads
@@ -298,6 +306,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
         } else {
           v[u][0] = srow[e0];
         }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) nan_seen = nan_seen || v[u][c] != v[u][c];
       }
     } else {
 #pragma unroll
@@ -314,6 +324,8 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
         } else {
           v[u][0] = (e0 < cols) ? srow[e0] : NAN;   // NaN never passes `>= tau`
         }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) nan_seen = nan_seen || (e0 + c < cols && v[u][c] != v[u][c]);
       }
     }
 #pragma unroll
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_rows_kernel(
   if (fill)
     for (int r = max(0, min(cut, take)) + lane; r < cut; r += NR_WAVE) rank[(int64_t)row * rank_ld + r] = 0;
   if (btie && take >= cut && cut >= 1 && nr::key_order(top[cut - 1]) == btie_order) tie = true;
-  const bool any_tie = __ballot(tie) != 0;
+  const bool any_tie = __ballot(tie || nan_seen) != 0;
   if (lane == 0) {
     flag[row] = any_tie ? 1 : 0;
     if (tie_mask) tie_mask[row] = any_tie ? ~0ull : 0ull;

@@ -77,6 +77,34 @@ def test_eval_scores_matches_oracle_random_and_ties(eng, rows, cols, k):
                                           native.arg_topk(s, k))
 
 
+@pytest.mark.parametrize("rows,cols,k", [(40, 300, 20), (16, 5000, 10), (6, 40981, 20), (12, 1682, 50)])
+def test_rows_with_nan_scores_are_ranked_as_the_reference_heap_ranks_them(eng, rows, cols, k):
+    """A NaN score (a diverged model) is not a key of the parallel selection; in the reference it sits in the heap of
+    std::partial_sort_copy like any value and every comparison with it is false (evaluate.h:38-42), so the answer is a
+    function of the row's whole history.  Such rows take the exact path — the heap replayed, NaNs included — and come
+    out as the reference evaluator's: whole NaN rows, NaNs sprinkled among scores, NaNs next to -inf (masked) entries."""
+    from oracle import native
+    rng = np.random.RandomState(rows + cols)
+    for mode in ("rows", "sprinkled", "with_masked"):
+        s = rng.randn(rows, cols).astype(np.float32)
+        if mode == "rows":
+            s[::3] = np.nan
+        else:
+            s[rng.rand(rows, cols) < 0.01] = np.nan
+            s[0, :] = rng.randn(cols)                          # (one clean row: the ordinary path next to them)
+        if mode == "with_masked":
+            s[rng.rand(rows, cols) < 0.3] = -np.inf
+        truth_l = [np.sort(rng.choice(cols, rng.randint(1, 60), replace=False)).tolist() for _ in range(rows)]
+        want, want_topk = native.eval_matrix(s, truth_l, [1, 2, 3, 4, 5], k, want_topk=True)
+        got, got_topk, n_exact = eng.eval_scores(_dev(s), _csr(eng, truth_l, cols), [1, 2, 3, 4, 5], k, want_topk=True,
+                                                 want_exact_count=True)
+        np.testing.assert_array_equal(got_topk.cpu().numpy(), want_topk, err_msg=mode)
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=mode)
+        assert int(n_exact) >= int(np.isnan(s).any(1).sum()), mode
+        if k <= cols:
+            np.testing.assert_array_equal(eng.arg_topk(_dev(s), k).cpu().numpy(), native.arg_topk(s, k), err_msg=mode)
+
+
 def test_eval_users_indirection_and_metric_order(eng):
     """Truth looked up through user ids in a global test CSR; metric order follows the argument."""
     from oracle import native
