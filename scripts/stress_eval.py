@@ -19,7 +19,7 @@ for case in range(n_cases):
     top_k = int(rng.choice([1, 3, 10, 20, 33, 50, 62]))
     if top_k > I // 4:
         top_k = max(1, I // 8)
-    kind = rng.choice(["gauss", "coarse", "zero_rows", "nan_rows", "popular"])
+    kind = rng.choice(["gauss", "coarse", "zero_rows", "nan_rows", "popular", "nan_items", "inf_items", "huge", "tiny"])
     P = (rng.randn(U, d) * 0.1).astype(np.float32)
     Q = (rng.randn(I, d) * 0.1).astype(np.float32)
     if kind == "coarse":
@@ -28,6 +28,14 @@ for case in range(n_cases):
         P[rng.rand(U) < 0.2] = 0
     if kind == "nan_rows":
         P[rng.rand(U) < 0.1] = np.nan
+    if kind == "nan_items":
+        Q[rng.choice(I, 3, replace=False)] = np.nan
+    if kind == "inf_items":
+        Q[rng.choice(I, 2, replace=False), 0] = np.inf
+    if kind == "huge":
+        P *= 1e18; Q *= 1e18                                     # products overflow to inf for some pairs
+    if kind == "tiny":
+        P *= 1e-22; Q *= 1e-22                                   # products are sub-normal or flush to zero
     if kind == "popular":
         Q[rng.choice(I, min(40, I), replace=False)] += (0.3 * np.sign(P.mean(0) + 1e-3)).astype(np.float32)
     tr, te = [], []
