@@ -1,0 +1,76 @@
+"""Randomised cross-check of the LightGCN training step (nrhip_lightgcn_step: propagation, head, backward hops, Adam)
+against the fp64 / fp32 oracle (oracle/train.py) over graph shapes with hubs and isolated nodes, widths, depths, batch
+sizes (1 ... 4,096; duplicates; the short last batch's sizes) and adjacency forms: losses and tables within 1e-5."""
+import os
+import sys
+import numpy as np
+import scipy.sparse as sp
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from neurec_amd.trainer import LightGCNEngine
+from oracle import train
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+bad = 0
+for case in range(n_cases):
+    U = int(rng.choice([60, 400, 2500, 9000])); I = int(rng.choice([40, 300, 3000, 12000]))
+    d = int(rng.choice([16, 32, 64, 128, 50])); L = int(rng.choice([1, 2, 3, 4]))
+    Bmax = int(rng.choice([1, 33, 256, 1024, 4096])); adj_type = str(rng.choice(["pre", "norm", "plain"]))
+    hubs = int(rng.choice([0, 1, 3]))
+    users, items = [], []
+    for u in range(U):
+        if rng.rand() < 0.05:
+            continue                                             # isolated users
+        n = rng.randint(1, min(30, I))
+        users += [u] * n; items += rng.choice(I, n, replace=False).tolist()
+    for h in range(hubs):
+        uu = rng.choice(U, int(U * 0.8), replace=False)
+        users += uu.tolist(); items += [h] * len(uu)
+    m = sp.csr_matrix((np.ones(len(users), np.float32), (users, items)), shape=(U, I)); m.data[:] = 1.0
+    coo = m.tocoo()
+    A = train.lightgcn_adjacency(coo.row, coo.col, U, I, adj_type)
+    At = A.T.tocsr(); At.sort_indices()
+    lim = np.sqrt(6.0 / (U + d))
+    E0 = rng.uniform(-lim, lim, (U + I, d)).astype(np.float32)
+    reg, lr = 1e-3, 0.01
+    lg = LightGCNEngine(A, U, I, E0, L, lr, reg, Bmax, adj_t_csr=None if adj_type == "pre" else At)
+    o64 = E0.astype(np.float64); m64, v64 = np.zeros_like(o64), np.zeros_like(o64)
+    o32, m32, v32 = E0.copy(), np.zeros_like(E0), np.zeros_like(E0)
+    ad32 = train.Adam(lr)
+    A64, At64 = A.astype(np.float64), At.astype(np.float64)
+    ad64 = train.Adam(lr, dtype=np.float64)
+    loss2 = torch.zeros(2, device="cuda")
+    worst = 0.0
+    ok = True
+    for step in range(4):
+        B = Bmax if step != 2 else max(1, Bmax // 3)             # (a shorter batch in between, like an epoch's last)
+        bu = rng.randint(0, U, B).astype(np.int32); bp = rng.randint(0, I, B).astype(np.int32); bn = rng.randint(0, I, B).astype(np.int32)
+        if B > 4:
+            bu[1] = bu[0]; bp[3] = bp[2]; bn[4] = bp[2]          # duplicates across the three roles
+        lg.step(dev(bu), dev(bp), dev(bn), loss2)
+        w64 = train.lightgcn_step(A64, At64, o64, m64, v64, U, L, bu, bp, bn, reg, ad64)
+        w32 = train.lightgcn_step(A, At, o32, m32, v32, U, L, bu, bp, bn, reg, ad32)
+        got = loss2.cpu().numpy()
+        # the fp32 oracle's own distance from the fp64 twin is the yardstick (an unnormalised adjacency with hubs, or
+        # Adam on gradients near zero, amplify fp32 rounding whatever computes it)
+        tol0 = 1e-5 * abs(w64[0]) + 1e-7 + 4 * abs(w32[0] - w64[0])
+        tol1 = 1e-5 * max(abs(w64[1]), 1e-3) + 4 * abs(w32[1] - w64[1])
+        if not (abs(got[0] - w64[0]) <= tol0 and abs(got[1] - w64[1]) <= tol1):
+            ok = False
+            print("  loss mismatch step %d: got %s fp32 oracle %s fp64 %s" % (step, got, w32, w64), flush=True)
+    gotE = lg.E0.cpu().numpy()[:, :d]
+    err, err_o = float(np.abs(gotE - o64).max()), float(np.abs(o32 - o64).max())
+    eu, ei = lg.final_embeddings()
+    want_star, _ = train.lightgcn_propagate(A64, o64, L)
+    star32, _ = train.lightgcn_propagate(A, o32, L)
+    err_star = float(np.abs(np.concatenate([eu.cpu().numpy(), ei.cpu().numpy()])[:, :d] - want_star).max())
+    err_star_o = float(np.abs(star32 - want_star).max())
+    if err >= 1e-5 + 4 * err_o or err_star >= 1e-5 + 4 * err_star_o or not ok:
+        bad += 1
+        print("MISMATCH", end=" ")
+    print("case %2d: U=%d I=%d nnz=%d d=%d L=%d B=%d %s hubs=%d  |E0 - fp64| %.2e (fp32 oracle %.2e)  |E* - fp64| %.2e (%.2e)"
+          % (case, U, I, A.nnz, d, L, Bmax, adj_type, hubs, err, err_o, err_star, err_star_o), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
