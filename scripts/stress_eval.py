@@ -19,7 +19,7 @@ for case in range(n_cases):
     top_k = int(rng.choice([1, 3, 10, 20, 33, 50, 62]))
     if top_k > I // 4:
         top_k = max(1, I // 8)
-    kind = rng.choice(["gauss", "coarse", "zero_rows", "nan_rows", "popular", "nan_items", "inf_items", "huge", "tiny"])
+    kind = rng.choice(["gauss", "coarse", "zero_rows", "nan_rows", "popular", "nan_items", "inf_items", "huge", "tiny", "dense_train", "repeat_users"])
     P = (rng.randn(U, d) * 0.1).astype(np.float32)
     Q = (rng.randn(I, d) * 0.1).astype(np.float32)
     if kind == "coarse":
@@ -42,12 +42,19 @@ for case in range(n_cases):
     for u in range(U):
         a = set(rng.randint(0, I, rng.randint(0, 40)).tolist())
         b = set(rng.randint(0, I, rng.randint(0, 8)).tolist()) - a
+        if kind == "dense_train" and rng.rand() < 0.15:         # almost every item struck: the rest of the ranking is -inf ties
+            keep = set(rng.choice(I, min(I, int(rng.choice([0, 3, 25]))), replace=False).tolist())
+            a = set(range(I)) - keep
+            b = set(list(keep)[:2])
         tr.append(sorted(a)); te.append(sorted(b))
     def csr(lists):
         ptr, idx = lists_to_csr(lists)
         return E.DeviceCSR(ptr, idx[:max(int(ptr[-1]), 1)], I)
     trc, tec = csr(tr), csr(te)
-    users = torch.from_numpy(np.asarray([u for u in range(U) if te[u]], np.int32)).cuda()
+    ulist = [u for u in range(U) if te[u]]
+    if kind == "repeat_users" and len(ulist) > 3:
+        ulist = ulist + ulist[:3] + [ulist[1]]                   # a user list with repeats (the in-loop strikes' case)
+    users = torch.from_numpy(np.asarray(ulist, np.int32)).cuda()
     if users.numel() == 0:
         continue
     Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
