@@ -26,13 +26,21 @@
 
 namespace {
 
+// element k of a d-column row, 0 beyond it: the load is UNCONDITIONAL on a clamped column and the result masked — a
+// load behind a branch cannot be counted, the compiler waits for it (s_waitcnt vmcnt(0)) before it issues the next, and
+// the heads here are nothing but chains of row loads (r06: mf_fused_step_kernel had 55 such waits for 94 loads)
+__device__ __forceinline__ float ld_col(const float* __restrict__ row, int k, int d) {
+  const float v = row[min(k, d - 1)];
+  return k < d ? v : 0.f;
+}
+
 template <int CPL>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int d,
                                          int lane, float (&out)[CPL]) {
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
-    out[c] = (k < d) ? base[row * d + k] : 0.f;
+    out[c] = ld_col(base + row * d, k, d);
   }
 }
 
@@ -63,7 +71,7 @@ __device__ __forceinline__ void load_row_lazy(const float* __restrict__ base, in
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
-    out[c] = k < d ? base[row * d + k] : 0.f;
+    out[c] = ld_col(base + row * d, k, d);
   }
   if (from >= lz.t) return;                      // current (the optimiser was told this batch was coming)
   float mm[CPL], vv[CPL];
@@ -468,14 +476,13 @@ __device__ __forceinline__ int fused_load_row(int64_t row, int d, int lane, cons
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
-    const bool in = k < d;
-    w0[c] = in ? ft.W[row * d + k] : 0.f;
-    w1[c] = in ? ft.W[other + row * d + k] : 0.f;
+    w0[c] = ld_col(ft.W + row * d, k, d);
+    w1[c] = ld_col(ft.W + other + row * d, k, d);
     if constexpr (WITH_MV) {
-      m0[c] = in ? ft.M[row * d + k] : 0.f;
-      m1[c] = in ? ft.M[other + row * d + k] : 0.f;
-      v0[c] = in ? ft.V[row * d + k] : 0.f;
-      v1[c] = in ? ft.V[other + row * d + k] : 0.f;
+      m0[c] = ld_col(ft.M + row * d, k, d);
+      m1[c] = ld_col(ft.M + other + row * d, k, d);
+      v0[c] = ld_col(ft.V + row * d, k, d);
+      v1[c] = ld_col(ft.V + other + row * d, k, d);
     }
   }
   int from;
@@ -494,8 +501,8 @@ __device__ __forceinline__ int fused_load_row(int64_t row, int d, int lane, cons
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const int k = lane + c * NR_WAVE;
-        mm[c] = k < d ? ft.M[cp * other + row * d + k] : 0.f;
-        vv[c] = k < d ? ft.V[cp * other + row * d + k] : 0.f;
+        mm[c] = ld_col(ft.M + cp * other + row * d, k, d);
+        vv[c] = ld_col(ft.V + cp * other + row * d, k, d);
       }
     }
     fused_replay<CPL>(w, mm, vv, from, ft.t - 1, a_mine, a_lo, lane, ft);
@@ -516,14 +523,71 @@ __device__ __forceinline__ int fused_occurrence(int d, int n_users, const int32_
   const int64_t u = __builtin_amdgcn_readfirstlane(users[b]);
   const int64_t i = (int64_t)n_users + __builtin_amdgcn_readfirstlane(pos[b]);
   const int64_t j = (int64_t)n_users + __builtin_amdgcn_readfirstlane(neg[b]);
-  float pu[CPL], qi[CPL], qj[CPL], tm[CPL], tv[CPL];
+  float pu[CPL], qi[CPL], qj[CPL];
   int cp = 0;
-  if (HEAD && cls == 0) cp = fused_load_row<CPL, true>(u, d, lane, ft, a_mine, a_lo, pu, mm, vv);
-  else fused_load_row<CPL, false>(u, d, lane, ft, a_mine, a_lo, pu, tm, tv);
-  if (HEAD && cls == 1) cp = fused_load_row<CPL, true>(i, d, lane, ft, a_mine, a_lo, qi, mm, vv);
-  else fused_load_row<CPL, false>(i, d, lane, ft, a_mine, a_lo, qi, tm, tv);
-  if (HEAD && cls == 2) cp = fused_load_row<CPL, true>(j, d, lane, ft, a_mine, a_lo, qj, mm, vv);
-  else fused_load_row<CPL, false>(j, d, lane, ft, a_mine, a_lo, qj, tm, tv);
+  {
+    // The three rows (stamps + both copies of each) and, for a head, the class row's moments are requested TOGETHER,
+    // then picked: fused_load_row one row after the other put a stamp-dependent branch between the rows' loads — three
+    // round trips where one does (r06).  Same values: the pick, the rare replay of a row that is behind, in row order.
+    const int64_t rows3[3] = {u, i, j};
+    const int64_t other = ft.rows * d;
+    int2 st[3];
+    float w0[3][CPL], w1[3][CPL], m0[CPL], m1[CPL], v0[CPL], v1[CPL];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      st[q] = ((const int2*)ft.tw)[rows3[q]];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int k = lane + c * NR_WAVE;
+        w0[q][c] = ld_col(ft.W + rows3[q] * d, k, d);
+        w1[q][c] = ld_col(ft.W + other + rows3[q] * d, k, d);
+      }
+    }
+    if (HEAD) {
+      const int64_t hr = cls == 0 ? u : cls == 1 ? i : j;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int k = lane + c * NR_WAVE;
+        m0[c] = ld_col(ft.M + hr * d, k, d);
+        m1[c] = ld_col(ft.M + other + hr * d, k, d);
+        v0[c] = ld_col(ft.V + hr * d, k, d);
+        v1[c] = ld_col(ft.V + other + hr * d, k, d);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      int from;
+      const int cq = __builtin_amdgcn_readfirstlane(fused_pick(st[q], ft.t, from));
+      from = __builtin_amdgcn_readfirstlane(from);
+      const bool is_head = HEAD && cls == q;                    // wave-uniform
+      float wq[CPL], mq[CPL], vq[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        wq[c] = cq ? w1[q][c] : w0[q][c];
+        mq[c] = is_head ? (cq ? m1[c] : m0[c]) : 0.f;
+        vq[c] = is_head ? (cq ? v1[c] : v0[c]) : 0.f;
+      }
+      if (from < ft.t) {                            // behind (the previous launch was not told this row was coming)
+        if (!is_head) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int k = lane + c * NR_WAVE;
+            mq[c] = ld_col(ft.M + cq * other + rows3[q] * d, k, d);
+            vq[c] = ld_col(ft.V + cq * other + rows3[q] * d, k, d);
+          }
+        }
+        fused_replay<CPL>(wq, mq, vq, from, ft.t - 1, a_mine, a_lo, lane, ft);
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        if (q == 0) pu[c] = wq[c];
+        if (q == 1) qi[c] = wq[c];
+        if (q == 2) qj[c] = wq[c];
+        if (is_head) { mm[c] = mq[c]; vv[c] = vq[c]; }
+      }
+      if (is_head) cp = cq;
+    }
+  }
   const float x = dot_rows<CPL>(pu, qi) - dot_rows<CPL>(pu, qj);      // MF.py:59,67
   const float g = nr::pairwise_dloss((int)nr::NR_PAIR_BPR, x);
 #pragma unroll
@@ -609,13 +673,12 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int k = lane + c * NR_WAVE;
-      const bool in = k < d;
-      w0[c] = in ? ft.W[row * d + k] : 0.f;
-      w1[c] = in ? ft.W[other + row * d + k] : 0.f;
-      m0[c] = in ? ft.M[row * d + k] : 0.f;
-      m1[c] = in ? ft.M[other + row * d + k] : 0.f;
-      v0[c] = in ? ft.V[row * d + k] : 0.f;
-      v1[c] = in ? ft.V[other + row * d + k] : 0.f;
+      w0[c] = ld_col(ft.W + row * d, k, d);
+      w1[c] = ld_col(ft.W + other + row * d, k, d);
+      m0[c] = ld_col(ft.M + row * d, k, d);
+      m1[c] = ld_col(ft.M + other + row * d, k, d);
+      v0[c] = ld_col(ft.V + row * d, k, d);
+      v1[c] = ld_col(ft.V + other + row * d, k, d);
     }
     if (preparing && lane == 0) ft.inb[row] = ft.t + 1;              // the next step's scheduled waves leave it alone
     if (mark >= ft.t || st.x == ft.t || st.y == ft.t) return;         // this batch's head / another role has it
@@ -710,9 +773,9 @@ __global__ __launch_bounds__(256) void mf_fused_flush_kernel(FusedTables ft, int
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int k = lane + c * NR_WAVE;
-    w[c] = k < d ? ft.W[base + k] : 0.f;
-    mm[c] = k < d ? ft.M[base + k] : 0.f;
-    vv[c] = k < d ? ft.V[base + k] : 0.f;
+    w[c] = ld_col(ft.W + base, k, d);
+    mm[c] = ld_col(ft.M + base, k, d);
+    vv[c] = ld_col(ft.V + base, k, d);
   }
   fused_replay<CPL>(w, mm, vv, from, ft.t, a_mine, a_lo, lane, ft);
   fused_store_row<CPL>(row, 0, d, lane, ft, w, mm, vv, ft.t);

@@ -1272,11 +1272,10 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ m
     // and with 8 loads in flight each it was eight memory round trips long (18 us for 29,858 x 100; one load per add: 64)
     constexpr int kMine = kSlabRows / 4;
     float v[kMine];
+    // (unconditional loads, the row clamped: a load behind a branch cannot be counted, and the compiler then waits for
+    //  each one before it issues the next — 64 round trips, which is what this kernel's 16-20 us were)
 #pragma unroll
-    for (int i = 0; i < kMine; ++i) {
-      const int r = r0 + g + 4 * i;
-      v[i] = r < r1 ? mat[(int64_t)r * ld + c] : 0.f;
-    }
+    for (int i = 0; i < kMine; ++i) v[i] = mat[(int64_t)min(r0 + g + 4 * i, r1 - 1) * ld + c];
 #pragma unroll
     for (int i = 0; i < kMine; ++i)
       if (r0 + g + 4 * i < r1) acc += (double)v[i];

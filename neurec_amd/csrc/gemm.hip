@@ -249,11 +249,16 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // (unconditional loads on a clamped position, masked afterwards: a load behind a branch is waited for before the
+  //  next is issued)
+  const int c = c0 + tx, cc = min(c, cols - 1);
+  float val[16];
+  if (rows > 0 && cols > 0) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int r = r0 + q * 4 + ty, c = c0 + tx;
-    tile[q * 4 + ty][tx] = (r < rows && c < cols) ? src[(int64_t)r * ld_src + c] : 0.f;
+    for (int q = 0; q < 16; ++q) val[q] = src[(int64_t)min(r0 + q * 4 + ty, rows - 1) * ld_src + cc];
   }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tile[q * 4 + ty][tx] = (rows > 0 && cols > 0 && r0 + q * 4 + ty < rows && c < cols) ? val[q] : 0.f;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) {

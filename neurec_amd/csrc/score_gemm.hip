@@ -33,16 +33,25 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(
   __shared__ float tile[64][65];
   const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // every load unconditional on a clamped (row, column), masked afterwards: a load behind a branch cannot be counted,
+  // and the compiler then waits for each one before it issues the next (r06: this kernel was 16 x 2 dependent round
+  // trips per thread, 13 us for a 10 MB table)
+  const int k = k0 + tx, kc = min(k, d - 1);
+  int64_t sr[16];
+  float val[16];
+  if (n > 0) {                                                  // (workgroup-uniform)
+    if (ids) {
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    const int r = r0 + rr * 4 + ty, k = k0 + tx;
-    float val = 0.f;
-    if (r < n && k < d) {
-      const int64_t sr = ids ? (int64_t)ids[r] : (int64_t)r;
-      val = src[sr * ld + k];
+      for (int rr = 0; rr < 16; ++rr) sr[rr] = (int64_t)ids[min(r0 + rr * 4 + ty, n - 1)];
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) sr[rr] = (int64_t)min(r0 + rr * 4 + ty, n - 1);
     }
-    tile[rr * 4 + ty][tx] = val;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) val[rr] = src[sr[rr] * ld + kc];
   }
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) tile[rr * 4 + ty][tx] = (n > 0 && r0 + rr * 4 + ty < n && k < d) ? val[rr] : 0.f;
   __syncthreads();
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
