@@ -234,6 +234,24 @@ __global__ __launch_bounds__(kPlanThreads) void bpr_plan_kernel(
 
 constexpr int kOccWaves = 16;                 // sorted occurrences per workgroup
 
+// plan keys s - 1, s, s + 1 (~0 beyond either end) — the three loads issued TOGETHER on clamped positions: each behind
+// its own `if` was a round trip of its own (a load behind a branch is waited for before the next is issued)
+__device__ __forceinline__ void plan_keys3(const uint64_t* __restrict__ skey, int s, int n_occ, uint64_t& key,
+                                           uint64_t& kprev, uint64_t& knext) {
+  const uint64_t k0 = skey[s], km = skey[max(s - 1, 0)], kp = skey[min(s + 1, n_occ - 1)];
+  uint32_t a0 = (uint32_t)k0, a1 = (uint32_t)(k0 >> 32), b0 = (uint32_t)km, b1 = (uint32_t)(km >> 32),
+           c0 = (uint32_t)kp, c1 = (uint32_t)(kp >> 32);
+  // (all six words are "used" here: the compiler may not sink a neighbour's load into the branch that needs it)
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
+  auto uni = [](uint32_t lo, uint32_t hi) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+  };
+  key = uni(a0, a1);
+  kprev = s > 0 ? uni(b0, b1) : ~0ull;
+  knext = s + 1 < n_occ ? uni(c0, c1) : ~0ull;
+}
+
 __device__ __forceinline__ uint64_t plan_key(const uint64_t* __restrict__ skey, int s) {
   const uint64_t k = skey[s];
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) |
@@ -380,11 +398,9 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_grad_sorted_kernel(
   uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
   float acc[1][CPL] = {};
   if (s < n_occ) {
-    key = plan_key(skey, s);
     // the neighbours in the sorted order decide "first occurrence of its row" and "another one
     // follows": requested now, with everything else, not as a dependent load after the barrier
-    if (s > 0) kprev = plan_key(skey, s - 1);
-    if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
+    plan_keys3(skey, s, n_occ, key, kprev, knext);
     mf_occurrence<CPL, PAIR, LAZY>(P, Q, d, n_users, users, items, third, batch, reg, scale, loss_kind,
                                    (uint32_t)key, lane, acc[0], term_mf, term_l2, true, lz);
   }
@@ -708,9 +724,7 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void mf_fused_step_kernel(
   float acc[1][CPL] = {}, w[CPL] = {}, mm[CPL] = {}, vv[CPL] = {};
   int cp = 0;
   if (s < n_occ) {
-    key = plan_key(skey, s);
-    if (s > 0) kprev = plan_key(skey, s - 1);
-    if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
+    plan_keys3(skey, s, n_occ, key, kprev, knext);
     const bool first = s == 0 || (uint32_t)(kprev >> 32) != (uint32_t)(key >> 32);   // wave-uniform
     NR_MF_STAMP(1);
     if (first)
@@ -851,9 +865,7 @@ __global__ __launch_bounds__(kOccWaves* NR_WAVE) void lightgcn_grad_sorted_kerne
   uint64_t key = 0, kprev = ~0ull, knext = ~0ull;
   float hr[2][CPL] = {};                          // [0]: dLoss/dE* row, [1]: regulariser row
   if (s < n_occ) {
-    key = plan_key(skey, s);
-    if (s > 0) kprev = plan_key(skey, s - 1);      // neighbours in the sorted order: see mf_grad_sorted_kernel
-    if (s + 1 < n_occ) knext = plan_key(skey, s + 1);
+    plan_keys3(skey, s, n_occ, key, kprev, knext);      // neighbours in the sorted order: see mf_grad_sorted_kernel
     lightgcn_occurrence<CPL>(Esum, E0, n_users, d, layers_p1, users, pos, neg, batch, reg, grad_div,
                              (uint32_t)key, lane, hr[0], hr[1], term_mf, term_l2, true, given);
   }
