@@ -88,11 +88,14 @@ def leg_mf(train, test, trc, tec, dev, eval_batch, eval_mode, with_eval, with_cp
     mf_loss = torch.zeros(max(avail + 1, 1), 2, device=dev)
     cut = lambda lo, hi: (mu[lo:hi], mp[lo:hi], mn[lo:hi])
     mf.run_batches(*cut(0, n_warm), B, mf_loss, mplans[:3 * n_warm])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    mf.run_batches(*cut(n_warm, n_warm + n_timed), B, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
-    torch.cuda.synchronize()
-    mf_dt = (time.perf_counter() - t0) / t_steps
+    win = []
+    for _ in range(3):                        # (the window is ~1-5 ms of wall clock: one stall would be the whole figure)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mf.run_batches(*cut(n_warm, n_warm + n_timed), B, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
+        torch.cuda.synchronize()
+        win.append((time.perf_counter() - t0) / t_steps)
+    mf_dt = sorted(win)[1]
     # ONE WHOLE EPOCH as MF.train_model runs it (MF.py:95-103): the sampler's launch, the batch plans, every batch of
     # the permuted stream including the short last one — E / epoch wall time, SURVEY 8d's metric
     ep = []
