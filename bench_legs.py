@@ -88,14 +88,20 @@ def leg_mf(train, test, trc, tec, dev, eval_batch, eval_mode, with_eval, with_cp
     mf_loss = torch.zeros(max(avail + 1, 1), 2, device=dev)
     cut = lambda lo, hi: (mu[lo:hi], mp[lo:hi], mn[lo:hi])
     mf.run_batches(*cut(0, n_warm), B, mf_loss, mplans[:3 * n_warm])
-    win = []
-    for _ in range(3):                        # (the window is ~1-5 ms of wall clock: one stall would be the whole figure)
+    # the window in three parts, the median part reported (it is ~1-5 ms of wall clock: one stall would be the whole
+    # figure); the same steps in the same order as one window, so the tables the evaluation below sees are the same
+    win, part = [], max(t_steps // 3, 1)
+    for lo_s in range(0, t_steps, part):
+        hi_s = t_steps if lo_s + 2 * part > t_steps else lo_s + part
+        lo, hi = n_warm + lo_s * B, n_warm + hi_s * B
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        mf.run_batches(*cut(n_warm, n_warm + n_timed), B, mf_loss, mplans[3 * n_warm:3 * (n_warm + n_timed)])
+        mf.run_batches(*cut(lo, hi), B, mf_loss, mplans[3 * lo:3 * hi])
         torch.cuda.synchronize()
-        win.append((time.perf_counter() - t0) / t_steps)
-    mf_dt = sorted(win)[1]
+        win.append((time.perf_counter() - t0) / (hi_s - lo_s))
+        if hi_s == t_steps:
+            break
+    mf_dt = sorted(win)[len(win) // 2]
     # ONE WHOLE EPOCH as MF.train_model runs it (MF.py:95-103): the sampler's launch, the batch plans, every batch of
     # the permuted stream including the short last one — E / epoch wall time, SURVEY 8d's metric
     ep = []
