@@ -415,14 +415,13 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void select_tiles_kernel(
 #pragma unroll
   for (int u = 0; u < FR; ++u) {
     const int e0 = (u * NR_WAVE + lane) * 4;
-    float v[4];
-    if (e0 + 3 < cols) {
-      const float4 t = *reinterpret_cast<const float4*>(srow + e0);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
+    // one float4 per (lane, u), unconditional: the row's stride ld is a multiple of 4 and >= cols, so a word that
+    // starts below ld lies inside the row (its pad) — a word past it is read at the row's start and masked.  (Loads
+    // behind the `e0 + 3 < cols` branch were waited for one by one: the last, partial word cost four round trips.)
+    const float4 t = *reinterpret_cast<const float4*>(srow + (e0 + 3 < ld ? e0 : 0));
+    float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = (e0 + c < cols) ? srow[e0 + c] : NAN;      // NaN: never a key
-    }
+    for (int c = 0; c < 4; ++c) v[c] = (e0 + c < cols) ? v[c] : NAN;                // NaN: never a key
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       ord[u][c] = v[c] >= -INFINITY ? nr::order_f32(v[c]) : 0u;
@@ -1164,12 +1163,11 @@ __global__ __launch_bounds__(kSelWaves* NR_WAVE) void rank_compact_kernel(
 #pragma unroll
   for (int u = 0; u < FR; ++u) {                              // the row is requested before the train list is walked
     const int e0 = (u * NR_WAVE + lane) * 4;
-    if (e0 < cols) {
-      const float4 t = *reinterpret_cast<const float4*>(srow + e0);
-      v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
-    } else {
-      v[u][0] = v[u][1] = v[u][2] = v[u][3] = NAN;            // NaN: never a key
-    }
+    // (unconditional, on a clamped position, masked afterwards: a load behind a branch is waited for before the next
+    //  one is issued — FR round trips for the row instead of one; cols is a multiple of 32 and >= 32)
+    const float4 t = *reinterpret_cast<const float4*>(srow + min(e0, cols - 4));
+    const bool in = e0 < cols;
+    v[u][0] = in ? t.x : NAN; v[u][1] = in ? t.y : NAN; v[u][2] = in ? t.z : NAN; v[u][3] = in ? t.w : NAN;   // NaN: never a key
   }
   wave_lds_sync();
   if (my_tile >= 0) atomicOr(&s_bits[wave][(my_tile & 2047) >> 5], 1u << (my_tile & 31));
