@@ -807,24 +807,16 @@ __global__ __launch_bounds__(16 * NR_WAVE) void spmm_wanted_wave_kernel(
   if (by_batch) {
     for (int i = tid; i < bitmap_words; i += 16 * NR_WAVE) s_bits[i] = 0u;
     __syncthreads();
-    // every workgroup reads the whole batch (an 8,192-triplet global batch: 24 ids per thread): the
-    // ids of a list are requested eight at a time, not one dependent round trip per id
-    auto mark = [&](const int32_t* __restrict__ ids, int offset) {
-      for (int i0 = tid; i0 < bl.batch; i0 += 8 * 16 * NR_WAVE) {
-        int r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = i0 + j * 16 * NR_WAVE;
-          r[j] = i < bl.batch ? ids[i] : -1;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (r[j] >= 0) atomicOr(&s_bits[(offset + r[j]) >> 5], 1u << ((offset + r[j]) & 31));
-      }
-    };
-    mark(bl.users, 0);
-    mark(bl.pos, bl.n_users);
-    mark(bl.neg, bl.n_users);
+    // every workgroup reads the whole batch (an 8,192-triplet global batch: 24 ids per thread).  A triplet's three ids
+    // are requested together, unconditionally inside the loop (r06: three lists one after the other, each id behind its
+    // own `i < batch` test, were waited for one by one — 3 round trips at B = 1,024, 24 at 8,192)
+    for (int i = tid; i < bl.batch; i += 16 * NR_WAVE) {
+      const int u = bl.users[i], p = bl.pos[i], q = bl.neg[i];
+      const int ru = u, rp = bl.n_users + p, rq = bl.n_users + q;
+      if (u >= 0) atomicOr(&s_bits[ru >> 5], 1u << (ru & 31));
+      if (p >= 0) atomicOr(&s_bits[rp >> 5], 1u << (rp & 31));
+      if (q >= 0) atomicOr(&s_bits[rq >> 5], 1u << (rq & 31));
+    }
     // publishing is shared out: a contiguous piece of the 3 * batch list positions per workgroup
     const int total = 3 * bl.batch, per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int i = wg * per + tid; i < min(total, (wg + 1) * per); i += 16 * NR_WAVE) {
