@@ -105,15 +105,17 @@ __device__ __forceinline__ void stage_w_tiles(const FusedArgs& a, int t0, int n,
 #pragma unroll
   for (int i0 = 0; i0 < 2 * MAXT; i0 += BATCH) {
     float v[BATCH];
+    // (loads unconditional on clamped positions, masked at the store: a load behind a condition is waited for before
+    //  the next one is issued, and the "one round trip per group" above was BATCH of them)
 #pragma unroll
     for (int i = 0; i < BATCH; ++i) {
       const int e = (i0 + i) * kThreads + tid, tt = e >> 10, it = (t0 + tt) * kT + ((e >> 5) & 31), k = e & 31;
-      v[i] = (tt < n && it < a.cols && k < a.h) ? a.Wp1[(int64_t)it * a.h + k] : 0.f;
+      v[i] = a.Wp1[(int64_t)min(it, a.cols - 1) * a.h + min(k, a.h - 1)];
     }
 #pragma unroll
     for (int i = 0; i < BATCH; ++i) {
-      const int e = (i0 + i) * kThreads + tid;
-      Wt[(e >> 10) * kScratch + ((e >> 5) & 31) * kLd + (e & 31)] = v[i];
+      const int e = (i0 + i) * kThreads + tid, tt = e >> 10, it = (t0 + tt) * kT + ((e >> 5) & 31), k = e & 31;
+      Wt[(e >> 10) * kScratch + ((e >> 5) & 31) * kLd + (e & 31)] = (tt < n && it < a.cols && k < a.h) ? v[i] : 0.f;
     }
   }
   if (tid < MAXT * kT) {
@@ -186,10 +188,9 @@ __global__ __launch_bounds__(kThreads, 2) void vae_dec_stats_kernel(const FusedA
   const int t_end = min(a.main_tiles, t_begin + a.tiles_per_wg);
   float gA[17];                                                // logits' B operand: lane = row, k = 2·step + hlf
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int k = 2 * s + hlf;
-    gA[s] = (row < a.batch && k < a.h) ? a.G1[(int64_t)row * a.h + k] : 0.f;
-  }
+  for (int s = 0; s < 16; ++s) gA[s] = a.G1[(int64_t)min(row, a.batch - 1) * a.h + min(2 * s + hlf, a.h - 1)];   // (unconditional,
+#pragma unroll                                                                                                  //  then masked)
+  for (int s = 0; s < 16; ++s) gA[s] = (row < a.batch && 2 * s + hlf < a.h) ? gA[s] : 0.f;
   gA[16] = hlf == 0 ? 1.0f : 0.f;                              // step 16: bias · 1
   float mx = -INFINITY, sm = 0.f;
   auto fold_tile = [&](const float* W, int t) {
@@ -282,12 +283,12 @@ __global__ __launch_bounds__(kThreads, 1) void vae_dec_grad_kernel(const FusedAr
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int e = e0 + i * kThreads, r = e >> 5, k = e & 31;
-        v[i] = (chunk0 + r < a.batch && k < a.h) ? a.G1[(int64_t)(chunk0 + r) * a.h + k] : 0.f;
+        v[i] = a.G1[(int64_t)min(chunk0 + r, a.batch - 1) * a.h + min(k, a.h - 1)];       // (unconditional, masked below)
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int e = e0 + i * kThreads, r = e >> 5, k = e & 31;
-        gS[r * kLd + k] = v[i];
+        gS[r * kLd + k] = (chunk0 + r < a.batch && k < a.h) ? v[i] : 0.f;
       }
     }
     __syncthreads();
