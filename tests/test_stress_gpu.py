@@ -1,4 +1,4 @@
-"""The randomised cross-checks of scripts/stress_*.py as tests (a fixed seed and a case count that runs in seconds):
+"""The randomised cross-checks of tests/stress_*.py as tests (a fixed seed and a case count that runs in seconds):
 the pruned evaluation against the materialised path over shapes / cut-offs / searches / awkward tables; the LightGCN
 step against the fp64 twin with the fp32 oracle as the yardstick; the BPR-MF lazy forms against the all-rows sweep."""
 import os
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(script, cases, seed):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), str(cases), str(seed)],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), str(cases), str(seed)],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     tail = (out.stdout + out.stderr)[-3000:]
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, tail
